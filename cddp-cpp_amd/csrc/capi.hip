@@ -1,0 +1,630 @@
+// C-ABI of the MI355X-native batched CLDDP / IPDDP solver core (include/cddp_hip.h).
+// Host side only: descriptor flattening, device-buffer ownership, kernel sequencing
+// (the device-resident per-trajectory state machine lives in kernels.hpp).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "launch.hpp"
+
+using namespace cddp_dev;
+
+namespace cddp_dev {
+// gather records for the RCCL all-gather
+static __global__ void k_gather_records(DevBuf d, cddp_hip_gather_record *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  cddp_hip_gather_record r;
+  r.final_objective = d.cost[b]; r.iterations = d.iter[b]; r.status = d.status[b];
+  out[b] = r;
+}
+
+}  // namespace cddp_dev
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                          \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                           \
+      return fail(-10, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+const std::vector<KernelSet> &registry() {
+  static std::vector<KernelSet> v = [] {
+    std::vector<KernelSet> r;
+    register_pendulum(r); register_cartpole(r); register_unicycle(r); register_lti(r);
+    register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r);
+    return r;
+  }();
+  return v;
+}
+
+}  // namespace
+
+struct cddp_hip_handle {
+  ProblemDev P;
+  DevBuf d;
+  const KernelSet *ks = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<void *> allocs;
+  ProblemDev *dP = nullptr;
+  double *d_xref_traj = nullptr;
+  unsigned long long *d_launched = nullptr;
+  bool initialized = false;
+  size_t bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int dalloc(cddp_hip_handle *h, T **p, size_t n) {
+  if (n == 0) n = 1;
+  void *q = nullptr;
+  HIPCHK(hipMalloc(&q, n * sizeof(T)));
+  HIPCHK(hipMemsetAsync(q, 0, n * sizeof(T), h->stream));
+  h->allocs.push_back(q);
+  h->bytes += n * sizeof(T);
+  *p = (T *)q;
+  return 0;
+}
+
+int pool_put(ProblemDev &P, int &top, const double *src, int n) {
+  if (top + n > kPool) return -1;
+  int off = top;
+  for (int i = 0; i < n; ++i) P.pool[off + i] = src[i];
+  top += n;
+  return off;
+}
+
+// cddp_hip_problem -> ProblemDev (constraints sorted by name as std::map iterates)
+int flatten(const cddp_hip_problem *p, ProblemDev &P) {
+  std::memset(&P, 0, sizeof(P));
+  if (p->abi_version != CDDP_HIP_ABI_VERSION) return fail(-2, "ABI version mismatch: got %d want %d", p->abi_version, CDDP_HIP_ABI_VERSION);
+  if (p->nx <= 0 || p->nu <= 0 || p->horizon <= 0 || !(p->dt > 0)) return fail(-2, "bad dimensions nx=%d nu=%d N=%d dt=%g", p->nx, p->nu, p->horizon, p->dt);
+  if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
+  if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP) return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
+  if (!p->options.use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
+  if (p->options.warm_start) return fail(-3, "warm_start is not supported by the HIP core yet");
+  P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
+  P.nx = p->nx; P.nu = p->nu; P.N = p->horizon; P.dt = p->dt; P.opt = p->options;
+  P.ls_rule = p->options.enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
+  for (int i = 0; i < CDDP_HIP_MAX_MODEL_PARAMS; ++i) P.mp[i] = p->model_params[i];
+  if (p->model == CDDP_HIP_MODEL_LTI) {
+    if (!p->lti_A || !p->lti_B) return fail(-2, "LTI model needs lti_A and lti_B");
+    if (p->nx * p->nx + p->nx * p->nu + 1 > 32) return fail(-3, "LTI dims too large for the device parameter block");
+    for (int i = 0; i < p->nx * p->nx; ++i) P.mp[i] = p->lti_A[i];
+    for (int i = 0; i < p->nx * p->nu; ++i) P.mp[p->nx * p->nx + i] = p->lti_B[i];
+    P.mp[p->nx * p->nx + p->nx * p->nu] = p->dt;
+  }
+  int top = 0;
+  {
+    std::vector<double> q((size_t)p->nx * p->nx), r((size_t)p->nu * p->nu);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = p->Q[i] * p->dt;   // objective.cpp:38-39
+    for (size_t i = 0; i < r.size(); ++i) r[i] = p->R[i] * p->dt;
+    P.off_Qdt = pool_put(P, top, q.data(), (int)q.size());
+    P.off_Rdt = pool_put(P, top, r.data(), (int)r.size());
+    P.off_Qf = pool_put(P, top, p->Qf, p->nx * p->nx);
+    P.off_xref = pool_put(P, top, p->x_ref, p->nx);
+    if (P.off_Qdt < 0 || P.off_Rdt < 0 || P.off_Qf < 0 || P.off_xref < 0) return fail(-3, "constant pool overflow");
+  }
+  P.has_xref_traj = p->x_ref_traj ? 1 : 0;
+  if (p->n_constraints > kMaxCons) return fail(-3, "too many path constraints (%d > %d)", p->n_constraints, kMaxCons);
+  std::vector<int> order(p->n_constraints);
+  for (int i = 0; i < p->n_constraints; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::strcmp(p->constraints[a].name, p->constraints[b].name) < 0; });
+  int off = 0;
+  P.clddp_box = -1;
+  for (int k = 0; k < p->n_constraints; ++k) {
+    const cddp_hip_constraint &c = p->constraints[order[k]];
+    ConDev &cd = P.cons[k];
+    cd.kind = c.kind; cd.dim = c.dim; cd.scale = c.scale; cd.radius = c.radius; cd.offset = off;
+    cd.off_lower = cd.off_upper = cd.off_center = cd.off_A = cd.off_b = -1;
+    switch (c.kind) {
+      case CDDP_HIP_CON_CONTROL_BOX:
+      case CDDP_HIP_CON_STATE_BOX:
+        if (!c.lower || !c.upper) return fail(-2, "Cannot add null constraint.");
+        if (c.dim != (c.kind == CDDP_HIP_CON_CONTROL_BOX ? p->nu : p->nx)) return fail(-2, "box constraint '%s' dimension mismatch", c.name);
+        cd.dual_dim = 2 * c.dim;
+        cd.off_lower = pool_put(P, top, c.lower, c.dim); cd.off_upper = pool_put(P, top, c.upper, c.dim);
+        if (c.kind == CDDP_HIP_CON_CONTROL_BOX && std::strcmp(c.name, "ControlConstraint") == 0) P.clddp_box = k;  // clddp_solver.cpp:85-86
+        break;
+      case CDDP_HIP_CON_BALL:
+        if (!c.center) return fail(-2, "Cannot add null constraint.");
+        cd.dual_dim = 1; cd.off_center = pool_put(P, top, c.center, c.dim); break;
+      case CDDP_HIP_CON_LINEAR:
+        if (!c.A || !c.b) return fail(-2, "Cannot add null constraint.");
+        cd.dual_dim = c.dim; cd.off_A = pool_put(P, top, c.A, c.dim * p->nx); cd.off_b = pool_put(P, top, c.b, c.dim); break;
+      default: return fail(-2, "unknown constraint kind %d", c.kind);
+    }
+    if (top > kPool || (cd.off_lower < 0 && cd.off_center < 0 && cd.off_A < 0)) return fail(-3, "constant pool overflow");
+    off += cd.dual_dim;
+  }
+  P.n_cons = p->n_constraints; P.m = off;
+  if (p->n_terminal > 0)
+    return fail(-3, "terminal constraints are not supported by the HIP core yet (IPDDP: terminal constraint has unsupported type)");
+  P.n_alphas = cddp_hip_build_alphas(&p->options, P.alphas, CDDP_HIP_MAX_ALPHAS);
+  if (P.n_alphas <= 0) return fail(-2, "empty line-search ladder");
+  return 0;
+}
+
+int free_all(cddp_hip_handle *h) {
+  for (void *q : h->allocs) hipFree(q);
+  h->allocs.clear();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cddp_hip_default_options(cddp_hip_options *o) {
+  std::memset(o, 0, sizeof(*o));
+  o->tolerance = 1e-5; o->acceptable_tolerance = 1e-6; o->max_iterations = 1; o->use_ilqr = 1;
+  o->termination_scaling_max_factor = 100.0;
+  o->ls_max_iterations = 11; o->ls_initial_step_size = 1.0; o->ls_min_step_size = 1e-8; o->ls_step_reduction_factor = 0.5;
+  o->reg_initial_value = 1e-6; o->reg_update_factor = 10.0; o->reg_max_value = 1e7; o->reg_min_value = 1e-10;
+  o->boxqp_max_iterations = 100; o->boxqp_min_gradient_norm = 1e-8; o->boxqp_min_relative_improvement = 1e-8;
+  o->boxqp_step_decrease_factor = 0.6; o->boxqp_min_step_size = 1e-22; o->boxqp_armijo_constant = 0.1;
+  o->filter_merit_acceptance_threshold = 1e-6; o->filter_violation_acceptance_threshold = 1e-6;
+  o->filter_max_violation_threshold = 1e4; o->filter_min_violation_for_armijo_check = 1e-7; o->filter_armijo_constant = 1e-4;
+  o->ipddp_dual_var_init_scale = 0.1; o->ipddp_slack_var_init_scale = 1e-2; o->ipddp_barrier_tol_mult = 0.1;
+  o->ipddp_barrier_update_dual_weight = 0.01; o->ipddp_mu_kappa_epsilon = 10.0; o->ipddp_max_filter_size = 5;
+  o->ipddp_theta_0_floor = 1.0; o->ipddp_warmstart_s_min = 1e-4; o->ipddp_warmstart_y_min = 1e-4;
+  o->ipddp_warmstart_interior_factor = 1.1; o->ipddp_jacobian_regularization_value = 1e-8;
+  o->ipddp_jacobian_regularization_exponent = 0.25;
+  o->barrier_mu_initial = 1.0; o->barrier_mu_min_value = 1e-10; o->barrier_mu_update_factor = 0.5;
+  o->barrier_mu_update_power = 1.2; o->barrier_min_fraction_to_boundary = 0.99; o->barrier_strategy = CDDP_HIP_BARRIER_ADAPTIVE;
+}
+
+int cddp_hip_abi_version(void) { return CDDP_HIP_ABI_VERSION; }
+const char *cddp_hip_last_error(void) { return g_err.c_str(); }
+
+int cddp_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *cddp_hip_status_string(int status) {
+  switch (status) {
+    case CDDP_HIP_STATUS_RUNNING: return "Running";
+    case CDDP_HIP_STATUS_OPTIMAL: return "OptimalSolutionFound";
+    case CDDP_HIP_STATUS_ACCEPTABLE: return "AcceptableSolutionFound";
+    case CDDP_HIP_STATUS_MAX_ITERATIONS: return "MaxIterationsReached";
+    case CDDP_HIP_STATUS_REG_LIMIT: return "RegularizationLimitReached_NotConverged";
+    case CDDP_HIP_STATUS_MAX_CPU_TIME: return "MaxCpuTimeReached";
+  }
+  return "Unknown";
+}
+
+// detail::buildLineSearchAlphas (reference cddp_context_utils.cpp:37-57)
+int cddp_hip_build_alphas(const cddp_hip_options *opt, double *alphas, int cap) {
+  int n = 0;
+  double cur = opt->ls_initial_step_size;
+  for (int i = 0; i < opt->ls_max_iterations; ++i) {
+    if (n < cap) alphas[n] = cur;
+    ++n;
+    cur *= opt->ls_step_reduction_factor;
+    if (cur < opt->ls_min_step_size && i < opt->ls_max_iterations - 1) {
+      if (n < cap) alphas[n] = opt->ls_min_step_size;
+      ++n;
+      break;
+    }
+  }
+  if (n == 0) { if (cap > 0) alphas[0] = opt->ls_initial_step_size; n = 1; }
+  return n > cap ? cap : n;
+}
+
+int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp_hip_handle **out) {
+  if (!problem || !out) return fail(-1, "null argument");
+  if (batch <= 0) return fail(-1, "batch must be positive");
+  int ndev = cddp_hip_device_count();
+  if (ndev <= 0) return fail(-20, "no HIP device available: the cddp_hip solver core has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(-1, "device %d out of range (%d devices)", device, ndev);
+  cddp_hip_handle *h = new cddp_hip_handle();
+  int rc = flatten(problem, h->P);
+  if (rc) { delete h; return rc; }
+  for (const KernelSet &k : registry()) if (k.matches(h->P)) { h->ks = &k; break; }
+  if (!h->ks) {
+    delete h;
+    return fail(-4, "no kernel instantiation for model=%d nx=%d nu=%d with this constraint layout (m=%d, %d constraints)",
+                problem->model, problem->nx, problem->nu, h->P.m, h->P.n_cons);
+  }
+  h->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { delete h; return fail(-10, "hipSetDevice: %s", hipGetErrorString(e)); }
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return fail(-10, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  h->own_stream = true;
+
+  const ProblemDev &P = h->P;
+  DevBuf &d = h->d;
+  std::memset(&d, 0, sizeof(d));
+  const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
+  d.B = B; d.Bp = Bp; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
+  d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
+  d.hist_cap = P.opt.max_iterations + 1;
+  d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
+  const bool ip = (P.solver == CDDP_HIP_SOLVER_IPDDP);
+#define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { free_all(h); delete h; return rc_; } } while (0)
+  DA(d.X, d.planeX * d.n_slots); DA(d.U, d.planeU * d.n_slots);
+  if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
+  DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
+  DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
+  DA(d.Vx, (size_t)(N + 1) * nx * Bp); DA(d.Vxx, (size_t)(N + 1) * nx * nx * Bp);
+  if (ip && m > 0) { DA(d.ks, (size_t)N * m * Bp); DA(d.ky, (size_t)N * m * Bp); DA(d.Ks, (size_t)N * m * nx * Bp); DA(d.Ky, (size_t)N * m * nx * Bp); }
+  double **scal[] = {&d.cost, &d.merit, &d.inf_pr, &d.inf_du, &d.inf_comp, &d.step_norm, &d.alpha_pr, &d.alpha_du, &d.reg, &d.mu,
+                     &d.dV0, &d.dV1, &d.phi, &d.theta, &d.filter_theta, &d.apr_max, &d.adu_max};
+  for (double **sp : scal) DA(*sp, Bp);
+  DA(d.filt, (size_t)2 * kFilterCap * Bp);
+  int **iscal[] = {&d.filt_n, &d.iter, &d.status, &d.phase, &d.cur, &d.n_bwd, &d.n_fwd, &d.bwd_ok};
+  for (int **sp : iscal) DA(*sp, Bp);
+  double **tr[] = {&d.t_cost, &d.t_merit, &d.t_theta, &d.t_inf_pr, &d.t_inf_comp, &d.t_apr, &d.t_adu};
+  for (double **sp : tr) DA(*sp, (size_t)d.n_alphas * Bp);
+  DA(d.t_success, (size_t)d.n_alphas * Bp);
+  DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
+  DA(d.hist_n, std::max(1, d.hist_batch));
+  DA(d.n_active, 1);
+  DA(h->d_launched, 1);
+  DA(h->dP, 1);
+  if (problem->x_ref_traj) {
+    DA(h->d_xref_traj, (size_t)(N + 1) * nx);
+    hipMemcpyAsync(h->d_xref_traj, problem->x_ref_traj, sizeof(double) * (N + 1) * nx, hipMemcpyHostToDevice, h->stream);
+    d.xref_traj = h->d_xref_traj;
+  }
+#undef DA
+  hipMemcpyAsync(h->dP, &h->P, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream);
+  d.P = h->dP;
+  d.launched = h->d_launched;
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { free_all(h); delete h; return fail(-10, "device initialisation failed: %s", hipGetErrorString(e)); }
+  *out = h;
+  return 0;
+}
+
+int cddp_hip_destroy(cddp_hip_handle *h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  free_all(h);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream) {
+  if (!h) return fail(-1, "null handle");
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)hip_stream;
+  h->own_stream = false;
+  return 0;
+}
+
+int cddp_hip_dual_dim(cddp_hip_handle *h) { return h ? h->P.m : -1; }
+int cddp_hip_batch(cddp_hip_handle *h) { return h ? h->d.B : -1; }
+
+// host batch-major [b][t][e]  <->  device batch-minor [t][e][b]
+static void to_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int e = 0; e < E; ++e) dst[((size_t)t * E + e) * Bp + b] = src[((size_t)b * T + t) * E + e];
+}
+static void from_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[((size_t)t * E + e) * Bp + b];
+}
+
+int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0, const double *X0) {
+  if (!h || !x0) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const DevBuf &d = h->d;
+  const int B = d.B, Bp = d.Bp, N = d.N, nx = h->P.nx, nu = h->P.nu;
+  std::vector<double> hx((size_t)(N + 1) * nx * Bp, 0.0), hu((size_t)N * nu * Bp, 0.0);
+  if (X0) to_soa(X0, hx.data(), B, Bp, N + 1, nx);
+  else
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t <= N; ++t)
+        for (int e = 0; e < nx; ++e) hx[((size_t)t * nx + e) * Bp + b] = x0[(size_t)b * nx + e];
+  for (int b = 0; b < B; ++b)
+    for (int e = 0; e < nx; ++e) hx[((size_t)0 * nx + e) * Bp + b] = x0[(size_t)b * nx + e];   // X_[0] = initial_state (cddp_core.cpp:294)
+  if (U0) to_soa(U0, hu.data(), B, Bp, N, nu);
+  HIPCHK(hipMemcpyAsync(d.X, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.U, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(d.cur, 0, sizeof(int) * Bp, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->initialized = false;
+  return 0;
+}
+
+int cddp_hip_initialize(cddp_hip_handle *h) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  h->ks->init(h->d, h->stream);
+  HIPCHK(hipGetLastError());
+  h->initialized = true;
+  return 0;
+}
+
+int cddp_hip_backward(cddp_hip_handle *h, int32_t *ok) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->initialized) { int rc = cddp_hip_initialize(h); if (rc) return rc; }
+  h->ks->derivs(h->d, 1, h->stream);
+  h->ks->backward(h->d, h->P.solver, 1, 0, h->stream);
+  HIPCHK(hipGetLastError());
+  if (ok) HIPCHK(hipMemcpyAsync(ok, h->d.bwd_ok, sizeof(int) * h->d.B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cddp_hip_trial *trials) {
+  if (!h || !alphas || !trials) return fail(-1, "null argument");
+  if (n_alphas <= 0 || n_alphas > h->d.n_alphas) return fail(-1, "n_alphas must be in [1, %d] (the handle's ladder size)", h->d.n_alphas);
+  HIPCHK(hipSetDevice(h->device));
+  // temporarily install the caller's alphas in the device problem block
+  ProblemDev tmp = h->P;
+  for (int i = 0; i < n_alphas; ++i) tmp.alphas[i] = alphas[i];
+  HIPCHK(hipMemcpyAsync(h->dP, &tmp, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
+  h->ks->forward(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, h->stream);
+  HIPCHK(hipGetLastError());
+  const DevBuf &d = h->d;
+  const size_t n = (size_t)n_alphas * d.Bp;
+  std::vector<double> c(n), mf(n), th(n), ipr(n), ic(n), ap(n), ad(n);
+  std::vector<int> su(n);
+  HIPCHK(hipMemcpyAsync(c.data(), d.t_cost, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(mf.data(), d.t_merit, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(th.data(), d.t_theta, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ipr.data(), d.t_inf_pr, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ic.data(), d.t_inf_comp, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ap.data(), d.t_apr, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ad.data(), d.t_adu, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(su.data(), d.t_success, n * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dP, &h->P, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < d.B; ++b)
+    for (int a = 0; a < n_alphas; ++a) {
+      cddp_hip_trial &t = trials[(size_t)b * n_alphas + a];
+      const size_t i = (size_t)a * d.Bp + b;
+      t.alpha = alphas[a]; t.alpha_pr = ap[i]; t.alpha_du = ad[i]; t.cost = c[i]; t.merit_function = mf[i];
+      t.theta = th[i]; t.inf_pr = ipr[i]; t.inf_comp = ic[i]; t.success = su[i]; t._pad = 0;
+    }
+  return 0;
+}
+
+int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  const ProblemDev &P = h->P;
+  const DevBuf &d = h->d;
+  hipStream_t s = h->stream;
+  const KernelSet *ks = h->ks;
+  const int max_it = P.opt.max_iterations;
+  const bool first_rule = (P.ls_rule == CDDP_HIP_LS_FIRST_SUCCESS);
+  const int na = d.n_alphas;
+  // events: [0]=start, [1]=end, then 4 per outer iteration
+  std::vector<hipEvent_t> ev;
+  const bool timing = (stats != nullptr);
+  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); ev.push_back(e); } };
+  hipEvent_t ev0, ev1;
+  HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+  HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
+  HIPCHK(hipEventRecord(ev0, s));
+  ks->init(d, s);
+  h->initialized = true;
+  int launches = 1, outer = 0;
+  int *h_active = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_active, sizeof(int)));
+  *h_active = d.B;
+  if (max_it <= 0) { ks->update(d, 2, 0, 1, s); ++launches; }
+  for (int it = 1; it <= max_it; ++it) {
+    ++outer;
+    const int last = (it == max_it) ? 1 : 0;
+    mark();
+    ks->derivs(d, 0, s);
+    ks->backward(d, P.solver, 0, 1, s);
+    mark();
+    if (first_rule) {
+      ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, s);
+      mark();
+      ks->update(d, 1, 1, last, s);
+      mark();
+      ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, s);
+      mark();
+      launches += (na > 1) ? 6 : 5;
+    } else {
+      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, s);
+      mark();
+      ks->update(d, 1, na, last, s);
+      mark();
+      mark();
+      launches += 5;
+    }
+    HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
+    ks->update(d, 2, na, last, s);
+    mark();
+    HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (*h_active == 0) break;
+  }
+  HIPCHK(hipEventRecord(ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  hipHostFree(h_active);
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    stats->solve_ms = ms;
+    for (size_t i = 0; i + 5 < ev.size(); i += 6) {
+      float a = 0, b = 0, c = 0, e2 = 0, f = 0;
+      hipEventElapsedTime(&a, ev[i], ev[i + 1]);       // derivs + backward
+      hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]);   // forward stage 1
+      hipEventElapsedTime(&c, ev[i + 2], ev[i + 3]);   // update 1
+      hipEventElapsedTime(&e2, ev[i + 3], ev[i + 4]);  // forward stage 2
+      hipEventElapsedTime(&f, ev[i + 4], ev[i + 5]);   // update 2
+      stats->backward_ms += a; stats->forward_ms += b + e2; stats->update_ms += c + f;
+    }
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+    std::vector<int> nb(d.B), nf(d.B), itv(d.B), stv(d.B);
+    HIPCHK(hipMemcpy(nb.data(), d.n_bwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nf.data(), d.n_fwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(itv.data(), d.iter, sizeof(int) * d.B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(stv.data(), d.status, sizeof(int) * d.B, hipMemcpyDeviceToHost));
+    for (int b = 0; b < d.B; ++b) {
+      stats->sweeps += nb[b]; stats->rollouts += nf[b]; stats->traj_iterations += itv[b];
+      if (stv[b] == CDDP_HIP_STATUS_OPTIMAL || stv[b] == CDDP_HIP_STATUS_ACCEPTABLE) stats->n_converged++;
+    }
+    unsigned long long nl = 0;
+    HIPCHK(hipMemcpy(&nl, h->d_launched, sizeof(nl), hipMemcpyDeviceToHost));
+    stats->rollouts_launched = (int64_t)nl;
+    stats->outer_iterations = outer; stats->kernel_launches = launches;
+  }
+  hipEventDestroy(ev0); hipEventDestroy(ev1);
+  return 0;
+}
+
+// ---- getters -----------------------------------------------------------------------------
+static int fetch(cddp_hip_handle *h, const double *dev, size_t n, std::vector<double> &host) {
+  host.resize(n);
+  HIPCHK(hipMemcpy(host.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) {
+  if (!h || !r) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  const int B = d.B;
+  std::vector<double> v[10];
+  const double *src[10] = {d.cost, d.merit, d.inf_pr, d.inf_du, d.inf_comp, d.mu, d.reg, d.alpha_pr, d.alpha_du, d.step_norm};
+  for (int i = 0; i < 10; ++i) { int rc = fetch(h, src[i], B, v[i]); if (rc) return rc; }
+  std::vector<int> it(B), st(B), nb(B), nf(B);
+  HIPCHK(hipMemcpy(it.data(), d.iter, sizeof(int) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(st.data(), d.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nb.data(), d.n_bwd, sizeof(int) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nf.data(), d.n_fwd, sizeof(int) * B, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b) {
+    r[b].final_objective = v[0][b]; r[b].merit_function = v[1][b]; r[b].inf_pr = v[2][b]; r[b].inf_du = v[3][b];
+    r[b].inf_comp = v[4][b]; r[b].barrier_mu = v[5][b]; r[b].regularization = v[6][b]; r[b].alpha_pr = v[7][b];
+    r[b].alpha_du = v[8][b]; r[b].step_norm = v[9][b]; r[b].iterations = it[b]; r[b].status = st[b];
+    r[b].n_backward = nb[b]; r[b].n_forward = nf[b];
+  }
+  return 0;
+}
+
+// copies the CURRENT slot of every trajectory of a slotted array
+static int fetch_current(cddp_hip_handle *h, const double *base, size_t plane, int T, int E, double *out) {
+  const DevBuf &d = h->d;
+  std::vector<int> cur(d.B);
+  HIPCHK(hipMemcpy(cur.data(), d.cur, sizeof(int) * d.B, hipMemcpyDeviceToHost));
+  std::vector<char> need(d.n_slots, 0);
+  for (int b = 0; b < d.B; ++b) need[cur[b]] = 1;
+  std::vector<double> buf;
+  for (int s = 0; s < d.n_slots; ++s) {
+    if (!need[s]) continue;
+    int rc = fetch(h, base + (size_t)s * plane, plane, buf);
+    if (rc) return rc;
+    for (int b = 0; b < d.B; ++b) {
+      if (cur[b] != s) continue;
+      for (int t = 0; t < T; ++t)
+        for (int e = 0; e < E; ++e) out[((size_t)b * T + t) * E + e] = buf[((size_t)t * E + e) * d.Bp + b];
+    }
+  }
+  return 0;
+}
+
+int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  if (X) { int rc = fetch_current(h, d.X, d.planeX, d.N + 1, h->P.nx, X); if (rc) return rc; }
+  if (U) { int rc = fetch_current(h, d.U, d.planeU, d.N, h->P.nu, U); if (rc) return rc; }
+  return 0;
+}
+
+int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  std::vector<double> buf;
+  if (K) { int rc = fetch(h, d.K, (size_t)d.N * h->P.nu * h->P.nx * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), K, d.B, d.Bp, d.N, h->P.nu * h->P.nx); }
+  if (k) { int rc = fetch(h, d.k, (size_t)d.N * h->P.nu * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), k, d.B, d.Bp, d.N, h->P.nu); }
+  return 0;
+}
+
+int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  std::vector<double> buf;
+  if (Vx) { int rc = fetch(h, d.Vx, (size_t)(d.N + 1) * h->P.nx * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), Vx, d.B, d.Bp, d.N + 1, h->P.nx); }
+  if (Vxx) { int rc = fetch(h, d.Vxx, (size_t)(d.N + 1) * h->P.nx * h->P.nx * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), Vxx, d.B, d.Bp, d.N + 1, h->P.nx * h->P.nx); }
+  return 0;
+}
+
+int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
+  if (!h) return fail(-1, "null handle");
+  if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m == 0) return fail(-1, "no slack/dual trajectories for this problem");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  if (S) { int rc = fetch_current(h, d.S, d.planeM, d.N, h->P.m, S); if (rc) return rc; }
+  if (Y) { int rc = fetch_current(h, d.Y, d.planeM, d.N, h->P.m, Y); if (rc) return rc; }
+  if (G) { int rc = fetch_current(h, d.G, d.planeM, d.N, h->P.m, G); if (rc) return rc; }
+  return 0;
+}
+
+int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  std::vector<double> a, b2;
+  if (dV) {
+    int rc = fetch(h, d.dV0, d.B, a); if (rc) return rc;
+    rc = fetch(h, d.dV1, d.B, b2); if (rc) return rc;
+    for (int b = 0; b < d.B; ++b) { dV[2 * b] = a[b]; dV[2 * b + 1] = b2[b]; }
+  }
+  if (reg) { int rc = fetch(h, d.reg, d.B, a); if (rc) return rc; for (int b = 0; b < d.B; ++b) reg[b] = a[b]; }
+  return 0;
+}
+
+int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts) {
+  if (!h || !hist || !counts) return fail(-1, "null argument");
+  const DevBuf &d = h->d;
+  if (hist_batch > d.hist_batch) return fail(-1, "history kept for %d trajectories only (options.return_iteration_info=%d)", d.hist_batch, h->P.opt.return_iteration_info);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(hist, d.hist, sizeof(double) * (size_t)hist_batch * d.hist_cap * kHistCols, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(counts, d.hist_n, sizeof(int) * hist_batch, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int cddp_hip_write_gather_records_device(cddp_hip_handle *h, void *device_ptr) {
+  if (!h || !device_ptr) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_gather_records, dim3((h->d.B + 255) / 256), dim3(256), 0, h->stream, h->d, (cddp_hip_gather_record *)device_ptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// Device-side path constraints g(x,u) <= upper (reference include/cddp-cpp/cddp_core/constraint.hpp)
+// and the quadratic objective (reference src/cddp_core/objective.cpp:30-154).
+//
+// The stacked dual layout of a problem (constraint objects in std::map order = sorted by name,
+// ipddp_solver.cpp:1371-1384) is a COMPILE-TIME type list ConList<C1, C2, ...>, so that every
+// index into the per-lane register arrays (y, s, g, Q_yx, Q_yu ...) is static after unrolling.
+// Bounds / centres are run-time constants read through scalar loads from ProblemDev::pool.
+#pragma once
+#include "dev_linalg.hpp"
+#include "dev_types.hpp"
+
+namespace cddp_dev {
+
+// BoxConstraint<Control> (constraint.hpp:144-251): g = [-u; u]*s - [-lb; ub]*s, G_u = [-I; I]*s
+template <int D>
+struct CtrlBox {
+  static constexpr int KIND = CDDP_HIP_CON_CONTROL_BOX, DUAL = 2 * D, DIM = D;
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *, const double *u, double *g) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      g[i] = (-u[i]) * c.scale - (-pool[c.off_lower + i]) * c.scale;
+      g[D + i] = u[i] * c.scale - pool[c.off_upper + i] * c.scale;
+    }
+  }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Gu[i * NU + i] = -c.scale; Gu[(D + i) * NU + i] = c.scale; }
+    (void)Gx;
+  }
+};
+
+// BoxConstraint<State>
+template <int D>
+struct StateBox {
+  static constexpr int KIND = CDDP_HIP_CON_STATE_BOX, DUAL = 2 * D, DIM = D;
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      g[i] = (-x[i]) * c.scale - (-pool[c.off_lower + i]) * c.scale;
+      g[D + i] = x[i] * c.scale - pool[c.off_upper + i] * c.scale;
+    }
+  }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Gx[i * NX + i] = -c.scale; Gx[(D + i) * NX + i] = c.scale; }
+    (void)Gu;
+  }
+};
+
+// BallConstraint (constraint.hpp:313-404): g = -s*|x[:d]-c|^2 - (-(r*r)*s), G_x = -2 s (x-c)
+template <int D>
+struct Ball {
+  static constexpr int KIND = CDDP_HIP_CON_BALL, DUAL = 1, DIM = D;
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { double df = x[i] - pool[c.off_center + i]; sq += df * df; }
+    g[0] = -(c.scale * sq) - (-(c.radius * c.radius) * c.scale);
+  }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *pool, const double *x, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) Gx[i] = -2.0 * c.scale * (x[i] - pool[c.off_center + i]);
+    (void)Gu;
+  }
+};
+
+// LinearConstraint (constraint.hpp:253-311): g = A x - b
+template <int R>
+struct Linear {
+  static constexpr int KIND = CDDP_HIP_CON_LINEAR, DUAL = R, DIM = R;
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += pool[c.off_A + r * NX + j] * x[j];
+      g[r] = s - pool[c.off_b + r];
+    }
+  }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *pool, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Gx[r * NX + j] = pool[c.off_A + r * NX + j];
+    (void)Gu;
+  }
+};
+
+template <int OFF, int CI, class... Cs> struct ConImpl;
+template <int OFF, int CI>
+struct ConImpl<OFF, CI> {
+  template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
+};
+template <int OFF, int CI, class C, class... Rest>
+struct ConImpl<OFF, CI, C, Rest...> {
+  template <int NX, int NU>
+  DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
+    C::template eval<NX, NU>(P->cons[CI], P->pool, x, u, g + OFF);
+    ConImpl<OFF + C::DUAL, CI + 1, Rest...>::template eval<NX, NU>(P, x, u, g);
+  }
+  template <int NX, int NU>
+  DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
+    C::template jac<NX, NU>(P->cons[CI], P->pool, x, Gx + OFF * NX, Gu + OFF * NU);
+    ConImpl<OFF + C::DUAL, CI + 1, Rest...>::template jac<NX, NU>(P, x, Gx, Gu);
+  }
+};
+
+template <class... Cs>
+struct ConList {
+  static constexpr int NSEG = sizeof...(Cs);
+  static constexpr int M = (0 + ... + Cs::DUAL);
+  // segment table (constraint-major loops of computeTheta / computeBarrierMerit)
+  DEV static int seg_dim(int c) { constexpr int dims[NSEG > 0 ? NSEG : 1] = {Cs::DUAL...}; return dims[c]; }
+  DEV static int seg_off(int c) {
+    constexpr int dims[NSEG > 0 ? NSEG : 1] = {Cs::DUAL...};
+    int o = 0;
+    for (int i = 0; i < c; ++i) o += dims[i];
+    return o;
+  }
+  static bool matches(const ProblemDev &P) {   // host-side signature check
+    constexpr int kinds[NSEG > 0 ? NSEG : 1] = {Cs::KIND...};
+    constexpr int dims[NSEG > 0 ? NSEG : 1] = {Cs::DIM...};
+    if (P.n_cons != NSEG) return false;
+    for (int i = 0; i < NSEG; ++i) if (P.cons[i].kind != kinds[i] || P.cons[i].dim != dims[i]) return false;
+    return true;
+  }
+  template <int NX, int NU>
+  DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
+    ConImpl<0, 0, Cs...>::template eval<NX, NU>(P, x, u, g);
+  }
+  // Gx (M x NX) and Gu (M x NU) must be zero-filled by the caller
+  template <int NX, int NU>
+  DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
+    ConImpl<0, 0, Cs...>::template jac<NX, NU>(P, x, Gx, Gu);
+  }
+};
+template <>
+struct ConList<> {
+  static constexpr int NSEG = 0;
+  static constexpr int M = 0;
+  DEV static int seg_dim(int) { return 0; }
+  DEV static int seg_off(int) { return 0; }
+  static bool matches(const ProblemDev &P) { return P.n_cons == 0; }
+  template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
+};
+
+// ---- QuadraticObjective (objective.cpp:80-154); Q_dt = Q*dt and R_dt = R*dt are stored in the pool
+template <int NX, int NU>
+struct Objective {
+  DEV static void state_error(const ProblemDev *P, const double *xref_traj, int t, const double *x, double *e) {
+    if (xref_traj) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) e[i] = x[i] - xref_traj[(size_t)t * NX + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) e[i] = x[i] - P->pool[P->off_xref + i];
+    }
+  }
+  // (e^T Q) e, row-vector-first association as `(e.transpose() * Q_ * e).value()`
+  DEV static double running_cost(const ProblemDev *P, const double *xref_traj, int t, const double *x, const double *u) {
+    double e[NX];
+    state_error(P, xref_traj, t, x, e);
+    const double *Q = P->pool + P->off_Qdt;
+    const double *R = P->pool + P->off_Rdt;
+    double sx = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) r += e[i] * Q[i * NX + j];
+      sx += r * e[j];
+    }
+    double su = 0.0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) r += u[i] * R[i * NU + j];
+      su += r * u[j];
+    }
+    return sx + su;
+  }
+  DEV static double terminal_cost(const ProblemDev *P, const double *x) {
+    double e[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) e[i] = x[i] - P->pool[P->off_xref + i];
+    const double *Q = P->pool + P->off_Qf;
+    double sx = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) r += e[i] * Q[i * NX + j];
+      sx += r * e[j];
+    }
+    return sx;
+  }
+  // l_x = (2 Q_dt) e, l_u = (2 R_dt) u
+  DEV static void lx(const ProblemDev *P, const double *xref_traj, int t, const double *x, double *out) {
+    double e[NX];
+    state_error(P, xref_traj, t, x, e);
+    const double *Q = P->pool + P->off_Qdt;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += (2.0 * Q[i * NX + j]) * e[j];
+      out[i] = s;
+    }
+  }
+  DEV static void lu(const ProblemDev *P, const double *u, double *out) {
+    const double *R = P->pool + P->off_Rdt;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) s += (2.0 * R[i * NU + j]) * u[j];
+      out[i] = s;
+    }
+  }
+  // V_x(N) = (2 Qf)(x_N - x_ref), V_xx(N) = 2 Qf
+  DEV static void final_grad(const ProblemDev *P, const double *x, double *out) {
+    const double *Q = P->pool + P->off_Qf;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += (2.0 * Q[i * NX + j]) * (x[j] - P->pool[P->off_xref + j]);
+      out[i] = s;
+    }
+  }
+};
+
+}  // namespace cddp_dev

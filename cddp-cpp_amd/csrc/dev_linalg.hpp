@@ -1,0 +1,195 @@
+// Device-side small dense linear algebra for the batched CLDDP / IPDDP kernels (gfx950).
+//
+// Execution model: ONE TRAJECTORY PER LANE.  Every matrix on the Riccati path is at most
+// 14 x 14 fp64, far below an MFMA tile for the single-GPU configs (nx <= 4), so each lane of a
+// 64-wide wavefront owns a complete trajectory and keeps its Q/V blocks in VGPRs; the batch
+// index is the fastest-varying memory index, so every load/store of a wavefront is one fully
+// coalesced 512-byte transaction (see DESIGN.md "Data layout").  All routines below are
+// therefore plain per-lane code on small fixed-size arrays with compile-time dimensions
+// (fully unrolled by hipcc); no cross-lane traffic is needed.
+//
+// Semantics follow the reference's linear-algebra dependency where solver decisions depend
+// on it (Eigen 3.4.0 LDLT with diagonal pivoting, PartialPivLU inverse) -- see the call sites
+// cited at each routine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+
+#define DEV __device__ __forceinline__
+
+namespace cddp_dev {
+
+DEV double dmax(double a, double b) { return (a < b) ? b : a; } // == std::max(a,b), NaN behaviour included
+DEV double dmin(double a, double b) { return (b < a) ? b : a; } // == std::min(a,b)
+DEV double dclamp(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }  // std::clamp
+DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN and +-Inf
+
+// Eigen::LDLT<MatrixXd>, restated (Eigen/src/Cholesky/LDLT.h, ldlt_inplace<Lower>::unblocked
+// and LDLT::_solve_impl).  Reference call sites: boxqp.cpp:105,147; ipddp_solver.cpp:456,583,
+// 1087,1428.  `n` is the runtime size (<= NMAX) so BoxQP can factor a free sub-block.
+template <int NMAX>
+struct LDLTd {
+  double m[NMAX * NMAX];
+  int tr[NMAX];
+  int n;
+  bool ok;
+
+  DEV void compute(const double *A, int n_) {
+    n = n_;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) m[i * NMAX + j] = A[i * NMAX + j];
+    ok = true;
+    if (n <= 1) { if (n == 1) tr[0] = 0; return; }
+    bool found_zero_pivot = false;
+    bool ret = true;
+    double temp[NMAX];
+    for (int k = 0; k < n; ++k) {
+      int big = k;
+      double bigv = fabs(m[k * NMAX + k]);
+      for (int i = k + 1; i < n; ++i) {
+        double v = fabs(m[i * NMAX + i]);
+        if (v > bigv) { bigv = v; big = i; }
+      }
+      tr[k] = big;
+      if (k != big) {
+        int s = n - big - 1;
+        for (int j = 0; j < k; ++j) { double t = m[k * NMAX + j]; m[k * NMAX + j] = m[big * NMAX + j]; m[big * NMAX + j] = t; }
+        for (int i = 0; i < s; ++i) {
+          double t = m[(big + 1 + i) * NMAX + k]; m[(big + 1 + i) * NMAX + k] = m[(big + 1 + i) * NMAX + big]; m[(big + 1 + i) * NMAX + big] = t;
+        }
+        { double t = m[k * NMAX + k]; m[k * NMAX + k] = m[big * NMAX + big]; m[big * NMAX + big] = t; }
+        for (int i = k + 1; i < big; ++i) { double t = m[i * NMAX + k]; m[i * NMAX + k] = m[big * NMAX + i]; m[big * NMAX + i] = t; }
+      }
+      int rs = n - k - 1;
+      if (k > 0) {
+        for (int j = 0; j < k; ++j) temp[j] = m[j * NMAX + j] * m[k * NMAX + j];
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += m[k * NMAX + j] * temp[j];
+        m[k * NMAX + k] -= s;
+        for (int i = 0; i < rs; ++i) {
+          double t = 0.0;
+          for (int j = 0; j < k; ++j) t += m[(k + 1 + i) * NMAX + j] * temp[j];
+          m[(k + 1 + i) * NMAX + k] -= t;
+        }
+      }
+      double akk = m[k * NMAX + k];
+      bool valid = fabs(akk) > 0.0;
+      if (k == 0 && !valid) {
+        for (int j = 0; j < n; ++j) {
+          tr[j] = j;
+          for (int i = j + 1; i < n; ++i) ret = ret && (m[i * NMAX + j] == 0.0);
+        }
+        ok = ret;
+        return;
+      }
+      if (rs > 0 && valid) { for (int i = 0; i < rs; ++i) m[(k + 1 + i) * NMAX + k] /= akk; }
+      else if (rs > 0) { for (int i = 0; i < rs; ++i) ret = ret && (m[(k + 1 + i) * NMAX + k] == 0.0); }
+      if (found_zero_pivot && valid) ret = false;
+      else if (!valid) found_zero_pivot = true;
+    }
+    ok = ret;
+  }
+
+  // in-place solve of one right-hand side column x (length n, stride 1)
+  DEV void solve(double *x) const {
+    for (int k = 0; k < n; ++k) { int t = tr[k]; if (t != k) { double v = x[k]; x[k] = x[t]; x[t] = v; } }
+    for (int i = 0; i < n; ++i) { double s = x[i]; for (int kk = 0; kk < i; ++kk) s -= m[i * NMAX + kk] * x[kk]; x[i] = s; }
+    for (int i = 0; i < n; ++i) { double d = m[i * NMAX + i]; x[i] = (fabs(d) > DBL_MIN) ? x[i] / d : 0.0; }
+    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int kk = i + 1; kk < n; ++kk) s -= m[kk * NMAX + i] * x[kk]; x[i] = s; }
+    for (int k = n - 1; k >= 0; --k) { int t = tr[k]; if (t != k) { double v = x[k]; x[k] = x[t]; x[t] = v; } }
+  }
+};
+
+// scalar specialisation: 1x1 LDLT always reports Success; D^+ with tolerance DBL_MIN.
+DEV double ldlt1_solve(double d, double x) { return (fabs(d) > DBL_MIN) ? x / d : 0.0; }
+
+// MatrixXd::inverse() (PartialPivLU) -- reference clddp_solver.cpp:143.
+template <int N>
+DEV void inverse_pplu(const double *A, double *inv) {
+  if (N == 1) { inv[0] = 1.0 / A[0]; return; }
+  double lu[N * N];
+  int perm[N];
+  for (int i = 0; i < N * N; ++i) lu[i] = A[i];
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int piv = k; double best = fabs(lu[k * N + k]);
+    for (int i = k + 1; i < N; ++i) if (fabs(lu[i * N + k]) > best) { best = fabs(lu[i * N + k]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < N; ++j) { double t = lu[k * N + j]; lu[k * N + j] = lu[piv * N + j]; lu[piv * N + j] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < N; ++i) {
+      lu[i * N + k] /= lu[k * N + k];
+      for (int j = k + 1; j < N; ++j) lu[i * N + j] -= lu[i * N + k] * lu[k * N + j];
+    }
+  }
+  for (int c = 0; c < N; ++c) {
+    double y[N];
+    for (int i = 0; i < N; ++i) { double s = (perm[i] == c) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= lu[i * N + k] * y[k]; y[i] = s; }
+    for (int i = N - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < N; ++k) s -= lu[i * N + k] * inv[k * N + c]; inv[i * N + c] = s / lu[i * N + i]; }
+  }
+}
+
+// min Re(eig) of Q_uu_reg -- EigenSolver(...).eigenvalues().real().minCoeff(), clddp_solver.cpp:133.
+// 1x1 / 2x2: closed form for a general real matrix; larger: cyclic Jacobi on the symmetric part
+// (Q_uu_reg is symmetric up to rounding; deviation noted in DESIGN.md).
+template <int N>
+DEV double min_real_eig(const double *M) {
+  if (N == 1) return M[0];
+  if (N == 2) {
+    double a = M[0], b = M[1], c = M[2], d = M[3];
+    double tr = a + d, det = a * d - b * c;
+    double disc = 0.25 * tr * tr - det;
+    if (disc < 0) return 0.5 * tr;
+    return 0.5 * tr - sqrt(disc);
+  }
+  double S[N * N];
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) S[i * N + j] = 0.5 * (M[i * N + j] + M[j * N + i]);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j) off += S[i * N + j] * S[i * N + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        if (S[p * N + q] == 0.0) continue;
+        double theta = (S[q * N + q] - S[p * N + p]) / (2.0 * S[p * N + q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < N; ++k) { double skp = S[k * N + p], skq = S[k * N + q]; S[k * N + p] = cs * skp - sn * skq; S[k * N + q] = sn * skp + cs * skq; }
+        for (int k = 0; k < N; ++k) { double spk = S[p * N + k], sqk = S[q * N + k]; S[p * N + k] = cs * spk - sn * sqk; S[q * N + k] = sn * spk + cs * sqk; }
+      }
+  }
+  double mn = S[0];
+  for (int i = 1; i < N; ++i) mn = dmin(mn, S[i * N + i]);
+  return mn;
+}
+
+// ---- tiny GEMM helpers, row-major, compile-time sizes, k-ascending accumulation ----------
+// C(RxC) = A^T(RxK) * B(KxC) where A is stored KxR
+template <int R, int K, int C>
+DEV void mm_tn(const double *A, const double *B, double *Cm) {
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s += A[k * R + i] * B[k * C + j];
+      Cm[i * C + j] = s;
+    }
+}
+// C(RxC) = A(RxK) * B(KxC)
+template <int R, int K, int C>
+DEV void mm_nn(const double *A, const double *B, double *Cm) {
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s += A[i * K + k] * B[k * C + j];
+      Cm[i * C + j] = s;
+    }
+}
+
+}  // namespace cddp_dev

@@ -1,0 +1,408 @@
+// Device-side plants: continuous dynamics f(x,u) and continuous-time Jacobians f_x, f_u
+// (the DynamicalSystem plugin surface, reference include/cddp-cpp/cddp_core/dynamical_system.hpp
+// and src/dynamics_model/*.cpp), enumerated by cddp_hip_model id.
+//
+// Derivative source per model:
+//   Pendulum / Unicycle : the reference's analytic Jacobians (pendulum.cpp:44-66, unicycle.cpp:44-66)
+//   CartPole            : hand-derived exact derivatives of the autodiff expression
+//                         (cartpole.cpp:69-103, which includes the damping term)
+//   Quadrotor           : forward-mode duals through the quaternion normalisation, i.e. what
+//                         autodiff::jacobian does on quadrotor.cpp:166-219
+//   Manipulator         : central finite differences, h = 2e-5 (manipulator.cpp:53-70, helper.hpp:95-118)
+//   LTI                 : (A - I)/dt, B/dt (lti_system.cpp:78-92)
+#pragma once
+#include "dev_linalg.hpp"
+#include "../../include/cddp_hip.h"
+
+namespace cddp_dev {
+
+// ---- forward-mode dual number with NP compile-time seeds (register resident) ------------
+template <int NP>
+struct DualN {
+  double v;
+  double d[NP];
+  DEV DualN() {}
+  DEV DualN(double x) : v(x) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) d[i] = 0.0;
+  }
+};
+template <int NP> DEV DualN<NP> operator+(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int NP> DEV DualN<NP> operator-(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int NP> DEV DualN<NP> operator-(const DualN<NP> &a) { DualN<NP> r; r.v = -a.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = -a.d[i]; return r; }
+template <int NP> DEV DualN<NP> operator*(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int NP> DEV DualN<NP> operator/(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v / b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
+template <int NP> DEV DualN<NP> dsin(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = c * a.d[i]; return r; }
+template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = c; double ms = -s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = ms * a.d[i]; return r; }
+template <int NP> DEV DualN<NP> dsqrt(const DualN<NP> &a) { DualN<NP> r; r.v = sqrt(a.v); double g = 0.5 / r.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
+DEV double dsin(double a) { return sin(a); }
+DEV double dcos(double a) { return cos(a); }
+DEV double dsqrt(double a) { return sqrt(a); }
+DEV double dval(double a) { return a; }
+template <int NP> DEV double dval(const DualN<NP> &a) { return a.v; }
+
+// Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
+template <class F, int NX, int NU>
+DEV void ad_jacobian(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+  typedef DualN<NX + NU> D;
+  D xs[NX], us[NU], xd[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { xs[i] = D(x[i]); xs[i].d[i] = 1.0; }
+#pragma unroll
+  for (int j = 0; j < NU; ++j) { us[j] = D(u[j]); us[j].d[NX + j] = 1.0; }
+  F::template eval<D>(p, xs, us, xd);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) Fx[i * NX + j] = xd[i].d[j];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) Fu[i * NU + j] = xd[i].d[NX + j];
+  }
+}
+
+// ================================================================================ Pendulum
+struct PendulumModel {   // pendulum.cpp:29-66; params: length, mass, damping, gravity
+  static constexpr int ID = CDDP_HIP_MODEL_PENDULUM, NX = 2, NU = 1;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) {
+    const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
+    const double inertia = mass * length * length;
+    xd[0] = x[1];
+    xd[1] = (u[0] - damping * x[1] + mass * gravity * length * sin(x[0])) / inertia;
+  }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
+    Fx[0] = 0.0; Fx[1] = 1.0;
+    Fx[2] = (gravity / length) * cos(x[0]);
+    Fx[3] = -damping / (mass * length * length);
+    Fu[0] = 0.0; Fu[1] = 1.0 / (mass * length * length);
+  }
+};
+
+// ================================================================================ CartPole
+struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, pole_length, gravity, damping
+  static constexpr int ID = CDDP_HIP_MODEL_CARTPOLE, NX = 4, NU = 1;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) {
+    // double path (cartpole.cpp:38-67): NO damping term
+    const double mc = p[0], mp = p[1], l = p[2], g = p[3];
+    const double theta_dot = x[3], force = u[0];
+    double s, c; sincos(x[1], &s, &c);
+    const double total_mass = mc + mp;
+    const double den = mc + mp * s * s;
+    xd[0] = x[2];
+    xd[1] = theta_dot;
+    xd[2] = (force + mp * s * (l * theta_dot * theta_dot + g * c)) / den;
+    xd[3] = (-force * c - mp * l * theta_dot * theta_dot * c * s - total_mass * g * s) / (l * den);
+  }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    // exact derivatives of the autodiff expression (cartpole.cpp:69-103, WITH -damping*theta_dot)
+    const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
+    const double w = x[3], F = u[0];
+    double s, c; sincos(x[1], &s, &c);
+    const double M = mc + mp;
+    const double den = mc + mp * s * s;
+    const double dden = 2.0 * mp * s * c;
+    const double inner = l * w * w + g * c;
+    const double num3 = F + mp * s * inner;
+    const double dnum3 = mp * c * inner - mp * s * g * s;
+    const double num4 = -F * c - mp * l * w * w * c * s - M * g * s - b * w;
+    const double dnum4 = F * s - mp * l * w * w * (c * c - s * s) - M * g * c;
+    const double den2 = den * den;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Fx[i] = 0.0;
+    Fx[0 * 4 + 2] = 1.0;
+    Fx[1 * 4 + 3] = 1.0;
+    Fx[2 * 4 + 1] = (dnum3 * den - num3 * dden) / den2;
+    Fx[2 * 4 + 3] = (mp * s * (2.0 * l * w)) / den;
+    Fx[3 * 4 + 1] = (dnum4 * den - num4 * dden) / (l * den2);
+    Fx[3 * 4 + 3] = (-2.0 * mp * l * w * c * s - b) / (l * den);
+    Fu[0] = 0.0; Fu[1] = 0.0;
+    Fu[2] = 1.0 / den;
+    Fu[3] = -c / (l * den);
+  }
+};
+
+// ================================================================================ Unicycle
+struct UnicycleModel {   // unicycle.cpp:28-66
+  static constexpr int ID = CDDP_HIP_MODEL_UNICYCLE, NX = 3, NU = 2;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *, const double *x, const double *u, double *xd) {
+    double s, c; sincos(x[2], &s, &c);
+    xd[0] = u[0] * c; xd[1] = u[0] * s; xd[2] = u[1];
+  }
+  DEV static void jac(const double *, const double *x, const double *u, double *Fx, double *Fu) {
+    double s, c; sincos(x[2], &s, &c);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Fx[i] = 0.0;
+    Fx[0 * 3 + 2] = -u[0] * s;
+    Fx[1 * 3 + 2] = u[0] * c;
+    Fu[0] = c; Fu[1] = 0.0; Fu[2] = s; Fu[3] = 0.0; Fu[4] = 0.0; Fu[5] = 1.0;
+  }
+};
+
+// ================================================================================ LTI
+// Discrete x+ = A x + B u (lti_system.cpp:71-76); A at p[0 .. NX*NX), B after it.
+template <int NX_, int NU_>
+struct LTIModel {
+  static constexpr int ID = CDDP_HIP_MODEL_LTI, NX = NX_, NU = NU_;
+  static constexpr bool kDiscrete = true;
+  DEV static void step(const double *p, const double *x, const double *u, double *xn) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0, t = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += p[i * NX + j] * x[j];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) t += p[NX * NX + i * NU + j] * u[j];
+      xn[i] = s + t;
+    }
+  }
+  DEV static void f(const double *, const double *, const double *, double *) {}
+  // continuous-equivalent Jacobians; dt arrives in p[NX*NX + NX*NU]
+  DEV static void jac(const double *p, const double *, const double *, double *Fx, double *Fu) {
+    const double dt = p[NX * NX + NX * NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Fx[i * NX + j] = (p[i * NX + j] - (i == j ? 1.0 : 0.0)) / dt;
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) Fu[i] = p[NX * NX + i] / dt;
+  }
+};
+
+// ================================================================================ Quadrotor (nx=13)
+struct QuadrotorDyn {   // quadrotor.cpp:33-104 == :166-219; params: mass, arm, Ixx, Iyy, Izz, gravity
+  template <class S>
+  DEV static void eval(const double *p, const S *x, const S *u, S *xd) {
+    const double mass = p[0], arm = p[1], Ixx = p[2], Iyy = p[3], Izz = p[4], grav = p[5];
+    xd[0] = x[7]; xd[1] = x[8]; xd[2] = x[9];
+    S qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+    S norm = dsqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    if (dval(norm) > 1e-6) { qw = qw / norm; qx = qx / norm; qy = qy / norm; qz = qz / norm; }
+    else { qw = S(1.0); qx = S(0.0); qy = S(0.0); qz = S(0.0); }
+    const S ox = x[10], oy = x[11], oz = x[12];
+    xd[3] = S(-0.5) * (qx * ox + qy * oy + qz * oz);
+    xd[4] = S(0.5) * (qw * ox + qy * oz - qz * oy);
+    xd[5] = S(0.5) * (qw * oy - qx * oz + qz * ox);
+    xd[6] = S(0.5) * (qw * oz + qx * oy - qy * ox);
+    const S f1 = u[0], f2 = u[1], f3 = u[2], f4 = u[3];
+    const S thrust = f1 + f2 + f3 + f4;
+    const S tau_x = S(arm) * (f1 - f3);
+    const S tau_y = S(arm) * (f2 - f4);
+    const S tau_z = S(0.1) * (f1 - f2 + f3 - f4);
+    const S R02 = S(2.0) * (qx * qz + qy * qw);
+    const S R12 = S(2.0) * (qy * qz - qx * qw);
+    const S R22 = S(1.0) - S(2.0) * (qx * qx + qy * qy);
+    const double invm = 1.0 / mass;
+    xd[7] = S(invm) * (R02 * thrust);
+    xd[8] = S(invm) * (R12 * thrust);
+    xd[9] = S(invm) * (R22 * thrust) - S(grav);
+    const double c00 = Iyy * Izz, c11 = Ixx * Izz, c22 = Ixx * Iyy;
+    const double det = c00 * Ixx;
+    const double invdet = 1.0 / det;
+    const double i00 = c00 * invdet, i11 = c11 * invdet, i22 = c22 * invdet;
+    const S Iox = S(Ixx) * ox, Ioy = S(Iyy) * oy, Ioz = S(Izz) * oz;
+    const S cx = oy * Ioz - oz * Ioy;
+    const S cy = oz * Iox - ox * Ioz;
+    const S cz = ox * Ioy - oy * Iox;
+    xd[10] = S(i00) * (tau_x - cx);
+    xd[11] = S(i11) * (tau_y - cy);
+    xd[12] = S(i22) * (tau_z - cz);
+  }
+};
+struct QuadrotorModel {
+  static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR, NX = 13, NU = 4;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) { QuadrotorDyn::eval<double>(p, x, u, xd); }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    ad_jacobian<QuadrotorDyn, NX, NU>(p, x, u, Fx, Fu);
+  }
+};
+
+// ================================================================================ SYNTHETIC quadrotor, Euler-ZYX, nx=12
+struct Quad12Dyn {
+  template <class S>
+  DEV static void eval(const double *p, const S *x, const S *u, S *xd) {
+    const double mass = p[0], arm = p[1], Ixx = p[2], Iyy = p[3], Izz = p[4], grav = p[5];
+    const S phi = x[6], th = x[7], psi = x[8];
+    const S ox = x[9], oy = x[10], oz = x[11];
+    const S sph = dsin(phi), cph = dcos(phi), sth = dsin(th), cth = dcos(th), sps = dsin(psi), cps = dcos(psi);
+    const S thrust = u[0] + u[1] + u[2] + u[3];
+    xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+    const double invm = 1.0 / mass;
+    xd[3] = S(invm) * ((cph * sth * cps + sph * sps) * thrust);
+    xd[4] = S(invm) * ((cph * sth * sps - sph * cps) * thrust);
+    xd[5] = S(invm) * ((cph * cth) * thrust) - S(grav);
+    const S tth = sth / cth;
+    xd[6] = ox + sph * tth * oy + cph * tth * oz;
+    xd[7] = cph * oy - sph * oz;
+    xd[8] = (sph * oy + cph * oz) / cth;
+    const S tau_x = S(arm) * (u[0] - u[2]);
+    const S tau_y = S(arm) * (u[1] - u[3]);
+    const S tau_z = S(0.1) * (u[0] - u[1] + u[2] - u[3]);
+    xd[9] = (tau_x - (S(Izz) - S(Iyy)) * oy * oz) / S(Ixx);
+    xd[10] = (tau_y - (S(Ixx) - S(Izz)) * oz * ox) / S(Iyy);
+    xd[11] = (tau_z - (S(Iyy) - S(Ixx)) * ox * oy) / S(Izz);
+  }
+};
+struct Quad12Model {
+  static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR_EULER12, NX = 12, NU = 4;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) { Quad12Dyn::eval<double>(p, x, u, xd); }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    ad_jacobian<Quad12Dyn, NX, NU>(p, x, u, Fx, Fu);
+  }
+};
+
+// ================================================================================ Manipulator (3-DOF)
+struct ManipulatorModel {   // manipulator.cpp:29-70,174-208
+  static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR, NX = 6, NU = 3;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *, const double *x, const double *u, double *xd) {
+    const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
+    const double m1 = 1.0, m2 = 1.0, m3 = 0.5;
+    double M[9];
+    const double c1 = cos(x[1]), c2 = cos(x[2]), c12 = cos(x[1] + x[2]);
+    M[0] = (m1 + m2 + m3) * (la * la);
+    M[4] = (m2 + m3) * (lb * lb);
+    M[8] = m3 * (lc * lc);
+    M[1] = M[3] = (m2 + m3) * la * lb * c1;
+    M[5] = M[7] = m3 * lb * lc * c2;
+    M[2] = M[6] = m3 * la * lc * c12;
+    double G[3];
+    G[0] = 0;
+    G[1] = -(m2 + m3) * grav * lb * c1 - m3 * grav * lc * c12;
+    G[2] = -m3 * grav * lc * c12;
+    double Minv[9];
+    inverse_pplu<3>(M, Minv);
+    double rhs[3] = {u[0] - G[0], u[1] - G[1], u[2] - G[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      xd[i] = x[3 + i];
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += Minv[i * 3 + k] * rhs[k];
+      xd[3 + i] = s;
+    }
+  }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    const double h = 2e-5;
+    double xp[NX], up[NU], fp[NX], fm[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xp[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) up[i] = u[i];
+    for (int i = 0; i < NX; ++i) {
+      xp[i] = x[i] + h; f(p, xp, u, fp);
+      xp[i] = x[i] - h; f(p, xp, u, fm);
+      for (int r = 0; r < NX; ++r) Fx[r * NX + i] = (fp[r] - fm[r]) / (2.0 * h);
+      xp[i] = x[i];
+    }
+    for (int i = 0; i < NU; ++i) {
+      up[i] = u[i] + h; f(p, x, up, fp);
+      up[i] = u[i] - h; f(p, x, up, fm);
+      for (int r = 0; r < NX; ++r) Fu[r * NU + i] = (fp[r] - fm[r]) / (2.0 * h);
+      up[i] = u[i];
+    }
+  }
+};
+
+// ================================================================================ SYNTHETIC 7-joint manipulator, nx=14
+struct Manip7Dyn {
+  template <class S>
+  DEV static void eval(const double *, const S *x, const S *u, S *xd) {
+    const double mi[7] = {2.5, 2.0, 1.6, 1.2, 0.9, 0.6, 0.4};
+    const double li[7] = {1.0, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3};
+    const double wi[7] = {0.0, 1.4, 1.1, 0.8, 0.5, 0.3, 0.15};
+    const double ci[7] = {0.0, 0.30, 0.25, 0.20, 0.15, 0.10, 0.05};
+    const double grav = 9.81;
+    S cum = S(0.0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      xd[i] = x[7 + i];
+      cum = cum + x[i];
+      S Mii = S(mi[i] * li[i] * li[i]);
+      if (i > 0) { S cd = dcos(x[i] - x[i - 1]); Mii = Mii + S(ci[i]) * cd * cd; }
+      S Gi = S(-grav * wi[i]) * dcos(cum);
+      xd[7 + i] = (u[i] - Gi) / Mii;
+    }
+  }
+};
+struct Manip7Model {
+  static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR7, NX = 14, NU = 7;
+  static constexpr bool kDiscrete = false;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) { Manip7Dyn::eval<double>(p, x, u, xd); }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    ad_jacobian<Manip7Dyn, NX, NU>(p, x, u, Fx, Fu);
+  }
+};
+
+// ---- explicit integrators (dynamical_system.cpp:28-83) --------------------------------------
+template <class Model, bool D = Model::kDiscrete> struct Stepper;
+template <class Model> struct Stepper<Model, true> {
+  DEV static void step(int, double, const double *p, const double *x, const double *u, double *xn) { Model::step(p, x, u, xn); }
+};
+template <class Model> struct Stepper<Model, false> {
+  DEV static void step(int integrator, double dt, const double *p, const double *x, const double *u, double *xn) {
+    constexpr int NX = Model::NX;
+    double k1[NX];
+    Model::f(p, x, u, k1);
+    if (integrator == CDDP_HIP_EULER) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + dt * k1[i];
+      return;
+    }
+    double xt[NX], k2[NX];
+    if (integrator == CDDP_HIP_HEUN) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt * k1[i];
+      Model::f(p, xt, u, k2);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + (0.5 * dt) * (k1[i] + k2[i]);
+      return;
+    }
+    double k3[NX];
+    if (integrator == CDDP_HIP_RK3) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = x[i] + (0.5 * dt) * k1[i];
+      Model::f(p, xt, u, k2);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = (x[i] - dt * k1[i]) + (2 * dt) * k2[i];
+      Model::f(p, xt, u, k3);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + (dt / 6) * ((k1[i] + 4.0 * k2[i]) + k3[i]);
+      return;
+    }
+    double k4[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + (0.5 * dt) * k1[i];
+    Model::f(p, xt, u, k2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + (0.5 * dt) * k2[i];
+    Model::f(p, xt, u, k3);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt * k3[i];
+    Model::f(p, xt, u, k4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = x[i] + (dt / 6) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+  }
+};
+
+}  // namespace cddp_dev

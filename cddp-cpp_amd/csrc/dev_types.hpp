@@ -1,0 +1,74 @@
+// Shared host/device POD types of the batched solver core.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/cddp_hip.h"
+
+namespace cddp_dev {
+
+constexpr int kMaxCons = 4;     // path-constraint objects per problem
+constexpr int kMaxTerms = 2;    // terminal-constraint objects per problem
+constexpr int kPool = 1024;     // doubles of problem constants (Q, R, Qf, x_ref, bounds, ...)
+constexpr int kFilterCap = 8;   // > ipddp.max_filter_size + 1
+constexpr int kHistCols = 9;
+
+// per-trajectory phases of the device state machine (cddp_solver_base.cpp:74-152)
+enum Phase : int { PH_ACTIVE = 0, PH_FWD1 = 1, PH_FWD2 = 2, PH_DONE = 3 };
+
+struct ConDev {
+  int kind, dim, dual_dim, offset;               // offset = first row in the stacked dual vector
+  int off_lower, off_upper, off_center, off_A, off_b;   // offsets into ProblemDev::pool
+  int _pad;
+  double scale, radius;
+};
+
+struct TermDev {
+  int kind, dim, offset;     // offset into stacked terminal-ineq rows (or terminal-eq rows)
+  int off_target, off_A, off_b;
+};
+
+struct ProblemDev {
+  int solver, model, integrator, nx, nu, N, m, n_cons;
+  int n_term, mT, pT, ls_rule, n_alphas, clddp_box;   // clddp_box: index of "ControlConstraint" box or -1
+  int has_xref_traj, _pad;
+  double dt;
+  double mp[32];                 // model parameters (LTI: A | B | dt)
+  cddp_hip_options opt;
+  ConDev cons[kMaxCons];
+  TermDev terms[kMaxTerms];
+  int off_Qdt, off_Rdt, off_Qf, off_xref;
+  double alphas[CDDP_HIP_MAX_ALPHAS];
+  double pool[kPool];
+};
+
+// All device buffers of one handle.  Trajectory-like arrays are batch-minor ("(N x batch) stacks"):
+// element e of step t of trajectory b lives at ((t*E + e) * Bp + b); a wavefront of 64 consecutive
+// trajectories therefore touches 512 contiguous bytes per (t, e).
+struct DevBuf {
+  int B, Bp, N, n_slots, n_alphas, hist_batch, hist_cap, _pad;
+  const ProblemDev *P;
+  const double *xref_traj;                 // [(N+1)][nx] shared by the batch, or null
+  // iterate + line-search trial slots: [n_slots] planes
+  double *X, *U, *S, *Y, *G, *Lam;
+  size_t planeX, planeU, planeM;           // plane strides in doubles
+  // derivative / gain / value stacks
+  double *A, *Bm, *K, *k, *Vx, *Vxx, *ks, *ky, *Ks, *Ky;
+  // terminal-constraint state [mT or pT][Bp]
+  double *ST, *YT, *GT, *dST, *dYT, *LamT, *dLamT;
+  double *STt, *YTt, *GTt, *LamTt;        // trial copies [n_alphas][mT|pT][Bp]
+  // per-trajectory scalars [Bp]
+  double *cost, *merit, *inf_pr, *inf_du, *inf_comp, *step_norm, *alpha_pr, *alpha_du, *reg, *mu;
+  double *dV0, *dV1, *phi, *theta, *filter_theta, *apr_max, *adu_max;
+  double *filt;                            // [2*kFilterCap][Bp]: merit then violation
+  int *filt_n, *iter, *status, *phase, *cur, *n_bwd, *n_fwd, *bwd_ok;
+  // trial records [n_alphas][Bp]
+  double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
+  int *t_success;
+  // history [hist_batch][hist_cap][9] (row-major) + counts
+  double *hist;
+  int *hist_n;
+  int *n_active;                           // device counter of trajectories still running
+  unsigned long long *launched;            // rollouts actually executed (speculative alphas included)
+};
+
+}  // namespace cddp_dev

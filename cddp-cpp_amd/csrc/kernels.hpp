@@ -1,0 +1,1289 @@
+// Hand-written HIP kernels (gfx950) of the batched CLDDP / IPDDP backward-forward sweep.
+//
+//   K1  k_derivs            grid (batch x N)   f_x/f_u -> A_t = I + dt f_x, B_t = dt f_u stacks
+//                                              (reference cddp_solver_base.cpp:319-394, clddp_solver.cpp:113-118)
+//   K2  k_backward_clddp    grid (batch)       Riccati sweep + BoxQP          (clddp_solver.cpp:79-204, boxqp.cpp)
+//       k_backward_ipddp    grid (batch)       Riccati sweep + KKT condensation + linear rollout
+//                                              + step-size caps               (ipddp_solver.cpp:960-1569, 2939-2988)
+//   K4  k_forward_clddp     grid (batch x n_a) clamped nonlinear rollout       (clddp_solver.cpp:215-262)
+//       k_forward_ipddp     grid (batch x n_a) primal-dual rollout + filter    (ipddp_solver.cpp:1571-1876)
+//   K5  k_update            grid (batch)       line-search selection, commit, barrier/filter update,
+//                                              regularisation schedule, convergence (cddp_solver_base.cpp:29-186,
+//                                              ipddp_solver.cpp:1878-2082, 2548-2660)
+//   K0  k_init              grid (batch)       ISolverAlgorithm::initialize   (clddp_solver.cpp:28-75, ipddp_solver.cpp:819-913)
+//
+// One trajectory per lane; time is serial inside a lane (the Riccati recursion is a length-N
+// dependency chain), the batch (and the alpha ladder) is the parallel axis.  All stacks are
+// batch-minor so each wavefront load/store is one coalesced 512-B transaction.
+#pragma once
+#include "dev_constraints.hpp"
+#include "dev_models.hpp"
+
+namespace cddp_dev {
+
+#define GI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)d.Bp + (size_t)b)
+
+constexpr double kSlackInteriorOffset = 1e-4;   // ipddp_solver.cpp:35-38
+constexpr double kEpsSlack = 1e-10;
+constexpr double kMaxBarrierRatio = 1e6;
+
+DEV double clip_pos(double num, double den) { return dclamp(num / den, 0.0, kMaxBarrierRatio); }
+DEV double clip_sgn(double num, double den) { return dclamp(num / den, -kMaxBarrierRatio, kMaxBarrierRatio); }
+
+template <int N> DEV void ld(const double *base, size_t stride, double *out) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = base[(size_t)i * stride];
+}
+template <int N> DEV void st(double *base, size_t stride, const double *in) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) base[(size_t)i * stride] = in[i];
+}
+
+// regularisation schedule (cddp_core.cpp:308-346)
+DEV double reg_increase(const cddp_hip_options &o, double r) { r *= o.reg_update_factor; return dmin(r, o.reg_max_value); }
+DEV double reg_decrease(const cddp_hip_options &o, double r) { r /= o.reg_update_factor; return dmax(r, o.reg_min_value); }
+
+DEV void hist_push(const DevBuf &d, int b, double mu_or_zero) {
+  if (b >= d.hist_batch) return;
+  int n = d.hist_n[b];
+  if (n >= d.hist_cap) return;
+  double *row = d.hist + ((size_t)b * d.hist_cap + n) * kHistCols;
+  row[0] = d.cost[b]; row[1] = d.merit[b]; row[2] = d.alpha_pr[b]; row[3] = d.alpha_du[b];
+  row[4] = d.inf_du[b]; row[5] = d.inf_pr[b]; row[6] = d.inf_comp[b]; row[7] = mu_or_zero; row[8] = d.reg[b];
+  d.hist_n[b] = n + 1;
+}
+
+// ================================================================================ K1
+template <class Model>
+__global__ __launch_bounds__(64) void k_derivs(DevBuf d, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *P = d.P;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  double x[NX], u[NU], Fx[NX * NX], Fu[NX * NU];
+  ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
+  ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+  Model::jac(P->mp, x, u, Fx, Fu);
+  const double dt = P->dt;
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      double a = dt * Fx[i * NX + j];
+      if (i == j) a += 1.0;
+      d.A[GI(t, NX * NX, i * NX + j)] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = dt * Fu[i];
+}
+
+// ================================================================================ BoxQP (boxqp.cpp:25-250)
+enum { BQ_HESSIAN_NOT_PD = -1, BQ_NO_DESCENT = 0, BQ_MAX_ITER = 1, BQ_MAX_LS = 2, BQ_SUCCESS = 4, BQ_ALL_CLAMPED = 5 };
+
+template <int N>
+DEV double boxqp_objective(const double *x, const double *H, const double *g) {
+  double q = 0.0, l = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double hx = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) hx += H[i * N + j] * x[j];
+    q += x[i] * hx;
+    l += g[i] * x[i];
+  }
+  return 0.5 * q + l;
+}
+
+// Returns status; x (in: warm start, out: solution), free mask, Hfree factor of the final free block.
+template <int N>
+DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g, const double *lower,
+                    const double *upper, double *x, int *free_, LDLTd<N> &Hfree) {
+  int status = BQ_MAX_ITER;
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = dmin(dmax(x[i], lower[i]), upper[i]);
+  int clamped[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { clamped[i] = 0; free_[i] = 1; }
+  double value = boxqp_objective<N>(x, H, g);
+  double old_value = INFINITY;
+  for (int iter = 0; iter < o.boxqp_max_iterations; ++iter) {
+    if (iter > 0 && fabs(old_value - value) < o.boxqp_min_relative_improvement * fabs(old_value)) { status = BQ_SUCCESS; break; }
+    old_value = value;
+    double grad[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double hx = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) hx += H[i * N + j] * x[j];
+      grad[i] = g[i] + hx;
+    }
+    int old_clamped[N];
+    int nclamped = 0;
+    bool any_different = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      old_clamped[i] = clamped[i];
+      clamped[i] = ((x[i] == lower[i] && grad[i] > 0) || (x[i] == upper[i] && grad[i] < 0)) ? 1 : 0;
+      nclamped += clamped[i];
+      free_[i] = 1 - clamped[i];
+      if (old_clamped[i] != clamped[i]) any_different = true;
+    }
+    if (nclamped == N) { status = BQ_ALL_CLAMPED; break; }
+    const bool factorize = (iter == 0) || any_different;
+    int free_idx[N];
+    int nf = 0;
+    for (int i = 0; i < N; ++i) if (!clamped[i]) free_idx[nf++] = i;
+    if (factorize) {
+      double Hf[N * N];
+      for (int i = 0; i < nf; ++i) for (int j = 0; j < nf; ++j) Hf[i * N + j] = H[free_idx[i] * N + free_idx[j]];
+      Hfree.compute(Hf, nf);
+      if (!Hfree.ok) { status = BQ_HESSIAN_NOT_PD; break; }
+    }
+    double grad_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (!clamped[i]) grad_norm += grad[i] * grad[i];
+    grad_norm = sqrt(grad_norm);
+    if (grad_norm < o.boxqp_min_gradient_norm) { status = BQ_SUCCESS; break; }
+    double search[N], grad_clamped[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { search[i] = 0.0; grad_clamped[i] = g[i]; }
+    for (int i = 0; i < N; ++i)
+      if (clamped[i]) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) grad_clamped[r] += H[r * N + i] * x[i];
+      }
+    double sf[N];
+    for (int i = 0; i < nf; ++i) sf[i] = grad_clamped[free_idx[i]];
+    Hfree.solve(sf);
+    for (int i = 0; i < nf; ++i) search[free_idx[i]] = (-sf[i]) - x[free_idx[i]];
+    double sdotg = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) sdotg += search[i] * grad[i];
+    if (sdotg >= 0) { status = BQ_NO_DESCENT; break; }
+    double step = 1.0;
+    bool ls_ok = false;
+    double xn[N];
+    while (step > o.boxqp_min_step_size) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) xn[i] = dmin(dmax(x[i] + step * search[i], lower[i]), upper[i]);
+      double value_new = boxqp_objective<N>(xn, H, g);
+      if ((value_new - value) <= o.boxqp_armijo_constant * step * sdotg) { ls_ok = true; break; }
+      step *= o.boxqp_step_decrease_factor;
+    }
+    if (!ls_ok) { status = BQ_MAX_LS; break; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = xn[i];
+    value = boxqp_objective<N>(x, H, g);
+  }
+  return status;
+}
+
+// Q-function blocks shared by both solvers:
+//   Q_x = l_x [+ Q_yx^T y] + A^T V_x, Q_u = l_u [+ Q_yu^T y] + B^T V_x,
+//   Q_xx = l_xx + (A^T V_xx) A, Q_ux = l_ux + (B^T V_xx) A, Q_uu = l_uu + (B^T V_xx) B
+template <int NX, int NU>
+DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const double *Vx, const double *Vxx,
+                  double *Qxx, double *Qux, double *Quu) {
+  double T1[NX * NX], T2[NU * NX];
+  mm_tn<NX, NX, NX>(A, Vxx, T1);    // A^T V_xx
+  mm_tn<NU, NX, NX>(Bm, Vxx, T2);   // B^T V_xx
+  mm_nn<NX, NX, NX>(T1, A, Qxx);
+  mm_nn<NU, NX, NX>(T2, A, Qux);
+  mm_nn<NU, NX, NU>(T2, Bm, Quu);
+  const double *Q = P->pool + P->off_Qdt;
+  const double *R = P->pool + P->off_Rdt;
+#pragma unroll
+  for (int i = 0; i < NX * NX; ++i) Qxx[i] = (2.0 * Q[i]) + Qxx[i];
+#pragma unroll
+  for (int i = 0; i < NU * NU; ++i) Quu[i] = (2.0 * R[i]) + Quu[i];
+  (void)Vx;
+}
+
+// ================================================================================ K2 (CLDDP)
+template <class Model>
+__global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  if (count_iter) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const int box = P->clddp_box;
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0;
+  for (;;) {
+    ++nb;
+    double xN[NX], Vx[NX], Vxx[NX * NX];
+    ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+    Obj::final_grad(P, xN, Vx);
+    const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Vxx[i] = 2.0 * Qf[i];
+    st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
+    dV0 = 0; dV1 = 0;
+    double norm_Vx = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
+    double Qu_error = 0.0;
+    bool fail = false;
+    for (int t = N - 1; t >= 0; --t) {
+      double A[NX * NX], Bm[NX * NU], x[NX], u[NU];
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
+      ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
+      Obj::lx(P, d.xref_traj, t, x, Qx);
+      Obj::lu(P, u, Qu);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += A[k * NX + i] * Vx[k];
+        Qx[i] = Qx[i] + s; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Bm[k * NU + i] * Vx[k];
+        Qu[i] = Qu[i] + s; }
+      q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+      double Quu_reg[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu_reg[i] = Quu[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Quu_reg[i * NU + i] += reg;
+      if (min_real_eig<NU>(Quu_reg) <= 0) { fail = true; break; }   // clddp_solver.cpp:133-140
+      double kk[NU], KK[NU * NX];
+      if (box < 0) {   // clddp_solver.cpp:142-145
+        double H[NU * NU];
+        inverse_pplu<NU>(Quu_reg, H);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) s += (-H[i * NU + j]) * Qu[j];
+          kk[i] = s;
+#pragma unroll
+          for (int c = 0; c < NX; ++c) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) s2 += (-H[i * NU + j]) * Qux[j * NX + c];
+            KK[i * NX + c] = s2;
+          }
+        }
+      } else {         // clddp_solver.cpp:147-178
+        const ConDev &cc = P->cons[box];
+        double lb[NU], ub[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - u[i]; ub[i] = P->pool[cc.off_upper + i] - u[i]; }
+        ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);   // warm start x0 = k_u_[t]
+        int free_[NU];
+        LDLTd<NU> Hfree;
+        int stq = boxqp_solve<NU>(o, Quu_reg, Qu, lb, ub, kk, free_, Hfree);
+        if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) { fail = true; break; }
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) KK[i] = 0.0;
+        int free_idx[NU]; int nf = 0;
+        for (int i = 0; i < NU; ++i) if (free_[i]) free_idx[nf++] = i;
+        if (nf > 0) {
+          for (int c = 0; c < NX; ++c) {
+            double col[NU];
+            for (int i = 0; i < nf; ++i) col[i] = Qux[free_idx[i] * NX + c];
+            Hfree.solve(col);
+            for (int i = 0; i < nf; ++i) KK[free_idx[i] * NX + c] = -col[i];
+          }
+        }
+      }
+      st<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      // dV (un-regularised Q_uu, clddp_solver.cpp:184-186)
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s; }
+      { double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { s0 += Qu[i] * kk[i]; s1 += kk[i] * Quuk[i]; }
+        dV0 += s0; dV1 += 0.5 * s1; }
+      // V_x = Q_x + (K^T Q_uu) k + Q_ux^T k + K^T Q_u ; V_xx = Q_xx + (K^T Q_uu) K + Q_ux^T K + K^T Q_ux
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KtQ[i * NU + j] * kk[j]; bb += Qux[j * NX + i] * kk[j]; c += KK[j * NX + i] * Qu[j]; }
+        Vx[i] = ((Qx[i] + a) + bb) + c;
+      }
+      double Vn[NX * NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a += KtQ[i * NU + j] * KK[j * NX + c]; bb += Qux[j * NX + i] * KK[j * NX + c]; e += KK[j * NX + i] * Qux[j * NX + c]; }
+          Vn[i * NX + c] = ((Qxx[i * NX + c] + a) + bb) + e;
+        }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
+      st<NX>(d.Vx + GI(t, NX, 0), d.Bp, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Vxx);
+      { double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) s += fabs(Vx[i]);
+        norm_Vx += s; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu_error = dmax(Qu_error, fabs(Qu[i]));
+    }
+    if (!fail) {
+      double scaling = o.termination_scaling_max_factor;
+      scaling = dmax(scaling, norm_Vx / (N * NX)) / scaling;
+      inf_du = Qu_error / scaling;
+      ok = true;
+      break;
+    }
+    if (force == 2) break;   // single un-retried pass (step-level API)
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  if (ok) { d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  if (inf_du < o.tolerance) {   // checkEarlyConvergence (clddp_solver.cpp:206-213)
+    d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, 0.0); return;
+  }
+  d.phase[b] = PH_FWD1;
+}
+
+// ================================================================================ K2 (IPDDP)
+// Unconstrained branch (ipddp_solver.cpp:1048-1118) when Cons::M == 0, path-constraint branch
+// (:1355-1568) otherwise; followed by the linear-policy rollout (:1511-1532) fused with
+// computeMaxStepSizes (:2939-2988).
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  const double *Sc = d.S + (size_t)cur * d.planeM;
+  const double *Yc = d.Y + (size_t)cur * d.planeM;
+  const double *Gc = d.G + (size_t)cur * d.planeM;
+  if (count_iter) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  for (;;) {
+    ++nb;
+    double xN[NX], Vx[NX], Vxx[NX * NX];
+    ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+    Obj::final_grad(P, xN, Vx);
+    const double *Qf = P->pool + P->off_Qf;
+    {  // V_xx = symmetrize(2 Qf)
+      double H2[NX * NX];
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) H2[i] = 2.0 * Qf[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (H2[i * NX + c] + H2[c * NX + i]);
+    }
+    st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
+    dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
+    bool fail = false;
+    for (int t = N - 1; t >= 0; --t) {
+      double A[NX * NX], Bm[NX * NU], x[NX], u[NU];
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
+      ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+      double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU];
+      if constexpr (M > 0) {
+        ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+        ld<M>(Sc + GI(t, M, 0), d.Bp, s);
+        ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+#pragma unroll
+        for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+        Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+      }
+      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
+      Obj::lx(P, d.xref_traj, t, x, Qx);
+      Obj::lu(P, u, Qu);
+      // Q_x = l_x + Q_yx^T y + A^T V_x ; Q_u = l_u + Q_yu^T y + B^T V_x
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double acc = Qx[i];
+        if constexpr (M > 0) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += Qyx[r * NX + i] * y[r];
+          acc = acc + s1; }
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += A[k * NX + i] * Vx[k];
+        Qx[i] = acc + s2;
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double acc = Qu[i];
+        if constexpr (M > 0) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += Qyu[r * NU + i] * y[r];
+          acc = acc + s1; }
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + i] * Vx[k];
+        Qu[i] = acc + s2;
+      }
+      q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+
+      double kk[NU], KK[NU * NX];
+      double YS[MM], rp[MM], rc[MM], rhat[MM], Sir[MM], s_safe[MM];
+      if constexpr (M == 0) {
+        // ---- unconstrained: regularisation stays in Q_uu (ipddp_solver.cpp:1084-1107)
+        double Qs[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]);
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Quu[i * NU + i] += reg;
+        if (NU == 1) {
+          kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
+#pragma unroll
+          for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Quu[0], Qux[c]);
+        } else {
+          LDLTd<NU> f;
+          f.compute(Quu, NU);
+          if (!f.ok) { fail = true; break; }
+          double col[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+          for (int c = 0; c < NX; ++c) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c];
+            f.solve(col);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+          }
+        }
+      } else {
+        // ---- KKT condensation (ipddp_solver.cpp:1410-1492)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          s_safe[i] = dmax(s[i], s_floor);
+          YS[i] = clip_pos(y[i], s_safe[i]);
+          rp[i] = g[i] + s[i];
+          rc[i] = y[i] * s[i] - mu;
+          rhat[i] = y[i] * rp[i] - rc[i];
+          Sir[i] = clip_sgn(rhat[i], s_safe[i]);
+        }
+        // W = Q_yu^T YSinv  (NU x M)
+        double W[NU * MM];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int r = 0; r < M; ++r) W[i * M + r] = Qyu[r * NU + i] * YS[r];
+        double WQyu[NU * NU], WQyx[NU * NX];
+        mm_nn<NU, M, NU>(W, Qyu, WQyu);
+        mm_nn<NU, M, NX>(W, Qyx, WQyx);
+        double Qr[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + WQyu[i * NU + c];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+        double QyuSir[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += Qyu[r * NU + i] * Sir[r];
+          QyuSir[i] = s1; }
+        if (NU == 1) {
+          kk[0] = -ldlt1_solve(Qr[0], Qu[0] + QyuSir[0]);
+#pragma unroll
+          for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Qr[0], Qux[c] + WQyx[c]);
+        } else {
+          LDLTd<NU> f;
+          f.compute(Qr, NU);
+          if (!f.ok) { fail = true; break; }
+          double col[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qu[i] + QyuSir[i];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+          for (int c = 0; c < NX; ++c) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c] + WQyx[i * NX + c];
+            f.solve(col);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+          }
+        }
+        // slack / dual gains (:1458-1472)
+        double temp[MM], ky[MM], ksv[MM], Ky[MM * NX], Ksm[MM * NX];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < NU; ++i) s1 += Qyu[r * NU + i] * kk[i];
+          temp[r] = s1;
+          ky[r] = clip_sgn(rhat[r] + y[r] * temp[r], s_safe[r]);
+          ksv[r] = (-rp[r]) - temp[r];
+#pragma unroll
+          for (int c = 0; c < NX; ++c) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) s2 += Qyu[r * NU + i] * KK[i * NX + c];
+            double inner = Qyx[r * NX + c] + s2;
+            Ky[r * NX + c] = dmin(dmax(YS[r] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+            Ksm[r * NX + c] = (-Qyx[r * NX + c]) - s2;
+          }
+        }
+        st<M>(d.ky + GI(t, M, 0), d.Bp, ky);
+        st<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
+        st<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
+        st<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+        // condensed, un-regularised Q blocks (:1488-1492)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qu[i] += QyuSir[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += Qyx[r * NX + i] * Sir[r];
+          Qx[i] += s1; }
+        double Wx[NX * MM], WxQyx[NX * NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+          for (int r = 0; r < M; ++r) Wx[i * M + r] = Qyx[r * NX + i] * YS[r];
+        mm_nn<NX, M, NX>(Wx, Qyx, WxQyx);
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) Qxx[i] += WxQyx[i];
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) Qux[i] += WQyx[i];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] += WQyu[i];
+#pragma unroll
+        for (int r = 0; r < M; ++r) { inf_pr = dmax(inf_pr, fabs(rp[r])); inf_comp = dmax(inf_comp, fabs(rc[r])); }
+      }
+      st<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      // dV, V_x, V_xx (:1494-1503 / :1098-1107)
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s1; }
+      { double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { s0 += kk[i] * Qu[i]; s1 += kk[i] * Quuk[i]; }
+        dV0 += s0; dV1 += 0.5 * s1; }
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qu[j]; bb += Qux[j * NX + i] * kk[j]; c += KtQ[i * NU + j] * kk[j]; }
+        Vx[i] = ((Qx[i] + a) + bb) + c;
+      }
+      double Vn[NX * NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qux[j * NX + c]; bb += Qux[j * NX + i] * KK[j * NX + c]; e += KtQ[i * NU + j] * KK[j * NX + c]; }
+          Vn[i * NX + c] = ((Qxx[i * NX + c] + a) + bb) + e;
+        }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
+      st<NX>(d.Vx + GI(t, NX, 0), d.Bp, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Vxx);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+    }
+    if (!fail) { ok = true; break; }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
+    d.inf_pr[b] = (M == 0) ? 0.0 : inf_pr;
+    d.inf_comp[b] = (M == 0) ? 0.0 : inf_comp;
+    // ---- linear-policy rollout dX (dx0 = 0) -> dS, dY -> fraction-to-boundary caps
+    double apr = 1.0, adu = 1.0;
+    if constexpr (M > 0) {
+      const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      for (int t = 0; t < N; ++t) {
+        double kk[NU], KK[NU * NX], ksv[M], ky[M], Ksm[M * NX], Ky[M * NX], s[M], y[M];
+        ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+        ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+        ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
+        ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
+        ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+        ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
+        ld<M>(Sc + GI(t, M, 0), d.Bp, s);
+        ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+          double a = 0.0, c = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
+          double ds = ksv[r] + a;
+          double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
+          if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
+          if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
+        }
+        if (t < N - 1) {
+          double du[NU], A[NX * NX], Bm[NX * NU], dxn[NX];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j];
+            du[i] = kk[i] + a; }
+          ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+          ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j];
+            dxn[i] = (a + c) + 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+        }
+      }
+      apr = dclamp(apr, 0.0, 1.0); adu = dclamp(adu, 0.0, 1.0);
+    }
+    d.apr_max[b] = apr; d.adu_max[b] = adu;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  // checkEarlyConvergence (ipddp_solver.cpp:925-958)
+  bool conv;
+  if (M == 0) conv = (d.inf_pr[b] < o.tolerance && inf_du < o.tolerance);
+  else {
+    const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+    const double asn = fabs(d.alpha_pr[b]) * step_norm;
+    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+  }
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
+  d.phase[b] = PH_FWD1;
+}
+
+// slot that trial `a` of trajectory b writes to: the a-th slot different from the current one
+DEV int trial_slot(int cur, int a) { return (a < cur) ? a : a + 1; }
+
+// ================================================================================ K4 (CLDDP)
+template <class Model>
+__global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, int a0, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = a0 + blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const int slot = trial_slot(cur, a);
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  double *Xn = d.X + (size_t)slot * d.planeX;
+  double *Un = d.U + (size_t)slot * d.planeU;
+  const double alpha = P->alphas[a];
+  const int box = P->clddp_box;
+  atomicAdd(d.launched, 1ull);
+  double x[NX];
+  ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);     // X_[0] == initial state
+  st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
+  double J = 0.0;
+  for (int t = 0; t < N; ++t) {
+    double xo[NX], uo[NU], kk[NU], KK[NU * NX], u[NU], dx[NX];
+    ld<NX>(Xc + GI(t, NX, 0), d.Bp, xo);
+    ld<NU>(Uc + GI(t, NU, 0), d.Bp, uo);
+    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += KK[i * NX + j] * dx[j];
+      u[i] = (uo[i] + alpha * kk[i]) + s;
+      if (box >= 0) u[i] = dmin(dmax(u[i], P->pool[P->cons[box].off_lower + i]), P->pool[P->cons[box].off_upper + i]);
+    }
+    J += Obj::running_cost(P, d.xref_traj, t, x, u);
+    double xn[NX];
+    Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+    st<NU>(Un + GI(t, NU, 0), d.Bp, u);
+    st<NX>(Xn + GI(t + 1, NX, 0), d.Bp, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  }
+  J += Obj::terminal_cost(P, x);
+  const double dJ = d.cost[b] - J;
+  const double expected = -alpha * (d.dV0[b] + 0.5 * alpha * d.dV1[b]);
+  const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+  const size_t ti = (size_t)a * d.Bp + b;
+  d.t_success[ti] = (ratio > o.filter_armijo_constant) ? 1 : 0;
+  d.t_cost[ti] = J; d.t_merit[ti] = J; d.t_theta[ti] = 0.0; d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
+  d.t_apr[ti] = alpha; d.t_adu[ti] = 1.0;
+}
+
+// Sums of computeTheta / computeBarrierMerit / computePrimalAndComplementarity over one slot, in the
+// reference's order (constraint-major, then t) -- ipddp_solver.cpp:2778-2937.
+template <class Cons>
+DEV void ip_reductions(const DevBuf &d, int b, int N, const double *S, const double *Y, const double *G,
+                       double mu, double cost0, bool l2, double &phi, double &theta, double &inf_pr, double &inf_comp) {
+  constexpr int M = Cons::M;
+  double total = 0.0, max_entry = 0.0, ipr = 0.0, icomp = 0.0, mer = cost0;
+  for (int c = 0; c < Cons::NSEG; ++c) {
+    const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+    for (int t = 0; t < N; ++t) {
+      double n1 = 0.0, ninf = 0.0;
+      for (int i = 0; i < dim; ++i) {
+        const size_t j = GI(t, M, off + i);
+        const double r = G[j] + S[j];
+        n1 += l2 ? r * r : fabs(r);
+        ninf = dmax(ninf, fabs(r));
+        icomp = dmax(icomp, fabs(Y[j] * S[j] - mu));
+      }
+      total += n1;
+      max_entry = dmax(max_entry, ninf);
+      ipr = dmax(ipr, ninf);
+    }
+  }
+  for (int c = 0; c < Cons::NSEG; ++c) {
+    const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+    for (int t = 0; t < N; ++t) {
+      double ls = 0.0;
+      for (int i = 0; i < dim; ++i) ls += log(dmax(S[GI(t, M, off + i)], kEpsSlack));
+      mer -= mu * ls;
+    }
+  }
+  const double th = l2 ? sqrt(total) : total;
+  theta = dmax(th, max_entry);
+  phi = mer; inf_pr = ipr; inf_comp = icomp;
+}
+
+// ================================================================================ K4 (IPDDP)
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = a0 + blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const int slot = trial_slot(cur, a);
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  const double *Sc = d.S + (size_t)cur * d.planeM;
+  const double *Yc = d.Y + (size_t)cur * d.planeM;
+  const double *Lc = d.Lam + (size_t)cur * d.planeX;
+  double *Xn = d.X + (size_t)slot * d.planeX;
+  double *Un = d.U + (size_t)slot * d.planeU;
+  double *Sn = d.S + (size_t)slot * d.planeM;
+  double *Yn = d.Y + (size_t)slot * d.planeM;
+  double *Gn = d.G + (size_t)slot * d.planeM;
+  double *Ln = d.Lam + (size_t)slot * d.planeX;
+  const double alpha = P->alphas[a];
+  const double mu = d.mu[b];
+  const double tau = (M == 0) ? 1.0 : dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const double a_pr = dmin(alpha, d.apr_max[b]);
+  const double a_du = dmin(alpha, d.adu_max[b]);
+  const size_t ti = (size_t)a * d.Bp + b;
+  atomicAdd(d.launched, 1ull);
+  d.t_apr[ti] = a_pr; d.t_adu[ti] = a_du;
+  d.t_success[ti] = 0;
+  d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
+  d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
+  double x[NX];
+  ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);
+  st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
+  double cost_new = 0.0;
+  for (int t = 0; t <= N; ++t) {
+    double xo[NX], dx[NX], lam[NX], vx[NX], vxx[NX * NX];
+    ld<NX>(Xc + GI(t, NX, 0), d.Bp, xo);
+    ld<NX>(Lc + GI(t, NX, 0), d.Bp, lam);
+    ld<NX>(d.Vx + GI(t, NX, 0), d.Bp, vx);
+    ld<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, vxx);
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += vxx[i * NX + j] * dx[j];
+      lam[i] = (lam[i] + a_pr * vx[i]) + s;
+      finite = finite && dfinite(lam[i]);
+    }
+    if (!finite) return;
+    st<NX>(Ln + GI(t, NX, 0), d.Bp, lam);
+    if (t == N) break;
+    if constexpr (M > 0) {
+      double s[MM], y[MM], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], sn[MM], yn[MM];
+      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
+      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+      ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
+      ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
+      ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+      ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
+      bool feas = true;
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { p1 += Ksm[r * NX + j] * dx[j]; p2 += Ky[r * NX + j] * dx[j]; }
+        sn[r] = (s[r] + a_pr * ksv[r]) + p1;
+        yn[r] = (y[r] + a_du * ky[r]) + p2;
+        if (sn[r] < (1.0 - tau) * s[r] || yn[r] < (1.0 - tau) * y[r]) feas = false;
+        if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
+      }
+      if (!feas) return;
+      st<M>(Sn + GI(t, M, 0), d.Bp, sn);
+      st<M>(Yn + GI(t, M, 0), d.Bp, yn);
+    }
+    double uo[NU], kk[NU], KK[NU * NX], u[NU], xn[NX];
+    ld<NU>(Uc + GI(t, NU, 0), d.Bp, uo);
+    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double s1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s1 += KK[i * NX + j] * dx[j];
+      u[i] = (uo[i] + a_pr * kk[i]) + s1;
+      finite = finite && dfinite(u[i]);
+    }
+    Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
+    if (!finite) return;
+    cost_new += Obj::running_cost(P, d.xref_traj, t, x, u);
+    if constexpr (M > 0) {
+      double g[MM];
+      Cons::template eval<NX, NU>(P, x, u, g);
+      st<M>(Gn + GI(t, M, 0), d.Bp, g);
+    }
+    st<NU>(Un + GI(t, NU, 0), d.Bp, u);
+    st<NX>(Xn + GI(t + 1, NX, 0), d.Bp, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  }
+  cost_new += Obj::terminal_cost(P, x);
+  double phi_new = cost_new, theta_new = 0.0, ipr = 0.0, icomp = 0.0;
+  if constexpr (M > 0) {
+    // second pass over this lane's own trial slot, in the reference's summation order
+    __threadfence_block();
+    ip_reductions<Cons>(d, b, N, Sn, Yn, Gn, mu, cost_new, o.ipddp_theta_norm_l2 != 0, phi_new, theta_new, ipr, icomp);
+  }
+  if (!dfinite(phi_new) || !dfinite(theta_new) || !dfinite(ipr) || !dfinite(icomp)) return;
+  bool accept = false;
+  if constexpr (M == 0) {   // ipddp_solver.cpp:1785-1792
+    const double dJ = d.cost[b] - cost_new;
+    const double expected = -a_pr * (d.dV0[b] + 0.5 * a_pr * d.dV1[b]);
+    const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+    accept = ratio > 1e-6;
+  } else {        // ipddp_solver.cpp:1793-1834
+    const double expected_improvement = a_pr * d.dV0[b];
+    const int fn = d.filt_n[b];
+    const double cv_old = (fn == 0) ? 0.0 : d.filt[(size_t)(kFilterCap + fn - 1) * d.Bp + b];
+    const double high_ref = (fn == 0) ? d.filter_theta[b] : cv_old;
+    const double merit_old = d.merit[b];
+    if (theta_new > o.filter_max_violation_threshold) {
+      if (theta_new < (1 - o.filter_violation_acceptance_threshold) * high_ref) accept = true;
+    } else if (dmax(theta_new, cv_old) < o.filter_min_violation_for_armijo_check && expected_improvement < 0) {
+      if (phi_new < merit_old + o.filter_armijo_constant * expected_improvement) accept = true;
+    } else {
+      if (phi_new < merit_old - o.filter_merit_acceptance_threshold * theta_new ||
+          theta_new < (1 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    }
+  }
+  d.t_cost[ti] = cost_new; d.t_merit[ti] = phi_new; d.t_theta[ti] = theta_new;
+  d.t_inf_pr[ti] = ipr; d.t_inf_comp[ti] = icomp;
+  d.t_success[ti] = accept ? 1 : 0;
+}
+
+// ---- filter helpers (interior_point_utils.cpp:79-139) on the per-trajectory filter columns
+DEV void filter_accept(const DevBuf &d, int b, double mf, double cv) {
+  int n = d.filt_n[b];
+  for (int i = 0; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(kFilterCap + i) * d.Bp + b];
+    if (fm <= mf && fv <= cv) return;   // dominated by an existing point
+  }
+  int w = 0;
+  for (int i = 0; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(kFilterCap + i) * d.Bp + b];
+    if (!(mf <= fm && cv <= fv)) {      // keep points the candidate does not dominate
+      d.filt[(size_t)w * d.Bp + b] = fm; d.filt[(size_t)(kFilterCap + w) * d.Bp + b] = fv; ++w;
+    }
+  }
+  if (w < kFilterCap) { d.filt[(size_t)w * d.Bp + b] = mf; d.filt[(size_t)(kFilterCap + w) * d.Bp + b] = cv; ++w; }
+  d.filt_n[b] = w;
+}
+DEV void filter_prune(const DevBuf &d, int b) {
+  int n = d.filt_n[b];
+  if (n == 0) return;
+  double bvm = d.filt[b], bvv = d.filt[(size_t)kFilterCap * d.Bp + b];
+  double bmm = bvm, bmv = bvv;
+  for (int i = 1; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(kFilterCap + i) * d.Bp + b];
+    if (fv < bvv) { bvm = fm; bvv = fv; }
+    if (fm < bmm) { bmm = fm; bmv = fv; }
+  }
+  d.filt[b] = bvm; d.filt[(size_t)kFilterCap * d.Bp + b] = bvv;
+  int w = 1;
+  if (fabs(bmv - bvv) > 1e-12 || fabs(bmm - bvm) > 1e-12) {
+    d.filt[(size_t)1 * d.Bp + b] = bmm; d.filt[(size_t)(kFilterCap + 1) * d.Bp + b] = bmv; w = 2;
+  }
+  d.filt_n[b] = w;
+}
+
+// computeScaledDualInfeasibility (ipddp_solver.cpp:2725-2776): G_x from the X slot of the last
+// backward pass (`xslot`), Y from the current slot.
+template <class Model, class Cons>
+DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  const ProblemDev *P = d.P;
+  double v = d.inf_du[b];
+  if (!P->opt.ipddp_check_state_stationarity || M == 0) return v;
+  const double *Xs = d.X + (size_t)xslot * d.planeX;
+  const double *Yc = d.Y + (size_t)d.cur[b] * d.planeM;
+  double ss = 0.0;
+  for (int t = 0; t < d.N; ++t) {
+    double x[NX], y[MM], Gx[MM * NX], Gu[MM * NU];
+    ld<NX>(Xs + GI(t, NX, 0), d.Bp, x);
+    ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+    for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
+    for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
+    Cons::template jac<NX, NU>(P, x, Gx, Gu);
+    for (int c = 0; c < Cons::NSEG; ++c) {
+      const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      for (int j = 0; j < NX; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < dim; ++i) s += Gx[(off + i) * NX + j] * y[off + i];
+        ss = dmax(ss, fabs(s));
+      }
+    }
+  }
+  return dmax(v, ss);
+}
+
+// ================================================================================ K5
+// stage 1: trials [0, n1) were evaluated for PH_FWD1 trajectories (n1 = 1 for the first-success rule,
+//          n1 = n_alphas for the best-merit rule); stage 2: trials [1, n_alphas) for PH_FWD2.
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int is_last_iter) {
+  constexpr int M = Cons::M;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
+  const int ph = d.phase[b];
+  const int n_alphas = d.n_alphas;
+  if ((stage == 1 && ph == PH_FWD1) || (stage == 2 && ph == PH_FWD2)) {
+    const int lo = (stage == 1) ? 0 : 1;
+    const int hi = (stage == 1) ? n1 : n_alphas;
+    int win = -1;
+    if (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) {
+      for (int a = lo; a < hi; ++a) if (d.t_success[(size_t)a * d.Bp + b]) { win = a; break; }
+    } else {
+      double best = INFINITY;
+      for (int a = lo; a < hi; ++a) {
+        const size_t ti = (size_t)a * d.Bp + b;
+        if (d.t_success[ti] && d.t_merit[ti] < best) { best = d.t_merit[ti]; win = a; }
+      }
+    }
+    if (win < 0 && hi < n_alphas) { d.phase[b] = PH_FWD2; goto count; }   // more alphas to try
+    {
+      const int iter = d.iter[b];
+      if (win >= 0) {
+        // ---- applyForwardPassResult (cddp_solver_base.cpp:190-198, ipddp_solver.cpp:1878-1951)
+        const size_t ti = (size_t)win * d.Bp + b;
+        const int old_cur = d.cur[b];
+        const double dJ = d.cost[b] - d.t_cost[ti];
+        d.n_fwd[b] += win + 1;
+        d.cur[b] = trial_slot(old_cur, win);
+        d.cost[b] = d.t_cost[ti];
+        d.merit[b] = d.t_merit[ti];
+        d.alpha_pr[b] = d.t_apr[ti];
+        d.alpha_du[b] = ipddp ? d.t_adu[ti] : 1.0;
+        int st = CDDP_HIP_STATUS_RUNNING;
+        bool conv = false;
+        if (ipddp) {
+          d.inf_pr[b] = d.t_inf_pr[ti]; d.inf_comp[b] = d.t_inf_comp[ti];
+          d.phi[b] = d.t_merit[ti]; d.filter_theta[b] = d.t_theta[ti]; d.theta[b] = d.t_theta[ti];
+          // ---- updateBarrierParameters(true) (ipddp_solver.cpp:2548-2660)
+          const double sdu = scaled_inf_du<Model, Cons>(d, b, old_cur);
+          double mu = d.mu[b];
+          const double mu_old = mu;
+          if constexpr (M > 0) {
+            if (o.barrier_strategy == CDDP_HIP_BARRIER_ADAPTIVE) {
+              const double kkt = dmax(dmax(d.inf_pr[b], sdu), d.inf_comp[b]);
+              const double threshold = dmax(o.barrier_mu_update_factor * mu, 2.0 * mu);
+              if (kkt <= threshold) {
+                double factor = o.barrier_mu_update_factor;
+                if (mu > 1e-20) {
+                  const double ratio = kkt / dmax(mu, 1e-20);
+                  if (ratio < 0.01) factor = 0.1 * o.barrier_mu_update_factor;
+                  else if (ratio < 0.1) factor = 0.3 * o.barrier_mu_update_factor;
+                  else if (ratio < 0.5) factor = 0.6 * o.barrier_mu_update_factor;
+                }
+                const double linear = factor * mu;
+                const double superlinear = pow(mu, o.barrier_mu_update_power);
+                mu = dmax(dmin(linear, superlinear), dmax(o.barrier_mu_min_value, o.tolerance / 100.0));
+              }
+            } else {
+              const double kkt = dmax(dmax(d.inf_pr[b], sdu * o.ipddp_barrier_update_dual_weight), d.inf_comp[b]);
+              if (kkt <= o.ipddp_mu_kappa_epsilon * mu) {
+                const double linear = o.barrier_mu_update_factor * mu;
+                const double superlinear = pow(mu, o.barrier_mu_update_power);
+                mu = dmax(o.barrier_mu_min_value, dmin(linear, superlinear));
+              }
+            }
+          }
+          d.mu[b] = mu;
+          const int cs = d.cur[b];
+          double phi_n = d.cost[b], theta_n = 0.0, ipr = 0.0, icomp = 0.0;
+          if constexpr (M > 0)
+            ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
+                                d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp);
+          const double ftheta = dmax(theta_n, 1e-8);
+          const bool reset = (mu < mu_old) && (mu > 0.0);
+          if (reset) { d.filt_n[b] = 0; }   // no terminal constraints on this path: filter left empty
+          else { filter_accept(d, b, d.phi[b], ftheta); if (d.filt_n[b] > o.ipddp_max_filter_size) filter_prune(d, b); }
+          d.inf_pr[b] = ipr; d.inf_comp[b] = icomp;
+          d.merit[b] = phi_n; d.phi[b] = phi_n; d.filter_theta[b] = ftheta;
+          d.theta[b] = dmax(ftheta, dmax(o.ipddp_theta_0_floor, 1e-8));
+          hist_push(d, b, mu);
+          d.reg[b] = reg_decrease(o, d.reg[b]);
+          // ---- checkConvergence (ipddp_solver.cpp:1953-2025)
+          const double sdu2 = scaled_inf_du<Model, Cons>(d, b, old_cur);
+          const double scomp = d.inf_comp[b], pr = d.inf_pr[b], sn = d.step_norm[b];
+          if constexpr (M == 0) {
+            if (pr < o.tolerance && sdu2 < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; conv = true; }
+            else if (o.acceptable_tolerance > 0.0) {
+              const double sq = sqrt(o.acceptable_tolerance);
+              bool acc = (pr < sq && sdu2 < sq && iter > 50);
+              if (dJ > 0.0) acc = acc || (dJ < o.acceptable_tolerance && iter > 50 && pr < sq && sdu2 < sq);
+              if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; conv = true; }
+            }
+          } else {
+            const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+            if (pr < tol && sdu2 < tol && scomp < tol && sn < o.tolerance * 10.0) { st = CDDP_HIP_STATUS_OPTIMAL; conv = true; }
+            else if (o.acceptable_tolerance > 0.0) {
+              const double at = sqrt(o.acceptable_tolerance);
+              const double bat = dmax(o.barrier_mu_min_value * 100.0, o.tolerance / 10.0);
+              const bool akkt = pr < at && sdu2 < at && scomp < at;
+              const bool bpc = mu <= bat;
+              bool acc = akkt && bpc && iter > 10 && fabs(dJ) < o.acceptable_tolerance;
+              acc = acc || (akkt && bpc && iter >= 1 && sn < o.tolerance * 10.0 && pr < 1e-4);
+              if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; conv = true; }
+            }
+          }
+        } else {
+          hist_push(d, b, 0.0);
+          d.reg[b] = reg_decrease(o, d.reg[b]);
+          // checkConvergence (clddp_solver.cpp:264-277)
+          if (d.inf_du[b] < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; conv = true; }
+          else if (dJ > 0.0 && dJ < o.acceptable_tolerance) { st = CDDP_HIP_STATUS_ACCEPTABLE; conv = true; }
+        }
+        if (conv) { d.status[b] = st; d.phase[b] = PH_DONE; }
+        else d.phase[b] = PH_ACTIVE;
+      } else {
+        // ---- handleForwardPassFailure (cddp_solver_base.cpp:206-218, ipddp_solver.cpp:2037-2082)
+        d.n_fwd[b] += n_alphas;
+        double reg = reg_increase(o, d.reg[b]);
+        d.reg[b] = reg;
+        if (reg >= o.reg_max_value) {
+          int st = CDDP_HIP_STATUS_REG_LIMIT;
+          if (ipddp) {
+            const double sdu = scaled_inf_du<Model, Cons>(d, b, d.cur[b]);
+            const double base = sqrt(dmax(o.acceptable_tolerance, o.tolerance));
+            const double at = (M == 0) ? base : dmax(base, o.ipddp_barrier_tol_mult * d.mu[b]);
+            const bool acc = o.acceptable_tolerance > 0.0 && d.inf_pr[b] < at && sdu < at && (M == 0 || d.inf_comp[b] < at);
+            if (acc) st = CDDP_HIP_STATUS_ACCEPTABLE;
+          }
+          d.status[b] = st; d.phase[b] = PH_DONE;
+        } else d.phase[b] = PH_ACTIVE;
+      }
+    }
+  }
+count:
+  if (stage == 2) {
+    if (is_last_iter && d.phase[b] != PH_DONE) { d.status[b] = CDDP_HIP_STATUS_MAX_ITERATIONS; d.phase[b] = PH_DONE; }
+    if (d.phase[b] != PH_DONE) atomicAdd(d.n_active, 1);
+  }
+}
+
+// ================================================================================ K0
+// ISolverAlgorithm::initialize.  CLDDP: cost of the given (X,U) (clddp_solver.cpp:68-74).
+// IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, s/y initialisation,
+// cost, filter reset.
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_init(DevBuf d) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
+  d.cur[b] = 0;
+  double *X0 = d.X, *U0 = d.U;
+  d.iter[b] = 0; d.status[b] = CDDP_HIP_STATUS_RUNNING; d.phase[b] = PH_ACTIVE;
+  d.n_bwd[b] = 0; d.n_fwd[b] = 0; d.bwd_ok[b] = 0; d.filt_n[b] = 0;
+  if (b < d.hist_batch) d.hist_n[b] = 0;
+  d.reg[b] = o.reg_initial_value;
+  d.dV0[b] = 0.0; d.dV1[b] = 0.0; d.step_norm[b] = 0.0;
+  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
+  double x[NX];
+  ld<NX>(X0 + GI(0, NX, 0), d.Bp, x);
+  double cost = 0.0;
+  if (!ipddp) {
+    for (int t = 0; t < N; ++t) {
+      double xt[NX], u[NU];
+      ld<NX>(X0 + GI(t, NX, 0), d.Bp, xt);
+      ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
+      cost += Obj::running_cost(P, d.xref_traj, t, xt, u);
+      double z[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) z[i] = 0.0;
+      st<NU>(d.k + GI(t, NU, 0), d.Bp, z);     // initializeGains: k_u_ = 0 (BoxQP warm start)
+    }
+    double xN[NX];
+    ld<NX>(X0 + GI(N, NX, 0), d.Bp, xN);
+    cost += Obj::terminal_cost(P, xN);
+    d.cost[b] = cost; d.merit[b] = cost;
+    d.inf_pr[b] = INFINITY; d.inf_du[b] = INFINITY; d.inf_comp[b] = INFINITY;   // cddp_core.cpp:297-301
+    d.alpha_pr[b] = o.ls_initial_step_size; d.alpha_du[b] = 0.0; d.mu[b] = 0.0;
+    d.phi[b] = cost; d.theta[b] = 0.0; d.filter_theta[b] = 0.0;
+    hist_push(d, b, 0.0);
+    return;
+  }
+  const double mu = (M == 0) ? dmax(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
+  d.mu[b] = mu;
+  d.alpha_pr[b] = 1.0; d.alpha_du[b] = 1.0;
+  double *S0 = d.S, *Y0 = d.Y, *G0 = d.G, *L0 = d.Lam;
+  for (int t = 0; t < N; ++t) {
+    double u[NU], xn[NX];
+    ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
+    cost += Obj::running_cost(P, d.xref_traj, t, x, u);
+    if constexpr (M > 0) {
+      double g[MM], s[MM], y[MM];
+      Cons::template eval<NX, NU>(P, x, u, g);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {   // initializeDualSlackVariables (:2456-2468)
+        s[i] = dmax(o.ipddp_slack_var_init_scale, -g[i] + kSlackInteriorOffset);
+        y[i] = (mu * o.ipddp_dual_var_init_scale) / dmax(s[i], kEpsSlack);
+      }
+      if (o.ipddp_warmstart_repair) {   // repairWarmstartInterior (:233-262), per constraint object
+        for (int c = 0; c < Cons::NSEG; ++c) {
+          const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+          double mn = INFINITY, mny = INFINITY;
+          for (int i = 0; i < dim; ++i) { s[off + i] = dmax(s[off + i], o.ipddp_warmstart_s_min); mn = dmin(mn, s[off + i]); }
+          if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) s[off + i] *= o.ipddp_warmstart_interior_factor;
+          for (int i = 0; i < dim; ++i) { y[off + i] = dmax(y[off + i], o.ipddp_warmstart_y_min); mny = dmin(mny, y[off + i]); }
+          if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) y[off + i] *= o.ipddp_warmstart_interior_factor;
+        }
+      }
+      st<M>(G0 + GI(t, M, 0), d.Bp, g);
+      st<M>(S0 + GI(t, M, 0), d.Bp, s);
+      st<M>(Y0 + GI(t, M, 0), d.Bp, y);
+    }
+    double z[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] = 0.0;
+    st<NX>(L0 + GI(t, NX, 0), d.Bp, z);
+    Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+    st<NX>(X0 + GI(t + 1, NX, 0), d.Bp, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  }
+  {
+    double z[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] = 0.0;
+    st<NX>(L0 + GI(N, NX, 0), d.Bp, z);
+  }
+  cost += Obj::terminal_cost(P, x);
+  d.cost[b] = cost;
+  // resetFilter (ipddp_solver.cpp:2484-2519)
+  double phi = cost, theta = 0.0, ipr = 0.0, icomp = 0.0;
+  if constexpr (M > 0) { __threadfence_block(); ip_reductions<Cons>(d, b, N, S0, Y0, G0, mu, cost, o.ipddp_theta_norm_l2 != 0, phi, theta, ipr, icomp); }
+  d.merit[b] = phi; d.phi[b] = phi; d.inf_pr[b] = ipr; d.inf_comp[b] = icomp;
+  const double ft = dmax(theta, 1e-8);
+  d.filter_theta[b] = ft;
+  d.theta[b] = dmax(ft, dmax(o.ipddp_theta_0_floor, 1e-8));
+  d.inf_du[b] = 0.0;
+  hist_push(d, b, mu);
+}
+
+#undef GI
+}  // namespace cddp_dev

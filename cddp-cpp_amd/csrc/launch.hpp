@@ -1,0 +1,66 @@
+// Host-side launch table: one KernelSet per (plant, constraint layout) instantiation.
+#pragma once
+#include <vector>
+#include "kernels.hpp"
+
+namespace cddp_dev {
+
+struct KernelSet {
+  int model, nx, nu, m;
+  const char *name;
+  bool (*matches)(const ProblemDev &);
+  void (*derivs)(const DevBuf &, int force, hipStream_t);
+  void (*backward)(const DevBuf &, int solver, int force, int count_iter, hipStream_t);
+  void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, hipStream_t);
+  void (*update)(const DevBuf &, int stage, int n1, int is_last, hipStream_t);
+  void (*init)(const DevBuf &, hipStream_t);
+};
+
+template <class Model, class Cons>
+struct Launcher {
+  static bool matches(const ProblemDev &P) {
+    return P.model == Model::ID && P.nx == Model::NX && P.nu == Model::NU && Cons::matches(P);
+  }
+  static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
+  static void derivs(const DevBuf &d, int force, hipStream_t s) {
+    hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, force);
+  }
+  static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
+    if (solver == CDDP_HIP_SOLVER_CLDDP)
+      hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, force, count_iter);
+    else
+      hipLaunchKernelGGL((k_backward_ipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, force, count_iter);
+  }
+  static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, hipStream_t s) {
+    if (na <= 0) return;
+    if (solver == CDDP_HIP_SOLVER_CLDDP)
+      hipLaunchKernelGGL((k_forward_clddp<Model>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
+    else
+      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
+  }
+  static void update(const DevBuf &d, int stage, int n1, int is_last, hipStream_t s) {
+    hipLaunchKernelGGL((k_update<Model, Cons>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last);
+  }
+  static void init(const DevBuf &d, hipStream_t s) {
+    hipLaunchKernelGGL((k_init<Model, Cons>), gridB(d), dim3(64), 0, s, d);
+  }
+  static KernelSet set(const char *name) {
+    KernelSet k;
+    k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name;
+    k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
+    k.update = &update; k.init = &init;
+    return k;
+  }
+};
+
+// one registration function per instantiation translation unit
+void register_pendulum(std::vector<KernelSet> &);
+void register_cartpole(std::vector<KernelSet> &);
+void register_unicycle(std::vector<KernelSet> &);
+void register_lti(std::vector<KernelSet> &);
+void register_quadrotor(std::vector<KernelSet> &);
+void register_quad12(std::vector<KernelSet> &);
+void register_manipulator(std::vector<KernelSet> &);
+void register_manip7(std::vector<KernelSet> &);
+
+}  // namespace cddp_dev

@@ -1,0 +1,691 @@
+"""ctypes binding of the C-ABI in include/cddp_hip.h (+ the oracle's probe ABI).
+
+This module is harness plumbing for tests/ and bench.py: it builds `cddp_hip_problem`
+descriptors (the POD twin of cddp::CDDP, reference include/cddp-cpp/cddp_core/cddp_core.hpp:215-423)
+and calls the shared libraries.  It contains no solver arithmetic.
+
+Two libraries can be loaded:
+  * HipBatchSolver  -> cddp-cpp_amd/lib/libcddp_hip.so  (the product; fails loudly if missing)
+  * Oracle          -> oracle/_build/libcddp_oracle.so   (CPU restatement; tests/bench only)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+HIP_LIB_PATH = os.path.join(_HERE, "lib", "libcddp_hip.so")
+ORACLE_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle.so")
+ORACLE_FAST_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle_fast.so")
+
+MAX_MODEL_PARAMS = 24
+NAME_LEN = 48
+
+# enums (include/cddp_hip.h)
+MODEL_PENDULUM, MODEL_CARTPOLE, MODEL_UNICYCLE, MODEL_LTI = 0, 1, 2, 3
+MODEL_QUADROTOR, MODEL_MANIPULATOR, MODEL_QUADROTOR_EULER12, MODEL_MANIPULATOR7 = 4, 5, 6, 7
+EULER, HEUN, RK3, RK4 = 0, 1, 2, 3
+SOLVER_CLDDP, SOLVER_IPDDP = 0, 1
+CON_CONTROL_BOX, CON_STATE_BOX, CON_BALL, CON_LINEAR = 0, 1, 2, 3
+TERM_EQUALITY, TERM_INEQUALITY = 0, 1
+STATUS_RUNNING, STATUS_OPTIMAL, STATUS_ACCEPTABLE, STATUS_MAX_ITERATIONS, STATUS_REG_LIMIT, STATUS_MAX_CPU_TIME = range(6)
+STATUS_STRINGS = [
+    "Running", "OptimalSolutionFound", "AcceptableSolutionFound", "MaxIterationsReached",
+    "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached",
+]
+
+_dp = C.POINTER(C.c_double)
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("tolerance", C.c_double), ("acceptable_tolerance", C.c_double),
+        ("max_iterations", C.c_int32), ("use_ilqr", C.c_int32), ("enable_parallel", C.c_int32),
+        ("return_iteration_info", C.c_int32), ("warm_start", C.c_int32), ("_pad0", C.c_int32),
+        ("termination_scaling_max_factor", C.c_double),
+        ("ls_max_iterations", C.c_int32), ("_pad1", C.c_int32),
+        ("ls_initial_step_size", C.c_double), ("ls_min_step_size", C.c_double),
+        ("ls_step_reduction_factor", C.c_double),
+        ("reg_initial_value", C.c_double), ("reg_update_factor", C.c_double),
+        ("reg_max_value", C.c_double), ("reg_min_value", C.c_double),
+        ("boxqp_max_iterations", C.c_int32), ("_pad2", C.c_int32),
+        ("boxqp_min_gradient_norm", C.c_double), ("boxqp_min_relative_improvement", C.c_double),
+        ("boxqp_step_decrease_factor", C.c_double), ("boxqp_min_step_size", C.c_double),
+        ("boxqp_armijo_constant", C.c_double),
+        ("filter_merit_acceptance_threshold", C.c_double),
+        ("filter_violation_acceptance_threshold", C.c_double),
+        ("filter_max_violation_threshold", C.c_double),
+        ("filter_min_violation_for_armijo_check", C.c_double),
+        ("filter_armijo_constant", C.c_double),
+        ("ipddp_dual_var_init_scale", C.c_double), ("ipddp_slack_var_init_scale", C.c_double),
+        ("ipddp_barrier_tol_mult", C.c_double), ("ipddp_barrier_update_dual_weight", C.c_double),
+        ("ipddp_mu_kappa_epsilon", C.c_double),
+        ("ipddp_check_state_stationarity", C.c_int32), ("ipddp_theta_norm_l2", C.c_int32),
+        ("ipddp_max_filter_size", C.c_int32), ("ipddp_warmstart_repair", C.c_int32),
+        ("ipddp_theta_0_floor", C.c_double), ("ipddp_warmstart_s_min", C.c_double),
+        ("ipddp_warmstart_y_min", C.c_double), ("ipddp_warmstart_interior_factor", C.c_double),
+        ("ipddp_jacobian_regularization_value", C.c_double),
+        ("ipddp_jacobian_regularization_exponent", C.c_double),
+        ("barrier_mu_initial", C.c_double), ("barrier_mu_min_value", C.c_double),
+        ("barrier_mu_update_factor", C.c_double), ("barrier_mu_update_power", C.c_double),
+        ("barrier_min_fraction_to_boundary", C.c_double),
+        ("barrier_strategy", C.c_int32), ("_pad3", C.c_int32),
+    ]
+
+
+def default_options():
+    """Reference defaults: include/cddp-cpp/cddp_core/options.hpp:41-251, boxqp.hpp:30-41."""
+    o = Options()
+    o.tolerance = 1e-5; o.acceptable_tolerance = 1e-6; o.max_iterations = 1; o.use_ilqr = 1
+    o.enable_parallel = 0; o.return_iteration_info = 0; o.warm_start = 0
+    o.termination_scaling_max_factor = 100.0
+    o.ls_max_iterations = 11; o.ls_initial_step_size = 1.0; o.ls_min_step_size = 1e-8
+    o.ls_step_reduction_factor = 0.5
+    o.reg_initial_value = 1e-6; o.reg_update_factor = 10.0; o.reg_max_value = 1e7; o.reg_min_value = 1e-10
+    o.boxqp_max_iterations = 100; o.boxqp_min_gradient_norm = 1e-8
+    o.boxqp_min_relative_improvement = 1e-8; o.boxqp_step_decrease_factor = 0.6
+    o.boxqp_min_step_size = 1e-22; o.boxqp_armijo_constant = 0.1
+    o.filter_merit_acceptance_threshold = 1e-6; o.filter_violation_acceptance_threshold = 1e-6
+    o.filter_max_violation_threshold = 1e4; o.filter_min_violation_for_armijo_check = 1e-7
+    o.filter_armijo_constant = 1e-4
+    o.ipddp_dual_var_init_scale = 0.1; o.ipddp_slack_var_init_scale = 1e-2
+    o.ipddp_barrier_tol_mult = 0.1; o.ipddp_barrier_update_dual_weight = 0.01
+    o.ipddp_mu_kappa_epsilon = 10.0; o.ipddp_check_state_stationarity = 0; o.ipddp_theta_norm_l2 = 0
+    o.ipddp_max_filter_size = 5; o.ipddp_warmstart_repair = 0; o.ipddp_theta_0_floor = 1.0
+    o.ipddp_warmstart_s_min = 1e-4; o.ipddp_warmstart_y_min = 1e-4
+    o.ipddp_warmstart_interior_factor = 1.1
+    o.ipddp_jacobian_regularization_value = 1e-8; o.ipddp_jacobian_regularization_exponent = 0.25
+    o.barrier_mu_initial = 1.0; o.barrier_mu_min_value = 1e-10; o.barrier_mu_update_factor = 0.5
+    o.barrier_mu_update_power = 1.2; o.barrier_min_fraction_to_boundary = 0.99; o.barrier_strategy = 0
+    return o
+
+
+class Constraint(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * NAME_LEN), ("kind", C.c_int32), ("dim", C.c_int32),
+        ("lower", _dp), ("upper", _dp), ("center", _dp), ("A", _dp), ("b", _dp),
+        ("radius", C.c_double), ("scale", C.c_double),
+    ]
+
+
+class TerminalConstraint(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * NAME_LEN), ("kind", C.c_int32), ("dim", C.c_int32),
+        ("target", _dp), ("A", _dp), ("b", _dp),
+    ]
+
+
+class ProblemStruct(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("solver", C.c_int32), ("model", C.c_int32), ("integrator", C.c_int32),
+        ("nx", C.c_int32), ("nu", C.c_int32), ("horizon", C.c_int32), ("_pad0", C.c_int32),
+        ("dt", C.c_double), ("model_params", C.c_double * MAX_MODEL_PARAMS),
+        ("lti_A", _dp), ("lti_B", _dp),
+        ("Q", _dp), ("R", _dp), ("Qf", _dp), ("x_ref", _dp), ("x_ref_traj", _dp),
+        ("n_constraints", C.c_int32), ("n_terminal", C.c_int32),
+        ("constraints", C.POINTER(Constraint)), ("terminal", C.POINTER(TerminalConstraint)),
+        ("options", Options),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("final_objective", C.c_double), ("merit_function", C.c_double),
+        ("inf_pr", C.c_double), ("inf_du", C.c_double), ("inf_comp", C.c_double),
+        ("barrier_mu", C.c_double), ("regularization", C.c_double),
+        ("alpha_pr", C.c_double), ("alpha_du", C.c_double), ("step_norm", C.c_double),
+        ("iterations", C.c_int32), ("status", C.c_int32), ("n_backward", C.c_int32), ("n_forward", C.c_int32),
+    ]
+
+
+RESULT_DTYPE = np.dtype([
+    ("final_objective", "f8"), ("merit_function", "f8"), ("inf_pr", "f8"), ("inf_du", "f8"),
+    ("inf_comp", "f8"), ("barrier_mu", "f8"), ("regularization", "f8"), ("alpha_pr", "f8"),
+    ("alpha_du", "f8"), ("step_norm", "f8"), ("iterations", "i4"), ("status", "i4"),
+    ("n_backward", "i4"), ("n_forward", "i4"),
+])
+TRIAL_DTYPE = np.dtype([
+    ("alpha", "f8"), ("alpha_pr", "f8"), ("alpha_du", "f8"), ("cost", "f8"), ("merit_function", "f8"),
+    ("theta", "f8"), ("inf_pr", "f8"), ("inf_comp", "f8"), ("success", "i4"), ("_pad", "i4"),
+])
+GATHER_DTYPE = np.dtype([("final_objective", "f8"), ("iterations", "i4"), ("status", "i4")])
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("solve_ms", C.c_double), ("backward_ms", C.c_double), ("forward_ms", C.c_double),
+        ("update_ms", C.c_double), ("sweeps", C.c_int64), ("rollouts", C.c_int64),
+        ("rollouts_launched", C.c_int64), ("traj_iterations", C.c_int64),
+        ("outer_iterations", C.c_int32), ("n_converged", C.c_int32), ("kernel_launches", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+def _arr(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Problem:
+    """Python-side owner of a cddp_hip_problem descriptor (keeps the numpy buffers alive)."""
+
+    def __init__(self, solver, model, integrator, nx, nu, horizon, dt, Q, R, Qf, x_ref,
+                 model_params=(), lti_A=None, lti_B=None, x_ref_traj=None, options=None):
+        self.keep = []
+        self.c = ProblemStruct()
+        self.c.abi_version = 1
+        self.c.solver = solver; self.c.model = model; self.c.integrator = integrator
+        self.c.nx = nx; self.c.nu = nu; self.c.horizon = horizon; self.c.dt = dt
+        for i, v in enumerate(model_params):
+            self.c.model_params[i] = float(v)
+        self.Q = _arr(Q).reshape(nx, nx); self.R = _arr(R).reshape(nu, nu); self.Qf = _arr(Qf).reshape(nx, nx)
+        self.x_ref = _arr(x_ref).reshape(nx)
+        self.c.Q = _ptr(self.Q); self.c.R = _ptr(self.R); self.c.Qf = _ptr(self.Qf); self.c.x_ref = _ptr(self.x_ref)
+        if lti_A is not None:
+            self.lti_A = _arr(lti_A).reshape(nx, nx); self.lti_B = _arr(lti_B).reshape(nx, nu)
+            self.c.lti_A = _ptr(self.lti_A); self.c.lti_B = _ptr(self.lti_B)
+        if x_ref_traj is not None:
+            self.x_ref_traj = _arr(x_ref_traj).reshape(horizon + 1, nx)
+            self.c.x_ref_traj = _ptr(self.x_ref_traj)
+        self.c.options = options if options is not None else default_options()
+        self._cons = []
+        self._terms = []
+        self.nx, self.nu, self.N, self.dt = nx, nu, horizon, dt
+
+    @property
+    def options(self):
+        return self.c.options
+
+    def _rebuild(self):
+        if self._cons:
+            arr = (Constraint * len(self._cons))(*self._cons)
+            self._cons_arr = arr
+            self.c.constraints = C.cast(arr, C.POINTER(Constraint)); self.c.n_constraints = len(self._cons)
+        else:
+            self.c.n_constraints = 0
+        if self._terms:
+            arr = (TerminalConstraint * len(self._terms))(*self._terms)
+            self._terms_arr = arr
+            self.c.terminal = C.cast(arr, C.POINTER(TerminalConstraint)); self.c.n_terminal = len(self._terms)
+        else:
+            self.c.n_terminal = 0
+
+    def add_control_box(self, name, lower, upper, scale=1.0):
+        lo, up = _arr(lower), _arr(upper); self.keep += [lo, up]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_CONTROL_BOX; c.dim = lo.size
+        c.lower = _ptr(lo); c.upper = _ptr(up); c.scale = scale
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_state_box(self, name, lower, upper, scale=1.0):
+        lo, up = _arr(lower), _arr(upper); self.keep += [lo, up]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_STATE_BOX; c.dim = lo.size
+        c.lower = _ptr(lo); c.upper = _ptr(up); c.scale = scale
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_ball(self, name, radius, center, scale=1.0):
+        ce = _arr(center); self.keep += [ce]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_BALL; c.dim = ce.size
+        c.center = _ptr(ce); c.radius = radius; c.scale = scale
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_linear(self, name, A, b):
+        A_, b_ = _arr(A), _arr(b); self.keep += [A_, b_]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_LINEAR; c.dim = b_.size
+        c.A = _ptr(A_); c.b = _ptr(b_); c.scale = 1.0
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_terminal_equality(self, name, target):
+        t_ = _arr(target); self.keep += [t_]
+        c = TerminalConstraint(); c.name = name.encode(); c.kind = TERM_EQUALITY; c.dim = t_.size; c.target = _ptr(t_)
+        self._terms.append(c); self._rebuild(); return self
+
+    def add_terminal_inequality(self, name, A, b):
+        A_, b_ = _arr(A), _arr(b); self.keep += [A_, b_]
+        c = TerminalConstraint(); c.name = name.encode(); c.kind = TERM_INEQUALITY; c.dim = b_.size
+        c.A = _ptr(A_); c.b = _ptr(b_)
+        self._terms.append(c); self._rebuild(); return self
+
+    def dual_dim(self):
+        m = 0
+        for c in self._cons:
+            m += {CON_CONTROL_BOX: 2 * c.dim, CON_STATE_BOX: 2 * c.dim, CON_BALL: 1, CON_LINEAR: c.dim}[c.kind]
+        return m
+
+
+# ----------------------------------------------------------------------------------------------
+# Problem builders for the BASELINE configs; constants from the
+# reference examples (examples/cddp_pendulum.cpp:24-65, cddp_cartpole.cpp:24-66,
+# cddp_unicycle.cpp / python_portfolio_lib.py:374-446, cddp_quadrotor_point.cpp:22-96,
+# cddp_manipulator.cpp:22-68).
+# ----------------------------------------------------------------------------------------------
+def pendulum_problem(solver=SOLVER_IPDDP, constrained=True, horizon=100):
+    o = default_options(); o.max_iterations = 30; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-5
+    o.reg_initial_value = 1e-6
+    dt = 0.02
+    p = Problem(solver, MODEL_PENDULUM, EULER, 2, 1, horizon, dt, np.zeros((2, 2)), 0.1 * np.eye(1),
+                100.0 * np.eye(2), [0.0, 0.0], model_params=[0.5, 1.0, 0.01, 9.81], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", [-20.0], [20.0])
+    p.x0 = np.array([np.pi, 0.0])
+    return p
+
+
+def cartpole_problem(solver=SOLVER_IPDDP, constrained=True, horizon=100):
+    o = default_options(); o.max_iterations = 80; o.tolerance = 1e-6; o.acceptable_tolerance = 1e-5
+    o.reg_initial_value = 1e-5
+    dt = 0.05
+    p = Problem(solver, MODEL_CARTPOLE, RK4, 4, 1, horizon, dt, np.zeros((4, 4)), 0.1 * np.eye(1),
+                100.0 * np.eye(4), [0.0, np.pi, 0.0, 0.0], model_params=[1.0, 0.2, 0.5, 9.81, 0.0], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", [-5.0], [5.0])
+    p.x0 = np.zeros(4)
+    return p
+
+
+def unicycle_problem(solver=SOLVER_IPDDP, horizon=200, obstacle=True):
+    o = default_options(); o.max_iterations = 100; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-6
+    dt = 0.03
+    p = Problem(solver, MODEL_UNICYCLE, EULER, 3, 2, horizon, dt, np.zeros((3, 3)), 0.05 * np.eye(2),
+                np.diag([100.0, 100.0, 50.0]), [2.0, 2.0, np.pi / 2], options=o)
+    p.add_control_box("control_limits", [-1.1, -np.pi], [1.1, np.pi])
+    if obstacle:
+        p.add_ball("obstacle", 0.4, [1.0, 1.0])
+    p.x0 = np.array([0.0, 0.0, np.pi / 4])
+    p.U0_const = np.array([0.5, 0.1])
+    return p
+
+
+def scalar_integrator_problem(horizon=8, path_constraint=False, terminal_inequality=False,
+                              terminal_equality=False, options=None, solver=SOLVER_IPDDP):
+    """LTI A=B=1 problems of tests/cddp_core/test_ipddp_solver.cpp:137-242, 1147-1637."""
+    o = options if options is not None else default_options()
+    p = Problem(solver, MODEL_LTI, EULER, 1, 1, horizon, 1.0, np.zeros((1, 1)), 1e-2 * np.eye(1),
+                100.0 * np.eye(1), [1.0], lti_A=np.eye(1), lti_B=np.eye(1), options=o)
+    if path_constraint:
+        p.add_control_box("ControlConstraint", [-0.5], [0.5])
+    if terminal_inequality:
+        p.add_terminal_inequality("TerminalUpperBound", np.eye(1), np.zeros(1))
+    if terminal_equality:
+        p.add_terminal_equality("TerminalEquality", [0.0])
+    p.x0 = np.zeros(1)
+    return p
+
+
+def quadrotor_problem(solver=SOLVER_IPDDP, horizon=120, constrained=True):
+    o = default_options(); o.max_iterations = 120; o.ls_max_iterations = 15; o.reg_initial_value = 1e-4
+    dt = 0.02
+    Q = np.zeros((13, 13)); Q[4, 4] = Q[5, 5] = Q[6, 6] = 0.1
+    R = 0.1 * np.eye(4)
+    Qf = np.zeros((13, 13))
+    for i in range(3): Qf[i, i] = 500.0
+    for i in range(3, 7): Qf[i, i] = 1.0
+    for i in range(7, 10): Qf[i, i] = 10.0
+    goal = np.zeros(13); goal[0] = 3.0; goal[2] = 2.0; goal[3] = 1.0
+    p = Problem(solver, MODEL_QUADROTOR, RK4, 13, 4, horizon, dt, Q, R, Qf, goal,
+                model_params=[1.0, 0.2, 0.01, 0.01, 0.02, 9.81], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", np.zeros(4), 5.0 * np.ones(4))
+    x0 = np.zeros(13); x0[3] = 1.0
+    p.x0 = x0
+    p.U0_const = (1.0 * 9.81 / 4.0) * np.ones(4)
+    return p
+
+
+def quadrotor12_problem(solver=SOLVER_IPDDP, horizon=400, constrained=True):
+    """SYNTHETIC throughput shape of BASELINE config 4 (nx=12, nu=4, N=400)."""
+    o = default_options(); o.max_iterations = 120; o.ls_max_iterations = 15; o.reg_initial_value = 1e-4
+    dt = 0.02
+    Q = np.zeros((12, 12)); Q[6, 6] = Q[7, 7] = Q[8, 8] = 0.1
+    R = 0.1 * np.eye(4)
+    Qf = np.diag([500.0] * 3 + [10.0] * 3 + [1.0] * 3 + [0.0] * 3)
+    goal = np.zeros(12); goal[0] = 3.0; goal[2] = 2.0
+    p = Problem(solver, MODEL_QUADROTOR_EULER12, RK4, 12, 4, horizon, dt, Q, R, Qf, goal,
+                model_params=[1.0, 0.2, 0.01, 0.01, 0.02, 9.81], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", np.zeros(4), 5.0 * np.ones(4))
+    p.x0 = np.zeros(12)
+    p.U0_const = (1.0 * 9.81 / 4.0) * np.ones(4)
+    return p
+
+
+def manipulator_problem(solver=SOLVER_IPDDP, horizon=160, terminal_equality=False, constrained=True):
+    """examples/cddp_manipulator.cpp:22-68 (3-DOF, rk4, FD Jacobians; X0 = linear interpolation)."""
+    o = default_options(); o.max_iterations = 80; o.ls_max_iterations = 20
+    dt = 0.01
+    goal = np.array([np.pi, -np.pi / 6, -np.pi / 3, 0.0, 0.0, 0.0])
+    Q = np.diag([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]); R = 0.1 * np.eye(3); Qf = 100.0 * Q
+    p = Problem(solver, MODEL_MANIPULATOR, RK4, 6, 3, horizon, dt, Q, R, Qf, goal, options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", -50.0 * np.ones(3), 50.0 * np.ones(3))
+    if terminal_equality:
+        p.add_terminal_equality("TerminalEquality", goal)
+    p.x0 = np.array([0.0, -np.pi / 2, np.pi, 0.0, 0.0, 0.0])
+    al = np.linspace(0.0, 1.0, horizon + 1)[:, None]
+    p.X0_single = (1.0 - al) * p.x0[None, :] + al * goal[None, :]
+    return p
+
+
+def manipulator7_problem(solver=SOLVER_IPDDP, horizon=150, terminal_equality=True, n_alphas=16):
+    """SYNTHETIC throughput shape of BASELINE config 5 (nx=14, nu=7, N=150)."""
+    o = default_options(); o.max_iterations = 80; o.tolerance = 1e-5; o.acceptable_tolerance = 1e-5
+    o.ls_max_iterations = n_alphas; o.enable_parallel = 1
+    dt = 0.01
+    goal = np.concatenate([np.array([0.6, -0.4, 0.5, -0.3, 0.4, -0.2, 0.3]), np.zeros(7)])
+    Q = np.zeros((14, 14)); R = 0.01 * np.eye(7); Qf = 100.0 * np.eye(14)
+    p = Problem(solver, MODEL_MANIPULATOR7, RK4, 14, 7, horizon, dt, Q, R, Qf, goal, options=o)
+    p.add_control_box("ControlConstraint", -50.0 * np.ones(7), 50.0 * np.ones(7))
+    if terminal_equality:
+        p.add_terminal_equality("TerminalEquality", goal)
+    p.x0 = np.zeros(14)
+    return p
+
+
+def batch_x0(problem, batch, seed, spread=None):
+    """Seeded per-trajectory x0 perturbations; trajectory 0 is the example."""
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(problem.x0, (batch, 1)).astype(np.float64)
+    if spread is None:
+        spread = 0.1 * np.ones(problem.nx)
+    pert = rng.uniform(-1.0, 1.0, size=(batch, problem.nx)) * np.asarray(spread)[None, :]
+    pert[0] = 0.0
+    return np.ascontiguousarray(x0 + pert)
+
+
+def batch_U0(problem, batch):
+    if hasattr(problem, "U0_const"):
+        return np.ascontiguousarray(np.tile(problem.U0_const, (batch, problem.N, 1)).astype(np.float64))
+    return None
+
+
+# ----------------------------------------------------------------------------------------------
+# Oracle binding (tests / bench cpu_baseline only)
+# ----------------------------------------------------------------------------------------------
+_oracle_libs = {}
+
+
+def load_oracle(fast=False):
+    path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
+    if path in _oracle_libs:
+        return _oracle_libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError("oracle library missing: %s (run __graft_entry__.build() or make -C oracle)" % path)
+    lib = C.CDLL(path)
+    lib.cddp_oracle_create.restype = C.c_void_p
+    lib.cddp_oracle_create.argtypes = [C.POINTER(ProblemStruct)]
+    lib.cddp_oracle_destroy.argtypes = [C.c_void_p]
+    for name in ["cddp_oracle_filter_theta", "cddp_oracle_filter_back_violation", "cddp_oracle_scaled_inf_du",
+                 "cddp_oracle_get_mu", "cddp_oracle_cost"]:
+        getattr(lib, name).restype = C.c_double
+    _oracle_libs[path] = lib
+    return lib
+
+
+class Oracle:
+    def __init__(self, problem, fast=False):
+        self.lib = load_oracle(fast)
+        self.p = problem
+        self.h = C.c_void_p(self.lib.cddp_oracle_create(C.byref(problem.c)))
+        self.m = self.lib.cddp_oracle_dual_dim(self.h)
+
+    def __del__(self):
+        try:
+            self.lib.cddp_oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_initial(self, x0, U0=None, X0=None):
+        x0 = _arr(x0); U0 = _arr(U0) if U0 is not None else None; X0 = _arr(X0) if X0 is not None else None
+        self.lib.cddp_oracle_set_initial(self.h, _ptr(x0), _ptr(U0), _ptr(X0))
+
+    def initialize(self):
+        self.lib.cddp_oracle_initialize(self.h)
+
+    def backward(self, retry=True):
+        return self.lib.cddp_oracle_backward(self.h, 1 if retry else 0)
+
+    def forward(self, alpha):
+        t = np.zeros(1, dtype=TRIAL_DTYPE)
+        self.lib.cddp_oracle_forward(self.h, C.c_double(alpha), t.ctypes.data_as(C.c_void_p))
+        return t[0]
+
+    def solve(self):
+        r = np.zeros(1, dtype=RESULT_DTYPE)
+        self.lib.cddp_oracle_solve(self.h, r.ctypes.data_as(C.c_void_p))
+        return r[0]
+
+    def result(self):
+        r = np.zeros(1, dtype=RESULT_DTYPE)
+        self.lib.cddp_oracle_get_result(self.h, r.ctypes.data_as(C.c_void_p))
+        return r[0]
+
+    def alphas(self):
+        a = np.zeros(64)
+        n = self.lib.cddp_oracle_num_alphas(self.h, _ptr(a), 64)
+        return a[:n].copy()
+
+    def trajectory(self):
+        X = np.zeros((self.p.N + 1, self.p.nx)); U = np.zeros((self.p.N, self.p.nu))
+        self.lib.cddp_oracle_get_trajectory(self.h, _ptr(X), _ptr(U))
+        return X, U
+
+    def gains(self):
+        K = np.zeros((self.p.N, self.p.nu, self.p.nx)); k = np.zeros((self.p.N, self.p.nu))
+        self.lib.cddp_oracle_get_gains(self.h, _ptr(K), _ptr(k))
+        return K, k
+
+    def value(self):
+        Vx = np.zeros((self.p.N + 1, self.p.nx)); Vxx = np.zeros((self.p.N + 1, self.p.nx, self.p.nx))
+        self.lib.cddp_oracle_get_value(self.h, _ptr(Vx), _ptr(Vxx))
+        return Vx, Vxx
+
+    def duals(self):
+        S = np.zeros((self.p.N, self.m)); Y = np.zeros((self.p.N, self.m)); G = np.zeros((self.p.N, self.m))
+        if self.m:
+            self.lib.cddp_oracle_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G))
+        return S, Y, G
+
+    def backward_scalars(self):
+        dV = np.zeros(2); reg = np.zeros(1)
+        self.lib.cddp_oracle_get_backward_scalars(self.h, _ptr(dV), _ptr(reg))
+        return dV, reg[0]
+
+    def history(self):
+        cap = self.p.options.max_iterations + 2
+        h = np.zeros((cap, 9))
+        n = self.lib.cddp_oracle_get_history(self.h, _ptr(h), cap)
+        return h[:n].copy()
+
+    def dynamics(self, x, u, time=0.0):
+        x = _arr(x); u = _arr(u)
+        xd = np.zeros(self.p.nx); xn = np.zeros(self.p.nx)
+        Fx = np.zeros((self.p.nx, self.p.nx)); Fu = np.zeros((self.p.nx, self.p.nu))
+        self.lib.cddp_oracle_dynamics(self.h, _ptr(x), _ptr(u), C.c_double(time), _ptr(xd), _ptr(xn), _ptr(Fx), _ptr(Fu))
+        return xd, xn, Fx, Fu
+
+    def constraint_eval(self, x, u):
+        x = _arr(x); u = _arr(u)
+        g = np.zeros(self.m); gx = np.zeros((self.m, self.p.nx)); gu = np.zeros((self.m, self.p.nu))
+        self.lib.cddp_oracle_constraint_eval(self.h, _ptr(x), _ptr(u), _ptr(g), _ptr(gx), _ptr(gu))
+        return g, gx, gu
+
+    def cost(self, X, U):
+        X = _arr(X); U = _arr(U)
+        return self.lib.cddp_oracle_cost(self.h, _ptr(X), _ptr(U))
+
+
+def oracle_solve_batch(problem, x0, U0=None, X0=None, n_threads=1, fast=False, want_traj=True):
+    lib = load_oracle(fast)
+    x0 = _arr(x0); B = x0.shape[0]
+    U0 = _arr(U0) if U0 is not None else None; X0 = _arr(X0) if X0 is not None else None
+    res = np.zeros(B, dtype=RESULT_DTYPE)
+    X = np.zeros((B, problem.N + 1, problem.nx)) if want_traj else None
+    U = np.zeros((B, problem.N, problem.nu)) if want_traj else None
+    K = np.zeros((B, problem.N, problem.nu, problem.nx)) if want_traj else None
+    ms = C.c_double(0.0)
+    lib.cddp_oracle_solve_batch(C.byref(problem.c), B, _ptr(x0), _ptr(U0), _ptr(X0), n_threads,
+                                res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K), C.byref(ms))
+    return res, X, U, K, ms.value
+
+
+def oracle_boxqp(H, g, lower, upper, x0=None, options=None):
+    lib = load_oracle()
+    o = options if options is not None else default_options()
+    H = _arr(H); g = _arr(g); lo = _arr(lower); up = _arr(upper); n = g.size
+    x0a = _arr(x0) if x0 is not None else None
+    x = np.zeros(n); free = np.zeros(n, dtype=np.int32); it = C.c_int(0); fc = C.c_int(0)
+    st = lib.cddp_oracle_boxqp(C.byref(o), n, _ptr(H), _ptr(g), _ptr(lo), _ptr(up), _ptr(x0a), _ptr(x),
+                               free.ctypes.data_as(C.POINTER(C.c_int)), C.byref(it), C.byref(fc))
+    return x, st, free, it.value, fc.value
+
+
+def oracle_ldlt_solve(A, B):
+    lib = load_oracle()
+    A = _arr(A); B = _arr(B); n = A.shape[0]; B2 = B.reshape(n, -1); X = np.zeros_like(B2)
+    ok = lib.cddp_oracle_ldlt_solve(n, B2.shape[1], _ptr(A), _ptr(B2), _ptr(X))
+    return X.reshape(B.shape), bool(ok)
+
+
+# ----------------------------------------------------------------------------------------------
+# Product binding
+# ----------------------------------------------------------------------------------------------
+_hip_lib = None
+
+
+def load_hip():
+    """Load the HIP C-ABI library.  Raises if it is missing: there is no fallback path."""
+    global _hip_lib
+    if _hip_lib is not None:
+        return _hip_lib
+    if not os.path.exists(HIP_LIB_PATH):
+        raise RuntimeError("HIP library missing: %s -- run __graft_entry__.build(); "
+                           "the product has no CPU fallback" % HIP_LIB_PATH)
+    lib = C.CDLL(HIP_LIB_PATH)
+    lib.cddp_hip_last_error.restype = C.c_char_p
+    lib.cddp_hip_status_string.restype = C.c_char_p
+    lib.cddp_hip_create.argtypes = [C.POINTER(ProblemStruct), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    _hip_lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "cddp_hip_default_options", "cddp_hip_abi_version", "cddp_hip_last_error", "cddp_hip_device_count",
+    "cddp_hip_status_string", "cddp_hip_build_alphas", "cddp_hip_create", "cddp_hip_destroy",
+    "cddp_hip_set_stream", "cddp_hip_set_initial", "cddp_hip_initialize", "cddp_hip_backward",
+    "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
+    "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
+    "cddp_hip_get_history", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
+    "cddp_hip_backward_stacks",
+]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class HipBatchSolver:
+    """Batch of independent trajectories of one problem on one GPU (C-ABI handle)."""
+
+    def __init__(self, problem, batch, device=0):
+        self.lib = load_hip()
+        self.p = problem; self.B = batch
+        self.h = C.c_void_p()
+        rc = self.lib.cddp_hip_create(C.byref(problem.c), batch, device, C.byref(self.h))
+        self._check(rc)
+        self.m = self.lib.cddp_hip_dual_dim(self.h)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipError("cddp_hip error %d: %s" % (rc, self.lib.cddp_hip_last_error().decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.cddp_hip_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.cddp_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_initial(self, x0, U0=None, X0=None):
+        x0 = _arr(x0); assert x0.shape == (self.B, self.p.nx)
+        U0 = _arr(U0) if U0 is not None else None; X0 = _arr(X0) if X0 is not None else None
+        self._check(self.lib.cddp_hip_set_initial(self.h, _ptr(x0), _ptr(U0), _ptr(X0)))
+
+    def initialize(self):
+        self._check(self.lib.cddp_hip_initialize(self.h))
+
+    def backward(self):
+        ok = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.cddp_hip_backward(self.h, ok.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ok
+
+    def forward(self, alphas):
+        a = _arr(alphas); t = np.zeros((self.B, a.size), dtype=TRIAL_DTYPE)
+        self._check(self.lib.cddp_hip_forward(self.h, _ptr(a), a.size, t.ctypes.data_as(C.c_void_p)))
+        return t
+
+    def solve(self):
+        st = Stats()
+        self._check(self.lib.cddp_hip_solve(self.h, C.byref(st)))
+        return st
+
+    def results(self):
+        r = np.zeros(self.B, dtype=RESULT_DTYPE)
+        self._check(self.lib.cddp_hip_get_results(self.h, r.ctypes.data_as(C.c_void_p)))
+        return r
+
+    def trajectory(self):
+        X = np.zeros((self.B, self.p.N + 1, self.p.nx)); U = np.zeros((self.B, self.p.N, self.p.nu))
+        self._check(self.lib.cddp_hip_get_trajectory(self.h, _ptr(X), _ptr(U)))
+        return X, U
+
+    def gains(self):
+        K = np.zeros((self.B, self.p.N, self.p.nu, self.p.nx)); k = np.zeros((self.B, self.p.N, self.p.nu))
+        self._check(self.lib.cddp_hip_get_gains(self.h, _ptr(K), _ptr(k)))
+        return K, k
+
+    def value(self):
+        Vx = np.zeros((self.B, self.p.N + 1, self.p.nx)); Vxx = np.zeros((self.B, self.p.N + 1, self.p.nx, self.p.nx))
+        self._check(self.lib.cddp_hip_get_value(self.h, _ptr(Vx), _ptr(Vxx)))
+        return Vx, Vxx
+
+    def duals(self):
+        S = np.zeros((self.B, self.p.N, self.m)); Y = np.zeros_like(S); G = np.zeros_like(S)
+        if self.m:
+            self._check(self.lib.cddp_hip_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G)))
+        return S, Y, G
+
+    def backward_scalars(self):
+        dV = np.zeros((self.B, 2)); reg = np.zeros(self.B)
+        self._check(self.lib.cddp_hip_get_backward_scalars(self.h, _ptr(dV), _ptr(reg)))
+        return dV, reg
+
+    def history(self, hist_batch=1):
+        cap = self.p.options.max_iterations + 1
+        h = np.zeros((hist_batch, cap, 9)); cnt = np.zeros(hist_batch, dtype=np.int32)
+        self._check(self.lib.cddp_hip_get_history(self.h, hist_batch, _ptr(h), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return [h[b, :cnt[b]].copy() for b in range(hist_batch)]
+
+    def write_gather_records_device(self, device_ptr):
+        self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
+
+
+def hip_backward_stacks(fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN, reg, reg_in_value, device=0):
+    lib = load_hip()
+    fx = _arr(fx); B, N, nx, _ = fx.shape; nu = _arr(fu).shape[3]
+    args = [_arr(a) for a in (fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN)]
+    K = np.zeros((B, N, nu, nx)); k = np.zeros((B, N, nu)); Vx = np.zeros((B, N + 1, nx)); Vxx = np.zeros((B, N + 1, nx, nx))
+    dV = np.zeros((B, 2)); ok = np.zeros(B, dtype=np.int32); ms = C.c_double(0.0)
+    rc = lib.cddp_hip_backward_stacks(device, B, nx, nu, N, *[_ptr(a) for a in args], C.c_double(reg), int(reg_in_value),
+                                      _ptr(K), _ptr(k), _ptr(Vx), _ptr(Vxx), _ptr(dV),
+                                      ok.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms))
+    if rc != 0:
+        raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    return K, k, Vx, Vxx, dV, ok, ms.value

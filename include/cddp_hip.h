@@ -1,0 +1,362 @@
+/*
+ * cddp_hip.h -- C-ABI of the MI355X-native batched CLDDP / IPDDP solver core.
+ *
+ * This is the drop-in boundary for the hot path of astomodynamics/cddp-cpp:
+ * everything cddp::ISolverAlgorithm::{initialize,solve} does for the "CLDDP"
+ * and "IPDDP" solvers (reference include/cddp-cpp/cddp_core/cddp_core.hpp:186-210,
+ * src/cddp_core/cddp_solver_base.cpp:29-186, clddp_solver.cpp, ipddp_solver.cpp,
+ * boxqp.cpp), executed for a whole BATCH of independent trajectories on one GPU.
+ *
+ * Conventions (nothing like this exists in the reference):
+ *   - extern "C", plain pointers and sizes, no exceptions / STL / Eigen / torch.
+ *   - every entry point returns 0 on success, <0 on error;
+ *     cddp_hip_last_error() returns a thread-local message.
+ *   - all matrices are ROW-MAJOR doubles; trajectories handed over the boundary
+ *     are batch-major: X[b][t][i], U[b][t][j], K[b][t][j][i].
+ *   - host buffers are caller-owned, device buffers are library-owned (unless a
+ *     *_device entry point says the pointer is a device pointer).
+ *   - a handle is bound to (device, stream) and is NOT thread-safe; distinct
+ *     handles are independent.
+ *
+ * The reference-side binding a maintainer adds is shown in INTEGRATION.md.
+ */
+#ifndef CDDP_HIP_H
+#define CDDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDDP_HIP_ABI_VERSION 1
+#define CDDP_HIP_MAX_MODEL_PARAMS 24
+#define CDDP_HIP_NAME_LEN 48
+#define CDDP_HIP_MAX_ALPHAS 32
+
+/* ---- enumerations -------------------------------------------------------- */
+
+/* Built-in plants with device-side dynamics + derivatives
+ * (reference src/dynamics_model/{pendulum,cartpole,unicycle,lti_system,quadrotor,
+ *  manipulator}.cpp).  model_params layout is documented per entry. */
+enum cddp_hip_model {
+  CDDP_HIP_MODEL_PENDULUM = 0,   /* params: length, mass, damping, gravity                     */
+  CDDP_HIP_MODEL_CARTPOLE = 1,   /* params: cart_mass, pole_mass, pole_length, gravity, damping */
+  CDDP_HIP_MODEL_UNICYCLE = 2,   /* params: (none)                                              */
+  CDDP_HIP_MODEL_LTI = 3,        /* discrete x+ = A x + B u; A,B via lti_A / lti_B              */
+  CDDP_HIP_MODEL_QUADROTOR = 4,  /* nx=13 quaternion; params: mass, arm, Ixx,Iyy,Izz, gravity   */
+  CDDP_HIP_MODEL_MANIPULATOR = 5,/* 3-DOF, central-FD Jacobians h=2e-5; params: (none)          */
+  CDDP_HIP_MODEL_QUADROTOR_EULER12 = 6, /* SYNTHETIC nx=12 (BASELINE config 4 shape)            */
+  CDDP_HIP_MODEL_MANIPULATOR7 = 7       /* SYNTHETIC nx=14/nu=7 (BASELINE config 5 shape)       */
+};
+
+/* reference src/cddp_core/dynamical_system.cpp:28-83 */
+enum cddp_hip_integrator {
+  CDDP_HIP_EULER = 0, CDDP_HIP_HEUN = 1, CDDP_HIP_RK3 = 2, CDDP_HIP_RK4 = 3
+};
+
+/* Which reference solver core is replaced (cddp_core.cpp:213-233). */
+enum cddp_hip_solver { CDDP_HIP_SOLVER_CLDDP = 0, CDDP_HIP_SOLVER_IPDDP = 1 };
+
+/* Path-constraint kinds (reference include/cddp-cpp/cddp_core/constraint.hpp:144-404). */
+enum cddp_hip_constraint_kind {
+  CDDP_HIP_CON_CONTROL_BOX = 0, /* BoxConstraint<Control>: g=[-u;u]*s, upper=[-lb;ub]*s  */
+  CDDP_HIP_CON_STATE_BOX = 1,   /* BoxConstraint<State>                                   */
+  CDDP_HIP_CON_BALL = 2,        /* BallConstraint: g=-s*|x[:d]-c|^2, upper=-s*r^2         */
+  CDDP_HIP_CON_LINEAR = 3       /* LinearConstraint: g=A x, upper=b                       */
+};
+
+/* reference include/cddp-cpp/cddp_core/terminal_constraint.hpp:62-263 */
+enum cddp_hip_terminal_kind { CDDP_HIP_TERM_EQUALITY = 0, CDDP_HIP_TERM_INEQUALITY = 1 };
+
+/* status_message strings of the reference (cddp_solver_base.cpp:69,82,202,210;
+ * clddp_solver.cpp:209,270,274; ipddp_solver.cpp:941,1968,1985,2070). */
+enum cddp_hip_status {
+  CDDP_HIP_STATUS_RUNNING = 0,
+  CDDP_HIP_STATUS_OPTIMAL = 1,            /* "OptimalSolutionFound"                       */
+  CDDP_HIP_STATUS_ACCEPTABLE = 2,         /* "AcceptableSolutionFound"                    */
+  CDDP_HIP_STATUS_MAX_ITERATIONS = 3,     /* "MaxIterationsReached"                       */
+  CDDP_HIP_STATUS_REG_LIMIT = 4,          /* "RegularizationLimitReached_NotConverged"    */
+  CDDP_HIP_STATUS_MAX_CPU_TIME = 5        /* "MaxCpuTimeReached"                          */
+};
+
+/* Line-search selection rule (cddp_solver_base.cpp:255-263 vs :264-314). */
+enum cddp_hip_linesearch_rule {
+  CDDP_HIP_LS_FIRST_SUCCESS = 0, /* enable_parallel=false: first successful alpha wins      */
+  CDDP_HIP_LS_BEST_MERIT = 1     /* enable_parallel=true : lowest merit among successes     */
+};
+
+enum cddp_hip_barrier_strategy { CDDP_HIP_BARRIER_ADAPTIVE = 0, CDDP_HIP_BARRIER_MONOTONIC = 1,
+                                 CDDP_HIP_BARRIER_IPOPT = 2 };
+
+/* ---- option POD (field-for-field twin of cddp::CDDPOptions, options.hpp:41-251) */
+typedef struct cddp_hip_options {
+  double tolerance;              /* 1e-5 */
+  double acceptable_tolerance;   /* 1e-6 */
+  int32_t max_iterations;        /* 1    */
+  int32_t use_ilqr;              /* 1 (only Gauss-Newton is implemented; 0 is rejected)   */
+  int32_t enable_parallel;       /* 0 -> CDDP_HIP_LS_FIRST_SUCCESS, 1 -> BEST_MERIT        */
+  int32_t return_iteration_info; /* 0 */
+  int32_t warm_start;            /* 0 */
+  int32_t _pad0;
+  double termination_scaling_max_factor; /* 100 */
+  /* LineSearchOptions */
+  int32_t ls_max_iterations;     /* 11 */
+  int32_t _pad1;
+  double ls_initial_step_size;   /* 1.0 */
+  double ls_min_step_size;       /* 1e-8 */
+  double ls_step_reduction_factor; /* 0.5 */
+  /* RegularizationOptions */
+  double reg_initial_value;      /* 1e-6 */
+  double reg_update_factor;      /* 10 */
+  double reg_max_value;          /* 1e7 */
+  double reg_min_value;          /* 1e-10 */
+  /* BoxQPOptions (boxqp.hpp:30-41) */
+  int32_t boxqp_max_iterations;  /* 100 */
+  int32_t _pad2;
+  double boxqp_min_gradient_norm;        /* 1e-8 */
+  double boxqp_min_relative_improvement; /* 1e-8 */
+  double boxqp_step_decrease_factor;     /* 0.6 */
+  double boxqp_min_step_size;            /* 1e-22 */
+  double boxqp_armijo_constant;          /* 0.1 */
+  /* SolverSpecificFilterOptions */
+  double filter_merit_acceptance_threshold;     /* 1e-6 */
+  double filter_violation_acceptance_threshold; /* 1e-6 */
+  double filter_max_violation_threshold;        /* 1e4 */
+  double filter_min_violation_for_armijo_check; /* 1e-7 */
+  double filter_armijo_constant;                /* 1e-4 */
+  /* IPDDPAlgorithmOptions */
+  double ipddp_dual_var_init_scale;   /* 0.1 */
+  double ipddp_slack_var_init_scale;  /* 1e-2 */
+  double ipddp_barrier_tol_mult;      /* 0.1 */
+  double ipddp_barrier_update_dual_weight; /* 0.01 */
+  double ipddp_mu_kappa_epsilon;      /* 10 */
+  int32_t ipddp_check_state_stationarity; /* 0 */
+  int32_t ipddp_theta_norm_l2;        /* 0 = "l1" */
+  int32_t ipddp_max_filter_size;      /* 5 */
+  int32_t ipddp_warmstart_repair;     /* 0 */
+  double ipddp_theta_0_floor;         /* 1.0 */
+  double ipddp_warmstart_s_min;       /* 1e-4 */
+  double ipddp_warmstart_y_min;       /* 1e-4 */
+  double ipddp_warmstart_interior_factor; /* 1.1 */
+  double ipddp_jacobian_regularization_value;    /* 1e-8 */
+  double ipddp_jacobian_regularization_exponent; /* 0.25 */
+  /* SolverSpecificBarrierOptions */
+  double barrier_mu_initial;          /* 1.0 */
+  double barrier_mu_min_value;        /* 1e-10 */
+  double barrier_mu_update_factor;    /* 0.5 */
+  double barrier_mu_update_power;     /* 1.2 */
+  double barrier_min_fraction_to_boundary; /* 0.99 */
+  int32_t barrier_strategy;           /* CDDP_HIP_BARRIER_ADAPTIVE */
+  int32_t _pad3;
+} cddp_hip_options;
+
+/* Fill *opt with the reference defaults (options.hpp in-class initialisers). */
+void cddp_hip_default_options(cddp_hip_options *opt);
+
+/* ---- constraint descriptors --------------------------------------------- */
+
+/* One entry of CDDP::path_constraint_set_ (std::map<std::string, unique_ptr<Constraint>>,
+ * cddp_core.hpp:422).  The library sorts entries by `name` (lexicographic, as std::map
+ * iterates) to reproduce the reference's dual stacking order (ipddp_solver.cpp:1371-1384).
+ * CLDDP only honours a CONTROL_BOX whose name is exactly "ControlConstraint"
+ * (clddp_solver.cpp:85-86). */
+typedef struct cddp_hip_constraint {
+  char name[CDDP_HIP_NAME_LEN];
+  int32_t kind;        /* cddp_hip_constraint_kind */
+  int32_t dim;         /* box: #variables (dual dim = 2*dim); ball: center size; linear: #rows */
+  const double *lower; /* box: dim */
+  const double *upper; /* box: dim */
+  const double *center;/* ball: dim */
+  const double *A;     /* linear: dim x nx row-major */
+  const double *b;     /* linear: dim */
+  double radius;       /* ball */
+  double scale;        /* scale_factor (box, ball); 1.0 default */
+} cddp_hip_constraint;
+
+/* One entry of CDDP::terminal_constraint_set_. */
+typedef struct cddp_hip_terminal_constraint {
+  char name[CDDP_HIP_NAME_LEN];
+  int32_t kind;         /* cddp_hip_terminal_kind */
+  int32_t dim;          /* equality: nx; inequality: #rows of A_N */
+  const double *target; /* equality: nx   (h = x_N - target)   */
+  const double *A;      /* inequality: dim x nx (g = A x_N - b) */
+  const double *b;      /* inequality: dim */
+} cddp_hip_terminal_constraint;
+
+/* ---- problem descriptor -------------------------------------------------- */
+
+/* Everything cddp::CDDP holds for one problem (cddp_core.hpp:215-423), as a POD.
+ * All trajectories of a batch share this descriptor; they differ in x0 / U0 only. */
+typedef struct cddp_hip_problem {
+  int32_t abi_version;  /* CDDP_HIP_ABI_VERSION */
+  int32_t solver;       /* cddp_hip_solver */
+  int32_t model;        /* cddp_hip_model */
+  int32_t integrator;   /* cddp_hip_integrator */
+  int32_t nx, nu, horizon;
+  int32_t _pad0;
+  double dt;
+  double model_params[CDDP_HIP_MAX_MODEL_PARAMS];
+  const double *lti_A;  /* CDDP_HIP_MODEL_LTI: nx*nx (discrete A) */
+  const double *lti_B;  /* CDDP_HIP_MODEL_LTI: nx*nu (discrete B) */
+  /* QuadraticObjective(Q, R, Qf, x_ref, reference_states, dt) -- objective.cpp:30-65.
+   * Q and R are given UNSCALED; the library multiplies them by dt as the ctor does. */
+  const double *Q;      /* nx*nx */
+  const double *R;      /* nu*nu */
+  const double *Qf;     /* nx*nx */
+  const double *x_ref;  /* nx    */
+  const double *x_ref_traj; /* (horizon+1)*nx per-step references or NULL (objective.cpp:83-88) */
+  int32_t n_constraints;
+  int32_t n_terminal;
+  const cddp_hip_constraint *constraints;
+  const cddp_hip_terminal_constraint *terminal;
+  cddp_hip_options options;
+} cddp_hip_problem;
+
+/* ---- per-trajectory result record --------------------------------------- */
+
+/* Twin of cddp::CDDPSolution scalars (cddp_core.hpp:54-76) plus work counters used
+ * for the roofline accounting. 96 bytes. */
+typedef struct cddp_hip_result {
+  double final_objective;
+  double merit_function;
+  double inf_pr, inf_du, inf_comp;
+  double barrier_mu;
+  double regularization;
+  double alpha_pr, alpha_du;
+  double step_norm;
+  int32_t iterations;
+  int32_t status;          /* cddp_hip_status */
+  int32_t n_backward;      /* backward sweeps executed (incl. regularisation retries) */
+  int32_t n_forward;       /* forward rollouts required by the sequential rule        */
+} cddp_hip_result;
+
+/* The 16-byte record that is all-gathered across GPUs. */
+typedef struct cddp_hip_gather_record {
+  double final_objective;
+  int32_t iterations;
+  int32_t status;
+} cddp_hip_gather_record;
+
+/* Result of one line-search trial (twin of ForwardPassResult scalars, cddp_core.hpp:105-145). */
+typedef struct cddp_hip_trial {
+  double alpha, alpha_pr, alpha_du;
+  double cost, merit_function, theta, inf_pr, inf_comp;
+  int32_t success;
+  int32_t _pad;
+} cddp_hip_trial;
+
+/* Timing / work summary of one cddp_hip_solve call. */
+typedef struct cddp_hip_stats {
+  double solve_ms;          /* hipEvent time of the device-resident loop           */
+  double backward_ms;       /* sum of K1+K2 kernel time (hipEvent)                 */
+  double forward_ms;        /* sum of K4 kernel time                               */
+  double update_ms;         /* sum of K5 kernel time                               */
+  int64_t sweeps;           /* sum over trajectories of n_backward                 */
+  int64_t rollouts;         /* sum over trajectories of n_forward                  */
+  int64_t rollouts_launched;/* rollouts actually executed (speculative alphas too) */
+  int64_t traj_iterations;  /* sum over trajectories of iterations                 */
+  int32_t outer_iterations; /* host loop trips                                     */
+  int32_t n_converged;      /* status OPTIMAL or ACCEPTABLE                        */
+  int32_t kernel_launches;
+  int32_t _pad;
+} cddp_hip_stats;
+
+typedef struct cddp_hip_handle cddp_hip_handle;
+
+/* ---- entry points -------------------------------------------------------- */
+
+int cddp_hip_abi_version(void);
+const char *cddp_hip_last_error(void);
+/* Number of visible HIP devices (0 when the runtime finds none). */
+int cddp_hip_device_count(void);
+const char *cddp_hip_status_string(int status);
+
+/* Build line-search ladder exactly as detail::buildLineSearchAlphas
+ * (cddp_context_utils.cpp:37-57). Returns the number of alphas written (<= cap). */
+int cddp_hip_build_alphas(const cddp_hip_options *opt, double *alphas, int cap);
+
+/* Create a solver instance for `batch` independent trajectories of `problem` on `device`.
+ * Replaces CDDP::createSolver + ISolverAlgorithm construction (cddp_core.cpp:213-241).
+ * Fails (returns <0) when no GPU/HIP runtime is available -- there is no CPU fallback. */
+int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device,
+                    cddp_hip_handle **out);
+int cddp_hip_destroy(cddp_hip_handle *h);
+
+/* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's). */
+int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream);
+
+/* CDDP::setInitialState / setInitialTrajectory for the whole batch (cddp_core.cpp:66-140).
+ * x0: batch*nx. U0: batch*N*nu or NULL (zeros). X0: batch*(N+1)*nx or NULL (x0 replicated,
+ * as cddp::example::makeInitialTrajectory does). CLDDP linearises X0 as given
+ * (clddp_solver.cpp:68-74); IPDDP re-rolls X from U (ipddp_solver.cpp:868-874). */
+int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
+                         const double *X0);
+
+/* ISolverAlgorithm::initialize for the batch (clddp_solver.cpp:28-75,
+ * ipddp_solver.cpp:644-914 cold-start path). */
+int cddp_hip_initialize(cddp_hip_handle *h);
+
+/* One backwardPass for every trajectory (clddp_solver.cpp:79-204 / ipddp_solver.cpp:960-1569),
+ * including the "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111.
+ * ok[b] (optional, batch ints) receives 1 when the sweep succeeded. */
+int cddp_hip_backward(cddp_hip_handle *h, int32_t *ok);
+
+/* forwardPass for every trajectory and every given alpha
+ * (clddp_solver.cpp:215-262 / ipddp_solver.cpp:1571-1876).  trials: batch*n_alphas records,
+ * trials[b*n_alphas + a]. Does not commit anything. */
+int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas,
+                     cddp_hip_trial *trials);
+
+/* ISolverAlgorithm::solve for the batch: cddp_solver_base.cpp:29-186 as a per-trajectory
+ * device state machine.  Calls cddp_hip_initialize first.  stats may be NULL. */
+int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats);
+
+/* ---- getters (host buffers, batch-major) -------------------------------- */
+int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *results /* batch */);
+int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X /* B*(N+1)*nx */, double *U /* B*N*nu */);
+/* feedback_gains K_u (B*N*nu*nx) and feed-forward k_u (B*N*nu); either may be NULL. */
+int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k);
+/* Value-function expansion along the horizon: Vx B*(N+1)*nx, Vxx B*(N+1)*nx*nx
+ * (k_lambda_/K_lambda_ of ipddp_solver.cpp:1050-1104; V_x/V_xx of clddp_solver.cpp:188-192). */
+int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx);
+/* Slack / dual / constraint residual trajectories, B*N*m each (m = total path dual dim). */
+int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G);
+/* Scalars of the last backward pass: dV (B*2), and per-trajectory regularisation (B). */
+int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg);
+/* CDDPSolution::History for the first `hist_batch` trajectories (requires
+ * options.return_iteration_info): hist[b][it][9] = {objective, merit, alpha_pr, alpha_du,
+ * inf_du, inf_pr, inf_comp, mu, regularization}; counts[b] = entries. max_it = max_iterations+1. */
+int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts);
+
+/* Write the 16-byte gather records of this handle's batch into a DEVICE buffer
+ * (batch * sizeof(cddp_hip_gather_record)), on the handle's stream: the send buffer of the
+ * single RCCL all-gather of SURVEY.md section 8(e). */
+int cddp_hip_write_gather_records_device(cddp_hip_handle *h, void *device_ptr);
+
+/* Total path dual dimension m and terminal-equality dimension p of the handle's problem. */
+int cddp_hip_dual_dim(cddp_hip_handle *h);
+int cddp_hip_batch(cddp_hip_handle *h);
+
+/* ---- stack-fed mode (host plugins) ---------------------------------------
+ * Arbitrary DynamicalSystem/Objective subclasses cannot run on the GPU.  In stack-fed mode
+ * the caller evaluates them on the host and hands over the (N x batch) derivative stacks;
+ * the GPU runs the Riccati sweep on them (reference precompute: cddp_solver_base.cpp:319-394).
+ * Layout: batch-major, fx[b][t][i][j] = A_t = I + dt*f_x, fu[b][t][i][j] = B_t = dt*f_u,
+ * lx[b][t][i], lu[b][t][j], lxx[b][t][i][i'], luu[b][t][j][j'], lux[b][t][j][i];
+ * VxN[b][i], VxxN[b][i][i'] = terminal cost gradient / Hessian.
+ * Runs the unconstrained Gauss-Newton sweep (ipddp_solver.cpp:1048-1118 when
+ * reg_in_value!=0, clddp_solver.cpp:79-204 without bounds otherwise) with regularisation
+ * `reg`, writes K (B*N*nu*nx), k (B*N*nu), Vx (B*(N+1)*nx), Vxx (B*(N+1)*nx*nx),
+ * dV (B*2), ok (B).  Host pointers. */
+int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
+                             const double *fx, const double *fu, const double *lx,
+                             const double *lu, const double *lxx, const double *luu,
+                             const double *lux, const double *VxN, const double *VxxN,
+                             double reg, int reg_in_value, double *K, double *k, double *Vx,
+                             double *Vxx, double *dV, int32_t *ok, double *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDDP_HIP_H */

