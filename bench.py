@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- batched CDDP solves on MI355X (BASELINE.json metric: trajectories/sec + HBM GB/s vs roofline).
+
+A "step" is one complete batch solve (all DDP iterations, converged-or-max-iter) of the workload
+BASELINE.json quotes the metric on: config[1], control-limited cart-pole (nx=4, nu=1, N=100),
+batch 4096 random x0 per GPU, solved with the interior-point core (IPDDP, the north_star target) --
+`--solver clddp` runs the BoxQP core instead.  Inputs (x0, U0) are resident in HBM before the timed
+region.  One process per GPU; ranks shard independent trajectories (weak scaling) and exchange a
+single RCCL all-gather of the 16-byte {cost, iterations, status} records per step.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_api():
+    name = "cddp_cpp_amd_pyapi"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "cddp-cpp_amd", "pyapi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def algorithmic_bytes(nx, nu, N, m, ipddp):
+    """bytes per trajectory of one derivative fill / backward sweep / rollout."""
+    D = 8
+    dyn = nx * nx + nx * nu
+    cost = nx + nu + nx * nx + nu * nu + nu * nx
+    con_in = 3 * m + m * nx + m * nu
+    gain = nu * nx + nu
+    val = nx + nx * nx
+    con_out = 2 * m + 2 * m * nx
+    b_fill = D * N * (nx + nu + dyn + cost + m + m * nx + m * nu)
+    if ipddp:
+        b_bwd = D * (N * (dyn + cost + con_in + gain + val + con_out) + val)
+        b_fwd = D * N * (2 * (nx + nu) + gain + val + 2 * m + con_out + 3 * m + nx)
+    else:
+        b_bwd = D * (N * (dyn + cost + nx + nu + gain) + val)
+        b_fwd = D * N * (2 * (nx + nu) + gain)
+    return b_fill, b_bwd, b_fwd
+
+
+def make_problem(api, workload, solver):
+    sv = api.SOLVER_IPDDP if solver == "ipddp" else api.SOLVER_CLDDP
+    if workload == "cartpole":
+        p = api.cartpole_problem(sv, True)
+        spread = [0.1, 0.3, 0.1, 0.1]
+        desc = "cartpole nx=4 nu=1 N=100 control-limited (u in [-5,5]), rk4, random x0"
+    elif workload == "unicycle":
+        p = api.unicycle_problem(sv, 200, True)
+        spread = [0.05, 0.05, 0.05]
+        desc = "unicycle nx=3 nu=2 N=200 control box + ball obstacle (m=5), euler, random x0"
+    elif workload == "pendulum":
+        p = api.pendulum_problem(sv, True)
+        spread = [0.1, 0.1]
+        desc = "pendulum nx=2 nu=1 N=100 control-limited"
+    else:
+        raise SystemExit("unknown workload " + workload)
+    return p, spread, desc
+
+
+def cpu_baseline(api, p, x0, U0, budget_s=15.0):
+    """Oracle (CPU restatement, kind 'port') timed on the host cores of this box on a bounded sample."""
+    cores = os.cpu_count() or 1
+    fast = False
+    try:   # rebuild the timing variant for THIS box's CPU (-march=native); fall back to the parity build
+        out = "/tmp/cddp_oracle_fast_%d.so" % os.getpid()
+        subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fPIC", "-shared", "-pthread", "-o", out,
+                               os.path.join(REPO, "oracle", "cddp_oracle.cpp")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        api.ORACLE_FAST_LIB_PATH = out
+        fast = True
+    except Exception:
+        fast = os.path.exists(api.ORACLE_FAST_LIB_PATH)
+    n1 = min(x0.shape[0], cores)
+    _, _, _, _, ms1 = api.oracle_solve_batch(p, x0[:n1], None if U0 is None else U0[:n1], n_threads=cores, fast=fast, want_traj=False)
+    per_round = max(ms1 / 1e3, 1e-3)
+    rounds = int(max(1, min(32, budget_s / per_round)))
+    n2 = min(x0.shape[0], cores * rounds)
+    res, _, _, _, ms2 = api.oracle_solve_batch(p, x0[:n2], None if U0 is None else U0[:n2], n_threads=cores, fast=fast, want_traj=False)
+    _, _, _, _, ms_single = api.oracle_solve_batch(p, x0[:2], None if U0 is None else U0[:2], n_threads=1, fast=fast, want_traj=False)
+    return {
+        "value": n2 / (ms2 / 1e3), "unit": "trajectories/s", "cores": cores, "kind": "port",
+        "sample": "first %d trajectories of the same batch, %d host threads, oracle (Eigen-free CPU restatement, %s)" %
+                  (n2, cores, "-O3 -march=native" if fast else "-O2 parity build"),
+        "single_thread_value": 2 / (ms_single / 1e3),
+        "mean_iterations": float(np.mean(res["iterations"])),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "unicycle", "pendulum"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the cddp_hip solver core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    api = load_api()
+    p, spread, desc = make_problem(api, args.workload, args.solver)
+    B = args.batch
+    seed = 20260928 + 1 + 1000 * rank          # seed = 20260928 + config_index; ranks get disjoint batches
+    x0 = api.batch_x0(p, B, seed, spread)
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B, device=local_rank)
+    hs.set_initial(x0, U0)                     # H2D once; solve() restarts from the device-resident copy
+    rec_dtype = torch.uint8
+    rec_local = torch.empty(B * 16, dtype=rec_dtype, device="cuda")
+    rec_all = torch.empty(B * 16 * world, dtype=rec_dtype, device="cuda") if world > 1 else rec_local
+
+    def step():
+        st = hs.solve()
+        hs.write_gather_records_device(rec_local.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(rec_all, rec_local)   # the single RCCL collective of the path
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    # work counters of this rank's last step (identical work every step: same inputs)
+    st = stats[-1]
+    res = hs.results()
+    m = hs.m
+    ipddp = args.solver == "ipddp"
+    b_fill, b_bwd, b_fwd = algorithmic_bytes(p.nx, p.nu, p.N, m, ipddp)
+    bwd_ms = float(np.mean([s.backward_ms for s in stats]))
+    fwd_ms = float(np.mean([s.forward_ms for s in stats]))
+    upd_ms = float(np.mean([s.update_ms for s in stats]))
+    solve_ms = float(np.mean([s.solve_ms for s in stats]))
+    bytes_bwd = b_fill * st.traj_iterations + b_bwd * st.sweeps
+    bytes_fwd = b_fwd * st.rollouts
+    gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+    gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+    gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
+    if bwd_ms >= fwd_ms:
+        dom = ("k_derivs+k_backward_%s" % args.solver, gbps_bwd, bwd_ms, bytes_bwd)
+    else:
+        dom = ("k_forward_%s" % args.solver, gbps_fwd, fwd_ms, bytes_fwd)
+    PEAK = 8000.0   # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+    n_launch = max(1, st.outer_iterations)
+    roofline = {
+        "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
+        "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": None,
+        "algorithmic_bytes_per_launch": dom[3] / n_launch, "avg_launch_ms": dom[2] / n_launch,
+        "launches": n_launch,
+        "classes": {
+            "backward(K1+K2)": {"ms": bwd_ms, "GBps": gbps_bwd}, "forward(K4)": {"ms": fwd_ms, "GBps": gbps_fwd},
+            "update(K5)": {"ms": upd_ms}, "whole_solve": {"ms": solve_ms, "GBps": gbps_all},
+        },
+        "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
+    }
+    status_hist = {api.STATUS_STRINGS[int(s)]: int(c) for s, c in zip(*np.unique(res["status"], return_counts=True))}
+    total_traj = B * world * args.steps
+    out = {
+        "metric": "trajectories_per_sec", "value": total_traj / dt_max, "unit": "trajectories/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config[1]: " + desc + ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
+            "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": B * world, "nx": p.nx, "nu": p.nu,
+            "horizon": p.N, "path_dual_dim": m, "max_iterations": int(p.options.max_iterations),
+            "line_search": "first-success rule, %d alphas" % int(p.options.ls_max_iterations),
+            "sharding": "independent trajectories, block partition, one RCCL all-gather of 16-B records per step",
+        },
+        "solve": {
+            "mean_iterations": float(np.mean(res["iterations"])), "max_iterations": int(np.max(res["iterations"])),
+            "status": status_hist, "sweeps": int(st.sweeps), "rollouts_useful": int(st.rollouts),
+            "rollouts_launched": int(st.rollouts_launched), "kernel_launches": int(st.kernel_launches),
+            "device_solve_ms": solve_ms,
+        },
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(api, p, x0, U0)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    hs.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

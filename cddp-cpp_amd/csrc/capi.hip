@@ -61,6 +61,8 @@ struct cddp_hip_handle {
   ProblemDev *dP = nullptr;
   double *d_xref_traj = nullptr;
   unsigned long long *d_launched = nullptr;
+  double *d_Xinit = nullptr, *d_Uinit = nullptr;   // initial trajectory kept on the device so solve() is repeatable
+  bool have_initial = false;
   bool initialized = false;
   size_t bytes = 0;
 };
@@ -155,6 +157,13 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
     return fail(-3, "terminal constraints are not supported by the HIP core yet (IPDDP: terminal constraint has unsupported type)");
   P.n_alphas = cddp_hip_build_alphas(&p->options, P.alphas, CDDP_HIP_MAX_ALPHAS);
   if (P.n_alphas <= 0) return fail(-2, "empty line-search ladder");
+  return 0;
+}
+
+int restore_initial(cddp_hip_handle *h) {
+  if (!h->have_initial) return fail(-1, "cddp_hip_set_initial must be called before initialize/solve");
+  HIPCHK(hipMemcpyAsync(h->d.X, h->d_Xinit, h->d.planeX * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d.U, h->d_Uinit, h->d.planeU * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
 
@@ -278,6 +287,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   DA(d.n_active, 1);
   DA(h->d_launched, 1);
   DA(h->dP, 1);
+  DA(h->d_Xinit, d.planeX); DA(h->d_Uinit, d.planeU);
   if (problem->x_ref_traj) {
     DA(h->d_xref_traj, (size_t)(N + 1) * nx);
     hipMemcpyAsync(h->d_xref_traj, problem->x_ref_traj, sizeof(double) * (N + 1) * nx, hipMemcpyHostToDevice, h->stream);
@@ -342,10 +352,10 @@ int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
   for (int b = 0; b < B; ++b)
     for (int e = 0; e < nx; ++e) hx[((size_t)0 * nx + e) * Bp + b] = x0[(size_t)b * nx + e];   // X_[0] = initial_state (cddp_core.cpp:294)
   if (U0) to_soa(U0, hu.data(), B, Bp, N, nu);
-  HIPCHK(hipMemcpyAsync(d.X, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(d.U, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemsetAsync(d.cur, 0, sizeof(int) * Bp, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_Xinit, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_Uinit, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_initial = true;
   h->initialized = false;
   return 0;
 }
@@ -353,6 +363,7 @@ int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
 int cddp_hip_initialize(cddp_hip_handle *h) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  { int rc = restore_initial(h); if (rc) return rc; }
   h->ks->init(h->d, h->stream);
   HIPCHK(hipGetLastError());
   h->initialized = true;
@@ -423,6 +434,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
   HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
   HIPCHK(hipEventRecord(ev0, s));
+  { int rc = restore_initial(h); if (rc) return rc; }
   ks->init(d, s);
   h->initialized = true;
   int launches = 1, outer = 0;
