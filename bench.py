@@ -26,6 +26,16 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 
 
+def load_module(name, fn):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "cddp-cpp_amd", fn))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_api():
     name = "cddp_cpp_amd_pyapi"
     if name in sys.modules:
@@ -133,21 +143,23 @@ def main():
     api = load_api()
     p, spread, desc = make_problem(api, args.workload, args.solver)
     B = args.batch
-    seed = 20260928 + 1 + 1000 * rank          # seed = 20260928 + config_index; ranks get disjoint batches
-    x0 = api.batch_x0(p, B, seed, spread)
+    sh = load_module("cddp_sharding", "sharding.py")
+    # one seeded global batch (seed = 20260928 + config_index); rank r owns the
+    # contiguous block [r*B, (r+1)*B) -- weak scaling: B trajectories per GPU.
+    x0_global = api.batch_x0(p, B * world, 20260928 + 1, spread)
+    lo, hi = sh.partition(B * world, world, rank)
+    x0 = np.ascontiguousarray(x0_global[lo:hi])
     U0 = api.batch_U0(p, B)
     hs = api.HipBatchSolver(p, B, device=local_rank)
     hs.set_initial(x0, U0)                     # H2D once; solve() restarts from the device-resident copy
     rec_dtype = torch.uint8
     rec_local = torch.empty(B * 16, dtype=rec_dtype, device="cuda")
-    rec_all = torch.empty(B * 16 * world, dtype=rec_dtype, device="cuda") if world > 1 else rec_local
 
     def step():
         st = hs.solve()
         hs.write_gather_records_device(rec_local.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(rec_all, rec_local)   # the single RCCL collective of the path
-        return st
+        gathered = sh.allgather_records(rec_local, world, dist)   # the single RCCL collective of the path
+        return st, gathered
 
     def sync():
         if world > 1:
@@ -159,8 +171,10 @@ def main():
     sync()
     t0 = time.perf_counter()
     stats = []
+    gathered = None
     for _ in range(args.steps):
-        stats.append(step())
+        st_, gathered = step()
+        stats.append(st_)
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -200,6 +214,9 @@ def main():
         },
         "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
     }
+    rec = sh.unpack_records(gathered.cpu().numpy())
+    assert len(rec) == B * world
+    gathered_converged = int(np.sum((rec["status"] == api.STATUS_OPTIMAL) | (rec["status"] == api.STATUS_ACCEPTABLE)))
     status_hist = {api.STATUS_STRINGS[int(s)]: int(c) for s, c in zip(*np.unique(res["status"], return_counts=True))}
     total_traj = B * world * args.steps
     out = {
@@ -218,7 +235,7 @@ def main():
             "mean_iterations": float(np.mean(res["iterations"])), "max_iterations": int(np.max(res["iterations"])),
             "status": status_hist, "sweeps": int(st.sweeps), "rollouts_useful": int(st.rollouts),
             "rollouts_launched": int(st.rollouts_launched), "kernel_launches": int(st.kernel_launches),
-            "device_solve_ms": solve_ms,
+            "device_solve_ms": solve_ms, "gathered_records": int(len(rec)), "gathered_converged": gathered_converged,
         },
         "roofline": roofline,
     }

@@ -1,0 +1,97 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/cddp_hip.h declares; host-only entry points behave; there is NO CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(api):
+    if not os.path.exists(api.HIP_LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return api.load_hip()
+
+
+def declared_symbols():
+    txt = open(os.path.join(REPO, "include", "cddp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cddp_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(api, lib):
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libcddp_hip.so does not export %s" % s
+    assert set(api.EXPORTED_SYMBOLS) == set(syms)
+
+
+def test_abi_version_and_status_strings(api, lib):
+    assert lib.cddp_hip_abi_version() == 1
+    want = ["Running", "OptimalSolutionFound", "AcceptableSolutionFound", "MaxIterationsReached",
+            "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached"]
+    for i, w in enumerate(want):
+        assert lib.cddp_hip_status_string(i).decode() == w   # status strings are API
+
+
+def test_struct_sizes_match_header(api):
+    assert C.sizeof(api.Result) == 96
+    assert api.RESULT_DTYPE.itemsize == 96
+    assert api.GATHER_DTYPE.itemsize == 16
+    assert api.TRIAL_DTYPE.itemsize == 72
+    assert C.sizeof(api.Stats) == 80
+
+
+def test_default_options_match_reference_defaults(api, lib):
+    o = api.Options()
+    lib.cddp_hip_default_options(C.byref(o))
+    d = api.default_options()
+    for name, _ in api.Options._fields_:
+        assert getattr(o, name) == getattr(d, name), name
+    # include/cddp-cpp/cddp_core/options.hpp:41-251
+    assert o.tolerance == 1e-5 and o.acceptable_tolerance == 1e-6 and o.max_iterations == 1
+    assert o.ls_max_iterations == 11 and o.reg_initial_value == 1e-6 and o.reg_max_value == 1e7
+    assert o.barrier_mu_initial == 1.0 and o.barrier_min_fraction_to_boundary == 0.99
+    assert o.boxqp_max_iterations == 100 and o.boxqp_min_step_size == 1e-22
+
+
+def test_build_alphas_matches_reference_ladder(api, lib):
+    o = api.default_options()
+    a = np.zeros(32)
+    n = lib.cddp_hip_build_alphas(C.byref(o), a.ctypes.data_as(C.POINTER(C.c_double)), 32)
+    assert n == 11 and np.allclose(a[:n], 0.5 ** np.arange(11))
+    o.ls_max_iterations = 40
+    n = lib.cddp_hip_build_alphas(C.byref(o), a.ctypes.data_as(C.POINTER(C.c_double)), 32)
+    assert a[n - 1] == 1e-8 and n < 32
+    # and it agrees with the oracle's ladder
+    p = api.pendulum_problem(); p.options.ls_max_iterations = 40
+    assert np.array_equal(api.Oracle(p).alphas(), a[:n])
+
+
+def test_no_cpu_fallback(api, lib):
+    """Without a GPU the product refuses to run (it must not route through the oracle)."""
+    if lib.cddp_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    p = api.cartpole_problem()
+    with pytest.raises(api.HipError) as e:
+        api.HipBatchSolver(p, 4)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_sources_do_not_reference_oracle():
+    """oracle/ is test infrastructure: nothing under the package may include, link or load it."""
+    root = os.path.join(REPO, "cddp-cpp_amd")
+    for dp, _, fns in os.walk(root):
+        if "build" in dp or "__pycache__" in dp:
+            continue
+        for fn in fns:
+            if not fn.endswith((".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                continue
+            txt = open(os.path.join(dp, fn), errors="ignore").read()
+            assert "oracle/" not in txt and "cddp_oracle" not in txt, os.path.join(dp, fn)

@@ -33,9 +33,32 @@ def make(api, name):
         "cartpole_clddp_box": lambda: S.cartpole_problem(S.SOLVER_CLDDP, True),
         "unicycle_ipddp_box_ball": lambda: S.unicycle_problem(S.SOLVER_IPDDP, 100, True),
         "unicycle_ipddp_box": lambda: S.unicycle_problem(S.SOLVER_IPDDP, 100, False),
+        "unicycle_clddp_box": lambda: _renamed_unicycle(S),
+        "quadrotor_ipddp_box": lambda: S.quadrotor_problem(S.SOLVER_IPDDP, 30, True),
+        "quadrotor_clddp_box": lambda: S.quadrotor_problem(S.SOLVER_CLDDP, 30, True),
+        "quad12_ipddp_box": lambda: S.quadrotor12_problem(S.SOLVER_IPDDP, 30, True),
+        "manipulator_clddp_box": lambda: S.manipulator_problem(S.SOLVER_CLDDP, 40, False, True),
+        "manipulator_ipddp_box": lambda: S.manipulator_problem(S.SOLVER_IPDDP, 40, False, True),
+        "manip7_ipddp_box": lambda: _manip7(S),
     }
     return table[name]()
 
+
+def _renamed_unicycle(S):
+    """CLDDP honours the box only when it is literally named 'ControlConstraint' (clddp_solver.cpp:85-86)."""
+    p = S.unicycle_problem(S.SOLVER_CLDDP, 100, False)
+    p._cons[0].name = b"ControlConstraint"; p._rebuild()
+    return p
+
+
+def _manip7(S):
+    p = S.manipulator7_problem(S.SOLVER_IPDDP, 30, terminal_equality=False, n_alphas=11)
+    p.options.enable_parallel = 0
+    return p
+
+
+BIG_CASES = ["unicycle_clddp_box", "quadrotor_ipddp_box", "quadrotor_clddp_box", "quad12_ipddp_box",
+             "manipulator_clddp_box", "manipulator_ipddp_box", "manip7_ipddp_box"]
 
 CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pendulum_clddp_box",
          "cartpole_ipddp_unc", "cartpole_ipddp_box", "cartpole_clddp_unc", "cartpole_clddp_box",
@@ -44,6 +67,8 @@ CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pend
 
 def spread_for(p):
     s = 0.1 * np.ones(p.nx)
+    if p.nx >= 6:
+        s[:] = 0.02
     if p.nx == 4:
         s[1] = 0.3
     if p.nx == 3:
@@ -51,15 +76,18 @@ def spread_for(p):
     return s
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + BIG_CASES)
 def test_step_level_parity(api, oracle_built, case):
     """initialize -> backward -> forward(alphas): K, k, V_x, V_xx, dV and every trial record."""
     p = make(api, case)
-    B = 8
+    B = 8 if p.nx <= 4 else 3
     x0 = api.batch_x0(p, B, 20260928, spread_for(p))
     U0 = api.batch_U0(p, B)
+    X0 = np.tile(p.X0_single, (B, 1, 1)) if hasattr(p, "X0_single") else None
+    if X0 is not None:
+        X0[:, 0, :] = x0
     hs = api.HipBatchSolver(p, B)
-    hs.set_initial(x0, U0)
+    hs.set_initial(x0, U0, X0)
     hs.initialize()
     ok = hs.backward()
     K, k = hs.gains()
@@ -69,7 +97,7 @@ def test_step_level_parity(api, oracle_built, case):
     trials = hs.forward(alphas)
     for b in range(B):
         o = api.Oracle(p)
-        o.set_initial(x0[b], None if U0 is None else U0[b])
+        o.set_initial(x0[b], None if U0 is None else U0[b], None if X0 is None else X0[b])
         o.initialize()
         ook = o.backward(retry=True)
         assert ok[b] == ook
