@@ -441,7 +441,12 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   int *h_active = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_active, sizeof(int)));
   *h_active = d.B;
-  if (max_it <= 0) { ks->update(d, 2, 0, 1, s); ++launches; }
+  // Speculative line search: when batch x n_alphas wavefronts still underfill the chip (256 CUs x 4 SIMDs),
+  // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
+  // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
+  const long waves_all = (long)((d.B + 63) / 64) * na;
+  const bool one_stage = !first_rule || na == 1 || waves_all <= 2048;
+  if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
     ++outer;
     const int last = (it == max_it) ? 1 : 0;
@@ -449,25 +454,26 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     ks->derivs(d, 0, s);
     ks->backward(d, P.solver, 0, 1, s);
     mark();
-    if (first_rule) {
+    HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
+    if (one_stage) {
+      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, s);
+      mark();
+      ks->update(d, 1, na, last, 1, s);
+      mark();
+      mark();
+      mark();
+      launches += 4;
+    } else {
       ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, s);
       mark();
-      ks->update(d, 1, 1, last, s);
+      ks->update(d, 1, 1, last, 0, s);
       mark();
       ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, s);
       mark();
-      launches += (na > 1) ? 6 : 5;
-    } else {
-      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, s);
+      ks->update(d, 2, na, last, 1, s);
       mark();
-      ks->update(d, 1, na, last, s);
-      mark();
-      mark();
-      launches += 5;
+      launches += 6;
     }
-    HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
-    ks->update(d, 2, na, last, s);
-    mark();
     HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (*h_active == 0) break;

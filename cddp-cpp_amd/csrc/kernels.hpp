@@ -240,12 +240,20 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int 
     for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
     double Qu_error = 0.0;
     bool fail = false;
+    struct StepIn { double A[NX * NX], Bm[NX * NU], x[NX], u[NU], k0[NU]; };
+    auto load_step = [&](int tt, StepIn &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.u);
+      ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.k0);      // BoxQP warm start x0 = k_u_[t] of the previous iteration
+    };
+    StepIn nxt;
+    load_step(N - 1, nxt);
     for (int t = N - 1; t >= 0; --t) {
-      double A[NX * NX], Bm[NX * NU], x[NX], u[NU];
-      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
-      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-      ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+      StepIn cs = nxt;
+      if (t > 0) load_step(t - 1, nxt);
+      double (&A)[NX * NX] = cs.A; double (&Bm)[NX * NU] = cs.Bm; double (&x)[NX] = cs.x; double (&u)[NU] = cs.u;
       double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
       Obj::lx(P, d.xref_traj, t, x, Qx);
       Obj::lu(P, u, Qu);
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int 
         double lb[NU], ub[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - u[i]; ub[i] = P->pool[cc.off_upper + i] - u[i]; }
-        ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);   // warm start x0 = k_u_[t]
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = cs.k0[i];   // warm start x0 = k_u_[t]
         int free_[NU];
         LDLTd<NU> Hfree;
         int stq = boxqp_solve<NU>(o, Quu_reg, Qu, lb, ub, kk, free_, Hfree);
@@ -422,17 +431,29 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
     st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
     dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
     bool fail = false;
-    for (int t = N - 1; t >= 0; --t) {
-      double A[NX * NX], Bm[NX * NU], x[NX], u[NU];
-      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
-      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-      ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
-      double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU];
+    // software pipeline: the record of step t-1 is in flight while step t is computed (the only
+    // latency hiding available along the serial chain with one wave per SIMD)
+    struct StepIn { double A[NX * NX], Bm[NX * NU], x[NX], u[NU], y[MM], s[MM], g[MM]; };
+    auto load_step = [&](int tt, StepIn &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.u);
       if constexpr (M > 0) {
-        ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-        ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-        ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+        ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
+        ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
+        ld<M>(Gc + GI(tt, M, 0), d.Bp, r.g);
+      }
+    };
+    StepIn nxt;
+    load_step(N - 1, nxt);
+    for (int t = N - 1; t >= 0; --t) {
+      StepIn cs = nxt;
+      if (t > 0) load_step(t - 1, nxt);
+      double (&A)[NX * NX] = cs.A; double (&Bm)[NX * NU] = cs.Bm; double (&x)[NX] = cs.x; double (&u)[NU] = cs.u;
+      double (&y)[MM] = cs.y; double (&s)[MM] = cs.s; double (&g)[MM] = cs.g;
+      double Qyx[MM * NX], Qyu[MM * NU];
+      if constexpr (M > 0) {
 #pragma unroll
         for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
@@ -864,59 +885,74 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);
   st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
   double cost_new = 0.0;
+  // software pipeline: record of step t+1 (old iterate, gains, value expansion) in flight during step t
+  struct StepIn {
+    double xo[NX], lam[NX], vx[NX], vxx[NX * NX], uo[NU], kk[NU], KK[NU * NX];
+    double s[MM], y[MM], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX];
+  };
+  auto load_step = [&](int tt, StepIn &r) {
+    ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.xo);
+    ld<NX>(Lc + GI(tt, NX, 0), d.Bp, r.lam);
+    ld<NX>(d.Vx + GI(tt, NX, 0), d.Bp, r.vx);
+    ld<NX * NX>(d.Vxx + GI(tt, NX * NX, 0), d.Bp, r.vxx);
+    if (tt < N) {
+      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.uo);
+      ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.kk);
+      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), d.Bp, r.KK);
+      if constexpr (M > 0) {
+        ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
+        ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
+        ld<M>(d.ks + GI(tt, M, 0), d.Bp, r.ksv);
+        ld<M>(d.ky + GI(tt, M, 0), d.Bp, r.ky);
+        ld<M * NX>(d.Ks + GI(tt, M * NX, 0), d.Bp, r.Ksm);
+        ld<M * NX>(d.Ky + GI(tt, M * NX, 0), d.Bp, r.Ky);
+      }
+    }
+  };
+  StepIn nxt;
+  load_step(0, nxt);
   for (int t = 0; t <= N; ++t) {
-    double xo[NX], dx[NX], lam[NX], vx[NX], vxx[NX * NX];
-    ld<NX>(Xc + GI(t, NX, 0), d.Bp, xo);
-    ld<NX>(Lc + GI(t, NX, 0), d.Bp, lam);
-    ld<NX>(d.Vx + GI(t, NX, 0), d.Bp, vx);
-    ld<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, vxx);
+    StepIn cs = nxt;
+    if (t < N) load_step(t + 1, nxt);
+    double dx[NX], lam[NX];
     bool finite = true;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - cs.xo[i];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s += vxx[i * NX + j] * dx[j];
-      lam[i] = (lam[i] + a_pr * vx[i]) + s;
+      for (int j = 0; j < NX; ++j) s += cs.vxx[i * NX + j] * dx[j];
+      lam[i] = (cs.lam[i] + a_pr * cs.vx[i]) + s;
       finite = finite && dfinite(lam[i]);
     }
     if (!finite) return;
     st<NX>(Ln + GI(t, NX, 0), d.Bp, lam);
     if (t == N) break;
     if constexpr (M > 0) {
-      double s[MM], y[MM], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], sn[MM], yn[MM];
-      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-      ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-      ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
-      ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
-      ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
+      double sn[MM], yn[MM];
       bool feas = true;
 #pragma unroll
       for (int r = 0; r < M; ++r) {
         double p1 = 0.0, p2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) { p1 += Ksm[r * NX + j] * dx[j]; p2 += Ky[r * NX + j] * dx[j]; }
-        sn[r] = (s[r] + a_pr * ksv[r]) + p1;
-        yn[r] = (y[r] + a_du * ky[r]) + p2;
-        if (sn[r] < (1.0 - tau) * s[r] || yn[r] < (1.0 - tau) * y[r]) feas = false;
+        for (int j = 0; j < NX; ++j) { p1 += cs.Ksm[r * NX + j] * dx[j]; p2 += cs.Ky[r * NX + j] * dx[j]; }
+        sn[r] = (cs.s[r] + a_pr * cs.ksv[r]) + p1;
+        yn[r] = (cs.y[r] + a_du * cs.ky[r]) + p2;
+        if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
         if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
       }
       if (!feas) return;
       st<M>(Sn + GI(t, M, 0), d.Bp, sn);
       st<M>(Yn + GI(t, M, 0), d.Bp, yn);
     }
-    double uo[NU], kk[NU], KK[NU * NX], u[NU], xn[NX];
-    ld<NU>(Uc + GI(t, NU, 0), d.Bp, uo);
-    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+    double u[NU], xn[NX];
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       double s1 = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s1 += KK[i * NX + j] * dx[j];
-      u[i] = (uo[i] + a_pr * kk[i]) + s1;
+      for (int j = 0; j < NX; ++j) s1 += cs.KK[i * NX + j] * dx[j];
+      u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
       finite = finite && dfinite(u[i]);
     }
     Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
@@ -1037,7 +1073,7 @@ DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
 // stage 1: trials [0, n1) were evaluated for PH_FWD1 trajectories (n1 = 1 for the first-success rule,
 //          n1 = n_alphas for the best-merit rule); stage 2: trials [1, n_alphas) for PH_FWD2.
 template <class Model, class Cons>
-__global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int is_last_iter) {
+__global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int is_last_iter, int do_count) {
   constexpr int M = Cons::M;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
@@ -1109,10 +1145,15 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
           }
           d.mu[b] = mu;
           const int cs = d.cur[b];
-          double phi_n = d.cost[b], theta_n = 0.0, ipr = 0.0, icomp = 0.0;
-          if constexpr (M > 0)
-            ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
-                                d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp);
+          // computeTheta / computeBarrierMerit / computePrimalAndComplementarity on the accepted iterate
+          // (ipddp_solver.cpp:2622-2656).  With an unchanged mu they are the very sums the winning trial
+          // already evaluated (same routine, same order), so the pass over S/Y/G is only repeated when mu moved.
+          double phi_n = d.t_merit[ti], theta_n = d.t_theta[ti], ipr = d.t_inf_pr[ti], icomp = d.t_inf_comp[ti];
+          if constexpr (M > 0) {
+            if (mu != mu_old)
+              ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
+                                  d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp);
+          }
           const double ftheta = dmax(theta_n, 1e-8);
           const bool reset = (mu < mu_old) && (mu > 0.0);
           if (reset) { d.filt_n[b] = 0; }   // no terminal constraints on this path: filter left empty
@@ -1175,7 +1216,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
     }
   }
 count:
-  if (stage == 2) {
+  if (do_count) {
     if (is_last_iter && d.phase[b] != PH_DONE) { d.status[b] = CDDP_HIP_STATUS_MAX_ITERATIONS; d.phase[b] = PH_DONE; }
     if (d.phase[b] != PH_DONE) atomicAdd(d.n_active, 1);
   }

@@ -12,7 +12,7 @@ struct KernelSet {
   void (*derivs)(const DevBuf &, int force, hipStream_t);
   void (*backward)(const DevBuf &, int solver, int force, int count_iter, hipStream_t);
   void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, hipStream_t);
-  void (*update)(const DevBuf &, int stage, int n1, int is_last, hipStream_t);
+  void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, hipStream_t);
 };
 
@@ -38,8 +38,8 @@ struct Launcher {
     else
       hipLaunchKernelGGL((k_forward_ipddp<Model, Cons>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
   }
-  static void update(const DevBuf &d, int stage, int n1, int is_last, hipStream_t s) {
-    hipLaunchKernelGGL((k_update<Model, Cons>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last);
+  static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
+    hipLaunchKernelGGL((k_update<Model, Cons>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, hipStream_t s) {
     hipLaunchKernelGGL((k_init<Model, Cons>), gridB(d), dim3(64), 0, s, d);
