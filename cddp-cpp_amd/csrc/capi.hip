@@ -42,7 +42,7 @@ const std::vector<KernelSet> &registry() {
   static std::vector<KernelSet> v = [] {
     std::vector<KernelSet> r;
     register_pendulum(r); register_cartpole(r); register_unicycle(r); register_lti(r);
-    register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r);
+    register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r); register_terminal(r);
     return r;
   }();
   return v;
@@ -153,8 +153,36 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
     off += cd.dual_dim;
   }
   P.n_cons = p->n_constraints; P.m = off;
-  if (p->n_terminal > 0)
-    return fail(-3, "terminal constraints are not supported by the HIP core yet (IPDDP: terminal constraint has unsupported type)");
+  // terminal constraints, in std::map (name) order; inequality rows and equality rows are stacked separately
+  if (p->n_terminal > kMaxTerms) return fail(-3, "too many terminal constraints (%d > %d)", p->n_terminal, kMaxTerms);
+  if (p->n_terminal > 0 && p->solver != CDDP_HIP_SOLVER_IPDDP) { /* CLDDP ignores the terminal set, as the reference does */ }
+  {
+    std::vector<int> tord(p->n_terminal);
+    for (int i = 0; i < p->n_terminal; ++i) tord[i] = i;
+    std::stable_sort(tord.begin(), tord.end(), [&](int a, int b) { return std::strcmp(p->terminal[a].name, p->terminal[b].name) < 0; });
+    int offI = 0, offE = 0;
+    for (int k = 0; k < p->n_terminal && p->solver == CDDP_HIP_SOLVER_IPDDP; ++k) {
+      const cddp_hip_terminal_constraint &c = p->terminal[tord[k]];
+      TermDev &td = P.terms[k];
+      td.kind = c.kind; td.dim = c.dim; td.off_target = td.off_A = td.off_b = -1;
+      if (c.kind == CDDP_HIP_TERM_EQUALITY) {
+        if (!c.target) return fail(-2, "Cannot add null constraint.");
+        if (c.dim > p->nx) return fail(-2, "TerminalEqualityConstraint: final_state dimension mismatch.");
+        td.offset = offE; offE += c.dim; td.off_target = pool_put(P, top, c.target, c.dim);
+        if (td.off_target < 0) return fail(-3, "constant pool overflow");
+      } else if (c.kind == CDDP_HIP_TERM_INEQUALITY) {
+        if (!c.A || !c.b) return fail(-2, "Cannot add null constraint.");
+        td.offset = offI; offI += c.dim; td.off_A = pool_put(P, top, c.A, c.dim * p->nx); td.off_b = pool_put(P, top, c.b, c.dim);
+        if (td.off_A < 0 || td.off_b < 0) return fail(-3, "constant pool overflow");
+      } else {
+        return fail(-2, "IPDDP: terminal constraint '%s' has unsupported type. Supported terminal constraints are "
+                        "TerminalEqualityConstraint and TerminalInequalityConstraint.", c.name);   // ipddp_solver.cpp:58-67
+      }
+      P.n_term = k + 1;
+    }
+    P.mT = offI; P.pT = offE;
+    if (P.mT > 8 || P.pT > 16) return fail(-3, "terminal constraint dimension too large (ineq %d > 8 or eq %d > 16)", P.mT, P.pT);
+  }
   P.n_alphas = cddp_hip_build_alphas(&p->options, P.alphas, CDDP_HIP_MAX_ALPHAS);
   if (P.n_alphas <= 0) return fail(-2, "empty line-search ladder");
   return 0;
@@ -284,6 +312,13 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   DA(d.t_success, (size_t)d.n_alphas * Bp);
   DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
   DA(d.hist_n, std::max(1, d.hist_batch));
+  if (ip && P.n_term > 0) {
+    DA(d.ST, (size_t)8 * Bp); DA(d.YT, (size_t)8 * Bp); DA(d.GT, (size_t)8 * Bp); DA(d.dST, (size_t)8 * Bp); DA(d.dYT, (size_t)8 * Bp);
+    DA(d.LamT, (size_t)16 * Bp); DA(d.dLamT, (size_t)16 * Bp);
+    DA(d.STt, (size_t)d.n_alphas * 8 * Bp); DA(d.YTt, (size_t)d.n_alphas * 8 * Bp); DA(d.GTt, (size_t)d.n_alphas * 8 * Bp);
+    DA(d.LamTt, (size_t)d.n_alphas * 16 * Bp);
+    if (P.pT > 0) { DA(d.te_k, (size_t)(P.pT + 1) * N * nu * Bp); DA(d.te_p, (size_t)(P.pT + 1) * (N + 1) * nx * Bp); }
+  }
   DA(d.n_active, 1);
   DA(h->d_launched, 1);
   DA(h->dP, 1);
@@ -607,6 +642,23 @@ int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
   if (S) { int rc = fetch_current(h, d.S, d.planeM, d.N, h->P.m, S); if (rc) return rc; }
   if (Y) { int rc = fetch_current(h, d.Y, d.planeM, d.N, h->P.m, Y); if (rc) return rc; }
   if (G) { int rc = fetch_current(h, d.G, d.planeM, d.N, h->P.m, G); if (rc) return rc; }
+  return 0;
+}
+
+int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  const int mT = h->P.mT, pT = h->P.pT;
+  if (dims) { dims[0] = mT; dims[1] = pT; }
+  std::vector<double> buf;
+  struct { const double *dev; double *host; int n; } items[] = {{d.ST, S_T, mT}, {d.YT, Y_T, mT}, {d.GT, G_T, mT}, {d.LamT, Lambda_T, pT}};
+  for (auto &it : items) {
+    if (!it.host || it.n == 0 || !it.dev) continue;
+    int rc = fetch(h, it.dev, (size_t)it.n * d.Bp, buf); if (rc) return rc;
+    for (int b = 0; b < d.B; ++b) for (int i = 0; i < it.n; ++i) it.host[(size_t)b * it.n + i] = buf[(size_t)i * d.Bp + b];
+  }
   return 0;
 }
 

@@ -23,6 +23,26 @@ DEV double dmax(double a, double b) { return (a < b) ? b : a; } // == std::max(a
 DEV double dmin(double a, double b) { return (b < a) ? b : a; } // == std::min(a,b)
 DEV double dclamp(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }  // std::clamp
 DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN and +-Inf
+// a*b + c with two roundings (no FMA contraction).  Used where an accept/reject decision sits exactly on a
+// rounding knife-edge: the fraction-to-boundary rule caps alpha at -tau*s/ds, so the trial slack
+// s + alpha*ds lands ON the bound (1-tau)*s and `s_new < (1-tau)*s` is decided by the last bit.  The
+// reference is built without FMA (plain -O3 x86-64, CMakeLists.txt:34-40), so the product must round first.
+DEV double madd_2r(double a, double b, double c) {
+#pragma clang fp contract(off)
+  double p = a * b;
+  return p + c;
+}
+// (base + a*k) + sum_j K[j]*dx[j], every product rounded before it is added (same knife-edge as above)
+template <int N>
+DEV double affine_2r(double base, double a, double k, const double *Krow, const double *dx) {
+#pragma clang fp contract(off)
+  double p = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { double m = Krow[j] * dx[j]; p = p + m; }
+  double q = a * k;
+  double r = base + q;
+  return r + p;
+}
 
 // Eigen::LDLT<MatrixXd>, restated (Eigen/src/Cholesky/LDLT.h, ldlt_inplace<Lower>::unblocked
 // and LDLT::_solve_impl).  Reference call sites: boxqp.cpp:105,147; ipddp_solver.cpp:456,583,

@@ -55,7 +55,8 @@ struct DevBuf {
   double *A, *Bm, *K, *k, *Vx, *Vxx, *ks, *ky, *Ks, *Ky;
   // terminal-constraint state [mT or pT][Bp]
   double *ST, *YT, *GT, *dST, *dYT, *LamT, *dLamT;
-  double *STt, *YTt, *GTt, *LamTt;        // trial copies [n_alphas][mT|pT][Bp]
+  double *STt, *YTt, *GTt, *LamTt;        // trial copies [n_alphas][kMTMax|kPTMax][Bp]
+  double *te_k, *te_p;                     // terminal-equality LQR variants: [(pT+1)][N][nu][Bp], [(pT+1)][N+1][nx][Bp]
   // per-trajectory scalars [Bp]
   double *cost, *merit, *inf_pr, *inf_du, *inf_comp, *step_norm, *alpha_pr, *alpha_du, *reg, *mu;
   double *dV0, *dV1, *phi, *theta, *filter_theta, *apr_max, *adu_max;

@@ -18,6 +18,7 @@
 #pragma once
 #include "dev_constraints.hpp"
 #include "dev_models.hpp"
+#include "dev_terminal.hpp"
 
 namespace cddp_dev {
 
@@ -385,11 +386,379 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int 
   d.phase[b] = PH_FWD1;
 }
 
+
+// rolloutLinearPolicy with dx0 = 0 (ipddp_solver.cpp:368-392, 1511-1520) fused with the slack / dual
+// directions dS = k_s + K_s dX, dY = clamp(k_y + K_y dX) (:1522-1532), the terminal-inequality
+// directions (:1534-1561) and computeMaxStepSizes (:2939-2988).  Nothing but the two caps is stored.
+template <class Model, class Cons, bool TERM>
+DEV void lin_rollout_caps(const DevBuf &d, int b, const double *Sc, const double *Yc, const double *Xc, double mu,
+                          double &apr, double &adu) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int mT = TERM ? P->mT : 0;
+  apr = 1.0; adu = 1.0;
+  if (M == 0 && mT == 0) return;
+  const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  double dx[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+  for (int t = 0; t < N; ++t) {
+    double kk[NU], KK[NU * NX];
+    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+    if constexpr (M > 0) {
+      double ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], s[MM], y[MM];
+      ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
+      ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
+      ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+      ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
+      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
+      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
+        double ds = ksv[r] + a;
+        double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
+        if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
+        if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
+      }
+    }
+    if (t < N - 1 || mT > 0) {
+      double du[NU], A[NX * NX], Bm[NX * NU], dxn[NX];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j];
+        du[i] = kk[i] + a; }
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j];
+        dxn[i] = (a + c) + 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+    }
+  }
+  if constexpr (TERM) {
+    if (mT > 0) {   // terminal-inequality directions from dX_N (ipddp_solver.cpp:1534-1561)
+      double xN[NX], gT[kMTMax];
+      ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+      term_ineq_eval<NX>(P, xN, gT);
+      const double fl0 = dmax(mu * 1e-3, kEpsSlack);
+      for (int i = 0; i < mT; ++i) {
+        const double *row = term_ineq_row(P, i);
+        const double sT = d.ST[(size_t)i * d.Bp + b], yT = d.YT[(size_t)i * d.Bp + b];
+        const double r_p = gT[i] + sT;
+        const double r_d = sT * yT - mu;
+        double gd = 0.0;
+        for (int j = 0; j < NX; ++j) gd += row[j] * dx[j];
+        const double dsT = (-r_p) - gd;
+        const double s_safe = dmax(sT, fl0);
+        const double dual_ratio = dclamp(yT / s_safe, 0.0, kMaxBarrierRatio);
+        const double affine = dclamp(-r_d / s_safe, -kMaxBarrierRatio, kMaxBarrierRatio);
+        const double dyT = dclamp(affine - dual_ratio * dsT, -kMaxBarrierRatio, kMaxBarrierRatio);
+        d.dST[(size_t)i * d.Bp + b] = dsT; d.dYT[(size_t)i * d.Bp + b] = dyT;
+        if (dsT < 0.0) apr = dmin(apr, -tau * sT / dsT);
+        if (dyT < 0.0) adu = dmin(adu, -tau * yT / dyT);
+      }
+    }
+  }
+  apr = dclamp(apr, 0.0, 1.0); adu = dclamp(adu, 0.0, 1.0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Terminal-equality reduced LQR branch of IPDDPSolver::backwardPass (ipddp_solver.cpp:1120-1353):
+// (p+1) sequential LQR sweeps (solveSequentialLQR :413-476) + linear rollouts (:368-392), the
+// p x p regularised normal-equation solve for the terminal multipliers (solveTerminalEqualityLQR
+// :478-639) and the recombination of k, p.  One lane does all variants of its trajectory.
+// ---------------------------------------------------------------------------------------------
+template <int NMAXP>
+DEV void singular_minmax(const double *A, int n, double &smax, double &smin) {   // one-sided Jacobi
+  double U[NMAXP * NMAXP];
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) U[i * NMAXP + j] = A[i * NMAXP + j];
+  for (int sweep = 0; sweep < 80; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < n; ++i) { alpha += U[i * NMAXP + p] * U[i * NMAXP + p]; beta += U[i * NMAXP + q] * U[i * NMAXP + q]; gamma += U[i * NMAXP + p] * U[i * NMAXP + q]; }
+        if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-16 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < n; ++i) { double up = U[i * NMAXP + p], uq = U[i * NMAXP + q]; U[i * NMAXP + p] = cs * up - sn * uq; U[i * NMAXP + q] = sn * up + cs * uq; }
+      }
+    if (!rotated) break;
+  }
+  smax = 0.0; smin = INFINITY;
+  for (int j = 0; j < n; ++j) { double s2 = 0; for (int i = 0; i < n; ++i) s2 += U[i * NMAXP + j] * U[i * NMAXP + j]; double sv = sqrt(s2); smax = dmax(smax, sv); smin = dmin(smin, sv); }
+  if (n == 0) { smax = 0.0; smin = 0.0; }
+}
+
+template <class Model, class Cons>
+DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc, const double *Sc, const double *Yc,
+                     const double *Gc, const double *VxN, const double *VxxN, double reg, double mu,
+                     double &inf_pr, double &inf_comp, double &inf_du, double &step_norm) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef Objective<NX, NU> Obj;
+  const ProblemDev *P = d.P;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N, pT = P->pT;
+  const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+  double xN[NX], hT[kPTMax], lam_prev[kPTMax];
+  ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+  term_eq_residual<NX>(P, xN, hT);
+  for (int r = 0; r < pT; ++r) { inf_pr = dmax(inf_pr, fabs(hT[r])); lam_prev[r] = d.LamT[(size_t)r * d.Bp + b]; }
+  // per-step LQ model (:1143-1245)
+  auto lq_model = [&](int t, double *Q, double *q, double *R, double *r, double *Mm, double *A, double *Bm, bool track) {
+    double x[NX], u[NU];
+    ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+    ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+    ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
+    ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+    const double *Qd = P->pool + P->off_Qdt, *Rd = P->pool + P->off_Rdt;
+    for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Q[i * NX + c] = 0.5 * ((2.0 * Qd[i * NX + c]) + (2.0 * Qd[c * NX + i]));
+    for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * ((2.0 * Rd[i * NU + c]) + (2.0 * Rd[c * NU + i]));
+    Obj::lx(P, d.xref_traj, t, x, q);
+    Obj::lu(P, u, r);
+    for (int i = 0; i < NX * NU; ++i) Mm[i] = 0.0;
+    if constexpr (M > 0) {
+      double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], YS[MM], ypS[MM];
+      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
+      ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+      for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+      for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+      Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+      for (int i = 0; i < M; ++i) {
+        const double ss = dmax(s[i], s_floor);
+        YS[i] = clip_pos(y[i], ss);
+        const double rp = g[i] + s[i], rc = y[i] * s[i] - mu;
+        const double rhat = y[i] * rp - rc;
+        ypS[i] = y[i] + clip_sgn(rhat, ss);
+        if (track) { inf_pr = dmax(inf_pr, fabs(rp)); inf_comp = dmax(inf_comp, fabs(rc)); }
+      }
+      for (int i = 0; i < NX; ++i) { double a = 0.0; for (int rr = 0; rr < M; ++rr) a += Qyx[rr * NX + i] * ypS[rr]; q[i] += a; }
+      for (int i = 0; i < NU; ++i) { double a = 0.0; for (int rr = 0; rr < M; ++rr) a += Qyu[rr * NU + i] * ypS[rr]; r[i] += a; }
+      double Qn[NX * NX], Rn[NU * NU];
+      for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) { double a = 0.0; for (int rr = 0; rr < M; ++rr) a += (Qyx[rr * NX + i] * YS[rr]) * Qyx[rr * NX + c]; Qn[i * NX + c] = Q[i * NX + c] + a; }
+      for (int i = 0; i < NU; ++i) for (int c = 0; c < NX; ++c) { double a = 0.0; for (int rr = 0; rr < M; ++rr) a += (Qyu[rr * NU + i] * YS[rr]) * Qyx[rr * NX + c]; Mm[c * NU + i] += a; }
+      for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) { double a = 0.0; for (int rr = 0; rr < M; ++rr) a += (Qyu[rr * NU + i] * YS[rr]) * Qyu[rr * NU + c]; Rn[i * NU + c] = R[i * NU + c] + a; }
+      for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Q[i * NX + c] = 0.5 * (Qn[i * NX + c] + Qn[c * NX + i]);
+      for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * (Rn[i * NU + c] + Rn[c * NU + i]);
+    }
+    for (int i = 0; i < NU; ++i) R[i * NU + i] += reg;
+  };
+  double xT[(kPTMax + 1) * NX];
+  for (int v = 0; v <= pT; ++v) {
+    double Pm[NX * NX], pv[NX];
+    for (int i = 0; i < NX; ++i) {
+      double a = VxN[i];
+      double add = 0.0;                                   // (H_T^T lambda_prev)_i, k ascending
+      for (int r = 0; r < pT; ++r) add += ((term_eq_col(P, r) == i) ? 1.0 : 0.0) * lam_prev[r];
+      a += add;
+      if (v > 0 && term_eq_col(P, v - 1) == i) a += 1.0;
+      pv[i] = a;
+    }
+    for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Pm[i * NX + c] = 0.5 * (VxxN[i * NX + c] + VxxN[c * NX + i]);
+    for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + N) * NX + i) * d.Bp + b] = pv[i];
+    if (v == 0) st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Pm);
+    for (int t = N - 1; t >= 0; --t) {
+      double Q[NX * NX], q[NX], R[NU * NU], r[NU], Mm[NX * NU], A[NX * NX], Bm[NX * NU];
+      lq_model(t, Q, q, R, r, Mm, A, Bm, v == 0);
+      double BtP[NU * NX], Quu[NU * NU], Qux[NU * NX], Qx[NX], Qu[NU];
+      mm_tn<NU, NX, NX>(Bm, Pm, BtP);
+      {
+        double T1[NU * NU], T2[NU * NU], PtB[NX * NU];
+        mm_nn<NU, NX, NU>(BtP, Bm, T1);                 // BtP * B
+        for (int i = 0; i < NX; ++i) for (int c = 0; c < NU; ++c) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Pm[k * NX + i] * Bm[k * NU + c]; PtB[i * NU + c] = a; }   // P^T B ... (B^T P^T) B
+        {   // (B^T * P^T) * B with left-to-right association
+          double BtPt[NU * NX];
+          for (int i = 0; i < NU; ++i) for (int c = 0; c < NX; ++c) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * Pm[c * NX + k]; BtPt[i * NX + c] = a; }
+          mm_nn<NU, NX, NU>(BtPt, Bm, T2);
+        }
+        (void)PtB;
+        for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) Quu[i * NU + c] = 0.5 * (((R[i * NU + c] + T1[i * NU + c]) + R[c * NU + i]) + T2[i * NU + c]);
+      }
+      {
+        double T3[NU * NX];
+        mm_nn<NU, NX, NX>(BtP, A, T3);
+        for (int i = 0; i < NU; ++i) for (int c = 0; c < NX; ++c) Qux[i * NX + c] = T3[i * NX + c] + Mm[c * NU + i];
+      }
+      double drift[NX];
+      for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Pm[i * NX + k] * 0.0; drift[i] = pv[i] + a; }
+      for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += A[k * NX + i] * drift[k]; Qx[i] = q[i] + a; }
+      for (int i = 0; i < NU; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * drift[k]; Qu[i] = r[i] + a; }
+      LDLTd<NU> f;
+      f.compute(Quu, NU);
+      if (!f.ok) return false;
+      double KK[NU * NX], kk[NU], col[NU];
+      for (int c = 0; c < NX; ++c) { for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c]; f.solve(col); for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i]; }
+      for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+      f.solve(col);
+      for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+      // P = Q + A^T P A + Q_xu K + K^T Q_ux + K^T Q_uu K ; p = Q_x + Q_xu k + K^T Q_u + K^T Q_uu k
+      double T1[NX * NX], AtPA[NX * NX], KtQ[NX * NU], Pn[NX * NX], pn[NX];
+      mm_tn<NX, NX, NX>(A, Pm, T1);
+      mm_nn<NX, NX, NX>(T1, A, AtPA);
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+      bool fin = true;
+      for (int i = 0; i < NX; ++i)
+        for (int c = 0; c < NX; ++c) {
+          double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          for (int j = 0; j < NU; ++j) { a1 += Qux[j * NX + i] * KK[j * NX + c]; a2 += KK[j * NX + i] * Qux[j * NX + c]; a3 += KtQ[i * NU + j] * KK[j * NX + c]; }
+          Pn[i * NX + c] = (((Q[i * NX + c] + AtPA[i * NX + c]) + a1) + a2) + a3;
+        }
+      for (int i = 0; i < NX; ++i) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int j = 0; j < NU; ++j) { a1 += Qux[j * NX + i] * kk[j]; a2 += KK[j * NX + i] * Qu[j]; a3 += KtQ[i * NU + j] * kk[j]; }
+        pn[i] = ((Qx[i] + a1) + a2) + a3;
+        fin = fin && dfinite(pn[i]);
+      }
+      for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) { Pm[i * NX + c] = 0.5 * (Pn[i * NX + c] + Pn[c * NX + i]); fin = fin && dfinite(Pm[i * NX + c]); }
+      for (int i = 0; i < NX; ++i) pv[i] = pn[i];
+      for (int i = 0; i < NU * NX; ++i) fin = fin && dfinite(KK[i]);
+      for (int i = 0; i < NU; ++i) fin = fin && dfinite(kk[i]);
+      if (!fin) return false;
+      if (v == 0) { st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK); st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Pm); }
+      for (int i = 0; i < NU; ++i) d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] = kk[i];
+      for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + t) * NX + i) * d.Bp + b] = pv[i];
+    }
+    // rolloutLinearPolicy for this variant (dx0 = 0)
+    double dx[NX];
+    for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+    for (int t = 0; t < N; ++t) {
+      double KK[NU * NX], A[NX * NX], Bm[NX * NU], du[NU], dxn[NX];
+      ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+      for (int i = 0; i < NU; ++i) { double a = 0.0; for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j]; du[i] = d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] + a; }
+      for (int i = 0; i < NX; ++i) { double a = 0.0, c = 0.0; for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j]; for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j]; dxn[i] = (a + c) + 0.0; }
+      for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+    }
+    for (int i = 0; i < NX; ++i) xT[v * NX + i] = dx[i];
+  }
+  // ---- reduced terminal system (:550-617)
+  double As[kPTMax * kPTMax], rhs[kPTMax], AtA[kPTMax * kPTMax], Atb[kPTMax];
+  for (int r = 0; r < pT; ++r) {
+    const int cr = term_eq_col(P, r);
+    for (int i = 0; i < pT; ++i) {   // (H_T S)(r,i) = sum_k H_T(r,k) S(k,i)
+      double a = 0.0;
+      for (int k = 0; k < NX; ++k) a += ((k == cr) ? 1.0 : 0.0) * (xT[(i + 1) * NX + k] - xT[k]);
+      As[r * kPTMax + i] = a;
+    }
+    double hx = 0.0;
+    for (int k = 0; k < NX; ++k) hx += ((k == cr) ? 1.0 : 0.0) * xT[k];
+    rhs[r] = (-hT[r]) - hx;
+  }
+  double tr = 0.0;
+  for (int i = 0; i < pT; ++i) {
+    for (int c = 0; c < pT; ++c) { double a = 0.0; for (int k = 0; k < pT; ++k) a += As[k * kPTMax + i] * As[k * kPTMax + c]; AtA[i * kPTMax + c] = a; }
+    double a = 0.0; for (int k = 0; k < pT; ++k) a += As[k * kPTMax + i] * rhs[k]; Atb[i] = a;
+  }
+  for (int i = 0; i < pT; ++i) tr += AtA[i * kPTMax + i];
+  const double trace_term = (tr > 1.0 ? tr / (pT > 1 ? pT : 1) : 1.0);
+  const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+  const double regv = dmax(base_floor, 1e-6 * trace_term);
+  double smax, smin;
+  singular_minmax<kPTMax>(As, pT, smax, smin);
+  const double svd_reg = dmax(1e-8 * smax - smin, 0.0);
+  const double reg_base = dmax(regv, svd_reg);
+  double rn = 0.0; for (int r = 0; r < pT; ++r) rn += rhs[r] * rhs[r];
+  const double cap = 100.0 * (1.0 + sqrt(rn));
+  const double scales[5] = {1.0, 10.0, 100.0, 1e3, 1e4};
+  double best[kPTMax]; for (int i = 0; i < pT; ++i) best[i] = 0.0;
+  double best_res = INFINITY; bool found = false;
+  for (int sc = 0; sc < 5; ++sc) {
+    const double reg_i = dmax(reg_base * scales[sc], 1e-12);
+    double Sh[kPTMax * kPTMax];
+    for (int i = 0; i < pT; ++i) for (int c = 0; c < pT; ++c) Sh[i * kPTMax + c] = AtA[i * kPTMax + c] + reg_i * ((i == c) ? 1.0 : 0.0);
+    LDLTd<kPTMax> f;
+    f.compute(Sh, pT);
+    if (!f.ok) continue;
+    double lam[kPTMax]; for (int i = 0; i < pT; ++i) lam[i] = Atb[i];
+    f.solve(lam);
+    bool fin = true; double ln = 0.0;
+    for (int i = 0; i < pT; ++i) { fin = fin && dfinite(lam[i]); ln += lam[i] * lam[i]; }
+    if (!fin) continue;
+    ln = sqrt(ln);
+    if (ln > cap) { const double f2 = cap / dmax(ln, 1e-12); for (int i = 0; i < pT; ++i) lam[i] = lam[i] * f2; }
+    double res = 0.0;
+    for (int r = 0; r < pT; ++r) { double a = 0.0; for (int i = 0; i < pT; ++i) a += As[r * kPTMax + i] * lam[i]; const double e = a - rhs[r]; res += e * e; }
+    res = sqrt(res);
+    if (!dfinite(res)) continue;
+    if (!found || res < best_res) { for (int i = 0; i < pT; ++i) best[i] = lam[i]; best_res = res; found = true; }
+  }
+  if (!found) for (int i = 0; i < pT; ++i) best[i] = 0.0;
+  for (int i = 0; i < pT; ++i) d.dLamT[(size_t)i * d.Bp + b] = best[i];   // dLambda_T_eq_ = lambda_delta (:1259)
+  // ---- recombination (:619-634), inf_du / step_norm (:1260-1266)
+  for (int t = 0; t <= N; ++t) {
+    if (t < N) {
+      double ko[NU];
+      for (int i = 0; i < NU; ++i) ko[i] = d.te_k[(((size_t)0 * N + t) * NU + i) * d.Bp + b];
+      for (int v = 0; v < pT; ++v)
+        for (int i = 0; i < NU; ++i) ko[i] += best[v] * (d.te_k[(((size_t)(v + 1) * N + t) * NU + i) * d.Bp + b] - d.te_k[(((size_t)0 * N + t) * NU + i) * d.Bp + b]);
+      st<NU>(d.k + GI(t, NU, 0), d.Bp, ko);
+      for (int i = 0; i < NU; ++i) step_norm = dmax(step_norm, fabs(ko[i]));
+    }
+    double po[NX];
+    for (int i = 0; i < NX; ++i) po[i] = d.te_p[(((size_t)0 * (N + 1) + t) * NX + i) * d.Bp + b];
+    for (int v = 0; v < pT; ++v)
+      for (int i = 0; i < NX; ++i) po[i] += best[v] * (d.te_p[(((size_t)(v + 1) * (N + 1) + t) * NX + i) * d.Bp + b] - d.te_p[(((size_t)0 * (N + 1) + t) * NX + i) * d.Bp + b]);
+    st<NX>(d.Vx + GI(t, NX, 0), d.Bp, po);
+  }
+  for (int t = 0; t < N; ++t) {
+    double Q[NX * NX], q[NX], R[NU * NU], r[NU], Mm[NX * NU], A[NX * NX], Bm[NX * NU], pn[NX];
+    lq_model(t, Q, q, R, r, Mm, A, Bm, false);
+    ld<NX>(d.Vx + GI(t + 1, NX, 0), d.Bp, pn);
+    for (int i = 0; i < NU; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * pn[k]; inf_du = dmax(inf_du, fabs(r[i] + a)); }
+    if constexpr (M > 0) {   // slack / dual gains with the final k, K (:1270-1312)
+      double x[NX], y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], kk[NU], KK[NU * NX];
+      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
+      ld<M>(Yc + GI(t, M, 0), d.Bp, y); ld<M>(Sc + GI(t, M, 0), d.Bp, s); ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+      ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+      for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+      Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+      double ky[MM], ksv[MM], Ky[MM * NX], Ksm[MM * NX];
+      for (int rr = 0; rr < M; ++rr) {
+        const double ss = dmax(s[rr], s_floor);
+        const double YSr = clip_pos(y[rr], ss);
+        const double rp = g[rr] + s[rr], rc = y[rr] * s[rr] - mu;
+        const double rhat = y[rr] * rp - rc;
+        double temp = 0.0; for (int i = 0; i < NU; ++i) temp += Qyu[rr * NU + i] * kk[i];
+        ky[rr] = clip_sgn(rhat + y[rr] * temp, ss);
+        ksv[rr] = (-rp) - temp;
+        for (int c = 0; c < NX; ++c) {
+          double s2 = 0.0; for (int i = 0; i < NU; ++i) s2 += Qyu[rr * NU + i] * KK[i * NX + c];
+          Ky[rr * NX + c] = dmin(dmax(YSr * (Qyx[rr * NX + c] + s2), -kMaxBarrierRatio), kMaxBarrierRatio);
+          Ksm[rr * NX + c] = (-Qyx[rr * NX + c]) - s2;
+        }
+      }
+      st<M>(d.ky + GI(t, M, 0), d.Bp, ky); st<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
+      st<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky); st<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+    }
+  }
+  return true;
+}
+
 // ================================================================================ K2 (IPDDP)
 // Unconstrained branch (ipddp_solver.cpp:1048-1118) when Cons::M == 0, path-constraint branch
 // (:1355-1568) otherwise; followed by the linear-policy rollout (:1511-1532) fused with
 // computeMaxStepSizes (:2939-2988).
-template <class Model, class Cons>
+template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
@@ -409,6 +778,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
   double reg = d.reg[b];
   const double mu = d.mu[b];
   const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+  const int mT = TERM ? P->mT : 0, pT = TERM ? P->pT : 0;
+  const bool nobar = (M == 0) && mT == 0;
+  const bool uncon = nobar && pT == 0;        // the unconstrained branch (ipddp_solver.cpp:1048)
+  const bool path_m0 = (M == 0) && !uncon;    // path / terminal-inequality branch with no path rows
   bool ok = false;
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
@@ -427,9 +800,45 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
 #pragma unroll
         for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (H2[i * NX + c] + H2[c * NX + i]);
     }
+    dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
+    if constexpr (TERM) {
+      if (mT > 0) {   // terminal-inequality barrier terms folded into V_x, V_xx (ipddp_solver.cpp:1000-1031)
+        double gT[kMTMax];
+        term_ineq_eval<NX>(P, xN, gT);
+        for (int c = 0; c < P->n_term; ++c) {
+          const TermDev &td = P->terms[c];
+          if (td.kind != CDDP_HIP_TERM_INEQUALITY) continue;
+          double sig[kMTMax], bg[kMTMax];
+          for (int r = 0; r < td.dim; ++r) {
+            const int j = td.offset + r;
+            const double sT = d.ST[(size_t)j * d.Bp + b], yT = d.YT[(size_t)j * d.Bp + b];
+            d.GT[(size_t)j * d.Bp + b] = gT[j];
+            const double s_safe = dmax(sT, s_floor);
+            const double y_safe = dmax(yT, 1e-10);
+            sig[r] = clip_pos(y_safe, s_safe);
+            bg[r] = y_safe + clip_sgn(y_safe * gT[j] + mu, s_safe);
+            inf_pr = dmax(inf_pr, fabs(gT[j] + sT));
+            inf_comp = dmax(inf_comp, fabs(yT * sT - mu));
+          }
+          const double *Am = P->pool + td.off_A;
+          for (int i = 0; i < NX; ++i) { double a = 0.0; for (int r = 0; r < td.dim; ++r) a += Am[r * NX + i] * bg[r]; Vx[i] += a; }
+          double Vn[NX * NX];
+          for (int i = 0; i < NX; ++i)
+            for (int c2 = 0; c2 < NX; ++c2) { double a = 0.0; for (int r = 0; r < td.dim; ++r) a += (Am[r * NX + i] * sig[r]) * Am[r * NX + c2]; Vn[i * NX + c2] = Vxx[i * NX + c2] + a; }
+          for (int i = 0; i < NX; ++i) for (int c2 = 0; c2 < NX; ++c2) Vxx[i * NX + c2] = 0.5 * (Vn[i * NX + c2] + Vn[c2 * NX + i]);
+        }
+      }
+      if (pT > 0) {   // terminal-equality reduced LQR branch (ipddp_solver.cpp:1120-1353)
+        const bool okte = te_backward<Model, Cons>(d, b, Xc, Uc, Sc, Yc, Gc, Vx, Vxx, reg, mu, inf_pr, inf_comp, inf_du, step_norm);
+        if (okte) { ok = true; break; }
+        if (force == 2) break;
+        reg = reg_increase(o, reg);
+        if (reg >= o.reg_max_value) break;
+        continue;
+      }
+    }
     st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
     st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
-    dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
     bool fail = false;
     // software pipeline: the record of step t-1 is in flight while step t is computed (the only
     // latency hiding available along the serial chain with one wave per SIMD)
@@ -493,23 +902,27 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
       double kk[NU], KK[NU * NX];
       double YS[MM], rp[MM], rc[MM], rhat[MM], Sir[MM], s_safe[MM];
       if constexpr (M == 0) {
-        // ---- unconstrained: regularisation stays in Q_uu (ipddp_solver.cpp:1084-1107)
+        // ---- unconstrained: regularisation stays in Q_uu (ipddp_solver.cpp:1084-1107).  With terminal
+        // inequalities only (path_m0) the path branch runs with zero path rows: same factor, but the
+        // V update keeps the un-symmetrised, un-regularised Q_uu (:1424-1426, 1497-1500).
         double Qs[NU * NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i)
 #pragma unroll
           for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]);
 #pragma unroll
-        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+        for (int i = 0; i < NU; ++i) Qs[i * NU + i] += reg;
+        if (!path_m0) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) Quu[i * NU + i] += reg;
+          for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+        }
         if (NU == 1) {
-          kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
+          kk[0] = -ldlt1_solve(Qs[0], Qu[0]);
 #pragma unroll
-          for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Quu[0], Qux[c]);
+          for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Qs[0], Qux[c]);
         } else {
           LDLTd<NU> f;
-          f.compute(Quu, NU);
+          f.compute(Qs, NU);
           if (!f.ok) { fail = true; break; }
           double col[NU];
 #pragma unroll
@@ -678,66 +1091,18 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
   d.bwd_ok[b] = ok ? 1 : 0;
   if (ok) {
     d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
-    d.inf_pr[b] = (M == 0) ? 0.0 : inf_pr;
-    d.inf_comp[b] = (M == 0) ? 0.0 : inf_comp;
+    d.inf_pr[b] = uncon ? 0.0 : inf_pr;
+    d.inf_comp[b] = uncon ? 0.0 : inf_comp;
     // ---- linear-policy rollout dX (dx0 = 0) -> dS, dY -> fraction-to-boundary caps
     double apr = 1.0, adu = 1.0;
-    if constexpr (M > 0) {
-      const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
-      double dx[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-      for (int t = 0; t < N; ++t) {
-        double kk[NU], KK[NU * NX], ksv[M], ky[M], Ksm[M * NX], Ky[M * NX], s[M], y[M];
-        ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-        ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
-        ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-        ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
-        ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
-        ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
-        ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-        ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-          double a = 0.0, c = 0.0;
-#pragma unroll
-          for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
-          double ds = ksv[r] + a;
-          double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
-          if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
-          if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
-        }
-        if (t < N - 1) {
-          double du[NU], A[NX * NX], Bm[NX * NU], dxn[NX];
-#pragma unroll
-          for (int i = 0; i < NU; ++i) { double a = 0.0;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j];
-            du[i] = kk[i] + a; }
-          ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-          ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
-#pragma unroll
-          for (int i = 0; i < NX; ++i) {
-            double a = 0.0, c = 0.0;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j];
-            dxn[i] = (a + c) + 0.0;
-          }
-#pragma unroll
-          for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
-        }
-      }
-      apr = dclamp(apr, 0.0, 1.0); adu = dclamp(adu, 0.0, 1.0);
-    }
+    lin_rollout_caps<Model, Cons, TERM>(d, b, Sc, Yc, Xc, mu, apr, adu);
     d.apr_max[b] = apr; d.adu_max[b] = adu;
   }
   if (force) return;
   if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
   // checkEarlyConvergence (ipddp_solver.cpp:925-958)
   bool conv;
-  if (M == 0) conv = (d.inf_pr[b] < o.tolerance && inf_du < o.tolerance);
+  if (nobar) conv = (d.inf_pr[b] < o.tolerance && inf_du < o.tolerance);
   else {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
@@ -813,7 +1178,8 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, int a0, int phas
 // reference's order (constraint-major, then t) -- ipddp_solver.cpp:2778-2937.
 template <class Cons>
 DEV void ip_reductions(const DevBuf &d, int b, int N, const double *S, const double *Y, const double *G,
-                       double mu, double cost0, bool l2, double &phi, double &theta, double &inf_pr, double &inf_comp) {
+                       double mu, double cost0, bool l2, double &phi, double &theta, double &inf_pr, double &inf_comp,
+                       const TermState *ts = nullptr, int mT = 0, int pT = 0) {
   constexpr int M = Cons::M;
   double total = 0.0, max_entry = 0.0, ipr = 0.0, icomp = 0.0, mer = cost0;
   for (int c = 0; c < Cons::NSEG; ++c) {
@@ -840,13 +1206,14 @@ DEV void ip_reductions(const DevBuf &d, int b, int N, const double *S, const dou
       mer -= mu * ls;
     }
   }
+  if (ts) term_reductions(d.P, *ts, mT, pT, mu, l2, total, max_entry, mer, ipr, icomp);
   const double th = l2 ? sqrt(total) : total;
   theta = dmax(th, max_entry);
   phi = mer; inf_pr = ipr; inf_comp = icomp;
 }
 
 // ================================================================================ K4 (IPDDP)
-template <class Model, class Cons>
+template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
@@ -872,7 +1239,9 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   double *Ln = d.Lam + (size_t)slot * d.planeX;
   const double alpha = P->alphas[a];
   const double mu = d.mu[b];
-  const double tau = (M == 0) ? 1.0 : dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const int mT = TERM ? P->mT : 0, pT = TERM ? P->pT : 0;
+  const double tau = (M == 0 && mT == 0) ? 1.0 : dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  TermState tn;   // terminal variables of the trial (TERM only)
   const double a_pr = dmin(alpha, d.apr_max[b]);
   const double a_du = dmin(alpha, d.adu_max[b]);
   const size_t ti = (size_t)a * d.Bp + b;
@@ -928,17 +1297,43 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
     }
     if (!finite) return;
     st<NX>(Ln + GI(t, NX, 0), d.Bp, lam);
+    if constexpr (TERM) {
+      if (t == N) {   // terminal slack / dual / multiplier trial (ipddp_solver.cpp:1667-1723)
+        TermState to;
+        term_load(d, b, mT, pT, to);
+        double g0[kMTMax];
+        term_ineq_eval<NX>(P, cs.xo, g0);           // residual at the CURRENT x_N
+        const double fl0 = dmax(mu * 1e-3, kEpsSlack);
+        for (int i = 0; i < mT; ++i) {
+          const double *row = term_ineq_row(P, i);
+          const double k_s_T = -(g0[i] + to.s[i]);
+          double crow[NX];
+          for (int j = 0; j < NX; ++j) crow[j] = -row[j];
+          tn.s[i] = affine_2r<NX>(to.s[i], a_pr, k_s_T, crow, dx);
+          const double s_safe = dmax(to.s[i], fl0);
+          const double r_d = to.y[i] * to.s[i] - mu;
+          const double dual_ratio = clip_pos(to.y[i], s_safe);
+          const double k_y = clip_sgn(-r_d - to.y[i] * k_s_T, s_safe);
+          for (int j = 0; j < NX; ++j) crow[j] = -(dual_ratio * (-row[j]));
+          tn.y[i] = affine_2r<NX>(to.y[i], a_du, k_y, crow, dx);
+          const double s_floor = dmax((1.0 - tau) * to.s[i], fl0);
+          if (tn.s[i] < s_floor || tn.y[i] < (1.0 - tau) * to.y[i]) return;
+          if (!dfinite(tn.s[i]) || !dfinite(tn.y[i])) return;
+        }
+        for (int i = 0; i < pT; ++i) {
+          tn.lam[i] = to.lam[i] + a_pr * d.dLamT[(size_t)i * d.Bp + b];
+          if (!dfinite(tn.lam[i])) return;
+        }
+      }
+    }
     if (t == N) break;
     if constexpr (M > 0) {
       double sn[MM], yn[MM];
       bool feas = true;
 #pragma unroll
       for (int r = 0; r < M; ++r) {
-        double p1 = 0.0, p2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) { p1 += cs.Ksm[r * NX + j] * dx[j]; p2 += cs.Ky[r * NX + j] * dx[j]; }
-        sn[r] = (cs.s[r] + a_pr * cs.ksv[r]) + p1;
-        yn[r] = (cs.y[r] + a_du * cs.ky[r]) + p2;
+        sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], cs.Ksm + r * NX, dx);
+        yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], cs.Ky + r * NX, dx);
         if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
         if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
       }
@@ -972,14 +1367,25 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   }
   cost_new += Obj::terminal_cost(P, x);
   double phi_new = cost_new, theta_new = 0.0, ipr = 0.0, icomp = 0.0;
-  if constexpr (M > 0) {
+  if constexpr (TERM) {
+    term_ineq_eval<NX>(P, x, tn.g);      // G_T_new, h_T_new at the trial's x_N (:1750-1760)
+    term_eq_residual<NX>(P, x, tn.h);
+    __threadfence_block();
+    ip_reductions<Cons>(d, b, N, Sn, Yn, Gn, mu, cost_new, o.ipddp_theta_norm_l2 != 0, phi_new, theta_new, ipr, icomp, &tn, mT, pT);
+    for (int i = 0; i < mT; ++i) {
+      const size_t k2 = ((size_t)a * kMTMax + i) * d.Bp + b;
+      d.STt[k2] = tn.s[i]; d.YTt[k2] = tn.y[i]; d.GTt[k2] = tn.g[i];
+    }
+    for (int i = 0; i < pT; ++i) d.LamTt[((size_t)a * kPTMax + i) * d.Bp + b] = tn.lam[i];
+  } else if constexpr (M > 0) {
     // second pass over this lane's own trial slot, in the reference's summation order
     __threadfence_block();
     ip_reductions<Cons>(d, b, N, Sn, Yn, Gn, mu, cost_new, o.ipddp_theta_norm_l2 != 0, phi_new, theta_new, ipr, icomp);
   }
   if (!dfinite(phi_new) || !dfinite(theta_new) || !dfinite(ipr) || !dfinite(icomp)) return;
   bool accept = false;
-  if constexpr (M == 0) {   // ipddp_solver.cpp:1785-1792
+  const bool uncon = (M == 0) && mT == 0 && pT == 0;
+  if (uncon) {   // ipddp_solver.cpp:1785-1792
     const double dJ = d.cost[b] - cost_new;
     const double expected = -a_pr * (d.dV0[b] + 0.5 * a_pr * d.dV1[b]);
     const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
@@ -1072,9 +1478,10 @@ DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
 // ================================================================================ K5
 // stage 1: trials [0, n1) were evaluated for PH_FWD1 trajectories (n1 = 1 for the first-success rule,
 //          n1 = n_alphas for the best-merit rule); stage 2: trials [1, n_alphas) for PH_FWD2.
-template <class Model, class Cons>
+template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int is_last_iter, int do_count) {
   constexpr int M = Cons::M;
+  constexpr int NXu = Model::NX;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
   const ProblemDev *P = d.P;
@@ -1082,6 +1489,8 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
   const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
   const int ph = d.phase[b];
   const int n_alphas = d.n_alphas;
+  const int mT = (TERM && ipddp) ? P->mT : 0, pT = (TERM && ipddp) ? P->pT : 0;
+  const bool nobar = (M == 0) && mT == 0;     // no_barrier_needed (ipddp_solver.cpp:2552-2554)
   if ((stage == 1 && ph == PH_FWD1) || (stage == 2 && ph == PH_FWD2)) {
     const int lo = (stage == 1) ? 0 : 1;
     const int hi = (stage == 1) ? n1 : n_alphas;
@@ -1114,11 +1523,18 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
         if (ipddp) {
           d.inf_pr[b] = d.t_inf_pr[ti]; d.inf_comp[b] = d.t_inf_comp[ti];
           d.phi[b] = d.t_merit[ti]; d.filter_theta[b] = d.t_theta[ti]; d.theta[b] = d.t_theta[ti];
+          if constexpr (TERM) {   // terminal slack / dual / residual / multipliers of the winner (:1900-1941)
+            for (int i = 0; i < mT; ++i) {
+              const size_t k2 = ((size_t)win * kMTMax + i) * d.Bp + b;
+              d.ST[(size_t)i * d.Bp + b] = d.STt[k2]; d.YT[(size_t)i * d.Bp + b] = d.YTt[k2]; d.GT[(size_t)i * d.Bp + b] = d.GTt[k2];
+            }
+            for (int i = 0; i < pT; ++i) d.LamT[(size_t)i * d.Bp + b] = d.LamTt[((size_t)win * kPTMax + i) * d.Bp + b];
+          }
           // ---- updateBarrierParameters(true) (ipddp_solver.cpp:2548-2660)
           const double sdu = scaled_inf_du<Model, Cons>(d, b, old_cur);
           double mu = d.mu[b];
           const double mu_old = mu;
-          if constexpr (M > 0) {
+          if (!nobar) {
             if (o.barrier_strategy == CDDP_HIP_BARRIER_ADAPTIVE) {
               const double kkt = dmax(dmax(d.inf_pr[b], sdu), d.inf_comp[b]);
               const double threshold = dmax(o.barrier_mu_update_factor * mu, 2.0 * mu);
@@ -1149,14 +1565,27 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
           // (ipddp_solver.cpp:2622-2656).  With an unchanged mu they are the very sums the winning trial
           // already evaluated (same routine, same order), so the pass over S/Y/G is only repeated when mu moved.
           double phi_n = d.t_merit[ti], theta_n = d.t_theta[ti], ipr = d.t_inf_pr[ti], icomp = d.t_inf_comp[ti];
-          if constexpr (M > 0) {
+          if constexpr (TERM) {
+            if (mu != mu_old) {
+              TermState ts;
+              term_load(d, b, mT, pT, ts);
+              double xN[NXu];
+              ld<NXu>(d.X + (size_t)cs * d.planeX + GI(d.N, NXu, 0), d.Bp, xN);
+              term_eq_residual<NXu>(P, xN, ts.h);
+              ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
+                                  d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp, &ts, mT, pT);
+            }
+          } else if constexpr (M > 0) {
             if (mu != mu_old)
               ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
                                   d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp);
           }
           const double ftheta = dmax(theta_n, 1e-8);
           const bool reset = (mu < mu_old) && (mu > 0.0);
-          if (reset) { d.filt_n[b] = 0; }   // no terminal constraints on this path: filter left empty
+          if (reset) {   // filter cleared; re-seeded only when terminal constraints exist (:2629-2637)
+            d.filt_n[b] = 0;
+            if (mT > 0 || pT > 0) filter_accept(d, b, d.phi[b], ftheta);
+          }
           else { filter_accept(d, b, d.phi[b], ftheta); if (d.filt_n[b] > o.ipddp_max_filter_size) filter_prune(d, b); }
           d.inf_pr[b] = ipr; d.inf_comp[b] = icomp;
           d.merit[b] = phi_n; d.phi[b] = phi_n; d.filter_theta[b] = ftheta;
@@ -1166,7 +1595,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
           // ---- checkConvergence (ipddp_solver.cpp:1953-2025)
           const double sdu2 = scaled_inf_du<Model, Cons>(d, b, old_cur);
           const double scomp = d.inf_comp[b], pr = d.inf_pr[b], sn = d.step_norm[b];
-          if constexpr (M == 0) {
+          if (nobar) {
             if (pr < o.tolerance && sdu2 < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; conv = true; }
             else if (o.acceptable_tolerance > 0.0) {
               const double sq = sqrt(o.acceptable_tolerance);
@@ -1200,14 +1629,15 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int 
         // ---- handleForwardPassFailure (cddp_solver_base.cpp:206-218, ipddp_solver.cpp:2037-2082)
         d.n_fwd[b] += n_alphas;
         double reg = reg_increase(o, d.reg[b]);
+        if (ipddp && !nobar && pT > 0) reg = reg_increase(o, reg);   // extra bump for terminal-equality problems (:2043-2050)
         d.reg[b] = reg;
         if (reg >= o.reg_max_value) {
           int st = CDDP_HIP_STATUS_REG_LIMIT;
           if (ipddp) {
             const double sdu = scaled_inf_du<Model, Cons>(d, b, d.cur[b]);
             const double base = sqrt(dmax(o.acceptable_tolerance, o.tolerance));
-            const double at = (M == 0) ? base : dmax(base, o.ipddp_barrier_tol_mult * d.mu[b]);
-            const bool acc = o.acceptable_tolerance > 0.0 && d.inf_pr[b] < at && sdu < at && (M == 0 || d.inf_comp[b] < at);
+            const double at = nobar ? base : dmax(base, o.ipddp_barrier_tol_mult * d.mu[b]);
+            const bool acc = o.acceptable_tolerance > 0.0 && d.inf_pr[b] < at && sdu < at && (nobar || d.inf_comp[b] < at);
             if (acc) st = CDDP_HIP_STATUS_ACCEPTABLE;
           }
           d.status[b] = st; d.phase[b] = PH_DONE;
@@ -1226,7 +1656,7 @@ count:
 // ISolverAlgorithm::initialize.  CLDDP: cost of the given (X,U) (clddp_solver.cpp:68-74).
 // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, s/y initialisation,
 // cost, filter reset.
-template <class Model, class Cons>
+template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_init(DevBuf d) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
@@ -1268,7 +1698,9 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d) {
     hist_push(d, b, 0.0);
     return;
   }
-  const double mu = (M == 0) ? dmax(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
+  const int mT = TERM ? P->mT : 0, pT = TERM ? P->pT : 0;
+  // mu_ = constraint_set.empty() && terminal set empty ? max(tol/10, mu_min) : mu_initial   (ipddp_solver.cpp:876-879)
+  const double mu = (M == 0 && !(TERM && P->n_term > 0)) ? dmax(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
   d.mu[b] = mu;
   d.alpha_pr[b] = 1.0; d.alpha_du[b] = 1.0;
   double *S0 = d.S, *Y0 = d.Y, *G0 = d.G, *L0 = d.Lam;
@@ -1317,12 +1749,43 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d) {
   d.cost[b] = cost;
   // resetFilter (ipddp_solver.cpp:2484-2519)
   double phi = cost, theta = 0.0, ipr = 0.0, icomp = 0.0;
-  if constexpr (M > 0) { __threadfence_block(); ip_reductions<Cons>(d, b, N, S0, Y0, G0, mu, cost, o.ipddp_theta_norm_l2 != 0, phi, theta, ipr, icomp); }
+  if constexpr (TERM) {
+    // terminal slack / dual initialisation (ipddp_solver.cpp:889-908) and multipliers (:829-830)
+    TermState ts;
+    term_ineq_eval<NX>(P, x, ts.g);
+    for (int c = 0; c < P->n_term; ++c) {
+      const TermDev &td = P->terms[c];
+      if (td.kind != CDDP_HIP_TERM_INEQUALITY) continue;
+      double mn = INFINITY, mny = INFINITY;
+      for (int r = 0; r < td.dim; ++r) {
+        const int j = td.offset + r;
+        ts.s[j] = dmax(o.ipddp_slack_var_init_scale, -ts.g[j] + kSlackInteriorOffset);
+        ts.y[j] = (mu * o.ipddp_dual_var_init_scale) / dmax(ts.s[j], kEpsSlack);
+      }
+      if (o.ipddp_warmstart_repair) {
+        for (int r = 0; r < td.dim; ++r) { const int j = td.offset + r; ts.s[j] = dmax(ts.s[j], o.ipddp_warmstart_s_min); mn = dmin(mn, ts.s[j]); }
+        if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int r = 0; r < td.dim; ++r) ts.s[td.offset + r] *= o.ipddp_warmstart_interior_factor;
+        for (int r = 0; r < td.dim; ++r) { const int j = td.offset + r; ts.y[j] = dmax(ts.y[j], o.ipddp_warmstart_y_min); mny = dmin(mny, ts.y[j]); }
+        if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int r = 0; r < td.dim; ++r) ts.y[td.offset + r] *= o.ipddp_warmstart_interior_factor;
+      }
+    }
+    for (int i = 0; i < mT; ++i) {
+      d.GT[(size_t)i * d.Bp + b] = ts.g[i]; d.ST[(size_t)i * d.Bp + b] = ts.s[i]; d.YT[(size_t)i * d.Bp + b] = ts.y[i];
+      d.dST[(size_t)i * d.Bp + b] = 0.0; d.dYT[(size_t)i * d.Bp + b] = 0.0;
+    }
+    for (int i = 0; i < pT; ++i) { ts.lam[i] = 0.0; d.LamT[(size_t)i * d.Bp + b] = 0.0; d.dLamT[(size_t)i * d.Bp + b] = 0.0; }
+    term_eq_residual<NX>(P, x, ts.h);
+    __threadfence_block();
+    ip_reductions<Cons>(d, b, N, S0, Y0, G0, mu, cost, o.ipddp_theta_norm_l2 != 0, phi, theta, ipr, icomp, &ts, mT, pT);
+  } else {
+    if constexpr (M > 0) { __threadfence_block(); ip_reductions<Cons>(d, b, N, S0, Y0, G0, mu, cost, o.ipddp_theta_norm_l2 != 0, phi, theta, ipr, icomp); }
+  }
   d.merit[b] = phi; d.phi[b] = phi; d.inf_pr[b] = ipr; d.inf_comp[b] = icomp;
   const double ft = dmax(theta, 1e-8);
   d.filter_theta[b] = ft;
   d.theta[b] = dmax(ft, dmax(o.ipddp_theta_0_floor, 1e-8));
   d.inf_du[b] = 0.0;
+  if constexpr (TERM) { if (mT > 0 || pT > 0) filter_accept(d, b, phi, ft); }   // resetFilter seeds the filter (:2513-2516)
   hist_push(d, b, mu);
 }
 

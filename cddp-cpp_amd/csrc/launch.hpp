@@ -16,10 +16,10 @@ struct KernelSet {
   void (*init)(const DevBuf &, hipStream_t);
 };
 
-template <class Model, class Cons>
+template <class Model, class Cons, bool TERM = false>
 struct Launcher {
   static bool matches(const ProblemDev &P) {
-    return P.model == Model::ID && P.nx == Model::NX && P.nu == Model::NU && Cons::matches(P);
+    return P.model == Model::ID && P.nx == Model::NX && P.nu == Model::NU && Cons::matches(P) && (TERM ? P.n_term > 0 : P.n_term == 0);
   }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
@@ -29,20 +29,20 @@ struct Launcher {
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, force, count_iter);
     else
-      hipLaunchKernelGGL((k_backward_ipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, force, count_iter);
+      hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, force, count_iter);
   }
   static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, hipStream_t s) {
     if (na <= 0) return;
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_forward_clddp<Model>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
     else
-      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
+      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
-    hipLaunchKernelGGL((k_update<Model, Cons>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last, do_count);
+    hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, hipStream_t s) {
-    hipLaunchKernelGGL((k_init<Model, Cons>), gridB(d), dim3(64), 0, s, d);
+    hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d);
   }
   static KernelSet set(const char *name) {
     KernelSet k;
@@ -62,5 +62,6 @@ void register_quadrotor(std::vector<KernelSet> &);
 void register_quad12(std::vector<KernelSet> &);
 void register_manipulator(std::vector<KernelSet> &);
 void register_manip7(std::vector<KernelSet> &);
+void register_terminal(std::vector<KernelSet> &);
 
 }  // namespace cddp_dev

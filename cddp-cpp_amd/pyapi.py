@@ -487,6 +487,14 @@ class Oracle:
             self.lib.cddp_oracle_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G))
         return S, Y, G
 
+    def terminal(self):
+        dims = np.zeros(2, dtype=np.int32)
+        self.lib.cddp_oracle_get_terminal(self.h, None, None, None, None, dims.ctypes.data_as(C.POINTER(C.c_int32)))
+        mT, pT = int(dims[0]), int(dims[1])
+        S = np.zeros(mT); Y = np.zeros(mT); G = np.zeros(mT); L = np.zeros(pT)
+        self.lib.cddp_oracle_get_terminal(self.h, _ptr(S), _ptr(Y), _ptr(G), _ptr(L), None)
+        return S, Y, G, L
+
     def backward_scalars(self):
         dV = np.zeros(2); reg = np.zeros(1)
         self.lib.cddp_oracle_get_backward_scalars(self.h, _ptr(dV), _ptr(reg))
@@ -576,7 +584,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_set_stream", "cddp_hip_set_initial", "cddp_hip_initialize", "cddp_hip_backward",
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
-    "cddp_hip_get_history", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
+    "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_backward_stacks",
 ]
 
@@ -661,6 +669,14 @@ class HipBatchSolver:
         if self.m:
             self._check(self.lib.cddp_hip_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G)))
         return S, Y, G
+
+    def terminal(self):
+        dims = np.zeros(2, dtype=np.int32)
+        self._check(self.lib.cddp_hip_get_terminal(self.h, None, None, None, None, dims.ctypes.data_as(C.POINTER(C.c_int32))))
+        mT, pT = int(dims[0]), int(dims[1])
+        S = np.zeros((self.B, mT)); Y = np.zeros((self.B, mT)); G = np.zeros((self.B, mT)); L = np.zeros((self.B, pT))
+        self._check(self.lib.cddp_hip_get_terminal(self.h, _ptr(S), _ptr(Y), _ptr(G), _ptr(L), None))
+        return S, Y, G, L
 
     def backward_scalars(self):
         dV = np.zeros((self.B, 2)); reg = np.zeros(self.B)

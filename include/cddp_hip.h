@@ -322,6 +322,10 @@ int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k);
 int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx);
 /* Slack / dual / constraint residual trajectories, B*N*m each (m = total path dual dim). */
 int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G);
+/* Terminal-constraint state (IPDDP): stacked terminal-inequality slack / dual / residual
+ * S_T, Y_T, G_T (B*mT each) and terminal-equality multipliers Lambda_T (B*pT); any may be NULL.
+ * dims[0] = mT, dims[1] = pT (S_T_, Y_T_, G_T_, Lambda_T_eq_ of ipddp_solver.hpp). */
+int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims);
 /* Scalars of the last backward pass: dV (B*2), and per-trajectory regularisation (B). */
 int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg);
 /* CDDPSolution::History for the first `hist_batch` trajectories (requires

@@ -1370,6 +1370,22 @@ int cddp_oracle_get_duals(void *o, double *S, double *Y, double *G) {
   }
   return 0;
 }
+// stacked terminal state in std::map order: inequality (S_T, Y_T, G_T) and equality multipliers
+int cddp_oracle_get_terminal(void *o, double *ST, double *YT, double *GT, double *LamT, int *dims) {
+  Solver *s = (Solver *)o; int mT = 0;
+  for (auto &td : s->terms) if (td.kind == CDDP_HIP_TERM_INEQUALITY) {
+    for (int i = 0; i < td.dim; ++i) {
+      if (ST) ST[mT + i] = s->S_T.at(td.name)(i);
+      if (YT) YT[mT + i] = s->Y_T.at(td.name)(i);
+      if (GT) GT[mT + i] = s->G_T.at(td.name)(i);
+    }
+    mT += td.dim;
+  }
+  int pT = s->term_eq_dim();
+  if (LamT) for (int i = 0; i < pT; ++i) LamT[i] = s->Lambda_T_eq(i);
+  if (dims) { dims[0] = mT; dims[1] = pT; }
+  return 0;
+}
 int cddp_oracle_get_backward_scalars(void *o, double *dV, double *reg) {
   Solver *s = (Solver *)o; if (dV) { dV[0] = s->dV[0]; dV[1] = s->dV[1]; } if (reg) *reg = s->reg; return 0;
 }
