@@ -68,7 +68,11 @@ def algorithmic_bytes(nx, nu, N, m, ipddp):
 
 def make_problem(api, workload, solver):
     sv = api.SOLVER_IPDDP if solver == "ipddp" else api.SOLVER_CLDDP
-    if workload == "cartpole":
+    if workload == "cartpole_unc":
+        p = api.cartpole_problem(sv, False)
+        spread = [0.1, 0.3, 0.1, 0.1]
+        desc = "cartpole nx=4 nu=1 N=100 UNCONSTRAINED (experiment), rk4, random x0"
+    elif workload == "cartpole":
         p = api.cartpole_problem(sv, True)
         spread = [0.1, 0.3, 0.1, 0.1]
         desc = "cartpole nx=4 nu=1 N=100 control-limited (u in [-5,5]), rk4, random x0"
@@ -120,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
     ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
-    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "unicycle", "pendulum"])
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

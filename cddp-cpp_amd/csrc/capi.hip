@@ -310,6 +310,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   double **tr[] = {&d.t_cost, &d.t_merit, &d.t_theta, &d.t_inf_pr, &d.t_inf_comp, &d.t_apr, &d.t_adu};
   for (double **sp : tr) DA(*sp, (size_t)d.n_alphas * Bp);
   DA(d.t_success, (size_t)d.n_alphas * Bp);
+  if (ip && P.n_cons > 0) DA(d.ev, (size_t)d.n_alphas * N * 2 * P.n_cons * Bp);
   DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
   DA(d.hist_n, std::max(1, d.hist_batch));
   if (ip && P.n_term > 0) {

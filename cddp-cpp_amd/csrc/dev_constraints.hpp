@@ -159,8 +159,11 @@ template <int NX, int NU>
 struct Objective {
   DEV static void state_error(const ProblemDev *P, const double *xref_traj, int t, const double *x, double *e) {
     if (xref_traj) {
+      // wave-uniform address -> scalar (SMEM) loads: a vector load here would sit on the vmcnt queue in front
+      // of the software-pipelined prefetch and force it to drain (see PIPELINE_FENCE in kernels.hpp)
+      const double *__restrict__ r = uniform_ptr(xref_traj + (size_t)t * NX);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) e[i] = x[i] - xref_traj[(size_t)t * NX + i];
+      for (int i = 0; i < NX; ++i) e[i] = x[i] - r[i];
     } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) e[i] = x[i] - P->pool[P->off_xref + i];

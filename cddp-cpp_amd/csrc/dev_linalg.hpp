@@ -23,6 +23,13 @@ DEV double dmax(double a, double b) { return (a < b) ? b : a; } // == std::max(a
 DEV double dmin(double a, double b) { return (b < a) ? b : a; } // == std::min(a,b)
 DEV double dclamp(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }  // std::clamp
 DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN and +-Inf
+// broadcast a wave-uniform pointer through SGPRs so that loads from it are scalar loads
+DEV const double *uniform_ptr(const double *p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull));
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const double *)(((unsigned long long)hi << 32) | lo);
+}
 // a*b + c with two roundings (no FMA contraction).  Used where an accept/reject decision sits exactly on a
 // rounding knife-edge: the fraction-to-boundary rule caps alpha at -tau*s/ds, so the trial slack
 // s + alpha*ds lands ON the bound (1-tau)*s and `s_new < (1-tau)*s` is decided by the last bit.  The

@@ -23,6 +23,9 @@
 namespace cddp_dev {
 
 #define GI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)d.Bp + (size_t)b)
+// hipcc sinks the prefetch loads of the software pipeline down to their first use (next iteration), which
+// removes the overlap; a compiler-level memory barrier right after issuing them pins them at the loop top.
+#define PIPELINE_FENCE() asm volatile("" ::: "memory")
 
 constexpr double kSlackInteriorOffset = 1e-4;   // ipddp_solver.cpp:35-38
 constexpr double kEpsSlack = 1e-10;
@@ -56,13 +59,13 @@ DEV void hist_push(const DevBuf &d, int b, double mu_or_zero) {
 
 // ================================================================================ K1
 template <class Model>
-__global__ __launch_bounds__(64) void k_derivs(DevBuf d, int force) {
+__global__ __launch_bounds__(64) void k_derivs(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const int cur = d.cur[b];
   const double *Xc = d.X + (size_t)cur * d.planeX;
   const double *Uc = d.U + (size_t)cur * d.planeU;
@@ -207,13 +210,13 @@ DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const 
 
 // ================================================================================ K2 (CLDDP)
 template <class Model>
-__global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int count_iter) {
+__global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const int cur = d.cur[b];
@@ -254,9 +257,10 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int 
     for (int t = N - 1; t >= 0; --t) {
       StepIn cs = nxt;
       if (t > 0) load_step(t - 1, nxt);
+      PIPELINE_FENCE();
       double (&A)[NX * NX] = cs.A; double (&Bm)[NX * NU] = cs.Bm; double (&x)[NX] = cs.x; double (&u)[NU] = cs.u;
       double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
-      Obj::lx(P, d.xref_traj, t, x, Qx);
+      Obj::lx(P, xrt, t, x, Qx);
       Obj::lu(P, u, Qu);
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
@@ -391,10 +395,9 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, int force, int 
 // directions dS = k_s + K_s dX, dY = clamp(k_y + K_y dX) (:1522-1532), the terminal-inequality
 // directions (:1534-1561) and computeMaxStepSizes (:2939-2988).  Nothing but the two caps is stored.
 template <class Model, class Cons, bool TERM>
-DEV void lin_rollout_caps(const DevBuf &d, int b, const double *Sc, const double *Yc, const double *Xc, double mu,
-                          double &apr, double &adu) {
+DEV void lin_rollout_caps(const DevBuf &d, const ProblemDev *__restrict__ P, int b, const double *Sc, const double *Yc,
+                          const double *Xc, double mu, double &apr, double &adu) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
-  const ProblemDev *P = d.P;
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const int mT = TERM ? P->mT : 0;
@@ -404,45 +407,56 @@ DEV void lin_rollout_caps(const DevBuf &d, int b, const double *Sc, const double
   double dx[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-  for (int t = 0; t < N; ++t) {
-    double kk[NU], KK[NU * NX];
-    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+  // software pipeline: gains / slack record of step t+1 in flight while step t is reduced
+  struct StepIn { double kk[NU], KK[NU * NX], A[NX * NX], Bm[NX * NU], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], s[MM], y[MM]; };
+  auto load_step = [&](int tt, StepIn &r) {
+    ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.kk);
+    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), d.Bp, r.KK);
+    if (tt < N - 1 || mT > 0) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
+    }
     if constexpr (M > 0) {
-      double ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], s[MM], y[MM];
-      ld<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-      ld<M>(d.ky + GI(t, M, 0), d.Bp, ky);
-      ld<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
-      ld<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
-      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+      ld<M>(d.ks + GI(tt, M, 0), d.Bp, r.ksv);
+      ld<M>(d.ky + GI(tt, M, 0), d.Bp, r.ky);
+      ld<M * NX>(d.Ks + GI(tt, M * NX, 0), d.Bp, r.Ksm);
+      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), d.Bp, r.Ky);
+      ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
+      ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
+    }
+  };
+  StepIn nxt;
+  load_step(0, nxt);
+  for (int t = 0; t < N; ++t) {
+    StepIn cs = nxt;
+    if (t + 1 < N) load_step(t + 1, nxt);
+    PIPELINE_FENCE();
+    if constexpr (M > 0) {
 #pragma unroll
       for (int r = 0; r < M; ++r) {
         double a = 0.0, c = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
-        double ds = ksv[r] + a;
-        double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
-        if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
-        if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
+        for (int j = 0; j < NX; ++j) { a += cs.Ksm[r * NX + j] * dx[j]; c += cs.Ky[r * NX + j] * dx[j]; }
+        double ds = cs.ksv[r] + a;
+        double dy = dmin(dmax(cs.ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
+        if (ds < 0.0) apr = dmin(apr, -tau * cs.s[r] / ds);
+        if (dy < 0.0) adu = dmin(adu, -tau * cs.y[r] / dy);
       }
     }
     if (t < N - 1 || mT > 0) {
-      double du[NU], A[NX * NX], Bm[NX * NU], dxn[NX];
+      double du[NU], dxn[NX];
 #pragma unroll
       for (int i = 0; i < NU; ++i) { double a = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j];
-        du[i] = kk[i] + a; }
-      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+        for (int j = 0; j < NX; ++j) a += cs.KK[i * NX + j] * dx[j];
+        du[i] = cs.kk[i] + a; }
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         double a = 0.0, c = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j];
+        for (int j = 0; j < NX; ++j) a += cs.A[i * NX + j] * dx[j];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j];
+        for (int j = 0; j < NU; ++j) c += cs.Bm[i * NU + j] * du[j];
         dxn[i] = (a + c) + 0.0;
       }
 #pragma unroll
@@ -759,13 +773,13 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
 // (:1355-1568) otherwise; followed by the linear-policy rollout (:1511-1532) fused with
 // computeMaxStepSizes (:2939-2988).
 template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int count_iter) {
+__global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const int cur = d.cur[b];
@@ -859,6 +873,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
     for (int t = N - 1; t >= 0; --t) {
       StepIn cs = nxt;
       if (t > 0) load_step(t - 1, nxt);
+      PIPELINE_FENCE();
       double (&A)[NX * NX] = cs.A; double (&Bm)[NX * NU] = cs.Bm; double (&x)[NX] = cs.x; double (&u)[NU] = cs.u;
       double (&y)[MM] = cs.y; double (&s)[MM] = cs.s; double (&g)[MM] = cs.g;
       double Qyx[MM * NX], Qyu[MM * NU];
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
         Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
       }
       double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
-      Obj::lx(P, d.xref_traj, t, x, Qx);
+      Obj::lx(P, xrt, t, x, Qx);
       Obj::lu(P, u, Qu);
       // Q_x = l_x + Q_yx^T y + A^T V_x ; Q_u = l_u + Q_yu^T y + B^T V_x
 #pragma unroll
@@ -1095,7 +1110,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, int force, int 
     d.inf_comp[b] = uncon ? 0.0 : inf_comp;
     // ---- linear-policy rollout dX (dx0 = 0) -> dS, dY -> fraction-to-boundary caps
     double apr = 1.0, adu = 1.0;
-    lin_rollout_caps<Model, Cons, TERM>(d, b, Sc, Yc, Xc, mu, apr, adu);
+    lin_rollout_caps<Model, Cons, TERM>(d, P, b, Sc, Yc, Xc, mu, apr, adu);
     d.apr_max[b] = apr; d.adu_max[b] = adu;
   }
   if (force) return;
@@ -1117,14 +1132,22 @@ DEV int trial_slot(int cur, int a) { return (a < cur) ? a : a + 1; }
 
 // ================================================================================ K4 (CLDDP)
 template <class Model>
-__global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, int a0, int phase_req, int force) {
+__global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int a = a0 + blockIdx.y;
+  int b, a;
+  if (na > 0) {   // alpha-adjacent lanes (measured slower at C2: 11-way scattered trial stores; kept for experiments)
+    const int tpw = 64 / na;
+    if ((int)threadIdx.x >= tpw * na) return;
+    b = blockIdx.x * tpw + (int)threadIdx.x / na;
+    a = a0 + (int)threadIdx.x % na;
+  } else {        // alpha on blockIdx.y: one wavefront = 64 trajectories of one alpha, fully coalesced stores
+    b = blockIdx.x * 64 + threadIdx.x;
+    a = a0 + blockIdx.y;
+  }
   if (b >= d.B) return;
   if (!force && d.phase[b] != phase_req) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const int cur = d.cur[b];
@@ -1156,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, int a0, int phas
       u[i] = (uo[i] + alpha * kk[i]) + s;
       if (box >= 0) u[i] = dmin(dmax(u[i], P->pool[P->cons[box].off_lower + i]), P->pool[P->cons[box].off_upper + i]);
     }
-    J += Obj::running_cost(P, d.xref_traj, t, x, u);
+    J += Obj::running_cost(P, xrt, t, x, u);
     double xn[NX];
     Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
     st<NU>(Un + GI(t, NU, 0), d.Bp, u);
@@ -1214,14 +1237,27 @@ DEV void ip_reductions(const DevBuf &d, int b, int N, const double *S, const dou
 
 // ================================================================================ K4 (IPDDP)
 template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phase_req, int force) {
+__global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int a = a0 + blockIdx.y;
+  // Lane mapping.  Default (na == 0): alpha on blockIdx.y, a wavefront = 64 consecutive trajectories of ONE
+  // alpha; the 11 alpha-wavefronts of a trajectory block have block ids congruent mod 8 (64 blocks per alpha
+  // row), i.e. they land on the same XCD and share its L2 for the re-read gains.  Alternative (na > 0):
+  // the trials of one trajectory in adjacent lanes -- fewer read transactions but 11-way scattered stores and
+  // no whole-wave early exit; measured 1.37x slower at C2 (72 vs 53 ms per solve), see DESIGN.md.
+  int b, a;
+  if (na > 0) {   // alpha-adjacent lanes (measured slower at C2: 11-way scattered trial stores; kept for experiments)
+    const int tpw = 64 / na;
+    if ((int)threadIdx.x >= tpw * na) return;
+    b = blockIdx.x * tpw + (int)threadIdx.x / na;
+    a = a0 + (int)threadIdx.x % na;
+  } else {        // alpha on blockIdx.y: one wavefront = 64 trajectories of one alpha, fully coalesced stores
+    b = blockIdx.x * 64 + threadIdx.x;
+    a = a0 + blockIdx.y;
+  }
   if (b >= d.B) return;
   if (!force && d.phase[b] != phase_req) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const int cur = d.cur[b];
@@ -1254,6 +1290,8 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);
   st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
   double cost_new = 0.0;
+  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
+  const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // software pipeline: record of step t+1 (old iterate, gains, value expansion) in flight during step t
   struct StepIn {
     double xo[NX], lam[NX], vx[NX], vxx[NX * NX], uo[NU], kk[NU], KK[NU * NX];
@@ -1283,6 +1321,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   for (int t = 0; t <= N; ++t) {
     StepIn cs = nxt;
     if (t < N) load_step(t + 1, nxt);
+    PIPELINE_FENCE();
     double dx[NX], lam[NX];
     bool finite = true;
 #pragma unroll
@@ -1327,8 +1366,8 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
       }
     }
     if (t == N) break;
+    double sn[MM], yn[MM];
     if constexpr (M > 0) {
-      double sn[MM], yn[MM];
       bool feas = true;
 #pragma unroll
       for (int r = 0; r < M; ++r) {
@@ -1354,11 +1393,34 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
 #pragma unroll
     for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
     if (!finite) return;
-    cost_new += Obj::running_cost(P, d.xref_traj, t, x, u);
+    cost_new += Obj::running_cost(P, xrt, t, x, u);
     if constexpr (M > 0) {
       double g[MM];
       Cons::template eval<NX, NU>(P, x, u, g);
       st<M>(Gn + GI(t, M, 0), d.Bp, g);
+      if constexpr (!TERM) {
+        // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity
+        // (ipddp_solver.cpp:2778-2937).  The reference sums constraint-major, then t: the first constraint
+        // object's |g+s| terms can therefore be accumulated right here in t order; the other objects' terms
+        // and every log-barrier term (whose chain starts from the still unknown cost_new) are parked in the
+        // ev scratch and added after the rollout in the reference's order -- no second pass over S/Y/G.
+        double *ev = d.ev + (((size_t)a * N + t) * (2 * Cons::NSEG)) * d.Bp + b;
+#pragma unroll
+        for (int c = 0; c < Cons::NSEG; ++c) {
+          const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+          double n1 = 0.0, ninf = 0.0, ls = 0.0;
+          for (int i = 0; i < dim; ++i) {
+            const double r = g[off + i] + sn[off + i];
+            n1 += l2norm ? r * r : fabs(r);
+            ninf = dmax(ninf, fabs(r));
+            ev_icomp = dmax(ev_icomp, fabs(yn[off + i] * sn[off + i] - mu));
+            ls += log(dmax(sn[off + i], kEpsSlack));
+          }
+          ev_max = dmax(ev_max, ninf);
+          if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * d.Bp] = n1;
+          ev[(size_t)c * d.Bp] = ls;
+        }
+      }
     }
     st<NU>(Un + GI(t, NU, 0), d.Bp, u);
     st<NX>(Xn + GI(t + 1, NX, 0), d.Bp, xn);
@@ -1378,9 +1440,31 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
     }
     for (int i = 0; i < pT; ++i) d.LamTt[((size_t)a * kPTMax + i) * d.Bp + b] = tn.lam[i];
   } else if constexpr (M > 0) {
-    // second pass over this lane's own trial slot, in the reference's summation order
-    __threadfence_block();
-    ip_reductions<Cons>(d, b, N, Sn, Yn, Gn, mu, cost_new, o.ipddp_theta_norm_l2 != 0, phi_new, theta_new, ipr, icomp);
+    // add the parked terms in the reference's order (loads are independent of the running sums)
+    double total = ev_total0, mer = cost_new;
+    const double *evb = d.ev + ((size_t)a * N * (2 * Cons::NSEG)) * d.Bp + b;
+    const size_t tstride = (size_t)(2 * Cons::NSEG) * d.Bp;
+    for (int c = 1; c < Cons::NSEG; ++c) {
+      const double *q = evb + (size_t)(Cons::NSEG + c) * d.Bp;
+      int t = 0;
+      for (; t + 3 < N; t += 4) {
+        const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+        total += v0; total += v1; total += v2; total += v3;
+      }
+      for (; t < N; ++t) total += q[(size_t)t * tstride];
+    }
+    for (int c = 0; c < Cons::NSEG; ++c) {
+      const double *q = evb + (size_t)c * d.Bp;
+      int t = 0;
+      for (; t + 3 < N; t += 4) {
+        const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+        mer -= mu * v0; mer -= mu * v1; mer -= mu * v2; mer -= mu * v3;
+      }
+      for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
+    }
+    const double th = l2norm ? sqrt(total) : total;
+    theta_new = dmax(th, ev_max);
+    phi_new = mer; ipr = ev_max; icomp = ev_icomp;
   }
   if (!dfinite(phi_new) || !dfinite(theta_new) || !dfinite(ipr) || !dfinite(icomp)) return;
   bool accept = false;
@@ -1409,6 +1493,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, int a0, int phas
   d.t_inf_pr[ti] = ipr; d.t_inf_comp[ti] = icomp;
   d.t_success[ti] = accept ? 1 : 0;
 }
+
 
 // ---- filter helpers (interior_point_utils.cpp:79-139) on the per-trajectory filter columns
 DEV void filter_accept(const DevBuf &d, int b, double mf, double cv) {
@@ -1479,12 +1564,12 @@ DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
 // stage 1: trials [0, n1) were evaluated for PH_FWD1 trajectories (n1 = 1 for the first-success rule,
 //          n1 = n_alphas for the best-merit rule); stage 2: trials [1, n_alphas) for PH_FWD2.
 template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(64) void k_update(DevBuf d, int stage, int n1, int is_last_iter, int do_count) {
+__global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int stage, int n1, int is_last_iter, int do_count) {
   constexpr int M = Cons::M;
   constexpr int NXu = Model::NX;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
   const int ph = d.phase[b];
@@ -1657,12 +1742,12 @@ count:
 // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, s/y initialisation,
 // cost, filter reset.
 template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(64) void k_init(DevBuf d) {
+__global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
-  const ProblemDev *P = d.P;
+  const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
@@ -1682,7 +1767,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d) {
       double xt[NX], u[NU];
       ld<NX>(X0 + GI(t, NX, 0), d.Bp, xt);
       ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
-      cost += Obj::running_cost(P, d.xref_traj, t, xt, u);
+      cost += Obj::running_cost(P, xrt, t, xt, u);
       double z[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) z[i] = 0.0;
@@ -1707,7 +1792,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d) {
   for (int t = 0; t < N; ++t) {
     double u[NU], xn[NX];
     ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
-    cost += Obj::running_cost(P, d.xref_traj, t, x, u);
+    cost += Obj::running_cost(P, xrt, t, x, u);
     if constexpr (M > 0) {
       double g[MM], s[MM], y[MM];
       Cons::template eval<NX, NU>(P, x, u, g);

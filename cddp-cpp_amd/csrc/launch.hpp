@@ -23,26 +23,27 @@ struct Launcher {
   }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
-    hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, force);
+    hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
   }
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     if (solver == CDDP_HIP_SOLVER_CLDDP)
-      hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, force, count_iter);
+      hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
     else
-      hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, force, count_iter);
+      hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
   }
   static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, hipStream_t s) {
     if (na <= 0) return;
+    const dim3 grid((d.B + 63) / 64, na);
     if (solver == CDDP_HIP_SOLVER_CLDDP)
-      hipLaunchKernelGGL((k_forward_clddp<Model>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
+      hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
-      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), dim3((d.B + 63) / 64, na), dim3(64), 0, s, d, a0, phase_req, force);
+      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
-    hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, stage, n1, is_last, do_count);
+    hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, hipStream_t s) {
-    hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d);
+    hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj);
   }
   static KernelSet set(const char *name) {
     KernelSet k;

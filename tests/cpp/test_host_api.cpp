@@ -127,12 +127,22 @@ static void gpu_tests() {
     int conv = 0; for (auto &s : sols) conv += (s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");
     EXPECT_TRUE(conv >= 120);
   }
-  {   // unsupported terminal constraint on the device: loud error, not a silent fallback
-    cddp::CDDP solver = makePendulum(opt);
+  {   // terminal equality constraint (tests/cddp_core/test_ipddp_solver.cpp:1580-1637 style): x_N pinned to the target
+    cddp::CDDPOptions o2 = opt; o2.max_iterations = 100;
+    cddp::CDDP solver = makePendulum(o2, 60);
     solver.addTerminalConstraint("TerminalTarget", std::make_unique<cddp::TerminalEqualityConstraint>(cddp::Vector{0.0, 0.0}));
+    cddp::CDDPSolution s = solver.solve("IPDDP");
+    std::cout << "IPDDP + terminal equality: " << s.status_message << " iterations " << s.iterations_completed
+              << " |x_N| " << std::fabs(s.state_trajectory.back()[0]) << "\n";
+    EXPECT_TRUE(s.iterations_completed > 0);
+    EXPECT_TRUE(std::fabs(s.state_trajectory.back()[0]) < 1e-2 && std::fabs(s.state_trajectory.back()[1]) < 1e-2);
+  }
+  {   // a layout that is not instantiated on the device: loud error, never a silent fallback
+    cddp::CDDP solver = makePendulum(opt);
+    solver.addPathConstraint("Extra", std::make_unique<cddp::StateConstraint>(cddp::Vector{-10.0, -10.0}, cddp::Vector{10.0, 10.0}));
     bool threw = false;
-    try { solver.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = true; std::cout << "expected: " << e.what() << "\n"; }
-    EXPECT_TRUE(threw || true);
+    try { solver.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("no kernel instantiation") != std::string::npos; }
+    EXPECT_TRUE(threw);
   }
 }
 
