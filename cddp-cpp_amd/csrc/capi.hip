@@ -300,6 +300,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
   DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
   DA(d.Vx, (size_t)(N + 1) * nx * Bp); DA(d.Vxx, (size_t)(N + 1) * nx * nx * Bp);
+  if (ip && h->ks->cst_size > 0) { DA(d.cst, (size_t)N * h->ks->cst_size * Bp); DA(d.dX, (size_t)N * nx * Bp); }
   if (ip && m > 0) { DA(d.ks, (size_t)N * m * Bp); DA(d.ky, (size_t)N * m * Bp); DA(d.Ks, (size_t)N * m * nx * Bp); DA(d.Ky, (size_t)N * m * nx * Bp); }
   double **scal[] = {&d.cost, &d.merit, &d.inf_pr, &d.inf_du, &d.inf_comp, &d.step_norm, &d.alpha_pr, &d.alpha_du, &d.reg, &d.mu,
                      &d.dV0, &d.dV1, &d.phi, &d.theta, &d.filter_theta, &d.apr_max, &d.adu_max};

@@ -15,6 +15,7 @@ namespace cddp_dev {
 template <int D>
 struct CtrlBox {
   static constexpr int KIND = CDDP_HIP_CON_CONTROL_BOX, DUAL = 2 * D, DIM = D;
+  static constexpr bool HAS_X = false;   // G_x == 0
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *, const double *u, double *g) {
 #pragma unroll
@@ -35,6 +36,7 @@ struct CtrlBox {
 template <int D>
 struct StateBox {
   static constexpr int KIND = CDDP_HIP_CON_STATE_BOX, DUAL = 2 * D, DIM = D;
+  static constexpr bool HAS_X = true;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
 #pragma unroll
@@ -55,6 +57,7 @@ struct StateBox {
 template <int D>
 struct Ball {
   static constexpr int KIND = CDDP_HIP_CON_BALL, DUAL = 1, DIM = D;
+  static constexpr bool HAS_X = true;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
     double sq = 0.0;
@@ -74,6 +77,7 @@ struct Ball {
 template <int R>
 struct Linear {
   static constexpr int KIND = CDDP_HIP_CON_LINEAR, DUAL = R, DIM = R;
+  static constexpr bool HAS_X = true;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
 #pragma unroll
@@ -118,6 +122,7 @@ template <class... Cs>
 struct ConList {
   static constexpr int NSEG = sizeof...(Cs);
   static constexpr int M = (0 + ... + Cs::DUAL);
+  static constexpr bool HAS_X = (false || ... || Cs::HAS_X);   // any state-dependent constraint row
   // segment table (constraint-major loops of computeTheta / computeBarrierMerit)
   DEV static int seg_dim(int c) { constexpr int dims[NSEG > 0 ? NSEG : 1] = {Cs::DUAL...}; return dims[c]; }
   DEV static int seg_off(int c) {
@@ -147,6 +152,7 @@ template <>
 struct ConList<> {
   static constexpr int NSEG = 0;
   static constexpr int M = 0;
+  static constexpr bool HAS_X = false;
   DEV static int seg_dim(int) { return 0; }
   DEV static int seg_off(int) { return 0; }
   static bool matches(const ProblemDev &P) { return P.n_cons == 0; }

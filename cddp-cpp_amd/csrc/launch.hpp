@@ -1,12 +1,13 @@
 // Host-side launch table: one KernelSet per (plant, constraint layout) instantiation.
 #pragma once
 #include <vector>
-#include "kernels.hpp"
+#include "kernels_lean.hpp"
 
 namespace cddp_dev {
 
 struct KernelSet {
   int model, nx, nu, m;
+  int cst_size;   // per-step doubles of the condensed-term stack (lean IPDDP backward), 0 = fused sweep
   const char *name;
   bool (*matches)(const ProblemDev &);
   void (*derivs)(const DevBuf &, int force, hipStream_t);
@@ -21,14 +22,23 @@ struct Launcher {
   static bool matches(const ProblemDev &P) {
     return P.model == Model::ID && P.nx == Model::NX && P.nu == Model::NU && Cons::matches(P) && (TERM ? P.n_term > 0 : P.n_term == 0);
   }
+  // path-constrained, no terminal set: condense -> lean sweep -> post (kernels_lean.hpp)
+  static constexpr bool kLean = !TERM && Cons::M > 0;
+  static constexpr int cst_size() { if constexpr (kLean) return CstLayout<Model, Cons>::SIZE; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
     hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+    if constexpr (kLean) {
+      if (d.cst) hipLaunchKernelGGL((k_condense<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+    }
   }
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-    else
+    else if constexpr (kLean) {
+      hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
+    } else
       hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
   }
   static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, hipStream_t s) {
@@ -47,7 +57,7 @@ struct Launcher {
   }
   static KernelSet set(const char *name) {
     KernelSet k;
-    k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name;
+    k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size();
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
     k.update = &update; k.init = &init;
     return k;
