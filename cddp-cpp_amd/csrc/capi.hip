@@ -289,7 +289,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   DevBuf &d = h->d;
   std::memset(&d, 0, sizeof(d));
   const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
-  d.B = B; d.Bp = Bp; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
+  d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
   d.hist_cap = P.opt.max_iterations + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
@@ -364,15 +364,17 @@ int cddp_hip_dual_dim(cddp_hip_handle *h) { return h ? h->P.m : -1; }
 int cddp_hip_batch(cddp_hip_handle *h) { return h ? h->d.B : -1; }
 
 // host batch-major [b][t][e]  <->  device batch-minor [t][e][b]
+// wave-tiled stack index (dev_types.hpp): element e of step t of trajectory b
+static inline size_t tix(int t, int E, int e, int b, int Bp) { return ((((size_t)t * (Bp / 64) + (size_t)(b >> 6)) * E + e) * 64) + (size_t)(b & 63); }
 static void to_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < T; ++t)
-      for (int e = 0; e < E; ++e) dst[((size_t)t * E + e) * Bp + b] = src[((size_t)b * T + t) * E + e];
+      for (int e = 0; e < E; ++e) dst[tix(t, E, e, b, Bp)] = src[((size_t)b * T + t) * E + e];
 }
 static void from_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < T; ++t)
-      for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[((size_t)t * E + e) * Bp + b];
+      for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[tix(t, E, e, b, Bp)];
 }
 
 int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0, const double *X0) {
@@ -385,9 +387,9 @@ int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
   else
     for (int b = 0; b < B; ++b)
       for (int t = 0; t <= N; ++t)
-        for (int e = 0; e < nx; ++e) hx[((size_t)t * nx + e) * Bp + b] = x0[(size_t)b * nx + e];
+        for (int e = 0; e < nx; ++e) hx[tix(t, nx, e, b, Bp)] = x0[(size_t)b * nx + e];
   for (int b = 0; b < B; ++b)
-    for (int e = 0; e < nx; ++e) hx[((size_t)0 * nx + e) * Bp + b] = x0[(size_t)b * nx + e];   // X_[0] = initial_state (cddp_core.cpp:294)
+    for (int e = 0; e < nx; ++e) hx[tix(0, nx, e, b, Bp)] = x0[(size_t)b * nx + e];   // X_[0] = initial_state (cddp_core.cpp:294)
   if (U0) to_soa(U0, hu.data(), B, Bp, N, nu);
   HIPCHK(hipMemcpyAsync(h->d_Xinit, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_Uinit, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -427,7 +429,7 @@ int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cdd
   ProblemDev tmp = h->P;
   for (int i = 0; i < n_alphas; ++i) tmp.alphas[i] = alphas[i];
   HIPCHK(hipMemcpyAsync(h->dP, &tmp, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
-  h->ks->forward(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, h->stream);
+  h->ks->forward(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
   HIPCHK(hipGetLastError());
   const DevBuf &d = h->d;
   const size_t n = (size_t)n_alphas * d.Bp;
@@ -493,7 +495,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     mark();
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
     if (one_stage) {
-      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, s);
+      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
       mark();
       ks->update(d, 1, na, last, 1, s);
       mark();
@@ -501,11 +503,11 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       mark();
       launches += 4;
     } else {
-      ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, s);
+      ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
       mark();
       ks->update(d, 1, 1, last, 0, s);
       mark();
-      ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, s);
+      ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
       mark();
       ks->update(d, 2, na, last, 1, s);
       mark();
@@ -597,7 +599,7 @@ static int fetch_current(cddp_hip_handle *h, const double *base, size_t plane, i
     for (int b = 0; b < d.B; ++b) {
       if (cur[b] != s) continue;
       for (int t = 0; t < T; ++t)
-        for (int e = 0; e < E; ++e) out[((size_t)b * T + t) * E + e] = buf[((size_t)t * E + e) * d.Bp + b];
+        for (int e = 0; e < E; ++e) out[((size_t)b * T + t) * E + e] = buf[tix(t, E, e, b, d.Bp)];
     }
   }
   return 0;

@@ -164,13 +164,12 @@ struct ConList<> {
 template <int NX, int NU>
 struct Objective {
   DEV static void state_error(const ProblemDev *P, const double *xref_traj, int t, const double *x, double *e) {
-    if (xref_traj) {
-      // wave-uniform address -> scalar (SMEM) loads: a vector load here would sit on the vmcnt queue in front
-      // of the software-pipelined prefetch and force it to drain (see PIPELINE_FENCE in kernels.hpp)
-      const double *__restrict__ r = uniform_ptr(xref_traj + (size_t)t * NX);
+    if (xref_traj) {   // per-step reference: constant-address-space scalar loads (see uniform_ptr)
+      cptr_t r = uniform_ptr(xref_traj + (size_t)t * NX);
 #pragma unroll
       for (int i = 0; i < NX; ++i) e[i] = x[i] - r[i];
-    } else {
+    } else {           // fixed goal from the problem pool.  NOT through uniform_ptr: the integer round trip would
+                       // capture the noalias ProblemDev argument and demote every later load from it to VMEM
 #pragma unroll
       for (int i = 0; i < NX; ++i) e[i] = x[i] - P->pool[P->off_xref + i];
     }

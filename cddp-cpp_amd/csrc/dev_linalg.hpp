@@ -23,12 +23,16 @@ DEV double dmax(double a, double b) { return (a < b) ? b : a; } // == std::max(a
 DEV double dmin(double a, double b) { return (b < a) ? b : a; } // == std::min(a,b)
 DEV double dclamp(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }  // std::clamp
 DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN and +-Inf
-// broadcast a wave-uniform pointer through SGPRs so that loads from it are scalar loads
-DEV const double *uniform_ptr(const double *p) {
+// Wave-uniform read-only data (reference trajectory, problem pool): route the address through SGPRs and load
+// through the CONSTANT address space so the compiler emits scalar (SMEM) loads.  A generic-pointer load becomes a
+// flat/global VECTOR load, which sits on the in-order vmcnt queue in front of the software-pipelined prefetch and
+// forces it to drain every step (measured: +270 us per K4 launch at C2).
+typedef const double __attribute__((address_space(4))) *cptr_t;
+DEV cptr_t uniform_ptr(const double *p) {
   unsigned long long v = (unsigned long long)p;
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull));
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const double *)(((unsigned long long)hi << 32) | lo);
+  return (cptr_t)(((unsigned long long)hi << 32) | lo);
 }
 // a*b + c with two roundings (no FMA contraction).  Used where an accept/reject decision sits exactly on a
 // rounding knife-edge: the fraction-to-boundary rule caps alpha at -tau*s/ds, so the trial slack

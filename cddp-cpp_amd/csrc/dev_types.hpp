@@ -41,11 +41,15 @@ struct ProblemDev {
   double pool[kPool];
 };
 
-// All device buffers of one handle.  Trajectory-like arrays are batch-minor ("(N x batch) stacks"):
-// element e of step t of trajectory b lives at ((t*E + e) * Bp + b); a wavefront of 64 consecutive
-// trajectories therefore touches 512 contiguous bytes per (t, e).
+// All device buffers of one handle.  Trajectory-like arrays are wave-tiled "(N x batch) stacks":
+// element e of step t of trajectory b lives at (((t*NB + b/64)*E + e)*64 + b%64), NB = Bp/64.  The E elements
+// of one (step, 64-trajectory tile) record are contiguous (E x 512 B): a wavefront reads its whole step record
+// from ONE scalar base address with compile-time immediate offsets e*512 (no per-element address VGPRs), and
+// the record sits in one or two DRAM / TLB pages instead of E pages Bp*8 bytes apart.
+constexpr int kLS = 64;   // lane stride of the wave-tiled stacks (doubles)
+
 struct DevBuf {
-  int B, Bp, N, n_slots, n_alphas, hist_batch, hist_cap, _pad;
+  int B, Bp, N, n_slots, n_alphas, hist_batch, hist_cap, NB;   // NB = Bp / 64 wave tiles
   const ProblemDev *P;
   const double *xref_traj;                 // [(N+1)][nx] shared by the batch, or null
   // iterate + line-search trial slots: [n_slots] planes

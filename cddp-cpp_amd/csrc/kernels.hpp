@@ -22,7 +22,7 @@
 
 namespace cddp_dev {
 
-#define GI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)d.Bp + (size_t)b)
+#define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
 // hipcc sinks the prefetch loads of the software pipeline down to their first use (next iteration), which
 // removes the overlap; a compiler-level memory barrier right after issuing them pins them at the loop top.
 #define PIPELINE_FENCE() asm volatile("" ::: "memory")
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(64) void k_derivs(DevBuf d, const ProblemDev *__res
   const double *Xc = d.X + (size_t)cur * d.planeX;
   const double *Uc = d.U + (size_t)cur * d.planeU;
   double x[NX], u[NU], Fx[NX * NX], Fu[NX * NU];
-  ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-  ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+  ld<NU>(Uc + GI(t, NU, 0), kLS, u);
   Model::jac(P->mp, x, u, Fx, Fu);
   const double dt = P->dt;
 #pragma unroll
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
   for (;;) {
     ++nb;
     double xN[NX], Vx[NX], Vxx[NX * NX];
-    ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+    ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
     Obj::final_grad(P, xN, Vx);
     const double *Qf = P->pool + P->off_Qf;
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) Vxx[i] = 2.0 * Qf[i];
-    st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
-    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
+    st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
     dV0 = 0; dV1 = 0;
     double norm_Vx = 0.0;
 #pragma unroll
@@ -246,11 +246,11 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
     bool fail = false;
     struct StepIn { double A[NX * NX], Bm[NX * NU], x[NX], u[NU], k0[NU]; };
     auto load_step = [&](int tt, StepIn &r) {
-      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
-      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
-      ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.x);
-      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.u);
-      ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.k0);      // BoxQP warm start x0 = k_u_[t] of the previous iteration
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.u);
+      ld<NU>(d.k + GI(tt, NU, 0), kLS, r.k0);      // BoxQP warm start x0 = k_u_[t] of the previous iteration
     };
     StepIn nxt;
     load_step(N - 1, nxt);
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
           }
         }
       }
-      st<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-      st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
       // dV (un-regularised Q_uu, clddp_solver.cpp:184-186)
       double Quuk[NU];
 #pragma unroll
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
       for (int i = 0; i < NX; ++i)
 #pragma unroll
         for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
-      st<NX>(d.Vx + GI(t, NX, 0), d.Bp, Vx);
-      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Vxx);
+      st<NX>(d.Vx + GI(t, NX, 0), kLS, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
       { double s = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) s += fabs(Vx[i]);
@@ -410,19 +410,19 @@ DEV void lin_rollout_caps(const DevBuf &d, const ProblemDev *__restrict__ P, int
   // software pipeline: gains / slack record of step t+1 in flight while step t is reduced
   struct StepIn { double kk[NU], KK[NU * NX], A[NX * NX], Bm[NX * NU], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX], s[MM], y[MM]; };
   auto load_step = [&](int tt, StepIn &r) {
-    ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.kk);
-    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), d.Bp, r.KK);
+    ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
     if (tt < N - 1 || mT > 0) {
-      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
-      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
     }
     if constexpr (M > 0) {
-      ld<M>(d.ks + GI(tt, M, 0), d.Bp, r.ksv);
-      ld<M>(d.ky + GI(tt, M, 0), d.Bp, r.ky);
-      ld<M * NX>(d.Ks + GI(tt, M * NX, 0), d.Bp, r.Ksm);
-      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), d.Bp, r.Ky);
-      ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
-      ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
+      ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
+      ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+      ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
+      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+      ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
+      ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
     }
   };
   StepIn nxt;
@@ -466,7 +466,7 @@ DEV void lin_rollout_caps(const DevBuf &d, const ProblemDev *__restrict__ P, int
   if constexpr (TERM) {
     if (mT > 0) {   // terminal-inequality directions from dX_N (ipddp_solver.cpp:1534-1561)
       double xN[NX], gT[kMTMax];
-      ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+      ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
       term_ineq_eval<NX>(P, xN, gT);
       const double fl0 = dmax(mu * 1e-3, kEpsSlack);
       for (int i = 0; i < mT; ++i) {
@@ -532,16 +532,16 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
   const int N = d.N, pT = P->pT;
   const double s_floor = dmax(mu * 1e-3, kEpsSlack);
   double xN[NX], hT[kPTMax], lam_prev[kPTMax];
-  ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+  ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
   term_eq_residual<NX>(P, xN, hT);
   for (int r = 0; r < pT; ++r) { inf_pr = dmax(inf_pr, fabs(hT[r])); lam_prev[r] = d.LamT[(size_t)r * d.Bp + b]; }
   // per-step LQ model (:1143-1245)
   auto lq_model = [&](int t, double *Q, double *q, double *R, double *r, double *Mm, double *A, double *Bm, bool track) {
     double x[NX], u[NU];
-    ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-    ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
-    ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-    ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
+    ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
+    ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
+    ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+    ld<NU>(Uc + GI(t, NU, 0), kLS, u);
     const double *Qd = P->pool + P->off_Qdt, *Rd = P->pool + P->off_Rdt;
     for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Q[i * NX + c] = 0.5 * ((2.0 * Qd[i * NX + c]) + (2.0 * Qd[c * NX + i]));
     for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * ((2.0 * Rd[i * NU + c]) + (2.0 * Rd[c * NU + i]));
@@ -550,9 +550,9 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
     for (int i = 0; i < NX * NU; ++i) Mm[i] = 0.0;
     if constexpr (M > 0) {
       double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], YS[MM], ypS[MM];
-      ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-      ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-      ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+      ld<M>(Yc + GI(t, M, 0), kLS, y);
+      ld<M>(Sc + GI(t, M, 0), kLS, s);
+      ld<M>(Gc + GI(t, M, 0), kLS, g);
       for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
       for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
       Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
@@ -588,7 +588,7 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
     }
     for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Pm[i * NX + c] = 0.5 * (VxxN[i * NX + c] + VxxN[c * NX + i]);
     for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + N) * NX + i) * d.Bp + b] = pv[i];
-    if (v == 0) st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Pm);
+    if (v == 0) st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Pm);
     for (int t = N - 1; t >= 0; --t) {
       double Q[NX * NX], q[NX], R[NU * NU], r[NU], Mm[NX * NU], A[NX * NX], Bm[NX * NU];
       lq_model(t, Q, q, R, r, Mm, A, Bm, v == 0);
@@ -646,7 +646,7 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
       for (int i = 0; i < NU * NX; ++i) fin = fin && dfinite(KK[i]);
       for (int i = 0; i < NU; ++i) fin = fin && dfinite(kk[i]);
       if (!fin) return false;
-      if (v == 0) { st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK); st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Pm); }
+      if (v == 0) { st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK); st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Pm); }
       for (int i = 0; i < NU; ++i) d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] = kk[i];
       for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + t) * NX + i) * d.Bp + b] = pv[i];
     }
@@ -655,9 +655,9 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
     for (int i = 0; i < NX; ++i) dx[i] = 0.0;
     for (int t = 0; t < N; ++t) {
       double KK[NU * NX], A[NX * NX], Bm[NX * NU], du[NU], dxn[NX];
-      ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
-      ld<NX * NX>(d.A + GI(t, NX * NX, 0), d.Bp, A);
-      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), d.Bp, Bm);
+      ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
       for (int i = 0; i < NU; ++i) { double a = 0.0; for (int j = 0; j < NX; ++j) a += KK[i * NX + j] * dx[j]; du[i] = d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] + a; }
       for (int i = 0; i < NX; ++i) { double a = 0.0, c = 0.0; for (int j = 0; j < NX; ++j) a += A[i * NX + j] * dx[j]; for (int j = 0; j < NU; ++j) c += Bm[i * NU + j] * du[j]; dxn[i] = (a + c) + 0.0; }
       for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
@@ -724,25 +724,25 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
       for (int i = 0; i < NU; ++i) ko[i] = d.te_k[(((size_t)0 * N + t) * NU + i) * d.Bp + b];
       for (int v = 0; v < pT; ++v)
         for (int i = 0; i < NU; ++i) ko[i] += best[v] * (d.te_k[(((size_t)(v + 1) * N + t) * NU + i) * d.Bp + b] - d.te_k[(((size_t)0 * N + t) * NU + i) * d.Bp + b]);
-      st<NU>(d.k + GI(t, NU, 0), d.Bp, ko);
+      st<NU>(d.k + GI(t, NU, 0), kLS, ko);
       for (int i = 0; i < NU; ++i) step_norm = dmax(step_norm, fabs(ko[i]));
     }
     double po[NX];
     for (int i = 0; i < NX; ++i) po[i] = d.te_p[(((size_t)0 * (N + 1) + t) * NX + i) * d.Bp + b];
     for (int v = 0; v < pT; ++v)
       for (int i = 0; i < NX; ++i) po[i] += best[v] * (d.te_p[(((size_t)(v + 1) * (N + 1) + t) * NX + i) * d.Bp + b] - d.te_p[(((size_t)0 * (N + 1) + t) * NX + i) * d.Bp + b]);
-    st<NX>(d.Vx + GI(t, NX, 0), d.Bp, po);
+    st<NX>(d.Vx + GI(t, NX, 0), kLS, po);
   }
   for (int t = 0; t < N; ++t) {
     double Q[NX * NX], q[NX], R[NU * NU], r[NU], Mm[NX * NU], A[NX * NX], Bm[NX * NU], pn[NX];
     lq_model(t, Q, q, R, r, Mm, A, Bm, false);
-    ld<NX>(d.Vx + GI(t + 1, NX, 0), d.Bp, pn);
+    ld<NX>(d.Vx + GI(t + 1, NX, 0), kLS, pn);
     for (int i = 0; i < NU; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * pn[k]; inf_du = dmax(inf_du, fabs(r[i] + a)); }
     if constexpr (M > 0) {   // slack / dual gains with the final k, K (:1270-1312)
       double x[NX], y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], kk[NU], KK[NU * NX];
-      ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-      ld<M>(Yc + GI(t, M, 0), d.Bp, y); ld<M>(Sc + GI(t, M, 0), d.Bp, s); ld<M>(Gc + GI(t, M, 0), d.Bp, g);
-      ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+      ld<M>(Yc + GI(t, M, 0), kLS, y); ld<M>(Sc + GI(t, M, 0), kLS, s); ld<M>(Gc + GI(t, M, 0), kLS, g);
+      ld<NU>(d.k + GI(t, NU, 0), kLS, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
       for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
       for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
       Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
@@ -761,8 +761,8 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
           Ksm[rr * NX + c] = (-Qyx[rr * NX + c]) - s2;
         }
       }
-      st<M>(d.ky + GI(t, M, 0), d.Bp, ky); st<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-      st<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky); st<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+      st<M>(d.ky + GI(t, M, 0), kLS, ky); st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+      st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky); st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ksm);
     }
   }
   return true;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
   for (;;) {
     ++nb;
     double xN[NX], Vx[NX], Vxx[NX * NX];
-    ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+    ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
     Obj::final_grad(P, xN, Vx);
     const double *Qf = P->pool + P->off_Qf;
     {  // V_xx = symmetrize(2 Qf)
@@ -851,21 +851,21 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
         continue;
       }
     }
-    st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
-    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
+    st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
     bool fail = false;
     // software pipeline: the record of step t-1 is in flight while step t is computed (the only
     // latency hiding available along the serial chain with one wave per SIMD)
     struct StepIn { double A[NX * NX], Bm[NX * NU], x[NX], u[NU], y[MM], s[MM], g[MM]; };
     auto load_step = [&](int tt, StepIn &r) {
-      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
-      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
-      ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.x);
-      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.u);
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.u);
       if constexpr (M > 0) {
-        ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
-        ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
-        ld<M>(Gc + GI(tt, M, 0), d.Bp, r.g);
+        ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
+        ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
+        ld<M>(Gc + GI(tt, M, 0), kLS, r.g);
       }
     };
     StepIn nxt;
@@ -1028,10 +1028,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
             Ksm[r * NX + c] = (-Qyx[r * NX + c]) - s2;
           }
         }
-        st<M>(d.ky + GI(t, M, 0), d.Bp, ky);
-        st<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-        st<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
-        st<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+        st<M>(d.ky + GI(t, M, 0), kLS, ky);
+        st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+        st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
+        st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ksm);
         // condensed, un-regularised Q blocks (:1488-1492)
 #pragma unroll
         for (int i = 0; i < NU; ++i) Qu[i] += QyuSir[i];
@@ -1055,8 +1055,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
 #pragma unroll
         for (int r = 0; r < M; ++r) { inf_pr = dmax(inf_pr, fabs(rp[r])); inf_comp = dmax(inf_comp, fabs(rc[r])); }
       }
-      st<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-      st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
       // dV, V_x, V_xx (:1494-1503 / :1098-1107)
       double Quuk[NU];
 #pragma unroll
@@ -1091,8 +1091,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
       for (int i = 0; i < NX; ++i)
 #pragma unroll
         for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
-      st<NX>(d.Vx + GI(t, NX, 0), d.Bp, Vx);
-      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Vxx);
+      st<NX>(d.Vx + GI(t, NX, 0), kLS, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
 #pragma unroll
       for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
     }
@@ -1135,16 +1135,12 @@ template <class Model>
 __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
-  int b, a;
-  if (na > 0) {   // alpha-adjacent lanes (measured slower at C2: 11-way scattered trial stores; kept for experiments)
-    const int tpw = 64 / na;
-    if ((int)threadIdx.x >= tpw * na) return;
-    b = blockIdx.x * tpw + (int)threadIdx.x / na;
-    a = a0 + (int)threadIdx.x % na;
-  } else {        // alpha on blockIdx.y: one wavefront = 64 trajectories of one alpha, fully coalesced stores
-    b = blockIdx.x * 64 + threadIdx.x;
-    a = a0 + blockIdx.y;
-  }
+  // alpha on blockIdx.y: one wavefront = the 64 trajectories of one wave tile at ONE alpha (coalesced 512-B
+  // rows, uniform tile base address).  The alternative -- the trials of one trajectory in adjacent lanes -- was
+  // measured 1.37x slower at C2 (11-way scattered trial stores, no whole-wave early exit); see DESIGN.md.
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = a0 + blockIdx.y;
+  (void)na;
   if (b >= d.B) return;
   if (!force && d.phase[b] != phase_req) return;
   const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
@@ -1160,15 +1156,15 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   const int box = P->clddp_box;
   atomicAdd(d.launched, 1ull);
   double x[NX];
-  ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);     // X_[0] == initial state
-  st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
+  ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // X_[0] == initial state
+  st<NX>(Xn + GI(0, NX, 0), kLS, x);
   double J = 0.0;
   for (int t = 0; t < N; ++t) {
     double xo[NX], uo[NU], kk[NU], KK[NU * NX], u[NU], dx[NX];
-    ld<NX>(Xc + GI(t, NX, 0), d.Bp, xo);
-    ld<NU>(Uc + GI(t, NU, 0), d.Bp, uo);
-    ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-    ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+    ld<NX>(Xc + GI(t, NX, 0), kLS, xo);
+    ld<NU>(Uc + GI(t, NU, 0), kLS, uo);
+    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
 #pragma unroll
@@ -1182,8 +1178,8 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
     J += Obj::running_cost(P, xrt, t, x, u);
     double xn[NX];
     Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
-    st<NU>(Un + GI(t, NU, 0), d.Bp, u);
-    st<NX>(Xn + GI(t + 1, NX, 0), d.Bp, xn);
+    st<NU>(Un + GI(t, NU, 0), kLS, u);
+    st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xn[i];
   }
@@ -1240,21 +1236,12 @@ template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
-  // Lane mapping.  Default (na == 0): alpha on blockIdx.y, a wavefront = 64 consecutive trajectories of ONE
-  // alpha; the 11 alpha-wavefronts of a trajectory block have block ids congruent mod 8 (64 blocks per alpha
-  // row), i.e. they land on the same XCD and share its L2 for the re-read gains.  Alternative (na > 0):
-  // the trials of one trajectory in adjacent lanes -- fewer read transactions but 11-way scattered stores and
-  // no whole-wave early exit; measured 1.37x slower at C2 (72 vs 53 ms per solve), see DESIGN.md.
-  int b, a;
-  if (na > 0) {   // alpha-adjacent lanes (measured slower at C2: 11-way scattered trial stores; kept for experiments)
-    const int tpw = 64 / na;
-    if ((int)threadIdx.x >= tpw * na) return;
-    b = blockIdx.x * tpw + (int)threadIdx.x / na;
-    a = a0 + (int)threadIdx.x % na;
-  } else {        // alpha on blockIdx.y: one wavefront = 64 trajectories of one alpha, fully coalesced stores
-    b = blockIdx.x * 64 + threadIdx.x;
-    a = a0 + blockIdx.y;
-  }
+  // alpha on blockIdx.y: one wavefront = the 64 trajectories of one wave tile at ONE alpha (coalesced 512-B
+  // rows, uniform tile base address).  The alternative -- the trials of one trajectory in adjacent lanes -- was
+  // measured 1.37x slower at C2 (11-way scattered trial stores, no whole-wave early exit); see DESIGN.md.
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = a0 + blockIdx.y;
+  (void)na;
   if (b >= d.B) return;
   if (!force && d.phase[b] != phase_req) return;
   const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
@@ -1287,32 +1274,35 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
   d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
   double x[NX];
-  ld<NX>(Xc + GI(0, NX, 0), d.Bp, x);
-  st<NX>(Xn + GI(0, NX, 0), d.Bp, x);
+  ld<NX>(Xc + GI(0, NX, 0), kLS, x);
+  st<NX>(Xn + GI(0, NX, 0), kLS, x);
   double cost_new = 0.0;
   double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // software pipeline: record of step t+1 (old iterate, gains, value expansion) in flight during step t
   struct StepIn {
-    double xo[NX], lam[NX], vx[NX], vxx[NX * NX], uo[NU], kk[NU], KK[NU * NX];
+    double xo[NX], lam[TERM ? NX : 1], vx[TERM ? NX : 1], vxx[TERM ? NX * NX : 1], uo[NU], kk[NU], KK[NU * NX];
     double s[MM], y[MM], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX];
   };
   auto load_step = [&](int tt, StepIn &r) {
-    ld<NX>(Xc + GI(tt, NX, 0), d.Bp, r.xo);
-    ld<NX>(Lc + GI(tt, NX, 0), d.Bp, r.lam);
-    ld<NX>(d.Vx + GI(tt, NX, 0), d.Bp, r.vx);
-    ld<NX * NX>(d.Vxx + GI(tt, NX * NX, 0), d.Bp, r.vxx);
+    ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+    if constexpr (TERM) {   // costate trial in the rollout (read back by the terminal-equality sweep);
+                            // without terminal constraints it is off the chain: k_costate (kernels_lean.hpp)
+      ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lam);
+      ld<NX>(d.Vx + GI(tt, NX, 0), kLS, r.vx);
+      ld<NX * NX>(d.Vxx + GI(tt, NX * NX, 0), kLS, r.vxx);
+    }
     if (tt < N) {
-      ld<NU>(Uc + GI(tt, NU, 0), d.Bp, r.uo);
-      ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.kk);
-      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), d.Bp, r.KK);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+      ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
       if constexpr (M > 0) {
-        ld<M>(Sc + GI(tt, M, 0), d.Bp, r.s);
-        ld<M>(Yc + GI(tt, M, 0), d.Bp, r.y);
-        ld<M>(d.ks + GI(tt, M, 0), d.Bp, r.ksv);
-        ld<M>(d.ky + GI(tt, M, 0), d.Bp, r.ky);
-        ld<M * NX>(d.Ks + GI(tt, M * NX, 0), d.Bp, r.Ksm);
-        ld<M * NX>(d.Ky + GI(tt, M * NX, 0), d.Bp, r.Ky);
+        ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
+        ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
+        ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
+        ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+        ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
+        ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
       }
     }
   };
@@ -1322,20 +1312,23 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
     StepIn cs = nxt;
     if (t < N) load_step(t + 1, nxt);
     PIPELINE_FENCE();
-    double dx[NX], lam[NX];
+    double dx[NX];
     bool finite = true;
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = x[i] - cs.xo[i];
+    if constexpr (TERM) {
+      double lam[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double s = 0.0;
+      for (int i = 0; i < NX; ++i) {
+        double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s += cs.vxx[i * NX + j] * dx[j];
-      lam[i] = (cs.lam[i] + a_pr * cs.vx[i]) + s;
-      finite = finite && dfinite(lam[i]);
+        for (int j = 0; j < NX; ++j) s += cs.vxx[i * NX + j] * dx[j];
+        lam[i] = (cs.lam[i] + a_pr * cs.vx[i]) + s;
+        finite = finite && dfinite(lam[i]);
+      }
+      if (!finite) return;
+      st<NX>(Ln + GI(t, NX, 0), kLS, lam);
     }
-    if (!finite) return;
-    st<NX>(Ln + GI(t, NX, 0), d.Bp, lam);
     if constexpr (TERM) {
       if (t == N) {   // terminal slack / dual / multiplier trial (ipddp_solver.cpp:1667-1723)
         TermState to;
@@ -1377,8 +1370,8 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
         if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
       }
       if (!feas) return;
-      st<M>(Sn + GI(t, M, 0), d.Bp, sn);
-      st<M>(Yn + GI(t, M, 0), d.Bp, yn);
+      st<M>(Sn + GI(t, M, 0), kLS, sn);
+      st<M>(Yn + GI(t, M, 0), kLS, yn);
     }
     double u[NU], xn[NX];
 #pragma unroll
@@ -1397,14 +1390,14 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
     if constexpr (M > 0) {
       double g[MM];
       Cons::template eval<NX, NU>(P, x, u, g);
-      st<M>(Gn + GI(t, M, 0), d.Bp, g);
+      st<M>(Gn + GI(t, M, 0), kLS, g);
       if constexpr (!TERM) {
         // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity
         // (ipddp_solver.cpp:2778-2937).  The reference sums constraint-major, then t: the first constraint
         // object's |g+s| terms can therefore be accumulated right here in t order; the other objects' terms
         // and every log-barrier term (whose chain starts from the still unknown cost_new) are parked in the
         // ev scratch and added after the rollout in the reference's order -- no second pass over S/Y/G.
-        double *ev = d.ev + (((size_t)a * N + t) * (2 * Cons::NSEG)) * d.Bp + b;
+        double *ev = d.ev + GI((size_t)a * N + t, 2 * Cons::NSEG, 0);
 #pragma unroll
         for (int c = 0; c < Cons::NSEG; ++c) {
           const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
@@ -1417,13 +1410,13 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
             ls += log(dmax(sn[off + i], kEpsSlack));
           }
           ev_max = dmax(ev_max, ninf);
-          if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * d.Bp] = n1;
-          ev[(size_t)c * d.Bp] = ls;
+          if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;
+          ev[(size_t)c * kLS] = ls;
         }
       }
     }
-    st<NU>(Un + GI(t, NU, 0), d.Bp, u);
-    st<NX>(Xn + GI(t + 1, NX, 0), d.Bp, xn);
+    st<NU>(Un + GI(t, NU, 0), kLS, u);
+    st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xn[i];
   }
@@ -1442,10 +1435,10 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   } else if constexpr (M > 0) {
     // add the parked terms in the reference's order (loads are independent of the running sums)
     double total = ev_total0, mer = cost_new;
-    const double *evb = d.ev + ((size_t)a * N * (2 * Cons::NSEG)) * d.Bp + b;
-    const size_t tstride = (size_t)(2 * Cons::NSEG) * d.Bp;
+    const double *evb = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
+    const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
     for (int c = 1; c < Cons::NSEG; ++c) {
-      const double *q = evb + (size_t)(Cons::NSEG + c) * d.Bp;
+      const double *q = evb + (size_t)(Cons::NSEG + c) * kLS;
       int t = 0;
       for (; t + 3 < N; t += 4) {
         const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
@@ -1454,7 +1447,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
       for (; t < N; ++t) total += q[(size_t)t * tstride];
     }
     for (int c = 0; c < Cons::NSEG; ++c) {
-      const double *q = evb + (size_t)c * d.Bp;
+      const double *q = evb + (size_t)c * kLS;
       int t = 0;
       for (; t + 3 < N; t += 4) {
         const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
@@ -1543,8 +1536,8 @@ DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
   double ss = 0.0;
   for (int t = 0; t < d.N; ++t) {
     double x[NX], y[MM], Gx[MM * NX], Gu[MM * NU];
-    ld<NX>(Xs + GI(t, NX, 0), d.Bp, x);
-    ld<M>(Yc + GI(t, M, 0), d.Bp, y);
+    ld<NX>(Xs + GI(t, NX, 0), kLS, x);
+    ld<M>(Yc + GI(t, M, 0), kLS, y);
     for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
     for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
     Cons::template jac<NX, NU>(P, x, Gx, Gu);
@@ -1655,7 +1648,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
               TermState ts;
               term_load(d, b, mT, pT, ts);
               double xN[NXu];
-              ld<NXu>(d.X + (size_t)cs * d.planeX + GI(d.N, NXu, 0), d.Bp, xN);
+              ld<NXu>(d.X + (size_t)cs * d.planeX + GI(d.N, NXu, 0), kLS, xN);
               term_eq_residual<NXu>(P, xN, ts.h);
               ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
                                   d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp, &ts, mT, pT);
@@ -1760,21 +1753,21 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
   d.dV0[b] = 0.0; d.dV1[b] = 0.0; d.step_norm[b] = 0.0;
   d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
   double x[NX];
-  ld<NX>(X0 + GI(0, NX, 0), d.Bp, x);
+  ld<NX>(X0 + GI(0, NX, 0), kLS, x);
   double cost = 0.0;
   if (!ipddp) {
     for (int t = 0; t < N; ++t) {
       double xt[NX], u[NU];
-      ld<NX>(X0 + GI(t, NX, 0), d.Bp, xt);
-      ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
+      ld<NX>(X0 + GI(t, NX, 0), kLS, xt);
+      ld<NU>(U0 + GI(t, NU, 0), kLS, u);
       cost += Obj::running_cost(P, xrt, t, xt, u);
       double z[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) z[i] = 0.0;
-      st<NU>(d.k + GI(t, NU, 0), d.Bp, z);     // initializeGains: k_u_ = 0 (BoxQP warm start)
+      st<NU>(d.k + GI(t, NU, 0), kLS, z);     // initializeGains: k_u_ = 0 (BoxQP warm start)
     }
     double xN[NX];
-    ld<NX>(X0 + GI(N, NX, 0), d.Bp, xN);
+    ld<NX>(X0 + GI(N, NX, 0), kLS, xN);
     cost += Obj::terminal_cost(P, xN);
     d.cost[b] = cost; d.merit[b] = cost;
     d.inf_pr[b] = INFINITY; d.inf_du[b] = INFINITY; d.inf_comp[b] = INFINITY;   // cddp_core.cpp:297-301
@@ -1791,7 +1784,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
   double *S0 = d.S, *Y0 = d.Y, *G0 = d.G, *L0 = d.Lam;
   for (int t = 0; t < N; ++t) {
     double u[NU], xn[NX];
-    ld<NU>(U0 + GI(t, NU, 0), d.Bp, u);
+    ld<NU>(U0 + GI(t, NU, 0), kLS, u);
     cost += Obj::running_cost(P, xrt, t, x, u);
     if constexpr (M > 0) {
       double g[MM], s[MM], y[MM];
@@ -1811,16 +1804,16 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
           if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) y[off + i] *= o.ipddp_warmstart_interior_factor;
         }
       }
-      st<M>(G0 + GI(t, M, 0), d.Bp, g);
-      st<M>(S0 + GI(t, M, 0), d.Bp, s);
-      st<M>(Y0 + GI(t, M, 0), d.Bp, y);
+      st<M>(G0 + GI(t, M, 0), kLS, g);
+      st<M>(S0 + GI(t, M, 0), kLS, s);
+      st<M>(Y0 + GI(t, M, 0), kLS, y);
     }
     double z[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) z[i] = 0.0;
-    st<NX>(L0 + GI(t, NX, 0), d.Bp, z);
+    st<NX>(L0 + GI(t, NX, 0), kLS, z);
     Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
-    st<NX>(X0 + GI(t + 1, NX, 0), d.Bp, xn);
+    st<NX>(X0 + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xn[i];
   }
@@ -1828,7 +1821,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
     double z[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) z[i] = 0.0;
-    st<NX>(L0 + GI(N, NX, 0), d.Bp, z);
+    st<NX>(L0 + GI(N, NX, 0), kLS, z);
   }
   cost += Obj::terminal_cost(P, x);
   d.cost[b] = cost;

@@ -19,7 +19,7 @@
 
 namespace cddp_dev {
 
-#define GI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)d.Bp + (size_t)b)
+#define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
 
 template <class Model, class Cons>
 struct CstLayout {
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
   const double mu = d.mu[b];
   const double s_floor = dmax(mu * 1e-3, kEpsSlack);
   double x[NX], u[NU], y[M], s[M], g[M], Qyx[M * NX], Qyu[M * NU];
-  ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-  ld<NU>(Uc + GI(t, NU, 0), d.Bp, u);
-  ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-  ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-  ld<M>(Gc + GI(t, M, 0), d.Bp, g);
+  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+  ld<NU>(Uc + GI(t, NU, 0), kLS, u);
+  ld<M>(Yc + GI(t, M, 0), kLS, y);
+  ld<M>(Sc + GI(t, M, 0), kLS, s);
+  ld<M>(Gc + GI(t, M, 0), kLS, g);
 #pragma unroll
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
     for (int r = 0; r < M; ++r) s1 += Qyu[r * NU + i] * Sir[r];
     QyuSir[i] = s1; }
   double *o = d.cst + GI(t, L::SIZE, 0);
-  st<NX>(o + (size_t)L::CX * d.Bp, d.Bp, cx);
-  st<NU>(o + (size_t)L::CU * d.Bp, d.Bp, cu);
-  st<NU * NU>(o + (size_t)L::WQYU * d.Bp, d.Bp, WQyu);
-  st<NU>(o + (size_t)L::QYUSIR * d.Bp, d.Bp, QyuSir);
-  o[(size_t)L::IPR * d.Bp] = ipr;
-  o[(size_t)L::ICOMP * d.Bp] = icomp;
+  st<NX>(o + (size_t)L::CX * kLS, kLS, cx);
+  st<NU>(o + (size_t)L::CU * kLS, kLS, cu);
+  st<NU * NU>(o + (size_t)L::WQYU * kLS, kLS, WQyu);
+  st<NU>(o + (size_t)L::QYUSIR * kLS, kLS, QyuSir);
+  o[(size_t)L::IPR * kLS] = ipr;
+  o[(size_t)L::ICOMP * kLS] = icomp;
   if constexpr (Cons::HAS_X) {
     double WQyx[NU * NX], QyxSir[NX], Wx[NX * M], WxQyx[NX * NX];
     mm_nn<NU, M, NX>(W, Qyx, WQyx);
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
 #pragma unroll
       for (int r = 0; r < M; ++r) Wx[i * M + r] = Qyx[r * NX + i] * YS[r];
     mm_nn<NX, M, NX>(Wx, Qyx, WxQyx);
-    st<NU * NX>(o + (size_t)L::WQYX * d.Bp, d.Bp, WQyx);
-    st<NX>(o + (size_t)L::QYXSIR * d.Bp, d.Bp, QyxSir);
-    st<NX * NX>(o + (size_t)L::WXQYX * d.Bp, d.Bp, WxQyx);
+    st<NU * NX>(o + (size_t)L::WQYX * kLS, kLS, WQyx);
+    st<NX>(o + (size_t)L::QYXSIR * kLS, kLS, QyxSir);
+    st<NX * NX>(o + (size_t)L::WXQYX * kLS, kLS, WxQyx);
   }
 }
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
   for (;;) {
     ++nb;
     double xN[NX], Vx[NX], Vxx[NX * NX];
-    ld<NX>(Xc + GI(N, NX, 0), d.Bp, xN);
+    ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
     Obj::final_grad(P, xN, Vx);
     const double *Qf = P->pool + P->off_Qf;
     {
@@ -158,14 +158,14 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
         for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (H2[i * NX + c] + H2[c * NX + i]);
     }
     dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
-    st<NX>(d.Vx + GI(N, NX, 0), d.Bp, Vx);
-    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), d.Bp, Vxx);
+    st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
     bool fail = false;
     struct StepIn { double A[NX * NX], Bm[NX * NU], c[CST]; };
     auto load_step = [&](int tt, StepIn &r) {
-      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
-      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
-      ld<CST>(d.cst + GI(tt, CST, 0), d.Bp, r.c);
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<CST>(d.cst + GI(tt, CST, 0), kLS, r.c);
     };
     StepIn nxt;
     load_step(N - 1, nxt);
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
           for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
         }
       }
-      st<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-      st<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
       // condensed, un-regularised Q blocks (ipddp_solver.cpp:1488-1492)
 #pragma unroll
       for (int i = 0; i < NU; ++i) Qu[i] += QyuSir[i];
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
       for (int i = 0; i < NX; ++i)
 #pragma unroll
         for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
-      st<NX>(d.Vx + GI(t, NX, 0), d.Bp, Vx);
-      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), d.Bp, Vxx);
+      st<NX>(d.Vx + GI(t, NX, 0), kLS, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
 #pragma unroll
       for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
     }
@@ -303,10 +303,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
       for (int i = 0; i < NX; ++i) dx[i] = 0.0;
       struct RIn { double kk[NU], KK[NU * NX], A[NX * NX], Bm[NX * NU]; };
       auto load_r = [&](int tt, RIn &r) {
-        ld<NU>(d.k + GI(tt, NU, 0), d.Bp, r.kk);
-        ld<NU * NX>(d.K + GI(tt, NU * NX, 0), d.Bp, r.KK);
-        ld<NX * NX>(d.A + GI(tt, NX * NX, 0), d.Bp, r.A);
-        ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), d.Bp, r.Bm);
+        ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+        ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+        ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+        ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
       };
       RIn rn;
       load_r(0, rn);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
         RIn rc = rn;
         if (t + 1 < N - 1) load_r(t + 1, rn);
         PIPELINE_FENCE();
-        st<NX>(d.dX + GI(t, NX, 0), d.Bp, dx);
+        st<NX>(d.dX + GI(t, NX, 0), kLS, dx);
         if (t < N - 1) {
           double du[NU], dxn[NX];
 #pragma unroll
@@ -368,13 +368,13 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
   const double s_floor = dmax(mu * 1e-3, kEpsSlack);
   const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
   double x[NX], y[M], s[M], g[M], Qyx[M * NX], Qyu[M * NU], kk[NU], KK[NU * NX], dx[NX];
-  ld<NX>(Xc + GI(t, NX, 0), d.Bp, x);
-  ld<M>(Yc + GI(t, M, 0), d.Bp, y);
-  ld<M>(Sc + GI(t, M, 0), d.Bp, s);
-  ld<M>(Gc + GI(t, M, 0), d.Bp, g);
-  ld<NU>(d.k + GI(t, NU, 0), d.Bp, kk);
-  ld<NU * NX>(d.K + GI(t, NU * NX, 0), d.Bp, KK);
-  ld<NX>(d.dX + GI(t, NX, 0), d.Bp, dx);
+  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+  ld<M>(Yc + GI(t, M, 0), kLS, y);
+  ld<M>(Sc + GI(t, M, 0), kLS, s);
+  ld<M>(Gc + GI(t, M, 0), kLS, g);
+  ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
+  ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+  ld<NX>(d.dX + GI(t, NX, 0), kLS, dx);
 #pragma unroll
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
@@ -411,12 +411,54 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
     if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
     if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
   }
-  st<M>(d.ky + GI(t, M, 0), d.Bp, ky);
-  st<M>(d.ks + GI(t, M, 0), d.Bp, ksv);
-  st<M * NX>(d.Ky + GI(t, M * NX, 0), d.Bp, Ky);
-  st<M * NX>(d.Ks + GI(t, M * NX, 0), d.Bp, Ksm);
+  st<M>(d.ky + GI(t, M, 0), kLS, ky);
+  st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+  st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
+  st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ksm);
   if (apr < 1.0) atomic_min_pos(d.apr_max + b, apr);
   if (adu < 1.0) atomic_min_pos(d.adu_max + b, adu);
+}
+
+// ================================================================================ K4b
+// Costate trial Lambda_new[t] = Lambda[t] + alpha_pr V_x[t] + V_xx[t] (x_new[t] - x[t]) (ipddp_solver.cpp:1613-1616,
+// 1660-1663) for problems without terminal constraints, where nothing reads it back during the solve: it is taken
+// off the serial rollout chain (24 of K4's 58 loads per step at nx = 4) and evaluated at (batch x N+1) width for the
+// trials that passed every other test.  A trial whose costate is not finite is failed here exactly as the reference
+// fails it inside forwardPass, before k_update applies the acceptance rule; under the first-success rule only the
+// first surviving trial is evaluated.
+template <class Model>
+__global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int phase_req, int force, int first_only) {
+  constexpr int NX = Model::NX;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  const int cur = d.cur[b];
+  double xo[NX], lo[NX], vx[NX], vxx[NX * NX];
+  ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+  ld<NX>(d.Lam + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, lo);
+  ld<NX>(d.Vx + GI(t, NX, 0), kLS, vx);
+  ld<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, vxx);
+  for (int a = a0; a < a0 + na; ++a) {
+    const size_t ti = (size_t)a * d.Bp + b;
+    if (!d.t_success[ti]) continue;
+    const int slot = trial_slot(cur, a);
+    const double a_pr = d.t_apr[ti];
+    double xn[NX], lam[NX];
+    ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xn);
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += vxx[i * NX + j] * (xn[j] - xo[j]);
+      lam[i] = (lo[i] + a_pr * vx[i]) + s;
+      finite = finite && dfinite(lam[i]);
+    }
+    if (!finite) { d.t_success[ti] = 0; continue; }
+    st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
+    if (first_only) break;
+  }
 }
 
 #undef GI

@@ -12,7 +12,7 @@ struct KernelSet {
   bool (*matches)(const ProblemDev &);
   void (*derivs)(const DevBuf &, int force, hipStream_t);
   void (*backward)(const DevBuf &, int solver, int force, int count_iter, hipStream_t);
-  void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, hipStream_t);
+  void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t);
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, hipStream_t);
 };
@@ -41,13 +41,17 @@ struct Launcher {
     } else
       hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
   }
-  static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, hipStream_t s) {
+  static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
     if (na <= 0) return;
     const dim3 grid((d.B + 63) / 64, na);
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
+    {
       hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      if constexpr (!TERM)
+        hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
+    }
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
