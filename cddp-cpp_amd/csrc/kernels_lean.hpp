@@ -461,5 +461,267 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
   }
 }
 
+// ================================================================================ K4 (two-role)
+// Line-searched IPDDP rollout for path-constrained problems without terminal constraints, as a PRODUCER /
+// CONSUMER pair of wavefronts per (64-trajectory tile, alpha).  Only x_{t+1} = f(x_t, u_t(x_t)) is a true serial
+// chain, and one wave per SIMD leaves every dependent f64 operation's latency exposed, so the work is split:
+//   wave 0 (producer)  u_t = u + a k + K dx, x_{t+1} = f(x_t, u_t), running / terminal cost, stores X, U of the trial
+//                      (ipddp_solver.cpp:1618-1627, 1726-1748);
+//   wave 1 (consumer)  a few steps behind: slack / dual trial + fraction-to-boundary test (:1629-1658), g(x_t, u_t)
+//                      (:1735-1745), the theta / barrier-merit / residual terms (:2778-2937), the filter test
+//                      (:1785-1834) and the trial record.
+// Hand-off: the producer's X/U trial stores ARE the channel.  VMEM operations of a wave retire in issue order on
+// gfx9-family parts (vmcnt counts loads and stores together), so once the prefetched record of step t has
+// arrived every store issued before that prefetch -- steps <= t-2 -- has reached L2.  The producer publishes that
+// step count through one LDS word; the consumer polls it and reads the trial rows with agent-scope loads.  A lane
+// whose rollout went non-finite is published through s_pstat before the counter moves.
+// Every lane runs straight-line code with UNCONDITIONAL stores (a dead lane keeps re-evaluating its frozen state;
+// rows of a failed trial are never read): with stores inside divergent branches the waitcnt pass cannot count the
+// operations behind the prefetch and falls back to vmcnt(0), i.e. it waits for a store acknowledge every step.
+template <class Model, class Cons>
+__global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                          int a0, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
+  typedef Objective<NX, NU> Obj;
+  static_assert(M > 0, "two-role rollout is for path-constrained problems");
+  __shared__ int s_prod;          // number of steps t whose (x_t, u_t) trial rows are visible in L2
+  __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
+  __shared__ double s_pcost[64];  // the producer lane's total trial cost
+  const int lane = threadIdx.x & 63;
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  const int b = blockIdx.x * 64 + lane;
+  const int a = a0 + blockIdx.y;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
+  if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in both waves: both leave
+  if (producer) { s_pstat[lane] = N + 2; if (lane == 0) s_prod = 0; }
+  __syncthreads();
+  // Inactive lanes (padding, or a trajectory in another phase) run along on their OWN rows: their trial slots are
+  // scratch (trial_slot never returns the current slot), so unconditional stores need no exec-mask branches.
+  const int bb = (b < d.B) ? b : 0;
+  const int cur = (b < d.B) ? d.cur[b] : 0;
+  const int slot = trial_slot(cur, a);
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  double *Xn = d.X + (size_t)slot * d.planeX;
+  double *Un = d.U + (size_t)slot * d.planeU;
+  const double alpha = P->alphas[a];
+  const double a_pr = dmin(alpha, d.apr_max[bb]);
+
+  if (producer) {
+    // ------------------------------------------------------------------ producer: the dynamics chain
+    const double *Uc = d.U + (size_t)cur * d.planeU;
+    bool alive = active;
+    double x[NX];
+    ld<NX>(Xc + GI(0, NX, 0), kLS, x);
+    st<NX>(Xn + GI(0, NX, 0), kLS, x);
+    double cost_new = 0.0;
+    struct StepIn { double xo[NX], uo[NU], kk[NU], KK[NU * NX]; };
+    constexpr int NPRE = NX + NU + NU + NU * NX, NST = NX + NU;
+    auto load_step = [&](int tt, StepIn &r) {
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+      ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+    };
+    StepIn nxt;
+    load_step(0, nxt);
+    // Prime the VMEM queue with the store pattern of one step (rows of step 0, rewritten by iteration 0): the
+    // waitcnt pass joins the loop-entry state with the back-edge state, and an entry state whose newest
+    // operations are the loads would make every iteration wait for vmcnt(0), i.e. for its own last stores.
+    {
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      st<NU>(Un + GI(0, NU, 0), kLS, z);
+      st<NX>(Xn + GI(1, NX, 0), kLS, z);
+    }
+    for (int t = 0; t < N; ++t) {
+      StepIn cs = nxt;
+      if (t + 1 < N) load_step(t + 1, nxt);
+      // record of step t has landed => every older VMEM op (the stores of steps <= t-2) is complete
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE + NST < 63 ? NPRE + NST : 63) : "memory");   // 6-bit field
+      if (t >= 2) __hip_atomic_store(&s_prod, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      PIPELINE_FENCE();
+      double dx[NX], u[NU], xn[NX];
+      bool finite = true;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = x[i] - cs.xo[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s1 += cs.KK[i * NX + j] * dx[j];
+        u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
+        finite = finite && dfinite(u[i]);
+      }
+      Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
+      const double lc = Obj::running_cost(P, xrt, t, x, u);
+      if (alive && !finite) { s_pstat[lane] = t; alive = false; }
+      st<NU>(Un + GI(t, NU, 0), kLS, u);
+      st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
+      if (alive) {
+        cost_new += lc;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+      }
+      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;   // nothing downstream reads the rows any more
+    }
+    if (alive) { cost_new += Obj::terminal_cost(P, x); s_pcost[lane] = cost_new; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(&s_prod, N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer: everything off the chain
+  const double *Sc = d.S + (size_t)cur * d.planeM;
+  const double *Yc = d.Y + (size_t)cur * d.planeM;
+  double *Sn = d.S + (size_t)slot * d.planeM;
+  double *Yn = d.Y + (size_t)slot * d.planeM;
+  double *Gn = d.G + (size_t)slot * d.planeM;
+  const double mu = d.mu[bb];
+  const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const double a_du = dmin(alpha, d.adu_max[bb]);
+  const size_t ti = (size_t)a * d.Bp + bb;
+  bool alive = active;
+  if (alive) {
+    atomicAdd(d.launched, 1ull);
+    d.t_apr[ti] = a_pr; d.t_adu[ti] = a_du;
+    d.t_success[ti] = 0;
+    d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
+    d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
+  }
+  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
+  const bool l2norm = o.ipddp_theta_norm_l2 != 0;
+  struct StepIn { double x[NX], u[NU], xo[NX], s[M], y[M], ksv[M], ky[M], Ksm[M * NX], Ky[M * NX]; };
+  auto wait_prod = [&](int need) {
+    while (__hip_atomic_load(&s_prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  auto load_step = [&](int tt, StepIn &r) {
+    // trial rows written by the producer wave during this launch: agent-scope loads (no stale L1 line)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r.x[i] = __hip_atomic_load(Xn + GI(tt, NX, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) r.u[i] = __hip_atomic_load(Un + GI(tt, NU, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+    ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
+    ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
+    ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
+    ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+    ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
+    ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+  };
+  StepIn nxt;
+  wait_prod(1);
+  load_step(0, nxt);
+  {   // prime the VMEM queue with one step's store pattern (see the producer)
+    double z[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) z[i] = 0.0;
+    st<M>(Sn + GI(0, M, 0), kLS, z);
+    st<M>(Yn + GI(0, M, 0), kLS, z);
+    st<M>(Gn + GI(0, M, 0), kLS, z);
+    double *ev = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
+#pragma unroll
+    for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
+  }
+  for (int t = 0; t < N; ++t) {
+    // every trial of the tile has failed (checked before this step's VMEM traffic so that every path to the
+    // loop latch carries the same load / store pattern -- see the priming note)
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    StepIn cs = nxt;
+    if (t + 1 < N) { wait_prod(t + 2); load_step(t + 1, nxt); }
+    PIPELINE_FENCE();
+    if (alive && s_pstat[lane] <= t) alive = false;
+    double dx[NX], sn[M], yn[M];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = cs.x[i] - cs.xo[i];
+    bool feas = true;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], cs.Ksm + r * NX, dx);
+      yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], cs.Ky + r * NX, dx);
+      if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
+      if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
+    }
+    if (!feas) alive = false;
+    st<M>(Sn + GI(t, M, 0), kLS, sn);
+    st<M>(Yn + GI(t, M, 0), kLS, yn);
+    double g[M];
+    Cons::template eval<NX, NU>(P, cs.x, cs.u, g);
+    st<M>(Gn + GI(t, M, 0), kLS, g);
+    // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity, parked exactly as
+    // in k_forward_ipddp: the first constraint object's |g+s| terms accumulate in t order right here, the other
+    // objects' terms and every log-barrier term are added after the rollout in the reference's order.
+    double *ev = d.ev + GI((size_t)a * N + t, 2 * Cons::NSEG, 0);
+#pragma unroll
+    for (int c = 0; c < Cons::NSEG; ++c) {
+      const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      double n1 = 0.0, ninf = 0.0, ls = 0.0;
+      for (int i = 0; i < dim; ++i) {
+        const double r = g[off + i] + sn[off + i];
+        n1 += l2norm ? r * r : fabs(r);
+        ninf = dmax(ninf, fabs(r));
+        ev_icomp = dmax(ev_icomp, fabs(yn[off + i] * sn[off + i] - mu));
+        ls += log(dmax(sn[off + i], kEpsSlack));
+      }
+      ev_max = dmax(ev_max, ninf);
+      if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;
+      ev[(size_t)c * kLS] = ls;
+    }
+  }
+  wait_prod(N + 1);
+  if (alive && s_pstat[lane] <= N) alive = false;
+  if (!alive) return;
+  const double cost_new = s_pcost[lane];
+  double total = ev_total0, mer = cost_new;
+  const double *evb = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
+  const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
+  for (int c = 1; c < Cons::NSEG; ++c) {
+    const double *q = evb + (size_t)(Cons::NSEG + c) * kLS;
+    int t = 0;
+    for (; t + 3 < N; t += 4) {
+      const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+      total += v0; total += v1; total += v2; total += v3;
+    }
+    for (; t < N; ++t) total += q[(size_t)t * tstride];
+  }
+  for (int c = 0; c < Cons::NSEG; ++c) {
+    const double *q = evb + (size_t)c * kLS;
+    int t = 0;
+    for (; t + 3 < N; t += 4) {
+      const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+      mer -= mu * v0; mer -= mu * v1; mer -= mu * v2; mer -= mu * v3;
+    }
+    for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
+  }
+  const double th = l2norm ? sqrt(total) : total;
+  const double theta_new = dmax(th, ev_max), phi_new = mer, ipr = ev_max, icomp = ev_icomp;
+  if (!dfinite(phi_new) || !dfinite(theta_new) || !dfinite(ipr) || !dfinite(icomp)) return;
+  bool accept = false;
+  {   // filter acceptance, ipddp_solver.cpp:1793-1834
+    const double expected_improvement = a_pr * d.dV0[b];
+    const int fn = d.filt_n[b];
+    const double cv_old = (fn == 0) ? 0.0 : d.filt[(size_t)(kFilterCap + fn - 1) * d.Bp + b];
+    const double high_ref = (fn == 0) ? d.filter_theta[b] : cv_old;
+    const double merit_old = d.merit[b];
+    if (theta_new > o.filter_max_violation_threshold) {
+      if (theta_new < (1 - o.filter_violation_acceptance_threshold) * high_ref) accept = true;
+    } else if (dmax(theta_new, cv_old) < o.filter_min_violation_for_armijo_check && expected_improvement < 0) {
+      if (phi_new < merit_old + o.filter_armijo_constant * expected_improvement) accept = true;
+    } else {
+      if (phi_new < merit_old - o.filter_merit_acceptance_threshold * theta_new ||
+          theta_new < (1 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    }
+  }
+  d.t_cost[ti] = cost_new; d.t_merit[ti] = phi_new; d.t_theta[ti] = theta_new;
+  d.t_inf_pr[ti] = ipr; d.t_inf_comp[ti] = icomp;
+  d.t_success[ti] = accept ? 1 : 0;
+}
+
 #undef GI
 }  // namespace cddp_dev

@@ -48,7 +48,10 @@ struct Launcher {
       hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
     {
-      hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      if constexpr (kLean)   // producer / consumer wave pair per (tile, alpha)
+        hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
+      else
+        hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
       if constexpr (!TERM)
         hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
     }

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
-HIP_LIB_PATH = os.path.join(_HERE, "lib", "libcddp_hip.so")
+HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
 ORACLE_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle.so")
 ORACLE_FAST_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle_fast.so")
 
