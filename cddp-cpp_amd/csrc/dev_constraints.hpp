@@ -30,6 +30,21 @@ struct CtrlBox {
     for (int i = 0; i < D; ++i) { Gu[i * NU + i] = -c.scale; Gu[(D + i) * NU + i] = c.scale; }
     (void)Gx;
   }
+  // loop-invariant constants in registers (serial kernels) + the same evaluation on them
+  struct K { double scale, lo[D], hi[D]; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) {
+    k.scale = c.scale;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { k.lo[i] = pool[c.off_lower + i]; k.hi[i] = pool[c.off_upper + i]; }
+  }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *, const double *u, double *g) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      g[i] = (-u[i]) * k.scale - (-k.lo[i]) * k.scale;
+      g[D + i] = u[i] * k.scale - k.hi[i] * k.scale;
+    }
+  }
 };
 
 // BoxConstraint<State>
@@ -51,6 +66,20 @@ struct StateBox {
     for (int i = 0; i < D; ++i) { Gx[i * NX + i] = -c.scale; Gx[(D + i) * NX + i] = c.scale; }
     (void)Gu;
   }
+  struct K { double scale, lo[D], hi[D]; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) {
+    k.scale = c.scale;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { k.lo[i] = pool[c.off_lower + i]; k.hi[i] = pool[c.off_upper + i]; }
+  }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *x, const double *, double *g) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      g[i] = (-x[i]) * k.scale - (-k.lo[i]) * k.scale;
+      g[D + i] = x[i] * k.scale - k.hi[i] * k.scale;
+    }
+  }
 };
 
 // BallConstraint (constraint.hpp:313-404): g = -s*|x[:d]-c|^2 - (-(r*r)*s), G_x = -2 s (x-c)
@@ -70,6 +99,19 @@ struct Ball {
 #pragma unroll
     for (int i = 0; i < D; ++i) Gx[i] = -2.0 * c.scale * (x[i] - pool[c.off_center + i]);
     (void)Gu;
+  }
+  struct K { double scale, radius, ctr[D]; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) {
+    k.scale = c.scale; k.radius = c.radius;
+#pragma unroll
+    for (int i = 0; i < D; ++i) k.ctr[i] = pool[c.off_center + i];
+  }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *x, const double *, double *g) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { double df = x[i] - k.ctr[i]; sq += df * df; }
+    g[0] = -(k.scale * sq) - (-(k.radius * k.radius) * k.scale);
   }
 };
 
@@ -96,16 +138,40 @@ struct Linear {
       for (int j = 0; j < NX; ++j) Gx[r * NX + j] = pool[c.off_A + r * NX + j];
     (void)Gu;
   }
+  // (rows stay in the pool: R x NX doubles do not fit the scalar register file next to the plant constants)
+  struct K { const double *A, *b; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) { k.A = pool + c.off_A; k.b = pool + c.off_b; }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *x, const double *, double *g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += k.A[r * NX + j] * x[j];
+      g[r] = s - k.b[r];
+    }
+  }
 };
 
 template <int OFF, int CI, class... Cs> struct ConImpl;
 template <int OFF, int CI>
 struct ConImpl<OFF, CI> {
+  struct Ctx {};
+  DEV static void load(const ProblemDev *, Ctx &) {}
+  template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
 };
 template <int OFF, int CI, class C, class... Rest>
 struct ConImpl<OFF, CI, C, Rest...> {
+  typedef ConImpl<OFF + C::DUAL, CI + 1, Rest...> Next;
+  struct Ctx { typename C::K k; typename Next::Ctx rest; };
+  DEV static void load(const ProblemDev *P, Ctx &c) { C::load(P->cons[CI], P->pool, c.k); Next::load(P, c.rest); }
+  template <int NX, int NU>
+  DEV static void eval(const Ctx &c, const double *x, const double *u, double *g) {
+    C::template eval<NX, NU>(c.k, x, u, g + OFF);
+    Next::template eval<NX, NU>(c.rest, x, u, g);
+  }
   template <int NX, int NU>
   DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
     C::template eval<NX, NU>(P->cons[CI], P->pool, x, u, g + OFF);
@@ -142,6 +208,13 @@ struct ConList {
   DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
     ConImpl<0, 0, Cs...>::template eval<NX, NU>(P, x, u, g);
   }
+  // hoisted-constant form for the serial kernels
+  typedef typename ConImpl<0, 0, Cs...>::Ctx Ctx;
+  DEV static void load(const ProblemDev *P, Ctx &c) { ConImpl<0, 0, Cs...>::load(P, c); }
+  template <int NX, int NU>
+  DEV static void eval(const Ctx &c, const double *x, const double *u, double *g) {
+    ConImpl<0, 0, Cs...>::template eval<NX, NU>(c, x, u, g);
+  }
   // Gx (M x NX) and Gu (M x NU) must be zero-filled by the caller
   template <int NX, int NU>
   DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
@@ -156,6 +229,9 @@ struct ConList<> {
   DEV static int seg_dim(int) { return 0; }
   DEV static int seg_off(int) { return 0; }
   static bool matches(const ProblemDev &P) { return P.n_cons == 0; }
+  struct Ctx {};
+  DEV static void load(const ProblemDev *, Ctx &) {}
+  template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
 };
@@ -173,6 +249,52 @@ struct Objective {
 #pragma unroll
       for (int i = 0; i < NX; ++i) e[i] = x[i] - P->pool[P->off_xref + i];
     }
+  }
+  // Loop-invariant cost matrices / goal in registers for the serial kernels (small plants only: NX*NX + NU*NU + NX
+  // scalar-register doubles); same arithmetic as the pool-reading forms below.
+  static constexpr bool kHoist = (NX * NX + NU * NU + NX) <= 40;
+  struct Ctx { double Q[kHoist ? NX * NX : 1], R[kHoist ? NU * NU : 1], xr[kHoist ? NX : 1]; const double *Qp, *Rp, *xrp; };
+  DEV static void load(const ProblemDev *P, Ctx &c) {
+    c.Qp = P->pool + P->off_Qdt; c.Rp = P->pool + P->off_Rdt; c.xrp = P->pool + P->off_xref;
+    if constexpr (kHoist) {
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) c.Q[i] = c.Qp[i];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) c.R[i] = c.Rp[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) c.xr[i] = c.xrp[i];
+    }
+  }
+  DEV static double running_cost(const Ctx &c, const double *xref_traj, int t, const double *x, const double *u) {
+    const double *Q = kHoist ? c.Q : c.Qp;
+    const double *R = kHoist ? c.R : c.Rp;
+    double e[NX];
+    if (xref_traj) {
+      cptr_t r = uniform_ptr(xref_traj + (size_t)t * NX);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) e[i] = x[i] - r[i];
+    } else {
+      const double *xr = kHoist ? c.xr : c.xrp;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) e[i] = x[i] - xr[i];
+    }
+    double sx = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) r += e[i] * Q[i * NX + j];
+      sx += r * e[j];
+    }
+    double su = 0.0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) r += u[i] * R[i * NU + j];
+      su += r * u[j];
+    }
+    return sx + su;
   }
   // (e^T Q) e, row-vector-first association as `(e.transpose() * Q_ * e).value()`
   DEV static double running_cost(const ProblemDev *P, const double *xref_traj, int t, const double *x, const double *u) {

@@ -355,9 +355,24 @@ struct Manip7Model {
 };
 
 // ---- explicit integrators (dynamical_system.cpp:28-83) --------------------------------------
+// Loop-invariant integrator constants held in registers (SGPRs) by the serial kernels: the step size products
+// and the plant parameters would otherwise be re-fetched through dependent scalar loads -- and dt/6 re-divided --
+// on every step of the chain.  Same values, same arithmetic as Stepper::step(integrator, dt, p, ...).
+struct DynCtx {
+  int integrator;
+  double dt, hdt, dt6, dt2;
+  double mp[32];
+  DEV void load(int integrator_, double dt_, const double *mp_) {
+    integrator = integrator_; dt = dt_; hdt = 0.5 * dt; dt6 = dt / 6; dt2 = 2 * dt;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mp[i] = mp_[i];   // unused entries are dead code after unrolling
+  }
+};
+
 template <class Model, bool D = Model::kDiscrete> struct Stepper;
 template <class Model> struct Stepper<Model, true> {
   DEV static void step(int, double, const double *p, const double *x, const double *u, double *xn) { Model::step(p, x, u, xn); }
+  DEV static void step(const DynCtx &c, const double *x, const double *u, double *xn) { Model::step(c.mp, x, u, xn); }
 };
 template <class Model> struct Stepper<Model, false> {
   DEV static void step(int integrator, double dt, const double *p, const double *x, const double *u, double *xn) {
@@ -402,6 +417,51 @@ template <class Model> struct Stepper<Model, false> {
     Model::f(p, xt, u, k4);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = x[i] + (dt / 6) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+  }
+  // the same integrators on hoisted constants
+  DEV static void step(const DynCtx &c, const double *x, const double *u, double *xn) {
+    constexpr int NX = Model::NX;
+    const double *p = c.mp;
+    double k1[NX];
+    Model::f(p, x, u, k1);
+    if (c.integrator == CDDP_HIP_EULER) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + c.dt * k1[i];
+      return;
+    }
+    double xt[NX], k2[NX];
+    if (c.integrator == CDDP_HIP_HEUN) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = x[i] + c.dt * k1[i];
+      Model::f(p, xt, u, k2);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + c.hdt * (k1[i] + k2[i]);
+      return;
+    }
+    double k3[NX];
+    if (c.integrator == CDDP_HIP_RK3) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = x[i] + c.hdt * k1[i];
+      Model::f(p, xt, u, k2);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xt[i] = (x[i] - c.dt * k1[i]) + c.dt2 * k2[i];
+      Model::f(p, xt, u, k3);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = x[i] + c.dt6 * ((k1[i] + 4.0 * k2[i]) + k3[i]);
+      return;
+    }
+    double k4[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + c.hdt * k1[i];
+    Model::f(p, xt, u, k2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + c.hdt * k2[i];
+    Model::f(p, xt, u, k3);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xt[i] = x[i] + c.dt * k3[i];
+    Model::f(p, xt, u, k4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = x[i] + c.dt6 * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
   }
 };
 

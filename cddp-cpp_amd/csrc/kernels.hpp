@@ -191,7 +191,7 @@ DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g,
 //   Q_x = l_x [+ Q_yx^T y] + A^T V_x, Q_u = l_u [+ Q_yu^T y] + B^T V_x,
 //   Q_xx = l_xx + (A^T V_xx) A, Q_ux = l_ux + (B^T V_xx) A, Q_uu = l_uu + (B^T V_xx) B
 template <int NX, int NU>
-DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const double *Vx, const double *Vxx,
+DEV void q_blocks(const double *Q, const double *R, const double *A, const double *Bm, const double *Vxx,
                   double *Qxx, double *Qux, double *Quu) {
   double T1[NX * NX], T2[NU * NX];
   mm_tn<NX, NX, NX>(A, Vxx, T1);    // A^T V_xx
@@ -199,12 +199,15 @@ DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const 
   mm_nn<NX, NX, NX>(T1, A, Qxx);
   mm_nn<NU, NX, NX>(T2, A, Qux);
   mm_nn<NU, NX, NU>(T2, Bm, Quu);
-  const double *Q = P->pool + P->off_Qdt;
-  const double *R = P->pool + P->off_Rdt;
 #pragma unroll
   for (int i = 0; i < NX * NX; ++i) Qxx[i] = (2.0 * Q[i]) + Qxx[i];
 #pragma unroll
   for (int i = 0; i < NU * NU; ++i) Quu[i] = (2.0 * R[i]) + Quu[i];
+}
+template <int NX, int NU>
+DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const double *Vx, const double *Vxx,
+                  double *Qxx, double *Qux, double *Quu) {
+  q_blocks<NX, NU>(P->pool + P->off_Qdt, P->pool + P->off_Rdt, A, Bm, Vxx, Qxx, Qux, Quu);
   (void)Vx;
 }
 
@@ -1531,6 +1534,7 @@ DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
   const ProblemDev *P = d.P;
   double v = d.inf_du[b];
   if (!P->opt.ipddp_check_state_stationarity || M == 0) return v;
+  if (!Cons::HAS_X) return dmax(v, 0.0);   // G_x == 0: every |G_x^T y| entry is exactly 0
   const double *Xs = d.X + (size_t)xslot * d.planeX;
   const double *Yc = d.Y + (size_t)d.cur[b] * d.planeM;
   double ss = 0.0;
@@ -1654,9 +1658,34 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
                                   d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp, &ts, mT, pT);
             }
           } else if constexpr (M > 0) {
-            if (mu != mu_old)
-              ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
-                                  d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp);
+            if (mu != mu_old) {
+              // theta and the primal residual do not depend on mu; the barrier merit and the complementarity
+              // residual do.  The log-barrier terms ls(c, t) of the accepted trial are still parked in the ev
+              // scratch (same values, K4), so the merit chain  mer -= mu * ls  is replayed in the reference's
+              // order without re-evaluating 2 N M logarithms on one lane.
+              const int N = d.N;
+              const double *Sw = d.S + (size_t)cs * d.planeM, *Yw = d.Y + (size_t)cs * d.planeM;
+              const double *evb = d.ev + GI((size_t)win * N, 2 * Cons::NSEG, 0);
+              const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
+              double mer = d.cost[b], ic = 0.0;
+              for (int c = 0; c < Cons::NSEG; ++c) {
+                const double *q = evb + (size_t)c * kLS;
+                int t = 0;
+                for (; t + 3 < N; t += 4) {
+                  const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+                  mer -= mu * v0; mer -= mu * v1; mer -= mu * v2; mer -= mu * v3;
+                }
+                for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
+              }
+              for (int t = 0; t < N; ++t) {
+                double sv[M], yv[M];
+                ld<M>(Sw + GI(t, M, 0), kLS, sv);
+                ld<M>(Yw + GI(t, M, 0), kLS, yv);
+#pragma unroll
+                for (int i = 0; i < M; ++i) ic = dmax(ic, fabs(yv[i] * sv[i] - mu));
+              }
+              phi_n = mer; icomp = ic;
+            }
           }
           const double ftheta = dmax(theta_n, 1e-8);
           const bool reset = (mu < mu_old) && (mu > 0.0);

@@ -142,6 +142,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
   bool ok = false;
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  typename Obj::Ctx oc;   // l_xx = 2 Q dt, l_uu = 2 R dt: loop-invariant, kept in scalar registers
+  Obj::load(P, oc);
+  const double *Qc = Obj::kHoist ? oc.Q : oc.Qp;
+  const double *Rc = Obj::kHoist ? oc.R : oc.Rp;
   for (;;) {
     ++nb;
     double xN[NX], Vx[NX], Vxx[NX * NX];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
 #pragma unroll
         for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + i] * Vx[k];
         Qu[i] = cu[i] + s2; }
-      q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+      q_blocks<NX, NU>(Qc, Rc, A, Bm, Vxx, Qxx, Qux, Quu);
       double Qr[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i)
@@ -525,6 +529,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
       ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
     };
+    DynCtx dc;   // loop-invariant constants in scalar registers
+    dc.load(P->integrator, P->dt, P->mp);
+    typename Obj::Ctx oc;
+    Obj::load(P, oc);
     StepIn nxt;
     load_step(0, nxt);
     // Prime the VMEM queue with the store pattern of one step (rows of step 0, rewritten by iteration 0): the
@@ -556,10 +564,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
         finite = finite && dfinite(u[i]);
       }
-      Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+      Stepper<Model>::step(dc, x, u, xn);
 #pragma unroll
       for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
-      const double lc = Obj::running_cost(P, xrt, t, x, u);
+      const double lc = Obj::running_cost(oc, xrt, t, x, u);
       if (alive && !finite) { s_pstat[lane] = t; alive = false; }
       st<NU>(Un + GI(t, NU, 0), kLS, u);
       st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
@@ -615,6 +623,8 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
     ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
   };
+  typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
+  Cons::load(P, cc);
   StepIn nxt;
   wait_prod(1);
   load_step(0, nxt);
@@ -652,7 +662,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
     double g[M];
-    Cons::template eval<NX, NU>(P, cs.x, cs.u, g);
+    Cons::template eval<NX, NU>(cc, cs.x, cs.u, g);
     st<M>(Gn + GI(t, M, 0), kLS, g);
     // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity, parked exactly as
     // in k_forward_ipddp: the first constraint object's |g+s| terms accumulate in t order right here, the other
