@@ -165,19 +165,21 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
     st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
     st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
     bool fail = false;
-    struct StepIn { double A[NX * NX], Bm[NX * NU], c[CST]; };
-    auto load_step = [&](int tt, StepIn &r) {
-      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+    // two prefetch groups: a wave stalls at VMEM issue beyond ~sixteen outstanding 512-B rows (see K4)
+    struct StepIn { double A[NX * NX]; };
+    struct StepIn2 { double Bm[NX * NU], c[CST]; };
+    auto load_step = [&](int tt, StepIn &r) { ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A); };
+    auto load_step2 = [&](int tt, StepIn2 &r) {
       ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
       ld<CST>(d.cst + GI(tt, CST, 0), kLS, r.c);
     };
-    StepIn nxt;
-    load_step(N - 1, nxt);
-    for (int t = N - 1; t >= 0; --t) {
-      StepIn cs = nxt;
-      if (t > 0) load_step(t - 1, nxt);
+    // Ping-pong record buffers, loop unrolled by two: a `cur = next` register copy per step makes the compiler
+    // wait for the freshly issued prefetch right where the copy lands (measured: vmcnt(0) mid-step).
+    auto step = [&](const int t, const StepIn &cs1, const StepIn2 &cs, StepIn &nxt, StepIn2 &nxt2) -> bool {
+      const int tp = t > 0 ? t - 1 : 0;   // unconditional (clamped) prefetch: no branch for the optimiser to merge
+      load_step(tp, nxt);
       PIPELINE_FENCE();
-      double (&A)[NX * NX] = cs.A; double (&Bm)[NX * NU] = cs.Bm;
+      const double (&A)[NX * NX] = cs1.A; const double (&Bm)[NX * NU] = cs.Bm;
       const double *cx = cs.c + L::CX, *cu = cs.c + L::CU, *WQyu = cs.c + L::WQYU, *QyuSir = cs.c + L::QYUSIR;
       double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
 #pragma unroll
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
         for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + i] * Vx[k];
         Qu[i] = cu[i] + s2; }
       q_blocks<NX, NU>(Qc, Rc, A, Bm, Vxx, Qxx, Qux, Quu);
+      __builtin_amdgcn_sched_barrier(0);   // keep the second group behind the Q-block arithmetic
+      load_step2(tp, nxt2);
+      PIPELINE_FENCE();
+      __builtin_amdgcn_sched_barrier(0);
       double Qr[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i)
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
       } else {
         LDLTd<NU> f;
         f.compute(Qr, NU);
-        if (!f.ok) { fail = true; break; }
+        if (!f.ok) return false;
         double col[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) col[i] = Qu[i] + QyuSir[i];
@@ -282,7 +288,18 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
       st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
 #pragma unroll
       for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+      return true;
+    };
+    StepIn a1, b1;
+    StepIn2 a2, b2;
+    load_step(N - 1, a1);
+    load_step2(N - 1, a2);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      if (!step(t, a1, a2, b1, b2)) { fail = true; break; }
+      if (!step(t - 1, b1, b2, a1, a2)) { fail = true; break; }
     }
+    if (!fail && t == 0) fail = !step(0, a1, a2, b1, b2);
     if (!fail) { ok = true; break; }
     if (force == 2) break;
     reg = reg_increase(o, reg);
@@ -604,12 +621,17 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   }
   double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
-  struct StepIn { double x[NX], u[NU], xo[NX], s[M], y[M], ksv[M], ky[M], Ksm[M * NX], Ky[M * NX]; };
+  // The record of a step is fetched in TWO groups.  A wave stalls at VMEM issue once ~8 KB (sixteen 512-B row
+  // loads) are outstanding (measured, scratch/ubench/vmem.hip), so a 33-row prefetch issued in one burst blocks
+  // for a full memory round trip every step.  Group A goes out at the top of the step, group B after the
+  // slack / dual arithmetic, when A has landed.
+  struct StepA { double x[NX], u[NU], xo[NX], s[M], y[M], ksv[M], ky[M]; };
+  struct StepB { double Ksm[M * NX], Ky[M * NX]; };
   auto wait_prod = [&](int need) {
     while (__hip_atomic_load(&s_prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
   };
-  auto load_step = [&](int tt, StepIn &r) {
+  auto load_a = [&](int tt, StepA &r) {
     // trial rows written by the producer wave during this launch: agent-scope loads (no stale L1 line)
 #pragma unroll
     for (int i = 0; i < NX; ++i) r.x[i] = __hip_atomic_load(Xn + GI(tt, NX, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -620,14 +642,18 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
     ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
     ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+  };
+  auto load_b = [&](int tt, StepB &r) {
     ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
     ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
   };
   typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
   Cons::load(P, cc);
-  StepIn nxt;
+  StepA na;
+  StepB nb;
   wait_prod(1);
-  load_step(0, nxt);
+  load_a(0, na);
+  load_b(0, nb);
   {   // prime the VMEM queue with one step's store pattern (see the producer)
     double z[M];
 #pragma unroll
@@ -643,8 +669,11 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     // every trial of the tile has failed (checked before this step's VMEM traffic so that every path to the
     // loop latch carries the same load / store pattern -- see the priming note)
     if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-    StepIn cs = nxt;
-    if (t + 1 < N) { wait_prod(t + 2); load_step(t + 1, nxt); }
+    StepA cs = na;
+    StepB cb = nb;
+    const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+    wait_prod(tn + 1);
+    load_a(tn, na);
     PIPELINE_FENCE();
     if (alive && s_pstat[lane] <= t) alive = false;
     double dx[NX], sn[M], yn[M];
@@ -653,12 +682,16 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     bool feas = true;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-      sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], cs.Ksm + r * NX, dx);
-      yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], cs.Ky + r * NX, dx);
+      sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], cb.Ksm + r * NX, dx);
+      yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], cb.Ky + r * NX, dx);
       if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
       if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
     }
     if (!feas) alive = false;
+    __builtin_amdgcn_sched_barrier(0);   // keep group B behind the slack / dual arithmetic
+    load_b(tn, nb);
+    PIPELINE_FENCE();
+    __builtin_amdgcn_sched_barrier(0);
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
     double g[M];
