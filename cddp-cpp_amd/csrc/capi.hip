@@ -513,9 +513,15 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       mark();
       launches += 6;
     }
-    HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (*h_active == 0) break;
+    // The "anything still running?" poll drains the queue (host round trip + an empty pipeline for the next
+    // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
+    // trajectory finished are launches whose every lane exits on its phase check.
+    constexpr int kPollEvery = 4;
+    if (it % kPollEvery == 0 || last) {
+      HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (*h_active == 0) break;
+    }
   }
   HIPCHK(hipEventRecord(ev1, s));
   HIPCHK(hipStreamSynchronize(s));
