@@ -1,0 +1,367 @@
+// Lane-cooperative IPDDP Riccati sweep: G lanes per trajectory, lane q owns COLUMN q of V_xx.
+//
+// The per-lane sweep (k_backward_ipddp_lean) runs ~740 f64 instructions per step on ONE wavefront per 64
+// trajectories: 64 wavefronts for the 4096-trajectory C2 batch, 6 % of the SIMDs, each bound by its own
+// instruction stream (a dependent f64 op costs ~9 cycles, an independent one ~5.4 on gfx950 -- scratch/ubench).
+// Here the small dense products of one step are split across the G lanes of a trajectory group:
+//
+//   round 1  T1[:,q] = A^T V_xx[:,q], T2[:,q] = B^T V_xx[:,q], Q_x[q]                  -> LDS
+//   round 2  Q_xx[:,q] = l_xx[:,q] + T1 A[:,q], Q_ux[:,q] = T2 A[:,q], Q_uu (replicated), factor (replicated),
+//            k (replicated), K[:,q]                                                   -> LDS
+//   round 3  V_x[q], Vn[:,q] = Q_xx[:,q] + K^T Q_ux[:,q] + Q_ux^T K[:,q] + K^T Q_uu K[:,q] -> LDS
+//            V_xx[:,q] = (Vn[:,q] + Vn[q,:]^T) / 2
+//
+// Every output element is still accumulated by ONE lane in the reference's order (same sums, same association
+// as k_backward_ipddp_lean / ipddp_solver.cpp:1392-1508), so the sweep stays bit-identical; only the column
+// loops are spread over lanes.  The wavefront is its own workgroup, so an LDS round trip needs no barrier,
+// only lgkmcnt(0).  Lanes q >= NX (when G > NX) shadow column NX-1 and write the same values to the same places.
+#pragma once
+#include "kernels_lean.hpp"
+
+namespace cddp_dev {
+
+#define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
+
+template <class Model>
+struct CoopCfg {
+  static constexpr int NX = Model::NX, NU = Model::NU;
+  static constexpr int G = NX <= 4 ? 4 : (NX <= 8 ? 8 : 16);   // lanes per trajectory
+  static constexpr int TPW = 64 / G;                            // trajectories per wavefront
+  static constexpr int oT1 = 0, oT2 = oT1 + NX * NX, oKK = oT2 + NU * NX, oQux = oKK + NU * NX, oVn = oQux + NU * NX,
+                       oVx = oVn + NX * NX, oDx = oVx + NX, RAW = oDx + NX;
+  static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;       // consecutive trajectories start 8 banks apart
+};
+
+DEV void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                            int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  typedef CstLayout<Model, Cons> L;
+  typedef CoopCfg<Model> C;
+  constexpr int CST = L::SIZE;
+  __shared__ double lds[C::TPW * C::STRIDE];
+  const int lane = threadIdx.x;
+  const int q = lane % C::G, tl = lane / C::G;
+  const int qc = q < NX ? q : NX - 1;
+  const int b = blockIdx.x * C::TPW + tl;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  double *Ls = lds + tl * C::STRIDE;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  if (count_iter && q == 0) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  // loop-invariant per-lane constants: column qc of l_xx / 2 = Q dt, and R dt
+  double Qq[NX], Rr[NU * NU];
+  {
+    const double *Qp = P->pool + P->off_Qdt, *Rp = P->pool + P->off_Rdt;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Qq[i] = Qp[i * NX + qc];
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Rr[i] = Rp[i];
+  }
+  for (;;) {
+    ++nb;
+    double Vx[NX], Vc[NX];   // V_x (replicated), V_xx[:, qc]
+    {
+      double xN[NX];
+      ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+      Obj::final_grad(P, xN, Vx);
+      const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
+    }
+    dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
+    {
+      // V_x(N)[qc]: dynamic element of a replicated register array -> route through LDS
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oVx + i] = Vx[i];
+      lds_sync();
+      d.Vx[GI(N, NX, qc)] = Ls[C::oVx + qc];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) d.Vxx[GI(N, NX * NX, i * NX + qc)] = Vc[i];
+    bool fail = false;
+    struct In1 { double A[NX * NX], Aq[NX]; };
+    struct In2 { double Bm[NX * NU], cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq, WxQyxq[NX]; };
+    auto load1 = [&](int tt, In1 &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, j * NX + qc)];
+    };
+    auto load2 = [&](int tt, In2 &r) {
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      const double *c = d.cst + GI(tt, CST, 0);
+      ld<NU>(c + (size_t)L::CU * kLS, kLS, r.cu);
+      ld<NU * NU>(c + (size_t)L::WQYU * kLS, kLS, r.WQyu);
+      ld<NU>(c + (size_t)L::QYUSIR * kLS, kLS, r.QyuSir);
+      r.ipr = c[(size_t)L::IPR * kLS]; r.icomp = c[(size_t)L::ICOMP * kLS];
+      r.cxq = c[(size_t)(L::CX + qc) * kLS];
+      if constexpr (Cons::HAS_X) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) r.WQyxq[u] = c[(size_t)(L::WQYX + u * NX + qc) * kLS];
+        r.QyxSirq = c[(size_t)(L::QYXSIR + qc) * kLS];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) r.WxQyxq[i] = c[(size_t)(L::WXQYX + i * NX + qc) * kLS];
+      }
+    };
+    auto step = [&](const int t, const In1 &c1, const In2 &c2, In1 &n1, In2 &n2) -> bool {
+      const int tp = t > 0 ? t - 1 : 0;
+      load1(tp, n1);
+      PIPELINE_FENCE();
+      const double (&A)[NX * NX] = c1.A; const double (&Bm)[NX * NU] = c2.Bm;
+      // ---- round 1: column qc of T1 = A^T V_xx and T2 = B^T V_xx; row qc of Q_x; Q_u (replicated)
+      double T1c[NX], T2c[NU], Qu[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += A[k * NX + i] * Vc[k];
+        T1c[i] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Bm[k * NU + u] * Vc[k];
+        T2c[u] = s; }
+      double Qxq;
+      { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += c1.Aq[k] * Vx[k];
+        Qxq = c2.cxq + s2; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + u] * Vx[k];
+        Qu[u] = c2.cu[u] + s2; }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
+      lds_sync();
+      __builtin_amdgcn_sched_barrier(0);
+      load2(tp, n2);
+      PIPELINE_FENCE();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- round 2: column qc of Q_xx, Q_ux; Q_uu, factor, k replicated; column qc of K
+      double T1[NX * NX], T2[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+      double Qxxc[NX], Quxc[NU], Quu[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += T1[i * NX + j] * c1.Aq[j];
+        Qxxc[i] = (2.0 * Qq[i]) + s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * c1.Aq[j];
+        Quxc[u] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < NU; ++v) { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * Bm[j * NU + v];
+          Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
+      double Qr[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + c2.WQyu[i * NU + c];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+      double kk[NU], KKc[NU];
+      // condensed Q_ux column: the right-hand side of the K solve IS the condensed value (:1453, :1491)
+      double Quxq[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double rhs = Quxc[u];
+        if constexpr (Cons::HAS_X) rhs = rhs + c2.WQyxq[u];
+        Quxq[u] = rhs;
+      }
+      if (NU == 1) {
+        kk[0] = -ldlt1_solve(Qr[0], Qu[0] + c2.QyuSir[0]);
+        KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
+      } else {
+        LDLTd<NU> f;
+        f.compute(Qr, NU);
+        if (!f.ok) return false;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + c2.QyuSir[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Quxq[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; }
+      lds_sync();
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+      // ---- round 3: value update
+      double KK[NU * NX], Qux[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] += c2.QyuSir[i];
+      if constexpr (Cons::HAS_X) {
+        Qxq += c2.QyxSirq;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Qxxc[i] += c2.WxQyxq[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu[i] += c2.WQyu[i];
+      inf_pr = dmax(inf_pr, c2.ipr); inf_comp = dmax(inf_comp, c2.icomp);
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s1; }
+      { double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { s0 += kk[i] * Qu[i]; s1 += kk[i] * Quuk[i]; }
+        dV0 += s0; dV1 += 0.5 * s1; }
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+      double Vxq;
+      {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxq[j] * kk[j]; }
+        // KtQ[qc, :] = sum_u K[u, qc] Q_uu[u, :]: recomputed from the lane's own column (same expression as mm_tn)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { double s = 0.0;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
+          c += s * kk[j]; }
+        Vxq = ((Qxq + a) + bb) + c;
+      }
+      double Vnc[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Quxq[j]; bb += Qux[j * NX + i] * KKc[j]; e += KtQ[i * NU + j] * KKc[j]; }
+        Vnc[i] = ((Qxxc[i] + a) + bb) + e;
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oVn + i * NX + qc] = Vnc[i];
+      Ls[C::oVx + qc] = Vxq;
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * (Vnc[i] + Ls[C::oVn + qc * NX + i]);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vx[i] = Ls[C::oVx + i];
+      lds_sync();   // reads done before the next step overwrites the regions
+      d.Vx[GI(t, NX, qc)] = Vxq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+      return true;
+    };
+    In1 a1, b1;
+    In2 a2, b2;
+    load1(N - 1, a1);
+    load2(N - 1, a2);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      if (!step(t, a1, a2, b1, b2)) { fail = true; break; }
+      if (!step(t - 1, b1, b2, a1, a2)) { fail = true; break; }
+    }
+    if (!fail && t == 0) fail = !step(0, a1, a2, b1, b2);
+    if (!fail) { ok = true; break; }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  bool conv = false;
+  if (ok) {
+    const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+    const double asn = fabs(d.alpha_pr[b]) * step_norm;
+    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    if (!conv || force) {
+      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      struct RIn { double kk[NU], KK[NU * NX], Aq[NX], Bq[NU]; };
+      auto load_r = [&](int tt, RIn &r) {
+        ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+        ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+      };
+      auto rstep = [&](const int t, const RIn &rc, RIn &rn) {
+        const int tn = t + 1 < N - 1 ? t + 1 : t;
+        load_r(tn, rn);
+        PIPELINE_FENCE();
+        d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+        if (t < N - 1) {
+          double du[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += rc.KK[i * NX + j] * dx[j];
+            du[i] = rc.kk[i] + a; }
+          double a = 0.0, c = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
+          const double dxq = (a + c) + 0.0;
+          lds_sync();              // every lane has read the old dx row
+          Ls[C::oDx + qc] = dxq;
+          lds_sync();
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
+      lds_sync();
+      RIn ra, rb;
+      load_r(0, ra);
+      int t = 0;
+      for (; t + 1 < N; t += 2) { rstep(t, ra, rb); rstep(t + 1, rb, ra); }
+      if (t < N) rstep(t, ra, rb);
+    }
+  }
+  if (q != 0) return;
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;        // K3 lowers them by atomic min
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
+    d.inf_pr[b] = inf_pr; d.inf_comp[b] = inf_comp;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
+  d.phase[b] = PH_FWD1;
+}
+
+#undef GI
+}  // namespace cddp_dev

@@ -1,7 +1,9 @@
 // Host-side launch table: one KernelSet per (plant, constraint layout) instantiation.
 #pragma once
 #include <vector>
-#include "kernels_lean.hpp"
+#include <cstdlib>
+#include <cstring>
+#include "kernels_coop.hpp"
 
 namespace cddp_dev {
 
@@ -36,7 +38,13 @@ struct Launcher {
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
     else if constexpr (kLean) {
-      hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      // lane-cooperative sweep (kernels_coop.hpp); CDDP_HIP_SWEEP=lane selects the one-lane-per-trajectory sweep
+      static const bool lane_sweep = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
+      if (lane_sweep)
+        hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else
+        hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), dim3((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW), dim3(64), 0, s,
+                           d, d.P, d.xref_traj, force, count_iter);
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
     } else
       hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
