@@ -201,20 +201,37 @@ def main():
     gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
     gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
+    lean = ipddp and m > 0
     if bwd_ms >= fwd_ms:
-        dom = ("k_derivs+k_backward_%s" % args.solver, gbps_bwd, bwd_ms, bytes_bwd)
+        dom = ("k_derivs+k_condense+k_backward_ipddp_coop+k_post" if lean else "k_derivs+k_backward_%s" % args.solver, gbps_bwd, bwd_ms, bytes_bwd)
+        pmc_key = None
     else:
-        dom = ("k_forward_%s" % args.solver, gbps_fwd, fwd_ms, bytes_fwd)
+        dom = ("k_forward_ipddp_pc" if lean else "k_forward_%s" % args.solver, gbps_fwd, fwd_ms, bytes_fwd)
+        pmc_key = dom[0]
     PEAK = 8000.0   # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
     n_launch = max(1, st.outer_iterations)
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
+    # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
+    # (profiles/r01_c_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
+    traffic = None
+    traffic_note = None
+    if pmc_key and args.workload == "cartpole" and B == 4096 and ipddp:
+        try:
+            pj = json.load(open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")))
+            traffic = pj["kernels"][pmc_key]["bytes_per_launch"]
+            traffic_note = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of one solve)"
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
-        "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": None,
+        "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": dom[3] / n_launch, "avg_launch_ms": dom[2] / n_launch,
         "launches": n_launch,
+        "algorithmic_bytes_note": "SURVEY 8(d) bytes per rollout x ACCEPTED-PATH rollouts only (first-success ladder as the reference walks it); "
+                                  "the speculative trials of the other alphas are executed but not credited",
         "classes": {
-            "backward(K1+K2)": {"ms": bwd_ms, "GBps": gbps_bwd}, "forward(K4)": {"ms": fwd_ms, "GBps": gbps_fwd},
-            "update(K5)": {"ms": upd_ms}, "whole_solve": {"ms": solve_ms, "GBps": gbps_all},
+            "backward(K1+K1b+K2+K3)": {"ms": bwd_ms, "GBps": gbps_bwd}, "forward(K4)": {"ms": fwd_ms, "GBps": gbps_fwd},
+            "update(K4b+K5)": {"ms": upd_ms}, "whole_solve": {"ms": solve_ms, "GBps": gbps_all},
         },
         "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
     }

@@ -300,7 +300,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
   DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
   DA(d.Vx, (size_t)(N + 1) * nx * Bp); DA(d.Vxx, (size_t)(N + 1) * nx * nx * Bp);
-  if (ip && h->ks->cst_size > 0) { DA(d.cst, (size_t)N * h->ks->cst_size * Bp); DA(d.dX, (size_t)N * nx * Bp); }
+  if (ip && h->ks->cst_size > 0) { DA(d.cst, (size_t)N * h->ks->cst_size * Bp); DA(d.dX, (size_t)N * nx * Bp); DA(d.ys, (size_t)N * (m > 0 ? m : 1) * Bp); }
   if (ip && m > 0) { DA(d.ks, (size_t)N * m * Bp); DA(d.ky, (size_t)N * m * Bp); DA(d.Ks, (size_t)N * m * nx * Bp); DA(d.Ky, (size_t)N * m * nx * Bp); }
   double **scal[] = {&d.cost, &d.merit, &d.inf_pr, &d.inf_du, &d.inf_comp, &d.step_norm, &d.alpha_pr, &d.alpha_du, &d.reg, &d.mu,
                      &d.dV0, &d.dV1, &d.phi, &d.theta, &d.filter_theta, &d.apr_max, &d.adu_max};
@@ -430,6 +430,7 @@ int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cdd
   for (int i = 0; i < n_alphas; ++i) tmp.alphas[i] = alphas[i];
   HIPCHK(hipMemcpyAsync(h->dP, &tmp, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
   h->ks->forward(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
+  h->ks->costate(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
   HIPCHK(hipGetLastError());
   const DevBuf &d = h->d;
   const size_t n = (size_t)n_alphas * d.Bp;
@@ -497,6 +498,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     if (one_stage) {
       ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
       mark();
+      ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
       ks->update(d, 1, na, last, 1, s);
       mark();
       mark();
@@ -505,10 +507,12 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     } else {
       ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
       mark();
+      ks->costate(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
       ks->update(d, 1, 1, last, 0, s);
       mark();
       ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
       mark();
+      ks->costate(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
       ks->update(d, 2, na, last, 1, s);
       mark();
       launches += 6;

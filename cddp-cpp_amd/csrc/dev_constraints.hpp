@@ -45,6 +45,12 @@ struct CtrlBox {
       g[D + i] = u[i] * k.scale - k.hi[i] * k.scale;
     }
   }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Gu[i * NU + i] = -k.scale; Gu[(D + i) * NU + i] = k.scale; }
+    (void)Gx;
+  }
 };
 
 // BoxConstraint<State>
@@ -80,6 +86,12 @@ struct StateBox {
       g[D + i] = x[i] * k.scale - k.hi[i] * k.scale;
     }
   }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Gx[i * NX + i] = -k.scale; Gx[(D + i) * NX + i] = k.scale; }
+    (void)Gu;
+  }
 };
 
 // BallConstraint (constraint.hpp:313-404): g = -s*|x[:d]-c|^2 - (-(r*r)*s), G_x = -2 s (x-c)
@@ -112,6 +124,12 @@ struct Ball {
 #pragma unroll
     for (int i = 0; i < D; ++i) { double df = x[i] - k.ctr[i]; sq += df * df; }
     g[0] = -(k.scale * sq) - (-(k.radius * k.radius) * k.scale);
+  }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *x, double *Gx, double *Gu) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) Gx[i] = -2.0 * k.scale * (x[i] - k.ctr[i]);
+    (void)Gu;
   }
 };
 
@@ -151,6 +169,14 @@ struct Linear {
       g[r] = s - k.b[r];
     }
   }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Gx[r * NX + j] = k.A[r * NX + j];
+    (void)Gu;
+  }
 };
 
 template <int OFF, int CI, class... Cs> struct ConImpl;
@@ -159,6 +185,7 @@ struct ConImpl<OFF, CI> {
   struct Ctx {};
   DEV static void load(const ProblemDev *, Ctx &) {}
   template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
 };
@@ -171,6 +198,11 @@ struct ConImpl<OFF, CI, C, Rest...> {
   DEV static void eval(const Ctx &c, const double *x, const double *u, double *g) {
     C::template eval<NX, NU>(c.k, x, u, g + OFF);
     Next::template eval<NX, NU>(c.rest, x, u, g);
+  }
+  template <int NX, int NU>
+  DEV static void jac(const Ctx &c, const double *x, double *Gx, double *Gu) {
+    C::template jac<NX, NU>(c.k, x, Gx + OFF * NX, Gu + OFF * NU);
+    Next::template jac<NX, NU>(c.rest, x, Gx, Gu);
   }
   template <int NX, int NU>
   DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
@@ -215,6 +247,10 @@ struct ConList {
   DEV static void eval(const Ctx &c, const double *x, const double *u, double *g) {
     ConImpl<0, 0, Cs...>::template eval<NX, NU>(c, x, u, g);
   }
+  template <int NX, int NU>
+  DEV static void jac(const Ctx &c, const double *x, double *Gx, double *Gu) {
+    ConImpl<0, 0, Cs...>::template jac<NX, NU>(c, x, Gx, Gu);
+  }
   // Gx (M x NX) and Gu (M x NU) must be zero-filled by the caller
   template <int NX, int NU>
   DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
@@ -232,6 +268,7 @@ struct ConList<> {
   struct Ctx {};
   DEV static void load(const ProblemDev *, Ctx &) {}
   template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
   template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
 };

@@ -70,6 +70,7 @@ struct DevBuf {
   double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
   int *t_success;
   double *cst;                             // [N][CST][Bp] V-independent condensed stage terms written by K1b (k_condense)
+  double *ys;                              // [N][m][Bp] Y S^-1 ratios of the last sweep (K3 -> rollout consumer)
   double *dX;                              // [N][nx][Bp] linear-policy rollout of the last sweep (read by K3 k_post)
   double *ev;                              // [n_alphas][N][2*NSEG][Bp]: per-step log-barrier / |g+s| terms parked by K4
   // history [hist_batch][hist_cap][9] (row-major) + counts

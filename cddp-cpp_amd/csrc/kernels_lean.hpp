@@ -401,12 +401,13 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
 #pragma unroll
   for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
   Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
-  double ky[M], ksv[M], Ky[M * NX], Ksm[M * NX];
+  double ky[M], ksv[M], Ky[M * NX], Ksm[M * NX], ysv[M];
   double apr = 1.0, adu = 1.0;
 #pragma unroll
   for (int r = 0; r < M; ++r) {
     const double ss = dmax(s[r], s_floor);
     const double YSr = clip_pos(y[r], ss);
+    ysv[r] = YSr;
     const double rp = g[r] + s[r];
     const double rc = y[r] * s[r] - mu;
     const double rhat = y[r] * rp - rc;
@@ -432,10 +433,12 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
     if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
     if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
   }
+  // The feedback blocks K_s = -(G_x + G_u K), K_y = clamp(YS (G_x + G_u K)) are NOT stored: the rollout consumer
+  // rebuilds the rows it needs from K and YS with this very arithmetic (2 M NX fewer rows per step to write here
+  // and to read there, where VMEM issue is the scarce resource).
   st<M>(d.ky + GI(t, M, 0), kLS, ky);
   st<M>(d.ks + GI(t, M, 0), kLS, ksv);
-  st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
-  st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ksm);
+  st<M>(d.ys + GI(t, M, 0), kLS, ysv);
   if (apr < 1.0) atomic_min_pos(d.apr_max + b, apr);
   if (adu < 1.0) atomic_min_pos(d.adu_max + b, adu);
 }
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   // for a full memory round trip every step.  Group A goes out at the top of the step, group B after the
   // slack / dual arithmetic, when A has landed.
   struct StepA { double x[NX], u[NU], xo[NX], s[M], y[M], ksv[M], ky[M]; };
-  struct StepB { double Ksm[M * NX], Ky[M * NX]; };
+  struct StepB { double KK[NU * NX], ys[M]; };
   auto wait_prod = [&](int need) {
     while (__hip_atomic_load(&s_prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
@@ -644,8 +647,8 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
   };
   auto load_b = [&](int tt, StepB &r) {
-    ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ksm);
-    ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+    ld<M>(d.ys + GI(tt, M, 0), kLS, r.ys);
   };
   typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
   Cons::load(P, cc);
@@ -680,10 +683,27 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = cs.x[i] - cs.xo[i];
     bool feas = true;
+    // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
+    double Gx[M * NX], Gu[M * NU];
+#pragma unroll
+    for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
+    Cons::template jac<NX, NU>(cc, cs.xo, Gx, Gu);
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-      sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], cb.Ksm + r * NX, dx);
-      yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], cb.Ky + r * NX, dx);
+      double Ksr[NX], Kyr[NX];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) s2 += Gu[r * NU + i] * cb.KK[i * NX + c];
+        const double inner = Gx[r * NX + c] + s2;
+        Kyr[c] = dmin(dmax(cb.ys[r] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+        Ksr[c] = (-Gx[r * NX + c]) - s2;
+      }
+      sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], Ksr, dx);
+      yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], Kyr, dx);
       if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
       if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
     }

@@ -15,6 +15,7 @@ struct KernelSet {
   void (*derivs)(const DevBuf &, int force, hipStream_t);
   void (*backward)(const DevBuf &, int solver, int force, int count_iter, hipStream_t);
   void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t);
+  void (*costate)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t);
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, hipStream_t);
 };
@@ -60,9 +61,14 @@ struct Launcher {
         hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
       else
         hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
-      if constexpr (!TERM)
-        hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
     }
+    (void)first_only;
+  }
+  // K4b: costate trial of the surviving trials (problems without terminal constraints; kernels_lean.hpp)
+  static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
+    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP) return;
+    if constexpr (!TERM)
+      hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
@@ -74,7 +80,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size();
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.update = &update; k.init = &init;
+    k.costate = &costate; k.update = &update; k.init = &init;
     return k;
   }
 };

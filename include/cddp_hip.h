@@ -250,8 +250,8 @@ typedef struct cddp_hip_trial {
 typedef struct cddp_hip_stats {
   double solve_ms;          /* hipEvent time of the device-resident loop           */
   double backward_ms;       /* sum of K1+K2 kernel time (hipEvent)                 */
-  double forward_ms;        /* sum of K4 kernel time                               */
-  double update_ms;         /* sum of K5 kernel time                               */
+  double forward_ms;        /* sum of K4 (rollout) kernel time                     */
+  double update_ms;         /* sum of K4b (costate) + K5 kernel time               */
   int64_t sweeps;           /* sum over trajectories of n_backward                 */
   int64_t rollouts;         /* sum over trajectories of n_forward                  */
   int64_t rollouts_launched;/* rollouts actually executed (speculative alphas too) */
