@@ -491,14 +491,16 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 // chain, and one wave per SIMD leaves every dependent f64 operation's latency exposed, so the work is split:
 //   wave 0 (producer)  u_t = u + a k + K dx, x_{t+1} = f(x_t, u_t), running / terminal cost, stores X, U of the trial
 //                      (ipddp_solver.cpp:1618-1627, 1726-1748);
-//   wave 1 (consumer)  a few steps behind: slack / dual trial + fraction-to-boundary test (:1629-1658), g(x_t, u_t)
-//                      (:1735-1745), the theta / barrier-merit / residual terms (:2778-2937), the filter test
-//                      (:1785-1834) and the trial record.
-// Hand-off: the producer's X/U trial stores ARE the channel.  VMEM operations of a wave retire in issue order on
-// gfx9-family parts (vmcnt counts loads and stores together), so once the prefetched record of step t has
-// arrived every store issued before that prefetch -- steps <= t-2 -- has reached L2.  The producer publishes that
-// step count through one LDS word; the consumer polls it and reads the trial rows with agent-scope loads.  A lane
-// whose rollout went non-finite is published through s_pstat before the counter moves.
+//   wave 1 (consumer)  slack / dual trial + fraction-to-boundary test (:1629-1658), g(x_t, u_t) (:1735-1745), the
+//                      theta / barrier-merit / residual terms (:2778-2937), the filter test (:1785-1834) and the
+//                      trial record.
+// Channel: an LDS ring of kRing steps carrying (dx_t or x_t, u_t) per lane, a produced-step counter and a
+// consumed-step counter (both LDS words, polled with s_sleep).  The producer publishes step t as soon as u_t is
+// known -- before it integrates -- so the consumer works on step t while the producer is inside the RK4 of step t.
+// A lane whose rollout went non-finite is published through s_pstat.
+// Why the consumer reads nothing of the trial from global memory: a wave stalls at VMEM issue once ~sixteen 512-B
+// row loads are outstanding (scratch/ubench/vmem.hip), so row loads, not arithmetic, set the consumer's pace; the
+// ring removes 2 NX + NU of them per step and K_s / K_y are rebuilt from K and YS (see k_post).
 // Every lane runs straight-line code with UNCONDITIONAL stores (a dead lane keeps re-evaluating its frozen state;
 // rows of a failed trial are never read): with stores inside divergent branches the waitcnt pass cannot count the
 // operations behind the prefetch and falls back to vmcnt(0), i.e. it waits for a store acknowledge every step.
@@ -508,7 +510,11 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
   static_assert(M > 0, "two-role rollout is for path-constrained problems");
-  __shared__ int s_prod;          // number of steps t whose (x_t, u_t) trial rows are visible in L2
+  constexpr int kRing = 8;                 // steps in flight between the two waves
+  constexpr int RW = NX + NU;              // doubles per lane per step: (x_t if the constraints read x, else dx_t), u_t
+  __shared__ double s_ring[kRing * RW * 64];
+  __shared__ int s_prod;          // steps published by the producer
+  __shared__ int s_cons;          // steps retired by the consumer
   __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
   __shared__ double s_pcost[64];  // the producer lane's total trial cost
   const int lane = threadIdx.x & 63;
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const int N = d.N;
   const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
   if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in both waves: both leave
-  if (producer) { s_pstat[lane] = N + 2; if (lane == 0) s_prod = 0; }
+  if (producer) { s_pstat[lane] = N + 2; if (lane == 0) { s_prod = 0; s_cons = 0; } }
   __syncthreads();
   // Inactive lanes (padding, or a trajectory in another phase) run along on their OWN rows: their trial slots are
   // scratch (trial_slot never returns the current slot), so unconditional stores need no exec-mask branches.
@@ -528,13 +534,17 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const int cur = (b < d.B) ? d.cur[b] : 0;
   const int slot = trial_slot(cur, a);
   const double *Xc = d.X + (size_t)cur * d.planeX;
-  double *Xn = d.X + (size_t)slot * d.planeX;
-  double *Un = d.U + (size_t)slot * d.planeU;
   const double alpha = P->alphas[a];
   const double a_pr = dmin(alpha, d.apr_max[bb]);
+  auto wait_ge = [&](int *ctr, int need) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
 
   if (producer) {
     // ------------------------------------------------------------------ producer: the dynamics chain
+    double *Xn = d.X + (size_t)slot * d.planeX;
+    double *Un = d.U + (size_t)slot * d.planeU;
     const double *Uc = d.U + (size_t)cur * d.planeU;
     bool alive = active;
     double x[NX];
@@ -542,7 +552,6 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     st<NX>(Xn + GI(0, NX, 0), kLS, x);
     double cost_new = 0.0;
     struct StepIn { double xo[NX], uo[NU], kk[NU], KK[NU * NX]; };
-    constexpr int NPRE = NX + NU + NU + NU * NX, NST = NX + NU;
     auto load_step = [&](int tt, StepIn &r) {
       ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
       ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
@@ -553,24 +562,19 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     dc.load(P->integrator, P->dt, P->mp);
     typename Obj::Ctx oc;
     Obj::load(P, oc);
-    StepIn nxt;
-    load_step(0, nxt);
     // Prime the VMEM queue with the store pattern of one step (rows of step 0, rewritten by iteration 0): the
     // waitcnt pass joins the loop-entry state with the back-edge state, and an entry state whose newest
     // operations are the loads would make every iteration wait for vmcnt(0), i.e. for its own last stores.
-    {
+    auto prime = [&]() {
       double z[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) z[i] = 0.0;
       st<NU>(Un + GI(0, NU, 0), kLS, z);
       st<NX>(Xn + GI(1, NX, 0), kLS, z);
-    }
-    for (int t = 0; t < N; ++t) {
-      StepIn cs = nxt;
-      if (t + 1 < N) load_step(t + 1, nxt);
-      // record of step t has landed => every older VMEM op (the stores of steps <= t-2) is complete
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE + NST < 63 ? NPRE + NST : 63) : "memory");   // 6-bit field
-      if (t >= 2) __hip_atomic_store(&s_prod, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto step = [&](const int t, const StepIn &cs, StepIn &nxt) {
+      const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+      load_step(tn, nxt);
       PIPELINE_FENCE();
       double dx[NX], u[NU], xn[NX];
       bool finite = true;
@@ -584,6 +588,18 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
         finite = finite && dfinite(u[i]);
       }
+      // publish step t: ring slot free once the consumer has retired step t - kRing
+      if (t >= kRing) wait_ge(&s_cons, t - kRing + 1);
+      {
+        double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rs[i * 64] = Cons::HAS_X ? x[i] : dx[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rs[(NX + i) * 64] = u[i];
+        if (alive && !finite) { s_pstat[lane] = t; alive = false; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       Stepper<Model>::step(dc, x, u, xn);
 #pragma unroll
       for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
@@ -596,11 +612,20 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
       }
-      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;   // nothing downstream reads the rows any more
+    };
+    StepIn ra, rb;
+    load_step(0, ra);
+    prime();
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      step(t, ra, rb);
+      step(t + 1, rb, ra);
+      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) { t = N; break; }   // nothing downstream reads the rows any more
     }
+    if (t < N) step(t, ra, rb);
     if (alive) { cost_new += Obj::terminal_cost(P, x); s_pcost[lane] = cost_new; }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __hip_atomic_store(&s_prod, N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
   }
 
@@ -624,40 +649,20 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   }
   double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
-  // The record of a step is fetched in TWO groups.  A wave stalls at VMEM issue once ~8 KB (sixteen 512-B row
-  // loads) are outstanding (measured, scratch/ubench/vmem.hip), so a 33-row prefetch issued in one burst blocks
-  // for a full memory round trip every step.  Group A goes out at the top of the step, group B after the
-  // slack / dual arithmetic, when A has landed.
-  struct StepA { double x[NX], u[NU], xo[NX], s[M], y[M], ksv[M], ky[M]; };
-  struct StepB { double KK[NU * NX], ys[M]; };
-  auto wait_prod = [&](int need) {
-    while (__hip_atomic_load(&s_prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-  };
-  auto load_a = [&](int tt, StepA &r) {
-    // trial rows written by the producer wave during this launch: agent-scope loads (no stale L1 line)
-#pragma unroll
-    for (int i = 0; i < NX; ++i) r.x[i] = __hip_atomic_load(Xn + GI(tt, NX, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int i = 0; i < NU; ++i) r.u[i] = __hip_atomic_load(Un + GI(tt, NU, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+  // per-step record of the CURRENT iterate (one prefetch group, <= 16 rows for the C2 layout)
+  struct StepIn { double xo[Cons::HAS_X ? NX : 1], s[M], y[M], ksv[M], ky[M], KK[NU * NX], ys[M]; };
+  auto load_step = [&](int tt, StepIn &r) {
+    if constexpr (Cons::HAS_X) ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
     ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
     ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
     ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
     ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
-  };
-  auto load_b = [&](int tt, StepB &r) {
     ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
     ld<M>(d.ys + GI(tt, M, 0), kLS, r.ys);
   };
   typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
   Cons::load(P, cc);
-  StepA na;
-  StepB nb;
-  wait_prod(1);
-  load_a(0, na);
-  load_b(0, nb);
-  {   // prime the VMEM queue with one step's store pattern (see the producer)
+  auto prime = [&]() {   // prime the VMEM queue with one step's store pattern (see the producer)
     double z[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) z[i] = 0.0;
@@ -667,21 +672,27 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     double *ev = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
 #pragma unroll
     for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
-  }
-  for (int t = 0; t < N; ++t) {
-    // every trial of the tile has failed (checked before this step's VMEM traffic so that every path to the
-    // loop latch carries the same load / store pattern -- see the priming note)
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-    StepA cs = na;
-    StepB cb = nb;
+  };
+  auto step = [&](const int t, const StepIn &cs, StepIn &nxt) {
     const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
-    wait_prod(tn + 1);
-    load_a(tn, na);
+    load_step(tn, nxt);
     PIPELINE_FENCE();
+    // take step t from the ring, then hand the slot back
+    wait_ge(&s_prod, t + 1);
+    double rx[NX], u[NU];
+    {
+      const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rx[i] = rs[i * 64];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = rs[(NX + i) * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (alive && s_pstat[lane] <= t) alive = false;
     double dx[NX], sn[M], yn[M];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = cs.x[i] - cs.xo[i];
+    for (int i = 0; i < NX; ++i) dx[i] = Cons::HAS_X ? rx[i] - cs.xo[Cons::HAS_X ? i : 0] : rx[i];
     bool feas = true;
     // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
     double Gx[M * NX], Gu[M * NU];
@@ -697,9 +708,9 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       for (int c = 0; c < NX; ++c) {
         double s2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) s2 += Gu[r * NU + i] * cb.KK[i * NX + c];
+        for (int i = 0; i < NU; ++i) s2 += Gu[r * NU + i] * cs.KK[i * NX + c];
         const double inner = Gx[r * NX + c] + s2;
-        Kyr[c] = dmin(dmax(cb.ys[r] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+        Kyr[c] = dmin(dmax(cs.ys[r] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
         Ksr[c] = (-Gx[r * NX + c]) - s2;
       }
       sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], Ksr, dx);
@@ -708,14 +719,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
     }
     if (!feas) alive = false;
-    __builtin_amdgcn_sched_barrier(0);   // keep group B behind the slack / dual arithmetic
-    load_b(tn, nb);
-    PIPELINE_FENCE();
-    __builtin_amdgcn_sched_barrier(0);
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
     double g[M];
-    Cons::template eval<NX, NU>(cc, cs.x, cs.u, g);
+    Cons::template eval<NX, NU>(cc, rx, u, g);   // rx is x_t whenever a constraint reads the state
     st<M>(Gn + GI(t, M, 0), kLS, g);
     // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity, parked exactly as
     // in k_forward_ipddp: the first constraint object's |g+s| terms accumulate in t order right here, the other
@@ -736,8 +743,23 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;
       ev[(size_t)c * kLS] = ls;
     }
+  };
+  StepIn ra, rb;
+  load_step(0, ra);
+  prime();
+  {
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      step(t, ra, rb);
+      step(t + 1, rb, ra);
+      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed: release the producer
+        __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+    }
+    if (t < N) step(t, ra, rb);
   }
-  wait_prod(N + 1);
+  wait_ge(&s_prod, N + kRing + 1);
   if (alive && s_pstat[lane] <= N) alive = false;
   if (!alive) return;
   const double cost_new = s_pcost[lane];
