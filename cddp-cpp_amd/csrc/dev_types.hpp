@@ -68,6 +68,7 @@ struct DevBuf {
   int *filt_n, *iter, *status, *phase, *cur, *n_bwd, *n_fwd, *bwd_ok;
   // trial records [n_alphas][Bp]
   double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
+  double *t_ysmin, *t_ysmax;               // extreme y*s products of the trial (complementarity residual under a new mu)
   int *t_success;
   double *cst;                             // [N][CST][Bp] V-independent condensed stage terms written by K1b (k_condense)
   double *ys;                              // [N][m][Bp] Y S^-1 ratios of the last sweep (K3 -> rollout consumer)

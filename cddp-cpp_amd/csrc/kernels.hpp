@@ -1664,26 +1664,24 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
               // scratch (same values, K4), so the merit chain  mer -= mu * ls  is replayed in the reference's
               // order without re-evaluating 2 N M logarithms on one lane.
               const int N = d.N;
-              const double *Sw = d.S + (size_t)cs * d.planeM, *Yw = d.Y + (size_t)cs * d.planeM;
               const double *evb = d.ev + GI((size_t)win * N, 2 * Cons::NSEG, 0);
               const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
-              double mer = d.cost[b], ic = 0.0;
+              double mer = d.cost[b];
               for (int c = 0; c < Cons::NSEG; ++c) {
                 const double *q = evb + (size_t)c * kLS;
                 int t = 0;
-                for (; t + 3 < N; t += 4) {
-                  const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
-                  mer -= mu * v0; mer -= mu * v1; mer -= mu * v2; mer -= mu * v3;
+                for (; t + 15 < N; t += 16) {   // sixteen row loads per round trip, then the ordered chain
+                  double v[16];
+#pragma unroll
+                  for (int k = 0; k < 16; ++k) v[k] = q[(size_t)(t + k) * tstride];
+#pragma unroll
+                  for (int k = 0; k < 16; ++k) mer -= mu * v[k];
                 }
                 for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
               }
-              for (int t = 0; t < N; ++t) {
-                double sv[M], yv[M];
-                ld<M>(Sw + GI(t, M, 0), kLS, sv);
-                ld<M>(Yw + GI(t, M, 0), kLS, yv);
-#pragma unroll
-                for (int i = 0; i < M; ++i) ic = dmax(ic, fabs(yv[i] * sv[i] - mu));
-              }
+              // max |y s - mu| over the iterate: |v - mu| is monotone in v on either side of mu (rounded
+              // subtraction is monotone), so the extreme products recorded by the trial give the same maximum
+              const double ic = dmax(fabs(d.t_ysmax[ti] - mu), fabs(d.t_ysmin[ti] - mu));
               phi_n = mer; icomp = ic;
             }
           }

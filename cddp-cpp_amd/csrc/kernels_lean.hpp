@@ -647,7 +647,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
     d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
   }
-  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0;
+  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0, ys_lo = INFINITY, ys_hi = -INFINITY;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // per-step record of the CURRENT iterate (one prefetch group, <= 16 rows for the C2 layout)
   struct StepIn { double xo[Cons::HAS_X ? NX : 1], s[M], y[M], ksv[M], ky[M], KK[NU * NX], ys[M]; };
@@ -736,7 +736,9 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         const double r = g[off + i] + sn[off + i];
         n1 += l2norm ? r * r : fabs(r);
         ninf = dmax(ninf, fabs(r));
-        ev_icomp = dmax(ev_icomp, fabs(yn[off + i] * sn[off + i] - mu));
+        const double ysp = yn[off + i] * sn[off + i];
+        ev_icomp = dmax(ev_icomp, fabs(ysp - mu));
+        ys_lo = dmin(ys_lo, ysp); ys_hi = dmax(ys_hi, ysp);   // for the residual under an updated mu (k_update)
         ls += log(dmax(sn[off + i], kEpsSlack));
       }
       ev_max = dmax(ev_max, ninf);
@@ -805,6 +807,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   }
   d.t_cost[ti] = cost_new; d.t_merit[ti] = phi_new; d.t_theta[ti] = theta_new;
   d.t_inf_pr[ti] = ipr; d.t_inf_comp[ti] = icomp;
+  d.t_ysmin[ti] = ys_lo; d.t_ysmax[ti] = ys_hi;
   d.t_success[ti] = accept ? 1 : 0;
 }
 
