@@ -489,14 +489,15 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 // Line-searched IPDDP rollout for path-constrained problems without terminal constraints, as a PRODUCER /
 // CONSUMER pair of wavefronts per (64-trajectory tile, alpha).  Only x_{t+1} = f(x_t, u_t(x_t)) is a true serial
 // chain, and one wave per SIMD leaves every dependent f64 operation's latency exposed, so the work is split:
-//   wave 0 (producer)  u_t = u + a k + K dx, x_{t+1} = f(x_t, u_t), running / terminal cost, stores X, U of the trial
-//                      (ipddp_solver.cpp:1618-1627, 1726-1748);
-//   wave 1 (consumer)  slack / dual trial + fraction-to-boundary test (:1629-1658), g(x_t, u_t) (:1735-1745), the
-//                      theta / barrier-merit / residual terms (:2778-2937), the filter test (:1785-1834) and the
-//                      trial record.
-// Channel: an LDS ring of kRing steps carrying (dx_t or x_t, u_t) per lane, a produced-step counter and a
+//   wave 0 (producer)  u_t = u + a k + K dx, x_{t+1} = f(x_t, u_t), l_f(x_N), stores X, U of the trial
+//                      (ipddp_solver.cpp:1618-1627);
+//   wave 1 (consumer)  slack / dual trial + fraction-to-boundary test (:1629-1658), running cost and g(x_t, u_t)
+//                      (:1726-1748), the theta / barrier-merit / residual terms (:2778-2937), the filter test
+//                      (:1785-1834) and the trial record.
+// Channel: an LDS ring of kRing steps carrying (x_t, dx_t, u_t) per lane, a produced-step counter and a
 // consumed-step counter (both LDS words, polled with s_sleep).  The producer publishes step t as soon as u_t is
-// known -- before it integrates -- so the consumer works on step t while the producer is inside the RK4 of step t.
+// known -- before it integrates -- so the consumer works on step t while the producer is inside the RK4 of step t;
+// the running cost is summed by the consumer (same t order), the producer hands over l_f(x_N) at the end.
 // A lane whose rollout went non-finite is published through s_pstat.
 // Why the consumer reads nothing of the trial from global memory: a wave stalls at VMEM issue once ~sixteen 512-B
 // row loads are outstanding (scratch/ubench/vmem.hip), so row loads, not arithmetic, set the consumer's pace; the
@@ -510,13 +511,13 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
   static_assert(M > 0, "two-role rollout is for path-constrained problems");
-  constexpr int kRing = 8;                 // steps in flight between the two waves
-  constexpr int RW = NX + NU;              // doubles per lane per step: (x_t if the constraints read x, else dx_t), u_t
+  constexpr int RW = 2 * NX + NU;          // doubles per lane per step: x_t, dx_t, u_t
+  constexpr int kRing = RW <= 10 ? 8 : (RW <= 20 ? 4 : 2);   // steps in flight between the two waves (<= 40 KB of LDS)
   __shared__ double s_ring[kRing * RW * 64];
   __shared__ int s_prod;          // steps published by the producer
   __shared__ int s_cons;          // steps retired by the consumer
   __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
-  __shared__ double s_pcost[64];  // the producer lane's total trial cost
+  __shared__ double s_pcost[64];  // the producer lane's terminal cost l_f(x_N)
   const int lane = threadIdx.x & 63;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
   const int b = blockIdx.x * 64 + lane;
@@ -550,7 +551,6 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     double x[NX];
     ld<NX>(Xc + GI(0, NX, 0), kLS, x);
     st<NX>(Xn + GI(0, NX, 0), kLS, x);
-    double cost_new = 0.0;
     struct StepIn { double xo[NX], uo[NU], kk[NU], KK[NU * NX]; };
     auto load_step = [&](int tt, StepIn &r) {
       ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
@@ -560,8 +560,6 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     };
     DynCtx dc;   // loop-invariant constants in scalar registers
     dc.load(P->integrator, P->dt, P->mp);
-    typename Obj::Ctx oc;
-    Obj::load(P, oc);
     // Prime the VMEM queue with the store pattern of one step (rows of step 0, rewritten by iteration 0): the
     // waitcnt pass joins the loop-entry state with the back-edge state, and an entry state whose newest
     // operations are the loads would make every iteration wait for vmcnt(0), i.e. for its own last stores.
@@ -588,14 +586,15 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
         finite = finite && dfinite(u[i]);
       }
-      // publish step t: ring slot free once the consumer has retired step t - kRing
-      if (t >= kRing) wait_ge(&s_cons, t - kRing + 1);
+      // publish step t.  Ring slots free up as the consumer retires steps; the counter is polled once every
+      // kRing/2 steps for the next kRing/2 slots (an LDS round trip on the chain otherwise).
+      if (t >= kRing && (t % (kRing / 2)) == 0) wait_ge(&s_cons, t - kRing / 2);   // kRing / 2 >= 1
       {
         double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) rs[i * 64] = Cons::HAS_X ? x[i] : dx[i];
+        for (int i = 0; i < NX; ++i) { rs[i * 64] = x[i]; rs[(NX + i) * 64] = dx[i]; }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) rs[(NX + i) * 64] = u[i];
+        for (int i = 0; i < NU; ++i) rs[(2 * NX + i) * 64] = u[i];
         if (alive && !finite) { s_pstat[lane] = t; alive = false; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -603,12 +602,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       Stepper<Model>::step(dc, x, u, xn);
 #pragma unroll
       for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
-      const double lc = Obj::running_cost(oc, xrt, t, x, u);
       if (alive && !finite) { s_pstat[lane] = t; alive = false; }
       st<NU>(Un + GI(t, NU, 0), kLS, u);
       st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
       if (alive) {
-        cost_new += lc;
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
       }
@@ -623,7 +620,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) { t = N; break; }   // nothing downstream reads the rows any more
     }
     if (t < N) step(t, ra, rb);
-    if (alive) { cost_new += Obj::terminal_cost(P, x); s_pcost[lane] = cost_new; }
+    if (alive) s_pcost[lane] = Obj::terminal_cost(P, x);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -647,7 +644,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
     d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
   }
-  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0, ys_lo = INFINITY, ys_hi = -INFINITY;
+  double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0, ys_lo = INFINITY, ys_hi = -INFINITY, run_cost = 0.0;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // per-step record of the CURRENT iterate (one prefetch group, <= 16 rows for the C2 layout)
   struct StepIn { double xo[Cons::HAS_X ? NX : 1], s[M], y[M], ksv[M], ky[M], KK[NU * NX], ys[M]; };
@@ -662,6 +659,8 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   };
   typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
   Cons::load(P, cc);
+  typename Obj::Ctx oc;    // running-cost matrices
+  Obj::load(P, oc);
   auto prime = [&]() {   // prime the VMEM queue with one step's store pattern (see the producer)
     double z[M];
 #pragma unroll
@@ -679,20 +678,18 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     PIPELINE_FENCE();
     // take step t from the ring, then hand the slot back
     wait_ge(&s_prod, t + 1);
-    double rx[NX], u[NU];
+    double rx[NX], dx[NX], u[NU];
     {
       const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) rx[i] = rs[i * 64];
+      for (int i = 0; i < NX; ++i) { rx[i] = rs[i * 64]; dx[i] = rs[(NX + i) * 64]; }
 #pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = rs[(NX + i) * 64];
+      for (int i = 0; i < NU; ++i) u[i] = rs[(2 * NX + i) * 64];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (alive && s_pstat[lane] <= t) alive = false;
-    double dx[NX], sn[M], yn[M];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = Cons::HAS_X ? rx[i] - cs.xo[Cons::HAS_X ? i : 0] : rx[i];
+    double sn[M], yn[M];
     bool feas = true;
     // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
     double Gx[M * NX], Gu[M * NU];
@@ -722,7 +719,8 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
     double g[M];
-    Cons::template eval<NX, NU>(cc, rx, u, g);   // rx is x_t whenever a constraint reads the state
+    Cons::template eval<NX, NU>(cc, rx, u, g);
+    run_cost += Obj::running_cost(oc, xrt, t, rx, u);   // same t-ordered sum the fused rollout keeps (:1726-1748)
     st<M>(Gn + GI(t, M, 0), kLS, g);
     // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity, parked exactly as
     // in k_forward_ipddp: the first constraint object's |g+s| terms accumulate in t order right here, the other
@@ -764,7 +762,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   wait_ge(&s_prod, N + kRing + 1);
   if (alive && s_pstat[lane] <= N) alive = false;
   if (!alive) return;
-  const double cost_new = s_pcost[lane];
+  const double cost_new = run_cost + s_pcost[lane];   // + l_f(x_N)
   double total = ev_total0, mer = cost_new;
   const double *evb = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
   const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
