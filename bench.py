@@ -212,14 +212,14 @@ def main():
     n_launch = max(1, st.outer_iterations)
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
     # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
-    # (profiles/r01_c_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
+    # (profiles/r01_d_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
     traffic = None
     traffic_note = None
     if pmc_key and args.workload == "cartpole" and B == 4096 and ipddp:
         try:
-            pj = json.load(open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")))
+            pj = json.load(open(os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")))
             traffic = pj["kernels"][pmc_key]["bytes_per_launch"]
-            traffic_note = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of one solve)"
+            traffic_note = "profiles/r01_d_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of one solve)"
         except Exception:
             traffic = None
     roofline = {
@@ -246,7 +246,8 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "BASELINE config[1]: " + desc + ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
+            "workload": {"cartpole": "BASELINE config[1]: ", "unicycle": "BASELINE config[2]: "}.get(args.workload, "experiment: ") + desc +
+                        ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
             "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": B * world, "nx": p.nx, "nu": p.nu,
             "horizon": p.N, "path_dual_dim": m, "max_iterations": int(p.options.max_iterations),
             "line_search": "first-success rule, %d alphas" % int(p.options.ls_max_iterations),
