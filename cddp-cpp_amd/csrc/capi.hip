@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -485,7 +486,11 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
   // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
   const long waves_all = (long)((d.B + 63) / 64) * na;
-  const bool one_stage = !first_rule || na == 1 || waves_all <= 2048;
+  // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
+  // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
+  const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
+  const bool force_two = ls_env && ls_env[0] == '2';
+  const bool one_stage = !first_rule || na == 1 || (waves_all <= 2048 && !force_two);
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
     ++outer;

@@ -252,3 +252,26 @@ def test_full_solve_parity(api, oracle_built, case):
     assert rel_err(hist[0], oh) < 1e-6
     assert st.n_converged == int(np.sum((ores["status"] == 1) | (ores["status"] == 2)))
     hs.close()
+
+
+@pytest.mark.parametrize("case", ["cartpole_ipddp_box", "unicycle_ipddp_box_ball", "cartpole_clddp_box"])
+def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
+    """The speculative single-launch ladder and the two-stage ladder (alpha_0, then the rest for the trajectories
+    that need them; used when batch x n_alpha overfills the chip) must accept the very same trials."""
+    p = make(api, case)
+    B = 96
+    x0 = api.batch_x0(p, B, 20260931, spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); hs.close()
+        return r, X, U, K, k
+
+    monkeypatch.delenv("CDDP_HIP_LS_STAGES", raising=False)
+    r1, X1, U1, K1, k1 = run()
+    monkeypatch.setenv("CDDP_HIP_LS_STAGES", "2")
+    r2, X2, U2, K2, k2 = run()
+    assert np.array_equal(r1["iterations"], r2["iterations"]) and np.array_equal(r1["status"], r2["status"])
+    assert np.array_equal(r1["final_objective"], r2["final_objective"])
+    assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
