@@ -131,6 +131,39 @@ struct LDLTd {
   }
 };
 
+// NMAX = 2 with static indexing only (the generic form's pivot / transposition arrays are dynamically indexed and
+// land in scratch memory): the same steps as LDLTd<NMAX>::compute / solve written out for n in {0, 1, 2}.
+template <>
+struct LDLTd<2> {
+  double m[4];
+  int n;
+  bool ok, swapped;
+
+  DEV void compute(const double *A, int n_) {
+    n = n_;
+    m[0] = A[0]; m[1] = A[1]; m[2] = A[2]; m[3] = A[3];
+    ok = true; swapped = false;
+    if (n <= 1) return;
+    swapped = fabs(m[3]) > fabs(m[0]);                    // pivot = first largest |diagonal|
+    if (swapped) { const double t = m[0]; m[0] = m[3]; m[3] = t; }
+    const double a00 = m[0];
+    if (!(fabs(a00) > 0.0)) { swapped = false; ok = (m[2] == 0.0); return; }
+    m[2] /= a00;
+    const double temp0 = m[0] * m[2];
+    m[3] -= m[2] * temp0;
+  }
+  DEV void solve(double *x) const {
+    if (n <= 0) return;
+    if (n == 1) { x[0] = (fabs(m[0]) > DBL_MIN) ? x[0] / m[0] : 0.0; return; }
+    if (swapped) { const double v = x[0]; x[0] = x[1]; x[1] = v; }
+    x[1] = x[1] - m[2] * x[0];
+    x[0] = (fabs(m[0]) > DBL_MIN) ? x[0] / m[0] : 0.0;
+    x[1] = (fabs(m[3]) > DBL_MIN) ? x[1] / m[3] : 0.0;
+    x[0] = x[0] - m[2] * x[1];
+    if (swapped) { const double v = x[0]; x[0] = x[1]; x[1] = v; }
+  }
+};
+
 // scalar specialisation: 1x1 LDLT always reports Success; D^+ with tolerance DBL_MIN.
 DEV double ldlt1_solve(double d, double x) { return (fabs(d) > DBL_MIN) ? x / d : 0.0; }
 
