@@ -363,5 +363,350 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
   d.phase[b] = PH_FWD1;
 }
 
+// ================================================================================ cooperative sweep, no path duals
+// The same column-per-lane decomposition for the two sweeps that carry no slack / dual blocks:
+//   CLDDP = true   clddp_solver.cpp:79-204 (regularisation only in the factorised matrix, EigenSolver PD test,
+//                  PartialPivLU inverse or BoxQP + LDLT of the free block, un-symmetrised terminal V_xx)
+//   CLDDP = false  the unconstrained IPDDP branch, ipddp_solver.cpp:1048-1118 (regularised, symmetrised Q_uu kept
+//                  in the value update)
+// Replicated per trajectory group: Q_u, Q_uu, the PD test / factor / BoxQP, k, dV.  Per lane: column qc of T1, T2,
+// Q_xx, Q_ux, K, V_xx and row qc of l_x, Q_x, V_x.  Same sums, same association as the fused per-lane kernels.
+template <class Model, bool CLDDP>
+__global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                            int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  typedef CoopCfg<Model> C;
+  __shared__ double lds[C::TPW * C::STRIDE];
+  const int lane = threadIdx.x;
+  const int q = lane % C::G, tl = lane / C::G;
+  const int qc = q < NX ? q : NX - 1;
+  const int b = blockIdx.x * C::TPW + tl;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  double *Ls = lds + tl * C::STRIDE;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  if (count_iter && q == 0) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const int box = CLDDP ? P->clddp_box : -1;
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0, step_norm = 0;
+  // loop-invariant per-lane constants: column / row qc of Q dt, R dt, the goal state
+  double Qq[NX], Qrow[NX], Rr[NU * NU], xg[NX];
+  {
+    const double *Qp = P->pool + P->off_Qdt, *Rp = P->pool + P->off_Rdt, *xp = P->pool + P->off_xref;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { Qq[i] = Qp[i * NX + qc]; Qrow[i] = Qp[qc * NX + i]; xg[i] = xp[i]; }
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Rr[i] = Rp[i];
+  }
+  for (;;) {
+    ++nb;
+    double Vx[NX], Vc[NX];   // V_x (replicated), V_xx[:, qc]
+    {
+      double xN[NX];
+      ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+      Obj::final_grad(P, xN, Vx);
+      const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        Vc[i] = CLDDP ? 2.0 * Qf[i * NX + qc] : 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
+    }
+    dV0 = 0; dV1 = 0; inf_du = 0; step_norm = 0;
+    {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oVx + i] = Vx[i];
+      lds_sync();
+      d.Vx[GI(N, NX, qc)] = Ls[C::oVx + qc];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) d.Vxx[GI(N, NX * NX, i * NX + qc)] = Vc[i];
+    double norm_Vx = 0.0, Qu_error = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
+    bool fail = false;
+    struct In1 { double A[NX * NX], Aq[NX]; };
+    struct In2 { double Bm[NX * NU], x[NX], u[NU], k0[NU]; };
+    auto load1 = [&](int tt, In1 &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, j * NX + qc)];
+    };
+    auto load2 = [&](int tt, In2 &r) {
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.u);
+      if constexpr (CLDDP) ld<NU>(d.k + GI(tt, NU, 0), kLS, r.k0);   // BoxQP warm start x0 = k_u_[t] of the previous iteration
+    };
+    auto step = [&](const int t, const In1 &c1, const In2 &c2, In1 &n1, In2 &n2) -> bool {
+      const int tp = t > 0 ? t - 1 : 0;
+      load1(tp, n1);
+      PIPELINE_FENCE();
+      const double (&A)[NX * NX] = c1.A; const double (&Bm)[NX * NU] = c2.Bm;
+      // ---- round 1
+      double T1c[NX], T2c[NU], Qu[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += A[k * NX + i] * Vc[k];
+        T1c[i] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Bm[k * NU + u] * Vc[k];
+        T2c[u] = s; }
+      double Qxq;
+      {   // l_x[qc] = sum_j (2 Q dt)[qc, j] e[j]  (objective.cpp:115-131), then + (A^T V_x)[qc]
+        double e[NX];
+        if (xrt) {
+          cptr_t r = uniform_ptr(xrt + (size_t)t * NX);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) e[i] = c2.x[i] - r[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) e[i] = c2.x[i] - xg[i];
+        }
+        double lxq = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) lxq += (2.0 * Qrow[j]) * e[j];
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += c1.Aq[k] * Vx[k];
+        Qxq = lxq + s2;
+      }
+      Obj::lu(P, c2.u, Qu);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + u] * Vx[k];
+        Qu[u] = Qu[u] + s2; }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
+      lds_sync();
+      __builtin_amdgcn_sched_barrier(0);
+      load2(tp, n2);
+      PIPELINE_FENCE();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- round 2
+      double T1[NX * NX], T2[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+      double Qxxc[NX], Quxc[NU], Quu[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += T1[i * NX + j] * c1.Aq[j];
+        Qxxc[i] = (2.0 * Qq[i]) + s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * c1.Aq[j];
+        Quxc[u] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < NU; ++v) { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * Bm[j * NU + v];
+          Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
+      double kk[NU], KKc[NU];
+      if constexpr (CLDDP) {
+        double Quu_reg[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu_reg[i] = Quu[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Quu_reg[i * NU + i] += reg;
+        if (min_real_eig<NU>(Quu_reg) <= 0) return false;   // clddp_solver.cpp:133-140
+        if (box < 0) {   // clddp_solver.cpp:142-145
+          double H[NU * NU];
+          inverse_pplu<NU>(Quu_reg, H);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) {
+            double s = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { s += (-H[i * NU + j]) * Qu[j]; s2 += (-H[i * NU + j]) * Quxc[j]; }
+            kk[i] = s; KKc[i] = s2;
+          }
+        } else {         // clddp_solver.cpp:147-178
+          const ConDev &cc = P->cons[box];
+          double lb[NU], ub[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - c2.u[i]; ub[i] = P->pool[cc.off_upper + i] - c2.u[i]; }
+#pragma unroll
+          for (int i = 0; i < NU; ++i) kk[i] = c2.k0[i];
+          int free_[NU];
+          LDLTd<NU> Hfree;
+          const int stq = boxqp_solve<NU>(o, Quu_reg, Qu, lb, ub, kk, free_, Hfree);
+          if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KKc[i] = 0.0;
+          int free_idx[NU]; int nf = 0;
+          for (int i = 0; i < NU; ++i) if (free_[i]) free_idx[nf++] = i;
+          if (nf > 0) {
+            double col[NU];
+            for (int i = 0; i < nf; ++i) col[i] = Quxc[free_idx[i]];
+            Hfree.solve(col);
+            for (int i = 0; i < nf; ++i) KKc[free_idx[i]] = -col[i];
+          }
+        }
+      } else {
+        // regularisation stays in Q_uu (ipddp_solver.cpp:1084-1107)
+        double Qs[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qs[i * NU + i] += reg;
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+        if (NU == 1) {
+          kk[0] = -ldlt1_solve(Qs[0], Qu[0]);
+          KKc[0] = -ldlt1_solve(Qs[0], Quxc[0]);
+        } else {
+          LDLTd<NU> f;
+          f.compute(Qs, NU);
+          if (!f.ok) return false;
+          double col[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Quxc[i];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxc[u]; }
+      lds_sync();
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+      // ---- round 3: value update
+      double KK[NU * NX], Qux[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s1; }
+      { double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { s0 += CLDDP ? Qu[i] * kk[i] : kk[i] * Qu[i]; s1 += kk[i] * Quuk[i]; }
+        dV0 += s0; dV1 += 0.5 * s1; }
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+      double KtQq[NU];   // row qc of K^T Q_uu from the lane's own column (same expression as mm_tn)
+#pragma unroll
+      for (int j = 0; j < NU; ++j) { double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
+        KtQq[j] = s; }
+      double Vxq, Vnc[NX];
+      if constexpr (CLDDP) {   // clddp_solver.cpp:187-191
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KtQq[j] * kk[j]; bb += Quxc[j] * kk[j]; c += KKc[j] * Qu[j]; }
+        Vxq = ((Qxq + a) + bb) + c;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double a2 = 0.0, b2 = 0.0, e2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a2 += KtQ[i * NU + j] * KKc[j]; b2 += Qux[j * NX + i] * KKc[j]; e2 += KK[j * NX + i] * Quxc[j]; }
+          Vnc[i] = ((Qxxc[i] + a2) + b2) + e2;
+        }
+      } else {                 // ipddp_solver.cpp:1098-1107
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxc[j] * kk[j]; c += KtQq[j] * kk[j]; }
+        Vxq = ((Qxq + a) + bb) + c;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double a2 = 0.0, b2 = 0.0, e2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a2 += KK[j * NX + i] * Quxc[j]; b2 += Qux[j * NX + i] * KKc[j]; e2 += KtQ[i * NU + j] * KKc[j]; }
+          Vnc[i] = ((Qxxc[i] + a2) + b2) + e2;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oVn + i * NX + qc] = Vnc[i];
+      Ls[C::oVx + qc] = Vxq;
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * (Vnc[i] + Ls[C::oVn + qc * NX + i]);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vx[i] = Ls[C::oVx + i];
+      lds_sync();
+      d.Vx[GI(t, NX, qc)] = Vxq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+      if constexpr (CLDDP) {
+        double sN = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sN += fabs(Vx[i]);
+        norm_Vx += sN;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qu_error = dmax(Qu_error, fabs(Qu[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+      }
+      return true;
+    };
+    In1 a1, b1;
+    In2 a2, b2;
+    load1(N - 1, a1);
+    load2(N - 1, a2);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      if (!step(t, a1, a2, b1, b2)) { fail = true; break; }
+      if (!step(t - 1, b1, b2, a1, a2)) { fail = true; break; }
+    }
+    if (!fail && t == 0) fail = !step(0, a1, a2, b1, b2);
+    if (!fail) {
+      if constexpr (CLDDP) {
+        double scaling = o.termination_scaling_max_factor;
+        scaling = dmax(scaling, norm_Vx / (N * NX)) / scaling;
+        inf_du = Qu_error / scaling;
+      }
+      ok = true;
+      break;
+    }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  if (q != 0) return;
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du;
+    if constexpr (!CLDDP) { d.step_norm[b] = step_norm; d.inf_pr[b] = 0.0; d.inf_comp[b] = 0.0; d.apr_max[b] = 1.0; d.adu_max[b] = 1.0; }
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  const bool conv = CLDDP ? (inf_du < o.tolerance)                      // clddp_solver.cpp:206-213
+                          : (0.0 < o.tolerance && inf_du < o.tolerance);  // ipddp_solver.cpp:925-958, no barrier
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, CLDDP ? 0.0 : d.mu[b]); return; }
+  d.phase[b] = PH_FWD1;
+}
+
 #undef GI
 }  // namespace cddp_dev

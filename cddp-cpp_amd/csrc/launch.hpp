@@ -36,17 +36,26 @@ struct Launcher {
     }
   }
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
-    if (solver == CDDP_HIP_SOLVER_CLDDP)
-      hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-    else if constexpr (kLean) {
-      // lane-cooperative sweep (kernels_coop.hpp); CDDP_HIP_SWEEP=lane selects the one-lane-per-trajectory sweep
-      static const bool lane_sweep = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
+    // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
+    // one-lane-per-trajectory kernels instead (comparison / experiments)
+    static const bool lane_sweep = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
+    const dim3 gridC((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW);
+    if (solver == CDDP_HIP_SOLVER_CLDDP) {
+      if (lane_sweep)
+        hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else
+        hipLaunchKernelGGL((k_backward_coop_plain<Model, true>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+    } else if constexpr (kLean) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       else
-        hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), dim3((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW), dim3(64), 0, s,
-                           d, d.P, d.xref_traj, force, count_iter);
+        hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
+    } else if constexpr (!TERM && Cons::M == 0) {
+      if (lane_sweep)
+        hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else
+        hipLaunchKernelGGL((k_backward_coop_plain<Model, false>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
     } else
       hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
   }
