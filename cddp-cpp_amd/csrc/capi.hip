@@ -65,6 +65,8 @@ struct cddp_hip_handle {
   double *d_Xinit = nullptr, *d_Uinit = nullptr;   // initial trajectory kept on the device so solve() is repeatable
   bool have_initial = false;
   bool initialized = false;
+  bool has_state = false;        // gains / duals of an earlier initialize() or solve() live on the device (warm start)
+  bool initial_dirty = false;    // set_initial() since the last initialize(): the caller supplied a new trajectory
   size_t bytes = 0;
 };
 
@@ -98,7 +100,6 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
   if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP) return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
   if (!p->options.use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
-  if (p->options.warm_start) return fail(-3, "warm_start is not supported by the HIP core yet");
   P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
   P.nx = p->nx; P.nu = p->nu; P.N = p->horizon; P.dt = p->dt; P.opt = p->options;
   P.ls_rule = p->options.enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
@@ -397,16 +398,108 @@ int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_initial = true;
   h->initialized = false;
+  h->initial_dirty = true;
+  return 0;
+}
+
+// ISolverAlgorithm::initialize on this handle (the handle IS the solver object).  Cold: the initial trajectory is
+// restored and everything re-initialised.  options.warm_start: "provided trajectory" on a fresh handle, "existing
+// solver state" afterwards -- the live slack / dual / costate rows are staged into slot 0 (and X, U too unless the
+// caller supplied a new trajectory since), see k_init.
+static int run_initialize(cddp_hip_handle *h) {
+  const bool ip = (h->P.solver == CDDP_HIP_SOLVER_IPDDP);
+  int mode = kInitCold;
+  if (h->P.opt.warm_start) mode = h->has_state ? kInitWarmExisting : kInitWarmProvided;
+  if (mode == kInitWarmExisting) {
+    h->ks->stage(h->d, h->initial_dirty ? 0 : 1, ip ? 1 : 0, h->stream);
+    if (h->initial_dirty) { int rc = restore_initial(h); if (rc) return rc; }
+  } else {
+    int rc = restore_initial(h); if (rc) return rc;
+  }
+  h->ks->init(h->d, mode, h->stream);
+  h->has_state = true;
+  h->initial_dirty = false;
+  h->initialized = true;
   return 0;
 }
 
 int cddp_hip_initialize(cddp_hip_handle *h) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
-  { int rc = restore_initial(h); if (rc) return rc; }
-  h->ks->init(h->d, h->stream);
+  { int rc = run_initialize(h); if (rc) return rc; }
   HIPCHK(hipGetLastError());
-  h->initialized = true;
+  return 0;
+}
+
+int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *opt) {
+  if (!h || !opt) return fail(-1, "null argument");
+  if (!opt->use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
+  HIPCHK(hipSetDevice(h->device));
+  double al[CDDP_HIP_MAX_ALPHAS];
+  const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);
+  if (na != h->P.n_alphas) return fail(-3, "the line-search ladder size is fixed at create time (%d alphas, new options give %d)", h->P.n_alphas, na);
+  if (opt->max_iterations > h->P.opt.max_iterations && h->P.opt.return_iteration_info)
+    return fail(-3, "max_iterations cannot grow on a handle created with return_iteration_info (history capacity)");
+  h->P.opt = *opt;
+  for (int i = 0; i < na; ++i) h->P.alphas[i] = al[i];
+  h->P.ls_rule = opt->enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
+  HIPCHK(hipMemcpyAsync(h->dP, &h->P, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0) {
+  if (!h || !x0) return fail(-1, "null argument");
+  if (!h->have_initial) return fail(-1, "cddp_hip_set_initial must be called once before cddp_hip_set_initial_state");
+  HIPCHK(hipSetDevice(h->device));
+  const DevBuf &d = h->d;
+  const int B = d.B, Bp = d.Bp, nx = h->P.nx;
+  // the t = 0 record of every tile is the first NB * nx * 64 doubles of an X plane
+  std::vector<double> row((size_t)d.NB * nx * 64, 0.0);
+  for (int b = 0; b < B; ++b)
+    for (int e = 0; e < nx; ++e) row[tix(0, nx, e, b, Bp)] = x0[(size_t)b * nx + e];
+  for (int sl = 0; sl < d.n_slots; ++sl)
+    HIPCHK(hipMemcpyAsync(d.X + (size_t)sl * d.planeX, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_Xinit, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->initialized = false;
+  return 0;
+}
+
+int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) {
+  if (!h) return fail(-1, "null handle");
+  if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m <= 0) return fail(-1, "cddp_hip_set_duals: the problem has no path duals");
+  if (!h->has_state) return fail(-1, "cddp_hip_set_duals needs an initialised handle (call cddp_hip_initialize or cddp_hip_solve first)");
+  HIPCHK(hipSetDevice(h->device));
+  const DevBuf &d = h->d;
+  std::vector<double> buf(d.planeM);
+  const double *src[2] = {S, Y};
+  double *dst[2] = {d.S, d.Y};
+  for (int k = 0; k < 2; ++k) {
+    if (!src[k]) continue;
+    std::fill(buf.begin(), buf.end(), 0.0);
+    to_soa(src[k], buf.data(), d.B, d.Bp, d.N, h->P.m);
+    for (int sl = 0; sl < d.n_slots; ++sl)   // the live slot differs per trajectory: every slot gets the rows
+      HIPCHK(hipMemcpyAsync(dst[k] + (size_t)sl * d.planeM, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T) {
+  if (!h) return fail(-1, "null handle");
+  if (h->P.n_term <= 0) return fail(-1, "cddp_hip_set_terminal: the problem has no terminal constraints");
+  if (!h->has_state) return fail(-1, "cddp_hip_set_terminal needs an initialised handle");
+  HIPCHK(hipSetDevice(h->device));
+  const DevBuf &d = h->d;
+  struct { const double *host; double *dev; int n; } items[] = {{S_T, d.ST, h->P.mT}, {Y_T, d.YT, h->P.mT}, {Lambda_T, d.LamT, h->P.pT}};
+  for (auto &it : items) {
+    if (!it.host || it.n <= 0) continue;
+    std::vector<double> buf((size_t)it.n * d.Bp, 0.0);
+    for (int b = 0; b < d.B; ++b) for (int i = 0; i < it.n; ++i) buf[(size_t)i * d.Bp + b] = it.host[(size_t)b * it.n + i];
+    HIPCHK(hipMemcpyAsync(it.dev, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   return 0;
 }
 
@@ -475,9 +568,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
   HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
   HIPCHK(hipEventRecord(ev0, s));
-  { int rc = restore_initial(h); if (rc) return rc; }
-  ks->init(d, s);
-  h->initialized = true;
+  { int rc = run_initialize(h); if (rc) return rc; }
   int launches = 1, outer = 0;
   int *h_active = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_active, sizeof(int)));

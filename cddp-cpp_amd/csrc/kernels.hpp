@@ -1761,8 +1761,63 @@ count:
 // ISolverAlgorithm::initialize.  CLDDP: cost of the given (X,U) (clddp_solver.cpp:68-74).
 // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, s/y initialisation,
 // cost, filter reset.
+// mode: kInitCold = fresh solver object (clddp_solver.cpp:62-74, ipddp_solver.cpp:819-913);
+//       kInitWarmProvided = options.warm_start with NO solver state ("warm start with provided trajectory",
+//                           ipddp_solver.cpp:733-816; CLDDP falls back to the cold start, clddp_solver.cpp:61-66);
+//       kInitWarmExisting = options.warm_start on a handle that already holds gains / duals ("existing solver state",
+//                           ipddp_solver.cpp:675-731, clddp_solver.cpp:51-60): the staged slack / dual / costate /
+//                           terminal variables are kept (per-constraint re-initialisation test + interior repair,
+//                           :264-292, 2345-2426), context scalars (regularisation, step lengths, inf_du) persist.
+enum { kInitCold = 0, kInitWarmProvided = 1, kInitWarmExisting = 2 };
+
+// repairWarmstartInterior (ipddp_solver.cpp:233-262) on one constraint object's slack / dual vector
+DEV void repair_interior(const cddp_hip_options &o, double *s, double *y, int dim) {
+  if (!o.ipddp_warmstart_repair) return;
+  double mn = INFINITY, mny = INFINITY;
+  for (int i = 0; i < dim; ++i) { s[i] = dmax(s[i], o.ipddp_warmstart_s_min); mn = dmin(mn, s[i]); }
+  if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) s[i] *= o.ipddp_warmstart_interior_factor;
+  for (int i = 0; i < dim; ++i) { y[i] = dmax(y[i], o.ipddp_warmstart_y_min); mny = dmin(mny, y[i]); }
+  if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) y[i] *= o.ipddp_warmstart_interior_factor;
+}
+// warmstartNeedsReinit (ipddp_solver.cpp:264-292)
+DEV bool needs_reinit(const cddp_hip_options &o, const double *y, const double *s, const double *g, int dim) {
+  for (int i = 0; i < dim; ++i) if (!dfinite(y[i]) || !dfinite(s[i])) return true;
+  for (int i = 0; i < dim; ++i) {
+    if (y[i] <= 1e-10 || s[i] <= kEpsSlack) return true;
+    const double required = dmax(o.ipddp_slack_var_init_scale, -g[i] + kSlackInteriorOffset);
+    if (s[i] < 0.1 * required) return true;
+  }
+  return false;
+}
+
+// Stage the live iterate of every trajectory into slot 0 before a warm re-initialisation: slack / dual / costate rows
+// always, X / U rows unless the caller supplied a new initial trajectory (copy_xu = 0).
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_stage(DevBuf d, int copy_xu, int ipddp) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  const int cur = d.cur[b];
+  if (cur == 0) return;
+  if (copy_xu) {
+    for (int i = 0; i < NX; ++i) d.X[GI(t, NX, i)] = d.X[(size_t)cur * d.planeX + GI(t, NX, i)];
+    if (t < d.N) for (int i = 0; i < NU; ++i) d.U[GI(t, NU, i)] = d.U[(size_t)cur * d.planeU + GI(t, NU, i)];
+  }
+  if (ipddp) {
+    for (int i = 0; i < NX; ++i) d.Lam[GI(t, NX, i)] = d.Lam[(size_t)cur * d.planeX + GI(t, NX, i)];
+    if constexpr (M > 0) {
+      if (t < d.N)
+        for (int i = 0; i < M; ++i) {
+          d.S[GI(t, M, i)] = d.S[(size_t)cur * d.planeM + GI(t, M, i)];
+          d.Y[GI(t, M, i)] = d.Y[(size_t)cur * d.planeM + GI(t, M, i)];
+        }
+    }
+  }
+}
+
 template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt) {
+__global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int mode) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef Objective<NX, NU> Obj;
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -1771,13 +1826,15 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
+  const bool existing = (mode == kInitWarmExisting);
   d.cur[b] = 0;
   double *X0 = d.X, *U0 = d.U;
   d.iter[b] = 0; d.status[b] = CDDP_HIP_STATUS_RUNNING; d.phase[b] = PH_ACTIVE;
   d.n_bwd[b] = 0; d.n_fwd[b] = 0; d.bwd_ok[b] = 0; d.filt_n[b] = 0;
   if (b < d.hist_batch) d.hist_n[b] = 0;
-  d.reg[b] = o.reg_initial_value;
-  d.dV0[b] = 0.0; d.dV1[b] = 0.0; d.step_norm[b] = 0.0;
+  if (!existing) d.reg[b] = o.reg_initial_value;
+  d.dV0[b] = 0.0; d.dV1[b] = 0.0;
+  if (!(existing && !ipddp)) d.step_norm[b] = 0.0;
   d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
   double x[NX];
   ld<NX>(X0 + GI(0, NX, 0), kLS, x);
@@ -1788,27 +1845,98 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
       ld<NX>(X0 + GI(t, NX, 0), kLS, xt);
       ld<NU>(U0 + GI(t, NU, 0), kLS, u);
       cost += Obj::running_cost(P, xrt, t, xt, u);
-      double z[NU];
+      if (!existing) {
+        double z[NU];
 #pragma unroll
-      for (int i = 0; i < NU; ++i) z[i] = 0.0;
-      st<NU>(d.k + GI(t, NU, 0), kLS, z);     // initializeGains: k_u_ = 0 (BoxQP warm start)
+        for (int i = 0; i < NU; ++i) z[i] = 0.0;
+        st<NU>(d.k + GI(t, NU, 0), kLS, z);     // initializeGains: k_u_ = 0 (BoxQP warm start)
+      }
     }
     double xN[NX];
     ld<NX>(X0 + GI(N, NX, 0), kLS, xN);
     cost += Obj::terminal_cost(P, xN);
     d.cost[b] = cost; d.merit[b] = cost;
-    d.inf_pr[b] = INFINITY; d.inf_du[b] = INFINITY; d.inf_comp[b] = INFINITY;   // cddp_core.cpp:297-301
-    d.alpha_pr[b] = o.ls_initial_step_size; d.alpha_du[b] = 0.0; d.mu[b] = 0.0;
+    if (!existing) {
+      d.inf_pr[b] = INFINITY; d.inf_du[b] = INFINITY; d.inf_comp[b] = INFINITY;   // cddp_core.cpp:297-301
+      d.alpha_pr[b] = o.ls_initial_step_size; d.alpha_du[b] = 0.0; d.mu[b] = 0.0;
+    }
     d.phi[b] = cost; d.theta[b] = 0.0; d.filter_theta[b] = 0.0;
     hist_push(d, b, 0.0);
     return;
   }
   const int mT = TERM ? P->mT : 0, pT = TERM ? P->pT : 0;
-  // mu_ = constraint_set.empty() && terminal set empty ? max(tol/10, mu_min) : mu_initial   (ipddp_solver.cpp:876-879)
-  const double mu = (M == 0 && !(TERM && P->n_term > 0)) ? dmax(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
-  d.mu[b] = mu;
-  d.alpha_pr[b] = 1.0; d.alpha_du[b] = 1.0;
+  const bool unconstrained = (M == 0 && !(TERM && P->n_term > 0));
+  // mu_ = constraint_set.empty() && terminal set empty ? max(tol/10, mu_min) : mu_initial   (ipddp_solver.cpp:876-879);
+  // existing solver state: 0.1 mu_initial (:684); provided trajectory: from the largest violation (:777-803, below)
+  double mu = unconstrained ? dmax(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
+  if (existing) mu = o.barrier_mu_initial * 0.1;
+  if (!existing) { d.alpha_pr[b] = 1.0; d.alpha_du[b] = 1.0; }
   double *S0 = d.S, *Y0 = d.Y, *G0 = d.G, *L0 = d.Lam;
+  if (mode != kInitCold) {
+    // ---- warm start: rollout + evaluateTrajectoryWarmStart (:2296-2343) first, mu next, the interior after that
+    double maxviol = 0.0;
+    for (int t = 0; t < N; ++t) {
+      double u[NU], xn[NX];
+      ld<NU>(U0 + GI(t, NU, 0), kLS, u);
+      cost += Obj::running_cost(P, xrt, t, x, u);
+      if constexpr (M > 0) {
+        double g[MM];
+        Cons::template eval<NX, NU>(P, x, u, g);
+#pragma unroll
+        for (int i = 0; i < M; ++i) maxviol = dmax(maxviol, g[i]);
+        st<M>(G0 + GI(t, M, 0), kLS, g);
+      }
+      if (!existing) {
+        double z[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) z[i] = 0.0;
+        st<NX>(L0 + GI(t, NX, 0), kLS, z);
+      }
+      Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+      st<NX>(X0 + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+    if (!existing) {
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      st<NX>(L0 + GI(N, NX, 0), kLS, z);
+    }
+    cost += Obj::terminal_cost(P, x);
+    if constexpr (TERM) {
+      double gT[kMTMax];
+      term_ineq_eval<NX>(P, x, gT);
+      for (int i = 0; i < mT; ++i) maxviol = dmax(maxviol, gT[i]);
+    }
+    if (mode == kInitWarmProvided && !unconstrained) {   // :786-803
+      if (maxviol <= o.tolerance) mu = dmax(o.tolerance, o.barrier_mu_min_value);
+      else if (maxviol <= 0.1) mu = dmax(o.tolerance * 10.0, o.barrier_mu_initial * 0.01);
+      else mu = o.barrier_mu_initial * 0.1;
+    }
+    // the provided-trajectory branch never evaluates the cost of an unconstrained problem (:777-781): it stays +inf
+    if (mode == kInitWarmProvided && unconstrained) cost = INFINITY;
+    if constexpr (M > 0) {
+      __threadfence_block();
+      for (int t = 0; t < N; ++t) {   // initializeDualSlackVariablesWarmStart (:2345-2426)
+        double g[MM], s[MM], y[MM];
+        ld<M>(G0 + GI(t, M, 0), kLS, g);
+        if (existing) { ld<M>(S0 + GI(t, M, 0), kLS, s); ld<M>(Y0 + GI(t, M, 0), kLS, y); }
+        for (int c = 0; c < Cons::NSEG; ++c) {
+          const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+          const bool need = !existing || needs_reinit(o, y + off, s + off, g + off, dim);
+          if (need)
+            for (int i = 0; i < dim; ++i) {
+              s[off + i] = dmax(o.ipddp_slack_var_init_scale, -g[off + i] + kSlackInteriorOffset);
+              y[off + i] = (mu * o.ipddp_dual_var_init_scale) / dmax(s[off + i], kEpsSlack);
+            }
+          repair_interior(o, s + off, y + off, dim);
+        }
+        st<M>(S0 + GI(t, M, 0), kLS, s);
+        st<M>(Y0 + GI(t, M, 0), kLS, y);
+      }
+    }
+  } else {
   for (int t = 0; t < N; ++t) {
     double u[NU], xn[NX];
     ld<NU>(U0 + GI(t, NU, 0), kLS, u);
@@ -1821,16 +1949,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
         s[i] = dmax(o.ipddp_slack_var_init_scale, -g[i] + kSlackInteriorOffset);
         y[i] = (mu * o.ipddp_dual_var_init_scale) / dmax(s[i], kEpsSlack);
       }
-      if (o.ipddp_warmstart_repair) {   // repairWarmstartInterior (:233-262), per constraint object
-        for (int c = 0; c < Cons::NSEG; ++c) {
-          const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
-          double mn = INFINITY, mny = INFINITY;
-          for (int i = 0; i < dim; ++i) { s[off + i] = dmax(s[off + i], o.ipddp_warmstart_s_min); mn = dmin(mn, s[off + i]); }
-          if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) s[off + i] *= o.ipddp_warmstart_interior_factor;
-          for (int i = 0; i < dim; ++i) { y[off + i] = dmax(y[off + i], o.ipddp_warmstart_y_min); mny = dmin(mny, y[off + i]); }
-          if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) y[off + i] *= o.ipddp_warmstart_interior_factor;
-        }
-      }
+      for (int c = 0; c < Cons::NSEG; ++c) repair_interior(o, s + Cons::seg_off(c), y + Cons::seg_off(c), Cons::seg_dim(c));
       st<M>(G0 + GI(t, M, 0), kLS, g);
       st<M>(S0 + GI(t, M, 0), kLS, s);
       st<M>(Y0 + GI(t, M, 0), kLS, y);
@@ -1851,6 +1970,8 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
     st<NX>(L0 + GI(N, NX, 0), kLS, z);
   }
   cost += Obj::terminal_cost(P, x);
+  }
+  d.mu[b] = mu;
   d.cost[b] = cost;
   // resetFilter (ipddp_solver.cpp:2484-2519)
   double phi = cost, theta = 0.0, ipr = 0.0, icomp = 0.0;
@@ -1858,27 +1979,29 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
     // terminal slack / dual initialisation (ipddp_solver.cpp:889-908) and multipliers (:829-830)
     TermState ts;
     term_ineq_eval<NX>(P, x, ts.g);
-    for (int c = 0; c < P->n_term; ++c) {
+    if (existing) for (int i = 0; i < mT; ++i) { ts.s[i] = d.ST[(size_t)i * d.Bp + b]; ts.y[i] = d.YT[(size_t)i * d.Bp + b]; }
+    for (int c = 0; c < P->n_term; ++c) {   // cold :889-908 / initializeTerminalWarmstartDualSlack :294-353
       const TermDev &td = P->terms[c];
       if (td.kind != CDDP_HIP_TERM_INEQUALITY) continue;
-      double mn = INFINITY, mny = INFINITY;
-      for (int r = 0; r < td.dim; ++r) {
-        const int j = td.offset + r;
-        ts.s[j] = dmax(o.ipddp_slack_var_init_scale, -ts.g[j] + kSlackInteriorOffset);
-        ts.y[j] = (mu * o.ipddp_dual_var_init_scale) / dmax(ts.s[j], kEpsSlack);
-      }
-      if (o.ipddp_warmstart_repair) {
-        for (int r = 0; r < td.dim; ++r) { const int j = td.offset + r; ts.s[j] = dmax(ts.s[j], o.ipddp_warmstart_s_min); mn = dmin(mn, ts.s[j]); }
-        if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int r = 0; r < td.dim; ++r) ts.s[td.offset + r] *= o.ipddp_warmstart_interior_factor;
-        for (int r = 0; r < td.dim; ++r) { const int j = td.offset + r; ts.y[j] = dmax(ts.y[j], o.ipddp_warmstart_y_min); mny = dmin(mny, ts.y[j]); }
-        if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int r = 0; r < td.dim; ++r) ts.y[td.offset + r] *= o.ipddp_warmstart_interior_factor;
-      }
+      const bool need = !existing || needs_reinit(o, ts.y + td.offset, ts.s + td.offset, ts.g + td.offset, td.dim);
+      if (need)
+        for (int r = 0; r < td.dim; ++r) {
+          const int j = td.offset + r;
+          ts.s[j] = dmax(o.ipddp_slack_var_init_scale, -ts.g[j] + kSlackInteriorOffset);
+          ts.y[j] = (mu * o.ipddp_dual_var_init_scale) / dmax(ts.s[j], kEpsSlack);
+        }
+      repair_interior(o, ts.s + td.offset, ts.y + td.offset, td.dim);
     }
     for (int i = 0; i < mT; ++i) {
       d.GT[(size_t)i * d.Bp + b] = ts.g[i]; d.ST[(size_t)i * d.Bp + b] = ts.s[i]; d.YT[(size_t)i * d.Bp + b] = ts.y[i];
       d.dST[(size_t)i * d.Bp + b] = 0.0; d.dYT[(size_t)i * d.Bp + b] = 0.0;
     }
-    for (int i = 0; i < pT; ++i) { ts.lam[i] = 0.0; d.LamT[(size_t)i * d.Bp + b] = 0.0; d.dLamT[(size_t)i * d.Bp + b] = 0.0; }
+    for (int i = 0; i < pT; ++i) {   // multipliers: zero, or kept when finite under a warm start with solver state (:355-366)
+      double lam = existing ? d.LamT[(size_t)i * d.Bp + b] : 0.0;
+      ts.lam[i] = lam;
+    }
+    if (existing) { bool fin = true; for (int i = 0; i < pT; ++i) fin = fin && dfinite(ts.lam[i]); if (!fin) for (int i = 0; i < pT; ++i) ts.lam[i] = 0.0; }
+    for (int i = 0; i < pT; ++i) { d.LamT[(size_t)i * d.Bp + b] = ts.lam[i]; d.dLamT[(size_t)i * d.Bp + b] = 0.0; }
     term_eq_residual<NX>(P, x, ts.h);
     __threadfence_block();
     ip_reductions<Cons>(d, b, N, S0, Y0, G0, mu, cost, o.ipddp_theta_norm_l2 != 0, phi, theta, ipr, icomp, &ts, mT, pT);
@@ -1889,7 +2012,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
   const double ft = dmax(theta, 1e-8);
   d.filter_theta[b] = ft;
   d.theta[b] = dmax(ft, dmax(o.ipddp_theta_0_floor, 1e-8));
-  d.inf_du[b] = 0.0;
+  if (!existing) d.inf_du[b] = 0.0;
   if constexpr (TERM) { if (mT > 0 || pT > 0) filter_accept(d, b, phi, ft); }   // resetFilter seeds the filter (:2513-2516)
   hist_push(d, b, mu);
 }

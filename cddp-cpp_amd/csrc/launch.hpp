@@ -17,7 +17,8 @@ struct KernelSet {
   void (*forward)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t);
   void (*costate)(const DevBuf &, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t);
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
-  void (*init)(const DevBuf &, hipStream_t);
+  void (*init)(const DevBuf &, int mode, hipStream_t);
+  void (*stage)(const DevBuf &, int copy_xu, int ipddp, hipStream_t);
 };
 
 template <class Model, class Cons, bool TERM = false>
@@ -82,14 +83,17 @@ struct Launcher {
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
   }
-  static void init(const DevBuf &d, hipStream_t s) {
-    hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj);
+  static void init(const DevBuf &d, int mode, hipStream_t s) {
+    hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
+  }
+  static void stage(const DevBuf &d, int copy_xu, int ipddp, hipStream_t s) {
+    hipLaunchKernelGGL((k_stage<Model, Cons>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, copy_xu, ipddp);
   }
   static KernelSet set(const char *name) {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size();
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage;
     return k;
   }
 };

@@ -443,6 +443,24 @@ class Oracle:
     def initialize(self):
         self.lib.cddp_oracle_initialize(self.h)
 
+    # ---- warm-start plumbing (reference: options.warm_start, IPDDPSolverTestAccess, setInitialState/Trajectory)
+    def set_warm_start(self, flag=True):
+        self.lib.cddp_oracle_set_warm_start(self.h, 1 if flag else 0)
+
+    def set_path_interior(self, s_val, y_val):
+        self.lib.cddp_oracle_set_path_interior(self.h, C.c_double(s_val), C.c_double(y_val))
+
+    def set_terminal_interior(self, s_val, y_val):
+        self.lib.cddp_oracle_set_terminal_interior(self.h, C.c_double(s_val), C.c_double(y_val))
+
+    def set_terminal_eq_multiplier(self, lam):
+        lam = _arr(lam)
+        self.lib.cddp_oracle_set_terminal_eq_multiplier(self.h, _ptr(lam))
+
+    def update_initial(self, x0, U0=None):
+        x0 = _arr(x0); U0 = _arr(U0) if U0 is not None else None
+        self.lib.cddp_oracle_update_initial(self.h, _ptr(x0), _ptr(U0))
+
     def backward(self, retry=True):
         return self.lib.cddp_oracle_backward(self.h, 1 if retry else 0)
 
@@ -585,7 +603,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
-    "cddp_hip_backward_stacks",
+    "cddp_hip_backward_stacks", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 
@@ -628,6 +646,26 @@ class HipBatchSolver:
 
     def initialize(self):
         self._check(self.lib.cddp_hip_initialize(self.h))
+
+    # ---- warm start / MPC restarts
+    def set_options(self, options):
+        self._check(self.lib.cddp_hip_set_options(self.h, C.byref(options)))
+
+    def set_warm_start(self, flag=True):
+        self.p.options.warm_start = 1 if flag else 0
+        self.set_options(self.p.options)
+
+    def set_initial_state(self, x0):
+        x0 = _arr(x0).reshape(self.B, self.p.nx)
+        self._check(self.lib.cddp_hip_set_initial_state(self.h, _ptr(x0)))
+
+    def set_duals(self, S=None, Y=None):
+        S = _arr(S) if S is not None else None; Y = _arr(Y) if Y is not None else None
+        self._check(self.lib.cddp_hip_set_duals(self.h, _ptr(S), _ptr(Y)))
+
+    def set_terminal_state(self, S_T=None, Y_T=None, Lambda_T=None):
+        a = [(_arr(v) if v is not None else None) for v in (S_T, Y_T, Lambda_T)]
+        self._check(self.lib.cddp_hip_set_terminal(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])))
 
     def backward(self):
         ok = np.zeros(self.B, dtype=np.int32)

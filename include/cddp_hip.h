@@ -293,9 +293,30 @@ int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream);
 int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
                          const double *X0);
 
-/* ISolverAlgorithm::initialize for the batch (clddp_solver.cpp:28-75,
- * ipddp_solver.cpp:644-914 cold-start path). */
+/* ISolverAlgorithm::initialize for the batch (clddp_solver.cpp:28-75, ipddp_solver.cpp:644-914).
+ * The handle is the solver object: with options.warm_start the first call takes the reference's "warm start
+ * with provided trajectory" branch (ipddp_solver.cpp:733-816; CLDDP falls back to its cold start), every later
+ * call the "existing solver state" branch (ipddp_solver.cpp:675-731, clddp_solver.cpp:51-60): gains, slack /
+ * dual / costate / terminal variables, regularisation and step lengths persist on the device, X is re-rolled
+ * out from the current (or newly supplied) controls.  Without warm_start every call is a cold start from the
+ * trajectory of the last cddp_hip_set_initial. */
 int cddp_hip_initialize(cddp_hip_handle *h);
+
+/* CDDP::setOptions on a live handle (e.g. to switch warm_start on between two solves).  The line-search
+ * ladder size is fixed at create time. */
+int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *options);
+
+/* CDDP::setInitialState for the batch: x0[b][i] only; controls, duals and gains on the device are kept
+ * (the MPC restart of SURVEY.md 8(f1)).  cddp_hip_set_initial additionally replaces the trajectory
+ * (CDDP::setInitialTrajectory). */
+int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0);
+
+/* Overwrite the path slack / dual variables S[b][t][m], Y[b][t][m] (either may be NULL) and the terminal
+ * slack / dual / multipliers S_T[b][mT], Y_T[b][mT], Lambda_T[b][pT] of an initialised handle: the
+ * reference's IPDDPSolverTestAccess::setPathInterior / setTerminalInterior / setTerminalEqualityMultiplier,
+ * and the hook for callers that shift duals between MPC solves. */
+int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y);
+int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T);
 
 /* One backwardPass for every trajectory (clddp_solver.cpp:79-204 / ipddp_solver.cpp:960-1569),
  * including the "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111.

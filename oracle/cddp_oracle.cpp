@@ -323,7 +323,18 @@ struct Solver {
   }
 
   // =============================================================== CLDDP
-  void clddp_initialize() {  // clddp_solver.cpp:28-75 (cold start; a fresh solver object per solve())
+  bool have_valid_gains() const {  // clddp_solver.cpp:36-49 == ipddp_solver.cpp:655-673
+    if ((int)k_u.size() != N || (int)K_u.size() != N || k_u.empty()) return false;
+    for (int t = 0; t < N; ++t)
+      if (k_u[t].size() != nu || K_u[t].r != nu || K_u[t].c != nx) return false;
+    return true;
+  }
+  void clddp_initialize() {  // clddp_solver.cpp:28-75
+    if (opt.warm_start && have_valid_gains()) {   // :51-60: keep the gains (BoxQP warm start x0 = k_u_), cost of the given X, U
+      if (Vx_t.size() != (size_t)(N + 1)) { Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx)); }
+      computeCost();
+      return;
+    }
     initializeGains();
     Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx));
     computeCost();
@@ -524,7 +535,131 @@ struct Solver {
     if (hti || hte) acceptFilterEntry(phi, filter_theta);
   }
 
+  // ---- warm start (ipddp_solver.cpp:264-366, 653-816, 2296-2426)
+  bool warmstartNeedsReinit(const Vec &y, const Vec &sv, const Vec &g) const {  // :264-292
+    if (y.size() != g.size() || sv.size() != g.size()) return true;
+    for (int i = 0; i < g.size(); ++i) if (!std::isfinite(y(i)) || !std::isfinite(sv(i))) return true;
+    for (int i = 0; i < g.size(); ++i) {
+      if (y(i) <= EPS_DUAL || sv(i) <= EPS_SLACK) return true;
+      const double required = std::max(opt.ipddp_slack_var_init_scale, -g(i) + kSlackInteriorOffset);
+      if (sv(i) < 0.1 * required) return true;
+    }
+    return false;
+  }
+  void evaluateTrajectoryWarmStart() {  // :2296-2343 (X is NOT re-propagated here)
+    double c = 0.0;
+    G.assign(N, Vec::Zero(m));
+    for (int t = 0; t < N; ++t) {
+      c += running_cost(X[t], U[t], t);
+      for (auto &cd : cons) G[t].setSegment(cd.offset, con_g(cd, X[t], U[t]));
+    }
+    c += terminal_cost(X.back());
+    for (auto &td : terms) if (td.kind == CDDP_HIP_TERM_INEQUALITY) G_T[td.name] = term_ineq_eval(td, X.back());
+    cost = c;
+  }
+  double computeMaxConstraintViolation() const {  // :2710-2723, interior_point_utils.cpp:141-155
+    double mv = 0.0;
+    for (auto &cd : cons) for (int t = 0; t < (int)G.size(); ++t) { Vec g = seg(G[t], cd); if (g.size() > 0) mv = std::max(mv, g.maxCoeff()); }
+    for (auto &kv : G_T) if (kv.second.size() > 0) mv = std::max(mv, kv.second.maxCoeff());
+    return mv;
+  }
+  void initializeDualSlackVariablesWarmStart(bool has_existing) {  // :2345-2426
+    if (!has_existing) { S.assign(N, Vec::Zero(m)); Y.assign(N, Vec::Zero(m)); }
+    dS.assign(N, Vec::Zero(m)); dY.assign(N, Vec::Zero(m));
+    k_s.assign(N, Vec::Zero(m)); k_y.assign(N, Vec::Zero(m)); K_s.assign(N, Mat::Zero(m, nx)); K_y.assign(N, Mat::Zero(m, nx));
+    Gx.assign(N, Mat::Zero(m, nx)); Gu.assign(N, Mat::Zero(m, nu));
+    for (auto &cd : cons)
+      for (int t = 0; t < N; ++t) {
+        Vec g_val = seg(G[t], cd);
+        Vec s_cur = Vec::Zero(cd.dual_dim), y_cur = Vec::Zero(cd.dual_dim);
+        bool need = !has_existing;
+        if (!need) { s_cur = seg(S[t], cd); y_cur = seg(Y[t], cd); need = warmstartNeedsReinit(y_cur, s_cur, g_val); }
+        if (need)
+          for (int i = 0; i < cd.dual_dim; ++i) {
+            s_cur(i) = std::max(opt.ipddp_slack_var_init_scale, -g_val(i) + kSlackInteriorOffset);
+            y_cur(i) = (mu * opt.ipddp_dual_var_init_scale) / std::max(s_cur(i), EPS_SLACK);
+          }
+        repairWarmstartInterior(s_cur, y_cur);
+        Y[t].setSegment(cd.offset, y_cur); S[t].setSegment(cd.offset, s_cur);
+      }
+  }
+  void initializeTerminalWarmstartDualSlack() {  // :294-353
+    bool has_existing = true;
+    for (auto &td : terms) if (td.kind == CDDP_HIP_TERM_INEQUALITY) {
+      auto yi = Y_T.find(td.name); auto si = S_T.find(td.name);
+      if (yi == Y_T.end() || si == S_T.end() || yi->second.size() != td.dim || si->second.size() != td.dim) { has_existing = false; break; }
+    }
+    for (auto &td : terms) if (td.kind == CDDP_HIP_TERM_INEQUALITY) {
+      const Vec &g_val = G_T.at(td.name);
+      Vec s_cur = Vec::Zero(td.dim), y_cur = Vec::Zero(td.dim);
+      bool need = !has_existing;
+      if (!need) { s_cur = S_T.at(td.name); y_cur = Y_T.at(td.name); need = warmstartNeedsReinit(y_cur, s_cur, g_val); }
+      if (need)
+        for (int i = 0; i < td.dim; ++i) {
+          s_cur(i) = std::max(opt.ipddp_slack_var_init_scale, -g_val(i) + kSlackInteriorOffset);
+          y_cur(i) = (mu * opt.ipddp_dual_var_init_scale) / std::max(s_cur(i), EPS_SLACK);
+        }
+      repairWarmstartInterior(s_cur, y_cur);
+      S_T[td.name] = s_cur; Y_T[td.name] = y_cur; dS_T[td.name] = Vec::Zero(td.dim); dY_T[td.name] = Vec::Zero(td.dim);
+    }
+  }
+  bool path_duals_exist() const {   // has_existing_dual_slack of :2351-2364 in the stacked representation
+    if (cons.empty()) return true;
+    if ((int)S.size() != N || (int)Y.size() != N) return false;
+    for (int t = 0; t < N; ++t) if (S[t].size() != m || Y[t].size() != m) return false;
+    return true;
+  }
+  void ipddp_initialize_warm() {
+    const bool existing = have_valid_gains();
+    const int pT = term_eq_dim();
+    bool lam_ok = Lambda_T_eq.size() == pT;
+    for (int i = 0; lam_ok && i < Lambda_T_eq.size(); ++i) lam_ok = std::isfinite(Lambda_T_eq(i));
+    if (!lam_ok) Lambda_T_eq = Vec::Zero(pT);        // initializeTerminalEqualityWarmstartMultipliers :355-366
+    dLambda_T_eq = Vec::Zero(pT);
+    dV[0] = dV[1] = 0;
+    const bool has_path = path_duals_exist();
+    G_T.clear(); dS_T.clear(); dY_T.clear();        // initializeConstraintStorage (:2662-2708); S_, Y_, S_T_, Y_T_ are restored (:719-727, 756-764)
+    if (existing) {   // ---- :675-731 existing solver state
+      mu = opt.barrier_mu_initial * 0.1;
+      step_norm = 0.0;
+      X.assign(N + 1, Vec::Zero(nx)); X[0] = x0;
+      for (int t = 0; t < N; ++t) X[t + 1] = model.step(X[t], U[t], t * dt);
+      if ((int)Lambda.size() != N + 1) Lambda.assign(N + 1, Vec::Zero(nx));
+      if ((int)Vx_t.size() != N + 1) { Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx)); }
+      if ((int)dX.size() != N + 1) { dX.assign(N + 1, Vec::Zero(nx)); dU.assign(N, Vec::Zero(nu)); }
+      evaluateTrajectoryWarmStart();
+      initializeDualSlackVariablesWarmStart(has_path);
+      initializeTerminalWarmstartDualSlack();
+      resetFilter();
+      return;
+    }
+    // ---- :733-816 provided trajectory, no solver state
+    k_u.assign(N, Vec::Zero(nu)); K_u.assign(N, Mat::Zero(nu, nx));
+    dX.assign(N + 1, Vec::Zero(nx)); dU.assign(N, Vec::Zero(nu));
+    Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx));
+    Lambda.assign(N + 1, Vec::Zero(nx));
+    if ((int)U.size() != N) U.assign(N, Vec::Zero(nu));
+    X.assign(N + 1, Vec::Zero(nx)); X[0] = x0;
+    for (int t = 0; t < N; ++t) X[t + 1] = model.step(X[t], U[t], t * dt);
+    if (cons.empty() && terms.empty()) {
+      mu = std::max(opt.tolerance / 10.0, opt.barrier_mu_min_value);
+      G.assign(N, Vec::Zero(m));
+    } else {
+      evaluateTrajectoryWarmStart();
+      const double mv = computeMaxConstraintViolation();
+      if (mv <= opt.tolerance) mu = std::max(opt.tolerance, opt.barrier_mu_min_value);
+      else if (mv <= 0.1) mu = std::max(opt.tolerance * 10.0, opt.barrier_mu_initial * 0.01);
+      else mu = opt.barrier_mu_initial * 0.1;
+    }
+    reg = opt.reg_initial_value; step_norm = 0.0; alpha_pr = 1.0; alpha_du = 1.0;
+    initializeDualSlackVariablesWarmStart(has_path && (int)S.size() == N);
+    initializeTerminalWarmstartDualSlack();
+    resetFilter();
+    inf_du = 0.0;
+  }
+
   void ipddp_initialize() {  // ipddp_solver.cpp:644-914, cold-start path :819-913
+    if (opt.warm_start) { ipddp_initialize_warm(); return; }
     k_u.assign(N, Vec::Zero(nu)); K_u.assign(N, Mat::Zero(nu, nx));
     dX.assign(N + 1, Vec::Zero(nx)); dU.assign(N, Vec::Zero(nu));
     Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx));
@@ -1312,6 +1447,29 @@ int cddp_oracle_num_alphas(void *o, double *out, int cap) {
 }
 int cddp_oracle_set_initial(void *o, const double *x0, const double *U0, const double *X0) { ((Solver *)o)->set_initial(x0, U0, X0); return 0; }
 int cddp_oracle_initialize(void *o) { ((Solver *)o)->initialize(); return 0; }
+// ---- warm-start plumbing (tests): options.warm_start, IPDDPSolverTestAccess-style setters, MPC-style x0 / U update
+void cddp_oracle_set_warm_start(void *o, int flag) { ((Solver *)o)->opt.warm_start = flag; }
+void cddp_oracle_set_path_interior(void *o, double s_val, double y_val) {
+  Solver *s = (Solver *)o;
+  for (auto &v : s->S) for (int i = 0; i < v.size(); ++i) v(i) = s_val;
+  for (auto &v : s->Y) for (int i = 0; i < v.size(); ++i) v(i) = y_val;
+}
+void cddp_oracle_set_terminal_interior(void *o, double s_val, double y_val) {
+  Solver *s = (Solver *)o;
+  for (auto &kv : s->S_T) for (int i = 0; i < kv.second.size(); ++i) kv.second(i) = s_val;
+  for (auto &kv : s->Y_T) for (int i = 0; i < kv.second.size(); ++i) kv.second(i) = y_val;
+}
+void cddp_oracle_set_terminal_eq_multiplier(void *o, const double *lam) {
+  Solver *s = (Solver *)o;
+  for (int i = 0; i < s->Lambda_T_eq.size(); ++i) s->Lambda_T_eq(i) = lam[i];
+}
+// CDDP::setInitialState (+ setInitialTrajectory when U0 != NULL) on a LIVE context: nothing else is reset
+void cddp_oracle_update_initial(void *o, const double *x0, const double *U0) {
+  Solver *s = (Solver *)o;
+  s->x0 = Vec::FromPtr(x0, s->nx);
+  if (U0) for (int t = 0; t < s->N; ++t) s->U[t] = Vec::FromPtr(U0 + (size_t)t * s->nu, s->nu);
+  if (!s->X.empty()) s->X[0] = s->x0;
+}
 // one backwardPass; retry != 0 adds the regularisation-retry loop of cddp_solver_base.cpp:93-111
 int cddp_oracle_backward(void *o, int retry) {
   Solver *s = (Solver *)o;
@@ -1333,6 +1491,8 @@ int cddp_oracle_forward(void *o, double alpha, cddp_hip_trial *out) {
 }
 int cddp_oracle_solve(void *o, cddp_hip_result *res) {
   Solver *s = (Solver *)o;
+  s->n_backward = s->n_forward = 0;   // per-solve work counters
+  s->history.rows.clear();            // cddp_solver_base.cpp:47-50
   s->initialize();
   s->solve();
   if (res) oracle::fill_result(s, res);
