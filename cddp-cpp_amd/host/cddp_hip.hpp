@@ -303,7 +303,20 @@ class HipBatchSolver : public ISolverAlgorithm {
   explicit HipBatchSolver(int solver_kind, int device = 0) : kind_(solver_kind), device_(device) {}
   ~HipBatchSolver() override { if (h_) cddp_hip_destroy(h_); }
   std::string getSolverName() const override { return kind_ == CDDP_HIP_SOLVER_IPDDP ? "IPDDP" : "CLDDP"; }
-  void initialize(CDDP &ctx) override { create(ctx, {ctx.getInitialState()}); }
+  // A second initialize() of the SAME solver object with options.warm_start keeps the device-resident solver state
+  // (gains, slack / dual / costate variables): the reference's "existing solver state" branch
+  // (clddp_solver.cpp:51-60, ipddp_solver.cpp:675-731).  CDDP::solve() creates a new solver per call, exactly as
+  // the reference does (cddp_core.cpp:235-270), so through it a warm start is the "provided trajectory" branch.
+  void initialize(CDDP &ctx) override {
+    if (h_ && ctx.getOptions().warm_start && batch_ == 1 && nx_ == ctx.getSystem().getStateDim() && nu_ == ctx.getSystem().getControlDim() && N_ == ctx.getHorizon()) {
+      ctx.initializeProblemIfNecessary();
+      cddp_hip_options o = ctx.getOptions().toPOD();
+      check(cddp_hip_set_options(h_, &o));
+      upload(ctx, {ctx.getInitialState()});
+      return;
+    }
+    create(ctx, {ctx.getInitialState()});
+  }
   CDDPSolution solve(CDDP &ctx) override {
     std::vector<CDDPSolution> s = collect(ctx, 1);
     // leave the context updated as the reference solvers do (cddp_solver_base.cpp:161-171)
@@ -324,12 +337,16 @@ class HipBatchSolver : public ISolverAlgorithm {
     CDDP::Flat f; ctx.flatten(kind_, f);
     const int B = (int)x0s.size(), nx = f.p.nx, nu = f.p.nu, N = f.p.horizon;
     check(cddp_hip_create(&f.p, B, device_, &h_));
+    nx_ = nx; nu_ = nu; N_ = N; dt_ = f.p.dt; ret_hist_ = f.p.options.return_iteration_info; max_it_ = f.p.options.max_iterations; batch_ = B;
+    upload(ctx, x0s);
+  }
+  void upload(CDDP &ctx, const std::vector<Vector> &x0s) {   // CDDP::setInitialState + setInitialTrajectory for the batch
+    const int B = (int)x0s.size(), nx = nx_, nu = nu_, N = N_;
     std::vector<double> x0((size_t)B * nx), U0, X0;
     for (int b = 0; b < B; ++b) for (int i = 0; i < nx; ++i) x0[(size_t)b * nx + i] = x0s[b][i];
     if ((int)ctx.U_.size() == N) { U0.resize((size_t)B * N * nu); for (int b = 0; b < B; ++b) for (int t = 0; t < N; ++t) for (int i = 0; i < nu; ++i) U0[((size_t)b * N + t) * nu + i] = ctx.U_[t][i]; }
     if ((int)ctx.X_.size() == N + 1) { X0.resize((size_t)B * (N + 1) * nx); for (int b = 0; b < B; ++b) for (int t = 0; t <= N; ++t) for (int i = 0; i < nx; ++i) X0[((size_t)b * (N + 1) + t) * nx + i] = ctx.X_[t][i]; }
     check(cddp_hip_set_initial(h_, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data()));
-    nx_ = nx; nu_ = nu; N_ = N; dt_ = f.p.dt; ret_hist_ = f.p.options.return_iteration_info; max_it_ = f.p.options.max_iterations;
   }
   std::vector<CDDPSolution> collect(CDDP &, int B) {
     check(cddp_hip_solve(h_, &stats));
@@ -362,7 +379,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     }
     return out;
   }
-  int kind_, device_; cddp_hip_handle *h_ = nullptr; int nx_ = 0, nu_ = 0, N_ = 0, max_it_ = 0; double dt_ = 0; bool ret_hist_ = false;
+  int kind_, device_; cddp_hip_handle *h_ = nullptr; int nx_ = 0, nu_ = 0, N_ = 0, max_it_ = 0, batch_ = 0; double dt_ = 0; bool ret_hist_ = false;
 };
 
 // Register the GPU core under the reference's own solver names: a true drop-in (cddp_core.cpp:215-219).

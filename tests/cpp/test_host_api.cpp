@@ -137,6 +137,27 @@ static void gpu_tests() {
     EXPECT_TRUE(s.iterations_completed > 0);
     EXPECT_TRUE(std::fabs(s.state_trajectory.back()[0]) < 1e-2 && std::fabs(s.state_trajectory.back()[1]) < 1e-2);
   }
+  {   // warm start (tests/cddp_core/test_ipddp_solver.cpp:474-549): previous solution as the initial trajectory of a
+      // NEW solver -> converges within cold + 5 iterations; then solver-object reuse from a perturbed state
+    cddp::CDDP cold = makePendulum(opt);
+    cddp::CDDPSolution c = cold.solve("IPDDP");
+    cddp::CDDPOptions wopt = opt; wopt.warm_start = true;
+    cddp::CDDP warm = makePendulum(wopt);
+    warm.setInitialTrajectory(c.state_trajectory, c.control_trajectory);
+    cddp::CDDPSolution w = warm.solve("IPDDP");
+    std::cout << "warm start: " << w.status_message << " iterations " << w.iterations_completed << " (cold " << c.iterations_completed << ")\n";
+    EXPECT_TRUE(w.status_message == "OptimalSolutionFound" || w.status_message == "AcceptableSolutionFound");
+    EXPECT_TRUE(w.iterations_completed <= c.iterations_completed + 5);
+    cddp::HipBatchSolver obj(CDDP_HIP_SOLVER_IPDDP);   // one solver object, two solves (MPC restart)
+    cddp::CDDP ctx = makePendulum(opt);
+    obj.initialize(ctx); cddp::CDDPSolution s1 = obj.solve(ctx);
+    ctx.setOptions(wopt);
+    ctx.setInitialState({3.14159265358979323846 - 0.05, 0.0});
+    obj.initialize(ctx); cddp::CDDPSolution s2 = obj.solve(ctx);
+    std::cout << "solver reuse: " << s2.status_message << " iterations " << s2.iterations_completed << " (first " << s1.iterations_completed << ")\n";
+    EXPECT_TRUE(s2.iterations_completed > 0);
+    EXPECT_TRUE(std::fabs(s2.state_trajectory.front()[0] - (3.14159265358979323846 - 0.05)) < 1e-15);
+  }
   {   // a layout that is not instantiated on the device: loud error, never a silent fallback
     cddp::CDDP solver = makePendulum(opt);
     solver.addPathConstraint("Extra", std::make_unique<cddp::StateConstraint>(cddp::Vector{-10.0, -10.0}, cddp::Vector{10.0, 10.0}));
