@@ -80,6 +80,14 @@ def make_problem(api, workload, solver):
         p = api.unicycle_problem(sv, 200, True)
         spread = [0.05, 0.05, 0.05]
         desc = "unicycle nx=3 nu=2 N=200 control box + ball obstacle (m=5), euler, random x0"
+    elif workload == "quadrotor":   # config[3] per-GPU share: 16384 / 8 GPUs = 2048 trajectories
+        p = api.quadrotor12_problem(sv, 400, True)
+        spread = [0.02] * 12
+        desc = "quadrotor (Euler-angle, nx=12 nu=4) N=400 thrust box, rk4, random x0"
+    elif workload == "manip7":      # config[4] per-GPU share: 32768 / 8 GPUs = 4096 trajectories
+        p = api.manipulator7_problem(sv, 150, True, 16)
+        spread = [0.02] * 14
+        desc = "7-joint manipulator nx=14 nu=7 N=150 torque box + terminal equality, 16-way parallel line search, rk4"
     elif workload == "pendulum":
         p = api.pendulum_problem(sv, True)
         spread = [0.1, 0.1]
@@ -124,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
     ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
-    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum"])
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -246,7 +254,7 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": {"cartpole": "BASELINE config[1]: ", "unicycle": "BASELINE config[2]: "}.get(args.workload, "experiment: ") + desc +
+            "workload": {"cartpole": "BASELINE config[1]: ", "unicycle": "BASELINE config[2]: ", "quadrotor": "BASELINE config[3] (one GPU share): ", "manip7": "BASELINE config[4] (one GPU share): "}.get(args.workload, "experiment: ") + desc +
                         ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
             "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": B * world, "nx": p.nx, "nu": p.nu,
             "horizon": p.N, "path_dual_dim": m, "max_iterations": int(p.options.max_iterations),
