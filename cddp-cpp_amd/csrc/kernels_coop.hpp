@@ -708,5 +708,352 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
   d.phase[b] = PH_FWD1;
 }
 
+// ================================================================================ cooperative sweep, nx > 8
+// Column ownership as above, but the step's dense operands live in LDS instead of registers: A_t and B_t are
+// fetched cooperatively (each lane of the group a 1/G slice, double-buffered), T1, T2, K, Q_ux, K^T Q_uu are
+// streamed from LDS inside the inner products.  With nx = 12..14 the register-resident form needs A (nx^2) twice
+// (ping-pong) plus T1 (nx^2) per lane -- > 512 VGPRs, i.e. scratch spills on every step (measured: 178 us per
+// step for the C4 quadrotor).  Same sums, same association.
+template <class Model, bool HAS_X>
+struct CoopBigCfg {
+  static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = CoopCfg<Model>::TPW;
+  static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G;     // per-lane slices of A, B
+  // oM holds T1, then (in place, row by row) Q_xx, then (in place, element by element) Vn
+  static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
+                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oVx = oKtQ + NX * NU, oDx = oVx + NX,
+                       oWx = oDx + NX, RAW = oWx + (HAS_X ? NX * NX : 0);
+  static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
+};
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                                int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  typedef CstLayout<Model, Cons> L;
+  typedef CoopBigCfg<Model, Cons::HAS_X> C;
+  constexpr int CST = L::SIZE, G = C::G;
+  __shared__ double lds[C::TPW * C::STRIDE];
+  __shared__ double ldsQ[NX * NX];   // Q dt (loop-invariant, shared by the trajectories of the wave)
+  const int lane = threadIdx.x;
+  {   // every lane of the wavefront takes part, BEFORE the per-trajectory early exits
+    const double *Qp = Pk->pool + Pk->off_Qdt;
+    for (int e = lane; e < NX * NX; e += 64) ldsQ[e] = Qp[e];
+    lds_sync();
+  }
+  const int q = lane % G, tl = lane / G;
+  const int qc = q < NX ? q : NX - 1;
+  const int b = blockIdx.x * C::TPW + tl;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  double *Ls = lds + tl * C::STRIDE;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  if (count_iter && q == 0) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  double Rr[NU * NU];
+  {
+    const double *Rp = P->pool + P->off_Rdt;
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Rr[i] = Rp[i];
+  }
+  struct InAB { double a[C::NA], bm[C::NB]; };
+  struct In2 { double cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq; };
+  auto loadAB = [&](int tt, InAB &r) {   // this lane's slice of A_t, B_t (element e = q + G j; clamped past the end)
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+  };
+  auto storeAB = [&](int buf, const InAB &r) {
+    double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU;
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; if (e < NX * NU) Lb[e] = r.bm[j]; }
+  };
+  auto load2 = [&](int tt, In2 &r) {
+    const double *c = d.cst + GI(tt, CST, 0);
+    ld<NU>(c + (size_t)L::CU * kLS, kLS, r.cu);
+    ld<NU * NU>(c + (size_t)L::WQYU * kLS, kLS, r.WQyu);
+    ld<NU>(c + (size_t)L::QYUSIR * kLS, kLS, r.QyuSir);
+    r.ipr = c[(size_t)L::IPR * kLS]; r.icomp = c[(size_t)L::ICOMP * kLS];
+    r.cxq = c[(size_t)(L::CX + qc) * kLS];
+    if constexpr (Cons::HAS_X) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) r.WQyxq[u] = c[(size_t)(L::WQYX + u * NX + qc) * kLS];
+      r.QyxSirq = c[(size_t)(L::QYXSIR + qc) * kLS];
+      // column qc of G_x^T YS^-1 G_x goes straight to LDS (indexed by a rolled loop below)
+#pragma unroll 4
+      for (int i = 0; i < NX; ++i) Ls[C::oWx + i * NX + qc] = c[(size_t)(L::WXQYX + i * NX + qc) * kLS];
+    }
+  };
+  for (;;) {
+    ++nb;
+    double Vx[NX], Vc[NX];
+    {
+      double xN[NX];
+      ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+      Obj::final_grad(P, xN, Vx);
+      const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
+    }
+    dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0;
+    {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oVx + i] = Vx[i];
+      lds_sync();
+      d.Vx[GI(N, NX, qc)] = Ls[C::oVx + qc];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) d.Vxx[GI(N, NX * NX, i * NX + qc)] = Vc[i];
+    bool fail = false;
+    // buf = parity of the step whose A, B sit in the LDS buffer
+    // (the condensed-term record is fetched at the top of its own step: round 1 covers the latency, and a second
+    //  register copy of it would push the kernel into scratch)
+    auto step = [&](const int t, In2 &c2, InAB &nab) -> bool {
+      const int tp = t > 0 ? t - 1 : 0;
+      load2(t, c2);
+      const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU;
+      loadAB(tp, nab);
+      PIPELINE_FENCE();
+      double Aq[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Aq[j] = La[j * NX + qc];
+      // ---- round 1
+      // (outer loops stay rolled and write to LDS: fully unrolled, the 3 nx^2-term products keep hundreds of LDS
+      //  operands live and spill)
+      double T2c[NU], Qu[NU];
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
+        Ls[C::oM + i * NX + qc] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Lb[k * NU + u] * Vc[k];
+        T2c[u] = s; }
+      double Qxq;
+      { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Aq[k] * Vx[k];
+        Qxq = c2.cxq + s2; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Lb[k * NU + u] * Vx[k];
+        Qu[u] = c2.cu[u] + s2; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
+      lds_sync();
+      // ---- round 2: Q_xx[i, qc] replaces T1[i, qc] in place (row i of T1 is dead once every lane has used it,
+      // and the lanes of a wavefront run this loop in lockstep)
+      double Quxc[NU], Quu[NU * NU];
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
+        Ls[C::oM + i * NX + qc] = (2.0 * ldsQ[i * NX + qc]) + s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Aq[j];
+        Quxc[u] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int v = 0; v < NU; ++v) { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Lb[j * NU + v];
+          Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
+      double Qr[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + c2.WQyu[i * NU + c];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+      double kk[NU], KKc[NU], Quxq[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double rhs = Quxc[u];
+        if constexpr (Cons::HAS_X) rhs = rhs + c2.WQyxq[u];
+        Quxq[u] = rhs;
+      }
+      if (NU == 1) {
+        kk[0] = -ldlt1_solve(Qr[0], Qu[0] + c2.QyuSir[0]);
+        KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
+      } else {
+        LDLTd<NU> f;
+        f.compute(Qr, NU);
+        if (!f.ok) return false;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + c2.QyuSir[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Quxq[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] += c2.QyuSir[i];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu[i] += c2.WQyu[i];
+      double KtQq[NU];   // row qc of K^T Q_uu (condensed Q_uu), mm_tn's expression
+#pragma unroll
+      for (int j = 0; j < NU; ++j) { double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
+        KtQq[j] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; Ls[C::oKtQ + qc * NU + u] = KtQq[u]; }
+      lds_sync();
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+      // ---- round 3
+      if constexpr (Cons::HAS_X) Qxq += c2.QyxSirq;
+      inf_pr = dmax(inf_pr, c2.ipr); inf_comp = dmax(inf_comp, c2.icomp);
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s1; }
+      { double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { s0 += kk[i] * Qu[i]; s1 += kk[i] * Quuk[i]; }
+        dV0 += s0; dV1 += 0.5 * s1; }
+      double Vxq;
+      {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxq[j] * kk[j]; c += KtQq[j] * kk[j]; }
+        Vxq = ((Qxq + a) + bb) + c;
+      }
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place
+        double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          a += Ls[C::oKK + j * NX + i] * Quxq[j]; bb += Ls[C::oQux + j * NX + i] * KKc[j]; e += Ls[C::oKtQ + i * NU + j] * KKc[j];
+        }
+        double qxx = Ls[C::oM + i * NX + qc];
+        if constexpr (Cons::HAS_X) qxx += Ls[C::oWx + i * NX + qc];
+        Ls[C::oM + i * NX + qc] = ((qxx + a) + bb) + e;
+      }
+      Ls[C::oVx + qc] = Vxq;
+      storeAB((t & 1) ^ 1, nab);     // next step's A, B into the other LDS buffer
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * (Ls[C::oM + i * NX + qc] + Ls[C::oM + qc * NX + i]);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Vx[i] = Ls[C::oVx + i];
+      lds_sync();
+      d.Vx[GI(t, NX, qc)] = Vxq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+      return true;
+    };
+    In2 a2;
+    InAB nab;
+    loadAB(N - 1, nab);
+    storeAB((N - 1) & 1, nab);
+    lds_sync();
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      if (!step(t, a2, nab)) { fail = true; break; }
+      if (!step(t - 1, a2, nab)) { fail = true; break; }
+    }
+    if (!fail && t == 0) fail = !step(0, a2, nab);
+    if (!fail) { ok = true; break; }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  bool conv = false;
+  if (ok) {
+    const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+    const double asn = fabs(d.alpha_pr[b]) * step_norm;
+    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    if (!conv || force) {
+      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      struct RIn { double kk[NU], KK[NU * NX], Aq[NX], Bq[NU]; };
+      auto load_r = [&](int tt, RIn &r) {
+        ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+        ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+      };
+      auto rstep = [&](const int t, const RIn &rc, RIn &rn) {
+        const int tn = t + 1 < N - 1 ? t + 1 : t;
+        load_r(tn, rn);
+        PIPELINE_FENCE();
+        d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+        if (t < N - 1) {
+          double du[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += rc.KK[i * NX + j] * dx[j];
+            du[i] = rc.kk[i] + a; }
+          double a = 0.0, c = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
+          const double dxq = (a + c) + 0.0;
+          lds_sync();
+          Ls[C::oDx + qc] = dxq;
+          lds_sync();
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
+      lds_sync();
+      RIn ra, rb;
+      load_r(0, ra);
+      int t = 0;
+      for (; t + 1 < N; t += 2) { rstep(t, ra, rb); rstep(t + 1, rb, ra); }
+      if (t < N) rstep(t, ra, rb);
+    }
+  }
+  if (q != 0) return;
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
+    d.inf_pr[b] = inf_pr; d.inf_comp[b] = inf_comp;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
+  d.phase[b] = PH_FWD1;
+}
+
 #undef GI
 }  // namespace cddp_dev

@@ -49,6 +49,8 @@ struct Launcher {
     } else if constexpr (kLean) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else if constexpr (Model::NX > 8)   // operands in LDS: the register-resident form spills for nx = 12..14
+        hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       else
         hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
