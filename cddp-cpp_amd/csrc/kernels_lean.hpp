@@ -570,9 +570,15 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       st<NU>(Un + GI(0, NU, 0), kLS, z);
       st<NX>(Xn + GI(1, NX, 0), kLS, z);
     };
-    auto step = [&](const int t, const StepIn &cs, StepIn &nxt) {
-      const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
-      load_step(tn, nxt);
+    // Large records (nx >= 12: the gain block alone is nu*nx rows) are fetched at the top of their own step into ONE
+    // register set: the ping-pong copy would push the kernel into scratch, whose spill traffic costs far more VMEM
+    // issue slots than one exposed round trip per step.
+    constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);
+    auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
+      if constexpr (kPing) {
+        const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+        load_step(tn, nxt);
+      } else load_step(t, cs);
       PIPELINE_FENCE();
       double dx[NX], u[NU], xn[NX];
       bool finite = true;
@@ -610,16 +616,24 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
       }
     };
-    StepIn ra, rb;
+    StepIn ra;
     load_step(0, ra);
     prime();
     int t = 0;
-    for (; t + 1 < N; t += 2) {
-      step(t, ra, rb);
-      step(t + 1, rb, ra);
-      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) { t = N; break; }   // nothing downstream reads the rows any more
+    if constexpr (kPing) {
+      StepIn rb;
+      for (; t + 1 < N; t += 2) {
+        step(t, ra, rb);
+        step(t + 1, rb, ra);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) { t = N; break; }   // nothing downstream reads the rows any more
+      }
+      if (t < N) step(t, ra, rb);
+    } else {
+      for (; t < N; ++t) {
+        step(t, ra, ra);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+      }
     }
-    if (t < N) step(t, ra, rb);
     if (alive) s_pcost[lane] = Obj::terminal_cost(P, x);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -672,9 +686,12 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
     for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
   };
-  auto step = [&](const int t, const StepIn &cs, StepIn &nxt) {
-    const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
-    load_step(tn, nxt);
+  constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);   // see the producer
+  auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
+    if constexpr (kPing) {
+      const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+      load_step(tn, nxt);
+    } else load_step(t, cs);
     PIPELINE_FENCE();
     // take step t from the ring, then hand the slot back
     wait_ge(&s_prod, t + 1);
@@ -744,10 +761,11 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       ev[(size_t)c * kLS] = ls;
     }
   };
-  StepIn ra, rb;
+  StepIn ra;
   load_step(0, ra);
   prime();
-  {
+  if constexpr (kPing) {
+    StepIn rb;
     int t = 0;
     for (; t + 1 < N; t += 2) {
       step(t, ra, rb);
@@ -758,6 +776,14 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
     }
     if (t < N) step(t, ra, rb);
+  } else {
+    for (int t = 0; t < N; ++t) {
+      step(t, ra, ra);
+      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
+        __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+    }
   }
   wait_ge(&s_prod, N + kRing + 1);
   if (alive && s_pstat[lane] <= N) alive = false;
