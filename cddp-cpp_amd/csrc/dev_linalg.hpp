@@ -131,6 +131,116 @@ struct LDLTd {
   }
 };
 
+// Full-size (n == N) LDLT with STATIC register indexing: the pivot position is a run-time value, so every
+// pivot-dependent access of LDLTd is rewritten as "for each compile-time candidate B: if (big == B) ...".  Same
+// arithmetic, same pivot rule, same D^+ as LDLTd<N>::compute / solve with n = N; nothing is dynamically indexed, so
+// nothing lands in scratch memory (the generic form costs ~100 scratch VMEM operations per factorisation).
+template <int N>
+struct LDLTs {
+  double m[N * N];
+  int tr[N];
+  bool ok;
+
+  DEV void compute(const double *A, int /*n == N*/) {
+#pragma unroll
+    for (int i = 0; i < N * N; ++i) m[i] = A[i];
+    ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) tr[i] = i;
+    if (N <= 1) return;
+    bool found_zero_pivot = false, ret = true, done = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (done) continue;
+      int big = k;
+      double bigv = fabs(m[k * N + k]);
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        const double v = fabs(m[i * N + i]);
+        if (v > bigv) { bigv = v; big = i; }
+      }
+      tr[k] = big;
+#pragma unroll
+      for (int B = k + 1; B < N; ++B) {
+        if (big == B) {
+#pragma unroll
+          for (int j = 0; j < k; ++j) { const double t = m[k * N + j]; m[k * N + j] = m[B * N + j]; m[B * N + j] = t; }
+#pragma unroll
+          for (int i = B + 1; i < N; ++i) { const double t = m[i * N + k]; m[i * N + k] = m[i * N + B]; m[i * N + B] = t; }
+          { const double t = m[k * N + k]; m[k * N + k] = m[B * N + B]; m[B * N + B] = t; }
+#pragma unroll
+          for (int i = k + 1; i < B; ++i) { const double t = m[i * N + k]; m[i * N + k] = m[B * N + i]; m[B * N + i] = t; }
+        }
+      }
+      if (k > 0) {
+        double temp[N];
+#pragma unroll
+        for (int j = 0; j < k; ++j) temp[j] = m[j * N + j] * m[k * N + j];
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) sacc += m[k * N + j] * temp[j];
+        m[k * N + k] -= sacc;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+          double t = 0.0;
+#pragma unroll
+          for (int j = 0; j < k; ++j) t += m[i * N + j] * temp[j];
+          m[i * N + k] -= t;
+        }
+      }
+      const double akk = m[k * N + k];
+      const bool valid = fabs(akk) > 0.0;
+      if (k == 0 && !valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          tr[j] = j;
+#pragma unroll
+          for (int i = j + 1; i < N; ++i) ret = ret && (m[i * N + j] == 0.0);
+        }
+        done = true;
+        continue;
+      }
+      if (k + 1 < N) {
+        if (valid) {
+#pragma unroll
+          for (int i = k + 1; i < N; ++i) m[i * N + k] /= akk;
+        } else {
+#pragma unroll
+          for (int i = k + 1; i < N; ++i) ret = ret && (m[i * N + k] == 0.0);
+        }
+      }
+      if (found_zero_pivot && valid) ret = false;
+      else if (!valid) found_zero_pivot = true;
+    }
+    ok = ret;
+  }
+
+  DEV void solve(double *x) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int B = k + 1; B < N; ++B) if (tr[k] == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double sacc = x[i];
+#pragma unroll
+      for (int kk = 0; kk < i; ++kk) sacc -= m[i * N + kk] * x[kk];
+      x[i] = sacc; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { const double dd = m[i * N + i]; x[i] = (fabs(dd) > DBL_MIN) ? x[i] / dd : 0.0; }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) { double sacc = x[i];
+#pragma unroll
+      for (int kk = i + 1; kk < N; ++kk) sacc -= m[kk * N + i] * x[kk];
+      x[i] = sacc; }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+      for (int B = k + 1; B < N; ++B) if (tr[k] == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+    }
+  }
+};
+
 // NMAX = 2 with static indexing only (the generic form's pivot / transposition arrays are dynamically indexed and
 // land in scratch memory): the same steps as LDLTd<NMAX>::compute / solve written out for n in {0, 1, 2}.
 template <>

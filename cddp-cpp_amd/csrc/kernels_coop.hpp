@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
         kk[0] = -ldlt1_solve(Qr[0], Qu[0] + c2.QyuSir[0]);
         KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
       } else {
-        LDLTd<NU> f;
+        LDLTs<NU> f;
         f.compute(Qr, NU);
         if (!f.ok) return false;
         double col[NU];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           kk[0] = -ldlt1_solve(Qs[0], Qu[0]);
           KKc[0] = -ldlt1_solve(Qs[0], Quxc[0]);
         } else {
-          LDLTd<NU> f;
+          LDLTs<NU> f;
           f.compute(Qs, NU);
           if (!f.ok) return false;
           double col[NU];
@@ -718,10 +718,12 @@ template <class Model, bool HAS_X>
 struct CoopBigCfg {
   static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = CoopCfg<Model>::TPW;
   static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G;     // per-lane slices of A, B
+  static constexpr int RC = NU + NU * NU + NU + 2, NC = (RC + G - 1) / G;          // replicated condensed terms c_u .. icomp
+  static constexpr int RK = NU * NX, NK = (RK + G - 1) / G;                         // gain block (rollout epilogue)
   // oM holds T1, then (in place, row by row) Q_xx, then (in place, element by element) Vn
   static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
                        oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oVx = oKtQ + NX * NU, oDx = oVx + NX,
-                       oWx = oDx + NX, RAW = oWx + (HAS_X ? NX * NX : 0);
+                       oC = oDx + NX, oWx = oC + 2 * RC, RAW = oWx + (HAS_X ? NX * NX : 0);
   static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
 };
 
@@ -764,13 +766,17 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
 #pragma unroll
     for (int i = 0; i < NU * NU; ++i) Rr[i] = Rp[i];
   }
-  struct InAB { double a[C::NA], bm[C::NB]; };
+  struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
   struct In2 { double cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq; };
+  static_assert(L::WQYU == L::CU + NU && L::QYUSIR == L::WQYU + NU * NU && L::IPR == L::QYUSIR + NU && L::ICOMP == L::IPR + 1, "contiguous replicated block");
   auto loadAB = [&](int tt, InAB &r) {   // this lane's slice of A_t, B_t (element e = q + G j; clamped past the end)
 #pragma unroll
     for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
 #pragma unroll
     for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+    // the terms every lane of the group needs (c_u, G_u^T YS^-1 G_u, G_u^T S^-1 rhat, residual maxima): one slice per lane
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.cst[GI(tt, CST, L::CU + (e < C::RC ? e : C::RC - 1))]; }
   };
   auto storeAB = [&](int buf, const InAB &r) {
     double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU;
@@ -778,13 +784,22 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
     for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
 #pragma unroll
     for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; if (e < NX * NU) Lb[e] = r.bm[j]; }
+    double *Lc = Ls + C::oC + buf * C::RC;
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; if (e < C::RC) Lc[e] = r.c[j]; }
   };
   auto load2 = [&](int tt, In2 &r) {
     const double *c = d.cst + GI(tt, CST, 0);
-    ld<NU>(c + (size_t)L::CU * kLS, kLS, r.cu);
-    ld<NU * NU>(c + (size_t)L::WQYU * kLS, kLS, r.WQyu);
-    ld<NU>(c + (size_t)L::QYUSIR * kLS, kLS, r.QyuSir);
-    r.ipr = c[(size_t)L::IPR * kLS]; r.icomp = c[(size_t)L::ICOMP * kLS];
+    {   // replicated block: from the LDS copy of this step
+      const double *Lc = Ls + C::oC + (tt & 1) * C::RC;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) r.cu[i] = Lc[i];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) r.WQyu[i] = Lc[NU + i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) r.QyuSir[i] = Lc[NU + NU * NU + i];
+      r.ipr = Lc[NU + NU * NU + NU]; r.icomp = Lc[NU + NU * NU + NU + 1];
+    }
     r.cxq = c[(size_t)(L::CX + qc) * kLS];
     if constexpr (Cons::HAS_X) {
 #pragma unroll
@@ -893,7 +908,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         kk[0] = -ldlt1_solve(Qr[0], Qu[0] + c2.QyuSir[0]);
         KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
       } else {
-        LDLTd<NU> f;
+        LDLTs<NU> f;
         f.compute(Qr, NU);
         if (!f.ok) return false;
         double col[NU];
@@ -975,12 +990,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
     loadAB(N - 1, nab);
     storeAB((N - 1) & 1, nab);
     lds_sync();
-    int t = N - 1;
-    for (; t >= 1; t -= 2) {
+    for (int t = N - 1; t >= 0; --t)
       if (!step(t, a2, nab)) { fail = true; break; }
-      if (!step(t - 1, a2, nab)) { fail = true; break; }
-    }
-    if (!fail && t == 0) fail = !step(0, a2, nab);
     if (!fail) { ok = true; break; }
     if (force == 2) break;
     reg = reg_increase(o, reg);
@@ -996,27 +1007,40 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       double dx[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-      struct RIn { double kk[NU], KK[NU * NX], Aq[NX], Bq[NU]; };
+      // the gain block [k | K] of a step is fetched cooperatively (one slice per lane) into the LDS area that held
+      // A during the sweep (double-buffered); each lane fetches its own row of A and B
+      struct RIn { double ks[C::NK], kq, Aq[NX], Bq[NU]; };
+      constexpr int GS = NU + NU * NX;   // LDS doubles per gain buffer (2 GS <= 2 nx^2)
+      static_assert(2 * GS <= 2 * NX * NX, "gain buffers fit the A area");
       auto load_r = [&](int tt, RIn &r) {
-        ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
-        ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < C::RK ? e : C::RK - 1)]; }
+        r.kq = d.k[GI(tt, NU, q < NU ? q : NU - 1)];
 #pragma unroll
         for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
 #pragma unroll
         for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
       };
-      auto rstep = [&](const int t, const RIn &rc, RIn &rn) {
+      auto store_r = [&](int buf, const RIn &r) {
+        double *Lg = Ls + C::oA + buf * GS;
+        if (q < NU) Lg[q] = r.kq;
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; if (e < C::RK) Lg[NU + e] = r.ks[j]; }
+      };
+      RIn rc, rn;
+      auto rstep = [&](const int t) {
         const int tn = t + 1 < N - 1 ? t + 1 : t;
         load_r(tn, rn);
         PIPELINE_FENCE();
         d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
         if (t < N - 1) {
+          const double *Lg = Ls + C::oA + (t & 1) * GS;
           double du[NU];
 #pragma unroll
           for (int i = 0; i < NU; ++i) { double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < NX; ++j) a += rc.KK[i * NX + j] * dx[j];
-            du[i] = rc.kk[i] + a; }
+            for (int j = 0; j < NX; ++j) a += Lg[NU + i * NX + j] * dx[j];
+            du[i] = Lg[i] + a; }
           double a = 0.0, c = 0.0;
 #pragma unroll
           for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
@@ -1025,19 +1049,19 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
           const double dxq = (a + c) + 0.0;
           lds_sync();
           Ls[C::oDx + qc] = dxq;
+          store_r((t & 1) ^ 1, rn);
           lds_sync();
 #pragma unroll
           for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
         }
+        rc = rn;
       };
 #pragma unroll
       for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
+      load_r(0, rc);
+      store_r(0, rc);
       lds_sync();
-      RIn ra, rb;
-      load_r(0, ra);
-      int t = 0;
-      for (; t + 1 < N; t += 2) { rstep(t, ra, rb); rstep(t + 1, rb, ra); }
-      if (t < N) rstep(t, ra, rb);
+      for (int t = 0; t < N; ++t) rstep(t);
     }
   }
   if (q != 0) return;
