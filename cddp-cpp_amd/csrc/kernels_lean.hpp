@@ -30,7 +30,9 @@ struct CstLayout {
 };
 
 // ================================================================================ K1b
-template <class Model, class Cons>
+// WITH_DERIVS: the same (batch x N) pass also writes A_t = I + dt f_x, B_t = dt f_u (K1, cddp_solver_base.cpp:319-394):
+// x, u are read once and one launch is saved per iteration.
+template <class Model, class Cons, bool WITH_DERIVS = false>
 __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
@@ -54,6 +56,21 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
   ld<M>(Yc + GI(t, M, 0), kLS, y);
   ld<M>(Sc + GI(t, M, 0), kLS, s);
   ld<M>(Gc + GI(t, M, 0), kLS, g);
+  if constexpr (WITH_DERIVS) {   // identical to k_derivs
+    double Fx[NX * NX], Fu[NX * NU];
+    Model::jac(P->mp, x, u, Fx, Fu);
+    const double dt = P->dt;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        double a = dt * Fx[i * NX + j];
+        if (i == j) a += 1.0;
+        d.A[GI(t, NX * NX, i * NX + j)] = a;
+      }
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = dt * Fu[i];
+  }
 #pragma unroll
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll

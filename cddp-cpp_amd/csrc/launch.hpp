@@ -31,10 +31,20 @@ struct Launcher {
   static constexpr int cst_size() { if constexpr (kLean) return CstLayout<Model, Cons>::SIZE; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
-    hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
     if constexpr (kLean) {
-      if (d.cst) hipLaunchKernelGGL((k_condense<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+      if (d.cst) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
+                     // for nx > 8 the two register sets together would spill)
+        if constexpr (Model::NX <= 8) {
+          hipLaunchKernelGGL((k_condense<Model, Cons, true>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+          return;
+        } else {
+          hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+          hipLaunchKernelGGL((k_condense<Model, Cons, false>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+          return;
+        }
+      }
     }
+    hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
   }
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
