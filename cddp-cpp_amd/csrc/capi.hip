@@ -43,7 +43,7 @@ const std::vector<KernelSet> &registry() {
   static std::vector<KernelSet> v = [] {
     std::vector<KernelSet> r;
     register_pendulum(r); register_cartpole(r); register_unicycle(r); register_lti(r);
-    register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r); register_terminal(r);
+    register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r); register_terminal(r); register_statebox(r);
     return r;
   }();
   return v;

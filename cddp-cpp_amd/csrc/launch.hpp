@@ -120,5 +120,6 @@ void register_quad12(std::vector<KernelSet> &);
 void register_manipulator(std::vector<KernelSet> &);
 void register_manip7(std::vector<KernelSet> &);
 void register_terminal(std::vector<KernelSet> &);
+void register_statebox(std::vector<KernelSet> &);
 
 }  // namespace cddp_dev

@@ -160,7 +160,7 @@ static void gpu_tests() {
   }
   {   // a layout that is not instantiated on the device: loud error, never a silent fallback
     cddp::CDDP solver = makePendulum(opt);
-    solver.addPathConstraint("Extra", std::make_unique<cddp::StateConstraint>(cddp::Vector{-10.0, -10.0}, cddp::Vector{10.0, 10.0}));
+    solver.addPathConstraint("Extra", std::make_unique<cddp::BallConstraint>(0.5, cddp::Vector{1.0, 1.0}));
     bool threw = false;
     try { solver.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("no kernel instantiation") != std::string::npos; }
     EXPECT_TRUE(threw);

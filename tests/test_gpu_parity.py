@@ -40,10 +40,20 @@ def make(api, name):
         "manipulator_clddp_box": lambda: S.manipulator_problem(S.SOLVER_CLDDP, 40, False, True),
         "manipulator_ipddp_box": lambda: S.manipulator_problem(S.SOLVER_IPDDP, 40, False, True),
         "manip7_ipddp_box": lambda: _manip7(S),
+        "pendulum_ipddp_box_state": lambda: _with_state_box(S.pendulum_problem(S.SOLVER_IPDDP, True), [-4.0, -9.0], [4.0, 9.0]),
+        "cartpole_ipddp_box_state": lambda: _with_state_box(S.cartpole_problem(S.SOLVER_IPDDP, True), [-1.5, -7.0, -8.0, -25.0], [1.5, 7.0, 8.0, 25.0]),
+        "unicycle_ipddp_box_state": lambda: _with_state_box(S.unicycle_problem(S.SOLVER_IPDDP, 100, False), [-0.5, -0.5, -4.0], [2.6, 2.6, 4.0],
+                                                            name="state_limits"),
     }
     if name in TERM_CASES:
         return TERM_CASES[name](S)
     return table[name]()
+
+
+def _with_state_box(p, lo, hi, name="StateConstraint"):
+    """StateConstraint next to the control box (sorted after it by name): rows that read x (G_x blocks)."""
+    p.add_state_box(name, lo, hi)
+    return p
 
 
 def _renamed_unicycle(S):
@@ -129,7 +139,8 @@ BIG_CASES = ["unicycle_clddp_box", "quadrotor_ipddp_box", "quadrotor_clddp_box",
 
 CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pendulum_clddp_box",
          "cartpole_ipddp_unc", "cartpole_ipddp_box", "cartpole_clddp_unc", "cartpole_clddp_box",
-         "unicycle_ipddp_box", "unicycle_ipddp_box_ball"]
+         "unicycle_ipddp_box", "unicycle_ipddp_box_ball",
+         "pendulum_ipddp_box_state", "cartpole_ipddp_box_state", "unicycle_ipddp_box_state"]
 
 
 def spread_for(p):
