@@ -578,35 +578,37 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
     }
     for (int i = 0; i < NU; ++i) R[i * NU + i] += reg;
   };
+  // The (p+1) sequential LQR sweeps of the reference (solveSequentialLQR :413-476, once per unit terminal direction)
+  // share every MATRIX quantity -- LQ model, P recursion, Q_uu factor, K -- and differ only in the gradient
+  // recursion p_v.  One sweep therefore carries the matrices once and the p+1 gradient variants side by side
+  // (their running values stream through the te_p stack); each variant's arithmetic is unchanged.
   double xT[(kPTMax + 1) * NX];
-  for (int v = 0; v <= pT; ++v) {
-    double Pm[NX * NX], pv[NX];
-    for (int i = 0; i < NX; ++i) {
-      double a = VxN[i];
-      double add = 0.0;                                   // (H_T^T lambda_prev)_i, k ascending
-      for (int r = 0; r < pT; ++r) add += ((term_eq_col(P, r) == i) ? 1.0 : 0.0) * lam_prev[r];
-      a += add;
-      if (v > 0 && term_eq_col(P, v - 1) == i) a += 1.0;
-      pv[i] = a;
-    }
+  {
+    double Pm[NX * NX];
     for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Pm[i * NX + c] = 0.5 * (VxxN[i * NX + c] + VxxN[c * NX + i]);
-    for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + N) * NX + i) * d.Bp + b] = pv[i];
-    if (v == 0) st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Pm);
+    for (int v = 0; v <= pT; ++v)
+      for (int i = 0; i < NX; ++i) {
+        double a = VxN[i];
+        double add = 0.0;                                   // (H_T^T lambda_prev)_i, k ascending
+        for (int r = 0; r < pT; ++r) add += ((term_eq_col(P, r) == i) ? 1.0 : 0.0) * lam_prev[r];
+        a += add;
+        if (v > 0 && term_eq_col(P, v - 1) == i) a += 1.0;
+        d.te_p[(((size_t)v * (N + 1) + N) * NX + i) * d.Bp + b] = a;
+      }
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Pm);
     for (int t = N - 1; t >= 0; --t) {
       double Q[NX * NX], q[NX], R[NU * NU], r[NU], Mm[NX * NU], A[NX * NX], Bm[NX * NU];
-      lq_model(t, Q, q, R, r, Mm, A, Bm, v == 0);
-      double BtP[NU * NX], Quu[NU * NU], Qux[NU * NX], Qx[NX], Qu[NU];
+      lq_model(t, Q, q, R, r, Mm, A, Bm, true);
+      double BtP[NU * NX], Quu[NU * NU], Qux[NU * NX];
       mm_tn<NU, NX, NX>(Bm, Pm, BtP);
       {
-        double T1[NU * NU], T2[NU * NU], PtB[NX * NU];
+        double T1[NU * NU], T2[NU * NU];
         mm_nn<NU, NX, NU>(BtP, Bm, T1);                 // BtP * B
-        for (int i = 0; i < NX; ++i) for (int c = 0; c < NU; ++c) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Pm[k * NX + i] * Bm[k * NU + c]; PtB[i * NU + c] = a; }   // P^T B ... (B^T P^T) B
         {   // (B^T * P^T) * B with left-to-right association
           double BtPt[NU * NX];
           for (int i = 0; i < NU; ++i) for (int c = 0; c < NX; ++c) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * Pm[c * NX + k]; BtPt[i * NX + c] = a; }
           mm_nn<NU, NX, NU>(BtPt, Bm, T2);
         }
-        (void)PtB;
         for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) Quu[i * NU + c] = 0.5 * (((R[i * NU + c] + T1[i * NU + c]) + R[c * NU + i]) + T2[i * NU + c]);
       }
       {
@@ -614,45 +616,52 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
         mm_nn<NU, NX, NX>(BtP, A, T3);
         for (int i = 0; i < NU; ++i) for (int c = 0; c < NX; ++c) Qux[i * NX + c] = T3[i * NX + c] + Mm[c * NU + i];
       }
-      double drift[NX];
-      for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Pm[i * NX + k] * 0.0; drift[i] = pv[i] + a; }
-      for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += A[k * NX + i] * drift[k]; Qx[i] = q[i] + a; }
-      for (int i = 0; i < NU; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * drift[k]; Qu[i] = r[i] + a; }
       LDLTd<NU> f;
       f.compute(Quu, NU);
       if (!f.ok) return false;
-      double KK[NU * NX], kk[NU], col[NU];
+      double KK[NU * NX], col[NU];
       for (int c = 0; c < NX; ++c) { for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c]; f.solve(col); for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i]; }
-      for (int i = 0; i < NU; ++i) col[i] = Qu[i];
-      f.solve(col);
-      for (int i = 0; i < NU; ++i) kk[i] = -col[i];
-      // P = Q + A^T P A + Q_xu K + K^T Q_ux + K^T Q_uu K ; p = Q_x + Q_xu k + K^T Q_u + K^T Q_uu k
-      double T1[NX * NX], AtPA[NX * NX], KtQ[NX * NU], Pn[NX * NX], pn[NX];
-      mm_tn<NX, NX, NX>(A, Pm, T1);
-      mm_nn<NX, NX, NX>(T1, A, AtPA);
+      double KtQ[NX * NU];
       mm_tn<NX, NU, NU>(KK, Quu, KtQ);
       bool fin = true;
+      for (int i = 0; i < NU * NX; ++i) fin = fin && dfinite(KK[i]);
+      // ---- gradient variants (uses P_{t+1} = Pm before it is overwritten: the drift term is P * 0)
+      for (int v = 0; v <= pT; ++v) {
+        double pv[NX], drift[NX], Qx[NX], Qu[NU], kk[NU], pn[NX];
+        for (int i = 0; i < NX; ++i) pv[i] = d.te_p[(((size_t)v * (N + 1) + t + 1) * NX + i) * d.Bp + b];
+        for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Pm[i * NX + k] * 0.0; drift[i] = pv[i] + a; }
+        for (int i = 0; i < NX; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += A[k * NX + i] * drift[k]; Qx[i] = q[i] + a; }
+        for (int i = 0; i < NU; ++i) { double a = 0.0; for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * drift[k]; Qu[i] = r[i] + a; }
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+        f.solve(col);
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        for (int i = 0; i < NX; ++i) {
+          double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          for (int j = 0; j < NU; ++j) { a1 += Qux[j * NX + i] * kk[j]; a2 += KK[j * NX + i] * Qu[j]; a3 += KtQ[i * NU + j] * kk[j]; }
+          pn[i] = ((Qx[i] + a1) + a2) + a3;
+          fin = fin && dfinite(pn[i]);
+        }
+        for (int i = 0; i < NU; ++i) fin = fin && dfinite(kk[i]);
+        for (int i = 0; i < NU; ++i) d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] = kk[i];
+        for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + t) * NX + i) * d.Bp + b] = pn[i];
+      }
+      // P = Q + A^T P A + Q_xu K + K^T Q_ux + K^T Q_uu K
+      double T1[NX * NX], AtPA[NX * NX], Pn[NX * NX];
+      mm_tn<NX, NX, NX>(A, Pm, T1);
+      mm_nn<NX, NX, NX>(T1, A, AtPA);
       for (int i = 0; i < NX; ++i)
         for (int c = 0; c < NX; ++c) {
           double a1 = 0.0, a2 = 0.0, a3 = 0.0;
           for (int j = 0; j < NU; ++j) { a1 += Qux[j * NX + i] * KK[j * NX + c]; a2 += KK[j * NX + i] * Qux[j * NX + c]; a3 += KtQ[i * NU + j] * KK[j * NX + c]; }
           Pn[i * NX + c] = (((Q[i * NX + c] + AtPA[i * NX + c]) + a1) + a2) + a3;
         }
-      for (int i = 0; i < NX; ++i) {
-        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int j = 0; j < NU; ++j) { a1 += Qux[j * NX + i] * kk[j]; a2 += KK[j * NX + i] * Qu[j]; a3 += KtQ[i * NU + j] * kk[j]; }
-        pn[i] = ((Qx[i] + a1) + a2) + a3;
-        fin = fin && dfinite(pn[i]);
-      }
       for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) { Pm[i * NX + c] = 0.5 * (Pn[i * NX + c] + Pn[c * NX + i]); fin = fin && dfinite(Pm[i * NX + c]); }
-      for (int i = 0; i < NX; ++i) pv[i] = pn[i];
-      for (int i = 0; i < NU * NX; ++i) fin = fin && dfinite(KK[i]);
-      for (int i = 0; i < NU; ++i) fin = fin && dfinite(kk[i]);
       if (!fin) return false;
-      if (v == 0) { st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK); st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Pm); }
-      for (int i = 0; i < NU; ++i) d.te_k[(((size_t)v * N + t) * NU + i) * d.Bp + b] = kk[i];
-      for (int i = 0; i < NX; ++i) d.te_p[(((size_t)v * (N + 1) + t) * NX + i) * d.Bp + b] = pv[i];
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Pm);
     }
+  }
+  for (int v = 0; v <= pT; ++v) {
     // rolloutLinearPolicy for this variant (dx0 = 0)
     double dx[NX];
     for (int i = 0; i < NX; ++i) dx[i] = 0.0;
