@@ -1265,13 +1265,13 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   const double *Uc = d.U + (size_t)cur * d.planeU;
   const double *Sc = d.S + (size_t)cur * d.planeM;
   const double *Yc = d.Y + (size_t)cur * d.planeM;
-  const double *Lc = d.Lam + (size_t)cur * d.planeX;
+
   double *Xn = d.X + (size_t)slot * d.planeX;
   double *Un = d.U + (size_t)slot * d.planeU;
   double *Sn = d.S + (size_t)slot * d.planeM;
   double *Yn = d.Y + (size_t)slot * d.planeM;
   double *Gn = d.G + (size_t)slot * d.planeM;
-  double *Ln = d.Lam + (size_t)slot * d.planeX;
+
   const double alpha = P->alphas[a];
   const double mu = d.mu[b];
   const int mT = TERM ? P->mT : 0, pT = TERM ? P->pT : 0;
@@ -1293,17 +1293,12 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // software pipeline: record of step t+1 (old iterate, gains, value expansion) in flight during step t
   struct StepIn {
-    double xo[NX], lam[TERM ? NX : 1], vx[TERM ? NX : 1], vxx[TERM ? NX * NX : 1], uo[NU], kk[NU], KK[NU * NX];
+    double xo[NX], uo[NU], kk[NU], KK[NU * NX];
     double s[MM], y[MM], ksv[MM], ky[MM], Ksm[MM * NX], Ky[MM * NX];
   };
   auto load_step = [&](int tt, StepIn &r) {
     ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
-    if constexpr (TERM) {   // costate trial in the rollout (read back by the terminal-equality sweep);
-                            // without terminal constraints it is off the chain: k_costate (kernels_lean.hpp)
-      ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lam);
-      ld<NX>(d.Vx + GI(tt, NX, 0), kLS, r.vx);
-      ld<NX * NX>(d.Vxx + GI(tt, NX * NX, 0), kLS, r.vxx);
-    }
+    // (the costate trial is evaluated by k_costate, kernels_lean.hpp, for the trials that survive the rollout)
     if (tt < N) {
       ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
       ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
@@ -1318,29 +1313,21 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
       }
     }
   };
+  // large records (nx >= 12: K_s, K_y alone are 2 m nx rows) are fetched at the top of their own step into one register
+  // set -- a second copy would only add scratch traffic
+  constexpr bool kPing = sizeof(StepIn) <= 48 * sizeof(double);
   StepIn nxt;
-  load_step(0, nxt);
+  if constexpr (kPing) load_step(0, nxt);
   for (int t = 0; t <= N; ++t) {
-    StepIn cs = nxt;
-    if (t < N) load_step(t + 1, nxt);
+    StepIn held;
+    if constexpr (kPing) { held = nxt; if (t < N) load_step(t + 1, nxt); }
+    else load_step(t, nxt);
+    StepIn &cs = kPing ? held : nxt;
     PIPELINE_FENCE();
     double dx[NX];
     bool finite = true;
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = x[i] - cs.xo[i];
-    if constexpr (TERM) {
-      double lam[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) s += cs.vxx[i * NX + j] * dx[j];
-        lam[i] = (cs.lam[i] + a_pr * cs.vx[i]) + s;
-        finite = finite && dfinite(lam[i]);
-      }
-      if (!finite) return;
-      st<NX>(Ln + GI(t, NX, 0), kLS, lam);
-    }
     if constexpr (TERM) {
       if (t == N) {   // terminal slack / dual / multiplier trial (ipddp_solver.cpp:1667-1723)
         TermState to;

@@ -86,11 +86,10 @@ struct Launcher {
     }
     (void)first_only;
   }
-  // K4b: costate trial of the surviving trials (problems without terminal constraints; kernels_lean.hpp)
+  // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
     if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP) return;
-    if constexpr (!TERM)
-      hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
+    hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
