@@ -576,7 +576,8 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // Speculative line search: when batch x n_alphas wavefronts still underfill the chip (256 CUs x 4 SIMDs),
   // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
   // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
-  const long waves_all = (long)((d.B + 63) / 64) * na;
+  // (the two-role rollout of the path-constrained layouts runs two wavefronts per tile and alpha)
+  const long waves_all = (long)((d.B + 63) / 64) * na * ((P.solver == CDDP_HIP_SOLVER_IPDDP && ks->cst_size > 0) ? 2 : 1);
   // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
   // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
   const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
