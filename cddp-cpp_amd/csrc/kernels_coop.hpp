@@ -2,7 +2,7 @@
 //
 // The per-lane sweep (k_backward_ipddp_lean) runs ~740 f64 instructions per step on ONE wavefront per 64
 // trajectories: 64 wavefronts for the 4096-trajectory C2 batch, 6 % of the SIMDs, each bound by its own
-// instruction stream (a dependent f64 op costs ~9 cycles, an independent one ~5.4 on gfx950 -- scratch/ubench).
+// instruction stream (a dependent f64 op costs ~9 cycles, an independent one ~5.4 on gfx950 -- profiles/ubench).
 // Here the small dense products of one step are split across the G lanes of a trajectory group:
 //
 //   round 1  T1[:,q] = A^T V_xx[:,q], T2[:,q] = B^T V_xx[:,q], Q_x[q]                  -> LDS

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 // the running cost is summed by the consumer (same t order), the producer hands over l_f(x_N) at the end.
 // A lane whose rollout went non-finite is published through s_pstat.
 // Why the consumer reads nothing of the trial from global memory: a wave stalls at VMEM issue once ~sixteen 512-B
-// row loads are outstanding (scratch/ubench/vmem.hip), so row loads, not arithmetic, set the consumer's pace; the
+// row loads are outstanding (profiles/ubench/vmem.hip), so row loads, not arithmetic, set the consumer's pace; the
 // ring removes 2 NX + NU of them per step and K_s / K_y are rebuilt from K and YS (see k_post).
 // Every lane runs straight-line code with UNCONDITIONAL stores (a dead lane keeps re-evaluating its frozen state;
 // rows of a failed trial are never read): with stores inside divergent branches the waitcnt pass cannot count the
