@@ -1,0 +1,396 @@
+"""pycddp-compatible Python front end of the MI355X solver core.
+
+Same class / method / attribute names as the reference's pybind module (`python/src/bind_options.cpp:24-126`,
+`bind_dynamics.cpp:104-247`, `bind_solver.cpp:519-663`, `python/pycddp/__init__.py`), so the scripts and tests
+written against `pycddp` run on the GPU core after `import pycddp_amd as pycddp` -- for the plants, objectives and
+constraint kinds the device has kernels for.  On top of it:
+
+    solver.solve_batch(x0s, solver_type)   ->  list of CDDPSolution, one per row of x0s (one device-resident batch)
+
+Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Anything the device core does
+not implement raises (custom Python dynamics / objectives, LogDDP, MSIPDDP, use_ilqr=False, un-instantiated layouts).
+"""
+import enum
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _api():
+    name = "cddp_cpp_amd_pyapi"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(_HERE, "pyapi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------------------------------------------------------------------------ enums / options
+class SolverType(enum.Enum):        # options.hpp / bind_options.cpp:31-35
+    CLDDP = "CLDDP"
+    LogDDP = "LogDDP"
+    IPDDP = "IPDDP"
+    MSIPDDP = "MSIPDDP"
+
+
+class BarrierStrategy(enum.IntEnum):   # bind_options.cpp:26-29
+    ADAPTIVE = 0
+    MONOTONIC = 1
+    IPOPT = 2
+
+
+class BoxQPOptions:                 # boxqp.hpp:30-41
+    def __init__(self):
+        self.max_iterations = 100; self.min_gradient_norm = 1e-8; self.min_relative_improvement = 1e-8
+        self.step_decrease_factor = 0.6; self.min_step_size = 1e-22; self.armijo_constant = 0.1; self.verbose = False
+
+
+class LineSearchOptions:            # options.hpp
+    def __init__(self):
+        self.max_iterations = 11; self.initial_step_size = 1.0; self.min_step_size = 1e-8; self.step_reduction_factor = 0.5
+
+
+class RegularizationOptions:
+    def __init__(self):
+        self.initial_value = 1e-6; self.update_factor = 10.0; self.max_value = 1e7; self.min_value = 1e-10
+        self.step_initial_value = 1.0
+
+
+class BarrierOptions:
+    def __init__(self):
+        self.mu_initial = 1.0; self.mu_min_value = 1e-10; self.mu_update_factor = 0.5; self.mu_update_power = 1.2
+        self.min_fraction_to_boundary = 0.99; self.strategy = BarrierStrategy.ADAPTIVE
+
+
+class FilterOptions:
+    def __init__(self):
+        self.merit_acceptance_threshold = 1e-6; self.violation_acceptance_threshold = 1e-6
+        self.max_violation_threshold = 1e4; self.min_violation_for_armijo_check = 1e-7; self.armijo_constant = 1e-4
+
+
+class IPDDPOptions:
+    def __init__(self):
+        self.dual_var_init_scale = 0.1; self.slack_var_init_scale = 1e-2; self.barrier = BarrierOptions()
+
+
+class LogBarrierOptions:            # accepted for source compatibility; the LogDDP solver is not on the device
+    def __init__(self):
+        self.use_relaxed_log_barrier_penalty = False; self.relaxed_log_barrier_delta = 1e-10; self.barrier = BarrierOptions()
+
+
+class MSIPDDPOptions(IPDDPOptions):
+    def __init__(self):
+        super().__init__()
+        self.segment_length = 5; self.rollout_type = "nonlinear"; self.use_controlled_rollout = False
+        self.costate_var_init_scale = 1e-6
+
+
+class CDDPOptions:                  # options.hpp:41-251 / bind_options.cpp:96-126
+    def __init__(self):
+        self.tolerance = 1e-5; self.acceptable_tolerance = 1e-6; self.max_iterations = 1; self.max_cpu_time = 0.0
+        self.verbose = True; self.debug = False; self.print_solver_header = True; self.print_solver_options = False
+        self.use_ilqr = True; self.enable_parallel = False; self.num_threads = 1; self.return_iteration_info = False
+        self.warm_start = False; self.termination_scaling_max_factor = 100.0
+        self.line_search = LineSearchOptions(); self.regularization = RegularizationOptions(); self.box_qp = BoxQPOptions()
+        self.filter = FilterOptions(); self.log_barrier = LogBarrierOptions(); self.ipddp = IPDDPOptions()
+        self.msipddp = MSIPDDPOptions()
+
+    def to_pod(self):
+        o = _api().default_options()
+        o.tolerance = self.tolerance; o.acceptable_tolerance = self.acceptable_tolerance
+        o.max_iterations = int(self.max_iterations); o.use_ilqr = 1 if self.use_ilqr else 0
+        o.enable_parallel = 1 if self.enable_parallel else 0
+        o.return_iteration_info = 1 if self.return_iteration_info else 0; o.warm_start = 1 if self.warm_start else 0
+        o.termination_scaling_max_factor = self.termination_scaling_max_factor
+        ls, rg, bq, fl, ip = self.line_search, self.regularization, self.box_qp, self.filter, self.ipddp
+        o.ls_max_iterations = int(ls.max_iterations); o.ls_initial_step_size = ls.initial_step_size
+        o.ls_min_step_size = ls.min_step_size; o.ls_step_reduction_factor = ls.step_reduction_factor
+        o.reg_initial_value = rg.initial_value; o.reg_update_factor = rg.update_factor
+        o.reg_max_value = rg.max_value; o.reg_min_value = rg.min_value
+        o.boxqp_max_iterations = int(bq.max_iterations); o.boxqp_min_gradient_norm = bq.min_gradient_norm
+        o.boxqp_min_relative_improvement = bq.min_relative_improvement; o.boxqp_step_decrease_factor = bq.step_decrease_factor
+        o.boxqp_min_step_size = bq.min_step_size; o.boxqp_armijo_constant = bq.armijo_constant
+        o.filter_merit_acceptance_threshold = fl.merit_acceptance_threshold
+        o.filter_violation_acceptance_threshold = fl.violation_acceptance_threshold
+        o.filter_max_violation_threshold = fl.max_violation_threshold
+        o.filter_min_violation_for_armijo_check = fl.min_violation_for_armijo_check
+        o.filter_armijo_constant = fl.armijo_constant
+        o.ipddp_dual_var_init_scale = ip.dual_var_init_scale; o.ipddp_slack_var_init_scale = ip.slack_var_init_scale
+        b = ip.barrier
+        o.barrier_mu_initial = b.mu_initial; o.barrier_mu_min_value = b.mu_min_value
+        o.barrier_mu_update_factor = b.mu_update_factor; o.barrier_mu_update_power = b.mu_update_power
+        o.barrier_min_fraction_to_boundary = b.min_fraction_to_boundary; o.barrier_strategy = int(b.strategy)
+        return o
+
+
+# ------------------------------------------------------------------------------------------------ plants
+_INTEGRATORS = {"euler": 0, "heun": 1, "rk3": 2, "rk4": 3}
+
+
+class DynamicalSystem:
+    """Device-resident plants only; a Python subclass overriding the dynamics cannot run on the GPU."""
+    model = None
+
+    def __init__(self, state_dim, control_dim, timestep, integration_type="euler"):
+        if type(self) is DynamicalSystem or self.model is None:
+            raise NotImplementedError("custom Python dynamics cannot run on the HIP core: use a built-in plant "
+                                      "(or the stack-fed sweep cddp_hip_backward_stacks)")
+        if integration_type not in _INTEGRATORS:
+            raise ValueError("Unknown integration type: " + str(integration_type))
+        self.state_dim, self.control_dim, self.timestep, self.integration_type = state_dim, control_dim, timestep, integration_type
+        self.params = []; self.lti_A = None; self.lti_B = None
+
+
+class Pendulum(DynamicalSystem):    # bind_dynamics.cpp:133-137
+    def __init__(self, timestep, length=1.0, mass=1.0, damping=0.0, integration_type="euler"):
+        self.model = _api().MODEL_PENDULUM
+        super().__init__(2, 1, timestep, integration_type); self.params = [length, mass, damping, 9.81]
+
+
+class CartPole(DynamicalSystem):    # :152-158
+    def __init__(self, timestep, integration_type="rk4", cart_mass=1.0, pole_mass=0.2, pole_length=0.5, gravity=9.81, damping=0.0):
+        self.model = _api().MODEL_CARTPOLE
+        super().__init__(4, 1, timestep, integration_type); self.params = [cart_mass, pole_mass, pole_length, gravity, damping]
+
+
+class Unicycle(DynamicalSystem):    # :139-141
+    def __init__(self, timestep, integration_type="euler"):
+        self.model = _api().MODEL_UNICYCLE
+        super().__init__(3, 2, timestep, integration_type)
+
+
+class Quadrotor(DynamicalSystem):   # :177-182
+    def __init__(self, timestep, mass, inertia_matrix, arm_length, integration_type="euler"):
+        self.model = _api().MODEL_QUADROTOR
+        super().__init__(13, 4, timestep, integration_type)
+        J = np.asarray(inertia_matrix, dtype=np.float64)
+        self.params = [mass, arm_length, J[0, 0], J[1, 1], J[2, 2], 9.81]
+
+
+class Manipulator(DynamicalSystem):  # :189-191
+    def __init__(self, timestep, integration_type="rk4"):
+        self.model = _api().MODEL_MANIPULATOR
+        super().__init__(6, 3, timestep, integration_type)
+
+
+class LTISystem(DynamicalSystem):   # :233-237
+    def __init__(self, A, B, timestep, integration_type="euler"):
+        A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("A matrix must be square")
+        if B.shape[0] != A.shape[0]:
+            raise ValueError("B matrix must have same number of rows as A")
+        self.model = _api().MODEL_LTI
+        super().__init__(A.shape[0], B.shape[1], timestep, integration_type)
+        self.lti_A, self.lti_B = A, B
+
+
+# ------------------------------------------------------------------------------------------------ objective / constraints
+class QuadraticObjective:           # objective.hpp: (Q, R, Qf, reference_state, reference_states, timestep)
+    def __init__(self, Q, R, Qf, reference_state, reference_states=(), timestep=0.1):
+        self.Q = np.asarray(Q, dtype=np.float64); self.R = np.asarray(R, dtype=np.float64); self.Qf = np.asarray(Qf, dtype=np.float64)
+        for M_, n in ((self.Q, "Q"), (self.R, "R"), (self.Qf, "Qf")):
+            if M_.ndim != 2 or M_.shape[0] != M_.shape[1]:
+                raise ValueError(n + " matrix must be square")
+        self.reference_state = np.asarray(reference_state, dtype=np.float64)
+        self.reference_states = [np.asarray(r, dtype=np.float64) for r in reference_states]
+        if self.reference_states and np.linalg.norm(self.reference_states[-1] - self.reference_state) > 1e-6:
+            raise ValueError("Last reference state must be same as the reference state")   # objective.cpp:55-63
+        self.timestep = timestep
+
+
+class ControlConstraint:            # constraint.hpp:144-251 (BoxConstraint<Control>)
+    def __init__(self, lower_bound, upper_bound, scale_factor=1.0):
+        self.lower = np.asarray(lower_bound, dtype=np.float64); self.upper = np.asarray(upper_bound, dtype=np.float64); self.scale = scale_factor
+
+
+class StateConstraint(ControlConstraint):
+    pass
+
+
+class BallConstraint:               # constraint.hpp:313-404
+    def __init__(self, radius, center, scale_factor=1.0):
+        self.radius = radius; self.center = np.asarray(center, dtype=np.float64); self.scale = scale_factor
+
+
+class LinearConstraint:             # constraint.hpp:253-311
+    def __init__(self, A, b, scale_factor=1.0):
+        self.A = np.asarray(A, dtype=np.float64); self.b = np.asarray(b, dtype=np.float64)
+
+
+class TerminalEqualityConstraint:   # terminal_constraint.hpp
+    def __init__(self, target_state):
+        self.target = np.asarray(target_state, dtype=np.float64)
+
+
+class TerminalInequalityConstraint:
+    def __init__(self, A, b):
+        self.A = np.asarray(A, dtype=np.float64); self.b = np.asarray(b, dtype=np.float64)
+
+
+# ------------------------------------------------------------------------------------------------ solution
+class SolutionHistory:              # bind_solver.cpp:523-540
+    def __init__(self):
+        self.objective = []; self.merit_function = []; self.step_length_primal = []; self.step_length_dual = []
+        self.dual_infeasibility = []; self.primal_infeasibility = []; self.complementary_infeasibility = []
+        self.barrier_mu = []; self.regularization = []
+
+
+class CDDPSolution:                 # cddp_core.hpp:54-103 / bind_solver.cpp:542-570
+    def __init__(self):
+        self.solver_name = ""; self.status_message = ""; self.iterations_completed = 0; self.solve_time_ms = 0.0
+        self.final_objective = 0.0; self.final_step_length = 1.0; self.final_regularization = 0.0
+        self.time_points = []; self.state_trajectory = []; self.control_trajectory = []; self.feedback_gains = []
+        self.final_primal_infeasibility = 0.0; self.final_dual_infeasibility = 0.0
+        self.final_complementary_infeasibility = 0.0; self.final_barrier_mu = 0.0
+        self.history = SolutionHistory()
+
+
+# ------------------------------------------------------------------------------------------------ CDDP
+class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:572-663
+    def __init__(self, initial_state, reference_state, horizon, timestep, options=None):
+        self._x0 = np.asarray(initial_state, dtype=np.float64).copy()
+        self._xref = np.asarray(reference_state, dtype=np.float64).copy()
+        self._N = int(horizon); self._dt = float(timestep)
+        self._opt = options if options is not None else CDDPOptions()
+        self._sys = None; self._obj = None; self._cons = {}; self._terms = {}
+        self._X = None; self._U = None
+
+    # -- setters (snake_case names of the pybind layer)
+    def set_initial_state(self, x0): self._x0 = np.asarray(x0, dtype=np.float64).copy()
+    def set_reference_state(self, xr): self._xref = np.asarray(xr, dtype=np.float64).copy()
+    def set_reference_states(self, xs): self._xref_traj = [np.asarray(x, dtype=np.float64) for x in xs]
+    def set_horizon(self, horizon): self._N = int(horizon)
+    def set_timestep(self, timestep): self._dt = float(timestep)
+    def set_options(self, options): self._opt = options
+    def set_dynamical_system(self, system):
+        if not isinstance(system, DynamicalSystem):
+            raise TypeError("set_dynamical_system expects a built-in plant of this module")
+        self._sys = system
+    def set_objective(self, objective):
+        if not isinstance(objective, QuadraticObjective):
+            raise NotImplementedError("only QuadraticObjective runs on the HIP core")
+        self._obj = objective
+    def add_constraint(self, name, constraint):
+        if constraint is None:
+            raise RuntimeError("Cannot add null constraint.")
+        self._cons[name] = constraint
+    def add_terminal_constraint(self, name, constraint):
+        if constraint is None:
+            raise RuntimeError("Cannot add null constraint.")
+        self._terms[name] = constraint
+    def remove_constraint(self, name): return self._cons.pop(name, None) is not None
+    def remove_terminal_constraint(self, name): return self._terms.pop(name, None) is not None
+    def set_initial_trajectory(self, X, U):
+        X = [np.asarray(x, dtype=np.float64) for x in X]; U = [np.asarray(u, dtype=np.float64) for u in U]
+        if len(X) != self._N + 1 or len(U) != self._N:   # cddp_core.cpp:124-140
+            raise ValueError("Invalid trajectory lengths")
+        self._X, self._U = np.stack(X), np.stack(U)
+
+    initial_state = property(lambda self: self._x0)
+    reference_state = property(lambda self: self._xref)
+    horizon = property(lambda self: self._N)
+    timestep = property(lambda self: self._dt)
+    state_dim = property(lambda self: self._sys.state_dim)
+    control_dim = property(lambda self: self._sys.control_dim)
+    options = property(lambda self: self._opt)
+
+    # -- problem descriptor for the C-ABI
+    def _problem(self, solver_kind):
+        api = _api()
+        if self._sys is None:
+            raise RuntimeError("Dynamical system must be set before solving.")   # cddp_core.cpp:277-282
+        if self._obj is None:
+            raise RuntimeError("Objective function must be set before solving.")
+        s, ob = self._sys, self._obj
+        traj = ob.reference_states if ob.reference_states else None
+        p = api.Problem(solver_kind, s.model, _INTEGRATORS[s.integration_type], s.state_dim, s.control_dim, self._N, self._dt,
+                        ob.Q, ob.R, ob.Qf, ob.reference_state, model_params=s.params, lti_A=s.lti_A, lti_B=s.lti_B,
+                        x_ref_traj=None if traj is None else np.stack(traj), options=self._opt.to_pod())
+        for name in sorted(self._cons):          # std::map order
+            c = self._cons[name]
+            if isinstance(c, StateConstraint): p.add_state_box(name, c.lower, c.upper, c.scale)
+            elif isinstance(c, ControlConstraint): p.add_control_box(name, c.lower, c.upper, c.scale)
+            elif isinstance(c, BallConstraint): p.add_ball(name, c.radius, c.center, c.scale)
+            elif isinstance(c, LinearConstraint): p.add_linear(name, c.A, c.b)
+            else: raise NotImplementedError("constraint type %s has no device kernel" % type(c).__name__)
+        for name in sorted(self._terms):
+            c = self._terms[name]
+            if isinstance(c, TerminalEqualityConstraint): p.add_terminal_equality(name, c.target)
+            elif isinstance(c, TerminalInequalityConstraint): p.add_terminal_inequality(name, c.A, c.b)
+            else: raise NotImplementedError("terminal constraint type %s has no device kernel" % type(c).__name__)
+        return p
+
+    def _solve(self, name, x0s):
+        api = _api()
+        if name not in ("CLDDP", "IPDDP"):
+            if name in ("LogDDP", "MSIPDDP"):
+                raise NotImplementedError(name + " is not implemented on the HIP core (CLDDP and IPDDP are)")
+            sol = CDDPSolution()                 # cddp_core.cpp:243-265: unknown names do not throw
+            sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
+            return [sol for _ in range(len(x0s))]
+        kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_CLDDP
+        p = self._problem(kind)
+        B = len(x0s)
+        x0 = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64) for x in x0s]))
+        U0 = None if self._U is None else np.ascontiguousarray(np.tile(self._U, (B, 1, 1)))
+        X0 = None if self._X is None else np.ascontiguousarray(np.tile(self._X, (B, 1, 1)))
+        hs = api.HipBatchSolver(p, B)
+        try:
+            hs.set_initial(x0, U0, X0)
+            st = hs.solve()
+            res = hs.results(); X, U = hs.trajectory(); K, _ = hs.gains()
+            hist = hs.history(min(B, 64)) if self._opt.return_iteration_info else None
+        finally:
+            hs.close()
+        out = []
+        for b in range(B):
+            s = CDDPSolution()
+            s.solver_name = name; s.status_message = api.STATUS_STRINGS[int(res["status"][b])]
+            s.iterations_completed = int(res["iterations"][b]); s.solve_time_ms = float(st.solve_ms)
+            s.final_objective = float(res["final_objective"][b]); s.final_step_length = float(res["alpha_pr"][b])
+            s.final_regularization = float(res["regularization"][b])
+            s.final_primal_infeasibility = float(res["inf_pr"][b]); s.final_dual_infeasibility = float(res["inf_du"][b])
+            s.final_complementary_infeasibility = float(res["inf_comp"][b]); s.final_barrier_mu = float(res["barrier_mu"][b])
+            s.time_points = [t * self._dt for t in range(self._N + 1)]
+            s.state_trajectory = [X[b, t].copy() for t in range(self._N + 1)]
+            s.control_trajectory = [U[b, t].copy() for t in range(self._N)]
+            s.feedback_gains = [K[b, t].copy() for t in range(self._N)]
+            if hist is not None and b < len(hist):
+                h = hist[b]
+                s.history.objective = list(h[:, 0]); s.history.merit_function = list(h[:, 1])
+                s.history.step_length_primal = list(h[:, 2]); s.history.step_length_dual = list(h[:, 3])
+                s.history.dual_infeasibility = list(h[:, 4]); s.history.primal_infeasibility = list(h[:, 5])
+                s.history.complementary_infeasibility = list(h[:, 6])
+                s.history.barrier_mu = list(h[:, 7]) if name == "IPDDP" else []
+                s.history.regularization = list(h[:, 8])
+            out.append(s)
+        return out
+
+    def solve(self, solver_type=SolverType.CLDDP):
+        name = solver_type.value if isinstance(solver_type, SolverType) else str(solver_type)
+        sol = self._solve(name, [self._x0])[0]
+        if sol.state_trajectory:     # the context keeps the solution, as the reference solvers leave it (cddp_solver_base.cpp:161-171)
+            self._X = np.stack(sol.state_trajectory); self._U = np.stack(sol.control_trajectory)
+        return sol
+
+    def solve_by_name(self, solver_name):   # bind_solver.cpp:95-100, 637-654; aliases of cddp_core.cpp:221-230
+        alias = {"CLCDDP": "CLDDP", "LOGDDP": "LogDDP"}
+        if solver_name not in ("CLDDP", "CLCDDP", "LogDDP", "LOGDDP", "IPDDP", "MSIPDDP"):
+            raise ValueError("Unknown solver '%s'." % solver_name)
+        return self.solve(alias.get(solver_name, solver_name))
+
+    def solve_batch(self, x0s, solver_type=SolverType.IPDDP):
+        """One device-resident batch: solution i starts from x0s[i] (same problem, same initial trajectory guess)."""
+        name = solver_type.value if isinstance(solver_type, SolverType) else str(solver_type)
+        return self._solve(name, list(x0s))
+
+
+__all__ = [n for n in dir() if not n.startswith("_") and n not in ("enum", "importlib", "os", "sys", "np")]
+__version__ = "0.1.0"
