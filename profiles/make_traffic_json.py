@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Build the per-kernel HBM traffic JSON bench.py reads from a summarize_pmc.py table.
+usage: make_traffic_json.py pmc_counters.md "<source note>" > rNN_x_pmc_traffic.json
+bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 correction, profiles/r01_c_pmc_calibration.md) + WRITE_SIZE x 1024."""
+import json
+import sys
+
+rows = [l.strip().strip("|").split("|") for l in open(sys.argv[1]) if l.startswith("|")]
+hdr = [c.strip() for c in rows[0]]
+fi, wi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
+kern = {}
+for r in rows[2:]:
+    c = [x.strip() for x in r]
+    if not c[fi] or not c[wi]:
+        continue
+    f, w = float(c[fi]), float(c[wi])
+    kern[c[0].strip("`")] = {"fetch_kb": f, "write_kb": w, "bytes_per_launch": f * 1024 * 2 + w * 1024}
+print(json.dumps({
+    "source": sys.argv[2],
+    "calibration": "FETCH_SIZE reads 0.488x the known bytes of the 8-B/lane and 16-B/lane row streams of "
+                   "profiles/ubench/vmem.hip on this gfx950 stack (guide: x2 correction); WRITE_SIZE reads 0.976x "
+                   "the bytes of hipMemset fills (no correction). profiles/r01_c_pmc_calibration.md",
+    "unit": "bytes per launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)",
+    "kernels": kern}, indent=1))
