@@ -321,7 +321,16 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
     DA(d.LamT, (size_t)16 * Bp); DA(d.dLamT, (size_t)16 * Bp);
     DA(d.STt, (size_t)d.n_alphas * 8 * Bp); DA(d.YTt, (size_t)d.n_alphas * 8 * Bp); DA(d.GTt, (size_t)d.n_alphas * 8 * Bp);
     DA(d.LamTt, (size_t)d.n_alphas * 16 * Bp);
-    if (P.pT > 0) { DA(d.te_k, (size_t)(P.pT + 1) * N * nu * Bp); DA(d.te_p, (size_t)(P.pT + 1) * (N + 1) * nx * Bp); }
+    if (P.pT > 0) {
+      // cooperative reduced-LQR sweep (kernels_te.hpp): one lane per gradient variant, variant stride 16
+      const bool te_coop = h->ks->te_rec_size > 0 && P.mT == 0 && P.pT + 1 <= h->ks->te_group;
+      const size_t nv = te_coop ? 16 : (size_t)(P.pT + 1);
+      DA(d.te_k, nv * N * nu * Bp); DA(d.te_p, nv * (N + 1) * nx * Bp);
+      if (te_coop) {
+        DA(d.te_cst, (size_t)N * h->ks->te_rec_size * Bp); DA(d.te_cnt, Bp);
+        if (!d.dX) DA(d.dX, (size_t)N * nx * Bp);
+      }
+    }
   }
   DA(d.n_active, 1);
   DA(h->d_launched, 1);

@@ -61,6 +61,9 @@ struct DevBuf {
   double *ST, *YT, *GT, *dST, *dYT, *LamT, *dLamT;
   double *STt, *YTt, *GTt, *LamTt;        // trial copies [n_alphas][kMTMax|kPTMax][Bp]
   double *te_k, *te_p;                     // terminal-equality LQR variants: [(pT+1)][N][nu][Bp], [(pT+1)][N+1][nx][Bp]
+                                           // (cooperative sweep, kernels_te.hpp: [N][Bp][nu][16], [N+1][Bp][nx][16])
+  double *te_cst;                          // [N][REC][Bp] LQ-model terms of the terminal-equality sweep (k_te_condense), or null
+  int *te_cnt;                             // [Bp] k_te_post: steps finished per trajectory (-1: sweep failed)
   // per-trajectory scalars [Bp]
   double *cost, *merit, *inf_pr, *inf_du, *inf_comp, *step_norm, *alpha_pr, *alpha_du, *reg, *mu;
   double *dV0, *dV1, *phi, *theta, *filter_theta, *apr_max, *adu_max;

@@ -1,0 +1,791 @@
+// Lane-cooperative form of the terminal-equality reduced-LQR backward pass (IPDDPSolver::backwardPass,
+// ipddp_solver.cpp:1120-1353; solveTerminalEqualityLQR :478-639; solveSequentialLQR :413-476).
+//
+// The one-lane-per-trajectory form (te_backward, kernels.hpp) keeps the nx x nx blocks of a 7-joint arm in scratch
+// memory on 64 wavefronts: 665 ms per sweep at BASELINE config 5 (profiles/r01_f).  Here G lanes share a
+// trajectory exactly as in kernels_coop.hpp (lane q owns column q of P_t, operands in LDS), and the p+1 gradient
+// recursions of the reduced LQR -- the nominal one and one per unit terminal direction -- ride along ONE PER LANE
+// (p + 1 <= G): lane v carries p_v(t) in registers, reads A_t, B_t, Q_ux, K, K^T Q_uu from LDS, and later rolls its
+// own closed-loop variant forward.  Passes of one sweep:
+//
+//   k_te_condense      (batch x N)   the per-step LQ model terms that do not depend on P: q, r, R, residual maxima
+//   k_backward_te_coop (G lanes per trajectory)
+//        P1  backward matrix recursion + p+1 gradient recursions           -> K, V_xx, te_k, te_p
+//        P2  linear rollout of the p+1 closed loops (lane v = variant v)   -> x_T variants (LDS)
+//        P3  p x p regularised normal equations for the multiplier step (lane 0; operands in LDS)
+//        P4  recombination k = k_0 + sum_v lambda_v (k_v - k_0), same for V_x  (elements spread over the lanes)
+//        P5  linear-policy rollout dX with the final gains (row per lane)
+//   k_te_post          (batch x N)   max |Q_u|, slack / dual gains k_s, k_y, K_s, K_y, step caps; the last step
+//                                     of a trajectory to finish applies the early-convergence test
+//
+// Every number is produced by the same expression, in the same order, as te_backward (the parity tests compare
+// both against the oracle).  Layouts with state-dependent path rows (HAS_X) or terminal inequalities keep the
+// one-lane kernel.
+#pragma once
+#include "kernels_coop.hpp"
+
+namespace cddp_dev {
+
+#define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
+
+template <class Model, class Cons>
+struct TeCfg {
+  static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = 64 / G;
+  static constexpr int PMAX = (G - 1 < kPTMax) ? G - 1 : kPTMax;   // one lane per gradient variant: pT + 1 <= G
+  static constexpr int VP = 16;                                     // variant stride of the te_k / te_p stacks
+  // per-step record written by k_te_condense
+  static constexpr int cQ = 0, cR = NX, cRR = NX + NU, cIPR = cRR + NU * NU, cICOMP = cIPR + 1, REC = cICOMP + 1;
+  static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G, NC = (REC + G - 1) / G, NK = (NU * NX + G - 1) / G;
+  // LDS map of one trajectory
+  static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
+                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oC = oKtQ + NX * NU, SWEEP_END = oC + 2 * REC;
+  static constexpr int P3 = 4 * PMAX * PMAX + 6 * PMAX;            // reduced-system work area (overlays the sweep area)
+  static constexpr int oXT = SWEEP_END > P3 ? SWEEP_END : P3;
+  static constexpr int oH = oXT + (PMAX + 1) * NX, oLam = oH + PMAX, oBest = oLam + PMAX, oDx = oBest + PMAX,
+                       oPv = oDx + NX, oRed = oPv + NX * G, RAW = oRed + G;
+  static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
+  static_assert(NX * NX >= NU, "gain buffers of the dX rollout fit the A/B area");
+};
+
+DEV void atomic_max_pos(double *addr, double v) {   // v >= 0: the IEEE bit pattern orders like an unsigned integer
+  if (!(v >= 0.0)) return;
+  atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// ================================================================================ LQ model terms, (batch x N)
+// q = l_x + G_x^T (y + S^-1 rhat), r = l_u + G_u^T (y + S^-1 rhat), R = sym(l_uu + G_u^T Y S^-1 G_u)
+// (ipddp_solver.cpp:1143-1245); Q and the cross term do not depend on the step for layouts without G_x.
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_te_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef Objective<NX, NU> Obj;
+  typedef TeCfg<Model, Cons> C;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  const double mu = d.mu[b];
+  const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+  double x[NX], u[NU], q[NX], r[NU], R[NU * NU];
+  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+  ld<NU>(Uc + GI(t, NU, 0), kLS, u);
+  const double *Rd = P->pool + P->off_Rdt;
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+#pragma unroll
+    for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * ((2.0 * Rd[i * NU + c]) + (2.0 * Rd[c * NU + i]));
+  Obj::lx(P, xrt, t, x, q);
+  Obj::lu(P, u, r);
+  double ipr = 0.0, icomp = 0.0;
+  if constexpr (M > 0) {
+    const double *Sc = d.S + (size_t)cur * d.planeM;
+    const double *Yc = d.Y + (size_t)cur * d.planeM;
+    const double *Gc = d.G + (size_t)cur * d.planeM;
+    double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], YS[MM], ypS[MM];
+    ld<M>(Yc + GI(t, M, 0), kLS, y);
+    ld<M>(Sc + GI(t, M, 0), kLS, s);
+    ld<M>(Gc + GI(t, M, 0), kLS, g);
+#pragma unroll
+    for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+    Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const double ss = dmax(s[i], s_floor);
+      YS[i] = clip_pos(y[i], ss);
+      const double rp = g[i] + s[i], rc = y[i] * s[i] - mu;
+      const double rhat = y[i] * rp - rc;
+      ypS[i] = y[i] + clip_sgn(rhat, ss);
+      ipr = dmax(ipr, fabs(rp)); icomp = dmax(icomp, fabs(rc));
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { double a = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) a += Qyx[rr * NX + i] * ypS[rr];
+      q[i] += a; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) a += Qyu[rr * NU + i] * ypS[rr];
+      r[i] += a; }
+    double Rn[NU * NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+      for (int c = 0; c < NU; ++c) { double a = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < M; ++rr) a += (Qyu[rr * NU + i] * YS[rr]) * Qyu[rr * NU + c];
+        Rn[i * NU + c] = R[i * NU + c] + a; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+      for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * (Rn[i * NU + c] + Rn[c * NU + i]);
+  }
+  double *rec = d.te_cst + GI(t, C::REC, 0);
+  st<NX>(rec + (size_t)C::cQ * kLS, kLS, q);
+  st<NU>(rec + (size_t)C::cR * kLS, kLS, r);
+  st<NU * NU>(rec + (size_t)C::cRR * kLS, kLS, R);
+  rec[(size_t)C::cIPR * kLS] = ipr;
+  rec[(size_t)C::cICOMP * kLS] = icomp;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduced-system helpers on memory operands (LDS): the steps of LDLTd<NMAX>::compute / solve and of
+// singular_minmax (kernels.hpp) with an explicit leading dimension; run-time size n.
+DEV bool ldlt_mem_compute(double *m, double *trd, double *temp, int n, int ld) {
+  if (n <= 1) { if (n == 1) trd[0] = 0.0; return true; }
+  bool found_zero_pivot = false, ret = true;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double bigv = fabs(m[k * ld + k]);
+    for (int i = k + 1; i < n; ++i) { const double v = fabs(m[i * ld + i]); if (v > bigv) { bigv = v; big = i; } }
+    trd[k] = (double)big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; ++j) { const double t = m[k * ld + j]; m[k * ld + j] = m[big * ld + j]; m[big * ld + j] = t; }
+      for (int i = 0; i < s; ++i) { const double t = m[(big + 1 + i) * ld + k]; m[(big + 1 + i) * ld + k] = m[(big + 1 + i) * ld + big]; m[(big + 1 + i) * ld + big] = t; }
+      { const double t = m[k * ld + k]; m[k * ld + k] = m[big * ld + big]; m[big * ld + big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = m[i * ld + k]; m[i * ld + k] = m[big * ld + i]; m[big * ld + i] = t; }
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = m[j * ld + j] * m[k * ld + j];
+      double s = 0.0;
+      for (int j = 0; j < k; ++j) s += m[k * ld + j] * temp[j];
+      m[k * ld + k] -= s;
+      for (int i = 0; i < rs; ++i) {
+        double t = 0.0;
+        for (int j = 0; j < k; ++j) t += m[(k + 1 + i) * ld + j] * temp[j];
+        m[(k + 1 + i) * ld + k] -= t;
+      }
+    }
+    const double akk = m[k * ld + k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < n; ++j) {
+        trd[j] = (double)j;
+        for (int i = j + 1; i < n; ++i) ret = ret && (m[i * ld + j] == 0.0);
+      }
+      return ret;
+    }
+    if (rs > 0 && valid) { for (int i = 0; i < rs; ++i) m[(k + 1 + i) * ld + k] /= akk; }
+    else if (rs > 0) { for (int i = 0; i < rs; ++i) ret = ret && (m[(k + 1 + i) * ld + k] == 0.0); }
+    if (found_zero_pivot && valid) ret = false;
+    else if (!valid) found_zero_pivot = true;
+  }
+  return ret;
+}
+DEV void ldlt_mem_solve(const double *m, const double *trd, int n, int ld, double *x) {
+  for (int k = 0; k < n; ++k) { const int t = (int)trd[k]; if (t != k) { const double v = x[k]; x[k] = x[t]; x[t] = v; } }
+  for (int i = 0; i < n; ++i) { double s = x[i]; for (int kk = 0; kk < i; ++kk) s -= m[i * ld + kk] * x[kk]; x[i] = s; }
+  for (int i = 0; i < n; ++i) { const double dd = m[i * ld + i]; x[i] = (fabs(dd) > DBL_MIN) ? x[i] / dd : 0.0; }
+  for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int kk = i + 1; kk < n; ++kk) s -= m[kk * ld + i] * x[kk]; x[i] = s; }
+  for (int k = n - 1; k >= 0; --k) { const int t = (int)trd[k]; if (t != k) { const double v = x[k]; x[k] = x[t]; x[t] = v; } }
+}
+DEV void singular_minmax_mem(double *U, const double *A, int n, int ld, double &smax, double &smin) {   // one-sided Jacobi
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) U[i * ld + j] = A[i * ld + j];
+  for (int sweep = 0; sweep < 80; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < n; ++i) { alpha += U[i * ld + p] * U[i * ld + p]; beta += U[i * ld + q] * U[i * ld + q]; gamma += U[i * ld + p] * U[i * ld + q]; }
+        if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-16 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < n; ++i) { const double up = U[i * ld + p], uq = U[i * ld + q]; U[i * ld + p] = cs * up - sn * uq; U[i * ld + q] = sn * up + cs * uq; }
+      }
+    if (!rotated) break;
+  }
+  smax = 0.0; smin = INFINITY;
+  for (int j = 0; j < n; ++j) { double s2 = 0; for (int i = 0; i < n; ++i) s2 += U[i * ld + j] * U[i * ld + j]; const double sv = sqrt(s2); smax = dmax(smax, sv); smin = dmin(smin, sv); }
+  if (n == 0) { smax = 0.0; smin = 0.0; }
+}
+
+// ================================================================================ cooperative sweep
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                         int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  typedef TeCfg<Model, Cons> C;
+  constexpr int G = C::G, REC = C::REC, VP = C::VP;
+  __shared__ double lds[C::TPW * C::STRIDE];
+  __shared__ double ldsQ[NX * NX];   // sym(2 Q dt): the LQ model's Q for layouts without G_x (loop-invariant)
+  __shared__ int ldsCol[kPTMax];     // state index selected by each stacked terminal-equality row
+  const int lane = threadIdx.x;
+  {   // every lane of the wavefront takes part, BEFORE the per-trajectory early exits
+    const double *Qp = Pk->pool + Pk->off_Qdt;
+    for (int e = lane; e < NX * NX; e += 64) { const int i = e / NX, c = e % NX; ldsQ[e] = 0.5 * ((2.0 * Qp[i * NX + c]) + (2.0 * Qp[c * NX + i])); }
+    if (lane < kPTMax) ldsCol[lane] = (lane < Pk->pT) ? term_eq_col(Pk, lane) : 0;
+    lds_sync();
+  }
+  const int q = lane % G, tl = lane / G;
+  const int qc = q < NX ? q : NX - 1;
+  const int b = blockIdx.x * C::TPW + tl;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  double *Ls = lds + tl * C::STRIDE;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N, pT = P->pT;
+  const bool hasv = q <= pT;           // this lane carries gradient variant v = q
+  const int v = q;
+  const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << (tl * G);
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  if (count_iter && q == 0) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  bool ok = false;
+  int nb = 0;
+  double inf_pr = 0, inf_comp = 0, step_norm = 0;
+  double *tek = d.te_k, *tep = d.te_p;
+  const size_t Bp = d.Bp;
+  struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
+  auto loadAB = [&](int tt, InAB &r) {   // this lane's slices of A_t, B_t and of the step's LQ record
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.te_cst[GI(tt, REC, e < REC ? e : REC - 1)]; }
+  };
+  auto storeAB = [&](int buf, const InAB &r) {
+    double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU, *Lc = Ls + C::oC + buf * REC;
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; if (e < NX * NU) Lb[e] = r.bm[j]; }
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; if (e < REC) Lc[e] = r.c[j]; }
+  };
+  for (;;) {
+    ++nb;
+    inf_pr = 0; inf_comp = 0; step_norm = 0;
+    double Vc[NX], pv[NX];
+    {   // ---- terminal data: h_T, previous multipliers, P_N, p_v(N)
+      double xN[NX], VxN[NX];
+      ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+      Obj::final_grad(P, xN, VxN);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = xN[i];
+      lds_sync();
+      if (q < pT) {
+        double h = 0.0;
+        for (int c = 0; c < P->n_term; ++c) {
+          const TermDev &td = P->terms[c];
+          if (td.kind != CDDP_HIP_TERM_EQUALITY) continue;
+          if (q >= td.offset && q < td.offset + td.dim) { const int r = q - td.offset; h = Ls[C::oDx + r] - P->pool[td.off_target + r]; }
+        }
+        Ls[C::oH + q] = h;
+        Ls[C::oLam + q] = d.LamT[(size_t)q * Bp + b];
+      }
+      lds_sync();
+      for (int r = 0; r < pT; ++r) inf_pr = dmax(inf_pr, fabs(Ls[C::oH + r]));
+      const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        // V_xx(N) = sym(2 Qf), then P_N = sym(V_xx(N)) (te_backward prologue)
+        const double vic = 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
+        const double vci = 0.5 * ((2.0 * Qf[qc * NX + i]) + (2.0 * Qf[i * NX + qc]));
+        Vc[i] = 0.5 * (vic + vci);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = VxN[i];
+        double add = 0.0;                                   // (H_T^T lambda_prev)_i, rows ascending
+        for (int r = 0; r < pT; ++r) add += ((ldsCol[r] == i) ? 1.0 : 0.0) * Ls[C::oLam + r];
+        a += add;
+        if (hasv && v > 0 && ldsCol[v - 1] == i) a += 1.0;
+        pv[i] = a;
+      }
+      if (hasv) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tep[(((size_t)N * Bp + b) * NX + i) * VP + v] = pv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d.Vxx[GI(N, NX * NX, i * NX + qc)] = Vc[i];
+    }
+    bool fail = false;
+    // ---- P1: matrix recursion + gradient variants
+    auto step = [&](const int t, InAB &nab) -> bool {
+      const int tp = t > 0 ? t - 1 : 0;
+      const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU, *Lc = Ls + C::oC + (t & 1) * REC;
+      loadAB(tp, nab);
+      PIPELINE_FENCE();
+      bool bad = false;
+      double Aq[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Aq[j] = La[j * NX + qc];
+      // round 1: column qc of T1 = A^T P and of BtP = B^T P
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
+        Ls[C::oM + i * NX + qc] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Lb[k * NU + u] * Vc[k];
+        Ls[C::oT2 + u * NX + qc] = s; }
+      lds_sync();
+      // round 2: Q + A^T P A (in place over T1, row by row), Q_ux column, Q_uu (replicated), factor, K column
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
+        Ls[C::oM + i * NX + qc] = ldsQ[i * NX + qc] + s; }
+      double Quxq[NU], Quu[NU * NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Aq[j];
+        Quxq[u] = s + 0.0; }          // + M^T, M = 0 without G_x
+      {
+        double Rm[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Rm[i] = Lc[C::cRR + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Rm[i * NU + i] += reg;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int w = 0; w < NU; ++w) { double s = 0.0;    // (B^T P) B; (B^T P^T) B is the same number: P is exactly symmetric
+#pragma unroll
+            for (int k = 0; k < NX; ++k) s += Ls[C::oT2 + u * NX + k] * Lb[k * NU + w];
+            Quu[u * NU + w] = s; }
+        double Qs[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (((Rm[i * NU + c] + Quu[i * NU + c]) + Rm[c * NU + i]) + Quu[i * NU + c]);
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+      }
+      double KKc[NU];
+      LDLTs<NU> f;
+      if constexpr (NU == 1) {
+        KKc[0] = -ldlt1_solve(Quu[0], Quxq[0]);
+      } else {
+        f.compute(Quu, NU);
+        if (!f.ok) bad = true;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Quxq[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) bad = bad || !dfinite(KKc[i]);
+      {
+        double KtQq[NU];   // row qc of K^T Q_uu
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { double s = 0.0;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
+          KtQq[j] = s; }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; Ls[C::oKtQ + qc * NU + u] = KtQq[u]; }
+      }
+      lds_sync();
+      inf_pr = dmax(inf_pr, Lc[C::cIPR]); inf_comp = dmax(inf_comp, Lc[C::cICOMP]);
+      // gradient variant of this lane
+      if (hasv) {
+        double drift[NX], Qu[NU], kk[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) drift[i] = pv[i] + 0.0;     // + P * 0 (no affine dynamics term)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) a += Lb[k * NU + i] * drift[k];
+          Qu[i] = Lc[C::cR + i] + a; }
+        if constexpr (NU == 1) kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
+        else {
+          double col[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        }
+#pragma unroll 2
+        for (int i = 0; i < NX; ++i) {
+          double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) a += La[k * NX + i] * drift[k];
+          const double Qx = Lc[C::cQ + i] + a;
+          double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a1 += Ls[C::oQux + j * NX + i] * kk[j]; a2 += Ls[C::oKK + j * NX + i] * Qu[j]; a3 += Ls[C::oKtQ + i * NU + j] * kk[j]; }
+          Ls[C::oPv + i * G + q] = ((Qx + a1) + a2) + a3;
+        }
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { pv[i] = Ls[C::oPv + i * G + q]; bad = bad || !dfinite(pv[i]); }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) bad = bad || !dfinite(kk[i]);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) tek[(((size_t)t * Bp + b) * NU + i) * VP + v] = kk[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tep[(((size_t)t * Bp + b) * NX + i) * VP + v] = pv[i];
+      }
+      // round 3: P_t column (in place over the lane's own Q + A^T P A column)
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a1 += Ls[C::oQux + j * NX + i] * KKc[j]; a2 += Ls[C::oKK + j * NX + i] * Quxq[j]; a3 += Ls[C::oKtQ + i * NU + j] * KKc[j]; }
+        Ls[C::oM + i * NX + qc] = ((Ls[C::oM + i * NX + qc] + a1) + a2) + a3;
+      }
+      storeAB((t & 1) ^ 1, nab);
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { Vc[i] = 0.5 * (Ls[C::oM + i * NX + qc] + Ls[C::oM + qc * NX + i]); bad = bad || !dfinite(Vc[i]); }
+      lds_sync();
+      if (__ballot(bad) & gmask) return false;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+      return true;
+    };
+    {
+      InAB nab;
+      loadAB(N - 1, nab);
+      storeAB((N - 1) & 1, nab);
+      lds_sync();
+      for (int t = N - 1; t >= 0; --t)
+        if (!step(t, nab)) { fail = true; break; }
+    }
+    if (!fail) {
+      // ---- P2: closed-loop linear rollout of every variant (lane v), dx0 = 0 (rolloutLinearPolicy :368-392)
+      struct RIn { double a[C::NA], bm[C::NB], ks[C::NK], kf[NU]; };
+      auto load_r = [&](int tt, RIn &r) {
+#pragma unroll
+        for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+#pragma unroll
+        for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < NU * NX ? e : NU * NX - 1)]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r.kf[i] = tek[(((size_t)tt * Bp + b) * NU + i) * VP + (hasv ? v : 0)];
+      };
+      auto store_r = [&](int buf, const RIn &r) {
+        double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU, *Lk = Ls + C::oT2 + buf * NU * NX;
+#pragma unroll
+        for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
+#pragma unroll
+        for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; if (e < NX * NU) Lb[e] = r.bm[j]; }
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; if (e < NU * NX) Lk[e] = r.ks[j]; }
+      };
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      RIn rc, rn;
+      load_r(0, rc);
+      store_r(0, rc);
+      lds_sync();
+      for (int t = 0; t < N; ++t) {
+        const int tn = t + 1 < N ? t + 1 : t;
+        load_r(tn, rn);
+        PIPELINE_FENCE();
+        const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU, *Lk = Ls + C::oT2 + (t & 1) * NU * NX;
+        double du[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += Lk[i * NX + j] * dx[j];
+          du[i] = rc.kf[i] + a; }
+#pragma unroll 2
+        for (int i = 0; i < NX; ++i) {
+          double a = 0.0, c = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += La[i * NX + j] * dx[j];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) c += Lb[i * NU + j] * du[j];
+          Ls[C::oPv + i * G + q] = (a + c) + 0.0;
+        }
+        store_r((t & 1) ^ 1, rn);
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oPv + i * G + q];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rc.kf[i] = rn.kf[i];
+      }
+      if (hasv) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Ls[C::oXT + v * NX + i] = dx[i];
+      }
+      lds_sync();
+      // ---- P3: reduced terminal system (:550-617), one lane; operands in LDS (overlaying the sweep area)
+      if (q == 0) {
+        const int p = pT, ld_ = pT;
+        double *As = Ls, *AtA = As + p * p, *Sh = AtA + p * p, *Uw = Sh + p * p, *rhs = Uw + p * p, *Atb = rhs + p,
+               *lam = Atb + p, *best = lam + p, *temp = best + p, *trd = temp + p;
+        const double *xT = Ls + C::oXT;
+        for (int r = 0; r < p; ++r) {
+          const int cr = ldsCol[r];
+          for (int i = 0; i < p; ++i) {
+            double a = 0.0;
+            for (int k = 0; k < NX; ++k) a += ((k == cr) ? 1.0 : 0.0) * (xT[(i + 1) * NX + k] - xT[k]);
+            As[r * ld_ + i] = a;
+          }
+          double hx = 0.0;
+          for (int k = 0; k < NX; ++k) hx += ((k == cr) ? 1.0 : 0.0) * xT[k];
+          rhs[r] = (-Ls[C::oH + r]) - hx;
+        }
+        double tr = 0.0;
+        for (int i = 0; i < p; ++i) {
+          for (int c = 0; c < p; ++c) { double a = 0.0; for (int k = 0; k < p; ++k) a += As[k * ld_ + i] * As[k * ld_ + c]; AtA[i * ld_ + c] = a; }
+          double a = 0.0; for (int k = 0; k < p; ++k) a += As[k * ld_ + i] * rhs[k]; Atb[i] = a;
+        }
+        for (int i = 0; i < p; ++i) tr += AtA[i * ld_ + i];
+        const double trace_term = (tr > 1.0 ? tr / (p > 1 ? p : 1) : 1.0);
+        const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+        const double regv = dmax(base_floor, 1e-6 * trace_term);
+        double smax, smin;
+        singular_minmax_mem(Uw, As, p, ld_, smax, smin);
+        const double svd_reg = dmax(1e-8 * smax - smin, 0.0);
+        const double reg_base = dmax(regv, svd_reg);
+        double rn2 = 0.0; for (int r = 0; r < p; ++r) rn2 += rhs[r] * rhs[r];
+        const double cap = 100.0 * (1.0 + sqrt(rn2));
+        for (int i = 0; i < p; ++i) best[i] = 0.0;
+        double best_res = INFINITY; bool found = false;
+        for (int sc = 0; sc < 5; ++sc) {
+          const double scale = (sc == 0) ? 1.0 : (sc == 1) ? 10.0 : (sc == 2) ? 100.0 : (sc == 3) ? 1e3 : 1e4;
+          const double reg_i = dmax(reg_base * scale, 1e-12);
+          for (int i = 0; i < p; ++i) for (int c = 0; c < p; ++c) Sh[i * ld_ + c] = AtA[i * ld_ + c] + reg_i * ((i == c) ? 1.0 : 0.0);
+          if (!ldlt_mem_compute(Sh, trd, temp, p, ld_)) continue;
+          for (int i = 0; i < p; ++i) lam[i] = Atb[i];
+          ldlt_mem_solve(Sh, trd, p, ld_, lam);
+          bool fin = true; double ln = 0.0;
+          for (int i = 0; i < p; ++i) { fin = fin && dfinite(lam[i]); ln += lam[i] * lam[i]; }
+          if (!fin) continue;
+          ln = sqrt(ln);
+          if (ln > cap) { const double f2 = cap / dmax(ln, 1e-12); for (int i = 0; i < p; ++i) lam[i] = lam[i] * f2; }
+          double res = 0.0;
+          for (int r = 0; r < p; ++r) { double a = 0.0; for (int i = 0; i < p; ++i) a += As[r * ld_ + i] * lam[i]; const double e = a - rhs[r]; res += e * e; }
+          res = sqrt(res);
+          if (!dfinite(res)) continue;
+          if (!found || res < best_res) { for (int i = 0; i < p; ++i) best[i] = lam[i]; best_res = res; found = true; }
+        }
+        if (!found) for (int i = 0; i < p; ++i) best[i] = 0.0;
+        for (int i = 0; i < p; ++i) { d.dLamT[(size_t)i * Bp + b] = best[i]; Ls[C::oBest + i] = best[i]; }
+      }
+      lds_sync();
+      // ---- P4: recombination (:619-634); elements (t, i) spread over the lanes of the group
+      double sn = 0.0;
+      for (int idx = q; idx < N * NU; idx += G) {
+        const int t = idx / NU, i = idx - t * NU;
+        const double *row = tek + (((size_t)t * Bp + b) * NU + i) * VP;
+        const double k0 = row[0];
+        double ko = k0;
+        for (int w = 0; w < pT; ++w) ko += Ls[C::oBest + w] * (row[w + 1] - k0);
+        d.k[GI(t, NU, i)] = ko;
+        sn = dmax(sn, fabs(ko));
+      }
+      for (int idx = q; idx < (N + 1) * NX; idx += G) {
+        const int t = idx / NX, i = idx - t * NX;
+        const double *row = tep + (((size_t)t * Bp + b) * NX + i) * VP;
+        const double p0 = row[0];
+        double po = p0;
+        for (int w = 0; w < pT; ++w) po += Ls[C::oBest + w] * (row[w + 1] - p0);
+        d.Vx[GI(t, NX, i)] = po;
+      }
+      Ls[C::oRed + q] = sn;
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < G; ++j) step_norm = dmax(step_norm, Ls[C::oRed + j]);
+      // ---- P5: linear-policy rollout dX with the final gains (ipddp_solver.cpp:1511-1520); lane qc = row qc
+      {
+        double dxr[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dxr[i] = 0.0;
+        struct GIn { double ks[C::NK], kq, Aq[NX], Bq[NU]; };
+        constexpr int GS = NU + NU * NX;
+        static_assert(2 * GS <= 2 * NX * NX + 2 * NX * NU, "gain buffers fit the A/B area");
+        auto load_g = [&](int tt, GIn &r) {
+#pragma unroll
+          for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < NU * NX ? e : NU * NX - 1)]; }
+          r.kq = d.k[GI(tt, NU, q < NU ? q : NU - 1)];
+#pragma unroll
+          for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+        };
+        auto store_g = [&](int buf, const GIn &r) {
+          double *Lg = Ls + C::oA + buf * GS;
+          if (q < NU) Lg[q] = r.kq;
+#pragma unroll
+          for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; if (e < NU * NX) Lg[NU + e] = r.ks[j]; }
+        };
+        GIn gc, gn;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
+        load_g(0, gc);
+        store_g(0, gc);
+        lds_sync();
+        for (int t = 0; t < N; ++t) {
+          const int tn = t + 1 < N - 1 ? t + 1 : t;
+          load_g(tn, gn);
+          PIPELINE_FENCE();
+          d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+          if (t < N - 1) {
+            const double *Lg = Ls + C::oA + (t & 1) * GS;
+            double du[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+              for (int j = 0; j < NX; ++j) a += Lg[NU + i * NX + j] * dxr[j];
+              du[i] = Lg[i] + a; }
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += gc.Aq[j] * dxr[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) c += gc.Bq[j] * du[j];
+            const double dxq = (a + c) + 0.0;
+            lds_sync();
+            Ls[C::oDx + qc] = dxq;
+            store_g((t & 1) ^ 1, gn);
+            lds_sync();
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dxr[i] = Ls[C::oDx + i];
+          }
+          gc = gn;
+        }
+      }
+      ok = true;
+      break;
+    }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  if (q != 0) return;
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
+  d.te_cnt[b] = ok ? 0 : -1;       // k_te_post: steps of this trajectory finished so far / "no post-processing"
+  if (ok) {
+    d.dV0[b] = 0.0; d.dV1[b] = 0.0; d.inf_du[b] = 0.0; d.step_norm[b] = step_norm;
+    d.inf_pr[b] = inf_pr; d.inf_comp[b] = inf_comp;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; }
+}
+
+// ================================================================================ post-processing, (batch x N)
+// max_t |r_t + B_t^T V_x(t+1)| (:1260-1266), slack / dual gains with the final k, K (:1270-1312), the directions
+// dS = k_s + K_s dX, dY = clamp(k_y + K_y dX) and computeMaxStepSizes (:1522-1532, 2939-2988).  The lane that
+// completes a trajectory's N-th step applies checkEarlyConvergence (:925-958).
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__restrict__ Pk, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  typedef TeCfg<Model, Cons> C;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  if (d.te_cnt[b] < 0) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double mu = d.mu[b];
+  {
+    double r[NU], Bm[NX * NU], pn[NX];
+    ld<NU>(d.te_cst + GI(t, C::REC, C::cR), kLS, r);
+    ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
+    ld<NX>(d.Vx + GI(t + 1, NX, 0), kLS, pn);
+    double idu = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * pn[k];
+      idu = dmax(idu, fabs(r[i] + a)); }
+    atomic_max_pos(d.inf_du + b, idu);
+  }
+  if constexpr (M > 0) {
+    const double *Xc = d.X + (size_t)cur * d.planeX;
+    const double *Sc = d.S + (size_t)cur * d.planeM;
+    const double *Yc = d.Y + (size_t)cur * d.planeM;
+    const double *Gc = d.G + (size_t)cur * d.planeM;
+    const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+    const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+    double x[NX], y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], kk[NU], KK[NU * NX], dx[NX];
+    ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+    ld<M>(Yc + GI(t, M, 0), kLS, y); ld<M>(Sc + GI(t, M, 0), kLS, s); ld<M>(Gc + GI(t, M, 0), kLS, g);
+    ld<NU>(d.k + GI(t, NU, 0), kLS, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+    ld<NX>(d.dX + GI(t, NX, 0), kLS, dx);
+#pragma unroll
+    for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+    Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+    double apr = 1.0, adu = 1.0;
+#pragma unroll
+    for (int rr = 0; rr < M; ++rr) {
+      const double ss = dmax(s[rr], s_floor);
+      const double YSr = clip_pos(y[rr], ss);
+      const double rp = g[rr] + s[rr], rc = y[rr] * s[rr] - mu;
+      const double rhat = y[rr] * rp - rc;
+      double temp = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) temp += Qyu[rr * NU + i] * kk[i];
+      const double kyr = clip_sgn(rhat + y[rr] * temp, ss);
+      const double ksr = (-rp) - temp;
+      double a = 0.0, c = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NX; ++cc) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) s2 += Qyu[rr * NU + i] * KK[i * NX + cc];
+        const double Kyv = dmin(dmax(YSr * (Qyx[rr * NX + cc] + s2), -kMaxBarrierRatio), kMaxBarrierRatio);
+        const double Ksv = (-Qyx[rr * NX + cc]) - s2;
+        d.Ky[GI(t, M * NX, rr * NX + cc)] = Kyv;
+        d.Ks[GI(t, M * NX, rr * NX + cc)] = Ksv;
+        a += Ksv * dx[cc]; c += Kyv * dx[cc];
+      }
+      d.ky[GI(t, M, rr)] = kyr;
+      d.ks[GI(t, M, rr)] = ksr;
+      const double ds = ksr + a;
+      const double dy = dmin(dmax(kyr + c, -kMaxBarrierRatio), kMaxBarrierRatio);
+      if (ds < 0.0) apr = dmin(apr, -tau * s[rr] / ds);
+      if (dy < 0.0) adu = dmin(adu, -tau * y[rr] / dy);
+    }
+    if (apr < 1.0) atomic_min_pos(d.apr_max + b, apr);
+    if (adu < 1.0) atomic_min_pos(d.adu_max + b, adu);
+  }
+  __threadfence();
+  const int done = atomicAdd(d.te_cnt + b, 1);
+  if (done != N - 1) return;
+  // ---- last step of this trajectory: every contribution is in; early-convergence test
+  __threadfence();
+  const double inf_du = __longlong_as_double((long long)atomicMax((unsigned long long *)(d.inf_du + b), 0ull));
+  d.inf_du[b] = inf_du;
+  if (force) return;
+  const double inf_pr = d.inf_pr[b], inf_comp = d.inf_comp[b], step_norm = d.step_norm[b];
+  bool conv;
+  if (M == 0) conv = (inf_pr < o.tolerance && inf_du < o.tolerance);   // no barrier terms (terminal equality only)
+  else {
+    const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+    const double asn = fabs(d.alpha_pr[b]) * step_norm;
+    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+  }
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
+  d.phase[b] = PH_FWD1;
+}
+
+#undef GI
+}  // namespace cddp_dev

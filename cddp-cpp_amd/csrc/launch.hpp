@@ -3,13 +3,14 @@
 #include <vector>
 #include <cstdlib>
 #include <cstring>
-#include "kernels_coop.hpp"
+#include "kernels_te.hpp"
 
 namespace cddp_dev {
 
 struct KernelSet {
   int model, nx, nu, m;
   int cst_size;   // per-step doubles of the condensed-term stack (lean IPDDP backward), 0 = fused sweep
+  int te_rec_size, te_group;   // cooperative terminal-equality sweep: per-step record doubles (0 = none), lanes per trajectory
   const char *name;
   bool (*matches)(const ProblemDev &);
   void (*derivs)(const DevBuf &, int force, hipStream_t);
@@ -29,6 +30,10 @@ struct Launcher {
   // path-constrained, no terminal set: condense -> lean sweep -> post (kernels_lean.hpp)
   static constexpr bool kLean = !TERM && Cons::M > 0;
   static constexpr int cst_size() { if constexpr (kLean) return CstLayout<Model, Cons>::SIZE; else return 0; }
+  // terminal equality, no state-dependent path rows: cooperative reduced-LQR sweep (kernels_te.hpp) when the host
+  // allocated its record stack (pT > 0, no terminal inequality, pT + 1 <= lanes per trajectory)
+  static constexpr bool kTeCoop = TERM && !Cons::HAS_X;
+  static constexpr int te_rec_size() { if constexpr (kTeCoop) return TeCfg<Model, Cons>::REC; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
     if constexpr (kLean) {
@@ -45,6 +50,8 @@ struct Launcher {
       }
     }
     hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
+    if constexpr (kTeCoop)
+      if (d.te_cst) hipLaunchKernelGGL((k_te_condense<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
   }
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
@@ -69,8 +76,16 @@ struct Launcher {
         hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       else
         hipLaunchKernelGGL((k_backward_coop_plain<Model, false>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-    } else
+    } else {
+      if constexpr (kTeCoop) {
+        if (d.te_cst && !lane_sweep) {
+          hipLaunchKernelGGL((k_backward_te_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          hipLaunchKernelGGL((k_te_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
+          return;
+        }
+      }
       hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+    }
   }
   static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
     if (na <= 0) return;
@@ -102,7 +117,7 @@ struct Launcher {
   }
   static KernelSet set(const char *name) {
     KernelSet k;
-    k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size();
+    k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
     k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage;
     return k;
