@@ -329,6 +329,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
       if (te_coop) {
         DA(d.te_cst, (size_t)N * h->ks->te_rec_size * Bp); DA(d.te_cnt, Bp);
         if (!d.dX) DA(d.dX, (size_t)N * nx * Bp);
+        if (!d.ys) DA(d.ys, (size_t)N * (m > 0 ? m : 1) * Bp);
       }
     }
   }
@@ -586,7 +587,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
   // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
   // (the two-role rollout of the path-constrained layouts runs two wavefronts per tile and alpha)
-  const long waves_all = (long)((d.B + 63) / 64) * na * ((P.solver == CDDP_HIP_SOLVER_IPDDP && ks->cst_size > 0) ? 2 : 1);
+  const long waves_all = (long)((d.B + 63) / 64) * na * ((P.solver == CDDP_HIP_SOLVER_IPDDP && (ks->cst_size > 0 || (d.te_cst && P.m > 0))) ? 2 : 1);
   // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
   // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
   const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");

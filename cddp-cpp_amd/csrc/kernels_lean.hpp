@@ -522,7 +522,10 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 // Every lane runs straight-line code with UNCONDITIONAL stores (a dead lane keeps re-evaluating its frozen state;
 // rows of a failed trial are never read): with stores inside divergent branches the waitcnt pass cannot count the
 // operations behind the prefetch and falls back to vmcnt(0), i.e. it waits for a store acknowledge every step.
-template <class Model, class Cons>
+// TERM = true: terminal-equality layouts solved by the cooperative reduced-LQR sweep (kernels_te.hpp; no terminal
+// inequality): the producer hands x_N over, the consumer appends the multiplier trial and the terminal terms of
+// computeTheta / computeBarrierMerit (ipddp_solver.cpp:1711-1723, 2812-2845, 2866-2878) in the reference's order.
+template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                           int a0, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
@@ -535,6 +538,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   __shared__ int s_cons;          // steps retired by the consumer
   __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
   __shared__ double s_pcost[64];  // the producer lane's terminal cost l_f(x_N)
+  __shared__ double s_xN[TERM ? NX * 64 : 1];   // the producer lane's x_N (terminal residual of the trial)
   const int lane = threadIdx.x & 63;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
   const int b = blockIdx.x * 64 + lane;
@@ -652,6 +656,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
     }
     if (alive) s_pcost[lane] = Obj::terminal_cost(P, x);
+    if constexpr (TERM) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) s_xN[i * 64 + lane] = x[i];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -826,6 +834,32 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       mer -= mu * v0; mer -= mu * v1; mer -= mu * v2; mer -= mu * v3;
     }
     for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
+  }
+  if constexpr (TERM) {   // terminal equality rows, stacked in constraint order (term_reductions, dev_terminal.hpp)
+    double n1 = 0.0, ninf = 0.0, dp = 0.0;
+    for (int c = 0; c < P->n_term; ++c) {
+      const TermDev &td = P->terms[c];
+      if (td.kind != CDDP_HIP_TERM_EQUALITY) continue;
+      for (int r = 0; r < td.dim; ++r) {
+        const double h = s_xN[r * 64 + lane] - P->pool[td.off_target + r];
+        n1 += l2norm ? h * h : fabs(h);
+        ninf = dmax(ninf, fabs(h));
+      }
+    }
+    total += n1; ev_max = dmax(ev_max, ninf);
+    for (int c = 0; c < P->n_term; ++c) {
+      const TermDev &td = P->terms[c];
+      if (td.kind != CDDP_HIP_TERM_EQUALITY) continue;
+      for (int r = 0; r < td.dim; ++r) {
+        const int j = td.offset + r;
+        const double h = s_xN[r * 64 + lane] - P->pool[td.off_target + r];
+        const double lam = d.LamT[(size_t)j * d.Bp + b] + a_pr * d.dLamT[(size_t)j * d.Bp + b];
+        if (!dfinite(lam)) return;
+        d.LamTt[((size_t)a * kPTMax + j) * d.Bp + b] = lam;
+        dp += lam * h;
+      }
+    }
+    mer += dp;
   }
   const double th = l2norm ? sqrt(total) : total;
   const double theta_new = dmax(th, ev_max), phi_new = mer, ipr = ev_max, icomp = ev_icomp;

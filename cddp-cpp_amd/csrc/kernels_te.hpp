@@ -15,7 +15,7 @@
 //        P3  p x p regularised normal equations for the multiplier step (lane 0; operands in LDS)
 //        P4  recombination k = k_0 + sum_v lambda_v (k_v - k_0), same for V_x  (elements spread over the lanes)
 //        P5  linear-policy rollout dX with the final gains (row per lane)
-//   k_te_post          (batch x N)   max |Q_u|, slack / dual gains k_s, k_y, K_s, K_y, step caps; the last step
+//   k_te_post          (batch x N)   max |Q_u|, slack / dual gains k_s, k_y (+ Y S^-1), step caps; the last step
 //                                     of a trajectory to finish applies the early-convergence test
 //
 // Every number is produced by the same expression, in the same order, as te_backward (the parity tests compare
@@ -26,6 +26,9 @@
 
 namespace cddp_dev {
 
+#ifndef TE_EXP
+#define TE_EXP 0
+#endif
 #define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
 
 template <class Model, class Cons>
@@ -35,10 +38,12 @@ struct TeCfg {
   static constexpr int VP = 16;                                     // variant stride of the te_k / te_p stacks
   // per-step record written by k_te_condense
   static constexpr int cQ = 0, cR = NX, cRR = NX + NU, cIPR = cRR + NU * NU, cICOMP = cIPR + 1, REC = cICOMP + 1;
-  static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G, NC = (REC + G - 1) / G, NK = (NU * NX + G - 1) / G;
+  static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G, NC = (REC + G - 1) / G, NK = (NU * NX + G - 1) / G,
+                       NQ = (NU * NU + G - 1) / G;
   // LDS map of one trajectory
   static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
-                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oC = oKtQ + NX * NU, SWEEP_END = oC + 2 * REC;
+                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oC = oKtQ + NX * NU, oQuu = oC + 2 * REC, oF = oQuu + NU * NU,
+                       SWEEP_END = oF + NU * NU + NU;
   static constexpr int P3 = 4 * PMAX * PMAX + 6 * PMAX;            // reduced-system work area (overlays the sweep area)
   static constexpr int oXT = SWEEP_END > P3 ? SWEEP_END : P3;
   static constexpr int oH = oXT + (PMAX + 1) * NX, oLam = oH + PMAX, oBest = oLam + PMAX, oDx = oBest + PMAX,
@@ -209,6 +214,35 @@ DEV void singular_minmax_mem(double *U, const double *A, int n, int ld, double &
   if (n == 0) { smax = 0.0; smin = 0.0; }
 }
 
+// LDLTs<N>::solve with the factor read from memory: F = m[N * N] followed by the transpositions (as doubles)
+template <int N>
+DEV void ldlt_lds_solve(const double *F, double *x) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int tk = (int)F[N * N + k];
+#pragma unroll
+    for (int B = k + 1; B < N; ++B) if (tk == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { double sacc = x[i];
+#pragma unroll
+    for (int kk = 0; kk < i; ++kk) sacc -= F[i * N + kk] * x[kk];
+    x[i] = sacc; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const double dd = F[i * N + i]; x[i] = (fabs(dd) > DBL_MIN) ? x[i] / dd : 0.0; }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) { double sacc = x[i];
+#pragma unroll
+    for (int kk = i + 1; kk < N; ++kk) sacc -= F[kk * N + i] * x[kk];
+    x[i] = sacc; }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    const int tk = (int)F[N * N + k];
+#pragma unroll
+    for (int B = k + 1; B < N; ++B) if (tk == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+  }
+}
+
 // ================================================================================ cooperative sweep
 template <class Model, class Cons>
 __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
@@ -337,45 +371,44 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int k = 0; k < NX; ++k) s += Lb[k * NU + u] * Vc[k];
         Ls[C::oT2 + u * NX + qc] = s; }
       lds_sync();
-      // round 2: Q + A^T P A (in place over T1, row by row), Q_ux column, Q_uu (replicated), factor, K column
+      // round 2a: Q + A^T P A (in place over T1, row by row), Q_ux column; the entries of Q_uu spread over the lanes
 #pragma unroll 2
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
         Ls[C::oM + i * NX + qc] = ldsQ[i * NX + qc] + s; }
-      double Quxq[NU], Quu[NU * NU];
+      double Quxq[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Aq[j];
-        Quxq[u] = s + 0.0; }          // + M^T, M = 0 without G_x
-      {
-        double Rm[NU * NU];
+        Quxq[u] = s + 0.0;            // + M^T, M = 0 without G_x
+        Ls[C::oQux + u * NX + qc] = Quxq[u]; }
 #pragma unroll
-        for (int i = 0; i < NU * NU; ++i) Rm[i] = Lc[C::cRR + i];
+      for (int j = 0; j < C::NQ; ++j) {
+        const int e = q + G * j;
+        const int ee = e < NU * NU ? e : NU * NU - 1;
+        const int u = ee / NU, w = ee - u * NU;
+        double s = 0.0;               // (B^T P) B; (B^T P^T) B is the same number: P is exactly symmetric
 #pragma unroll
-        for (int i = 0; i < NU; ++i) Rm[i * NU + i] += reg;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int w = 0; w < NU; ++w) { double s = 0.0;    // (B^T P) B; (B^T P^T) B is the same number: P is exactly symmetric
-#pragma unroll
-            for (int k = 0; k < NX; ++k) s += Ls[C::oT2 + u * NX + k] * Lb[k * NU + w];
-            Quu[u * NU + w] = s; }
-        double Qs[NU * NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i)
-#pragma unroll
-          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (((Rm[i * NU + c] + Quu[i * NU + c]) + Rm[c * NU + i]) + Quu[i * NU + c]);
-#pragma unroll
-        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
+        for (int k = 0; k < NX; ++k) s += Ls[C::oT2 + u * NX + k] * Lb[k * NU + w];
+        double ruw = Lc[C::cRR + u * NU + w], rwu = Lc[C::cRR + w * NU + u];
+        if (u == w) { ruw += reg; rwu += reg; }
+        if (e < NU * NU) Ls[C::oQuu + e] = 0.5 * (((ruw + s) + rwu) + s);
       }
+      lds_sync();
+      // round 2b: factor (replicated; lane 0 parks it in LDS for the variant solves), K column, row of K^T Q_uu
       double KKc[NU];
-      LDLTs<NU> f;
       if constexpr (NU == 1) {
-        KKc[0] = -ldlt1_solve(Quu[0], Quxq[0]);
+        KKc[0] = -ldlt1_solve(Ls[C::oQuu], Quxq[0]);
       } else {
-        f.compute(Quu, NU);
+        LDLTs<NU> f;
+        {
+          double Quu[NU * NU];
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) Quu[i] = Ls[C::oQuu + i];
+          f.compute(Quu, NU);
+        }
         if (!f.ok) bad = true;
         double col[NU];
 #pragma unroll
@@ -383,23 +416,26 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         f.solve(col);
 #pragma unroll
         for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+        if (q == 0) {
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) Ls[C::oF + i] = f.m[i];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) Ls[C::oF + NU * NU + i] = (double)f.tr[i];
+        }
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) bad = bad || !dfinite(KKc[i]);
-      {
-        double KtQq[NU];   // row qc of K^T Q_uu
 #pragma unroll
-        for (int j = 0; j < NU; ++j) { double s = 0.0;
+      for (int j = 0; j < NU; ++j) { double s = 0.0;     // row qc of K^T Q_uu
 #pragma unroll
-          for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
-          KtQq[j] = s; }
+        for (int u = 0; u < NU; ++u) s += KKc[u] * Ls[C::oQuu + u * NU + j];
+        Ls[C::oKtQ + qc * NU + j] = s; }
 #pragma unroll
-        for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; Ls[C::oKtQ + qc * NU + u] = KtQq[u]; }
-      }
+      for (int u = 0; u < NU; ++u) Ls[C::oKK + u * NX + qc] = KKc[u];
       lds_sync();
       inf_pr = dmax(inf_pr, Lc[C::cIPR]); inf_comp = dmax(inf_comp, Lc[C::cICOMP]);
       // gradient variant of this lane
-      if (hasv) {
+      if (hasv && !(TE_EXP & 1)) {
         double drift[NX], Qu[NU], kk[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) drift[i] = pv[i] + 0.0;     // + P * 0 (no affine dynamics term)
@@ -408,12 +444,12 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int k = 0; k < NX; ++k) a += Lb[k * NU + i] * drift[k];
           Qu[i] = Lc[C::cR + i] + a; }
-        if constexpr (NU == 1) kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
+        if constexpr (NU == 1) kk[0] = -ldlt1_solve(Ls[C::oQuu], Qu[0]);
         else {
           double col[NU];
 #pragma unroll
           for (int i = 0; i < NU; ++i) col[i] = Qu[i];
-          f.solve(col);
+          ldlt_lds_solve<NU>(Ls + C::oF, col);
 #pragma unroll
           for (int i = 0; i < NU; ++i) kk[i] = -col[i];
         }
@@ -495,7 +531,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       load_r(0, rc);
       store_r(0, rc);
       lds_sync();
-      for (int t = 0; t < N; ++t) {
+      for (int t = 0; t < ((TE_EXP & 2) ? 0 : N); ++t) {
         const int tn = t + 1 < N ? t + 1 : t;
         load_r(tn, rn);
         PIPELINE_FENCE();
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       }
       lds_sync();
       // ---- P3: reduced terminal system (:550-617), one lane; operands in LDS (overlaying the sweep area)
-      if (q == 0) {
+      if (q == 0 && !(TE_EXP & 4)) {
         const int p = pT, ld_ = pT;
         double *As = Ls, *AtA = As + p * p, *Sh = AtA + p * p, *Uw = Sh + p * p, *rhs = Uw + p * p, *Atb = rhs + p,
                *lam = Atb + p, *best = lam + p, *temp = best + p, *trd = temp + p;
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       lds_sync();
       // ---- P4: recombination (:619-634); elements (t, i) spread over the lanes of the group
       double sn = 0.0;
-      for (int idx = q; idx < N * NU; idx += G) {
+      for (int idx = q; idx < ((TE_EXP & 16) ? 0 : N * NU); idx += G) {
         const int t = idx / NU, i = idx - t * NU;
         const double *row = tek + (((size_t)t * Bp + b) * NU + i) * VP;
         const double k0 = row[0];
@@ -594,7 +630,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         d.k[GI(t, NU, i)] = ko;
         sn = dmax(sn, fabs(ko));
       }
-      for (int idx = q; idx < (N + 1) * NX; idx += G) {
+      for (int idx = q; idx < ((TE_EXP & 16) ? 0 : (N + 1) * NX); idx += G) {
         const int t = idx / NX, i = idx - t * NX;
         const double *row = tep + (((size_t)t * Bp + b) * NX + i) * VP;
         const double p0 = row[0];
@@ -635,7 +671,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         load_g(0, gc);
         store_g(0, gc);
         lds_sync();
-        for (int t = 0; t < N; ++t) {
+        for (int t = 0; t < ((TE_EXP & 8) ? 0 : N); ++t) {
           const int tn = t + 1 < N - 1 ? t + 1 : t;
           load_g(tn, gn);
           PIPELINE_FENCE();
@@ -753,12 +789,11 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
         for (int i = 0; i < NU; ++i) s2 += Qyu[rr * NU + i] * KK[i * NX + cc];
         const double Kyv = dmin(dmax(YSr * (Qyx[rr * NX + cc] + s2), -kMaxBarrierRatio), kMaxBarrierRatio);
         const double Ksv = (-Qyx[rr * NX + cc]) - s2;
-        d.Ky[GI(t, M * NX, rr * NX + cc)] = Kyv;
-        d.Ks[GI(t, M * NX, rr * NX + cc)] = Ksv;
         a += Ksv * dx[cc]; c += Kyv * dx[cc];
       }
       d.ky[GI(t, M, rr)] = kyr;
       d.ks[GI(t, M, rr)] = ksr;
+      d.ys[GI(t, M, rr)] = YSr;     // the rollout consumer rebuilds the rows of K_s, K_y from K and Y S^-1 (see k_post)
       const double ds = ksr + a;
       const double dy = dmin(dmax(kyr + c, -kMaxBarrierRatio), kMaxBarrierRatio);
       if (ds < 0.0) apr = dmin(apr, -tau * s[rr] / ds);

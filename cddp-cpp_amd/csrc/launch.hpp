@@ -35,6 +35,10 @@ struct Launcher {
   static constexpr bool kTeCoop = TERM && !Cons::HAS_X;
   static constexpr int te_rec_size() { if constexpr (kTeCoop) return TeCfg<Model, Cons>::REC; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
+  static bool lane_sweep_requested() {
+    static const bool v = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
+    return v;
+  }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
     if constexpr (kLean) {
       if (d.cst) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
@@ -56,7 +60,7 @@ struct Launcher {
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
     // one-lane-per-trajectory kernels instead (comparison / experiments)
-    static const bool lane_sweep = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
+    const bool lane_sweep = lane_sweep_requested();
     const dim3 gridC((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW);
     if (solver == CDDP_HIP_SOLVER_CLDDP) {
       if (lane_sweep)
@@ -96,8 +100,15 @@ struct Launcher {
     {
       if constexpr (kLean)   // producer / consumer wave pair per (tile, alpha)
         hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
-      else
+      else {
+        if constexpr (kTeCoop && Cons::M > 0) {   // same rollout after the cooperative terminal-equality sweep
+          if (d.te_cst && !lane_sweep_requested()) {
+            hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons, true>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
+            return;
+          }
+        }
         hipLaunchKernelGGL((k_forward_ipddp<Model, Cons, TERM>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      }
     }
     (void)first_only;
   }
