@@ -36,6 +36,7 @@ struct TeCfg {
   static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = 64 / G;
   static constexpr int PMAX = (G - 1 < kPTMax) ? G - 1 : kPTMax;   // one lane per gradient variant: pT + 1 <= G
   static constexpr int VP = 16;                                     // variant stride of the te_k / te_p stacks
+  static_assert(PMAX + 1 <= VP, "a row holds every variant");
   // per-step record written by k_te_condense
   static constexpr int cQ = 0, cR = NX, cRR = NX + NU, cIPR = cRR + NU * NU, cICOMP = cIPR + 1, REC = cICOMP + 1;
   static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G, NC = (REC + G - 1) / G, NK = (NU * NX + G - 1) / G,
@@ -589,9 +590,17 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         const double trace_term = (tr > 1.0 ? tr / (p > 1 ? p : 1) : 1.0);
         const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
         const double regv = dmax(base_floor, 1e-6 * trace_term);
-        double smax, smin;
-        singular_minmax_mem(Uw, As, p, ld_, smax, smin);
-        const double svd_reg = dmax(1e-8 * smax - smin, 0.0);
+        // te_backward adds svd_reg = max(1e-8 smax - smin, 0) of the singular values of A_s (80 Jacobi sweeps) and takes
+        // reg_base = max(regv, svd_reg).  Whenever tr = ||A_s||_F^2 is finite that maximum is regv, whatever the
+        // sweeps return: smax <= ||A_s||_F = sqrt(tr), so svd_reg <= 1e-8 sqrt(tr), while regv >= 1e-6 max(1, tr / p) --
+        // for tr <= 1 that is 1e-8 against 1e-6, for tr > 1 the ratio is <= 1e-2 p / sqrt(tr) <= 0.16 (p <= 16).  The
+        // sweeps therefore only run for a non-finite system, where they reproduce te_backward's NaN / inf handling.
+        double svd_reg = 0.0;
+        if (!dfinite(tr)) {
+          double smax, smin;
+          singular_minmax_mem(Uw, As, p, ld_, smax, smin);
+          svd_reg = dmax(1e-8 * smax - smin, 0.0);
+        }
         const double reg_base = dmax(regv, svd_reg);
         double rn2 = 0.0; for (int r = 0; r < p; ++r) rn2 += rhs[r] * rhs[r];
         const double cap = 100.0 * (1.0 + sqrt(rn2));
@@ -621,22 +630,31 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       lds_sync();
       // ---- P4: recombination (:619-634); elements (t, i) spread over the lanes of the group
       double sn = 0.0;
-      for (int idx = q; idx < ((TE_EXP & 16) ? 0 : N * NU); idx += G) {
-        const int t = idx / NU, i = idx - t * NU;
-        const double *row = tek + (((size_t)t * Bp + b) * NU + i) * VP;
-        const double k0 = row[0];
-        double ko = k0;
-        for (int w = 0; w < pT; ++w) ko += Ls[C::oBest + w] * (row[w + 1] - k0);
-        d.k[GI(t, NU, i)] = ko;
-        sn = dmax(sn, fabs(ko));
-      }
-      for (int idx = q; idx < ((TE_EXP & 16) ? 0 : (N + 1) * NX); idx += G) {
-        const int t = idx / NX, i = idx - t * NX;
-        const double *row = tep + (((size_t)t * Bp + b) * NX + i) * VP;
-        const double p0 = row[0];
-        double po = p0;
-        for (int w = 0; w < pT; ++w) po += Ls[C::oBest + w] * (row[w + 1] - p0);
-        d.Vx[GI(t, NX, i)] = po;
+      {
+        double bw[C::PMAX];                 // multiplier step, 0 beyond pT (those terms are skipped below)
+#pragma unroll
+        for (int w = 0; w < C::PMAX; ++w) bw[w] = (w < pT) ? Ls[C::oBest + w] : 0.0;
+        // one element (t, i) per lane and trip: its VP = 16 variant values are one 128-byte row, fetched whole
+        auto combine = [&](const double *row) {
+          double rv[VP];
+#pragma unroll
+          for (int w = 0; w < VP; ++w) rv[w] = row[w];
+          const double k0 = rv[0];
+          double ko = k0;
+#pragma unroll
+          for (int w = 0; w < C::PMAX; ++w) if (w < pT) ko += bw[w] * (rv[w + 1] - k0);
+          return ko;
+        };
+        for (int idx = q; idx < ((TE_EXP & 16) ? 0 : N * NU); idx += G) {
+          const int t = idx / NU, i = idx - t * NU;
+          const double ko = combine(tek + (((size_t)t * Bp + b) * NU + i) * VP);
+          d.k[GI(t, NU, i)] = ko;
+          sn = dmax(sn, fabs(ko));
+        }
+        for (int idx = q; idx < ((TE_EXP & 16) ? 0 : (N + 1) * NX); idx += G) {
+          const int t = idx / NX, i = idx - t * NX;
+          d.Vx[GI(t, NX, i)] = combine(tep + (((size_t)t * Bp + b) * NX + i) * VP);
+        }
       }
       Ls[C::oRed + q] = sn;
       lds_sync();
