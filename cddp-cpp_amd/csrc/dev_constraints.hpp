@@ -257,6 +257,15 @@ struct ConList {
     ConImpl<0, 0, Cs...>::template jac<NX, NU>(P, x, Gx, Gu);
   }
 };
+// Layouts whose only path constraint is a control box: every row of G_u has ONE entry (-s or +s) and G_x = 0.  The
+// serial rollout uses this to form a row of G_u K as one product instead of a nu-term sum over known zeros.
+template <class Cons> struct UDiag { static constexpr bool value = false; };
+template <int D> struct UDiag<ConList<CtrlBox<D>>> {
+  static constexpr bool value = true;
+  static constexpr int col(int r) { return r < D ? r : r - D; }
+  DEV static double val(const typename ConList<CtrlBox<D>>::Ctx &c, int r) { return r < D ? -c.k.scale : c.k.scale; }
+};
+
 template <>
 struct ConList<> {
   static constexpr int NSEG = 0;

@@ -734,6 +734,28 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     double sn[M], yn[M];
     bool feas = true;
     // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
+    if constexpr (UDiag<Cons>::value) {
+      // control box only: row r of G_u K is g_r K[col(r), :].  The dense sum adds products with exact zeros around
+      // that term (K is finite: the sweep checks it), which leaves it unchanged except that a -0 becomes +0 --
+      // hence the explicit 0.0 + ...; G_x = 0 enters as the same +0 / -0 the dense form adds.
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        const int ic = UDiag<Cons>::col(r);
+        const double gv = UDiag<Cons>::val(cc, r);
+        double Ksr[NX], Kyr[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          const double s2 = 0.0 + gv * cs.KK[ic * NX + c];
+          const double inner = 0.0 + s2;
+          Kyr[c] = dmin(dmax(cs.ys[r] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+          Ksr[c] = (-0.0) - s2;
+        }
+        sn[r] = affine_2r<NX>(cs.s[r], a_pr, cs.ksv[r], Ksr, dx);
+        yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], Kyr, dx);
+        if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
+        if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
+      }
+    } else {
     double Gx[M * NX], Gu[M * NU];
 #pragma unroll
     for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
@@ -756,6 +778,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       yn[r] = affine_2r<NX>(cs.y[r], a_du, cs.ky[r], Kyr, dx);
       if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
       if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
+    }
     }
     if (!feas) alive = false;
     st<M>(Sn + GI(t, M, 0), kLS, sn);
