@@ -26,9 +26,6 @@
 
 namespace cddp_dev {
 
-#ifndef TE_EXP
-#define TE_EXP 0
-#endif
 #define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
 
 template <class Model, class Cons>
@@ -354,8 +351,6 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
     auto step = [&](const int t, InAB &nab) -> bool {
       const int tp = t > 0 ? t - 1 : 0;
       const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU, *Lc = Ls + C::oC + (t & 1) * REC;
-      loadAB(tp, nab);
-      PIPELINE_FENCE();
       bool bad = false;
       double Aq[NX];
 #pragma unroll
@@ -434,9 +429,13 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
       for (int u = 0; u < NU; ++u) Ls[C::oKK + u * NX + qc] = KKc[u];
       lds_sync();
+      // next step's A, B, record: fetched behind the factorisation (its registers are free again), landed in LDS at
+      // the end of the step -- the gradient variant and round 3 cover the latency
+      loadAB(tp, nab);
+      PIPELINE_FENCE();
       inf_pr = dmax(inf_pr, Lc[C::cIPR]); inf_comp = dmax(inf_comp, Lc[C::cICOMP]);
       // gradient variant of this lane
-      if (hasv && !(TE_EXP & 1)) {
+      if (hasv) {
         double drift[NX], Qu[NU], kk[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) drift[i] = pv[i] + 0.0;     // + P * 0 (no affine dynamics term)
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       load_r(0, rc);
       store_r(0, rc);
       lds_sync();
-      for (int t = 0; t < ((TE_EXP & 2) ? 0 : N); ++t) {
+      for (int t = 0; t < N; ++t) {
         const int tn = t + 1 < N ? t + 1 : t;
         load_r(tn, rn);
         PIPELINE_FENCE();
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       }
       lds_sync();
       // ---- P3: reduced terminal system (:550-617), one lane; operands in LDS (overlaying the sweep area)
-      if (q == 0 && !(TE_EXP & 4)) {
+      if (q == 0) {
         const int p = pT, ld_ = pT;
         double *As = Ls, *AtA = As + p * p, *Sh = AtA + p * p, *Uw = Sh + p * p, *rhs = Uw + p * p, *Atb = rhs + p,
                *lam = Atb + p, *best = lam + p, *temp = best + p, *trd = temp + p;
@@ -645,13 +644,13 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           for (int w = 0; w < C::PMAX; ++w) if (w < pT) ko += bw[w] * (rv[w + 1] - k0);
           return ko;
         };
-        for (int idx = q; idx < ((TE_EXP & 16) ? 0 : N * NU); idx += G) {
+        for (int idx = q; idx < N * NU; idx += G) {
           const int t = idx / NU, i = idx - t * NU;
           const double ko = combine(tek + (((size_t)t * Bp + b) * NU + i) * VP);
           d.k[GI(t, NU, i)] = ko;
           sn = dmax(sn, fabs(ko));
         }
-        for (int idx = q; idx < ((TE_EXP & 16) ? 0 : (N + 1) * NX); idx += G) {
+        for (int idx = q; idx < (N + 1) * NX; idx += G) {
           const int t = idx / NX, i = idx - t * NX;
           d.Vx[GI(t, NX, i)] = combine(tep + (((size_t)t * Bp + b) * NX + i) * VP);
         }
@@ -689,7 +688,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         load_g(0, gc);
         store_g(0, gc);
         lds_sync();
-        for (int t = 0; t < ((TE_EXP & 8) ? 0 : N); ++t) {
+        for (int t = 0; t < N; ++t) {
           const int tn = t + 1 < N - 1 ? t + 1 : t;
           load_g(tn, gn);
           PIPELINE_FENCE();

@@ -35,9 +35,9 @@ struct Launcher {
   static constexpr bool kTeCoop = TERM && !Cons::HAS_X;
   static constexpr int te_rec_size() { if constexpr (kTeCoop) return TeCfg<Model, Cons>::REC; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
-  static bool lane_sweep_requested() {
-    static const bool v = [] { const char *e = std::getenv("CDDP_HIP_SWEEP"); return e && !std::strcmp(e, "lane"); }();
-    return v;
+  static bool lane_sweep_requested() {   // read per launch (the tests switch it between solves of one process)
+    const char *e = std::getenv("CDDP_HIP_SWEEP");
+    return e && !std::strcmp(e, "lane");
   }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
     if constexpr (kLean) {

@@ -288,6 +288,32 @@ def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
     assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
 
 
+@pytest.mark.parametrize("case", ["term_eq_only", "path_term_eq", "pendulum_term_eq", "manipulator_term_eq",
+                                  "manip7_term_eq_parallel_ls", "cartpole_ipddp_box", "quadrotor_ipddp_box"])
+def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
+    """The lane-cooperative sweeps (kernels_coop.hpp, kernels_te.hpp: column per lane, gradient variant per lane,
+    two-role rollout) restate the one-lane-per-trajectory kernels sum for sum; CDDP_HIP_SWEEP=lane selects the
+    latter.  Iterates, gains and counters of both must be the SAME bits (terminal-equality cases: the whole
+    reduced-LQR branch incl. the multiplier step)."""
+    p = TERM_CASES[case](api) if case in TERM_CASES else make(api, case)
+    B = 70
+    x0 = api.batch_x0(p, B, 20261005, spread_for(p) if p.nx > 1 else 0.05 * np.ones(1))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); hs.close()
+        return r, X, U, K, k
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    r1, X1, U1, K1, k1 = run()
+    monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
+    r2, X2, U2, K2, k2 = run()
+    assert np.array_equal(r1["iterations"], r2["iterations"]) and np.array_equal(r1["status"], r2["status"])
+    assert np.array_equal(r1["final_objective"], r2["final_objective"])
+    assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 5])
 @pytest.mark.parametrize("kind", ["scalar_path", "cartpole_box", "pendulum_clddp"])
 def test_tiny_horizons(api, kind, N):
