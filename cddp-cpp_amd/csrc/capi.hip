@@ -591,8 +591,8 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
   // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
   const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
-  const bool force_two = ls_env && ls_env[0] == '2';
-  const bool one_stage = !first_rule || na == 1 || (waves_all <= 2048 && !force_two);
+  const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
+  const bool one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
     ++outer;
