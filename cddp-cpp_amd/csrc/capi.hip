@@ -68,6 +68,8 @@ struct cddp_hip_handle {
   bool has_state = false;        // gains / duals of an earlier initialize() or solve() live on the device (warm start)
   bool initial_dirty = false;    // set_initial() since the last initialize(): the caller supplied a new trajectory
   size_t bytes = 0;
+  int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
+  std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
 };
 
 namespace {
@@ -357,8 +359,17 @@ int cddp_hip_destroy(cddp_hip_handle *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   free_all(h);
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
+  return 0;
+}
+
+int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail) {
+  if (!h) return fail(-1, "null handle");
+  if (detail != CDDP_HIP_TIMING_ROLLOUT && detail != CDDP_HIP_TIMING_ALL && detail != CDDP_HIP_TIMING_SWEEP)
+    return fail(-2, "unknown timing detail %d", detail);
+  h->timing_detail = detail;
   return 0;
 }
 
@@ -570,16 +581,31 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   const int max_it = P.opt.max_iterations;
   const bool first_rule = (P.ls_rule == CDDP_HIP_LS_FIRST_SUCCESS);
   const int na = d.n_alphas;
-  // events: [0]=start, [1]=end, then 4 per outer iteration
-  std::vector<hipEvent_t> ev;
-  const bool timing = (stats != nullptr);
-  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); ev.push_back(e); } };
+  // Class timing: up to six mark points per outer iteration (0 start, 1 after the sweep, 2 after rollout stage 1,
+  // 3 after update 1, 4 after rollout stage 2, 5 after update 2).  Every event costs ~5 us of queue time, so only
+  // the points the selected detail needs are recorded (cddp_hip_set_timing_detail): 2 per iteration by default.
+  const int detail = stats ? h->timing_detail : -1;
+  std::vector<int> ev_slot;        // ev_slot[6 * (iteration - 1) + point] = index into the pool, or -1
+  size_t ev_used = 0;
   hipEvent_t ev0, ev1;
   HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
   HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
   HIPCHK(hipEventRecord(ev0, s));
   { int rc = run_initialize(h); if (rc) return rc; }
   int launches = 1, outer = 0;
+  bool two_stage_marks = false;
+  auto mark = [&](int point) {
+    if (detail < 0) return;
+    const bool want = detail == CDDP_HIP_TIMING_ALL ||
+                      (detail == CDDP_HIP_TIMING_ROLLOUT && (point == 1 || point == 2 || (two_stage_marks && (point == 3 || point == 4)))) ||
+                      (detail == CDDP_HIP_TIMING_SWEEP && (point == 0 || point == 1));
+    if (!want) return;
+    if (ev_used == h->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev_pool.push_back(e); }
+    const size_t slot = (size_t)6 * (size_t)(outer - 1) + (size_t)point;
+    if (ev_slot.size() <= slot) ev_slot.resize(slot + 1, -1);
+    hipEventRecord(h->ev_pool[ev_used], s);
+    ev_slot[slot] = (int)ev_used++;
+  };
   int *h_active = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_active, sizeof(int)));
   *h_active = d.B;
@@ -593,35 +619,34 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
   const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
   const bool one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
+  two_stage_marks = !one_stage;
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
     ++outer;
     const int last = (it == max_it) ? 1 : 0;
-    mark();
+    mark(0);
     ks->derivs(d, 0, s);
     ks->backward(d, P.solver, 0, 1, s);
-    mark();
+    mark(1);
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
     if (one_stage) {
       ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
-      mark();
+      mark(2);
       ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
       ks->update(d, 1, na, last, 1, s);
-      mark();
-      mark();
-      mark();
+      mark(3);
       launches += 4;
     } else {
       ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
-      mark();
+      mark(2);
       ks->costate(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
       ks->update(d, 1, 1, last, 0, s);
-      mark();
+      mark(3);
       ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
-      mark();
+      mark(4);
       ks->costate(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
       ks->update(d, 2, na, last, 1, s);
-      mark();
+      mark(5);
       launches += 6;
     }
     // The "anything still running?" poll drains the queue (host round trip + an empty pipeline for the next
@@ -643,16 +668,19 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     float ms = 0;
     hipEventElapsedTime(&ms, ev0, ev1);
     stats->solve_ms = ms;
-    for (size_t i = 0; i + 5 < ev.size(); i += 6) {
-      float a = 0, b = 0, c = 0, e2 = 0, f = 0;
-      hipEventElapsedTime(&a, ev[i], ev[i + 1]);       // derivs + backward
-      hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]);   // forward stage 1
-      hipEventElapsedTime(&c, ev[i + 2], ev[i + 3]);   // update 1
-      hipEventElapsedTime(&e2, ev[i + 3], ev[i + 4]);  // forward stage 2
-      hipEventElapsedTime(&f, ev[i + 4], ev[i + 5]);   // update 2
-      stats->backward_ms += a; stats->forward_ms += b + e2; stats->update_ms += c + f;
+    auto span = [&](size_t it0, int pa, int pb) -> double {   // elapsed between two mark points of one iteration
+      const size_t ia = it0 * 6 + (size_t)pa, ib = it0 * 6 + (size_t)pb;
+      if (ib >= ev_slot.size() || ev_slot[ia] < 0 || ev_slot[ib] < 0) return 0.0;
+      float v = 0;
+      hipEventElapsedTime(&v, h->ev_pool[ev_slot[ia]], h->ev_pool[ev_slot[ib]]);
+      return v;
+    };
+    for (size_t it0 = 0; it0 * 6 < ev_slot.size(); ++it0) {
+      stats->backward_ms += span(it0, 0, 1);                     // derivs + sweep
+      stats->forward_ms += span(it0, 1, 2) + span(it0, 3, 4);    // rollout stage 1 (+ stage 2)
+      stats->update_ms += span(it0, 2, 3) + span(it0, 4, 5);     // costate + update
     }
-    for (hipEvent_t e : ev) hipEventDestroy(e);
+    stats->timing_detail = detail;
     std::vector<int> nb(d.B), nf(d.B), itv(d.B), stv(d.B);
     HIPCHK(hipMemcpy(nb.data(), d.n_bwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nf.data(), d.n_fwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));

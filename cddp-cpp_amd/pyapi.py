@@ -151,13 +151,16 @@ TRIAL_DTYPE = np.dtype([
 GATHER_DTYPE = np.dtype([("final_objective", "f8"), ("iterations", "i4"), ("status", "i4")])
 
 
+TIMING_ROLLOUT, TIMING_ALL, TIMING_SWEEP = 0, 1, 2
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("solve_ms", C.c_double), ("backward_ms", C.c_double), ("forward_ms", C.c_double),
         ("update_ms", C.c_double), ("sweeps", C.c_int64), ("rollouts", C.c_int64),
         ("rollouts_launched", C.c_int64), ("traj_iterations", C.c_int64),
         ("outer_iterations", C.c_int32), ("n_converged", C.c_int32), ("kernel_launches", C.c_int32),
-        ("_pad", C.c_int32),
+        ("timing_detail", C.c_int32),
     ]
 
 
@@ -603,6 +606,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
+    "cddp_hip_set_timing_detail",
     "cddp_hip_backward_stacks", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
@@ -638,6 +642,11 @@ class HipBatchSolver:
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.cddp_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_timing_detail(self, detail):
+        """TIMING_ROLLOUT (default): solve() brackets the rollout launches only; TIMING_ALL: every class;
+        TIMING_SWEEP: derivative fill + sweep only (each event costs ~5 us of queue time)."""
+        self._check(self.lib.cddp_hip_set_timing_detail(self.h, int(detail)))
 
     def set_initial(self, x0, U0=None, X0=None):
         x0 = _arr(x0); assert x0.shape == (self.B, self.p.nx)

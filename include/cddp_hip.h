@@ -249,9 +249,9 @@ typedef struct cddp_hip_trial {
 /* Timing / work summary of one cddp_hip_solve call. */
 typedef struct cddp_hip_stats {
   double solve_ms;          /* hipEvent time of the device-resident loop           */
-  double backward_ms;       /* sum of K1+K2 kernel time (hipEvent)                 */
-  double forward_ms;        /* sum of K4 (rollout) kernel time                     */
-  double update_ms;         /* sum of K4b (costate) + K5 kernel time               */
+  double backward_ms;       /* sum of K1+K2 kernel time (hipEvent); 0 unless the timing detail covers it */
+  double forward_ms;        /* sum of K4 (rollout) kernel time; 0 unless covered   */
+  double update_ms;         /* sum of K4b (costate) + K5 kernel time; 0 unless covered */
   int64_t sweeps;           /* sum over trajectories of n_backward                 */
   int64_t rollouts;         /* sum over trajectories of n_forward                  */
   int64_t rollouts_launched;/* rollouts actually executed (speculative alphas too) */
@@ -259,8 +259,17 @@ typedef struct cddp_hip_stats {
   int32_t outer_iterations; /* host loop trips                                     */
   int32_t n_converged;      /* status OPTIMAL or ACCEPTABLE                        */
   int32_t kernel_launches;
-  int32_t _pad;
+  int32_t timing_detail;    /* CDDP_HIP_TIMING_* the class times were taken with   */
 } cddp_hip_stats;
+
+/* Which kernel classes cddp_hip_solve brackets with hipEvents when a stats block is requested.  An event costs
+ * about 5 us of queue time, i.e. bracketing every class of every iteration adds ~5 % to a C2 solve; the default
+ * brackets the rollout launches only (2 events per iteration). */
+enum {
+  CDDP_HIP_TIMING_ROLLOUT = 0,   /* forward_ms only                       */
+  CDDP_HIP_TIMING_ALL = 1,       /* backward_ms, forward_ms, update_ms    */
+  CDDP_HIP_TIMING_SWEEP = 2      /* backward_ms only                      */
+};
 
 typedef struct cddp_hip_handle cddp_hip_handle;
 
@@ -285,6 +294,9 @@ int cddp_hip_destroy(cddp_hip_handle *h);
 
 /* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's). */
 int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream);
+
+/* Select the class-timing detail (CDDP_HIP_TIMING_*) of later cddp_hip_solve calls that pass a stats block. */
+int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail);
 
 /* CDDP::setInitialState / setInitialTrajectory for the whole batch (cddp_core.cpp:66-140).
  * x0: batch*nx. U0: batch*N*nu or NULL (zeros). X0: batch*(N+1)*nx or NULL (x0 replicated,
