@@ -628,7 +628,6 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     ks->derivs(d, 0, s);
     ks->backward(d, P.solver, 0, 1, s);
     mark(1);
-    HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int), s));
     if (one_stage) {
       ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
       mark(2);

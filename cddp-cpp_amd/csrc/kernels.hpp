@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64) void k_derivs(DevBuf d, const ProblemDev *__res
   constexpr int NX = Model::NX, NU = Model::NU;
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int t = blockIdx.y;
+  // first kernel of an outer iteration: reset the "still running" counter K5 adds to (saves a memset node per iteration)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic

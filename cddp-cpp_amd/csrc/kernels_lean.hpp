@@ -39,6 +39,9 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
   typedef CstLayout<Model, Cons> L;
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int t = blockIdx.y;
+  if constexpr (WITH_DERIVS) {   // first kernel of an outer iteration (see k_derivs)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
+  }
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   const ProblemDev *__restrict__ P = Pk;
