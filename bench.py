@@ -181,6 +181,8 @@ def main():
     # One untimed solve with every kernel class bracketed by hipEvents (the "classes" block below and the choice of
     # the dominant class); the timed steps then bracket ONLY the dominant class's launches -- every event costs ~5 us
     # of queue time, 6 per iteration are ~5 % of a C2 solve.
+    if world > 1:   # communicator set-up (lazy in RCCL) is not part of a step, whatever --warmup says
+        sh.allgather_records(rec_local, world, dist)
     hs.set_timing_detail(api.TIMING_ALL)
     prof = hs.solve()
     sweep_dominates = prof.backward_ms >= prof.forward_ms
