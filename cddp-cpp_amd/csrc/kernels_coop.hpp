@@ -723,7 +723,8 @@ struct CoopBigCfg {
   // oM holds T1, then (in place, row by row) Q_xx, then (in place, element by element) Vn
   static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
                        oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oVx = oKtQ + NX * NU, oDx = oVx + NX,
-                       oC = oDx + NX, oWx = oC + 2 * RC, RAW = oWx + (HAS_X ? NX * NX : 0);
+                       oC = oDx + NX, oWx = oC + 2 * RC, oQuu = oWx + (HAS_X ? NX * NX : 0), RAW = oQuu + NU * NU;
+  static constexpr int NQ = (NU * NU + G - 1) / G;                                   // Q_uu entries per lane
   static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
 };
 
@@ -737,10 +738,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   constexpr int CST = L::SIZE, G = C::G;
   __shared__ double lds[C::TPW * C::STRIDE];
   __shared__ double ldsQ[NX * NX];   // Q dt (loop-invariant, shared by the trajectories of the wave)
+  __shared__ double ldsR[NU * NU];   // R dt
   const int lane = threadIdx.x;
   {   // every lane of the wavefront takes part, BEFORE the per-trajectory early exits
-    const double *Qp = Pk->pool + Pk->off_Qdt;
+    const double *Qp = Pk->pool + Pk->off_Qdt, *Rp = Pk->pool + Pk->off_Rdt;
     for (int e = lane; e < NX * NX; e += 64) ldsQ[e] = Qp[e];
+    for (int e = lane; e < NU * NU; e += 64) ldsR[e] = Rp[e];
     lds_sync();
   }
   const int q = lane % G, tl = lane / G;
@@ -760,12 +763,6 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   bool ok = false;
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
-  double Rr[NU * NU];
-  {
-    const double *Rp = P->pool + P->off_Rdt;
-#pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Rr[i] = Rp[i];
-  }
   struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
   struct In2 { double cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq; };
   static_assert(L::WQYU == L::CU + NU && L::QYUSIR == L::WQYU + NU * NU && L::IPR == L::QYUSIR + NU && L::ICOMP == L::IPR + 1, "contiguous replicated block");
@@ -883,13 +880,21 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Aq[j];
         Quxc[u] = s; }
+      // Q_uu = 2 R dt + T2 B: its entries are spread over the lanes of the group (one LDS round) instead of every lane
+      // repeating the nu^2 nx-term products
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+      for (int jq = 0; jq < C::NQ; ++jq) {
+        const int e = q + G * jq;
+        const int ee = e < NU * NU ? e : NU * NU - 1;
+        const int u = ee / NU, v = ee - u * NU;
+        double s = 0.0;
 #pragma unroll
-        for (int v = 0; v < NU; ++v) { double s = 0.0;
+        for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Lb[j * NU + v];
+        if (e < NU * NU) Ls[C::oQuu + e] = (2.0 * ldsR[ee]) + s;
+      }
+      lds_sync();
 #pragma unroll
-          for (int j = 0; j < NX; ++j) s += Ls[C::oT2 + u * NX + j] * Lb[j * NU + v];
-          Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
+      for (int i = 0; i < NU * NU; ++i) Quu[i] = Ls[C::oQuu + i];
       double Qr[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i)
