@@ -215,11 +215,13 @@ struct LDLTs {
     ok = ret;
   }
 
+  // (the transpositions are applied as value selects: written as "if (tr[k] == B) swap(x[k], x[B])" the optimiser
+  //  re-rolls the chain into x[tr[k]], i.e. a dynamically indexed array in scratch memory)
   DEV void solve(double *x) const {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-      for (int B = k + 1; B < N; ++B) if (tr[k] == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+      for (int B = k + 1; B < N; ++B) { const bool sw = tr[k] == B; const double a = x[k], b = x[B]; x[k] = sw ? b : a; x[B] = sw ? a : b; }
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) { double sacc = x[i];
@@ -236,7 +238,7 @@ struct LDLTs {
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
 #pragma unroll
-      for (int B = k + 1; B < N; ++B) if (tr[k] == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+      for (int B = k + 1; B < N; ++B) { const bool sw = tr[k] == B; const double a = x[k], b = x[B]; x[k] = sw ? b : a; x[B] = sw ? a : b; }
     }
   }
 };

@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
   struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
-  struct In2 { double cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq; };
+  struct In2 { double cxq, WQyxq[NU], QyxSirq; };   // the replicated block (c_u .. icomp) is read from its LDS copy where it is used
   static_assert(L::WQYU == L::CU + NU && L::QYUSIR == L::WQYU + NU * NU && L::IPR == L::QYUSIR + NU && L::ICOMP == L::IPR + 1, "contiguous replicated block");
   auto loadAB = [&](int tt, InAB &r) {   // this lane's slice of A_t, B_t (element e = q + G j; clamped past the end)
 #pragma unroll
@@ -787,16 +787,6 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   };
   auto load2 = [&](int tt, In2 &r) {
     const double *c = d.cst + GI(tt, CST, 0);
-    {   // replicated block: from the LDS copy of this step
-      const double *Lc = Ls + C::oC + (tt & 1) * C::RC;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) r.cu[i] = Lc[i];
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) r.WQyu[i] = Lc[NU + i];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) r.QyuSir[i] = Lc[NU + NU * NU + i];
-      r.ipr = Lc[NU + NU * NU + NU]; r.icomp = Lc[NU + NU * NU + NU + 1];
-    }
     r.cxq = c[(size_t)(L::CX + qc) * kLS];
     if constexpr (Cons::HAS_X) {
 #pragma unroll
@@ -835,6 +825,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       const int tp = t > 0 ? t - 1 : 0;
       load2(t, c2);
       const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU;
+      const double *Lc = Ls + C::oC + (t & 1) * C::RC;   // c_u | G_u^T YS^-1 G_u | G_u^T S^-1 rhat | ipr | icomp
       loadAB(tp, nab);
       PIPELINE_FENCE();
       double Aq[NX];
@@ -844,7 +835,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // (outer loops stay rolled and write to LDS: fully unrolled, the 3 nx^2-term products keep hundreds of LDS
       //  operands live and spill)
       double T2c[NU], Qu[NU];
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
@@ -863,14 +854,14 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       for (int u = 0; u < NU; ++u) { double s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) s2 += Lb[k * NU + u] * Vx[k];
-        Qu[u] = c2.cu[u] + s2; }
+        Qu[u] = Lc[u] + s2; }
 #pragma unroll
       for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
       lds_sync();
       // ---- round 2: Q_xx[i, qc] replaces T1[i, qc] in place (row i of T1 is dead once every lane has used it,
       // and the lanes of a wavefront run this loop in lockstep)
       double Quxc[NU], Quu[NU * NU];
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
@@ -899,7 +890,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
 #pragma unroll
       for (int i = 0; i < NU; ++i)
 #pragma unroll
-        for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + c2.WQyu[i * NU + c];
+        for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + Lc[NU + i * NU + c];
 #pragma unroll
       for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
       double kk[NU], KKc[NU], Quxq[NU];
@@ -910,7 +901,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         Quxq[u] = rhs;
       }
       if (NU == 1) {
-        kk[0] = -ldlt1_solve(Qr[0], Qu[0] + c2.QyuSir[0]);
+        kk[0] = -ldlt1_solve(Qr[0], Qu[0] + Lc[NU + NU * NU]);
         KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
       } else {
         LDLTs<NU> f;
@@ -918,7 +909,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         if (!f.ok) return false;
         double col[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + c2.QyuSir[i];
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + Lc[NU + NU * NU + i];
         f.solve(col);
 #pragma unroll
         for (int i = 0; i < NU; ++i) kk[i] = -col[i];
@@ -929,9 +920,9 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
       }
 #pragma unroll
-      for (int i = 0; i < NU; ++i) Qu[i] += c2.QyuSir[i];
+      for (int i = 0; i < NU; ++i) Qu[i] += Lc[NU + NU * NU + i];
 #pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Quu[i] += c2.WQyu[i];
+      for (int i = 0; i < NU * NU; ++i) Quu[i] += Lc[NU + i];
       double KtQq[NU];   // row qc of K^T Q_uu (condensed Q_uu), mm_tn's expression
 #pragma unroll
       for (int j = 0; j < NU; ++j) { double s = 0.0;
@@ -946,7 +937,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
       // ---- round 3
       if constexpr (Cons::HAS_X) Qxq += c2.QyxSirq;
-      inf_pr = dmax(inf_pr, c2.ipr); inf_comp = dmax(inf_comp, c2.icomp);
+      inf_pr = dmax(inf_pr, Lc[NU + NU * NU + NU]); inf_comp = dmax(inf_comp, Lc[NU + NU * NU + NU + 1]);
       double Quuk[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) { double s1 = 0.0;
@@ -964,7 +955,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxq[j] * kk[j]; c += KtQq[j] * kk[j]; }
         Vxq = ((Qxq + a) + bb) + c;
       }
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place
         double a = 0.0, bb = 0.0, e = 0.0;
 #pragma unroll

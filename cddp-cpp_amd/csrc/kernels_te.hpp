@@ -219,7 +219,7 @@ DEV void ldlt_lds_solve(const double *F, double *x) {
   for (int k = 0; k < N; ++k) {
     const int tk = (int)F[N * N + k];
 #pragma unroll
-    for (int B = k + 1; B < N; ++B) if (tk == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+    for (int B = k + 1; B < N; ++B) { const bool sw = tk == B; const double a = x[k], b = x[B]; x[k] = sw ? b : a; x[B] = sw ? a : b; }
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) { double sacc = x[i];
@@ -237,7 +237,7 @@ DEV void ldlt_lds_solve(const double *F, double *x) {
   for (int k = N - 1; k >= 0; --k) {
     const int tk = (int)F[N * N + k];
 #pragma unroll
-    for (int B = k + 1; B < N; ++B) if (tk == B) { const double v = x[k]; x[k] = x[B]; x[B] = v; }
+    for (int B = k + 1; B < N; ++B) { const bool sw = tk == B; const double a = x[k], b = x[B]; x[k] = sw ? b : a; x[B] = sw ? a : b; }
   }
 }
 
