@@ -336,6 +336,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
     }
   }
   DA(d.n_active, 1);
+  DA(d.win_hist, CDDP_HIP_MAX_ALPHAS + 1);
   DA(h->d_launched, 1);
   DA(h->dP, 1);
   DA(h->d_Xinit, d.planeX); DA(h->d_Uinit, d.planeU);
@@ -618,12 +619,56 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
   const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
   const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
-  const bool one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
-  two_stage_marks = !one_stage;
+  // Ladder shape.  one_stage: all n_alpha trials of every trajectory in ONE launch.  Otherwise stage 1 evaluates the
+  // first k1 alphas for every trajectory and stage 2 the rest, only for the trajectories none of the first k1 worked
+  // for (a launch whose workgroups exit at once when there is no such trajectory).  The rollout is a latency chain:
+  // up to one wavefront per SIMD (1024) extra alphas in a launch cost no wall time, beyond that the chains slow
+  // each other down -- and a stage-2 launch costs a full chain as soon as ONE trajectory needs it.  The best shape
+  // therefore depends on how many alphas the problem at hand needs (measured on MI355X, ms per solve at B = 4096 /
+  // 8192: cart-pole, 5.3 alphas per iteration on average: one launch 48.7 / 98, k1 = 4: 54.6 / 89.5; unicycle, 1.4
+  // alphas: one launch 96 / 152, k1 = 4: 66.8 / 86.0, k1 = 1: - / 124), so it follows the accepted-alpha histogram
+  // K5 keeps (read with the "anything still running" poll): k1 = the smallest count that satisfies all but about one
+  // trajectory per four iterations, capped at one wavefront per SIMD; when nearly the whole ladder is needed, all of it
+  // in one launch if that fits two wavefronts per SIMD, else as many alphas as do (B = 16384 cart-pole: 210 vs 243 ms).  The selected trials do not depend on the shape
+  // (tests/test_gpu_parity.py::test_two_stage_ladder_selects_the_same_trials); CDDP_HIP_LS_STAGES=1|2 and
+  // CDDP_HIP_LS_FIRST=k pin it.
+  const long per_alpha = std::max(1L, waves_all / std::max(1, na));
+  const int k_cap = (int)std::max(1L, std::min((long)na - 1, 1024 / per_alpha));    // one wavefront per SIMD
+  const int k_cap2 = (int)std::max(1L, std::min((long)na - 1, 2048 / per_alpha));   // two (a ladder that is needed almost whole)
+  const char *kf_env = std::getenv("CDDP_HIP_LS_FIRST");
+  const int k_forced = kf_env ? std::atoi(kf_env) : 0;
+  const bool pinned = !first_rule || na == 1 || force_one || force_two || (k_forced >= 1 && k_forced < na);
+  bool one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
+  int k1 = force_two ? 1 : k_cap2;
+  if (k_forced >= 1 && k_forced < na && !force_one && first_rule) { one_stage = false; k1 = k_forced; }
+  std::vector<int> hist_now(na + 1, 0), hist_prev(na + 1, 0);
+  int *h_hist = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_hist, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1)));
+  HIPCHK(hipMemsetAsync(d.win_hist, 0, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1), s));
+  auto adapt_ladder = [&](int window_iters) {
+    if (pinned) return;
+    long total = 0;
+    std::vector<long> hd(na + 1);
+    for (int a = 0; a <= na; ++a) { hd[a] = (long)hist_now[a] - (long)hist_prev[a]; total += hd[a]; }
+    hist_prev = hist_now;
+    if (total <= 0) return;
+    const long allow = std::max(1L, (long)window_iters / 4);   // trajectory-iterations left to stage 2 per window
+    int kq = na;                                               // alphas needed to satisfy all but `allow`
+    long tail = hd[na];
+    for (int k = na - 1; k >= 1; --k) {                        // tail(k) = # not satisfied by the first k alphas
+      tail += hd[k];
+      if (tail <= allow) kq = k; else break;
+    }
+    if (kq >= na - 1) {
+      if (waves_all <= 2048) { one_stage = true; }
+      else { one_stage = false; k1 = k_cap2; }
+    } else { one_stage = false; k1 = std::max(1, std::min(kq, k_cap)); }
+  };
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
     ++outer;
     const int last = (it == max_it) ? 1 : 0;
+    two_stage_marks = !one_stage;
     mark(0);
     ks->derivs(d, 0, s);
     ks->backward(d, P.solver, 0, 1, s);
@@ -636,14 +681,14 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       mark(3);
       launches += 4;
     } else {
-      ks->forward(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
+      ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
       mark(2);
-      ks->costate(d, P.solver, 0, 1, PH_FWD1, 0, 1, s);
-      ks->update(d, 1, 1, last, 0, s);
+      ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+      ks->update(d, 1, k1, last, 0, s);
       mark(3);
-      ks->forward(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
+      ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
       mark(4);
-      ks->costate(d, P.solver, 1, na - 1, PH_FWD2, 0, 1, s);
+      ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
       ks->update(d, 2, na, last, 1, s);
       mark(5);
       launches += 6;
@@ -654,14 +699,18 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     constexpr int kPollEvery = 4;
     if (it % kPollEvery == 0 || last) {
       HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(h_hist, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       if (*h_active == 0) break;
+      for (int a = 0; a <= na; ++a) hist_now[a] = h_hist[a];
+      adapt_ladder(kPollEvery);
     }
   }
   HIPCHK(hipEventRecord(ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   hipHostFree(h_active);
+  hipHostFree(h_hist);
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     float ms = 0;

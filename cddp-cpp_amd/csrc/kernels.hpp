@@ -1569,6 +1569,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
   const bool ipddp = (P->solver == CDDP_HIP_SOLVER_IPDDP);
   const int ph = d.phase[b];
   const int n_alphas = d.n_alphas;
+  int ladder_bin = -1;   // index of the accepted alpha (n_alphas: none worked) for the host's ladder-shape statistics
   const int mT = (TERM && ipddp) ? P->mT : 0, pT = (TERM && ipddp) ? P->pT : 0;
   const bool nobar = (M == 0) && mT == 0;     // no_barrier_needed (ipddp_solver.cpp:2552-2554)
   if ((stage == 1 && ph == PH_FWD1) || (stage == 2 && ph == PH_FWD2)) {
@@ -1585,6 +1586,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
       }
     }
     if (win < 0 && hi < n_alphas) { d.phase[b] = PH_FWD2; goto count; }   // more alphas to try
+    ladder_bin = (win >= 0) ? win : n_alphas;
     {
       const int iter = d.iter[b];
       if (win >= 0) {
@@ -1749,6 +1751,12 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
     }
   }
 count:
+  if (d.win_hist) {   // one atomic per populated bin and wavefront
+    for (int a = 0; a <= n_alphas; ++a) {
+      const unsigned long long m = __ballot(ladder_bin == a);
+      if (m != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(d.win_hist + a, (int)__popcll(m));
+    }
+  }
   if (do_count) {
     if (is_last_iter && d.phase[b] != PH_DONE) { d.status[b] = CDDP_HIP_STATUS_MAX_ITERATIONS; d.phase[b] = PH_DONE; }
     if (d.phase[b] != PH_DONE) atomicAdd(d.n_active, 1);

@@ -286,6 +286,10 @@ def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
     assert np.array_equal(r1["iterations"], r2["iterations"]) and np.array_equal(r1["status"], r2["status"])
     assert np.array_equal(r1["final_objective"], r2["final_objective"])
     assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
+    monkeypatch.setenv("CDDP_HIP_LS_FIRST", "3")      # stage 1 = the first three alphas, stage 2 = the rest
+    r3, X3, U3, K3, k3 = run()
+    assert np.array_equal(r1["iterations"], r3["iterations"]) and np.array_equal(r1["status"], r3["status"])
+    assert np.array_equal(X1, X3) and np.array_equal(U1, U3) and np.array_equal(K1, K3) and np.array_equal(k1, k3)
 
 
 @pytest.mark.parametrize("case", ["term_eq_only", "path_term_eq", "pendulum_term_eq", "manipulator_term_eq",
