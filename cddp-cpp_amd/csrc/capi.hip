@@ -662,7 +662,12 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     if (kq >= na - 1) {
       if (waves_all <= 2048) { one_stage = true; }
       else { one_stage = false; k1 = k_cap2; }
-    } else { one_stage = false; k1 = std::max(1, std::min(kq, k_cap)); }
+    } else { one_stage = false; k1 = std::max(1, std::min(kq + 1, k_cap)); }   // + 1: the histogram drifts between polls
+    if (std::getenv("CDDP_HIP_DEBUG_LADDER")) {
+      std::fprintf(stderr, "[ladder] it=%d total=%ld kq=%d -> %s k1=%d hist:", outer, total, kq, one_stage ? "one" : "two", k1);
+      for (int a = 0; a <= na; ++a) std::fprintf(stderr, " %ld", hd[a]);
+      std::fprintf(stderr, "\n");
+    }
   };
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
   for (int it = 1; it <= max_it; ++it) {
@@ -697,13 +702,13 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
     // trajectory finished are launches whose every lane exits on its phase check.
     constexpr int kPollEvery = 4;
-    if (it % kPollEvery == 0 || last) {
+    if (it % kPollEvery == 0 || last || (it <= 2 && !pinned)) {   // (two early polls: the ladder statistics settle the shape)
       HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(h_hist, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       if (*h_active == 0) break;
       for (int a = 0; a <= na; ++a) hist_now[a] = h_hist[a];
-      adapt_ladder(kPollEvery);
+      adapt_ladder(it <= 2 ? 1 : (it == kPollEvery ? 2 : kPollEvery));
     }
   }
   HIPCHK(hipEventRecord(ev1, s));
