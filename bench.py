@@ -236,14 +236,16 @@ def main():
     n_launch = max(1, st.outer_iterations)
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
     # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
-    # (profiles/r01_h_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
+    # (profiles/r01_i_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
     traffic = None
     traffic_note = None
     if pmc_key and args.workload == "cartpole" and B == 4096 and ipddp:
         try:
-            pj = json.load(open(os.path.join(REPO, "profiles", "r01_h_pmc_traffic.json")))
-            traffic = pj["kernels"][pmc_key]["bytes_per_launch"]
-            traffic_note = "profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of one solve)"
+            pj = json.load(open(os.path.join(REPO, "profiles", "r01_i_pmc_traffic.json")))
+            # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
+            # depending on the ladder shape the solver picked)
+            traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
+            traffic_note = "profiles/r01_i_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the rollout launches of one solve / outer iterations)"
         except Exception:
             traffic = None
     roofline = {

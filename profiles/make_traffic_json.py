@@ -7,18 +7,22 @@ import sys
 
 rows = [l.strip().strip("|").split("|") for l in open(sys.argv[1]) if l.startswith("|")]
 hdr = [c.strip() for c in rows[0]]
-fi, wi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
+fi, wi, di = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE"), hdr.index("dispatches")
+SOLVES = 2   # `bench.py --steps 1 --warmup 0` = the profiling solve + one timed step
 kern = {}
 for r in rows[2:]:
     c = [x.strip() for x in r]
     if not c[fi] or not c[wi]:
         continue
     f, w = float(c[fi]), float(c[wi])
-    kern[c[0].strip("`")] = {"fetch_kb": f, "write_kb": w, "bytes_per_launch": f * 1024 * 2 + w * 1024}
+    n = int(c[di])
+    kern[c[0].strip("`")] = {"fetch_kb": f, "write_kb": w, "bytes_per_launch": f * 1024 * 2 + w * 1024, "dispatches": n,
+                             "bytes_per_solve": (f * 1024 * 2 + w * 1024) * n / SOLVES}
 print(json.dumps({
     "source": sys.argv[2],
     "calibration": "FETCH_SIZE reads 0.488x the known bytes of the 8-B/lane and 16-B/lane row streams of "
                    "profiles/ubench/vmem.hip on this gfx950 stack (guide: x2 correction); WRITE_SIZE reads 0.976x "
                    "the bytes of hipMemset fills (no correction). profiles/r01_c_pmc_calibration.md",
-    "unit": "bytes per launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)",
+    "unit": "bytes per launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024); bytes_per_solve = that x dispatches / solves in the profiled command",
+    "solves_in_profile": SOLVES,
     "kernels": kern}, indent=1))
