@@ -733,6 +733,11 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       stats->forward_ms += span(it0, 1, 2) + span(it0, 3, 4);    // rollout stage 1 (+ stage 2)
       stats->update_ms += span(it0, 2, 3) + span(it0, 4, 5);     // costate + update
     }
+    // (two-stage iterations record the point between update 1 and rollout 2 in every mode; only the classes the
+    //  detail names are reported)
+    if (detail != CDDP_HIP_TIMING_ALL) stats->update_ms = 0.0;
+    if (detail == CDDP_HIP_TIMING_ROLLOUT) stats->backward_ms = 0.0;
+    if (detail == CDDP_HIP_TIMING_SWEEP) stats->forward_ms = 0.0;
     stats->timing_detail = detail;
     std::vector<int> nb(d.B), nf(d.B), itv(d.B), stv(d.B);
     HIPCHK(hipMemcpy(nb.data(), d.n_bwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
