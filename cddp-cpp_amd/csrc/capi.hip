@@ -70,6 +70,8 @@ struct cddp_hip_handle {
   size_t bytes = 0;
   int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
   std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  int *h_poll = nullptr;                         // pinned host words of the solve loop's poll: [0] running count, [1..] alpha histogram
 };
 
 namespace {
@@ -361,6 +363,8 @@ int cddp_hip_destroy(cddp_hip_handle *h) {
   hipStreamSynchronize(h->stream);
   free_all(h);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+  if (h->ev_begin) { hipEventDestroy(h->ev_begin); hipEventDestroy(h->ev_end); }
+  if (h->h_poll) hipHostFree(h->h_poll);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -588,8 +592,9 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   const int detail = stats ? h->timing_detail : -1;
   std::vector<int> ev_slot;        // ev_slot[6 * (iteration - 1) + point] = index into the pool, or -1
   size_t ev_used = 0;
-  hipEvent_t ev0, ev1;
-  HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+  if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
+  if (!h->h_poll) HIPCHK(hipHostMalloc((void **)&h->h_poll, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 2)));
+  const hipEvent_t ev0 = h->ev_begin, ev1 = h->ev_end;
   HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
   HIPCHK(hipEventRecord(ev0, s));
   { int rc = run_initialize(h); if (rc) return rc; }
@@ -607,8 +612,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     hipEventRecord(h->ev_pool[ev_used], s);
     ev_slot[slot] = (int)ev_used++;
   };
-  int *h_active = nullptr;
-  HIPCHK(hipHostMalloc((void **)&h_active, sizeof(int)));
+  int *h_active = h->h_poll;
   *h_active = d.B;
   // Speculative line search: when batch x n_alphas wavefronts still underfill the chip (256 CUs x 4 SIMDs),
   // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
@@ -642,8 +646,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   int k1 = force_two ? 1 : k_cap2;
   if (k_forced >= 1 && k_forced < na && !force_one && first_rule) { one_stage = false; k1 = k_forced; }
   std::vector<int> hist_now(na + 1, 0), hist_prev(na + 1, 0);
-  int *h_hist = nullptr;
-  HIPCHK(hipHostMalloc((void **)&h_hist, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1)));
+  int *h_hist = h->h_poll + 1;
   HIPCHK(hipMemsetAsync(d.win_hist, 0, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1), s));
   auto adapt_ladder = [&](int window_iters) {
     if (pinned) return;
@@ -714,8 +717,6 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   HIPCHK(hipEventRecord(ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
-  hipHostFree(h_active);
-  hipHostFree(h_hist);
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     float ms = 0;
@@ -753,7 +754,6 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     stats->rollouts_launched = (int64_t)nl;
     stats->outer_iterations = outer; stats->kernel_launches = launches;
   }
-  hipEventDestroy(ev0); hipEventDestroy(ev1);
   return 0;
 }
 
