@@ -478,11 +478,21 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
   if (b >= d.B) return;
   if (!force && d.phase[b] != phase_req) return;
   const int cur = d.cur[b];
-  double xo[NX], lo[NX], vx[NX], vxx[NX * NX];
+  // V_xx is stored exactly symmetric (every sweep writes 0.5 (M + M^T), the terminal block is sym(2 Q_f) [+ folded
+  // terminal terms, symmetrised the same way]): only the upper triangle is fetched -- nx (nx - 1) / 2 rows less.
+  constexpr int NT = NX * (NX + 1) / 2;
+  double xo[NX], lo[NX], vx[NX], vt[NT];
   ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
   ld<NX>(d.Lam + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, lo);
   ld<NX>(d.Vx + GI(t, NX, 0), kLS, vx);
-  ld<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, vxx);
+  {
+    const double *vb = d.Vxx + GI(t, NX * NX, 0);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = i; j < NX; ++j) vt[k++] = vb[(size_t)(i * NX + j) * kLS];
+  }
   for (int a = a0; a < a0 + na; ++a) {
     const size_t ti = (size_t)a * d.Bp + b;
     if (!d.t_success[ti]) continue;
@@ -495,7 +505,10 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
     for (int i = 0; i < NX; ++i) {
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s += vxx[i * NX + j] * (xn[j] - xo[j]);
+      for (int j = 0; j < NX; ++j) {
+        const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;   // V_xx[i][j] from the stored upper triangle
+        s += vt[lo_ * NX - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)] * (xn[j] - xo[j]);
+      }
       lam[i] = (lo[i] + a_pr * vx[i]) + s;
       finite = finite && dfinite(lam[i]);
     }

@@ -318,6 +318,25 @@ def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
     assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
 
 
+@pytest.mark.parametrize("sweep", ["coop", "lane"])
+@pytest.mark.parametrize("case", ["cartpole_ipddp_box", "cartpole_ipddp_unc", "unicycle_ipddp_box_ball", "quadrotor_ipddp_box",
+                                  "pendulum_term_eq", "manip7_term_eq_parallel_ls", "term_ineq_only"])
+def test_value_hessian_is_stored_exactly_symmetric(api, case, sweep, monkeypatch):
+    """k_costate fetches only the upper triangle of V_xx[t]: every IPDDP sweep must store V_xx bitwise symmetric
+    (0.5 (M + M^T), sym(2 Q_f) at t = N), in the cooperative and in the one-lane kernels."""
+    if sweep == "lane":
+        monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
+    else:
+        monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    p = TERM_CASES[case](api) if case in TERM_CASES else make(api, case)
+    B = 20
+    x0 = api.batch_x0(p, B, 20261012, spread_for(p) if p.nx > 1 else 0.05 * np.ones(1))
+    hs = api.HipBatchSolver(p, B); hs.set_initial(x0, api.batch_U0(p, B)); hs.solve()
+    _, Vxx = hs.value(); hs.close()
+    assert np.all(np.isfinite(Vxx))
+    assert np.array_equal(Vxx, np.swapaxes(Vxx, 2, 3))
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 5])
 @pytest.mark.parametrize("kind", ["scalar_path", "cartpole_box", "pendulum_clddp"])
 def test_tiny_horizons(api, kind, N):
