@@ -785,7 +785,9 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
     for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-    Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+    typename Cons::Ctx cctx;
+    if constexpr (UDiag<Cons>::value) Cons::load(P, cctx);     // control box only: one entry per row of G_u (see k_forward_ipddp_pc)
+    else Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
     double apr = 1.0, adu = 1.0;
 #pragma unroll
     for (int rr = 0; rr < M; ++rr) {
@@ -794,18 +796,25 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
       const double rp = g[rr] + s[rr], rc = y[rr] * s[rr] - mu;
       const double rhat = y[rr] * rp - rc;
       double temp = 0.0;
+      if constexpr (UDiag<Cons>::value) temp = 0.0 + UDiag<Cons>::val(cctx, rr) * kk[UDiag<Cons>::col(rr)];
+      else {
 #pragma unroll
-      for (int i = 0; i < NU; ++i) temp += Qyu[rr * NU + i] * kk[i];
+        for (int i = 0; i < NU; ++i) temp += Qyu[rr * NU + i] * kk[i];
+      }
       const double kyr = clip_sgn(rhat + y[rr] * temp, ss);
       const double ksr = (-rp) - temp;
       double a = 0.0, c = 0.0;
 #pragma unroll
       for (int cc = 0; cc < NX; ++cc) {
-        double s2 = 0.0;
+        double s2 = 0.0, gx = 0.0;
+        if constexpr (UDiag<Cons>::value) s2 = 0.0 + UDiag<Cons>::val(cctx, rr) * KK[UDiag<Cons>::col(rr) * NX + cc];
+        else {
+          gx = Qyx[rr * NX + cc];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) s2 += Qyu[rr * NU + i] * KK[i * NX + cc];
-        const double Kyv = dmin(dmax(YSr * (Qyx[rr * NX + cc] + s2), -kMaxBarrierRatio), kMaxBarrierRatio);
-        const double Ksv = (-Qyx[rr * NX + cc]) - s2;
+          for (int i = 0; i < NU; ++i) s2 += Qyu[rr * NU + i] * KK[i * NX + cc];
+        }
+        const double Kyv = dmin(dmax(YSr * (gx + s2), -kMaxBarrierRatio), kMaxBarrierRatio);
+        const double Ksv = (-gx) - s2;
         a += Ksv * dx[cc]; c += Kyv * dx[cc];
       }
       d.ky[GI(t, M, rr)] = kyr;
