@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
       for (int j = 0; j < NX; ++j) Aq[j] = La[j * NX + qc];
       // round 1: column qc of T1 = A^T P and of BtP = B^T P
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         Ls[C::oT2 + u * NX + qc] = s; }
       lds_sync();
       // round 2a: Q + A^T P A (in place over T1, row by row), Q_ux column; the entries of Q_uu spread over the lanes
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int i = 0; i < NU; ++i) kk[i] = -col[i];
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < NX; ++i) {
           double a = 0.0;
 #pragma unroll
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int i = 0; i < NX; ++i) tep[(((size_t)t * Bp + b) * NX + i) * VP + v] = pv[i];
       }
       // round 3: P_t column (in place over the lane's own Q + A^T P A column)
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < NX; ++i) {
         double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int j = 0; j < NX; ++j) a += Lk[i * NX + j] * dx[j];
           du[i] = rc.kf[i] + a; }
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < NX; ++i) {
           double a = 0.0, c = 0.0;
 #pragma unroll
