@@ -81,6 +81,7 @@ struct DevBuf {
   double *hist;
   int *hist_n;
   int *n_active;                           // device counter of trajectories still running
+  int ev_valid;                            // set per K5 launch: the trials' parked barrier terms (ev, t_ysmin/max) were written by the two-role rollout
   int *win_hist;                           // [n_alphas + 1] accepted-alpha histogram of the solve so far (host picks the ladder shape)
   unsigned long long *launched;            // rollouts actually executed (speculative alphas included)
 };

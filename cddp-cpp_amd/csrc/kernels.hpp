@@ -1654,8 +1654,40 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
               double xN[NXu];
               ld<NXu>(d.X + (size_t)cs * d.planeX + GI(d.N, NXu, 0), kLS, xN);
               term_eq_residual<NXu>(P, xN, ts.h);
-              ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
-                                  d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp, &ts, mT, pT);
+              bool replayed = false;
+              if constexpr (M > 0) {
+                if (d.ev_valid && mT == 0) {
+                  // terminal equality only, trials evaluated by the two-role rollout: theta and the primal residual do
+                  // not depend on mu; the merit chain is replayed from the parked log-barrier terms and the multiplier
+                  // term lambda^T h is appended, exactly the order of ip_reductions + term_reductions (see the
+                  // branch below for layouts without a terminal set)
+                  const int N = d.N;
+                  const double *evb = d.ev + GI((size_t)win * N, 2 * Cons::NSEG, 0);
+                  const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
+                  double mer = d.cost[b];
+                  for (int c = 0; c < Cons::NSEG; ++c) {
+                    const double *q = evb + (size_t)c * kLS;
+                    int t = 0;
+                    for (; t + 15 < N; t += 16) {
+                      double v[16];
+#pragma unroll
+                      for (int k = 0; k < 16; ++k) v[k] = q[(size_t)(t + k) * tstride];
+#pragma unroll
+                      for (int k = 0; k < 16; ++k) mer -= mu * v[k];
+                    }
+                    for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
+                  }
+                  double dp = 0.0;
+                  for (int r = 0; r < pT; ++r) dp += ts.lam[r] * ts.h[r];
+                  mer += dp;
+                  phi_n = mer;
+                  icomp = dmax(fabs(d.t_ysmax[ti] - mu), fabs(d.t_ysmin[ti] - mu));
+                  replayed = true;
+                }
+              }
+              if (!replayed)
+                ip_reductions<Cons>(d, b, d.N, d.S + (size_t)cs * d.planeM, d.Y + (size_t)cs * d.planeM,
+                                    d.G + (size_t)cs * d.planeM, mu, d.cost[b], o.ipddp_theta_norm_l2 != 0, phi_n, theta_n, ipr, icomp, &ts, mT, pT);
             }
           } else if constexpr (M > 0) {
             if (mu != mu_old) {

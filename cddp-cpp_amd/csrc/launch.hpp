@@ -118,7 +118,9 @@ struct Launcher {
     hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
-    hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, stage, n1, is_last, do_count);
+    DevBuf dd = d;
+    if constexpr (kTeCoop && Cons::M > 0) dd.ev_valid = (d.te_cst && !lane_sweep_requested()) ? 1 : 0;
+    hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, dd, d.P, d.xref_traj, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, int mode, hipStream_t s) {
     hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
