@@ -47,6 +47,18 @@ def load_api():
     return mod
 
 
+def load_oracle_api():
+    """oracle/oracle_api.py: only the cpu_baseline leg below loads it."""
+    name = "cddp_oracle_api"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "oracle", "oracle_api.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def algorithmic_bytes(nx, nu, N, m, ipddp):
     """bytes per trajectory of one derivative fill / backward sweep / rollout."""
     D = 8
@@ -100,15 +112,17 @@ def make_problem(api, workload, solver):
 def cpu_baseline(api, p, x0, U0, budget_s=15.0):
     """Oracle (CPU restatement, kind 'port') timed on the host cores of this box on a bounded sample."""
     cores = os.cpu_count() or 1
+    oa = load_oracle_api()
+    oa.attach(api)
     fast = False
     try:   # rebuild the timing variant for THIS box's CPU (-march=native); fall back to the parity build
         out = "/tmp/cddp_oracle_fast_%d.so" % os.getpid()
         subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fPIC", "-shared", "-pthread", "-o", out,
                                os.path.join(REPO, "oracle", "cddp_oracle.cpp")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        api.ORACLE_FAST_LIB_PATH = out
+        oa.ORACLE_FAST_LIB_PATH = out
         fast = True
     except Exception:
-        fast = os.path.exists(api.ORACLE_FAST_LIB_PATH)
+        fast = os.path.exists(oa.ORACLE_FAST_LIB_PATH)
     n1 = min(x0.shape[0], cores)
     _, _, _, _, ms1 = api.oracle_solve_batch(p, x0[:n1], None if U0 is None else U0[:n1], n_threads=cores, fast=fast, want_traj=False)
     per_round = max(ms1 / 1e3, 1e-3)

@@ -1,12 +1,9 @@
-"""ctypes binding of the C-ABI in include/cddp_hip.h (+ the oracle's probe ABI).
+"""ctypes binding of the C-ABI in include/cddp_hip.h.
 
-This module is harness plumbing for tests/ and bench.py: it builds `cddp_hip_problem`
-descriptors (the POD twin of cddp::CDDP, reference include/cddp-cpp/cddp_core/cddp_core.hpp:215-423)
-and calls the shared libraries.  It contains no solver arithmetic.
-
-Two libraries can be loaded:
-  * HipBatchSolver  -> cddp-cpp_amd/lib/libcddp_hip.so  (the product; fails loudly if missing)
-  * Oracle          -> oracle/_build/libcddp_oracle.so   (CPU restatement; tests/bench only)
+Builds `cddp_hip_problem` descriptors (the POD twin of cddp::CDDP, reference
+include/cddp-cpp/cddp_core/cddp_core.hpp:215-423) and calls cddp-cpp_amd/lib/libcddp_hip.so (`HipBatchSolver`; fails
+loudly if the library or a GPU is missing).  It contains no solver arithmetic and knows nothing about the CPU checker:
+the tests / bench.py's cpu_baseline hang that on this namespace themselves.
 """
 import ctypes as C
 import os
@@ -15,8 +12,6 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
-ORACLE_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle.so")
-ORACLE_FAST_LIB_PATH = os.path.join(REPO, "oracle", "_build", "libcddp_oracle_fast.so")
 
 MAX_MODEL_PARAMS = 24
 NAME_LEN = 48
@@ -401,180 +396,6 @@ def batch_U0(problem, batch):
     if hasattr(problem, "U0_const"):
         return np.ascontiguousarray(np.tile(problem.U0_const, (batch, problem.N, 1)).astype(np.float64))
     return None
-
-
-# ----------------------------------------------------------------------------------------------
-# Oracle binding (tests / bench cpu_baseline only)
-# ----------------------------------------------------------------------------------------------
-_oracle_libs = {}
-
-
-def load_oracle(fast=False):
-    path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
-    if path in _oracle_libs:
-        return _oracle_libs[path]
-    if not os.path.exists(path):
-        raise RuntimeError("oracle library missing: %s (run __graft_entry__.build() or make -C oracle)" % path)
-    lib = C.CDLL(path)
-    lib.cddp_oracle_create.restype = C.c_void_p
-    lib.cddp_oracle_create.argtypes = [C.POINTER(ProblemStruct)]
-    lib.cddp_oracle_destroy.argtypes = [C.c_void_p]
-    for name in ["cddp_oracle_filter_theta", "cddp_oracle_filter_back_violation", "cddp_oracle_scaled_inf_du",
-                 "cddp_oracle_get_mu", "cddp_oracle_cost"]:
-        getattr(lib, name).restype = C.c_double
-    _oracle_libs[path] = lib
-    return lib
-
-
-class Oracle:
-    def __init__(self, problem, fast=False):
-        self.lib = load_oracle(fast)
-        self.p = problem
-        self.h = C.c_void_p(self.lib.cddp_oracle_create(C.byref(problem.c)))
-        self.m = self.lib.cddp_oracle_dual_dim(self.h)
-
-    def __del__(self):
-        try:
-            self.lib.cddp_oracle_destroy(self.h)
-        except Exception:
-            pass
-
-    def set_initial(self, x0, U0=None, X0=None):
-        x0 = _arr(x0); U0 = _arr(U0) if U0 is not None else None; X0 = _arr(X0) if X0 is not None else None
-        self.lib.cddp_oracle_set_initial(self.h, _ptr(x0), _ptr(U0), _ptr(X0))
-
-    def initialize(self):
-        self.lib.cddp_oracle_initialize(self.h)
-
-    # ---- warm-start plumbing (reference: options.warm_start, IPDDPSolverTestAccess, setInitialState/Trajectory)
-    def set_warm_start(self, flag=True):
-        self.lib.cddp_oracle_set_warm_start(self.h, 1 if flag else 0)
-
-    def set_path_interior(self, s_val, y_val):
-        self.lib.cddp_oracle_set_path_interior(self.h, C.c_double(s_val), C.c_double(y_val))
-
-    def set_terminal_interior(self, s_val, y_val):
-        self.lib.cddp_oracle_set_terminal_interior(self.h, C.c_double(s_val), C.c_double(y_val))
-
-    def set_terminal_eq_multiplier(self, lam):
-        lam = _arr(lam)
-        self.lib.cddp_oracle_set_terminal_eq_multiplier(self.h, _ptr(lam))
-
-    def update_initial(self, x0, U0=None):
-        x0 = _arr(x0); U0 = _arr(U0) if U0 is not None else None
-        self.lib.cddp_oracle_update_initial(self.h, _ptr(x0), _ptr(U0))
-
-    def backward(self, retry=True):
-        return self.lib.cddp_oracle_backward(self.h, 1 if retry else 0)
-
-    def forward(self, alpha):
-        t = np.zeros(1, dtype=TRIAL_DTYPE)
-        self.lib.cddp_oracle_forward(self.h, C.c_double(alpha), t.ctypes.data_as(C.c_void_p))
-        return t[0]
-
-    def solve(self):
-        r = np.zeros(1, dtype=RESULT_DTYPE)
-        self.lib.cddp_oracle_solve(self.h, r.ctypes.data_as(C.c_void_p))
-        return r[0]
-
-    def result(self):
-        r = np.zeros(1, dtype=RESULT_DTYPE)
-        self.lib.cddp_oracle_get_result(self.h, r.ctypes.data_as(C.c_void_p))
-        return r[0]
-
-    def alphas(self):
-        a = np.zeros(64)
-        n = self.lib.cddp_oracle_num_alphas(self.h, _ptr(a), 64)
-        return a[:n].copy()
-
-    def trajectory(self):
-        X = np.zeros((self.p.N + 1, self.p.nx)); U = np.zeros((self.p.N, self.p.nu))
-        self.lib.cddp_oracle_get_trajectory(self.h, _ptr(X), _ptr(U))
-        return X, U
-
-    def gains(self):
-        K = np.zeros((self.p.N, self.p.nu, self.p.nx)); k = np.zeros((self.p.N, self.p.nu))
-        self.lib.cddp_oracle_get_gains(self.h, _ptr(K), _ptr(k))
-        return K, k
-
-    def value(self):
-        Vx = np.zeros((self.p.N + 1, self.p.nx)); Vxx = np.zeros((self.p.N + 1, self.p.nx, self.p.nx))
-        self.lib.cddp_oracle_get_value(self.h, _ptr(Vx), _ptr(Vxx))
-        return Vx, Vxx
-
-    def duals(self):
-        S = np.zeros((self.p.N, self.m)); Y = np.zeros((self.p.N, self.m)); G = np.zeros((self.p.N, self.m))
-        if self.m:
-            self.lib.cddp_oracle_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G))
-        return S, Y, G
-
-    def terminal(self):
-        dims = np.zeros(2, dtype=np.int32)
-        self.lib.cddp_oracle_get_terminal(self.h, None, None, None, None, dims.ctypes.data_as(C.POINTER(C.c_int32)))
-        mT, pT = int(dims[0]), int(dims[1])
-        S = np.zeros(mT); Y = np.zeros(mT); G = np.zeros(mT); L = np.zeros(pT)
-        self.lib.cddp_oracle_get_terminal(self.h, _ptr(S), _ptr(Y), _ptr(G), _ptr(L), None)
-        return S, Y, G, L
-
-    def backward_scalars(self):
-        dV = np.zeros(2); reg = np.zeros(1)
-        self.lib.cddp_oracle_get_backward_scalars(self.h, _ptr(dV), _ptr(reg))
-        return dV, reg[0]
-
-    def history(self):
-        cap = self.p.options.max_iterations + 2
-        h = np.zeros((cap, 9))
-        n = self.lib.cddp_oracle_get_history(self.h, _ptr(h), cap)
-        return h[:n].copy()
-
-    def dynamics(self, x, u, time=0.0):
-        x = _arr(x); u = _arr(u)
-        xd = np.zeros(self.p.nx); xn = np.zeros(self.p.nx)
-        Fx = np.zeros((self.p.nx, self.p.nx)); Fu = np.zeros((self.p.nx, self.p.nu))
-        self.lib.cddp_oracle_dynamics(self.h, _ptr(x), _ptr(u), C.c_double(time), _ptr(xd), _ptr(xn), _ptr(Fx), _ptr(Fu))
-        return xd, xn, Fx, Fu
-
-    def constraint_eval(self, x, u):
-        x = _arr(x); u = _arr(u)
-        g = np.zeros(self.m); gx = np.zeros((self.m, self.p.nx)); gu = np.zeros((self.m, self.p.nu))
-        self.lib.cddp_oracle_constraint_eval(self.h, _ptr(x), _ptr(u), _ptr(g), _ptr(gx), _ptr(gu))
-        return g, gx, gu
-
-    def cost(self, X, U):
-        X = _arr(X); U = _arr(U)
-        return self.lib.cddp_oracle_cost(self.h, _ptr(X), _ptr(U))
-
-
-def oracle_solve_batch(problem, x0, U0=None, X0=None, n_threads=1, fast=False, want_traj=True):
-    lib = load_oracle(fast)
-    x0 = _arr(x0); B = x0.shape[0]
-    U0 = _arr(U0) if U0 is not None else None; X0 = _arr(X0) if X0 is not None else None
-    res = np.zeros(B, dtype=RESULT_DTYPE)
-    X = np.zeros((B, problem.N + 1, problem.nx)) if want_traj else None
-    U = np.zeros((B, problem.N, problem.nu)) if want_traj else None
-    K = np.zeros((B, problem.N, problem.nu, problem.nx)) if want_traj else None
-    ms = C.c_double(0.0)
-    lib.cddp_oracle_solve_batch(C.byref(problem.c), B, _ptr(x0), _ptr(U0), _ptr(X0), n_threads,
-                                res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K), C.byref(ms))
-    return res, X, U, K, ms.value
-
-
-def oracle_boxqp(H, g, lower, upper, x0=None, options=None):
-    lib = load_oracle()
-    o = options if options is not None else default_options()
-    H = _arr(H); g = _arr(g); lo = _arr(lower); up = _arr(upper); n = g.size
-    x0a = _arr(x0) if x0 is not None else None
-    x = np.zeros(n); free = np.zeros(n, dtype=np.int32); it = C.c_int(0); fc = C.c_int(0)
-    st = lib.cddp_oracle_boxqp(C.byref(o), n, _ptr(H), _ptr(g), _ptr(lo), _ptr(up), _ptr(x0a), _ptr(x),
-                               free.ctypes.data_as(C.POINTER(C.c_int)), C.byref(it), C.byref(fc))
-    return x, st, free, it.value, fc.value
-
-
-def oracle_ldlt_solve(A, B):
-    lib = load_oracle()
-    A = _arr(A); B = _arr(B); n = A.shape[0]; B2 = B.reshape(n, -1); X = np.zeros_like(B2)
-    ok = lib.cddp_oracle_ldlt_solve(n, B2.shape[1], _ptr(A), _ptr(B2), _ptr(X))
-    return X.reshape(B.shape), bool(ok)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -16,6 +16,19 @@ def load_api():
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
+    load_oracle_api().attach(mod)     # the checker: Oracle, oracle_solve_batch, ... on the same namespace
+    return mod
+
+
+def load_oracle_api():
+    """Import oracle/oracle_api.py -- test infrastructure, never loaded by the product package."""
+    name = "cddp_oracle_api"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "oracle", "oracle_api.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
     return mod
 
 

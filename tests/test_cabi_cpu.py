@@ -91,7 +91,7 @@ def test_product_sources_do_not_reference_oracle():
         if "build" in dp or "__pycache__" in dp:
             continue
         for fn in fns:
-            if not fn.endswith((".hip", ".hpp", ".h", ".cpp", "Makefile")):
+            if not fn.endswith((".hip", ".hpp", ".h", ".cpp", ".py", "Makefile")):
                 continue
             txt = open(os.path.join(dp, fn), errors="ignore").read()
             assert "oracle/" not in txt and "cddp_oracle" not in txt, os.path.join(dp, fn)

@@ -40,6 +40,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     api = _load("cddp_cpp_amd_pyapi", "cddp-cpp_amd/pyapi.py")
+    _load("cddp_oracle_api", "oracle/oracle_api.py").attach(api)
     sh = _load("cddp_sharding", "cddp-cpp_amd/sharding.py")
     p = api.pendulum_problem(api.SOLVER_IPDDP, True, horizon=40)
     B = 8
@@ -57,6 +58,7 @@ def _worker(rank, world, port, q):
 def test_two_rank_gloo_allgather_matches_single_process():
     import torch.multiprocessing as mp
     api = _load("cddp_cpp_amd_pyapi", "cddp-cpp_amd/pyapi.py")
+    _load("cddp_oracle_api", "oracle/oracle_api.py").attach(api)
     sh = _load("cddp_sharding", "cddp-cpp_amd/sharding.py")
     if not os.path.exists(api.ORACLE_LIB_PATH):
         import subprocess
