@@ -835,11 +835,33 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // (outer loops stay rolled and write to LDS: fully unrolled, the 3 nx^2-term products keep hundreds of LDS
       //  operands live and spill)
       double T2c[NU], Qu[NU];
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) { double s = 0.0;
+      // (rows in groups of four, the operands of group g + 1 fetched from LDS before group g is reduced: one LDS
+      //  round trip is covered by 4 nx multiply-adds instead of being waited for group by group)
+      {
+        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR;
+        double b0[GR * NX], b1[GR * NX];
+        auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
-        for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
-        Ls[C::oM + i * NX + qc] = s; }
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) buf[r * NX + k] = La[k * NX + i]; } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * NX]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) { double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) s += buf[r * NX + k] * Vc[k];
+            Ls[C::oM + i * NX + qc] = s; } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
@@ -861,11 +883,31 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // ---- round 2: Q_xx[i, qc] replaces T1[i, qc] in place (row i of T1 is dead once every lane has used it,
       // and the lanes of a wavefront run this loop in lockstep)
       double Quxc[NU], Quu[NU * NU];
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) { double s = 0.0;
+      {
+        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR;
+        double b0[GR * NX], b1[GR * NX];
+        auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
-        Ls[C::oM + i * NX + qc] = (2.0 * ldsQ[i * NX + qc]) + s; }
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) buf[r * NX + j] = Ls[C::oM + i * NX + j]; } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * NX]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) { double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) s += buf[r * NX + j] * Aq[j];
+            Ls[C::oM + i * NX + qc] = (2.0 * ldsQ[i * NX + qc]) + s; } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
