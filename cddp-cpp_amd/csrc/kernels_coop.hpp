@@ -997,16 +997,35 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxq[j] * kk[j]; c += KtQq[j] * kk[j]; }
         Vxq = ((Qxq + a) + bb) + c;
       }
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place
-        double a = 0.0, bb = 0.0, e = 0.0;
+      {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place; row groups pipelined as in rounds 1 and 2
+        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR, RW3 = 3 * NU + 2;
+        double b0[GR * RW3], b1[GR * RW3];
+        auto ldg = [&](const int g, double (&buf)[GR * RW3]) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          a += Ls[C::oKK + j * NX + i] * Quxq[j]; bb += Ls[C::oQux + j * NX + i] * KKc[j]; e += Ls[C::oKtQ + i * NU + j] * KKc[j];
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { buf[r * RW3 + j] = Ls[C::oKK + j * NX + i]; buf[r * RW3 + NU + j] = Ls[C::oQux + j * NX + i]; buf[r * RW3 + 2 * NU + j] = Ls[C::oKtQ + i * NU + j]; }
+            buf[r * RW3 + 3 * NU] = Ls[C::oM + i * NX + qc];
+            if constexpr (Cons::HAS_X) buf[r * RW3 + 3 * NU + 1] = Ls[C::oWx + i * NX + qc]; } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * RW3]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+            double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { a += buf[r * RW3 + j] * Quxq[j]; bb += buf[r * RW3 + NU + j] * KKc[j]; e += buf[r * RW3 + 2 * NU + j] * KKc[j]; }
+            double qxx = buf[r * RW3 + 3 * NU];
+            if constexpr (Cons::HAS_X) qxx += buf[r * RW3 + 3 * NU + 1];
+            Ls[C::oM + i * NX + qc] = ((qxx + a) + bb) + e; } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        double qxx = Ls[C::oM + i * NX + qc];
-        if constexpr (Cons::HAS_X) qxx += Ls[C::oWx + i * NX + qc];
-        Ls[C::oM + i * NX + qc] = ((qxx + a) + bb) + e;
       }
       Ls[C::oVx + qc] = Vxq;
       storeAB((t & 1) ^ 1, nab);     // next step's A, B into the other LDS buffer
