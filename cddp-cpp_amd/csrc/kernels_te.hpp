@@ -356,11 +356,34 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
       for (int j = 0; j < NX; ++j) Aq[j] = La[j * NX + qc];
       // round 1: column qc of T1 = A^T P and of BtP = B^T P
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) { double s = 0.0;
+      {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RWP = NX;
+        double b0[GR * RWP], b1[GR * RWP];
+        auto ldg = [&](const int g, double (&buf)[GR * RWP]) {
 #pragma unroll
-        for (int k = 0; k < NX; ++k) s += La[k * NX + i] * Vc[k];
-        Ls[C::oM + i * NX + qc] = s; }
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) buf[r * RWP + k] = La[k * NX + i];
+          } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * RWP]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) s += buf[r * RWP + k] * Vc[k];
+            Ls[C::oM + i * NX + qc] = s;
+          } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
@@ -368,11 +391,34 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         Ls[C::oT2 + u * NX + qc] = s; }
       lds_sync();
       // round 2a: Q + A^T P A (in place over T1, row by row), Q_ux column; the entries of Q_uu spread over the lanes
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) { double s = 0.0;
+      {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RWP = NX;
+        double b0[GR * RWP], b1[GR * RWP];
+        auto ldg = [&](const int g, double (&buf)[GR * RWP]) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += Ls[C::oM + i * NX + j] * Aq[j];
-        Ls[C::oM + i * NX + qc] = ldsQ[i * NX + qc] + s; }
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) buf[r * RWP + j] = Ls[C::oM + i * NX + j];
+          } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * RWP]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) s += buf[r * RWP + j] * Aq[j];
+            Ls[C::oM + i * NX + qc] = ldsQ[i * NX + qc] + s;
+          } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       double Quxq[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
@@ -475,12 +521,34 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int i = 0; i < NX; ++i) tep[(((size_t)t * Bp + b) * NX + i) * VP + v] = pv[i];
       }
       // round 3: P_t column (in place over the lane's own Q + A^T P A column)
-#pragma unroll 4
-      for (int i = 0; i < NX; ++i) {
-        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RWP = 3 * NU + 1;
+        double b0[GR * RWP], b1[GR * RWP];
+        auto ldg = [&](const int g, double (&buf)[GR * RWP]) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) { a1 += Ls[C::oQux + j * NX + i] * KKc[j]; a2 += Ls[C::oKK + j * NX + i] * Quxq[j]; a3 += Ls[C::oKtQ + i * NU + j] * KKc[j]; }
-        Ls[C::oM + i * NX + qc] = ((Ls[C::oM + i * NX + qc] + a1) + a2) + a3;
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { buf[r * RWP + j] = Ls[C::oQux + j * NX + i]; buf[r * RWP + NU + j] = Ls[C::oKK + j * NX + i]; buf[r * RWP + 2 * NU + j] = Ls[C::oKtQ + i * NU + j]; }
+            buf[r * RWP + 3 * NU] = Ls[C::oM + i * NX + qc];
+          } }
+        };
+        auto cmp = [&](const int g, const double (&buf)[GR * RWP]) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { a1 += buf[r * RWP + j] * KKc[j]; a2 += buf[r * RWP + NU + j] * Quxq[j]; a3 += buf[r * RWP + 2 * NU + j] * KKc[j]; }
+            Ls[C::oM + i * NX + qc] = ((buf[r * RWP + 3 * NU] + a1) + a2) + a3;
+          } }
+        };
+        ldg(0, b0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       storeAB((t & 1) ^ 1, nab);
       lds_sync();
