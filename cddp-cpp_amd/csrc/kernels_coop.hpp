@@ -835,10 +835,11 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // (outer loops stay rolled and write to LDS: fully unrolled, the 3 nx^2-term products keep hundreds of LDS
       //  operands live and spill)
       double T2c[NU], Qu[NU];
-      // (rows in groups of four, the operands of group g + 1 fetched from LDS before group g is reduced: one LDS
-      //  round trip is covered by 4 nx multiply-adds instead of being waited for group by group)
+      // (rows in pairs -- pairs measured best: 553 ms of sweep class at C4 against 565 / 607 / 1007 for groups of 3 / 4 / 6 --
+      //  the operands of group g + 1 fetched from LDS before group g is reduced: one LDS
+      //  round trip is covered by the multiply-adds of a group instead of being waited for group by group)
       {
-        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR;
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR;
         double b0[GR * NX], b1[GR * NX];
         auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // and the lanes of a wavefront run this loop in lockstep)
       double Quxc[NU], Quu[NU * NU];
       {
-        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR;
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR;
         double b0[GR * NX], b1[GR * NX];
         auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         Vxq = ((Qxq + a) + bb) + c;
       }
       {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place; row groups pipelined as in rounds 1 and 2
-        constexpr int GR = 4, NGRP = (NX + GR - 1) / GR, RW3 = 3 * NU + 2;
+        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RW3 = 3 * NU + 2;
         double b0[GR * RW3], b1[GR * RW3];
         auto ldg = [&](const int g, double (&buf)[GR * RW3]) {
 #pragma unroll
