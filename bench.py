@@ -109,6 +109,9 @@ def make_problem(api, workload, solver):
     return p, spread, desc
 
 
+DEFAULT_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 2048, "manip7": 4096}
+
+
 def cpu_baseline(api, p, x0, U0, budget_s=15.0):
     """Oracle (CPU restatement, kind 'port') timed on the host cores of this box on a bounded sample."""
     cores = os.cpu_count() or 1
@@ -144,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: the BASELINE config's per-GPU batch of the workload)")
     ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,7 +171,7 @@ def main():
 
     api = load_api()
     p, spread, desc = make_problem(api, args.workload, args.solver)
-    B = args.batch
+    B = args.batch if args.batch > 0 else DEFAULT_BATCH[args.workload]
     sh = load_module("cddp_sharding", "sharding.py")
     # one seeded global batch (seed = 20260928 + config_index); rank r owns the
     # contiguous block [r*B, (r+1)*B) -- weak scaling: B trajectories per GPU.

@@ -2,6 +2,7 @@
 // Host side only: descriptor flattening, device-buffer ownership, kernel sequencing
 // (the device-resident per-trajectory state machine lives in kernels.hpp).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,14 @@ static __global__ void k_gather_records(DevBuf d, cddp_hip_gather_record *out) {
   cddp_hip_gather_record r;
   r.final_objective = d.cost[b]; r.iterations = d.iter[b]; r.status = d.status[b];
   out[b] = r;
+}
+
+// CDDPOptions::max_cpu_time expired (cddp_solver_base.cpp:77-90): the check sits after ++iter and before the
+// backward pass, so every trajectory still running reports the iteration the check fired in.
+static __global__ void k_mark_cpu_time(DevBuf d) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B || d.phase[b] == PH_DONE) return;
+  d.iter[b] += 1; d.status[b] = CDDP_HIP_STATUS_MAX_CPU_TIME; d.phase[b] = PH_DONE;
 }
 
 }  // namespace cddp_dev
@@ -228,6 +237,7 @@ void cddp_hip_default_options(cddp_hip_options *o) {
   o->ipddp_jacobian_regularization_exponent = 0.25;
   o->barrier_mu_initial = 1.0; o->barrier_mu_min_value = 1e-10; o->barrier_mu_update_factor = 0.5;
   o->barrier_mu_update_power = 1.2; o->barrier_min_fraction_to_boundary = 0.99; o->barrier_strategy = CDDP_HIP_BARRIER_ADAPTIVE;
+  o->max_cpu_time = 0.0;
 }
 
 int cddp_hip_abi_version(void) { return CDDP_HIP_ABI_VERSION; }
@@ -464,8 +474,10 @@ int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *opt) {
   double al[CDDP_HIP_MAX_ALPHAS];
   const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);
   if (na != h->P.n_alphas) return fail(-3, "the line-search ladder size is fixed at create time (%d alphas, new options give %d)", h->P.n_alphas, na);
-  if (opt->max_iterations > h->P.opt.max_iterations && h->P.opt.return_iteration_info)
-    return fail(-3, "max_iterations cannot grow on a handle created with return_iteration_info (history capacity)");
+  if (opt->max_iterations + 1 > h->d.hist_cap && h->P.opt.return_iteration_info)
+    return fail(-3, "max_iterations cannot grow beyond %d on a handle created with return_iteration_info (history capacity)", h->d.hist_cap - 1);
+  if ((opt->return_iteration_info != 0) != (h->P.opt.return_iteration_info != 0))
+    return fail(-3, "return_iteration_info is fixed at create time (the history buffers are sized by cddp_hip_create)");
   h->P.opt = *opt;
   for (int i = 0; i < na; ++i) h->P.alphas[i] = al[i];
   h->P.ls_rule = opt->enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
@@ -509,6 +521,24 @@ int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) {
       HIPCHK(hipMemcpyAsync(dst[k] + (size_t)sl * d.planeM, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
+  return 0;
+}
+
+int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const double *reg) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->has_state) return fail(-1, "cddp_hip_set_barrier_state needs an initialised handle (call cddp_hip_initialize or cddp_hip_solve first)");
+  HIPCHK(hipSetDevice(h->device));
+  const DevBuf &d = h->d;
+  if (mu) {
+    if (h->P.solver != CDDP_HIP_SOLVER_IPDDP) return fail(-1, "cddp_hip_set_barrier_state: mu is an IPDDP quantity");
+    for (int b = 0; b < d.B; ++b) if (!(mu[b] > 0.0)) return fail(-2, "barrier parameter of trajectory %d must be positive (got %g)", b, mu[b]);
+    HIPCHK(hipMemcpyAsync(d.mu, mu, sizeof(double) * d.B, hipMemcpyHostToDevice, h->stream));
+  }
+  if (reg) {
+    for (int b = 0; b < d.B; ++b) if (!(reg[b] >= 0.0)) return fail(-2, "regularisation of trajectory %d must be non-negative (got %g)", b, reg[b]);
+    HIPCHK(hipMemcpyAsync(d.reg, reg, sizeof(double) * d.B, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -571,7 +601,7 @@ int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cdd
       cddp_hip_trial &t = trials[(size_t)b * n_alphas + a];
       const size_t i = (size_t)a * d.Bp + b;
       t.alpha = alphas[a]; t.alpha_pr = ap[i]; t.alpha_du = ad[i]; t.cost = c[i]; t.merit_function = mf[i];
-      t.theta = th[i]; t.inf_pr = ipr[i]; t.inf_comp = ic[i]; t.success = su[i]; t._pad = 0;
+      t.theta = th[i]; t.inf_pr = ipr[i]; t.inf_comp = ic[i]; t.success = (su[i] == 1) ? 1 : 0; t._pad = 0;   // 2 = non-finite costate (k_costate)
     }
   return 0;
 }
@@ -673,7 +703,17 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     }
   };
   if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
+  const auto wall0 = std::chrono::steady_clock::now();
   for (int it = 1; it <= max_it; ++it) {
+    if (P.opt.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (host clock, like the reference; the queue is drained first)
+      HIPCHK(hipStreamSynchronize(s));
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+      if (el > P.opt.max_cpu_time) {
+        hipLaunchKernelGGL(k_mark_cpu_time, dim3((d.B + 255) / 256), dim3(256), 0, s, d);
+        ++launches;
+        break;
+      }
+    }
     ++outer;
     const int last = (it == max_it) ? 1 : 0;
     two_stage_marks = !one_stage;
@@ -883,6 +923,8 @@ int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg) {
   if (reg) { int rc = fetch(h, d.reg, d.B, a); if (rc) return rc; for (int b = 0; b < d.B; ++b) reg[b] = a[b]; }
   return 0;
 }
+
+int cddp_hip_history_capacity(cddp_hip_handle *h) { return h ? h->d.hist_cap : -1; }
 
 int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts) {
   if (!h || !hist || !counts) return fail(-1, "null argument");

@@ -782,6 +782,38 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
   return true;
 }
 
+// computeScaledDualInfeasibility (ipddp_solver.cpp:2725-2776): max(v, max_t |G_x[t]^T y[t]|_inf) with G_x from the
+// X slot of the last backward pass (`xslot`) and Y from the current slot; v = the raw inf_du.
+template <class Model, class Cons>
+DEV double scaled_inf_du_v(const DevBuf &d, int b, int xslot, double v) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
+  const ProblemDev *P = d.P;
+  if (!P->opt.ipddp_check_state_stationarity || M == 0) return v;
+  if (!Cons::HAS_X) return dmax(v, 0.0);   // G_x == 0: every |G_x^T y| entry is exactly 0
+  const double *Xs = d.X + (size_t)xslot * d.planeX;
+  const double *Yc = d.Y + (size_t)d.cur[b] * d.planeM;
+  double ss = 0.0;
+  for (int t = 0; t < d.N; ++t) {
+    double x[NX], y[MM], Gx[MM * NX], Gu[MM * NU];
+    ld<NX>(Xs + GI(t, NX, 0), kLS, x);
+    ld<M>(Yc + GI(t, M, 0), kLS, y);
+    for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
+    for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
+    Cons::template jac<NX, NU>(P, x, Gx, Gu);
+    for (int c = 0; c < Cons::NSEG; ++c) {
+      const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      for (int j = 0; j < NX; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < dim; ++i) s += Gx[(off + i) * NX + j] * y[off + i];
+        ss = dmax(ss, fabs(s));
+      }
+    }
+  }
+  return dmax(v, ss);
+}
+template <class Model, class Cons>
+DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) { return scaled_inf_du_v<Model, Cons>(d, b, xslot, d.inf_du[b]); }
+
 // ================================================================================ K2 (IPDDP)
 // Unconstrained branch (ipddp_solver.cpp:1048-1118) when Cons::M == 0, path-constraint branch
 // (:1355-1568) otherwise; followed by the linear-policy rollout (:1511-1532) fused with
@@ -1131,11 +1163,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
   if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
   // checkEarlyConvergence (ipddp_solver.cpp:925-958)
   bool conv;
-  if (nobar) conv = (d.inf_pr[b] < o.tolerance && inf_du < o.tolerance);
+  const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+  if (nobar) conv = (d.inf_pr[b] < o.tolerance && sdu_early < o.tolerance);
   else {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
-    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
   }
   if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
   d.phase[b] = PH_FWD1;
@@ -1524,35 +1557,35 @@ DEV void filter_prune(const DevBuf &d, int b) {
   d.filt_n[b] = w;
 }
 
-// computeScaledDualInfeasibility (ipddp_solver.cpp:2725-2776): G_x from the X slot of the last
-// backward pass (`xslot`), Y from the current slot.
-template <class Model, class Cons>
-DEV double scaled_inf_du(const DevBuf &d, int b, int xslot) {
-  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
-  const ProblemDev *P = d.P;
-  double v = d.inf_du[b];
-  if (!P->opt.ipddp_check_state_stationarity || M == 0) return v;
-  if (!Cons::HAS_X) return dmax(v, 0.0);   // G_x == 0: every |G_x^T y| entry is exactly 0
-  const double *Xs = d.X + (size_t)xslot * d.planeX;
-  const double *Yc = d.Y + (size_t)d.cur[b] * d.planeM;
-  double ss = 0.0;
-  for (int t = 0; t < d.N; ++t) {
-    double x[NX], y[MM], Gx[MM * NX], Gu[MM * NU];
-    ld<NX>(Xs + GI(t, NX, 0), kLS, x);
-    ld<M>(Yc + GI(t, M, 0), kLS, y);
-    for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
-    for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
-    Cons::template jac<NX, NU>(P, x, Gx, Gu);
-    for (int c = 0; c < Cons::NSEG; ++c) {
-      const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+// Costate trial of ONE trial, every step, on the lane of trajectory b -- the arithmetic of k_costate (kernels_lean.hpp).
+// Only reached when the first-success rule has to move past a trial whose costate was not finite (k_costate stopped at
+// that trial, so the later candidates have no costate rows yet).  Returns false when this trial's costate is not finite either.
+template <int NX>
+DEV bool costate_trial_serial(const DevBuf &d, int b, int cur, int a) {
+  const size_t ti = (size_t)a * d.Bp + b;
+  const int slot = (a < cur) ? a : a + 1;   // trial_slot
+  const double a_pr = d.t_apr[ti];
+  bool finite = true;
+  for (int t = 0; t <= d.N; ++t) {
+    double xo[NX], lo[NX], vx[NX], xn[NX], lam[NX];
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+    ld<NX>(d.Lam + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, lo);
+    ld<NX>(d.Vx + GI(t, NX, 0), kLS, vx);
+    ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xn);
+    const double *vb = d.Vxx + GI(t, NX * NX, 0);
+    for (int i = 0; i < NX; ++i) {
+      double s = 0.0;
       for (int j = 0; j < NX; ++j) {
-        double s = 0.0;
-        for (int i = 0; i < dim; ++i) s += Gx[(off + i) * NX + j] * y[off + i];
-        ss = dmax(ss, fabs(s));
+        const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;   // upper triangle, as k_costate reads it
+        s += vb[(size_t)(lo_ * NX + hi_) * kLS] * (xn[j] - xo[j]);
       }
+      lam[i] = (lo[i] + a_pr * vx[i]) + s;
+      finite = finite && dfinite(lam[i]);
     }
+    if (!finite) return false;
+    st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
   }
-  return dmax(v, ss);
+  return true;
 }
 
 // ================================================================================ K5
@@ -1576,13 +1609,21 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
     const int lo = (stage == 1) ? 0 : 1;
     const int hi = (stage == 1) ? n1 : n_alphas;
     int win = -1;
+    // t_success: 0 failed, 1 passed, 2 passed every test but its costate trial is not finite (k_costate) = failed
     if (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) {
-      for (int a = lo; a < hi; ++a) if (d.t_success[(size_t)a * d.Bp + b]) { win = a; break; }
+      bool past_bad = false;   // k_costate stopped at a trial flagged 2: later candidates have no costate rows yet
+      for (int a = lo; a < hi; ++a) {
+        const int sc = d.t_success[(size_t)a * d.Bp + b];
+        if (sc == 0) continue;
+        if (sc == 2) { past_bad = ipddp; continue; }
+        if (past_bad && !costate_trial_serial<NXu>(d, b, d.cur[b], a)) continue;
+        win = a; break;
+      }
     } else {
       double best = INFINITY;
       for (int a = lo; a < hi; ++a) {
         const size_t ti = (size_t)a * d.Bp + b;
-        if (d.t_success[ti] && d.t_merit[ti] < best) { best = d.t_merit[ti]; win = a; }
+        if (d.t_success[ti] == 1 && d.t_merit[ti] < best) { best = d.t_merit[ti]; win = a; }
       }
     }
     if (win < 0 && hi < n_alphas) { d.phase[b] = PH_FWD2; goto count; }   // more alphas to try
@@ -1594,7 +1635,9 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
         const size_t ti = (size_t)win * d.Bp + b;
         const int old_cur = d.cur[b];
         const double dJ = d.cost[b] - d.t_cost[ti];
-        d.n_fwd[b] += win + 1;
+        // rollouts the reference runs to get here: the first-success rule stops at the winner, the best-merit rule
+        // (one std::async per alpha, cddp_solver_base.cpp:264-286) always evaluates the whole ladder
+        d.n_fwd[b] += (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
         d.cur[b] = trial_slot(old_cur, win);
         d.cost[b] = d.t_cost[ti];
         d.merit[b] = d.t_merit[ti];

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
   if (ok) {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
-    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
     if (!conv || force) {
       // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}
       double dx[NX];
@@ -1059,7 +1060,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   if (ok) {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
-    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
     if (!conv || force) {
       // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}
       double dx[NX];

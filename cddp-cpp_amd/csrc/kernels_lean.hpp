@@ -336,7 +336,8 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
     // checkEarlyConvergence (ipddp_solver.cpp:925-958), barrier problem
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
-    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
     if (!conv || force) {
       // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): dX stack for K3
       double dx[NX];
@@ -512,8 +513,13 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
       lam[i] = (lo[i] + a_pr * vx[i]) + s;
       finite = finite && dfinite(lam[i]);
     }
-    if (!finite) { d.t_success[ti] = 0; continue; }
-    st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
+    // A non-finite costate fails the trial (ipddp_solver.cpp:1613-1616).  The flag value 2 ("passed every other
+    // test, costate not finite") is the ONLY mutation of t_success in this grid-wide kernel and is still non-zero:
+    // the blocks of the other steps pick the same trial whether or not they have seen it, so the launch is free of
+    // ordering effects; k_update treats 2 as a failed trial and evaluates the costate of the next candidate itself
+    // (costate_trial_serial) when the first-success rule stopped this kernel at the failed one.
+    if (!finite) d.t_success[ti] = 2;
+    else st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
     if (first_only) break;
   }
 }

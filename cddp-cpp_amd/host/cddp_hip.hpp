@@ -72,7 +72,7 @@ struct CDDPOptions {
 
   cddp_hip_options toPOD() const {
     cddp_hip_options o; cddp_hip_default_options(&o);
-    o.tolerance = tolerance; o.acceptable_tolerance = acceptable_tolerance; o.max_iterations = max_iterations;
+    o.tolerance = tolerance; o.acceptable_tolerance = acceptable_tolerance; o.max_iterations = max_iterations; o.max_cpu_time = max_cpu_time;
     o.use_ilqr = use_ilqr; o.enable_parallel = enable_parallel; o.return_iteration_info = return_iteration_info; o.warm_start = warm_start;
     o.termination_scaling_max_factor = termination_scaling_max_factor;
     o.ls_max_iterations = line_search.max_iterations; o.ls_initial_step_size = line_search.initial_step_size;

@@ -65,6 +65,7 @@ class Options(C.Structure):
         ("barrier_mu_update_factor", C.c_double), ("barrier_mu_update_power", C.c_double),
         ("barrier_min_fraction_to_boundary", C.c_double),
         ("barrier_strategy", C.c_int32), ("_pad3", C.c_int32),
+        ("max_cpu_time", C.c_double),
     ]
 
 
@@ -92,6 +93,7 @@ def default_options():
     o.ipddp_jacobian_regularization_value = 1e-8; o.ipddp_jacobian_regularization_exponent = 0.25
     o.barrier_mu_initial = 1.0; o.barrier_mu_min_value = 1e-10; o.barrier_mu_update_factor = 0.5
     o.barrier_mu_update_power = 1.2; o.barrier_min_fraction_to_boundary = 0.99; o.barrier_strategy = 0
+    o.max_cpu_time = 0.0
     return o
 
 
@@ -427,7 +429,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
-    "cddp_hip_set_timing_detail",
+    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state",
     "cddp_hip_backward_stacks", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
@@ -493,6 +495,11 @@ class HipBatchSolver:
         S = _arr(S) if S is not None else None; Y = _arr(Y) if Y is not None else None
         self._check(self.lib.cddp_hip_set_duals(self.h, _ptr(S), _ptr(Y)))
 
+    def set_barrier_state(self, mu=None, reg=None):
+        mu = _arr(mu).reshape(self.B) if mu is not None else None
+        reg = _arr(reg).reshape(self.B) if reg is not None else None
+        self._check(self.lib.cddp_hip_set_barrier_state(self.h, _ptr(mu), _ptr(reg)))
+
     def set_terminal_state(self, S_T=None, Y_T=None, Lambda_T=None):
         a = [(_arr(v) if v is not None else None) for v in (S_T, Y_T, Lambda_T)]
         self._check(self.lib.cddp_hip_set_terminal(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])))
@@ -552,7 +559,7 @@ class HipBatchSolver:
         return dV, reg
 
     def history(self, hist_batch=1):
-        cap = self.p.options.max_iterations + 1
+        cap = self.lib.cddp_hip_history_capacity(self.h)   # fixed at create time (set_options may lower max_iterations)
         h = np.zeros((hist_batch, cap, 9)); cnt = np.zeros(hist_batch, dtype=np.int32)
         self._check(self.lib.cddp_hip_get_history(self.h, hist_batch, _ptr(h), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
         return [h[b, :cnt[b]].copy() for b in range(hist_batch)]

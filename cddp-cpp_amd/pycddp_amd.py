@@ -104,7 +104,7 @@ class CDDPOptions:                  # options.hpp:41-251 / bind_options.cpp:96-1
     def to_pod(self):
         o = _api().default_options()
         o.tolerance = self.tolerance; o.acceptable_tolerance = self.acceptable_tolerance
-        o.max_iterations = int(self.max_iterations); o.use_ilqr = 1 if self.use_ilqr else 0
+        o.max_iterations = int(self.max_iterations); o.max_cpu_time = float(self.max_cpu_time); o.use_ilqr = 1 if self.use_ilqr else 0
         o.enable_parallel = 1 if self.enable_parallel else 0
         o.return_iteration_info = 1 if self.return_iteration_info else 0; o.warm_start = 1 if self.warm_start else 0
         o.termination_scaling_max_factor = self.termination_scaling_max_factor

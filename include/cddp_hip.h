@@ -149,6 +149,10 @@ typedef struct cddp_hip_options {
   double barrier_min_fraction_to_boundary; /* 0.99 */
   int32_t barrier_strategy;           /* CDDP_HIP_BARRIER_ADAPTIVE */
   int32_t _pad3;
+  /* CDDPOptions::max_cpu_time [s], 0 = unlimited (options.hpp:212; checked at the top of every iteration,
+   * cddp_solver_base.cpp:77-90).  One clock for the batch: when it expires, every trajectory still running
+   * terminates with "MaxCpuTimeReached" and iterations = the iteration the check fired in. */
+  double max_cpu_time;                /* 0 */
 } cddp_hip_options;
 
 /* Fill *opt with the reference defaults (options.hpp in-class initialisers). */
@@ -329,6 +333,12 @@ int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0);
  * and the hook for callers that shift duals between MPC solves. */
 int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y);
 int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T);
+/* Overwrite the per-trajectory barrier parameter mu_[b] (IPDDP; mu_ of ipddp_solver.hpp) and / or the
+ * regularisation context.regularization_[b] of an initialised handle (either may be NULL): with
+ * cddp_hip_set_initial + cddp_hip_set_duals this installs an arbitrary iterate (X, U, S, Y, mu, reg), e.g. a late
+ * iterate of another solve, for one cddp_hip_backward / cddp_hip_forward -- the role of the reference's
+ * IPDDPSolverTestAccess (tests/cddp_core/test_ipddp_solver.cpp:30-135). */
+int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const double *reg);
 
 /* One backwardPass for every trajectory (clddp_solver.cpp:79-204 / ipddp_solver.cpp:960-1569),
  * including the "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111.
@@ -363,8 +373,12 @@ int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *
 int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg);
 /* CDDPSolution::History for the first `hist_batch` trajectories (requires
  * options.return_iteration_info): hist[b][it][9] = {objective, merit, alpha_pr, alpha_du,
- * inf_du, inf_pr, inf_comp, mu, regularization}; counts[b] = entries. max_it = max_iterations+1. */
+ * inf_du, inf_pr, inf_comp, mu, regularization}; counts[b] = entries; the `it` extent of the block is
+ * cddp_hip_history_capacity(h) rows. */
 int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts);
+/* Rows per trajectory of the history block above: max_iterations + 1 of the options the handle was CREATED with
+ * (cddp_hip_set_options may lower max_iterations afterwards; the row stride does not follow). */
+int cddp_hip_history_capacity(cddp_hip_handle *h);
 
 /* Write the 16-byte gather records of this handle's batch into a DEVICE buffer
  * (batch * sizeof(cddp_hip_gather_record)), on the handle's stream: the send buffer of the

@@ -1328,8 +1328,13 @@ struct Solver {
   void solve() {  // cddp_solver_base.cpp:29-186
     recordHistory();
     int iter = 0; bool converged = false; int reason = CDDP_HIP_STATUS_MAX_ITERATIONS; double dJ = 0.0;
+    const auto start_time = std::chrono::steady_clock::now();
     while (iter < opt.max_iterations) {
       ++iter;
+      if (opt.max_cpu_time > 0) {  // cddp_solver_base.cpp:77-90
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - start_time).count();
+        if (el > opt.max_cpu_time) { reason = CDDP_HIP_STATUS_MAX_CPU_TIME; break; }
+      }
       bool backward_ok = false;
       while (!backward_ok) {
         backward_ok = backwardPass();
@@ -1561,6 +1566,8 @@ double cddp_oracle_filter_back_violation(void *o) { Solver *s = (Solver *)o; ret
 void cddp_oracle_update_barrier(void *o, int fp_success) { ((Solver *)o)->updateBarrierParameters(fp_success != 0); }
 double cddp_oracle_scaled_inf_du(void *o) { return ((Solver *)o)->computeScaledDualInfeasibility(); }
 double cddp_oracle_get_mu(void *o) { return ((Solver *)o)->mu; }
+// libm-noise knob of models.hpp (process-wide): 0 = off (default), 1 = sin / cos results moved by -1 / 0 / +1 ulp
+void cddp_oracle_set_trig_noise(int v) { oracle::trig_noise() = v; }
 void cddp_oracle_set_inf_du(void *o, double v) { ((Solver *)o)->inf_du = v; }
 void cddp_oracle_set_check_state_stationarity(void *o, int v) { ((Solver *)o)->opt.ipddp_check_state_stationarity = v; }
 

@@ -1,0 +1,128 @@
+"""Golden vectors from the numpy twin (oracle/twin/cddp_twin.py) -- run in the build container only:
+
+    python tests/golden/make_twin_golden.py            # writes tests/golden/twin_<case>.json
+
+The twin is the second, independently written restatement of the reference path; the C++ oracle
+and the HIP path are held against these files by tests/test_twin_golden.py.  Problem constants: the reference examples
+(examples/cddp_pendulum.cpp:24-65, cddp_cartpole.cpp:24-66, python_portfolio_lib.py:374-446) and the scalar-integrator
+regressions of tests/cddp_core/test_ipddp_solver.cpp:137-242, 1147-1637 -- the same problems cddp-cpp_amd/pyapi.py builds,
+restated here as plain dictionaries so that the twin shares no code with the product or the oracle.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "oracle", "twin"))
+import cddp_twin as T  # noqa: E402
+
+
+def _pendulum(solver, box, N=100, **opt):
+    o = dict(max_iterations=30, tolerance=1e-4, acceptable_tolerance=1e-5, reg_initial_value=1e-6); o.update(opt)
+    return dict(solver=solver, model=T.Pendulum(0.5, 1.0, 0.01), integrator="euler", dt=0.02, N=N, Q=np.zeros((2, 2)), R=0.1 * np.eye(1),
+                Qf=100.0 * np.eye(2), xref=[0.0, 0.0], constraints={"ControlConstraint": T.ControlBox([-20.0], [20.0])} if box else {},
+                options=o, x0=[math.pi, 0.0])
+
+
+def _cartpole(solver, box, N=100, integrator="rk4", **opt):
+    o = dict(max_iterations=80, tolerance=1e-6, acceptable_tolerance=1e-5, reg_initial_value=1e-5); o.update(opt)
+    return dict(solver=solver, model=T.CartPole(1.0, 0.2, 0.5, 9.81, 0.0), integrator=integrator, dt=0.05, N=N, Q=np.zeros((4, 4)), R=0.1 * np.eye(1),
+                Qf=100.0 * np.eye(4), xref=[0.0, math.pi, 0.0, 0.0], constraints={"ControlConstraint": T.ControlBox([-5.0], [5.0])} if box else {},
+                options=o, x0=[0.0, 0.0, 0.0, 0.0])
+
+
+def _unicycle(solver, ball, N=100, box_name="control_limits", **opt):
+    o = dict(max_iterations=100, tolerance=1e-4, acceptable_tolerance=1e-6); o.update(opt)
+    cons = {box_name: T.ControlBox([-1.1, -math.pi], [1.1, math.pi])}
+    if ball:
+        cons["obstacle"] = T.Ball(0.4, [1.0, 1.0])
+    return dict(solver=solver, model=T.Unicycle(), integrator="euler", dt=0.03, N=N, Q=np.zeros((3, 3)), R=0.05 * np.eye(2),
+                Qf=np.diag([100.0, 100.0, 50.0]), xref=[2.0, 2.0, math.pi / 2], constraints=cons, options=o,
+                x0=[0.0, 0.0, math.pi / 4], U0=np.tile([0.5, 0.1], (N, 1)))
+
+
+def _lti(N, x0, goal, R, Qf, cons=None, term=None, **opt):
+    o = dict(max_iterations=100, tolerance=1e-6, acceptable_tolerance=1e-6, reg_initial_value=1e-6, mu_initial=1e-1); o.update(opt)
+    return dict(solver="IPDDP", model=T.LTI(np.eye(1), np.eye(1), 1.0), integrator="euler", dt=1.0, N=N, Q=np.zeros((1, 1)), R=R * np.eye(1),
+                Qf=Qf * np.eye(1), xref=[goal], constraints=cons or {}, terminal=term or {}, options=o, x0=[x0])
+
+
+CASES = {
+    # name -> (twin spec builder, pyapi case name of tests/test_gpu_parity.py::make / TERM_CASES)
+    "pendulum_ipddp_unc": lambda: _pendulum("IPDDP", False),
+    "pendulum_ipddp_box": lambda: _pendulum("IPDDP", True),
+    "pendulum_clddp_unc": lambda: _pendulum("CLDDP", False),
+    "pendulum_clddp_box": lambda: _pendulum("CLDDP", True),
+    "cartpole_ipddp_unc": lambda: _cartpole("IPDDP", False),
+    "cartpole_ipddp_box": lambda: _cartpole("IPDDP", True),
+    "cartpole_clddp_unc": lambda: _cartpole("CLDDP", False),
+    "cartpole_clddp_box": lambda: _cartpole("CLDDP", True),
+    "unicycle_ipddp_box": lambda: _unicycle("IPDDP", False),
+    "unicycle_ipddp_box_ball": lambda: _unicycle("IPDDP", True),
+    "unicycle_clddp_box": lambda: _unicycle("CLDDP", False, box_name="ControlConstraint"),
+    # scalar-integrator regressions (tests/cddp_core/test_ipddp_solver.cpp)
+    "term_ineq_only": lambda: _lti(8, 0.0, 1.0, 1e-2, 100.0, term={"TerminalUpperBound": ("ineq", np.eye(1), np.zeros(1))}, max_iterations=60),
+    "term_eq_only": lambda: _lti(8, 1.0, 0.0, 1e-2, 1.0, term={"TerminalTarget": ("eq", [0.0])}, mu_initial=1.0),
+    "path_term_eq": lambda: _lti(8, 1.0, 0.0, 1e-2, 0.0, cons={"LoosePathUpperBound": T.Linear(np.eye(1), [10.0])},
+                                 term={"TerminalTarget": ("eq", [0.0])}),
+    "path_term_ineq": lambda: _lti(4, 1.0, 0.0, 1e-2, 1.0, cons={"PathUpperBound": T.Linear(np.eye(1), [0.25])},
+                                   term={"TerminalUpperBound": ("ineq", np.eye(1), [0.25])}, max_iterations=20),
+    "pendulum_term_eq": lambda: dict(_pendulum("IPDDP", True, N=60), terminal={"TerminalTarget": ("eq", [0.0, 0.0])}),
+}
+
+
+def run_case(name, with_solve=True):
+    spec = CASES[name]()
+    tw = T.Twin(spec)
+    x0 = np.array(spec["x0"], float)
+    U0 = spec.get("U0")
+    tw.set_initial(x0, U0)
+    tw.initialize()
+    tw.X_lin, tw.U_lin = tw.X, tw.U
+    out = {"case": name, "nx": tw.nx, "nu": tw.nu, "N": tw.N, "m": tw.m, "alphas": list(tw.alphas)}
+    out["init"] = {"cost": tw.cost, "merit": tw.merit if math.isfinite(tw.merit) else None}
+    ok = False; reg_tries = 0
+    while not ok:
+        ok = tw.backward()
+        if not ok:
+            tw.reg_up(); reg_tries += 1
+            if tw.reg_limit():
+                break
+    N = tw.N
+    ts = sorted(set([0, N // 2, N - 1]))
+    out["sweep"] = {"ok": bool(ok), "reg": tw.reg, "t": ts, "K": [tw.K_u[t].tolist() for t in ts], "k": [tw.k_u[t].tolist() for t in ts],
+                    "Vx": [tw.Vx[t].tolist() for t in ts], "Vxx": [tw.Vxx[t].tolist() for t in ts], "dV": tw.dV.tolist(),
+                    "inf_du": tw.inf_du, "inf_pr": tw.inf_pr if math.isfinite(tw.inf_pr) else None,
+                    "inf_comp": tw.inf_comp if math.isfinite(tw.inf_comp) else None, "step_norm": tw.step_norm,
+                    "K_sum": float(np.sum(tw.K_u)), "Vxx_sum": float(np.sum(tw.Vxx))}
+    trials = []
+    for a in tw.alphas:
+        r = tw.forward(a)
+        trials.append({"alpha": a, "success": bool(r["success"]), "alpha_pr": r["alpha_pr"], "alpha_du": r.get("alpha_du", 1.0),
+                       "cost": r["cost"] if math.isfinite(r["cost"]) else None, "merit": r["merit"] if math.isfinite(r["merit"]) else None,
+                       "theta": r.get("theta")})
+    out["trials"] = trials
+    if with_solve:
+        tw2 = T.Twin(CASES[name]())
+        tw2.set_initial(x0, U0)
+        res = tw2.solve()
+        hist = np.array(tw2.history)
+        hist = np.where(np.isfinite(hist), hist, -1.0)     # +inf entries of the CLDDP row 0 -> -1 marker
+        out["solve"] = {"iterations": res["iterations"], "status": res["status"], "final_objective": res["final_objective"],
+                        "n_backward": res["n_backward"], "n_forward": res["n_forward"], "history": hist.tolist(),
+                        "U_first": tw2.U[0].tolist(), "U_last": tw2.U[-1].tolist(), "xN": tw2.X[-1].tolist(),
+                        "K0": tw2.K_u[0].tolist()}
+    return out
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        o = run_case(name)
+        with open(os.path.join(HERE, "twin_%s.json" % name), "w") as f:
+            json.dump(o, f)
+        print(name, "sweep ok", o["sweep"]["ok"], "solve", o["solve"]["iterations"], T.STATUS[o["solve"]["status"]], o["solve"]["final_objective"])

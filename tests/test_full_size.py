@@ -41,3 +41,124 @@ def test_full_batch_equals_sub_batches_and_oracle(api, config, oracle_built):
         assert ro["iterations"] == r["iterations"][b] and ro["status"] == r["status"][b]
         if ro["status"] in (api.STATUS_OPTIMAL, api.STATUS_ACCEPTABLE):
             assert abs(ro["final_objective"] - r["final_objective"][b]) <= 1e-6 * max(1.0, abs(ro["final_objective"]))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Round 2: the benchmarked batches themselves, whole-batch oracle comparison
+# ----------------------------------------------------------------------------------------------------------------
+import json
+import os
+
+BENCH_SEED = 20260928 + 1      # bench.py: api.batch_x0(p, B * world, 20260928 + 1, spread)
+REPORT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _report(name, obj):
+    try:
+        os.makedirs(REPORT_DIR, exist_ok=True)
+        with open(os.path.join(REPORT_DIR, "parity_report_%s.json" % name), "w") as f:
+            json.dump(obj, f)
+    except OSError:
+        pass
+    print("[parity-report] %s %s" % (name, json.dumps(obj)))
+
+
+def _bench_problem(api, workload):
+    """The problem / spread table of bench.py::make_problem (kept in step by test_bench_inputs_match below)."""
+    if workload == "cartpole":
+        return api.cartpole_problem(api.SOLVER_IPDDP, True), [0.1, 0.3, 0.1, 0.1], 4096
+    if workload == "cartpole_clddp":
+        return api.cartpole_problem(api.SOLVER_CLDDP, True), [0.1, 0.3, 0.1, 0.1], 4096
+    if workload == "unicycle":
+        return api.unicycle_problem(api.SOLVER_IPDDP, 200, True), [0.05, 0.05, 0.05], 8192
+    if workload == "quadrotor":
+        return api.quadrotor12_problem(api.SOLVER_IPDDP, 400, True), [0.02] * 12, 2048
+    if workload == "manip7":
+        return api.manipulator7_problem(api.SOLVER_IPDDP, 150, True, 16), [0.02] * 14, 4096
+    raise KeyError(workload)
+
+
+def test_bench_inputs_match(api):
+    """bench.py and this file must describe the same batches (same builder, spread, per-GPU batch)."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cddp_bench_module", os.path.join(repo, "bench.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    for wl, solver in (("cartpole", "ipddp"), ("unicycle", "ipddp"), ("quadrotor", "ipddp"), ("manip7", "ipddp")):
+        pb, sb, _ = mod.make_problem(api, wl, solver)
+        pt, st, B = _bench_problem(api, wl)
+        assert list(sb) == list(st) and (pb.nx, pb.nu, pb.N) == (pt.nx, pt.nu, pt.N)
+        assert np.array_equal(api.batch_x0(pb, 8, BENCH_SEED, sb), api.batch_x0(pt, 8, BENCH_SEED, st))
+        assert mod.DEFAULT_BATCH[wl] == B
+
+
+# Allowed fraction of trajectories whose (status, iterations, n_backward, n_forward) or objective (1e-7) differ from
+# the oracle's on the WHOLE benchmarked batch.  C2 / C3: no sin / cos knife edge in the accept / reject path of the
+# pendulum-class plants was observed; the bound is the measured rate on MI355X (profiles/r02_parity_report.md)
+# with head-room.  Solves that run into the iteration cap are chaotic in their rounding, so late line-search
+# decisions may differ; status + iteration count must still agree for at least (1 - COUNT_MISMATCH_MAX).
+WHOLE_BATCH = {"cartpole": (0.02, 0.25), "cartpole_clddp": (0.02, 0.25), "unicycle": (0.02, 0.25)}
+
+
+@pytest.mark.parametrize("workload", list(WHOLE_BATCH))
+def test_whole_bench_batch_against_oracle(api, oracle_built, workload):
+    """Every trajectory of the benchmarked batch (bench.py's own x0: spread, seed, size) against the oracle."""
+    count_mismatch_max, strict_mismatch_max = WHOLE_BATCH[workload]
+    p, spread, B = _bench_problem(api, workload)
+    x0 = api.batch_x0(p, B, BENCH_SEED, spread)
+    U0 = api.batch_U0(p, B)
+    r, X, U, K, k = _solve(api, p, x0, U0)
+    ores, _, _, _, ms = api.oracle_solve_batch(p, x0, U0, n_threads=os.cpu_count() or 8, want_traj=False)
+    same_counts = (r["iterations"] == ores["iterations"]) & (r["status"] == ores["status"])
+    same_work = same_counts & (r["n_backward"] == ores["n_backward"]) & (r["n_forward"] == ores["n_forward"])
+    obj_close = np.abs(r["final_objective"] - ores["final_objective"]) <= 1e-7 * np.maximum(1.0, np.abs(ores["final_objective"]))
+    strict = same_work & obj_close
+    conv = (ores["status"] == api.STATUS_OPTIMAL) | (ores["status"] == api.STATUS_ACCEPTABLE)
+    rep = {"B": B, "count_mismatch_frac": float(1.0 - same_counts.mean()), "work_mismatch_frac": float(1.0 - same_work.mean()),
+           "strict_mismatch_frac": float(1.0 - strict.mean()), "converged_oracle": int(conv.sum()),
+           "converged_strict": int((conv & strict).sum()), "oracle_ms": float(ms),
+           "status_hist_hip": {str(int(s)): int(c) for s, c in zip(*np.unique(r["status"], return_counts=True))},
+           "status_hist_oracle": {str(int(s)): int(c) for s, c in zip(*np.unique(ores["status"], return_counts=True))}}
+    _report("whole_" + workload, rep)
+    assert rep["count_mismatch_frac"] <= count_mismatch_max, rep
+    assert rep["strict_mismatch_frac"] <= strict_mismatch_max, rep
+    assert strict[0], "trajectory 0 (the unperturbed reference example) must match strictly"
+
+
+# BASELINE configs 4 and 5 at their per-GPU batch (16384 / 8 = 2048, 32768 / 8 = 4096), N = 400 / 150: the size
+# independent property (a trajectory's solve inside the full batch == its solve inside a small batch, bit for bit)
+# plus N_ORACLE trajectories against the oracle.  Both plants are knife-edge cases (sin / cos + binding caps, see
+# tests/test_gpu_parity.py): the agreement is measured and bounded, not assumed.
+BIG = {"quadrotor": (16, 8), "manip7": (16, 8)}     # workload -> (oracle-checked trajectories, min agreeing in status+iterations)
+
+
+@pytest.mark.parametrize("workload", list(BIG))
+def test_c4_c5_full_size_against_oracle(api, oracle_built, workload):
+    n_oracle, min_agree = BIG[workload]
+    p, spread, B = _bench_problem(api, workload)
+    x0 = api.batch_x0(p, B, BENCH_SEED, spread)
+    U0 = api.batch_U0(p, B)
+    r, X, U, K, k = _solve(api, p, x0, U0)
+    assert np.all(np.isfinite(r["final_objective"])) and r["iterations"].min() >= 1
+    idx = np.array([0, 1, 63, 64, 65, B // 2 - 1, B // 2, B - 65, B - 2, B - 1] + list(range(200, 200 + 22)))
+    rs, Xs, Us, Ks, ks = _solve(api, p, np.ascontiguousarray(x0[idx]), None if U0 is None else np.ascontiguousarray(U0[idx]))
+    for key in ("final_objective", "iterations", "status", "n_backward", "n_forward"):
+        assert np.array_equal(r[key][idx], rs[key]), key
+    assert np.array_equal(X[idx], Xs) and np.array_equal(U[idx], Us) and np.array_equal(K[idx], Ks) and np.array_equal(k[idx], ks)
+    oi = idx[:n_oracle]
+    ores, _, _, _, ms = api.oracle_solve_batch(p, np.ascontiguousarray(x0[oi]), None if U0 is None else np.ascontiguousarray(U0[oi]),
+                                               n_threads=min(n_oracle, os.cpu_count() or 8), want_traj=False)
+    same_counts = (r["iterations"][oi] == ores["iterations"]) & (r["status"][oi] == ores["status"])
+    same_work = same_counts & (r["n_backward"][oi] == ores["n_backward"]) & (r["n_forward"][oi] == ores["n_forward"])
+    rel = np.abs(r["final_objective"][oi] - ores["final_objective"]) / np.maximum(1.0, np.abs(ores["final_objective"]))
+    rep = {"B": B, "n_oracle": int(n_oracle), "same_counts": int(same_counts.sum()), "same_work": int(same_work.sum()),
+           "objective_rel_err": [float(v) for v in rel], "iterations_hip": [int(v) for v in r["iterations"][oi]],
+           "iterations_oracle": [int(v) for v in ores["iterations"]], "status_hip": [int(v) for v in r["status"][oi]],
+           "status_oracle": [int(v) for v in ores["status"]], "n_forward_hip": [int(v) for v in r["n_forward"][oi]],
+           "n_forward_oracle": [int(v) for v in ores["n_forward"]], "oracle_ms": float(ms)}
+    _report("full_" + workload, rep)
+    assert same_counts.sum() >= min_agree, rep
+    # (solves that stop on the iteration cap are chaotic in their rounding: the objective of such a trajectory is
+    #  compared at 1e-4, that of a converged one at 1e-7)
+    conv0 = ores["status"][0] in (api.STATUS_OPTIMAL, api.STATUS_ACCEPTABLE)
+    assert same_counts[0] and rel[0] < (1e-7 if conv0 else 1e-4), "trajectory 0 (unperturbed) must agree"
