@@ -232,7 +232,10 @@ def main():
     upd_ms = float(prof.update_ms)
     solve_ms = float(np.mean([s.solve_ms for s in stats]))
     bytes_bwd = b_fill * st.traj_iterations + b_bwd * st.sweeps
-    bytes_fwd = b_fwd * st.rollouts
+    # exact credit: the steps the walked trials actually traversed (a trial the reference abandons at its first
+    # fraction-to-boundary violation, ipddp_solver.cpp:1632-1645, is credited the steps completed before it, not N)
+    bytes_fwd = (b_fwd / p.N) * st.rollout_steps
+    bytes_fwd_full_rollouts = b_fwd * st.rollouts   # round-1 accounting (every walked trial credited N steps), for comparison
     gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
     gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
@@ -270,8 +273,12 @@ def main():
         "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": dom[3] / n_launch, "avg_launch_ms": dom[2] / n_launch,
         "launches": n_launch,
-        "algorithmic_bytes_note": "SURVEY 8(d) bytes per rollout x ACCEPTED-PATH rollouts only (first-success ladder as the reference walks it); "
-                                  "the speculative trials of the other alphas are executed but not credited",
+        "algorithmic_bytes_note": "SURVEY 8(d) bytes per rollout STEP x the steps the reference's line search traverses: the trials the "
+                                  "selection rule walks (first-success: up to the winner; best-merit: the whole ladder), each credited the steps "
+                                  "completed before it is abandoned (fraction-to-boundary violation), N if it runs through; speculative trials "
+                                  "of other alphas are executed but not credited",
+        "rollout_steps_credited": int(st.rollout_steps), "rollout_steps_if_full": int(st.rollouts) * int(p.N),
+        "frac_with_full_rollout_credit_r01": (bytes_fwd_full_rollouts / (fwd_ms * 1e-3) / 1e9 / PEAK) if fwd_ms > 0 else None,
         "timing": "hipEvents on the solver's stream around the dominant class's launches inside the timed steps; "
                   "the other classes from one untimed solve with every class bracketed (whole_solve_all_classes_ms)",
         "classes": {
@@ -296,7 +303,7 @@ def main():
                         ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
             "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": B * world, "nx": p.nx, "nu": p.nu,
             "horizon": p.N, "path_dual_dim": m, "max_iterations": int(p.options.max_iterations),
-            "line_search": "first-success rule, %d alphas" % int(p.options.ls_max_iterations),
+            "line_search": "%s rule, %d alphas" % ("best-merit (enable_parallel)" if p.options.enable_parallel else "first-success", int(p.options.ls_max_iterations)),
             "sharding": "independent trajectories, block partition, one RCCL all-gather of 16-B records per step",
         },
         "solve": {

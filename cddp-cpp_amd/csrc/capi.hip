@@ -44,6 +44,10 @@ int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
+}  // namespace
+extern "C" int cddp_hip_internal_set_error(int code, const char *msg) { g_err = msg ? msg : ""; return code; }   // comm.hip
+extern "C" int cddp_hip_internal_allgather(const void *send, void *recv, size_t bytes_per_rank, void *comm, void *stream);
+namespace {
 #define HIPCHK(expr)                                                                          \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                           \
       return fail(-10, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -60,7 +64,7 @@ const std::vector<KernelSet> &registry() {
 
 }  // namespace
 
-struct cddp_hip_handle {
+struct Inner {
   ProblemDev P;
   DevBuf d;
   const KernelSet *ks = nullptr;
@@ -79,14 +83,14 @@ struct cddp_hip_handle {
   size_t bytes = 0;
   int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
   std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll = nullptr;
   int *h_poll = nullptr;                         // pinned host words of the solve loop's poll: [0] running count, [1..] alpha histogram
 };
 
 namespace {
 
 template <class T>
-int dalloc(cddp_hip_handle *h, T **p, size_t n) {
+int dalloc(Inner *h, T **p, size_t n) {
   if (n == 0) n = 1;
   void *q = nullptr;
   HIPCHK(hipMalloc(&q, n * sizeof(T)));
@@ -203,14 +207,14 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   return 0;
 }
 
-int restore_initial(cddp_hip_handle *h) {
+int restore_initial(Inner *h) {
   if (!h->have_initial) return fail(-1, "cddp_hip_set_initial must be called before initialize/solve");
   HIPCHK(hipMemcpyAsync(h->d.X, h->d_Xinit, h->d.planeX * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d.U, h->d_Uinit, h->d.planeU * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
 
-int free_all(cddp_hip_handle *h) {
+int free_all(Inner *h) {
   for (void *q : h->allocs) hipFree(q);
   h->allocs.clear();
   return 0;
@@ -279,13 +283,13 @@ int cddp_hip_build_alphas(const cddp_hip_options *opt, double *alphas, int cap) 
   return n > cap ? cap : n;
 }
 
-int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp_hip_handle **out) {
+static int in_create(const cddp_hip_problem *problem, int batch, int device, Inner **out) {
   if (!problem || !out) return fail(-1, "null argument");
   if (batch <= 0) return fail(-1, "batch must be positive");
   int ndev = cddp_hip_device_count();
   if (ndev <= 0) return fail(-20, "no HIP device available: the cddp_hip solver core has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(-1, "device %d out of range (%d devices)", device, ndev);
-  cddp_hip_handle *h = new cddp_hip_handle();
+  Inner *h = new Inner();
   int rc = flatten(problem, h->P);
   if (rc) { delete h; return rc; }
   for (const KernelSet &k : registry()) if (k.matches(h->P)) { h->ks = &k; break; }
@@ -327,6 +331,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   double **tr[] = {&d.t_cost, &d.t_merit, &d.t_theta, &d.t_inf_pr, &d.t_inf_comp, &d.t_apr, &d.t_adu, &d.t_ysmin, &d.t_ysmax};
   for (double **sp : tr) DA(*sp, (size_t)d.n_alphas * Bp);
   DA(d.t_success, (size_t)d.n_alphas * Bp);
+  DA(d.t_steps, (size_t)d.n_alphas * Bp); DA(d.n_fwd_steps, Bp);
   if (ip && P.n_cons > 0) DA(d.ev, (size_t)d.n_alphas * N * 2 * P.n_cons * Bp);
   DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
   DA(d.hist_n, std::max(1, d.hist_batch));
@@ -367,20 +372,21 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   return 0;
 }
 
-int cddp_hip_destroy(cddp_hip_handle *h) {
+static int in_destroy(Inner *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   free_all(h);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->ev_begin) { hipEventDestroy(h->ev_begin); hipEventDestroy(h->ev_end); }
+  if (h->ev_poll) hipEventDestroy(h->ev_poll);
   if (h->h_poll) hipHostFree(h->h_poll);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
 
-int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail) {
+static int in_set_timing_detail(Inner *h, int detail) {
   if (!h) return fail(-1, "null handle");
   if (detail != CDDP_HIP_TIMING_ROLLOUT && detail != CDDP_HIP_TIMING_ALL && detail != CDDP_HIP_TIMING_SWEEP)
     return fail(-2, "unknown timing detail %d", detail);
@@ -388,7 +394,7 @@ int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail) {
   return 0;
 }
 
-int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream) {
+static int in_set_stream(Inner *h, void *hip_stream) {
   if (!h) return fail(-1, "null handle");
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
@@ -398,8 +404,8 @@ int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream) {
   return 0;
 }
 
-int cddp_hip_dual_dim(cddp_hip_handle *h) { return h ? h->P.m : -1; }
-int cddp_hip_batch(cddp_hip_handle *h) { return h ? h->d.B : -1; }
+static int in_dual_dim(Inner *h) { return h ? h->P.m : -1; }
+static int in_batch(Inner *h) { return h ? h->d.B : -1; }
 
 // host batch-major [b][t][e]  <->  device batch-minor [t][e][b]
 // wave-tiled stack index (dev_types.hpp): element e of step t of trajectory b
@@ -415,7 +421,7 @@ static void from_soa(const double *src, double *dst, int B, int Bp, int T, int E
       for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[tix(t, E, e, b, Bp)];
 }
 
-int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0, const double *X0) {
+static int in_set_initial(Inner *h, const double *x0, const double *U0, const double *X0) {
   if (!h || !x0) return fail(-1, "null argument");
   HIPCHK(hipSetDevice(h->device));
   const DevBuf &d = h->d;
@@ -442,7 +448,7 @@ int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0,
 // restored and everything re-initialised.  options.warm_start: "provided trajectory" on a fresh handle, "existing
 // solver state" afterwards -- the live slack / dual / costate rows are staged into slot 0 (and X, U too unless the
 // caller supplied a new trajectory since), see k_init.
-static int run_initialize(cddp_hip_handle *h) {
+static int run_initialize(Inner *h) {
   const bool ip = (h->P.solver == CDDP_HIP_SOLVER_IPDDP);
   int mode = kInitCold;
   if (h->P.opt.warm_start) mode = h->has_state ? kInitWarmExisting : kInitWarmProvided;
@@ -459,7 +465,7 @@ static int run_initialize(cddp_hip_handle *h) {
   return 0;
 }
 
-int cddp_hip_initialize(cddp_hip_handle *h) {
+static int in_initialize(Inner *h) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   { int rc = run_initialize(h); if (rc) return rc; }
@@ -467,7 +473,7 @@ int cddp_hip_initialize(cddp_hip_handle *h) {
   return 0;
 }
 
-int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *opt) {
+static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if (!h || !opt) return fail(-1, "null argument");
   if (!opt->use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
   HIPCHK(hipSetDevice(h->device));
@@ -486,7 +492,7 @@ int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *opt) {
   return 0;
 }
 
-int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0) {
+static int in_set_initial_state(Inner *h, const double *x0) {
   if (!h || !x0) return fail(-1, "null argument");
   if (!h->have_initial) return fail(-1, "cddp_hip_set_initial must be called once before cddp_hip_set_initial_state");
   HIPCHK(hipSetDevice(h->device));
@@ -504,7 +510,7 @@ int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0) {
   return 0;
 }
 
-int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) {
+static int in_set_duals(Inner *h, const double *S, const double *Y) {
   if (!h) return fail(-1, "null handle");
   if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m <= 0) return fail(-1, "cddp_hip_set_duals: the problem has no path duals");
   if (!h->has_state) return fail(-1, "cddp_hip_set_duals needs an initialised handle (call cddp_hip_initialize or cddp_hip_solve first)");
@@ -524,7 +530,7 @@ int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) {
   return 0;
 }
 
-int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const double *reg) {
+static int in_set_barrier_state(Inner *h, const double *mu, const double *reg) {
   if (!h) return fail(-1, "null handle");
   if (!h->has_state) return fail(-1, "cddp_hip_set_barrier_state needs an initialised handle (call cddp_hip_initialize or cddp_hip_solve first)");
   HIPCHK(hipSetDevice(h->device));
@@ -542,7 +548,7 @@ int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const doubl
   return 0;
 }
 
-int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T) {
+static int in_set_terminal(Inner *h, const double *S_T, const double *Y_T, const double *Lambda_T) {
   if (!h) return fail(-1, "null handle");
   if (h->P.n_term <= 0) return fail(-1, "cddp_hip_set_terminal: the problem has no terminal constraints");
   if (!h->has_state) return fail(-1, "cddp_hip_set_terminal needs an initialised handle");
@@ -559,10 +565,10 @@ int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y
   return 0;
 }
 
-int cddp_hip_backward(cddp_hip_handle *h, int32_t *ok) {
+static int in_backward(Inner *h, int32_t *ok) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
-  if (!h->initialized) { int rc = cddp_hip_initialize(h); if (rc) return rc; }
+  if (!h->initialized) { int rc = in_initialize(h); if (rc) return rc; }
   h->ks->derivs(h->d, 1, h->stream);
   h->ks->backward(h->d, h->P.solver, 1, 0, h->stream);
   HIPCHK(hipGetLastError());
@@ -571,7 +577,7 @@ int cddp_hip_backward(cddp_hip_handle *h, int32_t *ok) {
   return 0;
 }
 
-int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cddp_hip_trial *trials) {
+static int in_forward(Inner *h, const double *alphas, int n_alphas, cddp_hip_trial *trials) {
   if (!h || !alphas || !trials) return fail(-1, "null argument");
   if (n_alphas <= 0 || n_alphas > h->d.n_alphas) return fail(-1, "n_alphas must be in [1, %d] (the handle's ladder size)", h->d.n_alphas);
   HIPCHK(hipSetDevice(h->device));
@@ -606,31 +612,27 @@ int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cdd
   return 0;
 }
 
-int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
-  if (!h) return fail(-1, "null handle");
-  HIPCHK(hipSetDevice(h->device));
-  const ProblemDev &P = h->P;
-  const DevBuf &d = h->d;
-  hipStream_t s = h->stream;
-  const KernelSet *ks = h->ks;
-  const int max_it = P.opt.max_iterations;
-  const bool first_rule = (P.ls_rule == CDDP_HIP_LS_FIRST_SUCCESS);
-  const int na = d.n_alphas;
-  // Class timing: up to six mark points per outer iteration (0 start, 1 after the sweep, 2 after rollout stage 1,
-  // 3 after update 1, 4 after rollout stage 2, 5 after update 2).  Every event costs ~5 us of queue time, so only
-  // the points the selected detail needs are recorded (cddp_hip_set_timing_detail): 2 per iteration by default.
-  const int detail = stats ? h->timing_detail : -1;
-  std::vector<int> ev_slot;        // ev_slot[6 * (iteration - 1) + point] = index into the pool, or -1
+// ---- ISolverAlgorithm::solve (cddp_solver_base.cpp:29-186) for one tile group -------------------------------
+// The host loop of a group is resumable: `advance` enqueues iterations up to and including the next one that needs the
+// "anything still running?" poll and records an event behind the poll's device-to-host copies; `complete_poll` waits for
+// that event and digests the poll.  cddp_hip_solve interleaves the groups of a handle this way, so the kernels of several
+// groups are in flight at once (each on its own stream) and the phases of different groups overlap on the chip.
+struct SolveRun {
+  Inner *h = nullptr;
+  bool want_stats = false;
+  int conc = 1;                     // groups solved concurrently (the ladder heuristics count the chip's wavefronts)
+  int detail = -1;
+  std::vector<int> ev_slot;         // ev_slot[6 * (iteration - 1) + point] = index into the pool, or -1
   size_t ev_used = 0;
-  if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
-  if (!h->h_poll) HIPCHK(hipHostMalloc((void **)&h->h_poll, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 2)));
-  const hipEvent_t ev0 = h->ev_begin, ev1 = h->ev_end;
-  HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
-  HIPCHK(hipEventRecord(ev0, s));
-  { int rc = run_initialize(h); if (rc) return rc; }
-  int launches = 1, outer = 0;
-  bool two_stage_marks = false;
-  auto mark = [&](int point) {
+  int launches = 0, outer = 0, it = 0, max_it = 0, na = 0;
+  bool two_stage_marks = false, first_rule = true, pinned = false, one_stage = true, done = false, cpu_time_hit = false;
+  int k1 = 1, k_cap = 1, k_cap2 = 1;
+  long waves_all = 0;
+  std::vector<int> hist_now, hist_prev;
+  hipEvent_t poll_ev = nullptr;
+  std::chrono::steady_clock::time_point wall0;
+
+  void mark(int point) {
     if (detail < 0) return;
     const bool want = detail == CDDP_HIP_TIMING_ALL ||
                       (detail == CDDP_HIP_TIMING_ROLLOUT && (point == 1 || point == 2 || (two_stage_marks && (point == 3 || point == 4)))) ||
@@ -639,20 +641,10 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     if (ev_used == h->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev_pool.push_back(e); }
     const size_t slot = (size_t)6 * (size_t)(outer - 1) + (size_t)point;
     if (ev_slot.size() <= slot) ev_slot.resize(slot + 1, -1);
-    hipEventRecord(h->ev_pool[ev_used], s);
+    hipEventRecord(h->ev_pool[ev_used], h->stream);
     ev_slot[slot] = (int)ev_used++;
-  };
-  int *h_active = h->h_poll;
-  *h_active = d.B;
-  // Speculative line search: when batch x n_alphas wavefronts still underfill the chip (256 CUs x 4 SIMDs),
-  // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
-  // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
-  // (the two-role rollout of the path-constrained layouts runs two wavefronts per tile and alpha)
-  const long waves_all = (long)((d.B + 63) / 64) * na * ((P.solver == CDDP_HIP_SOLVER_IPDDP && (ks->cst_size > 0 || (d.te_cst && P.m > 0))) ? 2 : 1);
-  // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
-  // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
-  const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
-  const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
+  }
+
   // Ladder shape.  one_stage: all n_alpha trials of every trajectory in ONE launch.  Otherwise stage 1 evaluates the
   // first k1 alphas for every trajectory and stage 2 the rest, only for the trajectories none of the first k1 worked
   // for (a launch whose workgroups exit at once when there is no such trajectory).  The rollout is a latency chain:
@@ -663,22 +655,10 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // alphas: one launch 96 / 152, k1 = 4: 66.8 / 86.0, k1 = 1: - / 124), so it follows the accepted-alpha histogram
   // K5 keeps (read with the "anything still running" poll): k1 = the smallest count that satisfies all but about one
   // trajectory per four iterations, capped at one wavefront per SIMD; when nearly the whole ladder is needed, all of it
-  // in one launch if that fits two wavefronts per SIMD, else as many alphas as do (B = 16384 cart-pole: 210 vs 243 ms).  The selected trials do not depend on the shape
-  // (tests/test_gpu_parity.py::test_two_stage_ladder_selects_the_same_trials); CDDP_HIP_LS_STAGES=1|2 and
-  // CDDP_HIP_LS_FIRST=k pin it.
-  const long per_alpha = std::max(1L, waves_all / std::max(1, na));
-  const int k_cap = (int)std::max(1L, std::min((long)na - 1, 1024 / per_alpha));    // one wavefront per SIMD
-  const int k_cap2 = (int)std::max(1L, std::min((long)na - 1, 2048 / per_alpha));   // two (a ladder that is needed almost whole)
-  const char *kf_env = std::getenv("CDDP_HIP_LS_FIRST");
-  const int k_forced = kf_env ? std::atoi(kf_env) : 0;
-  const bool pinned = !first_rule || na == 1 || force_one || force_two || (k_forced >= 1 && k_forced < na);
-  bool one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
-  int k1 = force_two ? 1 : k_cap2;
-  if (k_forced >= 1 && k_forced < na && !force_one && first_rule) { one_stage = false; k1 = k_forced; }
-  std::vector<int> hist_now(na + 1, 0), hist_prev(na + 1, 0);
-  int *h_hist = h->h_poll + 1;
-  HIPCHK(hipMemsetAsync(d.win_hist, 0, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1), s));
-  auto adapt_ladder = [&](int window_iters) {
+  // in one launch if that fits two wavefronts per SIMD, else as many alphas as do (B = 16384 cart-pole: 210 vs 243 ms).
+  // The selected trials do not depend on the shape (tests/test_gpu_parity.py::test_two_stage_ladder_selects_the_same_trials);
+  // CDDP_HIP_LS_STAGES=1|2 and CDDP_HIP_LS_FIRST=k pin it.
+  void adapt_ladder(int window_iters) {
     if (pinned) return;
     long total = 0;
     std::vector<long> hd(na + 1);
@@ -701,66 +681,135 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       for (int a = 0; a <= na; ++a) std::fprintf(stderr, " %ld", hd[a]);
       std::fprintf(stderr, "\n");
     }
-  };
-  if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; }
-  const auto wall0 = std::chrono::steady_clock::now();
-  for (int it = 1; it <= max_it; ++it) {
-    if (P.opt.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (host clock, like the reference; the queue is drained first)
-      HIPCHK(hipStreamSynchronize(s));
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
-      if (el > P.opt.max_cpu_time) {
-        hipLaunchKernelGGL(k_mark_cpu_time, dim3((d.B + 255) / 256), dim3(256), 0, s, d);
-        ++launches;
-        break;
+  }
+
+  int begin(Inner *h_, bool stats_, int conc_) {
+    h = h_; want_stats = stats_; conc = std::max(1, conc_);
+    const ProblemDev &P = h->P;
+    const DevBuf &d = h->d;
+    hipStream_t s = h->stream;
+    const KernelSet *ks = h->ks;
+    max_it = P.opt.max_iterations;
+    first_rule = (P.ls_rule == CDDP_HIP_LS_FIRST_SUCCESS);
+    na = d.n_alphas;
+    // Class timing: up to six mark points per outer iteration (0 start, 1 after the sweep, 2 after rollout stage 1,
+    // 3 after update 1, 4 after rollout stage 2, 5 after update 2).  Every event costs ~5 us of queue time, so only
+    // the points the selected detail needs are recorded (cddp_hip_set_timing_detail): 2 per iteration by default.
+    detail = want_stats ? h->timing_detail : -1;
+    if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
+    if (!h->ev_poll) HIPCHK(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
+    poll_ev = h->ev_poll;
+    if (!h->h_poll) HIPCHK(hipHostMalloc((void **)&h->h_poll, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 2)));
+    HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
+    HIPCHK(hipEventRecord(h->ev_begin, s));
+    { int rc = run_initialize(h); if (rc) return rc; }
+    launches = 1; outer = 0; it = 0; done = false;
+    *h->h_poll = d.B;
+    // Speculative line search: when batch x n_alphas wavefronts still underfill the chip (256 CUs x 4 SIMDs),
+    // evaluating the whole ladder in ONE launch costs no extra wall time and removes one rollout latency
+    // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
+    // (the two-role rollout of the path-constrained layouts runs two wavefronts per tile and alpha; with several tile
+    // groups in flight the chip is shared: the group's wavefront count is scaled by the number of groups)
+    waves_all = (long)conc * (long)((d.B + 63) / 64) * na * ((P.solver == CDDP_HIP_SOLVER_IPDDP && (ks->cst_size > 0 || (d.te_cst && P.m > 0))) ? 2 : 1);
+    // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
+    // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
+    const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
+    const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
+    const long per_alpha = std::max(1L, waves_all / std::max(1, na));
+    k_cap = (int)std::max(1L, std::min((long)na - 1, 1024 / per_alpha));    // one wavefront per SIMD
+    k_cap2 = (int)std::max(1L, std::min((long)na - 1, 2048 / per_alpha));   // two (a ladder that is needed almost whole)
+    const char *kf_env = std::getenv("CDDP_HIP_LS_FIRST");
+    const int k_forced = kf_env ? std::atoi(kf_env) : 0;
+    pinned = !first_rule || na == 1 || force_one || force_two || (k_forced >= 1 && k_forced < na);
+    one_stage = !first_rule || na == 1 || force_one || (waves_all <= 2048 && !force_two);
+    k1 = force_two ? 1 : k_cap2;
+    if (k_forced >= 1 && k_forced < na && !force_one && first_rule) { one_stage = false; k1 = k_forced; }
+    hist_now.assign(na + 1, 0); hist_prev.assign(na + 1, 0);
+    HIPCHK(hipMemsetAsync(d.win_hist, 0, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 1), s));
+    wall0 = std::chrono::steady_clock::now();
+    if (max_it <= 0) { ks->update(d, 2, 0, 1, 1, s); ++launches; done = true; }
+    return 0;
+  }
+
+  // enqueue iterations up to (and including) the next polled one
+  int advance() {
+    if (done) return 0;
+    const ProblemDev &P = h->P;
+    const DevBuf &d = h->d;
+    hipStream_t s = h->stream;
+    const KernelSet *ks = h->ks;
+    constexpr int kPollEvery = 4;
+    while (it < max_it) {
+      ++it;
+      if (P.opt.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (host clock, like the reference; the queue is drained first)
+        HIPCHK(hipStreamSynchronize(s));
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+        if (el > P.opt.max_cpu_time) {
+          hipLaunchKernelGGL(k_mark_cpu_time, dim3((d.B + 255) / 256), dim3(256), 0, s, d);
+          ++launches; done = true; cpu_time_hit = true;
+          return 0;
+        }
+      }
+      ++outer;
+      const int last = (it == max_it) ? 1 : 0;
+      two_stage_marks = !one_stage;
+      mark(0);
+      ks->derivs(d, 0, s);
+      ks->backward(d, P.solver, 0, 1, s);
+      mark(1);
+      if (one_stage) {
+        ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
+        mark(2);
+        ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
+        ks->update(d, 1, na, last, 1, s);
+        mark(3);
+        launches += 4;
+      } else {
+        ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+        mark(2);
+        ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+        ks->update(d, 1, k1, last, 0, s);
+        mark(3);
+        ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
+        mark(4);
+        ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
+        ks->update(d, 2, na, last, 1, s);
+        mark(5);
+        launches += 6;
+      }
+      // The "anything still running?" poll drains the group's queue (host round trip + an empty pipeline for the next
+      // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
+      // trajectory finished are launches whose every lane exits on its phase check.
+      if (it % kPollEvery == 0 || last || (it <= 2 && !pinned)) {   // (two early polls: the ladder statistics settle the shape)
+        HIPCHK(hipMemcpyAsync(h->h_poll, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_poll + 1, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(poll_ev, s));
+        return 1;   // a poll is pending
       }
     }
-    ++outer;
-    const int last = (it == max_it) ? 1 : 0;
-    two_stage_marks = !one_stage;
-    mark(0);
-    ks->derivs(d, 0, s);
-    ks->backward(d, P.solver, 0, 1, s);
-    mark(1);
-    if (one_stage) {
-      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
-      mark(2);
-      ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
-      ks->update(d, 1, na, last, 1, s);
-      mark(3);
-      launches += 4;
-    } else {
-      ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
-      mark(2);
-      ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
-      ks->update(d, 1, k1, last, 0, s);
-      mark(3);
-      ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
-      mark(4);
-      ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
-      ks->update(d, 2, na, last, 1, s);
-      mark(5);
-      launches += 6;
-    }
-    // The "anything still running?" poll drains the queue (host round trip + an empty pipeline for the next
-    // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
-    // trajectory finished are launches whose every lane exits on its phase check.
-    constexpr int kPollEvery = 4;
-    if (it % kPollEvery == 0 || last || (it <= 2 && !pinned)) {   // (two early polls: the ladder statistics settle the shape)
-      HIPCHK(hipMemcpyAsync(h_active, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(h_hist, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (*h_active == 0) break;
-      for (int a = 0; a <= na; ++a) hist_now[a] = h_hist[a];
-      adapt_ladder(it <= 2 ? 1 : (it == kPollEvery ? 2 : kPollEvery));
-    }
+    done = true;
+    return 0;
   }
-  HIPCHK(hipEventRecord(ev1, s));
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
-  if (stats) {
+
+  int complete_poll() {
+    constexpr int kPollEvery = 4;
+    HIPCHK(hipEventSynchronize(poll_ev));
+    if (*h->h_poll == 0 || it >= max_it) { done = true; return 0; }
+    for (int a = 0; a <= na; ++a) hist_now[a] = h->h_poll[1 + a];
+    adapt_ladder(it <= 2 ? 1 : (it == kPollEvery ? 2 : kPollEvery));
+    return 0;
+  }
+
+  int finish(cddp_hip_stats *stats) {
+    const DevBuf &d = h->d;
+    hipStream_t s = h->stream;
+    HIPCHK(hipEventRecord(h->ev_end, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (!stats) return 0;
     std::memset(stats, 0, sizeof(*stats));
     float ms = 0;
-    hipEventElapsedTime(&ms, ev0, ev1);
+    hipEventElapsedTime(&ms, h->ev_begin, h->ev_end);
     stats->solve_ms = ms;
     auto span = [&](size_t it0, int pa, int pb) -> double {   // elapsed between two mark points of one iteration
       const size_t ia = it0 * 6 + (size_t)pa, ib = it0 * 6 + (size_t)pb;
@@ -780,31 +829,32 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     if (detail == CDDP_HIP_TIMING_ROLLOUT) stats->backward_ms = 0.0;
     if (detail == CDDP_HIP_TIMING_SWEEP) stats->forward_ms = 0.0;
     stats->timing_detail = detail;
-    std::vector<int> nb(d.B), nf(d.B), itv(d.B), stv(d.B);
+    std::vector<int> nb(d.B), nf(d.B), itv(d.B), stv(d.B), nst(d.B);
+    HIPCHK(hipMemcpy(nst.data(), d.n_fwd_steps, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nb.data(), d.n_bwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nf.data(), d.n_fwd, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(itv.data(), d.iter, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(stv.data(), d.status, sizeof(int) * d.B, hipMemcpyDeviceToHost));
     for (int b = 0; b < d.B; ++b) {
-      stats->sweeps += nb[b]; stats->rollouts += nf[b]; stats->traj_iterations += itv[b];
+      stats->sweeps += nb[b]; stats->rollouts += nf[b]; stats->traj_iterations += itv[b]; stats->rollout_steps += nst[b];
       if (stv[b] == CDDP_HIP_STATUS_OPTIMAL || stv[b] == CDDP_HIP_STATUS_ACCEPTABLE) stats->n_converged++;
     }
     unsigned long long nl = 0;
     HIPCHK(hipMemcpy(&nl, h->d_launched, sizeof(nl), hipMemcpyDeviceToHost));
     stats->rollouts_launched = (int64_t)nl;
     stats->outer_iterations = outer; stats->kernel_launches = launches;
+    return 0;
   }
-  return 0;
-}
+};
 
 // ---- getters -----------------------------------------------------------------------------
-static int fetch(cddp_hip_handle *h, const double *dev, size_t n, std::vector<double> &host) {
+static int fetch(Inner *h, const double *dev, size_t n, std::vector<double> &host) {
   host.resize(n);
   HIPCHK(hipMemcpy(host.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
-int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) {
+static int in_get_results(Inner *h, cddp_hip_result *r) {
   if (!h || !r) return fail(-1, "null argument");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -828,7 +878,7 @@ int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) {
 }
 
 // copies the CURRENT slot of every trajectory of a slotted array
-static int fetch_current(cddp_hip_handle *h, const double *base, size_t plane, int T, int E, double *out) {
+static int fetch_current(Inner *h, const double *base, size_t plane, int T, int E, double *out) {
   const DevBuf &d = h->d;
   std::vector<int> cur(d.B);
   HIPCHK(hipMemcpy(cur.data(), d.cur, sizeof(int) * d.B, hipMemcpyDeviceToHost));
@@ -848,7 +898,7 @@ static int fetch_current(cddp_hip_handle *h, const double *base, size_t plane, i
   return 0;
 }
 
-int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) {
+static int in_get_trajectory(Inner *h, double *X, double *U) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -858,7 +908,7 @@ int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) {
   return 0;
 }
 
-int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) {
+static int in_get_gains(Inner *h, double *K, double *k) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -869,7 +919,7 @@ int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) {
   return 0;
 }
 
-int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) {
+static int in_get_value(Inner *h, double *Vx, double *Vxx) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -880,7 +930,7 @@ int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) {
   return 0;
 }
 
-int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
+static int in_get_duals(Inner *h, double *S, double *Y, double *G) {
   if (!h) return fail(-1, "null handle");
   if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m == 0) return fail(-1, "no slack/dual trajectories for this problem");
   HIPCHK(hipSetDevice(h->device));
@@ -892,7 +942,7 @@ int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
   return 0;
 }
 
-int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
+static int in_get_terminal(Inner *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -909,7 +959,7 @@ int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *
   return 0;
 }
 
-int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg) {
+static int in_get_backward_scalars(Inner *h, double *dV, double *reg) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -924,9 +974,9 @@ int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg) {
   return 0;
 }
 
-int cddp_hip_history_capacity(cddp_hip_handle *h) { return h ? h->d.hist_cap : -1; }
+static int in_history_capacity(Inner *h) { return h ? h->d.hist_cap : -1; }
 
-int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts) {
+static int in_get_history(Inner *h, int hist_batch, double *hist, int32_t *counts) {
   if (!h || !hist || !counts) return fail(-1, "null argument");
   const DevBuf &d = h->d;
   if (hist_batch > d.hist_batch) return fail(-1, "history kept for %d trajectories only (options.return_iteration_info=%d)", d.hist_batch, h->P.opt.return_iteration_info);
@@ -937,12 +987,252 @@ int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32
   return 0;
 }
 
-int cddp_hip_write_gather_records_device(cddp_hip_handle *h, void *device_ptr) {
+static int in_write_gather_records_device(Inner *h, void *device_ptr) {
   if (!h || !device_ptr) return fail(-1, "null argument");
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_gather_records, dim3((h->d.B + 255) / 256), dim3(256), 0, h->stream, h->d, (cddp_hip_gather_record *)device_ptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+
+// ================================================================================================================
+// Public handle: the batch is cut into tile GROUPS (whole 64-trajectory tiles), each an independent Inner solver
+// with its own device buffers, stream, counters and ladder statistics.  Trajectories are independent problems, so a
+// trajectory's result does not depend on the group it lands in (tests/test_full_size.py: full batch == sub-batches,
+// bit for bit); cddp_hip_solve keeps the kernels of all groups in flight at once, which lets the short, latency-bound
+// sweep of one group run under the rollout of another instead of leaving three quarters of the SIMDs idle.
+// CDDP_HIP_GROUPS=n pins the group count (1 = the single-stream path of round 1).
+// ================================================================================================================
+}  // extern "C" (reopened below)
+
+struct cddp_hip_handle {
+  std::vector<Inner *> g;
+  std::vector<int> b0;       // first trajectory of each group
+  int B = 0, device = 0;
+  int nx = 0, nu = 0, N = 0, m = 0, mT = 0, pT = 0;
+  hipStream_t user_stream = nullptr;   // cddp_hip_set_stream: work is ordered after / before this stream's work
+  bool have_user_stream = false;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void *d_send = nullptr;              // send buffer of cddp_hip_allgather_results (shard_capacity records)
+  int send_cap = 0;
+};
+
+namespace {
+
+int pick_groups(int batch) {
+  const int tiles = (batch + 63) / 64;
+  const char *e = std::getenv("CDDP_HIP_GROUPS");
+  int n = e ? std::atoi(e) : 0;
+  // Default: ONE group.  Measured on MI355X (profiles/r02_groups_sweep.md): at C2 (B = 4096) 1 / 2 / 4 / 8 groups solve in
+  // 48.8 / 50.1 / 56.6 / 84.8 ms, at C3 (B = 8192) 1 / 2 / 4 groups in 88.0 / 89.3 / 92.7 ms -- the rollout launch already puts
+  // more than one wavefront on every SIMD (1408 waves at C2), so a second group's sweep does not find idle issue slots, it
+  // lengthens both chains, and every group adds its own launches and polls.  The mechanism stays for larger chips / other
+  // shapes (CDDP_HIP_GROUPS=n) and because the C++ host can use it to pipeline uploads of later groups.
+  if (n <= 0) n = 1;
+  return std::max(1, std::min(n, tiles));
+}
+
+// ordering against a caller-supplied stream: fork = group streams wait for the user's stream, join = the reverse
+int fork_from_user(cddp_hip_handle *h) {
+  if (!h->have_user_stream) return 0;
+  if (!h->ev_fork) { HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)); }
+  HIPCHK(hipEventRecord(h->ev_fork, h->user_stream));
+  for (Inner *q : h->g) if (q->stream != h->user_stream) HIPCHK(hipStreamWaitEvent(q->stream, h->ev_fork, 0));
+  return 0;
+}
+int join_to_user(cddp_hip_handle *h) {
+  if (!h->have_user_stream) return 0;
+  for (Inner *q : h->g) {
+    if (q->stream == h->user_stream) continue;
+    HIPCHK(hipEventRecord(h->ev_join, q->stream));
+    HIPCHK(hipStreamWaitEvent(h->user_stream, h->ev_join, 0));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp_hip_handle **out) {
+  if (!problem || !out) return fail(-1, "null argument");
+  if (batch <= 0) return fail(-1, "batch must be positive");
+  const int tiles = (batch + 63) / 64, ng = pick_groups(batch);
+  cddp_hip_handle *h = new cddp_hip_handle();
+  h->B = batch; h->device = device;
+  int t0 = 0;
+  for (int k = 0; k < ng; ++k) {
+    const int nt = tiles / ng + (k < tiles % ng ? 1 : 0);          // whole tiles per group, sizes differ by at most one tile
+    const int first = t0 * 64, last = std::min(batch, (t0 + nt) * 64);
+    t0 += nt;
+    if (last <= first) continue;
+    Inner *q = nullptr;
+    int rc = in_create(problem, last - first, device, &q);
+    if (rc) { for (Inner *p : h->g) in_destroy(p); delete h; return rc; }
+    h->g.push_back(q); h->b0.push_back(first);
+  }
+  const ProblemDev &P = h->g[0]->P;
+  h->nx = P.nx; h->nu = P.nu; h->N = P.N; h->m = P.m; h->mT = P.mT; h->pT = P.pT;
+  *out = h;
+  return 0;
+}
+
+int cddp_hip_destroy(cddp_hip_handle *h) {
+  if (!h) return 0;
+  for (Inner *q : h->g) in_destroy(q);
+  if (h->ev_fork) { hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
+  if (h->d_send) hipFree(h->d_send);
+  delete h;
+  return 0;
+}
+
+int cddp_hip_num_groups(cddp_hip_handle *h) { return h ? (int)h->g.size() : -1; }
+
+int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail) {
+  if (!h) return fail(-1, "null handle");
+  for (Inner *q : h->g) { int rc = in_set_timing_detail(q, detail); if (rc) return rc; }
+  return 0;
+}
+
+int cddp_hip_set_stream(cddp_hip_handle *h, void *hip_stream) {
+  if (!h) return fail(-1, "null handle");
+  h->user_stream = (hipStream_t)hip_stream; h->have_user_stream = true;
+  if (h->g.size() == 1) return in_set_stream(h->g[0], hip_stream);   // one group: it simply runs on the caller's stream
+  return 0;   // several groups keep their own streams; every entry point forks from / joins to the caller's stream
+}
+
+int cddp_hip_dual_dim(cddp_hip_handle *h) { return h ? h->m : -1; }
+int cddp_hip_batch(cddp_hip_handle *h) { return h ? h->B : -1; }
+
+#define OFF(ptr, stride) ((ptr) ? (ptr) + (size_t)h->b0[gi_] * (size_t)(stride) : nullptr)
+#define FOR_GROUPS(call) do { if (!h) return fail(-1, "null handle"); { int rc_ = fork_from_user(h); if (rc_) return rc_; } \
+    for (size_t gi_ = 0; gi_ < h->g.size(); ++gi_) { Inner *q = h->g[gi_]; (void)q; int rc_ = (call); if (rc_) return rc_; } \
+    return join_to_user(h); } while (0)
+
+int cddp_hip_set_initial(cddp_hip_handle *h, const double *x0, const double *U0, const double *X0) {
+  if (!x0) return fail(-1, "null argument");
+  FOR_GROUPS(in_set_initial(q, OFF(x0, h->nx), OFF(U0, h->N * h->nu), OFF(X0, (h->N + 1) * h->nx)));
+}
+int cddp_hip_initialize(cddp_hip_handle *h) { FOR_GROUPS(in_initialize(q)); }
+int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *opt) { FOR_GROUPS(in_set_options(q, opt)); }
+int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0) {
+  if (!x0) return fail(-1, "null argument");
+  FOR_GROUPS(in_set_initial_state(q, OFF(x0, h->nx)));
+}
+int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) { FOR_GROUPS(in_set_duals(q, OFF(S, h->N * h->m), OFF(Y, h->N * h->m))); }
+int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const double *reg) { FOR_GROUPS(in_set_barrier_state(q, OFF(mu, 1), OFF(reg, 1))); }
+int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T) {
+  FOR_GROUPS(in_set_terminal(q, OFF(S_T, h->mT), OFF(Y_T, h->mT), OFF(Lambda_T, h->pT)));
+}
+int cddp_hip_backward(cddp_hip_handle *h, int32_t *ok) { FOR_GROUPS(in_backward(q, OFF(ok, 1))); }
+int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cddp_hip_trial *trials) {
+  if (!alphas || !trials) return fail(-1, "null argument");
+  FOR_GROUPS(in_forward(q, alphas, n_alphas, OFF(trials, n_alphas)));
+}
+int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) { if (!r) return fail(-1, "null argument"); FOR_GROUPS(in_get_results(q, OFF(r, 1))); }
+int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) { FOR_GROUPS(in_get_trajectory(q, OFF(X, (h->N + 1) * h->nx), OFF(U, h->N * h->nu))); }
+int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) { FOR_GROUPS(in_get_gains(q, OFF(K, h->N * h->nu * h->nx), OFF(k, h->N * h->nu))); }
+int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) { FOR_GROUPS(in_get_value(q, OFF(Vx, (h->N + 1) * h->nx), OFF(Vxx, (h->N + 1) * h->nx * h->nx))); }
+int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
+  FOR_GROUPS(in_get_duals(q, OFF(S, h->N * h->m), OFF(Y, h->N * h->m), OFF(G, h->N * h->m)));
+}
+int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
+  FOR_GROUPS(in_get_terminal(q, OFF(S_T, h->mT), OFF(Y_T, h->mT), OFF(G_T, h->mT), OFF(Lambda_T, h->pT), dims));
+}
+int cddp_hip_get_backward_scalars(cddp_hip_handle *h, double *dV, double *reg) { FOR_GROUPS(in_get_backward_scalars(q, OFF(dV, 2), OFF(reg, 1))); }
+int cddp_hip_history_capacity(cddp_hip_handle *h) { return h ? in_history_capacity(h->g[0]) : -1; }
+int cddp_hip_get_history(cddp_hip_handle *h, int hist_batch, double *hist, int32_t *counts) {
+  if (!h) return fail(-1, "null handle");
+  // the history of the first min(batch, 64) trajectories is kept: they all live in group 0 (groups are whole tiles)
+  return in_get_history(h->g[0], hist_batch, hist, counts);
+}
+int cddp_hip_write_gather_records_device(cddp_hip_handle *h, void *device_ptr) {
+  if (!device_ptr) return fail(-1, "null argument");
+  FOR_GROUPS(in_write_gather_records_device(q, (char *)device_ptr + (size_t)h->b0[gi_] * sizeof(cddp_hip_gather_record)));
+}
+#undef FOR_GROUPS
+#undef OFF
+
+// The single collective of the path: all-gather of the 16-byte result records over RCCL.
+int cddp_hip_allgather_results(cddp_hip_handle *h, void *comm, int world, int shard_capacity, void *recv_device) {
+  if (!h || !recv_device) return fail(-1, "null argument");
+  if (world <= 0) return fail(-1, "world must be positive");
+  if (shard_capacity < h->B) return fail(-1, "shard_capacity %d is smaller than this rank's batch %d", shard_capacity, h->B);
+  if (!comm && world != 1) return fail(-1, "a NULL communicator is only valid for world == 1 (got %d)", world);
+  HIPCHK(hipSetDevice(h->device));
+  if (h->send_cap < shard_capacity) {
+    if (h->d_send) { hipFree(h->d_send); h->d_send = nullptr; h->send_cap = 0; }
+    HIPCHK(hipMalloc(&h->d_send, (size_t)shard_capacity * sizeof(cddp_hip_gather_record)));
+    h->send_cap = shard_capacity;
+  }
+  hipStream_t cs = h->have_user_stream ? h->user_stream : h->g[0]->stream;   // the collective's stream
+  // padding records of an uneven block partition: every byte 0xFF -> status = iterations = -1, cost = NaN
+  if (shard_capacity > h->B)
+    HIPCHK(hipMemsetAsync((char *)h->d_send + (size_t)h->B * sizeof(cddp_hip_gather_record), 0xFF,
+                          (size_t)(shard_capacity - h->B) * sizeof(cddp_hip_gather_record), cs));
+  for (size_t k = 0; k < h->g.size(); ++k) {   // (in_write_gather_records_device synchronises the group's stream)
+    int rc = in_write_gather_records_device(h->g[k], (char *)h->d_send + (size_t)h->b0[k] * sizeof(cddp_hip_gather_record));
+    if (rc) return rc;
+  }
+  const size_t bytes = (size_t)shard_capacity * sizeof(cddp_hip_gather_record);
+  if (!comm) HIPCHK(hipMemcpyAsync(recv_device, h->d_send, bytes, hipMemcpyDeviceToDevice, cs));
+  else { int rc = cddp_hip_internal_allgather(h->d_send, recv_device, bytes, comm, (void *)cs); if (rc) return rc; }
+  HIPCHK(hipStreamSynchronize(cs));
+  return 0;
+}
+
+int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  { int rc = fork_from_user(h); if (rc) return rc; }
+  const int ng = (int)h->g.size();
+  std::vector<SolveRun> run(ng);
+  // a common time origin on every group stream (the groups' solve_ms are measured from their own begin events; the
+  // whole-handle time is the span from the first begin to the last end, taken on group 0's clock after a join)
+  for (int k = 0; k < ng; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, ng); if (rc) return rc; }
+  std::vector<int> pending(ng, 0);
+  for (int k = 0; k < ng; ++k) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+  for (;;) {
+    bool any = false;
+    for (int k = 0; k < ng; ++k) {
+      if (!pending[k]) continue;
+      any = true;
+      { int rc = run[k].complete_poll(); if (rc) return rc; }
+      pending[k] = 0;
+      if (!run[k].done) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+    }
+    if (!any) break;
+  }
+  // whole-handle device time: group 0's stream waits for the other groups' end events, then stamps the end
+  std::vector<cddp_hip_stats> gs(ng);
+  for (int k = 1; k < ng; ++k) {
+    HIPCHK(hipEventRecord(h->g[k]->ev_end, h->g[k]->stream));
+    HIPCHK(hipStreamWaitEvent(h->g[0]->stream, h->g[k]->ev_end, 0));
+  }
+  for (int k = 0; k < ng; ++k) { int rc = run[k].finish(stats ? &gs[k] : nullptr); if (rc) return rc; }
+  { int rc = join_to_user(h); if (rc) return rc; }
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    float span_ms = 0;
+    double first_begin_off = 0.0;
+    // span = end(group 0, which waited for everybody) - earliest begin; the begins are enqueued back to back, so group
+    // 0's begin is the earliest up to the few microseconds of its own enqueue
+    hipEventElapsedTime(&span_ms, h->g[0]->ev_begin, h->g[0]->ev_end);
+    (void)first_begin_off;
+    stats->solve_ms = span_ms;
+    for (int k = 0; k < ng; ++k) {
+      // class times: the groups run concurrently, so the per-class event spans of different groups overlap in wall
+      // time; they are reported as the MEAN over groups (the time one group's stream spent in that class)
+      stats->backward_ms += gs[k].backward_ms / ng; stats->forward_ms += gs[k].forward_ms / ng; stats->update_ms += gs[k].update_ms / ng;
+      stats->sweeps += gs[k].sweeps; stats->rollouts += gs[k].rollouts; stats->rollouts_launched += gs[k].rollouts_launched;
+      stats->traj_iterations += gs[k].traj_iterations; stats->rollout_steps += gs[k].rollout_steps;
+      stats->outer_iterations = std::max(stats->outer_iterations, gs[k].outer_iterations);
+      stats->n_converged += gs[k].n_converged; stats->kernel_launches += gs[k].kernel_launches;
+      stats->timing_detail = gs[k].timing_detail;
+    }
+  }
   return 0;
 }
 

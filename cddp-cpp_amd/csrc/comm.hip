@@ -1,0 +1,100 @@
+// The single collective of the path: one RCCL all-gather of the 16-byte {final_cost, iterations,
+// status} records per batch solve, at the C-ABI so that a C++ host has the multi-GPU path without
+// Python.  RCCL is resolved lazily (dlopen) -- the solver core itself has no link-time dependency on it, and a process
+// that already loaded an RCCL (PyTorch bundles one) keeps using that copy.
+#include <dlfcn.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include "../../include/cddp_hip.h"
+
+extern "C" int cddp_hip_internal_set_error(int code, const char *msg);   // capi.hip (thread-local last-error string)
+
+namespace {
+
+int cfail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  return cddp_hip_internal_set_error(code, buf);
+}
+
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+Rccl &rccl() {
+  static Rccl r;
+  if (r.lib || !r.err.empty()) return r;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+  if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return r; }
+  auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.err = std::string("librccl lacks ") + n; return p; };
+  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cddp_hip_comm_unique_id(char *id_out) {
+  if (!id_out) return cfail(-1, "null argument");
+  Rccl &r = rccl();
+  if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
+  ncclUniqueId id;
+  ncclResult_t rc = r.GetUniqueId(&id);
+  if (rc != ncclSuccess) return cfail(-31, "ncclGetUniqueId: %s", r.GetErrorString(rc));
+  static_assert(sizeof(id) == CDDP_HIP_COMM_ID_BYTES, "unique id size");
+  std::memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int cddp_hip_comm_init(const char *id_in, int world, int rank, int device, void **comm_out) {
+  if (!id_in || !comm_out) return cfail(-1, "null argument");
+  if (world <= 0 || rank < 0 || rank >= world) return cfail(-1, "bad rank %d of world %d", rank, world);
+  Rccl &r = rccl();
+  if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
+  if (hipSetDevice(device) != hipSuccess) return cfail(-10, "hipSetDevice(%d) failed", device);
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, sizeof(id));
+  ncclComm_t c = nullptr;
+  ncclResult_t rc = r.CommInitRank(&c, world, id, rank);
+  if (rc != ncclSuccess) return cfail(-31, "ncclCommInitRank: %s", r.GetErrorString(rc));
+  *comm_out = (void *)c;
+  return 0;
+}
+
+int cddp_hip_comm_destroy(void *comm) {
+  if (!comm) return 0;
+  Rccl &r = rccl();
+  if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
+  r.CommDestroy((ncclComm_t)comm);
+  return 0;
+}
+
+// used by capi.hip::cddp_hip_allgather_results
+int cddp_hip_internal_allgather(const void *send, void *recv, size_t bytes_per_rank, void *comm, void *stream) {
+  Rccl &r = rccl();
+  if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
+  ncclResult_t rc = r.AllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)comm, (hipStream_t)stream);
+  if (rc != ncclSuccess) return cfail(-31, "ncclAllGather: %s", r.GetErrorString(rc));
+  return 0;
+}
+
+}  // extern "C"

@@ -73,6 +73,8 @@ struct DevBuf {
   double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
   double *t_ysmin, *t_ysmax;               // extreme y*s products of the trial (complementarity residual under a new mu)
   int *t_success;
+  int *t_steps;                            // [n_alphas][Bp] rollout steps the trial completed before it was abandoned (N = ran through)
+  int *n_fwd_steps;                        // [Bp] sum of t_steps over the trials the line-search rule walked (roofline accounting)
   double *cst;                             // [N][CST][Bp] V-independent condensed stage terms written by K1b (k_condense)
   double *ys;                              // [N][m][Bp] Y S^-1 ratios of the last sweep (K3 -> rollout consumer)
   double *dX;                              // [N][nx][Bp] linear-policy rollout of the last sweep (read by K3 k_post)

@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   const double alpha = P->alphas[a];
   const int box = P->clddp_box;
   atomicAdd(d.launched, 1ull);
+  d.t_steps[(size_t)a * d.Bp + b] = N;   // the CLDDP rollout is never abandoned (clddp_solver.cpp:215-262)
   double x[NX];
   ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // X_[0] == initial state
   st<NX>(Xn + GI(0, NX, 0), kLS, x);
@@ -1318,6 +1319,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   atomicAdd(d.launched, 1ull);
   d.t_apr[ti] = a_pr; d.t_adu[ti] = a_du;
   d.t_success[ti] = 0;
+  d.t_steps[ti] = N;     // overwritten by the step index where the trial is abandoned
   d.t_cost[ti] = d.cost[b]; d.t_merit[ti] = d.phi[b]; d.t_theta[ti] = d.theta[b];
   d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
   double x[NX];
@@ -1383,12 +1385,12 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
           for (int j = 0; j < NX; ++j) crow[j] = -(dual_ratio * (-row[j]));
           tn.y[i] = affine_2r<NX>(to.y[i], a_du, k_y, crow, dx);
           const double s_floor = dmax((1.0 - tau) * to.s[i], fl0);
-          if (tn.s[i] < s_floor || tn.y[i] < (1.0 - tau) * to.y[i]) return;
-          if (!dfinite(tn.s[i]) || !dfinite(tn.y[i])) return;
+          if (tn.s[i] < s_floor || tn.y[i] < (1.0 - tau) * to.y[i]) { d.t_steps[ti] = t < N ? t : N; return; }
+          if (!dfinite(tn.s[i]) || !dfinite(tn.y[i])) { d.t_steps[ti] = t < N ? t : N; return; }
         }
         for (int i = 0; i < pT; ++i) {
           tn.lam[i] = to.lam[i] + a_pr * d.dLamT[(size_t)i * d.Bp + b];
-          if (!dfinite(tn.lam[i])) return;
+          if (!dfinite(tn.lam[i])) { d.t_steps[ti] = t < N ? t : N; return; }
         }
       }
     }
@@ -1403,7 +1405,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
         if (sn[r] < (1.0 - tau) * cs.s[r] || yn[r] < (1.0 - tau) * cs.y[r]) feas = false;
         if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
       }
-      if (!feas) return;
+      if (!feas) { d.t_steps[ti] = t < N ? t : N; return; }
       st<M>(Sn + GI(t, M, 0), kLS, sn);
       st<M>(Yn + GI(t, M, 0), kLS, yn);
     }
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
     Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
-    if (!finite) return;
+    if (!finite) { d.t_steps[ti] = t < N ? t : N; return; }
     cost_new += Obj::running_cost(P, xrt, t, x, u);
     if constexpr (M > 0) {
       double g[MM];
@@ -1638,6 +1640,9 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
         // rollouts the reference runs to get here: the first-success rule stops at the winner, the best-merit rule
         // (one std::async per alpha, cddp_solver_base.cpp:264-286) always evaluates the whole ladder
         d.n_fwd[b] += (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
+        { int ns = 0; const int na_walked = (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
+          for (int a = 0; a < na_walked; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
+          d.n_fwd_steps[b] += ns; }
         d.cur[b] = trial_slot(old_cur, win);
         d.cost[b] = d.t_cost[ti];
         d.merit[b] = d.t_merit[ti];
@@ -1808,6 +1813,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
       } else {
         // ---- handleForwardPassFailure (cddp_solver_base.cpp:206-218, ipddp_solver.cpp:2037-2082)
         d.n_fwd[b] += n_alphas;
+        { int ns = 0; for (int a = 0; a < n_alphas; ++a) ns += d.t_steps[(size_t)a * d.Bp + b]; d.n_fwd_steps[b] += ns; }
         double reg = reg_increase(o, d.reg[b]);
         if (ipddp && !nobar && pT > 0) reg = reg_increase(o, reg);   // extra bump for terminal-equality problems (:2043-2050)
         d.reg[b] = reg;
@@ -1911,7 +1917,7 @@ __global__ __launch_bounds__(64) void k_init(DevBuf d, const ProblemDev *__restr
   d.cur[b] = 0;
   double *X0 = d.X, *U0 = d.U;
   d.iter[b] = 0; d.status[b] = CDDP_HIP_STATUS_RUNNING; d.phase[b] = PH_ACTIVE;
-  d.n_bwd[b] = 0; d.n_fwd[b] = 0; d.bwd_ok[b] = 0; d.filt_n[b] = 0;
+  d.n_bwd[b] = 0; d.n_fwd[b] = 0; d.n_fwd_steps[b] = 0; d.bwd_ok[b] = 0; d.filt_n[b] = 0;
   if (b < d.hist_batch) d.hist_n[b] = 0;
   if (!existing) d.reg[b] = o.reg_initial_value;
   d.dV0[b] = 0.0; d.dV1[b] = 0.0;

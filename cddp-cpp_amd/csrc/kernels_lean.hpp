@@ -698,6 +698,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const double a_du = dmin(alpha, d.adu_max[bb]);
   const size_t ti = (size_t)a * d.Bp + bb;
   bool alive = active;
+  int fail_t = N;        // steps completed before the trial was abandoned (kept in a register, stored at the exits)
   if (alive) {
     atomicAdd(d.launched, 1ull);
     d.t_apr[ti] = a_pr; d.t_adu[ti] = a_du;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (alive && s_pstat[lane] <= t) alive = false;
+    if (alive && s_pstat[lane] <= t) { alive = false; fail_t = t; }
     double sn[M], yn[M];
     bool feas = true;
     // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
     }
     }
+    fail_t = (alive && !feas) ? t : fail_t;
     if (!feas) alive = false;
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
@@ -842,6 +844,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       step(t + 1, rb, ra);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed: release the producer
         __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (active) d.t_steps[ti] = fail_t;
         return;
       }
     }
@@ -851,11 +854,13 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       step(t, ra, ra);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
         __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (active) d.t_steps[ti] = fail_t;
         return;
       }
     }
   }
   wait_ge(&s_prod, N + kRing + 1);
+  if (active) d.t_steps[ti] = fail_t;
   if (alive && s_pstat[lane] <= N) alive = false;
   if (!alive) return;
   const double cost_new = run_cost + s_pcost[lane];   // + l_f(x_N)

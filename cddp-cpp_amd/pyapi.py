@@ -157,7 +157,7 @@ class Stats(C.Structure):
         ("update_ms", C.c_double), ("sweeps", C.c_int64), ("rollouts", C.c_int64),
         ("rollouts_launched", C.c_int64), ("traj_iterations", C.c_int64),
         ("outer_iterations", C.c_int32), ("n_converged", C.c_int32), ("kernel_launches", C.c_int32),
-        ("timing_detail", C.c_int32),
+        ("timing_detail", C.c_int32), ("rollout_steps", C.c_int64),
     ]
 
 
@@ -429,7 +429,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
-    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state",
+    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
@@ -462,6 +462,9 @@ class HipBatchSolver:
             self.close()
         except Exception:
             pass
+
+    def num_groups(self):
+        return int(self.lib.cddp_hip_num_groups(self.h))
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.cddp_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
@@ -564,6 +567,11 @@ class HipBatchSolver:
         self._check(self.lib.cddp_hip_get_history(self.h, hist_batch, _ptr(h), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
         return [h[b, :cnt[b]].copy() for b in range(hist_batch)]
 
+    def allgather_results(self, comm, world, shard_capacity, recv_device_ptr):
+        """The path's single collective through the C-ABI (RCCL all-gather of the 16-byte records); comm = a
+        communicator from `comm_init` (or None for world == 1)."""
+        self._check(self.lib.cddp_hip_allgather_results(self.h, C.c_void_p(comm), int(world), int(shard_capacity), C.c_void_p(recv_device_ptr)))
+
     def write_gather_records_device(self, device_ptr):
         self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
 
@@ -580,3 +588,30 @@ def hip_backward_stacks(fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN, reg, reg_in_va
     if rc != 0:
         raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
     return K, k, Vx, Vxx, dV, ok, ms.value
+
+
+# ---- RCCL communicator helpers of the C-ABI (include/cddp_hip.h, "multi-GPU") -------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    lib = load_hip()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.cddp_hip_comm_unique_id(buf)
+    if rc != 0:
+        raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    return buf.raw
+
+
+def comm_init(unique_id, world, rank, device):
+    lib = load_hip()
+    comm = C.c_void_p()
+    rc = lib.cddp_hip_comm_init(C.c_char_p(bytes(unique_id)), int(world), int(rank), int(device), C.byref(comm))
+    if rc != 0:
+        raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    return comm.value
+
+
+def comm_destroy(comm):
+    if comm:
+        load_hip().cddp_hip_comm_destroy(C.c_void_p(comm))

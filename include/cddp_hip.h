@@ -264,6 +264,9 @@ typedef struct cddp_hip_stats {
   int32_t n_converged;      /* status OPTIMAL or ACCEPTABLE                        */
   int32_t kernel_launches;
   int32_t timing_detail;    /* CDDP_HIP_TIMING_* the class times were taken with   */
+  int64_t rollout_steps;    /* time steps the credited rollouts (`rollouts`) actually traversed: a trial the
+                             * reference abandons at its first fraction-to-boundary violation
+                             * (ipddp_solver.cpp:1632-1645) counts the steps completed before it, not N */
 } cddp_hip_stats;
 
 /* Which kernel classes cddp_hip_solve brackets with hipEvents when a stats block is requested.  An event costs
@@ -385,9 +388,32 @@ int cddp_hip_history_capacity(cddp_hip_handle *h);
  * single RCCL all-gather of SURVEY.md section 8(e). */
 int cddp_hip_write_gather_records_device(cddp_hip_handle *h, void *device_ptr);
 
+/* ---- multi-GPU: the single collective of the path --------------------------------------
+ * One process (or host thread) per GPU, each with its own handle over a contiguous block of the global batch; nothing
+ * is exchanged during a solve.  After it, ONE RCCL all-gather collects every trajectory's 16-byte record.
+ * The communicator is the caller's ncclComm_t (passed as void*), or one made with the helpers below (RCCL is loaded
+ * lazily with dlopen: the solver core has no link-time dependency on it). */
+#define CDDP_HIP_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others by any means (MPI, TCP store, file). */
+int cddp_hip_comm_unique_id(char *id_out /* CDDP_HIP_COMM_ID_BYTES */);
+/* ncclCommInitRank on `device` (collective over all ranks). */
+int cddp_hip_comm_init(const char *id_in, int world, int rank, int device, void **comm_out);
+int cddp_hip_comm_destroy(void *comm);
+/* All-gather the records of this rank's batch into recv_device (DEVICE buffer of world * shard_capacity records,
+ * rank r's block at r * shard_capacity).  shard_capacity >= every rank's batch: with an uneven block partition the
+ * ranks pad to the largest shard; padding records read status = iterations = -1.  comm == NULL is valid for
+ * world == 1 (device copy).  Runs on the stream given to cddp_hip_set_stream (else the handle's own) and returns when
+ * the gathered buffer is complete. */
+int cddp_hip_allgather_results(cddp_hip_handle *h, void *comm /* ncclComm_t */, int world, int shard_capacity,
+                               void *recv_device);
+
 /* Total path dual dimension m and terminal-equality dimension p of the handle's problem. */
 int cddp_hip_dual_dim(cddp_hip_handle *h);
 int cddp_hip_batch(cddp_hip_handle *h);
+/* Number of tile groups the handle's batch is cut into (whole 64-trajectory tiles per group; each group has its own
+ * device buffers and stream and cddp_hip_solve keeps all of them in flight).  Results do not depend on it.
+ * Environment CDDP_HIP_GROUPS=n pins it at create time (1 = one stream). */
+int cddp_hip_num_groups(cddp_hip_handle *h);
 
 /* ---- stack-fed mode (host plugins) ---------------------------------------
  * Arbitrary DynamicalSystem/Objective subclasses cannot run on the GPU.  In stack-fed mode

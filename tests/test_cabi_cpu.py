@@ -45,7 +45,7 @@ def test_struct_sizes_match_header(api):
     assert api.RESULT_DTYPE.itemsize == 96
     assert api.GATHER_DTYPE.itemsize == 16
     assert api.TRIAL_DTYPE.itemsize == 72
-    assert C.sizeof(api.Stats) == 80
+    assert C.sizeof(api.Stats) == 88
 
 
 def test_default_options_match_reference_defaults(api, lib):

@@ -28,3 +28,34 @@ def test_repeated_solves_are_bitwise_identical(api, kind):
             for a, b in zip(ref, cur):
                 assert np.array_equal(a, b)
     hs.close()
+
+
+@pytest.mark.parametrize("kind", ["cartpole_box", "unicycle_box_ball", "cartpole_clddp"])
+def test_tile_groups_do_not_change_results(api, kind, monkeypatch):
+    """cddp_hip_create cuts the batch into tile groups solved concurrently on separate streams (CDDP_HIP_GROUPS pins the
+    count): iterates, gains, counters and the gather records must be the same bits for 1, 2, 3 and 5 groups."""
+    if kind == "cartpole_box":
+        p, B, spread = api.cartpole_problem(api.SOLVER_IPDDP, True), 1000, np.array([0.1, 0.3, 0.1, 0.1])
+    elif kind == "unicycle_box_ball":
+        p, B, spread = api.unicycle_problem(api.SOLVER_IPDDP, 100, True), 700, 0.05 * np.ones(3)
+    else:
+        p, B, spread = api.cartpole_problem(api.SOLVER_CLDDP, True), 1000, np.array([0.1, 0.3, 0.1, 0.1])
+    x0 = api.batch_x0(p, B, 20261014, spread)
+    U0 = api.batch_U0(p, B)
+    ref = None
+    for ng in (1, 2, 3, 5):
+        monkeypatch.setenv("CDDP_HIP_GROUPS", str(ng))
+        hs = api.HipBatchSolver(p, B)
+        assert hs.num_groups() == ng
+        hs.set_initial(x0, U0)
+        st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); Vx, Vxx = hs.value()
+        S, Y, G = hs.duals() if p.c.solver == api.SOLVER_IPDDP else (None, None, None)
+        hs.close()
+        cur = [r[f].copy() for f in r.dtype.names] + [X, U, K, k, Vx, Vxx] + ([S, Y, G] if S is not None else [])
+        cur.append(np.array([st.sweeps, st.rollouts, st.traj_iterations, st.rollout_steps, st.n_converged]))
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert np.array_equal(a, b), (kind, ng)
