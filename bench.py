@@ -109,6 +109,7 @@ def make_problem(api, workload, solver):
     return p, spread, desc
 
 
+STRONG_GLOBAL_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 16384, "manip7": 32768}
 DEFAULT_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 2048, "manip7": 4096}
 
 
@@ -151,6 +152,9 @@ def main():
     ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch trajectories per GPU; strong: a fixed global batch (--global-batch or the BASELINE config's) over all GPUs")
+    ap.add_argument("--global-batch", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -163,43 +167,60 @@ def main():
         raise SystemExit("bench.py needs a GPU: the cddp_hip solver core has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    launched_by_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world > 1 or launched_by_torchrun:   # (also with one rank under torchrun: the RCCL path then runs with a size-1 communicator)
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     api = load_api()
     p, spread, desc = make_problem(api, args.workload, args.solver)
-    B = args.batch if args.batch > 0 else DEFAULT_BATCH[args.workload]
     sh = load_module("cddp_sharding", "sharding.py")
-    # one seeded global batch (seed = 20260928 + config_index); rank r owns the
-    # contiguous block [r*B, (r+1)*B) -- weak scaling: B trajectories per GPU.
-    x0_global = api.batch_x0(p, B * world, 20260928 + 1, spread)
-    lo, hi = sh.partition(B * world, world, rank)
+    # one seeded global batch (seed = 20260928 + config_index), block-partitioned over the ranks.
+    #   weak   (default): B trajectories per GPU, global batch B * world;
+    #   strong          : the config's fixed global batch (BASELINE configs 4 / 5: 16384 / 32768) cut into `world` blocks,
+    #                     uneven blocks padded in the gather (sharding.shard_capacity).
+    if args.scaling == "strong":
+        global_batch = args.global_batch if args.global_batch > 0 else STRONG_GLOBAL_BATCH[args.workload]
+    else:
+        global_batch = (args.batch if args.batch > 0 else DEFAULT_BATCH[args.workload]) * world
+    lo, hi = sh.partition(global_batch, world, rank)
+    B = hi - lo
+    cap = sh.shard_capacity(global_batch, world)
+    x0_global = api.batch_x0(p, global_batch, 20260928 + 1, spread)
     x0 = np.ascontiguousarray(x0_global[lo:hi])
+    del x0_global
     U0 = api.batch_U0(p, B)
     hs = api.HipBatchSolver(p, B, device=local_rank)
     hs.set_initial(x0, U0)                     # H2D once; solve() restarts from the device-resident copy
-    rec_dtype = torch.uint8
-    rec_local = torch.empty(B * 16, dtype=rec_dtype, device="cuda")
+    # The path's single collective goes through the C-ABI (cddp_hip_allgather_results = ncclAllGather on a communicator
+    # made with cddp_hip_comm_init); torch.distributed only carries the 128-byte unique id, the barrier and the timing max.
+    comm = None
+    if dist is not None:
+        idt = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm = api.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+    gathered_dev = torch.empty(world * cap * 16, dtype=torch.uint8, device="cuda")
 
     def step():
         st = hs.solve()
-        hs.write_gather_records_device(rec_local.data_ptr())
-        gathered = sh.allgather_records(rec_local, world, dist)   # the single RCCL collective of the path
-        return st, gathered
+        hs.allgather_results(comm, world, cap, gathered_dev.data_ptr())   # the single RCCL collective of the path
+        return st, gathered_dev
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     # One untimed solve with every kernel class bracketed by hipEvents (the "classes" block below and the choice of
     # the dominant class); the timed steps then bracket ONLY the dominant class's launches -- every event costs ~5 us
     # of queue time, 6 per iteration are ~5 % of a C2 solve.
-    if world > 1:   # communicator set-up (lazy in RCCL) is not part of a step, whatever --warmup says
-        sh.allgather_records(rec_local, world, dist)
+    if comm is not None:   # connection set-up (lazy in RCCL) is not part of a step, whatever --warmup says
+        hs.allgather_results(comm, world, cap, gathered_dev.data_ptr())
     hs.set_timing_detail(api.TIMING_ALL)
     prof = hs.solve()
     sweep_dominates = prof.backward_ms >= prof.forward_ms
@@ -216,7 +237,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
@@ -288,23 +309,26 @@ def main():
         },
         "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
     }
-    rec = sh.unpack_records(gathered.cpu().numpy())
-    assert len(rec) == B * world
+    rec = sh.compact_records(gathered.cpu().numpy(), global_batch, world)   # drops (and checks) the padding of uneven shards
+    assert len(rec) == global_batch
+    assert np.array_equal(rec["iterations"][lo:hi], res["iterations"]) and np.array_equal(rec["status"][lo:hi], res["status"])
     gathered_converged = int(np.sum((rec["status"] == api.STATUS_OPTIMAL) | (rec["status"] == api.STATUS_ACCEPTABLE)))
     status_hist = {api.STATUS_STRINGS[int(s)]: int(c) for s, c in zip(*np.unique(res["status"], return_counts=True))}
-    total_traj = B * world * args.steps
+    total_traj = global_batch * args.steps
     out = {
         "metric": "trajectories_per_sec", "value": total_traj / dt_max, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": {"cartpole": "BASELINE config[1]: ", "unicycle": "BASELINE config[2]: ", "quadrotor": "BASELINE config[3] (one GPU share): ", "manip7": "BASELINE config[4] (one GPU share): "}.get(args.workload, "experiment: ") + desc +
                         ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
-            "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": B * world, "nx": p.nx, "nu": p.nu,
+            "solver": args.solver.upper(), "batch_per_gpu": B, "global_batch": global_batch, "nx": p.nx, "nu": p.nu,
             "horizon": p.N, "path_dual_dim": m, "max_iterations": int(p.options.max_iterations),
             "line_search": "%s rule, %d alphas" % ("best-merit (enable_parallel)" if p.options.enable_parallel else "first-success", int(p.options.ls_max_iterations)),
-            "sharding": "independent trajectories, block partition, one RCCL all-gather of 16-B records per step",
+            "sharding": "independent trajectories, block partition (%s scaling), one RCCL all-gather of 16-B records per step through "
+                        "the C-ABI (cddp_hip_allgather_results)" % args.scaling,
+            "collective": "ncclAllGather, %d x %d records" % (world, cap) if comm is not None else "none (1 GPU, device copy)",
         },
         "solve": {
             "mean_iterations": float(np.mean(res["iterations"])), "max_iterations": int(np.max(res["iterations"])),
@@ -314,6 +338,8 @@ def main():
         },
         "roofline": roofline,
     }
+    if comm is not None:
+        api.comm_destroy(comm)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(api, p, x0, U0)
     elif rank == 0:
@@ -321,7 +347,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     hs.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

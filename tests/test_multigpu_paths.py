@@ -1,0 +1,56 @@
+"""Multi-GPU code paths that can run on the 1-GPU lease: the C-ABI's RCCL all-gather with a size-1 communicator, and
+bench.py under torch.distributed.run with one rank (nccl backend, the communicator exchange, the device-side gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_allgather_size1_communicator(api):
+    import torch
+    p = api.pendulum_problem(api.SOLVER_IPDDP, True, 30)
+    B = 70
+    x0 = api.batch_x0(p, B, 20260928, [0.1, 0.1])
+    hs = api.HipBatchSolver(p, B); hs.set_initial(x0); hs.solve()
+    ref = hs.results()
+    comm = api.comm_init(api.comm_unique_id(), 1, 0, 0)          # ncclCommInitRank through the C-ABI
+    try:
+        for cap, c in ((B, comm), (B + 7, comm), (B + 7, None)):   # exact fit / padded, RCCL and the world-1 device copy
+            dev = torch.zeros(cap * 16, dtype=torch.uint8, device="cuda")
+            hs.allgather_results(c, 1, cap, dev.data_ptr())
+            rec = np.frombuffer(dev.cpu().numpy().tobytes(), dtype=api.GATHER_DTYPE)
+            assert np.array_equal(rec["iterations"][:B], ref["iterations"]) and np.array_equal(rec["status"][:B], ref["status"])
+            assert np.array_equal(rec["final_objective"][:B], ref["final_objective"])
+            assert np.all(rec["status"][B:] == -1) and np.all(rec["iterations"][B:] == -1)
+        with pytest.raises(api.HipError):
+            hs.allgather_results(comm, 1, B - 1, dev.data_ptr())    # capacity below the batch
+        with pytest.raises(api.HipError):
+            hs.allgather_results(None, 2, B, dev.data_ptr())        # NULL communicator with world > 1
+    finally:
+        api.comm_destroy(comm)
+        hs.close()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_under_torchrun_one_rank(scaling):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: process group on nccl, unique-id broadcast,
+    cddp_hip_comm_init, the RCCL all-gather inside the timed step -- everything of the N > 1 path except a second GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--workload", "pendulum", "--no-cpu-baseline", "--scaling", scaling] + (["--global-batch", "1000"] if scaling == "strong" else ["--batch", "512"])
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["scaling"] == scaling
+    assert j["config"]["collective"].startswith("ncclAllGather")
+    assert j["solve"]["gathered_records"] == j["config"]["global_batch"] == (1000 if scaling == "strong" else 512)
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
