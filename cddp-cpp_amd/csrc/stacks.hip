@@ -1,10 +1,15 @@
-// Stack-fed Riccati backward sweep (cddp_hip_backward_stacks): host plugins evaluate arbitrary
-// DynamicalSystem / Objective subclasses and hand over the (N x batch) derivative stacks; the GPU
-// streams them once, one trajectory per lane, batch-minor so every wavefront load is a coalesced
-// 512-B transaction.  This kernel is the pure HBM-streaming form of K2:
-//   bytes read / trajectory  = 8 * (N*(nx^2 + nx*nu + nx + nu + nx^2 + nu^2 + nu*nx) + nx + nx^2)
-//   bytes written            = 8 * (N*(nu*nx + nu + nx + nx^2) + nx + nx^2 + 2)
-// Reference: ipddp_solver.cpp:1048-1118 (reg_in_value != 0) / clddp_solver.cpp:79-204 without bounds.
+// Stack-fed mode (host plugins): arbitrary DynamicalSystem / Objective / Constraint subclasses cannot run on the GPU, so
+// the caller evaluates them on the host and hands over the (N x batch) derivative stacks; the GPU runs the backward
+// pass on them -- the north_star's "coalesced HBM loads of the (N x batch) stacks of f_x/f_u/l_xx/l_uu/l_ux".
+// Bound to a handle (cddp_hip_stacks_*): device buffers persist between calls, stacks are uploaded once per iterate,
+// the sweep is ONE launch.  Three branches of the reference:
+//   CDDP_HIP_STACKS_CLDDP      clddp_solver.cpp:79-204 without bounds (PD test, dense inverse, reg only in the factor)
+//   CDDP_HIP_STACKS_IPDDP      ipddp_solver.cpp:1048-1118 (unconstrained: LDLT, reg kept in the value update)
+//   CDDP_HIP_STACKS_IPDDP_PATH ipddp_solver.cpp:1355-1568 (path constraints condensed: y, s, g, G_x, G_u stacks; gains of
+//                              the slack / dual directions, linear-policy rollout, dS, dY, computeMaxStepSizes :2939-2988)
+// One trajectory per lane, batch-minor stacks [t][e][Bp]: every wavefront load is one coalesced 512-B row.
+//   bytes read / trajectory  = 8 * (N*(nx^2 + nx*nu + nx + nu + nx^2 + nu^2 + nu*nx [+ 3m + m*nx + m*nu]) + nx + nx^2)
+//   bytes written            = 8 * (N*(nu*nx + nu + nx + nx^2 [+ 2m + 2m*nx]) + nx + nx^2 + 2)
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -15,29 +20,44 @@
 
 using namespace cddp_dev;
 
+extern "C" int cddp_hip_internal_set_error(int code, const char *msg);   // capi.hip (thread-local last-error string)
+
 namespace {
 
+constexpr double kEpsSlackS = 1e-10;          // EPS_SLACK            ipddp_solver.cpp:36
+constexpr double kMaxRatioS = 1e6;            // MAX_BARRIER_RATIO    ipddp_solver.cpp:38
+
 struct StackArgs {
-  int B, Bp, N, reg_in_value;
-  double reg;
+  int B, Bp, N, branch;
+  double reg_factor, reg_max, tau_min;
+  const double *reg_in, *mu;                   // [Bp]
   const double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *VxN, *VxxN;
+  const double *y, *s, *g, *Gx, *Gu;           // path-constraint stacks (branch IPDDP_PATH)
   double *K, *k, *Vx, *Vxx, *dV;
+  double *ky, *Ky, *ks, *Ks, *dX;              // IPDDP_PATH outputs
+  double *scal;                                // [6][Bp]: reg used, inf_du, inf_pr, inf_comp, step_norm, (unused)
+  double *caps;                                // [2][Bp]: alpha_pr_max, alpha_du_max
   int *ok;
 };
 
 #define SI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)a.Bp + (size_t)b)
 
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+DEV double clipp(double num, double den) { return dclamp(num / den, 0.0, kMaxRatioS); }
+DEV double clips(double num, double den) { return dclamp(num / den, -kMaxRatioS, kMaxRatioS); }
+
+// One backward sweep at regularisation `reg`; returns false where the reference's backwardPass returns false.
+template <int NX, int NU, int M>
+DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, double &dV1, double &inf_du, double &inf_pr,
+               double &inf_comp, double &step_norm) {
+  constexpr int MM = M > 0 ? M : 1;
   const int N = a.N;
+  const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP;
   double Vx[NX], Vxx[NX * NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) Vx[i] = a.VxN[(size_t)i * a.Bp + b];
 #pragma unroll
   for (int i = 0; i < NX * NX; ++i) Vxx[i] = a.VxxN[(size_t)i * a.Bp + b];
-  if (a.reg_in_value) {   // V_xx = symmetrize(V_xx)  (ipddp_solver.cpp:992)
+  if (ip) {   // V_xx = symmetrize(V_xx)  (ipddp_solver.cpp:992)
     double T[NX * NX];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) T[i] = Vxx[i];
@@ -50,8 +70,10 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
   for (int i = 0; i < NX; ++i) a.Vx[SI(N, NX, i)] = Vx[i];
 #pragma unroll
   for (int i = 0; i < NX * NX; ++i) a.Vxx[SI(N, NX * NX, i)] = Vxx[i];
-  double dV0 = 0.0, dV1 = 0.0;
-  bool ok = true;
+  dV0 = dV1 = 0.0; inf_du = inf_pr = inf_comp = step_norm = 0.0;
+  double norm_Vx = 0.0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
   for (int t = N - 1; t >= 0; --t) {
     double A[NX * NX], Bm[NX * NU], Qx[NX], Qu[NU], Qxx[NX * NX], Quu[NU * NU], Qux[NU * NX];
 #pragma unroll
@@ -68,16 +90,36 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
     for (int i = 0; i < NU * NU; ++i) Quu[i] = a.luu[SI(t, NU * NU, i)];
 #pragma unroll
     for (int i = 0; i < NU * NX; ++i) Qux[i] = a.lux[SI(t, NU * NX, i)];
+    double y[MM], s[MM], g[MM], Gx[MM * NX], Gu[MM * NU];
+    if constexpr (M > 0) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { double s = 0.0;
+      for (int i = 0; i < M; ++i) { y[i] = a.y[SI(t, M, i)]; s[i] = a.s[SI(t, M, i)]; g[i] = a.g[SI(t, M, i)]; }
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s += A[k * NX + i] * Vx[k];
-      Qx[i] = Qx[i] + s; }
+      for (int i = 0; i < M * NX; ++i) Gx[i] = a.Gx[SI(t, M * NX, i)];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) { double s = 0.0;
+      for (int i = 0; i < M * NU; ++i) Gu[i] = a.Gu[SI(t, M * NU, i)];
+      // Q_x = l_x + Q_yx^T y + A^T V_x ; Q_u = l_u + Q_yu^T y + B^T V_x   (:1391-1392)
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s += Bm[k * NU + i] * Vx[k];
-      Qu[i] = Qu[i] + s; }
+      for (int i = 0; i < NX; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s1 += Gx[r * NX + i] * y[r];
+        Qx[i] = Qx[i] + s1; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s1 += Gu[r * NU + i] * y[r];
+        Qu[i] = Qu[i] + s1; }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { double s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) s1 += A[k * NX + i] * Vx[k];
+      Qx[i] = Qx[i] + s1; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) s1 += Bm[k * NU + i] * Vx[k];
+      Qu[i] = Qu[i] + s1; }
     double T1[NX * NX], T2[NU * NX], P1[NX * NX], P2[NU * NX], P3[NU * NU];
     mm_tn<NX, NX, NX>(A, Vxx, T1);
     mm_tn<NU, NX, NX>(Bm, Vxx, T2);
@@ -91,7 +133,113 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
 #pragma unroll
     for (int i = 0; i < NU * NU; ++i) Quu[i] = Quu[i] + P3[i];
     double kk[NU], KK[NU * NX];
-    if (a.reg_in_value) {
+    // ---------------------------------------------------------------- gains
+    double YS[MM], rp[MM], rhat[MM], ssafe[MM], Sir[MM];
+    if constexpr (M > 0) {
+      const double s_floor = dmax(mu * 1e-3, kEpsSlackS);
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        ssafe[r] = dmax(s[r], s_floor);
+        YS[r] = clipp(y[r], ssafe[r]);
+        rp[r] = g[r] + s[r];
+        const double rc = y[r] * s[r] - mu;
+        rhat[r] = y[r] * rp[r] - rc;
+        Sir[r] = clips(rhat[r], ssafe[r]);
+        inf_pr = dmax(inf_pr, fabs(rp[r])); inf_comp = dmax(inf_comp, fabs(rc));
+      }
+      // Q_uu_reg = sym(Q_uu) + Q_yu^T YS Q_yu + reg I ; rhs = [Q_u + Q_yu^T S^-1 rhat | Q_ux + Q_yu^T YS Q_yx]   (:1424-1448)
+      double Qr[NU * NU], rhs_u[NU], rhs_x[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += (Gu[r * NU + i] * YS[r]) * Gu[r * NU + c];
+          Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + s1;
+        }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s1 += Gu[r * NU + i] * Sir[r];
+        rhs_u[i] = Qu[i] + s1;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s2 += (Gu[r * NU + i] * YS[r]) * Gx[r * NX + c];
+          rhs_x[i * NX + c] = Qux[i * NX + c] + s2;
+        }
+      }
+      if (NU == 1) {
+        kk[0] = -ldlt1_solve(Qr[0], rhs_u[0]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Qr[0], rhs_x[c]);
+      } else {
+        LDLTd<NU> f;
+        f.compute(Qr, NU);
+        if (!f.ok) return false;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = rhs_u[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        for (int c = 0; c < NX; ++c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = rhs_x[i * NX + c];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+        }
+      }
+      // slack / dual direction gains (:1458-1472)
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double temp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) temp += Gu[r * NU + i] * kk[i];
+        a.ky[SI(t, M, r)] = clips(rhat[r] + y[r] * temp, ssafe[r]);
+        a.ks[SI(t, M, r)] = (-rp[r]) - temp;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < NU; ++i) s2 += Gu[r * NU + i] * KK[i * NX + c];
+          const double inner = Gx[r * NX + c] + s2;
+          a.Ky[SI(t, M * NX, r * NX + c)] = dclamp(YS[r] * inner, -kMaxRatioS, kMaxRatioS);
+          a.Ks[SI(t, M * NX, r * NX + c)] = (-Gx[r * NX + c]) - s2;
+        }
+      }
+      // condensed terms into the Q blocks (:1488-1492): un-regularised, un-symmetrised Q_uu
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] = rhs_u[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s1 += Gx[r * NX + i] * Sir[r];
+        Qx[i] = Qx[i] + s1; }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += (Gx[r * NX + i] * YS[r]) * Gx[r * NX + c];
+          Qxx[i * NX + c] = Qxx[i * NX + c] + s1; }
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) Qux[i] = rhs_x[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) { double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += (Gu[r * NU + i] * YS[r]) * Gu[r * NU + c];
+          Quu[i * NU + c] = Quu[i * NU + c] + s1; }
+    } else if (ip) {
+      // unconstrained IPDDP: Q_uu = sym(Q_uu) + reg I, kept in the value update (:1084-1101)
       double Qs[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i)
@@ -100,7 +248,7 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
 #pragma unroll
-      for (int i = 0; i < NU; ++i) Quu[i * NU + i] += a.reg;
+      for (int i = 0; i < NU; ++i) Quu[i * NU + i] += reg;
       if (NU == 1) {
         kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
 #pragma unroll
@@ -108,7 +256,7 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
       } else {
         LDLTd<NU> f;
         f.compute(Quu, NU);
-        if (!f.ok) { ok = false; break; }
+        if (!f.ok) return false;
         double col[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) col[i] = Qu[i];
@@ -124,19 +272,20 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
         }
       }
     } else {
+      // CLDDP without bounds: PD test, H = (Q_uu + reg I)^-1, reg only in the factor (clddp_solver.cpp:130-145)
       double Qr[NU * NU], H[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) Qr[i] = Quu[i];
 #pragma unroll
-      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += a.reg;
-      if (min_real_eig<NU>(Qr) <= 0) { ok = false; break; }
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+      if (min_real_eig<NU>(Qr) <= 0) return false;
       inverse_pplu<NU>(Qr, H);
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
-        double s = 0.0;
+        double s1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) s += (-H[i * NU + j]) * Qu[j];
-        kk[i] = s;
+        for (int j = 0; j < NU; ++j) s1 += (-H[i * NU + j]) * Qu[j];
+        kk[i] = s1;
 #pragma unroll
         for (int c = 0; c < NX; ++c) {
           double s2 = 0.0;
@@ -152,10 +301,10 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
     for (int i = 0; i < NU * NX; ++i) a.K[SI(t, NU * NX, i)] = KK[i];
     double Quuk[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) { double s = 0.0;
+    for (int i = 0; i < NU; ++i) { double s1 = 0.0;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) s += Quu[i * NU + j] * kk[j];
-      Quuk[i] = s; }
+      for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+      Quuk[i] = s1; }
     { double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int i = 0; i < NU; ++i) { s0 += Qu[i] * kk[i]; s1 += kk[i] * Quuk[i]; }
@@ -163,7 +312,7 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
     double KtQ[NX * NU];
     mm_tn<NX, NU, NU>(KK, Quu, KtQ);
     double Vn[NX * NX];
-    if (a.reg_in_value) {   // IPDDP association order (ipddp_solver.cpp:1098-1101)
+    if (ip) {   // IPDDP association order (ipddp_solver.cpp:1098-1101, 1497-1500)
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         double p = 0.0, q = 0.0, r = 0.0;
@@ -180,7 +329,7 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
           for (int j = 0; j < NU; ++j) { p += KK[j * NX + i] * Qux[j * NX + c]; q += Qux[j * NX + i] * KK[j * NX + c]; r += KtQ[i * NU + j] * KK[j * NX + c]; }
           Vn[i * NX + c] = ((Qxx[i * NX + c] + p) + q) + r;
         }
-    } else {                // CLDDP association order (clddp_solver.cpp:188-191)
+    } else {    // CLDDP association order (clddp_solver.cpp:188-191)
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         double p = 0.0, q = 0.0, r = 0.0;
@@ -206,24 +355,101 @@ __global__ __launch_bounds__(64) void k_backward_stacks(StackArgs a) {
     for (int i = 0; i < NX; ++i) a.Vx[SI(t, NX, i)] = Vx[i];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) a.Vxx[SI(t, NX * NX, i)] = Vxx[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
   }
-  a.dV[(size_t)0 * a.Bp + b] = dV0;
-  a.dV[(size_t)1 * a.Bp + b] = dV1;
-  a.ok[b] = ok ? 1 : 0;
+  if (!ip) {   // CLDDP scales inf_du (clddp_solver.cpp:194-201); the caller passes termination_scaling_max_factor in tau_min
+    double sc = a.tau_min;
+    sc = dmax(sc, norm_Vx / (double)(N * NX)) / sc;
+    inf_du = inf_du / sc;
+  }
+  return true;
 }
 
-thread_local std::string g_serr;
+template <int NX, int NU, int M>
+__global__ __launch_bounds__(64) void k_stacks_backward(StackArgs a) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  const double mu = a.mu ? a.mu[b] : 0.0;
+  double reg = a.reg_in[b];
+  double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  bool ok = false;
+  for (;;) {   // "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111 (reg_factor <= 1: a single attempt)
+    ok = sweep<NX, NU, M>(a, b, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
+    if (ok || !(a.reg_factor > 1.0)) break;
+    reg = dmin(reg * a.reg_factor, a.reg_max);
+    if (reg >= a.reg_max) break;
+  }
+  a.ok[b] = ok ? 1 : 0;
+  a.dV[(size_t)0 * a.Bp + b] = dV0; a.dV[(size_t)1 * a.Bp + b] = dV1;
+  a.scal[(size_t)0 * a.Bp + b] = reg; a.scal[(size_t)1 * a.Bp + b] = inf_du; a.scal[(size_t)2 * a.Bp + b] = inf_pr;
+  a.scal[(size_t)3 * a.Bp + b] = inf_comp; a.scal[(size_t)4 * a.Bp + b] = step_norm;
+  double apr = 1.0, adu = 1.0;
+  if constexpr (M > 0) {
+    if (ok) {   // rolloutLinearPolicy from dx0 = 0 (:1511-1520), dS / dY (:1522-1532), computeMaxStepSizes (:2939-2988)
+      const int N = a.N;
+      const double tau = dmax(a.tau_min, 1.0 - mu);
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      for (int t = 0; t < N; ++t) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a.dX[SI(t, NX, i)] = dx[i];
+        for (int r = 0; r < M; ++r) {
+          double p = 0.0, q = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) { p += a.Ks[SI(t, M * NX, r * NX + j)] * dx[j]; q += a.Ky[SI(t, M * NX, r * NX + j)] * dx[j]; }
+          const double ds = a.ks[SI(t, M, r)] + p;
+          const double dy = dclamp(a.ky[SI(t, M, r)] + q, -kMaxRatioS, kMaxRatioS);
+          if (ds < 0.0) apr = dmin(apr, -tau * a.s[SI(t, M, r)] / ds);
+          if (dy < 0.0) adu = dmin(adu, -tau * a.y[SI(t, M, r)] / dy);
+        }
+        double du[NU], dxn[NX];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double p = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) p += a.K[SI(t, NU * NX, i * NX + j)] * dx[j];
+          du[i] = a.k[SI(t, NU, i)] + p; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { double p = 0.0, q = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) p += a.fx[SI(t, NX * NX, i * NX + j)] * dx[j];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) q += a.fu[SI(t, NX * NU, i * NU + j)] * du[j];
+          dxn[i] = (p + q) + 0.0; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a.dX[SI(N, NX, i)] = dx[i];
+      apr = dclamp(apr, 0.0, 1.0); adu = dclamp(adu, 0.0, 1.0);
+    }
+  }
+  a.caps[(size_t)0 * a.Bp + b] = apr; a.caps[(size_t)1 * a.Bp + b] = adu;
+}
+
 int sfail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-  g_serr = buf;
-  std::fprintf(stderr, "cddp_hip_backward_stacks: %s\n", buf);
-  return code;
+  return cddp_hip_internal_set_error(code, buf);
 }
+#define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return sfail(-10, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-template <int NX, int NU>
+template <int NX, int NU, int M>
 void launch(const StackArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL((k_backward_stacks<NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((k_stacks_backward<NX, NU, M>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+}
+typedef void (*LaunchFn)(const StackArgs &, hipStream_t);
+
+LaunchFn pick(int nx, int nu, int m) {
+#define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch<X, U, MM>;
+  PICK(1, 1, 0) PICK(1, 1, 1) PICK(1, 1, 2) PICK(2, 1, 0) PICK(2, 1, 2) PICK(4, 1, 0) PICK(4, 1, 2)
+  PICK(3, 2, 0) PICK(3, 2, 4) PICK(3, 2, 5) PICK(6, 3, 0) PICK(6, 3, 6)
+  PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0)
+#undef PICK
+  return nullptr;
 }
 
 void to_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
@@ -239,70 +465,217 @@ void from_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
 
 }  // namespace
 
-extern "C" int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon, const double *fx,
-                                        const double *fu, const double *lx, const double *lu, const double *lxx,
-                                        const double *luu, const double *lux, const double *VxN, const double *VxxN,
-                                        double reg, int reg_in_value, double *K, double *k, double *Vx, double *Vxx,
-                                        double *dV, int32_t *ok, double *kernel_ms) {
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(-20, "no HIP device available (no CPU fallback)");
-  if (hipSetDevice(device) != hipSuccess) return sfail(-10, "hipSetDevice failed");
-  void (*fn)(const StackArgs &, hipStream_t) = nullptr;
-#define PICK(X, U) if (nx == X && nu == U) fn = &launch<X, U>;
-  PICK(1, 1) PICK(2, 1) PICK(4, 1) PICK(3, 2) PICK(6, 3) PICK(12, 4) PICK(13, 4) PICK(14, 7)
-#undef PICK
-  if (!fn) return sfail(-4, "no stack-fed instantiation for nx=%d nu=%d", nx, nu);
-  const int B = batch, Bp = (batch + 63) / 64 * 64, N = horizon;
-  struct In { const double *src; int T, E; const double **dst; };
-  StackArgs a;
-  a.B = B; a.Bp = Bp; a.N = N; a.reg = reg; a.reg_in_value = reg_in_value;
-  In ins[] = {{fx, N, nx * nx, &a.fx}, {fu, N, nx * nu, &a.fu}, {lx, N, nx, &a.lx}, {lu, N, nu, &a.lu},
-              {lxx, N, nx * nx, &a.lxx}, {luu, N, nu * nu, &a.luu}, {lux, N, nu * nx, &a.lux},
-              {VxN, 1, nx, &a.VxN}, {VxxN, 1, nx * nx, &a.VxxN}};
+struct cddp_hip_stack_handle {
+  int device = 0, B = 0, Bp = 0, nx = 0, nu = 0, m = 0, N = 0;
+  LaunchFn fn = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<void *> allocs;
-  auto cleanup = [&]() { for (void *q : allocs) hipFree(q); };
+  StackArgs a{};
+  double *d_reg = nullptr, *d_mu = nullptr;
+  bool have_dyn = false, have_con = false, swept = false;
+  double last_ms = 0.0;
   std::vector<double> tmp;
-  for (In &in : ins) {
-    size_t n = (size_t)in.T * in.E * Bp;
-    tmp.assign(n, 0.0);
-    to_soa(in.src, tmp.data(), B, Bp, in.T, in.E);
-    void *q = nullptr;
-    if (hipMalloc(&q, n * 8) != hipSuccess) { cleanup(); return sfail(-10, "hipMalloc failed"); }
-    allocs.push_back(q);
-    hipMemcpy(q, tmp.data(), n * 8, hipMemcpyHostToDevice);
-    *in.dst = (const double *)q;
-  }
-  struct Out { double **dev; double *host; int T, E; };
-  Out outs[] = {{&a.K, K, N, nu * nx}, {&a.k, k, N, nu}, {&a.Vx, Vx, N + 1, nx}, {&a.Vxx, Vxx, N + 1, nx * nx}, {&a.dV, dV, 1, 2}};
-  for (Out &o : outs) {
-    size_t n = (size_t)o.T * o.E * Bp;
-    void *q = nullptr;
-    if (hipMalloc(&q, n * 8) != hipSuccess) { cleanup(); return sfail(-10, "hipMalloc failed"); }
-    hipMemset(q, 0, n * 8);
-    allocs.push_back(q);
-    *o.dev = (double *)q;
-  }
-  { void *q = nullptr; if (hipMalloc(&q, Bp * 4) != hipSuccess) { cleanup(); return sfail(-10, "hipMalloc failed"); } allocs.push_back(q); a.ok = (int *)q; }
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  fn(a, nullptr);                       // warm-up launch (code object load)
-  hipDeviceSynchronize();
-  const int reps = 5;
-  hipEventRecord(e0, nullptr);
-  for (int r = 0; r < reps; ++r) fn(a, nullptr);
-  hipEventRecord(e1, nullptr);
-  if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return sfail(-10, "kernel failed: %s", hipGetErrorString(hipGetLastError())); }
-  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-  if (kernel_ms) *kernel_ms = ms / reps;
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  for (Out &o : outs) {
-    if (!o.host) continue;
-    size_t n = (size_t)o.T * o.E * Bp;
-    tmp.resize(n);
-    hipMemcpy(tmp.data(), *o.dev, n * 8, hipMemcpyDeviceToHost);
-    from_soa(tmp.data(), o.host, B, Bp, o.T, o.E);
-  }
-  if (ok) hipMemcpy(ok, a.ok, B * 4, hipMemcpyDeviceToHost);
-  cleanup();
+};
+
+namespace {
+int salloc(cddp_hip_stack_handle *h, double **p, size_t n) {
+  void *q = nullptr;
+  SCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(double)));
+  SCHK(hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(double), h->stream));
+  h->allocs.push_back(q);
+  *p = (double *)q;
   return 0;
 }
+int upload(cddp_hip_stack_handle *h, const double *src, double *dst, int T, int E) {
+  if (!src) return 0;
+  const size_t n = (size_t)T * E * h->Bp;
+  h->tmp.assign(n, 0.0);
+  to_soa(src, h->tmp.data(), h->B, h->Bp, T, E);
+  SCHK(hipMemcpyAsync(dst, h->tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCHK(hipStreamSynchronize(h->stream));   // tmp is reused by the next upload
+  return 0;
+}
+int download(cddp_hip_stack_handle *h, const double *src, double *dst, int T, int E) {
+  if (!dst) return 0;
+  const size_t n = (size_t)T * E * h->Bp;
+  h->tmp.resize(n);
+  SCHK(hipMemcpy(h->tmp.data(), src, n * sizeof(double), hipMemcpyDeviceToHost));
+  from_soa(h->tmp.data(), dst, h->B, h->Bp, T, E);
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m, int horizon, cddp_hip_stack_handle **out) {
+  if (!out) return sfail(-1, "null argument");
+  if (batch <= 0 || nx <= 0 || nu <= 0 || m < 0 || horizon <= 0) return sfail(-1, "bad dimensions batch=%d nx=%d nu=%d m=%d N=%d", batch, nx, nu, m, horizon);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(-20, "no HIP device available: the stack-fed sweep has no CPU fallback");
+  if (device < 0 || device >= ndev) return sfail(-1, "device %d out of range (%d devices)", device, ndev);
+  LaunchFn fn = pick(nx, nu, m);
+  if (!fn) return sfail(-4, "no stack-fed instantiation for nx=%d nu=%d m=%d", nx, nu, m);
+  SCHK(hipSetDevice(device));
+  cddp_hip_stack_handle *h = new cddp_hip_stack_handle();
+  h->device = device; h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->nx = nx; h->nu = nu; h->m = m; h->N = horizon; h->fn = fn;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return sfail(-10, "hipStreamCreate failed"); }
+  hipEventCreate(&h->e0); hipEventCreate(&h->e1);
+  const size_t Bp = h->Bp, N = horizon;
+  StackArgs &a = h->a;
+  a.B = batch; a.Bp = h->Bp; a.N = horizon;
+  struct { double **p; size_t n; } bufs[] = {
+      {(double **)&a.fx, N * nx * nx * Bp}, {(double **)&a.fu, N * nx * nu * Bp}, {(double **)&a.lx, N * nx * Bp}, {(double **)&a.lu, N * nu * Bp},
+      {(double **)&a.lxx, N * nx * nx * Bp}, {(double **)&a.luu, N * nu * nu * Bp}, {(double **)&a.lux, N * nu * nx * Bp},
+      {(double **)&a.VxN, (size_t)nx * Bp}, {(double **)&a.VxxN, (size_t)nx * nx * Bp},
+      {(double **)&a.y, N * m * Bp}, {(double **)&a.s, N * m * Bp}, {(double **)&a.g, N * m * Bp}, {(double **)&a.Gx, N * m * nx * Bp}, {(double **)&a.Gu, N * m * nu * Bp},
+      {&a.K, N * nu * nx * Bp}, {&a.k, N * nu * Bp}, {&a.Vx, (N + 1) * nx * Bp}, {&a.Vxx, (N + 1) * nx * nx * Bp}, {&a.dV, 2 * Bp},
+      {&a.ky, N * m * Bp}, {&a.Ky, N * m * nx * Bp}, {&a.ks, N * m * Bp}, {&a.Ks, N * m * nx * Bp}, {&a.dX, (N + 1) * nx * Bp},
+      {&a.scal, 6 * Bp}, {&a.caps, 2 * Bp}, {&h->d_reg, Bp}, {&h->d_mu, Bp}};
+  for (auto &bf : bufs) { int rc = salloc(h, bf.p, bf.n); if (rc) { cddp_hip_stacks_destroy(h); return rc; } }
+  { void *q = nullptr; if (hipMalloc(&q, Bp * sizeof(int)) != hipSuccess) { cddp_hip_stacks_destroy(h); return sfail(-10, "hipMalloc failed"); } h->allocs.push_back(q); a.ok = (int *)q; }
+  a.reg_in = h->d_reg; a.mu = h->d_mu;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { cddp_hip_stacks_destroy(h); return sfail(-10, "device initialisation failed"); }
+  *out = h;
+  return 0;
+}
+
+int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void *q : h->allocs) hipFree(q);
+  if (h->e0) { hipEventDestroy(h->e0); hipEventDestroy(h->e1); }
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double *fu, const double *lx, const double *lu,
+                        const double *lxx, const double *luu, const double *lux, const double *VxN, const double *VxxN) {
+  if (!h) return sfail(-1, "null handle");
+  SCHK(hipSetDevice(h->device));
+  if (!h->have_dyn && !(fx && fu && lx && lu && lxx && luu && lux && VxN && VxxN))
+    return sfail(-1, "the first cddp_hip_set_stacks call must supply every stack (later calls may pass NULL to keep one)");
+  const int N = h->N, nx = h->nx, nu = h->nu;
+  struct { const double *src; const double *dst; int T, E; } items[] = {
+      {fx, h->a.fx, N, nx * nx}, {fu, h->a.fu, N, nx * nu}, {lx, h->a.lx, N, nx}, {lu, h->a.lu, N, nu}, {lxx, h->a.lxx, N, nx * nx},
+      {luu, h->a.luu, N, nu * nu}, {lux, h->a.lux, N, nu * nx}, {VxN, h->a.VxN, 1, nx}, {VxxN, h->a.VxxN, 1, nx * nx}};
+  for (auto &it : items) { int rc = upload(h, it.src, (double *)it.dst, it.T, it.E); if (rc) return rc; }
+  h->have_dyn = true; h->swept = false;
+  return 0;
+}
+
+int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, const double *s, const double *g, const double *Gx, const double *Gu) {
+  if (!h) return sfail(-1, "null handle");
+  if (h->m <= 0) return sfail(-1, "this stack handle was created without path constraints (m = 0)");
+  SCHK(hipSetDevice(h->device));
+  if (!h->have_con && !(y && s && g && Gx && Gu)) return sfail(-1, "the first cddp_hip_set_constraint_stacks call must supply y, s, g, G_x and G_u");
+  const int N = h->N, nx = h->nx, nu = h->nu, m = h->m;
+  struct { const double *src; const double *dst; int T, E; } items[] = {
+      {y, h->a.y, N, m}, {s, h->a.s, N, m}, {g, h->a.g, N, m}, {Gx, h->a.Gx, N, m * nx}, {Gu, h->a.Gu, N, m * nu}};
+  for (auto &it : items) { int rc = upload(h, it.src, (double *)it.dst, it.T, it.E); if (rc) return rc; }
+  h->have_con = true; h->swept = false;
+  return 0;
+}
+
+int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hip_options *opt, const double *reg, const double *mu,
+                             int retry, int32_t *ok) {
+  if (!h || !opt || !reg) return sfail(-1, "null argument");
+  if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH) return sfail(-2, "unknown stack-fed branch %d", branch);
+  if (!h->have_dyn) return sfail(-1, "cddp_hip_set_stacks must be called before cddp_hip_stacks_backward");
+  if (branch == CDDP_HIP_STACKS_IPDDP_PATH) {
+    if (h->m <= 0) return sfail(-1, "the path-constrained branch needs a handle created with m > 0");
+    if (!h->have_con) return sfail(-1, "cddp_hip_set_constraint_stacks must be called before the path-constrained sweep");
+    if (!mu) return sfail(-1, "the path-constrained branch needs the barrier parameter mu[b]");
+    for (int b = 0; b < h->B; ++b) if (!(mu[b] > 0.0)) return sfail(-2, "barrier parameter of trajectory %d must be positive (got %g)", b, mu[b]);
+  } else if (h->m > 0) {
+    return sfail(-1, "this handle carries path-constraint stacks (m = %d): use CDDP_HIP_STACKS_IPDDP_PATH, or a handle with m = 0", h->m);
+  }
+  for (int b = 0; b < h->B; ++b) if (!(reg[b] >= 0.0)) return sfail(-2, "regularisation of trajectory %d must be non-negative (got %g)", b, reg[b]);
+  SCHK(hipSetDevice(h->device));
+  SCHK(hipMemcpyAsync(h->d_reg, reg, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+  if (mu) SCHK(hipMemcpyAsync(h->d_mu, mu, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+  StackArgs a = h->a;
+  a.branch = branch;
+  a.mu = mu ? h->d_mu : nullptr;
+  a.reg_factor = retry ? opt->reg_update_factor : 0.0;
+  a.reg_max = opt->reg_max_value;
+  a.tau_min = (branch == CDDP_HIP_STACKS_CLDDP) ? opt->termination_scaling_max_factor : opt->barrier_min_fraction_to_boundary;
+  SCHK(hipEventRecord(h->e0, h->stream));
+  h->fn(a, h->stream);                              // ONE launch
+  SCHK(hipEventRecord(h->e1, h->stream));
+  SCHK(hipGetLastError());
+  if (ok) SCHK(hipMemcpyAsync(ok, a.ok, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+  SCHK(hipStreamSynchronize(h->stream));
+  float ms = 0; hipEventElapsedTime(&ms, h->e0, h->e1);
+  h->last_ms = ms; h->swept = true;
+  return 0;
+}
+
+double cddp_hip_stacks_last_kernel_ms(cddp_hip_stack_handle *h) { return h ? h->last_ms : -1.0; }
+
+int cddp_hip_stacks_get_gains(cddp_hip_stack_handle *h, double *K, double *k, double *Vx, double *Vxx, double *dV) {
+  if (!h) return sfail(-1, "null handle");
+  if (!h->swept) return sfail(-1, "no sweep result: call cddp_hip_stacks_backward first");
+  SCHK(hipSetDevice(h->device));
+  const int N = h->N, nx = h->nx, nu = h->nu;
+  int rc;
+  if ((rc = download(h, h->a.K, K, N, nu * nx))) return rc;
+  if ((rc = download(h, h->a.k, k, N, nu))) return rc;
+  if ((rc = download(h, h->a.Vx, Vx, N + 1, nx))) return rc;
+  if ((rc = download(h, h->a.Vxx, Vxx, N + 1, nx * nx))) return rc;
+  if ((rc = download(h, h->a.dV, dV, 1, 2))) return rc;
+  return 0;
+}
+
+int cddp_hip_stacks_get_constraint_gains(cddp_hip_stack_handle *h, double *k_y, double *K_y, double *k_s, double *K_s, double *dX) {
+  if (!h) return sfail(-1, "null handle");
+  if (!h->swept || h->m <= 0) return sfail(-1, "no path-constrained sweep result");
+  SCHK(hipSetDevice(h->device));
+  const int N = h->N, nx = h->nx, m = h->m;
+  int rc;
+  if ((rc = download(h, h->a.ky, k_y, N, m))) return rc;
+  if ((rc = download(h, h->a.Ky, K_y, N, m * nx))) return rc;
+  if ((rc = download(h, h->a.ks, k_s, N, m))) return rc;
+  if ((rc = download(h, h->a.Ks, K_s, N, m * nx))) return rc;
+  if ((rc = download(h, h->a.dX, dX, N + 1, nx))) return rc;
+  return 0;
+}
+
+int cddp_hip_stacks_get_scalars(cddp_hip_stack_handle *h, double *reg, double *inf_du, double *inf_pr, double *inf_comp, double *step_norm,
+                                double *alpha_pr_max, double *alpha_du_max) {
+  if (!h) return sfail(-1, "null handle");
+  if (!h->swept) return sfail(-1, "no sweep result: call cddp_hip_stacks_backward first");
+  SCHK(hipSetDevice(h->device));
+  std::vector<double> sc((size_t)6 * h->Bp), cp((size_t)2 * h->Bp);
+  SCHK(hipMemcpy(sc.data(), h->a.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+  SCHK(hipMemcpy(cp.data(), h->a.caps, cp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double *outs[5] = {reg, inf_du, inf_pr, inf_comp, step_norm};
+  for (int i = 0; i < 5; ++i) if (outs[i]) for (int b = 0; b < h->B; ++b) outs[i][b] = sc[(size_t)i * h->Bp + b];
+  if (alpha_pr_max) for (int b = 0; b < h->B; ++b) alpha_pr_max[b] = cp[b];
+  if (alpha_du_max) for (int b = 0; b < h->B; ++b) alpha_du_max[b] = cp[(size_t)h->Bp + b];
+  return 0;
+}
+
+// One-shot form of round 1 (kept for callers that sweep a set of stacks exactly once): create, upload, ONE launch,
+// download, destroy.  reg is a scalar, no retry.
+int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon, const double *fx, const double *fu, const double *lx,
+                             const double *lu, const double *lxx, const double *luu, const double *lux, const double *VxN,
+                             const double *VxxN, double reg, int reg_in_value, double *K, double *k, double *Vx, double *Vxx,
+                             double *dV, int32_t *ok, double *kernel_ms) {
+  if (!(fx && fu && lx && lu && lxx && luu && lux && VxN && VxxN)) return sfail(-1, "null input stack");
+  cddp_hip_stack_handle *h = nullptr;
+  int rc = cddp_hip_stacks_create(device, batch, nx, nu, 0, horizon, &h);
+  if (rc) return rc;
+  cddp_hip_options opt; cddp_hip_default_options(&opt);
+  std::vector<double> regv((size_t)batch, reg);
+  rc = cddp_hip_set_stacks(h, fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN);
+  if (!rc) rc = cddp_hip_stacks_backward(h, reg_in_value ? CDDP_HIP_STACKS_IPDDP : CDDP_HIP_STACKS_CLDDP, &opt, regv.data(), nullptr, 0, ok);
+  if (!rc) rc = cddp_hip_stacks_get_gains(h, K, k, Vx, Vxx, dV);
+  if (!rc && kernel_ms) *kernel_ms = cddp_hip_stacks_last_kernel_ms(h);
+  cddp_hip_stacks_destroy(h);
+  return rc;
+}
+
+}  // extern "C"

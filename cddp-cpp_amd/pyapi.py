@@ -430,7 +430,9 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
-    "cddp_hip_backward_stacks", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
+    "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_constraint_stacks",
+    "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
+    "cddp_hip_stacks_get_scalars", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 
@@ -574,6 +576,74 @@ class HipBatchSolver:
 
     def write_gather_records_device(self, device_ptr):
         self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
+
+
+STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH = 0, 1, 2
+
+
+class HipStackSolver:
+    """Stack-fed backward pass bound to a handle (include/cddp_hip.h, "stack-fed mode"): the caller's host plugins fill the
+    (N x batch) derivative stacks, the GPU sweeps them.  Arrays are batch-major numpy: fx (B,N,nx,nx), fu (B,N,nx,nu), lx (B,N,nx),
+    lu (B,N,nu), lxx (B,N,nx,nx), luu (B,N,nu,nu), lux (B,N,nu,nx), VxN (B,nx), VxxN (B,nx,nx); y, s, g (B,N,m), Gx (B,N,m,nx),
+    Gu (B,N,m,nu)."""
+
+    def __init__(self, batch, nx, nu, m, horizon, device=0):
+        self.lib = load_hip()
+        self.B, self.nx, self.nu, self.m, self.N = batch, nx, nu, m, horizon
+        self.h = C.c_void_p()
+        self.lib.cddp_hip_stacks_last_kernel_ms.restype = C.c_double
+        self._check(self.lib.cddp_hip_stacks_create(device, batch, nx, nu, m, horizon, C.byref(self.h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipError("cddp_hip error %d: %s" % (rc, self.lib.cddp_hip_last_error().decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.cddp_hip_stacks_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stacks(self, fx=None, fu=None, lx=None, lu=None, lxx=None, luu=None, lux=None, VxN=None, VxxN=None):
+        a = [(_arr(v) if v is not None else None) for v in (fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN)]
+        self._check(self.lib.cddp_hip_set_stacks(self.h, *[_ptr(v) for v in a]))
+
+    def set_constraint_stacks(self, y=None, s=None, g=None, Gx=None, Gu=None):
+        a = [(_arr(v) if v is not None else None) for v in (y, s, g, Gx, Gu)]
+        self._check(self.lib.cddp_hip_set_constraint_stacks(self.h, *[_ptr(v) for v in a]))
+
+    def backward(self, branch, options, reg, mu=None, retry=False):
+        reg = _arr(np.broadcast_to(np.asarray(reg, dtype=np.float64), (self.B,)))
+        mu = _arr(np.broadcast_to(np.asarray(mu, dtype=np.float64), (self.B,))) if mu is not None else None
+        ok = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.cddp_hip_stacks_backward(self.h, int(branch), C.byref(options), _ptr(reg), _ptr(mu), 1 if retry else 0,
+                                                      ok.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ok
+
+    def kernel_ms(self):
+        return float(self.lib.cddp_hip_stacks_last_kernel_ms(self.h))
+
+    def gains(self):
+        B, N, nx, nu = self.B, self.N, self.nx, self.nu
+        K = np.zeros((B, N, nu, nx)); k = np.zeros((B, N, nu)); Vx = np.zeros((B, N + 1, nx)); Vxx = np.zeros((B, N + 1, nx, nx)); dV = np.zeros((B, 2))
+        self._check(self.lib.cddp_hip_stacks_get_gains(self.h, _ptr(K), _ptr(k), _ptr(Vx), _ptr(Vxx), _ptr(dV)))
+        return K, k, Vx, Vxx, dV
+
+    def constraint_gains(self):
+        B, N, nx, m = self.B, self.N, self.nx, self.m
+        ky = np.zeros((B, N, m)); Ky = np.zeros((B, N, m, nx)); ks = np.zeros((B, N, m)); Ks = np.zeros((B, N, m, nx)); dX = np.zeros((B, N + 1, nx))
+        self._check(self.lib.cddp_hip_stacks_get_constraint_gains(self.h, _ptr(ky), _ptr(Ky), _ptr(ks), _ptr(Ks), _ptr(dX)))
+        return ky, Ky, ks, Ks, dX
+
+    def scalars(self):
+        names = ("reg", "inf_du", "inf_pr", "inf_comp", "step_norm", "alpha_pr_max", "alpha_du_max")
+        a = [np.zeros(self.B) for _ in names]
+        self._check(self.lib.cddp_hip_stacks_get_scalars(self.h, *[_ptr(v) for v in a]))
+        return dict(zip(names, a))
 
 
 def hip_backward_stacks(fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN, reg, reg_in_value, device=0):

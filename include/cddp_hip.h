@@ -416,16 +416,49 @@ int cddp_hip_batch(cddp_hip_handle *h);
 int cddp_hip_num_groups(cddp_hip_handle *h);
 
 /* ---- stack-fed mode (host plugins) ---------------------------------------
- * Arbitrary DynamicalSystem/Objective subclasses cannot run on the GPU.  In stack-fed mode
- * the caller evaluates them on the host and hands over the (N x batch) derivative stacks;
- * the GPU runs the Riccati sweep on them (reference precompute: cddp_solver_base.cpp:319-394).
- * Layout: batch-major, fx[b][t][i][j] = A_t = I + dt*f_x, fu[b][t][i][j] = B_t = dt*f_u,
- * lx[b][t][i], lu[b][t][j], lxx[b][t][i][i'], luu[b][t][j][j'], lux[b][t][j][i];
- * VxN[b][i], VxxN[b][i][i'] = terminal cost gradient / Hessian.
- * Runs the unconstrained Gauss-Newton sweep (ipddp_solver.cpp:1048-1118 when
- * reg_in_value!=0, clddp_solver.cpp:79-204 without bounds otherwise) with regularisation
- * `reg`, writes K (B*N*nu*nx), k (B*N*nu), Vx (B*(N+1)*nx), Vxx (B*(N+1)*nx*nx),
- * dV (B*2), ok (B).  Host pointers. */
+ * Arbitrary DynamicalSystem / Objective / Constraint subclasses (e.g. the user-defined QuadraticScalarSystem of
+ * tests/cddp_core/test_ipddp_solver.cpp:291-346) cannot run on the GPU.  In stack-fed mode the caller evaluates them
+ * on the host and hands over the (N x batch) derivative stacks the reference precomputes per backward pass
+ * (cddp_solver_base.cpp:319-394, ipddp_solver.cpp:2145-2250); the GPU runs the backward pass on them.  The forward
+ * rollout needs the plugin's f(x, u) and therefore stays with the host.
+ * A stack handle owns its device buffers: upload the stacks of an iterate once, sweep (one launch), read the results.
+ * Layout: batch-major host arrays, fx[b][t][i][j] = A_t = I + dt*f_x, fu[b][t][i][j] = B_t = dt*f_u,
+ * lx[b][t][i], lu[b][t][j], lxx[b][t][i][i'], luu[b][t][j][j'], lux[b][t][j][i]; VxN[b][i], VxxN[b][i][i'] = terminal cost
+ * gradient / Hessian; path constraints stacked in std::map (name) order: y, s, g [b][t][r] (g = evaluate - upper bound),
+ * Gx[b][t][r][i], Gu[b][t][r][j]. */
+typedef struct cddp_hip_stack_handle cddp_hip_stack_handle;
+enum cddp_hip_stacks_branch {
+  CDDP_HIP_STACKS_CLDDP = 0,      /* clddp_solver.cpp:79-204 without control bounds                    */
+  CDDP_HIP_STACKS_IPDDP = 1,      /* ipddp_solver.cpp:1048-1118 (no constraints)                       */
+  CDDP_HIP_STACKS_IPDDP_PATH = 2  /* ipddp_solver.cpp:1355-1568 (path constraints; handle with m > 0)  */
+};
+int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m /* total path dual dim, 0 = none */, int horizon,
+                           cddp_hip_stack_handle **out);
+int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h);
+/* Upload the dynamics / cost stacks of the current iterate.  The first call must supply all of them; later calls may
+ * pass NULL for stacks that did not change (e.g. constant cost Hessians). */
+int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double *fu, const double *lx, const double *lu,
+                        const double *lxx, const double *luu, const double *lux, const double *VxN, const double *VxxN);
+/* Upload the condensation inputs of the path-constrained branch (same NULL rule). */
+int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, const double *s, const double *g,
+                                   const double *Gx, const double *Gu);
+/* One backwardPass on the uploaded stacks.  reg[b] = context.regularization_ per trajectory; mu[b] = barrier parameter
+ * (path branch; NULL otherwise); retry != 0 adds the "increase regularisation and retry" loop of
+ * cddp_solver_base.cpp:93-111 (options->reg_update_factor / reg_max_value).  ok[b] (optional) = 1 where the sweep succeeded. */
+int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hip_options *options, const double *reg,
+                             const double *mu, int retry, int32_t *ok);
+/* hipEvent time of the last sweep launch [ms]. */
+double cddp_hip_stacks_last_kernel_ms(cddp_hip_stack_handle *h);
+/* K (B*N*nu*nx), k (B*N*nu), Vx (B*(N+1)*nx), Vxx (B*(N+1)*nx*nx), dV (B*2); any may be NULL. */
+int cddp_hip_stacks_get_gains(cddp_hip_stack_handle *h, double *K, double *k, double *Vx, double *Vxx, double *dV);
+/* Path branch: k_y, k_s (B*N*m), K_y, K_s (B*N*m*nx) and the linear-policy rollout dX (B*(N+1)*nx), ipddp_solver.cpp:1458-1520. */
+int cddp_hip_stacks_get_constraint_gains(cddp_hip_stack_handle *h, double *k_y, double *K_y, double *k_s, double *K_s, double *dX);
+/* Per-trajectory scalars of the sweep (B each, any may be NULL): regularisation used, inf_du, inf_pr, inf_comp, step_norm
+ * and computeMaxStepSizes' (alpha_pr_max, alpha_du_max) (ipddp_solver.cpp:2939-2988; 1 without path constraints). */
+int cddp_hip_stacks_get_scalars(cddp_hip_stack_handle *h, double *reg, double *inf_du, double *inf_pr, double *inf_comp,
+                                double *step_norm, double *alpha_pr_max, double *alpha_du_max);
+/* One-shot unconstrained form (create + upload + one launch + download + destroy): Gauss-Newton sweep of
+ * ipddp_solver.cpp:1048-1118 when reg_in_value != 0, clddp_solver.cpp:79-204 without bounds otherwise, scalar `reg`. */
 int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
                              const double *fx, const double *fu, const double *lx,
                              const double *lu, const double *lxx, const double *luu,

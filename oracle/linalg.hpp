@@ -25,7 +25,15 @@
 
 namespace oracle {
 
-constexpr int kMatCap = 512;  // max rows*cols of any matrix on the path (m x nx <= 32 x 16)
+// Capacity (rows*cols) of every Mat / Vec.  512 covers any layout on the path (m x nx <= 32 x 16) and is what the parity
+// build uses.  sizeof(Mat) = 8 + 8 * cap: at 512 every std::vector<Vec> trajectory copy of a line-search trial is a
+// >128 KB allocation, i.e. an mmap + page faults per trial, and 256 host threads serialise in the kernel's address-space
+// lock (round 1: 8.3x speed-up on 256 cores).  The timing build of bench.py's cpu_baseline therefore compiles with
+// -DORACLE_MAT_CAP=<the largest matrix of the workload> (a Mat that does not fit aborts, it never truncates).
+#ifndef ORACLE_MAT_CAP
+#define ORACLE_MAT_CAP 512
+#endif
+constexpr int kMatCap = ORACLE_MAT_CAP;
 
 struct Mat {
   int r = 0, c = 0;

@@ -78,3 +78,155 @@ def test_stack_fed_rejects_uninstantiated_shape(api):
     with pytest.raises(api.HipError):
         api.hip_backward_stacks(z(B, N, nx, nx), z(B, N, nx, nu), z(B, N, nx), z(B, N, nu), z(B, N, nx, nx), z(B, N, nu, nu),
                                 z(B, N, nu, nx), z(B, nx), z(B, nx, nx), reg=1e-6, reg_in_value=1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Handle-bound, path-constrained stack-fed mode on USER-DEFINED plugins (round 2)
+# ----------------------------------------------------------------------------------------------------------------------
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "twin"))
+
+
+class QuadraticScalarSystem:
+    """The reference's own user-defined DynamicalSystem (tests/cddp_core/test_ipddp_solver.cpp:291-346): a plant no
+    built-in device model covers.  x+ = x + u + x^2 / 2; getStateJacobian returns 1 + x, getControlJacobian 1."""
+    nx, nu = 1, 1
+    discrete = True
+
+    def step(self, x, u, t):
+        return np.array([x[0] + u[0] + 0.5 * x[0] * x[0]])
+
+    def jac(self, x, u, t):
+        return np.array([[1.0 + x[0]]]), np.array([[1.0]])
+
+
+class TiltedUnicycle:
+    """A second host plugin (nx = 3, nu = 2): unicycle with a state-dependent speed gain -- no device counterpart."""
+    nx, nu = 3, 2
+
+    def f(self, x, u, t):
+        g = 1.0 + 0.1 * np.tanh(x[0])
+        return np.array([g * u[0] * np.cos(x[2]), g * u[0] * np.sin(x[2]), u[1]])
+
+    def jac(self, x, u, t):
+        g = 1.0 + 0.1 * np.tanh(x[0]); dg = 0.1 * (1.0 - np.tanh(x[0]) ** 2)
+        A = np.zeros((3, 3)); B = np.zeros((3, 2))
+        A[0, 0] = dg * u[0] * np.cos(x[2]); A[1, 0] = dg * u[0] * np.sin(x[2])
+        A[0, 2] = -g * u[0] * np.sin(x[2]); A[1, 2] = g * u[0] * np.cos(x[2])
+        B[0, 0] = g * np.cos(x[2]); B[1, 0] = g * np.sin(x[2]); B[2, 1] = 1.0
+        return A, B
+
+
+def _plugin_problem(kind):
+    import cddp_twin as T
+    if kind == "quadratic_scalar_box":
+        return dict(solver="IPDDP", model=QuadraticScalarSystem(), integrator="euler", dt=1.0, N=6, Q=np.zeros((1, 1)), R=1e-2 * np.eye(1),
+                    Qf=10.0 * np.eye(1), xref=[0.3], constraints={"ControlConstraint": T.ControlBox([-0.4], [0.4])},
+                    options=dict(max_iterations=30, tolerance=1e-6, reg_initial_value=1e-6, mu_initial=0.1)), np.array([0.5])
+    if kind == "quadratic_scalar_linear":
+        return dict(solver="IPDDP", model=QuadraticScalarSystem(), integrator="euler", dt=1.0, N=6, Q=np.zeros((1, 1)), R=1e-2 * np.eye(1),
+                    Qf=10.0 * np.eye(1), xref=[0.3], constraints={"StateUpper": T.Linear(np.eye(1), [0.9])},
+                    options=dict(max_iterations=30, tolerance=1e-6, reg_initial_value=1e-6, mu_initial=0.1)), np.array([0.5])
+    if kind == "tilted_unicycle_box_ball":
+        return dict(solver="IPDDP", model=TiltedUnicycle(), integrator="rk4", dt=0.03, N=60, Q=np.zeros((3, 3)), R=0.05 * np.eye(2),
+                    Qf=np.diag([100.0, 100.0, 50.0]), xref=[1.5, 1.5, np.pi / 2],
+                    constraints={"control_limits": T.ControlBox([-1.1, -np.pi], [1.1, np.pi]), "obstacle": T.Ball(0.3, [0.8, 0.8])},
+                    options=dict(max_iterations=40, tolerance=1e-4)), np.array([0.0, 0.0, np.pi / 4])
+    raise KeyError(kind)
+
+
+def _twin_stacks(tw):
+    """What a host-plugin adapter hands to cddp_hip_set_stacks / cddp_hip_set_constraint_stacks for the twin's iterate."""
+    N, nx, nu, m = tw.N, tw.nx, tw.nu, tw.m
+    fx = np.zeros((N, nx, nx)); fu = np.zeros((N, nx, nu)); lx = np.zeros((N, nx)); lu = np.zeros((N, nu))
+    Gx = np.zeros((N, m, nx)); Gu = np.zeros((N, m, nu))
+    for t in range(N):
+        fx[t], fu[t] = tw.lin(t)
+        lx[t], lu[t], lxx, luu, lux = tw.cost_derivs(t)
+        off = 0
+        for _, c in tw.cons:
+            gx, gu = c.jac(tw.X[t], tw.U[t]); Gx[t, off:off + c.dim] = gx; Gu[t, off:off + c.dim] = gu; off += c.dim
+    H = 2.0 * tw.Qf
+    return dict(fx=fx, fu=fu, lx=lx, lu=lu, lxx=np.tile(lxx, (N, 1, 1)), luu=np.tile(luu, (N, 1, 1)), lux=np.tile(lux, (N, 1, 1)),
+                VxN=2.0 * tw.Qf @ (tw.X[N] - tw.xref), VxxN=H, y=tw.Y.copy(), s=tw.S.copy(), g=tw.G.copy(), Gx=Gx, Gu=Gu)
+
+
+@pytest.mark.parametrize("kind", ["quadratic_scalar_box", "quadratic_scalar_linear", "tilted_unicycle_box_ball"])
+def test_constrained_stack_fed_sweep_on_user_plugins(api, kind):
+    """A batch of host-plugin problems through the handle-bound stack-fed mode: at the initial iterate AND at later
+    iterates of the twin's own solve, the GPU sweep (K, k, V_x, V_xx, dV, k_y, K_y, k_s, K_s, dX, inf_*, step caps, the
+    regularisation-retry loop) equals the numpy twin's backward pass on the same stacks (1e-9: numpy BLAS order vs
+    the kernel's scalar loops)."""
+    import cddp_twin as T
+    spec, x0 = _plugin_problem(kind)
+    rng = np.random.default_rng(20261020)
+    B = 5
+    twins = []
+    for b in range(B):
+        tw = T.Twin(dict(spec))
+        xb = x0 + (0.0 if b == 0 else 1.0) * rng.uniform(-0.05, 0.05, size=x0.shape)
+        U0 = np.tile([0.4, 0.1], (tw.N, 1)) if tw.nu == 2 else None
+        tw.set_initial(xb, U0); tw.initialize(); tw.X_lin, tw.U_lin = tw.X, tw.U
+        twins.append(tw)
+    tw0 = twins[0]
+    hs = api.HipStackSolver(B, tw0.nx, tw0.nu, tw0.m, tw0.N)
+    opt = api.default_options()
+    for outer in range(4):          # iterate 0 and three accepted iterates later
+        st = [_twin_stacks(tw) for tw in twins]
+        stack = lambda key: np.stack([s_[key] for s_ in st])
+        hs.set_stacks(stack("fx"), stack("fu"), stack("lx"), stack("lu"), stack("lxx"), stack("luu"), stack("lux"), stack("VxN"), stack("VxxN"))
+        hs.set_constraint_stacks(stack("y"), stack("s"), stack("g"), stack("Gx"), stack("Gu"))
+        reg0 = np.array([tw.reg for tw in twins]); mu = np.array([tw.mu for tw in twins])
+        ok = hs.backward(api.STACKS_IPDDP_PATH, opt, reg0, mu, retry=True)
+        K, k, Vx, Vxx, dV = hs.gains(); ky, Ky, ks, Ks, dX = hs.constraint_gains(); sc = hs.scalars()
+        for b, tw in enumerate(twins):
+            okt = False
+            while not okt:          # the reference's retry loop (cddp_solver_base.cpp:93-111)
+                okt = tw.backward()
+                if not okt:
+                    tw.reg_up()
+                    if tw.reg_limit():
+                        break
+            assert bool(ok[b]) == okt and sc["reg"][b] == tw.reg, (kind, outer, b)
+            if not okt:
+                continue
+            for name, got, ref in (("K", K[b], tw.K_u), ("k", k[b], tw.k_u), ("Vx", Vx[b], tw.Vx), ("Vxx", Vxx[b], tw.Vxx), ("dV", dV[b], tw.dV),
+                                   ("k_y", ky[b], tw.k_y), ("K_y", Ky[b], tw.K_y), ("k_s", ks[b], tw.k_s), ("K_s", Ks[b], tw.K_s), ("dX", dX[b], tw.dX)):
+                assert rel(got, ref) < TOL, (kind, outer, b, name, rel(got, ref))
+            assert rel(sc["inf_du"][b], tw.inf_du) < TOL and rel(sc["inf_pr"][b], tw.inf_pr) < TOL
+            assert rel(sc["inf_comp"][b], tw.inf_comp) < TOL and rel(sc["step_norm"][b], tw.step_norm) < TOL
+            apm, adm = tw.max_step_sizes()
+            assert abs(sc["alpha_pr_max"][b] - apm) < 1e-12 and abs(sc["alpha_du_max"][b] - adm) < 1e-12
+            # the host side of the plugin loop: line search + apply with the twin (f(x, u) only exists on the host)
+            best = tw.line_search()
+            if best["success"]:
+                tw.apply(best); tw.reg_down()
+            else:
+                tw.forward_failure()
+    assert hs.kernel_ms() > 0.0
+    hs.close()
+
+
+def test_stack_handle_argument_checks(api):
+    hs = api.HipStackSolver(3, 1, 1, 2, 4)
+    opt = api.default_options()
+    with pytest.raises(api.HipError):
+        hs.backward(api.STACKS_IPDDP_PATH, opt, 1e-6, 0.1)            # no stacks yet
+    with pytest.raises(api.HipError):
+        hs.set_stacks(fx=np.zeros((3, 4, 1, 1)))                       # first call must supply every stack
+    with pytest.raises(api.HipError):
+        api.HipStackSolver(3, 5, 5, 0, 4)                              # no instantiation
+    z = lambda *sh: np.zeros(sh)
+    hs.set_stacks(np.ones((3, 4, 1, 1)), np.ones((3, 4, 1, 1)), z(3, 4, 1), z(3, 4, 1), np.ones((3, 4, 1, 1)), np.ones((3, 4, 1, 1)), z(3, 4, 1, 1), z(3, 1), np.ones((3, 1, 1)))
+    with pytest.raises(api.HipError):
+        hs.backward(api.STACKS_IPDDP_PATH, opt, 1e-6, 0.1)            # constraint stacks missing
+    with pytest.raises(api.HipError):
+        hs.backward(api.STACKS_IPDDP, opt, 1e-6)                      # handle with m > 0 needs the path branch
+    hs.set_constraint_stacks(np.ones((3, 4, 2)), np.ones((3, 4, 2)), -np.ones((3, 4, 2)), z(3, 4, 2, 1), np.ones((3, 4, 2, 1)))
+    with pytest.raises(api.HipError):
+        hs.backward(api.STACKS_IPDDP_PATH, opt, 1e-6, -1.0)           # non-positive mu
+    ok = hs.backward(api.STACKS_IPDDP_PATH, opt, 1e-6, 0.1)
+    assert ok.all()
+    hs.close()
