@@ -330,6 +330,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   for (int **sp : iscal) DA(*sp, Bp);
   double **tr[] = {&d.t_cost, &d.t_merit, &d.t_theta, &d.t_inf_pr, &d.t_inf_comp, &d.t_apr, &d.t_adu, &d.t_ysmin, &d.t_ysmax};
   for (double **sp : tr) DA(*sp, (size_t)d.n_alphas * Bp);
+  DA(d.sink, kSinkDoubles);
   DA(d.t_success, (size_t)d.n_alphas * Bp);
   DA(d.t_steps, (size_t)d.n_alphas * Bp); DA(d.n_fwd_steps, Bp);
   if (ip && P.n_cons > 0) DA(d.ev, (size_t)d.n_alphas * N * 2 * P.n_cons * Bp);

@@ -48,6 +48,8 @@ struct ProblemDev {
 // the record sits in one or two DRAM / TLB pages instead of E pages Bp*8 bytes apart.
 constexpr int kLS = 64;   // lane stride of the wave-tiled stacks (doubles)
 
+constexpr int kSinkDoubles = 1024 * 64;   // 512 KB
+
 struct DevBuf {
   int B, Bp, N, n_slots, n_alphas, hist_batch, hist_cap, NB;   // NB = Bp / 64 wave tiles
   const ProblemDev *P;
@@ -72,6 +74,7 @@ struct DevBuf {
   // trial records [n_alphas][Bp]
   double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
   double *t_ysmin, *t_ysmax;               // extreme y*s products of the trial (complementarity residual under a new mu)
+  double *sink;                            // [kSinkDoubles] write-only scratch: lanes without a real destination store here, so stores stay unconditional
   int *t_success;
   int *t_steps;                            // [n_alphas][Bp] rollout steps the trial completed before it was abandoned (N = ran through)
   int *n_fwd_steps;                        // [Bp] sum of t_steps over the trials the line-search rule walked (roofline accounting)

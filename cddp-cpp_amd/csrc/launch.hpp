@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "kernels_te.hpp"
+#include "kernels_mfma.hpp"
 
 namespace cddp_dev {
 
@@ -39,6 +40,10 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "lane");
   }
+  static bool mfma_sweep_requested() {   // CDDP_HIP_SWEEP=mfma | coop (default: see the note at the launch site)
+    const char *e = std::getenv("CDDP_HIP_SWEEP");
+    return e && !std::strcmp(e, "mfma");
+  }
   static void derivs(const DevBuf &d, int force, hipStream_t s) {
     if constexpr (kLean) {
       if (d.cst) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
@@ -70,8 +75,19 @@ struct Launcher {
     } else if constexpr (kLean) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-      else if constexpr (Model::NX > 8)   // operands in LDS: the register-resident form spills for nx = 12..14
-        hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else if constexpr (Model::NX > 8) {
+        bool launched = false;
+        if constexpr (Model::NX <= 15 && Model::NU <= 8) {
+          if (mfma_sweep_requested()) {   // one wavefront per trajectory on the f64 matrix core (kernels_mfma.hpp); grid = whole tiles per XCD
+            const dim3 gridW(((d.NB + 7) / 8) * 8 * 64);
+            hipLaunchKernelGGL((k_backward_ipddp_mfma<Model, Cons>), gridW, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+            hipLaunchKernelGGL((k_dx_rollout_wave<Model>), gridW, dim3(64), 0, s, d, force);
+            launched = true;
+          }
+        }
+        if (!launched)   // operands in LDS: the register-resident form spills for nx = 12..14
+          hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      }
       else
         hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);

@@ -1568,6 +1568,8 @@ double cddp_oracle_scaled_inf_du(void *o) { return ((Solver *)o)->computeScaledD
 double cddp_oracle_get_mu(void *o) { return ((Solver *)o)->mu; }
 // libm-noise knob of models.hpp (process-wide): 0 = off (default), 1 = sin / cos results moved by -1 / 0 / +1 ulp
 void cddp_oracle_set_trig_noise(int v) { oracle::trig_noise() = v; }
+// summation-order noise knob of linalg.hpp (process-wide): 0 = off (default), 1 = matrix-product entries moved by <= 1 ulp
+void cddp_oracle_set_matmul_noise(int v) { oracle::matmul_noise() = v; }
 void cddp_oracle_set_inf_du(void *o, double v) { ((Solver *)o)->inf_du = v; }
 void cddp_oracle_set_check_state_stationarity(void *o, int v) { ((Solver *)o)->opt.ipddp_check_state_stationarity = v; }
 

@@ -92,15 +92,29 @@ inline Mat operator*(const Mat &A, double s) { return s * A; }
 inline Mat operator/(const Mat &A, double s) { Mat m(A.r, A.c); for (int i = 0; i < m.size(); ++i) m.a[i] = A.a[i] / s; return m; }
 inline Mat &operator+=(Mat &A, const Mat &B) { assert(A.r == B.r && A.c == B.c); for (int i = 0; i < A.size(); ++i) A.a[i] += B.a[i]; return A; }
 inline Mat &operator-=(Mat &A, const Mat &B) { assert(A.r == B.r && A.c == B.c); for (int i = 0; i < A.size(); ++i) A.a[i] -= B.a[i]; return A; }
+// Summation-order noise knob (test infrastructure, default off): with matmul_noise() != 0 every entry of a matrix product
+// with an inner dimension >= 2 is moved by -1 / 0 / +1 ulp (hash of the value) -- what a different accumulation order
+// (Eigen's vectorised kernels, a matrix-core instruction, FMA contraction) does to a dot product.  The oracle-vs-noisy-
+// oracle decision-flip rate is the yardstick for kernels that cannot keep the reference's summation order
+// (cddp-cpp_amd/csrc/kernels_mfma.hpp; tests/test_mfma_sweep.py).
+inline int &matmul_noise() { static int v = 0; return v; }
+inline double matmul_perturb(double s) {
+  unsigned long long h; static_assert(sizeof(h) == sizeof(s), "");
+  __builtin_memcpy(&h, &s, sizeof(h));
+  h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  switch (h % 3u) { case 0: return s; case 1: return std::nextafter(s, std::numeric_limits<double>::infinity());
+                    default: return std::nextafter(s, -std::numeric_limits<double>::infinity()); }
+}
 // Plain triple loop, k innermost, ascending: sum_k A(i,k) B(k,j).
 inline Mat operator*(const Mat &A, const Mat &B) {
   assert(A.c == B.r);
   Mat m(A.r, B.c);
+  const bool noisy = matmul_noise() != 0 && A.c >= 2;
   for (int i = 0; i < A.r; ++i)
     for (int j = 0; j < B.c; ++j) {
       double s = 0.0;
       for (int k = 0; k < A.c; ++k) s += A(i, k) * B(k, j);
-      m(i, j) = s;
+      m(i, j) = noisy ? matmul_perturb(s) : s;
     }
   return m;
 }

@@ -37,9 +37,16 @@ def flip_rates(api, cases=None):
             r1 = api.oracle_solve_batch(p, x0, U0, X0, n_threads=os.cpu_count() or 8, want_traj=False)[0]
         finally:
             lib.cddp_oracle_set_trig_noise(0)
+        lib.cddp_oracle_set_matmul_noise(1)      # second yardstick: <= 1 ulp on every matrix-product entry (summation order)
+        try:
+            r2 = api.oracle_solve_batch(p, x0, U0, X0, n_threads=os.cpu_count() or 8, want_traj=False)[0]
+        finally:
+            lib.cddp_oracle_set_matmul_noise(0)
         same = (r0["iterations"] == r1["iterations"]) & (r0["status"] == r1["status"])
         work = same & (r0["n_backward"] == r1["n_backward"]) & (r0["n_forward"] == r1["n_forward"])
+        same2 = (r0["iterations"] == r2["iterations"]) & (r0["status"] == r2["status"])
         out[case] = {"B": B, "same_counts": int(same.sum()), "same_work": int(work.sum()),
+                     "matmul_noise_same_counts": int(same2.sum()),
                      "converged_clean": int(np.sum((r0["status"] == 1) | (r0["status"] == 2)))}
     return out
 
