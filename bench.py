@@ -297,18 +297,20 @@ def main():
     n_launch = max(1, st.outer_iterations)
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
     # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
-    # (profiles/r01_i_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
+    # (profiles/r02_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
     traffic = None
     traffic_note = None
     if pmc_key and args.workload == "cartpole" and B == 4096 and ipddp:
-        try:
-            pj = json.load(open(os.path.join(REPO, "profiles", "r01_i_pmc_traffic.json")))
-            # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
-            # depending on the ladder shape the solver picked)
-            traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
-            traffic_note = "profiles/r01_i_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the rollout launches of one solve / outer iterations)"
-        except Exception:
-            traffic = None
+        for fn in ("r02_pmc_traffic.json", "r01_i_pmc_traffic.json"):   # this round's passes; last round's as a fallback
+            try:
+                pj = json.load(open(os.path.join(REPO, "profiles", fn)))
+                # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
+                # depending on the ladder shape the solver picked)
+                traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
+                traffic_note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the rollout launches of one solve / outer iterations)" % fn
+                break
+            except Exception:
+                traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
         "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,

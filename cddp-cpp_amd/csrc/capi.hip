@@ -109,6 +109,11 @@ int pool_put(ProblemDev &P, int &top, const double *src, int n) {
   return off;
 }
 
+// plants with device-side Hessian tensors (dev_models.hpp: Model::kHasHess) -- full DDP (options.use_ilqr = 0) needs them
+bool model_has_hessians(int model) {
+  return model == CDDP_HIP_MODEL_PENDULUM || model == CDDP_HIP_MODEL_CARTPOLE || model == CDDP_HIP_MODEL_UNICYCLE || model == CDDP_HIP_MODEL_LTI;
+}
+
 // cddp_hip_problem -> ProblemDev (constraints sorted by name as std::map iterates)
 int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   std::memset(&P, 0, sizeof(P));
@@ -116,7 +121,8 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (p->nx <= 0 || p->nu <= 0 || p->horizon <= 0 || !(p->dt > 0)) return fail(-2, "bad dimensions nx=%d nu=%d N=%d dt=%g", p->nx, p->nu, p->horizon, p->dt);
   if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
   if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP) return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
-  if (!p->options.use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
+  if (!p->options.use_ilqr && !model_has_hessians(p->model))
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", p->model);
   P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
   P.nx = p->nx; P.nu = p->nu; P.N = p->horizon; P.dt = p->dt; P.opt = p->options;
   P.ls_rule = p->options.enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
@@ -310,6 +316,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   std::memset(&d, 0, sizeof(d));
   const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
+  d.ddp = P.opt.use_ilqr ? 0 : 1;
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
   d.hist_cap = P.opt.max_iterations + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
@@ -476,7 +483,8 @@ static int in_initialize(Inner *h) {
 
 static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if (!h || !opt) return fail(-1, "null argument");
-  if (!opt->use_ilqr) return fail(-3, "use_ilqr=false (second-order dynamics terms) is not supported by the HIP core");
+  if (!opt->use_ilqr && !model_has_hessians(h->P.model))
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", h->P.model);
   HIPCHK(hipSetDevice(h->device));
   double al[CDDP_HIP_MAX_ALPHAS];
   const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);
@@ -486,6 +494,7 @@ static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if ((opt->return_iteration_info != 0) != (h->P.opt.return_iteration_info != 0))
     return fail(-3, "return_iteration_info is fixed at create time (the history buffers are sized by cddp_hip_create)");
   h->P.opt = *opt;
+  h->d.ddp = opt->use_ilqr ? 0 : 1;
   for (int i = 0; i < na; ++i) h->P.alphas[i] = al[i];
   h->P.ls_rule = opt->enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
   HIPCHK(hipMemcpyAsync(h->dP, &h->P, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));

@@ -57,6 +57,44 @@ DEV double dsqrt(double a) { return sqrt(a); }
 DEV double dval(double a) { return a; }
 template <int NP> DEV double dval(const DualN<NP> &a) { return a.v; }
 
+// Second-order forward mode (the reference's autodiff::dual2nd, dynamical_system.cpp:137-217): value, gradient and Hessian
+// w.r.t. NP seeded variables z = [x, u].  Only for the plants whose Hessians the reference takes from autodiff (CartPole)
+// and only evaluated when options.use_ilqr == 0.
+template <int NP>
+struct Dual2N {
+  double v, d[NP], h[NP * NP];
+  DEV Dual2N() {}
+  DEV Dual2N(double x) : v(x) {
+    for (int i = 0; i < NP; ++i) d[i] = 0.0;
+    for (int i = 0; i < NP * NP; ++i) h[i] = 0.0;
+  }
+};
+template <int NP> DEV Dual2N<NP> d2_unary(const Dual2N<NP> &a, double val, double p1, double p2) {
+  Dual2N<NP> r; r.v = val;
+  for (int i = 0; i < NP; ++i) { r.d[i] = p1 * a.d[i]; for (int j = 0; j < NP; ++j) r.h[i * NP + j] = p2 * a.d[i] * a.d[j] + p1 * a.h[i * NP + j]; }
+  return r;
+}
+template <int NP> DEV Dual2N<NP> operator+(const Dual2N<NP> &a, const Dual2N<NP> &b) { Dual2N<NP> r; r.v = a.v + b.v;
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] + b.d[i];
+  for (int i = 0; i < NP * NP; ++i) r.h[i] = a.h[i] + b.h[i]; return r; }
+template <int NP> DEV Dual2N<NP> operator-(const Dual2N<NP> &a, const Dual2N<NP> &b) { Dual2N<NP> r; r.v = a.v - b.v;
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] - b.d[i];
+  for (int i = 0; i < NP * NP; ++i) r.h[i] = a.h[i] - b.h[i]; return r; }
+template <int NP> DEV Dual2N<NP> operator-(const Dual2N<NP> &a) { Dual2N<NP> r; r.v = -a.v;
+  for (int i = 0; i < NP; ++i) r.d[i] = -a.d[i];
+  for (int i = 0; i < NP * NP; ++i) r.h[i] = -a.h[i]; return r; }
+template <int NP> DEV Dual2N<NP> operator*(const Dual2N<NP> &a, const Dual2N<NP> &b) { Dual2N<NP> r; r.v = a.v * b.v;
+  for (int i = 0; i < NP; ++i) {
+    r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    for (int j = 0; j < NP; ++j) r.h[i * NP + j] = a.h[i * NP + j] * b.v + a.d[i] * b.d[j] + a.d[j] * b.d[i] + a.v * b.h[i * NP + j];
+  }
+  return r; }
+template <int NP> DEV Dual2N<NP> operator/(const Dual2N<NP> &a, const Dual2N<NP> &b) {
+  const double inv = 1.0 / b.v;
+  return a * d2_unary<NP>(b, inv, -inv * inv, 2.0 * inv * inv * inv); }
+template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
+template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
+
 // Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
 template <class F, int NX, int NU>
 DEV void ad_jacobian(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
@@ -92,6 +130,15 @@ struct PendulumModel {   // pendulum.cpp:29-66; params: length, mass, damping, g
     Fx[2] = (gravity / length) * cos(x[0]);
     Fx[3] = -damping / (mass * length * length);
     Fu[0] = 0.0; Fu[1] = 1.0 / (mass * length * length);
+  }
+  // Hessian tensors f_xx[i] (NX x NX), f_uu[i] (NU x NU), f_ux[i] (NU x NX), i = output row: state Hessian analytic
+  // (pendulum.cpp:68-78), control Hessian zero (:80-85), cross Hessian = autodiff of the -sin twin (:87-100) = zero
+  static constexpr bool kHasHess = true;
+  DEV static void hess(const double *p, const double *x, const double *, double *Fxx, double *Fuu, double *Fux) {
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
+    Fxx[1 * NX * NX + 0] = -(p[3] / p[0]) * sin(x[0]);
   }
 };
 
@@ -137,6 +184,33 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     Fu[2] = 1.0 / den;
     Fu[3] = -c / (l * den);
   }
+  // the autodiff expression (cartpole.cpp:69-103, with the damping term) on any scalar type
+  template <class S>
+  DEV static void f_ad(const double *p, const S *x, const S *u, S *xd) {
+    const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
+    const S theta = x[1], x_dot = x[2], theta_dot = x[3], force = u[0];
+    const S sin_theta = dsin(theta), cos_theta = dcos(theta);
+    const double total_mass = mc + mp;
+    const S den = S(mc) + S(mp) * sin_theta * sin_theta;
+    xd[0] = x_dot;
+    xd[1] = theta_dot;
+    xd[2] = (force + S(mp) * sin_theta * (S(l) * theta_dot * theta_dot + S(g) * cos_theta)) / den;
+    xd[3] = (-force * cos_theta - S(mp) * S(l) * theta_dot * theta_dot * cos_theta * sin_theta - S(total_mass) * S(g) * sin_theta - S(b) * theta_dot) / (S(l) * den);
+  }
+  // Hessians: the DynamicalSystem defaults (dual2nd through the autodiff path, cartpole.cpp:191-199)
+  static constexpr bool kHasHess = true;
+  DEV static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+    typedef Dual2N<5> D;
+    D xs[4], us[1], xd[4];
+    for (int i = 0; i < 4; ++i) { xs[i] = D(x[i]); xs[i].d[i] = 1.0; }
+    us[0] = D(u[0]); us[0].d[4] = 1.0;
+    f_ad<D>(p, xs, us, xd);
+    for (int i = 0; i < 4; ++i) {
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Fxx[i * 16 + a * 4 + b] = xd[i].h[a * 5 + b];
+      Fuu[i] = xd[i].h[4 * 5 + 4];
+      for (int b = 0; b < 4; ++b) Fux[i * 4 + b] = xd[i].h[4 * 5 + b];
+    }
+  }
 };
 
 // ================================================================================ Unicycle
@@ -155,6 +229,19 @@ struct UnicycleModel {   // unicycle.cpp:28-66
     Fx[1 * 3 + 2] = u[0] * c;
     Fu[0] = c; Fu[1] = 0.0; Fu[2] = s; Fu[3] = 0.0; Fu[4] = 0.0; Fu[5] = 1.0;
   }
+  // state Hessian analytic (unicycle.cpp:68-80), control Hessian zero (:82-89), cross Hessian = the autodiff default on
+  // getContinuousDynamicsAutodiff (:91-107): d2(v cos th)/dv dth = -sin th, d2(v sin th)/dv dth = cos th
+  static constexpr bool kHasHess = true;
+  DEV static void hess(const double *, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+    double s, c; sincos(x[2], &s, &c);
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
+    Fxx[0 * 9 + 2 * 3 + 2] = -u[0] * c;
+    Fxx[1 * 9 + 2 * 3 + 2] = -u[0] * s;
+    Fux[0 * 6 + 0 * 3 + 2] = -s;
+    Fux[1 * 6 + 0 * 3 + 2] = c;
+  }
 };
 
 // ================================================================================ LTI
@@ -163,6 +250,12 @@ template <int NX_, int NU_>
 struct LTIModel {
   static constexpr int ID = CDDP_HIP_MODEL_LTI, NX = NX_, NU = NU_;
   static constexpr bool kDiscrete = true;
+  static constexpr bool kHasHess = true;   // lti_system.cpp:94-115: zero
+  DEV static void hess(const double *, const double *, const double *, double *Fxx, double *Fuu, double *Fux) {
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
+  }
   DEV static void step(const double *p, const double *x, const double *u, double *xn) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -230,6 +323,7 @@ struct QuadrotorDyn {   // quadrotor.cpp:33-104 == :166-219; params: mass, arm, 
 struct QuadrotorModel {
   static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR, NX = 13, NU = 4;
   static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { QuadrotorDyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<QuadrotorDyn, NX, NU>(p, x, u, Fx, Fu);
@@ -265,6 +359,7 @@ struct Quad12Dyn {
 struct Quad12Model {
   static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR_EULER12, NX = 12, NU = 4;
   static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { Quad12Dyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<Quad12Dyn, NX, NU>(p, x, u, Fx, Fu);
@@ -275,6 +370,7 @@ struct Quad12Model {
 struct ManipulatorModel {   // manipulator.cpp:29-70,174-208
   static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR, NX = 6, NU = 3;
   static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
   DEV static void f(const double *, const double *x, const double *u, double *xd) {
     const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
     const double m1 = 1.0, m2 = 1.0, m3 = 0.5;
@@ -348,6 +444,7 @@ struct Manip7Dyn {
 struct Manip7Model {
   static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR7, NX = 14, NU = 7;
   static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { Manip7Dyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<Manip7Dyn, NX, NU>(p, x, u, Fx, Fu);

@@ -74,6 +74,7 @@ struct DevBuf {
   // trial records [n_alphas][Bp]
   double *t_cost, *t_merit, *t_theta, *t_inf_pr, *t_inf_comp, *t_apr, *t_adu;
   double *t_ysmin, *t_ysmax;               // extreme y*s products of the trial (complementarity residual under a new mu)
+  int ddp;                                 // options.use_ilqr == 0: second-order dynamics terms (one-lane sweeps)
   double *sink;                            // [kSinkDoubles] write-only scratch: lanes without a real destination store here, so stores stay unconditional
   int *t_success;
   int *t_steps;                            // [n_alphas][Bp] rollout steps the trial completed before it was abandoned (N = ran through)

@@ -213,6 +213,24 @@ DEV void q_blocks(const ProblemDev *P, const double *A, const double *Bm, const 
   (void)Vx;
 }
 
+// Second-order dynamics terms of full DDP (options.use_ilqr == 0): with F_xx_[t][i] = dt f_xx[i] etc.
+// (cddp_solver_base.cpp:346-356),  for i: Q_xx += w(i) F_xx[i]; Q_ux += w(i) F_ux[i]; Q_uu += w(i) F_uu[i]
+// (ipddp_solver.cpp:1070-1082, 1396-1408; w = V_x of step t + 1).
+template <class Model>
+DEV void ddp_tensor_terms(const ProblemDev *P, const double *x, const double *u, const double *w, double *Qxx, double *Qux, double *Quu) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  if constexpr (Model::kHasHess) {
+    double Fxx[NX * NX * NX], Fuu[NX * NU * NU], Fux[NX * NU * NX];
+    Model::hess(P->mp, x, u, Fxx, Fuu, Fux);
+    const double dt = P->dt;
+    for (int i = 0; i < NX; ++i) {
+      for (int e = 0; e < NX * NX; ++e) Qxx[e] = Qxx[e] + w[i] * (dt * Fxx[i * NX * NX + e]);
+      for (int e = 0; e < NU * NX; ++e) Qux[e] = Qux[e] + w[i] * (dt * Fux[i * NU * NX + e]);
+      for (int e = 0; e < NU * NU; ++e) Quu[e] = Quu[e] + w[i] * (dt * Fuu[i * NU * NU + e]);
+    }
+  }
+}
+
 // ================================================================================ K2 (CLDDP)
 template <class Model>
 __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force, int count_iter) {
@@ -553,6 +571,29 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
     Obj::lx(P, d.xref_traj, t, x, q);
     Obj::lu(P, u, r);
     for (int i = 0; i < NX * NU; ++i) Mm[i] = 0.0;
+    if (!P->opt.use_ilqr) {
+      // full DDP: the current costate iterate stands in for the value gradient (ipddp_solver.cpp:1160-1178):
+      // Q += lambda(i) F_xx[i], M += lambda(i) F_ux[i]^T, R += lambda(i) F_uu[i], then Q, R symmetrised
+      if constexpr (Model::kHasHess) {
+        double lam[NX], Fxx[NX * NX * NX], Fuu[NX * NU * NU], Fux[NX * NU * NX];
+        ld<NX>(d.Lam + (size_t)d.cur[b] * d.planeX + GI(t + 1, NX, 0), kLS, lam);
+        bool fin = true;
+        for (int i = 0; i < NX; ++i) fin = fin && dfinite(lam[i]);
+        if (!fin) for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+        Model::hess(P->mp, x, u, Fxx, Fuu, Fux);
+        const double dt = P->dt;
+        for (int i = 0; i < NX; ++i) {
+          for (int e = 0; e < NX * NX; ++e) Q[e] = Q[e] + lam[i] * (dt * Fxx[i * NX * NX + e]);
+          for (int a = 0; a < NU; ++a) for (int c = 0; c < NX; ++c) Mm[c * NU + a] = Mm[c * NU + a] + lam[i] * (dt * Fux[i * NU * NX + a * NX + c]);
+          for (int e = 0; e < NU * NU; ++e) R[e] = R[e] + lam[i] * (dt * Fuu[i * NU * NU + e]);
+        }
+        double Qs[NX * NX], Rs[NU * NU];
+        for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Qs[i * NX + c] = 0.5 * (Q[i * NX + c] + Q[c * NX + i]);
+        for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) Rs[i * NU + c] = 0.5 * (R[i * NU + c] + R[c * NU + i]);
+        for (int i = 0; i < NX * NX; ++i) Q[i] = Qs[i];
+        for (int i = 0; i < NU * NU; ++i) R[i] = Rs[i];
+      }
+    }
     if constexpr (M > 0) {
       double y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], YS[MM], ypS[MM];
       ld<M>(Yc + GI(t, M, 0), kLS, y);
@@ -959,6 +1000,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
         Qu[i] = acc + s2;
       }
       q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+      if (!o.use_ilqr) ddp_tensor_terms<Model>(P, x, u, Vx, Qxx, Qux, Quu);
 
       double kk[NU], KK[NU * NX];
       double YS[MM], rp[MM], rc[MM], rhat[MM], Sir[MM], s_safe[MM];

@@ -213,6 +213,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_lean(DevBuf d, const Prob
         for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + i] * Vx[k];
         Qu[i] = cu[i] + s2; }
       q_blocks<NX, NU>(Qc, Rc, A, Bm, Vxx, Qxx, Qux, Quu);
+      if (!o.use_ilqr) {   // full DDP: second-order dynamics terms at (x_t, u_t) (fetched only in this mode)
+        double x[NX], u[NU];
+        ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+        ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, u);
+        ddp_tensor_terms<Model>(P, x, u, Vx, Qxx, Qux, Quu);
+      }
       __builtin_amdgcn_sched_barrier(0);   // keep the second group behind the Q-block arithmetic
       load_step2(tp, nxt2);
       PIPELINE_FENCE();

@@ -65,7 +65,7 @@ struct Launcher {
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
     // one-lane-per-trajectory kernels instead (comparison / experiments)
-    const bool lane_sweep = lane_sweep_requested();
+    const bool lane_sweep = lane_sweep_requested() || d.ddp;   // full DDP (use_ilqr = 0): the one-lane kernels carry the tensor terms
     const dim3 gridC((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW);
     if (solver == CDDP_HIP_SOLVER_CLDDP) {
       if (lane_sweep)
@@ -118,7 +118,7 @@ struct Launcher {
         hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
       else {
         if constexpr (kTeCoop && Cons::M > 0) {   // same rollout after the cooperative terminal-equality sweep
-          if (d.te_cst && !lane_sweep_requested()) {
+          if (d.te_cst && !(lane_sweep_requested() || d.ddp)) {
             hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons, true>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
             return;
           }
@@ -135,7 +135,7 @@ struct Launcher {
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
     DevBuf dd = d;
-    if constexpr (kTeCoop && Cons::M > 0) dd.ev_valid = (d.te_cst && !lane_sweep_requested()) ? 1 : 0;
+    if constexpr (kTeCoop && Cons::M > 0) dd.ev_valid = (d.te_cst && !(lane_sweep_requested() || d.ddp)) ? 1 : 0;
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, dd, d.P, d.xref_traj, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, int mode, hipStream_t s) {

@@ -94,7 +94,8 @@ typedef struct cddp_hip_options {
   double tolerance;              /* 1e-5 */
   double acceptable_tolerance;   /* 1e-6 */
   int32_t max_iterations;        /* 1    */
-  int32_t use_ilqr;              /* 1 (only Gauss-Newton is implemented; 0 is rejected)   */
+  int32_t use_ilqr;              /* 1; 0 = full DDP (second-order dynamics terms, ipddp_solver.cpp:1070-1082, 1160-1178,
+                                  * 1396-1408): pendulum, cart-pole, unicycle, LTI; refused for the other plants        */
   int32_t enable_parallel;       /* 0 -> CDDP_HIP_LS_FIRST_SUCCESS, 1 -> BEST_MERIT        */
   int32_t return_iteration_info; /* 0 */
   int32_t warm_start;            /* 0 */

@@ -200,6 +200,7 @@ struct Solver {
   std::vector<Vec> Vx_t;   // value gradient per step (k_lambda_ for IPDDP)
   std::vector<Mat> Vxx_t;  // value Hessian per step (K_lambda_ for IPDDP)
   std::vector<Mat> F_x, F_u;
+  std::vector<std::vector<Mat>> F_xx, F_uu, F_ux;   // dt-scaled Hessian tensors per step (use_ilqr = false)
   double mu = 0.1;
   std::vector<Vec> S, Y, G, dS, dY, k_s, k_y, Lambda, dX, dU;
   std::vector<Mat> K_s, K_y, Gx, Gu;
@@ -871,6 +872,16 @@ struct Solver {
       F_x[t] = dt * Fx; for (int i = 0; i < nx; ++i) F_x[t](i, i) += 1.0;
       F_u[t] = dt * Fu;
     }
+    const bool ddp = !opt.use_ilqr;   // full DDP: second-order dynamics terms (cddp_solver_base.cpp:346-356)
+    if (ddp) {
+      F_xx.assign(N, {}); F_uu.assign(N, {}); F_ux.assign(N, {});
+      for (int t = 0; t < N; ++t) {
+        std::vector<Mat> Fxx, Fuu, Fux;
+        if (!model.hessians(X[t], U[t], t * dt, Fxx, Fuu, Fux)) { std::fprintf(stderr, "oracle: use_ilqr=false needs a plant with restated Hessians\n"); std::abort(); }
+        for (int i = 0; i < nx; ++i) { Fxx[i] = dt * Fxx[i]; Fuu[i] = dt * Fuu[i]; Fux[i] = dt * Fux[i]; }
+        F_xx[t] = Fxx; F_uu[t] = Fuu; F_ux[t] = Fux;
+      }
+    }
     // precomputeConstraintGradients (ipddp_solver.cpp:2145-2250)
     if (hpc) for (int t = 0; t < N; ++t) for (auto &c : cons) { Mat gx, gu; con_jac(c, X[t], gx, gu); Gx[t].setBlock(c.offset, 0, gx); Gu[t].setBlock(c.offset, 0, gu); }
 
@@ -920,6 +931,8 @@ struct Solver {
         Mat Q_xx = l_xx() + A.T() * V_xx * A;
         Mat Q_ux = l_ux() + B.T() * V_xx * A;
         Mat Q_uu = l_uu() + B.T() * V_xx * B;
+        if (ddp)   // :1070-1082
+          for (int i = 0; i < nx; ++i) { Q_xx += V_x(i) * F_xx[t][i]; Q_ux += V_x(i) * F_ux[t][i]; Q_uu += V_x(i) * F_uu[t][i]; }
         Q_uu = symmetrize(Q_uu);
         for (int i = 0; i < nu; ++i) Q_uu(i, i) += reg;
         LDLT ldlt(Q_uu);
@@ -951,6 +964,11 @@ struct Solver {
         const Vec &x = X[t]; const Vec &u = U[t];
         Q[t] = symmetrize(l_xx()); q[t] = l_x(x, t); R[t] = symmetrize(l_uu()); r[t] = l_u(u);
         M[t] = l_ux().T(); A_vec[t] = F_x[t]; B_vec[t] = F_u[t];
+        if (ddp) {   // :1160-1178: the current costate iterate stands in for the value gradient
+          const Vec lambda_next = ((int)Lambda.size() == N + 1 && Lambda[t + 1].size() == nx && Lambda[t + 1].allFinite()) ? Lambda[t + 1] : Vec::Zero(nx);
+          for (int i = 0; i < nx; ++i) { Q[t] += lambda_next(i) * F_xx[t][i]; M[t] += lambda_next(i) * F_ux[t][i].T(); R[t] += lambda_next(i) * F_uu[t][i]; }
+          Q[t] = symmetrize(Q[t]); R[t] = symmetrize(R[t]);
+        }
         if (hpc) {
           const Vec &y = Y[t]; const Vec &s = S[t]; const Vec &g = G[t];
           const Mat &Q_yx = Gx[t]; const Mat &Q_yu = Gu[t];
@@ -1017,6 +1035,8 @@ struct Solver {
       Mat Q_xx = l_xx() + A.T() * V_xx * A;
       Mat Q_ux = l_ux() + B.T() * V_xx * A;
       Mat Q_uu = l_uu() + B.T() * V_xx * B;
+      if (ddp)   // :1396-1408
+        for (int i = 0; i < nx; ++i) { Q_xx += V_x(i) * F_xx[t][i]; Q_ux += V_x(i) * F_ux[t][i]; Q_uu += V_x(i) * F_uu[t][i]; }
       Mat YSinv = Mat::Zero(m, m);
       for (int i = 0; i < m; ++i) { const double s_safe = std::max(s(i), std::max(mu * 1e-3, EPS_SLACK)); YSinv(i, i) = clipPositiveBarrierRatio(y(i), s_safe); }
       const Vec primal_residual = g + s;
@@ -1585,6 +1605,19 @@ int cddp_oracle_dynamics(void *o, const double *x, const double *u, double time,
     if (Fu) for (int i = 0; i < s->nx * s->nu; ++i) Fu[i] = B.a[i];
   }
   return 0;
+}
+// continuous-time Hessian tensors f_xx (nx*nx*nx), f_uu (nx*nu*nu), f_ux (nx*nu*nx); returns 0 for plants without them
+int cddp_oracle_hessians(void *o, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+  Solver *s = (Solver *)o;
+  std::vector<Mat> a, b, c;
+  if (!s->model.hessians(Vec::FromPtr(x, s->nx), Vec::FromPtr(u, s->nu), 0.0, a, b, c)) return 0;
+  const int nx = s->nx, nu = s->nu;
+  for (int i = 0; i < nx; ++i) {
+    for (int e = 0; e < nx * nx; ++e) Fxx[i * nx * nx + e] = a[i].a[e];
+    for (int e = 0; e < nu * nu; ++e) Fuu[i * nu * nu + e] = b[i].a[e];
+    for (int e = 0; e < nu * nx; ++e) Fux[i * nu * nx + e] = c[i].a[e];
+  }
+  return 1;
 }
 int cddp_oracle_constraint_eval(void *o, const double *x, const double *u, double *g, double *gx, double *gu) {
   Solver *s = (Solver *)o;

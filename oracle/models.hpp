@@ -63,6 +63,37 @@ inline Dual cos(const Dual &a) { Dual r; r.v = ocos(a.v); double s = -osin(a.v);
 inline Dual sqrt(const Dual &a) { Dual r; r.v = std::sqrt(a.v); double g = 0.5 / r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
 inline Dual tan(const Dual &a) { Dual r; r.v = std::tan(a.v); double g = 1.0 + r.v * r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
 
+// Second-order forward mode (autodiff::dual2nd of the reference, dynamical_system.cpp:137-217, restated): value, gradient and
+// Hessian w.r.t. up to kD2 seeded variables z = [x, u].  Only used for the plants whose Hessians the reference takes from
+// autodiff (CartPole).
+constexpr int kD2 = 6;
+struct Dual2 {
+  double v = 0.0, d[kD2], h[kD2][kD2];
+  Dual2() { for (int i = 0; i < kD2; ++i) { d[i] = 0.0; for (int j = 0; j < kD2; ++j) h[i][j] = 0.0; } }
+  Dual2(double x) : Dual2() { v = x; }
+};
+// r = phi(a) with phi', phi'' given:  grad = phi' a_d ; hess = phi'' a_d a_d^T + phi' a_h
+inline Dual2 d2_unary(const Dual2 &a, double val, double p1, double p2) {
+  Dual2 r; r.v = val;
+  for (int i = 0; i < kD2; ++i) { r.d[i] = p1 * a.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = p2 * a.d[i] * a.d[j] + p1 * a.h[i][j]; }
+  return r;
+}
+inline Dual2 operator+(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v + b.v; for (int i = 0; i < kD2; ++i) { r.d[i] = a.d[i] + b.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
+inline Dual2 operator-(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v - b.v; for (int i = 0; i < kD2; ++i) { r.d[i] = a.d[i] - b.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] - b.h[i][j]; } return r; }
+inline Dual2 operator-(const Dual2 &a) { Dual2 r; r.v = -a.v; for (int i = 0; i < kD2; ++i) { r.d[i] = -a.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = -a.h[i][j]; } return r; }
+inline Dual2 operator*(const Dual2 &a, const Dual2 &b) {
+  Dual2 r; r.v = a.v * b.v;
+  for (int i = 0; i < kD2; ++i) {
+    r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] * b.v + a.d[i] * b.d[j] + a.d[j] * b.d[i] + a.v * b.h[i][j];
+  }
+  return r;
+}
+inline Dual2 d2_recip(const Dual2 &b) { const double inv = 1.0 / b.v; return d2_unary(b, inv, -inv * inv, 2.0 * inv * inv * inv); }
+inline Dual2 operator/(const Dual2 &a, const Dual2 &b) { return a * d2_recip(b); }
+inline Dual2 sin(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, s, c, -s); }
+inline Dual2 cos(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, c, -s, -c); }
+
 struct Model {
   int id = 0, nx = 0, nu = 0, integrator = 0;
   double dt = 0.0;
@@ -282,6 +313,42 @@ struct Model {
       for (int j = 0; j < nu; ++j) Fu(i, j) = xd[i].d[nx + j];
     }
     Dual::np() = 0;
+  }
+
+  // ------------------------------------------------ continuous-time Hessian tensors f_xx[i] (nx x nx), f_uu[i] (nu x nu),
+  // f_ux[i] (nu x nx), each with the reference's own source: analytic overrides where the model has them, the autodiff
+  // default (dynamical_system.cpp:137-217) on getContinuousDynamicsAutodiff otherwise.  Returns false for plants without
+  // a restated Hessian (use_ilqr = false is then refused).
+  bool hessians(const Vec &x, const Vec &u, double /*time*/, std::vector<Mat> &Fxx, std::vector<Mat> &Fuu, std::vector<Mat> &Fux) const {
+    Fxx.assign(nx, Mat::Zero(nx, nx)); Fuu.assign(nx, Mat::Zero(nu, nu)); Fux.assign(nx, Mat::Zero(nu, nx));
+    switch (id) {
+      case CDDP_HIP_MODEL_PENDULUM: {   // pendulum.cpp:68-85 (state: analytic, control: zero); the cross Hessian is autodiff of the
+        const double length = p[0], gravity = p[3];   // -sin twin (:87-100), whose u-x second derivatives vanish
+        Fxx[1](0, 0) = -(gravity / length) * osin(x(0));
+        return true;
+      }
+      case CDDP_HIP_MODEL_UNICYCLE: {   // unicycle.cpp:68-89 analytic state / zero control Hessian; cross Hessian = autodiff of :91-107
+        Fxx[0](2, 2) = -u(0) * ocos(x(2));
+        Fxx[1](2, 2) = -u(0) * osin(x(2));
+        Fux[0](0, 2) = -osin(x(2));
+        Fux[1](0, 2) = ocos(x(2));
+        return true;
+      }
+      case CDDP_HIP_MODEL_LTI: return true;   // lti_system.cpp:94-115: zero
+      case CDDP_HIP_MODEL_CARTPOLE: {         // cartpole.cpp:191-199 -> DynamicalSystem defaults (dual2nd through the autodiff path)
+        Dual2 xs[4], us[1], xd[4];
+        for (int i = 0; i < 4; ++i) { xs[i] = Dual2(x(i)); xs[i].d[i] = 1.0; }
+        us[0] = Dual2(u(0)); us[0].d[4] = 1.0;
+        cartpole_f<Dual2>(xs, us, xd, true);
+        for (int i = 0; i < 4; ++i) {
+          for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Fxx[i](a, b) = xd[i].h[a][b];
+          Fuu[i](0, 0) = xd[i].h[4][4];
+          for (int b = 0; b < 4; ++b) Fux[i](0, b) = xd[i].h[4][b];
+        }
+        return true;
+      }
+      default: return false;
+    }
   }
 
   void jacobians(const Vec &x, const Vec &u, double time, Mat &Fx, Mat &Fu) const {

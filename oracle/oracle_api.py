@@ -149,6 +149,12 @@ class Oracle:
         self.lib.cddp_oracle_dynamics(self.h, _api()._ptr(x), _api()._ptr(u), C.c_double(time), _api()._ptr(xd), _api()._ptr(xn), _api()._ptr(Fx), _api()._ptr(Fu))
         return xd, xn, Fx, Fu
 
+    def hessians(self, x, u):
+        x = _api()._arr(x); u = _api()._arr(u); nx, nu = self.p.nx, self.p.nu
+        Fxx = np.zeros((nx, nx, nx)); Fuu = np.zeros((nx, nu, nu)); Fux = np.zeros((nx, nu, nx))
+        ok = self.lib.cddp_oracle_hessians(self.h, _api()._ptr(x), _api()._ptr(u), _api()._ptr(Fxx), _api()._ptr(Fuu), _api()._ptr(Fux))
+        return (Fxx, Fuu, Fux) if ok else None
+
     def constraint_eval(self, x, u):
         x = _api()._arr(x); u = _api()._arr(u)
         g = np.zeros(self.m); gx = np.zeros((self.m, self.p.nx)); gu = np.zeros((self.m, self.p.nu))

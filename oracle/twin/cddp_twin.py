@@ -170,6 +170,17 @@ class Pendulum:      # src/dynamics_model/pendulum.cpp:29-66 (double path: +sin,
         B[1, 0] = 1.0 / (self.m * self.l * self.l)
         return A, B
 
+    def hess(self, x, u, t):
+        """getStateHessian / getControlHessian are analytic (pendulum.cpp:68-85); getCrossHessian is NOT overridden, so it is
+        autodiff of getContinuousDynamicsAutodiff (the -sin variant, :87-100) -- whose u-x cross derivatives are zero."""
+        Fxx, Fuu, Fux = _zeros_hess(2, 1)
+        Fxx[1, 0, 0] = -(self.g / self.l) * _sin(x[0])
+        return Fxx, Fuu, Fux
+
+
+def _zeros_hess(nx, nu):
+    return np.zeros((nx, nx, nx)), np.zeros((nx, nu, nu)), np.zeros((nx, nu, nx))
+
 
 class CartPole:      # src/dynamics_model/cartpole.cpp:38-103; Jacobians = exact derivatives of the AUTODIFF twin (:69-93,
     nx, nu = 4, 1    # which carries the damping term the double path omits)
@@ -202,6 +213,22 @@ class CartPole:      # src/dynamics_model/cartpole.cpp:38-103; Jacobians = exact
         J = np.array(self._jac(x[0], x[1], x[2], x[3], u[0]), dtype=np.float64)
         return J[:, :4].copy(), J[:, 4:].copy()
 
+    def hess(self, x, u, t):
+        """DynamicalSystem::getStateHessian / getControlHessian / getCrossHessian (dynamical_system.cpp:137-217): second
+        derivatives of the autodiff path w.r.t. z = [x, u]; blocks H[:n, :n], H[n:, n:], H[n:, :n]."""
+        if getattr(self, "_hess", None) is None:
+            import sympy as sp
+            X, TH, XD, THD, F = sp.symbols("x th xd thd F")
+            sn, cs = sp.sin(TH), sp.cos(TH)
+            den = self.mc + self.mp * sn * sn
+            fx = [XD, THD, (F + self.mp * sn * (self.l * THD * THD + self.g * cs)) / den,
+                  (-F * cs - self.mp * self.l * THD * THD * cs * sn - (self.mc + self.mp) * self.g * sn - self.d * THD) / (self.l * den)]
+            z = [X, TH, XD, THD, F]
+            H = [[[sp.diff(fi, a, b) for b in z] for a in z] for fi in fx]
+            self._hess = sp.lambdify(z, H, "math")
+        H = np.array(self._hess(x[0], x[1], x[2], x[3], u[0]), dtype=np.float64)     # (4, 5, 5)
+        return H[:, :4, :4].copy(), H[:, 4:, 4:].copy(), H[:, 4:, :4].copy()
+
 
 class Unicycle:      # src/dynamics_model/unicycle.cpp:28-66
     nx, nu = 3, 2
@@ -215,6 +242,14 @@ class Unicycle:      # src/dynamics_model/unicycle.cpp:28-66
         B[0, 0] = _cos(x[2]); B[1, 0] = _sin(x[2]); B[2, 1] = 1.0
         return A, B
 
+    def hess(self, x, u, t):
+        """State Hessian analytic (unicycle.cpp:68-80), control Hessian zero (:82-89); the cross Hessian is the autodiff default
+        on getContinuousDynamicsAutodiff (:91-107): d2(v cos th)/dv dth = -sin th, d2(v sin th)/dv dth = cos th."""
+        Fxx, Fuu, Fux = _zeros_hess(3, 2)
+        Fxx[0, 2, 2] = -u[0] * _cos(x[2]); Fxx[1, 2, 2] = -u[0] * _sin(x[2])
+        Fux[0, 0, 2] = -_sin(x[2]); Fux[1, 0, 2] = _cos(x[2])
+        return Fxx, Fuu, Fux
+
 
 class LTI:           # src/dynamics_model/lti_system.cpp:71-92: discrete x+ = A x + B u; Jacobians (A - I)/dt, B/dt
     def __init__(self, A, B, dt):
@@ -227,6 +262,9 @@ class LTI:           # src/dynamics_model/lti_system.cpp:71-92: discrete x+ = A 
 
     def jac(self, x, u, t):
         return (self.A - np.eye(self.nx)) / self.dt, self.B / self.dt
+
+    def hess(self, x, u, t):           # lti_system.cpp:94-115: zero
+        return _zeros_hess(self.nx, self.nu)
 
 
 def discrete_step(model, integrator, dt, x, u, t):
@@ -590,6 +628,17 @@ class Twin:
         A[np.diag_indices(self.nx)] += 1.0
         return A, self.dt * Fu
 
+    def hess_stack(self, t):                   # cddp_solver_base.cpp:346-356: F_xx_[t][i] = dt * Fxx[i], ... (continuous Hessians)
+        Fxx, Fuu, Fux = self.model.hess(self.X[t], self.U[t], t * self.dt)
+        return self.dt * Fxx, self.dt * Fuu, self.dt * Fux
+
+    def add_tensor_terms(self, t, w, Q_xx, Q_ux, Q_uu):
+        """`for i: Q_xx += w(i) Fxx[i]; Q_ux += w(i) Fux[i]; Q_uu += w(i) Fuu[i]` (ipddp_solver.cpp:1070-1082, 1396-1408)."""
+        Fxx, Fuu, Fux = self.hess_stack(t)
+        for i in range(self.nx):
+            Q_xx = Q_xx + w[i] * Fxx[i]; Q_ux = Q_ux + w[i] * Fux[i]; Q_uu = Q_uu + w[i] * Fuu[i]
+        return Q_xx, Q_ux, Q_uu
+
     def cost_derivs(self, t):
         x, u = self.X[t], self.U[t]
         return 2.0 * self.Qdt @ self.err(x, t), 2.0 * self.Rdt @ u, 2.0 * self.Qdt, 2.0 * self.Rdt, np.zeros((self.nu, self.nx))
@@ -684,6 +733,8 @@ class Twin:
                 lx, lu, lxx, luu, lux = self.cost_derivs(t)
                 Q_x = lx + A.T @ V_x; Q_u = lu + B.T @ V_x
                 Q_xx = lxx + A.T @ V_xx @ A; Q_ux = lux + B.T @ V_xx @ A; Q_uu = luu + B.T @ V_xx @ B
+                if not o["use_ilqr"]:
+                    Q_xx, Q_ux, Q_uu = self.add_tensor_terms(t, V_x, Q_xx, Q_ux, Q_uu)
                 Q_uu = sym(Q_uu); Q_uu[np.diag_indices(nu)] += self.reg
                 f = EigenLDLT(Q_uu)
                 if not f.ok:
@@ -710,6 +761,8 @@ class Twin:
             Q_x = lx + Q_yx.T @ y + A.T @ V_x
             Q_u = lu + Q_yu.T @ y + B.T @ V_x
             Q_xx = lxx + A.T @ V_xx @ A; Q_ux = lux + B.T @ V_xx @ A; Q_uu = luu + B.T @ V_xx @ B
+            if not o["use_ilqr"]:
+                Q_xx, Q_ux, Q_uu = self.add_tensor_terms(t, V_x, Q_xx, Q_ux, Q_uu)
             s_safe = np.maximum(s, max(mu * 1e-3, EPS_SLACK))
             YS = np.array([clip_pos(y[i], s_safe[i]) for i in range(m)])
             rp = g + s; rc = y * s - mu; rhat = y * rp - rc

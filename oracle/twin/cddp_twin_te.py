@@ -128,6 +128,12 @@ def backward_term_eq(tw, AB, GJ, V_x, V_xx, hT, HT, inf_pr, inf_comp):
     for t in range(N):
         lx, lu, lxx, luu, lux = tw.cost_derivs(t)
         Q[t] = sym(lxx); q[t] = lx.copy(); R[t] = sym(luu); r[t] = lu.copy(); M[t] = lux.T.copy()
+        if not o["use_ilqr"]:            # :1160-1178: the current costate iterate stands in for the value gradient
+            lam = tw.Lam[t + 1] if (tw.Lam.shape == (N + 1, nx) and np.all(np.isfinite(tw.Lam[t + 1]))) else np.zeros(nx)
+            Fxx, Fuu, Fux = tw.hess_stack(t)
+            for i in range(nx):
+                Q[t] = Q[t] + lam[i] * Fxx[i]; M[t] = M[t] + lam[i] * Fux[i].T; R[t] = R[t] + lam[i] * Fuu[i]
+            Q[t] = sym(Q[t]); R[t] = sym(R[t])
         if m > 0:
             Q_yx, Q_yu = GJ[t]
             y, s, g = tw.Y[t], tw.S[t], tw.G[t]
