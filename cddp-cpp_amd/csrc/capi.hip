@@ -940,6 +940,17 @@ static int in_get_value(Inner *h, double *Vx, double *Vxx) {
   return 0;
 }
 
+static int in_get_linearization(Inner *h, double *A, double *Bm) {
+  if (!h) return fail(-1, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const DevBuf &d = h->d;
+  std::vector<double> buf;
+  if (A) { int rc = fetch(h, d.A, (size_t)d.N * h->P.nx * h->P.nx * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), A, d.B, d.Bp, d.N, h->P.nx * h->P.nx); }
+  if (Bm) { int rc = fetch(h, d.Bm, (size_t)d.N * h->P.nx * h->P.nu * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), Bm, d.B, d.Bp, d.N, h->P.nx * h->P.nu); }
+  return 0;
+}
+
 static int in_get_duals(Inner *h, double *S, double *Y, double *G) {
   if (!h) return fail(-1, "null handle");
   if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m == 0) return fail(-1, "no slack/dual trajectories for this problem");
@@ -1145,6 +1156,7 @@ int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) { if (!r) retur
 int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) { FOR_GROUPS(in_get_trajectory(q, OFF(X, (h->N + 1) * h->nx), OFF(U, h->N * h->nu))); }
 int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) { FOR_GROUPS(in_get_gains(q, OFF(K, h->N * h->nu * h->nx), OFF(k, h->N * h->nu))); }
 int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) { FOR_GROUPS(in_get_value(q, OFF(Vx, (h->N + 1) * h->nx), OFF(Vxx, (h->N + 1) * h->nx * h->nx))); }
+int cddp_hip_get_linearization(cddp_hip_handle *h, double *A, double *Bm) { FOR_GROUPS(in_get_linearization(q, OFF(A, h->N * h->nx * h->nx), OFF(Bm, h->N * h->nx * h->nu))); }
 int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
   FOR_GROUPS(in_get_duals(q, OFF(S, h->N * h->m), OFF(Y, h->N * h->m), OFF(G, h->N * h->m)));
 }

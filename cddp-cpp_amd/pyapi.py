@@ -427,7 +427,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_status_string", "cddp_hip_build_alphas", "cddp_hip_create", "cddp_hip_destroy",
     "cddp_hip_set_stream", "cddp_hip_set_initial", "cddp_hip_initialize", "cddp_hip_backward",
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
-    "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
+    "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_constraint_stacks",
@@ -543,6 +543,12 @@ class HipBatchSolver:
         Vx = np.zeros((self.B, self.p.N + 1, self.p.nx)); Vxx = np.zeros((self.B, self.p.N + 1, self.p.nx, self.p.nx))
         self._check(self.lib.cddp_hip_get_value(self.h, _ptr(Vx), _ptr(Vxx)))
         return Vx, Vxx
+
+    def linearization(self):
+        """A_t = I + dt f_x, B_t = dt f_u of the last backward pass (F_x_, F_u_ of cddp_solver_base.cpp:319-394)."""
+        A = np.zeros((self.B, self.p.N, self.p.nx, self.p.nx)); Bm = np.zeros((self.B, self.p.N, self.p.nx, self.p.nu))
+        self._check(self.lib.cddp_hip_get_linearization(self.h, _ptr(A), _ptr(Bm)))
+        return A, Bm
 
     def duals(self):
         S = np.zeros((self.B, self.p.N, self.m)); Y = np.zeros_like(S); G = np.zeros_like(S)

@@ -367,6 +367,9 @@ int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k);
 /* Value-function expansion along the horizon: Vx B*(N+1)*nx, Vxx B*(N+1)*nx*nx
  * (k_lambda_/K_lambda_ of ipddp_solver.cpp:1050-1104; V_x/V_xx of clddp_solver.cpp:188-192). */
 int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx);
+/* The dynamics linearisation of the last backward pass, i.e. what precomputeDynamicsDerivatives leaves in F_x_ / F_u_
+ * (cddp_solver_base.cpp:319-394): A[b][t] = I + dt f_x(x_t, u_t) (nx x nx, row-major), B[b][t] = dt f_u (nx x nu).  Either may be NULL. */
+int cddp_hip_get_linearization(cddp_hip_handle *h, double *A /* B*N*nx*nx */, double *Bm /* B*N*nx*nu */);
 /* Slack / dual / constraint residual trajectories, B*N*m each (m = total path dual dim). */
 int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G);
 /* Terminal-constraint state (IPDDP): stacked terminal-inequality slack / dual / residual
