@@ -300,6 +300,23 @@ struct Objective {
   // scalar-register doubles); same arithmetic as the pool-reading forms below.
   static constexpr bool kHoist = (NX * NX + NU * NU + NX) <= 40;
   struct Ctx { double Q[kHoist ? NX * NX : 1], R[kHoist ? NU * NU : 1], xr[kHoist ? NX : 1]; const double *Qp, *Rp, *xrp; };
+  // Large plants (not hoisted): the serial kernels stage Q dt | R dt | x_ref in LDS (kStage doubles, stage()) and point the
+  // context there.  Left on the problem pool the compiler hoists the loop-invariant scalar loads out of the step loop anyway,
+  // runs out of SGPRs (nx = 12: 144 + 16 + 12 doubles = 344 SGPRs) and spills them to VGPR lanes: the rollout consumer of
+  // the C4 quadrotor executed 861 v_readlane + 282 v_writelane per step, 30 % of its instruction stream.
+  static constexpr int kStage = kHoist ? 1 : NX * NX + NU * NU + NX;
+  DEV static void stage(const ProblemDev *P, double *lds, int tid, int nthreads) {
+    if constexpr (!kHoist) {
+      const double *Qp = P->pool + P->off_Qdt, *Rp = P->pool + P->off_Rdt, *xp = P->pool + P->off_xref;
+      for (int e = tid; e < NX * NX; e += nthreads) lds[e] = Qp[e];
+      for (int e = tid; e < NU * NU; e += nthreads) lds[NX * NX + e] = Rp[e];
+      for (int e = tid; e < NX; e += nthreads) lds[NX * NX + NU * NU + e] = xp[e];
+    }
+  }
+  DEV static void load_staged(const ProblemDev *P, Ctx &c, const double *lds) {
+    if constexpr (kHoist) load(P, c);
+    else { c.Qp = lds; c.Rp = lds + NX * NX; c.xrp = lds + NX * NX + NU * NU; }
+  }
   DEV static void load(const ProblemDev *P, Ctx &c) {
     c.Qp = P->pool + P->off_Qdt; c.Rp = P->pool + P->off_Rdt; c.xrp = P->pool + P->off_xref;
     if constexpr (kHoist) {

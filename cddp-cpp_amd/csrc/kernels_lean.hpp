@@ -567,6 +567,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
   __shared__ double s_pcost[64];  // the producer lane's terminal cost l_f(x_N)
   __shared__ double s_xN[TERM ? NX * 64 : 1];   // the producer lane's x_N (terminal residual of the trial)
+  __shared__ double s_obj[Obj::kStage];         // Q dt | R dt | x_ref of a large plant (Objective::stage)
   const int lane = threadIdx.x & 63;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
   const int b = blockIdx.x * 64 + lane;
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
   if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in both waves: both leave
   if (producer) { s_pstat[lane] = N + 2; if (lane == 0) { s_prod = 0; s_cons = 0; } }
+  Obj::stage(P, s_obj, (int)threadIdx.x, 128);
   __syncthreads();
   // Inactive lanes (padding, or a trajectory in another phase) run along on their OWN rows: their trial slots are
   // scratch (trial_slot never returns the current slot), so unconditional stores need no exec-mask branches.
@@ -727,8 +729,8 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   };
   typename Cons::Ctx cc;   // bounds / centres / scales in scalar registers
   Cons::load(P, cc);
-  typename Obj::Ctx oc;    // running-cost matrices
-  Obj::load(P, oc);
+  typename Obj::Ctx oc;    // running-cost matrices (scalar registers for small plants, LDS for large ones)
+  Obj::load_staged(P, oc, s_obj);
   auto prime = [&]() {   // prime the VMEM queue with one step's store pattern (see the producer)
     double z[M];
 #pragma unroll
