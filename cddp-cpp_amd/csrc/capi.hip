@@ -350,7 +350,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
     DA(d.LamTt, (size_t)d.n_alphas * 16 * Bp);
     if (P.pT > 0) {
       // cooperative reduced-LQR sweep (kernels_te.hpp): one lane per gradient variant, variant stride 16
-      const bool te_coop = h->ks->te_rec_size > 0 && P.mT == 0 && P.pT + 1 <= h->ks->te_group;
+      const bool te_coop = h->ks->te_rec_size > 0 && P.mT == 0 && P.pT + 1 <= h->ks->te_group && P.pT <= P.nx;   // TeCfg::PMAX
       const size_t nv = te_coop ? 16 : (size_t)(P.pT + 1);
       DA(d.te_k, nv * N * nu * Bp); DA(d.te_p, nv * (N + 1) * nx * Bp);
       if (te_coop) {

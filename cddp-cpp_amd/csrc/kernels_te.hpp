@@ -31,23 +31,38 @@ namespace cddp_dev {
 template <class Model, class Cons>
 struct TeCfg {
   static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = 64 / G;
-  static constexpr int PMAX = (G - 1 < kPTMax) ? G - 1 : kPTMax;   // one lane per gradient variant: pT + 1 <= G
+  // one lane per gradient variant (pT + 1 <= G); a terminal equality selects states, so more than NX rows never occur
+  static constexpr int PMAX0 = (G - 1 < kPTMax) ? G - 1 : kPTMax;
+  static constexpr int PMAX = PMAX0 < NX ? PMAX0 : NX;
   static constexpr int VP = 16;                                     // variant stride of the te_k / te_p stacks
   static_assert(PMAX + 1 <= VP, "a row holds every variant");
   // per-step record written by k_te_condense
   static constexpr int cQ = 0, cR = NX, cRR = NX + NU, cIPR = cRR + NU * NU, cICOMP = cIPR + 1, REC = cICOMP + 1;
   static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G, NC = (REC + G - 1) / G, NK = (NU * NX + G - 1) / G,
                        NQ = (NU * NU + G - 1) / G;
-  // LDS map of one trajectory
-  static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + NX * NX, oKK = oT2 + NU * NX,
-                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oC = oKtQ + NX * NU, oQuu = oC + 2 * REC, oF = oQuu + NU * NU,
+  // LDS map of one trajectory.  The kernel is LDS-bound in OCCUPANCY: at 16 KB per trajectory (round 1: A, B and the record
+  // double-buffered, every phase with its own area) a 4-trajectory workgroup took 64 KB, two workgroups = two wavefronts
+  // per CU, and the 1024 wavefronts of the C5 batch ran in two rounds on half the SIMDs.  Now <= 40 KB per workgroup
+  // (four per CU, one wavefront per SIMD, one round): A_t, B_t and the record are single-buffered (the prefetched slices
+  // wait in registers and land after round 3, when nothing reads the old ones), the staging area of the gradient
+  // variants overlays B^T P and Q_uu (dead once the gain column exists), and the later phases (variant rollouts P2,
+  // reduced system P3, x_T block) overlay the sweep's areas; only h_T, the multipliers, dx and the reduction row persist.
+  static constexpr bool kPvOverlay = NU > 1;                        // (NU = 1 solves against Q_uu itself in the variant pass)
+  static constexpr int oA = 0, oB = oA + NX * NX, oM = oB + NX * NU, oT2 = oM + NX * NX, oQuu = oT2 + NU * NX;
+  static constexpr int oPv = kPvOverlay ? oT2 : oQuu + NU * NU;
+  static constexpr int T2_END = (oPv + NX * G > oQuu + NU * NU) ? oPv + NX * G : oQuu + NU * NU;
+  static constexpr int oKK = T2_END, oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oC = oKtQ + NX * NU, oF = oC + REC,
                        SWEEP_END = oF + NU * NU + NU;
-  static constexpr int P3 = 4 * PMAX * PMAX + 6 * PMAX;            // reduced-system work area (overlays the sweep area)
-  static constexpr int oXT = SWEEP_END > P3 ? SWEEP_END : P3;
-  static constexpr int oH = oXT + (PMAX + 1) * NX, oLam = oH + PMAX, oBest = oLam + PMAX, oDx = oBest + PMAX,
-                       oPv = oDx + NX, oRed = oPv + NX * G, RAW = oRed + G;
+  // P2: closed-loop rollout of the variants -- its own double-buffered A, B, K and staging area, from 0
+  static constexpr int rA = 0, rB = rA + 2 * NX * NX, rK = rB + 2 * NX * NU, rPv = rK + 2 * NU * NX, P2_END = rPv + NX * G;
+  // P3: reduced-system work area from 0; the x_T block of the variants sits right behind it (written after P2's last read)
+  static constexpr int P3 = 4 * PMAX * PMAX + 6 * PMAX;
+  static constexpr int oXT = P3, XT_END = oXT + (PMAX + 1) * NX;
+  static constexpr int M1 = SWEEP_END > P2_END ? SWEEP_END : P2_END;
+  static constexpr int oPersist = M1 > XT_END ? M1 : XT_END;
+  static constexpr int oH = oPersist, oLam = oH + PMAX, oBest = oLam + PMAX, oDx = oBest + PMAX, oRed = oDx + NX, RAW = oRed + G;
   static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
-  static_assert(NX * NX >= NU, "gain buffers of the dX rollout fit the A/B area");
+  static_assert(2 * (NU + NU * NX) <= oPersist, "gain buffers of the dX rollout fit below the persistent block");
 };
 
 DEV void atomic_max_pos(double *addr, double v) {   // v >= 0: the IEEE bit pattern orders like an unsigned integer
@@ -290,8 +305,8 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
     for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.te_cst[GI(tt, REC, e < REC ? e : REC - 1)]; }
   };
-  auto storeAB = [&](int buf, const InAB &r) {
-    double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU, *Lc = Ls + C::oC + buf * REC;
+  auto storeAB = [&](const InAB &r) {
+    double *La = Ls + C::oA, *Lb = Ls + C::oB, *Lc = Ls + C::oC;
 #pragma unroll
     for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
 #pragma unroll
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
     // ---- P1: matrix recursion + gradient variants
     auto step = [&](const int t, InAB &nab) -> bool {
       const int tp = t > 0 ? t - 1 : 0;
-      const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU, *Lc = Ls + C::oC + (t & 1) * REC;
+      const double *La = Ls + C::oA, *Lb = Ls + C::oB, *Lc = Ls + C::oC;
       bool bad = false;
       double Aq[NX];
 #pragma unroll
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      storeAB((t & 1) ^ 1, nab);
+      storeAB(nab);   // A_{t-1}, B_{t-1}, record: nothing reads the step's own copies any more
       lds_sync();
 #pragma unroll
       for (int i = 0; i < NX; ++i) { Vc[i] = 0.5 * (Ls[C::oM + i * NX + qc] + Ls[C::oM + qc * NX + i]); bad = bad || !dfinite(Vc[i]); }
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
     {
       InAB nab;
       loadAB(N - 1, nab);
-      storeAB((N - 1) & 1, nab);
+      storeAB(nab);
       lds_sync();
       for (int t = N - 1; t >= 0; --t)
         if (!step(t, nab)) { fail = true; break; }
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int i = 0; i < NU; ++i) r.kf[i] = tek[(((size_t)tt * Bp + b) * NU + i) * VP + (hasv ? v : 0)];
       };
       auto store_r = [&](int buf, const RIn &r) {
-        double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU, *Lk = Ls + C::oT2 + buf * NU * NX;
+        double *La = Ls + C::rA + buf * NX * NX, *Lb = Ls + C::rB + buf * NX * NU, *Lk = Ls + C::rK + buf * NU * NX;
 #pragma unroll
         for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; if (e < NX * NX) La[e] = r.a[j]; }
 #pragma unroll
@@ -603,7 +618,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         const int tn = t + 1 < N ? t + 1 : t;
         load_r(tn, rn);
         PIPELINE_FENCE();
-        const double *La = Ls + C::oA + (t & 1) * NX * NX, *Lb = Ls + C::oB + (t & 1) * NX * NU, *Lk = Ls + C::oT2 + (t & 1) * NU * NX;
+        const double *La = Ls + C::rA + (t & 1) * NX * NX, *Lb = Ls + C::rB + (t & 1) * NX * NU, *Lk = Ls + C::rK + (t & 1) * NU * NX;
         double du[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) { double a = 0.0;
@@ -617,12 +632,12 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           for (int j = 0; j < NX; ++j) a += La[i * NX + j] * dx[j];
 #pragma unroll
           for (int j = 0; j < NU; ++j) c += Lb[i * NU + j] * du[j];
-          Ls[C::oPv + i * G + q] = (a + c) + 0.0;
+          Ls[C::rPv + i * G + q] = (a + c) + 0.0;
         }
         store_r((t & 1) ^ 1, rn);
         lds_sync();
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oPv + i * G + q];
+        for (int i = 0; i < NX; ++i) dx[i] = Ls[C::rPv + i * G + q];
 #pragma unroll
         for (int i = 0; i < NU; ++i) rc.kf[i] = rn.kf[i];
       }
