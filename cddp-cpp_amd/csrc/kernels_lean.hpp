@@ -621,15 +621,20 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       st<NU>(Un + GI(0, NU, 0), kLS, z);
       st<NX>(Xn + GI(1, NX, 0), kLS, z);
     };
-    // Large records (nx >= 12: the gain block alone is nu*nx rows) are fetched at the top of their own step into ONE
-    // register set: the ping-pong copy would push the kernel into scratch, whose spill traffic costs far more VMEM
-    // issue slots than one exposed round trip per step.
+    // Large records (nx >= 12: the gain block alone is nu*nx rows) live in ONE register set (a ping-pong copy would push the
+    // kernel into scratch).  The record of step t + 1 is fetched into that same set as soon as u_t is formed -- its
+    // registers are dead from there on -- so the loads fly behind the integrator stages instead of being waited for at
+    // the top of the next step (round 2 counters: the rollout waves of the 7-joint arm waited 52 % of their cycles).
+    // (Only while the record is moderate: the 126-double record of the 7-joint arm, kept live across the integrator, pushes
+    //  the kernel into scratch -- measured 680 -> 1039 ms of rollout class at C5 -- so the largest records are still fetched
+    //  at the top of their own step.)
     constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);
+    constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
     auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
       if constexpr (kPing) {
         const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
         load_step(tn, nxt);
-      } else load_step(t, cs);
+      } else if constexpr (!kEarly) load_step(t, cs);
       PIPELINE_FENCE();
       double dx[NX], u[NU], xn[NX];
       bool finite = true;
@@ -655,6 +660,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         if (alive && !finite) { s_pstat[lane] = t; alive = false; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if constexpr (kEarly) {   // next step's record into the (now dead) register set, behind the integrator
+        load_step(t + 1 < N ? t + 1 : t, cs);
+        PIPELINE_FENCE();
       }
       Stepper<Model>::step(dc, x, u, xn);
 #pragma unroll
@@ -743,11 +752,28 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
   };
   constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);   // see the producer
+  constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
+  // The largest records of control-box layouts (7-joint arm: 169 doubles per lane and step) are streamed in NU chunks
+  // instead: chunk i = gain row i and the slack / dual entries of the two constraint rows that read it (upper and lower
+  // bound of control i), two chunk buffers, chunk i + 1 in flight while chunk i is reduced, chunk 0 of the next step behind
+  // the cost / barrier terms.  Same products, same sums; the row pairs are visited as (0, NU), (1, NU + 1), ...
+  constexpr bool kChunk = !kPing && !kEarly && UDiag<Cons>::value && M == 2 * NU;
+  struct Chunk { double K[NX], s[2], y[2], ksv[2], ky[2], ys[2]; };
+  auto load_chunk = [&](int tt, const int i, Chunk &c) {
+    ld<NX>(d.K + GI(tt, NU * NX, i * NX), kLS, c.K);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = i + h * NU;
+      c.s[h] = Sc[GI(tt, M, r)]; c.y[h] = Yc[GI(tt, M, r)];
+      c.ksv[h] = d.ks[GI(tt, M, r)]; c.ky[h] = d.ky[GI(tt, M, r)]; c.ys[h] = d.ys[GI(tt, M, r)];
+    }
+  };
+  Chunk ck0, ck1;
   auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
     if constexpr (kPing) {
       const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
       load_step(tn, nxt);
-    } else load_step(t, cs);
+    } else if constexpr (!kEarly && !kChunk) load_step(t, cs);
     PIPELINE_FENCE();
     // take step t from the ring, then hand the slot back
     wait_ge(&s_prod, t + 1);
@@ -765,7 +791,36 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     double sn[M], yn[M];
     bool feas = true;
     // rows of K_s, K_y rebuilt from K and YS exactly as k_post forms them (ipddp_solver.cpp:1465-1472)
-    if constexpr (UDiag<Cons>::value) {
+    if constexpr (kChunk) {
+      auto rows = [&](const int i, const Chunk &c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = i + h * NU;
+          const double gv = UDiag<Cons>::val(cc, r);
+          double Ksr[NX], Kyr[NX];
+#pragma unroll
+          for (int cix = 0; cix < NX; ++cix) {
+            const double s2 = 0.0 + gv * c.K[cix];
+            const double inner = 0.0 + s2;
+            Kyr[cix] = dmin(dmax(c.ys[h] * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+            Ksr[cix] = (-0.0) - s2;
+          }
+          sn[r] = affine_2r<NX>(c.s[h], a_pr, c.ksv[h], Ksr, dx);
+          yn[r] = affine_2r<NX>(c.y[h], a_du, c.ky[h], Kyr, dx);
+          if (sn[r] < (1.0 - tau) * c.s[h] || yn[r] < (1.0 - tau) * c.y[h]) feas = false;
+          if (!dfinite(sn[r]) || !dfinite(yn[r])) feas = false;
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (i + 1 < NU) { if ((i & 1) == 0) load_chunk(t, i + 1, ck1); else load_chunk(t, i + 1, ck0); }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((i & 1) == 0) rows(i, ck0); else rows(i, ck1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_chunk(t + 1 < N ? t + 1 : t, 0, ck0);   // the next step's first chunk, behind the cost / barrier terms
+      PIPELINE_FENCE();
+    } else if constexpr (UDiag<Cons>::value) {
       // control box only: row r of G_u K is g_r K[col(r), :].  The dense sum adds products with exact zeros around
       // that term (K is finite: the sweep checks it), which leaves it unchanged except that a -0 becomes +0 --
       // hence the explicit 0.0 + ...; G_x = 0 enters as the same +0 / -0 the dense form adds.
@@ -815,6 +870,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     if (!feas) alive = false;
     st<M>(Sn + GI(t, M, 0), kLS, sn);
     st<M>(Yn + GI(t, M, 0), kLS, yn);
+    if constexpr (kEarly) {   // next step's record into the (now dead) register set, behind the cost / barrier terms
+      load_step(t + 1 < N ? t + 1 : t, cs);
+      PIPELINE_FENCE();
+    }
     double g[M];
     Cons::template eval<NX, NU>(cc, rx, u, g);
     run_cost += Obj::running_cost(oc, xrt, t, rx, u);   // same t-ordered sum the fused rollout keeps (:1726-1748)
@@ -842,7 +901,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     }
   };
   StepIn ra;
-  load_step(0, ra);
+  if constexpr (kChunk) load_chunk(0, 0, ck0); else load_step(0, ra);
   prime();
   if constexpr (kPing) {
     StepIn rb;
