@@ -37,8 +37,23 @@ struct Rccl {
 Rccl &rccl() {
   static Rccl r;
   if (r.lib || !r.err.empty()) return r;
+  // First the librccl that sits next to the HIP runtime THIS library is bound to: RCCL opens the HSA runtime of its own
+  // directory, and a process that holds two ROCm installations (PyTorch bundles one) must not mix them -- a communicator on
+  // the other copy fails with "no ROCm-capable device" (seen when this library initialised /opt/rocm's runtime before torch
+  // was imported).  With torch imported first both resolve to torch's copy; see INTEGRATION.md section 4.
+  {
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char *n : {"librccl.so.1", "librccl.so"}) { r.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+      }
+    }
+  }
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+  if (!r.lib) for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
   if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return r; }
   auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.err = std::string("librccl lacks ") + n; return p; };
   r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");

@@ -715,9 +715,14 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 // streamed from LDS inside the inner products.  With nx = 12..14 the register-resident form needs A (nx^2) twice
 // (ping-pong) plus T1 (nx^2) per lane -- > 512 VGPRs, i.e. scratch spills on every step (measured: 178 us per
 // step for the C4 quadrotor).  Same sums, same association.
-template <class Model, bool HAS_X>
+// H lanes per COLUMN (H = 1: a lane owns a whole column; H = 2: the rows of a column are split between two lanes, GG = 32
+// lanes per trajectory -- chosen by the launcher when the batch would otherwise leave more than half of the SIMDs without a
+// wavefront, e.g. the 2048-trajectory share of C4: 512 -> 1024 wavefronts, ~40 % fewer multiply-adds per lane).
+template <class Model, bool HAS_X, int H = 1>
 struct CoopBigCfg {
-  static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = CoopCfg<Model>::TPW;
+  static constexpr int NX = Model::NX, NU = Model::NU, GC = CoopCfg<Model>::G, G = GC * H, TPW = 64 / G;
+  static constexpr int RH = (NX + H - 1) / H;                                         // rows of a column per lane
+  static constexpr int UH = (NU + H - 1) / H;                                         // rows of B^T V_xx per lane
   static constexpr int NA = (NX * NX + G - 1) / G, NB = (NX * NU + G - 1) / G;     // per-lane slices of A, B
   static constexpr int RC = NU + NU * NU + NU + 2, NC = (RC + G - 1) / G;          // replicated condensed terms c_u .. icomp
   static constexpr int RK = NU * NX, NK = (RK + G - 1) / G;                         // gain block (rollout epilogue)
@@ -729,14 +734,14 @@ struct CoopBigCfg {
   static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
 };
 
-template <class Model, class Cons>
+template <class Model, class Cons, int H = 1>
 __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                                 int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
   typedef CstLayout<Model, Cons> L;
-  typedef CoopBigCfg<Model, Cons::HAS_X> C;
-  constexpr int CST = L::SIZE, G = C::G;
+  typedef CoopBigCfg<Model, Cons::HAS_X, H> C;
+  constexpr int CST = L::SIZE, G = C::G, GC = C::GC, RH = C::RH, UH = C::UH;
   __shared__ double lds[C::TPW * C::STRIDE];
   __shared__ double ldsQ[NX * NX];   // Q dt (loop-invariant, shared by the trajectories of the wave)
   __shared__ double ldsR[NU * NU];   // R dt
@@ -747,8 +752,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
     for (int e = lane; e < NU * NU; e += 64) ldsR[e] = Rp[e];
     lds_sync();
   }
-  const int q = lane % G, tl = lane / G;
-  const int qc = q < NX ? q : NX - 1;
+  const int q = lane % G, tl = lane / G;       // q: slice index of the cooperative fetches
+  const int col = q % GC, hh = q / GC;         // owned column, half of its rows
+  const int qc = col < NX ? col : NX - 1;
+  const int r0 = hh * RH, u0 = hh * UH;        // first owned row of a column / of B^T V_xx
   const int b = blockIdx.x * C::TPW + tl;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
@@ -835,22 +842,23 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       // ---- round 1
       // (outer loops stay rolled and write to LDS: fully unrolled, the 3 nx^2-term products keep hundreds of LDS
       //  operands live and spill)
-      double T2c[NU], Qu[NU];
+      double Qu[NU];
       // (rows in pairs -- pairs measured best: 553 ms of sweep class at C4 against 565 / 607 / 1007 for groups of 3 / 4 / 6 --
       //  the operands of group g + 1 fetched from LDS before group g is reduced: one LDS
       //  round trip is covered by the multiply-adds of a group instead of being waited for group by group)
+      // owned rows: r0 .. r0 + RH - 1 (all of them for H = 1); a row index past the end repeats row NX - 1 (same value)
       {
-        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR;
+        constexpr int GR = 2, NGRP = (RH + GR - 1) / GR;
         double b0[GR * NX], b1[GR * NX];
         auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1;
 #pragma unroll
             for (int k = 0; k < NX; ++k) buf[r * NX + k] = La[k * NX + i]; } }
         };
         auto cmp = [&](const int g, const double (&buf)[GR * NX]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) { double s = 0.0;
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1; double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NX; ++k) s += buf[r * NX + k] * Vc[k];
             Ls[C::oM + i * NX + qc] = s; } }
@@ -865,10 +873,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         }
       }
 #pragma unroll
-      for (int u = 0; u < NU; ++u) { double s = 0.0;
+      for (int ul = 0; ul < UH; ++ul) { const int u = (u0 + ul < NU) ? u0 + ul : NU - 1; double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) s += Lb[k * NU + u] * Vc[k];
-        T2c[u] = s; }
+        Ls[C::oT2 + u * NX + qc] = s; }
       double Qxq;
       { double s2 = 0.0;
 #pragma unroll
@@ -879,24 +887,22 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
 #pragma unroll
         for (int k = 0; k < NX; ++k) s2 += Lb[k * NU + u] * Vx[k];
         Qu[u] = Lc[u] + s2; }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
       lds_sync();
       // ---- round 2: Q_xx[i, qc] replaces T1[i, qc] in place (row i of T1 is dead once every lane has used it,
       // and the lanes of a wavefront run this loop in lockstep)
       double Quxc[NU], Quu[NU * NU];
       {
-        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR;
+        constexpr int GR = 2, NGRP = (RH + GR - 1) / GR;
         double b0[GR * NX], b1[GR * NX];
         auto ldg = [&](const int g, double (&buf)[GR * NX]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1;
 #pragma unroll
             for (int j = 0; j < NX; ++j) buf[r * NX + j] = Ls[C::oM + i * NX + j]; } }
         };
         auto cmp = [&](const int g, const double (&buf)[GR * NX]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) { double s = 0.0;
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1; double s = 0.0;
 #pragma unroll
             for (int j = 0; j < NX; ++j) s += buf[r * NX + j] * Aq[j];
             Ls[C::oM + i * NX + qc] = (2.0 * ldsQ[i * NX + qc]) + s; } }
@@ -1000,11 +1006,11 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         Vxq = ((Qxq + a) + bb) + c;
       }
       {   // Vn[i, qc] replaces the lane's own Q_xx[i, qc] in place; row groups pipelined as in rounds 1 and 2
-        constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RW3 = 3 * NU + 2;
+        constexpr int GR = 2, NGRP = (RH + GR - 1) / GR, RW3 = 3 * NU + 2;
         double b0[GR * RW3], b1[GR * RW3];
         auto ldg = [&](const int g, double (&buf)[GR * RW3]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1;
 #pragma unroll
             for (int j = 0; j < NU; ++j) { buf[r * RW3 + j] = Ls[C::oKK + j * NX + i]; buf[r * RW3 + NU + j] = Ls[C::oQux + j * NX + i]; buf[r * RW3 + 2 * NU + j] = Ls[C::oKtQ + i * NU + j]; }
             buf[r * RW3 + 3 * NU] = Ls[C::oM + i * NX + qc];
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
         };
         auto cmp = [&](const int g, const double (&buf)[GR * RW3]) {
 #pragma unroll
-          for (int r = 0; r < GR; ++r) { const int i = g * GR + r; if (i < NX) {
+          for (int r = 0; r < GR; ++r) { const int li = g * GR + r; if (li < RH) { const int i = (r0 + li < NX) ? r0 + li : NX - 1;
             double a = 0.0, bb = 0.0, e = 0.0;
 #pragma unroll
             for (int j = 0; j < NU; ++j) { a += buf[r * RW3 + j] * Quxq[j]; bb += buf[r * RW3 + NU + j] * KKc[j]; e += buf[r * RW3 + 2 * NU + j] * KKc[j]; }
@@ -1038,8 +1044,19 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       for (int i = 0; i < NX; ++i) Vx[i] = Ls[C::oVx + i];
       lds_sync();
       d.Vx[GI(t, NX, qc)] = Vxq;
+      if constexpr (H == 1) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+        for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+      } else {   // each half stores its own rows (value selects: no dynamic register index)
+#pragma unroll
+        for (int li = 0; li < RH; ++li) {
+          double v = Vc[li];
+#pragma unroll
+          for (int hx = 1; hx < H; ++hx) { const int ii = hx * RH + li; if (hh == hx) v = Vc[ii < NX ? ii : NX - 1]; }
+          const int i = (r0 + li < NX) ? r0 + li : NX - 1;
+          d.Vxx[GI(t, NX * NX, i * NX + qc)] = v;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
       return true;

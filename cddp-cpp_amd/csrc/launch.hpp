@@ -85,8 +85,19 @@ struct Launcher {
             launched = true;
           }
         }
-        if (!launched)   // operands in LDS: the register-resident form spills for nx = 12..14
-          hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+        if (!launched) {   // operands in LDS: the register-resident form spills for nx = 12..14
+          // CDDP_HIP_COOP_H=2: two lanes per column (32 lanes per trajectory, twice the wavefronts).  Bit-identical
+          // (tests/test_gpu_parity.py::test_row_split_sweep_agrees_bitwise) but measured SLOWER where it was meant to help --
+          // C4 share, 2048 trajectories: 512 -> 1024 wavefronts, 22 % fewer VALU instructions per wavefront, sweep class
+          // 553 -> 637 ms -- the step is a chain of LDS round trips and a replicated factorisation, not issue slots.  Opt-in.
+          constexpr int TPW1 = CoopCfg<Model>::TPW, TPW2 = TPW1 / 2;
+          int hsel = 1;
+          if (const char *e = std::getenv("CDDP_HIP_COOP_H")) { if (e[0] == '2') hsel = 2; }
+          if (hsel == 2)
+            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 2>), dim3((d.B + TPW2 - 1) / TPW2), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          else
+            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+        }
       }
       else
         hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);

@@ -12,6 +12,13 @@ def load_api():
     name = "cddp_cpp_amd_pyapi"
     if name in sys.modules:
         return sys.modules[name]
+    # PyTorch bundles its own ROCm runtime: a process that uses both must import torch FIRST, so that libcddp_hip.so binds the
+    # runtime torch already loaded (bench.py does the same).  Only when a GPU test session will want it.
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "cddp-cpp_amd", "pyapi.py"))
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod

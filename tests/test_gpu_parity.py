@@ -318,6 +318,35 @@ def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
     assert np.array_equal(X1, X2) and np.array_equal(U1, U2) and np.array_equal(K1, K2) and np.array_equal(k1, k2)
 
 
+@pytest.mark.parametrize("case", ["quad12_ipddp_box", "quadrotor_ipddp_box", "manip7_ipddp_box"])
+def test_row_split_sweep_agrees_bitwise(api, case, monkeypatch):
+    """nx > 8: the LDS-operand sweep with two lanes per column (32 lanes per trajectory, picked for small batches),
+    with one lane per column, and the one-lane-per-trajectory kernel -- the same bits, whole solves."""
+    p = make(api, case)
+    B = 37
+    x0 = api.batch_x0(p, B, 20261112, spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); Vx, Vxx = hs.value(); hs.close()
+        return r, X, U, K, k, Vx, Vxx
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    out = {}
+    for h in ("1", "2"):
+        monkeypatch.setenv("CDDP_HIP_COOP_H", h)
+        out[h] = run()
+    monkeypatch.delenv("CDDP_HIP_COOP_H", raising=False)
+    monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
+    out["lane"] = run()
+    for other in ("2", "lane"):
+        a, b = out["1"], out[other]
+        assert np.array_equal(a[0]["iterations"], b[0]["iterations"]) and np.array_equal(a[0]["status"], b[0]["status"]), other
+        assert np.array_equal(a[0]["final_objective"], b[0]["final_objective"]), other
+        for i in range(1, 7): assert np.array_equal(a[i], b[i]), (other, i)
+
+
 @pytest.mark.parametrize("sweep", ["coop", "lane"])
 @pytest.mark.parametrize("case", ["cartpole_ipddp_box", "cartpole_ipddp_unc", "unicycle_ipddp_box_ball", "quadrotor_ipddp_box",
                                   "pendulum_term_eq", "manip7_term_eq_parallel_ls", "term_ineq_only"])
