@@ -12,6 +12,7 @@
 //   LTI                 : (A - I)/dt, B/dt (lti_system.cpp:78-92)
 #pragma once
 #include "dev_linalg.hpp"
+#include "dev_trig.hpp"
 #include "../../include/cddp_hip.h"
 
 namespace cddp_dev {
@@ -42,20 +43,38 @@ template <int NP> DEV DualN<NP> operator*(const DualN<NP> &a, const DualN<NP> &b
 template <int NP> DEV DualN<NP> operator/(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v / b.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
-template <int NP> DEV DualN<NP> dsin(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = s;
+template <int NP> DEV DualN<NP> dsin(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos_1(a.v, &s, &c); r.v = s;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = c * a.d[i]; return r; }
-template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = c; double ms = -s;
+template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos_1(a.v, &s, &c); r.v = c; double ms = -s;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = ms * a.d[i]; return r; }
 template <int NP> DEV DualN<NP> dsqrt(const DualN<NP> &a) { DualN<NP> r; r.v = sqrt(a.v); double g = 0.5 / r.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
-DEV double dsin(double a) { return sin(a); }
-DEV double dcos(double a) { return cos(a); }
+DEV double dsin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
+DEV double dcos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
 DEV double dsqrt(double a) { return sqrt(a); }
 DEV double dval(double a) { return a; }
 template <int NP> DEV double dval(const DualN<NP> &a) { return a.v; }
+// sin / cos of N scalars of type S (double or a dual) from ONE batched evaluation of the values (dev_trig.hpp: the
+// independent angles of a plant share a basic block, so their chains interleave)
+DEV double lift_sin(double, double s, double) { return s; }
+DEV double lift_cos(double, double, double c) { return c; }
+template <int NP> DEV DualN<NP> lift_sin(const DualN<NP> &a, double s, double c) { DualN<NP> r; r.v = s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = c * a.d[i]; return r; }
+template <int NP> DEV DualN<NP> lift_cos(const DualN<NP> &a, double s, double c) { DualN<NP> r; r.v = c; const double ms = -s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = ms * a.d[i]; return r; }
+template <int N, class S> DEV void trig_n(const S *a, S *sn, S *cs) {
+  double av[N], sv[N], cv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) av[i] = dval(a[i]);
+  sincos_n<N>(av, sv, cv);
+#pragma unroll
+  for (int i = 0; i < N; ++i) { sn[i] = lift_sin(a[i], sv[i], cv[i]); cs[i] = lift_cos(a[i], sv[i], cv[i]); }
+}
 
 // Second-order forward mode (the reference's autodiff::dual2nd, dynamical_system.cpp:137-217): value, gradient and Hessian
 // w.r.t. NP seeded variables z = [x, u].  Only for the plants whose Hessians the reference takes from autodiff (CartPole)
@@ -92,8 +111,8 @@ template <int NP> DEV Dual2N<NP> operator*(const Dual2N<NP> &a, const Dual2N<NP>
 template <int NP> DEV Dual2N<NP> operator/(const Dual2N<NP> &a, const Dual2N<NP> &b) {
   const double inv = 1.0 / b.v;
   return a * d2_unary<NP>(b, inv, -inv * inv, 2.0 * inv * inv * inv); }
-template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
-template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
+template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; sincos_1(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
+template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; sincos_1(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
 
 // Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
 template <class F, int NX, int NU>
@@ -122,12 +141,12 @@ struct PendulumModel {   // pendulum.cpp:29-66; params: length, mass, damping, g
     const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
     const double inertia = mass * length * length;
     xd[0] = x[1];
-    xd[1] = (u[0] - damping * x[1] + mass * gravity * length * sin(x[0])) / inertia;
+    xd[1] = (u[0] - damping * x[1] + mass * gravity * length * dsin(x[0])) / inertia;
   }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     const double length = p[0], mass = p[1], damping = p[2], gravity = p[3];
     Fx[0] = 0.0; Fx[1] = 1.0;
-    Fx[2] = (gravity / length) * cos(x[0]);
+    Fx[2] = (gravity / length) * dcos(x[0]);
     Fx[3] = -damping / (mass * length * length);
     Fu[0] = 0.0; Fu[1] = 1.0 / (mass * length * length);
   }
@@ -138,7 +157,7 @@ struct PendulumModel {   // pendulum.cpp:29-66; params: length, mass, damping, g
     for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
     for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
     for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
-    Fxx[1 * NX * NX + 0] = -(p[3] / p[0]) * sin(x[0]);
+    Fxx[1 * NX * NX + 0] = -(p[3] / p[0]) * dsin(x[0]);
   }
 };
 
@@ -150,7 +169,7 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     // double path (cartpole.cpp:38-67): NO damping term
     const double mc = p[0], mp = p[1], l = p[2], g = p[3];
     const double theta_dot = x[3], force = u[0];
-    double s, c; sincos(x[1], &s, &c);
+    double s, c; sincos_1(x[1], &s, &c);
     const double total_mass = mc + mp;
     const double den = mc + mp * s * s;
     xd[0] = x[2];
@@ -162,7 +181,7 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     // exact derivatives of the autodiff expression (cartpole.cpp:69-103, WITH -damping*theta_dot)
     const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
     const double w = x[3], F = u[0];
-    double s, c; sincos(x[1], &s, &c);
+    double s, c; sincos_1(x[1], &s, &c);
     const double M = mc + mp;
     const double den = mc + mp * s * s;
     const double dden = 2.0 * mp * s * c;
@@ -218,11 +237,11 @@ struct UnicycleModel {   // unicycle.cpp:28-66
   static constexpr int ID = CDDP_HIP_MODEL_UNICYCLE, NX = 3, NU = 2;
   static constexpr bool kDiscrete = false;
   DEV static void f(const double *, const double *x, const double *u, double *xd) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; sincos_1(x[2], &s, &c);
     xd[0] = u[0] * c; xd[1] = u[0] * s; xd[2] = u[1];
   }
   DEV static void jac(const double *, const double *x, const double *u, double *Fx, double *Fu) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; sincos_1(x[2], &s, &c);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Fx[i] = 0.0;
     Fx[0 * 3 + 2] = -u[0] * s;
@@ -233,7 +252,7 @@ struct UnicycleModel {   // unicycle.cpp:28-66
   // getContinuousDynamicsAutodiff (:91-107): d2(v cos th)/dv dth = -sin th, d2(v sin th)/dv dth = cos th
   static constexpr bool kHasHess = true;
   DEV static void hess(const double *, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; sincos_1(x[2], &s, &c);
     for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
     for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
     for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
@@ -337,7 +356,9 @@ struct Quad12Dyn {
     const double mass = p[0], arm = p[1], Ixx = p[2], Iyy = p[3], Izz = p[4], grav = p[5];
     const S phi = x[6], th = x[7], psi = x[8];
     const S ox = x[9], oy = x[10], oz = x[11];
-    const S sph = dsin(phi), cph = dcos(phi), sth = dsin(th), cth = dcos(th), sps = dsin(psi), cps = dcos(psi);
+    const S ang[3] = {phi, th, psi}; S sn[3], cs[3];
+    trig_n<3, S>(ang, sn, cs);
+    const S sph = sn[0], cph = cs[0], sth = sn[1], cth = cs[1], sps = sn[2], cps = cs[2];
     const S thrust = u[0] + u[1] + u[2] + u[3];
     xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
     const double invm = 1.0 / mass;
@@ -375,7 +396,9 @@ struct ManipulatorModel {   // manipulator.cpp:29-70,174-208
     const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
     const double m1 = 1.0, m2 = 1.0, m3 = 0.5;
     double M[9];
-    const double c1 = cos(x[1]), c2 = cos(x[2]), c12 = cos(x[1] + x[2]);
+    const double ang[3] = {x[1], x[2], x[1] + x[2]}; double sn[3], cs[3];
+    sincos_n<3>(ang, sn, cs);
+    const double c1 = cs[0], c2 = cs[1], c12 = cs[2];
     M[0] = (m1 + m2 + m3) * (la * la);
     M[4] = (m2 + m3) * (lb * lb);
     M[8] = m3 * (lc * lc);
@@ -429,14 +452,22 @@ struct Manip7Dyn {
     const double wi[7] = {0.0, 1.4, 1.1, 0.8, 0.5, 0.3, 0.15};
     const double ci[7] = {0.0, 0.30, 0.25, 0.20, 0.15, 0.10, 0.05};
     const double grav = 9.81;
+    // the 13 angles (7 cumulative, 6 neighbour differences) first, one batched cosine evaluation, then the joint rows
+    S ang[13], sn[13], cs[13];
     S cum = S(0.0);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      xd[i] = x[7 + i];
       cum = cum + x[i];
+      ang[i] = cum;
+      if (i > 0) ang[6 + i] = x[i] - x[i - 1];
+    }
+    trig_n<13, S>(ang, sn, cs);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      xd[i] = x[7 + i];
       S Mii = S(mi[i] * li[i] * li[i]);
-      if (i > 0) { S cd = dcos(x[i] - x[i - 1]); Mii = Mii + S(ci[i]) * cd * cd; }
-      S Gi = S(-grav * wi[i]) * dcos(cum);
+      if (i > 0) { S cd = cs[6 + i]; Mii = Mii + S(ci[i]) * cd * cd; }
+      S Gi = S(-grav * wi[i]) * cs[i];
       xd[7 + i] = (u[i] - Gi) / Mii;
     }
   }
