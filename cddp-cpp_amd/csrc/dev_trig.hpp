@@ -66,6 +66,12 @@ DEV SinCosPair sincos_fast(double x) {
   return o;
 }
 
+#ifndef CDDP_TRIG_HOST
+// The libm fallback as a real function call: inlined N times it put N copies of the Payne-Hanek reduction into the calling
+// kernel and its register demand (the largest of the whole rollout kernel) set the kernel's allocation.
+__device__ __attribute__((noinline)) inline void sincos_libm(double a, double *s, double *c) { sincos(a, s, c); }
+#endif
+
 // sin and cos of N angles.  All fast paths first (one basic block); when ANY lane of the wavefront holds an argument outside
 // the fast range (or a non-finite one) every lane evaluates the libm and keeps its result where needed.
 template <int N>
@@ -86,7 +92,7 @@ DEV void sincos_n(const double *a, double *s, double *c) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double ts, tc;
-      sincos(a[i], &ts, &tc);
+      sincos_libm(a[i], &ts, &tc);
       const bool out = !(__builtin_fabs(a[i]) < kTrigFastLimit);
       s[i] = out ? ts : s[i];
       c[i] = out ? tc : c[i];

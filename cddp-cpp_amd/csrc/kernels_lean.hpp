@@ -630,14 +630,41 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     //  at the top of their own step.)
     constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);
     constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
+    // The largest records (7-joint arm: 126 doubles) are streamed: the old state row and, per control i, the gain row with
+    // u_old[i], k[i] -- two chunk buffers; x_old of step t + 1 and its first chunk are fetched behind the integrator (42
+    // doubles live there instead of 126).  Same sums.  With the consumer's chunks (below) the kernel fits two wavefronts per SIMD.
+    constexpr bool kChunkP = !kPing && !kEarly;
+    struct PChunk { double K[NX], uo, kk; };
+    auto load_pchunk = [&](int tt, const int i, PChunk &c) {
+      ld<NX>(d.K + GI(tt, NU * NX, i * NX), kLS, c.K);
+      c.uo = Uc[GI(tt, NU, i)]; c.kk = d.k[GI(tt, NU, i)];
+    };
+    PChunk pk0, pk1;
+    double xo_c[NX];
     auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
       if constexpr (kPing) {
         const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
         load_step(tn, nxt);
-      } else if constexpr (!kEarly) load_step(t, cs);
+      }
       PIPELINE_FENCE();
       double dx[NX], u[NU], xn[NX];
       bool finite = true;
+      if constexpr (kChunkP) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo_c[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          if (i + 1 < NU) { if ((i & 1) == 0) load_pchunk(t, i + 1, pk1); else load_pchunk(t, i + 1, pk0); }
+          __builtin_amdgcn_sched_barrier(0);
+          const PChunk &c = (i & 1) == 0 ? pk0 : pk1;
+          double s1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s1 += c.K[j] * dx[j];
+          u[i] = (c.uo + a_pr * c.kk) + s1;
+          finite = finite && dfinite(u[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) dx[i] = x[i] - cs.xo[i];
 #pragma unroll
@@ -647,6 +674,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         for (int j = 0; j < NX; ++j) s1 += cs.KK[i * NX + j] * dx[j];
         u[i] = (cs.uo[i] + a_pr * cs.kk[i]) + s1;
         finite = finite && dfinite(u[i]);
+      }
       }
       // publish step t.  Ring slots free up as the consumer retires steps; the counter is polled once every
       // kRing/2 steps for the next kRing/2 slots (an LDS round trip on the chain otherwise).
@@ -665,6 +693,12 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         load_step(t + 1 < N ? t + 1 : t, cs);
         PIPELINE_FENCE();
       }
+      if constexpr (kChunkP) {   // x_old and the first chunk of the next step, behind the integrator
+        const int tn = t + 1 < N ? t + 1 : t;
+        ld<NX>(Xc + GI(tn, NX, 0), kLS, xo_c);
+        load_pchunk(tn, 0, pk0);
+        PIPELINE_FENCE();
+      }
       Stepper<Model>::step(dc, x, u, xn);
 #pragma unroll
       for (int i = 0; i < NX; ++i) finite = finite && dfinite(xn[i]);
@@ -677,7 +711,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
     };
     StepIn ra;
-    load_step(0, ra);
+    if constexpr (kChunkP) { ld<NX>(Xc + GI(0, NX, 0), kLS, xo_c); load_pchunk(0, 0, pk0); } else load_step(0, ra);
     prime();
     int t = 0;
     if constexpr (kPing) {
