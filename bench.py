@@ -342,6 +342,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "parity": "checked against the CPU restatement (oracle/ + its numpy twin), not against a cddp-cpp binary: parity unpinned (DESIGN.md 5)",
         "config": {
             "workload": {"cartpole": "BASELINE config[1]: ", "unicycle": "BASELINE config[2]: ", "quadrotor": "BASELINE config[3] (one GPU share): ", "manip7": "BASELINE config[4] (one GPU share): "}.get(args.workload, "experiment: ") + desc +
                         ", batch %d per GPU, solver %s" % (B, args.solver.upper()),
