@@ -5,6 +5,9 @@
 // the sweep is ONE launch.  Three branches of the reference:
 //   CDDP_HIP_STACKS_CLDDP      clddp_solver.cpp:79-204 without bounds (PD test, dense inverse, reg only in the factor)
 //   CDDP_HIP_STACKS_IPDDP      ipddp_solver.cpp:1048-1118 (unconstrained: LDLT, reg kept in the value update)
+//   CDDP_HIP_STACKS_LOGDDP     logddp_solver.cpp:470-575 (the host folds the relaxed-log-barrier gradients / Hessians of
+//                              barrier.hpp:95-262 into the cost stacks: reg added THEN symmetrised, LDLT, the value update with
+//                              the un-regularised Q_uu in CLDDP's association order, raw max |Q_u|)
 //   CDDP_HIP_STACKS_IPDDP_PATH ipddp_solver.cpp:1355-1568 (path constraints condensed: y, s, g, G_x, G_u stacks; gains of
 //                              the slack / dual directions, linear-policy rollout, dS, dY, computeMaxStepSizes :2939-2988)
 // One trajectory per lane, batch-minor stacks [t][e][Bp]: every wavefront load is one coalesced 512-B row.
@@ -51,13 +54,14 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
                double &inf_comp, double &step_norm) {
   constexpr int MM = M > 0 ? M : 1;
   const int N = a.N;
-  const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP;
+  const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
+  const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP && !lg;
   double Vx[NX], Vxx[NX * NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) Vx[i] = a.VxN[(size_t)i * a.Bp + b];
 #pragma unroll
   for (int i = 0; i < NX * NX; ++i) Vxx[i] = a.VxxN[(size_t)i * a.Bp + b];
-  if (ip) {   // V_xx = symmetrize(V_xx)  (ipddp_solver.cpp:992)
+  if (ip || lg) {   // V_xx = symmetrize(V_xx)  (ipddp_solver.cpp:992, logddp_solver.cpp:475)
     double T[NX * NX];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) T[i] = Vxx[i];
@@ -271,6 +275,40 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
           for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
         }
       }
+    } else if (lg) {
+      // LogDDP (logddp_solver.cpp:524-548): Q_uu_reg = Q_uu + reg I, THEN symmetrised; LDLT; [k | K] = -solve([Q_u | Q_ux]);
+      // Q_uu itself stays as it is for the value update
+      double Qr[NU * NU], Qs[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Qr[i] = Quu[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Qr[i * NU + c] + Qr[c * NU + i]);
+      if (NU == 1) {
+        kk[0] = -ldlt1_solve(Qs[0], Qu[0]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Qs[0], Qux[c]);
+      } else {
+        LDLTd<NU> f;
+        f.compute(Qs, NU);
+        if (!f.ok) return false;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        for (int c = 0; c < NX; ++c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+        }
+      }
     } else {
       // CLDDP without bounds: PD test, H = (Q_uu + reg I)^-1, reg only in the factor (clddp_solver.cpp:130-145)
       double Qr[NU * NU], H[NU * NU];
@@ -329,7 +367,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
           for (int j = 0; j < NU; ++j) { p += KK[j * NX + i] * Qux[j * NX + c]; q += Qux[j * NX + i] * KK[j * NX + c]; r += KtQ[i * NU + j] * KK[j * NX + c]; }
           Vn[i * NX + c] = ((Qxx[i * NX + c] + p) + q) + r;
         }
-    } else {    // CLDDP association order (clddp_solver.cpp:188-191)
+    } else {    // CLDDP association order (clddp_solver.cpp:188-191); LogDDP writes the same expression (logddp_solver.cpp:565-569)
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         double p = 0.0, q = 0.0, r = 0.0;
@@ -360,7 +398,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
 #pragma unroll
     for (int i = 0; i < NX; ++i) norm_Vx += fabs(Vx[i]);
   }
-  if (!ip) {   // CLDDP scales inf_du (clddp_solver.cpp:194-201); the caller passes termination_scaling_max_factor in tau_min
+  if (!ip && !lg) {   // CLDDP scales inf_du (clddp_solver.cpp:194-201); the caller passes termination_scaling_max_factor in tau_min
     double sc = a.tau_min;
     sc = dmax(sc, norm_Vx / (double)(N * NX)) / sc;
     inf_du = inf_du / sc;
@@ -582,7 +620,8 @@ int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, co
 int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hip_options *opt, const double *reg, const double *mu,
                              int retry, int32_t *ok) {
   if (!h || !opt || !reg) return sfail(-1, "null argument");
-  if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH) return sfail(-2, "unknown stack-fed branch %d", branch);
+  if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH && branch != CDDP_HIP_STACKS_LOGDDP)
+    return sfail(-2, "unknown stack-fed branch %d", branch);
   if (!h->have_dyn) return sfail(-1, "cddp_hip_set_stacks must be called before cddp_hip_stacks_backward");
   if (branch == CDDP_HIP_STACKS_IPDDP_PATH) {
     if (h->m <= 0) return sfail(-1, "the path-constrained branch needs a handle created with m > 0");

@@ -584,7 +584,7 @@ class HipBatchSolver:
         self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
 
 
-STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH = 0, 1, 2
+STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP = 0, 1, 2, 3
 
 
 class HipStackSolver:

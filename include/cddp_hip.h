@@ -434,7 +434,9 @@ typedef struct cddp_hip_stack_handle cddp_hip_stack_handle;
 enum cddp_hip_stacks_branch {
   CDDP_HIP_STACKS_CLDDP = 0,      /* clddp_solver.cpp:79-204 without control bounds                    */
   CDDP_HIP_STACKS_IPDDP = 1,      /* ipddp_solver.cpp:1048-1118 (no constraints)                       */
-  CDDP_HIP_STACKS_IPDDP_PATH = 2  /* ipddp_solver.cpp:1355-1568 (path constraints; handle with m > 0)  */
+  CDDP_HIP_STACKS_IPDDP_PATH = 2, /* ipddp_solver.cpp:1355-1568 (path constraints; handle with m > 0)  */
+  CDDP_HIP_STACKS_LOGDDP = 3      /* logddp_solver.cpp:470-575: the caller folds the relaxed log barrier's gradients / Hessians (barrier.hpp:95-262)
+                                     into lx, lu, lxx, luu, lux; handle with m = 0                     */
 };
 int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m /* total path dual dim, 0 = none */, int horizon,
                            cddp_hip_stack_handle **out);
