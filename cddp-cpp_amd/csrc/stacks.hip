@@ -36,6 +36,7 @@ struct StackArgs {
   const double *reg_in, *mu;                   // [Bp]
   const double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *VxN, *VxxN;
   const double *y, *s, *g, *Gx, *Gu;           // path-constraint stacks (branch IPDDP_PATH)
+  const double *Fxx, *Fuu, *Fux;               // dt-scaled dynamics Hessian tensors (full DDP, use_ilqr = false); NULL = Gauss-Newton
   double *K, *k, *Vx, *Vxx, *dV;
   double *ky, *Ky, *ks, *Ks, *dX;              // IPDDP_PATH outputs
   double *scal;                                // [6][Bp]: reg used, inf_du, inf_pr, inf_comp, step_norm, (unused)
@@ -136,6 +137,19 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
     for (int i = 0; i < NU * NX; ++i) Qux[i] = Qux[i] + P2[i];
 #pragma unroll
     for (int i = 0; i < NU * NU; ++i) Quu[i] = Quu[i] + P3[i];
+    if (a.Fxx) {   // full DDP: Q_xx += V_x(i) F_xx[t][i], Q_ux += V_x(i) F_ux[t][i], Q_uu += V_x(i) F_uu[t][i], V_x of step t + 1
+                   // (ipddp_solver.cpp:1070-1082, 1396-1408; logddp_solver.cpp:505-515; CLDDP has no such terms and the entry
+                   // point refuses the combination); rolled: the tensors are streamed
+      for (int i = 0; i < NX; ++i) {
+        const double w = Vx[i];
+#pragma unroll
+        for (int e = 0; e < NX * NX; ++e) Qxx[e] = Qxx[e] + w * a.Fxx[SI(t, NX * NX * NX, i * NX * NX + e)];
+#pragma unroll
+        for (int e = 0; e < NU * NX; ++e) Qux[e] = Qux[e] + w * a.Fux[SI(t, NX * NU * NX, i * NU * NX + e)];
+#pragma unroll
+        for (int e = 0; e < NU * NU; ++e) Quu[e] = Quu[e] + w * a.Fuu[SI(t, NX * NU * NU, i * NU * NU + e)];
+      }
+    }
     double kk[NU], KK[NU * NX];
     // ---------------------------------------------------------------- gains
     double YS[MM], rp[MM], rhat[MM], ssafe[MM], Sir[MM];
@@ -511,6 +525,7 @@ struct cddp_hip_stack_handle {
   std::vector<void *> allocs;
   StackArgs a{};
   double *d_reg = nullptr, *d_mu = nullptr;
+  double *d_Fxx = nullptr, *d_Fuu = nullptr, *d_Fux = nullptr;   // allocated by the first cddp_hip_set_hessian_stacks
   bool have_dyn = false, have_con = false, swept = false;
   double last_ms = 0.0;
   std::vector<double> tmp;
@@ -604,6 +619,25 @@ int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double
   return 0;
 }
 
+int cddp_hip_set_hessian_stacks(cddp_hip_stack_handle *h, const double *Fxx, const double *Fuu, const double *Fux) {
+  if (!h) return sfail(-1, "null handle");
+  SCHK(hipSetDevice(h->device));
+  if (!Fxx && !Fuu && !Fux) { h->a.Fxx = h->a.Fuu = h->a.Fux = nullptr; h->swept = false; return 0; }   // back to Gauss-Newton
+  if (!(Fxx && Fuu && Fux)) return sfail(-1, "cddp_hip_set_hessian_stacks needs F_xx, F_uu and F_ux together (or three NULLs to drop them)");
+  const int N = h->N, nx = h->nx, nu = h->nu;
+  if (!h->d_Fxx) {
+    int rc = salloc(h, &h->d_Fxx, (size_t)N * nx * nx * nx * h->Bp); if (rc) return rc;
+    rc = salloc(h, &h->d_Fuu, (size_t)N * nx * nu * nu * h->Bp); if (rc) return rc;
+    rc = salloc(h, &h->d_Fux, (size_t)N * nx * nu * nx * h->Bp); if (rc) return rc;
+  }
+  struct { const double *src; double *dst; int T, E; } items[] = {
+      {Fxx, h->d_Fxx, N, nx * nx * nx}, {Fuu, h->d_Fuu, N, nx * nu * nu}, {Fux, h->d_Fux, N, nx * nu * nx}};
+  for (auto &it : items) { int rc = upload(h, it.src, it.dst, it.T, it.E); if (rc) return rc; }
+  h->a.Fxx = h->d_Fxx; h->a.Fuu = h->d_Fuu; h->a.Fux = h->d_Fux;
+  h->swept = false;
+  return 0;
+}
+
 int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, const double *s, const double *g, const double *Gx, const double *Gu) {
   if (!h) return sfail(-1, "null handle");
   if (h->m <= 0) return sfail(-1, "this stack handle was created without path constraints (m = 0)");
@@ -631,6 +665,8 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   } else if (h->m > 0) {
     return sfail(-1, "this handle carries path-constraint stacks (m = %d): use CDDP_HIP_STACKS_IPDDP_PATH, or a handle with m = 0", h->m);
   }
+  if (branch == CDDP_HIP_STACKS_CLDDP && h->a.Fxx)
+    return sfail(-1, "CLDDPSolver::backwardPass has no second-order dynamics terms (clddp_solver.cpp:79-204): drop the Hessian stacks for this branch");
   for (int b = 0; b < h->B; ++b) if (!(reg[b] >= 0.0)) return sfail(-2, "regularisation of trajectory %d must be non-negative (got %g)", b, reg[b]);
   SCHK(hipSetDevice(h->device));
   SCHK(hipMemcpyAsync(h->d_reg, reg, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));

@@ -445,6 +445,12 @@ int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h);
  * pass NULL for stacks that did not change (e.g. constant cost Hessians). */
 int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double *fu, const double *lx, const double *lu,
                         const double *lxx, const double *luu, const double *lux, const double *VxN, const double *VxxN);
+/* Full DDP (options.use_ilqr = false) for host plug-ins: the dynamics Hessian tensors of the current iterate, as the reference
+ * keeps them in F_xx_ / F_uu_ / F_ux_ (cddp_solver_base.cpp:346-356) but ALREADY multiplied by dt -- Fxx[b][t][i] (nx x nx),
+ * Fuu[b][t][i] (nu x nu), Fux[b][t][i] (nu x nx), i = output row of f.  The IPDDP and LogDDP branches then add V_x(i) times
+ * them to Q_xx, Q_uu, Q_ux (ipddp_solver.cpp:1070-1082, 1396-1408; logddp_solver.cpp:505-515); the reference's CLDDP backward pass
+ * has no such terms and cddp_hip_stacks_backward refuses that combination.  Three NULLs return to Gauss-Newton. */
+int cddp_hip_set_hessian_stacks(cddp_hip_stack_handle *h, const double *Fxx, const double *Fuu, const double *Fux);
 /* Upload the condensation inputs of the path-constrained branch (same NULL rule). */
 int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, const double *s, const double *g,
                                    const double *Gx, const double *Gu);

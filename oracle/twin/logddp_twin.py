@@ -74,8 +74,9 @@ def barrier_hessians(c, x, u, coeff, delta):          # getHessians, barrier.hpp
     return coeff * Hxx, coeff * Huu, coeff * Hux
 
 
-def backward(A, B, lx, lu, lxx, luu, lux, VxN, VxxN, cons, X, U, coeff, delta, reg):
+def backward(A, B, lx, lu, lxx, luu, lux, VxN, VxxN, cons, X, U, coeff, delta, reg, hess=None):
     """logddp_solver.cpp:470-575 for one trajectory; A[t] = I + dt f_x, B[t] = dt f_u; cons = list of BoxRows (may be empty).
+    hess (use_ilqr = false, :505-515): per step the dt-scaled tensors (F_xx, F_uu, F_ux), each indexed by the output row i.
     Returns ok, K, k, Vx (N+1), Vxx (N+1), dV (2), inf_du."""
     N = len(A); nx = A[0].shape[0]; nu = B[0].shape[1]
     V_x = np.array(VxN, float)
@@ -89,6 +90,10 @@ def backward(A, B, lx, lu, lxx, luu, lux, VxN, VxxN, cons, X, U, coeff, delta, r
         Q_xx = lxx[t] + A[t].T @ V_xx @ A[t]
         Q_ux = lux[t] + B[t].T @ V_xx @ A[t]
         Q_uu = luu[t] + B[t].T @ V_xx @ B[t]
+        if hess is not None:
+            Fxx, Fuu, Fux = hess[t]
+            for i in range(nx):
+                Q_xx = Q_xx + V_x[i] * Fxx[i]; Q_ux = Q_ux + V_x[i] * Fux[i]; Q_uu = Q_uu + V_x[i] * Fuu[i]
         for c in cons:
             gx, gu = barrier_gradients(c, X[t], U[t], coeff, delta)
             Q_x = Q_x + gx; Q_u = Q_u + gu

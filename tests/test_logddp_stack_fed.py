@@ -53,7 +53,8 @@ def _case(name, seed):
     lx = np.array([2.0 * Qd @ (X[t] - xref) for t in range(N)]); lu = np.array([2.0 * Rd @ U[t] for t in range(N)])
     lxx = np.tile(2.0 * Qd, (N, 1, 1)); luu = np.tile(2.0 * Rd, (N, 1, 1)); lux = np.zeros((N, m.nu, m.nx))
     VxN = 2.0 * Qf @ (X[N] - xref); VxxN = 2.0 * Qf
-    return dict(A=np.array(A), B=np.array(B), lx=lx, lu=lu, lxx=lxx, luu=luu, lux=lux, VxN=VxN, VxxN=VxxN, cons=cons, X=X, U=U, nx=m.nx, nu=m.nu, N=N)
+    hess = [tuple(dt * h for h in m.hess(X[t], U[t], t * dt)) for t in range(N)]      # dt-scaled F_xx, F_uu, F_ux (cddp_solver_base.cpp:346-356)
+    return dict(A=np.array(A), B=np.array(B), lx=lx, lu=lu, lxx=lxx, luu=luu, lux=lux, VxN=VxN, VxxN=VxxN, cons=cons, X=X, U=U, nx=m.nx, nu=m.nu, N=N, hess=hess)
 
 
 def test_relaxed_log_barrier_derivatives_match_finite_differences():
@@ -127,6 +128,17 @@ def test_hip_logddp_sweep_matches_the_restatement(api, name):
             for nm, got, ref in (("K", K[b], Kr), ("k", k[b], kr), ("Vx", Vx[b], Vxr), ("Vxx", Vxx[b], Vxxr), ("dV", dV[b], dVr)):
                 assert rel(got, ref) < TOL, (name, reg0, b, nm, rel(got, ref))
             assert rel(sc["inf_du"][b], qu) < TOL          # raw max |Q_u| (logddp_solver.cpp:572), no CLDDP scaling
+    # use_ilqr = false (logddp_solver.cpp:505-515): the dt-scaled Hessian tensors through cddp_hip_set_hessian_stacks
+    hs.set_hessian_stacks(np.array([[h[0] for h in c["hess"]] for c in cases]), np.array([[h[1] for h in c["hess"]] for c in cases]),
+                          np.array([[h[2] for h in c["hess"]] for c in cases]))
+    ok = hs.backward(api.STACKS_LOGDDP, opt, np.full(Bn, 1e-6), None, retry=False)
+    K, k, Vx, Vxx, dV = hs.gains()
+    for b, c in enumerate(cases):
+        okr, Kr, kr, Vxr, Vxxr, dVr, qu = Lg.backward(c["A"], c["B"], c["lx"], c["lu"], c["lxx"], c["luu"], c["lux"], c["VxN"], c["VxxN"],
+                                                    c["cons"], c["X"], c["U"], coeff, delta, 1e-6, hess=c["hess"])
+        assert bool(ok[b]) == okr
+        if okr: assert max(rel(K[b], Kr), rel(k[b], kr), rel(Vx[b], Vxr), rel(Vxx[b], Vxxr)) < 1e-6, (name, b)   # (indefinite Q_uu under full DDP: gains 1e3, measured 2e-8)
+    hs.set_hessian_stacks(None, None, None)
     # the retry loop of the outer solver (cddp_solver_base.cpp:93-111) with an indefinite start: l_uu made negative
     bad = np.stack([f[3] for f in folded]).copy(); bad[:, :, 0, 0] -= 50.0
     hs.set_stacks(luu=bad)

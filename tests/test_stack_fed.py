@@ -150,7 +150,8 @@ def _twin_stacks(tw):
             gx, gu = c.jac(tw.X[t], tw.U[t]); Gx[t, off:off + c.dim] = gx; Gu[t, off:off + c.dim] = gu; off += c.dim
     H = 2.0 * tw.Qf
     return dict(fx=fx, fu=fu, lx=lx, lu=lu, lxx=np.tile(lxx, (N, 1, 1)), luu=np.tile(luu, (N, 1, 1)), lux=np.tile(lux, (N, 1, 1)),
-                VxN=2.0 * tw.Qf @ (tw.X[N] - tw.xref), VxxN=H, y=tw.Y.copy(), s=tw.S.copy(), g=tw.G.copy(), Gx=Gx, Gu=Gu)
+                VxN=2.0 * tw.Qf @ (tw.X[N] - tw.xref), VxxN=H, y=getattr(tw, "Y", np.zeros((N, m))).copy(), s=getattr(tw, "S", np.zeros((N, m))).copy(),
+                g=getattr(tw, "G", np.zeros((N, m))).copy(), Gx=Gx, Gu=Gu)
 
 
 @pytest.mark.parametrize("kind", ["quadratic_scalar_box", "quadratic_scalar_linear", "tilted_unicycle_box_ball"])
@@ -206,6 +207,56 @@ def test_constrained_stack_fed_sweep_on_user_plugins(api, kind):
             else:
                 tw.forward_failure()
     assert hs.kernel_ms() > 0.0
+    hs.close()
+
+
+@pytest.mark.parametrize("name", ["pendulum_ipddp_box", "cartpole_ipddp_box", "unicycle_ipddp_box_ball", "cartpole_clddp_unc"])
+def test_stack_fed_full_ddp_with_hessian_stacks(api, name):
+    """options.use_ilqr = false for host plug-ins: the dt-scaled Hessian tensors F_xx, F_uu, F_ux (cddp_solver_base.cpp:346-356)
+    go in through cddp_hip_set_hessian_stacks and every branch adds V_x(i) times them (ipddp_solver.cpp:1070-1082, 1396-1408);
+    checked against the numpy twin's full-DDP sweep of the same iterate; dropping the stacks returns to Gauss-Newton."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_twin_golden as G
+    B = 4
+    rng = np.random.default_rng(20261130)
+    twins, twins_gn = [], []
+    for b in range(B):
+        pert = None
+        for ilqr, dst in ((False, twins), (True, twins_gn)):
+            spec = G.CASES[name](); spec["options"]["use_ilqr"] = ilqr
+            tw = G.T.Twin(spec)
+            if pert is None: pert = (0.0 if b == 0 else 1.0) * rng.uniform(-0.02, 0.02, size=len(spec["x0"]))
+            tw.set_initial(np.array(spec["x0"], float) + pert, spec.get("U0")); tw.initialize(); tw.X_lin, tw.U_lin = tw.X, tw.U
+            dst.append(tw)
+    tw0 = twins[0]
+    hs = api.HipStackSolver(B, tw0.nx, tw0.nu, tw0.m, tw0.N)
+    st = [_twin_stacks(tw) for tw in twins]
+    stack = lambda key: np.stack([s_[key] for s_ in st])
+    hs.set_stacks(stack("fx"), stack("fu"), stack("lx"), stack("lu"), stack("lxx"), stack("luu"), stack("lux"), stack("VxN"), stack("VxxN"))
+    if tw0.m: hs.set_constraint_stacks(stack("y"), stack("s"), stack("g"), stack("Gx"), stack("Gu"))
+    H = [[tw.hess_stack(t) for t in range(tw.N)] for tw in twins]
+    Fxx = np.array([[h[0] for h in Hb] for Hb in H]); Fuu = np.array([[h[1] for h in Hb] for Hb in H]); Fux = np.array([[h[2] for h in Hb] for Hb in H])
+    hs.set_hessian_stacks(Fxx, Fuu, Fux)
+    opt = api.default_options()
+    branch = api.STACKS_CLDDP if tw0.solver == "CLDDP" else (api.STACKS_IPDDP_PATH if tw0.m else api.STACKS_IPDDP)
+    reg = np.array([tw.reg for tw in twins]); mu = np.array([tw.mu for tw in twins]) if tw0.m else None
+    if branch == api.STACKS_CLDDP:      # CLDDPSolver::backwardPass has no second-order terms (clddp_solver.cpp:79-204): refused
+        with pytest.raises(api.HipError, match="second-order"):
+            hs.backward(branch, opt, reg, mu, retry=False)
+    for pass_, ref in (("ddp", twins), ("gauss-newton", twins_gn)):
+        if branch == api.STACKS_CLDDP and pass_ == "ddp": continue
+        if pass_ == "gauss-newton": hs.set_hessian_stacks(None, None, None)
+        ok = hs.backward(branch, opt, reg, mu, retry=False)
+        K, k, Vx, Vxx, dV = hs.gains()
+        for b, tw in enumerate(ref):
+            okt = tw.backward()
+            assert bool(ok[b]) == bool(okt), (name, pass_, b)
+            if not okt: continue
+            for nm, got, want in (("K", K[b], tw.K_u), ("k", k[b], tw.k_u), ("Vx", Vx[b], tw.Vx), ("Vxx", Vxx[b], tw.Vxx)):
+                assert rel(got, want) < 1e-8, (name, pass_, b, nm, rel(got, want))      # (1e-8: indefinite Q_uu blocks under full DDP)
+    # the tensor terms are not a no-op (trajectory 1 is off the equilibrium)
+    if name.startswith("unicycle"): assert rel(twins[1].K_u, twins_gn[1].K_u) > 1e-8
     hs.close()
 
 
