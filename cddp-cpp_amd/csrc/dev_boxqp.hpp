@@ -1,0 +1,109 @@
+// BoxQP: projected-Newton solver of  min 0.5 x^T H x + g^T x  s.t. lower <= x <= upper  (src/cddp_core/boxqp.cpp:25-250),
+// shared by the CLDDP sweeps of the solver core (kernels.hpp, kernels_coop.hpp) and of the stack-fed mode (stacks.hip).
+#pragma once
+#include "dev_linalg.hpp"
+#include "../../include/cddp_hip.h"
+
+namespace cddp_dev {
+
+enum { BQ_HESSIAN_NOT_PD = -1, BQ_NO_DESCENT = 0, BQ_MAX_ITER = 1, BQ_MAX_LS = 2, BQ_SUCCESS = 4, BQ_ALL_CLAMPED = 5 };
+
+template <int N>
+DEV double boxqp_objective(const double *x, const double *H, const double *g) {
+  double q = 0.0, l = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double hx = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) hx += H[i * N + j] * x[j];
+    q += x[i] * hx;
+    l += g[i] * x[i];
+  }
+  return 0.5 * q + l;
+}
+
+// Returns status; x (in: warm start, out: solution), free mask, Hfree factor of the final free block.
+template <int N>
+DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g, const double *lower,
+                    const double *upper, double *x, int *free_, LDLTd<N> &Hfree) {
+  int status = BQ_MAX_ITER;
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = dmin(dmax(x[i], lower[i]), upper[i]);
+  int clamped[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { clamped[i] = 0; free_[i] = 1; }
+  double value = boxqp_objective<N>(x, H, g);
+  double old_value = INFINITY;
+  for (int iter = 0; iter < o.boxqp_max_iterations; ++iter) {
+    if (iter > 0 && fabs(old_value - value) < o.boxqp_min_relative_improvement * fabs(old_value)) { status = BQ_SUCCESS; break; }
+    old_value = value;
+    double grad[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double hx = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) hx += H[i * N + j] * x[j];
+      grad[i] = g[i] + hx;
+    }
+    int old_clamped[N];
+    int nclamped = 0;
+    bool any_different = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      old_clamped[i] = clamped[i];
+      clamped[i] = ((x[i] == lower[i] && grad[i] > 0) || (x[i] == upper[i] && grad[i] < 0)) ? 1 : 0;
+      nclamped += clamped[i];
+      free_[i] = 1 - clamped[i];
+      if (old_clamped[i] != clamped[i]) any_different = true;
+    }
+    if (nclamped == N) { status = BQ_ALL_CLAMPED; break; }
+    const bool factorize = (iter == 0) || any_different;
+    int free_idx[N];
+    int nf = 0;
+    for (int i = 0; i < N; ++i) if (!clamped[i]) free_idx[nf++] = i;
+    if (factorize) {
+      double Hf[N * N];
+      for (int i = 0; i < nf; ++i) for (int j = 0; j < nf; ++j) Hf[i * N + j] = H[free_idx[i] * N + free_idx[j]];
+      Hfree.compute(Hf, nf);
+      if (!Hfree.ok) { status = BQ_HESSIAN_NOT_PD; break; }
+    }
+    double grad_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (!clamped[i]) grad_norm += grad[i] * grad[i];
+    grad_norm = sqrt(grad_norm);
+    if (grad_norm < o.boxqp_min_gradient_norm) { status = BQ_SUCCESS; break; }
+    double search[N], grad_clamped[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { search[i] = 0.0; grad_clamped[i] = g[i]; }
+    for (int i = 0; i < N; ++i)
+      if (clamped[i]) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) grad_clamped[r] += H[r * N + i] * x[i];
+      }
+    double sf[N];
+    for (int i = 0; i < nf; ++i) sf[i] = grad_clamped[free_idx[i]];
+    Hfree.solve(sf);
+    for (int i = 0; i < nf; ++i) search[free_idx[i]] = (-sf[i]) - x[free_idx[i]];
+    double sdotg = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) sdotg += search[i] * grad[i];
+    if (sdotg >= 0) { status = BQ_NO_DESCENT; break; }
+    double step = 1.0;
+    bool ls_ok = false;
+    double xn[N];
+    while (step > o.boxqp_min_step_size) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) xn[i] = dmin(dmax(x[i] + step * search[i], lower[i]), upper[i]);
+      double value_new = boxqp_objective<N>(xn, H, g);
+      if ((value_new - value) <= o.boxqp_armijo_constant * step * sdotg) { ls_ok = true; break; }
+      step *= o.boxqp_step_decrease_factor;
+    }
+    if (!ls_ok) { status = BQ_MAX_LS; break; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = xn[i];
+    value = boxqp_objective<N>(x, H, g);
+  }
+  return status;
+}
+
+}  // namespace cddp_dev

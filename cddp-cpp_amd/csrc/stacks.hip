@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "dev_linalg.hpp"
+#include "dev_boxqp.hpp"
 #include "../../include/cddp_hip.h"
 
 using namespace cddp_dev;
@@ -37,6 +38,8 @@ struct StackArgs {
   const double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *VxN, *VxxN;
   const double *y, *s, *g, *Gx, *Gu;           // path-constraint stacks (branch IPDDP_PATH)
   const double *Fxx, *Fuu, *Fux;               // dt-scaled dynamics Hessian tensors (full DDP, use_ilqr = false); NULL = Gauss-Newton
+  const double *U, *lo, *up;                   // CLDDP control box (clddp_solver.cpp:147-178): current controls [N][nu], bounds [nu]; lo = NULL: none
+  cddp_hip_options opt;                        // BoxQP parameters
   double *K, *k, *Vx, *Vxx, *dV;
   double *ky, *Ky, *ks, *Ks, *dX;              // IPDDP_PATH outputs
   double *scal;                                // [6][Bp]: reg used, inf_du, inf_pr, inf_comp, step_norm, (unused)
@@ -331,6 +334,28 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
 #pragma unroll
       for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
       if (min_real_eig<NU>(Qr) <= 0) return false;
+      if (a.lo) {   // control-limited step: BoxQP on [lower - u_t, upper - u_t], warm-started with the previous k_t; feedback on the
+                    // free directions only (clddp_solver.cpp:147-178)
+        double lb[NU], ub[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const double ut = a.U[SI(t, NU, i)]; lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = a.k[SI(t, NU, i)]; }
+        int free_[NU];
+        LDLTd<NU> Hfree;
+        const int stq = boxqp_solve<NU>(a.opt, Qr, Qu, lb, ub, kk, free_, Hfree);
+        if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) KK[i] = 0.0;
+        int free_idx[NU]; int nf = 0;
+        for (int i = 0; i < NU; ++i) if (free_[i]) free_idx[nf++] = i;
+        if (nf > 0) {
+          for (int c = 0; c < NX; ++c) {
+            double col[NU];
+            for (int i = 0; i < nf; ++i) col[i] = Qux[free_idx[i] * NX + c];
+            Hfree.solve(col);
+            for (int i = 0; i < nf; ++i) KK[free_idx[i] * NX + c] = -col[i];
+          }
+        }
+      } else {
       inverse_pplu<NU>(Qr, H);
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
@@ -345,6 +370,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
           for (int j = 0; j < NU; ++j) s2 += (-H[i * NU + j]) * Qux[j * NX + c];
           KK[i * NX + c] = s2;
         }
+      }
       }
     }
 #pragma unroll
@@ -526,6 +552,7 @@ struct cddp_hip_stack_handle {
   StackArgs a{};
   double *d_reg = nullptr, *d_mu = nullptr;
   double *d_Fxx = nullptr, *d_Fuu = nullptr, *d_Fux = nullptr;   // allocated by the first cddp_hip_set_hessian_stacks
+  double *d_U = nullptr, *d_lo = nullptr, *d_up = nullptr;      // allocated by the first cddp_hip_set_control_box
   bool have_dyn = false, have_con = false, swept = false;
   double last_ms = 0.0;
   std::vector<double> tmp;
@@ -619,6 +646,30 @@ int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double
   return 0;
 }
 
+int cddp_hip_set_control_box(cddp_hip_stack_handle *h, const double *lower, const double *upper, const double *U) {
+  if (!h) return sfail(-1, "null handle");
+  SCHK(hipSetDevice(h->device));
+  if (!lower && !upper && !U) { h->a.lo = h->a.up = h->a.U = nullptr; h->swept = false; return 0; }   // no bounds
+  if (!h->a.lo && !(lower && upper && U)) return sfail(-1, "the first cddp_hip_set_control_box call needs lower, upper and the control stack U");
+  if ((lower == nullptr) != (upper == nullptr)) return sfail(-1, "lower and upper bounds come together");
+  const int N = h->N, nu = h->nu;
+  if (!h->d_U) {
+    int rc = salloc(h, &h->d_U, (size_t)N * nu * h->Bp); if (rc) return rc;
+    rc = salloc(h, &h->d_lo, nu); if (rc) return rc;
+    rc = salloc(h, &h->d_up, nu); if (rc) return rc;
+  }
+  if (lower) {
+    for (int i = 0; i < nu; ++i) if (!(lower[i] <= upper[i])) return sfail(-2, "control bound %d: lower %g > upper %g", i, lower[i], upper[i]);
+    SCHK(hipMemcpyAsync(h->d_lo, lower, sizeof(double) * nu, hipMemcpyHostToDevice, h->stream));
+    SCHK(hipMemcpyAsync(h->d_up, upper, sizeof(double) * nu, hipMemcpyHostToDevice, h->stream));
+    SCHK(hipStreamSynchronize(h->stream));
+  }
+  if (U) { int rc = upload(h, U, h->d_U, N, nu); if (rc) return rc; }
+  h->a.lo = h->d_lo; h->a.up = h->d_up; h->a.U = h->d_U;
+  h->swept = false;
+  return 0;
+}
+
 int cddp_hip_set_hessian_stacks(cddp_hip_stack_handle *h, const double *Fxx, const double *Fuu, const double *Fux) {
   if (!h) return sfail(-1, "null handle");
   SCHK(hipSetDevice(h->device));
@@ -673,6 +724,8 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   if (mu) SCHK(hipMemcpyAsync(h->d_mu, mu, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
   StackArgs a = h->a;
   a.branch = branch;
+  a.opt = *opt;
+  if (branch != CDDP_HIP_STACKS_CLDDP) a.lo = a.up = a.U = nullptr;   // the box belongs to the CLDDP branch
   a.mu = mu ? h->d_mu : nullptr;
   a.reg_factor = retry ? opt->reg_update_factor : 0.0;
   a.reg_max = opt->reg_max_value;

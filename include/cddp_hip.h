@@ -445,6 +445,12 @@ int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h);
  * pass NULL for stacks that did not change (e.g. constant cost Hessians). */
 int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double *fu, const double *lx, const double *lu,
                         const double *lxx, const double *luu, const double *lux, const double *VxN, const double *VxxN);
+/* Control limits of the CLDDP branch (the constraint named "ControlConstraint", clddp_solver.cpp:85-86, 147-178): every step
+ * solves the BoxQP  min 0.5 k^T Q_uu_reg k + Q_u^T k,  lower - u_t <= k <= upper - u_t  (boxqp.cpp:25-250, parameters from
+ * options.boxqp_*), warm-started with the k_t of the handle's previous sweep, and the feedback gain lives on the free
+ * directions.  lower / upper: nu each; U: the current controls, batch-major [b][t][nu].  The first call supplies all three;
+ * later calls may pass NULL bounds to keep them (U changes every iteration); three NULLs remove the box. */
+int cddp_hip_set_control_box(cddp_hip_stack_handle *h, const double *lower, const double *upper, const double *U);
 /* Full DDP (options.use_ilqr = false) for host plug-ins: the dynamics Hessian tensors of the current iterate, as the reference
  * keeps them in F_xx_ / F_uu_ / F_ux_ (cddp_solver_base.cpp:346-356) but ALREADY multiplied by dt -- Fxx[b][t][i] (nx x nx),
  * Fuu[b][t][i] (nu x nu), Fux[b][t][i] (nu x nx), i = output row of f.  The IPDDP and LogDDP branches then add V_x(i) times

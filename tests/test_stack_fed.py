@@ -260,6 +260,63 @@ def test_stack_fed_full_ddp_with_hessian_stacks(api, name):
     hs.close()
 
 
+@pytest.mark.parametrize("name", ["pendulum_clddp_box", "cartpole_clddp_box", "unicycle_clddp_box"])
+def test_stack_fed_clddp_with_control_box(api, name):
+    """The control-limited step of CLDDP for host plug-ins (clddp_solver.cpp:147-178, boxqp.cpp:25-250): BoxQP per step on
+    [lower - u_t, upper - u_t], warm-started with the previous sweep's k_t, feedback on the free directions -- against the
+    numpy twin over the first iterations of its own solve (clamped and free steps both occur)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_twin_golden as G
+    B = 4
+    rng = np.random.default_rng(20261207)
+    twins = []
+    for b in range(B):
+        spec = G.CASES[name]()
+        tw = G.T.Twin(spec)
+        x0 = np.array(spec["x0"], float) + (0.0 if b == 0 else 1.0) * rng.uniform(-0.05, 0.05, size=len(spec["x0"]))
+        tw.set_initial(x0, spec.get("U0")); tw.initialize(); tw.X_lin, tw.U_lin = tw.X, tw.U
+        twins.append(tw)
+    tw0 = twins[0]
+    box = tw0.clddp_box()
+    assert box is not None
+    hs = api.HipStackSolver(B, tw0.nx, tw0.nu, 0, tw0.N)
+    opt = api.default_options()
+    for key, val in tw0.o.items():
+        if key.startswith("boxqp_") and hasattr(opt, key): setattr(opt, key, val)
+    clamped = free = 0
+    for outer in range(5):
+        st = [_twin_stacks(tw) for tw in twins]
+        stack = lambda key: np.stack([s_[key] for s_ in st])
+        hs.set_stacks(stack("fx"), stack("fu"), stack("lx"), stack("lu"), stack("lxx"), stack("luu"), stack("lux"), stack("VxN"), stack("VxxN"))
+        hs.set_control_box(box.lo if outer == 0 else None, box.up if outer == 0 else None, np.stack([tw.U for tw in twins]))
+        reg0 = np.array([tw.reg for tw in twins])
+        ok = hs.backward(api.STACKS_CLDDP, opt, reg0, None, retry=True)
+        K, k, Vx, Vxx, dV = hs.gains(); sc = hs.scalars()
+        for b, tw in enumerate(twins):
+            okt = False
+            while not okt:
+                okt = tw.backward()
+                if not okt:
+                    tw.reg_up()
+                    if tw.reg_limit(): break
+            assert bool(ok[b]) == okt and sc["reg"][b] == tw.reg, (name, outer, b)
+            if not okt: continue
+            for nm, got, ref in (("K", K[b], tw.K_u), ("k", k[b], tw.k_u), ("Vx", Vx[b], tw.Vx), ("Vxx", Vxx[b], tw.Vxx), ("dV", dV[b], tw.dV)):
+                assert rel(got, ref) < TOL, (name, outer, b, nm, rel(got, ref))
+            assert rel(sc["inf_du"][b], tw.inf_du) < TOL
+            rows = np.all(tw.K_u == 0.0, axis=2)          # a clamped control has a zero feedback row
+            clamped += int(rows.sum()); free += int((~rows).sum())
+            best = tw.line_search()
+            if best["success"]: tw.apply(best); tw.reg_down()
+            else: tw.forward_failure()
+    assert clamped > 0 and free > 0, (clamped, free)
+    # without the box the same handle is the unconstrained CLDDP sweep again
+    hs.set_control_box(None, None, None)
+    hs.backward(api.STACKS_CLDDP, opt, np.array([tw.reg for tw in twins]), None, retry=False)
+    hs.close()
+
+
 def test_stack_handle_argument_checks(api):
     hs = api.HipStackSolver(3, 1, 1, 2, 4)
     opt = api.default_options()
