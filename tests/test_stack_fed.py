@@ -338,3 +338,24 @@ def test_stack_handle_argument_checks(api):
     ok = hs.backward(api.STACKS_IPDDP_PATH, opt, 1e-6, 0.1)
     assert ok.all()
     hs.close()
+    # round-2 additions: control box, Hessian stacks, LogDDP branch
+    h0 = api.HipStackSolver(3, 1, 1, 0, 4)
+    h0.set_stacks(np.ones((3, 4, 1, 1)), np.ones((3, 4, 1, 1)), z(3, 4, 1), z(3, 4, 1), np.ones((3, 4, 1, 1)), np.ones((3, 4, 1, 1)), z(3, 4, 1, 1), z(3, 1), np.ones((3, 1, 1)))
+    with pytest.raises(api.HipError):
+        h0.set_control_box(np.array([-1.0]), None, z(3, 4, 1))         # bounds come together
+    with pytest.raises(api.HipError):
+        h0.set_control_box(None, None, z(3, 4, 1))                     # first call needs the bounds
+    with pytest.raises(api.HipError):
+        h0.set_control_box(np.array([1.0]), np.array([-1.0]), z(3, 4, 1))   # lower > upper
+    with pytest.raises(api.HipError):
+        h0.set_hessian_stacks(z(3, 4, 1, 1, 1), None, None)            # the three tensors come together
+    h0.set_hessian_stacks(z(3, 4, 1, 1, 1), z(3, 4, 1, 1, 1), z(3, 4, 1, 1, 1))
+    with pytest.raises(api.HipError, match="second-order"):
+        h0.backward(api.STACKS_CLDDP, opt, 1e-6)                       # CLDDP has no tensor terms
+    assert h0.backward(api.STACKS_LOGDDP, opt, 1e-6).all() and h0.backward(api.STACKS_IPDDP, opt, 1e-6).all()
+    h0.set_hessian_stacks(None, None, None)
+    h0.set_control_box(np.array([-1.0]), np.array([1.0]), z(3, 4, 1))
+    assert h0.backward(api.STACKS_CLDDP, opt, 1e-6).all()
+    with pytest.raises(api.HipError):
+        h0.backward(7, opt, 1e-6)                                      # unknown branch
+    h0.close()
