@@ -8,6 +8,8 @@
 //   CDDP_HIP_STACKS_LOGDDP     logddp_solver.cpp:470-575 (the host folds the relaxed-log-barrier gradients / Hessians of
 //                              barrier.hpp:95-262 into the cost stacks: reg added THEN symmetrised, LDLT, the value update with
 //                              the un-regularised Q_uu in CLDDP's association order, raw max |Q_u|)
+//   CDDP_HIP_STACKS_MSIPDDP    msipddp_solver.cpp:1112-1208 (no constraints): the IPDDP recursion with the multiple-shooting defect
+//                              d_t = f(x_t, u_t) - x_{t+1} entering as V_x + V_xx d_t in Q_x, Q_u (defect stack required)
 //   CDDP_HIP_STACKS_IPDDP_PATH ipddp_solver.cpp:1355-1568 (path constraints condensed: y, s, g, G_x, G_u stacks; gains of
 //                              the slack / dual directions, linear-policy rollout, dS, dY, computeMaxStepSizes :2939-2988)
 // One trajectory per lane, batch-minor stacks [t][e][Bp]: every wavefront load is one coalesced 512-B row.
@@ -38,6 +40,7 @@ struct StackArgs {
   const double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *VxN, *VxxN;
   const double *y, *s, *g, *Gx, *Gu;           // path-constraint stacks (branch IPDDP_PATH)
   const double *Fxx, *Fuu, *Fux;               // dt-scaled dynamics Hessian tensors (full DDP, use_ilqr = false); NULL = Gauss-Newton
+  const double *dfc;                           // MSIPDDP defects d_t [N][nx]
   const double *U, *lo, *up;                   // CLDDP control box (clddp_solver.cpp:147-178): current controls [N][nu], bounds [nu]; lo = NULL: none
   cddp_hip_options opt;                        // BoxQP parameters
   double *K, *k, *Vx, *Vxx, *dV;
@@ -59,6 +62,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
   constexpr int MM = M > 0 ? M : 1;
   const int N = a.N;
   const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
+  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP;          // = unconstrained IPDDP + defects
   const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP && !lg;
   double Vx[NX], Vxx[NX * NX];
 #pragma unroll
@@ -118,15 +122,25 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
         for (int r = 0; r < M; ++r) s1 += Gu[r * NU + i] * y[r];
         Qu[i] = Qu[i] + s1; }
     }
+    double w[NX];   // V_x, or V_x + V_xx d_t under multiple shooting (msipddp_solver.cpp:1144-1145)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) w[i] = Vx[i];
+    if (ms) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s1 += Vxx[i * NX + k] * a.dfc[SI(t, NX, k)];
+        w[i] = Vx[i] + s1; }
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { double s1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += A[k * NX + i] * Vx[k];
+      for (int k = 0; k < NX; ++k) s1 += A[k * NX + i] * w[k];
       Qx[i] = Qx[i] + s1; }
 #pragma unroll
     for (int i = 0; i < NU; ++i) { double s1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += Bm[k * NU + i] * Vx[k];
+      for (int k = 0; k < NX; ++k) s1 += Bm[k * NU + i] * w[k];
       Qu[i] = Qu[i] + s1; }
     double T1[NX * NX], T2[NU * NX], P1[NX * NX], P2[NU * NX], P3[NU * NU];
     mm_tn<NX, NX, NX>(A, Vxx, T1);
@@ -553,6 +567,7 @@ struct cddp_hip_stack_handle {
   double *d_reg = nullptr, *d_mu = nullptr;
   double *d_Fxx = nullptr, *d_Fuu = nullptr, *d_Fux = nullptr;   // allocated by the first cddp_hip_set_hessian_stacks
   double *d_U = nullptr, *d_lo = nullptr, *d_up = nullptr;      // allocated by the first cddp_hip_set_control_box
+  double *d_dfc = nullptr;                                      // allocated by the first cddp_hip_set_defect_stack
   bool have_dyn = false, have_con = false, swept = false;
   double last_ms = 0.0;
   std::vector<double> tmp;
@@ -646,6 +661,16 @@ int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double
   return 0;
 }
 
+int cddp_hip_set_defect_stack(cddp_hip_stack_handle *h, const double *defects) {
+  if (!h) return sfail(-1, "null handle");
+  SCHK(hipSetDevice(h->device));
+  if (!defects) { h->a.dfc = nullptr; h->swept = false; return 0; }
+  if (!h->d_dfc) { int rc = salloc(h, &h->d_dfc, (size_t)h->N * h->nx * h->Bp); if (rc) return rc; }
+  int rc = upload(h, defects, h->d_dfc, h->N, h->nx); if (rc) return rc;
+  h->a.dfc = h->d_dfc; h->swept = false;
+  return 0;
+}
+
 int cddp_hip_set_control_box(cddp_hip_stack_handle *h, const double *lower, const double *upper, const double *U) {
   if (!h) return sfail(-1, "null handle");
   SCHK(hipSetDevice(h->device));
@@ -705,8 +730,15 @@ int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, co
 int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hip_options *opt, const double *reg, const double *mu,
                              int retry, int32_t *ok) {
   if (!h || !opt || !reg) return sfail(-1, "null argument");
-  if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH && branch != CDDP_HIP_STACKS_LOGDDP)
+  if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH && branch != CDDP_HIP_STACKS_LOGDDP &&
+      branch != CDDP_HIP_STACKS_MSIPDDP)
     return sfail(-2, "unknown stack-fed branch %d", branch);
+  if (branch == CDDP_HIP_STACKS_MSIPDDP) {
+    if (h->m > 0)   // msipddp_solver.cpp:1398 adds an (nx x nu) product to the (nu x nx) block Q_ux: not a defined recursion for nx != nu
+      return sfail(-1, "the MSIPDDP branch covers the unconstrained recursion (msipddp_solver.cpp:1112-1208); handle with m = 0");
+    if (!h->a.dfc) return sfail(-1, "cddp_hip_set_defect_stack must be called before the MSIPDDP sweep");
+    if (h->a.Fxx) return sfail(-1, "the MSIPDDP branch is Gauss-Newton here: its second-order terms weigh the Hessians with the costates (msipddp_solver.cpp:1151-1163); drop the Hessian stacks");
+  }
   if (!h->have_dyn) return sfail(-1, "cddp_hip_set_stacks must be called before cddp_hip_stacks_backward");
   if (branch == CDDP_HIP_STACKS_IPDDP_PATH) {
     if (h->m <= 0) return sfail(-1, "the path-constrained branch needs a handle created with m > 0");

@@ -430,7 +430,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
-    "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
+    "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
@@ -584,7 +584,7 @@ class HipBatchSolver:
         self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
 
 
-STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP = 0, 1, 2, 3
+STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP = 0, 1, 2, 3, 4
 
 
 class HipStackSolver:
@@ -617,6 +617,11 @@ class HipStackSolver:
     def set_stacks(self, fx=None, fu=None, lx=None, lu=None, lxx=None, luu=None, lux=None, VxN=None, VxxN=None):
         a = [(_arr(v) if v is not None else None) for v in (fx, fu, lx, lu, lxx, luu, lux, VxN, VxxN)]
         self._check(self.lib.cddp_hip_set_stacks(self.h, *[_ptr(v) for v in a]))
+
+    def set_defect_stack(self, defects=None):
+        """Multiple-shooting defects f(x_t, u_t) - x_{t+1}, [B][N][nx] (MSIPDDP branch); None drops them."""
+        a = _arr(defects) if defects is not None else None
+        self._check(self.lib.cddp_hip_set_defect_stack(self.h, _ptr(a)))
 
     def set_control_box(self, lower=None, upper=None, U=None):
         """CLDDP branch: control bounds (nu each) and the current controls [B][N][nu]; all None removes the box."""

@@ -435,6 +435,7 @@ enum cddp_hip_stacks_branch {
   CDDP_HIP_STACKS_CLDDP = 0,      /* clddp_solver.cpp:79-204 without control bounds                    */
   CDDP_HIP_STACKS_IPDDP = 1,      /* ipddp_solver.cpp:1048-1118 (no constraints)                       */
   CDDP_HIP_STACKS_IPDDP_PATH = 2, /* ipddp_solver.cpp:1355-1568 (path constraints; handle with m > 0)  */
+  CDDP_HIP_STACKS_MSIPDDP = 4,    /* msipddp_solver.cpp:1112-1208 (no constraints): IPDDP recursion + defect stack (cddp_hip_set_defect_stack) */
   CDDP_HIP_STACKS_LOGDDP = 3      /* logddp_solver.cpp:470-575: the caller folds the relaxed log barrier's gradients / Hessians (barrier.hpp:95-262)
                                      into lx, lu, lxx, luu, lux; handle with m = 0                     */
 };
@@ -445,6 +446,10 @@ int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h);
  * pass NULL for stacks that did not change (e.g. constant cost Hessians). */
 int cddp_hip_set_stacks(cddp_hip_stack_handle *h, const double *fx, const double *fu, const double *lx, const double *lu,
                         const double *lxx, const double *luu, const double *lux, const double *VxN, const double *VxxN);
+/* Multiple-shooting defects d[b][t] = f(x_t, u_t) - x_{t+1} (nx each) for CDDP_HIP_STACKS_MSIPDDP: Q_x and Q_u are formed with
+ * V_x + V_xx d_t (msipddp_solver.cpp:1144-1145).  The caller derives k_lambda[t] = -lambda_t + V_x(t+1) + V_xx(t+1) d_t and
+ * K_lambda[t] = V_xx(t+1) (:1192-1194) from the returned value stacks.  NULL drops the stack. */
+int cddp_hip_set_defect_stack(cddp_hip_stack_handle *h, const double *defects);
 /* Control limits of the CLDDP branch (the constraint named "ControlConstraint", clddp_solver.cpp:85-86, 147-178): every step
  * solves the BoxQP  min 0.5 k^T Q_uu_reg k + Q_u^T k,  lower - u_t <= k <= upper - u_t  (boxqp.cpp:25-250, parameters from
  * options.boxqp_*), warm-started with the k_t of the handle's previous sweep, and the feedback gain lives on the free

@@ -1,4 +1,4 @@
-"""f4, first slice: the LogDDP backward pass (LogDDPSolver::backwardPass, logddp_solver.cpp:470-575, with the relaxed log
+"""f4, first slice (LogDDP; the unconstrained MSIPDDP recursion at the end of the file): the LogDDP backward pass (LogDDPSolver::backwardPass, logddp_solver.cpp:470-575, with the relaxed log
 barrier of barrier.hpp:37-262) on the GPU through the stack-fed boundary -- branch CDDP_HIP_STACKS_LOGDDP.  A host LogDDP
 solver keeps its outer loop and forward pass; it folds the barrier gradients / Hessians into the cost stacks and hands the
 (N x batch) stacks over.
@@ -152,4 +152,63 @@ def test_hip_logddp_sweep_matches_the_restatement(api, name):
         okr = Lg.backward(c["A"], c["B"], c["lx"], c["lu"], c["lxx"], luu_b, c["lux"], c["VxN"], c["VxxN"], c["cons"], c["X"], c["U"], coeff, delta, float(sc["reg"][b]))
         assert bool(ok[b]) == okr[0]
         if okr[0]: assert rel(K[b], okr[1]) < 1e-7 and rel(Vxx[b], okr[4]) < 1e-7      # (indefinite blocks: gains up to 1e3)
+    hs.close()
+
+
+def test_msipddp_backward_without_defects_is_the_discrete_riccati_recursion():
+    import msipddp_twin as Ms
+    rng = np.random.default_rng(5)
+    nx, nu, N = 3, 2, 10
+    A = [np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) for _ in range(N)]; B = [0.3 * rng.standard_normal((nx, nu)) for _ in range(N)]
+    Q = np.diag([1.0, 2.0, 0.5]); R = np.diag([0.3, 0.7]); Qf = np.diag([5.0, 5.0, 1.0]); z = np.zeros
+    out = Ms.backward(A, B, z((N, nx)), z((N, nu)), np.tile(Q, (N, 1, 1)), np.tile(R, (N, 1, 1)), z((N, nu, nx)), z(nx), Qf, z((N, nx)), z((N, nx)), 0.0)
+    assert out[0]
+    P = Qf.copy()
+    for t in range(N - 1, -1, -1):
+        Kt = -np.linalg.solve(R + B[t].T @ P @ B[t], B[t].T @ P @ A[t])
+        assert np.max(np.abs(out[1][t] - Kt)) < 1e-10
+        P = Q + A[t].T @ P @ A[t] + A[t].T @ P @ B[t] @ Kt
+    # a defect moves the feed-forward term only: k = -(R + B^T P B)^-1 B^T P d at the last step
+    d = z((N, nx)); d[N - 1] = np.array([0.1, -0.2, 0.05])
+    out2 = Ms.backward(A, B, z((N, nx)), z((N, nu)), np.tile(Q, (N, 1, 1)), np.tile(R, (N, 1, 1)), z((N, nu, nx)), z(nx), Qf, d, z((N, nx)), 0.0)
+    kref = -np.linalg.solve(R + B[N - 1].T @ Qf @ B[N - 1], B[N - 1].T @ Qf @ d[N - 1])
+    assert np.max(np.abs(out2[2][N - 1] - kref)) < 1e-10 and np.max(np.abs(out2[1] - out[1])) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "unicycle"])
+def test_hip_msipddp_sweep_matches_the_restatement(api, name):
+    """Branch CDDP_HIP_STACKS_MSIPDDP (msipddp_solver.cpp:1112-1208): defects through cddp_hip_set_defect_stack; the costate gains
+    follow on the host from the returned value stacks (:1192-1194)."""
+    import msipddp_twin as Ms
+    Bn = 5
+    rng = np.random.default_rng(77)
+    cases = [_case(name, 300 + b) for b in range(Bn)]
+    c0 = cases[0]; N, nx = c0["N"], c0["nx"]
+    dfc = [0.05 * rng.standard_normal((N, nx)) for _ in range(Bn)]
+    lam = [rng.standard_normal((N, nx)) for _ in range(Bn)]
+    hs = api.HipStackSolver(Bn, nx, c0["nu"], 0, N)
+    st = lambda key: np.stack([c[key] for c in cases])
+    hs.set_stacks(st("A"), st("B"), st("lx"), st("lu"), st("lxx"), st("luu"), st("lux"), st("VxN"), st("VxxN"))
+    opt = api.default_options()
+    with pytest.raises(api.HipError):
+        hs.backward(api.STACKS_MSIPDDP, opt, np.full(Bn, 1e-6))          # defect stack missing
+    hs.set_defect_stack(np.stack(dfc))
+    for reg0 in (0.0, 1e-3):
+        ok = hs.backward(api.STACKS_MSIPDDP, opt, np.full(Bn, reg0), None, retry=False)
+        K, k, Vx, Vxx, dV = hs.gains(); sc = hs.scalars()
+        for b, c in enumerate(cases):
+            ref = Ms.backward(c["A"], c["B"], c["lx"], c["lu"], c["lxx"], c["luu"], c["lux"], c["VxN"], c["VxxN"], dfc[b], lam[b], reg0)
+            assert bool(ok[b]) == ref[0]
+            if not ref[0]: continue
+            for nm, got, want in (("K", K[b], ref[1]), ("k", k[b], ref[2]), ("Vx", Vx[b], ref[3]), ("Vxx", Vxx[b], ref[4]), ("dV", dV[b], ref[5])):
+                assert rel(got, want) < TOL, (name, reg0, b, nm, rel(got, want))
+            assert rel(sc["inf_du"][b], ref[6]) < TOL and rel(sc["step_norm"][b], ref[7]) < TOL
+            kl = np.array([-lam[b][t] + Vx[b][t + 1] + Vxx[b][t + 1] @ dfc[b][t] for t in range(N)])      # host side, :1192
+            assert rel(kl, ref[9]) < TOL and rel(Vxx[b][1:], ref[10]) < TOL
+    # without defects the branch IS the unconstrained IPDDP sweep
+    hs.set_defect_stack(np.zeros((Bn, N, nx)))
+    hs.backward(api.STACKS_MSIPDDP, opt, np.full(Bn, 1e-6)); K1 = hs.gains()[0]
+    hs.backward(api.STACKS_IPDDP, opt, np.full(Bn, 1e-6)); K2 = hs.gains()[0]
+    assert np.array_equal(K1, K2)
     hs.close()
