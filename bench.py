@@ -163,6 +163,122 @@ def cpu_baseline(api, p, x0, U0, budget_s=12.0):
     }
 
 
+def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_dominates):
+    """`roofline` object of one workload: SURVEY 8(d) algorithmic bytes of the dominant kernel class / its hipEvent time.
+
+    st = stats of the last timed step, prof = stats of the untimed solve with every class bracketed, stats = all timed steps
+    (they bracket the dominant class only)."""
+    ipddp = solver == "ipddp"
+    b_fill, b_bwd, b_fwd = algorithmic_bytes(p.nx, p.nu, p.N, m, ipddp)
+    # the dominant class: hipEvent time inside the timed steps; the others: from the profiling solve
+    bwd_ms = float(np.mean([s.backward_ms for s in stats])) if sweep_dominates else float(prof.backward_ms)
+    fwd_ms = float(prof.forward_ms) if sweep_dominates else float(np.mean([s.forward_ms for s in stats]))
+    upd_ms = float(prof.update_ms)
+    solve_ms = float(np.mean([s.solve_ms for s in stats]))
+    bytes_bwd = b_fill * st.traj_iterations + b_bwd * st.sweeps
+    # exact credit: the steps the walked trials actually traversed (a trial the reference abandons at its first
+    # fraction-to-boundary violation, ipddp_solver.cpp:1632-1645, is credited the steps completed before it, not N)
+    bytes_fwd = (b_fwd / p.N) * st.rollout_steps
+    bytes_fwd_full_rollouts = b_fwd * st.rollouts   # round-1 accounting (every walked trial credited N steps), for comparison
+    gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+    gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+    gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
+    lean = ipddp and m > 0
+    if sweep_dominates:
+        if workload == "manip7" and ipddp:
+            sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
+        elif lean:
+            sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
+        else:
+            sweep_label = "k_derivs+k_backward_coop_plain"
+        dom = (sweep_label, gbps_bwd, bwd_ms, bytes_bwd)
+        pmc_key = None
+    else:
+        dom = ("k_forward_ipddp_pc" if lean else "k_forward_%s" % solver, gbps_fwd, fwd_ms, bytes_fwd)
+        pmc_key = dom[0]
+    PEAK = 8000.0   # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+    n_launch = max(1, st.outer_iterations)
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
+    # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
+    # (profiles/r0N_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
+    traffic = None
+    traffic_note = None
+    if pmc_key and workload == "cartpole" and B == 4096 and ipddp:
+        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_i_pmc_traffic.json"):   # this round's passes; earlier rounds' as a fallback
+            try:
+                pj = json.load(open(os.path.join(REPO, "profiles", fn)))
+                # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
+                # depending on the ladder shape the solver picked)
+                traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
+                traffic_note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the rollout launches of one solve / outer iterations)" % fn
+                break
+            except Exception:
+                traffic = None
+    return {
+        "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
+        "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,
+        "algorithmic_bytes_per_launch": dom[3] / n_launch, "avg_launch_ms": dom[2] / n_launch,
+        "launches": n_launch,
+        "algorithmic_bytes_note": "SURVEY 8(d) bytes per rollout STEP x the steps the reference's line search traverses: the trials the "
+                                  "selection rule walks (first-success: up to the winner; best-merit: the whole ladder), each credited the steps "
+                                  "completed before it is abandoned (fraction-to-boundary violation), N if it runs through; speculative trials "
+                                  "of other alphas are executed but not credited",
+        "rollout_steps_credited": int(st.rollout_steps), "rollout_steps_if_full": int(st.rollouts) * int(p.N),
+        "frac_with_full_rollout_credit_r01": (bytes_fwd_full_rollouts / (fwd_ms * 1e-3) / 1e9 / PEAK) if fwd_ms > 0 else None,
+        "timing": "hipEvents on the solver's stream around the dominant class's launches inside the timed steps; "
+                  "the other classes from one untimed solve with every class bracketed (whole_solve_all_classes_ms)",
+        "classes": {
+            "backward(K1+K1b+K2+K3)": {"ms": bwd_ms, "GBps": gbps_bwd}, "forward(K4)": {"ms": fwd_ms, "GBps": gbps_fwd},
+            "update(K4b+K5)": {"ms": upd_ms}, "whole_solve": {"ms": solve_ms, "GBps": gbps_all, "frac": gbps_all / PEAK},
+            "whole_solve_all_classes_ms": float(prof.solve_ms),
+        },
+        "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
+    }
+
+
+# The other BASELINE configurations (per-GPU shares) and the BoxQP core, measured AFTER the headline loop and outside its
+# timed region, so that the driver's record carries them too (VERDICT r02 item 5): (workload, solver, label)
+OTHER_WORKLOADS = [
+    ("cartpole", "clddp", "C2 cart-pole CLDDP (BoxQP core), B=4096"),
+    ("unicycle", "ipddp", "C3 unicycle N=200 box+ball, B=8192"),
+    ("quadrotor", "ipddp", "C4 share: quadrotor nx=12 N=400, B=2048 (16384 / 8 GPUs)"),
+    ("manip7", "ipddp", "C5 share: 7-joint arm nx=14 nu=7 N=150 terminal equality, 16 alphas, B=4096 (32768 / 8 GPUs)"),
+]
+
+
+def measure_other(api, workload, solver, label, steps=3, warmup=1, device=0):
+    """A short single-GPU measurement of one more workload with the same accounting as the headline line."""
+    p, spread, _ = make_problem(api, workload, solver)
+    B = DEFAULT_BATCH[workload]
+    x0 = api.batch_x0(p, B, 20260928 + 1, spread)
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B, device=device)
+    try:
+        hs.set_initial(x0, U0)
+        hs.set_timing_detail(api.TIMING_ALL)
+        prof = hs.solve()
+        sweep_dominates = prof.backward_ms >= prof.forward_ms
+        hs.set_timing_detail(api.TIMING_SWEEP if sweep_dominates else api.TIMING_ROLLOUT)
+        for _ in range(warmup):
+            hs.solve()
+        t0 = time.perf_counter()
+        stats = [hs.solve() for _ in range(steps)]     # cddp_hip_solve returns after the stream is drained
+        dt = time.perf_counter() - t0
+        res = hs.results()
+        rl = roofline_block(api, p, hs.m, B, workload, solver, stats[-1], prof, stats, sweep_dominates)
+        status_hist = {api.STATUS_STRINGS[int(s)]: int(c) for s, c in zip(*np.unique(res["status"], return_counts=True))}
+        return {
+            "workload": label, "solver": solver.upper(), "batch": B, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "trajectories/s",
+            "roofline": {"kernel": rl["kernel"], "frac": rl["frac"], "achieved": rl["achieved"], "unit": "GB/s",
+                         "avg_launch_ms": rl["avg_launch_ms"], "whole_solve_frac": rl["classes"]["whole_solve"]["frac"]},
+            "classes_ms": {k: v["ms"] for k, v in rl["classes"].items() if isinstance(v, dict)},
+            "mean_iterations": float(np.mean(res["iterations"])), "status": status_hist,
+        }
+    finally:
+        hs.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,22 +288,42 @@ def main():
     ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short C2-CLDDP / C3 / C4-share / C5-share measurements appended to the default (C2-IPDDP, 1 GPU) line")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch trajectories per GPU; strong: a fixed global batch (--global-batch or the BASELINE config's) over all GPUs")
     ap.add_argument("--global-batch", type=int, default=0)
     args = ap.parse_args()
 
     import torch
+    launched_by_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the cddp_hip solver core has no CPU fallback")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to report an N-GPU line measured on fewer devices"
+                         % (args.gpus, torch.cuda.device_count()))
+    if args.gpus > 1 and not launched_by_torchrun:
+        # Plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, RCCL over xGMI) instead of
+        # silently measuring one rank.  The children see RANK / WORLD_SIZE and take the normal path; rank 0 prints the line.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the cddp_hip solver core has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: launch with --nproc-per-node %d (or without torchrun: bench.py starts its own ranks)"
+                         % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    launched_by_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if world > 1 or launched_by_torchrun:   # (also with one rank under torchrun: the RCCL path then runs with a size-1 communicator)
         import torch.distributed as dist_
         dist = dist_
@@ -266,71 +402,8 @@ def main():
     res = hs.results()
     m = hs.m
     ipddp = args.solver == "ipddp"
-    b_fill, b_bwd, b_fwd = algorithmic_bytes(p.nx, p.nu, p.N, m, ipddp)
-    # the dominant class: hipEvent time inside the timed steps; the others: from the profiling solve
-    bwd_ms = float(np.mean([s.backward_ms for s in stats])) if sweep_dominates else float(prof.backward_ms)
-    fwd_ms = float(prof.forward_ms) if sweep_dominates else float(np.mean([s.forward_ms for s in stats]))
-    upd_ms = float(prof.update_ms)
     solve_ms = float(np.mean([s.solve_ms for s in stats]))
-    bytes_bwd = b_fill * st.traj_iterations + b_bwd * st.sweeps
-    # exact credit: the steps the walked trials actually traversed (a trial the reference abandons at its first
-    # fraction-to-boundary violation, ipddp_solver.cpp:1632-1645, is credited the steps completed before it, not N)
-    bytes_fwd = (b_fwd / p.N) * st.rollout_steps
-    bytes_fwd_full_rollouts = b_fwd * st.rollouts   # round-1 accounting (every walked trial credited N steps), for comparison
-    gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-    gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
-    gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
-    lean = ipddp and m > 0
-    if sweep_dominates:
-        if args.workload == "manip7" and ipddp:
-            sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
-        elif lean:
-            sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
-        else:
-            sweep_label = "k_derivs+k_backward_coop_plain"
-        dom = (sweep_label, gbps_bwd, bwd_ms, bytes_bwd)
-        pmc_key = None
-    else:
-        dom = ("k_forward_ipddp_pc" if lean else "k_forward_%s" % args.solver, gbps_fwd, fwd_ms, bytes_fwd)
-        pmc_key = dom[0]
-    PEAK = 8000.0   # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
-    n_launch = max(1, st.outer_iterations)
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure
-    # is the per-launch FETCH_SIZE/WRITE_SIZE mean of the committed rocprofv3 --pmc passes over this very command
-    # (profiles/r02_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
-    traffic = None
-    traffic_note = None
-    if pmc_key and args.workload == "cartpole" and B == 4096 and ipddp:
-        for fn in ("r02_pmc_traffic.json", "r01_i_pmc_traffic.json"):   # this round's passes; last round's as a fallback
-            try:
-                pj = json.load(open(os.path.join(REPO, "profiles", fn)))
-                # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
-                # depending on the ladder shape the solver picked)
-                traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
-                traffic_note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the rollout launches of one solve / outer iterations)" % fn
-                break
-            except Exception:
-                traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
-        "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,
-        "algorithmic_bytes_per_launch": dom[3] / n_launch, "avg_launch_ms": dom[2] / n_launch,
-        "launches": n_launch,
-        "algorithmic_bytes_note": "SURVEY 8(d) bytes per rollout STEP x the steps the reference's line search traverses: the trials the "
-                                  "selection rule walks (first-success: up to the winner; best-merit: the whole ladder), each credited the steps "
-                                  "completed before it is abandoned (fraction-to-boundary violation), N if it runs through; speculative trials "
-                                  "of other alphas are executed but not credited",
-        "rollout_steps_credited": int(st.rollout_steps), "rollout_steps_if_full": int(st.rollouts) * int(p.N),
-        "frac_with_full_rollout_credit_r01": (bytes_fwd_full_rollouts / (fwd_ms * 1e-3) / 1e9 / PEAK) if fwd_ms > 0 else None,
-        "timing": "hipEvents on the solver's stream around the dominant class's launches inside the timed steps; "
-                  "the other classes from one untimed solve with every class bracketed (whole_solve_all_classes_ms)",
-        "classes": {
-            "backward(K1+K1b+K2+K3)": {"ms": bwd_ms, "GBps": gbps_bwd}, "forward(K4)": {"ms": fwd_ms, "GBps": gbps_fwd},
-            "update(K4b+K5)": {"ms": upd_ms}, "whole_solve": {"ms": solve_ms, "GBps": gbps_all},
-            "whole_solve_all_classes_ms": float(prof.solve_ms),
-        },
-        "bytes_per_traj": {"fill": b_fill, "backward": b_bwd, "forward_per_alpha": b_fwd},
-    }
+    roofline = roofline_block(api, p, m, B, args.workload, args.solver, st, prof, stats, sweep_dominates)
     rec = sh.compact_records(gathered.cpu().numpy(), global_batch, world)   # drops (and checks) the padding of uneven shards
     assert len(rec) == global_batch
     assert np.array_equal(rec["iterations"][lo:hi], res["iterations"]) and np.array_equal(rec["status"][lo:hi], res["status"])
@@ -363,13 +436,22 @@ def main():
     }
     if comm is not None:
         api.comm_destroy(comm)
+    assert out["n_gpus"] == args.gpus
+    hs.close()
+    if rank == 0 and world == 1 and not args.no_other_workloads and args.workload == "cartpole" and args.solver == "ipddp" and args.batch in (0, 4096):
+        # the other BASELINE configurations, 3 steps each, after and outside the headline's timed region
+        out["other_workloads"] = []
+        for wl, sv, label in OTHER_WORKLOADS:
+            try:
+                out["other_workloads"].append(measure_other(api, wl, sv, label, device=local_rank))
+            except Exception as e:   # a failing extra workload must not lose the headline line
+                out["other_workloads"].append({"workload": label, "error": "%s: %s" % (type(e).__name__, e)})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(api, p, x0, U0)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    hs.close()
     if dist is not None:
         dist.destroy_process_group()
 

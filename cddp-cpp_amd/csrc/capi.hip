@@ -121,6 +121,10 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (p->nx <= 0 || p->nu <= 0 || p->horizon <= 0 || !(p->dt > 0)) return fail(-2, "bad dimensions nx=%d nu=%d N=%d dt=%g", p->nx, p->nu, p->horizon, p->dt);
   if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
   if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP) return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
+  // the device-resident retry loops (cddp_solver_base.cpp:93-111) terminate because the regularisation grows: a factor <= 1
+  // is an endless loop on the reference's host and would be a wedged queue here
+  if (!(p->options.reg_update_factor > 1.0) || !(p->options.reg_max_value > 0.0))
+    return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", p->options.reg_update_factor, p->options.reg_max_value);
   if (!p->options.use_ilqr && !model_has_hessians(p->model))
     return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", p->model);
   P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
@@ -317,6 +321,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
   d.ddp = P.opt.use_ilqr ? 0 : 1;
+  { const char *e = std::getenv("CDDP_HIP_XCD_MAP"); d.xcd_map = (e && e[0] == '0') ? 0 : 1; }
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
   d.hist_cap = P.opt.max_iterations + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
@@ -483,6 +488,8 @@ static int in_initialize(Inner *h) {
 
 static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if (!h || !opt) return fail(-1, "null argument");
+  if (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0))
+    return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", opt->reg_update_factor, opt->reg_max_value);
   if (!opt->use_ilqr && !model_has_hessians(h->P.model))
     return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", h->P.model);
   HIPCHK(hipSetDevice(h->device));
@@ -753,8 +760,9 @@ struct SolveRun {
       ++it;
       if (P.opt.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (host clock, like the reference; the queue is drained first)
         HIPCHK(hipStreamSynchronize(s));
-        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
-        if (el > P.opt.max_cpu_time) {
+        // whole elapsed milliseconds against max_cpu_time * 1000, as the reference's duration_cast<milliseconds> compares them
+        const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
+        if (el_ms > P.opt.max_cpu_time * 1000.0) {
           hipLaunchKernelGGL(k_mark_cpu_time, dim3((d.B + 255) / 256), dim3(256), 0, s, d);
           ++launches; done = true; cpu_time_hit = true;
           return 0;

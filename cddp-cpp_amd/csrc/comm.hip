@@ -10,7 +10,19 @@
 #include <string>
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+// The few RCCL declarations this file needs, restated so that the solver core builds on a box without the RCCL headers
+// (the library is resolved with dlopen at first use; cddp_hip_comm_* return -30 when it is absent).  They follow the
+// stable NCCL 2.x C interface: ncclUniqueId is 128 opaque bytes, ncclComm_t an opaque pointer, ncclSuccess == 0,
+// ncclUint8 == 1 in ncclDataType_t.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1;
 
 #include "../../include/cddp_hip.h"
 
@@ -99,7 +111,8 @@ int cddp_hip_comm_destroy(void *comm) {
   if (!comm) return 0;
   Rccl &r = rccl();
   if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
-  r.CommDestroy((ncclComm_t)comm);
+  ncclResult_t rc = r.CommDestroy((ncclComm_t)comm);
+  if (rc != ncclSuccess) return cfail(-31, "ncclCommDestroy: %s", r.GetErrorString(rc));
   return 0;
 }
 

@@ -43,17 +43,17 @@ template <int NP> DEV DualN<NP> operator*(const DualN<NP> &a, const DualN<NP> &b
 template <int NP> DEV DualN<NP> operator/(const DualN<NP> &a, const DualN<NP> &b) { DualN<NP> r; r.v = a.v / b.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
-template <int NP> DEV DualN<NP> dsin(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = s;
+template <int NP> DEV DualN<NP> dsin(const DualN<NP> &a) { DualN<NP> r; double s, c; plant_sincos(a.v, &s, &c); r.v = s;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = c * a.d[i]; return r; }
-template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s, c; sincos(a.v, &s, &c); r.v = c; double ms = -s;
+template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s, c; plant_sincos(a.v, &s, &c); r.v = c; double ms = -s;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = ms * a.d[i]; return r; }
 template <int NP> DEV DualN<NP> dsqrt(const DualN<NP> &a) { DualN<NP> r; r.v = sqrt(a.v); double g = 0.5 / r.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
-DEV double dsin(double a) { return sin(a); }
-DEV double dcos(double a) { return cos(a); }
+DEV double dsin(double a) { return plant_sin(a); }
+DEV double dcos(double a) { return plant_cos(a); }
 DEV double dsqrt(double a) { return sqrt(a); }
 DEV double dval(double a) { return a; }
 template <int NP> DEV double dval(const DualN<NP> &a) { return a.v; }
@@ -113,8 +113,8 @@ template <int NP> DEV Dual2N<NP> operator*(const Dual2N<NP> &a, const Dual2N<NP>
 template <int NP> DEV Dual2N<NP> operator/(const Dual2N<NP> &a, const Dual2N<NP> &b) {
   const double inv = 1.0 / b.v;
   return a * d2_unary<NP>(b, inv, -inv * inv, 2.0 * inv * inv * inv); }
-template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
-template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
+template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
+template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
 
 // Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
 template <class F, int NX, int NU>
@@ -171,7 +171,7 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     // double path (cartpole.cpp:38-67): NO damping term
     const double mc = p[0], mp = p[1], l = p[2], g = p[3];
     const double theta_dot = x[3], force = u[0];
-    double s, c; sincos(x[1], &s, &c);
+    double s, c; plant_sincos(x[1], &s, &c);
     const double total_mass = mc + mp;
     const double den = mc + mp * s * s;
     xd[0] = x[2];
@@ -183,7 +183,7 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     // exact derivatives of the autodiff expression (cartpole.cpp:69-103, WITH -damping*theta_dot)
     const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
     const double w = x[3], F = u[0];
-    double s, c; sincos(x[1], &s, &c);
+    double s, c; plant_sincos(x[1], &s, &c);
     const double M = mc + mp;
     const double den = mc + mp * s * s;
     const double dden = 2.0 * mp * s * c;
@@ -239,11 +239,11 @@ struct UnicycleModel {   // unicycle.cpp:28-66
   static constexpr int ID = CDDP_HIP_MODEL_UNICYCLE, NX = 3, NU = 2;
   static constexpr bool kDiscrete = false;
   DEV static void f(const double *, const double *x, const double *u, double *xd) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; plant_sincos(x[2], &s, &c);
     xd[0] = u[0] * c; xd[1] = u[0] * s; xd[2] = u[1];
   }
   DEV static void jac(const double *, const double *x, const double *u, double *Fx, double *Fu) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; plant_sincos(x[2], &s, &c);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Fx[i] = 0.0;
     Fx[0 * 3 + 2] = -u[0] * s;
@@ -254,7 +254,7 @@ struct UnicycleModel {   // unicycle.cpp:28-66
   // getContinuousDynamicsAutodiff (:91-107): d2(v cos th)/dv dth = -sin th, d2(v sin th)/dv dth = cos th
   static constexpr bool kHasHess = true;
   DEV static void hess(const double *, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; plant_sincos(x[2], &s, &c);
     for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
     for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
     for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
@@ -398,7 +398,7 @@ struct ManipulatorModel {   // manipulator.cpp:29-70,174-208
     const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
     const double m1 = 1.0, m2 = 1.0, m3 = 0.5;
     double M[9];
-    const double c1 = cos(x[1]), c2 = cos(x[2]), c12 = cos(x[1] + x[2]);
+    const double c1 = plant_cos(x[1]), c2 = plant_cos(x[2]), c12 = plant_cos(x[1] + x[2]);
     M[0] = (m1 + m2 + m3) * (la * la);
     M[4] = (m2 + m3) * (lb * lb);
     M[8] = m3 * (lc * lc);

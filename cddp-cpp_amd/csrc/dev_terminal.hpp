@@ -89,7 +89,7 @@ DEV void term_reductions(const ProblemDev *P, const TermState &ts, int mT, int p
     const TermDev &td = P->terms[c];
     if (td.kind != CDDP_HIP_TERM_INEQUALITY) continue;
     double ls = 0.0;
-    for (int r = 0; r < td.dim; ++r) ls += log(dmax(ts.s[td.offset + r], 1e-10));
+    for (int r = 0; r < td.dim; ++r) ls += solver_log(dmax(ts.s[td.offset + r], 1e-10));
     mer -= mu * ls;
   }
   if (pT > 0) {

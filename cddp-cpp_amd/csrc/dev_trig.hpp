@@ -103,4 +103,104 @@ DEV void sincos_n(const double *a, double *s, double *c) {
 
 DEV void sincos_1(double a, double *s, double *c) { sincos_n<1>(&a, s, c); }
 
+// ---- log, exp, pow with the same property: straight-line code from IEEE basic operations, host-compilable -----------------
+// The solver core itself calls three more libm routines: log (barrier merit, ipddp_solver.cpp:2850-2880), pow (barrier update
+// mu^1.2, :2569-2614; terminal-equality regularisation mu^0.25, :556-617).  The device libm and glibc agree on them to an ulp,
+// not to the bit, and over hundreds of iterations one ulp in mu moves a line-search decision (seen on the reference's N = 400
+// quadrotor test: 449 vs 445 iterations).  The parity build therefore routes them through the routines below as well.
+//   log   x = 2^k (1 + f), 1 + f in [sqrt(2)/2, sqrt(2)); s = f / (2 + f); log(1 + f) = 2 s + s R(s^2) with the Sun / FreeBSD
+//         msun e_log.c minimax coefficients Lg1..Lg7 (public-domain algorithm), result assembled as in that routine; < 1 ulp
+//   exp   k = rint(x / ln 2), r = x - k ln2_hi - k ln2_lo, e^r = 1 + (r c / (2 - c) - lo + hi), c = r - r^2 P(r^2) (msun e_exp.c
+//         coefficients P1..P5), scaled by 2^k through the exponent field; < 1 ulp for |x| <= 700
+//   pow   exp(y log x): relative error ~ |y log x| 2^-53 (a few ulp at mu^1.2, mu >= 1e-10) -- enough for a barrier parameter and,
+//         above all, the SAME value on both sides
+// Arguments outside the straight-line range (x <= 0, subnormal, non-finite, |y log x| > 700) fall back to the libm.
+DEV double bits_to_double(unsigned long long u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
+DEV unsigned long long double_to_bits(double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; }
+
+DEV bool log_fast_ok(double x) { return x >= 0x1p-1022 && x <= 0x1.fffffffffffffp+1023; }   // positive, normal, finite
+DEV double log_fast(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  unsigned long long u = double_to_bits(x);
+  unsigned hx = (unsigned)(u >> 32);
+  hx += 0x3ff00000u - 0x3fe6a09eu;                       // mantissa range [sqrt(2)/2, sqrt(2))
+  const int k = (int)(hx >> 20) - 0x3ff;
+  hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+  u = ((unsigned long long)hx << 32) | (u & 0xffffffffull);
+  const double f = bits_to_double(u) - 1.0;
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const double dk = (double)k;
+  return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+DEV bool exp_fast_ok(double x) { return __builtin_fabs(x) <= 700.0; }   // result normal, 2^k applied through the exponent field
+DEV double exp_fast(double x) {
+  const double invln2 = 1.44269504088896338700e+00, ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  const double dk = __builtin_rint(invln2 * x);
+  const double hi = x - dk * ln2hi;          // exact for |k| < 2^11: ln2hi carries 32 significant bits
+  const double lo = dk * ln2lo;
+  const double r = hi - lo;
+  const double xx = r * r;
+  const double c = r - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+  const double y = 1.0 + (r * c / (2.0 - c) - lo + hi);
+  const int k = (int)dk;
+  // y in (0.7, 1.42) and |k| <= 1010: y * 2^k stays normal; multiply by the power of two built in the exponent field
+  return y * bits_to_double((unsigned long long)(0x3ff + k) << 52);
+}
+
+#ifdef CDDP_TRIG_HOST
+inline double libm_log(double x) { return std::log(x); }
+inline double libm_pow(double x, double y) { return std::pow(x, y); }
+#else
+DEV double libm_log(double x) { return log(x); }
+DEV double libm_pow(double x, double y) { return pow(x, y); }
+#endif
+DEV double log_shared(double x) { return log_fast_ok(x) ? log_fast(x) : libm_log(x); }
+DEV double pow_shared(double x, double y) {
+  if (log_fast_ok(x)) {
+    const double t = y * log_fast(x);
+    if (exp_fast_ok(t)) return exp_fast(t);
+  }
+  return libm_pow(x, y);
+}
+
+// What the solver core calls (kernels*.hpp, dev_terminal.hpp): the device libm in the product build, the shared routines in
+// the parity build.
+#ifndef CDDP_TRIG_HOST
+#ifdef CDDP_TRIG_SHARED
+DEV double solver_log(double x) { return log_shared(x); }
+DEV double solver_pow(double x, double y) { return pow_shared(x, y); }
+#else
+DEV double solver_log(double x) { return log(x); }
+DEV double solver_pow(double x, double y) { return pow(x, y); }
+#endif
+#endif
+
+// sin / cos as the REFERENCE's own plants (pendulum, cart-pole, unicycle, quadrotor-13, 3-DOF manipulator) evaluate them.
+// Default build: the device libm.  Parity build (-DCDDP_TRIG_SHARED, lib/libcddp_hip_sharedtrig.so, selected with the
+// environment variable CDDP_HIP_TRIG=shared): the routine above -- which also compiles for the host (CDDP_TRIG_HOST), so a CPU
+// checker can evaluate the very same routine and both sides run the SAME IEEE add / mul / fma sequence for every sine and cosine and
+// the knife-edge plants (central-difference Jacobians amplify a last-bit libm difference 2.5e4 x) become bit-comparable.
+#ifndef CDDP_TRIG_HOST
+#ifdef CDDP_TRIG_SHARED
+DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
+DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
+DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
+#else
+DEV void plant_sincos(double a, double *s, double *c) { sincos(a, s, c); }
+DEV double plant_sin(double a) { return sin(a); }
+DEV double plant_cos(double a) { return cos(a); }
+#endif
+#endif
+
 }  // namespace cddp_dev

@@ -45,7 +45,15 @@ template <int N> DEV void st(double *base, size_t stride, const double *in) {
 }
 
 // regularisation schedule (cddp_core.cpp:308-346)
-DEV double reg_increase(const cddp_hip_options &o, double r) { r *= o.reg_update_factor; return dmin(r, o.reg_max_value); }
+// A regularisation of exactly 0 (cddp_hip_set_barrier_state, reg_initial_value = 0) is a fixed point of the reference's
+// rule reg = min(reg * f, max): its retry loop (cddp_solver_base.cpp:93-111) would spin forever on the host; here it would
+// wedge a GPU queue.  From 0 the step therefore restarts at reg_min_value (the value decreaseRegularization never goes
+// below; reg_max_value if that is 0 too, i.e. "limit reached").  Identical to the reference for every reg > 0.
+DEV double reg_increase(const cddp_hip_options &o, double r) {
+  r *= o.reg_update_factor;
+  if (!(r > 0.0)) r = (o.reg_min_value > 0.0) ? o.reg_min_value : o.reg_max_value;
+  return dmin(r, o.reg_max_value);
+}
 DEV double reg_decrease(const cddp_hip_options &o, double r) { r /= o.reg_update_factor; return dmax(r, o.reg_min_value); }
 
 DEV void hist_push(const DevBuf &d, int b, double mu_or_zero) {
@@ -639,7 +647,7 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
   }
   for (int i = 0; i < pT; ++i) tr += AtA[i * kPTMax + i];
   const double trace_term = (tr > 1.0 ? tr / (pT > 1 ? pT : 1) : 1.0);
-  const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+  const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * solver_pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
   const double regv = dmax(base_floor, 1e-6 * trace_term);
   double smax, smin;
   singular_minmax<kPTMax>(As, pT, smax, smin);
@@ -1211,7 +1219,7 @@ DEV void ip_reductions(const DevBuf &d, int b, int N, const double *S, const dou
     const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
     for (int t = 0; t < N; ++t) {
       double ls = 0.0;
-      for (int i = 0; i < dim; ++i) ls += log(dmax(S[GI(t, M, off + i)], kEpsSlack));
+      for (int i = 0; i < dim; ++i) ls += solver_log(dmax(S[GI(t, M, off + i)], kEpsSlack));
       mer -= mu * ls;
     }
   }
@@ -1385,7 +1393,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
             n1 += l2norm ? r * r : fabs(r);
             ninf = dmax(ninf, fabs(r));
             ev_icomp = dmax(ev_icomp, fabs(yn[off + i] * sn[off + i] - mu));
-            ls += log(dmax(sn[off + i], kEpsSlack));
+            ls += solver_log(dmax(sn[off + i], kEpsSlack));
           }
           ev_max = dmax(ev_max, ninf);
           if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;
@@ -1619,14 +1627,14 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
                   else if (ratio < 0.5) factor = 0.6 * o.barrier_mu_update_factor;
                 }
                 const double linear = factor * mu;
-                const double superlinear = pow(mu, o.barrier_mu_update_power);
+                const double superlinear = solver_pow(mu, o.barrier_mu_update_power);
                 mu = dmax(dmin(linear, superlinear), dmax(o.barrier_mu_min_value, o.tolerance / 100.0));
               }
             } else {
               const double kkt = dmax(dmax(d.inf_pr[b], sdu * o.ipddp_barrier_update_dual_weight), d.inf_comp[b]);
               if (kkt <= o.ipddp_mu_kappa_epsilon * mu) {
                 const double linear = o.barrier_mu_update_factor * mu;
-                const double superlinear = pow(mu, o.barrier_mu_update_power);
+                const double superlinear = solver_pow(mu, o.barrier_mu_update_power);
                 mu = dmax(o.barrier_mu_min_value, dmin(linear, superlinear));
               }
             }

@@ -34,6 +34,31 @@ struct CoopCfg {
 
 DEV void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// XCD-aware block -> trajectory-group map of the cooperative sweeps.
+// A single-wave workgroup with G lanes per trajectory holds TPW = 64 / G trajectories, i.e. it touches TPW * 8 bytes of every
+// 512-B row of the wave-tiled stacks: 32 B at G = 16.  The BPT = 64 / TPW workgroups that share the rows of one 64-trajectory
+// tile are consecutive block indices, and consecutive blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+// MI355X_MICROARCH.md "Workgroup dispatch"): every 128-B line was then fetched by up to four different L2s (round 2's counters:
+// 28 GB of fabric traffic per launch of the C5 sweep against 8.5 GB algorithmic).  Here block bid of XCD x = bid % 8 takes the
+// groups of tile (8 * super + x), so that all sharers of a line sit behind ONE L2 and run at the same time (same dispatch
+// round).  The grid is rounded up to whole super-groups of 8 * BPT blocks; surplus blocks see b >= B and leave.  Pure
+// placement: which block computes a trajectory does not enter its arithmetic (bitwise tests unchanged).
+template <int TPW> DEV int coop_group(int bid, int enable) {
+  constexpr int BPT = 64 / TPW;            // blocks per 64-trajectory tile
+  if (BPT < 8 || !enable) return bid;      // >= 128 B per block and row already (G <= 4): lines are not shared
+  constexpr int SUPER = 8 * BPT;
+  const int sup = bid / SUPER, r = bid - sup * SUPER;
+  const int xcd = r & 7, j = r >> 3;
+  return (sup * 8 + xcd) * BPT + j;
+}
+template <int TPW> inline unsigned coop_grid(int B, int enable) {
+  constexpr int BPT = 64 / TPW;
+  const unsigned n = (unsigned)((B + TPW - 1) / TPW);
+  if (BPT < 8 || !enable) return n;
+  constexpr unsigned SUPER = 8 * BPT;
+  return (n + SUPER - 1) / SUPER * SUPER;
+}
+
 template <class Model, class Cons>
 __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                             int force, int count_iter) {
@@ -46,7 +71,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
   const int lane = threadIdx.x;
   const int q = lane % C::G, tl = lane / C::G;
   const int qc = q < NX ? q : NX - 1;
-  const int b = blockIdx.x * C::TPW + tl;
+  const int b = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
   const int lane = threadIdx.x;
   const int q = lane % C::G, tl = lane / C::G;
   const int qc = q < NX ? q : NX - 1;
-  const int b = blockIdx.x * C::TPW + tl;
+  const int b = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;
@@ -756,7 +781,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   const int col = q % GC, hh = q / GC;         // owned column, half of its rows
   const int qc = col < NX ? col : NX - 1;
   const int r0 = hh * RH, u0 = hh * UH;        // first owned row of a column / of B^T V_xx
-  const int b = blockIdx.x * C::TPW + tl;
+  const int b = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;

@@ -927,7 +927,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         const double ysp = yn[off + i] * sn[off + i];
         ev_icomp = dmax(ev_icomp, fabs(ysp - mu));
         ys_lo = dmin(ys_lo, ysp); ys_hi = dmax(ys_hi, ysp);   // for the residual under an updated mu (k_update)
-        ls += log(dmax(sn[off + i], kEpsSlack));
+        ls += solver_log(dmax(sn[off + i], kEpsSlack));
       }
       ev_max = dmax(ev_max, ninf);
       if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
   }
   const int q = lane % G, tl = lane / G;
   const int qc = q < NX ? q : NX - 1;
-  const int b = blockIdx.x * C::TPW + tl;
+  const int b = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         }
         for (int i = 0; i < p; ++i) tr += AtA[i * ld_ + i];
         const double trace_term = (tr > 1.0 ? tr / (p > 1 ? p : 1) : 1.0);
-        const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+        const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * solver_pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
         const double regv = dmax(base_floor, 1e-6 * trace_term);
         // te_backward adds svd_reg = max(1e-8 smax - smin, 0) of the singular values of A_s (80 Jacobi sweeps) and takes
         // reg_base = max(regv, svd_reg).  Whenever tr = ||A_s||_F^2 is finite that maximum is regv, whatever the
@@ -921,11 +921,14 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
   if (force) return;
   const double inf_pr = d.inf_pr[b], inf_comp = d.inf_comp[b], step_norm = d.step_norm[b];
   bool conv;
-  if (M == 0) conv = (inf_pr < o.tolerance && inf_du < o.tolerance);   // no barrier terms (terminal equality only)
+  // computeScaledDualInfeasibility (ipddp_solver.cpp:931, 2725-2776), as every other sweep's early-convergence test uses it
+  // (this kernel is only instantiated for layouts without state-dependent path rows, where it returns inf_du unchanged)
+  const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, d.cur[b], inf_du);
+  if (M == 0) conv = (inf_pr < o.tolerance && sdu_early < o.tolerance);   // no barrier terms (terminal equality only)
   else {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
-    conv = (inf_pr < tol && inf_du < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
   }
   if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
   d.phase[b] = PH_FWD1;

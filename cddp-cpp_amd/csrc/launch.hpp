@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "kernels_te.hpp"
+#include "kernels_elem.hpp"
 #include "kernels_mfma.hpp"
 
 namespace cddp_dev {
@@ -40,6 +41,10 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "lane");
   }
+  static bool coop_sweep_requested() {   // CDDP_HIP_SWEEP=coop: the column-ownership sweep where the element-ownership one is the default
+    const char *e = std::getenv("CDDP_HIP_SWEEP");
+    return e && !std::strcmp(e, "coop");
+  }
   static bool mfma_sweep_requested() {   // CDDP_HIP_SWEEP=mfma | coop (default: see the note at the launch site)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "mfma");
@@ -65,8 +70,10 @@ struct Launcher {
   static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
     // one-lane-per-trajectory kernels instead (comparison / experiments)
-    const bool lane_sweep = lane_sweep_requested() || d.ddp;   // full DDP (use_ilqr = 0): the one-lane kernels carry the tensor terms
-    const dim3 gridC((d.B + CoopCfg<Model>::TPW - 1) / CoopCfg<Model>::TPW);
+    // full DDP (use_ilqr = 0): the one-lane IPDDP kernels carry the tensor terms; CLDDP's backward pass has none
+    // (clddp_solver.cpp:79-204 ignores use_ilqr), so it keeps the cooperative sweep
+    const bool lane_sweep = lane_sweep_requested() || (d.ddp && solver == CDDP_HIP_SOLVER_IPDDP);
+    const dim3 gridC(coop_grid<CoopCfg<Model>::TPW>(d.B, d.xcd_map));   // whole XCD super-groups when lines are shared between blocks
     if (solver == CDDP_HIP_SOLVER_CLDDP) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
@@ -94,13 +101,24 @@ struct Launcher {
           int hsel = 1;
           if (const char *e = std::getenv("CDDP_HIP_COOP_H")) { if (e[0] == '2') hsel = 2; }
           if (hsel == 2)
-            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 2>), dim3((d.B + TPW2 - 1) / TPW2), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 2>), dim3(coop_grid<TPW2>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
           else
             hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
         }
       }
-      else
-        hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else {
+        // nx <= 4, nu <= 2: element-ownership sweep (kernels_elem.hpp: 16 lanes per trajectory, four times the wavefronts of the
+        // column-ownership form, exchanges through the crossbar); CDDP_HIP_SWEEP=coop keeps the column form (bitwise equal)
+        bool launched = false;
+        if constexpr (Model::NX <= 4 && Model::NU <= 2) {
+          if (!coop_sweep_requested()) {
+            hipLaunchKernelGGL((k_backward_ipddp_elem<Model, Cons>), dim3(coop_grid<4>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+            launched = true;
+          }
+        }
+        if (!launched)
+          hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      }
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
     } else if constexpr (!TERM && Cons::M == 0) {
       if (lane_sweep)

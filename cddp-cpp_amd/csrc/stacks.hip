@@ -471,7 +471,9 @@ __global__ __launch_bounds__(64) void k_stacks_backward(StackArgs a) {
   for (;;) {   // "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111 (reg_factor <= 1: a single attempt)
     ok = sweep<NX, NU, M>(a, b, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
     if (ok || !(a.reg_factor > 1.0)) break;
-    reg = dmin(reg * a.reg_factor, a.reg_max);
+    reg = reg * a.reg_factor;
+    if (!(reg > 0.0)) reg = (a.opt.reg_min_value > 0.0) ? a.opt.reg_min_value : a.reg_max;   // 0 is a fixed point of reg * f (kernels.hpp::reg_increase)
+    reg = dmin(reg, a.reg_max);
     if (reg >= a.reg_max) break;
   }
   a.ok[b] = ok ? 1 : 0;
@@ -751,6 +753,8 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   if (branch == CDDP_HIP_STACKS_CLDDP && h->a.Fxx)
     return sfail(-1, "CLDDPSolver::backwardPass has no second-order dynamics terms (clddp_solver.cpp:79-204): drop the Hessian stacks for this branch");
   for (int b = 0; b < h->B; ++b) if (!(reg[b] >= 0.0)) return sfail(-2, "regularisation of trajectory %d must be non-negative (got %g)", b, reg[b]);
+  if (retry && (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0)))
+    return sfail(-2, "retry needs regularization.update_factor > 1 and max_value > 0 (got %g, %g)", opt->reg_update_factor, opt->reg_max_value);
   SCHK(hipSetDevice(h->device));
   SCHK(hipMemcpyAsync(h->d_reg, reg, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
   if (mu) SCHK(hipMemcpyAsync(h->d_mu, mu, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));

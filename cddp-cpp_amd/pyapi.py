@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
 
+ABI_VERSION = 2          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
 MAX_MODEL_PARAMS = 24
 NAME_LEN = 48
 
@@ -176,7 +177,7 @@ class Problem:
                  model_params=(), lti_A=None, lti_B=None, x_ref_traj=None, options=None):
         self.keep = []
         self.c = ProblemStruct()
-        self.c.abi_version = 1
+        self.c.abi_version = ABI_VERSION
         self.c.solver = solver; self.c.model = model; self.c.integrator = integrator
         self.c.nx = nx; self.c.nu = nu; self.c.horizon = horizon; self.c.dt = dt
         for i, v in enumerate(model_params):
@@ -334,6 +335,34 @@ def quadrotor_problem(solver=SOLVER_IPDDP, horizon=120, constrained=True):
     return p
 
 
+def quadrotor_figure8_problem(solver=SOLVER_IPDDP, horizon=400):
+    """The reference's own N = 400 quadrotor case: figure-8 tracking with per-step reference states
+    (tests/cddp_core/test_ipddp_solver.cpp:887-1080, test_clddp_solver.cpp:570-763): m = 1.2, arm = 0.165, u in [0, 4]^4,
+    Q = Qf = diag(1 x 7, 0 x 6), R = 0.01 I, hover U0, X0 = hover rollout.  It exercises the time-varying-reference branch of
+    QuadraticObjective (objective.cpp:83-88)."""
+    o = default_options(); o.tolerance = 1e-6; o.reg_initial_value = 1e-4; o.return_iteration_info = 1
+    if solver == SOLVER_IPDDP:
+        o.max_iterations = 500; o.acceptable_tolerance = 1e-5
+    else:
+        o.max_iterations = 200; o.acceptable_tolerance = 1e-6
+    dt = 0.02
+    Q = np.zeros((13, 13))
+    for i in range(7): Q[i, i] = 1.0
+    R = 0.01 * np.eye(4); Qf = Q.copy()
+    omega = 2.0 * np.pi / (horizon * dt)
+    ref = np.zeros((horizon + 1, 13))
+    for i in range(horizon + 1):
+        a = omega * (i * dt)
+        ref[i, 0] = 3.0 * np.cos(a); ref[i, 1] = 3.0 * np.sin(a) * np.cos(a); ref[i, 2] = 2.0; ref[i, 3] = 1.0
+    goal = np.zeros(13); goal[0] = 3.0; goal[2] = 2.0; goal[3] = 1.0
+    p = Problem(solver, MODEL_QUADROTOR, RK4, 13, 4, horizon, dt, Q, R, Qf, goal,
+                model_params=[1.2, 0.165, 7.782e-3, 7.782e-3, 1.439e-2, 9.81], x_ref_traj=ref, options=o)
+    p.add_control_box("ControlConstraint", np.zeros(4), 4.0 * np.ones(4))
+    p.x0 = goal.copy()
+    p.U0_const = (1.2 * 9.81 / 4.0) * np.ones(4)
+    return p
+
+
 def quadrotor12_problem(solver=SOLVER_IPDDP, horizon=400, constrained=True):
     """SYNTHETIC throughput shape of BASELINE config 4 (nx=12, nu=4, N=400)."""
     o = default_options(); o.max_iterations = 120; o.ls_max_iterations = 15; o.reg_initial_value = 1e-4
@@ -403,27 +432,37 @@ def batch_U0(problem, batch):
 # ----------------------------------------------------------------------------------------------
 # Product binding
 # ----------------------------------------------------------------------------------------------
-_hip_lib = None
+_hip_libs = {}
+# Parity build of the same library (csrc/Makefile: -DCDDP_TRIG_SHARED): the reference's plants evaluate sin / cos with the
+# branch-free routine of dev_trig.hpp instead of the device libm -- the routine the CPU checker can run too, which makes the
+# knife-edge plants bit-comparable.  Selected per process with CDDP_HIP_TRIG=shared, or per solver with trig="shared".
+HIP_SHAREDTRIG_LIB_PATH = os.path.join(_HERE, "lib", "libcddp_hip_sharedtrig.so")
 
 
-def load_hip():
-    """Load the HIP C-ABI library.  Raises if it is missing: there is no fallback path."""
-    global _hip_lib
-    if _hip_lib is not None:
-        return _hip_lib
-    if not os.path.exists(HIP_LIB_PATH):
+def default_trig():
+    return "shared" if os.environ.get("CDDP_HIP_TRIG", "") == "shared" else "libm"
+
+
+def load_hip(trig=None):
+    """Load the HIP C-ABI library (trig: None = per CDDP_HIP_TRIG, "libm" = the product build, "shared" = the parity build).
+    Raises if it is missing: there is no fallback path."""
+    trig = trig or default_trig()
+    if trig in _hip_libs:
+        return _hip_libs[trig]
+    path = HIP_SHAREDTRIG_LIB_PATH if trig == "shared" else HIP_LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError("HIP library missing: %s -- run __graft_entry__.build(); "
-                           "the product has no CPU fallback" % HIP_LIB_PATH)
-    lib = C.CDLL(HIP_LIB_PATH)
+                           "the product has no CPU fallback" % path)
+    lib = C.CDLL(path)
     lib.cddp_hip_last_error.restype = C.c_char_p
     lib.cddp_hip_status_string.restype = C.c_char_p
     lib.cddp_hip_create.argtypes = [C.POINTER(ProblemStruct), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
-    _hip_lib = lib
+    _hip_libs[trig] = lib
     return lib
 
 
 EXPORTED_SYMBOLS = [
-    "cddp_hip_default_options", "cddp_hip_abi_version", "cddp_hip_last_error", "cddp_hip_device_count",
+    "cddp_hip_default_options", "cddp_hip_abi_version", "cddp_hip_trig_shared", "cddp_hip_last_error", "cddp_hip_device_count",
     "cddp_hip_status_string", "cddp_hip_build_alphas", "cddp_hip_create", "cddp_hip_destroy",
     "cddp_hip_set_stream", "cddp_hip_set_initial", "cddp_hip_initialize", "cddp_hip_backward",
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
@@ -443,8 +482,8 @@ class HipError(RuntimeError):
 class HipBatchSolver:
     """Batch of independent trajectories of one problem on one GPU (C-ABI handle)."""
 
-    def __init__(self, problem, batch, device=0):
-        self.lib = load_hip()
+    def __init__(self, problem, batch, device=0, trig=None):
+        self.lib = load_hip(trig)
         self.p = problem; self.B = batch
         self.h = C.c_void_p()
         rc = self.lib.cddp_hip_create(C.byref(problem.c), batch, device, C.byref(self.h))

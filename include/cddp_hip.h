@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define CDDP_HIP_ABI_VERSION 1
+/* 2: cddp_hip_options gained max_cpu_time (shifts cddp_hip_problem's tail), cddp_hip_stats gained rollout_steps (80 -> 88 bytes).
+ * A host built against version 1 is refused by cddp_hip_create instead of being read at shifted offsets. */
+#define CDDP_HIP_ABI_VERSION 2
 #define CDDP_HIP_MAX_MODEL_PARAMS 24
 #define CDDP_HIP_NAME_LEN 48
 #define CDDP_HIP_MAX_ALPHAS 32
@@ -284,6 +286,11 @@ typedef struct cddp_hip_handle cddp_hip_handle;
 /* ---- entry points -------------------------------------------------------- */
 
 int cddp_hip_abi_version(void);
+/* 0: the reference's plants evaluate sin / cos with the device libm (lib/libcddp_hip.so, the product build); 1: with the
+ * branch-free routine of csrc/dev_trig.hpp (lib/libcddp_hip_sharedtrig.so, the parity build a host selects with
+ * CDDP_HIP_TRIG=shared): same C-ABI, same kernels; a CPU checker can run that routine too, which makes plants whose accept /
+ * reject decisions hinge on the last bit of a sine bit-comparable (tests/test_shared_trig_parity.py). */
+int cddp_hip_trig_shared(void);
 const char *cddp_hip_last_error(void);
 /* Number of visible HIP devices (0 when the runtime finds none). */
 int cddp_hip_device_count(void);

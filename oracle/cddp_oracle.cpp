@@ -462,10 +462,10 @@ struct Solver {
     double mer = c0;
     for (auto &c : cons)
       for (int t = 0; t < (int)Ss.size(); ++t) {
-        double s = 0; for (int i = 0; i < c.dual_dim; ++i) s += std::log(std::max(Ss[t](c.offset + i), EPS_SLACK));
+        double s = 0; for (int i = 0; i < c.dual_dim; ++i) s += olog(std::max(Ss[t](c.offset + i), EPS_SLACK));
         mer -= mu * s;
       }
-    if (ST) for (auto &kv : *ST) { double s = 0; for (int i = 0; i < kv.second.size(); ++i) s += std::log(std::max(kv.second(i), EPS_SLACK)); mer -= mu * s; }
+    if (ST) for (auto &kv : *ST) { double s = 0; for (int i = 0; i < kv.second.size(); ++i) s += olog(std::max(kv.second(i), EPS_SLACK)); mer -= mu * s; }
     if (lamT && hT && lamT->size() == hT->size() && hT->size() > 0) mer += lamT->dot(*hT);
     return mer;
   }
@@ -804,7 +804,7 @@ struct Solver {
     const Vec Atb = A_small.T() * rhs;
     const double trace_term = (AtA.trace() > 1.0 ? AtA.trace() / std::max(p_dim, 1) : 1.0);
     const double base_floor = std::max(1e-10, opt.ipddp_jacobian_regularization_value *
-                                                  std::pow(std::max(mu, 0.0), opt.ipddp_jacobian_regularization_exponent));
+                                                  opow(std::max(mu, 0.0), opt.ipddp_jacobian_regularization_exponent));
     const double regv = std::max(base_floor, 1e-6 * trace_term);
     std::vector<double> sv = singularValues(A_small);
     double sigma_max = 0.0, sigma_min = 0.0;
@@ -1233,7 +1233,7 @@ struct Solver {
           else if (ratio < 0.5) factor = 0.6 * opt.barrier_mu_update_factor;
         }
         const double linear = factor * mu;
-        const double superlinear = std::pow(mu, opt.barrier_mu_update_power);
+        const double superlinear = opow(mu, opt.barrier_mu_update_power);
         mu = std::max(std::min(linear, superlinear), std::max(opt.barrier_mu_min_value, opt.tolerance / 100.0));
       }
     } else {
@@ -1241,7 +1241,7 @@ struct Solver {
       const double kkt = std::max(std::max(inf_pr, wdu), scomp);
       if (kkt <= opt.ipddp_mu_kappa_epsilon * mu) {
         const double linear = opt.barrier_mu_update_factor * mu;
-        const double superlinear = std::pow(mu, opt.barrier_mu_update_power);
+        const double superlinear = opow(mu, opt.barrier_mu_update_power);
         mu = std::max(opt.barrier_mu_min_value, std::min(linear, superlinear));
       }
     }
@@ -1352,8 +1352,8 @@ struct Solver {
     while (iter < opt.max_iterations) {
       ++iter;
       if (opt.max_cpu_time > 0) {  // cddp_solver_base.cpp:77-90
-        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - start_time).count();
-        if (el > opt.max_cpu_time) { reason = CDDP_HIP_STATUS_MAX_CPU_TIME; break; }
+        const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start_time).count();
+        if (el_ms > opt.max_cpu_time * 1000) { reason = CDDP_HIP_STATUS_MAX_CPU_TIME; break; }   // whole milliseconds, as the reference casts
       }
       bool backward_ok = false;
       while (!backward_ok) {
@@ -1588,6 +1588,7 @@ double cddp_oracle_scaled_inf_du(void *o) { return ((Solver *)o)->computeScaledD
 double cddp_oracle_get_mu(void *o) { return ((Solver *)o)->mu; }
 // libm-noise knob of models.hpp (process-wide): 0 = off (default), 1 = sin / cos results moved by -1 / 0 / +1 ulp
 void cddp_oracle_set_trig_noise(int v) { oracle::trig_noise() = v; }
+void cddp_oracle_set_trig_mode(int v) { oracle::trig_mode() = v; }   // 0 = glibc, 1 = the HIP parity build's routine (models.hpp)
 // summation-order noise knob of linalg.hpp (process-wide): 0 = off (default), 1 = matrix-product entries moved by <= 1 ulp
 void cddp_oracle_set_matmul_noise(int v) { oracle::matmul_noise() = v; }
 void cddp_oracle_set_inf_du(void *o, double v) { ((Solver *)o)->inf_du = v; }

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <limits>
 #include "linalg.hpp"
+#include "../cddp-cpp_amd/csrc/dev_trig.hpp"   // host build of the shared sin / cos (trig_mode); a header of the product read by the checker, never the reverse
 #include "../include/cddp_hip.h"
 
 namespace oracle {
@@ -54,8 +55,20 @@ inline double trig_perturb(double r, double a) {
   switch (h % 3u) { case 0: return r; case 1: return std::nextafter(r, std::numeric_limits<double>::infinity());
                     default: return std::nextafter(r, -std::numeric_limits<double>::infinity()); }
 }
-inline double osin(double a) { return trig_perturb(std::sin(a), a); }
-inline double ocos(double a) { return trig_perturb(std::cos(a), a + 0.5); }
+// Shared-trig parity mode (test infrastructure, default off): with trig_mode() == 1 every sine / cosine goes through the
+// branch-free routine the HIP library's parity build uses for the reference's plants (cddp-cpp_amd/csrc/dev_trig.hpp, compiled
+// here for the host; 0.78 ulp against long-double libm, tests/test_dev_trig.py).  Both sides then execute the same IEEE
+// add / mul / fma sequence per angle, so solves of the knife-edge plants are compared bit for bit instead of statistically
+// (tests/test_shared_trig_parity.py).  The default (glibc) mode stays the independent check.
+inline int &trig_mode() { static int v = 0; return v; }
+inline double base_sin(double a) { if (trig_mode() == 1) { double s, c; cddp_dev::sincos_1(a, &s, &c); return s; } return std::sin(a); }
+inline double base_cos(double a) { if (trig_mode() == 1) { double s, c; cddp_dev::sincos_1(a, &s, &c); return c; } return std::cos(a); }
+// log / pow of the solver core (barrier merit, barrier update, terminal-equality regularisation): glibc by default, the HIP parity
+// build's straight-line routines in trig_mode 1
+inline double olog(double x) { return trig_mode() == 1 ? cddp_dev::log_shared(x) : std::log(x); }
+inline double opow(double x, double y) { return trig_mode() == 1 ? cddp_dev::pow_shared(x, y) : std::pow(x, y); }
+inline double osin(double a) { return trig_perturb(base_sin(a), a); }
+inline double ocos(double a) { return trig_perturb(base_cos(a), a + 0.5); }
 inline double sin(double a) { return osin(a); }   // found by the unqualified calls of the templated dynamics (S = double)
 inline double cos(double a) { return ocos(a); }
 inline Dual sin(const Dual &a) { Dual r; r.v = osin(a.v); double c = ocos(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = c * a.d[i]; return r; }

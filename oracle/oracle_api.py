@@ -200,10 +200,26 @@ def oracle_ldlt_solve(A, B):
 
 
 
+class shared_trig:
+    """Context manager: the oracle evaluates sin / cos with the HIP parity build's routine (models.hpp::trig_mode 1) inside the
+    block -- pair it with HipBatchSolver(..., trig="shared").  Process-global, like the noise knobs."""
+
+    def __init__(self, fast=False):
+        self.lib = load_oracle(fast)
+
+    def __enter__(self):
+        self.lib.cddp_oracle_set_trig_mode(1)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.cddp_oracle_set_trig_mode(0)
+        return False
+
+
 def attach(api):
     """Expose the oracle entry points on the harness module `api` (cddp-cpp_amd/pyapi.py)."""
     mod = sys.modules[__name__]
     for name in ("ORACLE_LIB_PATH", "ORACLE_FAST_LIB_PATH", "load_oracle", "Oracle", "oracle_solve_batch", "oracle_boxqp",
-                 "oracle_ldlt_solve"):
+                 "oracle_ldlt_solve", "shared_trig"):
         setattr(api, name, getattr(mod, name))
     return api

@@ -51,6 +51,11 @@ def _lti(N, x0, goal, R, Qf, cons=None, term=None, **opt):
                 Qf=Qf * np.eye(1), xref=[goal], constraints=cons or {}, terminal=term or {}, options=o, x0=[x0])
 
 
+def _with(spec, name, con):
+    spec["constraints"] = dict(spec["constraints"]); spec["constraints"][name] = con
+    return spec
+
+
 CASES = {
     # name -> (twin spec builder, pyapi case name of tests/test_gpu_parity.py::make / TERM_CASES)
     "pendulum_ipddp_unc": lambda: _pendulum("IPDDP", False),
@@ -72,6 +77,21 @@ CASES = {
     "path_term_ineq": lambda: _lti(4, 1.0, 0.0, 1e-2, 1.0, cons={"PathUpperBound": T.Linear(np.eye(1), [0.25])},
                                    term={"TerminalUpperBound": ("ineq", np.eye(1), [0.25])}, max_iterations=20),
     "pendulum_term_eq": lambda: dict(_pendulum("IPDDP", True, N=60), terminal={"TerminalTarget": ("eq", [0.0, 0.0])}),
+    # option branches (tests/test_gpu_parity.py::OPTION_CASES): non-ADAPTIVE barrier update (ipddp_solver.cpp:2601-2614),
+    # theta_norm = "l2" (:2778-2848), check_state_stationarity (:931, 2725-2776)
+    "cartpole_ipddp_box_monotonic": lambda: _cartpole("IPDDP", True, barrier_strategy="MONOTONIC"),
+    "pendulum_ipddp_box_ipopt": lambda: _pendulum("IPDDP", True, barrier_strategy="IPOPT"),
+    "unicycle_ipddp_box_ball_ipopt": lambda: _unicycle("IPDDP", True, barrier_strategy="IPOPT"),
+    "pendulum_ipddp_box_l2": lambda: _pendulum("IPDDP", True, theta_norm="l2"),
+    "unicycle_ipddp_box_ball_l2": lambda: _unicycle("IPDDP", True, theta_norm="l2"),
+    "path_term_ineq_l2": lambda: _lti(4, 1.0, 0.0, 1e-2, 1.0, cons={"PathUpperBound": T.Linear(np.eye(1), [0.25])},
+                                      term={"TerminalUpperBound": ("ineq", np.eye(1), [0.25])}, max_iterations=20, theta_norm="l2"),
+    "path_term_ineq_stationarity": lambda: _lti(4, 1.0, 0.0, 1e-2, 1.0, cons={"PathUpperBound": T.Linear(np.eye(1), [0.25])},
+                                                term={"TerminalUpperBound": ("ineq", np.eye(1), [0.25])}, max_iterations=20, check_state_stationarity=True),
+    "pendulum_ipddp_box_state_stationarity": lambda: _with(_pendulum("IPDDP", True, check_state_stationarity=True),
+                                                           "StateConstraint", T.StateBox([-4.0, -9.0], [4.0, 9.0])),
+    "cartpole_ipddp_box_state_stationarity": lambda: _with(_cartpole("IPDDP", True, check_state_stationarity=True),
+                                                           "StateConstraint", T.StateBox([-1.5, -7.0, -8.0, -25.0], [1.5, 7.0, 8.0, 25.0])),
 }
 
 

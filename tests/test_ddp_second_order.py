@@ -119,6 +119,42 @@ def _noise_yardstick(api, lib, p, x0b, U0b, ref_ok, ref, ref_reg):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", STEP_CASES)
 def test_hip_second_order_step_level(api, oracle_built, name):
+    """One sweep + the ladder with the tensor terms, HIP parity build (shared sin / cos, tests/test_shared_trig_parity.py) against the
+    oracle in its shared-trig mode: with the same trig routine on both sides there is no libm noise left to amplify, so EVERY
+    trajectory is held to the strict 1e-8 -- also the unicycle sweeps whose indefinite Q_uu drives the gains to 1e4..1e10 (round 2
+    compared those at 1e3 x a noise yardstick, and its `strict >= 0` clause was vacuous)."""
+    p = _problem(api, name)
+    B = 6
+    spread = np.asarray(spread_for(p)) * STEP_SCALE.get(name, 1.0) if p.nx > 1 else 0.05 * np.ones(1)
+    x0 = api.batch_x0(p, B, 20260928, spread)
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B, trig="shared"); hs.set_initial(x0, U0); hs.initialize()
+    ok = hs.backward()
+    K, k = hs.gains(); Vx, Vxx = hs.value(); dV, reg = hs.backward_scalars()
+    alphas = api.Oracle(p).alphas()
+    tr = hs.forward(alphas)
+    hs.close()
+    worst = 0.0
+    with api.shared_trig():
+        for b in range(B):
+            U0b = None if U0 is None else U0[b]
+            o, oko, ref, rego = _oracle_sweep(api, p, x0[b], U0b)
+            err = max(rel_err(g, r) for g, r in zip((K[b], k[b], Vx[b], Vxx[b], dV[b]), ref))
+            worst = max(worst, err)
+            assert oko == ok[b] and reg[b] == rego, (name, b)
+            assert err < TOL, (name, b, err)
+            for a, alpha in enumerate(alphas):
+                t = o.forward(alpha)
+                assert tr[b, a]["success"] == t["success"], (name, b, alpha)
+    print("%s: worst HIP-vs-oracle relative error %.2e over %d trajectories (shared-trig mode)" % (name, worst, B))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_hip_second_order_step_level_default_build(api, oracle_built, name):
+    """The product build (device libm) against the glibc-mode oracle: each trajectory at max(1e-8, 1e3 x its own noise yardstick)
+    -- the amplification of a <= 1 ulp libm difference by an indefinite Q_uu is a property of the problem, not of the port; the
+    well-conditioned cases must meet the strict bar everywhere."""
     p = _problem(api, name)
     lib = _oracle_lib(api)
     B = 6
@@ -128,8 +164,6 @@ def test_hip_second_order_step_level(api, oracle_built, name):
     hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.initialize()
     ok = hs.backward()
     K, k = hs.gains(); Vx, Vxx = hs.value(); dV, reg = hs.backward_scalars()
-    alphas = api.Oracle(p).alphas()
-    tr = hs.forward(alphas)
     hs.close()
     strict = 0
     for b in range(B):
@@ -142,40 +176,33 @@ def test_hip_second_order_step_level(api, oracle_built, name):
             strict += 1
             assert oko == ok[b] and reg[b] == rego
             assert err < TOL, (name, b, err)
-            for a, alpha in enumerate(alphas):
-                t = o.forward(alpha)
-                assert tr[b, a]["success"] == t["success"], (name, b, alpha)
         elif np.isfinite(yard):
             assert oko == ok[b] and reg[b] == rego
             assert err < max(TOL, 1e3 * yard), (name, b, err, yard)
-    assert strict == B if name in STRICT_EVERYWHERE else strict >= 0, (name, strict)
+    if name in STRICT_EVERYWHERE:
+        assert strict == B, (name, strict)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SOLVE_CASES)
 def test_hip_second_order_full_solve(api, oracle_built, name):
+    """Full-DDP solves, parity build vs the oracle's shared-trig mode: every trajectory has the oracle's status, iteration count and
+    rollout count (strict, no yardstick); converged ones agree in objective 1e-7 and trajectory 1e-6."""
     p = _problem(api, name)
-    lib = _oracle_lib(api)
     B = 12
     x0 = api.batch_x0(p, B, 20260929, spread_for(p) if p.nx > 1 else 0.05 * np.ones(1))
     U0 = api.batch_U0(p, B)
-    hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+    hs = api.HipBatchSolver(p, B, trig="shared"); hs.set_initial(x0, U0); hs.solve()
     res = hs.results(); X, U = hs.trajectory(); hs.close()
-    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0, n_threads=8)
-    try:   # yardstick: which trajectories keep (status, iterations) when the oracle's own sin / cos move by <= 1 ulp
-        lib.cddp_oracle_set_trig_noise(1)
-        nres = api.oracle_solve_batch(p, x0, U0, n_threads=8)[0]
-    finally:
-        lib.cddp_oracle_set_trig_noise(0)
-    stable = (nres["iterations"] == ores["iterations"]) & (nres["status"] == ores["status"])
-    same = (res["iterations"] == ores["iterations"]) & (res["status"] == ores["status"])
-    print("%s: HIP == oracle on %d / %d trajectories, oracle == noisy oracle on %d" % (name, same.sum(), B, stable.sum()))
-    assert same[stable].all() or same.sum() >= stable.sum(), list(zip(res["iterations"], ores["iterations"], res["status"], ores["status"], stable))
-    if name.startswith("pendulum") or name in TERM_CASES: assert stable.all() and same.all()
+    with api.shared_trig():
+        ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0, n_threads=8)
+    same = (res["iterations"] == ores["iterations"]) & (res["status"] == ores["status"]) & (res["n_forward"] == ores["n_forward"])
+    print("%s: HIP == oracle on %d / %d trajectories (shared-trig mode)" % (name, same.sum(), B))
+    assert same.all(), list(zip(res["iterations"], ores["iterations"], res["status"], ores["status"]))
     conv = (ores["status"] == api.STATUS_OPTIMAL) | (ores["status"] == api.STATUS_ACCEPTABLE)
     for b in range(B):
-        if conv[b] and same[b] and stable[b]:
-            assert res["n_forward"][b] == ores["n_forward"][b] and rel_err(res["final_objective"][b], ores["final_objective"][b]) < 1e-7
+        if conv[b]:
+            assert rel_err(res["final_objective"][b], ores["final_objective"][b]) < 1e-7
             assert rel_err(X[b], oX[b]) < 1e-6 and rel_err(U[b], oU[b]) < 1e-6
 
 

@@ -97,7 +97,10 @@ def test_bench_inputs_match(api):
 # pendulum-class plants was observed; the bound is the measured rate on MI355X (profiles/r02_parity_report.md)
 # with head-room.  Solves that run into the iteration cap are chaotic in their rounding, so late line-search
 # decisions may differ; status + iteration count must still agree for at least (1 - COUNT_MISMATCH_MAX).
-WHOLE_BATCH = {"cartpole": (0.02, 0.25), "cartpole_clddp": (0.02, 0.25), "unicycle": (0.02, 0.25)}
+# Round 3: bounds tightened to the measured figures + a small margin (measured on MI355X, profiles/r02_parity_report.md and
+# r03: 0 of 4096 / 4096 / 8192 trajectories differ in any of the compared quantities): at most 0.2 % of the batch may differ
+# in (status, iterations) and at most 1 % in the strict comparison.
+WHOLE_BATCH = {"cartpole": (0.002, 0.01), "cartpole_clddp": (0.002, 0.01), "unicycle": (0.002, 0.01)}
 
 
 @pytest.mark.parametrize("workload", list(WHOLE_BATCH))
@@ -129,7 +132,7 @@ def test_whole_bench_batch_against_oracle(api, oracle_built, workload):
 # independent property (a trajectory's solve inside the full batch == its solve inside a small batch, bit for bit)
 # plus N_ORACLE trajectories against the oracle.  Both plants are knife-edge cases (sin / cos + binding caps, see
 # tests/test_gpu_parity.py): the agreement is measured and bounded, not assumed.
-BIG = {"quadrotor": (16, 8), "manip7": (16, 8)}     # workload -> (oracle-checked trajectories, min agreeing in status+iterations)
+BIG = {"quadrotor": (16, 15), "manip7": (16, 15)}     # workload -> (oracle-checked trajectories, min agreeing in status+iterations; measured 16 / 16)
 
 
 @pytest.mark.parametrize("workload", list(BIG))

@@ -242,8 +242,9 @@ def test_late_iterate_gains(api, oracle_built, case, kit):
 # the ORACLE's own sin / cos results are moved by <= 1 ulp (tests/golden/make_trig_noise.py), i.e. under the difference
 # between glibc and the device libm.  A capped trial lands exactly on (1 - tau) s, so `s_new < (1 - tau) s` is decided by
 # the last bit; after a flip two solves follow different, equally valid iterates.  The HIP path may not flip more often
-# than that noise does (margin: 6 of 32 trajectories, about two binomial standard deviations at the observed rates).
-KNIFE_MARGIN = 6
+# than that noise does (margin: 3 of 32 trajectories, about one binomial standard deviation at the observed rates; the strict,
+# non-statistical comparison of the same cases is tests/test_shared_trig_parity.py).
+KNIFE_MARGIN = 3
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trig_noise_flip_rates.json")) as _f:
     TRIG_NOISE = json.load(_f)
 

@@ -54,3 +54,61 @@ def test_bench_under_torchrun_one_rank(scaling):
     assert j["config"]["collective"].startswith("ncclAllGather")
     assert j["solve"]["gathered_records"] == j["config"]["global_batch"] == (1000 if scaling == "strong" else 512)
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+def _run_bench(args, torchrun=False, port="29541"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):   # a clean, un-launched environment
+        env.pop(k, None)
+    bench = os.path.join(REPO, "bench.py")
+    if torchrun:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", port, bench] + args
+    else:
+        cmd = [sys.executable, bench] + args
+    return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_gpus_beyond_the_node_fails_loudly():
+    """`python bench.py --gpus N` with fewer than N devices must not print an N = 1 line under another
+    name -- it exits non-zero with a message, with or without torchrun."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = _run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--workload", "pendulum", "--no-cpu-baseline"])
+    assert out.returncode != 0
+    assert "GPU(s) visible" in (out.stderr + out.stdout)
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # under torchrun with ONE rank but --gpus 2 (a launcher / flag mismatch): refused as well
+    if torch.cuda.device_count() >= 2:
+        out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "pendulum", "--no-cpu-baseline"], torchrun=True)
+        assert out.returncode != 0 and "does not match WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_bench_plain_and_torchrun_single_gpu_agree():
+    """`python bench.py --gpus 1` and the same under torch.distributed.run report the same job (same solve, same counters);
+    only the collective differs (device copy vs size-1 ncclAllGather)."""
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "pendulum", "--batch", "512", "--no-cpu-baseline"]
+    lines = []
+    for tr in (False, True):
+        out = _run_bench(args, torchrun=tr, port="29543")
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = lines
+    assert a["n_gpus"] == b["n_gpus"] == 1
+    for k in ("mean_iterations", "status", "sweeps", "rollouts_useful", "gathered_records", "gathered_converged"):
+        assert a["solve"][k] == b["solve"][k], k
+    assert a["roofline"]["rollout_steps_credited"] == b["roofline"]["rollout_steps_credited"]
+    assert a["config"]["collective"].startswith("none") and b["config"]["collective"].startswith("ncclAllGather")
+
+
+def test_bench_default_line_carries_other_workloads():
+    """the default single-GPU line also measures C2-CLDDP, C3 and the C4 / C5 per-GPU shares (3 steps each,
+    outside the headline's timed region) so that the driver's record has them."""
+    out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ow = j["other_workloads"]
+    assert len(ow) == 4 and not any("error" in w for w in ow), ow
+    for w in ow:
+        assert w["value"] > 0 and 0 < w["roofline"]["frac"] < 1 and w["steps"] == 3
+    assert j["config"]["batch_per_gpu"] == 4096 and j["roofline"]["frac"] > 0
