@@ -180,6 +180,26 @@ struct CartPoleModel {   // cartpole.cpp:38-103; params: cart_mass, pole_mass, p
     xd[3] = (-force * c - mp * l * theta_dot * theta_dot * c * s - total_mass * g * s) / (l * den);
   }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+#ifdef CDDP_TRIG_SHARED
+    // parity build: forward-mode duals through the autodiff expression, operation for operation what autodiff::jacobian does
+    // (and what the CPU checker restates) -- the hand-derived form below is the same derivative from a different expression
+    // tree, i.e. equal up to the last bits only, and a non-converging solve amplifies last bits
+    {
+      typedef DualN<5> D;
+      D xs[4], us[1], xd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xs[i] = D(x[i]); xs[i].d[i] = 1.0; }
+      us[0] = D(u[0]); us[0].d[4] = 1.0;
+      f_ad<D>(p, xs, us, xd);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Fx[i * 4 + j] = xd[i].d[j];
+        Fu[i] = xd[i].d[4];
+      }
+      return;
+    }
+#endif
     // exact derivatives of the autodiff expression (cartpole.cpp:69-103, WITH -damping*theta_dot)
     const double mc = p[0], mp = p[1], l = p[2], g = p[3], b = p[4];
     const double w = x[3], F = u[0];

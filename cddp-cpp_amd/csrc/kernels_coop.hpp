@@ -34,6 +34,20 @@ struct CoopCfg {
 
 DEV void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// the value `v` holds in lane P of the caller's quad (DPP quad_perm broadcast: a VALU operand modifier, no LDS)
+template <int P> DEV double quad_bcast(double v) {
+  constexpr int ctrl = P | (P << 2) | (P << 4) | (P << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N> DEV void quad_gather(double v, double *out) {   // out[k] = v of quad lane k, k < N <= 4
+  out[0] = quad_bcast<0>(v);
+  if constexpr (N > 1) out[1] = quad_bcast<1>(v);
+  if constexpr (N > 2) out[2] = quad_bcast<2>(v);
+  if constexpr (N > 3) out[3] = quad_bcast<3>(v);
+}
+
 // XCD-aware block -> trajectory-group map of the cooperative sweeps.
 // A single-wave workgroup with G lanes per trajectory holds TPW = 64 / G trajectories, i.e. it touches TPW * 8 bytes of every
 // 512-B row of the wave-tiled stacks: 32 B at G = 16.  The BPT = 64 / TPW workgroups that share the rows of one 64-trajectory
@@ -67,6 +81,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
   typedef CstLayout<Model, Cons> L;
   typedef CoopCfg<Model> C;
   constexpr int CST = L::SIZE;
+  // kQuad: at G = 4 the lanes of a trajectory are a DPP quad, so rounds 1, 2 and the rollout's dx exchange can be quad broadcasts
+  // instead of LDS rounds (bitwise equal; tests/test_gpu_parity.py ran green with it).  MEASURED on MI355X (round 3,
+  // profiles/r03_element_sweep.md): no gain -- sweep class 16.5 ms vs 16.2 ms per C2 solve, C3 44.5 vs 42.8, CLDDP 19.5 vs 18.5.
+  // The kernel is bound by VALU issue (SQ_ACTIVE_INST_ANY 56 % of the wave cycles, 5.7 cycles per instruction, un-fused f64
+  // multiplies and adds), and the ~30 v_mov_dpp that replace ~20 LDS operations are more instructions, not fewer.  Off.
+  constexpr bool kQuad = false;
   __shared__ double lds[C::TPW * C::STRIDE];
   const int lane = threadIdx.x;
   const int q = lane % C::G, tl = lane / C::G;
@@ -167,21 +187,30 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 #pragma unroll
         for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + u] * Vx[k];
         Qu[u] = c2.cu[u] + s2; }
+      if constexpr (!kQuad) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
+        for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
-      lds_sync();
+        for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
+        lds_sync();
+      }
       __builtin_amdgcn_sched_barrier(0);
       load2(tp, n2);
       PIPELINE_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       // ---- round 2: column qc of Q_xx, Q_ux; Q_uu, factor, k replicated; column qc of K
       double T1[NX * NX], T2[NU * NX];
+      if constexpr (kQuad) {   // G = 4: the lanes of a trajectory are a quad -- column j of T1, T2 is lane j's, fetched by DPP broadcasts
 #pragma unroll
-      for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+        for (int i = 0; i < NX; ++i) quad_gather<NX>(T1c[i], T1 + i * NX);
 #pragma unroll
-      for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+        for (int u = 0; u < NU; ++u) quad_gather<NX>(T2c[u], T2 + u * NX);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+      }
       double Qxxc[NX], Quxc[NU], Quu[NU * NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
@@ -235,16 +264,23 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 #pragma unroll
         for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
       }
+      if constexpr (!kQuad) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; }
-      lds_sync();
+        for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; }
+        lds_sync();
+      }
       st<NU>(d.k + GI(t, NU, 0), kLS, kk);
 #pragma unroll
       for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
       // ---- round 3: value update
       double KK[NU * NX], Qux[NU * NX];
+      if constexpr (kQuad) {
 #pragma unroll
-      for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+        for (int u = 0; u < NU; ++u) { quad_gather<NX>(KKc[u], KK + u * NX); quad_gather<NX>(Quxq[u], Qux + u * NX); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+      }
 #pragma unroll
       for (int i = 0; i < NU; ++i) Qu[i] += c2.QyuSir[i];
       if constexpr (Cons::HAS_X) {
@@ -339,11 +375,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 #pragma unroll
         for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
       };
+      double dxown = 0.0;   // (kQuad) this lane's row of dx
       auto rstep = [&](const int t, const RIn &rc, RIn &rn) {
         const int tn = t + 1 < N - 1 ? t + 1 : t;
         load_r(tn, rn);
         PIPELINE_FENCE();
-        d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+        if constexpr (kQuad) d.dX[GI(t, NX, qc)] = dxown; else d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
         if (t < N - 1) {
           double du[NU];
 #pragma unroll
@@ -357,11 +394,16 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 #pragma unroll
           for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
           const double dxq = (a + c) + 0.0;
-          lds_sync();              // every lane has read the old dx row
-          Ls[C::oDx + qc] = dxq;
-          lds_sync();
+          if constexpr (kQuad) {   // rows of dx by quad broadcast: no LDS on this chain
+            dxown = dxq;
+            quad_gather<NX>(dxq, dx);
+          } else {
+            lds_sync();              // every lane has read the old dx row
+            Ls[C::oDx + qc] = dxq;
+            lds_sync();
 #pragma unroll
-          for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+            for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+          }
         }
       };
 #pragma unroll
@@ -403,6 +445,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
   typedef CoopCfg<Model> C;
+  constexpr bool kQuad = false;   // see k_backward_ipddp_coop (measured: no gain)
   __shared__ double lds[C::TPW * C::STRIDE];
   const int lane = threadIdx.x;
   const int q = lane % C::G, tl = lane / C::G;
@@ -512,21 +555,30 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 #pragma unroll
         for (int k = 0; k < NX; ++k) s2 += Bm[k * NU + u] * Vx[k];
         Qu[u] = Qu[u] + s2; }
+      if constexpr (!kQuad) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
+        for (int i = 0; i < NX; ++i) Ls[C::oT1 + i * NX + qc] = T1c[i];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
-      lds_sync();
+        for (int u = 0; u < NU; ++u) Ls[C::oT2 + u * NX + qc] = T2c[u];
+        lds_sync();
+      }
       __builtin_amdgcn_sched_barrier(0);
       load2(tp, n2);
       PIPELINE_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       // ---- round 2
       double T1[NX * NX], T2[NU * NX];
+      if constexpr (kQuad) {   // G = 4: the lanes of a trajectory are a quad -- column j of T1, T2 is lane j's, fetched by DPP broadcasts
 #pragma unroll
-      for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+        for (int i = 0; i < NX; ++i) quad_gather<NX>(T1c[i], T1 + i * NX);
 #pragma unroll
-      for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+        for (int u = 0; u < NU; ++u) quad_gather<NX>(T2c[u], T2 + u * NX);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+      }
       double Qxxc[NX], Quxc[NU], Quu[NU * NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
@@ -616,16 +668,23 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
         }
       }
+      if constexpr (!kQuad) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxc[u]; }
-      lds_sync();
+        for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxc[u]; }
+        lds_sync();
+      }
       st<NU>(d.k + GI(t, NU, 0), kLS, kk);
 #pragma unroll
       for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
       // ---- round 3: value update
       double KK[NU * NX], Qux[NU * NX];
+      if constexpr (kQuad) {
 #pragma unroll
-      for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+        for (int u = 0; u < NU; ++u) { quad_gather<NX>(KKc[u], KK + u * NX); quad_gather<NX>(Quxc[u], Qux + u * NX); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) { KK[i] = Ls[C::oKK + i]; Qux[i] = Ls[C::oQux + i]; }
+      }
       double Quuk[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) { double s1 = 0.0;

@@ -41,9 +41,9 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "lane");
   }
-  static bool coop_sweep_requested() {   // CDDP_HIP_SWEEP=coop: the column-ownership sweep where the element-ownership one is the default
+  static bool elem_sweep_requested() {   // CDDP_HIP_SWEEP=elem: the element-ownership sweep (kernels_elem.hpp), where instantiated
     const char *e = std::getenv("CDDP_HIP_SWEEP");
-    return e && !std::strcmp(e, "coop");
+    return e && !std::strcmp(e, "elem");
   }
   static bool mfma_sweep_requested() {   // CDDP_HIP_SWEEP=mfma | coop (default: see the note at the launch site)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
@@ -107,11 +107,11 @@ struct Launcher {
         }
       }
       else {
-        // nx <= 4, nu <= 2: element-ownership sweep (kernels_elem.hpp: 16 lanes per trajectory, four times the wavefronts of the
-        // column-ownership form, exchanges through the crossbar); CDDP_HIP_SWEEP=coop keeps the column form (bitwise equal)
+        // CDDP_HIP_SWEEP=elem (nx <= 4, nu <= 2): element-ownership sweep (kernels_elem.hpp: 16 lanes per trajectory, four times the
+        // wavefronts of the column-ownership form).  Bitwise equal, measured slower (165 vs 126 us at C2): opt-in.
         bool launched = false;
         if constexpr (Model::NX <= 4 && Model::NU <= 2) {
-          if (!coop_sweep_requested()) {
+          if (elem_sweep_requested()) {
             hipLaunchKernelGGL((k_backward_ipddp_elem<Model, Cons>), dim3(coop_grid<4>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
             launched = true;
           }

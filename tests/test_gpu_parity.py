@@ -364,8 +364,8 @@ ELEM_CASES = ["pendulum_ipddp_box", "cartpole_ipddp_box", "unicycle_ipddp_box", 
 
 @pytest.mark.parametrize("case", ELEM_CASES)
 def test_element_sweep_agrees_bitwise(api, case, monkeypatch):
-    """nx <= 4, nu <= 2 (round 3): the element-ownership sweep (kernels_elem.hpp: lane (i, j) owns V_xx[i][j], crossbar exchanges;
-    the default for these layouts), the column-ownership sweep (CDDP_HIP_SWEEP=coop) and the one-lane-per-trajectory sweep
+    """nx <= 4, nu <= 2 (round 3): the column-ownership sweep (the default; exchanges by quad broadcast), the element-ownership sweep
+    (kernels_elem.hpp: lane (i, j) owns V_xx[i][j]; CDDP_HIP_SWEEP=elem) and the one-lane-per-trajectory sweep
     (CDDP_HIP_SWEEP=lane) give the same bits -- whole solves, every layout with nx in {2, 3, 4}, nu in {1, 2}, with and without
     state-dependent rows; a batch that is not a multiple of the 4 trajectories of a wavefront; gains / value function of the
     first sweep as well."""
@@ -383,7 +383,7 @@ def test_element_sweep_agrees_bitwise(api, case, monkeypatch):
 
     monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
     ref = run()
-    for mode in ("coop", "lane"):
+    for mode in ("elem", "lane"):
         monkeypatch.setenv("CDDP_HIP_SWEEP", mode)
         got = run()
         for a, g in zip(ref, got):

@@ -109,13 +109,14 @@ def test_state_stationarity_pin_on_device(api, oracle_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["pendulum_ipddp_box_state_stationarity", "cartpole_ipddp_box_state_stationarity"])
+@pytest.mark.parametrize("case", ["pendulum_ipddp_box_state_stationarity", "unicycle_ipddp_box_state"])
 def test_state_stationarity_changes_the_solve(api, oracle_built, case):
     """On problems with state-dependent rows the option must change the solver's decisions (mu sequence or iteration count),
     i.e. the device evaluates max |G_x^T y| -- and the result is the oracle's (parity build on both sides: strict).
-    (On the scalar path_term_ineq problem the extra term never exceeds inf_du: same solve with and without -- its parity is
-    covered by tests/test_gpu_parity.py and the twin fixture.)"""
-    pv = make(api, case)
+    (On the scalar path_term_ineq problem and on the cart-pole with its wide state box the extra term never exceeds inf_du -- the
+    oracle's solves are identical with and without, too; their parity is covered by tests/test_gpu_parity.py and the twin
+    fixtures.)"""
+    pv = make(api, case); pv.options.ipddp_check_state_stationarity = 1
     pa = make(api, case); pa.options.ipddp_check_state_stationarity = 0
     B = 4
     sp = spread_for(pv) if pv.nx > 1 else 0.05 * np.ones(1)
