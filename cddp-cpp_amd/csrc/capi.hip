@@ -35,6 +35,9 @@ static __global__ void k_mark_cpu_time(DevBuf d) {
 
 }  // namespace cddp_dev
 
+int cddp_host_model_eval(int model, int integrator, double dt, const double *params, int nx, int nu, const double *x, const double *u, double *x_next,
+                         double *fx, double *fu, double *fxx, double *fuu, double *fux, std::string &err);   // host_models.cpp
+
 namespace {
 
 thread_local std::string g_err;
@@ -255,6 +258,14 @@ void cddp_hip_default_options(cddp_hip_options *o) {
 }
 
 int cddp_hip_abi_version(void) { return CDDP_HIP_ABI_VERSION; }
+
+int cddp_hip_model_eval(int model, int integrator, double dt, const double *model_params, int nx, int nu, const double *x, const double *u,
+                        double *x_next, double *fx, double *fu, double *fxx, double *fuu, double *fux) {
+  if (!model_params || !x || !u) return fail(-2, "cddp_hip_model_eval: null argument");
+  std::string err;
+  const int rc = cddp_host_model_eval(model, integrator, dt, model_params, nx, nu, x, u, x_next, fx, fu, fxx, fuu, fux, err);
+  return rc == 0 ? 0 : fail(rc, "cddp_hip_model_eval: %s", err.c_str());
+}
 const char *cddp_hip_last_error(void) { return g_err.c_str(); }
 
 int cddp_hip_device_count(void) {

@@ -12,10 +12,13 @@
 // on it (Eigen 3.4.0 LDLT with diagonal pivoting, PartialPivLU inverse) -- see the call sites
 // cited at each routine.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <cfloat>
-
+#ifndef CDDP_HOST_MODELS   // host_models.cpp compiles the plants (dev_models.hpp) for the host with DEV = inline
+#include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
+#else
+#include <cmath>
+#endif
 
 namespace cddp_dev {
 
@@ -27,6 +30,7 @@ DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN
 // through the CONSTANT address space so the compiler emits scalar (SMEM) loads.  A generic-pointer load becomes a
 // flat/global VECTOR load, which sits on the in-order vmcnt queue in front of the software-pipelined prefetch and
 // forces it to drain every step (measured: +270 us per K4 launch at C2).
+#ifndef CDDP_HOST_MODELS
 typedef const double __attribute__((address_space(4))) *cptr_t;
 DEV cptr_t uniform_ptr(const double *p) {
   unsigned long long v = (unsigned long long)p;
@@ -34,6 +38,7 @@ DEV cptr_t uniform_ptr(const double *p) {
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (cptr_t)(((unsigned long long)hi << 32) | lo);
 }
+#endif
 // a*b + c with two roundings (no FMA contraction).  Used where an accept/reject decision sits exactly on a
 // rounding knife-edge: the fraction-to-boundary rule caps alpha at -tau*s/ds, so the trial slack
 // s + alpha*ds lands ON the bound (1-tau)*s and `s_new < (1-tau)*s` is decided by the last bit.  The

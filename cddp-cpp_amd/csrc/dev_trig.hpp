@@ -201,6 +201,16 @@ DEV void plant_sincos(double a, double *s, double *c) { sincos(a, s, c); }
 DEV double plant_sin(double a) { return sin(a); }
 DEV double plant_cos(double a) { return cos(a); }
 #endif
+#elif defined(CDDP_HOST_MODELS)   // host_models.cpp: the plants compiled for the host (the host libm, or the shared routine)
+#ifdef CDDP_TRIG_SHARED
+DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
+DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
+DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
+#else
+DEV void plant_sincos(double a, double *s, double *c) { *s = std::sin(a); *c = std::cos(a); }
+DEV double plant_sin(double a) { return std::sin(a); }
+DEV double plant_cos(double a) { return std::cos(a); }
+#endif
 #endif
 
 }  // namespace cddp_dev

@@ -1,0 +1,578 @@
+// cddp_hip_plugin_solve: CDDP::solve() for HOST plug-ins -- arbitrary DynamicalSystem / Objective / Constraint subclasses
+// that cannot run on the GPU (the north_star's "keeps the DynamicsModel / Constraint / Objective plugin surface").
+//
+// Division of labour (SURVEY.md 7 hard parts (ii) / (iii)): the caller's plug-ins are evaluated on
+// the host through the callbacks of cddp_hip_plugin; the (N x batch) derivative stacks of every iterate go to the GPU, which
+// runs the backward pass of the whole batch in one launch (stack-fed sweeps, stacks.hip); the line-searched forward pass needs
+// the plug-in's f(x, u) at every step of every trial and therefore runs on the host, as does the outer loop.  The host side
+// below restates, per trajectory, exactly what the device-resident state machine of the built-in plants does:
+//
+//   outer loop, regularisation schedule, line search        cddp_solver_base.cpp:29-186, 248-317; cddp_core.cpp:308-346
+//   IPDDP  initialize / forwardPass / applyForwardPassResult / updateBarrierParameters / filter / convergence
+//                                                           ipddp_solver.cpp:819-913, 925-958, 1571-1876, 1878-2082, 2428-2519,
+//                                                           2548-2660, 2778-2937; interior_point_utils.cpp:79-139
+//   CLDDP  initialize / forwardPass / convergence           clddp_solver.cpp:28-75, 206-277
+//
+// (kernels.hpp holds the same logic as device code: k_init, k_forward_ipddp, k_forward_clddp, k_update.)  Not supported here:
+// terminal constraints (the stack-fed sweeps have no terminal-constraint branch), warm starts.
+// This file uses only the public C-ABI of include/cddp_hip.h for the GPU part.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/cddp_hip.h"
+
+extern "C" int cddp_hip_internal_set_error(int code, const char *msg);   // capi.hip (thread-local last-error string)
+
+namespace {
+
+int pfail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  return cddp_hip_internal_set_error(code, buf);
+}
+
+constexpr double kEpsSlack = 1e-10, kSlackOffset = 1e-4, kMaxRatio = 1e6;   // ipddp_solver.cpp:35-38
+const double kInf = std::numeric_limits<double>::infinity();
+inline bool fin(double v) { return std::fabs(v) <= std::numeric_limits<double>::max(); }
+inline double clampd(double v, double lo, double hi) { return std::min(std::max(v, lo), hi); }
+
+struct Trial {   // ForwardPassResult (cddp_core.hpp:105-145)
+  bool success = false;
+  double alpha_pr = 1.0, alpha_du = 1.0, cost = 0, merit = 0, theta = 0, inf_pr = 0, inf_comp = 0;
+  std::vector<double> X, U, S, Y, G, Lam;
+};
+
+struct Traj {
+  std::vector<double> X, U, S, Y, G, Lam;
+  double cost = 0, merit = 0, inf_pr = 0, inf_du = 0, inf_comp = 0, step_norm = 0, alpha_pr = 1.0, alpha_du = 1.0, reg = 0, mu = 0;
+  double dV0 = 0, dV1 = 0, phi = 0, theta = 0, filter_theta = 0, apr_max = 1.0, adu_max = 1.0;
+  std::vector<std::pair<double, double>> filter;   // (merit, violation)
+  int iter = 0, status = CDDP_HIP_STATUS_RUNNING, n_bwd = 0, n_fwd = 0;
+  bool done = false;
+};
+
+struct Ctx {
+  const cddp_hip_plugin *pl;
+  const cddp_hip_options *o;
+  int solver, nx, nu, m, N;
+  double dt;
+  std::vector<double> alphas;
+  bool ipddp() const { return solver == CDDP_HIP_SOLVER_IPDDP; }
+};
+
+// regularisation schedule (cddp_core.cpp:308-346); from exactly 0 the step restarts at reg_min_value (kernels.hpp::reg_increase)
+double reg_increase(const cddp_hip_options &o, double r) {
+  r *= o.reg_update_factor;
+  if (!(r > 0.0)) r = (o.reg_min_value > 0.0) ? o.reg_min_value : o.reg_max_value;
+  return std::min(r, o.reg_max_value);
+}
+double reg_decrease(const cddp_hip_options &o, double r) { r /= o.reg_update_factor; return std::max(r, o.reg_min_value); }
+
+// computeTheta / computeBarrierMerit / computePrimalAndComplementarity, constraint-major then t (ipddp_solver.cpp:2778-2937)
+void ip_reductions(const Ctx &c, const double *S, const double *Y, const double *G, double mu, double cost0,
+                   double &phi, double &theta, double &inf_pr, double &inf_comp) {
+  const int m = c.m, N = c.N;
+  const bool l2 = c.o->ipddp_theta_norm_l2 != 0;
+  double total = 0.0, max_entry = 0.0, ipr = 0.0, icomp = 0.0, mer = cost0;
+  int off = 0;
+  for (int s = 0; s < c.pl->n_constraints; ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < N; ++t) {
+      double n1 = 0.0, ninf = 0.0;
+      for (int i = 0; i < dim; ++i) {
+        const size_t j = (size_t)t * m + off + i;
+        const double r = G[j] + S[j];
+        n1 += l2 ? r * r : std::fabs(r);
+        ninf = std::max(ninf, std::fabs(r));
+        icomp = std::max(icomp, std::fabs(Y[j] * S[j] - mu));
+      }
+      total += n1; max_entry = std::max(max_entry, ninf); ipr = std::max(ipr, ninf);
+    }
+    off += dim;
+  }
+  off = 0;
+  for (int s = 0; s < c.pl->n_constraints; ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < N; ++t) {
+      double ls = 0.0;
+      for (int i = 0; i < dim; ++i) ls += std::log(std::max(S[(size_t)t * m + off + i], kEpsSlack));
+      mer -= mu * ls;
+    }
+    off += dim;
+  }
+  const double th = l2 ? std::sqrt(total) : total;
+  theta = std::max(th, max_entry);
+  phi = mer; inf_pr = ipr; inf_comp = icomp;
+}
+
+// filter helpers (interior_point_utils.cpp:79-139)
+void filter_accept(std::vector<std::pair<double, double>> &f, double mf, double cv) {
+  for (auto &p : f) if (p.first <= mf && p.second <= cv) return;   // dominated by an existing point
+  std::vector<std::pair<double, double>> keep;
+  for (auto &p : f) if (!(mf <= p.first && cv <= p.second)) keep.push_back(p);
+  keep.emplace_back(mf, cv);
+  f.swap(keep);
+}
+void filter_prune(std::vector<std::pair<double, double>> &f) {
+  if (f.empty()) return;
+  auto bv = f[0], bm = f[0];
+  for (size_t i = 1; i < f.size(); ++i) { if (f[i].second < bv.second) bv = f[i]; if (f[i].first < bm.first) bm = f[i]; }
+  std::vector<std::pair<double, double>> out{bv};
+  if (std::fabs(bm.second - bv.second) > 1e-12 || std::fabs(bm.first - bv.first) > 1e-12) out.push_back(bm);
+  f.swap(out);
+}
+
+double total_cost(const Ctx &c, const double *X, const double *U) {   // CDDPSolverBase::computeCost (:416-424)
+  double J = 0.0;
+  for (int t = 0; t < c.N; ++t) J += c.pl->running_cost(c.pl->user, X + (size_t)t * c.nx, U + (size_t)t * c.nu, t);
+  J += c.pl->terminal_cost(c.pl->user, X + (size_t)c.N * c.nx);
+  return J;
+}
+
+// ---- ISolverAlgorithm::initialize ------------------------------------------------------------------------------------
+void initialize(const Ctx &c, Traj &T, const double *x0, const double *U0, const double *X0) {
+  const int nx = c.nx, nu = c.nu, N = c.N, m = c.m;
+  const cddp_hip_options &o = *c.o;
+  T.X.assign((size_t)(N + 1) * nx, 0.0); T.U.assign((size_t)N * nu, 0.0);
+  if (U0) std::copy(U0, U0 + (size_t)N * nu, T.U.begin());
+  if (X0) std::copy(X0, X0 + (size_t)(N + 1) * nx, T.X.begin());
+  else for (int t = 0; t <= N; ++t) std::copy(x0, x0 + nx, T.X.begin() + (size_t)t * nx);
+  std::copy(x0, x0 + nx, T.X.begin());   // X_[0] = initial_state (cddp_core.cpp:294)
+  T.reg = o.reg_initial_value; T.iter = 0; T.status = CDDP_HIP_STATUS_RUNNING; T.done = false; T.n_bwd = T.n_fwd = 0;
+  T.dV0 = T.dV1 = 0.0; T.step_norm = 0.0; T.filter.clear();
+  if (!c.ipddp()) {   // clddp_solver.cpp:62-74: cost of the GIVEN (X, U)
+    T.cost = total_cost(c, T.X.data(), T.U.data()); T.merit = T.cost;
+    T.inf_pr = T.inf_du = T.inf_comp = kInf; T.alpha_pr = o.ls_initial_step_size; T.alpha_du = 0.0; T.mu = 0.0;
+    return;
+  }
+  // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, slack / dual initialisation, cost, filter reset
+  T.mu = (m == 0) ? std::max(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
+  T.alpha_pr = T.alpha_du = 1.0;
+  T.S.assign((size_t)N * m, 0.0); T.Y = T.S; T.G = T.S; T.Lam.assign((size_t)(N + 1) * nx, 0.0);
+  double cost = 0.0;
+  std::vector<double> xn(nx);
+  for (int t = 0; t < N; ++t) {
+    double *x = T.X.data() + (size_t)t * nx, *u = T.U.data() + (size_t)t * nu;
+    cost += c.pl->running_cost(c.pl->user, x, u, t);
+    if (m > 0) {
+      double *g = T.G.data() + (size_t)t * m, *s = T.S.data() + (size_t)t * m, *y = T.Y.data() + (size_t)t * m;
+      c.pl->constraints(c.pl->user, x, u, t, g, nullptr, nullptr);
+      for (int i = 0; i < m; ++i) {   // initializeDualSlackVariables (:2456-2468)
+        s[i] = std::max(o.ipddp_slack_var_init_scale, -g[i] + kSlackOffset);
+        y[i] = (T.mu * o.ipddp_dual_var_init_scale) / std::max(s[i], kEpsSlack);
+      }
+    }
+    c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, xn.data());
+    std::copy(xn.begin(), xn.end(), T.X.begin() + (size_t)(t + 1) * nx);
+  }
+  cost += c.pl->terminal_cost(c.pl->user, T.X.data() + (size_t)N * nx);
+  T.cost = cost;
+  double phi = cost, theta = 0.0, ipr = 0.0, icomp = 0.0;   // resetFilter (:2484-2519)
+  if (m > 0) ip_reductions(c, T.S.data(), T.Y.data(), T.G.data(), T.mu, cost, phi, theta, ipr, icomp);
+  T.merit = T.phi = phi; T.inf_pr = ipr; T.inf_comp = icomp; T.inf_du = 0.0;
+  T.filter_theta = std::max(theta, 1e-8);
+  T.theta = std::max(T.filter_theta, std::max(o.ipddp_theta_0_floor, 1e-8));
+}
+
+// ---- forwardPass ------------------------------------------------------------------------------------------------------
+struct Gains {   // results of the GPU sweep for one trajectory (batch-major slices)
+  const double *K, *k, *Vx, *Vxx, *ky, *Ky, *ks, *Ks;
+};
+
+Trial forward_clddp(const Ctx &c, const Traj &T, const Gains &g, double alpha) {   // clddp_solver.cpp:215-262
+  const int nx = c.nx, nu = c.nu, N = c.N;
+  Trial r; r.alpha_pr = alpha; r.alpha_du = 1.0;
+  r.X.assign(T.X.size(), 0.0); r.U.assign(T.U.size(), 0.0);
+  std::copy(T.X.begin(), T.X.begin() + nx, r.X.begin());
+  std::vector<double> dx(nx);
+  double J = 0.0;
+  for (int t = 0; t < N; ++t) {
+    const double *x = r.X.data() + (size_t)t * nx, *xo = T.X.data() + (size_t)t * nx, *uo = T.U.data() + (size_t)t * nu;
+    double *u = r.U.data() + (size_t)t * nu;
+    for (int i = 0; i < nx; ++i) dx[i] = x[i] - xo[i];
+    for (int i = 0; i < nu; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < nx; ++j) s += g.K[((size_t)t * nu + i) * nx + j] * dx[j];
+      u[i] = (uo[i] + alpha * g.k[(size_t)t * nu + i]) + s;
+      if (c.pl->control_lower && c.pl->control_upper) u[i] = std::min(std::max(u[i], c.pl->control_lower[i]), c.pl->control_upper[i]);
+    }
+    J += c.pl->running_cost(c.pl->user, x, u, t);
+    c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, r.X.data() + (size_t)(t + 1) * nx);
+  }
+  J += c.pl->terminal_cost(c.pl->user, r.X.data() + (size_t)N * nx);
+  const double dJ = T.cost - J;
+  const double expected = -alpha * (T.dV0 + 0.5 * alpha * T.dV1);
+  const double ratio = expected > 0.0 ? dJ / expected : std::copysign(1.0, dJ);
+  r.cost = r.merit = J;
+  r.success = ratio > c.o->filter_armijo_constant;
+  return r;
+}
+
+Trial forward_ipddp(const Ctx &c, const Traj &T, const Gains &g, double alpha) {   // ipddp_solver.cpp:1571-1876
+  const int nx = c.nx, nu = c.nu, N = c.N, m = c.m;
+  const cddp_hip_options &o = *c.o;
+  Trial r;
+  const double mu = T.mu;
+  const double tau = (m == 0) ? 1.0 : std::max(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const double a_pr = std::min(alpha, T.apr_max), a_du = std::min(alpha, T.adu_max);
+  r.alpha_pr = a_pr; r.alpha_du = a_du;
+  r.cost = T.cost; r.merit = T.phi; r.theta = T.theta;   // diagnostics of a failed trial (ForwardPassResult defaults)
+  r.X.assign(T.X.size(), 0.0); r.U.assign(T.U.size(), 0.0); r.Lam.assign(T.Lam.size(), 0.0);
+  r.S.assign(T.S.size(), 0.0); r.Y = r.S; r.G = r.S;
+  std::copy(T.X.begin(), T.X.begin() + nx, r.X.begin());
+  std::vector<double> dx(nx);
+  double cost_new = 0.0;
+  for (int t = 0; t <= N; ++t) {
+    const double *x = r.X.data() + (size_t)t * nx, *xo = T.X.data() + (size_t)t * nx;
+    for (int i = 0; i < nx; ++i) dx[i] = x[i] - xo[i];
+    // costate trial: Lambda' = Lambda + alpha_pr V_x + V_xx dx (:1613-1616, 1660-1663); a non-finite entry fails the trial
+    for (int i = 0; i < nx; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < nx; ++j) s += g.Vxx[((size_t)t * nx + i) * nx + j] * dx[j];
+      const double lam = (T.Lam[(size_t)t * nx + i] + a_pr * g.Vx[(size_t)t * nx + i]) + s;
+      if (!fin(lam)) return r;
+      r.Lam[(size_t)t * nx + i] = lam;
+    }
+    if (t == N) break;
+    if (m > 0) {   // slack / dual trial + fraction-to-boundary test (:1629-1658)
+      for (int q = 0; q < m; ++q) {
+        const size_t j = (size_t)t * m + q;
+        double ps = 0.0, py = 0.0;
+        for (int i = 0; i < nx; ++i) { ps = ps + g.Ks[j * nx + i] * dx[i]; py = py + g.Ky[j * nx + i] * dx[i]; }
+        const double sn = (T.S[j] + a_pr * g.ks[j]) + ps;
+        const double yn = (T.Y[j] + a_du * g.ky[j]) + py;
+        if (sn < (1.0 - tau) * T.S[j] || yn < (1.0 - tau) * T.Y[j]) return r;
+        if (!fin(sn) || !fin(yn)) return r;
+        r.S[j] = sn; r.Y[j] = yn;
+      }
+    }
+    const double *uo = T.U.data() + (size_t)t * nu;
+    double *u = r.U.data() + (size_t)t * nu;
+    for (int i = 0; i < nu; ++i) {   // no clamping (:1618-1622)
+      double s = 0.0;
+      for (int j = 0; j < nx; ++j) s += g.K[((size_t)t * nu + i) * nx + j] * dx[j];
+      u[i] = (uo[i] + a_pr * g.k[(size_t)t * nu + i]) + s;
+      if (!fin(u[i])) return r;
+    }
+    double *xn = r.X.data() + (size_t)(t + 1) * nx;
+    c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, xn);
+    for (int i = 0; i < nx; ++i) if (!fin(xn[i])) return r;
+    cost_new += c.pl->running_cost(c.pl->user, x, u, t);
+    if (m > 0) c.pl->constraints(c.pl->user, x, u, t, r.G.data() + (size_t)t * m, nullptr, nullptr);
+  }
+  cost_new += c.pl->terminal_cost(c.pl->user, r.X.data() + (size_t)N * nx);
+  double phi_new = cost_new, theta_new = 0.0, ipr = 0.0, icomp = 0.0;
+  if (m > 0) ip_reductions(c, r.S.data(), r.Y.data(), r.G.data(), mu, cost_new, phi_new, theta_new, ipr, icomp);
+  if (!fin(phi_new) || !fin(theta_new) || !fin(ipr) || !fin(icomp)) return r;
+  bool accept = false;
+  if (m == 0) {   // :1785-1792
+    const double dJ = T.cost - cost_new;
+    const double expected = -a_pr * (T.dV0 + 0.5 * a_pr * T.dV1);
+    const double ratio = expected > 0.0 ? dJ / expected : std::copysign(1.0, dJ);
+    accept = ratio > 1e-6;
+  } else {        // :1793-1834
+    const double expected_improvement = a_pr * T.dV0;
+    const bool fe = T.filter.empty();
+    const double cv_old = fe ? 0.0 : T.filter.back().second;
+    const double high_ref = fe ? T.filter_theta : cv_old;
+    const double merit_old = T.merit;
+    if (theta_new > o.filter_max_violation_threshold) {
+      if (theta_new < (1 - o.filter_violation_acceptance_threshold) * high_ref) accept = true;
+    } else if (std::max(theta_new, cv_old) < o.filter_min_violation_for_armijo_check && expected_improvement < 0) {
+      if (phi_new < merit_old + o.filter_armijo_constant * expected_improvement) accept = true;
+    } else {
+      if (phi_new < merit_old - o.filter_merit_acceptance_threshold * theta_new ||
+          theta_new < (1 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    }
+  }
+  r.cost = cost_new; r.merit = phi_new; r.theta = theta_new; r.inf_pr = ipr; r.inf_comp = icomp;
+  r.success = accept;
+  return r;
+}
+
+// computeScaledDualInfeasibility (ipddp_solver.cpp:2725-2776): G_x of the last backward pass (kept per trajectory), Y current
+double scaled_inf_du(const Ctx &c, const Traj &T, const std::vector<double> &Gx) {
+  double v = T.inf_du;
+  if (!c.o->ipddp_check_state_stationarity || c.m == 0) return v;
+  double ss = 0.0;
+  int off = 0;
+  for (int s = 0; s < c.pl->n_constraints; ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < c.N; ++t)
+      for (int j = 0; j < c.nx; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < dim; ++i) a += Gx[((size_t)t * c.m + off + i) * c.nx + j] * T.Y[(size_t)t * c.m + off + i];
+        ss = std::max(ss, std::fabs(a));
+      }
+    off += dim;
+  }
+  return std::max(v, ss);
+}
+
+}  // namespace
+
+extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int horizon, double dt, const cddp_hip_options *opt,
+                                     int device, int batch, const double *x0, const double *U0, const double *X0,
+                                     cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
+  if (!pl || !opt || !x0 || !results) return pfail(-1, "null argument");
+  if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP) return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
+  if (!pl->discrete_dynamics || !pl->jacobians) return pfail(-2, "Dynamical system must be set before solving.");
+  if (!pl->running_cost || !pl->terminal_cost || !pl->running_cost_derivatives || !pl->terminal_cost_derivatives)
+    return pfail(-2, "Objective function must be set before solving.");
+  const int nx = pl->nx, nu = pl->nu, N = horizon;
+  int m = 0;
+  if (pl->n_constraints < 0 || pl->n_constraints > CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) return pfail(-3, "too many path constraints (%d)", pl->n_constraints);
+  for (int s = 0; s < pl->n_constraints; ++s) m += pl->constraint_dims[s];
+  if (solver == CDDP_HIP_SOLVER_CLDDP) m = 0;   // CLDDP only honours the box named "ControlConstraint" (control_lower / control_upper)
+  if (m > 0 && !pl->constraints) return pfail(-2, "Cannot add null constraint.");
+  if (nx <= 0 || nu <= 0 || N <= 0 || batch <= 0 || !(dt > 0)) return pfail(-2, "bad dimensions nx=%d nu=%d N=%d batch=%d dt=%g", nx, nu, N, batch, dt);
+  if (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0)) return pfail(-2, "regularization.update_factor must be > 1 and max_value > 0");
+  if (!opt->use_ilqr && !pl->hessians) return pfail(-3, "use_ilqr=false needs the plug-in's Hessian callback");
+
+  Ctx c; c.pl = pl; c.o = opt; c.solver = solver; c.nx = nx; c.nu = nu; c.m = m; c.N = N; c.dt = dt;
+  { double al[CDDP_HIP_MAX_ALPHAS]; const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS); c.alphas.assign(al, al + na); }
+  const cddp_hip_options &o = *opt;
+
+  cddp_hip_stack_handle *sh = nullptr;
+  { int rc = cddp_hip_stacks_create(device, batch, nx, nu, m, N, &sh); if (rc) return rc; }
+  struct Guard { cddp_hip_stack_handle *h; ~Guard() { if (h) cddp_hip_stacks_destroy(h); } } guard{sh};
+
+  const size_t B = (size_t)batch;
+  std::vector<Traj> T(B);
+  for (size_t b = 0; b < B; ++b)
+    initialize(c, T[b], x0 + b * nx, U0 ? U0 + b * N * nu : nullptr, X0 ? X0 + b * (N + 1) * nx : nullptr);
+
+  // batch-major host stacks of the current iterates
+  std::vector<double> fx(B * N * nx * nx), fu(B * N * nx * nu), lx(B * N * nx), lu(B * N * nu), lxx(B * N * nx * nx), luu(B * N * nu * nu),
+      lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx), Ubuf(B * N * nu);
+  std::vector<double> gy, gs, gg, gGx, gGu, Fxx, Fuu, Fux;
+  if (m > 0) { gy.resize(B * N * m); gs = gy; gg = gy; gGx.resize(B * N * m * nx); gGu.resize(B * N * m * nu); }
+  if (!o.use_ilqr) { Fxx.resize(B * N * nx * nx * nx); Fuu.resize(B * N * nx * nu * nu); Fux.resize(B * N * nx * nu * nx); }
+  std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  std::vector<double> kyb, Kyb, ksb, Ksb, dXb;
+  if (m > 0) { kyb.resize(B * N * m); ksb = kyb; Kyb.resize(B * N * m * nx); Ksb = Kyb; dXb.resize(B * (N + 1) * nx); }
+  std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
+  std::vector<int32_t> okv(B);
+  std::vector<double> tfx(nx * nx), tfu(nx * nu);
+  const bool first_rule = !o.enable_parallel;
+  const auto wall0 = std::chrono::steady_clock::now();
+
+  for (int it = 1; it <= o.max_iterations; ++it) {
+    bool any = false;
+    for (auto &t : T) any = any || !t.done;
+    if (!any) break;
+    if (o.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (whole elapsed milliseconds)
+      const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
+      if (el_ms > o.max_cpu_time * 1000.0) {
+        for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; }
+        break;
+      }
+    }
+    // ---- precomputeDynamicsDerivatives / precomputeConstraintGradients on the host (cddp_solver_base.cpp:319-394,
+    //      ipddp_solver.cpp:2145-2250), cost derivatives (objective.hpp): the stacks of every running trajectory
+    for (size_t b = 0; b < B; ++b) {
+      Traj &t = T[b];
+      regv[b] = t.done ? std::max(t.reg, o.reg_min_value) : t.reg;
+      muv[b] = (t.mu > 0.0) ? t.mu : 1.0;
+      if (t.done) continue;
+      t.iter += 1;
+      for (int s = 0; s < N; ++s) {
+        const double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+        const size_t bs = b * N + s;
+        pl->jacobians(pl->user, x, u, s * dt, tfx.data(), tfu.data());
+        for (int i = 0; i < nx; ++i)
+          for (int j = 0; j < nx; ++j) { double a = dt * tfx[i * nx + j]; if (i == j) a += 1.0; fx[(bs * nx + i) * nx + j] = a; }   // A = I + dt f_x
+        for (int i = 0; i < nx * nu; ++i) fu[bs * nx * nu + i] = dt * tfu[i];                                                      // B = dt f_u
+        pl->running_cost_derivatives(pl->user, x, u, s, lx.data() + bs * nx, lu.data() + bs * nu, lxx.data() + bs * nx * nx,
+                                     luu.data() + bs * nu * nu, lux.data() + bs * nu * nx);
+        if (m > 0) {
+          pl->constraints(pl->user, x, u, s, gg.data() + bs * m, gGx.data() + bs * m * nx, gGu.data() + bs * m * nu);
+          // (g itself is the iterate's residual evaluated by the last accepted rollout; Jacobians are what is needed here)
+          std::copy(t.G.begin() + (size_t)s * m, t.G.begin() + (size_t)(s + 1) * m, gg.begin() + bs * m);
+          std::copy(t.S.begin() + (size_t)s * m, t.S.begin() + (size_t)(s + 1) * m, gs.begin() + bs * m);
+          std::copy(t.Y.begin() + (size_t)s * m, t.Y.begin() + (size_t)(s + 1) * m, gy.begin() + bs * m);
+        }
+        if (!o.use_ilqr) {
+          double *pxx = Fxx.data() + bs * nx * nx * nx, *puu = Fuu.data() + bs * nx * nu * nu, *pux = Fux.data() + bs * nx * nu * nx;
+          pl->hessians(pl->user, x, u, s * dt, pxx, puu, pux);
+          for (int e = 0; e < nx * nx * nx; ++e) pxx[e] = dt * pxx[e];   // F_xx_[t][i] = dt f_xx[i] (cddp_solver_base.cpp:346-356)
+          for (int e = 0; e < nx * nu * nu; ++e) puu[e] = dt * puu[e];
+          for (int e = 0; e < nx * nu * nx; ++e) pux[e] = dt * pux[e];
+        }
+      }
+      pl->terminal_cost_derivatives(pl->user, t.X.data() + (size_t)N * nx, VxN.data() + b * nx, VxxN.data() + b * nx * nx);
+      std::copy(t.U.begin(), t.U.end(), Ubuf.begin() + b * N * nu);
+    }
+    { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
+    if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, gy.data(), gs.data(), gg.data(), gGx.data(), gGu.data()); if (rc) return rc; }
+    if (!o.use_ilqr && c.ipddp()) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
+    if (!c.ipddp() && pl->control_lower && pl->control_upper) {
+      int rc = cddp_hip_set_control_box(sh, pl->control_lower, pl->control_upper, Ubuf.data()); if (rc) return rc;
+    }
+    // ---- backwardPass of the whole batch on the GPU, incl. the "increase regularisation and retry" loop (:93-111)
+    const int branch = !c.ipddp() ? CDDP_HIP_STACKS_CLDDP : (m > 0 ? CDDP_HIP_STACKS_IPDDP_PATH : CDDP_HIP_STACKS_IPDDP);
+    { int rc = cddp_hip_stacks_backward(sh, branch, opt, regv.data(), m > 0 ? muv.data() : nullptr, 1, okv.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
+
+    for (size_t b = 0; b < B; ++b) {
+      Traj &t = T[b];
+      if (t.done) continue;
+      // sweeps the retry loop ran: replay the schedule from the regularisation it started with
+      { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
+        if (!okv[b] && nb > 1) --nb;   // the loop stops when the schedule reaches reg_max: no sweep is run there
+        t.n_bwd += nb; }
+      t.reg = s_reg[b];
+      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; continue; }   // handleBackwardPassRegularizationLimit
+      t.dV0 = dVb[b * 2]; t.dV1 = dVb[b * 2 + 1]; t.inf_du = s_du[b];
+      Gains g;
+      g.K = Kb.data() + b * N * nu * nx; g.k = kb.data() + b * N * nu; g.Vx = Vxb.data() + b * (N + 1) * nx; g.Vxx = Vxxb.data() + b * (N + 1) * nx * nx;
+      g.ky = g.Ky = g.ks = g.Ks = nullptr;
+      std::vector<double> Gx_t;
+      if (c.ipddp()) {
+        t.step_norm = s_sn[b];
+        t.inf_pr = (m > 0) ? s_pr[b] : 0.0; t.inf_comp = (m > 0) ? s_comp[b] : 0.0;
+        t.apr_max = (m > 0) ? s_apr[b] : 1.0; t.adu_max = (m > 0) ? s_adu[b] : 1.0;
+        if (m > 0) {
+          g.ky = kyb.data() + b * N * m; g.ks = ksb.data() + b * N * m; g.Ky = Kyb.data() + b * N * m * nx; g.Ks = Ksb.data() + b * N * m * nx;
+          Gx_t.assign(gGx.begin() + b * N * m * nx, gGx.begin() + (b + 1) * N * m * nx);
+        }
+      }
+      // ---- checkEarlyConvergence (clddp_solver.cpp:206-213 / ipddp_solver.cpp:925-958)
+      bool conv = false;
+      if (!c.ipddp()) conv = t.inf_du < o.tolerance;
+      else {
+        const double sdu = scaled_inf_du(c, t, Gx_t);
+        if (m == 0) conv = (t.inf_pr < o.tolerance && sdu < o.tolerance);
+        else {
+          const double tol = std::max(o.tolerance, o.ipddp_barrier_tol_mult * t.mu);
+          conv = (t.inf_pr < tol && sdu < tol && t.inf_comp < tol && std::fabs(t.alpha_pr) * t.step_norm < o.tolerance * 10.0);
+        }
+      }
+      if (conv) { t.status = CDDP_HIP_STATUS_OPTIMAL; t.done = true; continue; }
+      // ---- performForwardPass (cddp_solver_base.cpp:248-317): first success, or lowest merit among the successes
+      Trial best; bool have = false;
+      int walked = 0;
+      for (double a : c.alphas) {
+        Trial r = c.ipddp() ? forward_ipddp(c, t, g, a) : forward_clddp(c, t, g, a);
+        ++walked;
+        if (!r.success) continue;
+        if (first_rule) { best = std::move(r); have = true; break; }
+        if (!have || r.merit < best.merit) { best = std::move(r); have = true; }
+      }
+      t.n_fwd += first_rule ? walked : (int)c.alphas.size();
+      if (have) {
+        // ---- applyForwardPassResult (cddp_solver_base.cpp:190-198, ipddp_solver.cpp:1878-1951)
+        const double dJ = t.cost - best.cost;
+        t.X.swap(best.X); t.U.swap(best.U);
+        t.cost = best.cost; t.merit = best.merit; t.alpha_pr = best.alpha_pr; t.alpha_du = c.ipddp() ? best.alpha_du : 1.0;
+        int st = CDDP_HIP_STATUS_RUNNING; bool done = false;
+        if (c.ipddp()) {
+          t.Lam.swap(best.Lam);
+          if (m > 0) { t.S.swap(best.S); t.Y.swap(best.Y); t.G.swap(best.G); }
+          t.inf_pr = best.inf_pr; t.inf_comp = best.inf_comp; t.phi = best.merit; t.filter_theta = best.theta; t.theta = best.theta;
+          // ---- updateBarrierParameters(true) (ipddp_solver.cpp:2548-2660)
+          const double sdu = scaled_inf_du(c, t, Gx_t);
+          double mu = t.mu; const double mu_old = mu;
+          if (m > 0) {
+            if (o.barrier_strategy == CDDP_HIP_BARRIER_ADAPTIVE) {
+              const double kkt = std::max(std::max(t.inf_pr, sdu), t.inf_comp);
+              const double threshold = std::max(o.barrier_mu_update_factor * mu, 2.0 * mu);
+              if (kkt <= threshold) {
+                double factor = o.barrier_mu_update_factor;
+                if (mu > 1e-20) {
+                  const double ratio = kkt / std::max(mu, 1e-20);
+                  if (ratio < 0.01) factor = 0.1 * o.barrier_mu_update_factor;
+                  else if (ratio < 0.1) factor = 0.3 * o.barrier_mu_update_factor;
+                  else if (ratio < 0.5) factor = 0.6 * o.barrier_mu_update_factor;
+                }
+                const double linear = factor * mu, superlinear = std::pow(mu, o.barrier_mu_update_power);
+                mu = std::max(std::min(linear, superlinear), std::max(o.barrier_mu_min_value, o.tolerance / 100.0));
+              }
+            } else {
+              const double kkt = std::max(std::max(t.inf_pr, sdu * o.ipddp_barrier_update_dual_weight), t.inf_comp);
+              if (kkt <= o.ipddp_mu_kappa_epsilon * mu) {
+                const double linear = o.barrier_mu_update_factor * mu, superlinear = std::pow(mu, o.barrier_mu_update_power);
+                mu = std::max(o.barrier_mu_min_value, std::min(linear, superlinear));
+              }
+            }
+          }
+          t.mu = mu;
+          double phi_n = t.cost, theta_n = 0.0, ipr = 0.0, icomp = 0.0;
+          if (m > 0) ip_reductions(c, t.S.data(), t.Y.data(), t.G.data(), mu, t.cost, phi_n, theta_n, ipr, icomp);
+          const double ftheta = std::max(theta_n, 1e-8);
+          const bool reset = (mu < mu_old) && (mu > 0.0);
+          if (reset) t.filter.clear();   // re-seeded only when terminal constraints exist (:2629-2637): none here
+          else { filter_accept(t.filter, t.phi, ftheta); if ((int)t.filter.size() > o.ipddp_max_filter_size) filter_prune(t.filter); }
+          t.inf_pr = ipr; t.inf_comp = icomp; t.merit = t.phi = phi_n; t.filter_theta = ftheta;
+          t.theta = std::max(ftheta, std::max(o.ipddp_theta_0_floor, 1e-8));
+          t.reg = reg_decrease(o, t.reg);
+          // ---- checkConvergence (ipddp_solver.cpp:1953-2025)
+          const double sdu2 = scaled_inf_du(c, t, Gx_t);
+          const double pr = t.inf_pr, scomp = t.inf_comp, sn = t.step_norm;
+          if (m == 0) {
+            if (pr < o.tolerance && sdu2 < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; done = true; }
+            else if (o.acceptable_tolerance > 0.0) {
+              const double sq = std::sqrt(o.acceptable_tolerance);
+              bool acc = (pr < sq && sdu2 < sq && t.iter > 50);
+              if (dJ > 0.0) acc = acc || (dJ < o.acceptable_tolerance && t.iter > 50 && pr < sq && sdu2 < sq);
+              if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; done = true; }
+            }
+          } else {
+            const double tol = std::max(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+            if (pr < tol && sdu2 < tol && scomp < tol && sn < o.tolerance * 10.0) { st = CDDP_HIP_STATUS_OPTIMAL; done = true; }
+            else if (o.acceptable_tolerance > 0.0) {
+              const double at = std::sqrt(o.acceptable_tolerance);
+              const double bat = std::max(o.barrier_mu_min_value * 100.0, o.tolerance / 10.0);
+              const bool akkt = pr < at && sdu2 < at && scomp < at, bpc = mu <= bat;
+              bool acc = akkt && bpc && t.iter > 10 && std::fabs(dJ) < o.acceptable_tolerance;
+              acc = acc || (akkt && bpc && t.iter >= 1 && sn < o.tolerance * 10.0 && pr < 1e-4);
+              if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; done = true; }
+            }
+          }
+        } else {
+          t.reg = reg_decrease(o, t.reg);
+          if (t.inf_du < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; done = true; }                      // clddp_solver.cpp:264-277
+          else if (dJ > 0.0 && dJ < o.acceptable_tolerance) { st = CDDP_HIP_STATUS_ACCEPTABLE; done = true; }
+        }
+        if (done) { t.status = st; t.done = true; }
+      } else {
+        // ---- handleForwardPassFailure (cddp_solver_base.cpp:206-218, ipddp_solver.cpp:2037-2082)
+        t.reg = reg_increase(o, t.reg);
+        if (t.reg >= o.reg_max_value) {
+          int st = CDDP_HIP_STATUS_REG_LIMIT;
+          if (c.ipddp()) {
+            const double sdu = scaled_inf_du(c, t, Gx_t);
+            const double base = std::sqrt(std::max(o.acceptable_tolerance, o.tolerance));
+            const double at = (m == 0) ? base : std::max(base, o.ipddp_barrier_tol_mult * t.mu);
+            if (o.acceptable_tolerance > 0.0 && t.inf_pr < at && sdu < at && (m == 0 || t.inf_comp < at)) st = CDDP_HIP_STATUS_ACCEPTABLE;
+          }
+          t.status = st; t.done = true;
+        }
+      }
+      if (!t.done && it == o.max_iterations) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+    }
+  }
+  for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }   // max_iterations <= 0
+
+  // ---- CDDPSolution fields (cddp_solver_base.cpp:161-171, ipddp_solver.cpp:2090-2097); feedback gains = K_u_ of the last sweep
+  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc && o.max_iterations > 0) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  for (size_t b = 0; b < B; ++b) {
+    const Traj &t = T[b];
+    cddp_hip_result &r = results[b];
+    std::memset(&r, 0, sizeof(r));
+    r.final_objective = t.cost; r.merit_function = t.merit; r.inf_pr = t.inf_pr; r.inf_du = t.inf_du; r.inf_comp = t.inf_comp;
+    r.barrier_mu = t.mu; r.regularization = t.reg; r.alpha_pr = t.alpha_pr; r.alpha_du = t.alpha_du; r.step_norm = t.step_norm;
+    r.iterations = t.iter; r.status = t.status; r.n_backward = t.n_bwd; r.n_forward = t.n_fwd;
+    if (Xout) std::copy(t.X.begin(), t.X.end(), Xout + b * (N + 1) * nx);
+    if (Uout) std::copy(t.U.begin(), t.U.end(), Uout + b * N * nu);
+  }
+  return 0;
+}

@@ -15,21 +15,26 @@
 // Differences that are forced by the boundary:
 //   * Eigen is not a dependency: cddp::Vector / cddp::Matrix are minimal row-major containers; when
 //     <Eigen/Dense> is available, ToVector()/ToMatrix() adapters accept Eigen types.
-//   * DynamicalSystem / Objective / Constraint subclasses are DESCRIPTORS of the built-in plug-ins the
-//     kernels implement on the device (enumerated by id); arbitrary host subclasses go through the
-//     stack-fed entry point cddp_hip_backward_stacks (they cannot run on the GPU).
+//   * The built-in DynamicalSystem / Objective / Constraint classes are DESCRIPTORS of plug-ins the kernels implement
+//     on the device (enumerated by id).  A user subclass overrides the reference's virtual functions
+//     (getDiscreteDynamics / getStateJacobian / running_cost / evaluate ...) and is served by the host plug-in solve
+//     (cddp_hip_plugin_solve: batched backward passes on the GPU, forward passes through the virtuals on the host);
+//     there is no autodiff here, so a plant must provide its Jacobians (and Hessians when use_ilqr is false).
 //   * "CLDDP" and "IPDDP" are served by HipBatchSolver through the same static registry the reference
 //     uses (CDDP::registerSolver, cddp_core.cpp:578-595); other names return the reference's
 //     "UnknownSolver - No solver registered for '<name>'" solution (cddp_core.cpp:243-265).
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <exception>
+#include <algorithm>
 #include <functional>
 #include <limits>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <typeinfo>
 #include <vector>
 
 #include "../../include/cddp_hip.h"
@@ -101,22 +106,97 @@ struct CDDPOptions {
 
 // ---- plug-in descriptors --------------------------------------------------------------------
 inline int integratorId(const std::string &s) {
-  if (s == "euler") return CDDP_HIP_EULER; if (s == "heun") return CDDP_HIP_HEUN; if (s == "rk3") return CDDP_HIP_RK3; if (s == "rk4") return CDDP_HIP_RK4;
+  if (s == "euler") return CDDP_HIP_EULER;
+  if (s == "heun") return CDDP_HIP_HEUN;
+  if (s == "rk3") return CDDP_HIP_RK3;
+  if (s == "rk4") return CDDP_HIP_RK4;
   return -1;   // reference prints "Integration type not supported!" and returns zeros (dynamical_system.cpp:79-82)
 }
 class DynamicalSystem {
  public:
   DynamicalSystem(int model, int nx, int nu, double timestep, std::string integration_type)
       : model_(model), state_dim_(nx), control_dim_(nu), timestep_(timestep), integration_type_(std::move(integration_type)) {}
+  // a user-defined (host) plant: override the virtuals below (dynamical_system.hpp:30-117)
+  DynamicalSystem(int nx, int nu, double timestep, std::string integration_type)
+      : DynamicalSystem(-1, nx, nu, timestep, std::move(integration_type)) {}
   virtual ~DynamicalSystem() = default;
   int getStateDim() const { return state_dim_; }
   int getControlDim() const { return control_dim_; }
   double getTimestep() const { return timestep_; }
   const std::string &getIntegrationType() const { return integration_type_; }
   int modelId() const { return model_; }
+  bool isHostPlant() const { return model_ < 0; }
   std::vector<double> params;         // cddp_hip_problem::model_params
   Matrix lti_A, lti_B;
+
+  virtual Vector getContinuousDynamics(const Vector &, const Vector &, double) const {
+    throw std::runtime_error("getContinuousDynamics is not implemented for this DynamicalSystem");
+  }
+  virtual Vector getDiscreteDynamics(const Vector &x, const Vector &u, double t) const {   // dynamical_system.cpp:28-83
+    if (!isHostPlant()) { Vector r(state_dim_); builtinEval(x, u, r.data(), nullptr, nullptr, nullptr, nullptr, nullptr); return r; }
+    const double dt = timestep_; const int n = state_dim_;
+    auto axpy = [n](const Vector &a, double s, const Vector &b) { Vector r(n); for (int i = 0; i < n; ++i) r[i] = a[i] + s * b[i]; return r; };
+    const Vector k1 = getContinuousDynamics(x, u, t);
+    Vector r(n);
+    if (integration_type_ == "euler") return axpy(x, dt, k1);
+    if (integration_type_ == "heun") {
+      const Vector k2 = getContinuousDynamics(axpy(x, dt, k1), u, t + dt);
+      for (int i = 0; i < n; ++i) r[i] = x[i] + (0.5 * dt) * (k1[i] + k2[i]);
+      return r;
+    }
+    if (integration_type_ == "rk3") {
+      const Vector k2 = getContinuousDynamics(axpy(x, 0.5 * dt, k1), u, t + 0.5 * dt);
+      Vector x3(n); for (int i = 0; i < n; ++i) x3[i] = (x[i] - dt * k1[i]) + (2 * dt) * k2[i];
+      const Vector k3 = getContinuousDynamics(x3, u, t + dt);
+      for (int i = 0; i < n; ++i) r[i] = x[i] + (dt / 6) * ((k1[i] + 4.0 * k2[i]) + k3[i]);
+      return r;
+    }
+    if (integration_type_ == "rk4") {
+      const Vector k2 = getContinuousDynamics(axpy(x, 0.5 * dt, k1), u, t + 0.5 * dt);
+      const Vector k3 = getContinuousDynamics(axpy(x, 0.5 * dt, k2), u, t + 0.5 * dt);
+      const Vector k4 = getContinuousDynamics(axpy(x, dt, k3), u, t + dt);
+      for (int i = 0; i < n; ++i) r[i] = x[i] + (dt / 6) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+      return r;
+    }
+    throw std::runtime_error("Integration type not supported!");
+  }
+  // CONTINUOUS-time Jacobians / Hessians, as in the reference (the solver forms A = I + dt f_x, B = dt f_u)
+  // (a built-in plant evaluates the kernels' model source compiled for the host: cddp_hip_model_eval)
+  virtual Matrix getStateJacobian(const Vector &x, const Vector &u, double) const {
+    if (isHostPlant()) noAutodiff("getStateJacobian");
+    Matrix fx(state_dim_, state_dim_); builtinEval(x, u, nullptr, fx.a.data(), nullptr, nullptr, nullptr, nullptr); return fx;
+  }
+  virtual Matrix getControlJacobian(const Vector &x, const Vector &u, double) const {
+    if (isHostPlant()) noAutodiff("getControlJacobian");
+    Matrix fu(state_dim_, control_dim_); builtinEval(x, u, nullptr, nullptr, fu.a.data(), nullptr, nullptr, nullptr); return fu;
+  }
+  virtual std::vector<Matrix> getStateHessian(const Vector &x, const Vector &u, double) const { if (isHostPlant()) noAutodiff("getStateHessian"); return builtinHess(x, u, 0); }
+  virtual std::vector<Matrix> getControlHessian(const Vector &x, const Vector &u, double) const { if (isHostPlant()) noAutodiff("getControlHessian"); return builtinHess(x, u, 1); }
+  virtual std::vector<Matrix> getCrossHessian(const Vector &x, const Vector &u, double) const { if (isHostPlant()) noAutodiff("getCrossHessian"); return builtinHess(x, u, 2); }
  protected:
+  void builtinEval(const Vector &x, const Vector &u, double *xn, double *fx, double *fu, double *fxx, double *fuu, double *fux) const {
+    double mp[CDDP_HIP_MAX_MODEL_PARAMS] = {0};
+    for (size_t i = 0; i < params.size() && i < CDDP_HIP_MAX_MODEL_PARAMS; ++i) mp[i] = params[i];
+    if ((int)x.size() != state_dim_ || (int)u.size() != control_dim_) throw std::invalid_argument("DynamicalSystem: state / control size mismatch");
+    int integ = -1;
+    if (integration_type_ == "euler") integ = CDDP_HIP_EULER; else if (integration_type_ == "heun") integ = CDDP_HIP_HEUN;
+    else if (integration_type_ == "rk3") integ = CDDP_HIP_RK3; else if (integration_type_ == "rk4") integ = CDDP_HIP_RK4;
+    if (cddp_hip_model_eval(model_, integ, timestep_, mp, state_dim_, control_dim_, x.data(), u.data(), xn, fx, fu, fxx, fuu, fux) != 0)
+      throw std::runtime_error(std::string("cddp_hip: ") + cddp_hip_last_error());
+  }
+  std::vector<Matrix> builtinHess(const Vector &x, const Vector &u, int which) const {
+    const int nx = state_dim_, nu = control_dim_;
+    std::vector<double> fxx((size_t)nx * nx * nx), fuu((size_t)nx * nu * nu), fux((size_t)nx * nu * nx);
+    builtinEval(x, u, nullptr, nullptr, nullptr, fxx.data(), fuu.data(), fux.data());
+    const int r = which == 0 ? nx : nu, c = which == 1 ? nu : nx;
+    const std::vector<double> &src = which == 0 ? fxx : which == 1 ? fuu : fux;
+    std::vector<Matrix> out(nx, Matrix(r, c));
+    for (int i = 0; i < nx; ++i) std::memcpy(out[i].a.data(), src.data() + (size_t)i * r * c, sizeof(double) * r * c);
+    return out;
+  }
+  static void noAutodiff(const char *what) {
+    throw std::runtime_error(std::string("DynamicalSystem::") + what + ": autodiff is not available in the HIP mirror; override it in the subclass");
+  }
   int model_, state_dim_, control_dim_; double timestep_; std::string integration_type_;
 };
 struct Pendulum : DynamicalSystem {   // pendulum.hpp: (timestep, length, mass, damping, integration_type)
@@ -137,6 +217,19 @@ struct LTISystem : DynamicalSystem {  // lti_system.hpp: (A, B, timestep, integr
     if (B.rows != A.rows) throw std::invalid_argument("B matrix must have same number of rows as A");
     lti_A = A; lti_B = B;
   }
+  // host evaluation (lti_system.cpp:92-135), used when the LTI plant is paired with a host Objective / Constraint
+  Vector getDiscreteDynamics(const Vector &x, const Vector &u, double) const override {
+    Vector r(state_dim_, 0.0);
+    for (int i = 0; i < state_dim_; ++i) { double a = 0.0, b = 0.0; for (int j = 0; j < state_dim_; ++j) a += lti_A(i, j) * x[j]; for (int j = 0; j < control_dim_; ++j) b += lti_B(i, j) * u[j]; r[i] = a + b; }
+    return r;
+  }
+  Matrix getStateJacobian(const Vector &, const Vector &, double) const override {
+    Matrix m = lti_A; for (int i = 0; i < state_dim_; ++i) m(i, i) -= 1.0; for (double &v : m.a) v /= timestep_; return m;
+  }
+  Matrix getControlJacobian(const Vector &, const Vector &, double) const override { Matrix m = lti_B; for (double &v : m.a) v /= timestep_; return m; }
+  std::vector<Matrix> getStateHessian(const Vector &, const Vector &, double) const override { return std::vector<Matrix>(state_dim_, Matrix(state_dim_, state_dim_)); }
+  std::vector<Matrix> getControlHessian(const Vector &, const Vector &, double) const override { return std::vector<Matrix>(state_dim_, Matrix(control_dim_, control_dim_)); }
+  std::vector<Matrix> getCrossHessian(const Vector &, const Vector &, double) const override { return std::vector<Matrix>(state_dim_, Matrix(control_dim_, state_dim_)); }
 };
 struct Quadrotor : DynamicalSystem {  // quadrotor.hpp: (timestep, mass, inertia_matrix(diag), arm_length, integration_type)
   Quadrotor(double dt, double mass, const Matrix &inertia, double arm_length, std::string integ = "rk4")
@@ -146,7 +239,23 @@ struct Manipulator : DynamicalSystem {
   Manipulator(double dt, std::string integ = "rk4") : DynamicalSystem(CDDP_HIP_MODEL_MANIPULATOR, 6, 3, dt, integ) {}
 };
 
-class Objective { public: virtual ~Objective() = default; };
+class Objective {                       // objective.hpp:30-120
+ public:
+  virtual ~Objective() = default;
+  virtual double running_cost(const Vector &x, const Vector &u, int index) const = 0;
+  virtual double terminal_cost(const Vector &x) const = 0;
+  virtual double evaluate(const std::vector<Vector> &X, const std::vector<Vector> &U) const {
+    double J = 0.0; for (size_t t = 0; t < U.size(); ++t) J += running_cost(X[t], U[t], (int)t);
+    return J + terminal_cost(X.back());
+  }
+  virtual Vector getRunningCostStateGradient(const Vector &x, const Vector &u, int index) const = 0;
+  virtual Vector getRunningCostControlGradient(const Vector &x, const Vector &u, int index) const = 0;
+  virtual Vector getFinalCostGradient(const Vector &x) const = 0;
+  virtual Matrix getRunningCostStateHessian(const Vector &x, const Vector &u, int index) const = 0;
+  virtual Matrix getRunningCostControlHessian(const Vector &x, const Vector &u, int index) const = 0;
+  virtual Matrix getRunningCostCrossHessian(const Vector &x, const Vector &u, int index) const = 0;   // nu x nx
+  virtual Matrix getFinalCostHessian(const Vector &x) const = 0;
+};
 class QuadraticObjective : public Objective {   // objective.hpp: (Q, R, Qf, reference_state, reference_states, timestep)
  public:
   QuadraticObjective(const Matrix &Q, const Matrix &R, const Matrix &Qf, const Vector &reference_state,
@@ -160,45 +269,145 @@ class QuadraticObjective : public Objective {   // objective.hpp: (Q, R, Qf, ref
       if (std::sqrt(n2) > 1e-6) throw std::invalid_argument("Last reference state must be same as the reference state");
     }
   }
+  // host evaluation (objective.cpp:66-154): the constructor scales Q and R by the timestep
+  double running_cost(const Vector &x, const Vector &u, int index) const override {
+    const Vector &r = ref(index); const int nx = Q_.rows, nu = R_.rows;
+    double qx = 0.0, ru = 0.0;
+    for (int i = 0; i < nx; ++i) { double a = 0.0; for (int j = 0; j < nx; ++j) a += (Q_(i, j) * timestep_) * (x[j] - r[j]); qx += (x[i] - r[i]) * a; }
+    for (int i = 0; i < nu; ++i) { double a = 0.0; for (int j = 0; j < nu; ++j) a += (R_(i, j) * timestep_) * u[j]; ru += u[i] * a; }
+    return qx + ru;
+  }
+  double terminal_cost(const Vector &x) const override {
+    const int nx = Qf_.rows; double q = 0.0;
+    for (int i = 0; i < nx; ++i) { double a = 0.0; for (int j = 0; j < nx; ++j) a += Qf_(i, j) * (x[j] - reference_state_[j]); q += (x[i] - reference_state_[i]) * a; }
+    return q;
+  }
+  Vector getRunningCostStateGradient(const Vector &x, const Vector &, int index) const override {
+    const Vector &r = ref(index); Vector g(Q_.rows);
+    for (int i = 0; i < Q_.rows; ++i) { double a = 0.0; for (int j = 0; j < Q_.rows; ++j) a += (Q_(i, j) * timestep_) * (x[j] - r[j]); g[i] = 2.0 * a; }
+    return g;
+  }
+  Vector getRunningCostControlGradient(const Vector &, const Vector &u, int) const override {
+    Vector g(R_.rows);
+    for (int i = 0; i < R_.rows; ++i) { double a = 0.0; for (int j = 0; j < R_.rows; ++j) a += (R_(i, j) * timestep_) * u[j]; g[i] = 2.0 * a; }
+    return g;
+  }
+  Vector getFinalCostGradient(const Vector &x) const override {
+    Vector g(Qf_.rows);
+    for (int i = 0; i < Qf_.rows; ++i) { double a = 0.0; for (int j = 0; j < Qf_.rows; ++j) a += Qf_(i, j) * (x[j] - reference_state_[j]); g[i] = 2.0 * a; }
+    return g;
+  }
+  Matrix getRunningCostStateHessian(const Vector &, const Vector &, int) const override { return (Q_ * timestep_) * 2.0; }
+  Matrix getRunningCostControlHessian(const Vector &, const Vector &, int) const override { return (R_ * timestep_) * 2.0; }
+  Matrix getRunningCostCrossHessian(const Vector &, const Vector &, int) const override { return Matrix(R_.rows, Q_.rows); }
+  Matrix getFinalCostHessian(const Vector &) const override { return Qf_ * 2.0; }
   Matrix Q_, R_, Qf_; Vector reference_state_; std::vector<Vector> reference_states_; double timestep_;
+ private:
+  const Vector &ref(int index) const { return reference_states_.empty() ? reference_state_ : reference_states_[index]; }
+};
+// NonlinearObjective (objective.cpp:156-288): derivatives by central finite differences unless overridden
+class NonlinearObjective : public Objective {
+ public:
+  explicit NonlinearObjective(double timestep = 0.1) : timestep_(timestep) {}
+  double running_cost(const Vector &, const Vector &, int) const override { return 0.0; }
+  double terminal_cost(const Vector &) const override { return 0.0; }
+  Vector getRunningCostStateGradient(const Vector &x, const Vector &u, int k) const override { return fdGradient([&](const Vector &s) { return running_cost(s, u, k); }, x); }
+  Vector getRunningCostControlGradient(const Vector &x, const Vector &u, int k) const override { return fdGradient([&](const Vector &c) { return running_cost(x, c, k); }, u); }
+  Vector getFinalCostGradient(const Vector &x) const override { return fdGradient([&](const Vector &s) { return terminal_cost(s); }, x); }
+  Matrix getRunningCostStateHessian(const Vector &x, const Vector &u, int k) const override { return fdHessian([&](const Vector &s) { return running_cost(s, u, k); }, x); }
+  Matrix getRunningCostControlHessian(const Vector &x, const Vector &u, int k) const override { return fdHessian([&](const Vector &c) { return running_cost(x, c, k); }, u); }
+  Matrix getFinalCostHessian(const Vector &x) const override { return fdHessian([&](const Vector &s) { return terminal_cost(s); }, x); }
+  Matrix getRunningCostCrossHessian(const Vector &x, const Vector &u, int k) const override {   // objective.cpp:245-277: h = 2e-8
+    const double h = 2e-8; const int nx = (int)x.size(), nu = (int)u.size();
+    Matrix H(nu, nx); Vector xp = x, up = u;
+    for (int i = 0; i < nu; ++i) for (int j = 0; j < nx; ++j) {
+      up[i] = u[i] + h; xp[j] = x[j] + h; const double fpp = running_cost(xp, up, k);
+      xp[j] = x[j] - h; const double fpm = running_cost(xp, up, k);
+      up[i] = u[i] - h; const double fmm = running_cost(xp, up, k);
+      xp[j] = x[j] + h; const double fmp = running_cost(xp, up, k);
+      H(i, j) = (((fpp - fpm) - fmp) + fmm) / (4.0 * h * h); up[i] = u[i]; xp[j] = x[j];
+    }
+    return H;
+  }
+  template <class F> static Vector fdGradient(F f, const Vector &x, double h = 2e-5) {   // helper.hpp:34-55
+    Vector g(x.size()), xp = x;
+    for (size_t i = 0; i < x.size(); ++i) { xp[i] = x[i] + h; const double fp = f(xp); xp[i] = x[i] - h; const double fm = f(xp); g[i] = (fp - fm) / (2.0 * h); xp[i] = x[i]; }
+    return g;
+  }
+  template <class F> static Matrix fdHessian(F f, const Vector &x, double h = 2e-5) {    // helper.hpp:158-179
+    const int n = (int)x.size(); Matrix H(n, n); Vector xp = x;
+    for (int i = 0; i < n; ++i) {
+      xp[i] = x[i] + h; const Vector gp = fdGradient(f, xp, h); xp[i] = x[i] - h; const Vector gm = fdGradient(f, xp, h); xp[i] = x[i];
+      for (int r = 0; r < n; ++r) H(r, i) = (gp[r] - gm[r]) / (2.0 * h);
+    }
+    return H;
+  }
+ protected:
+  double timestep_;
 };
 
-class Constraint {
+class Constraint {                      // constraint.hpp:40-142
  public:
   explicit Constraint(std::string name) : name_(std::move(name)) {}
   virtual ~Constraint() = default;
   const std::string &getName() const { return name_; }
   virtual int getDualDim() const = 0;
-  virtual void fill(cddp_hip_constraint &c) const = 0;
+  virtual Vector evaluate(const Vector &x, const Vector &u) const = 0;
+  virtual Vector getUpperBound() const = 0;
+  virtual Matrix getStateJacobian(const Vector &x, const Vector &u) const = 0;     // m x nx
+  virtual Matrix getControlJacobian(const Vector &x, const Vector &u) const = 0;   // m x nu
+  // device descriptor: true when a kernel implements this constraint; a user subclass keeps the default
+  virtual bool fill(cddp_hip_constraint &) const { return false; }
  protected:
   std::string name_;
 };
+namespace detail {
+inline Vector boxEval(const Vector &v, double s) { const size_t n = v.size(); Vector g(2 * n); for (size_t i = 0; i < n; ++i) { g[i] = -v[i] * s; g[n + i] = v[i] * s; } return g; }
+inline Vector boxUpper(const Vector &lo, const Vector &up, double s) { const size_t n = up.size(); Vector g(2 * n); for (size_t i = 0; i < n; ++i) { g[i] = -lo[i] * s; g[n + i] = up[i] * s; } return g; }
+inline Matrix boxJac(int n, double s) { Matrix J(2 * n, n); for (int i = 0; i < n; ++i) { J(i, i) = -s; J(n + i, i) = s; } return J; }
+}  // namespace detail
 class ControlConstraint : public Constraint {   // BoxConstraint<Control>, constraint.hpp:144-251
  public:
   ControlConstraint(const Vector &lower, const Vector &upper, double scale = 1.0) : Constraint("ControlConstraint"), lower_(lower), upper_(upper), scale_(scale) {}
   int getDualDim() const override { return 2 * (int)upper_.size(); }
-  void fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_CONTROL_BOX; c.dim = (int)upper_.size(); c.lower = lower_.data(); c.upper = upper_.data(); c.scale = scale_; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_CONTROL_BOX; c.dim = (int)upper_.size(); c.lower = lower_.data(); c.upper = upper_.data(); c.scale = scale_; return true; }
+  Vector evaluate(const Vector &, const Vector &u) const override { return detail::boxEval(u, scale_); }
+  Vector getUpperBound() const override { return detail::boxUpper(lower_, upper_, scale_); }
+  Matrix getStateJacobian(const Vector &x, const Vector &) const override { return Matrix(getDualDim(), (int)x.size()); }
+  Matrix getControlJacobian(const Vector &, const Vector &) const override { return detail::boxJac((int)upper_.size(), scale_); }
   Vector lower_, upper_; double scale_;
 };
 class StateConstraint : public Constraint {
  public:
   StateConstraint(const Vector &lower, const Vector &upper, double scale = 1.0) : Constraint("StateConstraint"), lower_(lower), upper_(upper), scale_(scale) {}
   int getDualDim() const override { return 2 * (int)upper_.size(); }
-  void fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_STATE_BOX; c.dim = (int)upper_.size(); c.lower = lower_.data(); c.upper = upper_.data(); c.scale = scale_; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_STATE_BOX; c.dim = (int)upper_.size(); c.lower = lower_.data(); c.upper = upper_.data(); c.scale = scale_; return true; }
+  Vector evaluate(const Vector &x, const Vector &) const override { return detail::boxEval(x, scale_); }
+  Vector getUpperBound() const override { return detail::boxUpper(lower_, upper_, scale_); }
+  Matrix getStateJacobian(const Vector &, const Vector &) const override { return detail::boxJac((int)upper_.size(), scale_); }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix(getDualDim(), (int)u.size()); }
   Vector lower_, upper_; double scale_;
 };
 class BallConstraint : public Constraint {      // constraint.hpp:313-404
  public:
   BallConstraint(double radius, const Vector &center, double scale = 1.0) : Constraint("BallConstraint"), radius_(radius), center_(center), scale_(scale) {}
   int getDualDim() const override { return 1; }
-  void fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_BALL; c.dim = (int)center_.size(); c.center = center_.data(); c.radius = radius_; c.scale = scale_; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_BALL; c.dim = (int)center_.size(); c.center = center_.data(); c.radius = radius_; c.scale = scale_; return true; }
+  Vector evaluate(const Vector &x, const Vector &) const override { double d2 = 0.0; for (size_t i = 0; i < center_.size(); ++i) { const double d = x[i] - center_[i]; d2 += d * d; } return {-scale_ * d2}; }
+  Vector getUpperBound() const override { return {-scale_ * radius_ * radius_}; }
+  Matrix getStateJacobian(const Vector &x, const Vector &) const override { Matrix J(1, (int)x.size()); for (size_t i = 0; i < center_.size(); ++i) J(0, (int)i) = -2.0 * scale_ * (x[i] - center_[i]); return J; }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix(1, (int)u.size()); }
   double radius_; Vector center_; double scale_;
 };
 class LinearConstraint : public Constraint {    // constraint.hpp:253-311
  public:
   LinearConstraint(const Matrix &A, const Vector &b, double scale = 1.0) : Constraint("LinearConstraint"), A_(A), b_(b), scale_(scale) {}
   int getDualDim() const override { return (int)b_.size(); }
-  void fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_LINEAR; c.dim = (int)b_.size(); c.A = A_.a.data(); c.b = b_.data(); c.scale = scale_; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_LINEAR; c.dim = (int)b_.size(); c.A = A_.a.data(); c.b = b_.data(); c.scale = scale_; return true; }
+  Vector evaluate(const Vector &x, const Vector &) const override { Vector g(b_.size(), 0.0); for (int i = 0; i < A_.rows; ++i) for (int j = 0; j < A_.cols; ++j) g[i] += A_(i, j) * x[j]; return g; }
+  Vector getUpperBound() const override { return b_; }
+  Matrix getStateJacobian(const Vector &, const Vector &) const override { return A_; }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix((int)b_.size(), (int)u.size()); }
   Matrix A_; Vector b_; double scale_;
 };
 class TerminalConstraint {
@@ -269,6 +478,17 @@ class CDDP {
   double getTimestep() const { return timestep_; }
   const Vector &getInitialState() const { return initial_state_; }
   const DynamicalSystem &getSystem() const { return *system_; }
+  const Objective &getObjective() const { return *objective_; }
+  const std::map<std::string, std::unique_ptr<Constraint>> &getConstraintSet() const { return path_constraint_set_; }
+  bool hasTerminalConstraints() const { return !terminal_constraint_set_.empty(); }
+  // true when some plug-in is a user subclass without a device kernel: the solve then goes through cddp_hip_plugin_solve
+  bool needsHostPlugins() const {
+    if (!system_ || !objective_) return false;
+    if (system_->isHostPlant() || typeid(*objective_) != typeid(QuadraticObjective)) return true;
+    cddp_hip_constraint c;
+    for (auto &kv : path_constraint_set_) if (!kv.second->fill(c)) return true;
+    return false;
+  }
 
   // --- static solver registry (cddp_core.cpp:34-35, 578-595): consulted BEFORE the built-ins
   using Factory = std::function<std::unique_ptr<ISolverAlgorithm>()>;
@@ -308,7 +528,7 @@ class HipBatchSolver : public ISolverAlgorithm {
   // (clddp_solver.cpp:51-60, ipddp_solver.cpp:675-731).  CDDP::solve() creates a new solver per call, exactly as
   // the reference does (cddp_core.cpp:235-270), so through it a warm start is the "provided trajectory" branch.
   void initialize(CDDP &ctx) override {
-    if (h_ && ctx.getOptions().warm_start && batch_ == 1 && nx_ == ctx.getSystem().getStateDim() && nu_ == ctx.getSystem().getControlDim() && N_ == ctx.getHorizon()) {
+    if (h_ && !ctx.needsHostPlugins() && ctx.getOptions().warm_start && batch_ == 1 && nx_ == ctx.getSystem().getStateDim() && nu_ == ctx.getSystem().getControlDim() && N_ == ctx.getHorizon()) {
       ctx.initializeProblemIfNecessary();
       cddp_hip_options o = ctx.getOptions().toPOD();
       check(cddp_hip_set_options(h_, &o));
@@ -334,6 +554,13 @@ class HipBatchSolver : public ISolverAlgorithm {
   void create(CDDP &ctx, const std::vector<Vector> &x0s) {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
+    plugin_ = ctx.needsHostPlugins();
+    if (plugin_) {
+      const DynamicalSystem &sys = ctx.getSystem();
+      nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;
+      x0s_ = x0s;
+      return;
+    }
     CDDP::Flat f; ctx.flatten(kind_, f);
     const int B = (int)x0s.size(), nx = f.p.nx, nu = f.p.nu, N = f.p.horizon;
     check(cddp_hip_create(&f.p, B, device_, &h_));
@@ -348,7 +575,126 @@ class HipBatchSolver : public ISolverAlgorithm {
     if ((int)ctx.X_.size() == N + 1) { X0.resize((size_t)B * (N + 1) * nx); for (int b = 0; b < B; ++b) for (int t = 0; t <= N; ++t) for (int i = 0; i < nx; ++i) X0[((size_t)b * (N + 1) + t) * nx + i] = ctx.X_[t][i]; }
     check(cddp_hip_set_initial(h_, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data()));
   }
-  std::vector<CDDPSolution> collect(CDDP &, int B) {
+  // ---- host plug-in route: the reference's virtual functions behind the flat callbacks of cddp_hip_plugin ----
+  struct PluginCtx {
+    const DynamicalSystem *sys; const Objective *obj; std::vector<const Constraint *> cons; int nx, nu, m;
+    std::exception_ptr error;   // a C++ exception must not unwind through the C library: parked here, rethrown after the call
+    Vector x, u;
+    void load(const double *xp, const double *up) { x.assign(xp, xp + nx); if (up) u.assign(up, up + nu); }
+  };
+  template <class F> static void guarded(PluginCtx *c, F f) { if (c->error) return; try { f(); } catch (...) { c->error = std::current_exception(); } }
+  static void copyM(const Matrix &M, int r, int cc, double *out, const char *what) {
+    if (M.rows != r || M.cols != cc) throw std::runtime_error(std::string(what) + ": unexpected shape");
+    std::memcpy(out, M.a.data(), sizeof(double) * r * cc);
+  }
+  static void cbDyn(void *p, const double *x, const double *u, double t, double *xn) {
+    auto *c = (PluginCtx *)p; std::fill(xn, xn + c->nx, std::numeric_limits<double>::quiet_NaN());
+    guarded(c, [&] { c->load(x, u); Vector r = c->sys->getDiscreteDynamics(c->x, c->u, t); if ((int)r.size() != c->nx) throw std::runtime_error("getDiscreteDynamics: unexpected size"); std::copy(r.begin(), r.end(), xn); });
+  }
+  static void cbJac(void *p, const double *x, const double *u, double t, double *fx, double *fu) {
+    auto *c = (PluginCtx *)p; std::fill(fx, fx + c->nx * c->nx, 0.0); std::fill(fu, fu + c->nx * c->nu, 0.0);
+    guarded(c, [&] { c->load(x, u); copyM(c->sys->getStateJacobian(c->x, c->u, t), c->nx, c->nx, fx, "getStateJacobian"); copyM(c->sys->getControlJacobian(c->x, c->u, t), c->nx, c->nu, fu, "getControlJacobian"); });
+  }
+  static void cbHess(void *p, const double *x, const double *u, double t, double *fxx, double *fuu, double *fux) {
+    auto *c = (PluginCtx *)p; const int nx = c->nx, nu = c->nu;
+    std::fill(fxx, fxx + nx * nx * nx, 0.0); std::fill(fuu, fuu + nx * nu * nu, 0.0); std::fill(fux, fux + nx * nu * nx, 0.0);
+    guarded(c, [&] {
+      c->load(x, u);
+      auto a = c->sys->getStateHessian(c->x, c->u, t); auto b = c->sys->getControlHessian(c->x, c->u, t); auto d = c->sys->getCrossHessian(c->x, c->u, t);
+      if ((int)a.size() != nx || (int)b.size() != nx || (int)d.size() != nx) throw std::runtime_error("dynamics Hessians: one matrix per state row expected");
+      for (int i = 0; i < nx; ++i) { copyM(a[i], nx, nx, fxx + i * nx * nx, "getStateHessian"); copyM(b[i], nu, nu, fuu + i * nu * nu, "getControlHessian"); copyM(d[i], nu, nx, fux + i * nu * nx, "getCrossHessian"); }
+    });
+  }
+  static double cbRun(void *p, const double *x, const double *u, int k) {
+    auto *c = (PluginCtx *)p; double v = std::numeric_limits<double>::quiet_NaN();
+    guarded(c, [&] { c->load(x, u); v = c->obj->running_cost(c->x, c->u, k); }); return v;
+  }
+  static double cbTerm(void *p, const double *x) {
+    auto *c = (PluginCtx *)p; double v = std::numeric_limits<double>::quiet_NaN();
+    guarded(c, [&] { c->load(x, nullptr); v = c->obj->terminal_cost(c->x); }); return v;
+  }
+  static void cbRunD(void *p, const double *x, const double *u, int k, double *lx, double *lu, double *lxx, double *luu, double *lux) {
+    auto *c = (PluginCtx *)p; const int nx = c->nx, nu = c->nu;
+    std::fill(lx, lx + nx, 0.0); std::fill(lu, lu + nu, 0.0); std::fill(lxx, lxx + nx * nx, 0.0); std::fill(luu, luu + nu * nu, 0.0); std::fill(lux, lux + nu * nx, 0.0);
+    guarded(c, [&] {
+      c->load(x, u);
+      Vector gx = c->obj->getRunningCostStateGradient(c->x, c->u, k), gu = c->obj->getRunningCostControlGradient(c->x, c->u, k);
+      if ((int)gx.size() != nx || (int)gu.size() != nu) throw std::runtime_error("running-cost gradients: unexpected size");
+      std::copy(gx.begin(), gx.end(), lx); std::copy(gu.begin(), gu.end(), lu);
+      copyM(c->obj->getRunningCostStateHessian(c->x, c->u, k), nx, nx, lxx, "getRunningCostStateHessian");
+      copyM(c->obj->getRunningCostControlHessian(c->x, c->u, k), nu, nu, luu, "getRunningCostControlHessian");
+      copyM(c->obj->getRunningCostCrossHessian(c->x, c->u, k), nu, nx, lux, "getRunningCostCrossHessian");
+    });
+  }
+  static void cbTermD(void *p, const double *x, double *lx, double *lxx) {
+    auto *c = (PluginCtx *)p; std::fill(lx, lx + c->nx, 0.0); std::fill(lxx, lxx + c->nx * c->nx, 0.0);
+    guarded(c, [&] { c->load(x, nullptr); Vector g = c->obj->getFinalCostGradient(c->x); if ((int)g.size() != c->nx) throw std::runtime_error("getFinalCostGradient: unexpected size");
+                     std::copy(g.begin(), g.end(), lx); copyM(c->obj->getFinalCostHessian(c->x), c->nx, c->nx, lxx, "getFinalCostHessian"); });
+  }
+  static void cbCon(void *p, const double *x, const double *u, int, double *g, double *gx, double *gu) {
+    auto *c = (PluginCtx *)p; std::fill(g, g + c->m, -1.0);
+    if (gx) std::fill(gx, gx + c->m * c->nx, 0.0);
+    if (gu) std::fill(gu, gu + c->m * c->nu, 0.0);
+    guarded(c, [&] {
+      c->load(x, u); int off = 0;
+      for (const Constraint *k : c->cons) {
+        const int d = k->getDualDim(); Vector e = k->evaluate(c->x, c->u), ub = k->getUpperBound();
+        if ((int)e.size() != d || (int)ub.size() != d) throw std::runtime_error("constraint '" + k->getName() + "': evaluate / getUpperBound size differs from getDualDim");
+        for (int i = 0; i < d; ++i) g[off + i] = e[i] - ub[i];
+        if (gx) copyM(k->getStateJacobian(c->x, c->u), d, c->nx, gx + off * c->nx, "Constraint::getStateJacobian");
+        if (gu) copyM(k->getControlJacobian(c->x, c->u), d, c->nu, gu + off * c->nu, "Constraint::getControlJacobian");
+        off += d;
+      }
+    });
+  }
+  std::vector<CDDPSolution> collectPlugin(CDDP &ctx, int B) {
+    if (ctx.hasTerminalConstraints()) throw std::runtime_error("HipBatchSolver: terminal constraints are not supported on host plug-in problems");
+    PluginCtx pc; pc.sys = &ctx.getSystem(); pc.obj = &ctx.getObjective(); pc.nx = nx_; pc.nu = nu_; pc.m = 0;
+    cddp_hip_plugin pl; std::memset(&pl, 0, sizeof(pl));
+    pl.user = &pc; pl.nx = nx_; pl.nu = nu_;
+    const ControlConstraint *box = nullptr;
+    if (kind_ == CDDP_HIP_SOLVER_IPDDP) {
+      for (auto &kv : ctx.getConstraintSet()) {   // std::map order == dual stacking order
+        if ((int)pc.cons.size() == CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) throw std::runtime_error("HipBatchSolver: too many path constraints for the plug-in solve");
+        pl.constraint_dims[pc.cons.size()] = kv.second->getDualDim(); pc.m += kv.second->getDualDim(); pc.cons.push_back(kv.second.get());
+      }
+      pl.n_constraints = (int)pc.cons.size();
+    } else {   // clddp_solver.cpp:85-86: only the constraint literally named "ControlConstraint"
+      auto it = ctx.getConstraintSet().find("ControlConstraint");
+      if (it != ctx.getConstraintSet().end()) box = dynamic_cast<const ControlConstraint *>(it->second.get());
+      if (box) { pl.control_lower = box->lower_.data(); pl.control_upper = box->upper_.data(); }
+    }
+    pl.discrete_dynamics = cbDyn; pl.jacobians = cbJac; pl.hessians = ctx.getOptions().use_ilqr ? nullptr : cbHess;
+    pl.running_cost = cbRun; pl.terminal_cost = cbTerm; pl.running_cost_derivatives = cbRunD; pl.terminal_cost_derivatives = cbTermD;
+    pl.constraints = pc.cons.empty() ? nullptr : cbCon;
+    const int nx = nx_, nu = nu_, N = N_;
+    std::vector<double> x0((size_t)B * nx), U0, X0;
+    for (int b = 0; b < B; ++b) for (int i = 0; i < nx; ++i) x0[(size_t)b * nx + i] = x0s_[b][i];
+    if ((int)ctx.U_.size() == N) { U0.resize((size_t)B * N * nu); for (int b = 0; b < B; ++b) for (int t = 0; t < N; ++t) for (int i = 0; i < nu; ++i) U0[((size_t)b * N + t) * nu + i] = ctx.U_[t][i]; }
+    if ((int)ctx.X_.size() == N + 1) { X0.resize((size_t)B * (N + 1) * nx); for (int b = 0; b < B; ++b) for (int t = 0; t <= N; ++t) for (int i = 0; i < nx; ++i) X0[((size_t)b * (N + 1) + t) * nx + i] = ctx.X_[t][i]; }
+    std::vector<cddp_hip_result> r(B);
+    std::vector<double> X((size_t)B * (N + 1) * nx), U((size_t)B * N * nu), K((size_t)B * N * nu * nx);
+    cddp_hip_options o = ctx.getOptions().toPOD();
+    const int rc = cddp_hip_plugin_solve(&pl, kind_, N, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(), r.data(), X.data(), U.data(), K.data());
+    if (pc.error) std::rethrow_exception(pc.error);
+    check(rc);
+    std::vector<CDDPSolution> out(B);
+    for (int b = 0; b < B; ++b) {
+      CDDPSolution &s = out[b];
+      s.solver_name = getSolverName(); s.status_message = cddp_hip_status_string(r[b].status);
+      s.iterations_completed = r[b].iterations; s.final_objective = r[b].final_objective;
+      s.final_step_length = r[b].alpha_pr; s.final_regularization = r[b].regularization;
+      s.final_primal_infeasibility = r[b].inf_pr; s.final_dual_infeasibility = r[b].inf_du; s.final_complementary_infeasibility = r[b].inf_comp; s.final_barrier_mu = r[b].barrier_mu;
+      for (int t = 0; t <= N; ++t) { s.time_points.push_back(t * dt_); s.state_trajectory.emplace_back(X.begin() + ((size_t)b * (N + 1) + t) * nx, X.begin() + ((size_t)b * (N + 1) + t + 1) * nx); }
+      for (int t = 0; t < N; ++t) {
+        s.control_trajectory.emplace_back(U.begin() + ((size_t)b * N + t) * nu, U.begin() + ((size_t)b * N + t + 1) * nu);
+        Matrix Kt(nu, nx); std::memcpy(Kt.a.data(), K.data() + ((size_t)b * N + t) * nu * nx, sizeof(double) * nu * nx); s.feedback_gains.push_back(Kt);
+      }
+    }
+    return out;
+  }
+  std::vector<CDDPSolution> collect(CDDP &ctx, int B) {
+    if (plugin_) return collectPlugin(ctx, B);
     check(cddp_hip_solve(h_, &stats));
     std::vector<cddp_hip_result> r(B);
     check(cddp_hip_get_results(h_, r.data()));
@@ -380,6 +726,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     return out;
   }
   int kind_, device_; cddp_hip_handle *h_ = nullptr; int nx_ = 0, nu_ = 0, N_ = 0, max_it_ = 0, batch_ = 0; double dt_ = 0; bool ret_hist_ = false;
+  bool plugin_ = false; std::vector<Vector> x0s_;
 };
 
 // Register the GPU core under the reference's own solver names: a true drop-in (cddp_core.cpp:215-219).
@@ -400,7 +747,7 @@ inline void CDDP::initializeProblemIfNecessary() {   // cddp_core.cpp:272-306
 inline void CDDP::flatten(int solver, Flat &f) const {
   std::memset(&f.p, 0, sizeof(f.p));
   const auto *qo = dynamic_cast<const QuadraticObjective *>(objective_.get());
-  if (!qo) throw std::runtime_error("HipBatchSolver: only QuadraticObjective runs on the device (use the stack-fed entry point for other objectives)");
+  if (!qo || system_->isHostPlant()) throw std::runtime_error("CDDP::flatten: host plug-ins have no device descriptor (they are served by cddp_hip_plugin_solve)");
   cddp_hip_problem &p = f.p;
   p.abi_version = CDDP_HIP_ABI_VERSION; p.solver = solver; p.model = system_->modelId();
   p.integrator = integratorId(system_->getIntegrationType());
@@ -411,7 +758,7 @@ inline void CDDP::flatten(int solver, Flat &f) const {
   p.Q = qo->Q_.a.data(); p.R = qo->R_.a.data(); p.Qf = qo->Qf_.a.data(); p.x_ref = qo->reference_state_.data();
   if (!qo->reference_states_.empty()) { for (auto &v : qo->reference_states_) f.xref_traj.insert(f.xref_traj.end(), v.begin(), v.end()); p.x_ref_traj = f.xref_traj.data(); }
   for (auto &kv : path_constraint_set_) {
-    cddp_hip_constraint c; std::memset(&c, 0, sizeof(c)); std::strncpy(c.name, kv.first.c_str(), CDDP_HIP_NAME_LEN - 1); c.scale = 1.0; kv.second->fill(c); f.cons.push_back(c);
+    cddp_hip_constraint c; std::memset(&c, 0, sizeof(c)); std::strncpy(c.name, kv.first.c_str(), CDDP_HIP_NAME_LEN - 1); c.scale = 1.0; if (!kv.second->fill(c)) throw std::runtime_error("CDDP::flatten: constraint '" + kv.first + "' has no device descriptor"); f.cons.push_back(c);
   }
   for (auto &kv : terminal_constraint_set_) {
     cddp_hip_terminal_constraint c; std::memset(&c, 0, sizeof(c)); std::strncpy(c.name, kv.first.c_str(), CDDP_HIP_NAME_LEN - 1); kv.second->fill(c); f.terms.push_back(c);

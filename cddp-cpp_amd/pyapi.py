@@ -471,7 +471,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
-    "cddp_hip_stacks_get_scalars", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
+    "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 
@@ -621,6 +621,141 @@ class HipBatchSolver:
 
     def write_gather_records_device(self, device_ptr):
         self._check(self.lib.cddp_hip_write_gather_records_device(self.h, C.c_void_p(device_ptr)))
+
+
+def model_eval(model, integrator, dt, params, nx, nu, x, u, want=("step",), trig=None):
+    """cddp_hip_model_eval: host evaluation of a built-in plant at one (x, u).  want: any of "step" (x_next), "jac" (f_x, f_u
+    continuous-time), "hess" (f_xx[nx][nx][nx], f_uu[nx][nu][nu], f_ux[nx][nu][nx]).  Returns a dict."""
+    lib = load_hip(trig)
+    pv = np.zeros(MAX_MODEL_PARAMS); pv[:len(params)] = params
+    x = _arr(x).reshape(nx); u = _arr(u).reshape(nu)
+    out = {}
+    xn = np.empty(nx) if "step" in want else None
+    fx = np.empty((nx, nx)) if "jac" in want else None; fu = np.empty((nx, nu)) if "jac" in want else None
+    fxx = np.empty((nx, nx, nx)) if "hess" in want else None; fuu = np.empty((nx, nu, nu)) if "hess" in want else None
+    fux = np.empty((nx, nu, nx)) if "hess" in want else None
+    lib.cddp_hip_model_eval.restype = C.c_int
+    rc = lib.cddp_hip_model_eval(int(model), int(integrator), C.c_double(dt), _ptr(pv), int(nx), int(nu), _ptr(x), _ptr(u),
+                                 _ptr(xn), _ptr(fx), _ptr(fu), _ptr(fxx), _ptr(fuu), _ptr(fux))
+    if rc != 0:
+        lib.cddp_hip_last_error.restype = C.c_char_p
+        raise HipError(lib.cddp_hip_last_error().decode())
+    if xn is not None: out["step"] = xn
+    if fx is not None: out["jac"] = (fx, fu)
+    if fxx is not None: out["hess"] = (fxx, fuu, fux)
+    return out
+
+
+# ---- host plug-in solve (include/cddp_hip.h: cddp_hip_plugin / cddp_hip_plugin_solve) ----------------------------------------
+PLUGIN_MAX_CONSTRAINTS = 8
+_F_DYN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_double, _dp)
+_F_JAC = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_double, _dp, _dp)
+_F_HES = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_double, _dp, _dp, _dp)
+_F_RC = C.CFUNCTYPE(C.c_double, C.c_void_p, _dp, _dp, C.c_int)
+_F_TC = C.CFUNCTYPE(C.c_double, C.c_void_p, _dp)
+_F_RCD = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp)
+_F_TCD = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, _dp)
+_F_CON = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp)
+
+
+class PluginStruct(C.Structure):
+    _fields_ = [
+        ("user", C.c_void_p), ("nx", C.c_int32), ("nu", C.c_int32), ("n_constraints", C.c_int32),
+        ("constraint_dims", C.c_int32 * PLUGIN_MAX_CONSTRAINTS),
+        ("discrete_dynamics", _F_DYN), ("jacobians", _F_JAC), ("hessians", _F_HES),
+        ("running_cost", _F_RC), ("terminal_cost", _F_TC), ("running_cost_derivatives", _F_RCD),
+        ("terminal_cost_derivatives", _F_TCD), ("constraints", _F_CON),
+        ("control_lower", _dp), ("control_upper", _dp),
+    ]
+
+
+def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, discrete_dynamics, jacobians, running_cost, terminal_cost,
+                 running_cost_derivatives, terminal_cost_derivatives, hessians=None, constraints=None, constraint_dims=(),
+                 control_lower=None, control_upper=None, device=0, trig=None):
+    """CDDP::solve() for HOST plug-ins through the C-ABI (cddp_hip_plugin_solve): the callables are the reference's virtual functions
+    on numpy vectors -- discrete_dynamics(x, u, t) -> x_next; jacobians(x, u, t) -> (f_x, f_u) continuous-time;
+    hessians(x, u, t) -> (f_xx[nx][nx][nx], f_uu[nx][nu][nu], f_ux[nx][nu][nx]); running_cost(x, u, index) -> float;
+    terminal_cost(x) -> float; running_cost_derivatives(x, u, index) -> (l_x, l_u, l_xx, l_uu, l_ux); terminal_cost_derivatives(x)
+    -> (l_x, l_xx); constraints(x, u, index, want_jacobians) -> (g - upper, G_x, G_u) stacked in name order.  The GPU runs the
+    batched backward passes, the host the forward passes.  An exception raised by a callable stops the solve and is re-raised here.
+    Returns (results, X, U, K)."""
+    lib = load_hip(trig)
+    x0 = _arr(x0).reshape(-1, nx); B = x0.shape[0]; N = int(horizon)
+    U0 = _arr(U0).reshape(B, N, nu) if U0 is not None else None
+    X0 = _arr(X0).reshape(B, N + 1, nx) if X0 is not None else None
+    m = int(sum(constraint_dims))
+    err = []
+
+    def vec(ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,))
+
+    def guard(fn, default=None):
+        def w(*a):
+            if err:
+                return default
+            try:
+                return fn(*a)
+            except BaseException as e:   # noqa: B902 -- re-raised by the caller thread after the C call returns
+                err.append(e)
+                return default
+        return w
+
+    def _dyn(_, x, u, t, out):
+        vec(out, nx)[:] = np.asarray(discrete_dynamics(vec(x, nx).copy(), vec(u, nu).copy(), t), dtype=np.float64).reshape(nx)
+
+    def _jac(_, x, u, t, fx, fu):
+        a, b = jacobians(vec(x, nx).copy(), vec(u, nu).copy(), t)
+        vec(fx, nx * nx)[:] = np.asarray(a, dtype=np.float64).reshape(nx * nx); vec(fu, nx * nu)[:] = np.asarray(b, dtype=np.float64).reshape(nx * nu)
+
+    def _hes(_, x, u, t, fxx, fuu, fux):
+        a, b, c2 = hessians(vec(x, nx).copy(), vec(u, nu).copy(), t)
+        vec(fxx, nx * nx * nx)[:] = np.asarray(a, dtype=np.float64).reshape(-1); vec(fuu, nx * nu * nu)[:] = np.asarray(b, dtype=np.float64).reshape(-1)
+        vec(fux, nx * nu * nx)[:] = np.asarray(c2, dtype=np.float64).reshape(-1)
+
+    def _rc(_, x, u, idx):
+        return float(running_cost(vec(x, nx).copy(), vec(u, nu).copy(), idx))
+
+    def _tc(_, x):
+        return float(terminal_cost(vec(x, nx).copy()))
+
+    def _rcd(_, x, u, idx, lx, lu, lxx, luu, lux):
+        a = running_cost_derivatives(vec(x, nx).copy(), vec(u, nu).copy(), idx)
+        for dst, src, n in ((lx, a[0], nx), (lu, a[1], nu), (lxx, a[2], nx * nx), (luu, a[3], nu * nu), (lux, a[4], nu * nx)):
+            vec(dst, n)[:] = np.asarray(src, dtype=np.float64).reshape(n)
+
+    def _tcd(_, x, lx, lxx):
+        a, b = terminal_cost_derivatives(vec(x, nx).copy())
+        vec(lx, nx)[:] = np.asarray(a, dtype=np.float64).reshape(nx); vec(lxx, nx * nx)[:] = np.asarray(b, dtype=np.float64).reshape(nx * nx)
+
+    def _con(_, x, u, idx, g, gx, gu):
+        want = bool(gx) or bool(gu)
+        gv, Gx, Gu = constraints(vec(x, nx).copy(), vec(u, nu).copy(), idx, want)
+        vec(g, m)[:] = np.asarray(gv, dtype=np.float64).reshape(m)
+        if gx: vec(gx, m * nx)[:] = np.asarray(Gx, dtype=np.float64).reshape(m * nx)
+        if gu: vec(gu, m * nu)[:] = np.asarray(Gu, dtype=np.float64).reshape(m * nu)
+
+    ps = PluginStruct()
+    ps.nx, ps.nu, ps.n_constraints = nx, nu, len(constraint_dims)
+    for i, dmy in enumerate(constraint_dims):
+        ps.constraint_dims[i] = int(dmy)
+    keep = [_F_DYN(guard(_dyn)), _F_JAC(guard(_jac)), _F_RC(guard(_rc, 0.0)), _F_TC(guard(_tc, 0.0)), _F_RCD(guard(_rcd)), _F_TCD(guard(_tcd))]
+    ps.discrete_dynamics, ps.jacobians, ps.running_cost, ps.terminal_cost, ps.running_cost_derivatives, ps.terminal_cost_derivatives = keep
+    if hessians is not None:
+        keep.append(_F_HES(guard(_hes))); ps.hessians = keep[-1]
+    if constraints is not None and m > 0:
+        keep.append(_F_CON(guard(_con))); ps.constraints = keep[-1]
+    lo = _arr(control_lower) if control_lower is not None else None
+    up = _arr(control_upper) if control_upper is not None else None
+    ps.control_lower, ps.control_upper = _ptr(lo), _ptr(up)
+    res = np.zeros(B, dtype=RESULT_DTYPE)
+    X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); K = np.zeros((B, N, nu, nx))
+    rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(solver), N, C.c_double(dt), C.byref(options), int(device), B, _ptr(x0), _ptr(U0), _ptr(X0),
+                                   res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K))
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    return res, X, U, K
 
 
 STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP = 0, 1, 2, 3, 4

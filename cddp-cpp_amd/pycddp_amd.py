@@ -7,8 +7,11 @@ constraint kinds the device has kernels for.  On top of it:
 
     solver.solve_batch(x0s, solver_type)   ->  list of CDDPSolution, one per row of x0s (one device-resident batch)
 
-Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Anything the device core does
-not implement raises (custom Python dynamics / objectives, LogDDP, MSIPDDP, use_ilqr=False, un-instantiated layouts).
+Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Python subclasses of `DynamicalSystem`,
+`Objective` / `NonlinearObjective` and `Constraint` (the reference's trampolines, `bind_dynamics.cpp:31-103`, `bind_objective.cpp`,
+`bind_constraints.cpp`) run through the host plug-in solve (`cddp_hip_plugin_solve`: batched backward passes on the GPU, forward
+passes on the host, callbacks into Python); anything the core does not implement raises (LogDDP, MSIPDDP, terminal constraints on
+plug-in problems, un-instantiated layouts).
 """
 import enum
 import importlib.util
@@ -134,38 +137,87 @@ _INTEGRATORS = {"euler": 0, "heun": 1, "rk3": 2, "rk4": 3}
 
 
 class DynamicalSystem:
-    """Device-resident plants only; a Python subclass overriding the dynamics cannot run on the GPU."""
+    """dynamical_system.hpp / bind_dynamics.cpp:31-131.  The built-in plants below are descriptors of device kernels (`model` id);
+    a Python subclass (model None) overrides get_continuous_dynamics (+ Jacobians) and runs through the host plug-in solve."""
     model = None
 
     def __init__(self, state_dim, control_dim, timestep, integration_type="euler"):
-        if type(self) is DynamicalSystem or self.model is None:
-            raise NotImplementedError("custom Python dynamics cannot run on the HIP core: use a built-in plant "
-                                      "(or the stack-fed sweep cddp_hip_backward_stacks)")
         if integration_type not in _INTEGRATORS:
             raise ValueError("Unknown integration type: " + str(integration_type))
         self.state_dim, self.control_dim, self.timestep, self.integration_type = state_dim, control_dim, timestep, integration_type
         self.params = []; self.lti_A = None; self.lti_B = None
 
+    # -- the virtual interface (snake_case names of the pybind layer)
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        raise RuntimeError("get_continuous_dynamics is not implemented for " + type(self).__name__)
 
-class Pendulum(DynamicalSystem):    # bind_dynamics.cpp:133-137
+    def get_discrete_dynamics(self, state, control, time=0.0):   # dynamical_system.cpp:28-83
+        f, dt = self.get_continuous_dynamics, self.timestep
+        x = np.asarray(state, dtype=np.float64); u = np.asarray(control, dtype=np.float64)
+        it = self.integration_type
+        k1 = np.asarray(f(x, u, time), dtype=np.float64)
+        if it == "euler":
+            return x + dt * k1
+        if it == "heun":
+            k2 = np.asarray(f(x + dt * k1, u, time + dt), dtype=np.float64)
+            return x + (0.5 * dt) * (k1 + k2)
+        if it == "rk3":
+            k2 = np.asarray(f(x + (0.5 * dt) * k1, u, time + 0.5 * dt), dtype=np.float64)
+            k3 = np.asarray(f((x - dt * k1) + (2 * dt) * k2, u, time + dt), dtype=np.float64)
+            return x + (dt / 6) * ((k1 + 4.0 * k2) + k3)
+        k2 = np.asarray(f(x + (0.5 * dt) * k1, u, time + 0.5 * dt), dtype=np.float64)
+        k3 = np.asarray(f(x + (0.5 * dt) * k2, u, time + 0.5 * dt), dtype=np.float64)
+        k4 = np.asarray(f(x + dt * k3, u, time + dt), dtype=np.float64)
+        return x + (dt / 6) * (((k1 + 2.0 * k2) + 2.0 * k3) + k4)
+
+    def _no_autodiff(self):   # bind_dynamics.cpp:35-45
+        raise RuntimeError("Python-defined DynamicalSystem objects do not support getContinuousDynamicsAutodiff. Override "
+                           "get_state_jacobian, get_control_jacobian, and any needed Hessian methods in Python, or use a built-in "
+                           "C++ dynamics model.")
+
+    def get_state_jacobian(self, state, control, time=0.0): self._no_autodiff()
+    def get_control_jacobian(self, state, control, time=0.0): self._no_autodiff()
+    def get_state_hessian(self, state, control, time=0.0): self._no_autodiff()
+    def get_control_hessian(self, state, control, time=0.0): self._no_autodiff()
+    def get_cross_hessian(self, state, control, time=0.0): self._no_autodiff()
+
+
+class _BuiltinPlant(DynamicalSystem):
+    """A plant the kernels implement (descriptor: model id + parameters).  Its host-side virtuals evaluate the SAME model source
+    compiled for the host (cddp_hip_model_eval), so it can also be paired with Python objectives / constraints (plug-in solve)."""
+    def _eval(self, state, control, want):
+        api = _api()
+        return api.model_eval(self.model, _INTEGRATORS[self.integration_type], self.timestep, self.params, self.state_dim, self.control_dim,
+                              state, control, want=(want,))[want]
+    def get_discrete_dynamics(self, state, control, time=0.0): return self._eval(state, control, "step")
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        raise NotImplementedError("continuous dynamics of built-in plants are not exported; use get_discrete_dynamics / the Jacobians")
+    def get_state_jacobian(self, state, control, time=0.0): return self._eval(state, control, "jac")[0]
+    def get_control_jacobian(self, state, control, time=0.0): return self._eval(state, control, "jac")[1]
+    def get_state_hessian(self, state, control, time=0.0): return list(self._eval(state, control, "hess")[0])
+    def get_control_hessian(self, state, control, time=0.0): return list(self._eval(state, control, "hess")[1])
+    def get_cross_hessian(self, state, control, time=0.0): return list(self._eval(state, control, "hess")[2])
+
+
+class Pendulum(_BuiltinPlant):    # bind_dynamics.cpp:133-137
     def __init__(self, timestep, length=1.0, mass=1.0, damping=0.0, integration_type="euler"):
         self.model = _api().MODEL_PENDULUM
         super().__init__(2, 1, timestep, integration_type); self.params = [length, mass, damping, 9.81]
 
 
-class CartPole(DynamicalSystem):    # :152-158
+class CartPole(_BuiltinPlant):    # :152-158
     def __init__(self, timestep, integration_type="rk4", cart_mass=1.0, pole_mass=0.2, pole_length=0.5, gravity=9.81, damping=0.0):
         self.model = _api().MODEL_CARTPOLE
         super().__init__(4, 1, timestep, integration_type); self.params = [cart_mass, pole_mass, pole_length, gravity, damping]
 
 
-class Unicycle(DynamicalSystem):    # :139-141
+class Unicycle(_BuiltinPlant):    # :139-141
     def __init__(self, timestep, integration_type="euler"):
         self.model = _api().MODEL_UNICYCLE
         super().__init__(3, 2, timestep, integration_type)
 
 
-class Quadrotor(DynamicalSystem):   # :177-182
+class Quadrotor(_BuiltinPlant):   # :177-182
     def __init__(self, timestep, mass, inertia_matrix, arm_length, integration_type="euler"):
         self.model = _api().MODEL_QUADROTOR
         super().__init__(13, 4, timestep, integration_type)
@@ -173,7 +225,7 @@ class Quadrotor(DynamicalSystem):   # :177-182
         self.params = [mass, arm_length, J[0, 0], J[1, 1], J[2, 2], 9.81]
 
 
-class Manipulator(DynamicalSystem):  # :189-191
+class Manipulator(_BuiltinPlant):  # :189-191
     def __init__(self, timestep, integration_type="rk4"):
         self.model = _api().MODEL_MANIPULATOR
         super().__init__(6, 3, timestep, integration_type)
@@ -190,9 +242,85 @@ class LTISystem(DynamicalSystem):   # :233-237
         super().__init__(A.shape[0], B.shape[1], timestep, integration_type)
         self.lti_A, self.lti_B = A, B
 
+    # host-side evaluation (lti_system.cpp:71-92), used when this plant is paired with a Python objective / constraint
+    def get_discrete_dynamics(self, state, control, time=0.0): return self.lti_A @ np.asarray(state) + self.lti_B @ np.asarray(control)
+    def get_state_jacobian(self, state, control, time=0.0): return (self.lti_A - np.eye(self.state_dim)) / self.timestep
+    def get_control_jacobian(self, state, control, time=0.0): return self.lti_B / self.timestep
+    def get_state_hessian(self, state, control, time=0.0): return [np.zeros((self.state_dim, self.state_dim))] * self.state_dim
+    def get_control_hessian(self, state, control, time=0.0): return [np.zeros((self.control_dim, self.control_dim))] * self.state_dim
+    def get_cross_hessian(self, state, control, time=0.0): return [np.zeros((self.control_dim, self.state_dim))] * self.state_dim
+
 
 # ------------------------------------------------------------------------------------------------ objective / constraints
-class QuadraticObjective:           # objective.hpp: (Q, R, Qf, reference_state, reference_states, timestep)
+class Objective:                    # objective.hpp:30-120: the virtual interface a Python subclass overrides
+    def running_cost(self, state, control, index): raise RuntimeError("running_cost is not implemented")
+    def terminal_cost(self, final_state): raise RuntimeError("terminal_cost is not implemented")
+    def evaluate(self, states, controls):
+        total = 0.0
+        for t in range(len(controls)):
+            total += self.running_cost(states[t], controls[t], t)
+        return total + self.terminal_cost(states[-1])
+
+
+def _fd_gradient(f, x, h=2e-5):     # helper.hpp:34-55 (central differences)
+    x = np.asarray(x, dtype=np.float64); g = np.zeros(x.size); xp = x.copy()
+    for i in range(x.size):
+        xp[i] = x[i] + h; fp = f(xp)
+        xp[i] = x[i] - h; fm = f(xp)
+        g[i] = (fp - fm) / (2.0 * h); xp[i] = x[i]
+    return g
+
+
+def _fd_hessian(f, x, h=2e-5):      # helper.hpp:158-179 (central differences of central-difference gradients)
+    x = np.asarray(x, dtype=np.float64); H = np.zeros((x.size, x.size)); xp = x.copy()
+    for i in range(x.size):
+        xp[i] = x[i] + h; gp = _fd_gradient(f, xp, h)
+        xp[i] = x[i] - h; gm = _fd_gradient(f, xp, h)
+        H[:, i] = (gp - gm) / (2.0 * h); xp[i] = x[i]
+    return H
+
+
+class NonlinearObjective(Objective):   # objective.cpp:156-288: derivatives by finite differences unless overridden
+    def __init__(self, timestep=0.1):
+        self.timestep = timestep
+
+    def running_cost(self, state, control, index): return 0.0
+    def terminal_cost(self, final_state): return 0.0
+    def get_running_cost_state_gradient(self, x, u, index): return _fd_gradient(lambda s: self.running_cost(s, u, index), x)
+    def get_running_cost_control_gradient(self, x, u, index): return _fd_gradient(lambda c: self.running_cost(x, c, index), u)
+    def get_final_cost_gradient(self, x): return _fd_gradient(lambda s: self.terminal_cost(s), x)
+    def get_running_cost_state_hessian(self, x, u, index): return _fd_hessian(lambda s: self.running_cost(s, u, index), x)
+    def get_running_cost_control_hessian(self, x, u, index): return _fd_hessian(lambda c: self.running_cost(x, c, index), u)
+    def get_final_cost_hessian(self, x): return _fd_hessian(lambda s: self.terminal_cost(s), x, 2e-5)
+
+    def get_running_cost_cross_hessian(self, x, u, index):   # objective.cpp:245-277: h = 2e-8, four-point stencil
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64); h = 2e-8
+        M = np.zeros((u.size, x.size))
+        for i in range(u.size):
+            for j in range(x.size):
+                sp = x.copy(); sp[j] += h; sm = x.copy(); sm[j] -= h; cp = u.copy(); cp[i] += h; cm = u.copy(); cm[i] -= h
+                M[i, j] = (self.running_cost(sp, cp, index) - self.running_cost(sp, cm, index) - self.running_cost(sm, cp, index)
+                           + self.running_cost(sm, cm, index)) / (4.0 * h * h)
+        return M
+
+
+class QuadraticObjective(Objective):   # objective.hpp: (Q, R, Qf, reference_state, reference_states, timestep)
+    # host-side evaluation (objective.cpp:80-154), used when this objective meets a Python plant / constraint
+    def _ref(self, index): return self.reference_states[index] if self.reference_states else self.reference_state
+    def running_cost(self, x, u, index):
+        e = np.asarray(x) - self._ref(index)
+        return float(e @ (self.Q * self.timestep) @ e + np.asarray(u) @ (self.R * self.timestep) @ np.asarray(u))
+    def terminal_cost(self, x):
+        e = np.asarray(x) - self.reference_state
+        return float(e @ self.Qf @ e)
+    def get_running_cost_state_gradient(self, x, u, index): return 2.0 * (self.Q * self.timestep) @ (np.asarray(x) - self._ref(index))
+    def get_running_cost_control_gradient(self, x, u, index): return 2.0 * (self.R * self.timestep) @ np.asarray(u)
+    def get_final_cost_gradient(self, x): return 2.0 * self.Qf @ (np.asarray(x) - self.reference_state)
+    def get_running_cost_state_hessian(self, x, u, index): return 2.0 * self.Q * self.timestep
+    def get_running_cost_control_hessian(self, x, u, index): return 2.0 * self.R * self.timestep
+    def get_running_cost_cross_hessian(self, x, u, index): return np.zeros((self.R.shape[0], self.Q.shape[0]))
+    def get_final_cost_hessian(self, x): return 2.0 * self.Qf
+
     def __init__(self, Q, R, Qf, reference_state, reference_states=(), timestep=0.1):
         self.Q = np.asarray(Q, dtype=np.float64); self.R = np.asarray(R, dtype=np.float64); self.Qf = np.asarray(Qf, dtype=np.float64)
         for M_, n in ((self.Q, "Q"), (self.R, "R"), (self.Qf, "Qf")):
@@ -205,23 +333,44 @@ class QuadraticObjective:           # objective.hpp: (Q, R, Qf, reference_state,
         self.timestep = timestep
 
 
-class ControlConstraint:            # constraint.hpp:144-251 (BoxConstraint<Control>)
+class Constraint:                   # constraint.hpp:40-142: the virtual interface a Python subclass overrides
+    """evaluate(x, u), get_upper_bound(), get_state_jacobian(x, u), get_control_jacobian(x, u), get_dual_dim()."""
+    def get_dual_dim(self): return int(np.asarray(self.get_upper_bound()).size)
+
+
+class ControlConstraint(Constraint):   # constraint.hpp:144-251 (BoxConstraint<Control>): g = [-u; u] s, upper = [-lb; ub] s
     def __init__(self, lower_bound, upper_bound, scale_factor=1.0):
         self.lower = np.asarray(lower_bound, dtype=np.float64); self.upper = np.asarray(upper_bound, dtype=np.float64); self.scale = scale_factor
+    def _v(self, x, u): return np.asarray(u, dtype=np.float64)
+    def evaluate(self, x, u): v = self._v(x, u); return np.concatenate([-v, v]) * self.scale
+    def get_upper_bound(self): return np.concatenate([-self.lower, self.upper]) * self.scale
+    def get_state_jacobian(self, x, u): return np.zeros((2 * self.upper.size, np.asarray(x).size))
+    def get_control_jacobian(self, x, u): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
 
 
 class StateConstraint(ControlConstraint):
-    pass
+    def _v(self, x, u): return np.asarray(x, dtype=np.float64)
+    def get_state_jacobian(self, x, u): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
+    def get_control_jacobian(self, x, u): return np.zeros((2 * self.upper.size, np.asarray(u).size))
 
 
-class BallConstraint:               # constraint.hpp:313-404
+class BallConstraint(Constraint):   # constraint.hpp:313-404: g = -s |x[:d] - c|^2, upper = -s r^2
     def __init__(self, radius, center, scale_factor=1.0):
         self.radius = radius; self.center = np.asarray(center, dtype=np.float64); self.scale = scale_factor
+    def evaluate(self, x, u): dlt = np.asarray(x)[:self.center.size] - self.center; return np.array([-self.scale * float(dlt @ dlt)])
+    def get_upper_bound(self): return np.array([-self.scale * self.radius * self.radius])
+    def get_state_jacobian(self, x, u):
+        J = np.zeros((1, np.asarray(x).size)); J[0, :self.center.size] = -2.0 * self.scale * (np.asarray(x)[:self.center.size] - self.center); return J
+    def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
 
 
-class LinearConstraint:             # constraint.hpp:253-311
+class LinearConstraint(Constraint):   # constraint.hpp:253-311: g = A x, upper = b
     def __init__(self, A, b, scale_factor=1.0):
         self.A = np.asarray(A, dtype=np.float64); self.b = np.asarray(b, dtype=np.float64)
+    def evaluate(self, x, u): return self.A @ np.asarray(x)
+    def get_upper_bound(self): return self.b
+    def get_state_jacobian(self, x, u): return self.A
+    def get_control_jacobian(self, x, u): return np.zeros((self.b.size, np.asarray(u).size))
 
 
 class TerminalEqualityConstraint:   # terminal_constraint.hpp
@@ -271,11 +420,11 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def set_options(self, options): self._opt = options
     def set_dynamical_system(self, system):
         if not isinstance(system, DynamicalSystem):
-            raise TypeError("set_dynamical_system expects a built-in plant of this module")
+            raise TypeError("set_dynamical_system expects a DynamicalSystem (a built-in plant or a Python subclass)")
         self._sys = system
     def set_objective(self, objective):
-        if not isinstance(objective, QuadraticObjective):
-            raise NotImplementedError("only QuadraticObjective runs on the HIP core")
+        if not isinstance(objective, Objective):
+            raise TypeError("set_objective expects an Objective (QuadraticObjective or a Python subclass)")
         self._obj = objective
     def add_constraint(self, name, constraint):
         if constraint is None:
@@ -336,6 +485,8 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
             sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
             return [sol for _ in range(len(x0s))]
         kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_CLDDP
+        if self._needs_host_plugins():
+            return self._solve_plugins(name, kind, x0s)
         p = self._problem(kind)
         B = len(x0s)
         x0 = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64) for x in x0s]))
@@ -371,6 +522,74 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                 s.history.barrier_mu = list(h[:, 7]) if name == "IPDDP" else []
                 s.history.regularization = list(h[:, 8])
             out.append(s)
+        return out
+
+    # -- host plug-in path: Python subclasses of DynamicalSystem / Objective / Constraint (cddp_hip_plugin_solve)
+    def _needs_host_plugins(self):
+        if self._sys is None or self._obj is None:
+            return False
+        builtin_con = (ControlConstraint, StateConstraint, BallConstraint, LinearConstraint)
+        return (self._sys.model is None or type(self._obj) is not QuadraticObjective
+                or any(type(c) not in builtin_con for c in self._cons.values()))
+
+    def _solve_plugins(self, name, kind, x0s):
+        api = _api()
+        if self._terms:
+            raise NotImplementedError("terminal constraints are not supported on host plug-in problems")
+        s, ob = self._sys, self._obj
+        nx, nu, N, dt = s.state_dim, s.control_dim, self._N, self._dt
+        names = sorted(self._cons)          # std::map order
+        ipddp = kind == api.SOLVER_IPDDP
+        cons = [self._cons[n] for n in names] if ipddp else []
+        dims = [int(c.get_dual_dim()) for c in cons]
+        lo = up = None
+        if not ipddp and "ControlConstraint" in self._cons and isinstance(self._cons["ControlConstraint"], ControlConstraint):
+            lo, up = self._cons["ControlConstraint"].lower, self._cons["ControlConstraint"].upper   # clddp_solver.cpp:85-86
+
+        def constraints(x, u, index, want):
+            g = np.concatenate([np.asarray(c.evaluate(x, u), dtype=np.float64) - np.asarray(c.get_upper_bound(), dtype=np.float64) for c in cons])
+            if not want:
+                return g, None, None
+            return (g, np.vstack([np.asarray(c.get_state_jacobian(x, u), dtype=np.float64).reshape(-1, nx) for c in cons]),
+                    np.vstack([np.asarray(c.get_control_jacobian(x, u), dtype=np.float64).reshape(-1, nu) for c in cons]))
+
+        def hessians(x, u, t):
+            return (np.stack([np.asarray(h) for h in s.get_state_hessian(x, u, t)]), np.stack([np.asarray(h) for h in s.get_control_hessian(x, u, t)]),
+                    np.stack([np.asarray(h) for h in s.get_cross_hessian(x, u, t)]))
+
+        B = len(x0s)
+        x0 = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64) for x in x0s]))
+        U0 = None if self._U is None else np.ascontiguousarray(np.tile(self._U, (B, 1, 1)))
+        X0 = None if self._X is None else np.ascontiguousarray(np.tile(self._X, (B, 1, 1)))
+        import time as _time
+        t0 = _time.perf_counter()
+        res, X, U, K = api.plugin_solve(
+            kind, nx, nu, N, dt, self._opt.to_pod(), x0, U0, X0,
+            discrete_dynamics=lambda x, u, t: s.get_discrete_dynamics(x, u, t),
+            jacobians=(lambda x, u, t: s._eval(x, u, "jac")) if isinstance(s, _BuiltinPlant) else
+                      (lambda x, u, t: (s.get_state_jacobian(x, u, t), s.get_control_jacobian(x, u, t))),
+            hessians=None if self._opt.use_ilqr else hessians,
+            running_cost=lambda x, u, i: ob.running_cost(x, u, i), terminal_cost=lambda x: ob.terminal_cost(x),
+            running_cost_derivatives=lambda x, u, i: (ob.get_running_cost_state_gradient(x, u, i), ob.get_running_cost_control_gradient(x, u, i),
+                                                      ob.get_running_cost_state_hessian(x, u, i), ob.get_running_cost_control_hessian(x, u, i),
+                                                      ob.get_running_cost_cross_hessian(x, u, i)),
+            terminal_cost_derivatives=lambda x: (ob.get_final_cost_gradient(x), ob.get_final_cost_hessian(x)),
+            constraints=constraints if cons else None, constraint_dims=dims, control_lower=lo, control_upper=up)
+        ms = (_time.perf_counter() - t0) * 1e3
+        out = []
+        for b in range(B):
+            sol = CDDPSolution()
+            sol.solver_name = name; sol.status_message = api.STATUS_STRINGS[int(res["status"][b])]
+            sol.iterations_completed = int(res["iterations"][b]); sol.solve_time_ms = ms
+            sol.final_objective = float(res["final_objective"][b]); sol.final_step_length = float(res["alpha_pr"][b])
+            sol.final_regularization = float(res["regularization"][b])
+            sol.final_primal_infeasibility = float(res["inf_pr"][b]); sol.final_dual_infeasibility = float(res["inf_du"][b])
+            sol.final_complementary_infeasibility = float(res["inf_comp"][b]); sol.final_barrier_mu = float(res["barrier_mu"][b])
+            sol.time_points = [t * dt for t in range(N + 1)]
+            sol.state_trajectory = [X[b, t].copy() for t in range(N + 1)]
+            sol.control_trajectory = [U[b, t].copy() for t in range(N)]
+            sol.feedback_gains = [K[b, t].copy() for t in range(N)]
+            out.append(sol)
         return out
 
     def solve(self, solver_type=SolverType.CLDDP):

@@ -49,7 +49,9 @@ enum cddp_hip_model {
   CDDP_HIP_MODEL_QUADROTOR = 4,  /* nx=13 quaternion; params: mass, arm, Ixx,Iyy,Izz, gravity   */
   CDDP_HIP_MODEL_MANIPULATOR = 5,/* 3-DOF, central-FD Jacobians h=2e-5; params: (none)          */
   CDDP_HIP_MODEL_QUADROTOR_EULER12 = 6, /* SYNTHETIC nx=12 (BASELINE config 4 shape)            */
-  CDDP_HIP_MODEL_MANIPULATOR7 = 7       /* SYNTHETIC nx=14/nu=7 (BASELINE config 5 shape)       */
+  CDDP_HIP_MODEL_MANIPULATOR7 = 7,      /* SYNTHETIC nx=14/nu=7 (BASELINE config 5 shape)       */
+  CDDP_HIP_MODEL_BICYCLE = 8,    /* kinematic bicycle [x,y,theta,v] / [a,delta] (bicycle.cpp); params: wheelbase            */
+  CDDP_HIP_MODEL_CAR = 9         /* DISCRETE car [x,y,theta,v] / [delta,a] (car.cpp:24-60, h = dt); params: wheelbase      */
 };
 
 /* reference src/cddp_core/dynamical_system.cpp:28-83 */
@@ -495,6 +497,60 @@ int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
                              const double *lux, const double *VxN, const double *VxxN,
                              double reg, int reg_in_value, double *K, double *k, double *Vx,
                              double *Vxx, double *dV, int32_t *ok, double *kernel_ms);
+
+/* ---- host plug-in solve (north_star: "keeps cddp-cpp's DynamicsModel / Constraint / Objective plugin surface") ----------------
+ * CDDP::solve() for problems whose DynamicalSystem / Objective / Constraint objects are arbitrary HOST subclasses (the reference's
+ * QuadraticScalarSystem of tests/cddp_core/test_ipddp_solver.cpp:291-346, Python plug-ins of python/tests/test_custom_dynamics.py,
+ * NonlinearObjective subclasses ...).  The callbacks are the reference's virtual functions, flattened to plain pointers:
+ *   discrete_dynamics            DynamicalSystem::getDiscreteDynamics(x, u, t)                       (dynamical_system.hpp)
+ *   jacobians                    getStateJacobian / getControlJacobian: CONTINUOUS-time f_x (nx x nx), f_u (nx x nu), row-major;
+ *                                the library forms A = I + dt f_x, B = dt f_u (cddp_solver_base.cpp:340-344)
+ *   hessians                     getStateHessian / getControlHessian / getCrossHessian (needed iff options.use_ilqr == 0):
+ *                                fxx[i] (nx x nx), fuu[i] (nu x nu), fux[i] (nu x nx), i = output row of f; or NULL
+ *   running_cost, terminal_cost  Objective::running_cost(x, u, index), terminal_cost(x_N)           (objective.hpp)
+ *   running_cost_derivatives     l_x (nx), l_u (nu), l_xx (nx x nx), l_uu (nu x nu), l_ux (nu x nx)
+ *   terminal_cost_derivatives    getFinalCostGradient (nx), getFinalCostHessian (nx x nx)
+ *   constraints                  the path-constraint set, stacked in std::map (name) order: g = evaluate(x, u) - getUpperBound()
+ *                                (m rows), getStateJacobian (m x nx), getControlJacobian (m x nu); gx / gu may be NULL when only g
+ *                                is wanted.  n_constraints objects of constraint_dims[] rows each (the reference sums the
+ *                                barrier / violation terms constraint by constraint, ipddp_solver.cpp:2778-2937).
+ *   control_lower / control_upper  CLDDP only: the bounds of the constraint literally named "ControlConstraint"
+ *                                (clddp_solver.cpp:85-86, 147-178, 227-228) or NULL; CLDDP ignores every other constraint.
+ * The GPU runs the backward pass of the whole batch (stack-fed sweeps above); the forward pass needs the plug-in's f(x, u) and runs
+ * on the host (csrc/plugin_solve.hip).  All trajectories of the batch share the plug-in; they differ in x0 / U0 / X0.  Callbacks are
+ * called from the calling thread only.  Not supported: terminal constraints, warm starts (use the built-in plants for those). */
+/* Host evaluation of a BUILT-IN plant (the kernels' own model source compiled for the host, csrc/host_models.cpp): the reference's
+ * DynamicalSystem::getDiscreteDynamics (x_next), getStateJacobian / getControlJacobian (continuous-time f_x nx*nx, f_u nx*nu,
+ * row-major) and getStateHessian / getControlHessian / getCrossHessian (fxx[i] nx*nx, fuu[i] nu*nu, fux[i] nu*nx per state row i;
+ * the three come together) for one (x, u).  Any output may be NULL.  This is what lets a built-in plant be paired with a user
+ * Objective / Constraint in the plug-in solve below (the reference's car-parking test has exactly that shape).  model_params:
+ * CDDP_HIP_MAX_MODEL_PARAMS doubles as in cddp_hip_problem.  LTI plants are not served here (x+ = A x + B u is the caller's). */
+int cddp_hip_model_eval(int model /* cddp_hip_model */, int integrator /* cddp_hip_integrator */, double dt, const double *model_params,
+                        int nx, int nu, const double *x, const double *u, double *x_next, double *fx, double *fu,
+                        double *fxx, double *fuu, double *fux);
+
+#define CDDP_HIP_PLUGIN_MAX_CONSTRAINTS 8
+typedef struct cddp_hip_plugin {
+  void *user;
+  int32_t nx, nu;
+  int32_t n_constraints;
+  int32_t constraint_dims[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS];
+  void (*discrete_dynamics)(void *user, const double *x, const double *u, double time, double *x_next);
+  void (*jacobians)(void *user, const double *x, const double *u, double time, double *fx, double *fu);
+  void (*hessians)(void *user, const double *x, const double *u, double time, double *fxx, double *fuu, double *fux);
+  double (*running_cost)(void *user, const double *x, const double *u, int index);
+  double (*terminal_cost)(void *user, const double *x);
+  void (*running_cost_derivatives)(void *user, const double *x, const double *u, int index, double *lx, double *lu, double *lxx, double *luu, double *lux);
+  void (*terminal_cost_derivatives)(void *user, const double *x, double *lx, double *lxx);
+  void (*constraints)(void *user, const double *x, const double *u, int index, double *g, double *gx, double *gu);
+  const double *control_lower, *control_upper;
+} cddp_hip_plugin;
+/* ISolverAlgorithm::initialize + solve for `batch` trajectories of a host plug-in problem.  x0: batch*nx; U0: batch*N*nu or NULL
+ * (zeros); X0: batch*(N+1)*nx or NULL (x0 replicated).  results: batch records; X (batch*(N+1)*nx), U (batch*N*nu), K
+ * (batch*N*nu*nx, feedback gains of the last sweep) may be NULL. */
+int cddp_hip_plugin_solve(const cddp_hip_plugin *plugin, int solver /* cddp_hip_solver */, int horizon, double dt,
+                          const cddp_hip_options *options, int device, int batch, const double *x0, const double *U0, const double *X0,
+                          cddp_hip_result *results, double *X, double *U, double *K);
 
 #ifdef __cplusplus
 }

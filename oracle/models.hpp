@@ -69,36 +69,40 @@ inline double olog(double x) { return trig_mode() == 1 ? cddp_dev::log_shared(x)
 inline double opow(double x, double y) { return trig_mode() == 1 ? cddp_dev::pow_shared(x, y) : std::pow(x, y); }
 inline double osin(double a) { return trig_perturb(base_sin(a), a); }
 inline double ocos(double a) { return trig_perturb(base_cos(a), a + 0.5); }
+inline double otan(double a) { return trig_mode() == 1 ? base_sin(a) / base_cos(a) : std::tan(a); }   // parity build: sin / cos of the shared routine
+inline double tan(double a) { return otan(a); }
 inline double sin(double a) { return osin(a); }   // found by the unqualified calls of the templated dynamics (S = double)
 inline double cos(double a) { return ocos(a); }
 inline Dual sin(const Dual &a) { Dual r; r.v = osin(a.v); double c = ocos(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = c * a.d[i]; return r; }
 inline Dual cos(const Dual &a) { Dual r; r.v = ocos(a.v); double s = -osin(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = s * a.d[i]; return r; }
 inline Dual sqrt(const Dual &a) { Dual r; r.v = std::sqrt(a.v); double g = 0.5 / r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
-inline Dual tan(const Dual &a) { Dual r; r.v = std::tan(a.v); double g = 1.0 + r.v * r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
+inline Dual tan(const Dual &a) { Dual r; r.v = otan(a.v); double g = 1.0 + r.v * r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
+inline Dual asin(const Dual &a) { Dual r; r.v = std::asin(a.v); double g = 1.0 / std::sqrt(1.0 - a.v * a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
 
 // Second-order forward mode (autodiff::dual2nd of the reference, dynamical_system.cpp:137-217, restated): value, gradient and
 // Hessian w.r.t. up to kD2 seeded variables z = [x, u].  Only used for the plants whose Hessians the reference takes from
 // autodiff (CartPole).
-constexpr int kD2 = 6;
+constexpr int kD2 = 17;   // quadrotor: 13 + 4 seeds
 struct Dual2 {
   double v = 0.0, d[kD2], h[kD2][kD2];
-  Dual2() { for (int i = 0; i < kD2; ++i) { d[i] = 0.0; for (int j = 0; j < kD2; ++j) h[i][j] = 0.0; } }
+  static int &n() { static thread_local int k = 0; return k; }   // active seeds (set by Model::hessians)
+  Dual2() { for (int i = 0; i < n(); ++i) { d[i] = 0.0; for (int j = 0; j < n(); ++j) h[i][j] = 0.0; } }
   Dual2(double x) : Dual2() { v = x; }
 };
 // r = phi(a) with phi', phi'' given:  grad = phi' a_d ; hess = phi'' a_d a_d^T + phi' a_h
 inline Dual2 d2_unary(const Dual2 &a, double val, double p1, double p2) {
   Dual2 r; r.v = val;
-  for (int i = 0; i < kD2; ++i) { r.d[i] = p1 * a.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = p2 * a.d[i] * a.d[j] + p1 * a.h[i][j]; }
+  for (int i = 0; i < Dual2::n(); ++i) { r.d[i] = p1 * a.d[i]; for (int j = 0; j < Dual2::n(); ++j) r.h[i][j] = p2 * a.d[i] * a.d[j] + p1 * a.h[i][j]; }
   return r;
 }
-inline Dual2 operator+(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v + b.v; for (int i = 0; i < kD2; ++i) { r.d[i] = a.d[i] + b.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
-inline Dual2 operator-(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v - b.v; for (int i = 0; i < kD2; ++i) { r.d[i] = a.d[i] - b.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] - b.h[i][j]; } return r; }
-inline Dual2 operator-(const Dual2 &a) { Dual2 r; r.v = -a.v; for (int i = 0; i < kD2; ++i) { r.d[i] = -a.d[i]; for (int j = 0; j < kD2; ++j) r.h[i][j] = -a.h[i][j]; } return r; }
+inline Dual2 operator+(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v + b.v; for (int i = 0; i < Dual2::n(); ++i) { r.d[i] = a.d[i] + b.d[i]; for (int j = 0; j < Dual2::n(); ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
+inline Dual2 operator-(const Dual2 &a, const Dual2 &b) { Dual2 r; r.v = a.v - b.v; for (int i = 0; i < Dual2::n(); ++i) { r.d[i] = a.d[i] - b.d[i]; for (int j = 0; j < Dual2::n(); ++j) r.h[i][j] = a.h[i][j] - b.h[i][j]; } return r; }
+inline Dual2 operator-(const Dual2 &a) { Dual2 r; r.v = -a.v; for (int i = 0; i < Dual2::n(); ++i) { r.d[i] = -a.d[i]; for (int j = 0; j < Dual2::n(); ++j) r.h[i][j] = -a.h[i][j]; } return r; }
 inline Dual2 operator*(const Dual2 &a, const Dual2 &b) {
   Dual2 r; r.v = a.v * b.v;
-  for (int i = 0; i < kD2; ++i) {
+  for (int i = 0; i < Dual2::n(); ++i) {
     r.d[i] = a.d[i] * b.v + a.v * b.d[i];
-    for (int j = 0; j < kD2; ++j) r.h[i][j] = a.h[i][j] * b.v + a.d[i] * b.d[j] + a.d[j] * b.d[i] + a.v * b.h[i][j];
+    for (int j = 0; j < Dual2::n(); ++j) r.h[i][j] = a.h[i][j] * b.v + a.d[i] * b.d[j] + a.d[j] * b.d[i] + a.v * b.h[i][j];
   }
   return r;
 }
@@ -106,6 +110,9 @@ inline Dual2 d2_recip(const Dual2 &b) { const double inv = 1.0 / b.v; return d2_
 inline Dual2 operator/(const Dual2 &a, const Dual2 &b) { return a * d2_recip(b); }
 inline Dual2 sin(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, s, c, -s); }
 inline Dual2 cos(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, c, -s, -c); }
+inline Dual2 sqrt(const Dual2 &a) { const double r = std::sqrt(a.v); return d2_unary(a, r, 0.5 / r, -0.25 / (a.v * r)); }
+inline Dual2 asin(const Dual2 &a) { const double w = 1.0 - a.v * a.v, r = std::sqrt(w); return d2_unary(a, std::asin(a.v), 1.0 / r, a.v / (w * r)); }
+inline Dual2 tan(const Dual2 &a) { const double t = otan(a.v), g = 1.0 + t * t; return d2_unary(a, t, g, 2.0 * t * g); }
 
 struct Model {
   int id = 0, nx = 0, nu = 0, integrator = 0;
@@ -176,6 +183,7 @@ struct Model {
   }
   static double val(double v) { return v; }
   static double val(const Dual &v) { return v.v; }
+  static double val(const Dual2 &v) { return v.v; }
 
   void manipulator_f(const double *x, const double *u, double *xd) const {
     // manipulator.cpp:29-51, 174-208 (la=1, lb=0.2, lc=1, g=9.81; manipulator.hpp:153-156)
@@ -197,6 +205,75 @@ struct Model {
     for (int i = 0; i < 3; ++i) rhs(i) = u[i] - G(i);
     Vec ddq = inversePartialPivLU(M) * rhs;
     for (int i = 0; i < 3; ++i) { xd[i] = dq[i]; xd[3 + i] = ddq(i); }
+  }
+
+  // manipulator.cpp:210-275: the autodiff path (the base class's Hessian defaults differentiate THIS, dynamical_system.cpp:137-217):
+  // ddq = M(q).inverse() * (tau - G(q)) with Eigen's generic inverse (PartialPivLU) in dual arithmetic
+  template <typename S>
+  void manipulator_f_ad(const S *x, const S *u, S *xd) const {
+    const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81, m1 = 1.0, m2 = 1.0, m3 = 0.5;
+    const S cos_q1 = cos(x[1]), cos_q2 = cos(x[2]), cos_q12 = cos(x[1] + x[2]);
+    S M[3][3];
+    M[0][0] = S((m1 + m2 + m3) * (la * la)); M[1][1] = S((m2 + m3) * (lb * lb)); M[2][2] = S(m3 * (lc * lc));
+    M[0][1] = M[1][0] = S((m2 + m3) * la * lb) * cos_q1;
+    M[1][2] = M[2][1] = S(m3 * lb * lc) * cos_q2;
+    M[0][2] = M[2][0] = S(m3 * la * lc) * cos_q12;
+    S G[3];
+    G[0] = S(0.0);
+    G[1] = S(-(m2 + m3) * grav * lb) * cos(x[1]) - S(m3 * grav * lc) * cos_q12;
+    G[2] = S(-m3 * grav * lc) * cos_q12;
+    // PartialPivLU of M (row pivoting on |value|), then inverse = U^-1 L^-1 P applied to the right-hand side
+    int perm[3] = {0, 1, 2};
+    for (int k = 0; k < 3; ++k) {
+      int piv = k; double best = std::fabs(val2(M[k][k]));
+      for (int r = k + 1; r < 3; ++r) if (std::fabs(val2(M[r][k])) > best) { best = std::fabs(val2(M[r][k])); piv = r; }
+      if (piv != k) { for (int c = 0; c < 3; ++c) std::swap(M[k][c], M[piv][c]); std::swap(perm[k], perm[piv]); }
+      for (int r = k + 1; r < 3; ++r) {
+        M[r][k] = M[r][k] / M[k][k];
+        for (int c = k + 1; c < 3; ++c) M[r][c] = M[r][c] - M[r][k] * M[k][c];
+      }
+    }
+    S rhs[3], y[3], z[3];
+    for (int i = 0; i < 3; ++i) rhs[i] = u[i] - G[i];
+    for (int i = 0; i < 3; ++i) { y[i] = rhs[perm[i]]; for (int c = 0; c < i; ++c) y[i] = y[i] - M[i][c] * y[c]; }
+    for (int i = 2; i >= 0; --i) { z[i] = y[i]; for (int c = i + 1; c < 3; ++c) z[i] = z[i] - M[i][c] * z[c]; z[i] = z[i] / M[i][i]; }
+    for (int i = 0; i < 3; ++i) { xd[i] = x[3 + i]; xd[3 + i] = z[i]; }
+  }
+  static double val2(double v) { return v; }
+  static double val2(const Dual2 &v) { return v.v; }
+  static double val2(const Dual &v) { return v.v; }
+
+  // bicycle.cpp:28-45 (double) == :47-66 (autodiff); params: wheelbase; state [x, y, theta, v], control [a, delta]
+  template <typename S>
+  void bicycle_f(const S *x, const S *u, S *xd) const {
+    const double L = p[0];
+    const S theta = x[2], v = x[3], a = u[0], delta = u[1];
+    xd[0] = v * cos(theta);
+    xd[1] = v * sin(theta);
+    xd[2] = (v / S(L)) * tan(delta);
+    xd[3] = a;
+  }
+
+  // car.cpp:24-60 (getDiscreteDynamics, double) and :164-216 (getDiscreteDynamicsAutodiff: the same tree plus the two clamps);
+  // params: wheelbase; state [x, y, theta, v], control [steering delta, acceleration a]; a DISCRETE plant: h = timestep
+  template <typename S>
+  void car_next(const S *x, const S *u, S *xn, bool clamps) const {
+    using std::sqrt; using std::asin;
+    const double d = p[0], h = dt;
+    const S theta = x[2], v = x[3], delta = u[0], a = u[1];
+    const S cos_theta = cos(theta), sin_theta = sin(theta);
+    const S f = S(h) * v;
+    const S f_sin_delta = f * sin(delta);
+    S inside = S(d * d) - f_sin_delta * f_sin_delta;
+    if (clamps && val2(inside) < 0.0) inside = S(0.0);
+    const S b = S(d) + f * cos(delta) - sqrt(inside);
+    S asin_arg = sin(delta) * f / S(d);
+    if (clamps && std::fabs(val2(asin_arg)) > 1.0) asin_arg = S(val2(asin_arg) > 0.0 ? 1.0 : -1.0);
+    const S dtheta = asin(asin_arg);
+    xn[0] = x[0] + b * cos_theta;
+    xn[1] = x[1] + b * sin_theta;
+    xn[2] = x[2] + dtheta;
+    xn[3] = x[3] + S(h) * a;
   }
 
   // SYNTHETIC (not in the reference): BASELINE config 4 shape nx=12 -- the same rigid-body
@@ -278,6 +355,12 @@ struct Model {
       }
       case CDDP_HIP_MODEL_QUADROTOR: quadrotor_f<double>(x, u, xd); break;
       case CDDP_HIP_MODEL_MANIPULATOR: manipulator_f(x, u, xd); break;
+      case CDDP_HIP_MODEL_BICYCLE: bicycle_f<double>(x, u, xd); break;
+      case CDDP_HIP_MODEL_CAR: {   // DynamicalSystem::getContinuousDynamics default (dynamical_system.cpp:85-99): (x+ - x) / dt
+        double xn[4]; car_next<double>(x, u, xn, false);
+        for (int i = 0; i < 4; ++i) xd[i] = (xn[i] - x[i]) / dt;
+        break;
+      }
       case CDDP_HIP_MODEL_QUADROTOR_EULER12: quad12_f<double>(x, u, xd); break;
       case CDDP_HIP_MODEL_MANIPULATOR7: manip7_f<double>(x, u, xd); break;
       default: std::fprintf(stderr, "oracle: unknown model %d\n", id); std::abort();
@@ -287,6 +370,7 @@ struct Model {
   // ------------------------------------------------ discrete dynamics (dynamical_system.cpp:28-83)
   Vec step(const Vec &x, const Vec &u, double time) const {
     if (id == CDDP_HIP_MODEL_LTI) return A * x + B * u;  // lti_system.cpp:71-76
+    if (id == CDDP_HIP_MODEL_CAR) { Vec xn(4, 1); car_next<double>(x.a, u.a, xn.a, false); return xn; }   // car.cpp:24-60 overrides getDiscreteDynamics
     const int n = nx;
     auto F = [&](const Vec &xx, double tt) { Vec k(n, 1); f(xx.a, u.a, tt, k.a); return k; };
     switch (integrator) {
@@ -332,6 +416,21 @@ struct Model {
   // f_ux[i] (nu x nx), each with the reference's own source: analytic overrides where the model has them, the autodiff
   // default (dynamical_system.cpp:137-217) on getContinuousDynamicsAutodiff otherwise.  Returns false for plants without
   // a restated Hessian (use_ilqr = false is then refused).
+  template <typename FN>
+  void ad_hess(FN fn, const Vec &x, const Vec &u, std::vector<Mat> &Fxx, std::vector<Mat> &Fuu, std::vector<Mat> &Fux, double div = 1.0) const {
+    Dual2::n() = nx + nu;
+    std::vector<Dual2> xs(nx), us(nu), xd(nx);
+    for (int i = 0; i < nx; ++i) { xs[i] = Dual2(x(i)); xs[i].d[i] = 1.0; }
+    for (int j = 0; j < nu; ++j) { us[j] = Dual2(u(j)); us[j].d[nx + j] = 1.0; }
+    fn(xs.data(), us.data(), xd.data());
+    for (int i = 0; i < nx; ++i) {
+      for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) Fxx[i](a, b) = xd[i].h[a][b] / div;
+      for (int a = 0; a < nu; ++a) for (int b = 0; b < nu; ++b) Fuu[i](a, b) = xd[i].h[nx + a][nx + b] / div;
+      for (int a = 0; a < nu; ++a) for (int b = 0; b < nx; ++b) Fux[i](a, b) = xd[i].h[nx + a][b] / div;
+    }
+    Dual2::n() = 0;
+  }
+
   bool hessians(const Vec &x, const Vec &u, double /*time*/, std::vector<Mat> &Fxx, std::vector<Mat> &Fuu, std::vector<Mat> &Fux) const {
     Fxx.assign(nx, Mat::Zero(nx, nx)); Fuu.assign(nx, Mat::Zero(nu, nu)); Fux.assign(nx, Mat::Zero(nu, nx));
     switch (id) {
@@ -348,18 +447,35 @@ struct Model {
         return true;
       }
       case CDDP_HIP_MODEL_LTI: return true;   // lti_system.cpp:94-115: zero
-      case CDDP_HIP_MODEL_CARTPOLE: {         // cartpole.cpp:191-199 -> DynamicalSystem defaults (dual2nd through the autodiff path)
-        Dual2 xs[4], us[1], xd[4];
-        for (int i = 0; i < 4; ++i) { xs[i] = Dual2(x(i)); xs[i].d[i] = 1.0; }
-        us[0] = Dual2(u(0)); us[0].d[4] = 1.0;
-        cartpole_f<Dual2>(xs, us, xd, true);
-        for (int i = 0; i < 4; ++i) {
-          for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Fxx[i](a, b) = xd[i].h[a][b];
-          Fuu[i](0, 0) = xd[i].h[4][4];
-          for (int b = 0; b < 4; ++b) Fux[i](0, b) = xd[i].h[4][b];
-        }
+      case CDDP_HIP_MODEL_CARTPOLE:           // cartpole.cpp:191-199 -> DynamicalSystem defaults (dual2nd through the autodiff path)
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { cartpole_f<Dual2>(xs, us, xd, true); }, x, u, Fxx, Fuu, Fux);
+        return true;
+      case CDDP_HIP_MODEL_BICYCLE: {          // bicycle.cpp:113-156 analytic state / control Hessians; cross = base default (autodiff)
+        std::vector<Mat> sx, su;
+        sx.assign(nx, Mat::Zero(nx, nx)); su.assign(nx, Mat::Zero(nu, nu));
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { bicycle_f<Dual2>(xs, us, xd); }, x, u, sx, su, Fux);
+        const double L = p[0], theta = x(2), v = x(3), delta = u(1);
+        Fxx[0](2, 2) = -v * ocos(theta); Fxx[0](2, 3) = -osin(theta); Fxx[0](3, 2) = -osin(theta);
+        Fxx[1](2, 2) = -v * osin(theta); Fxx[1](2, 3) = ocos(theta); Fxx[1](3, 2) = ocos(theta);
+        const double c = ocos(delta);
+        Fuu[2](1, 1) = 2.0 * v * osin(delta) / (L * (c * c * c));   // std::pow(cos, 3) in the reference
         return true;
       }
+      case CDDP_HIP_MODEL_CAR:                // car.cpp:113-161: hessian of the discrete map / timestep; cross = base default on (x+ - x) / dt
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { car_next<Dual2>(xs, us, xd, true); }, x, u, Fxx, Fuu, Fux, dt);
+        return true;
+      case CDDP_HIP_MODEL_MANIPULATOR: {      // manipulator.cpp:72-86: state / control Hessians are ZERO overrides; cross = base default
+        std::vector<Mat> sx, su;
+        sx.assign(nx, Mat::Zero(nx, nx)); su.assign(nx, Mat::Zero(nu, nu));
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { manipulator_f_ad<Dual2>(xs, us, xd); }, x, u, sx, su, Fux);
+        return true;
+      }
+      case CDDP_HIP_MODEL_QUADROTOR:          // quadrotor.cpp:224-278: dual2nd through the normalised-quaternion dynamics.  The reference's
+        // getCrossHessian returns nx x nu matrices (a Jacobian over u of the x-gradient) where the solvers add nu x nx blocks
+        // (ipddp_solver.cpp:1070-1082): an Eigen size mismatch, i.e. use_ilqr = false is not defined behaviour for this plant there.
+        // Restated with the block the solver's formula needs (d2 f_i / du dx, nu x nx).
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { quadrotor_f<Dual2>(xs, us, xd); }, x, u, Fxx, Fuu, Fux);
+        return true;
       default: return false;
     }
   }
@@ -397,6 +513,22 @@ struct Model {
       case CDDP_HIP_MODEL_QUADROTOR:
         ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { quadrotor_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
         break;
+      case CDDP_HIP_MODEL_BICYCLE: {   // bicycle.cpp:68-111 analytic
+        const double L = p[0], theta = x(2), v = x(3), delta = u(1);
+        Fx(0, 2) = -v * osin(theta); Fx(0, 3) = ocos(theta);
+        Fx(1, 2) = v * ocos(theta); Fx(1, 3) = osin(theta);
+        Fx(2, 3) = otan(delta) / L;
+        Fu(3, 0) = 1.0;
+        const double c = ocos(delta);
+        Fu(2, 1) = v / (L * (c * c));   // std::pow(cos, 2)
+        break;
+      }
+      case CDDP_HIP_MODEL_CAR: {       // car.cpp:62-111: autodiff of the DISCRETE map, J.diagonal() -= 1, J /= timestep
+        ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { car_next<Dual>(xs, us, xd, true); }, x, u, Fx, Fu);
+        for (int i = 0; i < nx; ++i) Fx(i, i) -= 1.0;
+        Fx = Fx / dt; Fu = Fu / dt;
+        break;
+      }
       case CDDP_HIP_MODEL_QUADROTOR_EULER12:
         ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { quad12_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
         break;

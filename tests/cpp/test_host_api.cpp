@@ -21,6 +21,68 @@ class MockExternalSolver : public cddp::ISolverAlgorithm {   // test_cddp_core.c
   bool initialized = false;
 };
 
+// ---- user-defined plug-ins (host subclasses of the reference's virtual interfaces) ----
+class QuadraticScalarSystem final : public cddp::DynamicalSystem {   // tests/cddp_core/test_ipddp_solver.cpp:291-346
+ public:
+  QuadraticScalarSystem() : cddp::DynamicalSystem(1, 1, 1.0, "euler") {}
+  cddp::Vector getDiscreteDynamics(const cddp::Vector &x, const cddp::Vector &u, double) const override { return {x[0] + u[0] + 0.5 * x[0] * x[0]}; }
+  cddp::Matrix getStateJacobian(const cddp::Vector &x, const cddp::Vector &, double) const override { cddp::Matrix J(1, 1); J(0, 0) = 1.0 + x[0]; return J; }
+  cddp::Matrix getControlJacobian(const cddp::Vector &, const cddp::Vector &, double) const override { return cddp::Matrix::Identity(1); }
+  std::vector<cddp::Matrix> getStateHessian(const cddp::Vector &, const cddp::Vector &, double) const override { return {cddp::Matrix::Identity(1)}; }
+  std::vector<cddp::Matrix> getControlHessian(const cddp::Vector &, const cddp::Vector &, double) const override { return {cddp::Matrix::Zero(1, 1)}; }
+  std::vector<cddp::Matrix> getCrossHessian(const cddp::Vector &, const cddp::Vector &, double) const override { return {cddp::Matrix::Zero(1, 1)}; }
+};
+class HostPendulum final : public cddp::DynamicalSystem {   // pendulum.cpp:29-66 as a user plant (continuous dynamics + analytic Jacobians)
+ public:
+  HostPendulum(double dt, double l, double m, double b, int boom_after = -1) : cddp::DynamicalSystem(2, 1, dt, "euler"), l_(l), m_(m), b_(b), boom_after_(boom_after) {}
+  cddp::Vector getContinuousDynamics(const cddp::Vector &x, const cddp::Vector &u, double) const override {
+    if (boom_after_ >= 0 && ++calls_ > boom_after_) throw std::runtime_error("boom from the user plant");
+    return {x[1], (u[0] - b_ * x[1] + m_ * 9.81 * l_ * std::sin(x[0])) / (m_ * l_ * l_)};
+  }
+  cddp::Matrix getStateJacobian(const cddp::Vector &x, const cddp::Vector &, double) const override {
+    cddp::Matrix A(2, 2); A(0, 1) = 1.0; A(1, 0) = (9.81 / l_) * std::cos(x[0]); A(1, 1) = -b_ / (m_ * l_ * l_); return A;
+  }
+  cddp::Matrix getControlJacobian(const cddp::Vector &, const cddp::Vector &, double) const override { cddp::Matrix B(2, 1); B(1, 0) = 1.0 / (m_ * l_ * l_); return B; }
+ private:
+  double l_, m_, b_; int boom_after_; mutable int calls_ = 0;
+};
+class QuadraticAsNonlinear final : public cddp::NonlinearObjective {   // finite-difference derivatives of a quadratic cost
+ public:
+  explicit QuadraticAsNonlinear(double dt) : cddp::NonlinearObjective(dt) {}
+  double running_cost(const cddp::Vector &x, const cddp::Vector &u, int) const override { return 0.1 * timestep_ * u[0] * u[0] + 0.0 * x[0]; }
+  double terminal_cost(const cddp::Vector &x) const override { return 100.0 * (x[0] * x[0] + x[1] * x[1]); }
+};
+class TorqueBand final : public cddp::Constraint {   // a user constraint: |u| <= c as two rows
+ public:
+  explicit TorqueBand(double c) : cddp::Constraint("TorqueBand"), c_(c) {}
+  int getDualDim() const override { return 2; }
+  cddp::Vector evaluate(const cddp::Vector &, const cddp::Vector &u) const override { return {-u[0], u[0]}; }
+  cddp::Vector getUpperBound() const override { return {c_, c_}; }
+  cddp::Matrix getStateJacobian(const cddp::Vector &x, const cddp::Vector &) const override { return cddp::Matrix(2, (int)x.size()); }
+  cddp::Matrix getControlJacobian(const cddp::Vector &, const cddp::Vector &) const override { cddp::Matrix J(2, 1); J(0, 0) = -1.0; J(1, 0) = 1.0; return J; }
+ private:
+  double c_;
+};
+
+cddp::CDDP makeHostPendulum(const cddp::CDDPOptions &options, std::unique_ptr<cddp::DynamicalSystem> plant, std::unique_ptr<cddp::Objective> objective,
+                            std::unique_ptr<cddp::Constraint> con, const char *con_name = "ControlConstraint") {
+  const double dt = 0.02; const int horizon = 100;
+  cddp::Vector x0 = {3.14159265358979323846, 0.0}, goal = {0.0, 0.0};
+  cddp::CDDP solver(x0, goal, horizon, dt, std::move(plant), std::move(objective), options);
+  solver.addPathConstraint(con_name, std::move(con));
+  std::vector<cddp::Vector> X(horizon + 1, x0), U(horizon, cddp::Vector{0.0});
+  solver.setInitialTrajectory(X, U);
+  return solver;
+}
+std::unique_ptr<cddp::DynamicalSystem> doubleIntegrator(double dt) {
+  cddp::Matrix A = cddp::Matrix::Identity(2), B(2, 1); A(0, 1) = dt; B(1, 0) = dt;
+  return std::make_unique<cddp::LTISystem>(A, B, dt);
+}
+std::unique_ptr<cddp::Objective> pendulumCost() {
+  const cddp::Vector goal = {0.0, 0.0};
+  return std::make_unique<cddp::QuadraticObjective>(cddp::Matrix::Zero(2, 2), 0.1 * cddp::Matrix::Identity(1), 100.0 * cddp::Matrix::Identity(2), goal, std::vector<cddp::Vector>{}, 0.02);
+}
+
 cddp::CDDP makePendulum(const cddp::CDDPOptions &options, int horizon = 100) {
   const double dt = 0.02;
   cddp::Vector x0 = {3.14159265358979323846, 0.0}, goal = {0.0, 0.0};
@@ -80,6 +142,41 @@ static void cpu_tests() {
     cddp_hip_options p = o.toPOD();
     EXPECT_TRUE(p.tolerance == 1e-4 && p.barrier_mu_initial == 0.1 && p.ls_max_iterations == 15 && p.enable_parallel == 1);
     EXPECT_TRUE(p.reg_initial_value == 1e-6 && p.boxqp_max_iterations == 100 && p.ipddp_max_filter_size == 5);
+  }
+  {   // host evaluation of the plug-in surface (what the plug-in solve calls back into)
+    const double dt = 0.1;
+    cddp::Matrix Q = cddp::Matrix::Identity(2), R = 0.5 * cddp::Matrix::Identity(1), Qf = 10.0 * cddp::Matrix::Identity(2);
+    cddp::QuadraticObjective q(Q, R, Qf, cddp::Vector{1.0, 0.0}, std::vector<cddp::Vector>{}, dt);
+    cddp::Vector x = {0.5, -0.25}, u = {2.0};
+    EXPECT_TRUE(std::fabs(q.running_cost(x, u, 0) - dt * (0.25 + 0.0625 + 0.5 * 4.0)) < 1e-15);       // objective.cpp:66-84: Q, R scaled by dt
+    EXPECT_TRUE(std::fabs(q.terminal_cost(x) - 10.0 * (0.25 + 0.0625)) < 1e-15);
+    EXPECT_TRUE(std::fabs(q.getRunningCostStateGradient(x, u, 0)[0] - 2.0 * dt * (-0.5)) < 1e-15);
+    EXPECT_TRUE(std::fabs(q.getRunningCostControlGradient(x, u, 0)[0] - 2.0 * dt * 0.5 * 2.0) < 1e-15);
+    EXPECT_TRUE(q.getRunningCostStateHessian(x, u, 0)(1, 1) == 2.0 * dt && q.getFinalCostHessian(x)(0, 0) == 20.0);
+    EXPECT_TRUE(q.getRunningCostCrossHessian(x, u, 0).rows == 1 && q.getRunningCostCrossHessian(x, u, 0).cols == 2);
+    EXPECT_TRUE(std::fabs(q.evaluate({x, x, x}, {u, u}) - (2 * q.running_cost(x, u, 0) + q.terminal_cost(x))) < 1e-14);
+    QuadraticAsNonlinear nl(dt);                                                                          // objective.cpp:188-288 finite differences
+    EXPECT_TRUE(std::fabs(nl.getFinalCostGradient(x)[0] - 200.0 * 0.5) < 1e-6 && std::fabs(nl.getFinalCostHessian(x)(1, 1) - 200.0) < 1e-3);
+    EXPECT_TRUE(std::fabs(nl.getRunningCostControlGradient(x, u, 0)[0] - 0.2 * dt * 2.0) < 1e-8);
+    HostPendulum hp(0.02, 0.5, 1.0, 0.01);                                                               // default integrators (dynamical_system.cpp:28-83)
+    cddp::Vector xn = hp.getDiscreteDynamics({0.1, 0.2}, {0.3}, 0.0);
+    EXPECT_TRUE(std::fabs(xn[0] - (0.1 + 0.02 * 0.2)) < 1e-16);
+    EXPECT_TRUE(std::fabs(xn[1] - (0.2 + 0.02 * ((0.3 - 0.01 * 0.2 + 9.81 * 0.5 * std::sin(0.1)) / 0.25))) < 1e-15);
+    bool threw = false;
+    try { hp.getStateHessian({0.1, 0.2}, {0.3}, 0.0); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("autodiff is not available") != std::string::npos; }
+    EXPECT_TRUE(threw);
+    cddp::BallConstraint ball(0.4, cddp::Vector{1.0, 1.0});
+    EXPECT_TRUE(std::fabs(ball.evaluate({1.5, 1.0, 0.3}, {0.0})[0] + 0.25) < 1e-16 && std::fabs(ball.getUpperBound()[0] + 0.16) < 1e-16);
+    EXPECT_TRUE(ball.getStateJacobian({1.5, 1.0, 0.3}, {0.0})(0, 0) == -1.0 && ball.getStateJacobian({1.5, 1.0, 0.3}, {0.0}).cols == 3);
+    cddp::ControlConstraint box(cddp::Vector{-1.0, -2.0}, cddp::Vector{3.0, 4.0});
+    cddp::Vector ub = box.getUpperBound(), g = box.evaluate({0.0}, {0.5, -0.5});
+    EXPECT_TRUE(ub[0] == 1.0 && ub[1] == 2.0 && ub[2] == 3.0 && ub[3] == 4.0 && g[0] == -0.5 && g[1] == 0.5 && g[2] == 0.5 && g[3] == -0.5);
+    // routing: built-in descriptors stay on the device path, any user subclass selects the plug-in solve
+    cddp::CDDPOptions o;
+    EXPECT_TRUE(!makePendulum(o).needsHostPlugins());
+    EXPECT_TRUE(makeHostPendulum(o, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0})).needsHostPlugins());
+    EXPECT_TRUE(makeHostPendulum(o, std::make_unique<cddp::Pendulum>(0.02, 0.5, 1.0, 0.01, "euler"), std::make_unique<QuadraticAsNonlinear>(0.02), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0})).needsHostPlugins());
+    EXPECT_TRUE(makeHostPendulum(o, std::make_unique<cddp::Pendulum>(0.02, 0.5, 1.0, 0.01, "euler"), pendulumCost(), std::make_unique<TorqueBand>(20.0), "TorqueBand").needsHostPlugins());
   }
   {   // registering the GPU core under the reference's names overrides nothing else (drop-in)
     cddp::registerHipSolvers();
@@ -157,6 +254,64 @@ static void gpu_tests() {
     std::cout << "solver reuse: " << s2.status_message << " iterations " << s2.iterations_completed << " (first " << s1.iterations_completed << ")\n";
     EXPECT_TRUE(s2.iterations_completed > 0);
     EXPECT_TRUE(std::fabs(s2.state_trajectory.front()[0] - (3.14159265358979323846 - 0.05)) < 1e-15);
+  }
+  {   // host plug-ins (g1): a user plant with the SAME dynamics as the built-in pendulum must reproduce the device path's decisions
+    cddp::CDDPOptions o2 = opt; o2.return_iteration_info = false;
+    for (const char *name : {"IPDDP", "CLDDP"}) {
+      cddp::CDDP dev = makePendulum(o2);
+      cddp::CDDPSolution d = dev.solve(name);
+      cddp::CDDP host = makeHostPendulum(o2, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
+      cddp::CDDPSolution h = host.solve(name);
+      std::cout << "host plant " << name << ": " << h.status_message << " iterations " << h.iterations_completed << " (device " << d.iterations_completed << ") cost " << h.final_objective << " vs " << d.final_objective << "\n";
+      EXPECT_EQ(h.status_message, d.status_message);
+      EXPECT_EQ(h.iterations_completed, d.iterations_completed);
+      EXPECT_TRUE(std::fabs(h.final_objective - d.final_objective) <= 1e-8 * std::fabs(d.final_objective));
+      EXPECT_EQ((int)h.state_trajectory.size(), 101); EXPECT_EQ((int)h.feedback_gains.size(), 100);
+      EXPECT_TRUE(std::fabs(host.cost_ - h.final_objective) == 0.0);
+    }
+    // a user constraint (two rows, same set as the box) and a finite-difference objective: same optimum as the device path
+    cddp::CDDP dev = makePendulum(o2);
+    cddp::CDDPSolution d = dev.solve("IPDDP");
+    cddp::CDDP band = makeHostPendulum(o2, doubleIntegrator(0.02), pendulumCost(), std::make_unique<TorqueBand>(20.0), "TorqueBand");
+    cddp::CDDPSolution bs = band.solve("IPDDP");   // LTI plant with a user constraint: host route, LQ problem
+    std::cout << "LTI + user constraint: " << bs.status_message << " iterations " << bs.iterations_completed << " cost " << bs.final_objective << "\n";
+    EXPECT_TRUE(bs.status_message == "OptimalSolutionFound" || bs.status_message == "AcceptableSolutionFound");
+    cddp::CDDP fd = makeHostPendulum(o2, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01), std::make_unique<QuadraticAsNonlinear>(0.02), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
+    cddp::CDDPSolution fs = fd.solve("IPDDP");
+    std::cout << "finite-difference objective: " << fs.status_message << " iterations " << fs.iterations_completed << " cost " << fs.final_objective << " (analytic " << d.final_objective << ")\n";
+    EXPECT_TRUE(std::fabs(fs.final_objective - d.final_objective) < 1e-3 * std::fabs(d.final_objective));
+    // the reference's QuadraticScalarSystem through full solves, Gauss-Newton and full DDP (its Hessian virtuals).  Its reported
+    // Jacobian is not the derivative of its step (A = I + dt (1 + x) = 2 + x against 1 + x), so convergence is not the claim: the
+    // solve must run on the user's virtuals, improve the cost, respect the box, and return the plant's own rollout.  (The numpy twin
+    // driven by the same plug-in pins iteration counts and trajectories: tests/test_host_plugins.py.)
+    for (int ddp = 0; ddp < 2; ++ddp) {
+      cddp::CDDPOptions o3 = opt; o3.max_iterations = 40; o3.use_ilqr = !ddp; o3.tolerance = 1e-6; o3.return_iteration_info = false; o3.ipddp.barrier.mu_initial = 0.1;
+      cddp::Vector goal = {0.0};
+      cddp::QuadraticObjective cost(cddp::Matrix::Identity(1), 0.1 * cddp::Matrix::Identity(1), 10.0 * cddp::Matrix::Identity(1), goal, std::vector<cddp::Vector>{}, 1.0);
+      cddp::CDDP p(cddp::Vector{0.3}, goal, 8, 1.0, std::make_unique<QuadraticScalarSystem>(), std::make_unique<cddp::QuadraticObjective>(cost), o3);
+      p.addPathConstraint("ControlConstraint", std::make_unique<cddp::ControlConstraint>(cddp::Vector{-0.5}, cddp::Vector{0.5}));
+      std::vector<cddp::Vector> X0(9, cddp::Vector{0.3}), U0(8, cddp::Vector{0.0});
+      for (int t = 0; t < 8; ++t) X0[t + 1] = QuadraticScalarSystem().getDiscreteDynamics(X0[t], U0[t], 0.0);
+      const double J0 = cost.evaluate(X0, U0);
+      cddp::CDDPSolution s = p.solve("IPDDP");
+      std::cout << "QuadraticScalarSystem use_ilqr=" << !ddp << ": " << s.status_message << " iterations " << s.iterations_completed << " cost " << s.final_objective << " (u = 0: " << J0 << ")\n";
+      EXPECT_TRUE(s.iterations_completed > 0 && s.final_objective < 0.1 * J0);
+      for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 0.5);
+      cddp::Vector x = {0.3};   // the returned trajectory is the plant's own rollout of the returned controls
+      for (int t = 0; t < 8; ++t) { x = QuadraticScalarSystem().getDiscreteDynamics(x, s.control_trajectory[t], 0.0); EXPECT_TRUE(std::fabs(x[0] - s.state_trajectory[t + 1][0]) < 1e-15); }
+      EXPECT_TRUE(std::fabs(cost.evaluate(s.state_trajectory, s.control_trajectory) - s.final_objective) < 1e-12);
+    }
+    // an exception thrown inside a user virtual surfaces to the caller of solve()
+    cddp::CDDP boom = makeHostPendulum(o2, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01, 150), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
+    bool threw = false;
+    try { boom.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = std::string(e.what()) == "boom from the user plant"; }
+    EXPECT_TRUE(threw);
+    // full DDP without Hessian virtuals: the autodiff-less default explains itself
+    cddp::CDDPOptions o4 = o2; o4.use_ilqr = false;
+    cddp::CDDP nohess = makeHostPendulum(o4, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
+    threw = false;
+    try { nohess.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("autodiff is not available") != std::string::npos; }
+    EXPECT_TRUE(threw);
   }
   {   // a layout that is not instantiated on the device: loud error, never a silent fallback
     cddp::CDDP solver = makePendulum(opt);

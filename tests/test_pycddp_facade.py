@@ -56,8 +56,9 @@ def test_solver_errors(pycddp):                                           # pyth
         solver.solve(pycddp.SolverType.IPDDP)
     with pytest.raises(ValueError):
         solver.set_initial_trajectory([x0] * 3, [np.zeros(1)] * 6)
-    with pytest.raises(NotImplementedError):
-        pycddp.DynamicalSystem(2, 1, 0.1)
+    bare = pycddp.DynamicalSystem(2, 1, 0.1)                              # the trampoline base: constructible, nothing implemented
+    with pytest.raises(RuntimeError, match="do not support getContinuousDynamicsAutodiff"):
+        bare.get_state_jacobian(x0, np.zeros(1))
     with pytest.raises(ValueError, match="Q matrix must be square"):
         pycddp.QuadraticObjective(np.zeros((2, 3)), np.eye(1), np.eye(2), x0)
     unknown = solver.solve("FooDDP")                                      # cddp_core.cpp:243-265: no throw through solve()
