@@ -16,8 +16,10 @@
 #ifndef CDDP_HOST_MODELS   // host_models.cpp compiles the plants (dev_models.hpp) for the host with DEV = inline
 #include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
+#define DEV_NOINLINE __device__ __attribute__((noinline))   // large, cold device routines (second-order duals with many seeds)
 #else
 #include <cmath>
+#define DEV_NOINLINE
 #endif
 
 namespace cddp_dev {

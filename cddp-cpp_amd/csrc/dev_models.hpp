@@ -52,6 +52,14 @@ template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s
 template <int NP> DEV DualN<NP> dsqrt(const DualN<NP> &a) { DualN<NP> r; r.v = sqrt(a.v); double g = 0.5 / r.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
+template <int NP> DEV DualN<NP> dasin(const DualN<NP> &a) { DualN<NP> r; r.v = asin(a.v); double g = 1.0 / sqrt(1.0 - a.v * a.v);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
+template <int NP> DEV DualN<NP> dtan(const DualN<NP> &a) { DualN<NP> r; r.v = plant_tan(a.v); double g = 1.0 + r.v * r.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
+DEV double dasin(double a) { return asin(a); }
+DEV double dtan(double a) { return plant_tan(a); }
 DEV double dsin(double a) { return plant_sin(a); }
 DEV double dcos(double a) { return plant_cos(a); }
 DEV double dsqrt(double a) { return sqrt(a); }
@@ -115,6 +123,27 @@ template <int NP> DEV Dual2N<NP> operator/(const Dual2N<NP> &a, const Dual2N<NP>
   return a * d2_unary<NP>(b, inv, -inv * inv, 2.0 * inv * inv * inv); }
 template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
 template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
+template <int NP> DEV Dual2N<NP> dsqrt(const Dual2N<NP> &a) { const double r = sqrt(a.v); return d2_unary<NP>(a, r, 0.5 / r, -0.25 / (a.v * r)); }
+template <int NP> DEV Dual2N<NP> dasin(const Dual2N<NP> &a) { const double w = 1.0 - a.v * a.v, r = sqrt(w); return d2_unary<NP>(a, asin(a.v), 1.0 / r, a.v / (w * r)); }
+template <int NP> DEV Dual2N<NP> dtan(const Dual2N<NP> &a) { const double t = plant_tan(a.v), g = 1.0 + t * t; return d2_unary<NP>(a, t, g, 2.0 * t * g); }
+template <int NP> DEV double dval(const Dual2N<NP> &a) { return a.v; }
+
+// Hessian tensors by second-order duals of a templated functor F::template eval<S>(p, x, u, out): out_i's Hessian w.r.t. z = [x, u],
+// split into the solver's three blocks (f_xx[i] nx x nx, f_uu[i] nu x nu, f_ux[i] nu x nx), each entry divided by `div`
+template <class F, int NX, int NU>
+DEV void ad_hessian(const double *p, const double *x, const double *u, double div, double *Fxx, double *Fuu, double *Fux) {
+  typedef Dual2N<NX + NU> D;
+  D xs[NX], us[NU], xd[NX];
+  for (int i = 0; i < NX; ++i) { xs[i] = D(x[i]); xs[i].d[i] = 1.0; }
+  for (int j = 0; j < NU; ++j) { us[j] = D(u[j]); us[j].d[NX + j] = 1.0; }
+  F::template eval<D>(p, xs, us, xd);
+  constexpr int NP = NX + NU;
+  for (int i = 0; i < NX; ++i) {
+    for (int a = 0; a < NX; ++a) for (int b = 0; b < NX; ++b) Fxx[(i * NX + a) * NX + b] = xd[i].h[a * NP + b] / div;
+    for (int a = 0; a < NU; ++a) for (int b = 0; b < NU; ++b) Fuu[(i * NU + a) * NU + b] = xd[i].h[(NX + a) * NP + NX + b] / div;
+    for (int a = 0; a < NU; ++a) for (int b = 0; b < NX; ++b) Fux[(i * NU + a) * NX + b] = xd[i].h[(NX + a) * NP + b] / div;
+  }
+}
 
 // Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
 template <class F, int NX, int NU>
@@ -321,6 +350,99 @@ struct LTIModel {
   }
 };
 
+// ================================================================================ Bicycle (bicycle.cpp)
+// Kinematic bicycle, state [x, y, theta, v], control [a, delta]; params: wheelbase.  Analytic Jacobians (:68-111) and state /
+// control Hessians (:113-156); the cross Hessian is the base class's autodiff default (dynamical_system.cpp:190-217).
+struct BicycleDyn {
+  template <class S>
+  DEV static void eval(const double *p, const S *x, const S *u, S *xd) {
+    const S theta = x[2], v = x[3];
+    xd[0] = v * dcos(theta);
+    xd[1] = v * dsin(theta);
+    xd[2] = (v / S(p[0])) * dtan(u[1]);
+    xd[3] = u[0];
+  }
+};
+struct BicycleModel {
+  static constexpr int ID = CDDP_HIP_MODEL_BICYCLE, NX = 4, NU = 2;
+  static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = true;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) { BicycleDyn::eval<double>(p, x, u, xd); }
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    double s, c; plant_sincos(x[2], &s, &c);
+    const double v = x[3], L = p[0], cd = plant_cos(u[1]);
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Fx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) Fu[i] = 0.0;
+    Fx[0 * NX + 2] = -v * s; Fx[0 * NX + 3] = c;
+    Fx[1 * NX + 2] = v * c;  Fx[1 * NX + 3] = s;
+    Fx[2 * NX + 3] = plant_tan(u[1]) / L;
+    Fu[3 * NU + 0] = 1.0;
+    Fu[2 * NU + 1] = v / (L * (cd * cd));
+  }
+  DEV static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+    double sxx[NX * NX * NX], suu[NX * NU * NU];   // the autodiff blocks the analytic overrides replace
+    ad_hessian<BicycleDyn, NX, NU>(p, x, u, 1.0, sxx, suu, Fux);
+    double s, c; plant_sincos(x[2], &s, &c);
+    const double v = x[3], L = p[0], cd = plant_cos(u[1]);
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    Fxx[(0 * NX + 2) * NX + 2] = -v * c; Fxx[(0 * NX + 2) * NX + 3] = -s; Fxx[(0 * NX + 3) * NX + 2] = -s;
+    Fxx[(1 * NX + 2) * NX + 2] = -v * s; Fxx[(1 * NX + 2) * NX + 3] = c;  Fxx[(1 * NX + 3) * NX + 2] = c;
+    Fuu[(2 * NU + 1) * NU + 1] = 2.0 * v * plant_sin(u[1]) / (L * (cd * cd * cd));
+  }
+};
+
+// ================================================================================ Car (car.cpp)
+// A DISCRETE plant: getDiscreteDynamics is overridden (:24-60) and everything else differentiates it -- Jacobians are the autodiff
+// gradient of the discrete map with J.diagonal() -= 1 and J /= timestep (:62-111), Hessians its autodiff Hessian / timestep
+// (:113-161; the cross Hessian through the base default on (x+ - x) / timestep is the same block).  State [x, y, theta, v],
+// control [steering delta, acceleration a]; params: wheelbase, p[1] = timestep (filled in by the library).
+struct CarDyn {
+  template <class S, bool kClamps>
+  DEV static void next(const double *p, const S *x, const S *u, S *xn) {
+    const double d = p[0], h = p[1];
+    const S theta = x[2], v = x[3], delta = u[0], a = u[1];
+    const S cos_theta = dcos(theta), sin_theta = dsin(theta);
+    const S f = S(h) * v;
+    const S sin_delta = dsin(delta);
+    const S f_sin_delta = f * sin_delta;
+    S inside = S(d * d) - f_sin_delta * f_sin_delta;
+    if (kClamps && dval(inside) < 0.0) inside = S(0.0);            // autodiff path only (:183-186)
+    const S b = S(d) + f * dcos(delta) - dsqrt(inside);
+    S asin_arg = sin_delta * f / S(d);
+    if (kClamps && fabs(dval(asin_arg)) > 1.0) asin_arg = S(dval(asin_arg) > 0.0 ? 1.0 : -1.0);   // :196-199
+    const S dtheta = dasin(asin_arg);
+    xn[0] = x[0] + b * cos_theta;
+    xn[1] = x[1] + b * sin_theta;
+    xn[2] = x[2] + dtheta;
+    xn[3] = x[3] + S(h) * a;
+  }
+  template <class S>
+  DEV static void eval(const double *p, const S *x, const S *u, S *xn) { next<S, true>(p, x, u, xn); }
+};
+struct CarModel {
+  static constexpr int ID = CDDP_HIP_MODEL_CAR, NX = 4, NU = 2;
+  static constexpr bool kDiscrete = true;
+  static constexpr bool kHasHess = true;
+  DEV static void step(const double *p, const double *x, const double *u, double *xn) { CarDyn::next<double, false>(p, x, u, xn); }
+  DEV static void f(const double *, const double *, const double *, double *) {}
+  DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
+    ad_jacobian<CarDyn, NX, NU>(p, x, u, Fx, Fu);
+    const double h = p[1];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Fx[i * NX + i] -= 1.0;
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Fx[i] = Fx[i] / h;
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) Fu[i] = Fu[i] / h;
+  }
+  DEV static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+    ad_hessian<CarDyn, NX, NU>(p, x, u, p[1], Fxx, Fuu, Fux);
+  }
+};
+
 // ================================================================================ Quadrotor (nx=13)
 struct QuadrotorDyn {   // quadrotor.cpp:33-104 == :166-219; params: mass, arm, Ixx, Iyy, Izz, gravity
   template <class S>
@@ -364,7 +486,14 @@ struct QuadrotorDyn {   // quadrotor.cpp:33-104 == :166-219; params: mass, arm, 
 struct QuadrotorModel {
   static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR, NX = 13, NU = 4;
   static constexpr bool kDiscrete = false;
-  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
+  // quadrotor.cpp:224-278: dual2nd through the normalised-quaternion dynamics.  The reference's getCrossHessian returns nx x nu
+  // matrices where the solvers add nu x nx blocks (an Eigen size mismatch: use_ilqr = false is not defined behaviour there for this
+  // plant); here the cross block has the shape the solver's formula needs.  17 seeds: 307 doubles per dual, scratch-resident -- a
+  // correctness path (full DDP on the quadrotor), not a tuned one.
+  static constexpr bool kHasHess = true;
+  DEV_NOINLINE static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+    ad_hessian<QuadrotorDyn, NX, NU>(p, x, u, 1.0, Fxx, Fuu, Fux);
+  }
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { QuadrotorDyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<QuadrotorDyn, NX, NU>(p, x, u, Fx, Fu);
@@ -413,7 +542,32 @@ struct Quad12Model {
 struct ManipulatorModel {   // manipulator.cpp:29-70,174-208
   static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR, NX = 6, NU = 3;
   static constexpr bool kDiscrete = false;
-  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
+  // manipulator.cpp:72-86: the state and control Hessians are ZERO overrides; the cross Hessian is the base class's autodiff default
+  // on ddq = M(q)^-1 (tau - G(q)) (dynamical_system.cpp:190-217), i.e. d2 ddq_i / dtau_j dq_k = d(M^-1)_ij / dq_k, evaluated here in
+  // closed form: -(M^-1 (dM/dq_k) M^-1)_ij, k = 1, 2 (M does not depend on q_0).
+  static constexpr bool kHasHess = true;
+  DEV static void hess(const double *, const double *x, const double *, double *Fxx, double *Fuu, double *Fux) {
+    const double la = 1.0, lb = 0.2, lc = 1.0, m1 = 1.0, m2 = 1.0, m3 = 0.5;
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
+    double s1, c1, s2, c2, s12, c12;
+    plant_sincos(x[1], &s1, &c1); plant_sincos(x[2], &s2, &c2); plant_sincos(x[1] + x[2], &s12, &c12);
+    double M[9], Minv[9];
+    M[0] = (m1 + m2 + m3) * (la * la); M[4] = (m2 + m3) * (lb * lb); M[8] = m3 * (lc * lc);
+    M[1] = M[3] = (m2 + m3) * la * lb * c1; M[5] = M[7] = m3 * lb * lc * c2; M[2] = M[6] = m3 * la * lc * c12;
+    inverse_pplu<3>(M, Minv);
+    for (int k = 1; k <= 2; ++k) {
+      double dM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      dM[2] = dM[6] = -(m3 * la * lc) * s12;
+      if (k == 1) dM[1] = dM[3] = -((m2 + m3) * la * lb) * s1;
+      else dM[5] = dM[7] = -(m3 * lb * lc) * s2;
+      double T[9], R[9];
+      mm_nn<3, 3, 3>(Minv, dM, T);
+      mm_nn<3, 3, 3>(T, Minv, R);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fux[((3 + i) * NU + j) * NX + k] = -R[i * 3 + j];
+    }
+  }
   DEV static void f(const double *, const double *x, const double *u, double *xd) {
     const double la = 1.0, lb = 0.2, lc = 1.0, grav = 9.81;
     const double m1 = 1.0, m2 = 1.0, m3 = 0.5;

@@ -196,20 +196,24 @@ DEV double solver_pow(double x, double y) { return pow(x, y); }
 DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
 DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
 DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
+DEV double plant_tan(double a) { double s, c; sincos_1(a, &s, &c); return s / c; }   // bicycle steering: sin / cos of the shared routine
 #else
 DEV void plant_sincos(double a, double *s, double *c) { sincos(a, s, c); }
 DEV double plant_sin(double a) { return sin(a); }
 DEV double plant_cos(double a) { return cos(a); }
+DEV double plant_tan(double a) { return tan(a); }
 #endif
 #elif defined(CDDP_HOST_MODELS)   // host_models.cpp: the plants compiled for the host (the host libm, or the shared routine)
 #ifdef CDDP_TRIG_SHARED
 DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
 DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
 DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
+DEV double plant_tan(double a) { double s, c; sincos_1(a, &s, &c); return s / c; }
 #else
 DEV void plant_sincos(double a, double *s, double *c) { *s = std::sin(a); *c = std::cos(a); }
 DEV double plant_sin(double a) { return std::sin(a); }
 DEV double plant_cos(double a) { return std::cos(a); }
+DEV double plant_tan(double a) { return std::tan(a); }
 #endif
 #endif
 
