@@ -60,6 +60,7 @@ const std::vector<KernelSet> &registry() {
     std::vector<KernelSet> r;
     register_pendulum(r); register_cartpole(r); register_unicycle(r); register_lti(r);
     register_quadrotor(r); register_quad12(r); register_manipulator(r); register_manip7(r); register_terminal(r); register_statebox(r);
+    register_vehicles(r);
     return r;
   }();
   return v;
@@ -114,7 +115,8 @@ int pool_put(ProblemDev &P, int &top, const double *src, int n) {
 
 // plants with device-side Hessian tensors (dev_models.hpp: Model::kHasHess) -- full DDP (options.use_ilqr = 0) needs them
 bool model_has_hessians(int model) {
-  return model == CDDP_HIP_MODEL_PENDULUM || model == CDDP_HIP_MODEL_CARTPOLE || model == CDDP_HIP_MODEL_UNICYCLE || model == CDDP_HIP_MODEL_LTI;
+  return model == CDDP_HIP_MODEL_PENDULUM || model == CDDP_HIP_MODEL_CARTPOLE || model == CDDP_HIP_MODEL_UNICYCLE || model == CDDP_HIP_MODEL_LTI ||
+         model == CDDP_HIP_MODEL_BICYCLE || model == CDDP_HIP_MODEL_CAR || model == CDDP_HIP_MODEL_MANIPULATOR;
 }
 
 // cddp_hip_problem -> ProblemDev (constraints sorted by name as std::map iterates)
@@ -129,11 +131,12 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (!(p->options.reg_update_factor > 1.0) || !(p->options.reg_max_value > 0.0))
     return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", p->options.reg_update_factor, p->options.reg_max_value);
   if (!p->options.use_ilqr && !model_has_hessians(p->model))
-    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", p->model);
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: on the device for pendulum, cart-pole, unicycle, LTI, bicycle, car and the 3-DOF manipulator (model id %d; the quadrotor's are host-only: plug-in solve)", p->model);
   P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
   P.nx = p->nx; P.nu = p->nu; P.N = p->horizon; P.dt = p->dt; P.opt = p->options;
   P.ls_rule = p->options.enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
   for (int i = 0; i < CDDP_HIP_MAX_MODEL_PARAMS; ++i) P.mp[i] = p->model_params[i];
+  if (p->model == CDDP_HIP_MODEL_CAR) P.mp[1] = p->dt;   // the car is a discrete plant: its step uses the timestep (car.cpp:24-60)
   if (p->model == CDDP_HIP_MODEL_LTI) {
     if (!p->lti_A || !p->lti_B) return fail(-2, "LTI model needs lti_A and lti_B");
     if (p->nx * p->nx + p->nx * p->nu + 1 > 32) return fail(-3, "LTI dims too large for the device parameter block");
@@ -179,6 +182,25 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
       case CDDP_HIP_CON_LINEAR:
         if (!c.A || !c.b) return fail(-2, "Cannot add null constraint.");
         cd.dual_dim = c.dim; cd.off_A = pool_put(P, top, c.A, c.dim * p->nx); cd.off_b = pool_put(P, top, c.b, c.dim); break;
+      case CDDP_HIP_CON_SOC: {   // constraint.hpp:626-668: state dimension >= 3, the opening direction stored as a unit vector
+        if (!c.center || !c.lower) return fail(-2, "Cannot add null constraint.");
+        if (p->nx < 3 || c.dim != 3) return fail(-2, "SecondOrderConeConstraint: State dimension must be at least 3.");
+        if (!(c.scale > 0.0)) return fail(-2, "SecondOrderConeConstraint: Regularization epsilon must be positive.");
+        const double n2 = c.lower[0] * c.lower[0] + c.lower[1] * c.lower[1] + c.lower[2] * c.lower[2];
+        if (n2 == 0.0) return fail(-2, "SecondOrderConeConstraint: Opening direction cannot be zero vector.");
+        if (std::fabs(std::sqrt(n2) - 1.0) > 1e-6) return fail(-2, "SecondOrderConeConstraint: pass the opening direction normalised (the reference's constructor normalises it)");
+        cd.dual_dim = 1; cd.off_center = pool_put(P, top, c.center, 3); cd.off_lower = pool_put(P, top, c.lower, 3); break;
+      }
+      case CDDP_HIP_CON_THRUST:
+      case CDDP_HIP_CON_MAX_THRUST: {   // constraint.hpp:802-838, 929-953
+        if (c.dim != p->nu) return fail(-2, "thrust-magnitude constraint '%s' dimension mismatch", c.name);
+        if (!(c.scale > 0.0)) return fail(-2, "ThrustMagnitudeConstraint: epsilon must be positive.");
+        const double mn = (c.kind == CDDP_HIP_CON_THRUST && c.lower) ? c.lower[0] : 0.0;
+        if (c.kind == CDDP_HIP_CON_THRUST && !c.lower) return fail(-2, "Cannot add null constraint.");
+        if (mn < 0.0) return fail(-2, "ThrustMagnitudeConstraint: min_thrust_norm must be non-negative.");
+        if (c.radius < mn) return fail(-2, "ThrustMagnitudeConstraint: max_thrust_norm must be greater than or equal to min_thrust_norm.");
+        cd.dual_dim = c.kind == CDDP_HIP_CON_THRUST ? 2 : 1; cd.off_lower = pool_put(P, top, &mn, 1); break;
+      }
       default: return fail(-2, "unknown constraint kind %d", c.kind);
     }
     if (top > kPool || (cd.off_lower < 0 && cd.off_center < 0 && cd.off_A < 0)) return fail(-3, "constant pool overflow");
@@ -502,7 +524,7 @@ static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0))
     return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", opt->reg_update_factor, opt->reg_max_value);
   if (!opt->use_ilqr && !model_has_hessians(h->P.model))
-    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: restated for pendulum, cart-pole, unicycle and LTI only (model id %d)", h->P.model);
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: on the device for pendulum, cart-pole, unicycle, LTI, bicycle, car and the 3-DOF manipulator (model id %d; the quadrotor's are host-only: plug-in solve)", h->P.model);
   HIPCHK(hipSetDevice(h->device));
   double al[CDDP_HIP_MAX_ALPHAS];
   const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);

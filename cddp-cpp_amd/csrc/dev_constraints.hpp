@@ -16,6 +16,7 @@ template <int D>
 struct CtrlBox {
   static constexpr int KIND = CDDP_HIP_CON_CONTROL_BOX, DUAL = 2 * D, DIM = D;
   static constexpr bool HAS_X = false;   // G_x == 0
+  static constexpr bool JAC_U = false;   // Jacobians do not depend on u
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *, const double *u, double *g) {
 #pragma unroll
@@ -25,7 +26,7 @@ struct CtrlBox {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const ConDev &c, const double *, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const ConDev &c, const double *, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) { Gu[i * NU + i] = -c.scale; Gu[(D + i) * NU + i] = c.scale; }
     (void)Gx;
@@ -46,7 +47,7 @@ struct CtrlBox {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const K &k, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) { Gu[i * NU + i] = -k.scale; Gu[(D + i) * NU + i] = k.scale; }
     (void)Gx;
@@ -58,6 +59,7 @@ template <int D>
 struct StateBox {
   static constexpr int KIND = CDDP_HIP_CON_STATE_BOX, DUAL = 2 * D, DIM = D;
   static constexpr bool HAS_X = true;
+  static constexpr bool JAC_U = false;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
 #pragma unroll
@@ -67,7 +69,7 @@ struct StateBox {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const ConDev &c, const double *, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const ConDev &c, const double *, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) { Gx[i * NX + i] = -c.scale; Gx[(D + i) * NX + i] = c.scale; }
     (void)Gu;
@@ -87,7 +89,7 @@ struct StateBox {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const K &k, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) { Gx[i * NX + i] = -k.scale; Gx[(D + i) * NX + i] = k.scale; }
     (void)Gu;
@@ -99,6 +101,7 @@ template <int D>
 struct Ball {
   static constexpr int KIND = CDDP_HIP_CON_BALL, DUAL = 1, DIM = D;
   static constexpr bool HAS_X = true;
+  static constexpr bool JAC_U = false;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
     double sq = 0.0;
@@ -107,7 +110,7 @@ struct Ball {
     g[0] = -(c.scale * sq) - (-(c.radius * c.radius) * c.scale);
   }
   template <int NX, int NU>
-  DEV static void jac(const ConDev &c, const double *pool, const double *x, double *Gx, double *Gu) {
+  DEV static void jac(const ConDev &c, const double *pool, const double *x, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) Gx[i] = -2.0 * c.scale * (x[i] - pool[c.off_center + i]);
     (void)Gu;
@@ -126,7 +129,7 @@ struct Ball {
     g[0] = -(k.scale * sq) - (-(k.radius * k.radius) * k.scale);
   }
   template <int NX, int NU>
-  DEV static void jac(const K &k, const double *x, double *Gx, double *Gu) {
+  DEV static void jac(const K &k, const double *x, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int i = 0; i < D; ++i) Gx[i] = -2.0 * k.scale * (x[i] - k.ctr[i]);
     (void)Gu;
@@ -138,6 +141,7 @@ template <int R>
 struct Linear {
   static constexpr int KIND = CDDP_HIP_CON_LINEAR, DUAL = R, DIM = R;
   static constexpr bool HAS_X = true;
+  static constexpr bool JAC_U = false;
   template <int NX, int NU>
   DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *, double *g) {
 #pragma unroll
@@ -149,7 +153,7 @@ struct Linear {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const ConDev &c, const double *pool, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const ConDev &c, const double *pool, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -170,7 +174,7 @@ struct Linear {
     }
   }
   template <int NX, int NU>
-  DEV static void jac(const K &k, const double *, double *Gx, double *Gu) {
+  DEV static void jac(const K &k, const double *, const double *, double *Gx, double *Gu) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -179,15 +183,88 @@ struct Linear {
   }
 };
 
+// SecondOrderConeConstraint (constraint.hpp:626-800): g = cos(fov) sqrt(|p - o|^2 + eps) - (p - o) . axis, p = x[:3]; upper 0.
+// Descriptor: center = cone origin (3), lower = unit opening direction (3; normalised by the caller as the reference's constructor
+// does), radius = cos(fov), scale = eps.
+struct SecondOrderCone {
+  static constexpr int KIND = CDDP_HIP_CON_SOC, DUAL = 1, DIM = 3;
+  static constexpr bool HAS_X = true;
+  static constexpr bool JAC_U = false;
+  struct K { double cosf, eps, o[3], ax[3]; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) {
+    k.cosf = c.radius; k.eps = c.scale;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { k.o[i] = pool[c.off_center + i]; k.ax[i] = pool[c.off_lower + i]; }
+  }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *x, const double *, double *g) {
+    const double v0 = x[0] - k.o[0], v1 = x[1] - k.o[1], v2 = x[2] - k.o[2];
+    const double reg_norm = sqrt(((v0 * v0 + v1 * v1) + v2 * v2) + k.eps);
+    const double dot = (v0 * k.ax[0] + v1 * k.ax[1]) + v2 * k.ax[2];
+    g[0] = reg_norm * k.cosf - dot;
+  }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *x, const double *, double *Gx, double *Gu) {
+    const double v[3] = {x[0] - k.o[0], x[1] - k.o[1], x[2] - k.o[2]};
+    const double reg_norm = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + k.eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Gx[i] = (reg_norm > 1e-9) ? k.cosf * (v[i] / reg_norm) - k.ax[i] : -k.ax[i];
+    (void)Gu;
+  }
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *u, double *g) { K k; load(c, pool, k); eval<NX, NU>(k, x, u, g); }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *pool, const double *x, const double *u, double *Gx, double *Gu) { K k; load(c, pool, k); jac<NX, NU>(k, x, u, Gx, Gu); }
+};
+
+// ThrustMagnitudeConstraint (constraint.hpp:802-927; TWO = true: g = [min - |u|, |u| - max]) and MaxThrustMagnitudeConstraint
+// (:929-1048; TWO = false: g = |u| - max); upper 0.  The value uses the plain norm, the Jacobian the regularised one
+// u^T / sqrt(|u|^2 + eps), as the reference does.  Descriptor: radius = max, scale = eps, lower[0] = min (TWO only).
+template <int D, bool TWO>
+struct ThrustMagnitude {
+  static constexpr int KIND = TWO ? CDDP_HIP_CON_THRUST : CDDP_HIP_CON_MAX_THRUST, DUAL = TWO ? 2 : 1, DIM = D;
+  static constexpr bool HAS_X = false;
+  static constexpr bool JAC_U = true;
+  struct K { double mn, mx, eps; };
+  DEV static void load(const ConDev &c, const double *pool, K &k) { k.mx = c.radius; k.eps = c.scale; k.mn = TWO ? pool[c.off_lower] : 0.0; }
+  template <int NX, int NU>
+  DEV static void eval(const K &k, const double *, const double *u, double *g) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sq += u[i] * u[i];
+    const double n = sqrt(sq);
+    if (TWO) { g[0] = k.mn - n; g[1] = n - k.mx; } else g[0] = n - k.mx;
+  }
+  template <int NX, int NU>
+  DEV static void jac(const K &k, const double *, const double *u, double *Gx, double *Gu) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sq += u[i] * u[i];
+    const double rn = sqrt(sq + k.eps);
+    // :861-872 zeroes the rows when the regularised norm is below eps, :988-992 when it is not above DBL_MIN
+    const bool ok = TWO ? !(rn < k.eps) : (rn > DBL_MIN);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const double d = ok ? u[i] / rn : 0.0;
+      if (TWO) { Gu[i] = -d; Gu[NU + i] = d; } else Gu[i] = d;
+    }
+    (void)Gx;
+  }
+  template <int NX, int NU>
+  DEV static void eval(const ConDev &c, const double *pool, const double *x, const double *u, double *g) { K k; load(c, pool, k); eval<NX, NU>(k, x, u, g); }
+  template <int NX, int NU>
+  DEV static void jac(const ConDev &c, const double *pool, const double *x, const double *u, double *Gx, double *Gu) { K k; load(c, pool, k); jac<NX, NU>(k, x, u, Gx, Gu); }
+};
+
 template <int OFF, int CI, class... Cs> struct ConImpl;
 template <int OFF, int CI>
 struct ConImpl<OFF, CI> {
   struct Ctx {};
   DEV static void load(const ProblemDev *, Ctx &) {}
   template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
-  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, const double *, double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
-  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, const double *, double *, double *) {}
 };
 template <int OFF, int CI, class C, class... Rest>
 struct ConImpl<OFF, CI, C, Rest...> {
@@ -200,9 +277,9 @@ struct ConImpl<OFF, CI, C, Rest...> {
     Next::template eval<NX, NU>(c.rest, x, u, g);
   }
   template <int NX, int NU>
-  DEV static void jac(const Ctx &c, const double *x, double *Gx, double *Gu) {
-    C::template jac<NX, NU>(c.k, x, Gx + OFF * NX, Gu + OFF * NU);
-    Next::template jac<NX, NU>(c.rest, x, Gx, Gu);
+  DEV static void jac(const Ctx &c, const double *x, const double *u, double *Gx, double *Gu) {
+    C::template jac<NX, NU>(c.k, x, u, Gx + OFF * NX, Gu + OFF * NU);
+    Next::template jac<NX, NU>(c.rest, x, u, Gx, Gu);
   }
   template <int NX, int NU>
   DEV static void eval(const ProblemDev *P, const double *x, const double *u, double *g) {
@@ -210,9 +287,9 @@ struct ConImpl<OFF, CI, C, Rest...> {
     ConImpl<OFF + C::DUAL, CI + 1, Rest...>::template eval<NX, NU>(P, x, u, g);
   }
   template <int NX, int NU>
-  DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
-    C::template jac<NX, NU>(P->cons[CI], P->pool, x, Gx + OFF * NX, Gu + OFF * NU);
-    ConImpl<OFF + C::DUAL, CI + 1, Rest...>::template jac<NX, NU>(P, x, Gx, Gu);
+  DEV static void jac(const ProblemDev *P, const double *x, const double *u, double *Gx, double *Gu) {
+    C::template jac<NX, NU>(P->cons[CI], P->pool, x, u, Gx + OFF * NX, Gu + OFF * NU);
+    ConImpl<OFF + C::DUAL, CI + 1, Rest...>::template jac<NX, NU>(P, x, u, Gx, Gu);
   }
 };
 
@@ -221,6 +298,7 @@ struct ConList {
   static constexpr int NSEG = sizeof...(Cs);
   static constexpr int M = (0 + ... + Cs::DUAL);
   static constexpr bool HAS_X = (false || ... || Cs::HAS_X);   // any state-dependent constraint row
+  static constexpr bool NEEDS_U = (false || ... || Cs::JAC_U); // some G_u depends on u (thrust-magnitude rows): call sites load u for jac()
   // segment table (constraint-major loops of computeTheta / computeBarrierMerit)
   DEV static int seg_dim(int c) { constexpr int dims[NSEG > 0 ? NSEG : 1] = {Cs::DUAL...}; return dims[c]; }
   DEV static int seg_off(int c) {
@@ -248,13 +326,13 @@ struct ConList {
     ConImpl<0, 0, Cs...>::template eval<NX, NU>(c, x, u, g);
   }
   template <int NX, int NU>
-  DEV static void jac(const Ctx &c, const double *x, double *Gx, double *Gu) {
-    ConImpl<0, 0, Cs...>::template jac<NX, NU>(c, x, Gx, Gu);
+  DEV static void jac(const Ctx &c, const double *x, const double *u, double *Gx, double *Gu) {
+    ConImpl<0, 0, Cs...>::template jac<NX, NU>(c, x, u, Gx, Gu);
   }
   // Gx (M x NX) and Gu (M x NU) must be zero-filled by the caller
   template <int NX, int NU>
-  DEV static void jac(const ProblemDev *P, const double *x, double *Gx, double *Gu) {
-    ConImpl<0, 0, Cs...>::template jac<NX, NU>(P, x, Gx, Gu);
+  DEV static void jac(const ProblemDev *P, const double *x, const double *u, double *Gx, double *Gu) {
+    ConImpl<0, 0, Cs...>::template jac<NX, NU>(P, x, u, Gx, Gu);
   }
 };
 // Layouts whose only path constraint is a control box: every row of G_u has ONE entry (-s or +s) and G_x = 0.  The
@@ -271,15 +349,16 @@ struct ConList<> {
   static constexpr int NSEG = 0;
   static constexpr int M = 0;
   static constexpr bool HAS_X = false;
+  static constexpr bool NEEDS_U = false;
   DEV static int seg_dim(int) { return 0; }
   DEV static int seg_off(int) { return 0; }
   static bool matches(const ProblemDev &P) { return P.n_cons == 0; }
   struct Ctx {};
   DEV static void load(const ProblemDev *, Ctx &) {}
   template <int NX, int NU> DEV static void eval(const Ctx &, const double *, const double *, double *) {}
-  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const Ctx &, const double *, const double *, double *, double *) {}
   template <int NX, int NU> DEV static void eval(const ProblemDev *, const double *, const double *, double *) {}
-  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, double *, double *) {}
+  template <int NX, int NU> DEV static void jac(const ProblemDev *, const double *, const double *, double *, double *) {}
 };
 
 // ---- QuadraticObjective (objective.cpp:80-154); Q_dt = Q*dt and R_dt = R*dt are stored in the pool

@@ -52,13 +52,13 @@ template <int NP> DEV DualN<NP> dcos(const DualN<NP> &a) { DualN<NP> r; double s
 template <int NP> DEV DualN<NP> dsqrt(const DualN<NP> &a) { DualN<NP> r; r.v = sqrt(a.v); double g = 0.5 / r.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
-template <int NP> DEV DualN<NP> dasin(const DualN<NP> &a) { DualN<NP> r; r.v = asin(a.v); double g = 1.0 / sqrt(1.0 - a.v * a.v);
+template <int NP> DEV DualN<NP> dasin(const DualN<NP> &a) { DualN<NP> r; r.v = plant_asin(a.v); double g = 1.0 / sqrt(1.0 - a.v * a.v);
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
 template <int NP> DEV DualN<NP> dtan(const DualN<NP> &a) { DualN<NP> r; r.v = plant_tan(a.v); double g = 1.0 + r.v * r.v;
 #pragma unroll
   for (int i = 0; i < NP; ++i) r.d[i] = g * a.d[i]; return r; }
-DEV double dasin(double a) { return asin(a); }
+DEV double dasin(double a) { return plant_asin(a); }
 DEV double dtan(double a) { return plant_tan(a); }
 DEV double dsin(double a) { return plant_sin(a); }
 DEV double dcos(double a) { return plant_cos(a); }
@@ -124,7 +124,7 @@ template <int NP> DEV Dual2N<NP> operator/(const Dual2N<NP> &a, const Dual2N<NP>
 template <int NP> DEV Dual2N<NP> dsin(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, s, c, -s); }
 template <int NP> DEV Dual2N<NP> dcos(const Dual2N<NP> &a) { double s, c; plant_sincos(a.v, &s, &c); return d2_unary<NP>(a, c, -s, -c); }
 template <int NP> DEV Dual2N<NP> dsqrt(const Dual2N<NP> &a) { const double r = sqrt(a.v); return d2_unary<NP>(a, r, 0.5 / r, -0.25 / (a.v * r)); }
-template <int NP> DEV Dual2N<NP> dasin(const Dual2N<NP> &a) { const double w = 1.0 - a.v * a.v, r = sqrt(w); return d2_unary<NP>(a, asin(a.v), 1.0 / r, a.v / (w * r)); }
+template <int NP> DEV Dual2N<NP> dasin(const Dual2N<NP> &a) { const double w = 1.0 - a.v * a.v, r = sqrt(w); return d2_unary<NP>(a, plant_asin(a.v), 1.0 / r, a.v / (w * r)); }
 template <int NP> DEV Dual2N<NP> dtan(const Dual2N<NP> &a) { const double t = plant_tan(a.v), g = 1.0 + t * t; return d2_unary<NP>(a, t, g, 2.0 * t * g); }
 template <int NP> DEV double dval(const Dual2N<NP> &a) { return a.v; }
 
@@ -486,14 +486,20 @@ struct QuadrotorDyn {   // quadrotor.cpp:33-104 == :166-219; params: mass, arm, 
 struct QuadrotorModel {
   static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR, NX = 13, NU = 4;
   static constexpr bool kDiscrete = false;
-  // quadrotor.cpp:224-278: dual2nd through the normalised-quaternion dynamics.  The reference's getCrossHessian returns nx x nu
-  // matrices where the solvers add nu x nx blocks (an Eigen size mismatch: use_ilqr = false is not defined behaviour there for this
-  // plant); here the cross block has the shape the solver's formula needs.  17 seeds: 307 doubles per dual, scratch-resident -- a
-  // correctness path (full DDP on the quadrotor), not a tuned one.
+  // quadrotor.cpp:224-278: dual2nd through the normalised-quaternion dynamics (17 seeds: 307 doubles per dual number).  On the
+  // device that is a 180-KB private frame per lane -- beyond the 128-KB limit -- so the tensors exist in the HOST build of this file
+  // only (host_models.cpp -> cddp_hip_model_eval -> the plug-in solve), and the device-resident solve refuses use_ilqr = 0 for this
+  // plant.  Little is lost: the reference's own getCrossHessian returns nx x nu matrices where its solvers add nu x nx blocks (an
+  // Eigen size mismatch), i.e. full DDP on the quadrotor is not defined behaviour there; here the cross block has the shape the
+  // solver's formula needs.
+#ifdef CDDP_HOST_MODELS
   static constexpr bool kHasHess = true;
-  DEV_NOINLINE static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
+  static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
     ad_hessian<QuadrotorDyn, NX, NU>(p, x, u, 1.0, Fxx, Fuu, Fux);
   }
+#else
+  static constexpr bool kHasHess = false;
+#endif
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { QuadrotorDyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<QuadrotorDyn, NX, NU>(p, x, u, Fx, Fu);

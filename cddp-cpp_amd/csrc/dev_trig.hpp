@@ -158,13 +158,31 @@ DEV double exp_fast(double x) {
   return y * bits_to_double((unsigned long long)(0x3ff + k) << 52);
 }
 
+// asin on |x| < 0.5 (the car's steering kinematics: asin(sin(delta) h v / wheelbase), |argument| << 0.5): the Sun / FreeBSD msun e_asin.c
+// rational approximation asin(x) = x + x R(x^2), R = p / q (public-domain algorithm, coefficients pS0..pS5, qS1..qS4); < 1 ulp.
+DEV bool asin_fast_ok(double x) { return __builtin_fabs(x) < 0.5; }
+DEV double asin_fast(double x) {
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  if (__builtin_fabs(x) < 0x1p-26) return x;
+  const double t = x * x;
+  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+  return x + x * (p / q);
+}
+
 #ifdef CDDP_TRIG_HOST
+inline double libm_asin(double x) { return std::asin(x); }
 inline double libm_log(double x) { return std::log(x); }
 inline double libm_pow(double x, double y) { return std::pow(x, y); }
 #else
+DEV double libm_asin(double x) { return asin(x); }
 DEV double libm_log(double x) { return log(x); }
 DEV double libm_pow(double x, double y) { return pow(x, y); }
 #endif
+DEV double asin_shared(double x) { return asin_fast_ok(x) ? asin_fast(x) : libm_asin(x); }
 DEV double log_shared(double x) { return log_fast_ok(x) ? log_fast(x) : libm_log(x); }
 DEV double pow_shared(double x, double y) {
   if (log_fast_ok(x)) {
@@ -197,11 +215,13 @@ DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
 DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
 DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
 DEV double plant_tan(double a) { double s, c; sincos_1(a, &s, &c); return s / c; }   // bicycle steering: sin / cos of the shared routine
+DEV double plant_asin(double a) { return asin_shared(a); }
 #else
 DEV void plant_sincos(double a, double *s, double *c) { sincos(a, s, c); }
 DEV double plant_sin(double a) { return sin(a); }
 DEV double plant_cos(double a) { return cos(a); }
 DEV double plant_tan(double a) { return tan(a); }
+DEV double plant_asin(double a) { return asin(a); }
 #endif
 #elif defined(CDDP_HOST_MODELS)   // host_models.cpp: the plants compiled for the host (the host libm, or the shared routine)
 #ifdef CDDP_TRIG_SHARED
@@ -209,11 +229,13 @@ DEV void plant_sincos(double a, double *s, double *c) { sincos_1(a, s, c); }
 DEV double plant_sin(double a) { double s, c; sincos_1(a, &s, &c); return s; }
 DEV double plant_cos(double a) { double s, c; sincos_1(a, &s, &c); return c; }
 DEV double plant_tan(double a) { double s, c; sincos_1(a, &s, &c); return s / c; }
+DEV double plant_asin(double a) { return asin_shared(a); }
 #else
 DEV void plant_sincos(double a, double *s, double *c) { *s = std::sin(a); *c = std::cos(a); }
 DEV double plant_sin(double a) { return std::sin(a); }
 DEV double plant_cos(double a) { return std::cos(a); }
 DEV double plant_tan(double a) { return std::tan(a); }
+DEV double plant_asin(double a) { return std::asin(a); }
 #endif
 #endif
 

@@ -509,7 +509,7 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
       ld<M>(Gc + GI(t, M, 0), kLS, g);
       for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
       for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-      Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+      Cons::template jac<NX, NU>(P, x, u, Qyx, Qyu);
       for (int i = 0; i < M; ++i) {
         const double ss = dmax(s[i], s_floor);
         YS[i] = clip_pos(y[i], ss);
@@ -708,7 +708,9 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
       ld<NU>(d.k + GI(t, NU, 0), kLS, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
       for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
       for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-      Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+      double uj[NU];
+      if constexpr (Cons::NEEDS_U) ld<NU>(Uc + GI(t, NU, 0), kLS, uj);
+      Cons::template jac<NX, NU>(P, x, uj, Qyx, Qyu);
       double ky[MM], ksv[MM], Ky[MM * NX], Ksm[MM * NX];
       for (int rr = 0; rr < M; ++rr) {
         const double ss = dmax(s[rr], s_floor);
@@ -748,7 +750,9 @@ DEV double scaled_inf_du_v(const DevBuf &d, int b, int xslot, double v) {
     ld<M>(Yc + GI(t, M, 0), kLS, y);
     for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
     for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
-    Cons::template jac<NX, NU>(P, x, Gx, Gu);
+    double uz[NU];
+    for (int i = 0; i < NU; ++i) uz[i] = 0.0;   // only G_x is read below; rows whose Jacobian depends on u have G_x = 0
+    Cons::template jac<NX, NU>(P, x, uz, Gx, Gu);
     for (int c = 0; c < Cons::NSEG; ++c) {
       const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
       for (int j = 0; j < NX; ++j) {
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(64) void k_backward_ipddp(DevBuf d, const ProblemDe
         for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-        Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+        Cons::template jac<NX, NU>(P, x, u, Qyx, Qyu);
       }
       double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
       Obj::lx(P, xrt, t, x, Qx);

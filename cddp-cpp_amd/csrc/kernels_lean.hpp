@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-  Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+  Cons::template jac<NX, NU>(P, x, u, Qyx, Qyu);
   double cx[NX], cu[NU];
   Obj::lx(P, xrt, t, x, cx);
   Obj::lu(P, u, cu);
@@ -427,7 +427,9 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-  Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+  double uj[NU];
+  if constexpr (Cons::NEEDS_U) ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, uj);
+  Cons::template jac<NX, NU>(P, x, uj, Qyx, Qyu);
   double ky[M], ksv[M], Ky[M * NX], Ksm[M * NX], ysv[M];
   double apr = 1.0, adu = 1.0;
 #pragma unroll
@@ -760,9 +762,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   double ev_total0 = 0.0, ev_max = 0.0, ev_icomp = 0.0, ys_lo = INFINITY, ys_hi = -INFINITY, run_cost = 0.0;
   const bool l2norm = o.ipddp_theta_norm_l2 != 0;
   // per-step record of the CURRENT iterate (one prefetch group, <= 16 rows for the C2 layout)
-  struct StepIn { double xo[Cons::HAS_X ? NX : 1], s[M], y[M], ksv[M], ky[M], KK[NU * NX], ys[M]; };
+  struct StepIn { double xo[Cons::HAS_X ? NX : 1], uo[Cons::NEEDS_U ? NU : 1], s[M], y[M], ksv[M], ky[M], KK[NU * NX], ys[M]; };
   auto load_step = [&](int tt, StepIn &r) {
     if constexpr (Cons::HAS_X) ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+    if constexpr (Cons::NEEDS_U) ld<NU>(d.U + (size_t)cur * d.planeU + GI(tt, NU, 0), kLS, r.uo);
     ld<M>(Sc + GI(tt, M, 0), kLS, r.s);
     ld<M>(Yc + GI(tt, M, 0), kLS, r.y);
     ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     for (int i = 0; i < M * NX; ++i) Gx[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < M * NU; ++i) Gu[i] = 0.0;
-    Cons::template jac<NX, NU>(cc, cs.xo, Gx, Gu);
+    Cons::template jac<NX, NU>(cc, cs.xo, cs.uo, Gx, Gu);
 #pragma unroll
     for (int r = 0; r < M; ++r) {
       double Ksr[NX], Kyr[NX];

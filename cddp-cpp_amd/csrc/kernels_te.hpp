@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void k_te_condense(DevBuf d, const ProblemDev *
     for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
-    Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+    Cons::template jac<NX, NU>(P, x, u, Qyx, Qyu);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const double ss = dmax(s[i], s_floor);
@@ -870,7 +870,11 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
     for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
     typename Cons::Ctx cctx;
     if constexpr (UDiag<Cons>::value) Cons::load(P, cctx);     // control box only: one entry per row of G_u (see k_forward_ipddp_pc)
-    else Cons::template jac<NX, NU>(P, x, Qyx, Qyu);
+    else {
+      double uj[NU];
+      if constexpr (Cons::NEEDS_U) ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, uj);
+      Cons::template jac<NX, NU>(P, x, uj, Qyx, Qyu);
+    }
     double apr = 1.0, adu = 1.0;
 #pragma unroll
     for (int rr = 0; rr < M; ++rr) {

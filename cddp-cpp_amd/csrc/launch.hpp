@@ -186,6 +186,7 @@ struct Launcher {
 void register_pendulum(std::vector<KernelSet> &);
 void register_cartpole(std::vector<KernelSet> &);
 void register_unicycle(std::vector<KernelSet> &);
+void register_vehicles(std::vector<KernelSet> &);
 void register_lti(std::vector<KernelSet> &);
 void register_quadrotor(std::vector<KernelSet> &);
 void register_quad12(std::vector<KernelSet> &);

@@ -235,6 +235,12 @@ struct Quadrotor : DynamicalSystem {  // quadrotor.hpp: (timestep, mass, inertia
   Quadrotor(double dt, double mass, const Matrix &inertia, double arm_length, std::string integ = "rk4")
       : DynamicalSystem(CDDP_HIP_MODEL_QUADROTOR, 13, 4, dt, integ) { params = {mass, arm_length, inertia(0, 0), inertia(1, 1), inertia(2, 2), 9.81}; }
 };
+struct Bicycle : DynamicalSystem {    // bicycle.hpp: (timestep, wheelbase, integration_type); state [x, y, theta, v], control [a, delta]
+  Bicycle(double dt, double wheelbase, std::string integ = "euler") : DynamicalSystem(CDDP_HIP_MODEL_BICYCLE, 4, 2, dt, integ) { params = {wheelbase}; }
+};
+struct Car : DynamicalSystem {        // car.hpp: (timestep, wheelbase, integration_type); a DISCRETE plant (car.cpp:24-60); control [delta, a]
+  Car(double dt = 0.03, double wheelbase = 2.0, std::string integ = "euler") : DynamicalSystem(CDDP_HIP_MODEL_CAR, 4, 2, dt, integ) { params = {wheelbase}; }
+};
 struct Manipulator : DynamicalSystem {
   Manipulator(double dt, std::string integ = "rk4") : DynamicalSystem(CDDP_HIP_MODEL_MANIPULATOR, 6, 3, dt, integ) {}
 };
@@ -410,6 +416,78 @@ class LinearConstraint : public Constraint {    // constraint.hpp:253-311
   Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix((int)b_.size(), (int)u.size()); }
   Matrix A_; Vector b_; double scale_;
 };
+class SecondOrderConeConstraint : public Constraint {   // constraint.hpp:626-800
+ public:
+  SecondOrderConeConstraint(const Vector &cone_origin, const Vector &opening_direction, double cone_angle_fov, double regularization_epsilon = 1e-6,
+                            const std::string &name = "SecondOrderConeConstraint")
+      : Constraint(name), origin_(cone_origin), axis_(opening_direction), cos_fov_(std::cos(cone_angle_fov)), epsilon_(regularization_epsilon) {
+    if (cone_angle_fov < 0 || cone_angle_fov > 3.14159265358979323846) throw std::invalid_argument("SecondOrderConeConstraint: Cone angle must be between 0 and PI.");
+    if (regularization_epsilon <= 0) throw std::invalid_argument("SecondOrderConeConstraint: Regularization epsilon must be positive.");
+    if (origin_.size() != 3 || axis_.size() != 3) throw std::invalid_argument("SecondOrderConeConstraint: origin and direction are 3-vectors");
+    const double n = std::sqrt(axis_[0] * axis_[0] + axis_[1] * axis_[1] + axis_[2] * axis_[2]);
+    if (n == 0.0) throw std::invalid_argument("SecondOrderConeConstraint: Opening direction cannot be zero vector.");
+    for (double &v : axis_) v /= n;
+  }
+  int getDualDim() const override { return 1; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_SOC; c.dim = 3; c.center = origin_.data(); c.lower = axis_.data(); c.radius = cos_fov_; c.scale = epsilon_; return true; }
+  Vector evaluate(const Vector &x, const Vector &) const override {
+    if (x.size() < 3) throw std::invalid_argument("SecondOrderConeConstraint: State dimension must be at least 3.");
+    const double v0 = x[0] - origin_[0], v1 = x[1] - origin_[1], v2 = x[2] - origin_[2];
+    return {std::sqrt(((v0 * v0 + v1 * v1) + v2 * v2) + epsilon_) * cos_fov_ - ((v0 * axis_[0] + v1 * axis_[1]) + v2 * axis_[2])};
+  }
+  Vector getUpperBound() const override { return {0.0}; }
+  Matrix getStateJacobian(const Vector &x, const Vector &) const override {
+    Matrix J(1, (int)x.size());
+    const double v[3] = {x[0] - origin_[0], x[1] - origin_[1], x[2] - origin_[2]};
+    const double rn = std::sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + epsilon_);
+    for (int i = 0; i < 3; ++i) J(0, i) = rn > 1e-9 ? cos_fov_ * (v[i] / rn) - axis_[i] : -axis_[i];
+    return J;
+  }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix(1, (int)u.size()); }
+  Vector origin_, axis_; double cos_fov_, epsilon_;
+};
+class ThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:802-927
+ public:
+  ThrustMagnitudeConstraint(double min_thrust_norm, double max_thrust_norm, double epsilon = 1e-6)
+      : Constraint("ThrustMagnitudeConstraint"), min_{min_thrust_norm}, max_(max_thrust_norm), epsilon_(epsilon) {
+    if (min_thrust_norm < 0.0) throw std::invalid_argument("ThrustMagnitudeConstraint: min_thrust_norm must be non-negative.");
+    if (max_thrust_norm < min_thrust_norm) throw std::invalid_argument("ThrustMagnitudeConstraint: max_thrust_norm must be greater than or equal to min_thrust_norm.");
+    if (epsilon <= 0.0) throw std::invalid_argument("ThrustMagnitudeConstraint: epsilon must be positive.");
+  }
+  int getDualDim() const override { return 2; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_THRUST; c.dim = dim_; c.lower = min_.data(); c.radius = max_; c.scale = epsilon_; return dim_ > 0; }
+  void setControlDim(int nu) { dim_ = nu; }   // the device descriptor carries the control dimension (CDDP::addPathConstraint sets it)
+  Vector evaluate(const Vector &, const Vector &u) const override { double sq = 0; for (double v : u) sq += v * v; const double n = std::sqrt(sq); return {min_[0] - n, n - max_}; }
+  Vector getUpperBound() const override { return {0.0, 0.0}; }
+  Matrix getStateJacobian(const Vector &x, const Vector &) const override { return Matrix(2, (int)x.size()); }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override {
+    Matrix J(2, (int)u.size()); double sq = 0; for (double v : u) sq += v * v;
+    const double rn = std::sqrt(sq + epsilon_);
+    if (!(rn < epsilon_)) for (int i = 0; i < (int)u.size(); ++i) { J(0, i) = -(u[i] / rn); J(1, i) = u[i] / rn; }
+    return J;
+  }
+  Vector min_; double max_, epsilon_; int dim_ = 0;
+};
+class MaxThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:929-1048
+ public:
+  explicit MaxThrustMagnitudeConstraint(double max_thrust_norm, double epsilon = 1e-6) : Constraint("MaxThrustMagnitudeConstraint"), max_(max_thrust_norm), epsilon_(epsilon) {
+    if (max_thrust_norm < 0.0) throw std::invalid_argument("MaxThrustMagnitudeConstraint: max_thrust_norm must be non-negative.");
+    if (epsilon <= 0.0) throw std::invalid_argument("MaxThrustMagnitudeConstraint: epsilon must be positive.");
+  }
+  int getDualDim() const override { return 1; }
+  bool fill(cddp_hip_constraint &c) const override { c.kind = CDDP_HIP_CON_MAX_THRUST; c.dim = dim_; c.radius = max_; c.scale = epsilon_; return dim_ > 0; }
+  void setControlDim(int nu) { dim_ = nu; }
+  Vector evaluate(const Vector &, const Vector &u) const override { double sq = 0; for (double v : u) sq += v * v; return {std::sqrt(sq) - max_}; }
+  Vector getUpperBound() const override { return {0.0}; }
+  Matrix getStateJacobian(const Vector &x, const Vector &) const override { return Matrix(1, (int)x.size()); }
+  Matrix getControlJacobian(const Vector &, const Vector &u) const override {
+    Matrix J(1, (int)u.size()); double sq = 0; for (double v : u) sq += v * v;
+    const double rn = std::sqrt(sq + epsilon_);
+    if (rn > std::numeric_limits<double>::min()) for (int i = 0; i < (int)u.size(); ++i) J(0, i) = u[i] / rn;
+    return J;
+  }
+  double max_, epsilon_; int dim_ = 0;
+};
 class TerminalConstraint {
  public:
   virtual ~TerminalConstraint() = default;
@@ -486,7 +564,11 @@ class CDDP {
     if (!system_ || !objective_) return false;
     if (system_->isHostPlant() || typeid(*objective_) != typeid(QuadraticObjective)) return true;
     cddp_hip_constraint c;
-    for (auto &kv : path_constraint_set_) if (!kv.second->fill(c)) return true;
+    for (auto &kv : path_constraint_set_) {
+      if (auto *tm = dynamic_cast<ThrustMagnitudeConstraint *>(kv.second.get())) tm->setControlDim(system_->getControlDim());
+      if (auto *mt = dynamic_cast<MaxThrustMagnitudeConstraint *>(kv.second.get())) mt->setControlDim(system_->getControlDim());
+      if (!kv.second->fill(c)) return true;
+    }
     return false;
   }
 
@@ -758,6 +840,8 @@ inline void CDDP::flatten(int solver, Flat &f) const {
   p.Q = qo->Q_.a.data(); p.R = qo->R_.a.data(); p.Qf = qo->Qf_.a.data(); p.x_ref = qo->reference_state_.data();
   if (!qo->reference_states_.empty()) { for (auto &v : qo->reference_states_) f.xref_traj.insert(f.xref_traj.end(), v.begin(), v.end()); p.x_ref_traj = f.xref_traj.data(); }
   for (auto &kv : path_constraint_set_) {
+    if (auto *tm = dynamic_cast<ThrustMagnitudeConstraint *>(kv.second.get())) tm->setControlDim(system_->getControlDim());
+    if (auto *mt = dynamic_cast<MaxThrustMagnitudeConstraint *>(kv.second.get())) mt->setControlDim(system_->getControlDim());
     cddp_hip_constraint c; std::memset(&c, 0, sizeof(c)); std::strncpy(c.name, kv.first.c_str(), CDDP_HIP_NAME_LEN - 1); c.scale = 1.0; if (!kv.second->fill(c)) throw std::runtime_error("CDDP::flatten: constraint '" + kv.first + "' has no device descriptor"); f.cons.push_back(c);
   }
   for (auto &kv : terminal_constraint_set_) {

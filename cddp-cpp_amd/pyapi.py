@@ -20,9 +20,11 @@ NAME_LEN = 48
 # enums (include/cddp_hip.h)
 MODEL_PENDULUM, MODEL_CARTPOLE, MODEL_UNICYCLE, MODEL_LTI = 0, 1, 2, 3
 MODEL_QUADROTOR, MODEL_MANIPULATOR, MODEL_QUADROTOR_EULER12, MODEL_MANIPULATOR7 = 4, 5, 6, 7
+MODEL_BICYCLE, MODEL_CAR = 8, 9
 EULER, HEUN, RK3, RK4 = 0, 1, 2, 3
 SOLVER_CLDDP, SOLVER_IPDDP = 0, 1
 CON_CONTROL_BOX, CON_STATE_BOX, CON_BALL, CON_LINEAR = 0, 1, 2, 3
+CON_SOC, CON_THRUST, CON_MAX_THRUST = 4, 5, 6
 TERM_EQUALITY, TERM_INEQUALITY = 0, 1
 STATUS_RUNNING, STATUS_OPTIMAL, STATUS_ACCEPTABLE, STATUS_MAX_ITERATIONS, STATUS_REG_LIMIT, STATUS_MAX_CPU_TIME = range(6)
 STATUS_STRINGS = [
@@ -238,6 +240,45 @@ class Problem:
         c.A = _ptr(A_); c.b = _ptr(b_); c.scale = 1.0
         self._cons.append(c); self._rebuild(); return self
 
+    def add_second_order_cone(self, name, cone_origin, opening_direction, cone_angle_fov, regularization_epsilon=1e-6):
+        """SecondOrderConeConstraint (constraint.hpp:626-668): the constructor's checks and normalisation happen here."""
+        if cone_angle_fov < 0 or cone_angle_fov > np.pi:
+            raise ValueError("SecondOrderConeConstraint: Cone angle must be between 0 and PI.")
+        if regularization_epsilon <= 0:
+            raise ValueError("SecondOrderConeConstraint: Regularization epsilon must be positive.")
+        o = _arr(cone_origin).reshape(3); a = _arr(opening_direction).reshape(3)
+        n = float(np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]))
+        if n == 0.0:
+            raise ValueError("SecondOrderConeConstraint: Opening direction cannot be zero vector.")
+        a = a / n
+        self.keep += [o, a]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_SOC; c.dim = 3
+        c.center = _ptr(o); c.lower = _ptr(a); c.radius = float(np.cos(cone_angle_fov)); c.scale = regularization_epsilon
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_thrust_magnitude(self, name, min_thrust_norm, max_thrust_norm, epsilon=1e-6):
+        """ThrustMagnitudeConstraint (constraint.hpp:802-838)."""
+        if min_thrust_norm < 0.0:
+            raise ValueError("ThrustMagnitudeConstraint: min_thrust_norm must be non-negative.")
+        if max_thrust_norm < min_thrust_norm:
+            raise ValueError("ThrustMagnitudeConstraint: max_thrust_norm must be greater than or equal to min_thrust_norm.")
+        if epsilon <= 0.0:
+            raise ValueError("ThrustMagnitudeConstraint: epsilon must be positive.")
+        mn = _arr([min_thrust_norm]); self.keep += [mn]
+        c = Constraint(); c.name = name.encode(); c.kind = CON_THRUST; c.dim = self.nu
+        c.lower = _ptr(mn); c.radius = max_thrust_norm; c.scale = epsilon
+        self._cons.append(c); self._rebuild(); return self
+
+    def add_max_thrust_magnitude(self, name, max_thrust_norm, epsilon=1e-6):
+        """MaxThrustMagnitudeConstraint (constraint.hpp:929-953)."""
+        if max_thrust_norm < 0.0:
+            raise ValueError("MaxThrustMagnitudeConstraint: max_thrust_norm must be non-negative.")
+        if epsilon <= 0.0:
+            raise ValueError("MaxThrustMagnitudeConstraint: epsilon must be positive.")
+        c = Constraint(); c.name = name.encode(); c.kind = CON_MAX_THRUST; c.dim = self.nu
+        c.radius = max_thrust_norm; c.scale = epsilon
+        self._cons.append(c); self._rebuild(); return self
+
     def add_terminal_equality(self, name, target):
         t_ = _arr(target); self.keep += [t_]
         c = TerminalConstraint(); c.name = name.encode(); c.kind = TERM_EQUALITY; c.dim = t_.size; c.target = _ptr(t_)
@@ -252,7 +293,7 @@ class Problem:
     def dual_dim(self):
         m = 0
         for c in self._cons:
-            m += {CON_CONTROL_BOX: 2 * c.dim, CON_STATE_BOX: 2 * c.dim, CON_BALL: 1, CON_LINEAR: c.dim}[c.kind]
+            m += {CON_CONTROL_BOX: 2 * c.dim, CON_STATE_BOX: 2 * c.dim, CON_BALL: 1, CON_LINEAR: c.dim, CON_SOC: 1, CON_THRUST: 2, CON_MAX_THRUST: 1}[c.kind]
         return m
 
 
@@ -294,6 +335,62 @@ def unicycle_problem(solver=SOLVER_IPDDP, horizon=200, obstacle=True):
     p.add_control_box("control_limits", [-1.1, -np.pi], [1.1, np.pi])
     if obstacle:
         p.add_ball("obstacle", 0.4, [1.0, 1.0])
+    p.x0 = np.array([0.0, 0.0, np.pi / 4])
+    p.U0_const = np.array([0.5, 0.1])
+    return p
+
+
+def bicycle_problem(solver=SOLVER_IPDDP, horizon=100, constrained=True, integrator=None):
+    """Kinematic bicycle (src/dynamics_model/bicycle.cpp; constants of tests/dynamics_model/test_bicycle.cpp:28-40: dt 0.05, wheelbase
+    2): drive from the origin to (2, 1, pi/4) at rest; state [x, y, theta, v], control [a, delta]."""
+    o = default_options(); o.max_iterations = 60; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-6
+    dt = 0.05
+    p = Problem(solver, MODEL_BICYCLE, EULER if integrator is None else integrator, 4, 2, horizon, dt, np.zeros((4, 4)), np.diag([0.05, 0.5]),
+                np.diag([100.0, 100.0, 50.0, 10.0]), [2.0, 1.0, np.pi / 4, 0.0], model_params=[2.0], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", [-2.0, -0.5], [2.0, 0.5])
+    p.x0 = np.array([0.0, 0.0, 0.0, 0.5])
+    p.U0_const = np.array([0.1, 0.05])
+    return p
+
+
+def car_problem(solver=SOLVER_IPDDP, horizon=100, constrained=True):
+    """The reference's car (src/dynamics_model/car.cpp, a DISCRETE plant; dt 0.03, wheelbase 2, control box +-[0.5, 2] of
+    tests/cddp_core/test_ipddp_solver.cpp:686-750) with a QUADRATIC parking cost, so that the device-resident solve can be compared with
+    the oracle (the reference's own test pairs it with a user NonlinearObjective: that shape runs through the plug-in solve)."""
+    o = default_options(); o.max_iterations = 80; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-6
+    o.reg_initial_value = 1e-2
+    dt = 0.03
+    p = Problem(solver, MODEL_CAR, EULER, 4, 2, horizon, dt, np.diag([1e-2, 1e-2, 0.0, 0.0]), np.diag([1e-2, 1e-4]),
+                np.diag([10.0, 10.0, 10.0, 3.0]), [0.0, 0.0, 0.0, 0.0], model_params=[2.0], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", [-0.5, -2.0], [0.5, 2.0])
+    p.x0 = np.array([1.0, 1.0, 1.5 * np.pi, 0.0])
+    p.U0_const = np.array([0.01, 0.1])
+    return p
+
+
+def unicycle_cone_problem(solver=SOLVER_IPDDP, horizon=100):
+    """Unicycle with a control box and a SecondOrderConeConstraint on (x, y, theta) (constraint.hpp:626-800; geometry of
+    tests/cddp_core/test_constraint.cpp:236-243: a 45-degree cone opening along +y from below the start), m = 5."""
+    p = unicycle_problem(solver, horizon, obstacle=False)
+    p.add_second_order_cone("SecondOrderConeConstraint", [0.0, -0.5, 0.0], [0.0, 1.0, 0.0], np.pi / 4.0 + 0.35, 1e-6)
+    return p
+
+
+def unicycle_thrust_problem(solver=SOLVER_IPDDP, horizon=100, two_sided=True):
+    """Unicycle whose control norm |(v, omega)| is bounded by the thrust-magnitude rows (constraint.hpp:802-1048): the two-sided
+    ThrustMagnitudeConstraint (m = 2) or MaxThrustMagnitudeConstraint (m = 1) under the reference names.  Weights chosen so that the
+    reference algorithm converges: IPDDP linearises path constraints to first order only (no constraint Hessians in
+    ipddp_solver.cpp), and with a norm bound that ends up ACTIVE its iterates do not settle (oracle and twin agree on that)."""
+    o = default_options(); o.max_iterations = 100; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-6
+    dt = 0.03
+    p = Problem(solver, MODEL_UNICYCLE, EULER, 3, 2, horizon, dt, np.zeros((3, 3)), (0.5 if two_sided else 2.0) * np.eye(2),
+                np.diag([10.0, 10.0, 5.0]), [2.0, 2.0, np.pi / 2], options=o)
+    if two_sided:
+        p.add_thrust_magnitude("ThrustMagnitudeConstraint", 0.3, 2.0, 1e-6)
+    else:
+        p.add_max_thrust_magnitude("MaxThrustMagnitudeConstraint", 2.0, 1e-6)
     p.x0 = np.array([0.0, 0.0, np.pi / 4])
     p.U0_const = np.array([0.5, 0.1])
     return p

@@ -225,6 +225,18 @@ class Quadrotor(_BuiltinPlant):   # :177-182
         self.params = [mass, arm_length, J[0, 0], J[1, 1], J[2, 2], 9.81]
 
 
+class Bicycle(_BuiltinPlant):       # bind_dynamics.cpp:143-146: (timestep, wheelbase, integration_type)
+    def __init__(self, timestep, wheelbase, integration_type="euler"):
+        self.model = _api().MODEL_BICYCLE
+        super().__init__(4, 2, timestep, integration_type); self.params = [wheelbase]
+
+
+class Car(_BuiltinPlant):           # bind_dynamics.cpp:148-150: (timestep, wheelbase, integration_type); a discrete plant (car.cpp:24-60)
+    def __init__(self, timestep=0.03, wheelbase=2.0, integration_type="euler"):
+        self.model = _api().MODEL_CAR
+        super().__init__(4, 2, timestep, integration_type); self.params = [wheelbase]
+
+
 class Manipulator(_BuiltinPlant):  # :189-191
     def __init__(self, timestep, integration_type="rk4"):
         self.model = _api().MODEL_MANIPULATOR
@@ -373,6 +385,67 @@ class LinearConstraint(Constraint):   # constraint.hpp:253-311: g = A x, upper =
     def get_control_jacobian(self, x, u): return np.zeros((self.b.size, np.asarray(u).size))
 
 
+class SecondOrderConeConstraint(Constraint):   # constraint.hpp:626-800 / bind_constraints.cpp:146-150
+    def __init__(self, cone_origin, opening_direction, cone_angle_fov, regularization_epsilon=1e-6, name="SecondOrderConeConstraint"):
+        if cone_angle_fov < 0 or cone_angle_fov > np.pi:
+            raise ValueError("SecondOrderConeConstraint: Cone angle must be between 0 and PI.")
+        if regularization_epsilon <= 0:
+            raise ValueError("SecondOrderConeConstraint: Regularization epsilon must be positive.")
+        a = np.asarray(opening_direction, dtype=np.float64).reshape(3); n = float(np.sqrt(a @ a))
+        if n == 0.0:
+            raise ValueError("SecondOrderConeConstraint: Opening direction cannot be zero vector.")
+        self.origin = np.asarray(cone_origin, dtype=np.float64).reshape(3); self.axis = a / n
+        self.fov = float(cone_angle_fov); self.cos_fov = float(np.cos(cone_angle_fov)); self.epsilon = float(regularization_epsilon)
+    def get_dual_dim(self): return 1
+    def evaluate(self, x, u):
+        v = np.asarray(x, dtype=np.float64)[:3] - self.origin
+        return np.array([np.sqrt(float(v @ v) + self.epsilon) * self.cos_fov - float(v @ self.axis)])
+    def get_upper_bound(self): return np.zeros(1)
+    def get_state_jacobian(self, x, u):
+        x = np.asarray(x, dtype=np.float64); v = x[:3] - self.origin; rn = np.sqrt(float(v @ v) + self.epsilon)
+        J = np.zeros((1, x.size)); J[0, :3] = self.cos_fov * (v / rn) - self.axis if rn > 1e-9 else -self.axis
+        return J
+    def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
+
+
+class ThrustMagnitudeConstraint(Constraint):   # constraint.hpp:802-927
+    def __init__(self, min_thrust_norm, max_thrust_norm, epsilon=1e-6):
+        if min_thrust_norm < 0.0:
+            raise ValueError("ThrustMagnitudeConstraint: min_thrust_norm must be non-negative.")
+        if max_thrust_norm < min_thrust_norm:
+            raise ValueError("ThrustMagnitudeConstraint: max_thrust_norm must be greater than or equal to min_thrust_norm.")
+        if epsilon <= 0.0:
+            raise ValueError("ThrustMagnitudeConstraint: epsilon must be positive.")
+        self.min_norm, self.max_norm, self.epsilon = float(min_thrust_norm), float(max_thrust_norm), float(epsilon)
+    def get_dual_dim(self): return 2
+    def evaluate(self, x, u): n = np.sqrt(float(np.asarray(u) @ np.asarray(u))); return np.array([self.min_norm - n, n - self.max_norm])
+    def get_upper_bound(self): return np.zeros(2)
+    def get_state_jacobian(self, x, u): return np.zeros((2, np.asarray(x).size))
+    def get_control_jacobian(self, x, u):
+        u = np.asarray(u, dtype=np.float64); rn = np.sqrt(float(u @ u) + self.epsilon); J = np.zeros((2, u.size))
+        if not rn < self.epsilon:
+            J[0] = -(u / rn); J[1] = u / rn
+        return J
+
+
+class MaxThrustMagnitudeConstraint(Constraint):   # constraint.hpp:929-1048
+    def __init__(self, max_thrust_norm, epsilon=1e-6):
+        if max_thrust_norm < 0.0:
+            raise ValueError("MaxThrustMagnitudeConstraint: max_thrust_norm must be non-negative.")
+        if epsilon <= 0.0:
+            raise ValueError("MaxThrustMagnitudeConstraint: epsilon must be positive.")
+        self.max_norm, self.epsilon = float(max_thrust_norm), float(epsilon)
+    def get_dual_dim(self): return 1
+    def evaluate(self, x, u): return np.array([np.sqrt(float(np.asarray(u) @ np.asarray(u))) - self.max_norm])
+    def get_upper_bound(self): return np.zeros(1)
+    def get_state_jacobian(self, x, u): return np.zeros((1, np.asarray(x).size))
+    def get_control_jacobian(self, x, u):
+        u = np.asarray(u, dtype=np.float64); rn = np.sqrt(float(u @ u) + self.epsilon); J = np.zeros((1, u.size))
+        if rn > sys.float_info.min:
+            J[0] = u / rn
+        return J
+
+
 class TerminalEqualityConstraint:   # terminal_constraint.hpp
     def __init__(self, target_state):
         self.target = np.asarray(target_state, dtype=np.float64)
@@ -468,6 +541,9 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
             elif isinstance(c, ControlConstraint): p.add_control_box(name, c.lower, c.upper, c.scale)
             elif isinstance(c, BallConstraint): p.add_ball(name, c.radius, c.center, c.scale)
             elif isinstance(c, LinearConstraint): p.add_linear(name, c.A, c.b)
+            elif isinstance(c, SecondOrderConeConstraint): p.add_second_order_cone(name, c.origin, c.axis, c.fov, c.epsilon)
+            elif isinstance(c, ThrustMagnitudeConstraint): p.add_thrust_magnitude(name, c.min_norm, c.max_norm, c.epsilon)
+            elif isinstance(c, MaxThrustMagnitudeConstraint): p.add_max_thrust_magnitude(name, c.max_norm, c.epsilon)
             else: raise NotImplementedError("constraint type %s has no device kernel" % type(c).__name__)
         for name in sorted(self._terms):
             c = self._terms[name]
@@ -528,7 +604,8 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def _needs_host_plugins(self):
         if self._sys is None or self._obj is None:
             return False
-        builtin_con = (ControlConstraint, StateConstraint, BallConstraint, LinearConstraint)
+        builtin_con = (ControlConstraint, StateConstraint, BallConstraint, LinearConstraint, SecondOrderConeConstraint,
+                       ThrustMagnitudeConstraint, MaxThrustMagnitudeConstraint)
         return (self._sys.model is None or type(self._obj) is not QuadraticObjective
                 or any(type(c) not in builtin_con for c in self._cons.values()))
 

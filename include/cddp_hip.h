@@ -67,7 +67,11 @@ enum cddp_hip_constraint_kind {
   CDDP_HIP_CON_CONTROL_BOX = 0, /* BoxConstraint<Control>: g=[-u;u]*s, upper=[-lb;ub]*s  */
   CDDP_HIP_CON_STATE_BOX = 1,   /* BoxConstraint<State>                                   */
   CDDP_HIP_CON_BALL = 2,        /* BallConstraint: g=-s*|x[:d]-c|^2, upper=-s*r^2         */
-  CDDP_HIP_CON_LINEAR = 3       /* LinearConstraint: g=A x, upper=b                       */
+  CDDP_HIP_CON_LINEAR = 3,      /* LinearConstraint: g=A x, upper=b                       */
+  CDDP_HIP_CON_SOC = 4,         /* SecondOrderConeConstraint (constraint.hpp:626-800): g = cos(fov) sqrt(|x[:3]-o|^2+eps) - (x[:3]-o).axis;
+                                   center = origin o (3), lower = UNIT opening direction (3), radius = cos(fov), scale = eps, dim = 3 */
+  CDDP_HIP_CON_THRUST = 5,      /* ThrustMagnitudeConstraint (:802-927): g = [min-|u|, |u|-max]; lower[0] = min, radius = max, scale = eps, dim = nu */
+  CDDP_HIP_CON_MAX_THRUST = 6   /* MaxThrustMagnitudeConstraint (:929-1048): g = |u|-max; radius = max, scale = eps, dim = nu */
 };
 
 /* reference include/cddp-cpp/cddp_core/terminal_constraint.hpp:62-263 */

@@ -255,10 +255,26 @@ struct Solver {
       case CDDP_HIP_CON_LINEAR: {  // constraint.hpp:263-277
         return c.A * x - c.b;
       }
+      case CDDP_HIP_CON_SOC: {     // constraint.hpp:672-692: g = cos(fov) sqrt(|p_s - p_o|^2 + eps) - (p_s - p_o) . axis; upper bound 0
+        const double v0 = x(0) - c.center(0), v1 = x(1) - c.center(1), v2 = x(2) - c.center(2);
+        const double v_squared = (v0 * v0 + v1 * v1) + v2 * v2;           // Vector3d::squaredNorm (fixed size, unrolled)
+        const double reg_norm = std::sqrt(v_squared + c.scale);
+        const double dot_prod = (v0 * c.lower(0) + v1 * c.lower(1)) + v2 * c.lower(2);
+        g(0) = reg_norm * c.radius - dot_prod;
+        return g;
+      }
+      case CDDP_HIP_CON_THRUST:    // constraint.hpp:840-851: g = [min - |u|, |u| - max]
+      case CDDP_HIP_CON_MAX_THRUST: {   // :955-964: g = |u| - max
+        double sq = 0; for (int i = 0; i < c.dim; ++i) sq += u(i) * u(i);
+        const double u_norm = std::sqrt(sq);
+        if (c.kind == CDDP_HIP_CON_THRUST) { g(0) = c.lower(0) - u_norm; g(1) = u_norm - c.radius; }
+        else g(0) = u_norm - c.radius;
+        return g;
+      }
     }
     return g;
   }
-  void con_jac(const ConstraintDesc &c, const Vec &x, Mat &gx, Mat &gu) const {
+  void con_jac(const ConstraintDesc &c, const Vec &x, const Vec &u, Mat &gx, Mat &gu) const {
     gx = Mat(c.dual_dim, nx); gu = Mat(c.dual_dim, nu);
     switch (c.kind) {
       case CDDP_HIP_CON_CONTROL_BOX:  // constraint.hpp:203-219
@@ -271,6 +287,24 @@ struct Solver {
         for (int i = 0; i < c.dim; ++i) gx(0, i) = -2.0 * c.scale * (x(i) - c.center(i));
         break;
       case CDDP_HIP_CON_LINEAR: gx = c.A; break;
+      case CDDP_HIP_CON_SOC: {     // constraint.hpp:710-741
+        const double v[3] = {x(0) - c.center(0), x(1) - c.center(1), x(2) - c.center(2)};
+        const double reg_norm = std::sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + c.scale);
+        for (int i = 0; i < 3; ++i) gx(0, i) = (reg_norm > 1e-9) ? c.radius * (v[i] / reg_norm) - c.lower(i) : -c.lower(i);
+        break;
+      }
+      case CDDP_HIP_CON_THRUST: {  // constraint.hpp:861-880: rows -/+ u^T / sqrt(|u|^2 + eps), zero when that norm is below eps
+        double sq = 0; for (int i = 0; i < c.dim; ++i) sq += u(i) * u(i);
+        const double u_reg_norm = std::sqrt(sq + c.scale);
+        if (!(u_reg_norm < c.scale)) for (int i = 0; i < c.dim; ++i) { gu(0, i) = -(u(i) / u_reg_norm); gu(1, i) = u(i) / u_reg_norm; }
+        break;
+      }
+      case CDDP_HIP_CON_MAX_THRUST: {   // :979-993
+        double sq = 0; for (int i = 0; i < c.dim; ++i) sq += u(i) * u(i);
+        const double u_reg_norm = std::sqrt(sq + c.scale);
+        if (u_reg_norm > std::numeric_limits<double>::min()) for (int i = 0; i < c.dim; ++i) gu(0, i) = u(i) / u_reg_norm;
+        break;
+      }
     }
   }
   const ConstraintDesc *clddp_control_constraint() const {  // clddp_solver.cpp:85-86
@@ -883,7 +917,7 @@ struct Solver {
       }
     }
     // precomputeConstraintGradients (ipddp_solver.cpp:2145-2250)
-    if (hpc) for (int t = 0; t < N; ++t) for (auto &c : cons) { Mat gx, gu; con_jac(c, X[t], gx, gu); Gx[t].setBlock(c.offset, 0, gx); Gu[t].setBlock(c.offset, 0, gu); }
+    if (hpc) for (int t = 0; t < N; ++t) for (auto &c : cons) { Mat gx, gu; con_jac(c, X[t], U[t], gx, gu); Gx[t].setBlock(c.offset, 0, gx); Gu[t].setBlock(c.offset, 0, gu); }
 
     Vec V_x = final_grad(X.back());
     Mat V_xx = symmetrize(final_hess());
@@ -1421,6 +1455,12 @@ static Solver *build(const cddp_hip_problem *p) {
         d.dual_dim = 1; d.center = Vec::FromPtr(c.center, c.dim); d.ip_upper = Vec(1, 1); d.ip_upper(0) = -(c.radius * c.radius) * c.scale; break;
       case CDDP_HIP_CON_LINEAR:
         d.dual_dim = c.dim; d.A = Mat::FromPtr(c.A, c.dim, p->nx); d.b = Vec::FromPtr(c.b, c.dim); break;
+      case CDDP_HIP_CON_SOC:      // center = cone origin, lower = unit opening direction, radius = cos(fov), scale = eps
+        d.dual_dim = 1; d.center = Vec::FromPtr(c.center, 3); d.lower = Vec::FromPtr(c.lower, 3); break;
+      case CDDP_HIP_CON_THRUST:   // lower[0] = min, radius = max, scale = eps
+        d.dual_dim = 2; d.lower = Vec::FromPtr(c.lower, 1); break;
+      case CDDP_HIP_CON_MAX_THRUST:
+        d.dual_dim = 1; break;
     }
     s->cons.push_back(d);
   }
@@ -1624,7 +1664,7 @@ int cddp_oracle_constraint_eval(void *o, const double *x, const double *u, doubl
   Solver *s = (Solver *)o;
   Vec xv = Vec::FromPtr(x, s->nx), uv = Vec::FromPtr(u, s->nu);
   for (auto &c : s->cons) {
-    Vec gv = s->con_g(c, xv, uv); Mat jx, ju; s->con_jac(c, xv, jx, ju);
+    Vec gv = s->con_g(c, xv, uv); Mat jx, ju; s->con_jac(c, xv, uv, jx, ju);
     for (int i = 0; i < c.dual_dim; ++i) {
       if (g) g[c.offset + i] = gv(i);
       if (gx) for (int j = 0; j < s->nx; ++j) gx[(c.offset + i) * s->nx + j] = jx(i, j);

@@ -69,15 +69,17 @@ inline double olog(double x) { return trig_mode() == 1 ? cddp_dev::log_shared(x)
 inline double opow(double x, double y) { return trig_mode() == 1 ? cddp_dev::pow_shared(x, y) : std::pow(x, y); }
 inline double osin(double a) { return trig_perturb(base_sin(a), a); }
 inline double ocos(double a) { return trig_perturb(base_cos(a), a + 0.5); }
+inline double oasin(double a) { return trig_mode() == 1 ? cddp_dev::asin_shared(a) : std::asin(a); }
 inline double otan(double a) { return trig_mode() == 1 ? base_sin(a) / base_cos(a) : std::tan(a); }   // parity build: sin / cos of the shared routine
 inline double tan(double a) { return otan(a); }
+inline double asin(double a) { return oasin(a); }
 inline double sin(double a) { return osin(a); }   // found by the unqualified calls of the templated dynamics (S = double)
 inline double cos(double a) { return ocos(a); }
 inline Dual sin(const Dual &a) { Dual r; r.v = osin(a.v); double c = ocos(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = c * a.d[i]; return r; }
 inline Dual cos(const Dual &a) { Dual r; r.v = ocos(a.v); double s = -osin(a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = s * a.d[i]; return r; }
 inline Dual sqrt(const Dual &a) { Dual r; r.v = std::sqrt(a.v); double g = 0.5 / r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
 inline Dual tan(const Dual &a) { Dual r; r.v = otan(a.v); double g = 1.0 + r.v * r.v; for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
-inline Dual asin(const Dual &a) { Dual r; r.v = std::asin(a.v); double g = 1.0 / std::sqrt(1.0 - a.v * a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
+inline Dual asin(const Dual &a) { Dual r; r.v = oasin(a.v); double g = 1.0 / std::sqrt(1.0 - a.v * a.v); for (int i = 0; i < Dual::np(); ++i) r.d[i] = g * a.d[i]; return r; }
 
 // Second-order forward mode (autodiff::dual2nd of the reference, dynamical_system.cpp:137-217, restated): value, gradient and
 // Hessian w.r.t. up to kD2 seeded variables z = [x, u].  Only used for the plants whose Hessians the reference takes from
@@ -111,7 +113,7 @@ inline Dual2 operator/(const Dual2 &a, const Dual2 &b) { return a * d2_recip(b);
 inline Dual2 sin(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, s, c, -s); }
 inline Dual2 cos(const Dual2 &a) { const double s = osin(a.v), c = ocos(a.v); return d2_unary(a, c, -s, -c); }
 inline Dual2 sqrt(const Dual2 &a) { const double r = std::sqrt(a.v); return d2_unary(a, r, 0.5 / r, -0.25 / (a.v * r)); }
-inline Dual2 asin(const Dual2 &a) { const double w = 1.0 - a.v * a.v, r = std::sqrt(w); return d2_unary(a, std::asin(a.v), 1.0 / r, a.v / (w * r)); }
+inline Dual2 asin(const Dual2 &a) { const double w = 1.0 - a.v * a.v, r = std::sqrt(w); return d2_unary(a, oasin(a.v), 1.0 / r, a.v / (w * r)); }
 inline Dual2 tan(const Dual2 &a) { const double t = otan(a.v), g = 1.0 + t * t; return d2_unary(a, t, g, 2.0 * t * g); }
 
 struct Model {
@@ -258,7 +260,7 @@ struct Model {
   // params: wheelbase; state [x, y, theta, v], control [steering delta, acceleration a]; a DISCRETE plant: h = timestep
   template <typename S>
   void car_next(const S *x, const S *u, S *xn, bool clamps) const {
-    using std::sqrt; using std::asin;
+    using std::sqrt;
     const double d = p[0], h = dt;
     const S theta = x[2], v = x[3], delta = u[0], a = u[1];
     const S cos_theta = cos(theta), sin_theta = sin(theta);

@@ -17,6 +17,7 @@ control box, state box, ball, linear path constraints.  Python loops: small prob
 All citations are relative to /root/reference/.
 """
 import math
+import sys
 
 import numpy as np
 
@@ -251,6 +252,97 @@ class Unicycle:      # src/dynamics_model/unicycle.cpp:28-66
         return Fxx, Fuu, Fux
 
 
+class Bicycle:       # src/dynamics_model/bicycle.cpp:28-156: state [x, y, theta, v], control [a, delta]
+    nx, nu = 4, 2
+
+    def __init__(self, wheelbase):
+        self.L = wheelbase
+
+    def f(self, x, u, t):
+        return np.array([x[3] * _cos(x[2]), x[3] * _sin(x[2]), (x[3] / self.L) * math.tan(u[1]), u[0]])
+
+    def jac(self, x, u, t):      # :68-111 analytic
+        A = np.zeros((4, 4)); B = np.zeros((4, 2))
+        th, v, dl = x[2], x[3], u[1]
+        A[0, 2] = -v * _sin(th); A[0, 3] = _cos(th); A[1, 2] = v * _cos(th); A[1, 3] = _sin(th); A[2, 3] = math.tan(dl) / self.L
+        B[3, 0] = 1.0; B[2, 1] = v / (self.L * _cos(dl) ** 2)
+        return A, B
+
+    def hess(self, x, u, t):     # state / control Hessians :113-156 analytic; cross Hessian: the base-class autodiff default, in closed form
+        Fxx, Fuu, Fux = _zeros_hess(4, 2)
+        th, v, dl = x[2], x[3], u[1]
+        Fxx[0, 2, 2] = -v * _cos(th); Fxx[0, 2, 3] = Fxx[0, 3, 2] = -_sin(th)
+        Fxx[1, 2, 2] = -v * _sin(th); Fxx[1, 2, 3] = Fxx[1, 3, 2] = _cos(th)
+        Fuu[2, 1, 1] = 2.0 * v * _sin(dl) / (self.L * _cos(dl) ** 3)
+        Fux[2, 1, 3] = 1.0 / (self.L * _cos(dl) ** 2)          # d2 (v tan(delta) / L) / d delta d v
+        return Fxx, Fuu, Fux
+
+
+class Car:           # src/dynamics_model/car.cpp: a DISCRETE plant; state [x, y, theta, v], control [delta, a]
+    nx, nu = 4, 2
+    discrete = True
+
+    def __init__(self, wheelbase, dt):
+        self.d, self.h = wheelbase, dt
+
+    def step(self, x, u, t):     # :24-60
+        d, h = self.d, self.h
+        f = h * x[3]
+        b = d + f * _cos(u[0]) - math.sqrt(d * d - (f * _sin(u[0])) ** 2)
+        return x + np.array([b * _cos(x[2]), b * _sin(x[2]), math.asin(_sin(u[0]) * f / d), h * u[1]])
+
+    def _parts(self, x, u):
+        """First and second partials of b(f, delta) and phi(v, delta) -- the hand-derived derivatives of what the reference
+        differentiates with autodiff (:62-161), including its two clamps (:183-186, 196-199)."""
+        d, h = self.d, self.h
+        f = h * x[3]; s, c = _sin(u[0]), _cos(u[0])
+        I = d * d - (f * s) ** 2
+        clamped = I < 0.0
+        if clamped:
+            I = 0.0
+        r = math.sqrt(I)
+        if clamped or r == 0.0:
+            rf = rd = rff = rfd = rdd = 0.0 if clamped else float("inf")
+        else:
+            If, Id = -2.0 * f * s * s, -2.0 * f * f * s * c
+            Iff, Ifd, Idd = -2.0 * s * s, -4.0 * f * s * c, -2.0 * f * f * (c * c - s * s)
+            rf, rd = If / (2 * r), Id / (2 * r)
+            rff = Iff / (2 * r) - If * If / (4 * r ** 3); rfd = Ifd / (2 * r) - If * Id / (4 * r ** 3); rdd = Idd / (2 * r) - Id * Id / (4 * r ** 3)
+        b = d + f * c - r
+        bv, bd = h * (c - rf), -f * s - rd
+        bvv, bvd, bdd = h * h * (-rff), h * (-s - rfd), -f * c - rdd
+        w = s * f / d
+        if abs(w) > 1.0:      # clamped argument: a constant
+            pv = pd = pvv = pvd = pdd = 0.0
+        else:
+            p1 = 1.0 / math.sqrt(1.0 - w * w); p2 = w / (1.0 - w * w) ** 1.5
+            wv, wd, wvd, wdd = s * h / d, c * f / d, c * h / d, -w
+            pv, pd = p1 * wv, p1 * wd
+            pvv, pvd, pdd = p2 * wv * wv, p2 * wv * wd + p1 * wvd, p2 * wd * wd + p1 * wdd
+        return b, bv, bd, bvv, bvd, bdd, pv, pd, pvv, pvd, pdd
+
+    def jac(self, x, u, t):      # :62-111: gradient of the discrete map, J.diagonal() -= 1, J /= timestep
+        b, bv, bd, _, _, _, pv, pd, _, _, _ = self._parts(x, u)
+        ct, st = _cos(x[2]), _sin(x[2])
+        A = np.eye(4); B = np.zeros((4, 2))
+        A[0, 2] = -b * st; A[0, 3] = ct * bv; A[1, 2] = b * ct; A[1, 3] = st * bv; A[2, 3] = pv
+        B[0, 0] = ct * bd; B[1, 0] = st * bd; B[2, 0] = pd; B[3, 1] = self.h
+        return (A - np.eye(4)) / self.h, B / self.h
+
+    def hess(self, x, u, t):     # :113-161 (+ the base-class cross Hessian on (x+ - x) / timestep): Hessian of the discrete map / timestep
+        b, bv, bd, bvv, bvd, bdd, pv, pd, pvv, pvd, pdd = self._parts(x, u)
+        ct, st = _cos(x[2]), _sin(x[2])
+        Fxx, Fuu, Fux = _zeros_hess(4, 2)
+        Fxx[0, 2, 2] = -b * ct; Fxx[0, 2, 3] = Fxx[0, 3, 2] = -st * bv; Fxx[0, 3, 3] = ct * bvv
+        Fxx[1, 2, 2] = -b * st; Fxx[1, 2, 3] = Fxx[1, 3, 2] = ct * bv; Fxx[1, 3, 3] = st * bvv
+        Fxx[2, 3, 3] = pvv
+        Fuu[0, 0, 0] = ct * bdd; Fuu[1, 0, 0] = st * bdd; Fuu[2, 0, 0] = pdd
+        Fux[0, 0, 2] = -st * bd; Fux[0, 0, 3] = ct * bvd
+        Fux[1, 0, 2] = ct * bd; Fux[1, 0, 3] = st * bvd
+        Fux[2, 0, 3] = pvd
+        return Fxx / self.h, Fuu / self.h, Fux / self.h
+
+
 class LTI:           # src/dynamics_model/lti_system.cpp:71-92: discrete x+ = A x + B u; Jacobians (A - I)/dt, B/dt
     def __init__(self, A, B, dt):
         self.A, self.B, self.dt = np.array(A, float), np.array(B, float), dt
@@ -341,6 +433,50 @@ class Linear:        # LinearConstraint :253-311: g = A x, upper = b
 
     def jac(self, x, u):
         return self.A.copy(), np.zeros((self.dim, u.size))
+
+
+class SecondOrderCone:   # SecondOrderConeConstraint :626-800: g = cos(fov) sqrt(|p - o|^2 + eps) - (p - o) . axis, p = x[:3]; upper 0
+    dim = 1
+
+    def __init__(self, origin, direction, fov, eps=1e-6):
+        if fov < 0 or fov > math.pi:
+            raise ValueError("SecondOrderConeConstraint: Cone angle must be between 0 and PI.")
+        if eps <= 0:
+            raise ValueError("SecondOrderConeConstraint: Regularization epsilon must be positive.")
+        a = np.array(direction, float); n = math.sqrt(float(a @ a))
+        if n == 0.0:
+            raise ValueError("SecondOrderConeConstraint: Opening direction cannot be zero vector.")
+        self.o, self.ax, self.cosf, self.eps = np.array(origin, float), a / n, math.cos(fov), eps
+
+    def g(self, x, u):
+        v = x[:3] - self.o
+        return np.array([math.sqrt(float(v @ v) + self.eps) * self.cosf - float(v @ self.ax)])
+
+    def jac(self, x, u):
+        Gx = np.zeros((1, x.size)); Gu = np.zeros((1, u.size))
+        v = x[:3] - self.o; rn = math.sqrt(float(v @ v) + self.eps)
+        Gx[0, :3] = self.cosf * (v / rn) - self.ax if rn > 1e-9 else -self.ax
+        return Gx, Gu
+
+
+class ThrustMagnitude:   # ThrustMagnitudeConstraint :802-927 (two rows) / MaxThrustMagnitudeConstraint :929-1048 (min_norm None: one row)
+    def __init__(self, min_norm, max_norm, eps=1e-6):
+        self.mn, self.mx, self.eps = min_norm, max_norm, eps
+        self.dim = 1 if min_norm is None else 2
+
+    def g(self, x, u):
+        n = math.sqrt(float(u @ u))
+        return np.array([n - self.mx]) if self.mn is None else np.array([self.mn - n, n - self.mx])
+
+    def jac(self, x, u):     # the Jacobian uses the REGULARISED norm, the value the plain one
+        Gx = np.zeros((self.dim, x.size)); Gu = np.zeros((self.dim, u.size))
+        rn = math.sqrt(float(u @ u) + self.eps)
+        if self.mn is None:
+            if rn > sys.float_info.min:
+                Gu[0] = u / rn
+        elif not rn < self.eps:
+            Gu[0] = -(u / rn); Gu[1] = u / rn
+        return Gx, Gu
 
 
 # --------------------------------------------------------------------------------------------------------------

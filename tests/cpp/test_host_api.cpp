@@ -52,6 +52,24 @@ class QuadraticAsNonlinear final : public cddp::NonlinearObjective {   // finite
   double running_cost(const cddp::Vector &x, const cddp::Vector &u, int) const override { return 0.1 * timestep_ * u[0] * u[0] + 0.0 * x[0]; }
   double terminal_cost(const cddp::Vector &x) const override { return 100.0 * (x[0] * x[0] + x[1] * x[1]); }
 };
+class CarParkingObjective final : public cddp::NonlinearObjective {   // tests/cddp_core/test_ipddp_solver.cpp:628-683 (derivatives: the base class's finite differences)
+ public:
+  CarParkingObjective(const cddp::Vector &goal, double dt) : cddp::NonlinearObjective(dt), goal_(goal) {}
+  double running_cost(const cddp::Vector &x, const cddp::Vector &u, int) const override {
+    const double lu = 1e-2 * (u[0] * u[0]) + 1e-4 * (u[1] * u[1]);
+    const double lx = 1e-3 * sabs(x[0], 0.1) + 1e-3 * sabs(x[1], 0.1);
+    return lu + lx;
+  }
+  double terminal_cost(const cddp::Vector &x) const override {
+    const double cf[4] = {0.1, 0.1, 1.0, 0.3}, pf[4] = {0.01, 0.01, 0.01, 1.0};
+    double c = 0.0;
+    for (int i = 0; i < 4; ++i) c += cf[i] * sabs(x[i], pf[i]);
+    return c + running_cost(x, cddp::Vector{0.0, 0.0}, 0);
+  }
+ private:
+  static double sabs(double x, double p) { return std::sqrt(x * x / (p * p) + 1.0) * p - p; }
+  cddp::Vector goal_;
+};
 class TorqueBand final : public cddp::Constraint {   // a user constraint: |u| <= c as two rows
  public:
   explicit TorqueBand(double c) : cddp::Constraint("TorqueBand"), c_(c) {}
@@ -312,6 +330,34 @@ static void gpu_tests() {
     threw = false;
     try { nohess.solve("IPDDP"); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("autodiff is not available") != std::string::npos; }
     EXPECT_TRUE(threw);
+  }
+  {   // the reference's car-parking test (tests/cddp_core/test_ipddp_solver.cpp:686-885): the BUILT-IN Car with a user NonlinearObjective
+      // whose derivatives are the base class's finite differences -> host plug-in solve (GPU backward passes on stacks the host fills,
+      // forward passes on the plant's host evaluation).  Same problem, options and expectations as the reference's own assertions.
+    const int horizon = 500; const double dt = 0.03;
+    cddp::Vector x0 = {1.0, 1.0, 1.5 * 3.14159265358979323846, 0.0}, goal = {0.0, 0.0, 0.0, 0.0};
+    cddp::CDDPOptions o; o.max_iterations = 150; o.tolerance = 1e-4; o.acceptable_tolerance = 1e-6; o.verbose = false;
+    o.regularization.initial_value = 1e-2; o.ipddp.barrier.mu_initial = 1.0;
+    cddp::Car car(dt, 2.0, "euler");
+    CarParkingObjective cost(goal, dt);
+    std::vector<cddp::Vector> X(horizon + 1, x0), U(horizon, cddp::Vector{0.0, 0.0});
+    for (int t = 0; t < horizon; ++t) X[t + 1] = car.getDiscreteDynamics(X[t], U[t], t * dt);
+    const double J0 = cost.evaluate(X, U);
+    cddp::CDDP solver(x0, goal, horizon, dt, std::make_unique<cddp::Car>(dt, 2.0, "euler"), std::make_unique<CarParkingObjective>(goal, dt), o);
+    solver.addPathConstraint("ControlConstraint", std::make_unique<cddp::ControlConstraint>(cddp::Vector{-0.5, -2.0}, cddp::Vector{0.5, 2.0}));
+    solver.setInitialTrajectory(X, U);
+    EXPECT_TRUE(solver.needsHostPlugins());
+    cddp::CDDPSolution s = solver.solve("IPDDP");
+    const cddp::Vector &xf = s.state_trajectory.back();
+    const double dist = std::sqrt(xf[0] * xf[0] + xf[1] * xf[1]);
+    std::cout << "car parking (reference test replay): " << s.status_message << " iterations " << s.iterations_completed << " cost " << s.final_objective
+              << " (initial " << J0 << ") final state [" << xf[0] << " " << xf[1] << " " << xf[2] << " " << xf[3] << "]\n";
+    EXPECT_TRUE(s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");   // "Algorithm should converge"
+    EXPECT_TRUE(s.iterations_completed > 0);
+    EXPECT_TRUE(s.final_objective < J0);
+    EXPECT_TRUE(s.final_objective < 1.91);      // "Cold-start IPDDP should reach the low-cost parking solution"
+    EXPECT_TRUE(dist < std::sqrt(2.0) && dist < 0.5);   // "Car should park reasonably close to the goal"
+    for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 0.5 && std::fabs(u[1]) <= 2.0);
   }
   {   // a layout that is not instantiated on the device: loud error, never a silent fallback
     cddp::CDDP solver = makePendulum(opt);

@@ -45,6 +45,30 @@ def _unicycle(solver, ball, N=100, box_name="control_limits", **opt):
                 x0=[0.0, 0.0, math.pi / 4], U0=np.tile([0.5, 0.1], (N, 1)))
 
 
+def _bicycle(solver, box, N=100, integrator="euler", **opt):   # pyapi.bicycle_problem
+    o = dict(max_iterations=60, tolerance=1e-4, acceptable_tolerance=1e-6); o.update(opt)
+    return dict(solver=solver, model=T.Bicycle(2.0), integrator=integrator, dt=0.05, N=N, Q=np.zeros((4, 4)), R=np.diag([0.05, 0.5]),
+                Qf=np.diag([100.0, 100.0, 50.0, 10.0]), xref=[2.0, 1.0, math.pi / 4, 0.0],
+                constraints={"ControlConstraint": T.ControlBox([-2.0, -0.5], [2.0, 0.5])} if box else {}, options=o,
+                x0=[0.0, 0.0, 0.0, 0.5], U0=np.tile([0.1, 0.05], (N, 1)))
+
+
+def _car(solver, box, N=100, **opt):   # pyapi.car_problem
+    o = dict(max_iterations=80, tolerance=1e-4, acceptable_tolerance=1e-6, reg_initial_value=1e-2); o.update(opt)
+    return dict(solver=solver, model=T.Car(2.0, 0.03), integrator="euler", dt=0.03, N=N, Q=np.diag([1e-2, 1e-2, 0.0, 0.0]), R=np.diag([1e-2, 1e-4]),
+                Qf=np.diag([10.0, 10.0, 10.0, 3.0]), xref=[0.0, 0.0, 0.0, 0.0],
+                constraints={"ControlConstraint": T.ControlBox([-0.5, -2.0], [0.5, 2.0])} if box else {}, options=o,
+                x0=[1.0, 1.0, 1.5 * math.pi, 0.0], U0=np.tile([0.01, 0.1], (N, 1)))
+
+
+def _unicycle_thrust(two_sided, N=100, **opt):   # pyapi.unicycle_thrust_problem
+    spec = _unicycle("IPDDP", False, N, **opt)
+    spec["R"] = (0.5 if two_sided else 2.0) * np.eye(2); spec["Qf"] = np.diag([10.0, 10.0, 5.0])
+    spec["constraints"] = ({"ThrustMagnitudeConstraint": T.ThrustMagnitude(0.3, 2.0, 1e-6)} if two_sided
+                           else {"MaxThrustMagnitudeConstraint": T.ThrustMagnitude(None, 2.0, 1e-6)})
+    return spec
+
+
 def _lti(N, x0, goal, R, Qf, cons=None, term=None, **opt):
     o = dict(max_iterations=100, tolerance=1e-6, acceptable_tolerance=1e-6, reg_initial_value=1e-6, mu_initial=1e-1); o.update(opt)
     return dict(solver="IPDDP", model=T.LTI(np.eye(1), np.eye(1), 1.0), integrator="euler", dt=1.0, N=N, Q=np.zeros((1, 1)), R=R * np.eye(1),
@@ -92,6 +116,16 @@ CASES = {
                                                            "StateConstraint", T.StateBox([-4.0, -9.0], [4.0, 9.0])),
     "cartpole_ipddp_box_state_stationarity": lambda: _with(_cartpole("IPDDP", True, check_state_stationarity=True),
                                                            "StateConstraint", T.StateBox([-1.5, -7.0, -8.0, -25.0], [1.5, 7.0, 8.0, 25.0])),
+    # f3 tail: bicycle / car plants, cone and thrust-magnitude rows (constraint.hpp:626-1048); their full-DDP variants: tests/test_ddp_second_order.py
+    "bicycle_ipddp_box": lambda: _bicycle("IPDDP", True),
+    "bicycle_ipddp_box_rk4": lambda: _bicycle("IPDDP", True, integrator="rk4"),
+    "bicycle_clddp_box": lambda: _bicycle("CLDDP", True),
+    "car_ipddp_box": lambda: _car("IPDDP", True),
+    "car_clddp_box": lambda: _car("CLDDP", True),
+    "unicycle_ipddp_box_soc": lambda: _with(_unicycle("IPDDP", False), "SecondOrderConeConstraint",
+                                            T.SecondOrderCone([0.0, -0.5, 0.0], [0.0, 1.0, 0.0], math.pi / 4.0 + 0.35, 1e-6)),
+    "unicycle_ipddp_thrust": lambda: _unicycle_thrust(True),
+    "unicycle_ipddp_maxthrust": lambda: _unicycle_thrust(False),
 }
 
 

@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 STEP_CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "cartpole_ipddp_unc", "cartpole_ipddp_box", "unicycle_ipddp_box", "unicycle_ipddp_box_ball",
-              "pendulum_term_eq", "path_term_eq", "term_eq_only", "cartpole_ipddp_box_state"]
+              "pendulum_term_eq", "path_term_eq", "term_eq_only", "cartpole_ipddp_box_state",
+              "bicycle_ipddp_box", "car_ipddp_box"]     # f3 tail: analytic + autodiff-default Hessians (bicycle), dual2nd of the discrete map (car)
 SOLVE_CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "unicycle_ipddp_box_ball", "pendulum_term_eq", "path_term_eq"]   # (cart-pole full DDP from
 # the hanging start factors indefinite Q_uu blocks: its iterates are chaotic in the rounding, compared at step level only)
 
@@ -68,7 +69,8 @@ def test_oracle_matches_twin_with_second_order_terms(api, oracle_built, name):
     assert bool(o.backward(retry=False)) == bool(okt)
     K, k = o.gains(); Vx, Vxx = o.value()
     # (1e-8: with the tensor terms Q_uu may be indefinite -- LDLT accepts it -- and the gains reach 1e3..1e4)
-    assert max(rel_err(K, tw.K_u), rel_err(k, tw.k_u), rel_err(Vx, tw.Vx), rel_err(Vxx, tw.Vxx)) < 1e-8
+    # (bicycle / car: gains of 1e3..6e3 from the initial guess; the oracle against ITSELF with <= 1 ulp noise on its sines moves by 6e-9..8e-9 there)
+    assert max(rel_err(K, tw.K_u), rel_err(k, tw.k_u), rel_err(Vx, tw.Vx), rel_err(Vxx, tw.Vxx)) < (1e-7 if name in ("bicycle_ipddp_box", "car_ipddp_box") else 1e-8)
     # the second-order terms are not a no-op: the feed-forward gain moves by more than 1e-8 (test_ipddp_solver.cpp:1512-1578)
     p2 = TERM_CASES[name](api) if name in TERM_CASES else make(api, name)
     o2 = api.Oracle(p2); o2.set_initial(p2.x0, None if U0 is None else U0[0]); o2.initialize(); o2.backward(retry=False)

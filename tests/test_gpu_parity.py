@@ -46,6 +46,15 @@ def make(api, name):
         "cartpole_ipddp_box_state": lambda: _with_state_box(S.cartpole_problem(S.SOLVER_IPDDP, True), [-1.5, -7.0, -8.0, -25.0], [1.5, 7.0, 8.0, 25.0]),
         "unicycle_ipddp_box_state": lambda: _with_state_box(S.unicycle_problem(S.SOLVER_IPDDP, 100, False), [-0.5, -0.5, -4.0], [2.6, 2.6, 4.0],
                                                             name="state_limits"),
+        # f3 tail: ground-vehicle plants, cone / thrust-magnitude rows
+        "bicycle_ipddp_box": lambda: S.bicycle_problem(S.SOLVER_IPDDP),
+        "bicycle_ipddp_box_rk4": lambda: S.bicycle_problem(S.SOLVER_IPDDP, integrator=S.RK4),
+        "bicycle_clddp_box": lambda: S.bicycle_problem(S.SOLVER_CLDDP),
+        "car_ipddp_box": lambda: S.car_problem(S.SOLVER_IPDDP),
+        "car_clddp_box": lambda: S.car_problem(S.SOLVER_CLDDP),
+        "unicycle_ipddp_box_soc": lambda: S.unicycle_cone_problem(S.SOLVER_IPDDP),
+        "unicycle_ipddp_thrust": lambda: S.unicycle_thrust_problem(S.SOLVER_IPDDP, two_sided=True),
+        "unicycle_ipddp_maxthrust": lambda: S.unicycle_thrust_problem(S.SOLVER_IPDDP, two_sided=False),
     }
     if name in OPTION_CASES:
         return OPTION_CASES[name](S)
@@ -170,6 +179,11 @@ KNIFE_EDGE_CASES = {"manipulator_term_eq", "manip7_term_eq_parallel_ls", "manip7
 BIG_CASES = ["unicycle_clddp_box", "quadrotor_ipddp_box", "quadrotor_clddp_box", "quad12_ipddp_box",
              "manipulator_clddp_box", "manipulator_ipddp_box", "manip7_ipddp_box"]
 
+# f3 tail: car / bicycle plants, cone and thrust-magnitude rows.  Their solves run on the parity build (shared sin / cos / asin / tan):
+# asin and tan are two more libm routines whose device and host versions agree to an ulp, not to the bit.
+F3_CASES = ["bicycle_ipddp_box", "bicycle_ipddp_box_rk4", "bicycle_clddp_box", "car_ipddp_box", "car_clddp_box",
+            "unicycle_ipddp_box_soc", "unicycle_ipddp_thrust", "unicycle_ipddp_maxthrust"]
+
 CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pendulum_clddp_box",
          "cartpole_ipddp_unc", "cartpole_ipddp_box", "cartpole_clddp_unc", "cartpole_clddp_box",
          "unicycle_ipddp_box", "unicycle_ipddp_box_ball",
@@ -187,7 +201,7 @@ def spread_for(p):
     return s
 
 
-@pytest.mark.parametrize("case", CASES + BIG_CASES + list(TERM_CASES) + list(OPTION_CASES))
+@pytest.mark.parametrize("case", CASES + BIG_CASES + list(TERM_CASES) + list(OPTION_CASES) + F3_CASES)
 def test_step_level_parity(api, oracle_built, case):
     """initialize -> backward -> forward(alphas): K, k, V_x, V_xx, dV and every trial record."""
     p = make(api, case)
@@ -237,7 +251,7 @@ def test_step_level_parity(api, oracle_built, case):
     hs.close()
 
 
-@pytest.mark.parametrize("case", CASES + list(TERM_CASES) + list(OPTION_CASES))
+@pytest.mark.parametrize("case", CASES + list(TERM_CASES) + list(OPTION_CASES) + F3_CASES)
 def test_full_solve_parity(api, oracle_built, case):
     """cddp_hip_solve vs oracle solve: identical iteration counts / status; trajectories, gains within 1e-8...
     (full trajectories pass through up to 80 nonlinear iterations, so they are compared at 1e-6)."""
@@ -252,7 +266,7 @@ def test_full_solve_parity(api, oracle_built, case):
     # Option variants run on the shared-trig parity build against the oracle in its shared-trig mode (tests/test_shared_trig_parity.py):
     # most of them never converge inside the iteration cap (the cart-pole example itself does not), and a non-converging solve
     # is a chaotic map of the last bit of every sine -- with the same routine on both sides the comparison is strict.
-    shared = case in OPTION_CASES
+    shared = case in OPTION_CASES or case in F3_CASES
     octx = api.shared_trig if shared else contextlib.nullcontext
     hs = api.HipBatchSolver(p, B, trig="shared" if shared else None)
     hs.set_initial(x0, U0, X0)
