@@ -277,6 +277,7 @@ void cddp_hip_default_options(cddp_hip_options *o) {
   o->barrier_mu_initial = 1.0; o->barrier_mu_min_value = 1e-10; o->barrier_mu_update_factor = 0.5;
   o->barrier_mu_update_power = 1.2; o->barrier_min_fraction_to_boundary = 0.99; o->barrier_strategy = CDDP_HIP_BARRIER_ADAPTIVE;
   o->max_cpu_time = 0.0;
+  o->logddp_mu_initial = 1.0; o->logddp_mu_min_value = 1e-10; o->logddp_mu_update_factor = 0.5; o->logddp_relaxed_delta = 1e-10;
 }
 
 int cddp_hip_abi_version(void) { return CDDP_HIP_ABI_VERSION; }
@@ -304,6 +305,7 @@ const char *cddp_hip_status_string(int status) {
     case CDDP_HIP_STATUS_MAX_ITERATIONS: return "MaxIterationsReached";
     case CDDP_HIP_STATUS_REG_LIMIT: return "RegularizationLimitReached_NotConverged";
     case CDDP_HIP_STATUS_MAX_CPU_TIME: return "MaxCpuTimeReached";
+    case CDDP_HIP_STATUS_REG_LIMIT_CONVERGED: return "RegularizationLimitReached_Converged";
   }
   return "Unknown";
 }
@@ -337,9 +339,10 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   if (rc) { delete h; return rc; }
   for (const KernelSet &k : registry()) if (k.matches(h->P)) { h->ks = &k; break; }
   if (!h->ks) {
+    const int m = h->P.m, nc = h->P.n_cons;
     delete h;
     return fail(-4, "no kernel instantiation for model=%d nx=%d nu=%d with this constraint layout (m=%d, %d constraints)",
-                problem->model, problem->nx, problem->nu, h->P.m, h->P.n_cons);
+                problem->model, problem->nx, problem->nu, m, nc);
   }
   h->device = device;
   hipError_t e = hipSetDevice(device);

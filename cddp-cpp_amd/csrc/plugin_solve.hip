@@ -315,13 +315,232 @@ double scaled_inf_du(const Ctx &c, const Traj &T, const std::vector<double> &Gx)
   return std::max(v, ss);
 }
 
+
+// ======================================================================================================================
+// LogDDP (logddp_solver.cpp:43-707 on the CDDPSolverBase loop): single shooting; every path constraint enters through the relaxed
+// log barrier (barrier.hpp:37-296), whose value joins the merit function and whose gradients / Hessians are FOLDED into the cost
+// derivative stacks here on the host; the GPU runs the unconstrained Riccati sweep of the batch (CDDP_HIP_STACKS_LOGDDP: Q_uu + reg I
+// symmetrised, LDLT, dV, inf_du = max |Q_u|).
+// ======================================================================================================================
+struct LTraj {
+  std::vector<double> X, U;
+  double cost = 0, merit = 0, violation = 0, inf_pr = 0, inf_du = kInf, alpha_pr = 1.0, reg = 0, mu = 0, dV0 = 0;
+  int iter = 0, status = CDDP_HIP_STATUS_RUNNING, n_bwd = 0, n_fwd = 0;
+  bool done = false;
+};
+
+void lg_beta(double z, double delta, double &b0, double &b1, double &b2) {   // calculate_beta_derivatives (barrier.hpp:274-296)
+  if (z > delta) {
+    if (z <= 1e-12) { b0 = -std::log(1e-12); b1 = -1.0 / 1e-12; b2 = 1.0 / (1e-12 * 1e-12); }
+    else { b0 = -std::log(z); b1 = -1.0 / z; b2 = 1.0 / (z * z); }
+  } else {
+    const double td = (z - 2.0 * delta) / delta;
+    b0 = 0.5 * (td * td - 1.0) - std::log(delta); b1 = td / delta; b2 = 1.0 / (delta * delta);
+  }
+}
+
+// barrier value of the whole trajectory and its constraint violation (resetFilter :333-361 / forwardPass :637-660): constraint by
+// constraint inside a step, as the reference's loops run; every constraint kind has lower bound -inf, so s_U = U - g = -(g - U)
+void lg_merit_terms(const Ctx &c, const double *X, const double *U, double mu, double delta, double &barrier, double &violation, std::vector<double> &g) {
+  const int m = c.m, N = c.N;
+  barrier = 0.0; violation = 0.0;
+  if (m == 0) return;
+  g.resize(m);
+  for (int t = 0; t < N; ++t) {
+    c.pl->constraints(c.pl->user, X + (size_t)t * c.nx, U + (size_t)t * c.nu, t, g.data(), nullptr, nullptr);
+    int off = 0;
+    for (int s = 0; s < c.pl->n_constraints; ++s) {
+      const int dim = c.pl->constraint_dims[s];
+      double tot = 0.0;
+      for (int i = 0; i < dim; ++i) { double b0, b1, b2; lg_beta(-g[off + i], delta, b0, b1, b2); tot += b0; }
+      barrier += mu * tot;
+      for (int i = 0; i < dim; ++i) if (g[off + i] > 0.0) violation += g[off + i];
+      off += dim;
+    }
+  }
+}
+
+int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const double *U0, cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
+  const cddp_hip_plugin *pl = c.pl; const cddp_hip_options &o = *c.o;
+  const int nx = c.nx, nu = c.nu, m = c.m, N = c.N; const double dt = c.dt;
+  const size_t B = (size_t)batch;
+  cddp_hip_stack_handle *sh = nullptr;
+  { int rc = cddp_hip_stacks_create(device, batch, nx, nu, 0, N, &sh); if (rc) return rc; }
+  struct Guard { cddp_hip_stack_handle *h; ~Guard() { if (h) cddp_hip_stacks_destroy(h); } } guard{sh};
+  std::vector<double> alphas;   // logddp_solver.cpp:171-177: the plain geometric ladder
+  { double a = o.ls_initial_step_size; for (int i = 0; i < o.ls_max_iterations; ++i) { alphas.push_back(a); a *= o.ls_step_reduction_factor; } }
+  const double delta = o.logddp_relaxed_delta;
+  if (!(delta > 0.0)) return pfail(-2, "Relaxation delta must be positive.");
+  std::vector<double> gtmp;
+
+  std::vector<LTraj> T(B);
+  for (size_t b = 0; b < B; ++b) {   // initialize (:45-205, cold start): roll the control guess out, cost, barrier merit
+    LTraj &t = T[b];
+    t.X.assign((size_t)(N + 1) * nx, 0.0); t.U.assign((size_t)N * nu, 0.0);
+    if (U0) std::copy(U0 + b * N * nu, U0 + (b + 1) * N * nu, t.U.begin());
+    std::copy(x0 + b * nx, x0 + (b + 1) * nx, t.X.begin());
+    for (int s = 0; s < N; ++s) pl->discrete_dynamics(pl->user, t.X.data() + (size_t)s * nx, t.U.data() + (size_t)s * nu, s * dt, t.X.data() + (size_t)(s + 1) * nx);
+    t.reg = o.reg_initial_value; t.mu = o.logddp_mu_initial; t.alpha_pr = o.ls_initial_step_size;
+    t.cost = total_cost(c, t.X.data(), t.U.data());
+    double bar, viol; lg_merit_terms(c, t.X.data(), t.U.data(), t.mu, delta, bar, viol, gtmp);
+    t.merit = t.cost + bar; t.violation = viol; t.inf_pr = viol;
+  }
+
+  std::vector<double> fx(B * N * nx * nx), fu(B * N * nx * nu), lx(B * N * nx), lu(B * N * nu), lxx(B * N * nx * nx), luu(B * N * nu * nu),
+      lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx), Fxx, Fuu, Fux;
+  if (!o.use_ilqr) { Fxx.resize(B * N * nx * nx * nx); Fuu.resize(B * N * nx * nu * nu); Fux.resize(B * N * nx * nu * nx); }
+  std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  std::vector<double> regv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
+  std::vector<int32_t> okv(B);
+  std::vector<double> tfx(nx * nx), tfu(nx * nu), g(std::max(m, 1)), Gx((size_t)std::max(m, 1) * nx), Gu((size_t)std::max(m, 1) * nu);
+  std::vector<double> Cxx, Cuu, Cux;
+  if (m > 0 && pl->constraint_hessians) { Cxx.resize((size_t)m * nx * nx); Cuu.resize((size_t)m * nu * nu); Cux.resize((size_t)m * nu * nx); }
+  std::vector<double> Xn((size_t)(N + 1) * nx), Un((size_t)N * nu), Xb, Ub;
+  const bool first_rule = !o.enable_parallel;
+  const auto wall0 = std::chrono::steady_clock::now();
+
+  for (int it = 1; it <= o.max_iterations; ++it) {
+    bool any = false;
+    for (auto &t : T) any = any || !t.done;
+    if (!any) break;
+    if (o.max_cpu_time > 0.0) {
+      const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
+      if (el_ms > o.max_cpu_time * 1000.0) { for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; } break; }
+    }
+    for (size_t b = 0; b < B; ++b) {
+      LTraj &t = T[b];
+      regv[b] = t.done ? std::max(t.reg, o.reg_min_value) : t.reg;
+      if (t.done) continue;
+      t.iter += 1;
+      for (int s = 0; s < N; ++s) {
+        const double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+        const size_t bs = b * N + s;
+        pl->jacobians(pl->user, x, u, s * dt, tfx.data(), tfu.data());
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double a = dt * tfx[i * nx + j]; if (i == j) a += 1.0; fx[(bs * nx + i) * nx + j] = a; }
+        for (int i = 0; i < nx * nu; ++i) fu[bs * nx * nu + i] = dt * tfu[i];
+        double *plx = lx.data() + bs * nx, *plu = lu.data() + bs * nu, *plxx = lxx.data() + bs * nx * nx, *pluu = luu.data() + bs * nu * nu, *plux = lux.data() + bs * nu * nx;
+        pl->running_cost_derivatives(pl->user, x, u, s, plx, plu, plxx, pluu, plux);
+        if (m > 0) {   // getGradients / getHessians of every constraint (barrier.hpp:95-213), scaled by the barrier coefficient, folded in
+          pl->constraints(pl->user, x, u, s, g.data(), Gx.data(), Gu.data());
+          if (!Cxx.empty()) {
+            std::fill(Cxx.begin(), Cxx.end(), 0.0); std::fill(Cuu.begin(), Cuu.end(), 0.0); std::fill(Cux.begin(), Cux.end(), 0.0);
+            pl->constraint_hessians(pl->user, x, u, s, Cxx.data(), Cuu.data(), Cux.data());
+          }
+          for (int r = 0; r < m; ++r) {
+            double b0, b1, b2; lg_beta(-g[r], delta, b0, b1, b2);
+            const double dC = t.mu * (-b1), t1 = t.mu * b2, t2 = t.mu * (-b1);
+            const double *gx = Gx.data() + (size_t)r * nx, *gu = Gu.data() + (size_t)r * nu;
+            for (int a = 0; a < nx; ++a) plx[a] += dC * gx[a];
+            for (int a = 0; a < nu; ++a) plu[a] += dC * gu[a];
+            for (int a = 0; a < nx; ++a) for (int e = 0; e < nx; ++e) plxx[a * nx + e] += (t1 * gx[a]) * gx[e];
+            for (int a = 0; a < nu; ++a) for (int e = 0; e < nu; ++e) pluu[a * nu + e] += (t1 * gu[a]) * gu[e];
+            for (int a = 0; a < nu; ++a) for (int e = 0; e < nx; ++e) plux[a * nx + e] += (t1 * gu[a]) * gx[e];
+            if (!Cxx.empty()) {
+              for (int e = 0; e < nx * nx; ++e) plxx[e] += t2 * Cxx[(size_t)r * nx * nx + e];
+              for (int e = 0; e < nu * nu; ++e) pluu[e] += t2 * Cuu[(size_t)r * nu * nu + e];
+              for (int e = 0; e < nu * nx; ++e) plux[e] += t2 * Cux[(size_t)r * nu * nx + e];
+            }
+          }
+        }
+        if (!o.use_ilqr) {
+          double *pxx = Fxx.data() + bs * nx * nx * nx, *puu = Fuu.data() + bs * nx * nu * nu, *pux = Fux.data() + bs * nx * nu * nx;
+          pl->hessians(pl->user, x, u, s * dt, pxx, puu, pux);
+          for (int e = 0; e < nx * nx * nx; ++e) pxx[e] = dt * pxx[e];
+          for (int e = 0; e < nx * nu * nu; ++e) puu[e] = dt * puu[e];
+          for (int e = 0; e < nx * nu * nx; ++e) pux[e] = dt * pux[e];
+        }
+      }
+      pl->terminal_cost_derivatives(pl->user, t.X.data() + (size_t)N * nx, VxN.data() + b * nx, VxxN.data() + b * nx * nx);
+    }
+    { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
+    if (!o.use_ilqr) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_backward(sh, CDDP_HIP_STACKS_LOGDDP, c.o, regv.data(), nullptr, 1, okv.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
+
+    for (size_t b = 0; b < B; ++b) {
+      LTraj &t = T[b];
+      if (t.done) continue;
+      { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
+        if (!okv[b] && nb > 1) --nb;
+        t.n_bwd += nb; }
+      t.reg = s_reg[b];
+      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT_CONVERGED; t.done = true; continue; }   // handleBackwardPassRegularizationLimit (:216-222)
+      t.dV0 = dVb[b * 2]; t.inf_du = s_du[b];
+      const double *K = Kb.data() + b * N * nu * nx, *k = kb.data() + b * N * nu;
+      // ---- performForwardPass over forwardPass(alpha) (:594-707)
+      bool have = false; double best_cost = 0, best_merit = kInf, best_viol = 0, best_alpha = 0; int walked = 0;
+      for (double a : alphas) {
+        ++walked;
+        std::copy(t.X.begin(), t.X.begin() + nx, Xn.begin());
+        bool finite = true;
+        for (int s = 0; s < N && finite; ++s) {
+          const double *xs = Xn.data() + (size_t)s * nx, *xo = t.X.data() + (size_t)s * nx;
+          double *us = Un.data() + (size_t)s * nu;
+          for (int i = 0; i < nu; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += K[((size_t)s * nu + i) * nx + j] * (xs[j] - xo[j]);
+            us[i] = (t.U[(size_t)s * nu + i] + a * k[(size_t)s * nu + i]) + acc;
+          }
+          pl->discrete_dynamics(pl->user, xs, us, s * dt, Xn.data() + (size_t)(s + 1) * nx);
+          for (int i = 0; i < nx; ++i) finite = finite && fin(Xn[(size_t)(s + 1) * nx + i]);
+          for (int i = 0; i < nu; ++i) finite = finite && fin(us[i]);
+        }
+        if (!finite) continue;
+        const double cost_new = total_cost(c, Xn.data(), Un.data());
+        double bar, cv_new; lg_merit_terms(c, Xn.data(), Un.data(), t.mu, delta, bar, cv_new, gtmp);
+        const double merit_new = bar + cost_new;
+        const double cv_old = t.violation, expected = a * t.dV0;
+        bool accept = false;
+        if (cv_new > o.filter_max_violation_threshold) accept = cv_new < (1.0 - o.filter_violation_acceptance_threshold) * cv_old;
+        else if (std::max(cv_new, cv_old) < o.filter_min_violation_for_armijo_check && expected < 0) accept = merit_new < t.merit + o.filter_armijo_constant * expected;
+        else accept = merit_new < t.merit - o.filter_merit_acceptance_threshold * cv_old || cv_new < (1.0 - o.filter_violation_acceptance_threshold) * cv_old;
+        if (!accept) continue;
+        if (first_rule || !have || merit_new < best_merit) { Xb = Xn; Ub = Un; best_cost = cost_new; best_merit = merit_new; best_viol = cv_new; best_alpha = a; have = true; }
+        if (first_rule) break;
+      }
+      t.n_fwd += first_rule ? walked : (int)alphas.size();
+      bool converged = false;
+      if (have) {
+        const double dJ = t.cost - best_cost, dL = t.merit - best_merit;
+        t.X.swap(Xb); t.U.swap(Ub); t.cost = best_cost; t.merit = best_merit; t.alpha_pr = best_alpha; t.violation = best_viol;
+        t.reg = reg_decrease(o, t.reg);
+        if (std::max(t.inf_du, t.inf_pr) <= o.tolerance) { t.status = CDDP_HIP_STATUS_OPTIMAL; converged = true; }          // checkConvergence (:233-261);
+        else if (std::fabs(dJ) < o.acceptable_tolerance && std::fabs(dL) < o.acceptable_tolerance) { t.status = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }   // inf_pr is still the last resetFilter's
+      } else {
+        t.reg = reg_increase(o, t.reg);
+        if (t.reg >= o.reg_max_value) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; continue; }
+      }
+      if (converged) { t.done = true; continue; }
+      // ---- postIterationUpdate (:263-277): barrier coefficient, then resetFilter with it
+      t.mu = have ? std::max(o.logddp_mu_min_value, t.mu * o.logddp_mu_update_factor) : std::min(o.logddp_mu_initial, t.mu * 5.0);
+      double bar, viol; lg_merit_terms(c, t.X.data(), t.U.data(), t.mu, delta, bar, viol, gtmp);
+      t.merit = t.cost + bar; t.violation = viol; t.inf_pr = viol;
+      if (it == o.max_iterations) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+    }
+  }
+  for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  for (size_t b = 0; b < B; ++b) {   // CDDPSolution (+ populateSolverSpecificSolution :286-291)
+    const LTraj &t = T[b];
+    cddp_hip_result &r = results[b];
+    std::memset(&r, 0, sizeof(r));
+    r.final_objective = t.cost; r.merit_function = t.merit; r.inf_pr = t.violation; r.inf_du = t.inf_du; r.inf_comp = kInf;
+    r.barrier_mu = t.mu; r.regularization = t.reg; r.alpha_pr = t.alpha_pr; r.alpha_du = 0.0;
+    r.iterations = t.iter; r.status = t.status; r.n_backward = t.n_bwd; r.n_forward = t.n_fwd;
+    if (Xout) std::copy(t.X.begin(), t.X.end(), Xout + b * (N + 1) * nx);
+    if (Uout) std::copy(t.U.begin(), t.U.end(), Uout + b * N * nu);
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int horizon, double dt, const cddp_hip_options *opt,
                                      int device, int batch, const double *x0, const double *U0, const double *X0,
                                      cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
   if (!pl || !opt || !x0 || !results) return pfail(-1, "null argument");
-  if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP) return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
+  if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP && solver != CDDP_HIP_SOLVER_LOGDDP) return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
   if (!pl->discrete_dynamics || !pl->jacobians) return pfail(-2, "Dynamical system must be set before solving.");
   if (!pl->running_cost || !pl->terminal_cost || !pl->running_cost_derivatives || !pl->terminal_cost_derivatives)
     return pfail(-2, "Objective function must be set before solving.");
@@ -338,6 +557,7 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   Ctx c; c.pl = pl; c.o = opt; c.solver = solver; c.nx = nx; c.nu = nu; c.m = m; c.N = N; c.dt = dt;
   { double al[CDDP_HIP_MAX_ALPHAS]; const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS); c.alphas.assign(al, al + na); }
   const cddp_hip_options &o = *opt;
+  if (solver == CDDP_HIP_SOLVER_LOGDDP) return logddp_solve(c, device, batch, x0, U0, results, Xout, Uout, Kout);
 
   cddp_hip_stack_handle *sh = nullptr;
   { int rc = cddp_hip_stacks_create(device, batch, nx, nu, m, N, &sh); if (rc) return rc; }

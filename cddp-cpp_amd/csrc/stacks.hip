@@ -17,6 +17,8 @@
 //   bytes written            = 8 * (N*(nu*nx + nu + nx + nx^2 [+ 2m + 2m*nx]) + nx + nx^2 + 2)
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -531,6 +533,8 @@ int sfail(int code, const char *fmt, ...) {
 }
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return sfail(-10, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+#include "stacks_coop.hpp"
+
 template <int NX, int NU, int M>
 void launch(const StackArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((k_stacks_backward<NX, NU, M>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
@@ -542,6 +546,16 @@ LaunchFn pick(int nx, int nu, int m) {
   PICK(1, 1, 0) PICK(1, 1, 1) PICK(1, 1, 2) PICK(2, 1, 0) PICK(2, 1, 2) PICK(4, 1, 0) PICK(4, 1, 2)
   PICK(3, 2, 0) PICK(3, 2, 4) PICK(3, 2, 5) PICK(4, 2, 0) PICK(4, 2, 4) PICK(6, 3, 0) PICK(6, 3, 6)
   PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0)
+#undef PICK
+  return nullptr;
+}
+
+// lane-cooperative form (stacks_coop.hpp): the default for nx > 8, where the one-lane kernel runs from scratch memory; the small
+// shapes are instantiated for the bitwise cross-check of the two forms (CDDP_HIP_STACKS_SWEEP=coop | lane overrides the default)
+LaunchFn pick_coop(int nx, int nu, int m) {
+#define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch_coop<X, U, MM>;
+  PICK(4, 1, 0) PICK(4, 1, 2) PICK(3, 2, 0) PICK(3, 2, 5) PICK(6, 3, 0) PICK(6, 3, 6)
+  PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0) PICK(14, 7, 14)
 #undef PICK
   return nullptr;
 }
@@ -561,7 +575,9 @@ void from_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
 
 struct cddp_hip_stack_handle {
   int device = 0, B = 0, Bp = 0, nx = 0, nu = 0, m = 0, N = 0;
-  LaunchFn fn = nullptr;
+  LaunchFn fn = nullptr;        // one lane per trajectory
+  LaunchFn fn_coop = nullptr;   // sixteen lanes per trajectory (stacks_coop.hpp)
+  int used_coop = 0;            // form of the last sweep
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<void *> allocs;
@@ -611,11 +627,11 @@ int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m, int hor
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(-20, "no HIP device available: the stack-fed sweep has no CPU fallback");
   if (device < 0 || device >= ndev) return sfail(-1, "device %d out of range (%d devices)", device, ndev);
-  LaunchFn fn = pick(nx, nu, m);
-  if (!fn) return sfail(-4, "no stack-fed instantiation for nx=%d nu=%d m=%d", nx, nu, m);
+  LaunchFn fn = pick(nx, nu, m), fn_coop = pick_coop(nx, nu, m);
+  if (!fn && !fn_coop) return sfail(-4, "no stack-fed instantiation for nx=%d nu=%d m=%d", nx, nu, m);
   SCHK(hipSetDevice(device));
   cddp_hip_stack_handle *h = new cddp_hip_stack_handle();
-  h->device = device; h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->nx = nx; h->nu = nu; h->m = m; h->N = horizon; h->fn = fn;
+  h->device = device; h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->nx = nx; h->nu = nu; h->m = m; h->N = horizon; h->fn = fn; h->fn_coop = fn_coop;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return sfail(-10, "hipStreamCreate failed"); }
   hipEventCreate(&h->e0); hipEventCreate(&h->e1);
   const size_t Bp = h->Bp, N = horizon;
@@ -767,7 +783,15 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   a.reg_max = opt->reg_max_value;
   a.tau_min = (branch == CDDP_HIP_STACKS_CLDDP) ? opt->termination_scaling_max_factor : opt->barrier_min_fraction_to_boundary;
   SCHK(hipEventRecord(h->e0, h->stream));
-  h->fn(a, h->stream);                              // ONE launch
+  {   // ONE launch; nx > 8 defaults to the cooperative form
+    LaunchFn f = (h->nx > 8 && h->fn_coop) ? h->fn_coop : (h->fn ? h->fn : h->fn_coop);
+    if (const char *e = std::getenv("CDDP_HIP_STACKS_SWEEP")) {
+      if (!std::strcmp(e, "coop") && h->fn_coop) f = h->fn_coop;
+      else if (!std::strcmp(e, "lane") && h->fn) f = h->fn;
+    }
+    h->used_coop = (f == h->fn_coop) ? 1 : 0;
+    f(a, h->stream);
+  }
   SCHK(hipEventRecord(h->e1, h->stream));
   SCHK(hipGetLastError());
   if (ok) SCHK(hipMemcpyAsync(ok, a.ok, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
@@ -778,6 +802,7 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
 }
 
 double cddp_hip_stacks_last_kernel_ms(cddp_hip_stack_handle *h) { return h ? h->last_ms : -1.0; }
+int cddp_hip_stacks_last_sweep_form(cddp_hip_stack_handle *h) { return h ? h->used_coop : -1; }
 
 int cddp_hip_stacks_get_gains(cddp_hip_stack_handle *h, double *K, double *k, double *Vx, double *Vxx, double *dV) {
   if (!h) return sfail(-1, "null handle");

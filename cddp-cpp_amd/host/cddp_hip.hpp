@@ -69,11 +69,13 @@ struct IPDDPAlgorithmOptions {
   double jacobian_regularization_value = 1e-8, jacobian_regularization_exponent = 0.25;
   SolverSpecificBarrierOptions barrier;
 };
+struct LogBarrierOptions { bool use_relaxed_log_barrier_penalty = false; double relaxed_log_barrier_delta = 1e-10; SolverSpecificBarrierOptions barrier; };   // options.hpp:135-143
 struct CDDPOptions {
   double tolerance = 1e-5, acceptable_tolerance = 1e-6; int max_iterations = 1; double max_cpu_time = 0.0;
   bool verbose = true, debug = false, print_solver_header = true, print_solver_options = false, use_ilqr = true, enable_parallel = false;
   int num_threads = 1; bool return_iteration_info = false, warm_start = false; double termination_scaling_max_factor = 100.0;
   LineSearchOptions line_search; RegularizationOptions regularization; BoxQPOptions box_qp; SolverSpecificFilterOptions filter; IPDDPAlgorithmOptions ipddp;
+  LogBarrierOptions log_barrier;
 
   cddp_hip_options toPOD() const {
     cddp_hip_options o; cddp_hip_default_options(&o);
@@ -100,6 +102,8 @@ struct CDDPOptions {
     o.barrier_mu_initial = ipddp.barrier.mu_initial; o.barrier_mu_min_value = ipddp.barrier.mu_min_value; o.barrier_mu_update_factor = ipddp.barrier.mu_update_factor;
     o.barrier_mu_update_power = ipddp.barrier.mu_update_power; o.barrier_min_fraction_to_boundary = ipddp.barrier.min_fraction_to_boundary;
     o.barrier_strategy = (int)ipddp.barrier.strategy;
+    o.logddp_mu_initial = log_barrier.barrier.mu_initial; o.logddp_mu_min_value = log_barrier.barrier.mu_min_value;
+    o.logddp_mu_update_factor = log_barrier.barrier.mu_update_factor; o.logddp_relaxed_delta = log_barrier.relaxed_log_barrier_delta;
     return o;
   }
 };
@@ -362,6 +366,9 @@ class Constraint {                      // constraint.hpp:40-142
   virtual Vector getUpperBound() const = 0;
   virtual Matrix getStateJacobian(const Vector &x, const Vector &u) const = 0;     // m x nx
   virtual Matrix getControlJacobian(const Vector &x, const Vector &u) const = 0;   // m x nu
+  // second derivatives of the rows (constraint.hpp:86-120: zero matrices by default); `false` = "not provided" (the reference's
+  // std::logic_error).  Used by LogDDP's relaxed log barrier only.  gxx[r] nx*nx, guu[r] nu*nu, gux[r] nu*nx, zero-filled by the caller.
+  virtual bool getHessians(const Vector &, const Vector &, double * /*gxx*/, double * /*guu*/, double * /*gux*/) const { return true; }
   // device descriptor: true when a kernel implements this constraint; a user subclass keeps the default
   virtual bool fill(cddp_hip_constraint &) const { return false; }
  protected:
@@ -403,6 +410,9 @@ class BallConstraint : public Constraint {      // constraint.hpp:313-404
   Vector getUpperBound() const override { return {-scale_ * radius_ * radius_}; }
   Matrix getStateJacobian(const Vector &x, const Vector &) const override { Matrix J(1, (int)x.size()); for (size_t i = 0; i < center_.size(); ++i) J(0, (int)i) = -2.0 * scale_ * (x[i] - center_[i]); return J; }
   Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix(1, (int)u.size()); }
+  bool getHessians(const Vector &x, const Vector &, double *gxx, double *, double *) const override {   // constraint.hpp:387-396
+    const int nx = (int)x.size(); for (size_t i = 0; i < center_.size(); ++i) gxx[i * nx + i] = -2.0 * scale_; return true;
+  }
   double radius_; Vector center_; double scale_;
 };
 class LinearConstraint : public Constraint {    // constraint.hpp:253-311
@@ -444,6 +454,7 @@ class SecondOrderConeConstraint : public Constraint {   // constraint.hpp:626-80
     return J;
   }
   Matrix getControlJacobian(const Vector &, const Vector &u) const override { return Matrix(1, (int)u.size()); }
+  bool getHessians(const Vector &, const Vector &, double *, double *, double *) const override { return false; }   // constraint.hpp:772-786 throw
   Vector origin_, axis_; double cos_fov_, epsilon_;
 };
 class ThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:802-927
@@ -466,6 +477,13 @@ class ThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:802-92
     if (!(rn < epsilon_)) for (int i = 0; i < (int)u.size(); ++i) { J(0, i) = -(u[i] / rn); J(1, i) = u[i] / rn; }
     return J;
   }
+  bool getHessians(const Vector &, const Vector &u, double *, double *guu, double *) const override {   // constraint.hpp:899-920: {-H, H}
+    const int nu = (int)u.size(); double sq = 0; for (double v : u) sq += v * v;
+    const double term = sq + epsilon_, den = std::pow(term, 1.5);
+    if (den > std::numeric_limits<double>::min()) for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) {
+      const double h = ((i == j ? term : 0.0) - u[i] * u[j]) / den; guu[i * nu + j] = -h; guu[nu * nu + i * nu + j] = h; }
+    return true;
+  }
   Vector min_; double max_, epsilon_; int dim_ = 0;
 };
 class MaxThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:929-1048
@@ -485,6 +503,12 @@ class MaxThrustMagnitudeConstraint : public Constraint {   // constraint.hpp:929
     const double rn = std::sqrt(sq + epsilon_);
     if (rn > std::numeric_limits<double>::min()) for (int i = 0; i < (int)u.size(); ++i) J(0, i) = u[i] / rn;
     return J;
+  }
+  bool getHessians(const Vector &, const Vector &u, double *, double *guu, double *) const override {   // constraint.hpp:1021-1042
+    const int nu = (int)u.size(); double sq = 0; for (double v : u) sq += v * v;
+    const double term = sq + epsilon_, den = std::pow(term, 1.5);
+    if (den > std::numeric_limits<double>::min()) for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) guu[i * nu + j] = ((i == j ? term : 0.0) - u[i] * u[j]) / den;
+    return true;
   }
   double max_, epsilon_; int dim_ = 0;
 };
@@ -604,7 +628,7 @@ class HipBatchSolver : public ISolverAlgorithm {
  public:
   explicit HipBatchSolver(int solver_kind, int device = 0) : kind_(solver_kind), device_(device) {}
   ~HipBatchSolver() override { if (h_) cddp_hip_destroy(h_); }
-  std::string getSolverName() const override { return kind_ == CDDP_HIP_SOLVER_IPDDP ? "IPDDP" : "CLDDP"; }
+  std::string getSolverName() const override { return kind_ == CDDP_HIP_SOLVER_IPDDP ? "IPDDP" : kind_ == CDDP_HIP_SOLVER_LOGDDP ? "LogDDP" : "CLDDP"; }
   // A second initialize() of the SAME solver object with options.warm_start keeps the device-resident solver state
   // (gains, slack / dual / costate variables): the reference's "existing solver state" branch
   // (clddp_solver.cpp:51-60, ipddp_solver.cpp:675-731).  CDDP::solve() creates a new solver per call, exactly as
@@ -636,7 +660,7 @@ class HipBatchSolver : public ISolverAlgorithm {
   void create(CDDP &ctx, const std::vector<Vector> &x0s) {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
-    plugin_ = ctx.needsHostPlugins();
+    plugin_ = ctx.needsHostPlugins() || kind_ == CDDP_HIP_SOLVER_LOGDDP;   // LogDDP: host loop + stack-fed GPU sweeps for every problem
     if (plugin_) {
       const DynamicalSystem &sys = ctx.getSystem();
       nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;
@@ -729,13 +753,27 @@ class HipBatchSolver : public ISolverAlgorithm {
       }
     });
   }
+  static void cbConHess(void *p, const double *x, const double *u, int, double *gxx, double *guu, double *gux) {
+    auto *c = (PluginCtx *)p;
+    guarded(c, [&] {
+      c->load(x, u); int off = 0;
+      for (const Constraint *k : c->cons) {
+        const int d = k->getDualDim();
+        double *pxx = gxx + (size_t)off * c->nx * c->nx, *puu = guu + (size_t)off * c->nu * c->nu, *pux = gux + (size_t)off * c->nu * c->nx;
+        if (!k->getHessians(c->x, c->u, pxx, puu, pux)) {   // "not provided": the rows stay zero
+          std::fill(pxx, pxx + (size_t)d * c->nx * c->nx, 0.0); std::fill(puu, puu + (size_t)d * c->nu * c->nu, 0.0); std::fill(pux, pux + (size_t)d * c->nu * c->nx, 0.0);
+        }
+        off += d;
+      }
+    });
+  }
   std::vector<CDDPSolution> collectPlugin(CDDP &ctx, int B) {
     if (ctx.hasTerminalConstraints()) throw std::runtime_error("HipBatchSolver: terminal constraints are not supported on host plug-in problems");
     PluginCtx pc; pc.sys = &ctx.getSystem(); pc.obj = &ctx.getObjective(); pc.nx = nx_; pc.nu = nu_; pc.m = 0;
     cddp_hip_plugin pl; std::memset(&pl, 0, sizeof(pl));
     pl.user = &pc; pl.nx = nx_; pl.nu = nu_;
     const ControlConstraint *box = nullptr;
-    if (kind_ == CDDP_HIP_SOLVER_IPDDP) {
+    if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP) {
       for (auto &kv : ctx.getConstraintSet()) {   // std::map order == dual stacking order
         if ((int)pc.cons.size() == CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) throw std::runtime_error("HipBatchSolver: too many path constraints for the plug-in solve");
         pl.constraint_dims[pc.cons.size()] = kv.second->getDualDim(); pc.m += kv.second->getDualDim(); pc.cons.push_back(kv.second.get());
@@ -749,6 +787,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     pl.discrete_dynamics = cbDyn; pl.jacobians = cbJac; pl.hessians = ctx.getOptions().use_ilqr ? nullptr : cbHess;
     pl.running_cost = cbRun; pl.terminal_cost = cbTerm; pl.running_cost_derivatives = cbRunD; pl.terminal_cost_derivatives = cbTermD;
     pl.constraints = pc.cons.empty() ? nullptr : cbCon;
+    pl.constraint_hessians = (kind_ == CDDP_HIP_SOLVER_LOGDDP && !pc.cons.empty()) ? cbConHess : nullptr;
     const int nx = nx_, nu = nu_, N = N_;
     std::vector<double> x0((size_t)B * nx), U0, X0;
     for (int b = 0; b < B; ++b) for (int i = 0; i < nx; ++i) x0[(size_t)b * nx + i] = x0s_[b][i];
@@ -816,6 +855,8 @@ inline void registerHipSolvers(int device = 0) {
   CDDP::registerSolver("IPDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_IPDDP, device); });
   CDDP::registerSolver("CLDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_CLDDP, device); });
   CDDP::registerSolver("CLCDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_CLDDP, device); });
+  CDDP::registerSolver("LogDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_LOGDDP, device); });
+  CDDP::registerSolver("LOGDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_LOGDDP, device); });
 }
 
 inline void CDDP::initializeProblemIfNecessary() {   // cddp_core.cpp:272-306
@@ -869,7 +910,8 @@ inline CDDPSolution CDDP::solve(const std::string &solver_type) {
 
 inline std::vector<CDDPSolution> CDDP::solveBatch(const std::string &solver_type, const std::vector<Vector> &x0s, int device) {
   initializeProblemIfNecessary();
-  const int kind = (solver_type == "IPDDP") ? CDDP_HIP_SOLVER_IPDDP : (solver_type == "CLDDP" || solver_type == "CLCDDP") ? CDDP_HIP_SOLVER_CLDDP : -1;
+  const int kind = (solver_type == "IPDDP") ? CDDP_HIP_SOLVER_IPDDP : (solver_type == "CLDDP" || solver_type == "CLCDDP") ? CDDP_HIP_SOLVER_CLDDP
+                   : (solver_type == "LogDDP" || solver_type == "LOGDDP") ? CDDP_HIP_SOLVER_LOGDDP : -1;
   if (kind < 0) throw std::runtime_error("UnknownSolver - No solver registered for '" + solver_type + "'");
   HipBatchSolver s(kind, device);
   return s.solveBatch(*this, x0s);

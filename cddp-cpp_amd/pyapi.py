@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
 
-ABI_VERSION = 2          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
+ABI_VERSION = 3          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
 MAX_MODEL_PARAMS = 24
 NAME_LEN = 48
 
@@ -22,14 +22,14 @@ MODEL_PENDULUM, MODEL_CARTPOLE, MODEL_UNICYCLE, MODEL_LTI = 0, 1, 2, 3
 MODEL_QUADROTOR, MODEL_MANIPULATOR, MODEL_QUADROTOR_EULER12, MODEL_MANIPULATOR7 = 4, 5, 6, 7
 MODEL_BICYCLE, MODEL_CAR = 8, 9
 EULER, HEUN, RK3, RK4 = 0, 1, 2, 3
-SOLVER_CLDDP, SOLVER_IPDDP = 0, 1
+SOLVER_CLDDP, SOLVER_IPDDP, SOLVER_LOGDDP = 0, 1, 2
 CON_CONTROL_BOX, CON_STATE_BOX, CON_BALL, CON_LINEAR = 0, 1, 2, 3
 CON_SOC, CON_THRUST, CON_MAX_THRUST = 4, 5, 6
 TERM_EQUALITY, TERM_INEQUALITY = 0, 1
-STATUS_RUNNING, STATUS_OPTIMAL, STATUS_ACCEPTABLE, STATUS_MAX_ITERATIONS, STATUS_REG_LIMIT, STATUS_MAX_CPU_TIME = range(6)
+STATUS_RUNNING, STATUS_OPTIMAL, STATUS_ACCEPTABLE, STATUS_MAX_ITERATIONS, STATUS_REG_LIMIT, STATUS_MAX_CPU_TIME, STATUS_REG_LIMIT_CONVERGED = range(7)
 STATUS_STRINGS = [
     "Running", "OptimalSolutionFound", "AcceptableSolutionFound", "MaxIterationsReached",
-    "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached",
+    "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached", "RegularizationLimitReached_Converged",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -69,6 +69,8 @@ class Options(C.Structure):
         ("barrier_min_fraction_to_boundary", C.c_double),
         ("barrier_strategy", C.c_int32), ("_pad3", C.c_int32),
         ("max_cpu_time", C.c_double),
+        ("logddp_mu_initial", C.c_double), ("logddp_mu_min_value", C.c_double), ("logddp_mu_update_factor", C.c_double),
+        ("logddp_relaxed_delta", C.c_double),
     ]
 
 
@@ -97,6 +99,7 @@ def default_options():
     o.barrier_mu_initial = 1.0; o.barrier_mu_min_value = 1e-10; o.barrier_mu_update_factor = 0.5
     o.barrier_mu_update_power = 1.2; o.barrier_min_fraction_to_boundary = 0.99; o.barrier_strategy = 0
     o.max_cpu_time = 0.0
+    o.logddp_mu_initial = 1.0; o.logddp_mu_min_value = 1e-10; o.logddp_mu_update_factor = 0.5; o.logddp_relaxed_delta = 1e-10
     return o
 
 
@@ -374,6 +377,7 @@ def unicycle_cone_problem(solver=SOLVER_IPDDP, horizon=100):
     """Unicycle with a control box and a SecondOrderConeConstraint on (x, y, theta) (constraint.hpp:626-800; geometry of
     tests/cddp_core/test_constraint.cpp:236-243: a 45-degree cone opening along +y from below the start), m = 5."""
     p = unicycle_problem(solver, horizon, obstacle=False)
+    p._cons[0].name = b"ControlConstraint"; p._rebuild()   # std::map order: "ControlConstraint" < "SecondOrderConeConstraint" (the device layout); 'S' < 'c'
     p.add_second_order_cone("SecondOrderConeConstraint", [0.0, -0.5, 0.0], [0.0, 1.0, 0.0], np.pi / 4.0 + 0.35, 1e-6)
     return p
 
@@ -567,7 +571,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
-    "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
+    "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
@@ -753,6 +757,7 @@ _F_TC = C.CFUNCTYPE(C.c_double, C.c_void_p, _dp)
 _F_RCD = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp)
 _F_TCD = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, _dp)
 _F_CON = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp)
+_F_CHS = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp)
 
 
 class PluginStruct(C.Structure):
@@ -762,20 +767,21 @@ class PluginStruct(C.Structure):
         ("discrete_dynamics", _F_DYN), ("jacobians", _F_JAC), ("hessians", _F_HES),
         ("running_cost", _F_RC), ("terminal_cost", _F_TC), ("running_cost_derivatives", _F_RCD),
         ("terminal_cost_derivatives", _F_TCD), ("constraints", _F_CON),
-        ("control_lower", _dp), ("control_upper", _dp),
+        ("control_lower", _dp), ("control_upper", _dp), ("constraint_hessians", _F_CHS),
     ]
 
 
 def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, discrete_dynamics, jacobians, running_cost, terminal_cost,
                  running_cost_derivatives, terminal_cost_derivatives, hessians=None, constraints=None, constraint_dims=(),
-                 control_lower=None, control_upper=None, device=0, trig=None):
+                 control_lower=None, control_upper=None, constraint_hessians=None, device=0, trig=None):
     """CDDP::solve() for HOST plug-ins through the C-ABI (cddp_hip_plugin_solve): the callables are the reference's virtual functions
     on numpy vectors -- discrete_dynamics(x, u, t) -> x_next; jacobians(x, u, t) -> (f_x, f_u) continuous-time;
     hessians(x, u, t) -> (f_xx[nx][nx][nx], f_uu[nx][nu][nu], f_ux[nx][nu][nx]); running_cost(x, u, index) -> float;
     terminal_cost(x) -> float; running_cost_derivatives(x, u, index) -> (l_x, l_u, l_xx, l_uu, l_ux); terminal_cost_derivatives(x)
     -> (l_x, l_xx); constraints(x, u, index, want_jacobians) -> (g - upper, G_x, G_u) stacked in name order.  The GPU runs the
     batched backward passes, the host the forward passes.  An exception raised by a callable stops the solve and is re-raised here.
-    Returns (results, X, U, K)."""
+    solver = SOLVER_LOGDDP runs the reference's LogDDP on the same callbacks; constraint_hessians(x, u, index) -> (g_xx[m][nx][nx],
+    g_uu[m][nu][nu], g_ux[m][nu][nx]) or None supplies constraint curvature to its relaxed log barrier.  Returns (results, X, U, K)."""
     lib = load_hip(trig)
     x0 = _arr(x0).reshape(-1, nx); B = x0.shape[0]; N = int(horizon)
     U0 = _arr(U0).reshape(B, N, nu) if U0 is not None else None
@@ -831,6 +837,13 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
         if gx: vec(gx, m * nx)[:] = np.asarray(Gx, dtype=np.float64).reshape(m * nx)
         if gu: vec(gu, m * nu)[:] = np.asarray(Gu, dtype=np.float64).reshape(m * nu)
 
+    def _chs(_, x, u, idx, gxx, guu, gux):
+        r = constraint_hessians(vec(x, nx).copy(), vec(u, nu).copy(), idx)
+        if r is None:
+            return
+        vec(gxx, m * nx * nx)[:] = np.asarray(r[0], dtype=np.float64).reshape(-1); vec(guu, m * nu * nu)[:] = np.asarray(r[1], dtype=np.float64).reshape(-1)
+        vec(gux, m * nu * nx)[:] = np.asarray(r[2], dtype=np.float64).reshape(-1)
+
     ps = PluginStruct()
     ps.nx, ps.nu, ps.n_constraints = nx, nu, len(constraint_dims)
     for i, dmy in enumerate(constraint_dims):
@@ -841,6 +854,8 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
         keep.append(_F_HES(guard(_hes))); ps.hessians = keep[-1]
     if constraints is not None and m > 0:
         keep.append(_F_CON(guard(_con))); ps.constraints = keep[-1]
+    if constraint_hessians is not None and m > 0:
+        keep.append(_F_CHS(guard(_chs))); ps.constraint_hessians = keep[-1]
     lo = _arr(control_lower) if control_lower is not None else None
     up = _arr(control_upper) if control_upper is not None else None
     ps.control_lower, ps.control_upper = _ptr(lo), _ptr(up)
@@ -918,6 +933,10 @@ class HipStackSolver:
 
     def kernel_ms(self):
         return float(self.lib.cddp_hip_stacks_last_kernel_ms(self.h))
+
+    def sweep_form(self):
+        """0 = one lane per trajectory, 1 = lane-cooperative (the default for nx > 8)."""
+        return int(self.lib.cddp_hip_stacks_last_sweep_form(self.h))
 
     def gains(self):
         B, N, nx, nu = self.B, self.N, self.nx, self.nu

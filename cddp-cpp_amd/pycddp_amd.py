@@ -82,7 +82,7 @@ class IPDDPOptions:
         self.dual_var_init_scale = 0.1; self.slack_var_init_scale = 1e-2; self.barrier = BarrierOptions()
 
 
-class LogBarrierOptions:            # accepted for source compatibility; the LogDDP solver is not on the device
+class LogBarrierOptions:            # options.hpp:135-143 (LogDDP)
     def __init__(self):
         self.use_relaxed_log_barrier_penalty = False; self.relaxed_log_barrier_delta = 1e-10; self.barrier = BarrierOptions()
 
@@ -129,6 +129,9 @@ class CDDPOptions:                  # options.hpp:41-251 / bind_options.cpp:96-1
         o.barrier_mu_initial = b.mu_initial; o.barrier_mu_min_value = b.mu_min_value
         o.barrier_mu_update_factor = b.mu_update_factor; o.barrier_mu_update_power = b.mu_update_power
         o.barrier_min_fraction_to_boundary = b.min_fraction_to_boundary; o.barrier_strategy = int(b.strategy)
+        lb = self.log_barrier
+        o.logddp_mu_initial = lb.barrier.mu_initial; o.logddp_mu_min_value = lb.barrier.mu_min_value
+        o.logddp_mu_update_factor = lb.barrier.mu_update_factor; o.logddp_relaxed_delta = lb.relaxed_log_barrier_delta
         return o
 
 
@@ -346,6 +349,10 @@ class QuadraticObjective(Objective):   # objective.hpp: (Q, R, Qf, reference_sta
 
 
 class Constraint:                   # constraint.hpp:40-142: the virtual interface a Python subclass overrides
+    def get_hessians(self, x, u):
+        """(g_xx[rows][nx][nx], g_uu[rows][nu][nu], g_ux[rows][nu][nx]) or None (constraint.hpp:86-120: zeros by default)."""
+        r, nx, nu = self.get_dual_dim(), np.asarray(x).size, np.asarray(u).size
+        return np.zeros((r, nx, nx)), np.zeros((r, nu, nu)), np.zeros((r, nu, nx))
     """evaluate(x, u), get_upper_bound(), get_state_jacobian(x, u), get_control_jacobian(x, u), get_dual_dim()."""
     def get_dual_dim(self): return int(np.asarray(self.get_upper_bound()).size)
 
@@ -374,6 +381,10 @@ class BallConstraint(Constraint):   # constraint.hpp:313-404: g = -s |x[:d] - c|
     def get_state_jacobian(self, x, u):
         J = np.zeros((1, np.asarray(x).size)); J[0, :self.center.size] = -2.0 * self.scale * (np.asarray(x)[:self.center.size] - self.center); return J
     def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
+    def get_hessians(self, x, u):    # constraint.hpp:387-396
+        nx, nu = np.asarray(x).size, np.asarray(u).size; d = self.center.size
+        H = np.zeros((1, nx, nx)); H[0, :d, :d] = -2.0 * self.scale * np.eye(d)
+        return H, np.zeros((1, nu, nu)), np.zeros((1, nu, nx))
 
 
 class LinearConstraint(Constraint):   # constraint.hpp:253-311: g = A x, upper = b
@@ -406,6 +417,12 @@ class SecondOrderConeConstraint(Constraint):   # constraint.hpp:626-800 / bind_c
         J = np.zeros((1, x.size)); J[0, :3] = self.cos_fov * (v / rn) - self.axis if rn > 1e-9 else -self.axis
         return J
     def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
+    def get_hessians(self, x, u): return None     # constraint.hpp:772-786: std::logic_error -> the barrier drops the curvature term
+
+
+def _norm_hessian(u, eps):          # constraint.hpp:899-920
+    u = np.asarray(u, dtype=np.float64); term = float(u @ u) + eps; den = term ** 1.5
+    return (term * np.eye(u.size) - np.outer(u, u)) / den if den > sys.float_info.min else np.zeros((u.size, u.size))
 
 
 class ThrustMagnitudeConstraint(Constraint):   # constraint.hpp:802-927
@@ -426,6 +443,9 @@ class ThrustMagnitudeConstraint(Constraint):   # constraint.hpp:802-927
         if not rn < self.epsilon:
             J[0] = -(u / rn); J[1] = u / rn
         return J
+    def get_hessians(self, x, u):
+        nx, nu = np.asarray(x).size, np.asarray(u).size; H = _norm_hessian(u, self.epsilon)
+        return np.zeros((2, nx, nx)), np.stack([-H, H]), np.zeros((2, nu, nx))
 
 
 class MaxThrustMagnitudeConstraint(Constraint):   # constraint.hpp:929-1048
@@ -444,6 +464,9 @@ class MaxThrustMagnitudeConstraint(Constraint):   # constraint.hpp:929-1048
         if rn > sys.float_info.min:
             J[0] = u / rn
         return J
+    def get_hessians(self, x, u):
+        nx, nu = np.asarray(x).size, np.asarray(u).size
+        return np.zeros((1, nx, nx)), _norm_hessian(u, self.epsilon)[None], np.zeros((1, nu, nx))
 
 
 class TerminalEqualityConstraint:   # terminal_constraint.hpp
@@ -554,9 +577,11 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
 
     def _solve(self, name, x0s):
         api = _api()
+        if name == "LogDDP":             # host loop + stack-fed GPU sweeps for every problem (cddp_hip_plugin_solve)
+            return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
         if name not in ("CLDDP", "IPDDP"):
-            if name in ("LogDDP", "MSIPDDP"):
-                raise NotImplementedError(name + " is not implemented on the HIP core (CLDDP and IPDDP are)")
+            if name == "MSIPDDP":
+                raise NotImplementedError(name + " is not implemented on the HIP core (CLDDP, IPDDP and LogDDP are)")
             sol = CDDPSolution()                 # cddp_core.cpp:243-265: unknown names do not throw
             sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
             return [sol for _ in range(len(x0s))]
@@ -616,7 +641,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         s, ob = self._sys, self._obj
         nx, nu, N, dt = s.state_dim, s.control_dim, self._N, self._dt
         names = sorted(self._cons)          # std::map order
-        ipddp = kind == api.SOLVER_IPDDP
+        ipddp = kind in (api.SOLVER_IPDDP, api.SOLVER_LOGDDP)
         cons = [self._cons[n] for n in names] if ipddp else []
         dims = [int(c.get_dual_dim()) for c in cons]
         lo = up = None
@@ -629,6 +654,12 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                 return g, None, None
             return (g, np.vstack([np.asarray(c.get_state_jacobian(x, u), dtype=np.float64).reshape(-1, nx) for c in cons]),
                     np.vstack([np.asarray(c.get_control_jacobian(x, u), dtype=np.float64).reshape(-1, nu) for c in cons]))
+
+        def constraint_hessians(x, u, index):
+            hs = [c.get_hessians(x, u) for c in cons]
+            z = lambda c: (np.zeros((c.get_dual_dim(), nx, nx)), np.zeros((c.get_dual_dim(), nu, nu)), np.zeros((c.get_dual_dim(), nu, nx)))
+            hs = [h if h is not None else z(c) for h, c in zip(hs, cons)]
+            return tuple(np.concatenate([np.asarray(h[k], dtype=np.float64) for h in hs]) for k in range(3))
 
         def hessians(x, u, t):
             return (np.stack([np.asarray(h) for h in s.get_state_hessian(x, u, t)]), np.stack([np.asarray(h) for h in s.get_control_hessian(x, u, t)]),
@@ -651,7 +682,8 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                                                       ob.get_running_cost_state_hessian(x, u, i), ob.get_running_cost_control_hessian(x, u, i),
                                                       ob.get_running_cost_cross_hessian(x, u, i)),
             terminal_cost_derivatives=lambda x: (ob.get_final_cost_gradient(x), ob.get_final_cost_hessian(x)),
-            constraints=constraints if cons else None, constraint_dims=dims, control_lower=lo, control_upper=up)
+            constraints=constraints if cons else None, constraint_dims=dims, control_lower=lo, control_upper=up,
+            constraint_hessians=constraint_hessians if (cons and kind == api.SOLVER_LOGDDP) else None)
         ms = (_time.perf_counter() - t0) * 1e3
         out = []
         for b in range(B):

@@ -31,7 +31,7 @@ extern "C" {
 
 /* 2: cddp_hip_options gained max_cpu_time (shifts cddp_hip_problem's tail), cddp_hip_stats gained rollout_steps (80 -> 88 bytes).
  * A host built against version 1 is refused by cddp_hip_create instead of being read at shifted offsets. */
-#define CDDP_HIP_ABI_VERSION 2
+#define CDDP_HIP_ABI_VERSION 3
 #define CDDP_HIP_MAX_MODEL_PARAMS 24
 #define CDDP_HIP_NAME_LEN 48
 #define CDDP_HIP_MAX_ALPHAS 32
@@ -60,7 +60,11 @@ enum cddp_hip_integrator {
 };
 
 /* Which reference solver core is replaced (cddp_core.cpp:213-233). */
-enum cddp_hip_solver { CDDP_HIP_SOLVER_CLDDP = 0, CDDP_HIP_SOLVER_IPDDP = 1 };
+enum cddp_hip_solver {
+  CDDP_HIP_SOLVER_CLDDP = 0, CDDP_HIP_SOLVER_IPDDP = 1,
+  CDDP_HIP_SOLVER_LOGDDP = 2   /* logddp_solver.cpp: single-shooting relaxed-log-barrier DDP; served by cddp_hip_plugin_solve (host loop +
+                                  stack-fed GPU sweeps), not by the device-resident cddp_hip_create / cddp_hip_solve */
+};
 
 /* Path-constraint kinds (reference include/cddp-cpp/cddp_core/constraint.hpp:144-404). */
 enum cddp_hip_constraint_kind {
@@ -85,7 +89,8 @@ enum cddp_hip_status {
   CDDP_HIP_STATUS_ACCEPTABLE = 2,         /* "AcceptableSolutionFound"                    */
   CDDP_HIP_STATUS_MAX_ITERATIONS = 3,     /* "MaxIterationsReached"                       */
   CDDP_HIP_STATUS_REG_LIMIT = 4,          /* "RegularizationLimitReached_NotConverged"    */
-  CDDP_HIP_STATUS_MAX_CPU_TIME = 5        /* "MaxCpuTimeReached"                          */
+  CDDP_HIP_STATUS_MAX_CPU_TIME = 5,       /* "MaxCpuTimeReached"                          */
+  CDDP_HIP_STATUS_REG_LIMIT_CONVERGED = 6 /* "RegularizationLimitReached_Converged" (LogDDP, logddp_solver.cpp:216-222) */
 };
 
 /* Line-search selection rule (cddp_solver_base.cpp:255-263 vs :264-314). */
@@ -162,6 +167,12 @@ typedef struct cddp_hip_options {
    * cddp_solver_base.cpp:77-90).  One clock for the batch: when it expires, every trajectory still running
    * terminates with "MaxCpuTimeReached" and iterations = the iteration the check fired in. */
   double max_cpu_time;                /* 0 */
+  /* LogBarrierOptions (options.hpp:135-143; LogDDP only): log_barrier.barrier.{mu_initial, mu_min_value, mu_update_factor} and
+   * log_barrier.relaxed_log_barrier_delta */
+  double logddp_mu_initial;           /* 1.0 */
+  double logddp_mu_min_value;         /* 1e-10 */
+  double logddp_mu_update_factor;     /* 0.5 */
+  double logddp_relaxed_delta;        /* 1e-10 */
 } cddp_hip_options;
 
 /* Fill *opt with the reference defaults (options.hpp in-class initialisers). */
@@ -485,6 +496,10 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
                              const double *mu, int retry, int32_t *ok);
 /* hipEvent time of the last sweep launch [ms]. */
 double cddp_hip_stacks_last_kernel_ms(cddp_hip_stack_handle *h);
+/* Form of the last sweep launch: 0 = one lane per trajectory, 1 = lane-cooperative (sixteen lanes per trajectory, step state in
+ * LDS: the default for nx > 8; CDDP_HIP_STACKS_SWEEP=lane|coop overrides where both forms are instantiated).  Bitwise the same
+ * results either way. */
+int cddp_hip_stacks_last_sweep_form(cddp_hip_stack_handle *h);
 /* K (B*N*nu*nx), k (B*N*nu), Vx (B*(N+1)*nx), Vxx (B*(N+1)*nx*nx), dV (B*2); any may be NULL. */
 int cddp_hip_stacks_get_gains(cddp_hip_stack_handle *h, double *K, double *k, double *Vx, double *Vxx, double *dV);
 /* Path branch: k_y, k_s (B*N*m), K_y, K_s (B*N*m*nx) and the linear-policy rollout dX (B*(N+1)*nx), ipddp_solver.cpp:1458-1520. */
@@ -522,7 +537,10 @@ int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
  *                                (clddp_solver.cpp:85-86, 147-178, 227-228) or NULL; CLDDP ignores every other constraint.
  * The GPU runs the backward pass of the whole batch (stack-fed sweeps above); the forward pass needs the plug-in's f(x, u) and runs
  * on the host (csrc/plugin_solve.hip).  All trajectories of the batch share the plug-in; they differ in x0 / U0 / X0.  Callbacks are
- * called from the calling thread only.  Not supported: terminal constraints, warm starts (use the built-in plants for those). */
+ * called from the calling thread only.  Not supported: terminal constraints, warm starts (use the built-in plants for those).
+ * solver = CDDP_HIP_SOLVER_LOGDDP runs the reference's LogDDP (logddp_solver.cpp:43-707: single shooting, relaxed log barrier of every
+ * path constraint folded into the cost derivatives on the host, Riccati sweep of the batch on the GPU, filter line search on the
+ * host); it takes the same callbacks, plus constraint_hessians when a constraint has curvature. */
 /* Host evaluation of a BUILT-IN plant (the kernels' own model source compiled for the host, csrc/host_models.cpp): the reference's
  * DynamicalSystem::getDiscreteDynamics (x_next), getStateJacobian / getControlJacobian (continuous-time f_x nx*nx, f_u nx*nu,
  * row-major) and getStateHessian / getControlHessian / getCrossHessian (fxx[i] nx*nx, fuu[i] nu*nu, fux[i] nu*nx per state row i;
@@ -548,6 +566,10 @@ typedef struct cddp_hip_plugin {
   void (*terminal_cost_derivatives)(void *user, const double *x, double *lx, double *lxx);
   void (*constraints)(void *user, const double *x, const double *u, int index, double *g, double *gx, double *gu);
   const double *control_lower, *control_upper;
+  /* LogDDP only (may be NULL): second derivatives of the m stacked constraint rows, gxx[r] (nx x nx), guu[r] (nu x nu), gux[r] (nu x nx),
+   * Constraint::getHessians; rows of constraints that provide none (or throw std::logic_error in the reference) stay zero.  They
+   * enter the relaxed log barrier's Hessian (barrier.hpp:137-213). */
+  void (*constraint_hessians)(void *user, const double *x, const double *u, int index, double *gxx, double *guu, double *gux);
 } cddp_hip_plugin;
 /* ISolverAlgorithm::initialize + solve for `batch` trajectories of a host plug-in problem.  x0: batch*nx; U0: batch*N*nu or NULL
  * (zeros); X0: batch*(N+1)*nx or NULL (x0 replicated).  results: batch records; X (batch*(N+1)*nx), U (batch*N*nu), K

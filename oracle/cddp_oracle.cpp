@@ -1358,15 +1358,191 @@ struct Solver {
     return false;
   }
 
+
+  // =============================================================== LogDDP (logddp_solver.cpp; RelaxedLogBarrier barrier.hpp:37-296)
+  double lg_mu = 1e-1, lg_delta = 1e-5, lg_violation = 1e7;   // LogDDPSolver members mu_, relaxation_delta_, constraint_violation_ (:43-44)
+
+  // beta_delta(z) and its first two derivatives (barrier.hpp:274-296)
+  static void lg_beta(double z, double delta, double &b0, double &b1, double &b2) {
+    if (z > delta) {
+      if (z <= 1e-12) { b0 = -std::log(1e-12); b1 = -1.0 / 1e-12; b2 = 1.0 / (1e-12 * 1e-12); }
+      else { b0 = -olog(z); b1 = -1.0 / z; b2 = 1.0 / (z * z); }
+    } else {
+      const double term_div_delta = (z - 2.0 * delta) / delta;
+      b0 = 0.5 * (term_div_delta * term_div_delta - 1.0) - olog(delta);
+      b1 = term_div_delta / delta;
+      b2 = 1.0 / (delta * delta);
+    }
+  }
+  // RelaxedLogBarrier::evaluate (:61-91): every constraint kind here has lower bound -inf, so only the upper side s_U = U - g enters;
+  // con_g returns g - U, i.e. s_U = -con_g
+  double lg_barrier_value(const ConstraintDesc &c, const Vec &x, const Vec &u) const {
+    const Vec g = con_g(c, x, u);
+    double total = 0.0;
+    for (int i = 0; i < c.dual_dim; ++i) { double b0, b1, b2; lg_beta(-g(i), lg_delta, b0, b1, b2); total += b0; }
+    return lg_mu * total;
+  }
+  // second derivatives of the constraint rows (Constraint::getHessians): false when the constraint throws logic_error (the cone),
+  // zero matrices for the kinds that keep the base-class defaults (constraint.hpp:86-120)
+  bool con_hess(const ConstraintDesc &c, const Vec &u, std::vector<Mat> &Hxx, std::vector<Mat> &Huu, std::vector<Mat> &Hux) const {
+    if (c.kind == CDDP_HIP_CON_SOC) return false;                      // :772-786 throw std::logic_error
+    Hxx.assign(c.dual_dim, Mat::Zero(nx, nx)); Huu.assign(c.dual_dim, Mat::Zero(nu, nu)); Hux.assign(c.dual_dim, Mat::Zero(nu, nx));
+    if (c.kind == CDDP_HIP_CON_BALL) for (int i = 0; i < c.dim; ++i) Hxx[0](i, i) = -2.0 * c.scale;   // :387-396
+    if (c.kind == CDDP_HIP_CON_THRUST || c.kind == CDDP_HIP_CON_MAX_THRUST) {   // :899-920, 1021-1042: (|u|^2 + eps) I - u u^T over (|u|^2 + eps)^1.5
+      double sq = 0; for (int i = 0; i < nu; ++i) sq += u(i) * u(i);
+      const double term = sq + c.scale, den = opow(term, 1.5);
+      Mat H = Mat::Zero(nu, nu);
+      if (den > std::numeric_limits<double>::min()) for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) H(i, j) = ((i == j ? term : 0.0) - u(i) * u(j)) / den;
+      if (c.kind == CDDP_HIP_CON_THRUST) { Huu[0] = -1.0 * H; Huu[1] = H; } else Huu[0] = H;
+    }
+    return true;
+  }
+  // getGradients (:95-135) and getHessians (:137-213) of one constraint, added to the Q blocks by the caller
+  void lg_barrier_derivs(const ConstraintDesc &c, const Vec &x, const Vec &u, Vec &gx, Vec &gu, Mat &Hxx, Mat &Huu, Mat &Hux) const {
+    const Vec g = con_g(c, x, u);
+    Mat Gx, Gu; con_jac(c, x, u, Gx, Gu);
+    gx = Vec::Zero(nx); gu = Vec::Zero(nu); Hxx = Mat::Zero(nx, nx); Huu = Mat::Zero(nu, nu); Hux = Mat::Zero(nu, nx);
+    std::vector<Mat> Cxx, Cuu, Cux;
+    const bool provides = con_hess(c, u, Cxx, Cuu, Cux);
+    for (int i = 0; i < c.dual_dim; ++i) {
+      double b0, b1, b2; lg_beta(-g(i), lg_delta, b0, b1, b2);
+      double dCost = 0.0; dCost -= b1;                 // upper side only
+      double t1 = 0.0, t2 = 0.0; t1 += b2; t2 -= b1;
+      for (int a = 0; a < nx; ++a) gx(a) += dCost * Gx(i, a);
+      for (int a = 0; a < nu; ++a) gu(a) += dCost * Gu(i, a);
+      for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) Hxx(a, b) += (t1 * Gx(i, a)) * Gx(i, b);
+      for (int a = 0; a < nu; ++a) for (int b = 0; b < nu; ++b) Huu(a, b) += (t1 * Gu(i, a)) * Gu(i, b);
+      for (int a = 0; a < nu; ++a) for (int b = 0; b < nx; ++b) Hux(a, b) += (t1 * Gu(i, a)) * Gx(i, b);
+      if (provides) { Hxx = Hxx + t2 * Cxx[i]; Huu = Huu + t2 * Cuu[i]; Hux = Hux + t2 * Cux[i]; }
+    }
+    gx = lg_mu * gx; gu = lg_mu * gu; Hxx = lg_mu * Hxx; Huu = lg_mu * Huu; Hux = lg_mu * Hux;
+  }
+  void lg_evaluate_trajectory() {   // :316-331
+    double c = 0.0;
+    for (int t = 0; t < N; ++t) c += running_cost(X[t], U[t], t);
+    c += terminal_cost(X.back());
+    cost = c;
+  }
+  void lg_reset_filter() {          // :333-361
+    merit = cost; lg_violation = 0.0;
+    for (int t = 0; t < N; ++t) for (auto &c : cons) {
+      const Vec g = con_g(c, X[t], U[t]);
+      merit += lg_barrier_value(c, X[t], U[t]);
+      for (int i = 0; i < c.dual_dim; ++i) if (g(i) > 0.0) lg_violation += g(i);
+    }
+    inf_pr = lg_violation;
+  }
+  void logddp_initialize() {        // :45-205 (cold start; the warm start branch keeps gains and re-rolls out the same way)
+    const bool warm = opt.warm_start && have_valid_gains();
+    X[0] = x0;                      // rollOutNominalTrajectory (:30-38): the state guess is only a guess
+    for (int t = 0; t < N; ++t) X[t + 1] = model.step(X[t], U[t], t * dt);
+    if (!warm) { initializeGains(); cost = objective_evaluate(X, U); }
+    alpha_pr = opt.ls_initial_step_size; dV[0] = dV[1] = 0.0;
+    reg = opt.reg_initial_value;
+    lg_violation = std::numeric_limits<double>::infinity();
+    lg_mu = opt.logddp_mu_initial; lg_delta = opt.logddp_relaxed_delta;
+    Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx));
+    lg_evaluate_trajectory(); lg_reset_filter();
+  }
+  bool logddp_backward() {          // :365-590
+    ++n_backward;
+    Vec V_x = final_grad(X.back());
+    Mat V_xx = final_hess(); V_xx = 0.5 * (V_xx + V_xx.T());
+    Vx_t[N] = V_x; Vxx_t[N] = V_xx;
+    dV[0] = dV[1] = 0.0;
+    double Qu_err = 0.0;
+    for (int t = N - 1; t >= 0; --t) {
+      const Vec &x = X[t]; const Vec &u = U[t];
+      Mat Fx, Fu; model.jacobians(x, u, t * dt, Fx, Fu);
+      Mat A = dt * Fx; for (int i = 0; i < nx; ++i) A(i, i) += 1.0;
+      Mat B = dt * Fu;
+      Vec Q_x = l_x(x, t) + A.T() * V_x;
+      Vec Q_u = l_u(u) + B.T() * V_x;
+      Mat Q_xx = l_xx() + A.T() * V_xx * A;
+      Mat Q_ux = l_ux() + B.T() * V_xx * A;
+      Mat Q_uu = l_uu() + B.T() * V_xx * B;
+      if (!opt.use_ilqr) {          // :505-515
+        std::vector<Mat> Fxx, Fuu, Fux;
+        if (!model.hessians(x, u, t * dt, Fxx, Fuu, Fux)) { std::fprintf(stderr, "oracle: use_ilqr=false needs Hessians\n"); std::abort(); }
+        for (int i = 0; i < nx; ++i) { Q_xx = Q_xx + (dt * V_x(i)) * Fxx[i]; Q_ux = Q_ux + (dt * V_x(i)) * Fux[i]; Q_uu = Q_uu + (dt * V_x(i)) * Fuu[i]; }
+      }
+      for (auto &c : cons) {        // :518-530
+        Vec gx, gu; Mat Hxx, Huu, Hux; lg_barrier_derivs(c, x, u, gx, gu, Hxx, Huu, Hux);
+        Q_x = Q_x + gx; Q_u = Q_u + gu; Q_xx = Q_xx + Hxx; Q_uu = Q_uu + Huu; Q_ux = Q_ux + Hux;
+      }
+      Mat Q_uu_reg = Q_uu; for (int i = 0; i < nu; ++i) Q_uu_reg(i, i) += reg;
+      Q_uu_reg = 0.5 * (Q_uu_reg + Q_uu_reg.T());
+      LDLT ldlt(Q_uu_reg);
+      if (!ldlt.ok) return false;
+      Mat bigRHS(nu, 1 + nx);
+      for (int i = 0; i < nu; ++i) { bigRHS(i, 0) = Q_u(i); for (int c = 0; c < nx; ++c) bigRHS(i, c + 1) = Q_ux(i, c); }
+      const Mat kK = -ldlt.solve(bigRHS);
+      Vec k(nu, 1); Mat K(nu, nx);
+      for (int i = 0; i < nu; ++i) { k(i) = kK(i, 0); for (int c = 0; c < nx; ++c) K(i, c) = kK(i, c + 1); }
+      k_u[t] = k; K_u[t] = K;
+      dV[0] += Q_u.dot(k);
+      dV[1] += 0.5 * k.dot(Q_uu * k);
+      V_x = Q_x + K.T() * Q_uu * k + Q_ux.T() * k + K.T() * Q_u;
+      V_xx = Q_xx + K.T() * Q_uu * K + Q_ux.T() * K + K.T() * Q_ux;
+      V_xx = 0.5 * (V_xx + V_xx.T());
+      Vx_t[t] = V_x; Vxx_t[t] = V_xx;
+      Qu_err = std::max(Qu_err, Q_u.lpNormInf());
+    }
+    inf_du = Qu_err;
+    return true;
+  }
+  FPResult logddp_forward(double a) {   // :594-707
+    FPResult r; r.alpha = a; r.alpha_pr = a; r.success = false;
+    r.cost = r.merit = std::numeric_limits<double>::infinity();
+    r.X = X; r.U = U; r.X[0] = x0;
+    for (int t = 0; t < N; ++t) {
+      const Vec delta_x = r.X[t] - X[t];
+      r.U[t] = U[t] + a * k_u[t] + K_u[t] * delta_x;
+      r.X[t + 1] = model.step(r.X[t], r.U[t], t * dt);
+      if (!r.X[t + 1].allFinite() || !r.U[t].allFinite()) return r;
+    }
+    double cost_new = 0.0, merit_new = 0.0, rp_err = 0.0;
+    for (int t = 0; t < N; ++t) {
+      cost_new += running_cost(r.X[t], r.U[t], t);
+      for (auto &c : cons) {
+        const Vec g = con_g(c, r.X[t], r.U[t]);
+        // (lg_barrier_value on the trial point)
+        double total = 0.0;
+        for (int i = 0; i < c.dual_dim; ++i) { double b0, b1, b2; lg_beta(-g(i), lg_delta, b0, b1, b2); total += b0; }
+        merit_new += lg_mu * total;
+        for (int i = 0; i < c.dual_dim; ++i) if (g(i) > 0.0) rp_err += g(i);
+      }
+    }
+    cost_new += terminal_cost(r.X.back());
+    merit_new += cost_new;
+    const double cv_old = lg_violation, cv_new = rp_err, merit_old = merit;
+    bool accept = false;
+    const double expected = a * dV[0];
+    if (cv_new > opt.filter_max_violation_threshold) {
+      if (cv_new < (1.0 - opt.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    } else if (std::max(cv_new, cv_old) < opt.filter_min_violation_for_armijo_check && expected < 0) {
+      if (merit_new < merit_old + opt.filter_armijo_constant * expected) accept = true;
+    } else {
+      if (merit_new < merit_old - opt.filter_merit_acceptance_threshold * cv_old || cv_new < (1.0 - opt.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    }
+    if (accept) { r.success = true; r.cost = cost_new; r.merit = merit_new; r.inf_pr = cv_new; }
+    return r;
+  }
+  void logddp_post_iteration(bool fp_success) {   // :263-277
+    if (fp_success) lg_mu = std::max(opt.logddp_mu_min_value, lg_mu * opt.logddp_mu_update_factor);
+    else lg_mu = std::min(opt.logddp_mu_initial, lg_mu * 5.0);
+    lg_reset_filter();
+  }
+
   // =============================================================== dispatch + main loop
-  void initialize() { if (solver_kind == CDDP_HIP_SOLVER_CLDDP) clddp_initialize(); else ipddp_initialize(); }
-  bool backwardPass() { return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_backward() : ipddp_backward(); }
-  FPResult forwardPass(double a) { ++n_forward; return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_forward(a) : ipddp_forward(a); }
+  void initialize() { if (solver_kind == CDDP_HIP_SOLVER_CLDDP) clddp_initialize(); else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) logddp_initialize(); else ipddp_initialize(); }
+  bool backwardPass() { return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_backward() : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_backward() : ipddp_backward(); }
+  FPResult forwardPass(double a) { ++n_forward; return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_forward(a) : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_forward(a) : ipddp_forward(a); }
 
   void recordHistory() {  // cddp_solver_base.cpp:220-232, ipddp_solver.cpp:2084-2088
     if (!opt.return_iteration_info) return;
     history.rows.push_back({cost, merit, alpha_pr, alpha_du, inf_du, inf_pr, inf_comp,
-                            solver_kind == CDDP_HIP_SOLVER_IPDDP ? mu : 0.0, reg});
+                            solver_kind == CDDP_HIP_SOLVER_IPDDP ? mu : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? lg_mu : 0.0, reg});
   }
 
   FPResult performForwardPass() {  // cddp_solver_base.cpp:248-317
@@ -1380,8 +1556,9 @@ struct Solver {
   }
 
   void solve() {  // cddp_solver_base.cpp:29-186
+    if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) { lg_evaluate_trajectory(); lg_reset_filter(); }   // preIterationSetup (logddp_solver.cpp:211-214)
     recordHistory();
-    int iter = 0; bool converged = false; int reason = CDDP_HIP_STATUS_MAX_ITERATIONS; double dJ = 0.0;
+    int iter = 0; bool converged = false; int reason = CDDP_HIP_STATUS_MAX_ITERATIONS; double dJ = 0.0, dL = 0.0;
     const auto start_time = std::chrono::steady_clock::now();
     while (iter < opt.max_iterations) {
       ++iter;
@@ -1394,30 +1571,39 @@ struct Solver {
         backward_ok = backwardPass();
         if (!backward_ok) {
           increaseRegularization();
-          if (isRegularizationLimitReached()) { reason = CDDP_HIP_STATUS_REG_LIMIT; converged = false; break; }
+          if (isRegularizationLimitReached()) {
+            if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) { reason = CDDP_HIP_STATUS_REG_LIMIT_CONVERGED; converged = true; }   // logddp_solver.cpp:216-222
+            else { reason = CDDP_HIP_STATUS_REG_LIMIT; converged = false; }
+            break;
+          }
         }
       }
       if (!backward_ok) break;
       bool early = false;
       if (solver_kind == CDDP_HIP_SOLVER_CLDDP) { if (inf_du < opt.tolerance) { reason = CDDP_HIP_STATUS_OPTIMAL; early = true; } }
+      else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) early = false;   // base default (cddp_solver_base.hpp)
       else early = ipddp_checkEarlyConvergence(reason);
       if (early) { converged = true; recordHistory(); break; }
       FPResult best = performForwardPass();
       bool fp_success = best.success;
       if (fp_success) {
-        dJ = cost - best.cost;
-        if (solver_kind == CDDP_HIP_SOLVER_CLDDP) {  // cddp_solver_base.cpp:190-198
+        dJ = cost - best.cost; dL = merit - best.merit;
+        if (solver_kind == CDDP_HIP_SOLVER_CLDDP || solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // cddp_solver_base.cpp:190-198
           X = best.X; U = best.U; cost = best.cost; merit = best.merit; alpha_pr = best.alpha_pr; alpha_du = best.alpha_du;
+          if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) lg_violation = best.inf_pr;   // logddp_solver.cpp:224-231
         } else ipddp_apply(best);
         recordHistory();
         decreaseRegularization();
         if (solver_kind == CDDP_HIP_SOLVER_CLDDP) {  // clddp_solver.cpp:264-277
           if (inf_du < opt.tolerance) { reason = CDDP_HIP_STATUS_OPTIMAL; converged = true; }
           else if (dJ > 0.0 && dJ < opt.acceptable_tolerance) { reason = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }
+        } else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // logddp_solver.cpp:233-261
+          if (std::max(inf_du, inf_pr) <= opt.tolerance) { reason = CDDP_HIP_STATUS_OPTIMAL; converged = true; }
+          else if (std::fabs(dJ) < opt.acceptable_tolerance && std::fabs(dL) < opt.acceptable_tolerance) { reason = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }
         } else converged = ipddp_checkConvergence(dJ, iter, reason);
       } else {
         bool brk;
-        if (solver_kind == CDDP_HIP_SOLVER_CLDDP) {  // cddp_solver_base.cpp:206-218
+        if (solver_kind == CDDP_HIP_SOLVER_CLDDP || solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // cddp_solver_base.cpp:206-218
           increaseRegularization();
           brk = isRegularizationLimitReached();
           if (brk) reason = CDDP_HIP_STATUS_REG_LIMIT;
@@ -1425,7 +1611,8 @@ struct Solver {
         if (brk) break;
       }
       if (converged) break;
-      // postIterationUpdate: only acts on failure, and then returns immediately (:2027-2035, :2556-2559)
+      // postIterationUpdate: IPDDP's only acts on failure, and then returns immediately (:2027-2035, :2556-2559); LogDDP's updates mu
+      if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) logddp_post_iteration(fp_success);
     }
     iterations = iter; status = reason;
   }
@@ -1489,7 +1676,7 @@ static Solver *build(const cddp_hip_problem *p) {
 
 static void fill_result(const Solver *s, cddp_hip_result *r) {
   r->final_objective = s->cost; r->merit_function = s->merit; r->inf_pr = s->inf_pr; r->inf_du = s->inf_du;
-  r->inf_comp = s->inf_comp; r->barrier_mu = s->solver_kind == CDDP_HIP_SOLVER_IPDDP ? s->mu : 0.0;
+  r->inf_comp = s->inf_comp; r->barrier_mu = s->solver_kind == CDDP_HIP_SOLVER_IPDDP ? s->mu : s->solver_kind == CDDP_HIP_SOLVER_LOGDDP ? s->lg_mu : 0.0;
   r->regularization = s->reg; r->alpha_pr = s->alpha_pr; r->alpha_du = s->alpha_du; r->step_norm = s->step_norm;
   r->iterations = s->iterations; r->status = s->status; r->n_backward = s->n_backward; r->n_forward = s->n_forward;
 }

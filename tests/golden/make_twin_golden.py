@@ -122,7 +122,7 @@ CASES = {
     "bicycle_clddp_box": lambda: _bicycle("CLDDP", True),
     "car_ipddp_box": lambda: _car("IPDDP", True),
     "car_clddp_box": lambda: _car("CLDDP", True),
-    "unicycle_ipddp_box_soc": lambda: _with(_unicycle("IPDDP", False), "SecondOrderConeConstraint",
+    "unicycle_ipddp_box_soc": lambda: _with(_unicycle("IPDDP", False, box_name="ControlConstraint"), "SecondOrderConeConstraint",
                                             T.SecondOrderCone([0.0, -0.5, 0.0], [0.0, 1.0, 0.0], math.pi / 4.0 + 0.35, 1e-6)),
     "unicycle_ipddp_thrust": lambda: _unicycle_thrust(True),
     "unicycle_ipddp_maxthrust": lambda: _unicycle_thrust(False),

@@ -109,5 +109,5 @@ def test_solve_batch_and_warm_start(pycddp, api):
 @pytest.mark.gpu
 def test_unsupported_solver_is_loud(pycddp):
     solver, _, _ = _pendulum(pycddp)
-    with pytest.raises(NotImplementedError, match="LogDDP is not implemented"):
-        solver.solve(pycddp.SolverType.LogDDP)
+    with pytest.raises(NotImplementedError, match="MSIPDDP is not implemented"):
+        solver.solve(pycddp.SolverType.MSIPDDP)
