@@ -543,9 +543,11 @@ typedef void (*LaunchFn)(const StackArgs &, hipStream_t);
 
 LaunchFn pick(int nx, int nu, int m) {
 #define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch<X, U, MM>;
+#ifndef CDDP_STACKS_DEV_SHAPE   // (kernel-development builds define it: one cooperative shape, seconds per compile; never set by the Makefile)
   PICK(1, 1, 0) PICK(1, 1, 1) PICK(1, 1, 2) PICK(2, 1, 0) PICK(2, 1, 2) PICK(4, 1, 0) PICK(4, 1, 2)
   PICK(3, 2, 0) PICK(3, 2, 4) PICK(3, 2, 5) PICK(4, 2, 0) PICK(4, 2, 4) PICK(6, 3, 0) PICK(6, 3, 6)
   PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0)
+#endif
 #undef PICK
   return nullptr;
 }
@@ -554,8 +556,12 @@ LaunchFn pick(int nx, int nu, int m) {
 // shapes are instantiated for the bitwise cross-check of the two forms (CDDP_HIP_STACKS_SWEEP=coop | lane overrides the default)
 LaunchFn pick_coop(int nx, int nu, int m) {
 #define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch_coop<X, U, MM>;
+#ifdef CDDP_STACKS_DEV_SHAPE
+  PICK(12, 4, 8)
+#else
   PICK(4, 1, 0) PICK(4, 1, 2) PICK(3, 2, 0) PICK(3, 2, 5) PICK(6, 3, 0) PICK(6, 3, 6)
   PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0) PICK(14, 7, 14)
+#endif
 #undef PICK
   return nullptr;
 }

@@ -37,6 +37,30 @@ struct SCfg {
 
 // "for e in my elements of [0, E)": element e of a step quantity belongs to lane e mod 16 of the trajectory's group
 #define SC_EACH(E, e) _Pragma("unroll") for (int e##_it = 0; e##_it < ((E) + 15) / 16; ++e##_it) if (const int e = e##_it * 16 + gl; e < (E))
+// the same for the matrix-sized quantities, rolled: unrolled, the scheduler hoists every LDS read of the phase and the kernel
+// needs all 512 registers plus scratch
+// "for c in my columns of an NC-column matrix"
+// Global element e of step t of an [t][E][Bp] stack: a wave-uniform 64-bit base (SGPR pair) plus a 32-bit lane offset, so the access
+// is "global_load v, v_off, s[base]" -- written as base + ((t * E + e) * Bp + b) the compiler strength-reduces EVERY access into its own
+// 64-bit VGPR pointer that lives across the whole sweep (~70 pairs: the first version spilled 250 registers).  eu = the part of the
+// element index that does not depend on the lane (e - gl).
+DEV double *sc_at(const double *base, int t, int E, int eu, unsigned lane8, unsigned bp8, int Bp) {
+  const unsigned long long v = (unsigned long long)(base + ((size_t)t * E + eu) * Bp);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull)), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  char *q = (char *)(((unsigned long long)hi << 32) | lo);
+  (void)bp8;
+  return (double *)(q + lane8);
+}
+#define SC_G(stack, t, E, e) (*sc_at((stack), (t), (E), (e) - gl, lane8, bp8, bpo))
+// the same for an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): uniform step
+// base, per-lane 32-bit offset e * Bp + b
+#define SC_GV(stack, t, E, e) (*(double *)((char *)sc_at((stack), (t), (E), 0, 0u, bp8, bpo) + ((unsigned)(e) * bp8 + (unsigned)b * 8u)))
+// The step index and the batch pitch are laundered through an empty asm once per step: otherwise the optimiser turns every access into
+// its own loop-carried 64-bit induction variable (~70 SGPR pairs, spilled to VGPR lanes: 628 v_readlane / v_writelane in the step
+// loop); laundered, the address arithmetic stays inside the step on the otherwise idle scalar unit.
+#define SC_OPAQUE(tt, bpo, t) int tt = (t), bpo = a.Bp; asm volatile("" : "+s"(tt), "+s"(bpo))
+#define SC_COLS(NC, c) for (int c = gl; c < (NC); c += 16)
+#define SC_LOOP(E, e) _Pragma("unroll 3") for (int e = gl; e < (E); e += 16)
 
 template <int NU>
 struct SCFactor {   // the factorisation the one-lane kernel uses for this size, on register copies
@@ -57,58 +81,134 @@ struct SCFactor<1> {
   DEV void solve(double *x) const { x[0] = ldlt1_solve(d, x[0]); }
 };
 
+// One step's input record, spread over the sixteen lanes of a group (element e on lane e mod 16), in registers between its
+// fetch (issued a step ahead) and the moment the LDS areas of the previous step are free.
+template <int NX, int NU, int M>
+struct SCRec {
+  typedef SCfg<NX, NU, M> C;
+  static constexpr int cdiv(int x) { return (x + 15) / 16; }
+  static constexpr int MM = M > 0 ? M : 1;
+  double A[cdiv(NX * NX)], Bm[cdiv(NX * NU)], lx[cdiv(NX)], lu[cdiv(NU)], lxx[cdiv(NX * NX)], luu[cdiv(NU * NU)], lux[cdiv(NU * NX)];
+  double y[cdiv(MM)], s[cdiv(MM)], g[cdiv(MM)], Gx[cdiv(MM * NX)], Gu[cdiv(MM * NU)];
+  DEV void fetch(const StackArgs &a, int t0, int b, int gl) {
+    SC_OPAQUE(t, bpo, t0);
+    const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
+    SC_EACH(NX * NX, e) A[e_it] = SC_G(a.fx, t, NX * NX, e);
+    SC_EACH(NX * NU, e) Bm[e_it] = SC_G(a.fu, t, NX * NU, e);
+    SC_EACH(NX, e) lx[e_it] = SC_G(a.lx, t, NX, e);
+    SC_EACH(NU, e) lu[e_it] = SC_G(a.lu, t, NU, e);
+    SC_EACH(NX * NX, e) lxx[e_it] = SC_G(a.lxx, t, NX * NX, e);
+    SC_EACH(NU * NU, e) luu[e_it] = SC_G(a.luu, t, NU * NU, e);
+    SC_EACH(NU * NX, e) lux[e_it] = SC_G(a.lux, t, NU * NX, e);
+    if constexpr (M > 0) {
+      SC_EACH(M, e) { y[e_it] = SC_G(a.y, t, M, e); s[e_it] = SC_G(a.s, t, M, e); g[e_it] = SC_G(a.g, t, M, e); }
+      SC_EACH(M * NX, e) Gx[e_it] = SC_G(a.Gx, t, M * NX, e);
+      SC_EACH(M * NU, e) Gu[e_it] = SC_G(a.Gu, t, M * NU, e);
+    }
+  }
+  DEV void park(double *__restrict__ L, int gl) const {
+    SC_EACH(NX * NX, e) L[C::oA + e] = A[e_it];
+    SC_EACH(NX * NU, e) L[C::oB + e] = Bm[e_it];
+    SC_EACH(NX, e) L[C::oQx + e] = lx[e_it];
+    SC_EACH(NU, e) L[C::oQu + e] = lu[e_it];
+    SC_EACH(NX * NX, e) L[C::oQxx + e] = lxx[e_it];
+    SC_EACH(NU * NU, e) L[C::oQuu + e] = luu[e_it];
+    SC_EACH(NU * NX, e) L[C::oQux + e] = lux[e_it];
+    if constexpr (M > 0) {
+      SC_EACH(M, e) { L[C::oY + e] = y[e_it]; L[C::oS + e] = s[e_it]; L[C::oGg + e] = g[e_it]; }
+      SC_EACH(M * NX, e) L[C::oGx + e] = Gx[e_it];
+      SC_EACH(M * NU, e) L[C::oGu + e] = Gu[e_it];
+    }
+  }
+};
+
+// R rows of  out(i) = sum_k L[addr(i, k)] * v[k]  (k ascending from 0.0): the operand rows are double-buffered by hand -- the LDS
+// reads of rows i + 2, i + 3 are in flight while rows i, i + 1 are reduced (two independent chains).  With one wavefront per SIMD
+// nothing else hides the LDS round trip: the counters of the first version showed the wave waiting 60 % of its cycles
+// (profiles/r03_stackfed_sweeps.md).  sched_barrier keeps the compiler from hoisting every read of the phase to its top (which
+// needs all 512 registers plus scratch).
+template <int R, int K, class Addr, class Term, class Out>
+DEV void sc_rows_t(const double *__restrict__ L, Addr addr, Term term, Out out) {
+  double buf[2][2][K];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (h < R) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) buf[0][h][k] = L[addr(h, k)];
+    }
+#pragma unroll
+  for (int i = 0; i < R; i += 2) {
+    const int cur = (i >> 1) & 1, nxt = cur ^ 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (i + 2 + h < R) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) buf[nxt][h][k] = L[addr(i + 2 + h, k)];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      s0 += term(k, buf[cur][0][k]);
+      if (i + 1 < R) s1 += term(k, buf[cur][1][k]);
+    }
+    out(i, s0);
+    if (i + 1 < R) out(i + 1, s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R, int K, class Addr, class Out>
+DEV void sc_rows(const double *__restrict__ L, const double (&v)[K], Addr addr, Out out) {
+  sc_rows_t<R, K>(L, addr, [&](int k, double x) { return x * v[k]; }, out);
+}
+
 template <int NX, int NU, int M>
 DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__restrict__ L, const double reg, const double mu, double &dV0,
                     double &dV1, double &inf_du, double &inf_pr, double &inf_comp, double &step_norm) {
   typedef SCfg<NX, NU, M> C;
-  const int N = a.N;
+  const int N = a.N, bpo = a.Bp;
+  const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
   const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
   const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP;
   const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP && !lg;
   SC_EACH(NX, i) L[C::oVx + i] = a.VxN[(size_t)i * a.Bp + b];
   if (ip || lg) {
-    SC_EACH(NX * NX, e) {
+    SC_LOOP(NX * NX, e) {
       const int i = e / NX, c = e - i * NX;
       L[C::oVxx + e] = 0.5 * (a.VxxN[(size_t)(i * NX + c) * a.Bp + b] + a.VxxN[(size_t)(c * NX + i) * a.Bp + b]);
     }
   } else {
-    SC_EACH(NX * NX, e) L[C::oVxx + e] = a.VxxN[(size_t)e * a.Bp + b];
+    SC_LOOP(NX * NX, e) L[C::oVxx + e] = a.VxxN[(size_t)e * a.Bp + b];
   }
   lds_sync();
-  SC_EACH(NX, i) a.Vx[SI(N, NX, i)] = L[C::oVx + i];
-  SC_EACH(NX * NX, e) a.Vxx[SI(N, NX * NX, e)] = L[C::oVxx + e];
+  SC_EACH(NX, i) SC_G(a.Vx, N, NX, i) = L[C::oVx + i];
+  SC_LOOP(NX * NX, e) SC_G(a.Vxx, N, NX * NX, e) = L[C::oVxx + e];
   dV0 = dV1 = 0.0; inf_du = inf_pr = inf_comp = step_norm = 0.0;
   double norm_Vx = 0.0;
   if (!ip && !lg) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
   }
-  for (int t = N - 1; t >= 0; --t) {
-    // ---------------------------------------------------------------- step record -> LDS
-    SC_EACH(NX * NX, e) L[C::oA + e] = a.fx[SI(t, NX * NX, e)];
-    SC_EACH(NX * NU, e) L[C::oB + e] = a.fu[SI(t, NX * NU, e)];
-    SC_EACH(NX, e) L[C::oQx + e] = a.lx[SI(t, NX, e)];
-    SC_EACH(NU, e) L[C::oQu + e] = a.lu[SI(t, NU, e)];
-    SC_EACH(NX * NX, e) L[C::oQxx + e] = a.lxx[SI(t, NX * NX, e)];
-    SC_EACH(NU * NU, e) L[C::oQuu + e] = a.luu[SI(t, NU * NU, e)];
-    SC_EACH(NU * NX, e) L[C::oQux + e] = a.lux[SI(t, NU * NX, e)];
-    if constexpr (M > 0) {
-      SC_EACH(M, e) { L[C::oY + e] = a.y[SI(t, M, e)]; L[C::oS + e] = a.s[SI(t, M, e)]; L[C::oGg + e] = a.g[SI(t, M, e)]; }
-      SC_EACH(M * NX, e) L[C::oGx + e] = a.Gx[SI(t, M * NX, e)];
-      SC_EACH(M * NU, e) L[C::oGu + e] = a.Gu[SI(t, M * NU, e)];
-    }
+  SCRec<NX, NU, M> rec;
+  rec.fetch(a, N - 1, b, gl);
+  for (int t_ = N - 1; t_ >= 0; --t_) {
+    SC_OPAQUE(t, bpo, t_);
+    // ---------------------------------------------------------------- step record -> LDS (fetched during the previous step)
+    rec.park(L, gl);
     // w = V_x, or V_x + V_xx d_t under multiple shooting (V of step t + 1 is already in LDS)
     if (ms) {
       SC_EACH(NX, i) {
         double s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NX; ++k) s1 += L[C::oVxx + i * NX + k] * a.dfc[SI(t, NX, k)];
+        for (int k = 0; k < NX; ++k) s1 += L[C::oVxx + i * NX + k] * SC_GV(a.dfc, t, NX, k);
         L[C::oW + i] = L[C::oVx + i] + s1;
       }
     } else {
       SC_EACH(NX, i) L[C::oW + i] = L[C::oVx + i];
     }
     lds_sync();
+    if (t > 0) rec.fetch(a, t - 1, b, gl);   // in flight behind this step's arithmetic
     // ---------------------------------------------------------------- Q_x, Q_u, T1 = A^T V_xx, T2 = B^T V_xx
     SC_EACH(NX, i) {
       double q = L[C::oQx + i];
@@ -136,39 +236,33 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       for (int k = 0; k < NX; ++k) s2 += L[C::oB + k * NU + i] * L[C::oW + k];
       L[C::oQu + i] = q + s2;
     }
-    SC_EACH(NX * NX, e) {
-      const int i = e / NX, c = e - i * NX;
-      double s1 = 0.0;
+    // column owners: lane c keeps column c of the right-hand operand in registers and walks the rows; the other operand arrives
+    // as group-wide broadcast reads (one LDS address per trajectory and instruction)
+    SC_COLS(NX, c) {
+      double v[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += L[C::oA + k * NX + i] * L[C::oVxx + k * NX + c];
-      L[C::oT1 + e] = s1;
-    }
-    SC_EACH(NU * NX, e) {
-      const int i = e / NX, c = e - i * NX;
-      double s1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += L[C::oB + k * NU + i] * L[C::oVxx + k * NX + c];
-      L[C::oT2 + e] = s1;
+      for (int k = 0; k < NX; ++k) v[k] = L[C::oVxx + k * NX + c];
+      sc_rows<NX, NX>(L, v, [](int i, int k) { return C::oA + k * NX + i; }, [&](int i, double s1) { L[C::oT1 + i * NX + c] = s1; });
+      sc_rows<NU, NX>(L, v, [](int i, int k) { return C::oB + k * NU + i; }, [&](int i, double s1) { L[C::oT2 + i * NX + c] = s1; });
     }
     lds_sync();
     // ---------------------------------------------------------------- Q_xx += T1 A, Q_ux += T2 A, Q_uu += T2 B (+ tensor terms)
-    SC_EACH(NX * NX, e) {
-      const int i = e / NX, c = e - i * NX;
-      double s1 = 0.0;
+    SC_COLS(NX, c) {
+      double v[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += L[C::oT1 + i * NX + k] * L[C::oA + k * NX + c];
-      double q = L[C::oQxx + e] + s1;
-      if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * a.Fxx[SI(t, NX * NX * NX, j * NX * NX + e)];
-      L[C::oQxx + e] = q;
-    }
-    SC_EACH(NU * NX, e) {
-      const int i = e / NX, c = e - i * NX;
-      double s1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) s1 += L[C::oT2 + i * NX + k] * L[C::oA + k * NX + c];
-      double q = L[C::oQux + e] + s1;
-      if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * a.Fux[SI(t, NX * NU * NX, j * NU * NX + e)];
-      L[C::oQux + e] = q;
+      for (int k = 0; k < NX; ++k) v[k] = L[C::oA + k * NX + c];
+      sc_rows<NX, NX>(L, v, [](int i, int k) { return C::oT1 + i * NX + k; }, [&](int i, double s1) {
+        const int e = i * NX + c;
+        double q = L[C::oQxx + e] + s1;
+        if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fxx, t, NX * NX * NX, j * NX * NX + e);
+        L[C::oQxx + e] = q;
+      });
+      sc_rows<NU, NX>(L, v, [](int i, int k) { return C::oT2 + i * NX + k; }, [&](int i, double s1) {
+        const int e = i * NX + c;
+        double q = L[C::oQux + e] + s1;
+        if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fux, t, NX * NU * NX, j * NU * NX + e);
+        L[C::oQux + e] = q;
+      });
     }
     SC_EACH(NU * NU, e) {
       const int i = e / NU, c = e - i * NU;
@@ -176,7 +270,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
 #pragma unroll
       for (int k = 0; k < NX; ++k) s1 += L[C::oT2 + i * NX + k] * L[C::oB + k * NU + c];
       double q = L[C::oQuu + e] + s1;
-      if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * a.Fuu[SI(t, NX * NU * NU, j * NU * NU + e)];
+      if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fuu, t, NX * NU * NU, j * NU * NU + e);
       L[C::oQuu + e] = q;
     }
     lds_sync();
@@ -209,12 +303,12 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         for (int r = 0; r < M; ++r) s1 += L[C::oGu + r * NU + i] * L[C::oSir + r];
         L[C::oRu + i] = L[C::oQu + i] + s1;
       }
-      SC_EACH(NU * NX, e) {
-        const int i = e / NX, c = e - i * NX;
-        double s2 = 0.0;
+      SC_COLS(NX, c) {
+        double gxc[M], ys[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) s2 += (L[C::oGu + r * NU + i] * L[C::oYS + r]) * L[C::oGx + r * NX + c];
-        L[C::oRx + e] = L[C::oQux + e] + s2;
+        for (int r = 0; r < M; ++r) { gxc[r] = L[C::oGx + r * NX + c]; ys[r] = L[C::oYS + r]; }
+        sc_rows_t<NU, M>(L, [](int i, int r) { return C::oGu + r * NU + i; }, [&](int r, double x) { return (x * ys[r]) * gxc[r]; },
+                         [&](int i, double s2) { L[C::oRx + i * NX + c] = L[C::oQux + i * NX + c] + s2; });
       }
       lds_sync();
       {
@@ -243,18 +337,24 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         double temp = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; ++i) temp += L[C::oGu + r * NU + i] * kk[i];
-        a.ky[SI(t, M, r)] = clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]);
-        a.ks[SI(t, M, r)] = (-L[C::oRp + r]) - temp;
+        SC_G(a.ky, t, M, r) = clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]);
+        SC_G(a.ks, t, M, r) = (-L[C::oRp + r]) - temp;
       }
-      SC_EACH(M * NX, e) {
-        const int r = e / NX, c = e - r * NX;
-        double s2 = 0.0;
+      SC_COLS(NX, c) {
+        double kc[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) s2 += L[C::oGu + r * NU + i] * L[C::oKK + i * NX + c];
-        const double gx = L[C::oGx + e];
-        const double inner = gx + s2;
-        a.Ky[SI(t, M * NX, e)] = dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS);
-        a.Ks[SI(t, M * NX, e)] = (-gx) - s2;
+        for (int i = 0; i < NU; ++i) kc[i] = L[C::oKK + i * NX + c];
+#pragma unroll 2
+        for (int r = 0; r < M; ++r) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < NU; ++i) s2 += L[C::oGu + r * NU + i] * kc[i];
+          const int e = r * NX + c;
+          const double gx = L[C::oGx + e];
+          const double inner = gx + s2;
+          SC_G(a.Ky, t, M * NX, e) = dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS);
+          SC_G(a.Ks, t, M * NX, e) = (-gx) - s2;
+        }
       }
       // condensed terms into the Q blocks (:1488-1492)
       SC_EACH(NX, i) {
@@ -263,12 +363,12 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         for (int r = 0; r < M; ++r) s1 += L[C::oGx + r * NX + i] * L[C::oSir + r];
         L[C::oQx + i] = L[C::oQx + i] + s1;
       }
-      SC_EACH(NX * NX, e) {
-        const int i = e / NX, c = e - i * NX;
-        double s1 = 0.0;
+      SC_COLS(NX, c) {
+        double gxc[M], ys[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) s1 += (L[C::oGx + r * NX + i] * L[C::oYS + r]) * L[C::oGx + r * NX + c];
-        L[C::oQxx + e] = L[C::oQxx + e] + s1;
+        for (int r = 0; r < M; ++r) { gxc[r] = L[C::oGx + r * NX + c]; ys[r] = L[C::oYS + r]; }
+        sc_rows_t<NX, M>(L, [](int i, int r) { return C::oGx + r * NX + i; }, [&](int r, double x) { return (x * ys[r]) * gxc[r]; },
+                         [&](int i, double s1) { L[C::oQxx + i * NX + c] = L[C::oQxx + i * NX + c] + s1; });
       }
       SC_EACH(NU * NU, e) {
         const int i = e / NU, c = e - i * NU;
@@ -278,7 +378,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         L[C::oQuu + e] = L[C::oQuu + e] + s1;
       }
       SC_EACH(NU, i) L[C::oQu + i] = L[C::oRu + i];
-      SC_EACH(NU * NX, e) L[C::oQux + e] = L[C::oRx + e];
+      SC_LOOP(NU * NX, e) L[C::oQux + e] = L[C::oRx + e];
     } else if (ip || lg) {
       // IPDDP: Q_uu = sym(Q_uu) + reg I, kept (:1084-1101).  LogDDP: factor sym(Q_uu + reg I), Q_uu itself untouched (:524-548)
       double qs[(NU * NU + 15) / 16];
@@ -322,7 +422,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       if (a.lo) {
         double lb[NU], ub[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { const double ut = a.U[SI(t, NU, i)]; lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = a.k[SI(t, NU, i)]; }
+        for (int i = 0; i < NU; ++i) { const double ut = SC_GV(a.U, t, NU, i); lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = SC_GV(a.k, t, NU, i); }
         int free_[NU];
         LDLTd<NU> Hfree;
         const int stq = boxqp_solve<NU>(a.opt, Qr, Qu, lb, ub, kk, free_, Hfree);
@@ -361,8 +461,8 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       }
     }
     lds_sync();
-    SC_EACH(NU, i) a.k[SI(t, NU, i)] = kk[i];
-    SC_EACH(NU * NX, e) a.K[SI(t, NU * NX, e)] = L[C::oKK + e];
+    SC_EACH(NU, i) SC_G(a.k, t, NU, i) = kk[i];
+    SC_LOOP(NU * NX, e) SC_G(a.K, t, NU * NX, e) = L[C::oKK + e];
     {   // expected-decrease terms: the scalar chain every lane repeats
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -376,7 +476,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
 #pragma unroll
       for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(L[C::oQu + i])); step_norm = dmax(step_norm, fabs(kk[i])); }
     }
-    SC_EACH(NX * NU, e) {   // K^T Q_uu
+    SC_LOOP(NX * NU, e) {   // K^T Q_uu
       const int i = e / NU, j = e - i * NU;
       double s1 = 0.0;
 #pragma unroll
@@ -397,24 +497,29 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       }
       vxn[i_it] = ((L[C::oQx + i] + p) + q) + r;
     }
-    SC_EACH(NX * NX, e) {
-      const int i = e / NX, c = e - i * NX;
-      double p = 0.0, q = 0.0, r = 0.0;
-      if (ip) {
+    SC_COLS(NX, c) {
+      double kc[NU], qc[NU];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) { p += L[C::oKK + j * NX + i] * L[C::oQux + j * NX + c]; q += L[C::oQux + j * NX + i] * L[C::oKK + j * NX + c]; r += L[C::oKtQ + i * NU + j] * L[C::oKK + j * NX + c]; }
-      } else {
+      for (int j = 0; j < NU; ++j) { kc[j] = L[C::oKK + j * NX + c]; qc[j] = L[C::oQux + j * NX + c]; }
+#pragma unroll 2
+      for (int i = 0; i < NX; ++i) {
+        double p = 0.0, q = 0.0, r = 0.0;
+        if (ip) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) { p += L[C::oKtQ + i * NU + j] * L[C::oKK + j * NX + c]; q += L[C::oQux + j * NX + i] * L[C::oKK + j * NX + c]; r += L[C::oKK + j * NX + i] * L[C::oQux + j * NX + c]; }
+          for (int j = 0; j < NU; ++j) { p += L[C::oKK + j * NX + i] * qc[j]; q += L[C::oQux + j * NX + i] * kc[j]; r += L[C::oKtQ + i * NU + j] * kc[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { p += L[C::oKtQ + i * NU + j] * kc[j]; q += L[C::oQux + j * NX + i] * kc[j]; r += L[C::oKK + j * NX + i] * qc[j]; }
+        }
+        L[C::oVn + i * NX + c] = ((L[C::oQxx + i * NX + c] + p) + q) + r;
       }
-      L[C::oVn + e] = ((L[C::oQxx + e] + p) + q) + r;
     }
-    SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; a.Vx[SI(t, NX, i)] = vxn[i_it]; }
+    SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; SC_G(a.Vx, t, NX, i) = vxn[i_it]; }
     lds_sync();
-    SC_EACH(NX * NX, e) {
+    SC_LOOP(NX * NX, e) {
       const int i = e / NX, c = e - i * NX;
       const double v = 0.5 * (L[C::oVn + i * NX + c] + L[C::oVn + c * NX + i]);
-      L[C::oVxx + e] = v; a.Vxx[SI(t, NX * NX, e)] = v;
+      L[C::oVxx + e] = v; SC_G(a.Vxx, t, NX * NX, e) = v;
     }
     if (!ip && !lg) {
 #pragma unroll
@@ -437,6 +542,36 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
   }
   return true;
 }
+
+// Rows of one step of the linear-policy rollout, per lane: constraint row r = lane (K_s, K_y, k_s, k_y, s, y), control row i = lane
+// (K, k), state row i = lane (A, B).
+template <int NX, int NU, int M>
+struct SCRoll {
+  static constexpr int cdiv(int x) { return (x + 15) / 16; }
+  static constexpr int MM = M > 0 ? M : 1;
+  double Ks[cdiv(MM)][NX], Ky[cdiv(MM)][NX], ks[cdiv(MM)], ky[cdiv(MM)], s[cdiv(MM)], y[cdiv(MM)];
+  double K[cdiv(NU)][NX], k[cdiv(NU)], fx[cdiv(NX)][NX], fu[cdiv(NX)][NU];
+  DEV void load(const StackArgs &a, int t0, int b, int gl) {
+    SC_OPAQUE(t, bpo, t0);
+    const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
+    SC_EACH(M, r) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { Ks[r_it][j] = SC_GV(a.Ks, t, M * NX, r * NX + j); Ky[r_it][j] = SC_GV(a.Ky, t, M * NX, r * NX + j); }
+      ks[r_it] = SC_G(a.ks, t, M, r); ky[r_it] = SC_G(a.ky, t, M, r); s[r_it] = SC_G(a.s, t, M, r); y[r_it] = SC_G(a.y, t, M, r);
+    }
+    SC_EACH(NU, i) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) K[i_it][j] = SC_GV(a.K, t, NU * NX, i * NX + j);
+      k[i_it] = SC_G(a.k, t, NU, i);
+    }
+    SC_EACH(NX, i) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) fx[i_it][j] = SC_GV(a.fx, t, NX * NX, i * NX + j);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) fu[i_it][j] = SC_GV(a.fu, t, NX * NU, i * NU + j);
+    }
+  }
+};
 
 template <int NX, int NU, int M>
 __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
@@ -464,41 +599,47 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
     if (ok) {   // rolloutLinearPolicy from dx0 = 0, dS / dY, computeMaxStepSizes (ipddp_solver.cpp:1511-1532, 2939-2988)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the gains were written through other lanes of this group
       const int N = a.N;
+      const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
       const double tau = dmax(a.tau_min, 1.0 - mu);
       SC_EACH(NX, i) L[C::oW + i] = 0.0;
       lds_sync();
-      for (int t = 0; t < N; ++t) {
-        SC_EACH(NX, i) a.dX[SI(t, NX, i)] = L[C::oW + i];
+      const int bpo = a.Bp;
+      SCRoll<NX, NU, M> cur, nxt;   // the rows a lane needs at a step do not depend on dx: fetched one step ahead
+      cur.load(a, 0, b, gl);
+      for (int t_ = 0; t_ < N; ++t_) {
+        if (t_ + 1 < N) nxt.load(a, t_ + 1, b, gl);
+        SC_EACH(NX, i) SC_G(a.dX, t_, NX, i) = L[C::oW + i];
         SC_EACH(M, r) {
           double p = 0.0, q = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) { const double dxj = L[C::oW + j]; p += a.Ks[SI(t, M * NX, r * NX + j)] * dxj; q += a.Ky[SI(t, M * NX, r * NX + j)] * dxj; }
-          const double ds = a.ks[SI(t, M, r)] + p;
-          const double dy = dclamp(a.ky[SI(t, M, r)] + q, -kMaxRatioS, kMaxRatioS);
-          if (ds < 0.0) apr = dmin(apr, -tau * a.s[SI(t, M, r)] / ds);
-          if (dy < 0.0) adu = dmin(adu, -tau * a.y[SI(t, M, r)] / dy);
+          for (int j = 0; j < NX; ++j) { const double dxj = L[C::oW + j]; p += cur.Ks[r_it][j] * dxj; q += cur.Ky[r_it][j] * dxj; }
+          const double ds = cur.ks[r_it] + p;
+          const double dy = dclamp(cur.ky[r_it] + q, -kMaxRatioS, kMaxRatioS);
+          if (ds < 0.0) apr = dmin(apr, -tau * cur.s[r_it] / ds);
+          if (dy < 0.0) adu = dmin(adu, -tau * cur.y[r_it] / dy);
         }
         SC_EACH(NU, i) {
           double p = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) p += a.K[SI(t, NU * NX, i * NX + j)] * L[C::oW + j];
-          L[C::oQu + i] = a.k[SI(t, NU, i)] + p;
+          for (int j = 0; j < NX; ++j) p += cur.K[i_it][j] * L[C::oW + j];
+          L[C::oQu + i] = cur.k[i_it] + p;
         }
         lds_sync();
         double dxn[(NX + 15) / 16];
         SC_EACH(NX, i) {
           double p = 0.0, q = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) p += a.fx[SI(t, NX * NX, i * NX + j)] * L[C::oW + j];
+          for (int j = 0; j < NX; ++j) p += cur.fx[i_it][j] * L[C::oW + j];
 #pragma unroll
-          for (int j = 0; j < NU; ++j) q += a.fu[SI(t, NX * NU, i * NU + j)] * L[C::oQu + j];
+          for (int j = 0; j < NU; ++j) q += cur.fu[i_it][j] * L[C::oQu + j];
           dxn[i_it] = (p + q) + 0.0;
         }
         lds_sync();
         SC_EACH(NX, i) L[C::oW + i] = dxn[i_it];
         lds_sync();
+        cur = nxt;
       }
-      SC_EACH(NX, i) a.dX[SI(N, NX, i)] = L[C::oW + i];
+      SC_EACH(NX, i) SC_G(a.dX, N, NX, i) = L[C::oW + i];
       L[C::oRed + gl] = apr; L[C::oRed + 16 + gl] = adu;
       lds_sync();
 #pragma unroll

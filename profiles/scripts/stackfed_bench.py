@@ -10,7 +10,7 @@ from conftest import load_api
 api = load_api()
 rng = np.random.default_rng(1)
 rows = []
-for (nx, nu, m, N, B) in ((4, 1, 2, 100, 4096), (3, 2, 5, 200, 8192), (12, 4, 8, 400, 2048)):
+for (nx, nu, m, N, B) in ((4, 1, 2, 100, 4096), (3, 2, 5, 200, 8192), (12, 4, 8, 400, 2048), (14, 7, 14, 150, 4096)):
     fx = np.tile(np.eye(nx), (B, N, 1, 1)) + 0.05 * rng.standard_normal((B, N, nx, nx)); fu = 0.1 * rng.standard_normal((B, N, nx, nu))
     lx = rng.standard_normal((B, N, nx)); lu = rng.standard_normal((B, N, nu))
     lxx = np.tile(np.eye(nx), (B, N, 1, 1)); luu = np.tile(np.eye(nu), (B, N, 1, 1)); lux = np.zeros((B, N, nu, nx))
@@ -29,18 +29,23 @@ for (nx, nu, m, N, B) in ((4, 1, 2, 100, 4096), (3, 2, 5, 200, 8192), (12, 4, 8,
             Gx = 0.1 * rng.standard_normal((B, N, mm, nx)); Gu = 0.3 * rng.standard_normal((B, N, mm, nu))
             hs.set_constraint_stacks(y, s, g, Gx, Gu); mu = np.full(B, 0.1)
         reg = np.full(B, 1e-6)
-        ms = []
-        for _ in range(4):
-            ok = hs.backward(branch, opt, reg, mu, retry=False); ms.append(hs.kernel_ms())
         dyn = nx * nx + nx * nu; cost = nx + nu + nx * nx + nu * nu + nu * nx; gain = nu * nx + nu; val = nx + nx * nx
         con = (3 * mm + mm * nx + mm * nu) + (2 * mm + 2 * mm * nx) if mm else 0
         bytes_ = 8.0 * B * (N * (dyn + cost + gain + val + con) + val)
-        t = min(ms[1:])
-        rows.append((nx, nu, mm, N, B, name, t, bytes_ / t / 1e6, int(ok.sum())))
-        print(rows[-1], flush=True)
+        for form in ("lane", "coop"):   # one lane per trajectory | sixteen lanes per trajectory (stacks_coop.hpp)
+            os.environ["CDDP_HIP_STACKS_SWEEP"] = form
+            ms = []
+            for _ in range(4):
+                ok = hs.backward(branch, opt, reg, mu, retry=False); ms.append(hs.kernel_ms())
+            if hs.sweep_form() != (1 if form == "coop" else 0):
+                continue   # this form is not instantiated for the shape
+            t = min(ms[1:])
+            rows.append((nx, nu, mm, N, B, name, form, t, bytes_ / t / 1e6, int(ok.sum())))
+            print(rows[-1], flush=True)
+        os.environ.pop("CDDP_HIP_STACKS_SWEEP", None)
         hs.close()
 with open(sys.argv[1], "w") as f:
-    f.write("# Stack-fed sweeps (host plug-in mode): kernel time per sweep of a whole batch, one lane per trajectory, MI355X, round 2\n\n")
+    f.write("# Stack-fed sweeps (host plug-in mode): kernel time per sweep of a whole batch, one-lane and lane-cooperative forms, MI355X, round 3\n\n")
     f.write("`python profiles/scripts/stackfed_bench.py`; hipEvent time of the single launch (`cddp_hip_stacks_last_kernel_ms`), best of 3; GB/s = the "
-            "backward class's algorithmic bytes of DESIGN.md section 4 over that time.\n\n| nx | nu | m | N | batch | branch | ms | GB/s | sweeps ok |\n|---|---|---|---|---|---|---|---|---|\n")
-    for r in rows: f.write("| %d | %d | %d | %d | %d | %s | %.3f | %.0f | %d |\n" % r)
+            "backward class's algorithmic bytes of DESIGN.md section 4 over that time.\n\n| nx | nu | m | N | batch | branch | form | ms | GB/s | sweeps ok |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    for r in rows: f.write("| %d | %d | %d | %d | %d | %s | %s | %.3f | %.0f | %d |\n" % r)
