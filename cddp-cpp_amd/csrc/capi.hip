@@ -278,6 +278,7 @@ void cddp_hip_default_options(cddp_hip_options *o) {
   o->barrier_mu_update_power = 1.2; o->barrier_min_fraction_to_boundary = 0.99; o->barrier_strategy = CDDP_HIP_BARRIER_ADAPTIVE;
   o->max_cpu_time = 0.0;
   o->logddp_mu_initial = 1.0; o->logddp_mu_min_value = 1e-10; o->logddp_mu_update_factor = 0.5; o->logddp_relaxed_delta = 1e-10;
+  o->msipddp_costate_var_init_scale = 1e-6; o->msipddp_segment_length = 5; o->msipddp_rollout_type = 0; o->msipddp_use_controlled_rollout = 0; o->_pad4 = 0;
 }
 
 int cddp_hip_abi_version(void) { return CDDP_HIP_ABI_VERSION; }

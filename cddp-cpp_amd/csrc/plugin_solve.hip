@@ -534,13 +534,461 @@ int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const do
   return 0;
 }
 
+
+// ---- MSIPDDP (msipddp_solver.cpp:33-1930): multiple-shooting interior-point DDP on the host loop ---------------------------------
+// The iterate carries costates and the dynamics values F_t = f(x_t, u_t); the defects d_t = F_t - x_{t+1} go to the GPU as a stack.
+// Backward pass: CDDP_HIP_STACKS_MSIPDDP with the per-step factor cache (no path constraints: the reference solves every sweep after
+// the first with the factor of the step's FIRST sweep, :1169-1185) or CDDP_HIP_STACKS_MSIPDDP_PATH (plain y / s condensation,
+// :1222-1420).  Forward pass with gap closing at the segment boundaries ("nonlinear" / "hybrid" / plain), filter, barrier update and
+// convergence tests on the host.  use_ilqr = false: the costate-weighted dynamics Hessians and the dual-weighted constraint
+// Hessians (:1151-1163, 1279-1310) are folded into the cost-Hessian stacks (last-bit association difference against the reference's
+// "Q += ..." after the A^T V A products; the tests hold that case to 1e-9, not to equality).
+struct MTraj {
+  std::vector<double> X, U, F, Lam, S, Y, G;
+  std::vector<std::pair<double, double>> filter;
+  double cost = kInf, merit = kInf, inf_pr = kInf, inf_du = kInf, inf_comp = kInf, step_norm = 0, alpha_pr = 1.0, alpha_du = 0.0, reg = 0, mu = 0;
+  double dV0 = 0, dV1 = 0;
+  int iter = 0, status = CDDP_HIP_STATUS_RUNNING, n_bwd = 0, n_fwd = 0;
+  bool done = false;
+};
+
+void ms_reset_filter(const Ctx &c, MTraj &t) {   // resetBarrierFilter :711-763
+  const int nx = c.nx, m = c.m, N = c.N;
+  double mf = t.cost, ipr = 0.0, fcv = 0.0, icomp = 0.0, idef = 0.0;
+  if (m > 0) {
+    for (int s = 0; s < N; ++s) {
+      int off = 0;
+      for (int q = 0; q < c.pl->n_constraints; ++q) {
+        const int dim = c.pl->constraint_dims[q];
+        double lsum = 0.0, l1 = 0.0;
+        for (int i = 0; i < dim; ++i) {
+          const size_t j = (size_t)s * m + off + i;
+          lsum += std::log(t.S[j]);
+          const double pr = t.G[j] + t.S[j];
+          ipr = std::max(ipr, std::fabs(pr)); l1 += std::fabs(pr);
+          icomp = std::max(icomp, std::fabs(t.Y[j] * t.S[j] - t.mu));
+        }
+        mf -= t.mu * lsum; fcv += l1; off += dim;
+      }
+      double dn = 0.0, d1 = 0.0;
+      for (int i = 0; i < nx; ++i) { const double d = t.F[(size_t)s * nx + i] - t.X[(size_t)(s + 1) * nx + i]; dn = std::max(dn, std::fabs(d)); d1 += std::fabs(d); }
+      idef = std::max(idef, dn); fcv += d1;
+    }
+  }
+  t.inf_pr = std::max(ipr, idef); t.merit = mf; t.inf_comp = icomp;
+  t.filter.clear(); t.filter.emplace_back(mf, fcv);
+}
+
+void ms_init_pair(const cddp_hip_options &o, double mu, const double *g, double *s, double *y, int m) {   // :578-596 == :667-685
+  for (int i = 0; i < m; ++i) {
+    s[i] = std::max(o.ipddp_slack_var_init_scale, -g[i]);
+    y[i] = (s[i] < 1e-12) ? mu / 1e-12 : mu / s[i];
+    y[i] = std::max(o.ipddp_dual_var_init_scale * 0.01, std::min(y[i], o.ipddp_dual_var_init_scale * 100.0));
+  }
+}
+
+double ms_scaled_inf_du(const Ctx &c, const MTraj &t) {   // computeScaledDualInfeasibility :1886-1930
+  if (c.m == 0) return t.inf_du;
+  double yn = 0.0, sn = 0.0;
+  int off = 0;
+  for (int q = 0; q < c.pl->n_constraints; ++q) {   // constraint-major, then t, as the reference's maps are walked
+    const int dim = c.pl->constraint_dims[q];
+    for (int s = 0; s < c.N; ++s) {
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < dim; ++i) { a += std::fabs(t.Y[(size_t)s * c.m + off + i]); b += std::fabs(t.S[(size_t)s * c.m + off + i]); }
+      yn += a; sn += b;
+    }
+    off += dim;
+  }
+  const int mpn = c.m * c.N + c.nu * c.N;
+  const double num = mpn > 0 ? (yn + sn) / (double)mpn : 0.0;
+  return t.inf_du / (std::max(100.0, num) / 100.0);
+}
+
+bool ms_filter_acceptable(const cddp_hip_options &o, const std::vector<std::pair<double, double>> &f, double mf, double cv, double expected) {   // :771-808
+  if (f.empty()) return true;
+  for (auto &p : f) if (p.first <= mf && p.second <= cv) return false;
+  double best_v = kInf, best_m = kInf;
+  for (auto &p : f) if (p.second < best_v) { best_v = p.second; best_m = p.first; }
+  const bool v_imp = cv < best_v * (1.0 - o.filter_violation_acceptance_threshold);
+  const bool m_imp = mf < best_m - o.filter_merit_acceptance_threshold * cv;
+  if (cv < o.filter_min_violation_for_armijo_check && expected < 0) return mf < best_m + o.filter_armijo_constant * expected;
+  if (cv < 1e-6 && mf <= best_m * (1.0 + 1e-8)) return true;
+  return v_imp || m_imp;
+}
+
+int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const double *U0, const double *X0, cddp_hip_result *results,
+                  double *Xout, double *Uout, double *Kout) {
+  const cddp_hip_plugin *pl = c.pl; const cddp_hip_options &o = *c.o;
+  const int nx = c.nx, nu = c.nu, m = c.m, N = c.N; const double dt = c.dt;
+  const size_t B = (size_t)batch;
+  if (m > 0 && !(nu == 1 || nx == nu))
+    return pfail(-3, "MSIPDDP with path constraints is only defined for nu = 1 or nx = nu: the reference adds an (nx x nu) product to its (nu x nx) block Q_ux (msipddp_solver.cpp:1398); got nx = %d, nu = %d", nx, nu);
+  if (o.msipddp_segment_length < 0) return pfail(-2, "MSIPDDP: ms_segment_length must be non-negative");
+  if (!o.use_ilqr && m > 0 && !pl->constraint_hessians) return pfail(-3, "MSIPDDP with use_ilqr=false needs the constraint Hessian callback");
+  cddp_hip_stack_handle *sh = nullptr;
+  { int rc = cddp_hip_stacks_create(device, batch, nx, nu, m, N, &sh); if (rc) return rc; }
+  struct Guard { cddp_hip_stack_handle *h; ~Guard() { if (h) cddp_hip_stacks_destroy(h); } } guard{sh};
+  if (m == 0) { int rc = cddp_hip_stacks_factor_cache(sh, 1); if (rc) return rc; }
+  const int seg = o.msipddp_segment_length, rtype = o.msipddp_rollout_type;
+  std::vector<double> alphas;
+  { double a = o.ls_initial_step_size; for (int i = 0; i < o.ls_max_iterations; ++i) { alphas.push_back(a); a *= o.ls_step_reduction_factor; } }
+
+  std::vector<MTraj> T(B);
+  std::vector<double> xn(nx);
+  for (size_t b = 0; b < B; ++b) {   // initialize :33-264
+    MTraj &t = T[b];
+    t.X.assign((size_t)(N + 1) * nx, 0.0); t.U.assign((size_t)N * nu, 0.0);
+    if (U0) std::copy(U0 + b * N * nu, U0 + (b + 1) * N * nu, t.U.begin());
+    if (X0) std::copy(X0 + b * (N + 1) * nx, X0 + (b + 1) * (N + 1) * nx, t.X.begin());
+    else for (int s = 0; s <= N; ++s) std::copy(x0 + b * nx, x0 + (b + 1) * nx, t.X.begin() + (size_t)s * nx);
+    std::copy(x0 + b * nx, x0 + (b + 1) * nx, t.X.begin());
+    t.F.assign((size_t)N * nx, 0.0); t.Lam.assign((size_t)N * nx, o.msipddp_costate_var_init_scale);
+    t.S.assign((size_t)N * m, 0.0); t.Y = t.S; t.G = t.S;
+    t.alpha_pr = o.ls_initial_step_size; t.alpha_du = 0.0; t.reg = o.reg_initial_value; t.step_norm = 0.0;
+    if (o.warm_start) {   // no gains of an earlier solve in this call: the branch :108-160 -- the state guess is kept as it is
+      if (m == 0) t.mu = 1e-8;
+      else {
+        double cost = 0.0, mv = 0.0;   // evaluateTrajectoryWarmStart :457-495
+        for (int s = 0; s < N; ++s) {
+          double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+          cost += pl->running_cost(pl->user, x, u, s);
+          pl->constraints(pl->user, x, u, s, t.G.data() + (size_t)s * m, nullptr, nullptr);
+          pl->discrete_dynamics(pl->user, x, u, s * dt, t.F.data() + (size_t)s * nx);
+          if (o.msipddp_use_controlled_rollout) std::copy(t.F.begin() + (size_t)s * nx, t.F.begin() + (size_t)(s + 1) * nx, t.X.begin() + (size_t)(s + 1) * nx);
+        }
+        cost += pl->terminal_cost(pl->user, t.X.data() + (size_t)N * nx);
+        t.cost = cost;
+        for (double g : t.G) mv = std::max(mv, g);   // detail::computeMaxConstraintViolation (interior_point_utils.cpp:141-155)
+        t.mu = (mv <= o.tolerance) ? o.tolerance * 0.01 : (mv <= 0.1) ? o.tolerance : o.barrier_mu_initial * 0.1;
+        for (int s = 0; s < N; ++s) ms_init_pair(o, t.mu, t.G.data() + (size_t)s * m, t.S.data() + (size_t)s * m, t.Y.data() + (size_t)s * m, m);
+      }
+      ms_reset_filter(c, t);
+      continue;
+    }
+    t.mu = (m == 0) ? 1e-8 : o.barrier_mu_initial;   // cold start :199-263
+    for (int s = 0; s < N && m > 0; ++s) {           // initializeDualSlackCostateVariables, on the GUESS trajectory
+      pl->constraints(pl->user, t.X.data() + (size_t)s * nx, t.U.data() + (size_t)s * nu, s, t.G.data() + (size_t)s * m, nullptr, nullptr);
+      ms_init_pair(o, t.mu, t.G.data() + (size_t)s * m, t.S.data() + (size_t)s * m, t.Y.data() + (size_t)s * m, m);
+    }
+    double cost = 0.0;                               // evaluateTrajectory :425-455
+    for (int s = 0; s < N; ++s) {
+      double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+      cost += pl->running_cost(pl->user, x, u, s);
+      if (m > 0) pl->constraints(pl->user, x, u, s, t.G.data() + (size_t)s * m, nullptr, nullptr);
+      pl->discrete_dynamics(pl->user, x, u, s * dt, t.F.data() + (size_t)s * nx);
+      std::copy(t.F.begin() + (size_t)s * nx, t.F.begin() + (size_t)(s + 1) * nx, t.X.begin() + (size_t)(s + 1) * nx);
+    }
+    cost += pl->terminal_cost(pl->user, t.X.data() + (size_t)N * nx);
+    t.cost = cost;
+    ms_reset_filter(c, t);
+  }
+
+  std::vector<double> fx(B * N * nx * nx), fu(B * N * nx * nu), lx(B * N * nx), lu(B * N * nu), lxx(B * N * nx * nx), luu(B * N * nu * nu),
+      lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx), dfc(B * N * nx);
+  std::vector<double> ys(B * N * m), ss(B * N * m), gs(B * N * m), Gxs(B * N * m * nx), Gus(B * N * m * nu);
+  std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  std::vector<double> kyb(B * N * m), Kyb(B * N * m * nx), ksb(B * N * m), Ksb(B * N * m * nx), dXb(m > 0 ? B * (N + 1) * nx : 0);
+  std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
+  std::vector<int32_t> okv(B);
+  std::vector<double> tfx(nx * nx), tfu(nx * nu), Hxx, Huu, Hux, Cxx, Cuu, Cux, gtmp(std::max(m, 1));
+  if (!o.use_ilqr) {
+    Hxx.resize((size_t)nx * nx * nx); Huu.resize((size_t)nx * nu * nu); Hux.resize((size_t)nx * nu * nx);
+    if (m > 0) { Cxx.resize((size_t)m * nx * nx); Cuu.resize((size_t)m * nu * nu); Cux.resize((size_t)m * nu * nx); }
+  }
+  std::vector<double> kl((size_t)N * nx), Kl((size_t)N * nx * nx), dxs((size_t)N * nx), Xn, Un, Fn, Ln, Sn, Yn, Gn, Yt, ynew(std::max(m, 1)), snew(std::max(m, 1));
+  std::vector<double> Abuf((size_t)nx * nx), Bbuf((size_t)nx * nu), tmpx(nx);
+  const bool first_rule = !o.enable_parallel;
+  const auto wall0 = std::chrono::steady_clock::now();
+
+  for (int it = 1; it <= o.max_iterations; ++it) {
+    bool any = false;
+    for (auto &t : T) any = any || !t.done;
+    if (!any) break;
+    if (o.max_cpu_time > 0.0) {
+      const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
+      if (el_ms > o.max_cpu_time * 1000.0) { for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; } break; }
+    }
+    // ---- derivative stacks of every running iterate (precomputeDynamicsDerivatives / precomputeConstraintGradients :846-1110)
+    for (size_t b = 0; b < B; ++b) {
+      MTraj &t = T[b];
+      regv[b] = t.done ? std::max(t.reg, o.reg_min_value) : t.reg;
+      muv[b] = (t.mu > 0.0) ? t.mu : 1e-8;
+      if (t.done) continue;
+      t.iter += 1;
+      for (int s = 0; s < N; ++s) {
+        const double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+        const size_t bs = b * N + s;
+        for (int i = 0; i < nx; ++i) dfc[bs * nx + i] = t.F[(size_t)s * nx + i] - t.X[(size_t)(s + 1) * nx + i];
+        pl->jacobians(pl->user, x, u, s * dt, tfx.data(), tfu.data());
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double a = dt * tfx[i * nx + j]; if (i == j) a += 1.0; fx[(bs * nx + i) * nx + j] = a; }
+        for (int i = 0; i < nx * nu; ++i) fu[bs * nx * nu + i] = dt * tfu[i];
+        double *plxx = lxx.data() + bs * nx * nx, *pluu = luu.data() + bs * nu * nu, *plux = lux.data() + bs * nu * nx;
+        pl->running_cost_derivatives(pl->user, x, u, s, lx.data() + bs * nx, lu.data() + bs * nu, plxx, pluu, plux);
+        if (m > 0) {
+          std::copy(t.Y.begin() + (size_t)s * m, t.Y.begin() + (size_t)(s + 1) * m, ys.begin() + bs * m);
+          std::copy(t.S.begin() + (size_t)s * m, t.S.begin() + (size_t)(s + 1) * m, ss.begin() + bs * m);
+          std::copy(t.G.begin() + (size_t)s * m, t.G.begin() + (size_t)(s + 1) * m, gs.begin() + bs * m);
+          pl->constraints(pl->user, x, u, s, gtmp.data(), Gxs.data() + bs * m * nx, Gus.data() + bs * m * nu);
+        }
+        if (!o.use_ilqr) {   // :1151-1163, 1279-1310, folded into the cost Hessians
+          pl->hessians(pl->user, x, u, s * dt, Hxx.data(), Huu.data(), Hux.data());
+          for (int i = 0; i < nx; ++i) {
+            const double w = dt * t.Lam[(size_t)s * nx + i];
+            for (int e = 0; e < nx * nx; ++e) plxx[e] += w * Hxx[(size_t)i * nx * nx + e];
+            for (int e = 0; e < nu * nx; ++e) plux[e] += w * Hux[(size_t)i * nu * nx + e];
+            for (int e = 0; e < nu * nu; ++e) pluu[e] += w * Huu[(size_t)i * nu * nu + e];
+          }
+          if (m > 0) {
+            std::fill(Cxx.begin(), Cxx.end(), 0.0); std::fill(Cuu.begin(), Cuu.end(), 0.0); std::fill(Cux.begin(), Cux.end(), 0.0);
+            pl->constraint_hessians(pl->user, x, u, s, Cxx.data(), Cuu.data(), Cux.data());
+            for (int r = 0; r < m; ++r) {
+              const double w = t.Y[(size_t)s * m + r];
+              for (int e = 0; e < nx * nx; ++e) plxx[e] += w * Cxx[(size_t)r * nx * nx + e];
+              for (int e = 0; e < nu * nx; ++e) plux[e] += w * Cux[(size_t)r * nu * nx + e];
+              for (int e = 0; e < nu * nu; ++e) pluu[e] += w * Cuu[(size_t)r * nu * nu + e];
+            }
+          }
+        }
+      }
+      pl->terminal_cost_derivatives(pl->user, t.X.data() + (size_t)N * nx, VxN.data() + b * nx, VxxN.data() + b * nx * nx);
+    }
+    { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
+    { int rc = cddp_hip_set_defect_stack(sh, dfc.data()); if (rc) return rc; }
+    if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, ys.data(), ss.data(), gs.data(), Gxs.data(), Gus.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_backward(sh, m > 0 ? CDDP_HIP_STACKS_MSIPDDP_PATH : CDDP_HIP_STACKS_MSIPDDP, c.o, regv.data(), m > 0 ? muv.data() : nullptr, 1, okv.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
+
+    for (size_t b = 0; b < B; ++b) {
+      MTraj &t = T[b];
+      if (t.done) continue;
+      { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
+        if (!okv[b] && nb > 1) --nb;
+        t.n_bwd += nb; }
+      t.reg = s_reg[b];
+      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; continue; }   // handleBackwardPassRegularizationLimit (base)
+      t.dV0 = dVb[b * 2]; t.dV1 = dVb[b * 2 + 1]; t.inf_du = s_du[b]; t.step_norm = s_sn[b];
+      double idef = 0.0;
+      for (size_t e = 0; e < (size_t)N * nx; ++e) idef = std::max(idef, std::fabs(dfc[b * N * nx + e]));
+      if (m > 0) { t.inf_pr = std::max(s_pr[b], idef); t.inf_comp = s_comp[b]; } else { t.inf_pr = idef; t.inf_comp = 0.0; }
+      const double *K = Kb.data() + b * N * nu * nx, *k = kb.data() + b * N * nu, *Vx = Vxb.data() + b * (N + 1) * nx, *Vxx = Vxxb.data() + b * (N + 1) * nx * nx;
+      const double *ky = kyb.data() + b * N * m, *Ky = Kyb.data() + b * N * m * nx, *ks = ksb.data() + b * N * m, *Ks = Ksb.data() + b * N * m * nx;
+      for (int s = 0; s < N; ++s) {   // k_lambda = -lambda + V_x + V_xx d, K_lambda = sym(V_xx) of step s + 1 (:1196-1198)
+        const double *vx = Vx + (size_t)(s + 1) * nx, *vxx = Vxx + (size_t)(s + 1) * nx * nx, *d = dfc.data() + (b * N + s) * nx;
+        for (int i = 0; i < nx; ++i) {
+          double acc = 0.0;
+          for (int j = 0; j < nx; ++j) acc += vxx[i * nx + j] * d[j];
+          kl[(size_t)s * nx + i] = (-t.Lam[(size_t)s * nx + i] + vx[i]) + acc;
+          for (int j = 0; j < nx; ++j) Kl[((size_t)s * nx + i) * nx + j] = 0.5 * (vxx[i * nx + j] + vxx[j * nx + i]);
+        }
+      }
+      const double tau = std::max(o.barrier_min_fraction_to_boundary, 1.0 - t.mu);
+      // ---- performForwardPass over forwardPass(alpha) :1432-1724
+      bool have = false; int walked = 0;
+      double b_cost = 0, b_merit = kInf, b_cv = 0, b_alpha = 0, b_adu = 1.0;
+      std::vector<double> bX, bU, bF, bL, bS, bY, bG;
+      for (double a : alphas) {
+        ++walked;
+        Xn = t.X; Un = t.U; Fn = t.F; Ln = t.Lam; Sn = t.S;
+        std::copy(x0 + b * nx, x0 + (b + 1) * nx, Xn.begin());
+        bool s_ok = true;
+        double cost_new = 0.0;
+        for (int s = 0; s < N && s_ok; ++s) {
+          const double *xs = Xn.data() + (size_t)s * nx, *xo = t.X.data() + (size_t)s * nx;
+          double *dx = dxs.data() + (size_t)s * nx;
+          for (int i = 0; i < nx; ++i) dx[i] = xs[i] - xo[i];
+          if (m > 0) {
+            for (int r = 0; r < m; ++r) {
+              double acc = 0.0;
+              for (int j = 0; j < nx; ++j) acc += Ks[((size_t)s * m + r) * nx + j] * dx[j];
+              snew[r] = (t.S[(size_t)s * m + r] + a * ks[(size_t)s * m + r]) + acc;
+              if (snew[r] < (1.0 - tau) * t.S[(size_t)s * m + r]) { s_ok = false; break; }
+            }
+            if (!s_ok) break;
+            std::copy(snew.begin(), snew.begin() + m, Sn.begin() + (size_t)s * m);
+          }
+          double *us = Un.data() + (size_t)s * nu;
+          for (int i = 0; i < nu; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += K[((size_t)s * nu + i) * nx + j] * dx[j];
+            us[i] = (t.U[(size_t)s * nu + i] + a * k[(size_t)s * nu + i]) + acc;
+          }
+          if (m == 0) {
+            for (int i = 0; i < nx; ++i) {
+              double acc = 0.0;
+              for (int j = 0; j < nx; ++j) acc += Kl[((size_t)s * nx + i) * nx + j] * dx[j];
+              Ln[(size_t)s * nx + i] = (t.Lam[(size_t)s * nx + i] + a * kl[(size_t)s * nx + i]) + acc;
+            }
+          }
+          double *fn = Fn.data() + (size_t)s * nx, *xnext = Xn.data() + (size_t)(s + 1) * nx;
+          pl->discrete_dynamics(pl->user, xs, us, s * dt, fn);
+          const bool boundary = (seg > 1) && ((s + 1) % seg == 0) && (s + 1 < N);
+          const double *fo = t.F.data() + (size_t)s * nx, *xon = t.X.data() + (size_t)(s + 1) * nx;
+          if (boundary && rtype == 0) {
+            for (int i = 0; i < nx; ++i) xnext[i] = (xon[i] + (fn[i] - fo[i])) + a * (fo[i] - xon[i]);
+          } else if (boundary && rtype == 2) {
+            pl->jacobians(pl->user, xo, t.U.data() + (size_t)s * nu, s * dt, tfx.data(), tfu.data());
+            for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double v = dt * tfx[i * nx + j]; if (i == j) v = 1.0 + v; Abuf[i * nx + j] = v; }
+            for (int i = 0; i < nx * nu; ++i) Bbuf[i] = dt * tfu[i];
+            for (int i = 0; i < nx; ++i) {
+              double p1 = 0.0;   // ((A + B K) dx)_i
+              for (int j = 0; j < nx; ++j) {
+                double bk = 0.0;
+                for (int q = 0; q < nu; ++q) bk += Bbuf[i * nu + q] * K[((size_t)s * nu + q) * nx + j];
+                p1 += (Abuf[i * nx + j] + bk) * dx[j];
+              }
+              double p2 = 0.0;   // (B k)_i
+              for (int q = 0; q < nu; ++q) p2 += Bbuf[i * nu + q] * k[(size_t)s * nu + q];
+              xnext[i] = (xon[i] + p1) + a * ((p2 + fo[i]) - xon[i]);
+            }
+          } else {
+            for (int i = 0; i < nx; ++i) xnext[i] = fn[i];
+          }
+          if (m == 0) cost_new += pl->running_cost(pl->user, xs, us, s);
+        }
+        if (!s_ok) continue;
+        if (m == 0) {
+          cost_new += pl->terminal_cost(pl->user, Xn.data() + (size_t)N * nx);
+          const double dJ = t.cost - cost_new;
+          const double expected = -a * (t.dV0 + 0.5 * a * t.dV1);
+          const double ratio = expected > 0.0 ? dJ / expected : std::copysign(1.0, dJ);
+          if (!(ratio > 1e-6)) continue;
+          if (first_rule || !have || cost_new < b_merit) { bX = Xn; bU = Un; bF = Fn; bL = Ln; b_cost = cost_new; b_merit = cost_new; b_cv = 0.0; b_alpha = a; b_adu = 1.0; have = true; }
+          if (first_rule) break;
+          continue;
+        }
+        bool found = false; double adu = 1.0;
+        for (double ay : alphas) {   // dual step: the first ladder entry that keeps every y above (1 - tau) y_old
+          bool feas = true;
+          Yt = t.Y;
+          for (int s = 0; s < N && feas; ++s) {
+            const double *dx = dxs.data() + (size_t)s * nx;
+            for (int r = 0; r < m; ++r) {
+              double acc = 0.0;
+              for (int j = 0; j < nx; ++j) acc += Ky[((size_t)s * m + r) * nx + j] * dx[j];
+              ynew[r] = (t.Y[(size_t)s * m + r] + ay * ky[(size_t)s * m + r]) + acc;
+            }
+            int off = 0;
+            for (int q = 0; q < pl->n_constraints && feas; ++q) {   // a constraint's block is stored only when ALL its rows pass
+              const int dim = pl->constraint_dims[q];
+              for (int i = 0; i < dim; ++i) if (ynew[off + i] < (1.0 - tau) * t.Y[(size_t)s * m + off + i]) { feas = false; break; }
+              if (feas) std::copy(ynew.begin() + off, ynew.begin() + off + dim, Yt.begin() + (size_t)s * m + off);
+              off += dim;
+            }
+          }
+          if (feas) { found = true; adu = ay; break; }
+        }
+        if (!found) continue;
+        for (int s = 0; s < N; ++s) {
+          const double *dx = dxs.data() + (size_t)s * nx;
+          for (int i = 0; i < nx; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += Kl[((size_t)s * nx + i) * nx + j] * dx[j];
+            Ln[(size_t)s * nx + i] = (t.Lam[(size_t)s * nx + i] + a * kl[(size_t)s * nx + i]) + acc;
+          }
+        }
+        Gn = t.G;
+        double merit_new = 0.0, cv_new = 0.0;
+        for (int s = 0; s < N; ++s) {
+          const double *xs = Xn.data() + (size_t)s * nx, *us = Un.data() + (size_t)s * nu;
+          cost_new += pl->running_cost(pl->user, xs, us, s);
+          pl->constraints(pl->user, xs, us, s, Gn.data() + (size_t)s * m, nullptr, nullptr);
+          int off = 0;
+          for (int q = 0; q < pl->n_constraints; ++q) {
+            const int dim = pl->constraint_dims[q];
+            double lsum = 0.0, l1 = 0.0;
+            for (int i = 0; i < dim; ++i) { const size_t j = (size_t)s * m + off + i; lsum += std::log(Sn[j]); l1 += std::fabs(Gn[j] + Sn[j]); }
+            merit_new -= t.mu * lsum; cv_new += l1; off += dim;
+          }
+          double d1 = 0.0;
+          for (int i = 0; i < nx; ++i) d1 += std::fabs(Fn[(size_t)s * nx + i] - Xn[(size_t)(s + 1) * nx + i]);
+          cv_new += d1;
+        }
+        cost_new += pl->terminal_cost(pl->user, Xn.data() + (size_t)N * nx);
+        merit_new += cost_new;
+        if (!ms_filter_acceptable(o, t.filter, merit_new, cv_new, a * t.dV0)) continue;
+        if (first_rule || !have || merit_new < b_merit) { bX = Xn; bU = Un; bF = Fn; bL = Ln; bS = Sn; bY = Yt; bG = Gn; b_cost = cost_new; b_merit = merit_new; b_cv = cv_new; b_alpha = a; b_adu = adu; have = true; }
+        if (first_rule) break;
+      }
+      t.n_fwd += first_rule ? walked : (int)alphas.size();
+      bool converged = false;
+      if (have) {   // applyForwardPassResult :287-304, decreaseRegularization, checkConvergence :306-364
+        const double dJ = t.cost - b_cost;
+        t.X.swap(bX); t.U.swap(bU); t.F.swap(bF); t.Lam.swap(bL);
+        if (m > 0) { t.S.swap(bS); t.Y.swap(bY); t.G.swap(bG); }
+        t.cost = b_cost; t.merit = b_merit; t.alpha_pr = b_alpha; t.alpha_du = b_adu;
+        filter_accept(t.filter, b_merit, b_cv);
+        t.reg = reg_decrease(o, t.reg);
+        const double metric = std::max(std::max(ms_scaled_inf_du(c, t), t.inf_pr), t.inf_comp);
+        if (metric <= o.tolerance) { t.status = CDDP_HIP_STATUS_OPTIMAL; converged = true; }
+        else if (std::fabs(dJ) < o.acceptable_tolerance && it > 10 && t.inf_pr < std::sqrt(o.acceptable_tolerance) && t.inf_comp < std::sqrt(o.acceptable_tolerance)) { t.status = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }
+        else if (it >= 1 && t.step_norm < o.tolerance * 10.0 && t.inf_pr < 1e-4) { t.status = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }
+      } else {      // handleForwardPassFailure :371-398
+        bool needs = t.filter.size() > 5;
+        if (!needs) for (auto &p : t.filter) if (!fin(p.first) || !fin(p.second)) { needs = true; break; }
+        if (needs && !t.filter.empty()) filter_prune(t.filter);
+        else {
+          t.reg = reg_increase(o, t.reg);
+          if (t.reg >= o.reg_max_value) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; continue; }
+        }
+      }
+      if (converged) { t.done = true; continue; }
+      if (m > 0) {   // postIterationUpdate -> updateBarrierParameters :1751-1850
+        if (o.barrier_strategy == CDDP_HIP_BARRIER_MONOTONIC) {
+          t.mu = std::max(o.barrier_mu_min_value, o.barrier_mu_update_factor * t.mu); ms_reset_filter(c, t);
+        } else if (o.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
+          const double err = std::max(std::max(ms_scaled_inf_du(c, t), t.inf_pr), t.inf_comp);
+          if (err <= 10.0 * t.mu) {
+            t.mu = std::max(o.tolerance / 10.0, std::min(o.barrier_mu_update_factor * t.mu, std::pow(t.mu, o.barrier_mu_update_power)));
+            ms_reset_filter(c, t);
+          }
+        } else {
+          const double metric = std::max(std::max(ms_scaled_inf_du(c, t), t.inf_pr), t.inf_comp);
+          const double thr = (t.mu < 1e-5) ? std::max(metric * 10.0, t.mu * 100.0) : std::max(o.barrier_mu_update_factor * t.mu, t.mu * 2.0);
+          const bool slow = have && t.alpha_pr > 0 && (metric < 1e-3);
+          if (metric <= thr || slow) {
+            double fac = o.barrier_mu_update_factor;
+            if (t.mu > 1e-12) {
+              const double ratio = metric / t.mu;
+              if (ratio < 0.01) fac = o.barrier_mu_update_factor * 0.1;
+              else if (ratio < 0.1) fac = o.barrier_mu_update_factor * 0.3;
+              else if (ratio < 0.5) fac = o.barrier_mu_update_factor * 0.6;
+            }
+            const double lin = fac * t.mu, sup = std::pow(t.mu, o.barrier_mu_update_power);
+            if (slow && t.mu > o.tolerance) t.mu = std::min(lin, sup);
+            else t.mu = std::max(o.tolerance / 100.0, std::min(lin, sup));
+            ms_reset_filter(c, t);
+          }
+        }
+      }
+      if (it == o.max_iterations) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+    }
+  }
+  for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  for (size_t b = 0; b < B; ++b) {   // CDDPSolution + populateSolverSpecificSolution :406-413
+    const MTraj &t = T[b];
+    cddp_hip_result &r = results[b];
+    std::memset(&r, 0, sizeof(r));
+    r.final_objective = t.cost; r.merit_function = t.merit; r.inf_pr = t.inf_pr; r.inf_du = t.inf_du; r.inf_comp = t.inf_comp;
+    r.barrier_mu = t.mu; r.regularization = t.reg; r.alpha_pr = t.alpha_pr; r.alpha_du = t.alpha_du;
+    r.iterations = t.iter; r.status = t.status; r.n_backward = t.n_bwd; r.n_forward = t.n_fwd;
+    if (Xout) std::copy(t.X.begin(), t.X.end(), Xout + b * (N + 1) * nx);
+    if (Uout) std::copy(t.U.begin(), t.U.end(), Uout + b * N * nu);
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int horizon, double dt, const cddp_hip_options *opt,
                                      int device, int batch, const double *x0, const double *U0, const double *X0,
                                      cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
   if (!pl || !opt || !x0 || !results) return pfail(-1, "null argument");
-  if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP && solver != CDDP_HIP_SOLVER_LOGDDP) return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
+  if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP && solver != CDDP_HIP_SOLVER_LOGDDP && solver != CDDP_HIP_SOLVER_MSIPDDP)
+    return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
   if (!pl->discrete_dynamics || !pl->jacobians) return pfail(-2, "Dynamical system must be set before solving.");
   if (!pl->running_cost || !pl->terminal_cost || !pl->running_cost_derivatives || !pl->terminal_cost_derivatives)
     return pfail(-2, "Objective function must be set before solving.");
@@ -558,6 +1006,7 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   { double al[CDDP_HIP_MAX_ALPHAS]; const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS); c.alphas.assign(al, al + na); }
   const cddp_hip_options &o = *opt;
   if (solver == CDDP_HIP_SOLVER_LOGDDP) return logddp_solve(c, device, batch, x0, U0, results, Xout, Uout, Kout);
+  if (solver == CDDP_HIP_SOLVER_MSIPDDP) return msipddp_solve(c, device, batch, x0, U0, X0, results, Xout, Uout, Kout);
 
   cddp_hip_stack_handle *sh = nullptr;
   { int rc = cddp_hip_stacks_create(device, batch, nx, nu, m, N, &sh); if (rc) return rc; }

@@ -43,6 +43,8 @@ struct StackArgs {
   const double *y, *s, *g, *Gx, *Gu;           // path-constraint stacks (branch IPDDP_PATH)
   const double *Fxx, *Fuu, *Fux;               // dt-scaled dynamics Hessian tensors (full DDP, use_ilqr = false); NULL = Gauss-Newton
   const double *dfc;                           // MSIPDDP defects d_t [N][nx]
+  double *QuuF;                                // MSIPDDP factor cache [N][nu*nu] (cddp_hip_stacks_factor_cache), or NULL
+  int *fvalid;                                 // [N][Bp] 1 = step t has a cached matrix
   const double *U, *lo, *up;                   // CLDDP control box (clddp_solver.cpp:147-178): current controls [N][nu], bounds [nu]; lo = NULL: none
   cddp_hip_options opt;                        // BoxQP parameters
   double *K, *k, *Vx, *Vxx, *dV;
@@ -64,7 +66,8 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
   constexpr int MM = M > 0 ? M : 1;
   const int N = a.N;
   const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
-  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP;          // = unconstrained IPDDP + defects
+  const bool msp = a.branch == CDDP_HIP_STACKS_MSIPDDP_PATH;    // MSIPDDP's condensation (plain ratios) + defects
+  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP || msp;   // defects enter Q_x, Q_u
   const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP && !lg;
   double Vx[NX], Vxx[NX * NX];
 #pragma unroll
@@ -176,12 +179,12 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
       const double s_floor = dmax(mu * 1e-3, kEpsSlackS);
 #pragma unroll
       for (int r = 0; r < M; ++r) {
-        ssafe[r] = dmax(s[r], s_floor);
-        YS[r] = clipp(y[r], ssafe[r]);
+        ssafe[r] = msp ? s[r] : dmax(s[r], s_floor);
+        YS[r] = msp ? y[r] / s[r] : clipp(y[r], ssafe[r]);       // msipddp_solver.cpp:1312-1316: YSinv(i, i) = y(i) / s(i)
         rp[r] = g[r] + s[r];
         const double rc = y[r] * s[r] - mu;
         rhat[r] = y[r] * rp[r] - rc;
-        Sir[r] = clips(rhat[r], ssafe[r]);
+        Sir[r] = msp ? rhat[r] / s[r] : clips(rhat[r], ssafe[r]);
         inf_pr = dmax(inf_pr, fabs(rp[r])); inf_comp = dmax(inf_comp, fabs(rc));
       }
       // Q_uu_reg = sym(Q_uu) + Q_yu^T YS Q_yu + reg I ; rhs = [Q_u + Q_yu^T S^-1 rhat | Q_ux + Q_yu^T YS Q_yx]   (:1424-1448)
@@ -239,7 +242,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
         double temp = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; ++i) temp += Gu[r * NU + i] * kk[i];
-        a.ky[SI(t, M, r)] = clips(rhat[r] + y[r] * temp, ssafe[r]);
+        a.ky[SI(t, M, r)] = msp ? (rhat[r] + y[r] * temp) / s[r] : clips(rhat[r] + y[r] * temp, ssafe[r]);
         a.ks[SI(t, M, r)] = (-rp[r]) - temp;
 #pragma unroll
         for (int c = 0; c < NX; ++c) {
@@ -247,7 +250,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
 #pragma unroll
           for (int i = 0; i < NU; ++i) s2 += Gu[r * NU + i] * KK[i * NX + c];
           const double inner = Gx[r * NX + c] + s2;
-          a.Ky[SI(t, M * NX, r * NX + c)] = dclamp(YS[r] * inner, -kMaxRatioS, kMaxRatioS);
+          a.Ky[SI(t, M * NX, r * NX + c)] = msp ? YS[r] * inner : dclamp(YS[r] * inner, -kMaxRatioS, kMaxRatioS);
           a.Ks[SI(t, M * NX, r * NX + c)] = (-Gx[r * NX + c]) - s2;
         }
       }
@@ -266,8 +269,22 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
 #pragma unroll
           for (int r = 0; r < M; ++r) s1 += (Gx[r * NX + i] * YS[r]) * Gx[r * NX + c];
           Qxx[i * NX + c] = Qxx[i * NX + c] + s1; }
+      if (msp) {   // msipddp_solver.cpp:1398: Q_ux += Q_yx^T YS^-1 Q_yu, an (nx x nu) product on the (nu x nx) block: the transpose for
+                   // nu = 1 (same linear layout), elementwise for nx = nu; the entry point refuses every other shape
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) {
+            const int pi = (NU == 1) ? c : i, pc = (NU == 1) ? 0 : c;   // entry (pi, pc) of the product
+            double s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) s1 += (Gx[r * NX + pi] * YS[r]) * Gu[r * NU + (pc < NU ? pc : 0)];
+            Qux[i * NX + c] = Qux[i * NX + c] + s1;
+          }
+      } else {
 #pragma unroll
       for (int i = 0; i < NU * NX; ++i) Qux[i] = rhs_x[i];
+      }
 #pragma unroll
       for (int i = 0; i < NU; ++i)
 #pragma unroll
@@ -286,14 +303,29 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
       for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];
 #pragma unroll
       for (int i = 0; i < NU; ++i) Quu[i * NU + i] += reg;
-      if (NU == 1) {
-        kk[0] = -ldlt1_solve(Quu[0], Qu[0]);
+      double Qf[NU * NU];   // the matrix that is factored: this sweep's, or the cached one of the step (MSIPDDP, msipddp_solver.cpp:1169-1185)
 #pragma unroll
-        for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Quu[0], Qux[c]);
+      for (int i = 0; i < NU * NU; ++i) Qf[i] = Quu[i];
+      const bool caching = ms && a.QuuF != nullptr;
+      const bool cached = caching && a.fvalid[(size_t)t * a.Bp + b] != 0;
+      if (cached) {
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Qf[i] = a.QuuF[SI(t, NU * NU, i)];
+      }
+      if (NU == 1) {
+        if (caching && !cached) { a.QuuF[SI(t, 1, 0)] = Qf[0]; a.fvalid[(size_t)t * a.Bp + b] = 1; }
+        kk[0] = -ldlt1_solve(Qf[0], Qu[0]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) KK[c] = -ldlt1_solve(Qf[0], Qux[c]);
       } else {
         LDLTd<NU> f;
-        f.compute(Quu, NU);
-        if (!f.ok) return false;
+        f.compute(Qf, NU);
+        if (!f.ok) { if (caching) a.fvalid[(size_t)t * a.Bp + b] = 0; return false; }
+        if (caching && !cached) {
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) a.QuuF[SI(t, NU * NU, i)] = Qf[i];
+          a.fvalid[(size_t)t * a.Bp + b] = 1;
+        }
         double col[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) col[i] = Qu[i];
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(64) void k_stacks_backward(StackArgs a) {
   a.scal[(size_t)3 * a.Bp + b] = inf_comp; a.scal[(size_t)4 * a.Bp + b] = step_norm;
   double apr = 1.0, adu = 1.0;
   if constexpr (M > 0) {
-    if (ok) {   // rolloutLinearPolicy from dx0 = 0 (:1511-1520), dS / dY (:1522-1532), computeMaxStepSizes (:2939-2988)
+    if (ok && a.branch != CDDP_HIP_STACKS_MSIPDDP_PATH) {   // rolloutLinearPolicy from dx0 = 0 (:1511-1520), dS / dY (:1522-1532), computeMaxStepSizes (:2939-2988)
       const int N = a.N;
       const double tau = dmax(a.tau_min, 1.0 - mu);
       double dx[NX];
@@ -592,6 +624,8 @@ struct cddp_hip_stack_handle {
   double *d_Fxx = nullptr, *d_Fuu = nullptr, *d_Fux = nullptr;   // allocated by the first cddp_hip_set_hessian_stacks
   double *d_U = nullptr, *d_lo = nullptr, *d_up = nullptr;      // allocated by the first cddp_hip_set_control_box
   double *d_dfc = nullptr;                                      // allocated by the first cddp_hip_set_defect_stack
+  double *d_QuuF = nullptr; int *d_fvalid = nullptr;            // allocated by the first cddp_hip_stacks_factor_cache(h, 1)
+  bool factor_cache = false;
   bool have_dyn = false, have_con = false, swept = false;
   double last_ms = 0.0;
   std::vector<double> tmp;
@@ -695,6 +729,21 @@ int cddp_hip_set_defect_stack(cddp_hip_stack_handle *h, const double *defects) {
   return 0;
 }
 
+int cddp_hip_stacks_factor_cache(cddp_hip_stack_handle *h, int enable) {
+  if (!h) return sfail(-1, "null handle");
+  SCHK(hipSetDevice(h->device));
+  if (!enable) { h->factor_cache = false; return 0; }
+  const size_t nq = (size_t)h->N * h->nu * h->nu * h->Bp, nv = (size_t)h->N * h->Bp;
+  if (!h->d_QuuF) {
+    int rc = salloc(h, &h->d_QuuF, nq); if (rc) return rc;
+    void *q = nullptr; SCHK(hipMalloc(&q, nv * sizeof(int))); h->allocs.push_back(q); h->d_fvalid = (int *)q;
+  }
+  SCHK(hipMemsetAsync(h->d_fvalid, 0, nv * sizeof(int), h->stream));
+  SCHK(hipStreamSynchronize(h->stream));
+  h->factor_cache = true;
+  return 0;
+}
+
 int cddp_hip_set_control_box(cddp_hip_stack_handle *h, const double *lower, const double *upper, const double *U) {
   if (!h) return sfail(-1, "null handle");
   SCHK(hipSetDevice(h->device));
@@ -755,8 +804,13 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
                              int retry, int32_t *ok) {
   if (!h || !opt || !reg) return sfail(-1, "null argument");
   if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH && branch != CDDP_HIP_STACKS_LOGDDP &&
-      branch != CDDP_HIP_STACKS_MSIPDDP)
+      branch != CDDP_HIP_STACKS_MSIPDDP && branch != CDDP_HIP_STACKS_MSIPDDP_PATH)
     return sfail(-2, "unknown stack-fed branch %d", branch);
+  if (branch == CDDP_HIP_STACKS_MSIPDDP_PATH) {
+    if (!(h->nu == 1 || h->nx == h->nu))   // msipddp_solver.cpp:1398 adds an (nx x nu) product to the (nu x nx) block Q_ux
+      return sfail(-1, "the path-constrained MSIPDDP recursion is only defined for nu = 1 or nx = nu (msipddp_solver.cpp:1398 adds an (nx x nu) product to the (nu x nx) block Q_ux); got nx = %d, nu = %d", h->nx, h->nu);
+    if (!h->a.dfc) return sfail(-1, "cddp_hip_set_defect_stack must be called before the MSIPDDP sweep");
+  }
   if (branch == CDDP_HIP_STACKS_MSIPDDP) {
     if (h->m > 0)   // msipddp_solver.cpp:1398 adds an (nx x nu) product to the (nu x nx) block Q_ux: not a defined recursion for nx != nu
       return sfail(-1, "the MSIPDDP branch covers the unconstrained recursion (msipddp_solver.cpp:1112-1208); handle with m = 0");
@@ -764,13 +818,13 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
     if (h->a.Fxx) return sfail(-1, "the MSIPDDP branch is Gauss-Newton here: its second-order terms weigh the Hessians with the costates (msipddp_solver.cpp:1151-1163); drop the Hessian stacks");
   }
   if (!h->have_dyn) return sfail(-1, "cddp_hip_set_stacks must be called before cddp_hip_stacks_backward");
-  if (branch == CDDP_HIP_STACKS_IPDDP_PATH) {
+  if (branch == CDDP_HIP_STACKS_IPDDP_PATH || branch == CDDP_HIP_STACKS_MSIPDDP_PATH) {
     if (h->m <= 0) return sfail(-1, "the path-constrained branch needs a handle created with m > 0");
     if (!h->have_con) return sfail(-1, "cddp_hip_set_constraint_stacks must be called before the path-constrained sweep");
     if (!mu) return sfail(-1, "the path-constrained branch needs the barrier parameter mu[b]");
     for (int b = 0; b < h->B; ++b) if (!(mu[b] > 0.0)) return sfail(-2, "barrier parameter of trajectory %d must be positive (got %g)", b, mu[b]);
   } else if (h->m > 0) {
-    return sfail(-1, "this handle carries path-constraint stacks (m = %d): use CDDP_HIP_STACKS_IPDDP_PATH, or a handle with m = 0", h->m);
+    return sfail(-1, "this handle carries path-constraint stacks (m = %d): use CDDP_HIP_STACKS_IPDDP_PATH / CDDP_HIP_STACKS_MSIPDDP_PATH, or a handle with m = 0", h->m);
   }
   if (branch == CDDP_HIP_STACKS_CLDDP && h->a.Fxx)
     return sfail(-1, "CLDDPSolver::backwardPass has no second-order dynamics terms (clddp_solver.cpp:79-204): drop the Hessian stacks for this branch");
@@ -785,6 +839,8 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   a.opt = *opt;
   if (branch != CDDP_HIP_STACKS_CLDDP) a.lo = a.up = a.U = nullptr;   // the box belongs to the CLDDP branch
   a.mu = mu ? h->d_mu : nullptr;
+  a.QuuF = (h->factor_cache && branch == CDDP_HIP_STACKS_MSIPDDP) ? h->d_QuuF : nullptr;
+  a.fvalid = a.QuuF ? h->d_fvalid : nullptr;
   a.reg_factor = retry ? opt->reg_update_factor : 0.0;
   a.reg_max = opt->reg_max_value;
   a.tau_min = (branch == CDDP_HIP_STACKS_CLDDP) ? opt->termination_scaling_max_factor : opt->barrier_min_fraction_to_boundary;

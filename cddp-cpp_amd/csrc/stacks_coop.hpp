@@ -170,7 +170,8 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
   const int N = a.N, bpo = a.Bp;
   const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
   const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
-  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP;
+  const bool msp = a.branch == CDDP_HIP_STACKS_MSIPDDP_PATH;
+  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP || msp;
   const bool ip = a.branch != CDDP_HIP_STACKS_CLDDP && !lg;
   SC_EACH(NX, i) L[C::oVx + i] = a.VxN[(size_t)i * a.Bp + b];
   if (ip || lg) {
@@ -280,11 +281,12 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       const double s_floor = dmax(mu * 1e-3, kEpsSlackS);
       SC_EACH(M, r) {
         const double y = L[C::oY + r], s = L[C::oS + r], g = L[C::oGg + r];
-        const double ssafe = dmax(s, s_floor);
+        const double ssafe = msp ? s : dmax(s, s_floor);
         const double rp = g + s;
         const double rc = y * s - mu;
         const double rhat = y * rp - rc;
-        L[C::oSs + r] = ssafe; L[C::oYS + r] = clipp(y, ssafe); L[C::oRp + r] = rp; L[C::oRhat + r] = rhat; L[C::oSir + r] = clips(rhat, ssafe);
+        L[C::oSs + r] = ssafe; L[C::oYS + r] = msp ? y / s : clipp(y, ssafe); L[C::oRp + r] = rp; L[C::oRhat + r] = rhat;
+        L[C::oSir + r] = msp ? rhat / s : clips(rhat, ssafe);
         inf_pr = dmax(inf_pr, fabs(rp)); inf_comp = dmax(inf_comp, fabs(rc));
       }
       lds_sync();
@@ -337,7 +339,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         double temp = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; ++i) temp += L[C::oGu + r * NU + i] * kk[i];
-        SC_G(a.ky, t, M, r) = clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]);
+        SC_G(a.ky, t, M, r) = msp ? (L[C::oRhat + r] + L[C::oY + r] * temp) / L[C::oSs + r] : clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]);
         SC_G(a.ks, t, M, r) = (-L[C::oRp + r]) - temp;
       }
       SC_COLS(NX, c) {
@@ -352,7 +354,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
           const int e = r * NX + c;
           const double gx = L[C::oGx + e];
           const double inner = gx + s2;
-          SC_G(a.Ky, t, M * NX, e) = dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS);
+          SC_G(a.Ky, t, M * NX, e) = msp ? L[C::oYS + r] * inner : dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS);
           SC_G(a.Ks, t, M * NX, e) = (-gx) - s2;
         }
       }
@@ -378,7 +380,18 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         L[C::oQuu + e] = L[C::oQuu + e] + s1;
       }
       SC_EACH(NU, i) L[C::oQu + i] = L[C::oRu + i];
-      SC_LOOP(NU * NX, e) L[C::oQux + e] = L[C::oRx + e];
+      if (msp) {   // msipddp_solver.cpp:1398 (see stacks.hip::sweep)
+        SC_LOOP(NU * NX, e) {
+          const int i = e / NX, c = e - i * NX;
+          const int pi = (NU == 1) ? c : i, pc = (NU == 1) ? 0 : c;
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += (L[C::oGx + r * NX + pi] * L[C::oYS + r]) * L[C::oGu + r * NU + (pc < NU ? pc : 0)];
+          L[C::oQux + e] = L[C::oQux + e] + s1;
+        }
+      } else {
+        SC_LOOP(NU * NX, e) L[C::oQux + e] = L[C::oRx + e];
+      }
     } else if (ip || lg) {
       // IPDDP: Q_uu = sym(Q_uu) + reg I, kept (:1084-1101).  LogDDP: factor sym(Q_uu + reg I), Q_uu itself untouched (:524-548)
       double qs[(NU * NU + 15) / 16];
@@ -389,14 +402,23 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         else { double v = 0.5 * (p + q); if (i == c) v += reg; qs[e_it] = v; }
       }
       lds_sync();
-      SC_EACH(NU * NU, e) { L[C::oQr + e] = qs[e_it]; if (!lg) L[C::oQuu + e] = qs[e_it]; }
+      const bool caching = ms && !lg && a.QuuF != nullptr;   // MSIPDDP's per-step factor cache (msipddp_solver.cpp:1169-1185)
+      const bool cached = caching && a.fvalid[(size_t)t * a.Bp + b] != 0;
+      SC_EACH(NU * NU, e) {
+        if (!lg) L[C::oQuu + e] = qs[e_it];
+        L[C::oQr + e] = cached ? SC_G(a.QuuF, t, NU * NU, e) : qs[e_it];
+      }
       lds_sync();
       {
         double Qr[NU * NU];
 #pragma unroll
         for (int i = 0; i < NU * NU; ++i) Qr[i] = L[C::oQr + i];
         SCFactor<NU> f;
-        if (!f.compute(Qr)) return false;
+        if (!f.compute(Qr)) { if (caching && gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 0; return false; }
+        if (caching && !cached) {
+          SC_EACH(NU * NU, e) SC_G(a.QuuF, t, NU * NU, e) = L[C::oQr + e];
+          if (gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 1;
+        }
         double col[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) col[i] = L[C::oQu + i];
@@ -593,10 +615,11 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
     reg = dmin(reg, a.reg_max);
     if (reg >= a.reg_max) break;
     lds_sync();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the next attempt reads what other lanes of the group stored (BoxQP warm start k, factor cache)
   }
   double apr = 1.0, adu = 1.0;
   if constexpr (M > 0) {
-    if (ok) {   // rolloutLinearPolicy from dx0 = 0, dS / dY, computeMaxStepSizes (ipddp_solver.cpp:1511-1532, 2939-2988)
+    if (ok && a.branch != CDDP_HIP_STACKS_MSIPDDP_PATH) {   // rolloutLinearPolicy from dx0 = 0, dS / dY, computeMaxStepSizes (ipddp_solver.cpp:1511-1532, 2939-2988)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the gains were written through other lanes of this group
       const int N = a.N;
       const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;

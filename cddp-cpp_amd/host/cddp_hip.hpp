@@ -69,6 +69,10 @@ struct IPDDPAlgorithmOptions {
   double jacobian_regularization_value = 1e-8, jacobian_regularization_exponent = 0.25;
   SolverSpecificBarrierOptions barrier;
 };
+struct MSIPDDPAlgorithmOptions {   // options.hpp:110-130, 190: InteriorPointOptions + MultiShootingOptions
+  double dual_var_init_scale = 1e-1, slack_var_init_scale = 1e-2; SolverSpecificBarrierOptions barrier;
+  int segment_length = 5; std::string rollout_type = "nonlinear"; bool use_controlled_rollout = false; double costate_var_init_scale = 1e-6;
+};
 struct LogBarrierOptions { bool use_relaxed_log_barrier_penalty = false; double relaxed_log_barrier_delta = 1e-10; SolverSpecificBarrierOptions barrier; };   // options.hpp:135-143
 struct CDDPOptions {
   double tolerance = 1e-5, acceptable_tolerance = 1e-6; int max_iterations = 1; double max_cpu_time = 0.0;
@@ -76,8 +80,10 @@ struct CDDPOptions {
   int num_threads = 1; bool return_iteration_info = false, warm_start = false; double termination_scaling_max_factor = 100.0;
   LineSearchOptions line_search; RegularizationOptions regularization; BoxQPOptions box_qp; SolverSpecificFilterOptions filter; IPDDPAlgorithmOptions ipddp;
   LogBarrierOptions log_barrier;
+  MSIPDDPAlgorithmOptions msipddp;
 
-  cddp_hip_options toPOD() const {
+  // msipddp = true: the InteriorPointOptions half of options.msipddp travels in the ipddp_* / barrier_* fields (include/cddp_hip.h)
+  cddp_hip_options toPOD(bool for_msipddp = false) const {
     cddp_hip_options o; cddp_hip_default_options(&o);
     o.tolerance = tolerance; o.acceptable_tolerance = acceptable_tolerance; o.max_iterations = max_iterations; o.max_cpu_time = max_cpu_time;
     o.use_ilqr = use_ilqr; o.enable_parallel = enable_parallel; o.return_iteration_info = return_iteration_info; o.warm_start = warm_start;
@@ -104,6 +110,15 @@ struct CDDPOptions {
     o.barrier_strategy = (int)ipddp.barrier.strategy;
     o.logddp_mu_initial = log_barrier.barrier.mu_initial; o.logddp_mu_min_value = log_barrier.barrier.mu_min_value;
     o.logddp_mu_update_factor = log_barrier.barrier.mu_update_factor; o.logddp_relaxed_delta = log_barrier.relaxed_log_barrier_delta;
+    o.msipddp_costate_var_init_scale = msipddp.costate_var_init_scale; o.msipddp_segment_length = msipddp.segment_length;
+    o.msipddp_rollout_type = msipddp.rollout_type == "nonlinear" ? 0 : msipddp.rollout_type == "hybrid" ? 2 : 1;
+    o.msipddp_use_controlled_rollout = msipddp.use_controlled_rollout;
+    if (for_msipddp) {
+      o.ipddp_dual_var_init_scale = msipddp.dual_var_init_scale; o.ipddp_slack_var_init_scale = msipddp.slack_var_init_scale;
+      o.barrier_mu_initial = msipddp.barrier.mu_initial; o.barrier_mu_min_value = msipddp.barrier.mu_min_value; o.barrier_mu_update_factor = msipddp.barrier.mu_update_factor;
+      o.barrier_mu_update_power = msipddp.barrier.mu_update_power; o.barrier_min_fraction_to_boundary = msipddp.barrier.min_fraction_to_boundary;
+      o.barrier_strategy = (int)msipddp.barrier.strategy;
+    }
     return o;
   }
 };
@@ -628,7 +643,7 @@ class HipBatchSolver : public ISolverAlgorithm {
  public:
   explicit HipBatchSolver(int solver_kind, int device = 0) : kind_(solver_kind), device_(device) {}
   ~HipBatchSolver() override { if (h_) cddp_hip_destroy(h_); }
-  std::string getSolverName() const override { return kind_ == CDDP_HIP_SOLVER_IPDDP ? "IPDDP" : kind_ == CDDP_HIP_SOLVER_LOGDDP ? "LogDDP" : "CLDDP"; }
+  std::string getSolverName() const override { return kind_ == CDDP_HIP_SOLVER_IPDDP ? "IPDDP" : kind_ == CDDP_HIP_SOLVER_LOGDDP ? "LogDDP" : kind_ == CDDP_HIP_SOLVER_MSIPDDP ? "MSIPDDP" : "CLDDP"; }
   // A second initialize() of the SAME solver object with options.warm_start keeps the device-resident solver state
   // (gains, slack / dual / costate variables): the reference's "existing solver state" branch
   // (clddp_solver.cpp:51-60, ipddp_solver.cpp:675-731).  CDDP::solve() creates a new solver per call, exactly as
@@ -660,7 +675,7 @@ class HipBatchSolver : public ISolverAlgorithm {
   void create(CDDP &ctx, const std::vector<Vector> &x0s) {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
-    plugin_ = ctx.needsHostPlugins() || kind_ == CDDP_HIP_SOLVER_LOGDDP;   // LogDDP: host loop + stack-fed GPU sweeps for every problem
+    plugin_ = ctx.needsHostPlugins() || kind_ == CDDP_HIP_SOLVER_LOGDDP || kind_ == CDDP_HIP_SOLVER_MSIPDDP;   // LogDDP, MSIPDDP: host loop + stack-fed GPU sweeps for every problem
     if (plugin_) {
       const DynamicalSystem &sys = ctx.getSystem();
       nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;
@@ -773,7 +788,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     cddp_hip_plugin pl; std::memset(&pl, 0, sizeof(pl));
     pl.user = &pc; pl.nx = nx_; pl.nu = nu_;
     const ControlConstraint *box = nullptr;
-    if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP) {
+    if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP || kind_ == CDDP_HIP_SOLVER_MSIPDDP) {
       for (auto &kv : ctx.getConstraintSet()) {   // std::map order == dual stacking order
         if ((int)pc.cons.size() == CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) throw std::runtime_error("HipBatchSolver: too many path constraints for the plug-in solve");
         pl.constraint_dims[pc.cons.size()] = kv.second->getDualDim(); pc.m += kv.second->getDualDim(); pc.cons.push_back(kv.second.get());
@@ -787,7 +802,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     pl.discrete_dynamics = cbDyn; pl.jacobians = cbJac; pl.hessians = ctx.getOptions().use_ilqr ? nullptr : cbHess;
     pl.running_cost = cbRun; pl.terminal_cost = cbTerm; pl.running_cost_derivatives = cbRunD; pl.terminal_cost_derivatives = cbTermD;
     pl.constraints = pc.cons.empty() ? nullptr : cbCon;
-    pl.constraint_hessians = (kind_ == CDDP_HIP_SOLVER_LOGDDP && !pc.cons.empty()) ? cbConHess : nullptr;
+    pl.constraint_hessians = ((kind_ == CDDP_HIP_SOLVER_LOGDDP || (kind_ == CDDP_HIP_SOLVER_MSIPDDP && !ctx.getOptions().use_ilqr)) && !pc.cons.empty()) ? cbConHess : nullptr;
     const int nx = nx_, nu = nu_, N = N_;
     std::vector<double> x0((size_t)B * nx), U0, X0;
     for (int b = 0; b < B; ++b) for (int i = 0; i < nx; ++i) x0[(size_t)b * nx + i] = x0s_[b][i];
@@ -795,7 +810,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     if ((int)ctx.X_.size() == N + 1) { X0.resize((size_t)B * (N + 1) * nx); for (int b = 0; b < B; ++b) for (int t = 0; t <= N; ++t) for (int i = 0; i < nx; ++i) X0[((size_t)b * (N + 1) + t) * nx + i] = ctx.X_[t][i]; }
     std::vector<cddp_hip_result> r(B);
     std::vector<double> X((size_t)B * (N + 1) * nx), U((size_t)B * N * nu), K((size_t)B * N * nu * nx);
-    cddp_hip_options o = ctx.getOptions().toPOD();
+    cddp_hip_options o = ctx.getOptions().toPOD(kind_ == CDDP_HIP_SOLVER_MSIPDDP);
     const int rc = cddp_hip_plugin_solve(&pl, kind_, N, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(), r.data(), X.data(), U.data(), K.data());
     if (pc.error) std::rethrow_exception(pc.error);
     check(rc);
@@ -857,6 +872,7 @@ inline void registerHipSolvers(int device = 0) {
   CDDP::registerSolver("CLCDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_CLDDP, device); });
   CDDP::registerSolver("LogDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_LOGDDP, device); });
   CDDP::registerSolver("LOGDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_LOGDDP, device); });
+  CDDP::registerSolver("MSIPDDP", [device] { return std::make_unique<HipBatchSolver>(CDDP_HIP_SOLVER_MSIPDDP, device); });
 }
 
 inline void CDDP::initializeProblemIfNecessary() {   // cddp_core.cpp:272-306
@@ -911,7 +927,7 @@ inline CDDPSolution CDDP::solve(const std::string &solver_type) {
 inline std::vector<CDDPSolution> CDDP::solveBatch(const std::string &solver_type, const std::vector<Vector> &x0s, int device) {
   initializeProblemIfNecessary();
   const int kind = (solver_type == "IPDDP") ? CDDP_HIP_SOLVER_IPDDP : (solver_type == "CLDDP" || solver_type == "CLCDDP") ? CDDP_HIP_SOLVER_CLDDP
-                   : (solver_type == "LogDDP" || solver_type == "LOGDDP") ? CDDP_HIP_SOLVER_LOGDDP : -1;
+                   : (solver_type == "LogDDP" || solver_type == "LOGDDP") ? CDDP_HIP_SOLVER_LOGDDP : (solver_type == "MSIPDDP") ? CDDP_HIP_SOLVER_MSIPDDP : -1;
   if (kind < 0) throw std::runtime_error("UnknownSolver - No solver registered for '" + solver_type + "'");
   HipBatchSolver s(kind, device);
   return s.solveBatch(*this, x0s);

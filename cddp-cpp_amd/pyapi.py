@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
 
-ABI_VERSION = 3          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
+ABI_VERSION = 4          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
 MAX_MODEL_PARAMS = 24
 NAME_LEN = 48
 
@@ -22,7 +22,7 @@ MODEL_PENDULUM, MODEL_CARTPOLE, MODEL_UNICYCLE, MODEL_LTI = 0, 1, 2, 3
 MODEL_QUADROTOR, MODEL_MANIPULATOR, MODEL_QUADROTOR_EULER12, MODEL_MANIPULATOR7 = 4, 5, 6, 7
 MODEL_BICYCLE, MODEL_CAR = 8, 9
 EULER, HEUN, RK3, RK4 = 0, 1, 2, 3
-SOLVER_CLDDP, SOLVER_IPDDP, SOLVER_LOGDDP = 0, 1, 2
+SOLVER_CLDDP, SOLVER_IPDDP, SOLVER_LOGDDP, SOLVER_MSIPDDP = 0, 1, 2, 3
 CON_CONTROL_BOX, CON_STATE_BOX, CON_BALL, CON_LINEAR = 0, 1, 2, 3
 CON_SOC, CON_THRUST, CON_MAX_THRUST = 4, 5, 6
 TERM_EQUALITY, TERM_INEQUALITY = 0, 1
@@ -71,6 +71,8 @@ class Options(C.Structure):
         ("max_cpu_time", C.c_double),
         ("logddp_mu_initial", C.c_double), ("logddp_mu_min_value", C.c_double), ("logddp_mu_update_factor", C.c_double),
         ("logddp_relaxed_delta", C.c_double),
+        ("msipddp_costate_var_init_scale", C.c_double), ("msipddp_segment_length", C.c_int32), ("msipddp_rollout_type", C.c_int32),
+        ("msipddp_use_controlled_rollout", C.c_int32), ("_pad4", C.c_int32),
     ]
 
 
@@ -100,6 +102,7 @@ def default_options():
     o.barrier_mu_update_power = 1.2; o.barrier_min_fraction_to_boundary = 0.99; o.barrier_strategy = 0
     o.max_cpu_time = 0.0
     o.logddp_mu_initial = 1.0; o.logddp_mu_min_value = 1e-10; o.logddp_mu_update_factor = 0.5; o.logddp_relaxed_delta = 1e-10
+    o.msipddp_costate_var_init_scale = 1e-6; o.msipddp_segment_length = 5; o.msipddp_rollout_type = 0; o.msipddp_use_controlled_rollout = 0
     return o
 
 
@@ -571,7 +574,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
-    "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
+    "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
@@ -870,7 +873,7 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     return res, X, U, K
 
 
-STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP = 0, 1, 2, 3, 4
+STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP, STACKS_MSIPDDP_PATH = 0, 1, 2, 3, 4, 5
 
 
 class HipStackSolver:
@@ -918,6 +921,10 @@ class HipStackSolver:
         """dt-scaled dynamics Hessian tensors [B][N][nx][...] (full DDP); all None returns to Gauss-Newton."""
         a = [(_arr(v) if v is not None else None) for v in (Fxx, Fuu, Fux)]
         self._check(self.lib.cddp_hip_set_hessian_stacks(self.h, *[_ptr(v) for v in a]))
+
+    def factor_cache(self, enable=True):
+        """MSIPDDP's per-step factor cache (msipddp_solver.cpp:1169-1185): enable=True allocates / CLEARS it (start of a solve)."""
+        self._check(self.lib.cddp_hip_stacks_factor_cache(self.h, 1 if enable else 0))
 
     def set_constraint_stacks(self, y=None, s=None, g=None, Gx=None, Gu=None):
         a = [(_arr(v) if v is not None else None) for v in (y, s, g, Gx, Gu)]

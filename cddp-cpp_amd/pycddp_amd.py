@@ -10,8 +10,8 @@ constraint kinds the device has kernels for.  On top of it:
 Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Python subclasses of `DynamicalSystem`,
 `Objective` / `NonlinearObjective` and `Constraint` (the reference's trampolines, `bind_dynamics.cpp:31-103`, `bind_objective.cpp`,
 `bind_constraints.cpp`) run through the host plug-in solve (`cddp_hip_plugin_solve`: batched backward passes on the GPU, forward
-passes on the host, callbacks into Python); anything the core does not implement raises (LogDDP, MSIPDDP, terminal constraints on
-plug-in problems, un-instantiated layouts).
+passes on the host, callbacks into Python) -- as do LogDDP and MSIPDDP for every problem; anything the core does not implement raises
+(terminal constraints on plug-in problems, un-instantiated layouts, path-constrained MSIPDDP outside nu = 1 / nx = nu).
 """
 import enum
 import importlib.util
@@ -104,14 +104,16 @@ class CDDPOptions:                  # options.hpp:41-251 / bind_options.cpp:96-1
         self.filter = FilterOptions(); self.log_barrier = LogBarrierOptions(); self.ipddp = IPDDPOptions()
         self.msipddp = MSIPDDPOptions()
 
-    def to_pod(self):
+    def to_pod(self, msipddp=False):
+        """The POD of include/cddp_hip.h.  msipddp=True: the InteriorPointOptions half of options.msipddp (slack / dual init scale, barrier)
+        travels in the ipddp_* / barrier_* fields, as the header documents for solver = MSIPDDP."""
         o = _api().default_options()
         o.tolerance = self.tolerance; o.acceptable_tolerance = self.acceptable_tolerance
         o.max_iterations = int(self.max_iterations); o.max_cpu_time = float(self.max_cpu_time); o.use_ilqr = 1 if self.use_ilqr else 0
         o.enable_parallel = 1 if self.enable_parallel else 0
         o.return_iteration_info = 1 if self.return_iteration_info else 0; o.warm_start = 1 if self.warm_start else 0
         o.termination_scaling_max_factor = self.termination_scaling_max_factor
-        ls, rg, bq, fl, ip = self.line_search, self.regularization, self.box_qp, self.filter, self.ipddp
+        ls, rg, bq, fl, ip = self.line_search, self.regularization, self.box_qp, self.filter, (self.msipddp if msipddp else self.ipddp)
         o.ls_max_iterations = int(ls.max_iterations); o.ls_initial_step_size = ls.initial_step_size
         o.ls_min_step_size = ls.min_step_size; o.ls_step_reduction_factor = ls.step_reduction_factor
         o.reg_initial_value = rg.initial_value; o.reg_update_factor = rg.update_factor
@@ -132,6 +134,10 @@ class CDDPOptions:                  # options.hpp:41-251 / bind_options.cpp:96-1
         lb = self.log_barrier
         o.logddp_mu_initial = lb.barrier.mu_initial; o.logddp_mu_min_value = lb.barrier.mu_min_value
         o.logddp_mu_update_factor = lb.barrier.mu_update_factor; o.logddp_relaxed_delta = lb.relaxed_log_barrier_delta
+        ms = self.msipddp
+        o.msipddp_costate_var_init_scale = ms.costate_var_init_scale; o.msipddp_segment_length = int(ms.segment_length)
+        o.msipddp_rollout_type = {"nonlinear": 0, "hybrid": 2}.get(ms.rollout_type, 1)
+        o.msipddp_use_controlled_rollout = 1 if ms.use_controlled_rollout else 0
         return o
 
 
@@ -579,9 +585,9 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         api = _api()
         if name == "LogDDP":             # host loop + stack-fed GPU sweeps for every problem (cddp_hip_plugin_solve)
             return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
+        if name == "MSIPDDP":            # same route; path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
+            return self._solve_plugins(name, api.SOLVER_MSIPDDP, x0s)
         if name not in ("CLDDP", "IPDDP"):
-            if name == "MSIPDDP":
-                raise NotImplementedError(name + " is not implemented on the HIP core (CLDDP, IPDDP and LogDDP are)")
             sol = CDDPSolution()                 # cddp_core.cpp:243-265: unknown names do not throw
             sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
             return [sol for _ in range(len(x0s))]
@@ -641,7 +647,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         s, ob = self._sys, self._obj
         nx, nu, N, dt = s.state_dim, s.control_dim, self._N, self._dt
         names = sorted(self._cons)          # std::map order
-        ipddp = kind in (api.SOLVER_IPDDP, api.SOLVER_LOGDDP)
+        ipddp = kind in (api.SOLVER_IPDDP, api.SOLVER_LOGDDP, api.SOLVER_MSIPDDP)
         cons = [self._cons[n] for n in names] if ipddp else []
         dims = [int(c.get_dual_dim()) for c in cons]
         lo = up = None
@@ -672,7 +678,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         import time as _time
         t0 = _time.perf_counter()
         res, X, U, K = api.plugin_solve(
-            kind, nx, nu, N, dt, self._opt.to_pod(), x0, U0, X0,
+            kind, nx, nu, N, dt, self._opt.to_pod(msipddp=(kind == api.SOLVER_MSIPDDP)), x0, U0, X0,
             discrete_dynamics=lambda x, u, t: s.get_discrete_dynamics(x, u, t),
             jacobians=(lambda x, u, t: s._eval(x, u, "jac")) if isinstance(s, _BuiltinPlant) else
                       (lambda x, u, t: (s.get_state_jacobian(x, u, t), s.get_control_jacobian(x, u, t))),
@@ -683,7 +689,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                                                       ob.get_running_cost_cross_hessian(x, u, i)),
             terminal_cost_derivatives=lambda x: (ob.get_final_cost_gradient(x), ob.get_final_cost_hessian(x)),
             constraints=constraints if cons else None, constraint_dims=dims, control_lower=lo, control_upper=up,
-            constraint_hessians=constraint_hessians if (cons and kind == api.SOLVER_LOGDDP) else None)
+            constraint_hessians=constraint_hessians if (cons and (kind == api.SOLVER_LOGDDP or (kind == api.SOLVER_MSIPDDP and not self._opt.use_ilqr))) else None)
         ms = (_time.perf_counter() - t0) * 1e3
         out = []
         for b in range(B):

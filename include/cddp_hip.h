@@ -30,8 +30,10 @@ extern "C" {
 #endif
 
 /* 2: cddp_hip_options gained max_cpu_time (shifts cddp_hip_problem's tail), cddp_hip_stats gained rollout_steps (80 -> 88 bytes).
- * A host built against version 1 is refused by cddp_hip_create instead of being read at shifted offsets. */
-#define CDDP_HIP_ABI_VERSION 3
+ * A host built against version 1 is refused by cddp_hip_create instead of being read at shifted offsets.
+ * 3: cddp_hip_options gained the LogDDP barrier fields, cddp_hip_plugin gained constraint_hessians.
+ * 4: cddp_hip_options gained the MSIPDDP multi-shooting fields. */
+#define CDDP_HIP_ABI_VERSION 4
 #define CDDP_HIP_MAX_MODEL_PARAMS 24
 #define CDDP_HIP_NAME_LEN 48
 #define CDDP_HIP_MAX_ALPHAS 32
@@ -62,8 +64,12 @@ enum cddp_hip_integrator {
 /* Which reference solver core is replaced (cddp_core.cpp:213-233). */
 enum cddp_hip_solver {
   CDDP_HIP_SOLVER_CLDDP = 0, CDDP_HIP_SOLVER_IPDDP = 1,
-  CDDP_HIP_SOLVER_LOGDDP = 2   /* logddp_solver.cpp: single-shooting relaxed-log-barrier DDP; served by cddp_hip_plugin_solve (host loop +
+  CDDP_HIP_SOLVER_LOGDDP = 2,  /* logddp_solver.cpp: single-shooting relaxed-log-barrier DDP; served by cddp_hip_plugin_solve (host loop +
                                   stack-fed GPU sweeps), not by the device-resident cddp_hip_create / cddp_hip_solve */
+  CDDP_HIP_SOLVER_MSIPDDP = 3  /* msipddp_solver.cpp: multiple-shooting interior-point DDP (costates, dynamics defects at segment
+                                  boundaries); served by cddp_hip_plugin_solve like LogDDP.  Path constraints with nu > 1 and nx != nu are
+                                  refused: the reference adds an (nx x nu) product to its (nu x nx) block Q_ux there (msipddp_solver.cpp:1398),
+                                  which is only defined for nu = 1 (same linear layout) or nx = nu */
 };
 
 /* Path-constraint kinds (reference include/cddp-cpp/cddp_core/constraint.hpp:144-404). */
@@ -173,6 +179,14 @@ typedef struct cddp_hip_options {
   double logddp_mu_min_value;         /* 1e-10 */
   double logddp_mu_update_factor;     /* 0.5 */
   double logddp_relaxed_delta;        /* 1e-10 */
+  /* MultiShootingOptions (options.hpp:120-130; MSIPDDP only).  With solver = MSIPDDP the InteriorPointOptions half of options.msipddp
+   * (dual_var_init_scale, slack_var_init_scale, barrier.*) travels in ipddp_dual_var_init_scale / ipddp_slack_var_init_scale /
+   * barrier_* above -- the mirrors copy options.msipddp there instead of options.ipddp. */
+  double msipddp_costate_var_init_scale;  /* 1e-6 */
+  int32_t msipddp_segment_length;         /* 5 */
+  int32_t msipddp_rollout_type;           /* 0 = "nonlinear", 2 = "hybrid", 1 = any other string (plain rollout at the boundary) */
+  int32_t msipddp_use_controlled_rollout; /* 0 */
+  int32_t _pad4;
 } cddp_hip_options;
 
 /* Fill *opt with the reference defaults (options.hpp in-class initialisers). */
@@ -460,6 +474,9 @@ enum cddp_hip_stacks_branch {
   CDDP_HIP_STACKS_IPDDP = 1,      /* ipddp_solver.cpp:1048-1118 (no constraints)                       */
   CDDP_HIP_STACKS_IPDDP_PATH = 2, /* ipddp_solver.cpp:1355-1568 (path constraints; handle with m > 0)  */
   CDDP_HIP_STACKS_MSIPDDP = 4,    /* msipddp_solver.cpp:1112-1208 (no constraints): IPDDP recursion + defect stack (cddp_hip_set_defect_stack) */
+  CDDP_HIP_STACKS_MSIPDDP_PATH = 5, /* msipddp_solver.cpp:1222-1420 (path constraints; handle with m > 0, defect stack): the condensation with
+                                     plain y / s ratios (no slack floor, no clipping), Q_ux updated as :1398 writes it -- nu = 1 or nx = nu
+                                     only --, no linear-policy rollout / step caps */
   CDDP_HIP_STACKS_LOGDDP = 3      /* logddp_solver.cpp:470-575: the caller folds the relaxed log barrier's gradients / Hessians (barrier.hpp:95-262)
                                      into lx, lu, lxx, luu, lux; handle with m = 0                     */
 };
@@ -486,6 +503,12 @@ int cddp_hip_set_control_box(cddp_hip_stack_handle *h, const double *lower, cons
  * them to Q_xx, Q_uu, Q_ux (ipddp_solver.cpp:1070-1082, 1396-1408; logddp_solver.cpp:505-515); the reference's CLDDP backward pass
  * has no such terms and cddp_hip_stacks_backward refuses that combination.  Three NULLs return to Gauss-Newton. */
 int cddp_hip_set_hessian_stacks(cddp_hip_stack_handle *h, const double *Fxx, const double *Fuu, const double *Fux);
+/* MSIPDDP's per-step factor cache (msipddp_solver.cpp:1169-1185, unconstrained branch): the reference keeps one LDLT of
+ * sym(Q_uu) + reg I per step and refactors a step only while its cached factor is invalid, so from the second sweep of a solve on
+ * every step is solved with the matrix of its FIRST sweep.  enable != 0 allocates (first call) and CLEARS the cache: call it at
+ * the start of each solve; the CDDP_HIP_STACKS_MSIPDDP branch then factors the cached matrix of a step where there is one and
+ * caches the one it factored where there was none.  enable == 0 (the default of a new handle): every sweep factors its own. */
+int cddp_hip_stacks_factor_cache(cddp_hip_stack_handle *h, int enable);
 /* Upload the condensation inputs of the path-constrained branch (same NULL rule). */
 int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, const double *s, const double *g,
                                    const double *Gx, const double *Gu);

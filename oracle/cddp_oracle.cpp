@@ -168,6 +168,7 @@ struct FPResult {
   bool success = false;
   double theta = 0, inf_pr = 0, inf_comp = 0;
   std::vector<Vec> S, Y, G, Lambda;
+  std::vector<Vec> F;                    // MSIPDDP: dynamics values f(x_t, u_t) of the trial (dynamics_trajectory)
   std::map<std::string, Vec> S_T, Y_T, G_T;
   Vec Lambda_T_eq;
   bool has_ip = false;
@@ -1534,15 +1535,456 @@ struct Solver {
     lg_reset_filter();
   }
 
+
+  // =============================================================== MSIPDDP (msipddp_solver.cpp): multiple-shooting interior-point DDP.
+  // The iterate carries costates Lambda_t and the dynamics values F_t = f(x_t, u_t); the defect d_t = F_t - x_{t+1} enters the backward
+  // pass.  Stacked duals / slacks reuse the IPDDP containers (Y, S, G, k_y, K_y, k_s, K_s: one vector of total dual dimension per step,
+  // constraints in std::map order).  Two properties of the reference are restated as they are, not repaired:
+  //  * the unconstrained branch caches the LDLT of Q_uu per step and only refactors a step whose cached factor is invalid
+  //    (:1169-1185): after the first successful sweep every later sweep solves with the FIRST factor of its step;
+  //  * the constrained branch adds the (nx x nu) product Q_yx^T YS^-1 Q_yu to the (nu x nx) block Q_ux (:1398): defined for nu = 1
+  //    (same linear layout: the transpose lands) and for nx = nu (elementwise, untransposed); every other shape is refused here.
+  std::vector<Vec> ms_F, ms_kl;
+  std::vector<Mat> ms_Kl;
+  std::vector<LDLT> ms_ldlt;
+  std::vector<char> ms_ldlt_valid;
+  bool ms_workspace = false;
+  int ms_seg = 5;
+
+  void ms_evaluate_trajectory() {            // evaluateTrajectory :425-455
+    double c = 0.0;
+    X[0] = x0;
+    for (int t = 0; t < N; ++t) {
+      c += running_cost(X[t], U[t], t);
+      for (auto &cd : cons) G[t].setSegment(cd.offset, con_g(cd, X[t], U[t]));
+      ms_F[t] = model.step(X[t], U[t], t * dt);
+      X[t + 1] = ms_F[t];
+    }
+    c += terminal_cost(X.back());
+    cost = c;
+  }
+  void ms_evaluate_trajectory_warm() {       // evaluateTrajectoryWarmStart :457-495
+    double c = 0.0;
+    G.assign(N, Vec::Zero(m));
+    for (int t = 0; t < N; ++t) {
+      c += running_cost(X[t], U[t], t);
+      for (auto &cd : cons) G[t].setSegment(cd.offset, con_g(cd, X[t], U[t]));
+      ms_F[t] = model.step(X[t], U[t], t * dt);
+      if (opt.msipddp_use_controlled_rollout) X[t + 1] = ms_F[t];
+    }
+    c += terminal_cost(X.back());
+    cost = c;
+  }
+  void ms_init_pair(const Vec &g, Vec &s_init, Vec &y_init, const ConstraintDesc &cd) const {   // :578-596 == :667-685
+    for (int i = 0; i < cd.dual_dim; ++i) {
+      const int j = cd.offset + i;
+      s_init(j) = std::max(opt.ipddp_slack_var_init_scale, -g(j));
+      y_init(j) = (s_init(j) < 1e-12) ? mu / 1e-12 : mu / s_init(j);
+      y_init(j) = std::max(opt.ipddp_dual_var_init_scale * 0.01, std::min(y_init(j), opt.ipddp_dual_var_init_scale * 100.0));
+    }
+  }
+  void ms_zero_path_gains() {
+    k_y.assign(N, Vec::Zero(m)); k_s.assign(N, Vec::Zero(m)); K_y.assign(N, Mat::Zero(m, nx)); K_s.assign(N, Mat::Zero(m, nx));
+  }
+  void ms_init_dual_slack_costate() {        // initializeDualSlackCostateVariables :643-709
+    G.assign(N, Vec::Zero(m)); Y.assign(N, Vec::Zero(m)); S.assign(N, Vec::Zero(m));
+    for (auto &cd : cons)
+      for (int t = 0; t < N; ++t) {
+        G[t].setSegment(cd.offset, con_g(cd, X[t], U[t]));
+        ms_init_pair(G[t], S[t], Y[t], cd);
+      }
+    ms_zero_path_gains();
+    for (int t = 0; t < N; ++t) {
+      Lambda[t] = opt.msipddp_costate_var_init_scale * Vec::Ones(nx);
+      ms_kl[t] = Vec::Zero(nx); ms_Kl[t] = Mat::Zero(nx, nx);
+    }
+    cost = objective_evaluate(X, U);
+  }
+  void ms_init_dual_slack_costate_warm(bool has_existing) {   // initializeDualSlackCostateVariablesWarmStart :497-641
+    if (!has_existing) { Y.assign(N, Vec::Zero(m)); S.assign(N, Vec::Zero(m)); }
+    for (auto &cd : cons)
+      for (int t = 0; t < N; ++t) {
+        bool need_reinit = !has_existing;
+        if (has_existing)
+          for (int i = 0; i < cd.dual_dim; ++i) {
+            const int j = cd.offset + i;
+            if (Y[t](j) <= 1e-12 || S[t](j) <= 1e-12) { need_reinit = true; break; }
+            const double required = std::max(opt.ipddp_slack_var_init_scale, -G[t](j));
+            if (S[t](j) < 0.1 * required) { need_reinit = true; break; }
+          }
+        if (need_reinit) ms_init_pair(G[t], S[t], Y[t], cd);
+      }
+    ms_zero_path_gains();
+    const bool has_costate = (int)Lambda.size() == N;
+    if (!has_costate) Lambda.assign(N, opt.msipddp_costate_var_init_scale * Vec::Ones(nx));
+    ms_kl.assign(N, Vec::Zero(nx)); ms_Kl.assign(N, Mat::Zero(nx, nx));
+  }
+  void ms_reset_filter() {                   // resetBarrierFilter :711-763
+    double mf = cost, ipr = 0.0, fcv = 0.0, icomp = 0.0, idef = 0.0;
+    if (!cons.empty()) {
+      for (int t = 0; t < N; ++t) {
+        for (auto &cd : cons) {
+          double lsum = 0.0, l1 = 0.0;
+          for (int i = 0; i < cd.dual_dim; ++i) {
+            const int j = cd.offset + i;
+            lsum += olog(S[t](j));
+            const double pr = G[t](j) + S[t](j);
+            ipr = std::max(ipr, std::fabs(pr)); l1 += std::fabs(pr);
+            icomp = std::max(icomp, std::fabs(Y[t](j) * S[t](j) - mu));
+          }
+          mf -= mu * lsum; fcv += l1;
+        }
+        if (t < (int)ms_F.size() && t + 1 < (int)X.size()) {
+          const Vec dres = ms_F[t] - X[t + 1];
+          idef = std::max(idef, dres.lpNormInf());
+          fcv += dres.lpNorm1();
+        }
+      }
+    }
+    inf_pr = std::max(ipr, idef); merit = mf; inf_comp = icomp;
+    filter.clear(); filter.push_back(FilterPoint{mf, fcv});
+  }
+  bool ms_filter_acceptable(double mf, double cv, double expected_improvement) const {   // isFilterAcceptable :771-808
+    if (filter.empty()) return true;
+    FilterPoint cand{mf, cv};
+    for (auto &p : filter) if (p.dominates(cand)) return false;
+    double best_v = std::numeric_limits<double>::infinity(), best_m = std::numeric_limits<double>::infinity();
+    for (auto &p : filter) if (p.constraint_violation < best_v) { best_v = p.constraint_violation; best_m = p.merit_function; }
+    const bool v_imp = cv < best_v * (1.0 - opt.filter_violation_acceptance_threshold);
+    const bool m_imp = mf < best_m - opt.filter_merit_acceptance_threshold * cv;
+    if (cv < opt.filter_min_violation_for_armijo_check && expected_improvement < 0) return mf < best_m + opt.filter_armijo_constant * expected_improvement;
+    if (cv < 1e-6 && mf <= best_m * (1.0 + 1e-8)) return true;
+    return v_imp || m_imp;
+  }
+  double ms_scaled_inf_du() const {          // computeScaledDualInfeasibility :1886-1930
+    if (cons.empty()) return inf_du;
+    const double smax = 100.0;
+    double yn = 0.0, sn = 0.0; int total = 0;
+    for (auto &cd : cons)
+      for (int t = 0; t < N; ++t) { yn += seg(Y[t], cd).lpNorm1(); sn += seg(S[t], cd).lpNorm1(); total += cd.dual_dim; }
+    const int mpn = total + nu * N;
+    const double num = mpn > 0 ? (yn + sn) / (double)mpn : 0.0;
+    const double sd = std::max(smax, num) / smax;
+    return inf_du / sd;
+  }
+  bool ms_shape_defined() const { return cons.empty() || nu == 1 || nx == nu; }
+  void msipddp_initialize() {                // initialize :33-264
+    if (!ms_shape_defined()) { std::fprintf(stderr, "oracle: MSIPDDP with path constraints is only defined for nu = 1 or nx = nu (msipddp_solver.cpp:1398)\n"); std::abort(); }
+    if (!ms_workspace) { ms_ldlt.assign(N, LDLT()); ms_ldlt_valid.assign(N, 0); ms_workspace = true; }
+    ms_seg = opt.msipddp_segment_length;
+    Vx_t.assign(N + 1, Vec::Zero(nx)); Vxx_t.assign(N + 1, Mat::Zero(nx, nx));
+    if (opt.warm_start) {
+      if (have_valid_gains()) {              // :95-106
+        mu = opt.barrier_mu_initial * 0.1; step_norm = 0.0;
+        if ((int)ms_F.size() != N) ms_F.assign(N, Vec::Zero(nx));
+        const bool has_existing = path_duals_exist();
+        ms_evaluate_trajectory_warm();
+        ms_init_dual_slack_costate_warm(has_existing);
+        ms_reset_filter();
+        return;
+      }
+      initializeGains();                     // :108-160
+      Lambda.assign(N, opt.msipddp_costate_var_init_scale * Vec::Ones(nx));
+      ms_kl.assign(N, Vec::Zero(nx)); ms_Kl.assign(N, Mat::Zero(nx, nx)); ms_F.assign(N, Vec::Zero(nx));
+      G.clear(); Y.clear(); S.clear();
+      if (cons.empty()) mu = 1e-8;
+      else {
+        ms_evaluate_trajectory_warm();
+        const double mv = computeMaxConstraintViolation();
+        if (mv <= opt.tolerance) mu = opt.tolerance * 0.01;
+        else if (mv <= 0.1) mu = opt.tolerance;
+        else mu = opt.barrier_mu_initial * 0.1;
+      }
+      reg = opt.reg_initial_value; step_norm = 0.0;
+      if (cons.empty()) G.assign(N, Vec::Zero(m));
+      ms_init_dual_slack_costate_warm(false);
+      ms_reset_filter();
+      return;
+    }
+    initializeGains();                       // cold start :199-263 (the trajectory guess of set_initial counts as provided)
+    Lambda.assign(N, Vec::Zero(nx)); ms_kl.assign(N, Vec::Zero(nx)); ms_Kl.assign(N, Mat::Zero(nx, nx)); ms_F.assign(N, Vec::Zero(nx));
+    mu = cons.empty() ? 1e-8 : opt.barrier_mu_initial;
+    ms_init_dual_slack_costate();
+    reg = opt.reg_initial_value; step_norm = 0.0;
+    ms_evaluate_trajectory();
+    ms_reset_filter();
+  }
+  bool msipddp_backward() {                  // backwardPass :1112-1430
+    ++n_backward;
+    Vec V_x = final_grad(X.back());
+    Mat V_xx = final_hess(); V_xx = 0.5 * (V_xx + V_xx.T());
+    Vx_t[N] = V_x; Vxx_t[N] = V_xx;
+    dV[0] = dV[1] = 0.0;
+    double idu = 0.0, ipr = 0.0, icomp = 0.0, idef = 0.0, snorm = 0.0;
+    if ((int)Gx.size() != N) { Gx.assign(N, Mat::Zero(m, nx)); Gu.assign(N, Mat::Zero(m, nu)); }
+    for (int t = N - 1; t >= 0; --t) {
+      const Vec &x = X[t]; const Vec &u = U[t]; const Vec &lambda = Lambda[t];
+      Vec d = Vec::Zero(nx);
+      if (t + 1 < (int)X.size()) d = ms_F[t] - X[t + 1];
+      Mat Fx, Fu; model.jacobians(x, u, t * dt, Fx, Fu);
+      Mat A = dt * Fx; for (int i = 0; i < nx; ++i) A(i, i) += 1.0;
+      Mat B = dt * Fu;
+      const Vec lx = l_x(x, t), lu = l_u(u);
+      const Vec w = V_x + V_xx * d;
+      Vec y = Vec::Zero(m), sv = Vec::Zero(m), g = Vec::Zero(m);
+      Mat Q_yu = Mat::Zero(m, nu), Q_yx = Mat::Zero(m, nx);
+      if (!cons.empty()) {
+        for (auto &cd : cons) {
+          Mat gx, gu; con_jac(cd, x, u, gx, gu);
+          Q_yx.setBlock(cd.offset, 0, gx); Q_yu.setBlock(cd.offset, 0, gu);
+        }
+        Gx[t] = Q_yx; Gu[t] = Q_yu;
+        y = Y[t]; sv = S[t]; g = G[t];
+      }
+      Vec Q_x = cons.empty() ? lx + A.T() * w : lx + Q_yx.T() * y + A.T() * w;
+      Vec Q_u = cons.empty() ? lu + B.T() * w : lu + Q_yu.T() * y + B.T() * w;
+      Mat Q_xx = l_xx() + A.T() * V_xx * A;
+      Mat Q_ux = l_ux() + B.T() * V_xx * A;
+      Mat Q_uu = l_uu() + B.T() * V_xx * B;
+      if (!opt.use_ilqr) {                   // :1151-1163, :1279-1310: the Hessians are weighted with the costates
+        std::vector<Mat> Fxx, Fuu, Fux;
+        if (!model.hessians(x, u, t * dt, Fxx, Fuu, Fux)) { std::fprintf(stderr, "oracle: use_ilqr=false needs Hessians\n"); std::abort(); }
+        for (int i = 0; i < nx; ++i) { Q_xx = Q_xx + (dt * lambda(i)) * Fxx[i]; Q_ux = Q_ux + (dt * lambda(i)) * Fux[i]; Q_uu = Q_uu + (dt * lambda(i)) * Fuu[i]; }
+        for (auto &cd : cons) {
+          std::vector<Mat> Cxx, Cuu, Cux;
+          if (!con_hess(cd, u, Cxx, Cuu, Cux)) { std::fprintf(stderr, "oracle: constraint without Hessians under use_ilqr=false\n"); std::abort(); }
+          for (int i = 0; i < cd.dual_dim; ++i) { Q_xx = Q_xx + y(cd.offset + i) * Cxx[i]; Q_ux = Q_ux + y(cd.offset + i) * Cux[i]; Q_uu = Q_uu + y(cd.offset + i) * Cuu[i]; }
+        }
+      }
+      Vec k(nu, 1); Mat K(nu, nx);
+      if (cons.empty()) {
+        Q_uu = 0.5 * (Q_uu + Q_uu.T());
+        for (int i = 0; i < nu; ++i) Q_uu(i, i) += reg;
+        const bool need_recompute = !ms_ldlt_valid[t] || (ms_ldlt_valid[t] && ms_ldlt[t].n != nu);   // :1169-1176
+        if (need_recompute) { ms_ldlt[t].compute(Q_uu); ms_ldlt_valid[t] = 1; }
+        if (!ms_ldlt[t].ok) { ms_ldlt_valid[t] = 0; return false; }
+        k = -ms_ldlt[t].solve(Q_u);
+        K = -ms_ldlt[t].solve(Q_ux);
+        k_u[t] = k; K_u[t] = K;
+        ms_kl[t] = -lambda + V_x + V_xx * d;
+        ms_Kl[t] = 0.5 * (V_xx + V_xx.T());
+        V_x = Q_x + K.T() * Q_u + Q_ux.T() * k + K.T() * Q_uu * k;
+        V_xx = Q_xx + K.T() * Q_ux + Q_ux.T() * K + K.T() * Q_uu * K;
+        V_xx = 0.5 * (V_xx + V_xx.T());
+        dV[0] += k.dot(Q_u);
+        dV[1] += 0.5 * k.dot(Q_uu * k);
+      } else {
+        Mat YSinv = Mat::Zero(m, m);
+        for (int i = 0; i < m; ++i) YSinv(i, i) = y(i) / sv(i);
+        const Vec pres = g + sv;
+        Vec cres(m, 1), rhat(m, 1), Sir(m, 1);
+        for (int i = 0; i < m; ++i) { cres(i) = y(i) * sv(i) - mu; rhat(i) = y(i) * pres(i) - cres(i); Sir(i) = rhat(i) / sv(i); }
+        Mat Q_uu_reg = 0.5 * (Q_uu + Q_uu.T());
+        Q_uu_reg = Q_uu_reg + Q_yu.T() * YSinv * Q_yu;
+        for (int i = 0; i < nu; ++i) Q_uu_reg(i, i) += reg;
+        LDLT ldlt(Q_uu_reg);
+        if (!ldlt.ok) return false;
+        Mat bigRHS(nu, 1 + nx);
+        const Vec r0 = Q_u + Q_yu.T() * Sir;
+        const Mat r1 = Q_ux + Q_yu.T() * YSinv * Q_yx;
+        for (int i = 0; i < nu; ++i) { bigRHS(i, 0) = r0(i); for (int c = 0; c < nx; ++c) bigRHS(i, c + 1) = r1(i, c); }
+        const Mat kK = -ldlt.solve(bigRHS);
+        for (int i = 0; i < nu; ++i) { k(i) = kK(i, 0); for (int c = 0; c < nx; ++c) K(i, c) = kK(i, c + 1); }
+        k_u[t] = k; K_u[t] = K;
+        const Vec temp = Q_yu * k;
+        Vec ky(m, 1);
+        for (int i = 0; i < m; ++i) ky(i) = (rhat(i) + y(i) * temp(i)) / sv(i);
+        k_y[t] = ky;
+        K_y[t] = YSinv * (Q_yx + Q_yu * K);
+        k_s[t] = -pres - temp;
+        K_s[t] = -Q_yx - Q_yu * K;
+        ms_kl[t] = -lambda + V_x + V_xx * d;
+        ms_Kl[t] = 0.5 * (V_xx + V_xx.T());
+        Q_u = Q_u + Q_yu.T() * Sir;
+        Q_x = Q_x + Q_yx.T() * Sir;
+        Q_xx = Q_xx + Q_yx.T() * YSinv * Q_yx;
+        {   // :1398  Q_ux.noalias() += Q_yx^T * YSinv * Q_yu  -- an (nx x nu) product added to the (nu x nx) block
+          const Mat P = Q_yx.T() * YSinv * Q_yu;
+          if (nu == 1) for (int c = 0; c < nx; ++c) Q_ux(0, c) += P(c, 0);          // same linear layout
+          else for (int i = 0; i < nu; ++i) for (int c = 0; c < nx; ++c) Q_ux(i, c) += P(i, c);   // nx == nu: elementwise
+        }
+        Q_uu = Q_uu + Q_yu.T() * YSinv * Q_yu;
+        dV[0] += k.dot(Q_u);
+        dV[1] += 0.5 * k.dot(Q_uu * k);
+        V_x = Q_x + K.T() * Q_u + Q_ux.T() * k + K.T() * Q_uu * k;
+        V_xx = Q_xx + K.T() * Q_ux + Q_ux.T() * K + K.T() * Q_uu * K;
+        V_xx = 0.5 * (V_xx + V_xx.T());
+        ipr = std::max(ipr, pres.lpNormInf());
+        icomp = std::max(icomp, cres.lpNormInf());
+      }
+      Vx_t[t] = V_x; Vxx_t[t] = V_xx;
+      idu = std::max(idu, Q_u.lpNormInf());
+      snorm = std::max(snorm, k.lpNormInf());
+      idef = std::max(idef, d.lpNormInf());
+    }
+    inf_du = idu; step_norm = snorm;
+    if (cons.empty()) { inf_pr = idef; inf_comp = 0.0; }
+    else { inf_pr = std::max(ipr, idef); inf_comp = icomp; }
+    return true;
+  }
+  Vec ms_next_state(int t, const FPResult &r, const Vec &Fn, const Vec &delta_x, double a) const {   // gap closing :1483-1509 == :1575-1601
+    const bool boundary = (ms_seg > 1) && ((t + 1) % ms_seg == 0) && (t + 1 < N);
+    if (!boundary) return Fn;
+    if (opt.msipddp_rollout_type == 0) return X[t + 1] + (Fn - ms_F[t]) + a * (ms_F[t] - X[t + 1]);
+    if (opt.msipddp_rollout_type == 2) {
+      Mat Fx, Fu; model.jacobians(X[t], U[t], t * dt, Fx, Fu);
+      Mat A = dt * Fx; for (int i = 0; i < nx; ++i) A(i, i) += 1.0;
+      const Mat B = dt * Fu;
+      return X[t + 1] + (A + B * K_u[t]) * delta_x + a * (B * k_u[t] + ms_F[t] - X[t + 1]);
+    }
+    (void)r;
+    return Fn;
+  }
+  FPResult msipddp_forward(double a) {       // forwardPass :1432-1724
+    FPResult r; r.alpha = a; r.alpha_pr = a; r.success = false;
+    r.cost = r.merit = std::numeric_limits<double>::infinity();
+    const double tau = std::max(opt.barrier_min_fraction_to_boundary, 1.0 - mu);
+    r.X = X; r.U = U; r.X[0] = x0;
+    r.F = ms_F; r.Lambda = Lambda; r.Y = Y; r.S = S; r.G = G;
+    std::vector<Vec> dxs(N, Vec::Zero(nx));
+    double cost_new = 0.0, merit_new = 0.0, cv_new = 0.0;
+    if (cons.empty()) {
+      for (int t = 0; t < N; ++t) {
+        const Vec delta_x = r.X[t] - X[t];
+        r.U[t] = U[t] + a * k_u[t] + K_u[t] * delta_x;
+        r.Lambda[t] = Lambda[t] + a * ms_kl[t] + ms_Kl[t] * delta_x;
+        r.F[t] = model.step(r.X[t], r.U[t], t * dt);
+        r.X[t + 1] = ms_next_state(t, r, r.F[t], delta_x, a);
+        cost_new += running_cost(r.X[t], r.U[t], t);
+      }
+      cost_new += terminal_cost(r.X.back());
+      const double dJ = cost - cost_new;
+      const double expected = -a * (dV[0] + 0.5 * a * dV[1]);
+      const double ratio = expected > 0.0 ? dJ / expected : std::copysign(1.0, dJ);
+      r.success = ratio > 1e-6;
+      r.cost = cost_new; r.merit = cost_new; r.theta = 0.0; r.alpha_du = 1.0; r.has_ip = false;
+      return r;
+    }
+    for (int t = 0; t < N; ++t) {
+      const Vec delta_x = r.X[t] - X[t];
+      dxs[t] = delta_x;
+      const Vec s_new = S[t] + a * k_s[t] + K_s[t] * delta_x;
+      for (auto &cd : cons)
+        for (int i = 0; i < cd.dual_dim; ++i) {
+          const int j = cd.offset + i;
+          if (s_new(j) < (1.0 - tau) * S[t](j)) return r;
+        }
+      r.S[t] = s_new;
+      r.U[t] = U[t] + a * k_u[t] + K_u[t] * delta_x;
+      r.F[t] = model.step(r.X[t], r.U[t], t * dt);
+      r.X[t + 1] = ms_next_state(t, r, r.F[t], delta_x, a);
+    }
+    bool found = false;
+    for (double ay : alphas) {
+      bool feasible = true;
+      std::vector<Vec> Yt = Y;
+      for (int t = 0; t < N && feasible; ++t) {
+        const Vec y_new = Y[t] + ay * k_y[t] + K_y[t] * dxs[t];
+        for (auto &cd : cons) {
+          for (int i = 0; i < cd.dual_dim; ++i) {
+            const int j = cd.offset + i;
+            if (y_new(j) < (1.0 - tau) * Y[t](j)) { feasible = false; break; }
+          }
+          if (!feasible) break;
+          Yt[t].setSegment(cd.offset, seg(y_new, cd));
+        }
+        r.Lambda[t] = Lambda[t] + a * ms_kl[t] + ms_Kl[t] * dxs[t];
+      }
+      if (feasible) { found = true; r.Y = Yt; r.alpha_du = ay; break; }
+    }
+    if (!found) return r;
+    for (int t = 0; t < N; ++t) {
+      cost_new += running_cost(r.X[t], r.U[t], t);
+      for (auto &cd : cons) {
+        r.G[t].setSegment(cd.offset, con_g(cd, r.X[t], r.U[t]));
+        double lsum = 0.0, l1 = 0.0;
+        for (int i = 0; i < cd.dual_dim; ++i) { const int j = cd.offset + i; lsum += olog(r.S[t](j)); l1 += std::fabs(r.G[t](j) + r.S[t](j)); }
+        merit_new -= mu * lsum; cv_new += l1;
+      }
+      cv_new += (r.F[t] - r.X[t + 1]).lpNorm1();
+    }
+    cost_new += terminal_cost(r.X.back());
+    merit_new += cost_new;
+    if (ms_filter_acceptable(merit_new, cv_new, a * dV[0])) {
+      r.success = true; r.cost = cost_new; r.merit = merit_new; r.theta = cv_new; r.has_ip = true;
+    }
+    return r;
+  }
+  void msipddp_apply(const FPResult &r) {    // applyForwardPassResult :287-304
+    X = r.X; U = r.U; cost = r.cost; merit = r.merit; alpha_pr = r.alpha_pr; alpha_du = r.alpha_du;
+    if (r.has_ip) { Y = r.Y; S = r.S; G = r.G; }
+    ms_F = r.F; Lambda = r.Lambda;
+    acceptFilterEntry(r.merit, r.theta);
+  }
+  bool msipddp_checkConvergence(double dJ, int iter, int &st) {   // :306-364
+    const double metric = std::max(std::max(ms_scaled_inf_du(), inf_pr), inf_comp);
+    if (metric <= opt.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; return true; }
+    if (std::fabs(dJ) < opt.acceptable_tolerance && iter > 10) {
+      const double sq = std::sqrt(opt.acceptable_tolerance);
+      if (inf_pr < sq && inf_comp < sq) { st = CDDP_HIP_STATUS_ACCEPTABLE; return true; }
+    }
+    if (iter >= 1 && step_norm < opt.tolerance * 10.0 && inf_pr < 1e-4) { st = CDDP_HIP_STATUS_ACCEPTABLE; return true; }
+    return false;
+  }
+  bool msipddp_handleForwardPassFailure(int &st) {   // :371-398, checkAndPerformFilterRestoration :810-836
+    bool needs = filter.size() > 5;
+    if (!needs) for (auto &p : filter) if (!std::isfinite(p.merit_function) || !std::isfinite(p.constraint_violation)) { needs = true; break; }
+    if (needs && !filter.empty()) { pruneFilterToBestPoints(); return false; }
+    increaseRegularization();
+    if (isRegularizationLimitReached()) { st = CDDP_HIP_STATUS_REG_LIMIT; return true; }
+    return false;
+  }
+  void msipddp_update_barrier(bool fp_success) {   // updateBarrierParameters :1751-1850
+    if (cons.empty()) return;
+    if (opt.barrier_strategy == CDDP_HIP_BARRIER_MONOTONIC) {
+      mu = std::max(opt.barrier_mu_min_value, opt.barrier_mu_update_factor * mu);
+      ms_reset_filter();
+    } else if (opt.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
+      const double err = std::max(std::max(ms_scaled_inf_du(), inf_pr), inf_comp);
+      if (err <= 10.0 * mu) {
+        const double lin = opt.barrier_mu_update_factor * mu, sup = opow(mu, opt.barrier_mu_update_power);
+        mu = std::max(opt.tolerance / 10.0, std::min(lin, sup));
+        ms_reset_filter();
+      }
+    } else {
+      const double metric = std::max(std::max(ms_scaled_inf_du(), inf_pr), inf_comp);
+      const double threshold = (mu < 1e-5) ? std::max(metric * 10.0, mu * 100.0) : std::max(opt.barrier_mu_update_factor * mu, mu * 2.0);
+      const bool slow = fp_success && alpha_pr > 0 && (metric < 1e-3);
+      if (metric <= threshold || slow) {
+        double factor = opt.barrier_mu_update_factor;
+        if (mu > 1e-12) {
+          const double ratio = metric / mu;
+          if (ratio < 0.01) factor = opt.barrier_mu_update_factor * 0.1;
+          else if (ratio < 0.1) factor = opt.barrier_mu_update_factor * 0.3;
+          else if (ratio < 0.5) factor = opt.barrier_mu_update_factor * 0.6;
+        }
+        const double lin = factor * mu, sup = opow(mu, opt.barrier_mu_update_power);
+        if (slow && mu > opt.tolerance) mu = std::min(lin, sup);
+        else mu = std::max(opt.tolerance / 100.0, std::min(lin, sup));
+        ms_reset_filter();
+      }
+    }
+  }
+
   // =============================================================== dispatch + main loop
-  void initialize() { if (solver_kind == CDDP_HIP_SOLVER_CLDDP) clddp_initialize(); else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) logddp_initialize(); else ipddp_initialize(); }
-  bool backwardPass() { return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_backward() : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_backward() : ipddp_backward(); }
-  FPResult forwardPass(double a) { ++n_forward; return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_forward(a) : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_forward(a) : ipddp_forward(a); }
+  void initialize() {
+    if (solver_kind == CDDP_HIP_SOLVER_CLDDP) clddp_initialize(); else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) logddp_initialize();
+    else if (solver_kind == CDDP_HIP_SOLVER_MSIPDDP) msipddp_initialize(); else ipddp_initialize();
+  }
+  bool backwardPass() {
+    return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_backward() : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_backward()
+         : solver_kind == CDDP_HIP_SOLVER_MSIPDDP ? msipddp_backward() : ipddp_backward();
+  }
+  FPResult forwardPass(double a) {
+    ++n_forward;
+    return solver_kind == CDDP_HIP_SOLVER_CLDDP ? clddp_forward(a) : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? logddp_forward(a)
+         : solver_kind == CDDP_HIP_SOLVER_MSIPDDP ? msipddp_forward(a) : ipddp_forward(a);
+  }
 
   void recordHistory() {  // cddp_solver_base.cpp:220-232, ipddp_solver.cpp:2084-2088
     if (!opt.return_iteration_info) return;
     history.rows.push_back({cost, merit, alpha_pr, alpha_du, inf_du, inf_pr, inf_comp,
-                            solver_kind == CDDP_HIP_SOLVER_IPDDP ? mu : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? lg_mu : 0.0, reg});
+                            (solver_kind == CDDP_HIP_SOLVER_IPDDP || solver_kind == CDDP_HIP_SOLVER_MSIPDDP) ? mu : solver_kind == CDDP_HIP_SOLVER_LOGDDP ? lg_mu : 0.0, reg});
   }
 
   FPResult performForwardPass() {  // cddp_solver_base.cpp:248-317
@@ -1581,7 +2023,7 @@ struct Solver {
       if (!backward_ok) break;
       bool early = false;
       if (solver_kind == CDDP_HIP_SOLVER_CLDDP) { if (inf_du < opt.tolerance) { reason = CDDP_HIP_STATUS_OPTIMAL; early = true; } }
-      else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) early = false;   // base default (cddp_solver_base.hpp)
+      else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP || solver_kind == CDDP_HIP_SOLVER_MSIPDDP) early = false;   // base default (cddp_solver_base.hpp)
       else early = ipddp_checkEarlyConvergence(reason);
       if (early) { converged = true; recordHistory(); break; }
       FPResult best = performForwardPass();
@@ -1591,7 +2033,8 @@ struct Solver {
         if (solver_kind == CDDP_HIP_SOLVER_CLDDP || solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // cddp_solver_base.cpp:190-198
           X = best.X; U = best.U; cost = best.cost; merit = best.merit; alpha_pr = best.alpha_pr; alpha_du = best.alpha_du;
           if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) lg_violation = best.inf_pr;   // logddp_solver.cpp:224-231
-        } else ipddp_apply(best);
+        } else if (solver_kind == CDDP_HIP_SOLVER_MSIPDDP) msipddp_apply(best);
+        else ipddp_apply(best);
         recordHistory();
         decreaseRegularization();
         if (solver_kind == CDDP_HIP_SOLVER_CLDDP) {  // clddp_solver.cpp:264-277
@@ -1600,19 +2043,22 @@ struct Solver {
         } else if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // logddp_solver.cpp:233-261
           if (std::max(inf_du, inf_pr) <= opt.tolerance) { reason = CDDP_HIP_STATUS_OPTIMAL; converged = true; }
           else if (std::fabs(dJ) < opt.acceptable_tolerance && std::fabs(dL) < opt.acceptable_tolerance) { reason = CDDP_HIP_STATUS_ACCEPTABLE; converged = true; }
-        } else converged = ipddp_checkConvergence(dJ, iter, reason);
+        } else if (solver_kind == CDDP_HIP_SOLVER_MSIPDDP) converged = msipddp_checkConvergence(dJ, iter, reason);
+        else converged = ipddp_checkConvergence(dJ, iter, reason);
       } else {
         bool brk;
         if (solver_kind == CDDP_HIP_SOLVER_CLDDP || solver_kind == CDDP_HIP_SOLVER_LOGDDP) {  // cddp_solver_base.cpp:206-218
           increaseRegularization();
           brk = isRegularizationLimitReached();
           if (brk) reason = CDDP_HIP_STATUS_REG_LIMIT;
-        } else brk = ipddp_handleForwardPassFailure(reason);
+        } else if (solver_kind == CDDP_HIP_SOLVER_MSIPDDP) brk = msipddp_handleForwardPassFailure(reason);
+        else brk = ipddp_handleForwardPassFailure(reason);
         if (brk) break;
       }
       if (converged) break;
       // postIterationUpdate: IPDDP's only acts on failure, and then returns immediately (:2027-2035, :2556-2559); LogDDP's updates mu
       if (solver_kind == CDDP_HIP_SOLVER_LOGDDP) logddp_post_iteration(fp_success);
+      if (solver_kind == CDDP_HIP_SOLVER_MSIPDDP) msipddp_update_barrier(fp_success);   // postIterationUpdate (msipddp_solver.cpp:366-369)
     }
     iterations = iter; status = reason;
   }
@@ -1676,7 +2122,7 @@ static Solver *build(const cddp_hip_problem *p) {
 
 static void fill_result(const Solver *s, cddp_hip_result *r) {
   r->final_objective = s->cost; r->merit_function = s->merit; r->inf_pr = s->inf_pr; r->inf_du = s->inf_du;
-  r->inf_comp = s->inf_comp; r->barrier_mu = s->solver_kind == CDDP_HIP_SOLVER_IPDDP ? s->mu : s->solver_kind == CDDP_HIP_SOLVER_LOGDDP ? s->lg_mu : 0.0;
+  r->inf_comp = s->inf_comp; r->barrier_mu = (s->solver_kind == CDDP_HIP_SOLVER_IPDDP || s->solver_kind == CDDP_HIP_SOLVER_MSIPDDP) ? s->mu : s->solver_kind == CDDP_HIP_SOLVER_LOGDDP ? s->lg_mu : 0.0;
   r->regularization = s->reg; r->alpha_pr = s->alpha_pr; r->alpha_du = s->alpha_du; r->step_norm = s->step_norm;
   r->iterations = s->iterations; r->status = s->status; r->n_backward = s->n_backward; r->n_forward = s->n_forward;
 }

@@ -51,6 +51,7 @@ struct Mat {
   double operator()(int i) const { return a[i]; }
   int size() const { return r * c; }
   static Mat Zero(int r, int c = 1) { return Mat(r, c); }
+  static Mat Ones(int r, int c = 1) { Mat m(r, c); for (int i = 0; i < r * c; ++i) m.a[i] = 1.0; return m; }
   static Mat Identity(int n) { Mat m(n, n); for (int i = 0; i < n; ++i) m(i, i) = 1.0; return m; }
   static Mat FromPtr(const double *p, int r, int c = 1) {
     Mat m(r, c); for (int i = 0; i < r * c; ++i) m.a[i] = p[i]; return m;

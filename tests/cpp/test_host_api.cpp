@@ -365,6 +365,28 @@ static void gpu_tests() {
     EXPECT_TRUE(dist < std::sqrt(2.0) && dist < 0.05);   // reference: "Car should park reasonably close to the goal" (< 0.5)
     for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 0.5 && std::fabs(u[1]) <= 2.0);
   }
+  {   // f4: LogDDP and MSIPDDP through the same registry names (host loop + stack-fed GPU sweeps; logddp_solver.cpp, msipddp_solver.cpp)
+    EXPECT_TRUE(cddp::CDDP::isSolverRegistered("LogDDP") && cddp::CDDP::isSolverRegistered("MSIPDDP"));
+    cddp::CDDPOptions o2 = opt; o2.return_iteration_info = false; o2.max_iterations = 60;
+    for (const char *name : {"LogDDP", "MSIPDDP"}) {
+      cddp::CDDP solver = makePendulum(o2);
+      const double J0 = solver.getObjective().evaluate(std::vector<cddp::Vector>(101, cddp::Vector{3.14159265358979323846, 0.0}), std::vector<cddp::Vector>(100, cddp::Vector{0.0}));
+      cddp::CDDPSolution s = solver.solve(name);
+      std::cout << name << ": " << s.status_message << " iterations " << s.iterations_completed << " cost " << s.final_objective << "\n";
+      EXPECT_EQ(s.solver_name, std::string(name));
+      EXPECT_TRUE(s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");
+      EXPECT_TRUE(s.iterations_completed > 0 && s.final_objective < J0);
+      EXPECT_TRUE(std::fabs(s.state_trajectory.back()[0]) < 0.05);
+      for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 20.0 + 1e-9);
+    }
+    // multiple-shooting options travel: a hybrid rollout with segment length 10 still converges
+    o2.msipddp.rollout_type = "hybrid"; o2.msipddp.segment_length = 10;
+    cddp::CDDP solver = makePendulum(o2);
+    cddp::CDDPSolution s = solver.solve(cddp::SolverType::MSIPDDP);
+    EXPECT_TRUE(s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");
+    cddp_hip_options pod = o2.toPOD(true);
+    EXPECT_EQ(pod.msipddp_rollout_type, 2); EXPECT_EQ(pod.msipddp_segment_length, 10);
+  }
   {   // a layout that is not instantiated on the device: loud error, never a silent fallback
     cddp::CDDP solver = makePendulum(opt);
     solver.addPathConstraint("Extra", std::make_unique<cddp::BallConstraint>(0.5, cddp::Vector{1.0, 1.0}));

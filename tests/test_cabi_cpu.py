@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(api, lib):
 
 
 def test_abi_version_and_status_strings(api, lib):
-    assert lib.cddp_hip_abi_version() == api.ABI_VERSION == 3
+    assert lib.cddp_hip_abi_version() == api.ABI_VERSION == 4
     want = ["Running", "OptimalSolutionFound", "AcceptableSolutionFound", "MaxIterationsReached",
             "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached"]
     for i, w in enumerate(want):
