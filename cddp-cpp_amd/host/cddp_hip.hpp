@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <functional>
 #include <limits>
+#include <iostream>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -280,6 +281,10 @@ class Objective {                       // objective.hpp:30-120
   virtual Matrix getRunningCostControlHessian(const Vector &x, const Vector &u, int index) const = 0;
   virtual Matrix getRunningCostCrossHessian(const Vector &x, const Vector &u, int index) const = 0;   // nu x nx
   virtual Matrix getFinalCostHessian(const Vector &x) const = 0;
+  // objective.hpp:60-75: the context pushes its reference state / trajectory into the objective (cddp_core.cpp:56-60, 75-100, 115-124)
+  virtual void setReferenceState(const Vector &) {}
+  virtual void setReferenceStates(const std::vector<Vector> &) {}
+  virtual Vector getReferenceState() const { return {}; }
 };
 class QuadraticObjective : public Objective {   // objective.hpp: (Q, R, Qf, reference_state, reference_states, timestep)
  public:
@@ -326,6 +331,9 @@ class QuadraticObjective : public Objective {   // objective.hpp: (Q, R, Qf, ref
   Matrix getRunningCostControlHessian(const Vector &, const Vector &, int) const override { return (R_ * timestep_) * 2.0; }
   Matrix getRunningCostCrossHessian(const Vector &, const Vector &, int) const override { return Matrix(R_.rows, Q_.rows); }
   Matrix getFinalCostHessian(const Vector &) const override { return Qf_ * 2.0; }
+  void setReferenceState(const Vector &r) override { reference_state_ = r; }                      // objective.hpp:170-176
+  void setReferenceStates(const std::vector<Vector> &rs) override { reference_states_ = rs; }
+  Vector getReferenceState() const override { return reference_state_; }
   Matrix Q_, R_, Qf_; Vector reference_state_; std::vector<Vector> reference_states_; double timestep_;
  private:
   const Vector &ref(int index) const { return reference_states_.empty() ? reference_state_ : reference_states_[index]; }
@@ -531,6 +539,7 @@ class TerminalConstraint {
  public:
   virtual ~TerminalConstraint() = default;
   virtual void fill(cddp_hip_terminal_constraint &c) const = 0;
+  virtual int getDualDim() const { cddp_hip_terminal_constraint c; std::memset(&c, 0, sizeof(c)); fill(c); return c.dim; }
 };
 class TerminalEqualityConstraint : public TerminalConstraint {   // terminal_constraint.hpp:62-158
  public:
@@ -571,25 +580,64 @@ class CDDP {
        std::unique_ptr<DynamicalSystem> system = nullptr, std::unique_ptr<Objective> objective = nullptr,
        const CDDPOptions &options = CDDPOptions())
       : initial_state_(initial_state), reference_state_(reference_state), horizon_(horizon), timestep_(timestep),
-        system_(std::move(system)), objective_(std::move(objective)), options_(options) {}
+        system_(std::move(system)), objective_(std::move(objective)), options_(options) {
+    alpha_pr_ = options.line_search.initial_step_size; regularization_ = options.regularization.initial_value;
+    if (objective_ && !reference_state_.empty() && !isZero(reference_state_)) objective_->setReferenceState(reference_state_);   // cddp_core.cpp:56-60
+  }
 
-  void setDynamicalSystem(std::unique_ptr<DynamicalSystem> s) { system_ = std::move(s); }
-  void setObjective(std::unique_ptr<Objective> o) { objective_ = std::move(o); }
+  // --- setters, as cddp_core.cpp:62-212 writes them
+  void setDynamicalSystem(std::unique_ptr<DynamicalSystem> s) { system_ = std::move(s); initialized_ = false; }
+  void setObjective(std::unique_ptr<Objective> o) {                       // :115-124
+    objective_ = std::move(o);
+    if (objective_ && !reference_states_.empty()) { objective_->setReferenceState(reference_state_); objective_->setReferenceStates(reference_states_); }
+    else if (objective_ && !reference_state_.empty() && !isZero(reference_state_)) objective_->setReferenceState(reference_state_);
+  }
   void setOptions(const CDDPOptions &o) { options_ = o; }
-  void setInitialState(const Vector &x0) { initial_state_ = x0; }
-  void setHorizon(int h) { horizon_ = h; }
+  void setInitialState(const Vector &x0) {                                // :68-76
+    initial_state_ = x0;
+    if (!X_.empty() && X_[0].size() == x0.size()) X_[0] = initial_state_;
+  }
+  void setReferenceState(const Vector &r) {                               // :78-86
+    reference_state_ = r;
+    if (objective_) objective_->setReferenceState(reference_state_);
+    reference_states_.clear(); reference_states_.push_back(reference_state_);
+  }
+  void setReferenceStates(const std::vector<Vector> &rs) {                // :88-100
+    reference_states_ = rs;
+    if (!reference_states_.empty()) reference_state_ = reference_states_.back();
+    if (objective_) {
+      if (!reference_states_.empty()) objective_->setReferenceState(reference_state_);
+      objective_->setReferenceStates(reference_states_);
+    }
+  }
+  void setHorizon(int h) { horizon_ = h; initialized_ = false; }
   void setTimestep(double dt) { timestep_ = dt; }
-  void setInitialTrajectory(const std::vector<Vector> &X, const std::vector<Vector> &U) { X_ = X; U_ = U; }
+  void setInitialTrajectory(const std::vector<Vector> &X, const std::vector<Vector> &U) {   // :126-141
+    if ((int)X.size() != horizon_ + 1 || (int)U.size() != horizon_) std::cerr << "Warning: Provided initial trajectory dimensions do not match horizon." << std::endl;
+    X_ = X; U_ = U;
+    if (!X_.empty()) initial_state_ = X_[0];
+  }
   void addPathConstraint(std::string name, std::unique_ptr<Constraint> c) {
     if (!c) throw std::runtime_error("Cannot add null constraint.");   // cddp_context_utils.cpp:82-84
-    path_constraint_set_[name] = std::move(c);
+    path_constraint_set_[name] = std::move(c); initialized_ = false;
   }
-  bool removePathConstraint(const std::string &name) { return path_constraint_set_.erase(name) > 0; }
+  bool removePathConstraint(const std::string &name) { const bool r = path_constraint_set_.erase(name) > 0; if (r) initialized_ = false; return r; }
   void addTerminalConstraint(std::string name, std::unique_ptr<TerminalConstraint> c) {
     if (!c) throw std::runtime_error("Cannot add null constraint.");
-    terminal_constraint_set_[name] = std::move(c);
+    terminal_constraint_set_[name] = std::move(c); initialized_ = false;
   }
-  int getTotalDualDim() const { int m = 0; for (auto &kv : path_constraint_set_) m += kv.second->getDualDim(); return m; }
+  bool removeTerminalConstraint(const std::string &name) { const bool r = terminal_constraint_set_.erase(name) > 0; if (r) initialized_ = false; return r; }
+  // total_dual_dim_ of cddp_core.cpp:161-198: path AND terminal entries, replacement subtracts the old entry
+  int getTotalDualDim() const {
+    int m = 0;
+    for (auto &kv : path_constraint_set_) m += kv.second->getDualDim();
+    for (auto &kv : terminal_constraint_set_) m += kv.second->getDualDim();
+    return m;
+  }
+  int getStateDim() const { if (!system_) throw std::runtime_error("Dynamical system not set."); return system_->getStateDim(); }
+  int getControlDim() const { if (!system_) throw std::runtime_error("Dynamical system not set."); return system_->getControlDim(); }
+  const Vector &getReferenceState() const { return reference_state_; }
+  const std::vector<Vector> &getReferenceStates() const { return reference_states_; }
   const CDDPOptions &getOptions() const { return options_; }
   int getHorizon() const { return horizon_; }
   double getTimestep() const { return timestep_; }
@@ -632,7 +680,9 @@ class CDDP {
 
  private:
   static std::map<std::string, Factory> &registry() { static std::map<std::string, Factory> r; return r; }
-  Vector initial_state_, reference_state_; int horizon_; double timestep_;
+  static bool isZero(const Vector &v) { for (double x : v) if (x != 0.0) return false; return true; }
+  Vector initial_state_, reference_state_; std::vector<Vector> reference_states_; int horizon_; double timestep_;
+  bool initialized_ = false;
   std::unique_ptr<DynamicalSystem> system_; std::unique_ptr<Objective> objective_; CDDPOptions options_;
   std::map<std::string, std::unique_ptr<Constraint>> path_constraint_set_;          // std::map: name order == dual stacking order
   std::map<std::string, std::unique_ptr<TerminalConstraint>> terminal_constraint_set_;
@@ -876,11 +926,24 @@ inline void registerHipSolvers(int device = 0) {
 }
 
 inline void CDDP::initializeProblemIfNecessary() {   // cddp_core.cpp:272-306
+  if (initialized_) return;
   if (!system_) throw std::runtime_error("Dynamical system must be set before solving.");
   if (!objective_) throw std::runtime_error("Objective function must be set before solving.");
+  const int nx = system_->getStateDim(), nu = system_->getControlDim();
+  auto compatible = [](const std::vector<Vector> &tr, int n, int dim) {   // detail::hasCompatibleVectorLayout (cddp_context_utils.cpp:40-57)
+    if ((int)tr.size() != n) return false;
+    for (auto &v : tr) if ((int)v.size() != dim) return false;
+    return true;
+  };
+  // (the reference keeps a compatible trajectory only under warm_start and otherwise re-shapes a stale one; a compatible
+  //  trajectory a caller provided through setInitialTrajectory has the right shape already and is left alone by ensureTrajectoryShape)
+  if (!compatible(X_, horizon_ + 1, nx)) X_.assign((size_t)horizon_ + 1, Vector(nx, 0.0));
+  if (!compatible(U_, horizon_, nu)) U_.assign((size_t)horizon_, Vector(nu, 0.0));
+  X_[0] = initial_state_;
   const double inf = std::numeric_limits<double>::infinity();
   cost_ = merit_function_ = inf_pr_ = inf_du_ = inf_comp_ = inf;
   regularization_ = options_.regularization.initial_value;
+  initialized_ = true;
 }
 
 inline void CDDP::flatten(int solver, Flat &f) const {

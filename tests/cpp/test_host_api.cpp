@@ -143,6 +143,69 @@ static void cpu_tests() {
     EXPECT_TRUE(solver.removePathConstraint("Obstacle"));
     EXPECT_EQ(solver.getTotalDualDim(), 2);
   }
+  {   // the CDDP container, replayed from tests/cddp_core/test_cddp_core.cpp (unicycle, horizon 10, dt 0.1 of its fixture :236-262)
+    const int horizon = 10, nx = 3, nu = 2; const double dt = 0.1;
+    const cddp::Vector x0 = {0.0, 0.0, 0.0}, goal = {1.0, 1.0, 0.0};
+    cddp::CDDPOptions o; o.verbose = false;
+    auto mkObj = [&] { return std::make_unique<cddp::QuadraticObjective>(cddp::Matrix::Identity(nx), cddp::Matrix::Identity(nu), 10.0 * cddp::Matrix::Identity(nx), goal, std::vector<cddp::Vector>{}, dt); };
+    {   // :547-577 SolveReinitializesStaleTrajectoryDimensions
+      cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Unicycle>(dt, "euler"), mkObj(), o);
+      c.X_.assign((size_t)horizon + 1, cddp::Vector(nx + 1, 0.0)); c.U_.assign((size_t)horizon, cddp::Vector(nu + 1, 0.0));
+      cddp::CDDPSolution s = c.solve("MockSolver");
+      EXPECT_EQ(s.status_message, std::string("MockSolved"));
+      EXPECT_EQ((int)c.X_.size(), horizon + 1); EXPECT_EQ((int)c.U_.size(), horizon);
+      for (auto &x : c.X_) EXPECT_EQ((int)x.size(), nx);
+      for (auto &u : c.U_) EXPECT_EQ((int)u.size(), nu);
+      EXPECT_TRUE(c.X_.front() == x0);
+    }
+    {   // :579-606 SetReferenceStatesUpdatesObjectiveTerminalReference
+      cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Unicycle>(dt, "euler"), mkObj(), o);
+      std::vector<cddp::Vector> refs((size_t)horizon + 1, cddp::Vector(nx, 0.0));
+      for (int k = 0; k <= horizon; ++k) refs[k] = {0.1 * k, 0.2 * k, 0.3 * k};
+      c.setReferenceStates(refs);
+      EXPECT_TRUE(c.getReferenceState() == refs.back());
+      EXPECT_TRUE(std::fabs(c.getObjective().running_cost(refs.front(), cddp::Vector(nu, 0.0), 0)) < 1e-12);
+      EXPECT_TRUE(std::fabs(c.getObjective().terminal_cost(refs.back())) < 1e-12);
+    }
+    {   // :608-635 SetObjectiveUsesExistingReferenceTrajectoryTerminalState
+      cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Unicycle>(dt, "euler"), nullptr, o);
+      std::vector<cddp::Vector> refs((size_t)horizon + 1, cddp::Vector(nx, 0.0));
+      for (int k = 0; k < horizon; ++k) refs[k] = {1.0 + 0.1 * k, 0.5 + 0.1 * k, 0.2 + 0.1 * k};
+      c.setReferenceStates(refs);
+      c.setObjective(mkObj());
+      EXPECT_TRUE(std::fabs(c.getObjective().running_cost(refs.front(), cddp::Vector(nu, 0.0), 0)) < 1e-12);
+      EXPECT_TRUE(std::fabs(c.getObjective().terminal_cost(refs.back())) < 1e-12);
+    }
+    {   // :637-677 ReplacingConstraintsKeepsTotalDualDimensionAccurate (path AND terminal entries)
+      struct FixedDualDim final : cddp::TerminalConstraint {
+        explicit FixedDualDim(int d) : d_(d) {}
+        void fill(cddp_hip_terminal_constraint &c) const override { c.kind = CDDP_HIP_TERM_EQUALITY; c.dim = d_; }
+        int getDualDim() const override { return d_; }
+        int d_;
+      };
+      cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Unicycle>(dt, "euler"), mkObj(), o);
+      c.addPathConstraint("RepeatedPathConstraint", std::make_unique<cddp::ControlConstraint>(cddp::Vector(nu, -1.0), cddp::Vector(nu, 1.0)));
+      EXPECT_EQ(c.getTotalDualDim(), 2 * nu);
+      c.addPathConstraint("RepeatedPathConstraint", std::make_unique<cddp::ControlConstraint>(cddp::Vector(1, -1.0), cddp::Vector(1, 1.0)));
+      EXPECT_EQ(c.getTotalDualDim(), 2);
+      c.addTerminalConstraint("RepeatedTerminalConstraint", std::make_unique<FixedDualDim>(nx));
+      EXPECT_EQ(c.getTotalDualDim(), 2 + nx);
+      c.addTerminalConstraint("RepeatedTerminalConstraint", std::make_unique<FixedDualDim>(1));
+      EXPECT_EQ(c.getTotalDualDim(), 3);
+      EXPECT_TRUE(c.removePathConstraint("RepeatedPathConstraint"));
+      EXPECT_EQ(c.getTotalDualDim(), 1);
+      EXPECT_TRUE(c.removeTerminalConstraint("RepeatedTerminalConstraint"));
+      EXPECT_EQ(c.getTotalDualDim(), 0);
+    }
+    {   // setInitialTrajectory makes X[0] the initial state (:126-141); setInitialState updates a compatible X[0] (:68-76)
+      cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Unicycle>(dt, "euler"), mkObj(), o);
+      std::vector<cddp::Vector> X((size_t)horizon + 1, cddp::Vector{0.5, -0.5, 0.1}), U((size_t)horizon, cddp::Vector(nu, 0.0));
+      c.setInitialTrajectory(X, U);
+      EXPECT_TRUE(c.getInitialState() == X[0]);
+      c.setInitialState({0.2, 0.3, 0.4});
+      EXPECT_TRUE(c.X_[0] == (cddp::Vector{0.2, 0.3, 0.4}));
+    }
+  }
   {   // missing system / objective -> runtime_error with the reference's messages (cddp_core.cpp:277-282)
     cddp::CDDP bare(cddp::Vector{0.0}, cddp::Vector{0.0}, 4, 1.0);
     bool threw = false;
