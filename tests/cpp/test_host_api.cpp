@@ -428,6 +428,55 @@ static void gpu_tests() {
     EXPECT_TRUE(dist < std::sqrt(2.0) && dist < 0.05);   // reference: "Car should park reasonably close to the goal" (< 0.5)
     for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 0.5 && std::fabs(u[1]) <= 2.0);
   }
+  {   // the car-parking tests of the other two solvers: CLDDP (tests/cddp_core/test_clddp_solver.cpp:373-568: controls 0.01 everywhere, 500
+      // iterations, tolerances 1e-6, regularisation 1e-6; warm start with 20 iterations) and LogDDP (test_logddp_solver.cpp:492-691: zero
+      // controls, 1000 iterations, best-merit line search, delta 1e-5, mu 0.1 x 0.2, regularisation 1e-7; warm start with 100 iterations),
+      // with the reference's assertions.  Same noise caveat as the IPDDP replay above for anything tighter than those assertions.
+    const int horizon = 500; const double dt = 0.03;
+    const cddp::Vector x0 = {1.0, 1.0, 1.5 * 3.14159265358979323846, 0.0}, goal = {0.0, 0.0, 0.0, 0.0};
+    struct Case { const char *name; double u0; int it, warm_it, warm_slack; };
+    for (const Case &cs : {Case{"CLDDP", 0.01, 500, 20, 10}, Case{"LogDDP", 0.0, 1000, 100, 10}}) {
+      cddp::CDDPOptions o; o.max_iterations = cs.it; o.tolerance = 1e-6; o.acceptable_tolerance = 1e-6; o.verbose = false;
+      if (std::string(cs.name) == "CLDDP") o.regularization.initial_value = 1e-6;
+      else {
+        o.enable_parallel = true; o.num_threads = 10; o.regularization.initial_value = 1e-7;
+        o.log_barrier.relaxed_log_barrier_delta = 1e-5; o.log_barrier.barrier.mu_initial = 1e-1; o.log_barrier.barrier.mu_update_factor = 0.2; o.log_barrier.barrier.mu_update_power = 1.2;
+      }
+      cddp::Car car(dt, 2.0, "euler");
+      CarParkingObjective cost(goal, dt);
+      std::vector<cddp::Vector> X(horizon + 1, x0), U(horizon, cddp::Vector{cs.u0, cs.u0});
+      for (int t = 0; t < horizon; ++t) X[t + 1] = car.getDiscreteDynamics(X[t], U[t], t * dt);
+      const double J0 = cost.evaluate(X, U);
+      auto mk = [&](const cddp::CDDPOptions &oo) {
+        cddp::CDDP c(x0, goal, horizon, dt, std::make_unique<cddp::Car>(dt, 2.0, "euler"), std::make_unique<CarParkingObjective>(goal, dt), oo);
+        c.addPathConstraint("ControlConstraint", std::make_unique<cddp::ControlConstraint>(cddp::Vector{-0.5, -2.0}, cddp::Vector{0.5, 2.0}));
+        return c;
+      };
+      cddp::CDDP solver = mk(o);
+      solver.setInitialTrajectory(X, U);
+      cddp::CDDPSolution s = solver.solve(cs.name);
+      const cddp::Vector &xf = s.state_trajectory.back();
+      const double dist = std::sqrt(xf[0] * xf[0] + xf[1] * xf[1]);
+      std::cout << cs.name << " car parking (reference test replay): " << s.status_message << " iterations " << s.iterations_completed << " cost " << s.final_objective
+                << " (initial " << J0 << ") distance " << dist << "\n";
+      EXPECT_TRUE(s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");   // "Algorithm should converge"
+      EXPECT_TRUE(s.iterations_completed > 0);
+      EXPECT_TRUE(s.final_objective < J0);                                                                          // "better than initial cost"
+      EXPECT_TRUE(dist < std::sqrt(2.0) && dist < 0.5);                                                             // "closer to the goal", "park reasonably close"
+      // CLDDP clamps its controls into the box.  LogDDP's RELAXED barrier is a quadratic penalty of weight mu / delta^2 beyond the bound
+      // (barrier.hpp:247-262) and mu falls by 0.2 per accepted step towards mu_min_value = 1e-10 (weight 1 at delta = 1e-5): late iterates
+      // leave the box, in the reference too -- its test does not bound the controls, and neither does this replay (the excess is printed)
+      if (std::string(cs.name) == "CLDDP") for (auto &u : s.control_trajectory) EXPECT_TRUE(std::fabs(u[0]) <= 0.5 + 1e-9 && std::fabs(u[1]) <= 2.0 + 1e-9);
+      else { double ex = 0.0; for (auto &u : s.control_trajectory) ex = std::max(ex, std::max(std::fabs(u[0]) - 0.5, std::fabs(u[1]) - 2.0)); std::cout << "LogDDP car parking: largest control excess over the box " << ex << "\n"; }
+      cddp::CDDPOptions ow = o; ow.warm_start = true; ow.max_iterations = cs.warm_it;
+      cddp::CDDP warm = mk(ow);
+      warm.setInitialTrajectory(s.state_trajectory, s.control_trajectory);
+      cddp::CDDPSolution w = warm.solve(cs.name);
+      std::cout << cs.name << " car parking, warm start: " << w.status_message << " iterations " << w.iterations_completed << " cost " << w.final_objective << "\n";
+      EXPECT_TRUE(w.status_message == "OptimalSolutionFound" || w.status_message == "AcceptableSolutionFound");   // "Warm start should also converge"
+      EXPECT_TRUE(w.iterations_completed <= s.iterations_completed + cs.warm_slack);
+    }
+  }
   {   // f4: LogDDP and MSIPDDP through the same registry names (host loop + stack-fed GPU sweeps; logddp_solver.cpp, msipddp_solver.cpp)
     EXPECT_TRUE(cddp::CDDP::isSolverRegistered("LogDDP") && cddp::CDDP::isSolverRegistered("MSIPDDP"));
     cddp::CDDPOptions o2 = opt; o2.return_iteration_info = false; o2.max_iterations = 60;
