@@ -394,6 +394,40 @@ struct BicycleModel {
   }
 };
 
+// ================================================================================ HCW (spacecraft_linear.cpp)
+// Hill-Clohessy-Wiltshire equations of relative orbital motion: state [x, y, z, vx, vy, vz] (radial, along-track, cross-track), control
+// [Fx, Fy, Fz]; params: mean motion n, mass.  Linear and time-invariant in continuous time: constant Jacobians (:56-83), zero Hessians
+// (:85-120).
+struct HCWModel {
+  static constexpr int ID = CDDP_HIP_MODEL_HCW, NX = 6, NU = 3;
+  static constexpr bool kDiscrete = false;
+  static constexpr bool kHasHess = true;
+  DEV static void f(const double *p, const double *x, const double *u, double *xd) {
+    const double n = p[0], n2 = n * n, mass = p[1];
+    xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+    xd[3] = 2.0 * n * x[4] + 3.0 * n2 * x[0] + u[0] / mass;
+    xd[4] = -2.0 * n * x[3] + u[1] / mass;
+    xd[5] = -n2 * x[2] + u[2] / mass;
+  }
+  DEV static void jac(const double *p, const double *, const double *, double *Fx, double *Fu) {
+    const double n = p[0], n2 = n * n, mass = p[1];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Fx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) Fu[i] = 0.0;
+    Fx[0 * NX + 3] = 1.0; Fx[1 * NX + 4] = 1.0; Fx[2 * NX + 5] = 1.0;
+    Fx[3 * NX + 0] = 3.0 * n2; Fx[3 * NX + 4] = 2.0 * n;
+    Fx[4 * NX + 3] = -2.0 * n;
+    Fx[5 * NX + 2] = -n2;
+    Fu[3 * NU + 0] = 1.0 / mass; Fu[4 * NU + 1] = 1.0 / mass; Fu[5 * NU + 2] = 1.0 / mass;
+  }
+  DEV static void hess(const double *, const double *, const double *, double *Fxx, double *Fuu, double *Fux) {
+    for (int i = 0; i < NX * NX * NX; ++i) Fxx[i] = 0.0;
+    for (int i = 0; i < NX * NU * NU; ++i) Fuu[i] = 0.0;
+    for (int i = 0; i < NX * NU * NX; ++i) Fux[i] = 0.0;
+  }
+};
+
 // ================================================================================ Car (car.cpp)
 // A DISCRETE plant: getDiscreteDynamics is overridden (:24-60) and everything else differentiates it -- Jacobians are the autodiff
 // gradient of the discrete map with J.diagonal() -= 1 and J /= timestep (:62-111), Hessians its autodiff Hessian / timestep

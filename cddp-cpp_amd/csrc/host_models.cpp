@@ -59,6 +59,7 @@ int cddp_host_model_eval(int model, int integrator, double dt, const double *par
     case CDDP_HIP_MODEL_MANIPULATOR: return eval<ManipulatorModel>(integrator, dt, params, nx, nu, x, u, x_next, fx, fu, fxx, fuu, fux, err);
     case CDDP_HIP_MODEL_MANIPULATOR7: return eval<Manip7Model>(integrator, dt, params, nx, nu, x, u, x_next, fx, fu, fxx, fuu, fux, err);
     case CDDP_HIP_MODEL_BICYCLE: return eval<BicycleModel>(integrator, dt, params, nx, nu, x, u, x_next, fx, fu, fxx, fuu, fux, err);
+    case CDDP_HIP_MODEL_HCW: return eval<HCWModel>(integrator, dt, params, nx, nu, x, u, x_next, fx, fu, fxx, fuu, fux, err);
     case CDDP_HIP_MODEL_CAR: {   // a discrete plant: its step needs the timestep, which travels as params[1] (as in the device descriptor)
       double pc[CDDP_HIP_MAX_MODEL_PARAMS];
       for (int i = 0; i < CDDP_HIP_MAX_MODEL_PARAMS; ++i) pc[i] = params[i];

@@ -255,6 +255,9 @@ struct Quadrotor : DynamicalSystem {  // quadrotor.hpp: (timestep, mass, inertia
   Quadrotor(double dt, double mass, const Matrix &inertia, double arm_length, std::string integ = "rk4")
       : DynamicalSystem(CDDP_HIP_MODEL_QUADROTOR, 13, 4, dt, integ) { params = {mass, arm_length, inertia(0, 0), inertia(1, 1), inertia(2, 2), 9.81}; }
 };
+struct HCW : DynamicalSystem {        // spacecraft_linear.hpp:33: (timestep, mean_motion, mass, integration_type); state [x, y, z, vx, vy, vz], control [Fx, Fy, Fz]
+  HCW(double dt, double mean_motion, double mass, std::string integ = "euler") : DynamicalSystem(CDDP_HIP_MODEL_HCW, 6, 3, dt, integ) { params = {mean_motion, mass}; }
+};
 struct Bicycle : DynamicalSystem {    // bicycle.hpp: (timestep, wheelbase, integration_type); state [x, y, theta, v], control [a, delta]
   Bicycle(double dt, double wheelbase, std::string integ = "euler") : DynamicalSystem(CDDP_HIP_MODEL_BICYCLE, 4, 2, dt, integ) { params = {wheelbase}; }
 };

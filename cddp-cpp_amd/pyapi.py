@@ -20,7 +20,7 @@ NAME_LEN = 48
 # enums (include/cddp_hip.h)
 MODEL_PENDULUM, MODEL_CARTPOLE, MODEL_UNICYCLE, MODEL_LTI = 0, 1, 2, 3
 MODEL_QUADROTOR, MODEL_MANIPULATOR, MODEL_QUADROTOR_EULER12, MODEL_MANIPULATOR7 = 4, 5, 6, 7
-MODEL_BICYCLE, MODEL_CAR = 8, 9
+MODEL_BICYCLE, MODEL_CAR, MODEL_HCW = 8, 9, 10
 EULER, HEUN, RK3, RK4 = 0, 1, 2, 3
 SOLVER_CLDDP, SOLVER_IPDDP, SOLVER_LOGDDP, SOLVER_MSIPDDP = 0, 1, 2, 3
 CON_CONTROL_BOX, CON_STATE_BOX, CON_BALL, CON_LINEAR = 0, 1, 2, 3
@@ -343,6 +343,20 @@ def unicycle_problem(solver=SOLVER_IPDDP, horizon=200, obstacle=True):
         p.add_ball("obstacle", 0.4, [1.0, 1.0])
     p.x0 = np.array([0.0, 0.0, np.pi / 4])
     p.U0_const = np.array([0.5, 0.1])
+    return p
+
+
+def hcw_problem(solver=SOLVER_IPDDP, horizon=80, constrained=True, integrator=None):
+    """Hill-Clohessy-Wiltshire rendezvous (src/dynamics_model/spacecraft_linear.cpp; orbit of tests/dynamics_model/test_spacecraft_linear.cpp:
+    500 km altitude, dt = 10 s, m = 1 kg as its DiscreteDynamics case): from its drifting initial state to the origin, thrust box."""
+    o = default_options(); o.max_iterations = 40; o.tolerance = 1e-5; o.acceptable_tolerance = 1e-6; o.reg_initial_value = 1e-6
+    n = float(np.sqrt(3.986004418e14 / (6371e3 + 500e3) ** 3))
+    dt = 10.0
+    p = Problem(solver, MODEL_HCW, RK4 if integrator is None else integrator, 6, 3, horizon, dt, np.diag([1e-4] * 3 + [1e-2] * 3), 1.0 * np.eye(3),
+                np.diag([10.0] * 3 + [100.0] * 3), np.zeros(6), model_params=[n, 1.0], options=o)
+    if constrained:
+        p.add_control_box("ControlConstraint", -0.5 * np.ones(3), 0.5 * np.ones(3))
+    p.x0 = np.array([-37.59664132226163, 27.312455860666148, 13.656227930333074, 0.015161970413423813, 0.08348413138390476, 0.04174206569195238])
     return p
 
 

@@ -234,6 +234,12 @@ class Quadrotor(_BuiltinPlant):   # :177-182
         self.params = [mass, arm_length, J[0, 0], J[1, 1], J[2, 2], 9.81]
 
 
+class HCW(_BuiltinPlant):           # spacecraft_linear.hpp:33: (timestep, mean_motion, mass, integration_type)
+    def __init__(self, timestep, mean_motion, mass, integration_type="euler"):
+        self.model = _api().MODEL_HCW
+        super().__init__(6, 3, timestep, integration_type); self.params = [mean_motion, mass]
+
+
 class Bicycle(_BuiltinPlant):       # bind_dynamics.cpp:143-146: (timestep, wheelbase, integration_type)
     def __init__(self, timestep, wheelbase, integration_type="euler"):
         self.model = _api().MODEL_BICYCLE

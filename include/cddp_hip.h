@@ -53,7 +53,9 @@ enum cddp_hip_model {
   CDDP_HIP_MODEL_QUADROTOR_EULER12 = 6, /* SYNTHETIC nx=12 (BASELINE config 4 shape)            */
   CDDP_HIP_MODEL_MANIPULATOR7 = 7,      /* SYNTHETIC nx=14/nu=7 (BASELINE config 5 shape)       */
   CDDP_HIP_MODEL_BICYCLE = 8,    /* kinematic bicycle [x,y,theta,v] / [a,delta] (bicycle.cpp); params: wheelbase            */
-  CDDP_HIP_MODEL_CAR = 9         /* DISCRETE car [x,y,theta,v] / [delta,a] (car.cpp:24-60, h = dt); params: wheelbase      */
+  CDDP_HIP_MODEL_CAR = 9,        /* DISCRETE car [x,y,theta,v] / [delta,a] (car.cpp:24-60, h = dt); params: wheelbase      */
+  CDDP_HIP_MODEL_HCW = 10        /* Hill-Clohessy-Wiltshire relative motion [x,y,z,vx,vy,vz] / [Fx,Fy,Fz] (spacecraft_linear.cpp:24-120);
+                                    params: mean_motion, mass                                                                  */
 };
 
 /* reference src/cddp_core/dynamical_system.cpp:28-83 */

@@ -358,6 +358,14 @@ struct Model {
       case CDDP_HIP_MODEL_QUADROTOR: quadrotor_f<double>(x, u, xd); break;
       case CDDP_HIP_MODEL_MANIPULATOR: manipulator_f(x, u, xd); break;
       case CDDP_HIP_MODEL_BICYCLE: bicycle_f<double>(x, u, xd); break;
+      case CDDP_HIP_MODEL_HCW: {   // spacecraft_linear.cpp:32-54; params: mean_motion, mass
+        const double n = p[0], n2 = n * n, mass = p[1];
+        xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+        xd[3] = 2.0 * n * x[4] + 3.0 * n2 * x[0] + u[0] / mass;
+        xd[4] = -2.0 * n * x[3] + u[1] / mass;
+        xd[5] = -n2 * x[2] + u[2] / mass;
+        break;
+      }
       case CDDP_HIP_MODEL_CAR: {   // DynamicalSystem::getContinuousDynamics default (dynamical_system.cpp:85-99): (x+ - x) / dt
         double xn[4]; car_next<double>(x, u, xn, false);
         for (int i = 0; i < 4; ++i) xd[i] = (xn[i] - x[i]) / dt;
@@ -449,6 +457,7 @@ struct Model {
         return true;
       }
       case CDDP_HIP_MODEL_LTI: return true;   // lti_system.cpp:94-115: zero
+      case CDDP_HIP_MODEL_HCW: return true;   // spacecraft_linear.cpp:85-120: zero
       case CDDP_HIP_MODEL_CARTPOLE:           // cartpole.cpp:191-199 -> DynamicalSystem defaults (dual2nd through the autodiff path)
         ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { cartpole_f<Dual2>(xs, us, xd, true); }, x, u, Fxx, Fuu, Fux);
         return true;
@@ -515,6 +524,13 @@ struct Model {
       case CDDP_HIP_MODEL_QUADROTOR:
         ad_jac([&](const Dual *xs, const Dual *us, Dual *xd) { quadrotor_f<Dual>(xs, us, xd); }, x, u, Fx, Fu);
         break;
+      case CDDP_HIP_MODEL_HCW: {       // spacecraft_linear.cpp:56-83
+        const double n = p[0], n2 = n * n, mass = p[1];
+        Fx(0, 3) = 1.0; Fx(1, 4) = 1.0; Fx(2, 5) = 1.0;
+        Fx(3, 0) = 3.0 * n2; Fx(3, 4) = 2.0 * n; Fx(4, 3) = -2.0 * n; Fx(5, 2) = -n2;
+        Fu(3, 0) = 1.0 / mass; Fu(4, 1) = 1.0 / mass; Fu(5, 2) = 1.0 / mass;
+        break;
+      }
       case CDDP_HIP_MODEL_BICYCLE: {   // bicycle.cpp:68-111 analytic
         const double L = p[0], theta = x(2), v = x(3), delta = u(1);
         Fx(0, 2) = -v * osin(theta); Fx(0, 3) = ocos(theta);

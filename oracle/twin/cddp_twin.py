@@ -278,6 +278,30 @@ class Bicycle:       # src/dynamics_model/bicycle.cpp:28-156: state [x, y, theta
         return Fxx, Fuu, Fux
 
 
+class HCW:           # src/dynamics_model/spacecraft_linear.cpp:24-120: Hill-Clohessy-Wiltshire relative motion, linear time-invariant
+    nx, nu = 6, 3
+
+    def __init__(self, mean_motion, mass):
+        n = mean_motion
+        self.A = np.zeros((6, 6)); self.B = np.zeros((6, 3))
+        self.A[0, 3] = self.A[1, 4] = self.A[2, 5] = 1.0
+        n2 = n * n                                           # the reference forms n2 first (spacecraft_linear.cpp:49, 60)
+        self.A[3, 0] = 3.0 * n2; self.A[3, 4] = 2.0 * n; self.A[4, 3] = -2.0 * n; self.A[5, 2] = -n2
+        self.B[3, 0] = self.B[4, 1] = self.B[5, 2] = 1.0 / mass
+        self.n, self.mass = n, mass
+
+    def f(self, x, u, t):
+        n = self.n; n2 = n * n
+        return np.array([x[3], x[4], x[5], 2.0 * n * x[4] + 3.0 * n2 * x[0] + u[0] / self.mass, -2.0 * n * x[3] + u[1] / self.mass,
+                         -n2 * x[2] + u[2] / self.mass])
+
+    def jac(self, x, u, t):
+        return self.A.copy(), self.B.copy()
+
+    def hess(self, x, u, t):
+        return _zeros_hess(6, 3)
+
+
 class Car:           # src/dynamics_model/car.cpp: a DISCRETE plant; state [x, y, theta, v], control [delta, a]
     nx, nu = 4, 2
     discrete = True

@@ -53,6 +53,15 @@ def _bicycle(solver, box, N=100, integrator="euler", **opt):   # pyapi.bicycle_p
                 x0=[0.0, 0.0, 0.0, 0.5], U0=np.tile([0.1, 0.05], (N, 1)))
 
 
+def _hcw(solver, box, N=80, integrator="rk4", **opt):   # pyapi.hcw_problem
+    o = dict(max_iterations=40, tolerance=1e-5, acceptable_tolerance=1e-6, reg_initial_value=1e-6); o.update(opt)
+    n = math.sqrt(3.986004418e14 / (6371e3 + 500e3) ** 3)
+    return dict(solver=solver, model=T.HCW(n, 1.0), integrator=integrator, dt=10.0, N=N, Q=np.diag([1e-4] * 3 + [1e-2] * 3), R=np.eye(3),
+                Qf=np.diag([10.0] * 3 + [100.0] * 3), xref=[0.0] * 6,
+                constraints={"ControlConstraint": T.ControlBox([-0.5] * 3, [0.5] * 3)} if box else {}, options=o,
+                x0=[-37.59664132226163, 27.312455860666148, 13.656227930333074, 0.015161970413423813, 0.08348413138390476, 0.04174206569195238])
+
+
 def _car(solver, box, N=100, **opt):   # pyapi.car_problem
     o = dict(max_iterations=80, tolerance=1e-4, acceptable_tolerance=1e-6, reg_initial_value=1e-2); o.update(opt)
     return dict(solver=solver, model=T.Car(2.0, 0.03), integrator="euler", dt=0.03, N=N, Q=np.diag([1e-2, 1e-2, 0.0, 0.0]), R=np.diag([1e-2, 1e-4]),
@@ -120,6 +129,8 @@ CASES = {
     "bicycle_ipddp_box": lambda: _bicycle("IPDDP", True),
     "bicycle_ipddp_box_rk4": lambda: _bicycle("IPDDP", True, integrator="rk4"),
     "bicycle_clddp_box": lambda: _bicycle("CLDDP", True),
+    "hcw_ipddp_box": lambda: _hcw("IPDDP", True),
+    "hcw_clddp_box": lambda: _hcw("CLDDP", True, integrator="euler"),
     "car_ipddp_box": lambda: _car("IPDDP", True),
     "car_clddp_box": lambda: _car("CLDDP", True),
     "unicycle_ipddp_box_soc": lambda: _with(_unicycle("IPDDP", False, box_name="ControlConstraint"), "SecondOrderConeConstraint",

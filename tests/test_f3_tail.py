@@ -50,6 +50,41 @@ def test_car_known_answers_of_the_reference(api, oracle_built):
         assert dt * H0[0][2][3, 3] < 8.71e-08 and abs(dt * H0[1][2][0, 0]) < 0.00443
 
 
+def test_hcw_properties(api, oracle_built):
+    """The Hill-Clohessy-Wiltshire plant (src/dynamics_model/spacecraft_linear.cpp:24-120; the reference's own tests,
+    tests/dynamics_model/test_spacecraft_linear.cpp:31-140, only propagate and check dimensions): the radial-hover thrust of its
+    ContinuousDynamics case balances the tidal term; the RK4 step on its 500-km orbit (dt = 10 s, the DiscreteDynamics case) follows the
+    closed-form solution of the equations over one revolution; constant Jacobians, zero Hessians; oracle, twin and the product's host model
+    agree."""
+    import cddp_twin as T
+    p = api.hcw_problem(api.SOLVER_IPDDP, 10)
+    n, mass = p.c.model_params[0], p.c.model_params[1]
+    o = api.Oracle(p)
+    x = np.zeros(6); x[0] = 100.0
+    u = np.array([-mass * 3.0 * n * n * x[0], 0.0, 0.0])
+    xd = o.dynamics(x, u)[0]
+    assert np.max(np.abs(xd)) < 1e-12                                     # hover: nothing moves
+    # closed form of the unforced equations (Clohessy & Wiltshire 1960) from the reference test's initial state
+    x0 = p.x0.copy(); t = 0.0
+    xs = x0.copy()
+    period = 2.0 * np.pi / n
+    steps = int(period / p.dt)
+    for _ in range(steps):
+        xs = o.dynamics(xs, np.zeros(3))[1]
+    T_ = steps * p.dt; s, c = np.sin(n * T_), np.cos(n * T_)
+    X, Y, Z, VX, VY, VZ = x0
+    xa = (4 - 3 * c) * X + s / n * VX + 2 / n * (1 - c) * VY
+    ya = 6 * (s - n * T_) * X + Y - 2 / n * (1 - c) * VX + (4 * s - 3 * n * T_) / n * VY
+    za = c * Z + s / n * VZ
+    assert np.allclose(xs[:3], [xa, ya, za], rtol=0, atol=1e-6 * np.max(np.abs(x0[:3])) + 2e-4)
+    (xn, Fx, Fu, H), (sn, fx, fu, h) = _eval_all(api, p, x0, np.array([0.1, -0.2, 0.05]))
+    assert np.array_equal(xn, sn) and np.array_equal(Fx, fx) and np.array_equal(Fu, fu)
+    tw = T.HCW(n, mass)
+    A, B = tw.jac(x0, np.zeros(3), 0.0)
+    assert np.array_equal(A, Fx) and np.array_equal(B, Fu)
+    assert all(np.all(np.asarray(b) == 0.0) for b in H) and all(np.all(np.asarray(b) == 0.0) for b in h)
+
+
 def test_bicycle_properties_of_the_reference(api, oracle_built):
     """tests/dynamics_model/test_bicycle.cpp:26-140: straight motion, steering turns, analytic Jacobians against finite differences."""
     p = api.bicycle_problem(api.SOLVER_IPDDP, 10)

@@ -50,6 +50,8 @@ def make(api, name):
         "bicycle_ipddp_box": lambda: S.bicycle_problem(S.SOLVER_IPDDP),
         "bicycle_ipddp_box_rk4": lambda: S.bicycle_problem(S.SOLVER_IPDDP, integrator=S.RK4),
         "bicycle_clddp_box": lambda: S.bicycle_problem(S.SOLVER_CLDDP),
+        "hcw_ipddp_box": lambda: S.hcw_problem(S.SOLVER_IPDDP),
+        "hcw_clddp_box": lambda: S.hcw_problem(S.SOLVER_CLDDP, integrator=S.EULER),
         "car_ipddp_box": lambda: S.car_problem(S.SOLVER_IPDDP),
         "car_clddp_box": lambda: S.car_problem(S.SOLVER_CLDDP),
         "unicycle_ipddp_box_soc": lambda: S.unicycle_cone_problem(S.SOLVER_IPDDP),
@@ -181,7 +183,7 @@ BIG_CASES = ["unicycle_clddp_box", "quadrotor_ipddp_box", "quadrotor_clddp_box",
 
 # f3 tail: car / bicycle plants, cone and thrust-magnitude rows.  Their solves run on the parity build (shared sin / cos / asin / tan):
 # asin and tan are two more libm routines whose device and host versions agree to an ulp, not to the bit.
-F3_CASES = ["bicycle_ipddp_box", "bicycle_ipddp_box_rk4", "bicycle_clddp_box", "car_ipddp_box", "car_clddp_box",
+F3_CASES = ["bicycle_ipddp_box", "bicycle_ipddp_box_rk4", "bicycle_clddp_box", "hcw_ipddp_box", "hcw_clddp_box", "car_ipddp_box", "car_clddp_box",
             "unicycle_ipddp_box_soc", "unicycle_ipddp_thrust", "unicycle_ipddp_maxthrust"]
 
 CASES = ["pendulum_ipddp_unc", "pendulum_ipddp_box", "pendulum_clddp_unc", "pendulum_clddp_box",

@@ -20,6 +20,7 @@ def _cases(api):
         ("bicycle", api.bicycle_problem(api.SOLVER_IPDDP, 10), True),
         ("bicycle_rk4", api.bicycle_problem(api.SOLVER_IPDDP, 10, integrator=api.RK4), True),
         ("car", api.car_problem(api.SOLVER_IPDDP, 10), True),
+        ("hcw", api.hcw_problem(api.SOLVER_IPDDP, 10), True),
     ]
 
 
