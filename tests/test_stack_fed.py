@@ -1,7 +1,6 @@
 """Stack-fed mode (`cddp_hip_backward_stacks`, include/cddp_hip.h): the host evaluates the plug-ins and hands
-over the (N x batch) derivative stacks; the GPU runs the Riccati sweep on them.  Checked against the device
-solver's own sweep on the same iterate (which tests/test_gpu_parity.py checks against the oracle) and against
-the oracle's gains directly.  Tolerance 1e-9 relative: the stacks are assembled in numpy, not in the kernels'
+over the (N x batch) derivative stacks; the GPU runs the Riccati sweep on them.  Checked against the oracle's
+gains and value function on every trajectory, and for consistency against the device solver's own sweep on the same iterate.  Tolerance 1e-9 relative: the stacks are assembled in numpy, not in the kernels'
 association order."""
 import numpy as np
 import pytest
@@ -65,11 +64,14 @@ def test_stack_fed_sweep_matches_solver_sweep(api, case):
     assert rel(K2, K) < TOL and rel(k2, k) < TOL
     assert rel(Vx2, Vx) < TOL and rel(Vxx2, Vxx) < TOL
     assert rel(dV2, dV) < TOL
-    # and against the oracle directly (trajectory 0)
-    o = S.Oracle(p); o.set_initial(x0[0], None if U0 is None else U0[0]); o.initialize()
-    assert o.backward()
-    Ko, ko = o.gains()
-    assert rel(K2[0], Ko) < 1e-8 and rel(k2[0], ko) < 1e-8
+    # and against the oracle directly, every trajectory of the batch (the comparison with the device solver's own sweep above is a
+    # consistency check between two products of this repository; THIS is the parity check)
+    for b in range(B):
+        o = S.Oracle(p); o.set_initial(x0[b], None if U0 is None else U0[b]); o.initialize()
+        assert o.backward()
+        Ko, ko = o.gains(); Vxo, Vxxo = o.value()
+        assert rel(K2[b], Ko) < 1e-8 and rel(k2[b], ko) < 1e-8, b
+        assert rel(Vx2[b], Vxo) < 1e-8 and rel(Vxx2[b], Vxxo) < 1e-8, b
 
 
 def test_stack_fed_rejects_uninstantiated_shape(api):
