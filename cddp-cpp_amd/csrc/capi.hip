@@ -815,7 +815,7 @@ struct SolveRun {
       if (one_stage) {
         ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
         mark(2);
-        ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
+        ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 2, s);   // best-merit rule: the candidate winner's costate only (k_costate)
         ks->update(d, 1, na, last, 1, s);
         mark(3);
         launches += 4;

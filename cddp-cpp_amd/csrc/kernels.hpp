@@ -1576,10 +1576,30 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
         win = a; break;
       }
     } else {
-      double best = INFINITY;
+      // best-merit rule: k_costate evaluated the costate of ONE trial per trajectory, the least-merit trial among those that passed
+      // every other test (flag 1 or 2).  Flag 1: that trial wins (no other successful trial has less merit).  Flag 2 (its costate was
+      // not finite): the remaining successful trials are walked in merit order and their costate is evaluated here.
+      double best = INFINITY; int cand = -1;
       for (int a = lo; a < hi; ++a) {
         const size_t ti = (size_t)a * d.Bp + b;
-        if (d.t_success[ti] == 1 && d.t_merit[ti] < best) { best = d.t_merit[ti]; win = a; }
+        if (d.t_success[ti] != 0 && d.t_merit[ti] < best) { best = d.t_merit[ti]; cand = a; }
+      }
+      if (cand >= 0 && (d.t_success[(size_t)cand * d.Bp + b] == 1 || !ipddp)) win = cand;
+      else if (cand >= 0) {
+        double floor_m = best; int floor_a = cand;   // trials already ruled out: merit < floor, or == floor with index <= floor_a
+        for (;;) {
+          double nb = INFINITY; int na_ = -1;
+          for (int a = lo; a < hi; ++a) {
+            const size_t ti = (size_t)a * d.Bp + b;
+            const double mt = d.t_merit[ti];
+            if (d.t_success[ti] != 1) continue;
+            if (mt < floor_m || (mt == floor_m && a <= floor_a)) continue;
+            if (mt < nb) { nb = mt; na_ = a; }
+          }
+          if (na_ < 0) break;
+          if (costate_trial_serial<NXu>(d, b, d.cur[b], na_)) { win = na_; break; }
+          floor_m = nb; floor_a = na_;
+        }
       }
     }
     if (win < 0 && hi < n_alphas) { d.phase[b] = PH_FWD2; goto count; }   // more alphas to try

@@ -502,8 +502,33 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 #pragma unroll
       for (int j = i; j < NX; ++j) vt[k++] = vb[(size_t)(i * NX + j) * kLS];
   }
+  // first_only == 2 (best-merit rule, cddp_solver_base.cpp:264-317): the only costate rows anybody reads are the WINNER's, and
+  // the winner is the successful trial of least merit.  Its candidate is picked here exactly as k_update picks it (same order, strict
+  // <) among the trials that passed every other test -- flag 1 or 2, so that a block which already sees another block's "costate not
+  // finite" mark still picks the same one -- and only that trial is evaluated; should its costate turn out non-finite, k_update moves
+  // to the next-best trial and evaluates that one itself (costate_trial_serial).  With all sixteen trials of the C5 share passing,
+  // evaluating every one wrote 1.8 GB of costate rows per launch of which 1 / 16 was ever read.
+  int only = -1;
+  if (first_only == 2) {
+    // (both rows of every trial are fetched unconditionally and up front: one memory round trip instead of up to 2 na dependent ones)
+    int sc[CDDP_HIP_MAX_ALPHAS]; double mt[CDDP_HIP_MAX_ALPHAS];
+#pragma unroll
+    for (int j = 0; j < CDDP_HIP_MAX_ALPHAS; ++j) {
+      sc[j] = 0; mt[j] = 0.0;
+      if (j < na) {   // wave-uniform
+        const size_t ti = (size_t)(a0 + j) * d.Bp + b;
+        sc[j] = d.t_success[ti]; mt[j] = d.t_merit[ti];
+      }
+    }
+    double best = INFINITY;
+#pragma unroll
+    for (int j = 0; j < CDDP_HIP_MAX_ALPHAS; ++j)
+      if (j < na && sc[j] != 0 && mt[j] < best) { best = mt[j]; only = a0 + j; }
+    if (only < 0) return;
+  }
   for (int a = a0; a < a0 + na; ++a) {
     const size_t ti = (size_t)a * d.Bp + b;
+    if (only >= 0 && a != only) continue;
     if (!d.t_success[ti]) continue;
     const int slot = trial_slot(cur, a);
     const double a_pr = d.t_apr[ti];
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
     // (costate_trial_serial) when the first-success rule stopped this kernel at the failed one.
     if (!finite) d.t_success[ti] = 2;
     else st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
-    if (first_only) break;
+    if (first_only == 1) break;
   }
 }
 
