@@ -381,7 +381,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   for (double **sp : tr) DA(*sp, (size_t)d.n_alphas * Bp);
   DA(d.sink, kSinkDoubles);
   DA(d.t_success, (size_t)d.n_alphas * Bp);
-  DA(d.t_steps, (size_t)d.n_alphas * Bp); DA(d.n_fwd_steps, Bp);
+  DA(d.t_steps, (size_t)d.n_alphas * Bp); DA(d.n_fwd_steps, Bp); DA(d.cand, Bp);
   if (ip && P.n_cons > 0) DA(d.ev, (size_t)d.n_alphas * N * 2 * P.n_cons * Bp);
   DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
   DA(d.hist_n, std::max(1, d.hist_batch));

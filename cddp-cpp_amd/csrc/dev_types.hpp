@@ -90,6 +90,7 @@ struct DevBuf {
   int ev_valid;                            // set per K5 launch: the trials' parked barrier terms (ev, t_ysmin/max) were written by the two-role rollout
   int *win_hist;                           // [n_alphas + 1] accepted-alpha histogram of the solve so far (host picks the ladder shape)
   unsigned long long *launched;            // rollouts actually executed (speculative alphas included)
+  int *cand;                               // [Bp] best-merit rule: the trial whose costate K4b evaluates (k_pick_candidate), -1 = none
   int xcd_map;                             // cooperative sweeps: groups of one 64-trajectory tile on one XCD (kernels_coop.hpp::coop_group); CDDP_HIP_XCD_MAP=0 turns it off
 };
 

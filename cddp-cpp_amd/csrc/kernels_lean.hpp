@@ -479,6 +479,67 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
 // trials that passed every other test.  A trial whose costate is not finite is failed here exactly as the reference
 // fails it inside forwardPass, before k_update applies the acceptance rule; under the first-success rule only the
 // first surviving trial is evaluated.
+// Best-merit rule: the candidate winner of every trajectory -- least merit among the trials that passed every other test (flag 1 or 2),
+// first of equals, the order and comparison k_update uses.  One lane per trajectory, launched in front of k_costate.
+template <int kUnused = 0>
+__global__ __launch_bounds__(64) void k_pick_candidate(DevBuf d, int a0, int na, int phase_req, int force) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  double best = INFINITY; int only = -1;
+  for (int a = a0; a < a0 + na; ++a) {
+    const size_t ti = (size_t)a * d.Bp + b;
+    const int sc = d.t_success[ti]; const double mt = d.t_merit[ti];
+    if (sc != 0 && mt < best) { best = mt; only = a; }
+  }
+  d.cand[b] = only;
+}
+
+// K4b for large states when ONE trial per trajectory is evaluated (every launch of the solve loop: the first surviving trial under the
+// first-success rule, the candidate winner under the best-merit rule).  A separate kernel because register allocation is per kernel: the
+// general form below holds V_xx as a register-resident triangle (105 doubles at nx = 14: 494 registers plus scratch, one wave per SIMD).
+template <class Model>
+__global__ __launch_bounds__(64) void k_costate_one(DevBuf d, int a0, int na, int phase_req, int first_only) {
+  constexpr int NX = Model::NX;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (d.phase[b] != phase_req) return;
+  const int cur = d.cur[b];
+  // V_xx is STREAMED row by row against dx = x_new - x_old.  Same products in the same order as the general kernel (V_xx is stored
+  // exactly symmetric, so row i of the full matrix holds the values the triangle supplies there); the rows of a trial whose costate
+  // turns out non-finite may be partly written before the flag is set -- nobody reads them.
+  int only = -1;
+  if (first_only == 2) only = d.cand[b];
+  else for (int a = a0; a < a0 + na; ++a) if (d.t_success[(size_t)a * d.Bp + b] != 0) { only = a; break; }
+  if (only < 0) return;
+  const size_t ti = (size_t)only * d.Bp + b;
+  const int slot = trial_slot(cur, only);
+  const double a_pr = d.t_apr[ti];
+  double dx[NX];
+  {
+    double xo[NX], xn[NX];
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+    ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xn);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) dx[j] = xn[j] - xo[j];
+  }
+  const double *vb = d.Vxx + GI(t, NX * NX, 0);
+  const double *lop = d.Lam + (size_t)cur * d.planeX + GI(t, NX, 0), *vxp = d.Vx + GI(t, NX, 0);
+  double *lamp = d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0);
+  bool finite = true;
+#pragma unroll 2
+  for (int i = 0; i < NX; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) s += vb[(size_t)(i * NX + j) * kLS] * dx[j];
+    const double lam = (lop[(size_t)i * kLS] + a_pr * vxp[(size_t)i * kLS]) + s;
+    finite = finite && dfinite(lam);
+    lamp[(size_t)i * kLS] = lam;
+  }
+  if (!finite) d.t_success[ti] = 2;
+}
+
 template <class Model>
 __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int phase_req, int force, int first_only) {
   constexpr int NX = Model::NX;
@@ -509,21 +570,8 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
   // to the next-best trial and evaluates that one itself (costate_trial_serial).  With all sixteen trials of the C5 share passing,
   // evaluating every one wrote 1.8 GB of costate rows per launch of which 1 / 16 was ever read.
   int only = -1;
-  if (first_only == 2) {
-    // (both rows of every trial are fetched unconditionally and up front: one memory round trip instead of up to 2 na dependent ones)
-    int sc[CDDP_HIP_MAX_ALPHAS]; double mt[CDDP_HIP_MAX_ALPHAS];
-#pragma unroll
-    for (int j = 0; j < CDDP_HIP_MAX_ALPHAS; ++j) {
-      sc[j] = 0; mt[j] = 0.0;
-      if (j < na) {   // wave-uniform
-        const size_t ti = (size_t)(a0 + j) * d.Bp + b;
-        sc[j] = d.t_success[ti]; mt[j] = d.t_merit[ti];
-      }
-    }
-    double best = INFINITY;
-#pragma unroll
-    for (int j = 0; j < CDDP_HIP_MAX_ALPHAS; ++j)
-      if (j < na && sc[j] != 0 && mt[j] < best) { best = mt[j]; only = a0 + j; }
+  if (first_only == 2) {   // picked once per trajectory by k_pick_candidate (the same launch sequence), not once per (trajectory, step)
+    only = d.cand[b];
     if (only < 0) return;
   }
   for (int a = a0; a < a0 + na; ++a) {

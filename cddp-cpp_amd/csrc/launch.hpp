@@ -160,6 +160,13 @@ struct Launcher {
   // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
     if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP) return;
+    if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
+    if constexpr (Model::NX > 8) {
+      if (!force && first_only != 0) {   // one trial per trajectory: the streaming kernel (2 - 4 waves per SIMD instead of one)
+        hipLaunchKernelGGL((k_costate_one<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, first_only);
+        return;
+      }
+    }
     hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
