@@ -481,6 +481,22 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
 // first surviving trial is evaluated.
 // Best-merit rule: the candidate winner of every trajectory -- least merit among the trials that passed every other test (flag 1 or 2),
 // first of equals, the order and comparison k_update uses.  One lane per trajectory, launched in front of k_costate.
+// First trial of [a0, a0 + na) that passed every other test (flag 1 or 2): the one the first-success rule evaluates.  The flags are
+// fetched eight at a time so that the loads are in flight together -- walking them one by one puts up to n_alpha dependent L2 round
+// trips in front of every (trajectory, step) lane of K4b.
+DEV int first_surviving_trial(const DevBuf &d, int a0, int na, int b) {
+  for (int base = 0; base < na; base += 8) {
+    int f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (base + i < na) ? d.t_success[(size_t)(a0 + base + i) * d.Bp + b] : 0;
+    int hit = -1;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) if (f[i] != 0) hit = i;
+    if (hit >= 0) return a0 + base + hit;
+  }
+  return -1;
+}
+
 template <int kUnused = 0>
 __global__ __launch_bounds__(64) void k_pick_candidate(DevBuf d, int a0, int na, int phase_req, int force) {
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -509,9 +525,7 @@ __global__ __launch_bounds__(64) void k_costate_one(DevBuf d, int a0, int na, in
   // V_xx is STREAMED row by row against dx = x_new - x_old.  Same products in the same order as the general kernel (V_xx is stored
   // exactly symmetric, so row i of the full matrix holds the values the triangle supplies there); the rows of a trial whose costate
   // turns out non-finite may be partly written before the flag is set -- nobody reads them.
-  int only = -1;
-  if (first_only == 2) only = d.cand[b];
-  else for (int a = a0; a < a0 + na; ++a) if (d.t_success[(size_t)a * d.Bp + b] != 0) { only = a; break; }
+  const int only = first_only == 2 ? d.cand[b] : first_surviving_trial(d, a0, na, b);
   if (only < 0) return;
   const size_t ti = (size_t)only * d.Bp + b;
   const int slot = trial_slot(cur, only);
@@ -569,14 +583,14 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
   // finite" mark still picks the same one -- and only that trial is evaluated; should its costate turn out non-finite, k_update moves
   // to the next-best trial and evaluates that one itself (costate_trial_serial).  With all sixteen trials of the C5 share passing,
   // evaluating every one wrote 1.8 GB of costate rows per launch of which 1 / 16 was ever read.
-  int only = -1;
-  if (first_only == 2) {   // picked once per trajectory by k_pick_candidate (the same launch sequence), not once per (trajectory, step)
-    only = d.cand[b];
+  int a_lo = a0, a_hi = a0 + na;
+  if (first_only != 0) {   // best-merit: picked once per trajectory by k_pick_candidate (the same launch sequence); first-success: here
+    const int only = first_only == 2 ? d.cand[b] : first_surviving_trial(d, a0, na, b);
     if (only < 0) return;
+    a_lo = only; a_hi = only + 1;
   }
-  for (int a = a0; a < a0 + na; ++a) {
+  for (int a = a_lo; a < a_hi; ++a) {
     const size_t ti = (size_t)a * d.Bp + b;
-    if (only >= 0 && a != only) continue;
     if (!d.t_success[ti]) continue;
     const int slot = trial_slot(cur, a);
     const double a_pr = d.t_apr[ti];
@@ -601,7 +615,6 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
     // (costate_trial_serial) when the first-success rule stopped this kernel at the failed one.
     if (!finite) d.t_success[ti] = 2;
     else st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
-    if (first_only == 1) break;
   }
 }
 

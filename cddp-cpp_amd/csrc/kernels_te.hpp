@@ -826,11 +826,13 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 // dS = k_s + K_s dX, dY = clamp(k_y + K_y dX) and computeMaxStepSizes (:1522-1532, 2939-2988).  The lane that
 // completes a trajectory's N-th step applies checkEarlyConvergence (:925-958).
 template <class Model, class Cons>
-__global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__restrict__ Pk, int force) {
+__global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__restrict__ Pk, int force, int tstep) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = (M > 0 ? M : 1);
   typedef TeCfg<Model, Cons> C;
   const int b = blockIdx.x * 64 + threadIdx.x;
-  const int t = blockIdx.y;
+  // a lane walks tstep consecutive steps and publishes ONE max / min / count per quantity: the device-scope atomics of 150 blocks on
+  // the same 64 words, not the 1.6 GB of rows, set the pace of the one-step-per-block form at C5's size
+  const int t0 = blockIdx.y * tstep, t1 = (t0 + tstep < d.N) ? t0 + tstep : d.N;
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   if (d.te_cnt[b] < 0) return;
@@ -839,18 +841,30 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
   const int N = d.N;
   const int cur = d.cur[b];
   const double mu = d.mu[b];
+  // accumulated as the bit patterns the atomics compare (atomic_max_pos / atomic_min_pos: unsigned order of non-negative doubles), so
+  // that a lane's several steps combine exactly as their separate atomics did
+  unsigned long long idu_all = 0ull, apr_all = (unsigned long long)__double_as_longlong(1.0), adu_all = apr_all;
+#pragma unroll 1
+  for (int t = t0; t < t1; ++t) {
   {
-    double r[NU], Bm[NX * NU], pn[NX];
+    // B^T p with B streamed a row at a time (row k enters every a_i as its k-th term: the sums run in the same order as column by
+    // column, with nu accumulators instead of the nx nu block in registers)
+    double r[NU], pn[NX], acc[NU];
     ld<NU>(d.te_cst + GI(t, C::REC, C::cR), kLS, r);
-    ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
     ld<NX>(d.Vx + GI(t + 1, NX, 0), kLS, pn);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      double Bk[NU];
+      ld<NU>(d.Bm + GI(t, NX * NU, k * NU), kLS, Bk);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) acc[i] += Bk[i] * pn[k];
+    }
     double idu = 0.0;
 #pragma unroll
-    for (int i = 0; i < NU; ++i) { double a = 0.0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) a += Bm[k * NU + i] * pn[k];
-      idu = dmax(idu, fabs(r[i] + a)); }
-    atomic_max_pos(d.inf_du + b, idu);
+    for (int i = 0; i < NU; ++i) idu = dmax(idu, fabs(r[i] + acc[i]));
+    if (idu >= 0.0) { const unsigned long long u = (unsigned long long)__double_as_longlong(idu); idu_all = u > idu_all ? u : idu_all; }
   }
   if constexpr (M > 0) {
     const double *Xc = d.X + (size_t)cur * d.planeX;
@@ -859,10 +873,15 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
     const double *Gc = d.G + (size_t)cur * d.planeM;
     const double s_floor = dmax(mu * 1e-3, kEpsSlack);
     const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
-    double x[NX], y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], kk[NU], KK[NU * NX], dx[NX];
+    // control box only (UDiag): row rr of G_u K is one entry of G_u times ONE row of K, so K is streamed a row at a time (the second
+    // box half re-reads the rows out of L2) instead of held whole -- 98 doubles at (14, 7), which with the rest made this a
+    // one-wave-per-SIMD kernel
+    constexpr bool kStreamK = UDiag<Cons>::value;
+    double x[NX], y[MM], s[MM], g[MM], Qyx[MM * NX], Qyu[MM * NU], kk[NU], KK[kStreamK ? NX : NU * NX], dx[NX];
     ld<NX>(Xc + GI(t, NX, 0), kLS, x);
     ld<M>(Yc + GI(t, M, 0), kLS, y); ld<M>(Sc + GI(t, M, 0), kLS, s); ld<M>(Gc + GI(t, M, 0), kLS, g);
-    ld<NU>(d.k + GI(t, NU, 0), kLS, kk); ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
+    if constexpr (!kStreamK) ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
     ld<NX>(d.dX + GI(t, NX, 0), kLS, dx);
 #pragma unroll
     for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
@@ -891,10 +910,11 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
       const double kyr = clip_sgn(rhat + y[rr] * temp, ss);
       const double ksr = (-rp) - temp;
       double a = 0.0, c = 0.0;
+      if constexpr (kStreamK) ld<NX>(d.K + GI(t, NU * NX, UDiag<Cons>::col(rr) * NX), kLS, KK);
 #pragma unroll
       for (int cc = 0; cc < NX; ++cc) {
         double s2 = 0.0, gx = 0.0;
-        if constexpr (UDiag<Cons>::value) s2 = 0.0 + UDiag<Cons>::val(cctx, rr) * KK[UDiag<Cons>::col(rr) * NX + cc];
+        if constexpr (UDiag<Cons>::value) s2 = 0.0 + UDiag<Cons>::val(cctx, rr) * KK[cc];
         else {
           gx = Qyx[rr * NX + cc];
 #pragma unroll
@@ -912,12 +932,17 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
       if (ds < 0.0) apr = dmin(apr, -tau * s[rr] / ds);
       if (dy < 0.0) adu = dmin(adu, -tau * y[rr] / dy);
     }
-    if (apr < 1.0) atomic_min_pos(d.apr_max + b, apr);
-    if (adu < 1.0) atomic_min_pos(d.adu_max + b, adu);
+    if (apr < 1.0) { const unsigned long long u = (unsigned long long)__double_as_longlong(apr >= 0.0 ? apr : 0.0); apr_all = u < apr_all ? u : apr_all; }
+    if (adu < 1.0) { const unsigned long long u = (unsigned long long)__double_as_longlong(adu >= 0.0 ? adu : 0.0); adu_all = u < adu_all ? u : adu_all; }
   }
+  }
+  const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
+  if (idu_all != 0ull) atomicMax((unsigned long long *)(d.inf_du + b), idu_all);
+  if (apr_all != one_bits) atomicMin((unsigned long long *)(d.apr_max + b), apr_all);
+  if (adu_all != one_bits) atomicMin((unsigned long long *)(d.adu_max + b), adu_all);
   __threadfence();
-  const int done = atomicAdd(d.te_cnt + b, 1);
-  if (done != N - 1) return;
+  const int done = atomicAdd(d.te_cnt + b, t1 - t0);
+  if (done + (t1 - t0) != N) return;
   // ---- last step of this trajectory: every contribution is in; early-convergence test
   __threadfence();
   const double inf_du = __longlong_as_double((long long)atomicMax((unsigned long long *)(d.inf_du + b), 0ull));

@@ -129,7 +129,10 @@ struct Launcher {
       if constexpr (kTeCoop) {
         if (d.te_cst && !lane_sweep) {
           hipLaunchKernelGGL((k_backward_te_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-          hipLaunchKernelGGL((k_te_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
+          // steps per block: as many as keep >= ~1024 waves in the grid (1 for small batches)
+          const int tiles = (d.B + 63) / 64;
+          int tstep = (int)(((long long)tiles * d.N) / 1024); if (tstep < 1) tstep = 1; if (tstep > 16) tstep = 16;
+          hipLaunchKernelGGL((k_te_post<Model, Cons>), dim3(tiles, (d.N + tstep - 1) / tstep), dim3(64), 0, s, d, d.P, force, tstep);
           return;
         }
       }
