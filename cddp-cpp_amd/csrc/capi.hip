@@ -681,7 +681,7 @@ struct SolveRun {
   int launches = 0, outer = 0, it = 0, max_it = 0, na = 0;
   bool two_stage_marks = false, first_rule = true, pinned = false, one_stage = true, done = false, cpu_time_hit = false;
   int k1 = 1, k_cap = 1, k_cap2 = 1;
-  long waves_all = 0;
+  long waves_all = 0, per_alpha_waves = 1, two_stage_max_waves = 768;
   std::vector<int> hist_now, hist_prev;
   hipEvent_t poll_ev = nullptr;
   std::chrono::steady_clock::time_point wall0;
@@ -729,7 +729,15 @@ struct SolveRun {
     if (kq >= na - 1) {
       if (waves_all <= 2048) { one_stage = true; }
       else { one_stage = false; k1 = k_cap2; }
-    } else { one_stage = false; k1 = std::max(1, std::min(kq + 1, k_cap)); }   // + 1: the histogram drifts between polls
+    } else {
+      one_stage = false; k1 = std::max(1, std::min(kq + 1, k_cap));   // + 1: the histogram drifts between polls
+      // A chip that the whole ladder fills at most twice (one-stage territory) gains from a short first stage only what the
+      // smaller launch saves over the rollout's latency floor (C2: 291 -> ~200 us at five step sizes), and loses a full second
+      // rollout + costate + update (~235 us) whenever ONE trajectory walks past k1: kept only for a first stage of at most 768
+      // waves (CDDP_HIP_LS_TWO_MAX_WAVES; profiles/r03_ladder_sweep.md: 512 / 640 / 768 / 1024 -> 47.3 / 46.8 / 46.1 / 46.4 ms
+      // per C2 solve on one box, differences at the box-to-box noise level).
+      if (waves_all <= 2048 && (long)k1 * per_alpha_waves > two_stage_max_waves) one_stage = true;
+    }
     if (std::getenv("CDDP_HIP_DEBUG_LADDER")) {
       std::fprintf(stderr, "[ladder] it=%d total=%ld kq=%d -> %s k1=%d hist:", outer, total, kq, one_stage ? "one" : "two", k1);
       for (int a = 0; a <= na; ++a) std::fprintf(stderr, " %ld", hd[a]);
@@ -770,6 +778,8 @@ struct SolveRun {
     const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");
     const bool force_two = ls_env && ls_env[0] == '2', force_one = ls_env && ls_env[0] == '1';
     const long per_alpha = std::max(1L, waves_all / std::max(1, na));
+    per_alpha_waves = per_alpha;
+    { const char *e = std::getenv("CDDP_HIP_LS_TWO_MAX_WAVES"); two_stage_max_waves = e ? std::atol(e) : 768; }
     k_cap = (int)std::max(1L, std::min((long)na - 1, 1024 / per_alpha));    // one wavefront per SIMD
     k_cap2 = (int)std::max(1L, std::min((long)na - 1, 2048 / per_alpha));   // two (a ladder that is needed almost whole)
     const char *kf_env = std::getenv("CDDP_HIP_LS_FIRST");
