@@ -641,6 +641,15 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
 // TERM = true: terminal-equality layouts solved by the cooperative reduced-LQR sweep (kernels_te.hpp; no terminal
 // inequality): the producer hands x_N over, the consumer appends the multiplier trial and the terminal terms of
 // computeTheta / computeBarrierMerit (ipddp_solver.cpp:1711-1723, 2812-2845, 2866-2878) in the reference's order.
+#ifdef CDDP_K4_TIMING   // experiment: per-wave duration and steps walked of the LAST rollout launch (profiles/scripts/k4_block_times.py)
+__device__ unsigned long long g_k4_times[16384 * 4];
+#define K4_TIME_BEGIN const unsigned long long k4_t0 = wall_clock64();
+#define K4_TIME_END(role, steps) do { if (lane == 0) { const size_t k4_i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (role) * 2; \
+    g_k4_times[k4_i] = wall_clock64() - k4_t0; g_k4_times[k4_i + 1] = (unsigned long long)(steps); } } while (0)
+#else
+#define K4_TIME_BEGIN
+#define K4_TIME_END(role, steps)
+#endif
 template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                           int a0, int phase_req, int force) {
@@ -657,6 +666,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   __shared__ double s_xN[TERM ? NX * 64 : 1];   // the producer lane's x_N (terminal residual of the trial)
   __shared__ double s_obj[Obj::kStage];         // Q dt | R dt | x_ref of a large plant (Objective::stage)
   const int lane = threadIdx.x & 63;
+  K4_TIME_BEGIN
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
   const int b = blockIdx.x * 64 + lane;
   const int a = a0 + blockIdx.y;
@@ -718,6 +728,16 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     //  at the top of their own step.)
     constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);
     constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
+    // Prefetch distance of the ping-pong form, in steps (kDepth + 1 rotating register sets).  Measured at C2 on one box
+    // (profiles/r03_ladder_sweep.md): producer / consumer distance 1 / 1: 22.7 ms of rollout class per solve, 3 / 1: 23.5, 1 / 2: 23.1,
+    // 5 / 3: 25.0 -- one step of look-ahead already covers the loaded memory latency; more sets only cost registers.
+#ifndef CDDP_K4_DEPTH_P
+#define CDDP_K4_DEPTH_P 1
+#endif
+#ifndef CDDP_K4_DEPTH_C
+#define CDDP_K4_DEPTH_C 1
+#endif
+    constexpr int kDepthP = (kPing && sizeof(StepIn) <= 12 * sizeof(double)) ? CDDP_K4_DEPTH_P : 1;
     // The largest records (7-joint arm: 126 doubles) are streamed: the old state row and, per control i, the gain row with
     // u_old[i], k[i] -- two chunk buffers; x_old of step t + 1 and its first chunk are fetched behind the integrator (42
     // doubles live there instead of 126).  Same sums.  With the consumer's chunks (below) the kernel fits two wavefronts per SIMD.
@@ -731,7 +751,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     double xo_c[NX];
     auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
       if constexpr (kPing) {
-        const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+        const int tn = t + kDepthP < N ? t + kDepthP : N - 1;   // unconditional (clamped) prefetch
         load_step(tn, nxt);
       }
       PIPELINE_FENCE();
@@ -799,18 +819,22 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
     };
     StepIn ra;
-    if constexpr (kChunkP) { ld<NX>(Xc + GI(0, NX, 0), kLS, xo_c); load_pchunk(0, 0, pk0); } else load_step(0, ra);
-    prime();
     int t = 0;
     if constexpr (kPing) {
-      StepIn rb;
-      for (; t + 1 < N; t += 2) {
-        step(t, ra, rb);
-        step(t + 1, rb, ra);
+      StepIn R[kDepthP + 1];   // step t lives in R[t % (kDepthP + 1)]; every index below is a compile-time constant
+#pragma unroll
+      for (int j = 0; j < kDepthP; ++j) load_step(j < N ? j : N - 1, R[j]);
+      prime();
+      for (; t + kDepthP < N; t += kDepthP + 1) {
+#pragma unroll
+        for (int j = 0; j <= kDepthP; ++j) step(t + j, R[j], R[(j + kDepthP) % (kDepthP + 1)]);
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) { t = N; break; }   // nothing downstream reads the rows any more
       }
-      if (t < N) step(t, ra, rb);
+#pragma unroll
+      for (int j = 0; j <= kDepthP; ++j) if (t + j < N) step(t + j, R[j], R[(j + kDepthP) % (kDepthP + 1)]);
     } else {
+      if constexpr (kChunkP) { ld<NX>(Xc + GI(0, NX, 0), kLS, xo_c); load_pchunk(0, 0, pk0); } else load_step(0, ra);
+      prime();
       for (; t < N; ++t) {
         step(t, ra, ra);
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
@@ -823,6 +847,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    K4_TIME_END(0, t);
     return;
   }
 
@@ -876,6 +901,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   };
   constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);   // see the producer
   constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
+  constexpr int kDepthC = (kPing && sizeof(StepIn) <= 16 * sizeof(double)) ? CDDP_K4_DEPTH_C : 1;
   // The largest records of control-box layouts (7-joint arm: 169 doubles per lane and step) are streamed in NU chunks
   // instead: chunk i = gain row i and the slack / dual entries of the two constraint rows that read it (upper and lower
   // bound of control i), two chunk buffers, chunk i + 1 in flight while chunk i is reduced, chunk 0 of the next step behind
@@ -894,7 +920,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   Chunk ck0, ck1;
   auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
     if constexpr (kPing) {
-      const int tn = t + 1 < N ? t + 1 : t;   // unconditional (clamped) prefetch
+      const int tn = t + kDepthC < N ? t + kDepthC : N - 1;   // unconditional (clamped) prefetch
       load_step(tn, nxt);
     } else if constexpr (!kEarly && !kChunk) load_step(t, cs);
     PIPELINE_FENCE();
@@ -1024,22 +1050,27 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     }
   };
   StepIn ra;
-  if constexpr (kChunk) load_chunk(0, 0, ck0); else load_step(0, ra);
-  prime();
   if constexpr (kPing) {
-    StepIn rb;
+    StepIn R[kDepthC + 1];   // see the producer
+#pragma unroll
+    for (int j = 0; j < kDepthC; ++j) load_step(j < N ? j : N - 1, R[j]);
+    prime();
     int t = 0;
-    for (; t + 1 < N; t += 2) {
-      step(t, ra, rb);
-      step(t + 1, rb, ra);
+    for (; t + kDepthC < N; t += kDepthC + 1) {
+#pragma unroll
+      for (int j = 0; j <= kDepthC; ++j) step(t + j, R[j], R[(j + kDepthC) % (kDepthC + 1)]);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed: release the producer
         __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (active) d.t_steps[ti] = fail_t;
+        K4_TIME_END(1, t);
         return;
       }
     }
-    if (t < N) step(t, ra, rb);
+#pragma unroll
+    for (int j = 0; j <= kDepthC; ++j) if (t + j < N) step(t + j, R[j], R[(j + kDepthC) % (kDepthC + 1)]);
   } else {
+    if constexpr (kChunk) load_chunk(0, 0, ck0); else load_step(0, ra);
+    prime();
     for (int t = 0; t < N; ++t) {
       step(t, ra, ra);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
@@ -1050,6 +1081,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     }
   }
   wait_ge(&s_prod, N + kRing + 1);
+  K4_TIME_END(1, N);
   if (active) d.t_steps[ti] = fail_t;
   if (alive && s_pstat[lane] <= N) alive = false;
   if (!alive) return;
