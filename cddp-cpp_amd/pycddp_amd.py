@@ -279,7 +279,10 @@ class LTISystem(DynamicalSystem):   # :233-237
 
 
 # ------------------------------------------------------------------------------------------------ objective / constraints
-class Objective:                    # objective.hpp:30-120: the virtual interface a Python subclass overrides
+class Objective:                    # objective.hpp:30-120 / bind_objective.cpp:34-45: bound WITHOUT a constructor
+    def __init__(self, *args, **kwargs):
+        # pybind11's message for a class bound without py::init; Python-defined objectives derive from NonlinearObjective (:62-63)
+        raise TypeError("pycddp.Objective: No constructor defined!")
     def running_cost(self, state, control, index): raise RuntimeError("running_cost is not implemented")
     def terminal_cost(self, final_state): raise RuntimeError("terminal_cost is not implemented")
     def evaluate(self, states, controls):
@@ -360,55 +363,92 @@ class QuadraticObjective(Objective):   # objective.hpp: (Q, R, Qf, reference_sta
         self.timestep = timestep
 
 
-class Constraint:                   # constraint.hpp:40-142: the virtual interface a Python subclass overrides
-    def get_hessians(self, x, u):
-        """(g_xx[rows][nx][nx], g_uu[rows][nu][nu], g_ux[rows][nu][nx]) or None (constraint.hpp:86-120: zeros by default)."""
-        r, nx, nu = self.get_dual_dim(), np.asarray(x).size, np.asarray(u).size
-        return np.zeros((r, nx, nx)), np.zeros((r, nu, nu)), np.zeros((r, nu, nx))
-    """evaluate(x, u), get_upper_bound(), get_state_jacobian(x, u), get_control_jacobian(x, u), get_dual_dim()."""
+def _pure_virtual(cls, name):       # what pybind11's PYBIND11_OVERRIDE_PURE raises when a Python subclass leaves the method out
+    raise RuntimeError('Tried to call pure virtual function "%s::%s"' % (cls, name))
+
+
+class Constraint:                   # constraint.hpp:31-142 / bind_constraints.cpp:9-117: the virtual interface a Python subclass overrides
+    """Same surface as the pybind class: Constraint(name); evaluate / get_state_jacobian / get_control_jacobian / compute_violation
+    (state, control, index=0), get_lower_bound, get_upper_bound, compute_violation_from_value(g), get_center, get_state_hessian /
+    get_control_hessian / get_cross_hessian (lists of matrices, zero by default), get_dual_dim, name."""
+    def __init__(self, name): self._name = str(name)
+    name = property(lambda self: getattr(self, "_name", type(self).__name__))
+    def get_dual_dim(self): return 0                                          # constraint.hpp:42
+    def evaluate(self, state, control, index=0): _pure_virtual("Constraint", "evaluate")
+    def get_lower_bound(self): _pure_virtual("Constraint", "get_lower_bound")
+    def get_upper_bound(self): _pure_virtual("Constraint", "get_upper_bound")
+    def get_state_jacobian(self, state, control, index=0): _pure_virtual("Constraint", "get_state_jacobian")
+    def get_control_jacobian(self, state, control, index=0): _pure_virtual("Constraint", "get_control_jacobian")
+    def compute_violation(self, state, control, index=0): _pure_virtual("Constraint", "compute_violation")
+    def compute_violation_from_value(self, g): _pure_virtual("Constraint", "compute_violation_from_value")
+    def get_center(self): raise RuntimeError("This constraint type does not have a center.")   # :86-89 (std::logic_error)
+    def get_state_hessian(self, state, control, index=0):                      # :91-120: zero blocks by default
+        n = np.asarray(state).size; return [np.zeros((n, n)) for _ in range(self.get_dual_dim())]
+    def get_control_hessian(self, state, control, index=0):
+        n = np.asarray(control).size; return [np.zeros((n, n)) for _ in range(self.get_dual_dim())]
+    def get_cross_hessian(self, state, control, index=0):
+        nx, nu = np.asarray(state).size, np.asarray(control).size; return [np.zeros((nu, nx)) for _ in range(self.get_dual_dim())]
+
+
+class _BuiltinConstraint(Constraint):
+    """Shared pieces of the built-in rows: -inf lower bounds, computeViolation = computeViolationFromValue(evaluate)."""
     def get_dual_dim(self): return int(np.asarray(self.get_upper_bound()).size)
+    def get_lower_bound(self): return np.full(self.get_dual_dim(), -np.inf)
+    def compute_violation(self, state, control, index=0): return self.compute_violation_from_value(self.evaluate(state, control, index))
+    def compute_violation_from_value(self, g): return float(max(0.0, np.asarray(g, dtype=np.float64)[0]))
 
 
-class ControlConstraint(Constraint):   # constraint.hpp:144-251 (BoxConstraint<Control>): g = [-u; u] s, upper = [-lb; ub] s
+class ControlConstraint(_BuiltinConstraint):   # constraint.hpp:144-251 (BoxConstraint<Control>): g = [-u; u] s, upper = [-lb; ub] s
+    _NAME = "ControlConstraint"
     def __init__(self, lower_bound, upper_bound, scale_factor=1.0):
+        Constraint.__init__(self, self._NAME)
         self.lower = np.asarray(lower_bound, dtype=np.float64); self.upper = np.asarray(upper_bound, dtype=np.float64); self.scale = scale_factor
     def _v(self, x, u): return np.asarray(u, dtype=np.float64)
-    def evaluate(self, x, u): v = self._v(x, u); return np.concatenate([-v, v]) * self.scale
+    def evaluate(self, x, u, index=0): v = self._v(x, u); return np.concatenate([-v, v]) * self.scale
     def get_upper_bound(self): return np.concatenate([-self.lower, self.upper]) * self.scale
-    def get_state_jacobian(self, x, u): return np.zeros((2 * self.upper.size, np.asarray(x).size))
-    def get_control_jacobian(self, x, u): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
+    def get_state_jacobian(self, x, u, index=0): return np.zeros((2 * self.upper.size, np.asarray(x).size))
+    def get_control_jacobian(self, x, u, index=0): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
+    def compute_violation_from_value(self, g):   # :237-240
+        return float(np.maximum(np.asarray(g, dtype=np.float64) - self.get_upper_bound(), 0.0).sum())
 
 
 class StateConstraint(ControlConstraint):
+    _NAME = "StateConstraint"
     def _v(self, x, u): return np.asarray(x, dtype=np.float64)
-    def get_state_jacobian(self, x, u): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
-    def get_control_jacobian(self, x, u): return np.zeros((2 * self.upper.size, np.asarray(u).size))
+    def get_state_jacobian(self, x, u, index=0): n = self.upper.size; return np.vstack([-np.eye(n), np.eye(n)]) * self.scale
+    def get_control_jacobian(self, x, u, index=0): return np.zeros((2 * self.upper.size, np.asarray(u).size))
 
 
-class BallConstraint(Constraint):   # constraint.hpp:313-404: g = -s |x[:d] - c|^2, upper = -s r^2
+class BallConstraint(_BuiltinConstraint):   # constraint.hpp:313-404: g = -s |x[:d] - c|^2, upper = -s r^2
     def __init__(self, radius, center, scale_factor=1.0):
+        Constraint.__init__(self, "BallConstraint")
         self.radius = radius; self.center = np.asarray(center, dtype=np.float64); self.scale = scale_factor
-    def evaluate(self, x, u): dlt = np.asarray(x)[:self.center.size] - self.center; return np.array([-self.scale * float(dlt @ dlt)])
+    def evaluate(self, x, u, index=0): dlt = np.asarray(x)[:self.center.size] - self.center; return np.array([-self.scale * float(dlt @ dlt)])
     def get_upper_bound(self): return np.array([-self.scale * self.radius * self.radius])
-    def get_state_jacobian(self, x, u):
+    def get_center(self): return self.center.copy()
+    def compute_violation_from_value(self, g):   # :353-358: max(0, g - lower bound) with lower bound -inf, as the reference has it
+        return float(max(0.0, float(np.asarray(g)[0]) - (-np.inf)))
+    def get_state_jacobian(self, x, u, index=0):
         J = np.zeros((1, np.asarray(x).size)); J[0, :self.center.size] = -2.0 * self.scale * (np.asarray(x)[:self.center.size] - self.center); return J
-    def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
-    def get_hessians(self, x, u):    # constraint.hpp:387-396
-        nx, nu = np.asarray(x).size, np.asarray(u).size; d = self.center.size
-        H = np.zeros((1, nx, nx)); H[0, :d, :d] = -2.0 * self.scale * np.eye(d)
-        return H, np.zeros((1, nu, nu)), np.zeros((1, nu, nx))
+    def get_control_jacobian(self, x, u, index=0): return np.zeros((1, np.asarray(u).size))
+    def get_state_hessian(self, x, u, index=0):    # :387-396
+        nx = np.asarray(x).size; d = self.center.size
+        H = np.zeros((nx, nx)); H[:d, :d] = -2.0 * self.scale * np.eye(d)
+        return [H]
 
 
-class LinearConstraint(Constraint):   # constraint.hpp:253-311: g = A x, upper = b
+class LinearConstraint(_BuiltinConstraint):   # constraint.hpp:253-311: g = A x, upper = b
     def __init__(self, A, b, scale_factor=1.0):
+        Constraint.__init__(self, "LinearConstraint")
         self.A = np.asarray(A, dtype=np.float64); self.b = np.asarray(b, dtype=np.float64)
-    def evaluate(self, x, u): return self.A @ np.asarray(x)
+    def evaluate(self, x, u, index=0): return self.A @ np.asarray(x)
     def get_upper_bound(self): return self.b
-    def get_state_jacobian(self, x, u): return self.A
-    def get_control_jacobian(self, x, u): return np.zeros((self.b.size, np.asarray(u).size))
+    def get_state_jacobian(self, x, u, index=0): return self.A
+    def get_control_jacobian(self, x, u, index=0): return np.zeros((self.b.size, np.asarray(u).size))
+    def compute_violation_from_value(self, g): return float(max(0.0, float((self.b - np.asarray(g, dtype=np.float64)).max())))   # :302-305, as written
 
 
-class SecondOrderConeConstraint(Constraint):   # constraint.hpp:626-800 / bind_constraints.cpp:146-150
+class SecondOrderConeConstraint(_BuiltinConstraint):   # constraint.hpp:626-800 / bind_constraints.cpp:146-150
     def __init__(self, cone_origin, opening_direction, cone_angle_fov, regularization_epsilon=1e-6, name="SecondOrderConeConstraint"):
         if cone_angle_fov < 0 or cone_angle_fov > np.pi:
             raise ValueError("SecondOrderConeConstraint: Cone angle must be between 0 and PI.")
@@ -417,19 +457,22 @@ class SecondOrderConeConstraint(Constraint):   # constraint.hpp:626-800 / bind_c
         a = np.asarray(opening_direction, dtype=np.float64).reshape(3); n = float(np.sqrt(a @ a))
         if n == 0.0:
             raise ValueError("SecondOrderConeConstraint: Opening direction cannot be zero vector.")
+        Constraint.__init__(self, name)
         self.origin = np.asarray(cone_origin, dtype=np.float64).reshape(3); self.axis = a / n
         self.fov = float(cone_angle_fov); self.cos_fov = float(np.cos(cone_angle_fov)); self.epsilon = float(regularization_epsilon)
     def get_dual_dim(self): return 1
-    def evaluate(self, x, u):
+    def evaluate(self, x, u, index=0):
         v = np.asarray(x, dtype=np.float64)[:3] - self.origin
         return np.array([np.sqrt(float(v @ v) + self.epsilon) * self.cos_fov - float(v @ self.axis)])
     def get_upper_bound(self): return np.zeros(1)
-    def get_state_jacobian(self, x, u):
+    def get_state_jacobian(self, x, u, index=0):
         x = np.asarray(x, dtype=np.float64); v = x[:3] - self.origin; rn = np.sqrt(float(v @ v) + self.epsilon)
         J = np.zeros((1, x.size)); J[0, :3] = self.cos_fov * (v / rn) - self.axis if rn > 1e-9 else -self.axis
         return J
-    def get_control_jacobian(self, x, u): return np.zeros((1, np.asarray(u).size))
-    def get_hessians(self, x, u): return None     # constraint.hpp:772-786: std::logic_error -> the barrier drops the curvature term
+    def get_control_jacobian(self, x, u, index=0): return np.zeros((1, np.asarray(u).size))
+    def _no_hessian(self, *a, **k):              # constraint.hpp:783-800: std::logic_error -> the barrier drops the curvature term
+        raise RuntimeError("SecondOrderConeConstraint: Hessians are not implemented.")
+    get_state_hessian = get_control_hessian = get_cross_hessian = _no_hessian
 
 
 def _norm_hessian(u, eps):          # constraint.hpp:899-920
@@ -437,7 +480,7 @@ def _norm_hessian(u, eps):          # constraint.hpp:899-920
     return (term * np.eye(u.size) - np.outer(u, u)) / den if den > sys.float_info.min else np.zeros((u.size, u.size))
 
 
-class ThrustMagnitudeConstraint(Constraint):   # constraint.hpp:802-927
+class ThrustMagnitudeConstraint(_BuiltinConstraint):   # constraint.hpp:802-927
     def __init__(self, min_thrust_norm, max_thrust_norm, epsilon=1e-6):
         if min_thrust_norm < 0.0:
             raise ValueError("ThrustMagnitudeConstraint: min_thrust_norm must be non-negative.")
@@ -445,40 +488,39 @@ class ThrustMagnitudeConstraint(Constraint):   # constraint.hpp:802-927
             raise ValueError("ThrustMagnitudeConstraint: max_thrust_norm must be greater than or equal to min_thrust_norm.")
         if epsilon <= 0.0:
             raise ValueError("ThrustMagnitudeConstraint: epsilon must be positive.")
+        Constraint.__init__(self, "ThrustMagnitudeConstraint")
         self.min_norm, self.max_norm, self.epsilon = float(min_thrust_norm), float(max_thrust_norm), float(epsilon)
     def get_dual_dim(self): return 2
-    def evaluate(self, x, u): n = np.sqrt(float(np.asarray(u) @ np.asarray(u))); return np.array([self.min_norm - n, n - self.max_norm])
+    def evaluate(self, x, u, index=0): n = np.sqrt(float(np.asarray(u) @ np.asarray(u))); return np.array([self.min_norm - n, n - self.max_norm])
     def get_upper_bound(self): return np.zeros(2)
-    def get_state_jacobian(self, x, u): return np.zeros((2, np.asarray(x).size))
-    def get_control_jacobian(self, x, u):
+    def compute_violation_from_value(self, g): return float(np.maximum(np.asarray(g, dtype=np.float64), 0.0).sum())
+    def get_state_jacobian(self, x, u, index=0): return np.zeros((2, np.asarray(x).size))
+    def get_control_jacobian(self, x, u, index=0):
         u = np.asarray(u, dtype=np.float64); rn = np.sqrt(float(u @ u) + self.epsilon); J = np.zeros((2, u.size))
         if not rn < self.epsilon:
             J[0] = -(u / rn); J[1] = u / rn
         return J
-    def get_hessians(self, x, u):
-        nx, nu = np.asarray(x).size, np.asarray(u).size; H = _norm_hessian(u, self.epsilon)
-        return np.zeros((2, nx, nx)), np.stack([-H, H]), np.zeros((2, nu, nx))
+    def get_control_hessian(self, x, u, index=0): H = _norm_hessian(u, self.epsilon); return [-H, H]
 
 
-class MaxThrustMagnitudeConstraint(Constraint):   # constraint.hpp:929-1048
+class MaxThrustMagnitudeConstraint(_BuiltinConstraint):   # constraint.hpp:929-1048
     def __init__(self, max_thrust_norm, epsilon=1e-6):
         if max_thrust_norm < 0.0:
             raise ValueError("MaxThrustMagnitudeConstraint: max_thrust_norm must be non-negative.")
         if epsilon <= 0.0:
             raise ValueError("MaxThrustMagnitudeConstraint: epsilon must be positive.")
+        Constraint.__init__(self, "MaxThrustMagnitudeConstraint")
         self.max_norm, self.epsilon = float(max_thrust_norm), float(epsilon)
     def get_dual_dim(self): return 1
-    def evaluate(self, x, u): return np.array([np.sqrt(float(np.asarray(u) @ np.asarray(u))) - self.max_norm])
+    def evaluate(self, x, u, index=0): return np.array([np.sqrt(float(np.asarray(u) @ np.asarray(u))) - self.max_norm])
     def get_upper_bound(self): return np.zeros(1)
-    def get_state_jacobian(self, x, u): return np.zeros((1, np.asarray(x).size))
-    def get_control_jacobian(self, x, u):
+    def get_state_jacobian(self, x, u, index=0): return np.zeros((1, np.asarray(x).size))
+    def get_control_jacobian(self, x, u, index=0):
         u = np.asarray(u, dtype=np.float64); rn = np.sqrt(float(u @ u) + self.epsilon); J = np.zeros((1, u.size))
         if rn > sys.float_info.min:
             J[0] = u / rn
         return J
-    def get_hessians(self, x, u):
-        nx, nu = np.asarray(x).size, np.asarray(u).size
-        return np.zeros((1, nx, nx)), _norm_hessian(u, self.epsilon)[None], np.zeros((1, nu, nx))
+    def get_control_hessian(self, x, u, index=0): return [_norm_hessian(u, self.epsilon)]
 
 
 class TerminalEqualityConstraint:   # terminal_constraint.hpp
@@ -529,6 +571,9 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def set_dynamical_system(self, system):
         if not isinstance(system, DynamicalSystem):
             raise TypeError("set_dynamical_system expects a DynamicalSystem (a built-in plant or a Python subclass)")
+        if type(system) is DynamicalSystem:     # bind_solver.cpp:478-484
+            raise TypeError("pycddp.DynamicalSystem is an abstract base class. Pass a concrete built-in model or a Python subclass that "
+                            "implements the required methods.")
         self._sys = system
     def set_objective(self, objective):
         if not isinstance(objective, Objective):
@@ -537,6 +582,9 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def add_constraint(self, name, constraint):
         if constraint is None:
             raise RuntimeError("Cannot add null constraint.")
+        if type(constraint) is Constraint:      # bind_solver.cpp:504-510
+            raise TypeError("pycddp.Constraint is an abstract base class. Pass a concrete built-in constraint or a Python subclass that "
+                            "implements the required methods.")
         self._cons[name] = constraint
     def add_terminal_constraint(self, name, constraint):
         if constraint is None:
@@ -545,9 +593,20 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def remove_constraint(self, name): return self._cons.pop(name, None) is not None
     def remove_terminal_constraint(self, name): return self._terms.pop(name, None) is not None
     def set_initial_trajectory(self, X, U):
-        X = [np.asarray(x, dtype=np.float64) for x in X]; U = [np.asarray(u, dtype=np.float64) for u in U]
-        if len(X) != self._N + 1 or len(U) != self._N:   # cddp_core.cpp:124-140
-            raise ValueError("Invalid trajectory lengths")
+        X = [np.asarray(x, dtype=np.float64).reshape(-1) for x in X]; U = [np.asarray(u, dtype=np.float64).reshape(-1) for u in U]
+        if self._sys is None:   # validateInitialTrajectory, bind_solver.cpp:106-152 (getStateDim throws without a system, cddp_core.cpp)
+            raise ValueError("set_initial_trajectory failed while querying dimensions (is a dynamical system set?): "
+                             "Dynamical system is not set")
+        nx, nu = self._sys.state_dim, self._sys.control_dim
+        if len(X) != self._N + 1 or len(U) != self._N:
+            raise ValueError("set_initial_trajectory expected X length %d and U length %d, got X length %d and U length %d."
+                             % (self._N + 1, self._N, len(X), len(U)))
+        for i, x in enumerate(X):
+            if x.size != nx:
+                raise ValueError("set_initial_trajectory expected state vector %d to have dimension %d, got %d." % (i, nx, x.size))
+        for i, u in enumerate(U):
+            if u.size != nu:
+                raise ValueError("set_initial_trajectory expected control vector %d to have dimension %d, got %d." % (i, nu, u.size))
         self._X, self._U = np.stack(X), np.stack(U)
 
     initial_state = property(lambda self: self._x0)
@@ -660,18 +719,24 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         if not ipddp and "ControlConstraint" in self._cons and isinstance(self._cons["ControlConstraint"], ControlConstraint):
             lo, up = self._cons["ControlConstraint"].lower, self._cons["ControlConstraint"].upper   # clddp_solver.cpp:85-86
 
-        def constraints(x, u, index, want):
-            g = np.concatenate([np.asarray(c.evaluate(x, u), dtype=np.float64) - np.asarray(c.get_upper_bound(), dtype=np.float64) for c in cons])
+        def constraints(x, u, index, want):   # evaluate / Jacobians with the step index, as the solvers call them (constraint.hpp:44-72)
+            g = np.concatenate([np.asarray(c.evaluate(x, u, index), dtype=np.float64) - np.asarray(c.get_upper_bound(), dtype=np.float64) for c in cons])
             if not want:
                 return g, None, None
-            return (g, np.vstack([np.asarray(c.get_state_jacobian(x, u), dtype=np.float64).reshape(-1, nx) for c in cons]),
-                    np.vstack([np.asarray(c.get_control_jacobian(x, u), dtype=np.float64).reshape(-1, nu) for c in cons]))
+            return (g, np.vstack([np.asarray(c.get_state_jacobian(x, u, index), dtype=np.float64).reshape(-1, nx) for c in cons]),
+                    np.vstack([np.asarray(c.get_control_jacobian(x, u, index), dtype=np.float64).reshape(-1, nu) for c in cons]))
 
-        def constraint_hessians(x, u, index):
-            hs = [c.get_hessians(x, u) for c in cons]
-            z = lambda c: (np.zeros((c.get_dual_dim(), nx, nx)), np.zeros((c.get_dual_dim(), nu, nu)), np.zeros((c.get_dual_dim(), nu, nx)))
-            hs = [h if h is not None else z(c) for h, c in zip(hs, cons)]
-            return tuple(np.concatenate([np.asarray(h[k], dtype=np.float64) for h in hs]) for k in range(3))
+        def constraint_hessians(x, u, index):   # getHessians (constraint.hpp:122-131); a constraint that throws contributes no curvature
+            out = ([], [], [])
+            for c, r in zip(cons, dims):
+                try:
+                    trip = (c.get_state_hessian(x, u, index), c.get_control_hessian(x, u, index), c.get_cross_hessian(x, u, index))
+                    trip = tuple(np.asarray(np.stack([np.asarray(h, dtype=np.float64) for h in hl]) if len(hl) else np.zeros((0, 1, 1))) for hl in trip)
+                except RuntimeError:
+                    trip = (np.zeros((r, nx, nx)), np.zeros((r, nu, nu)), np.zeros((r, nu, nx)))
+                for k, shape in enumerate(((r, nx, nx), (r, nu, nu), (r, nu, nx))):
+                    out[k].append(trip[k].reshape(shape))
+            return tuple(np.concatenate(o) for o in out)
 
         def hessians(x, u, t):
             return (np.stack([np.asarray(h) for h in s.get_state_hessian(x, u, t)]), np.stack([np.asarray(h) for h in s.get_control_hessian(x, u, t)]),

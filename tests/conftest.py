@@ -11,7 +11,10 @@ def load_api():
     """Import cddp-cpp_amd/pyapi.py (the directory name is not a valid Python identifier)."""
     name = "cddp_cpp_amd_pyapi"
     if name in sys.modules:
-        return sys.modules[name]
+        mod = sys.modules[name]
+        if not hasattr(mod, "ORACLE_LIB_PATH"):   # first imported by the product facade (pycddp_amd), which never loads the checker
+            load_oracle_api().attach(mod)
+        return mod
     # PyTorch bundles its own ROCm runtime: a process that uses both must import torch FIRST, so that libcddp_hip.so binds the
     # runtime torch already loaded (INTEGRATION.md section 4; bench.py does the same).  Only when a GPU test session will want it.
     if os.path.exists("/dev/kfd"):
