@@ -12,9 +12,9 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (twin_*.json are the numpy twin's vectors -> tests/test_twin_golden.py; trig_noise_flip_rates.json -> test_oracle_trig_noise.py;
-#  portfolio_thresholds.json -> test_pycddp_portfolio.py)
+#  portfolio_thresholds.json -> test_pycddp_portfolio.py; ref_boxqp_inputs.json -> test_reference_plant_pins.py)
 FIXTURES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.json"))
-                  if not os.path.basename(f).startswith(("twin_", "trig_noise", "portfolio_")))
+                  if not os.path.basename(f).startswith(("twin_", "trig_noise", "portfolio_", "ref_")))
 TOL_GPU = 1e-8
 TOL_CPU = 1e-11   # same code, possibly another libm build
 
