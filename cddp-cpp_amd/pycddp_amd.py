@@ -279,6 +279,144 @@ class LTISystem(DynamicalSystem):   # :233-237
 
 
 # ------------------------------------------------------------------------------------------------ objective / constraints
+# ---- plants without device kernels: evaluated on the host and solved through the plug-in route (GPU backward passes, host rollouts)
+def _fd_jacobian(f, x, h=2e-5):     # helper.hpp:95-119 (finite_difference_jacobian, central differences)
+    x = np.asarray(x, dtype=np.float64); xp = x.copy(); cols = []
+    for i in range(x.size):
+        xp[i] = x[i] + h; fp = np.asarray(f(xp), dtype=np.float64)
+        xp[i] = x[i] - h; fm = np.asarray(f(xp), dtype=np.float64)
+        cols.append((fp - fm) / (2.0 * h)); xp[i] = x[i]
+    return np.stack(cols, axis=1)
+
+
+class _HostPlant(DynamicalSystem):
+    """A plant of the reference restated on the host only (model None: no kernels).  Zero Hessian blocks unless the subclass has some."""
+    def get_state_hessian(self, state, control, time=0.0): return [np.zeros((self.state_dim, self.state_dim)) for _ in range(self.state_dim)]
+    def get_control_hessian(self, state, control, time=0.0): return [np.zeros((self.control_dim, self.control_dim)) for _ in range(self.state_dim)]
+    def get_cross_hessian(self, state, control, time=0.0): return [np.zeros((self.control_dim, self.state_dim)) for _ in range(self.state_dim)]
+
+
+class DubinsCar(_HostPlant):        # dubins_car.cpp:24-141 / bind_dynamics.cpp:160-162: state [x, y, theta], control [omega], constant speed
+    def __init__(self, speed, timestep, integration_type="euler"):
+        super().__init__(3, 1, timestep, integration_type); self.speed = float(speed)
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        return np.array([self.speed * np.cos(state[2]), self.speed * np.sin(state[2]), control[0]])
+    def get_state_jacobian(self, state, control, time=0.0):
+        A = np.zeros((3, 3)); A[0, 2] = -self.speed * np.sin(state[2]); A[1, 2] = self.speed * np.cos(state[2]); return A
+    def get_control_jacobian(self, state, control, time=0.0): B = np.zeros((3, 1)); B[2, 0] = 1.0; return B
+    def get_state_hessian(self, state, control, time=0.0):
+        H = super().get_state_hessian(state, control, time)
+        H[0][2, 2] = -self.speed * np.cos(state[2]); H[1][2, 2] = -self.speed * np.sin(state[2]); return H
+
+
+class DreyfusRocket(_HostPlant):    # dreyfus_rocket.cpp:24-83 / bind_dynamics.cpp:212-216: state [x, x_dot], control [theta]
+    def __init__(self, timestep, integration_type="rk4", thrust_acceleration=64.0, gravity_acceleration=32.0):
+        super().__init__(2, 1, timestep, integration_type)
+        self.thrust_acceleration, self.gravity_acceleration = float(thrust_acceleration), float(gravity_acceleration)
+    def get_thrust_acceleration(self): return self.thrust_acceleration
+    def get_gravity_acceleration(self): return self.gravity_acceleration
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        return np.array([state[1], self.thrust_acceleration * np.cos(control[0]) - self.gravity_acceleration])
+    def get_state_jacobian(self, state, control, time=0.0): A = np.zeros((2, 2)); A[0, 1] = 1.0; return A
+    def get_control_jacobian(self, state, control, time=0.0):
+        B = np.zeros((2, 1)); B[1, 0] = -self.thrust_acceleration * np.sin(control[0]); return B
+    def get_control_hessian(self, state, control, time=0.0):
+        H = super().get_control_hessian(state, control, time); H[1][0, 0] = -self.thrust_acceleration * np.cos(control[0]); return H
+
+
+def _cs_jacobian(f, x, h=1e-30):    # complex-step derivative: the value autodiff's forward duals give, to rounding (no subtraction, no step error)
+    x = np.asarray(x, dtype=np.complex128); cols = []
+    for i in range(x.size):
+        xp = x.copy(); xp[i] += 1j * h
+        cols.append(np.asarray(f(xp)).imag / h)
+    return np.stack(cols, axis=1)
+
+
+class Acrobot(_HostPlant):          # acrobot.cpp:24-96 / bind_dynamics.cpp:172-175: state [theta1, theta2, theta1_dot, theta2_dot], control [torque]
+    """The reference differentiates its autodiff twin of the same expressions (dynamical_system.cpp: getStateJacobian by forward
+    duals); here the Jacobians are complex-step derivatives of the one restatement below -- equal to the dual-number values to rounding."""
+    gravity, friction = 9.81, 1.0     # acrobot.hpp:138-139
+    def __init__(self, timestep, l1=1.0, l2=1.0, m1=1.0, m2=1.0, J1=1.0, J2=1.0, integration_type="euler"):
+        super().__init__(4, 1, timestep, integration_type); self.l1, self.l2, self.m1, self.m2, self.J1, self.J2 = l1, l2, m1, m2, J1, J2
+    def _f(self, s, c):
+        l1, l2, m1, m2, J1, J2 = self.l1, self.l2, self.m1, self.m2, self.J1, self.J2
+        th1, th2, w1, w2 = s[0], s[1], s[2], s[3]
+        c1, s2, c2, c12 = np.cos(th1), np.sin(th2), np.cos(th2), np.cos(th1 + th2)
+        m11 = m1 * l1 * l1 + J1 + m2 * (l1 * l1 + l2 * l2 + 2 * l1 * l2 * c2) + J2
+        m12 = m2 * (l2 * l2 + l1 * l2 * c2) + J2
+        m22 = l2 * l2 * m2 + J2
+        tmp = l1 * l2 * m2 * s2
+        b1 = -(2 * w1 * w2 + w2 * w2) * tmp; b2 = tmp * w1 * w1
+        g1 = ((m1 + m2) * l1 * c1 + m2 * l2 * c12) * self.gravity; g2 = m2 * l2 * c12 * self.gravity
+        r1 = 0.0 - b1 - g1 - self.friction * w1; r2 = c[0] - b2 - g2 - self.friction * w2
+        inv_det = 1.0 / (m11 * m22 - m12 * m12)       # Eigen's 2 x 2 inverse: cofactors times 1 / det
+        return np.array([w1, w2, (m22 * inv_det) * r1 + (-m12 * inv_det) * r2, (-m12 * inv_det) * r1 + (m11 * inv_det) * r2])
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        return self._f(np.asarray(state, dtype=np.float64), np.asarray(control, dtype=np.float64))
+    def get_state_jacobian(self, state, control, time=0.0):
+        return _cs_jacobian(lambda s: self._f(s, np.asarray(control, dtype=np.complex128)), state)
+    def get_control_jacobian(self, state, control, time=0.0):
+        return _cs_jacobian(lambda c: self._f(np.asarray(state, dtype=np.complex128), c), control)
+    def _no_hessian(self, *a, **k):
+        raise NotImplementedError("Acrobot: second derivatives are not restated (the reference takes them from autodiff); use_ilqr = True")
+    get_state_hessian = get_control_hessian = get_cross_hessian = _no_hessian
+
+
+def _inv3_cofactor(M):              # Eigen's fixed 3 x 3 inverse: cofactors times 1 / det
+    c = lambda i, j: M[(i + 1) % 3, (j + 1) % 3] * M[(i + 2) % 3, (j + 2) % 3] - M[(i + 1) % 3, (j + 2) % 3] * M[(i + 2) % 3, (j + 1) % 3]
+    C = np.array([[c(i, j) for j in range(3)] for i in range(3)])
+    det = M[0, 0] * C[0, 0] + M[0, 1] * C[0, 1] + M[0, 2] * C[0, 2]
+    return C.T * (1.0 / det)
+
+
+class Usv3Dof(_HostPlant):          # usv_3dof.cpp:11-110 / bind_dynamics.cpp: state [x, y, psi, u, v, r], control [tau_u, tau_v, tau_r]
+    """Generic surface-vessel parameters of the reference (:17-34).  Jacobians: complex-step derivatives of the restated dynamics (the
+    reference writes the same derivatives out by hand, :152-227); the control Hessian is zero (:237-248), the others are not restated."""
+    def __init__(self, timestep, integration_type="euler"):
+        super().__init__(6, 3, timestep, integration_type)
+        self.m, self.Iz = 100.0, 10.0
+        self.X_udot, self.Y_vdot, self.Y_rdot, self.N_vdot, self.N_rdot = -10.0, -50.0, -5.0, -5.0, -5.0
+        self.X_u, self.Y_v, self.Y_r, self.N_v, self.N_r = -20.0, -100.0, 0.0, 0.0, -20.0
+        M = np.diag([self.m, self.m, self.Iz]) + np.array([[-self.X_udot, 0, 0], [0, -self.Y_vdot, -self.Y_rdot], [0, -self.N_vdot, -self.N_rdot]])
+        self.M_inv = _inv3_cofactor(M)
+        self.D_L = np.array([[-self.X_u, 0, 0], [0, -self.Y_v, -self.Y_r], [0, -self.N_v, -self.N_r]])
+    def _f(self, s, tau):
+        psi, u, v, r = s[2], s[3], s[4], s[5]
+        c, sn = np.cos(psi), np.sin(psi)
+        m_x, m_y, m_yr = self.m - self.X_udot, self.m - self.Y_vdot, -self.Y_rdot
+        nu = np.array([u, v, r])
+        Cnu = np.array([(-m_y * v - m_yr * r) * r, (m_x * u) * r, (m_y * v + m_yr * r) * u + (-m_x * u) * v])
+        nd = self.M_inv @ (tau - Cnu - self.D_L @ nu)
+        return np.array([c * u - sn * v, sn * u + c * v, r, nd[0], nd[1], nd[2]])
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        return self._f(np.asarray(state, dtype=np.float64), np.asarray(control, dtype=np.float64))
+    def get_state_jacobian(self, state, control, time=0.0):
+        return _cs_jacobian(lambda s: self._f(s, np.asarray(control, dtype=np.complex128)), state)
+    def get_control_jacobian(self, state, control, time=0.0):
+        return _cs_jacobian(lambda c: self._f(np.asarray(state, dtype=np.complex128), c), control)
+    def _no_hessian(self, *a, **k):
+        raise NotImplementedError("Usv3Dof: state / cross second derivatives are not restated (autodiff in the reference); use_ilqr = True")
+    get_state_hessian = get_cross_hessian = _no_hessian
+
+
+class SpacecraftLinearFuel(_HostPlant):   # spacecraft_linear_fuel.cpp:29-158 / bind_dynamics.cpp:199-203
+    """HCW relative motion with mass: state [x, y, z, vx, vy, vz, mass, accumulated control effort], control [Fx, Fy, Fz]; the
+    reference's Jacobians are central finite differences of the continuous dynamics (:124-141), its Hessians zero (:144-158)."""
+    def __init__(self, timestep, mean_motion, isp, g0=9.80665, integration_type="euler"):
+        super().__init__(8, 3, timestep, integration_type)
+        self.mean_motion, self.isp, self.g0, self.epsilon = float(mean_motion), float(isp), float(g0), 1e-8
+    def get_continuous_dynamics(self, state, control, time=0.0):
+        x, y, z, vx, vy, vz, mass = (state[i] for i in range(7)); Fx, Fy, Fz = control[0], control[1], control[2]
+        n = self.mean_motion; n2 = n * n
+        t2 = Fx * Fx + Fy * Fy + Fz * Fz
+        return np.array([vx, vy, vz, 2.0 * n * vy + 3.0 * n2 * x + Fx / mass, -2.0 * n * vx + Fy / mass, -n2 * z + Fz / mass,
+                         -np.sqrt(t2 + self.epsilon) / (self.isp * self.g0), 0.5 * t2])
+    def get_state_jacobian(self, state, control, time=0.0):
+        return _fd_jacobian(lambda s: self.get_continuous_dynamics(s, control, time), state)
+    def get_control_jacobian(self, state, control, time=0.0):
+        return _fd_jacobian(lambda c: self.get_continuous_dynamics(state, c, time), control)
+
+
 class Objective:                    # objective.hpp:30-120 / bind_objective.cpp:34-45: bound WITHOUT a constructor
     def __init__(self, *args, **kwargs):
         # pybind11's message for a class bound without py::init; Python-defined objectives derive from NonlinearObjective (:62-63)

@@ -1,8 +1,9 @@
 """The reference's Python-facing tests that are about the API surface (no solve, or a short one), restated against the facade so that they
 travel to the GPU box: python/tests/test_constraints.py, python/tests/test_solver_errors.py:21-124, python/tests/test_all_dynamics.py.
 In the build container the reference's own files were also run UNCHANGED against the facade (`sys.modules["pycddp"] = pycddp_amd`):
-every test that needs neither a GPU nor a plant the facade does not provide passes (29 of 50; the remainder are 16 solves -- replayed
-on the GPU here and in test_pycddp_facade / test_host_plugins / test_pycddp_portfolio -- and the five plants listed at the bottom).
+every test that needs no GPU passes (34 of 50; the remainder are 16 solves -- replayed
+on the GPU here and in test_pycddp_facade / test_host_plugins / test_pycddp_portfolio; with the five host-only plants at the bottom all
+13 tests of test_all_dynamics.py pass).
 Error types and message fragments are the ones the reference's tests match on (bind_solver.cpp:106-152, 478-510, 640-650)."""
 import importlib.util
 import os
@@ -159,8 +160,60 @@ def test_all_provided_dynamics_models(pycddp):
     _check_model(pycddp.LTISystem(np.array([[0, 1], [-1, 0]]), np.array([[0], [1]]), 0.01), np.array([1.0, 0.0]), np.array([0.5]))   # :82-86
 
 
-def test_plants_of_the_reference_that_are_not_provided(pycddp):
-    """DubinsCar, Acrobot, SpacecraftLinearFuel, DreyfusRocket, Usv3Dof (test_all_dynamics.py:47-79) have no device kernels and no
-    host model here: the names are absent rather than present and silently different."""
-    for name in ("DubinsCar", "Acrobot", "SpacecraftLinearFuel", "DreyfusRocket", "Usv3Dof"):
-        assert not hasattr(pycddp, name)
+def test_host_only_plants(pycddp):
+    """DubinsCar, Acrobot, SpacecraftLinearFuel, DreyfusRocket, Usv3Dof (test_all_dynamics.py:47-79) have no device kernels: the facade
+    restates them on the host (analytic / complex-step / the reference's finite-difference Jacobians) and solves them through the
+    plug-in route.  Shapes as the reference checks them, Jacobians against central differences, and the properties the reference's C++
+    plant tests assert (tests/dynamics_model/test_{dreyfus_rocket,acrobot,usv_3dof}.cpp)."""
+    cases = [(pycddp.DubinsCar(1.0, 0.1), np.zeros(3), np.array([0.5])),                                                    # :47-49
+             (pycddp.Acrobot(0.01), np.zeros(4), np.array([1.0])),                                                         # :52-54
+             (pycddp.SpacecraftLinearFuel(1.0, mean_motion=0.001, isp=300.0), np.r_[np.zeros(6), 50.0, 0.0], np.array([0.01, 0.01, 0.01])),   # :67-69 (mass 50: the reference's all-zero state divides by the mass)
+             (pycddp.DreyfusRocket(0.01), np.array([0.0, 100.0]), np.array([0.5])),                                         # :72-74
+             (pycddp.Usv3Dof(0.1), np.zeros(6), np.array([1.0, 0.0, 0.0]))]                                                 # :77-79
+    rng = np.random.default_rng(4)
+    for model, x, u in cases:
+        _check_model(model, x, u)
+        xr = x + 0.3 * rng.standard_normal(x.size); ur = u + 0.3 * rng.standard_normal(u.size)
+        if isinstance(model, pycddp.SpacecraftLinearFuel): xr[6] = 50.0
+        A = model.get_state_jacobian(xr, ur); B = model.get_control_jacobian(xr, ur)
+        Afd = pycddp._fd_jacobian(lambda s: model.get_continuous_dynamics(s, ur), xr, 1e-6)
+        Bfd = pycddp._fd_jacobian(lambda c: model.get_continuous_dynamics(xr, c), ur, 1e-6)
+        assert np.max(np.abs(A - Afd)) < 1e-6 and np.max(np.abs(B - Bfd)) < 1e-6, type(model).__name__
+    rocket = pycddp.DreyfusRocket(0.05)                                   # test_dreyfus_rocket.cpp:27-68
+    assert rocket.integration_type == "rk4" and rocket.get_thrust_acceleration() == 64.0 and rocket.get_gravity_acceleration() == 32.0
+    st = np.array([0.0, 0.0]); h0 = st[0]
+    for _ in range(100):
+        st = rocket.get_discrete_dynamics(st, np.array([0.0]))
+    assert st[0] > h0 and st[1] > 0.0
+    acro = pycddp.Acrobot(0.01, integration_type="rk4")                   # test_acrobot.cpp:104-187
+    B = acro.get_control_jacobian(np.array([0.1, 0.2, 0.0, 0.0]), np.array([0.5]))
+    assert B[0, 0] == 0.0 and B[1, 0] == 0.0 and B[2, 0] != 0.0 and B[3, 0] != 0.0
+    sd = acro.get_continuous_dynamics(np.array([np.pi / 4, np.pi / 6, 0.0, 0.0]), np.array([0.0]))
+    assert abs(sd[0]) < 1e-10 and abs(sd[1]) < 1e-10 and abs(sd[2]) > 1e-6
+    pos = acro.get_continuous_dynamics(np.array([0.1, 0.2, 0.0, 0.0]), np.array([1.0])); neg = acro.get_continuous_dynamics(np.array([0.1, 0.2, 0.0, 0.0]), np.array([-1.0]))
+    assert pos[0] == neg[0] and pos[1] == neg[1] and pos[2] != neg[2] and pos[3] != neg[3]
+    usv = pycddp.Usv3Dof(0.1)                                             # test_usv_3dof.cpp:30-90
+    x0 = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0]); u0 = np.array([10.0, 0.0, 1.0])
+    assert not np.allclose(usv.get_discrete_dynamics(x0, u0), x0)
+    assert all(np.allclose(h, 0.0) and h.shape == (3, 3) for h in usv.get_control_hessian(x0, u0)) and len(usv.get_control_hessian(x0, u0)) == 6
+
+
+@pytest.mark.gpu
+def test_host_only_plant_solves_through_the_plugin_route(pycddp):
+    """A Dubins car steered to a pose by CLDDP and IPDDP: GPU backward passes on the stack-fed sweep, host rollouts of the restated plant."""
+    dt, N = 0.1, 40
+    x0 = np.zeros(3); goal = np.array([2.0, 1.0, 0.5])
+    for stype in (pycddp.SolverType.CLDDP, pycddp.SolverType.IPDDP):
+        opts = pycddp.CDDPOptions(); opts.max_iterations = 60; opts.verbose = False; opts.print_solver_header = False
+        solver = pycddp.CDDP(x0, goal, N, dt, opts)
+        solver.set_dynamical_system(pycddp.DubinsCar(1.0, dt))
+        solver.set_objective(pycddp.QuadraticObjective(np.zeros((3, 3)), 0.1 * np.eye(1), 50.0 * np.eye(3), goal, [], dt))
+        solver.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([-1.5]), np.array([1.5])))
+        sol = solver.solve(stype)
+        X = np.stack(sol.state_trajectory); U = np.stack(sol.control_trajectory)
+        assert sol.status_message and np.all(np.isfinite(X)) and np.max(np.abs(U)) <= 1.5 + 1e-9
+        assert sol.final_objective < 0.5 * 50.0 * float((x0 - goal) @ (x0 - goal))      # well below the cost of standing still
+        x = x0.copy()
+        for t in range(N):                                                # the returned trajectory is a rollout of the plant
+            x = pycddp.DubinsCar(1.0, dt).get_discrete_dynamics(x, U[t])
+            assert np.max(np.abs(x - X[t + 1])) < 1e-9
