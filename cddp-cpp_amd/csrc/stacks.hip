@@ -576,8 +576,8 @@ typedef void (*LaunchFn)(const StackArgs &, hipStream_t);
 LaunchFn pick(int nx, int nu, int m) {
 #define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch<X, U, MM>;
 #ifndef CDDP_STACKS_DEV_SHAPE   // (kernel-development builds define it: one cooperative shape, seconds per compile; never set by the Makefile)
-  PICK(1, 1, 0) PICK(1, 1, 1) PICK(1, 1, 2) PICK(2, 1, 0) PICK(2, 1, 2) PICK(4, 1, 0) PICK(4, 1, 2)
-  PICK(3, 2, 0) PICK(3, 2, 4) PICK(3, 2, 5) PICK(4, 2, 0) PICK(4, 2, 4) PICK(6, 3, 0) PICK(6, 3, 6)
+  PICK(1, 1, 0) PICK(1, 1, 1) PICK(1, 1, 2) PICK(2, 1, 0) PICK(2, 1, 2) PICK(3, 1, 0) PICK(3, 1, 2) PICK(4, 1, 0) PICK(4, 1, 2)
+  PICK(3, 2, 0) PICK(3, 2, 4) PICK(3, 2, 5) PICK(4, 2, 0) PICK(4, 2, 4) PICK(6, 3, 0) PICK(6, 3, 6) PICK(8, 3, 0) PICK(8, 3, 6)
   PICK(12, 4, 0) PICK(12, 4, 8) PICK(13, 4, 0) PICK(13, 4, 8) PICK(14, 7, 0)
 #endif
 #undef PICK
