@@ -1567,13 +1567,28 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
     int win = -1;
     // t_success: 0 failed, 1 passed, 2 passed every test but its costate trial is not finite (k_costate) = failed
     if (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) {
-      bool past_bad = false;   // k_costate stopped at a trial flagged 2: later candidates have no costate rows yet
-      for (int a = lo; a < hi; ++a) {
-        const int sc = d.t_success[(size_t)a * d.Bp + b];
-        if (sc == 0) continue;
-        if (sc == 2) { past_bad = ipddp; continue; }
-        if (past_bad && !costate_trial_serial<NXu>(d, b, d.cur[b], a)) continue;
-        win = a; break;
+      // The flags are fetched eight at a time (loads in flight together): walking them one by one is up to n_alpha dependent L2 round
+      // trips on this one-lane-per-trajectory kernel, and a wave walks as far as its worst lane -- the whole ladder whenever one of
+      // its 64 trajectories accepts nothing.  first1 = the first trial flagged 1, bad = a trial flagged 2 in front of it.
+      int first1 = -1; bool bad = false;
+      for (int base = lo; base < hi && first1 < 0; base += 8) {
+        int f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (base + i < hi) ? d.t_success[(size_t)(base + i) * d.Bp + b] : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (first1 < 0) { if (f[i] == 1) first1 = base + i; else if (f[i] == 2) bad = true; }
+      }
+      if (first1 < 0 || !(bad && ipddp)) win = first1;
+      else {
+        bool past_bad = false;   // k_costate stopped at a trial flagged 2: later candidates have no costate rows yet
+        for (int a = lo; a < hi; ++a) {
+          const int sc = d.t_success[(size_t)a * d.Bp + b];
+          if (sc == 0) continue;
+          if (sc == 2) { past_bad = ipddp; continue; }
+          if (past_bad && !costate_trial_serial<NXu>(d, b, d.cur[b], a)) continue;
+          win = a; break;
+        }
       }
     } else {
       // best-merit rule: k_costate evaluated the costate of ONE trial per trajectory, the least-merit trial among those that passed
