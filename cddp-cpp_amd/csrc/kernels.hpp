@@ -1624,24 +1624,32 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
       if (win >= 0) {
         // ---- applyForwardPassResult (cddp_solver_base.cpp:190-198, ipddp_solver.cpp:1878-1951)
         const size_t ti = (size_t)win * d.Bp + b;
+        // Every word this block reads is fetched BEFORE its first store: the DevBuf arrays may alias as far as the compiler knows, so a
+        // load behind a store cannot be hoisted above it, and "d.x[b] = d.t_x[ti]" line by line is one dependent L2 round trip per line
+        // on this one-lane-per-trajectory kernel (measured: 10 us of the kernel's 26, profiles/r03_k4_block_times.md).
         const int old_cur = d.cur[b];
-        const double dJ = d.cost[b] - d.t_cost[ti];
+        const double w_cost = d.t_cost[ti], w_merit = d.t_merit[ti], w_apr = d.t_apr[ti], w_theta = d.t_theta[ti];
+        const double w_adu = ipddp ? d.t_adu[ti] : 1.0, w_ipr = ipddp ? d.t_inf_pr[ti] : 0.0, w_icomp = ipddp ? d.t_inf_comp[ti] : 0.0;
+        const double dJ = d.cost[b] - w_cost;
+        const double c_reg = d.reg[b], c_sn = d.step_norm[b];   // not written before their use below
         // rollouts the reference runs to get here: the first-success rule stops at the winner, the best-merit rule
         // (one std::async per alpha, cddp_solver_base.cpp:264-286) always evaluates the whole ladder
-        d.n_fwd[b] += (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
-        { int ns = 0; const int na_walked = (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
-          for (int a = 0; a < na_walked; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
-          d.n_fwd_steps[b] += ns; }
+        const int na_walked = (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
+        int ns = d.n_fwd_steps[b];
+        for (int a = 0; a < na_walked; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
+        const int nf = d.n_fwd[b] + na_walked;
+        d.n_fwd[b] = nf;
+        d.n_fwd_steps[b] = ns;
         d.cur[b] = trial_slot(old_cur, win);
-        d.cost[b] = d.t_cost[ti];
-        d.merit[b] = d.t_merit[ti];
-        d.alpha_pr[b] = d.t_apr[ti];
-        d.alpha_du[b] = ipddp ? d.t_adu[ti] : 1.0;
+        d.cost[b] = w_cost;
+        d.merit[b] = w_merit;
+        d.alpha_pr[b] = w_apr;
+        d.alpha_du[b] = w_adu;
         int st = CDDP_HIP_STATUS_RUNNING;
         bool conv = false;
         if (ipddp) {
-          d.inf_pr[b] = d.t_inf_pr[ti]; d.inf_comp[b] = d.t_inf_comp[ti];
-          d.phi[b] = d.t_merit[ti]; d.filter_theta[b] = d.t_theta[ti]; d.theta[b] = d.t_theta[ti];
+          d.inf_pr[b] = w_ipr; d.inf_comp[b] = w_icomp;
+          d.phi[b] = w_merit; d.filter_theta[b] = w_theta; d.theta[b] = w_theta;
           if constexpr (TERM) {   // terminal slack / dual / residual / multipliers of the winner (:1900-1941)
             for (int i = 0; i < mT; ++i) {
               const size_t k2 = ((size_t)win * kMTMax + i) * d.Bp + b;
@@ -1655,7 +1663,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
           const double mu_old = mu;
           if (!nobar) {
             if (o.barrier_strategy == CDDP_HIP_BARRIER_ADAPTIVE) {
-              const double kkt = dmax(dmax(d.inf_pr[b], sdu), d.inf_comp[b]);
+              const double kkt = dmax(dmax(w_ipr, sdu), w_icomp);   // = d.inf_pr[b], d.inf_comp[b], stored above
               const double threshold = dmax(o.barrier_mu_update_factor * mu, 2.0 * mu);
               if (kkt <= threshold) {
                 double factor = o.barrier_mu_update_factor;
@@ -1670,7 +1678,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
                 mu = dmax(dmin(linear, superlinear), dmax(o.barrier_mu_min_value, o.tolerance / 100.0));
               }
             } else {
-              const double kkt = dmax(dmax(d.inf_pr[b], sdu * o.ipddp_barrier_update_dual_weight), d.inf_comp[b]);
+              const double kkt = dmax(dmax(w_ipr, sdu * o.ipddp_barrier_update_dual_weight), w_icomp);
               if (kkt <= o.ipddp_mu_kappa_epsilon * mu) {
                 const double linear = o.barrier_mu_update_factor * mu;
                 const double superlinear = solver_pow(mu, o.barrier_mu_update_power);
@@ -1683,7 +1691,7 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
           // computeTheta / computeBarrierMerit / computePrimalAndComplementarity on the accepted iterate
           // (ipddp_solver.cpp:2622-2656).  With an unchanged mu they are the very sums the winning trial
           // already evaluated (same routine, same order), so the pass over S/Y/G is only repeated when mu moved.
-          double phi_n = d.t_merit[ti], theta_n = d.t_theta[ti], ipr = d.t_inf_pr[ti], icomp = d.t_inf_comp[ti];
+          double phi_n = w_merit, theta_n = w_theta, ipr = w_ipr, icomp = w_icomp;
           if constexpr (TERM) {
             if (mu != mu_old) {
               TermState ts;
@@ -1758,17 +1766,17 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
           const bool reset = (mu < mu_old) && (mu > 0.0);
           if (reset) {   // filter cleared; re-seeded only when terminal constraints exist (:2629-2637)
             d.filt_n[b] = 0;
-            if (mT > 0 || pT > 0) filter_accept(d, b, d.phi[b], ftheta);
+            if (mT > 0 || pT > 0) filter_accept(d, b, w_merit, ftheta);   // (w_merit = d.phi[b], stored above)
           }
-          else { filter_accept(d, b, d.phi[b], ftheta); if (d.filt_n[b] > o.ipddp_max_filter_size) filter_prune(d, b); }
+          else { filter_accept(d, b, w_merit, ftheta); if (d.filt_n[b] > o.ipddp_max_filter_size) filter_prune(d, b); }
           d.inf_pr[b] = ipr; d.inf_comp[b] = icomp;
           d.merit[b] = phi_n; d.phi[b] = phi_n; d.filter_theta[b] = ftheta;
           d.theta[b] = dmax(ftheta, dmax(o.ipddp_theta_0_floor, 1e-8));
           hist_push(d, b, mu);
-          d.reg[b] = reg_decrease(o, d.reg[b]);
+          d.reg[b] = reg_decrease(o, c_reg);
           // ---- checkConvergence (ipddp_solver.cpp:1953-2025)
           const double sdu2 = scaled_inf_du<Model, Cons>(d, b, old_cur);
-          const double scomp = d.inf_comp[b], pr = d.inf_pr[b], sn = d.step_norm[b];
+          const double scomp = icomp, pr = ipr, sn = c_sn;   // the values just stored / fetched at the top
           if (nobar) {
             if (pr < o.tolerance && sdu2 < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; conv = true; }
             else if (o.acceptable_tolerance > 0.0) {
