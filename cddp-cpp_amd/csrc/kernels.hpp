@@ -1551,6 +1551,7 @@ template <class Model, class Cons, bool TERM = false>
 __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int stage, int n1, int is_last_iter, int do_count) {
   constexpr int M = Cons::M;
   constexpr int NXu = Model::NX;
+  constexpr int kRB = (NXu <= 6 && !TERM) ? 32 : 16;   // parked log-barrier terms fetched per round trip by the merit replay (registers permitting)
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= d.B) return;
   const ProblemDev *__restrict__ P = Pk;   // direct kernel argument: scalar (SMEM) loads, no vmcnt traffic
@@ -1713,12 +1714,12 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
                   for (int c = 0; c < Cons::NSEG; ++c) {
                     const double *q = evb + (size_t)c * kLS;
                     int t = 0;
-                    for (; t + 15 < N; t += 16) {
-                      double v[16];
+                    for (; t + kRB - 1 < N; t += kRB) {
+                      double v[kRB];
 #pragma unroll
-                      for (int k = 0; k < 16; ++k) v[k] = q[(size_t)(t + k) * tstride];
+                      for (int k = 0; k < kRB; ++k) v[k] = q[(size_t)(t + k) * tstride];
 #pragma unroll
-                      for (int k = 0; k < 16; ++k) mer -= mu * v[k];
+                      for (int k = 0; k < kRB; ++k) mer -= mu * v[k];
                     }
                     for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
                   }
@@ -1747,12 +1748,12 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
               for (int c = 0; c < Cons::NSEG; ++c) {
                 const double *q = evb + (size_t)c * kLS;
                 int t = 0;
-                for (; t + 15 < N; t += 16) {   // sixteen row loads per round trip, then the ordered chain
-                  double v[16];
+                for (; t + kRB - 1 < N; t += kRB) {   // kRB row loads per round trip, then the ordered chain
+                  double v[kRB];
 #pragma unroll
-                  for (int k = 0; k < 16; ++k) v[k] = q[(size_t)(t + k) * tstride];
+                  for (int k = 0; k < kRB; ++k) v[k] = q[(size_t)(t + k) * tstride];
 #pragma unroll
-                  for (int k = 0; k < 16; ++k) mer -= mu * v[k];
+                  for (int k = 0; k < kRB; ++k) mer -= mu * v[k];
                 }
                 for (; t < N; ++t) mer -= mu * q[(size_t)t * tstride];
               }
@@ -1809,9 +1810,11 @@ __global__ __launch_bounds__(64) void k_update(DevBuf d, const ProblemDev *__res
         else d.phase[b] = PH_ACTIVE;
       } else {
         // ---- handleForwardPassFailure (cddp_solver_base.cpp:206-218, ipddp_solver.cpp:2037-2082)
-        d.n_fwd[b] += n_alphas;
-        { int ns = 0; for (int a = 0; a < n_alphas; ++a) ns += d.t_steps[(size_t)a * d.Bp + b]; d.n_fwd_steps[b] += ns; }
-        double reg = reg_increase(o, d.reg[b]);
+        const int nf0 = d.n_fwd[b]; int ns = d.n_fwd_steps[b]; const double reg0 = d.reg[b];   // fetched before the first store (see above)
+        for (int a = 0; a < n_alphas; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
+        d.n_fwd[b] = nf0 + n_alphas;
+        d.n_fwd_steps[b] = ns;
+        double reg = reg_increase(o, reg0);
         if (ipddp && !nobar && pT > 0) reg = reg_increase(o, reg);   // extra bump for terminal-equality problems (:2043-2050)
         d.reg[b] = reg;
         if (reg >= o.reg_max_value) {
