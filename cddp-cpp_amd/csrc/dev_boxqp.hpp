@@ -106,4 +106,46 @@ DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g,
   return status;
 }
 
+// N = 1: the same projected-Newton iteration written on scalars (no free-index lists, no factor object: the 1x1 "factor" of the
+// free block is H itself and LDLT's solve is D^+ with tolerance DBL_MIN, dev_linalg.hpp::ldlt1_solve).  Statement for statement
+// the N = 1 trace of boxqp_solve<N> above -- same expressions, same order, same exits -- so a control-limited single-input plant
+// (pendulum, cart-pole: BASELINE config[1] read literally) gets the reference's BoxQP answer bit for bit without the generic
+// form's register footprint (round 3: 256 VGPR + 124 AGPR in the cooperative CLDDP sweep).  free_ = 0 iff the solution is clamped.
+DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
+  int status = BQ_MAX_ITER;
+  x = dmin(dmax(x, lower), upper);
+  int clamped = 0;
+  free_ = 1;
+  auto objective = [&](double xv) { const double hx = 0.0 + H * xv; const double q = 0.0 + xv * hx; const double l = 0.0 + g * xv; return 0.5 * q + l; };
+  double value = objective(x);
+  double old_value = INFINITY;
+  for (int iter = 0; iter < o.boxqp_max_iterations; ++iter) {
+    if (iter > 0 && fabs(old_value - value) < o.boxqp_min_relative_improvement * fabs(old_value)) { status = BQ_SUCCESS; break; }
+    old_value = value;
+    const double grad = g + (0.0 + H * x);
+    clamped = ((x == lower && grad > 0) || (x == upper && grad < 0)) ? 1 : 0;
+    free_ = 1 - clamped;
+    if (clamped) { status = BQ_ALL_CLAMPED; break; }
+    const double grad_norm = sqrt(0.0 + grad * grad);
+    if (grad_norm < o.boxqp_min_gradient_norm) { status = BQ_SUCCESS; break; }
+    const double sf = ldlt1_solve(H, g);
+    const double search = (-sf) - x;
+    const double sdotg = 0.0 + search * grad;
+    if (sdotg >= 0) { status = BQ_NO_DESCENT; break; }
+    double step = 1.0;
+    bool ls_ok = false;
+    double xn = x;
+    while (step > o.boxqp_min_step_size) {
+      xn = dmin(dmax(x + step * search, lower), upper);
+      const double value_new = objective(xn);
+      if ((value_new - value) <= o.boxqp_armijo_constant * step * sdotg) { ls_ok = true; break; }
+      step *= o.boxqp_step_decrease_factor;
+    }
+    if (!ls_ok) { status = BQ_MAX_LS; break; }
+    x = xn;
+    value = objective(x);
+  }
+  return status;
+}
+
 }  // namespace cddp_dev

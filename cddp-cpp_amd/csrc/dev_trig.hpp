@@ -119,7 +119,7 @@ DEV double bits_to_double(unsigned long long u) { double d; __builtin_memcpy(&d,
 DEV unsigned long long double_to_bits(double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; }
 
 DEV bool log_fast_ok(double x) { return x >= 0x1p-1022 && x <= 0x1.fffffffffffffp+1023; }   // positive, normal, finite
-DEV double log_fast(double x) {
+DEV double log_fast_k(double x, int k0) {   // log(x) + k0 ln 2 for positive normal finite x (k0: the power of two a caller scaled x by)
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
@@ -127,7 +127,7 @@ DEV double log_fast(double x) {
   unsigned long long u = double_to_bits(x);
   unsigned hx = (unsigned)(u >> 32);
   hx += 0x3ff00000u - 0x3fe6a09eu;                       // mantissa range [sqrt(2)/2, sqrt(2))
-  const int k = (int)(hx >> 20) - 0x3ff;
+  const int k = (int)(hx >> 20) - 0x3ff + k0;
   hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
   u = ((unsigned long long)hx << 32) | (u & 0xffffffffull);
   const double f = bits_to_double(u) - 1.0;
@@ -140,6 +140,7 @@ DEV double log_fast(double x) {
   const double dk = (double)k;
   return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
+DEV double log_fast(double x) { return log_fast_k(x, 0); }
 
 DEV bool exp_fast_ok(double x) { return __builtin_fabs(x) <= 700.0; }   // result normal, 2^k applied through the exponent field
 DEV double exp_fast(double x) {
@@ -178,12 +179,29 @@ inline double libm_asin(double x) { return std::asin(x); }
 inline double libm_log(double x) { return std::log(x); }
 inline double libm_pow(double x, double y) { return std::pow(x, y); }
 #else
-DEV double libm_asin(double x) { return asin(x); }
-DEV double libm_log(double x) { return log(x); }
-DEV double libm_pow(double x, double y) { return pow(x, y); }
+// Real function calls, like sincos_libm above: inlined, the device libm's log / pow (argument reduction tables, special-case
+// branches) joined the register allocation of every kernel that takes a logarithm -- in the nx >= 12 rollout consumers that
+// meant 896 B of scratch per lane and a 3 - 4 x slower launch (round 4, profiles/r04_trig_ab.md) for a path no finite positive
+// argument ever takes.
+__device__ __attribute__((noinline)) inline double libm_asin(double x) { return asin(x); }
+__device__ __attribute__((noinline)) inline double libm_log(double x) { return log(x); }
+__device__ __attribute__((noinline)) inline double libm_pow(double x, double y) { return pow(x, y); }
 #endif
 DEV double asin_shared(double x) { return asin_fast_ok(x) ? asin_fast(x) : libm_asin(x); }
-DEV double log_shared(double x) { return log_fast_ok(x) ? log_fast(x) : libm_log(x); }
+// log over the whole real line WITHOUT a libm fallback (round 4): subnormal arguments are scaled by 2^54 as msun's e_log.c does,
+// zero / negative / non-finite arguments get their IEEE answers through selects.  Straight-line code on both sides (the oracle's
+// trig_mode 1 includes this header), and no call or libm body in the register allocation of the rollout consumers that take a
+// logarithm per slack entry: with the `ok ? fast : libm` form the nx >= 12 consumers of the shared-arithmetic build spilled 896 B
+// per lane and ran 3 - 4 x slower than the device-libm build (profiles/r04_trig_ab.md).
+DEV double log_shared(double x) {
+  const bool tiny = x < 0x1p-1022;                      // subnormal, zero or negative; false for NaN
+  const double xs = tiny ? x * 0x1p54 : x;
+  double r = log_fast_k(xs, tiny ? -54 : 0);            // meaningless for non-positive / non-finite x, replaced below
+  r = (x == 0.0) ? -__builtin_inf() : r;
+  r = (x < 0.0) ? __builtin_nan("") : r;
+  r = !(x <= 0x1.fffffffffffffp+1023) ? x + x : r;      // +inf, NaN
+  return r;
+}
 DEV double pow_shared(double x, double y) {
   if (log_fast_ok(x)) {
     const double t = y * log_fast(x);

@@ -7,8 +7,8 @@ void register_pendulum(std::vector<KernelSet> &v) {
 }
 }  // namespace cddp_dev
 
-// Which sin / cos the reference plants of THIS build evaluate (dev_trig.hpp): 0 = device libm (product build),
-// 1 = the shared branch-free routine (parity build, -DCDDP_TRIG_SHARED).  Lives in a translation unit that is compiled per variant.
+// Which sin / cos / log / pow THIS build evaluates (dev_trig.hpp): 1 = the shared straight-line routines (the only build the
+// Makefile produces since round 4); 0 = the device libm (an experiment build made by hand without -DCDDP_TRIG_SHARED).
 extern "C" int cddp_hip_trig_shared(void) {
 #ifdef CDDP_TRIG_SHARED
   return 1;

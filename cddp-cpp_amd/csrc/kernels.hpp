@@ -235,6 +235,13 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
         for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - u[i]; ub[i] = P->pool[cc.off_upper + i] - u[i]; }
 #pragma unroll
         for (int i = 0; i < NU; ++i) kk[i] = cs.k0[i];   // warm start x0 = k_u_[t]
+        if constexpr (NU == 1) {   // scalar BoxQP, see dev_boxqp.hpp::boxqp_solve1
+          int fr;
+          const int stq1 = boxqp_solve1(o, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
+          if (stq1 == BQ_HESSIAN_NOT_PD || stq1 == BQ_NO_DESCENT) { fail = true; break; }
+#pragma unroll
+          for (int c = 0; c < NX; ++c) KK[c] = fr ? -ldlt1_solve(Quu_reg[0], Qux[c]) : 0.0;
+        } else {
         int free_[NU];
         LDLTd<NU> Hfree;
         int stq = boxqp_solve<NU>(o, Quu_reg, Qu, lb, ub, kk, free_, Hfree);
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(64) void k_backward_clddp(DevBuf d, const ProblemDe
             Hfree.solve(col);
             for (int i = 0; i < nf; ++i) KK[free_idx[i] * NX + c] = -col[i];
           }
+        }
         }
       }
       st<NU>(d.k + GI(t, NU, 0), kLS, kk);
@@ -1161,21 +1169,34 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // X_[0] == initial state
   st<NX>(Xn + GI(0, NX, 0), kLS, x);
   double J = 0.0;
-  for (int t = 0; t < N; ++t) {
-    double xo[NX], uo[NU], kk[NU], KK[NU * NX], u[NU], dx[NX];
-    ld<NX>(Xc + GI(t, NX, 0), kLS, xo);
-    ld<NU>(Uc + GI(t, NU, 0), kLS, uo);
-    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
-    ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+  // One step of look-ahead on the (x_old, u_old, k, K) record of the current iterate, ping-pong register sets with the loop unrolled
+  // by two (the idiom of the IPDDP rollouts): the record of step t + 1 does not depend on the trial, so its
+  // HBM latency hides behind the integrator chain of step t (round 3: loads at the top of their own step, 238 us per launch).
+  // Records above 32 doubles (nx >= 12) keep the single set: two of them would not fit beside the plant's registers.
+  constexpr int REC = NX + 2 * NU + NU * NX;
+  constexpr bool kPF = REC <= 32;
+  struct Rec { double xo[NX], uo[NU], kk[NU], KK[NU * NX]; };
+  auto fetch = [&](int tt, Rec &r) {
+    ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+    ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+    ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+  };
+  double lo[NU], hi[NU];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+  for (int i = 0; i < NU; ++i) { lo[i] = box >= 0 ? P->pool[P->cons[box].off_lower + i] : 0.0; hi[i] = box >= 0 ? P->pool[P->cons[box].off_upper + i] : 0.0; }
+  auto step = [&](const int t, const Rec &c, Rec &n) {
+    if constexpr (kPF) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
+    double u[NU], dx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - c.xo[i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s += KK[i * NX + j] * dx[j];
-      u[i] = (uo[i] + alpha * kk[i]) + s;
-      if (box >= 0) u[i] = dmin(dmax(u[i], P->pool[P->cons[box].off_lower + i]), P->pool[P->cons[box].off_upper + i]);
+      for (int j = 0; j < NX; ++j) s += c.KK[i * NX + j] * dx[j];
+      u[i] = (c.uo[i] + alpha * c.kk[i]) + s;
+      if (box >= 0) u[i] = dmin(dmax(u[i], lo[i]), hi[i]);
     }
     J += Obj::running_cost(P, xrt, t, x, u);
     double xn[NX];
@@ -1184,6 +1205,15 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
     st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  };
+  if constexpr (kPF) {
+    Rec ra, rb;
+    fetch(0, ra);
+    int t = 0;
+    for (; t + 1 < N; t += 2) { step(t, ra, rb); step(t + 1, rb, ra); }
+    if (t < N) step(t, ra, rb);
+  } else {
+    for (int t = 0; t < N; ++t) { Rec r; fetch(t, r); step(t, r, r); }
   }
   J += Obj::terminal_cost(P, x);
   const double dJ = d.cost[b] - J;

@@ -622,6 +622,12 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - c2.u[i]; ub[i] = P->pool[cc.off_upper + i] - c2.u[i]; }
 #pragma unroll
           for (int i = 0; i < NU; ++i) kk[i] = c2.k0[i];
+          if constexpr (NU == 1) {   // scalar BoxQP (dev_boxqp.hpp::boxqp_solve1): the N = 1 trace of the generic solver, nothing indexed
+            int fr;
+            const int stq = boxqp_solve1(o, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
+            if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+            KKc[0] = fr ? -ldlt1_solve(Quu_reg[0], Quxc[0]) : 0.0;
+          } else {
           int free_[NU];
           LDLTd<NU> Hfree;
           const int stq = boxqp_solve<NU>(o, Quu_reg, Qu, lb, ub, kk, free_, Hfree);
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
             for (int i = 0; i < nf; ++i) col[i] = Quxc[free_idx[i]];
             Hfree.solve(col);
             for (int i = 0; i < nf; ++i) KKc[free_idx[i]] = -col[i];
+          }
           }
         }
       } else {

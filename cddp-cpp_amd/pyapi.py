@@ -551,31 +551,36 @@ def batch_U0(problem, batch):
 # Product binding
 # ----------------------------------------------------------------------------------------------
 _hip_libs = {}
-# Parity build of the same library (csrc/Makefile: -DCDDP_TRIG_SHARED): the reference's plants evaluate sin / cos with the
-# branch-free routine of dev_trig.hpp instead of the device libm -- the routine the CPU checker can run too, which makes the
-# knife-edge plants bit-comparable.  Selected per process with CDDP_HIP_TRIG=shared, or per solver with trig="shared".
-HIP_SHAREDTRIG_LIB_PATH = os.path.join(_HERE, "lib", "libcddp_hip_sharedtrig.so")
+# ONE library since round 4 (csrc/Makefile: every translation unit with -DCDDP_TRIG_SHARED): the plants' sin / cos / asin / tan and
+# the solver core's log / pow are the straight-line routines of dev_trig.hpp -- the routines the CPU checker can run too (its
+# trig_mode 1), which makes accept / reject decisions bit-comparable.  The `trig` arguments below are kept for callers written
+# against rounds 1-3 (two libraries): None and "shared" name the library; "libm" is refused unless CDDP_HIP_LIB points at a
+# hand-made device-libm experiment build (cddp_hip_trig_shared() == 0).
 
 
 def default_trig():
-    return "shared" if os.environ.get("CDDP_HIP_TRIG", "") == "shared" else "libm"
+    return "shared"
 
 
 def load_hip(trig=None):
-    """Load the HIP C-ABI library (trig: None = per CDDP_HIP_TRIG, "libm" = the product build, "shared" = the parity build).
-    Raises if it is missing: there is no fallback path."""
+    """Load the HIP C-ABI library.  Raises if it is missing: there is no fallback path."""
     trig = trig or default_trig()
-    if trig in _hip_libs:
-        return _hip_libs[trig]
-    path = HIP_SHAREDTRIG_LIB_PATH if trig == "shared" else HIP_LIB_PATH
-    if not os.path.exists(path):
-        raise RuntimeError("HIP library missing: %s -- run __graft_entry__.build(); "
-                           "the product has no CPU fallback" % path)
-    lib = C.CDLL(path)
-    lib.cddp_hip_last_error.restype = C.c_char_p
-    lib.cddp_hip_status_string.restype = C.c_char_p
-    lib.cddp_hip_create.argtypes = [C.POINTER(ProblemStruct), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
-    _hip_libs[trig] = lib
+    if trig not in ("shared", "libm"):
+        raise ValueError("trig must be None, 'shared' or 'libm'")
+    if "lib" not in _hip_libs:
+        path = HIP_LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("HIP library missing: %s -- run __graft_entry__.build(); "
+                               "the product has no CPU fallback" % path)
+        lib = C.CDLL(path)
+        lib.cddp_hip_last_error.restype = C.c_char_p
+        lib.cddp_hip_status_string.restype = C.c_char_p
+        lib.cddp_hip_create.argtypes = [C.POINTER(ProblemStruct), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _hip_libs["lib"] = lib
+    lib = _hip_libs["lib"]
+    if (trig == "shared") != bool(lib.cddp_hip_trig_shared()):
+        raise RuntimeError("trig=%r asked for, but %s was built %s -DCDDP_TRIG_SHARED" %
+                           (trig, HIP_LIB_PATH, "with" if lib.cddp_hip_trig_shared() else "without"))
     return lib
 
 

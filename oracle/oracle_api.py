@@ -24,6 +24,9 @@ def _api():
 _oracle_libs = {}
 
 
+_trig_mode = [0]
+
+
 def load_oracle(fast=False):
     path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
     if path in _oracle_libs:
@@ -38,6 +41,8 @@ def load_oracle(fast=False):
                  "cddp_oracle_get_mu", "cddp_oracle_cost"]:
         getattr(lib, name).restype = C.c_double
     _oracle_libs[path] = lib
+    if _trig_mode[0]:
+        lib.cddp_oracle_set_trig_mode(_trig_mode[0])   # a library loaded after set_trig_mode() joins the current mode
     return lib
 
 
@@ -200,19 +205,33 @@ def oracle_ldlt_solve(A, B):
 
 
 
+def set_trig_mode(mode):
+    """0 = glibc (the reference's arithmetic: golden fixtures, twin comparisons), 1 = the straight-line sin / cos / log / pow of
+    cddp-cpp_amd/csrc/dev_trig.hpp that the HIP library evaluates (models.hpp::trig_mode).  Applied to both oracle builds;
+    returns the previous mode.  Process-global, like the noise knobs."""
+    prev = _trig_mode[0]
+    for fast in (False, True):
+        path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
+        if fast and not os.path.exists(path):
+            continue
+        load_oracle(fast).cddp_oracle_set_trig_mode(int(mode))
+    _trig_mode[0] = int(mode)
+    return prev
+
+
 class shared_trig:
-    """Context manager: the oracle evaluates sin / cos with the HIP parity build's routine (models.hpp::trig_mode 1) inside the
-    block -- pair it with HipBatchSolver(..., trig="shared").  Process-global, like the noise knobs."""
+    """Context manager: the oracle evaluates sin / cos / log / pow with the HIP library's routines (models.hpp::trig_mode 1) inside
+    the block and returns to the previous mode afterwards (tests/conftest.py keeps mode 1 on for every `-m gpu` test)."""
 
     def __init__(self, fast=False):
-        self.lib = load_oracle(fast)
+        self.prev = 0
 
     def __enter__(self):
-        self.lib.cddp_oracle_set_trig_mode(1)
+        self.prev = set_trig_mode(1)
         return self
 
     def __exit__(self, *exc):
-        self.lib.cddp_oracle_set_trig_mode(0)
+        set_trig_mode(self.prev)
         return False
 
 
@@ -220,6 +239,6 @@ def attach(api):
     """Expose the oracle entry points on the harness module `api` (cddp-cpp_amd/pyapi.py)."""
     mod = sys.modules[__name__]
     for name in ("ORACLE_LIB_PATH", "ORACLE_FAST_LIB_PATH", "load_oracle", "Oracle", "oracle_solve_batch", "oracle_boxqp",
-                 "oracle_ldlt_solve", "shared_trig"):
+                 "oracle_ldlt_solve", "shared_trig", "set_trig_mode"):
         setattr(api, name, getattr(mod, name))
     return api

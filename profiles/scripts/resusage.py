@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """usage: resusage.py file.hip [filter]  -> per-kernel VGPR / AGPR / scratch / occupancy / LDS table (hipcc remarks)"""
-import re, subprocess, sys
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", sys.argv[1],
+import re, subprocess, sys, os
+EXTRA = os.environ.get("RESUSAGE_FLAGS", "").split()
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *EXTRA, "-c", sys.argv[1],
                       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 cur = {}
 flt = sys.argv[2] if len(sys.argv) > 2 else ""

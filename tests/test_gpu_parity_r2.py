@@ -159,7 +159,7 @@ def test_variant_full_solve(api, oracle_built, case):
                                 "mean_iterations": float(np.mean(res["iterations"]))})
     assert same_counts.all(), (case, list(zip(res["iterations"], ores["iterations"], res["status"], ores["status"])))
     assert strict[conv].all(), (case, strict, conv)
-    assert strict[0] and strict.sum() >= int(np.ceil(0.9 * B)), (case, strict)
+    assert strict[0] and strict.sum() == B, (case, strict)   # round 4: same arithmetic on both sides, every trajectory strict
 
 
 def test_best_merit_differs_from_first_success(api):
@@ -261,7 +261,9 @@ def test_knife_edge_flip_rate(api, oracle_built, case):
                               "converged_oracle": int(conv.sum()), "flip_rate": float(1.0 - same_counts.mean()),
                               "oracle_trig_noise_same_counts": TRIG_NOISE[case]["same_counts"],
                               "max_objective_rel_err_converged": float(max(obj_err)) if obj_err else 0.0})
-    assert same_counts.sum() >= TRIG_NOISE[case]["same_counts"] - KNIFE_MARGIN, (case, int(same_counts.sum()), TRIG_NOISE[case])
+    # Round 4: the shipped library runs the oracle's arithmetic (trig_mode 1 in every gpu test), so the yardstick of rounds 2-3 (the
+    # oracle's own agreement under 1-ulp trig noise, minus a margin) is replaced by the strict statement: no trajectory flips.
+    assert same_counts.sum() == B and same_work.sum() == B, (case, int(same_counts.sum()), int(same_work.sum()), TRIG_NOISE[case])
     for b in range(B):   # where both converge they converge to the same optimum
         if both_conv[b]:
             assert rel_err(res["final_objective"][b], ores["final_objective"][b]) < 1e-4, (case, b)
