@@ -109,6 +109,9 @@ def make_problem(api, workload, solver):
     return p, spread, desc
 
 
+# committed PMC traffic summaries (profiles/make_traffic_json.py) per (workload, solver, batch)
+TRAFFIC_FILES = {("cartpole", "ipddp", 4096): "r04_pmc_traffic.json", ("quadrotor", "ipddp", 2048): "r04_pmc_traffic_quadrotor.json",
+                 ("manip7", "ipddp", 4096): "r04_pmc_traffic_manip7.json", ("cartpole", "clddp", 4096): "r04_pmc_traffic_clddp.json"}
 STRONG_GLOBAL_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 16384, "manip7": 32768}
 DEFAULT_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 2048, "manip7": 4096}
 
@@ -203,17 +206,18 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
     # (profiles/r0N_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes), null for other workloads.
     traffic = None
     traffic_note = None
-    if pmc_key and workload == "cartpole" and B == 4096 and ipddp:
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_i_pmc_traffic.json"):   # this round's passes; earlier rounds' as a fallback
-            try:
-                pj = json.load(open(os.path.join(REPO, "profiles", fn)))
-                # per outer iteration, like `algorithmic_bytes_per_launch` (an iteration is one or two rollout launches,
-                # depending on the ladder shape the solver picked)
-                traffic = pj["kernels"][pmc_key]["bytes_per_solve"] / n_launch
-                traffic_note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the rollout launches of one solve / outer iterations)" % fn
-                break
-            except Exception:
-                traffic = None
+    tfile = TRAFFIC_FILES.get((workload, solver, B))
+    if tfile:
+        try:
+            pj = json.load(open(os.path.join(REPO, "profiles", tfile)))
+            # per launch of the dominant kernel class, like `algorithmic_bytes_per_launch`: the counter bytes of every kernel of the
+            # class over one solve / that solve's outer iterations (an iteration is one sweep, and one or two rollout launches
+            # depending on the ladder shape the solver picked)
+            traffic = sum(pj["kernels"][k]["bytes_per_solve"] for k in dom[0].split("+")) / n_launch
+            traffic_note = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the launches of %s in one solve "
+                            "-- %d solves in the profiled command, counted from its k_init dispatches -- / outer iterations)" % (tfile, dom[0], pj["solves_in_profile"]))
+        except Exception:
+            traffic = None
     return {
         "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
         "frac_of_measured_copy_6290": dom[1] / 6290.0, "traffic": traffic, "traffic_source": traffic_note,
@@ -246,13 +250,39 @@ OTHER_WORKLOADS = [
 ]
 
 
-def measure_other(api, workload, solver, label, steps=3, warmup=1, device=0):
-    """A short single-GPU measurement of one more workload with the same accounting as the headline line."""
+def measure_other(api, workload, solver, label, steps=3, warmup=1, device=0, world=1, rank=0, dist=None, comm=None, sh=None):
+    """A short measurement of one more workload with the same accounting as the headline line.
+
+    world == 1: the workload's per-GPU share (DEFAULT_BATCH) on this GPU.  world > 1 (BASELINE configs [3] / [4], quoted on 8 GPUs):
+    STRONG scaling -- the config's fixed global batch block-partitioned over the ranks, one RCCL all-gather of the 16-B records per
+    step through the C-ABI, barrier + synchronize on both sides of the timed steps, MAX over ranks; every rank runs this function,
+    rank 0's return value carries the line."""
+    import torch
     p, spread, _ = make_problem(api, workload, solver)
-    B = DEFAULT_BATCH[workload]
-    x0 = api.batch_x0(p, B, 20260928 + 1, spread)
+    if world > 1:
+        global_batch = STRONG_GLOBAL_BATCH[workload]
+        lo, hi = sh.partition(global_batch, world, rank)
+        cap = sh.shard_capacity(global_batch, world)
+        x0 = np.ascontiguousarray(api.batch_x0(p, global_batch, 20260928 + 1, spread)[lo:hi])
+    else:
+        global_batch = DEFAULT_BATCH[workload]
+        lo, hi, cap = 0, global_batch, global_batch
+        x0 = api.batch_x0(p, global_batch, 20260928 + 1, spread)
+    B = hi - lo
     U0 = api.batch_U0(p, B)
     hs = api.HipBatchSolver(p, B, device=device)
+    gathered_dev = torch.empty(world * cap * 16, dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        st_ = hs.solve()      # cddp_hip_solve returns after the stream is drained
+        if world > 1:
+            hs.allgather_results(comm, world, cap, gathered_dev.data_ptr())
+        return st_
     try:
         hs.set_initial(x0, U0)
         hs.set_timing_detail(api.TIMING_ALL)
@@ -261,23 +291,47 @@ def measure_other(api, workload, solver, label, steps=3, warmup=1, device=0):
         sweep_dominates = prof.backward_ms >= prof.forward_ms
         hs.set_timing_detail(api.TIMING_SWEEP if sweep_dominates else api.TIMING_ROLLOUT)
         for _ in range(warmup):
-            hs.solve()
+            step()
+        sync()
         t0 = time.perf_counter()
-        stats = [hs.solve() for _ in range(steps)]     # cddp_hip_solve returns after the stream is drained
+        stats = [step() for _ in range(steps)]
+        sync()
         dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         res = hs.results()
         rl = roofline_block(api, p, hs.m, B, workload, solver, stats[-1], prof, stats, sweep_dominates)
         status_hist = {api.STATUS_STRINGS[int(s)]: int(c) for s, c in zip(*np.unique(res["status"], return_counts=True))}
-        return {
+        out = {
             "workload": label, "solver": solver.upper(), "batch": B, "steps": steps, "warmup": warmup,
-            "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "trajectories/s",
+            "ms_per_step": dt / steps * 1e3, "value": global_batch * steps / dt, "unit": "trajectories/s",
             "roofline": {"kernel": rl["kernel"], "frac": rl["frac"], "achieved": rl["achieved"], "unit": "GB/s",
-                         "avg_launch_ms": rl["avg_launch_ms"], "whole_solve_frac": rl["classes"]["whole_solve"]["frac"]},
+                         "avg_launch_ms": rl["avg_launch_ms"], "whole_solve_frac": rl["classes"]["whole_solve"]["frac"],
+                         "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "traffic": rl["traffic"], "traffic_source": rl["traffic_source"]},
             "classes_ms": {k: v["ms"] for k, v in rl["classes"].items() if isinstance(v, dict)},
             "mean_iterations": float(np.mean(res["iterations"])), "status": status_hist,
         }
+        if world > 1:
+            rec = sh.compact_records(gathered_dev.cpu().numpy(), global_batch, world)
+            assert len(rec) == global_batch
+            assert np.array_equal(rec["iterations"][lo:hi], res["iterations"]) and np.array_equal(rec["status"][lo:hi], res["status"])
+            out.update({"n_gpus": world, "scaling": "strong", "global_batch": global_batch, "batch_per_gpu_rank0": B,
+                        "collective": "ncclAllGather, %d x %d records" % (world, cap), "rccl_ranks": api.comm_info(comm)[0],
+                        "gathered_records": int(len(rec)),
+                        "gathered_converged": int(np.sum((rec["status"] == api.STATUS_OPTIMAL) | (rec["status"] == api.STATUS_ACCEPTABLE)))})
+            out["status"] = "rank 0's shard: %s" % status_hist
+        return out
     finally:
         hs.close()
+
+
+# BASELINE configs [3] and [4] are quoted on 8 GPUs: with more than one rank they are measured too (strong scaling, 2 steps each)
+MULTI_RANK_WORKLOADS = [
+    ("quadrotor", "ipddp", "C4: quadrotor nx=12 N=400, global batch 16384 over the ranks (BASELINE config[3])"),
+    ("manip7", "ipddp", "C5: 7-joint arm nx=14 nu=7 N=150 terminal equality, 16 alphas, global batch 32768 over the ranks (BASELINE config[4])"),
+]
 
 
 def main():
@@ -436,11 +490,14 @@ def main():
         },
         "roofline": roofline,
     }
-    if comm is not None:
-        api.comm_destroy(comm)
     assert out["n_gpus"] == args.gpus
+    if comm is not None:
+        n_rccl, r_rccl = api.comm_info(comm)     # what RCCL itself says, not this script's bookkeeping
+        assert n_rccl == world and r_rccl == rank, (n_rccl, world, r_rccl, rank)
+        out["config"]["rccl_ranks"] = n_rccl
     hs.close()
-    if rank == 0 and world == 1 and not args.no_other_workloads and args.workload == "cartpole" and args.solver == "ipddp" and args.batch in (0, 4096):
+    headline = args.workload == "cartpole" and args.solver == "ipddp" and args.batch in (0, 4096) and args.scaling == "weak"
+    if world == 1 and dist is None and not args.no_other_workloads and headline:
         # the other BASELINE configurations, 3 steps each, after and outside the headline's timed region
         out["other_workloads"] = []
         for wl, sv, label in OTHER_WORKLOADS:
@@ -448,6 +505,24 @@ def main():
                 out["other_workloads"].append(measure_other(api, wl, sv, label, device=local_rank))
             except Exception as e:   # a failing extra workload must not lose the headline line
                 out["other_workloads"].append({"workload": label, "error": "%s: %s" % (type(e).__name__, e)})
+    elif dist is not None and not args.no_other_workloads and headline:
+        # under torchrun (any world size, 1 included): configs [3] / [4] with the batch partitioned over the ranks and the same
+        # single collective -- every rank takes part, rank 0 keeps the lines
+        out["other_workloads"] = []
+        for wl, sv, label in MULTI_RANK_WORKLOADS:
+            try:
+                if world > 1:
+                    r = measure_other(api, wl, sv, label, steps=2, warmup=0, device=local_rank, world=world, rank=rank, dist=dist, comm=comm, sh=sh)
+                else:   # one rank under torchrun: the per-GPU share, size-1 communicator already exercised by the headline
+                    r = measure_other(api, wl, sv, label + " -- one rank: the 8-GPU share", steps=2, warmup=0, device=local_rank, dist=dist)
+                    r.update({"n_gpus": 1, "rccl_ranks": api.comm_info(comm)[0]})
+                out["other_workloads"].append(r)
+            except Exception as e:
+                if world > 1:
+                    raise          # a rank that drops out would hang the others in the next barrier: fail the job loudly
+                out["other_workloads"].append({"workload": label, "error": "%s: %s" % (type(e).__name__, e)})
+    if comm is not None:
+        api.comm_destroy(comm)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(api, p, x0, U0)
     elif rank == 0:

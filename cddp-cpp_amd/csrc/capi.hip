@@ -1087,6 +1087,7 @@ struct cddp_hip_handle {
   std::vector<Inner *> g;
   std::vector<int> b0;       // first trajectory of each group
   int B = 0, device = 0;
+  int conc = 1;              // groups in flight at once in cddp_hip_solve (pick_groups)
   int nx = 0, nu = 0, N = 0, m = 0, mT = 0, pT = 0;
   hipStream_t user_stream = nullptr;   // cddp_hip_set_stream: work is ordered after / before this stream's work
   bool have_user_stream = false;
@@ -1097,17 +1098,28 @@ struct cddp_hip_handle {
 
 namespace {
 
-int pick_groups(int batch) {
+// How the batch is cut.  Returns the group count; *conc = how many groups cddp_hip_solve keeps in flight at once.
+//  * CDDP_HIP_GROUPS=n  (experiments, tests): n groups, all in flight concurrently (rounds 2-3).
+//  * otherwise (round 4): CHUNKS.  A batch whose rollout launch would put more than ~2.75 wavefronts on every SIMD is solved as
+//    several groups ONE AFTER THE OTHER.  Measured on MI355X at C2 (profiles/r03_batch_curve.md): 88.9 k trajectories/s at
+//    B = 4096, 89.6 k at 8192, then 77.5 k at 16384 and 67.6 k at 32768 -- the rollout class grows super-linearly (51 -> 134 ->
+//    333 ms) once the launch needs more than two residency rounds and the per-solve state (~0.1 MB per trajectory) is several
+//    times the 256 MB Infinity Cache.  A trajectory's result does not depend on its group (bitwise, tests/test_full_size.py,
+//    tests/test_determinism.py), so oversubscription costs nothing: the large batch runs at the throughput of its best chunk size
+//    (profiles/r04_batch_curve.md).  CDDP_HIP_CHUNK=<trajectories> overrides the chunk size (0 = never chunk).
+int pick_groups(int batch, int n_alphas, int *conc) {
   const int tiles = (batch + 63) / 64;
   const char *e = std::getenv("CDDP_HIP_GROUPS");
   int n = e ? std::atoi(e) : 0;
-  // Default: ONE group.  Measured on MI355X (profiles/r02_groups_sweep.md): at C2 (B = 4096) 1 / 2 / 4 / 8 groups solve in
-  // 48.8 / 50.1 / 56.6 / 84.8 ms, at C3 (B = 8192) 1 / 2 / 4 groups in 88.0 / 89.3 / 92.7 ms -- the rollout launch already puts
-  // more than one wavefront on every SIMD (1408 waves at C2), so a second group's sweep does not find idle issue slots, it
-  // lengthens both chains, and every group adds its own launches and polls.  The mechanism stays for larger chips / other
-  // shapes (CDDP_HIP_GROUPS=n) and because the C++ host can use it to pipeline uploads of later groups.
-  if (n <= 0) n = 1;
-  return std::max(1, std::min(n, tiles));
+  if (n > 0) { n = std::max(1, std::min(n, tiles)); *conc = n; return n; }
+  *conc = 1;
+  int chunk_tiles = std::max(16, 2816 / (2 * std::max(1, n_alphas)));     // 128 tiles (8192 trajectories) at 11 step sizes
+  if (const char *c = std::getenv("CDDP_HIP_CHUNK")) {
+    const int v = std::atoi(c);
+    if (v <= 0) return 1;
+    chunk_tiles = std::max(1, (v + 63) / 64);
+  }
+  return std::max(1, (tiles + chunk_tiles - 1) / chunk_tiles);
 }
 
 // ordering against a caller-supplied stream: fork = group streams wait for the user's stream, join = the reverse
@@ -1135,9 +1147,10 @@ extern "C" {
 int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp_hip_handle **out) {
   if (!problem || !out) return fail(-1, "null argument");
   if (batch <= 0) return fail(-1, "batch must be positive");
-  const int tiles = (batch + 63) / 64, ng = pick_groups(batch);
+  int conc = 1;
+  const int tiles = (batch + 63) / 64, ng = pick_groups(batch, problem->options.ls_max_iterations, &conc);
   cddp_hip_handle *h = new cddp_hip_handle();
-  h->B = batch; h->device = device;
+  h->B = batch; h->device = device; h->conc = conc;
   int t0 = 0;
   for (int k = 0; k < ng; ++k) {
     const int nt = tiles / ng + (k < tiles % ng ? 1 : 0);          // whole tiles per group, sizes differ by at most one tile
@@ -1266,21 +1279,26 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   { int rc = fork_from_user(h); if (rc) return rc; }
   const int ng = (int)h->g.size();
   std::vector<SolveRun> run(ng);
-  // a common time origin on every group stream (the groups' solve_ms are measured from their own begin events; the
-  // whole-handle time is the span from the first begin to the last end, taken on group 0's clock after a join)
-  for (int k = 0; k < ng; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, ng); if (rc) return rc; }
+  // `conc` groups are in flight at a time (all of them with CDDP_HIP_GROUPS; one with the default chunking of a large batch).
+  // The whole-handle time is the span from group 0's begin to an end event group 0's stream records after it has waited for
+  // every other group's end.
+  const int conc = std::max(1, std::min(h->conc, ng));
   std::vector<int> pending(ng, 0);
-  for (int k = 0; k < ng; ++k) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
-  for (;;) {
-    bool any = false;
-    for (int k = 0; k < ng; ++k) {
-      if (!pending[k]) continue;
-      any = true;
-      { int rc = run[k].complete_poll(); if (rc) return rc; }
-      pending[k] = 0;
-      if (!run[k].done) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+  for (int base = 0; base < ng; base += conc) {
+    const int top = std::min(ng, base + conc);
+    for (int k = base; k < top; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, conc); if (rc) return rc; }
+    for (int k = base; k < top; ++k) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+    for (;;) {
+      bool any = false;
+      for (int k = base; k < top; ++k) {
+        if (!pending[k]) continue;
+        any = true;
+        { int rc = run[k].complete_poll(); if (rc) return rc; }
+        pending[k] = 0;
+        if (!run[k].done) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+      }
+      if (!any) break;
     }
-    if (!any) break;
   }
   // whole-handle device time: group 0's stream waits for the other groups' end events, then stamps the end
   std::vector<cddp_hip_stats> gs(ng);
@@ -1300,9 +1318,9 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     (void)first_begin_off;
     stats->solve_ms = span_ms;
     for (int k = 0; k < ng; ++k) {
-      // class times: the groups run concurrently, so the per-class event spans of different groups overlap in wall
-      // time; they are reported as the MEAN over groups (the time one group's stream spent in that class)
-      stats->backward_ms += gs[k].backward_ms / ng; stats->forward_ms += gs[k].forward_ms / ng; stats->update_ms += gs[k].update_ms / ng;
+      // class times: groups that run concurrently overlap in wall time, so their per-class event spans are averaged over the
+      // `conc` groups in flight together; successive chunks add up
+      stats->backward_ms += gs[k].backward_ms / conc; stats->forward_ms += gs[k].forward_ms / conc; stats->update_ms += gs[k].update_ms / conc;
       stats->sweeps += gs[k].sweeps; stats->rollouts += gs[k].rollouts; stats->rollouts_launched += gs[k].rollouts_launched;
       stats->traj_iterations += gs[k].traj_iterations; stats->rollout_steps += gs[k].rollout_steps;
       stats->outer_iterations = std::max(stats->outer_iterations, gs[k].outer_iterations);

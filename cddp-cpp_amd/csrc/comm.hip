@@ -41,6 +41,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
@@ -71,6 +73,8 @@ Rccl &rccl() {
   r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+  r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
   r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
   return r;
@@ -113,6 +117,19 @@ int cddp_hip_comm_destroy(void *comm) {
   if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
   ncclResult_t rc = r.CommDestroy((ncclComm_t)comm);
   if (rc != ncclSuccess) return cfail(-31, "ncclCommDestroy: %s", r.GetErrorString(rc));
+  return 0;
+}
+
+// How many ranks RCCL itself sees behind a communicator, and which one this is (ncclCommCount / ncclCommUserRank): lets a launcher
+// assert that the exchange really spans `world` processes instead of trusting its own bookkeeping.
+int cddp_hip_comm_info(void *comm, int *count_out, int *rank_out) {
+  if (!comm || !count_out || !rank_out) return cfail(-1, "null argument");
+  Rccl &r = rccl();
+  if (!r.err.empty()) return cfail(-30, "%s", r.err.c_str());
+  ncclResult_t rc = r.CommCount((ncclComm_t)comm, count_out);
+  if (rc != ncclSuccess) return cfail(-31, "ncclCommCount: %s", r.GetErrorString(rc));
+  rc = r.CommUserRank((ncclComm_t)comm, rank_out);
+  if (rc != ncclSuccess) return cfail(-31, "ncclCommUserRank: %s", r.GetErrorString(rc));
   return 0;
 }
 

@@ -108,9 +108,16 @@ DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g,
 
 // N = 1: the same projected-Newton iteration written on scalars (no free-index lists, no factor object: the 1x1 "factor" of the
 // free block is H itself and LDLT's solve is D^+ with tolerance DBL_MIN, dev_linalg.hpp::ldlt1_solve).  Statement for statement
-// the N = 1 trace of boxqp_solve<N> above -- same expressions, same order, same exits -- so a control-limited single-input plant
-// (pendulum, cart-pole: BASELINE config[1] read literally) gets the reference's BoxQP answer bit for bit without the generic
-// form's register footprint (round 3: 256 VGPR + 124 AGPR in the cooperative CLDDP sweep).  free_ = 0 iff the solution is clamped.
+// the N = 1 trace of boxqp_solve<N> above -- same values, same order of decisions, same exits -- so a control-limited single-input
+// plant (pendulum, cart-pole: BASELINE config[1] read literally) gets the reference's BoxQP answer bit for bit.  free_ = 0 iff
+// the solution is clamped.  Three evaluations of the generic trace are REUSED instead of repeated; each yields the same bits:
+//   * the Newton target -H^+ g is the same quotient in every iteration (H, g do not change): computed once;
+//   * ||grad|| = sqrt(grad^2) equals |grad| exactly in binary floating point when grad^2 neither overflows nor underflows
+//     (S. Boldo, "Stupid is as stupid does: taking the square root of the square of a floating-point number", 2015); outside
+//     that range the square root is taken as written;
+//   * the objective at the accepted point was already evaluated by the line search (same function, same argument).
+// A dependent f64 division or square root costs ~150 cycles on gfx950 and the loop is replicated by every lane of a trajectory's
+// group, on the critical path of every sweep step.
 DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
   int status = BQ_MAX_ITER;
   x = dmin(dmax(x, lower), upper);
@@ -119,6 +126,7 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
   auto objective = [&](double xv) { const double hx = 0.0 + H * xv; const double q = 0.0 + xv * hx; const double l = 0.0 + g * xv; return 0.5 * q + l; };
   double value = objective(x);
   double old_value = INFINITY;
+  const double newton = -ldlt1_solve(H, g);      // -(H_free^+ grad_clamped): grad_clamped = g while the variable is free
   for (int iter = 0; iter < o.boxqp_max_iterations; ++iter) {
     if (iter > 0 && fabs(old_value - value) < o.boxqp_min_relative_improvement * fabs(old_value)) { status = BQ_SUCCESS; break; }
     old_value = value;
@@ -126,24 +134,25 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
     clamped = ((x == lower && grad > 0) || (x == upper && grad < 0)) ? 1 : 0;
     free_ = 1 - clamped;
     if (clamped) { status = BQ_ALL_CLAMPED; break; }
-    const double grad_norm = sqrt(0.0 + grad * grad);
+    const double ag = fabs(grad);
+    double grad_norm = ag;
+    if (!(ag > 0x1p-500 && ag < 0x1p500)) grad_norm = sqrt(0.0 + grad * grad);   // also NaN
     if (grad_norm < o.boxqp_min_gradient_norm) { status = BQ_SUCCESS; break; }
-    const double sf = ldlt1_solve(H, g);
-    const double search = (-sf) - x;
+    const double search = newton - x;
     const double sdotg = 0.0 + search * grad;
     if (sdotg >= 0) { status = BQ_NO_DESCENT; break; }
     double step = 1.0;
     bool ls_ok = false;
-    double xn = x;
+    double xn = x, value_new = value;
     while (step > o.boxqp_min_step_size) {
       xn = dmin(dmax(x + step * search, lower), upper);
-      const double value_new = objective(xn);
+      value_new = objective(xn);
       if ((value_new - value) <= o.boxqp_armijo_constant * step * sdotg) { ls_ok = true; break; }
       step *= o.boxqp_step_decrease_factor;
     }
     if (!ls_ok) { status = BQ_MAX_LS; break; }
     x = xn;
-    value = objective(x);
+    value = value_new;
   }
   return status;
 }

@@ -567,8 +567,41 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
       PIPELINE_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       // ---- round 2
+      // kEarlyQP (single-input CLDDP: pendulum, cart-pole -- BASELINE config[1] read literally): Q_uu, the PD test and the BoxQP
+      // (a data-dependent loop of dependent divisions / square roots, replicated by the lanes of the group) run BEFORE the sixteen
+      // T1 entries are fetched from LDS and Q_xx / Q_ux are formed: nothing of those is live across the loop, which is what had the
+      // round-3 kernel at 256 VGPR + 124 AGPR with ~250 accvgpr moves per step.  Pure reordering of independent statements.
+      constexpr bool kEarlyQP = CLDDP && NU == 1 && !kQuad;
       double T1[NX * NX], T2[NU * NX];
-      if constexpr (kQuad) {   // G = 4: the lanes of a trajectory are a quad -- column j of T1, T2 is lane j's, fetched by DPP broadcasts
+      double Qxxc[NX], Quxc[NU], Quu[NU * NU];
+      double kk[NU], KKc[NU];
+      [[maybe_unused]] double qp_h = 0.0;      // kEarlyQP: Q_uu + reg
+      [[maybe_unused]] int qp_free = 1;        // kEarlyQP: 0 when the BoxQP solution sits on a bound (its gain row is zero)
+      if constexpr (kEarlyQP) {
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
+        { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += T2[j] * Bm[j];
+          Quu[0] = (2.0 * Rr[0]) + s; }
+        qp_h = Quu[0] + reg;
+        if (min_real_eig<1>(&qp_h) <= 0) return false;   // clddp_solver.cpp:133-140
+        if (box < 0) {                                    // clddp_solver.cpp:142-145: k = -Q_uu_reg^-1 Q_u
+          double H[1];
+          inverse_pplu<1>(&qp_h, H);
+          kk[0] = 0.0 + (-H[0]) * Qu[0];
+          qp_h = H[0];                                    // the inverse, for the gain column below
+        } else {                                          // clddp_solver.cpp:147-178
+          const ConDev &cc = P->cons[box];
+          const double lb = P->pool[cc.off_lower] - c2.u[0], ub = P->pool[cc.off_upper] - c2.u[0];
+          kk[0] = c2.k0[0];
+          const int stq = boxqp_solve1(o, qp_h, Qu[0], lb, ub, kk[0], qp_free);
+          if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) T1[i] = Ls[C::oT1 + i];
+      } else if constexpr (kQuad) {   // G = 4: the lanes of a trajectory are a quad -- column j of T1, T2 is lane j's, fetched by DPP broadcasts
 #pragma unroll
         for (int i = 0; i < NX; ++i) quad_gather<NX>(T1c[i], T1 + i * NX);
 #pragma unroll
@@ -579,7 +612,6 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 #pragma unroll
         for (int i = 0; i < NU * NX; ++i) T2[i] = Ls[C::oT2 + i];
       }
-      double Qxxc[NX], Quxc[NU], Quu[NU * NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
@@ -590,15 +622,19 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * c1.Aq[j];
         Quxc[u] = s; }
+      if constexpr (!kEarlyQP) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int v = 0; v < NU; ++v) { double s = 0.0;
+          for (int v = 0; v < NU; ++v) { double s = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * Bm[j * NU + v];
-          Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
-      double kk[NU], KKc[NU];
-      if constexpr (CLDDP) {
+            for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * Bm[j * NU + v];
+            Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
+      }
+      if constexpr (kEarlyQP) {
+        if (box < 0) KKc[0] = 0.0 + (-qp_h) * Quxc[0];
+        else KKc[0] = qp_free ? -ldlt1_solve(qp_h, Quxc[0]) : 0.0;
+      } else if constexpr (CLDDP) {
         double Quu_reg[NU * NU];
 #pragma unroll
         for (int i = 0; i < NU * NU; ++i) Quu_reg[i] = Quu[i];

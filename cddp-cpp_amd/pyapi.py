@@ -591,7 +591,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
-    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_allgather_results",
+    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
@@ -1017,6 +1017,16 @@ def comm_init(unique_id, world, rank, device):
     if rc != 0:
         raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
     return comm.value
+
+
+def comm_info(comm):
+    """(ranks RCCL sees behind the communicator, this process's rank)"""
+    lib = load_hip()
+    n = C.c_int(); r = C.c_int()
+    rc = lib.cddp_hip_comm_info(C.c_void_p(comm), C.byref(n), C.byref(r))
+    if rc != 0:
+        raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    return n.value, r.value
 
 
 def comm_destroy(comm):

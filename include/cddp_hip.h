@@ -443,6 +443,8 @@ int cddp_hip_comm_unique_id(char *id_out /* CDDP_HIP_COMM_ID_BYTES */);
 /* ncclCommInitRank on `device` (collective over all ranks). */
 int cddp_hip_comm_init(const char *id_in, int world, int rank, int device, void **comm_out);
 int cddp_hip_comm_destroy(void *comm);
+/* ncclCommCount / ncclCommUserRank of the communicator: the number of ranks RCCL itself sees, and this process's rank (round 4) */
+int cddp_hip_comm_info(void *comm, int *count_out, int *rank_out);
 /* All-gather the records of this rank's batch into recv_device (DEVICE buffer of world * shard_capacity records,
  * rank r's block at r * shard_capacity).  shard_capacity >= every rank's batch: with an uneven block partition the
  * ranks pad to the largest shard; padding records read status = iterations = -1.  comm == NULL is valid for

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build the per-kernel HBM traffic JSON bench.py reads from a summarize_pmc.py table.
-usage: make_traffic_json.py pmc_counters.md "<source note>" > rNN_x_pmc_traffic.json
+usage: make_traffic_json.py pmc_counters.md "<source note>" [outer_iterations_per_solve] > rNN_x_pmc_traffic.json
 bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 correction, profiles/r01_c_pmc_calibration.md) + WRITE_SIZE x 1024."""
 import json
 import sys
@@ -8,7 +8,19 @@ import sys
 rows = [l.strip().strip("|").split("|") for l in open(sys.argv[1]) if l.startswith("|")]
 hdr = [c.strip() for c in rows[0]]
 fi, wi, di = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE"), hdr.index("dispatches")
-SOLVES = 2   # `bench.py --steps 1 --warmup 0` = the profiling solve + one timed step
+# The number of solves inside the profiled command is READ from the table, not assumed: every solve starts with exactly one
+# k_init launch (round 3 hard-coded 2 while `bench.py --steps 1 --warmup 0` had grown to three solves -- cold, profiling, timed --
+# and the driver line's `traffic` was 1.5x too large).  With the optional third argument (outer iterations of one solve, e.g.
+# the bench line's solve.max_iterations when no trajectory converges) the count is cross-checked against the sweep launches.
+def _disp(prefix):
+    return sum(int(r[di].strip()) for r in rows[2:] if r[0].strip().strip("`").startswith(prefix))
+SOLVES = _disp("k_init")
+if SOLVES <= 0:
+    raise SystemExit("no k_init dispatches in %s: cannot tell how many solves the profiled command ran" % sys.argv[1])
+if len(sys.argv) > 3:
+    sweeps = _disp("k_backward")
+    if sweeps != SOLVES * int(sys.argv[3]):
+        raise SystemExit("k_backward* dispatches %d != k_init dispatches %d x %s outer iterations" % (sweeps, SOLVES, sys.argv[3]))
 kern = {}
 for r in rows[2:]:
     c = [x.strip() for x in r]

@@ -112,3 +112,26 @@ def test_bench_default_line_carries_other_workloads():
     for w in ow:
         assert w["value"] > 0 and 0 < w["roofline"]["frac"] < 1 and w["steps"] == 3
     assert j["config"]["batch_per_gpu"] == 4096 and j["roofline"]["frac"] > 0
+
+
+def test_bench_torchrun_line_carries_c4_c5_and_rccl_rank_count():
+    """under torch.distributed.run the headline line is followed by BASELINE configs [3] / [4] (quadrotor,
+    7-joint arm) measured through the same partition + all-gather path; with one rank it is the 8-GPU share on a size-1
+    communicator -- the code path a world of 8 takes -- and the line reports the rank count RCCL itself sees."""
+    out = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], torchrun=True, port="29547")
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["config"]["rccl_ranks"] == 1 and j["config"]["collective"].startswith("ncclAllGather")
+    ow = j["other_workloads"]
+    assert len(ow) == 2 and not any("error" in w for w in ow), ow
+    assert "config[3]" in ow[0]["workload"] and "config[4]" in ow[1]["workload"]
+    for w in ow:
+        assert w["value"] > 0 and 0 < w["roofline"]["frac"] < 1 and w["n_gpus"] == 1 and w["rccl_ranks"] == 1
+
+
+def test_comm_info_reports_what_rccl_sees(api):
+    comm = api.comm_init(api.comm_unique_id(), 1, 0, 0)
+    try:
+        assert api.comm_info(comm) == (1, 0)
+    finally:
+        api.comm_destroy(comm)

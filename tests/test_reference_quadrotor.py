@@ -64,9 +64,9 @@ def test_oracle_quadrotor_warm_start_continuation(api, oracle_built):
 @pytest.mark.parametrize("solver", ["CLDDP", "IPDDP"])
 def test_hip_passes_the_reference_quadrotor_test(api, oracle_built, solver):
     """The same problem through the C-ABI, as trajectory 0 of a small batch (the others start from perturbed positions): the
-    reference's assertions hold for the device result; the default (device libm) build agrees with the oracle in status and, for
-    this converging solve, in the optimum it reaches (objective 1e-6); the shared-trig parity build agrees bit for bit in the
-    decisions (iteration count, sweep / rollout counts) and to 1e-9 in the objective."""
+    reference's assertions hold for the device result, which agrees bit for bit in the decisions (iteration count, sweep / rollout
+    counts) and to 1e-9 in the objective with the oracle in the library's arithmetic, and in status and optimum (objective 1e-6)
+    with the oracle in glibc arithmetic."""
     sv = api.SOLVER_CLDDP if solver == "CLDDP" else api.SOLVER_IPDDP
     p = api.quadrotor_figure8_problem(sv)
     U0, X0 = _hover_rollout(api, p)
@@ -79,28 +79,28 @@ def test_hip_passes_the_reference_quadrotor_test(api, oracle_built, solver):
         for b in range(1, B):
             for i in range(p.N):
                 X0b[b, i + 1] = o.dynamics(X0b[b, i], U0b[b, i])[1]
-    out = {}
-    for trig in ("libm", "shared"):
-        hs = api.HipBatchSolver(p, B, trig=trig)
-        hs.set_initial(x0, U0b, X0b)
-        st = hs.solve()
-        r = hs.results(); X, U = hs.trajectory(); hs.close()
-        out[trig] = (r, X, U, st.solve_ms)
-        _reference_asserts(api, p, r["status"][0], r["iterations"][0], X[0])
-        assert np.all(U[0] >= -1e-9) and np.all(U[0] <= 4.0 + 1e-9)
-    with api.shared_trig():
-        ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0b, X0b, n_threads=B)
-    r, X, U, ms = out["shared"]
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0b, X0b)
+    st = hs.solve()
+    r = hs.results(); X, U = hs.trajectory(); hs.close()
+    ms = st.solve_ms
+    _reference_asserts(api, p, r["status"][0], r["iterations"][0], X[0])
+    assert np.all(U[0] >= -1e-9) and np.all(U[0] <= 4.0 + 1e-9)
+    # the oracle in the library's arithmetic (trig_mode 1, tests/conftest.py): decisions bit for bit
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0b, X0b, n_threads=B)
     print("quadrotor figure-8 %s: HIP iterations %s oracle %s, solve %.1f ms for B = %d" % (solver, list(r["iterations"]), list(ores["iterations"]), ms, B))
     for key in ("iterations", "status", "n_backward", "n_forward"):
         assert np.array_equal(r[key], ores[key]), (key, r[key], ores[key])
     assert np.max(np.abs(r["final_objective"] - ores["final_objective"]) / np.maximum(1.0, np.abs(ores["final_objective"]))) < 1e-9
     assert np.max(np.abs(X - oX)) < 1e-8
-    # default build against the glibc-mode oracle: same outcome for the reference's own trajectory
-    ores2 = api.oracle_solve_batch(p, x0[:1], U0b[:1], X0b[:1], n_threads=1, want_traj=False)[0]
-    r2 = out["libm"][0]
-    assert api.STATUS_STRINGS[int(ores2["status"][0])] in OK and api.STATUS_STRINGS[int(r2["status"][0])] in OK
-    assert abs(r2["final_objective"][0] - ores2["final_objective"][0]) <= 1e-6 * max(1.0, abs(ores2["final_objective"][0]))
+    # against the glibc-mode oracle (the reference's own arithmetic): same outcome for the reference's own trajectory
+    prev = api.set_trig_mode(0)
+    try:
+        ores2 = api.oracle_solve_batch(p, x0[:1], U0b[:1], X0b[:1], n_threads=1, want_traj=False)[0]
+    finally:
+        api.set_trig_mode(prev)
+    assert api.STATUS_STRINGS[int(ores2["status"][0])] in OK and api.STATUS_STRINGS[int(r["status"][0])] in OK
+    assert abs(r["final_objective"][0] - ores2["final_objective"][0]) <= 1e-6 * max(1.0, abs(ores2["final_objective"][0]))
 
 
 @pytest.mark.gpu
