@@ -359,6 +359,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
   d.ddp = P.opt.use_ilqr ? 0 : 1;
   { const char *e = std::getenv("CDDP_HIP_XCD_MAP"); d.xcd_map = (e && e[0] == '0') ? 0 : 1; }
+  d.t4 = 0;   // set per launch by launch.hpp::derivs / backward (kernels.hpp::GT)
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
   d.hist_cap = P.opt.max_iterations + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
@@ -368,6 +369,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
   DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
   DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
+  if (ip && nx > 8) DA(d.Kt, (size_t)N * (nu * nx + nu) * Bp);   // G = 16 sweeps (launch.hpp::t4_layout)
   DA(d.Vx, (size_t)(N + 1) * nx * Bp); DA(d.Vxx, (size_t)(N + 1) * nx * nx * Bp);
   if (ip && h->ks->cst_size > 0) { DA(d.cst, (size_t)N * h->ks->cst_size * Bp); DA(d.dX, (size_t)N * nx * Bp); DA(d.ys, (size_t)N * (m > 0 ? m : 1) * Bp); }
   if (ip && m > 0) { DA(d.ks, (size_t)N * m * Bp); DA(d.ky, (size_t)N * m * Bp); DA(d.Ks, (size_t)N * m * nx * Bp); DA(d.Ky, (size_t)N * m * nx * Bp); }
@@ -469,6 +471,14 @@ static void from_soa(const double *src, double *dst, int B, int Bp, int T, int E
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < T; ++t)
       for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[tix(t, E, e, b, Bp)];
+}
+
+// the same, from the sub-tile-minor layout of the G = 16 sweeps' input stacks (kernels.hpp::GT)
+static void from_t4(const double *src, double *dst, int B, int Bp, int T, int E) {
+  const size_t NB16 = (size_t)(Bp / 64) * 16;
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[((((size_t)t * NB16 + (size_t)(b >> 2)) * (size_t)E + (size_t)e) * 4) + (size_t)(b & 3)];
 }
 
 static int in_set_initial(Inner *h, const double *x0, const double *U0, const double *X0) {
@@ -1001,8 +1011,11 @@ static int in_get_linearization(Inner *h, double *A, double *Bm) {
   HIPCHK(hipStreamSynchronize(h->stream));
   const DevBuf &d = h->d;
   std::vector<double> buf;
-  if (A) { int rc = fetch(h, d.A, (size_t)d.N * h->P.nx * h->P.nx * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), A, d.B, d.Bp, d.N, h->P.nx * h->P.nx); }
-  if (Bm) { int rc = fetch(h, d.Bm, (size_t)d.N * h->P.nx * h->P.nu * d.Bp, buf); if (rc) return rc; from_soa(buf.data(), Bm, d.B, d.Bp, d.N, h->P.nx * h->P.nu); }
+  // (the layout the last derivative fill wrote: the rule of launch.hpp, a function of the handle and the environment)
+  const bool t4 = h->P.solver == CDDP_HIP_SOLVER_IPDDP && h->ks->t4_layout(d) != 0;
+  auto conv = t4 ? &from_t4 : &from_soa;
+  if (A) { int rc = fetch(h, d.A, (size_t)d.N * h->P.nx * h->P.nx * d.Bp, buf); if (rc) return rc; conv(buf.data(), A, d.B, d.Bp, d.N, h->P.nx * h->P.nx); }
+  if (Bm) { int rc = fetch(h, d.Bm, (size_t)d.N * h->P.nx * h->P.nu * d.Bp, buf); if (rc) return rc; conv(buf.data(), Bm, d.B, d.Bp, d.N, h->P.nx * h->P.nu); }
   return 0;
 }
 

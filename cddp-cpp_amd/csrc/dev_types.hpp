@@ -81,6 +81,7 @@ struct DevBuf {
   int *n_fwd_steps;                        // [Bp] sum of t_steps over the trials the line-search rule walked (roofline accounting)
   double *cst;                             // [N][CST][Bp] V-independent condensed stage terms written by K1b (k_condense)
   double *ys;                              // [N][m][Bp] Y S^-1 ratios of the last sweep (K3 -> rollout consumer)
+  double *Kt;                              // [N][nu nx + nu] sub-tile-minor copy of K | k: what the G = 16 sweeps' own linear rollouts re-read (kernels.hpp::G4); NULL for nx <= 8
   double *dX;                              // [N][nx][Bp] linear-policy rollout of the last sweep (read by K3 k_post)
   double *ev;                              // [n_alphas][N][2*NSEG][Bp]: per-step log-barrier / |g+s| terms parked by K4
   // history [hist_batch][hist_cap][9] (row-major) + counts
@@ -91,6 +92,7 @@ struct DevBuf {
   int *win_hist;                           // [n_alphas + 1] accepted-alpha histogram of the solve so far (host picks the ladder shape)
   unsigned long long *launched;            // rollouts actually executed (speculative alphas included)
   int *cand;                               // [Bp] best-merit rule: the trial whose costate K4b evaluates (k_pick_candidate), -1 = none
+  int t4;                                  // 1: A / B / cst / te_cst stacks in the sub-tile-minor layout of the G = 16 cooperative sweeps (kernels.hpp::GT)
   int xcd_map;                             // cooperative sweeps: groups of one 64-trajectory tile on one XCD (kernels_coop.hpp::coop_group); CDDP_HIP_XCD_MAP=0 turns it off
 };
 

@@ -70,10 +70,3 @@ int cddp_host_model_eval(int model, int integrator, double dt, const double *par
   }
 }
 
-// The solver core's log / pow for the HOST loops of the plug-in route (plugin_solve.hip: IPDDP merit, LogDDP barrier, MSIPDDP filter,
-// barrier updates): the same straight-line routines the kernels call (dev_trig.hpp::solver_log / solver_pow on the device), so an
-// accept / reject decision of a plug-in solve sees the same last bit as the device-resident solve and as the checker's trig_mode 1.
-namespace cddp_hostfn {
-double solver_log(double x) { return cddp_dev::log_shared(x); }
-double solver_pow(double x, double y) { return cddp_dev::pow_shared(x, y); }
-}  // namespace cddp_hostfn

@@ -27,6 +27,19 @@ namespace cddp_dev {
 // hipcc sinks the prefetch loads of the software pipeline down to their first use (next iteration), which
 // removes the overlap; a compiler-level memory barrier right after issuing them pins them at the loop top.
 #define PIPELINE_FENCE() asm volatile("" ::: "memory")
+// Sub-tile-minor ("T4") layout of the SWEEP-INPUT stacks (A_t, B_t, condensed terms) of the G = 16 cooperative sweeps (nx > 8:
+// kernels_coop.hpp::k_backward_ipddp_coop_big, kernels_te.hpp::k_backward_te_coop).  A single-wave workgroup of those sweeps holds
+// 4 trajectories, i.e. 32 B of every 512-B row of the wave-tiled layout: sixteen workgroups share each row (four share each
+// 128-B line) and, drifting apart over 150 - 400 dependent steps, fetch it again and again (round 3, after the XCD map: 7.1 GB
+// fetched per launch against 3.7 GB at C4, 17.5 against 4.7 at C5 -- profiles/r03_pmc_counters_*.md).  Here element e of step t
+// of trajectory b lives at (((t * NB * 16 + b / 4) * E + e) * 4 + b % 4): the step record of one workgroup's 4 trajectories is
+// E * 32 B of CONTIGUOUS memory that no other workgroup touches, and a cooperative fetch of 16 consecutive elements x 4
+// trajectories is one 512-B coalesced access.  Written by the (batch x N) producers (k_derivs, k_condense, k_te_condense), read
+// by the sweeps, k_te_post and the host getter; d.t4 is set per launch by launch.hpp (same rule in derivs() and backward()).
+#define GT(t, E, e) (d.t4 ? ((((size_t)(t) * (size_t)d.NB * 16 + (size_t)(b >> 2)) * (size_t)(E) + (size_t)(e)) * 4 + (size_t)(b & 3)) : GI(t, E, e))
+// index into a stack that exists ONLY in the sub-tile-minor form (d.Kt: the gains the sweep just wrote, re-read by its own rollouts)
+#define G4(t, E, e) ((((size_t)(t) * (size_t)d.NB * 16 + (size_t)(b >> 2)) * (size_t)(E) + (size_t)(e)) * 4 + (size_t)(b & 3))
+#define TSTRIDE (d.t4 ? (size_t)4 : (size_t)kLS)   // distance between consecutive elements of one trajectory's record
 
 constexpr double kSlackInteriorOffset = 1e-4;   // ipddp_solver.cpp:35-38
 constexpr double kEpsSlack = 1e-10;
@@ -91,10 +104,10 @@ __global__ __launch_bounds__(64) void k_derivs(DevBuf d, const ProblemDev *__res
     for (int j = 0; j < NX; ++j) {
       double a = dt * Fx[i * NX + j];
       if (i == j) a += 1.0;
-      d.A[GI(t, NX * NX, i * NX + j)] = a;
+      d.A[GT(t, NX * NX, i * NX + j)] = a;
     }
 #pragma unroll
-  for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = dt * Fu[i];
+  for (int i = 0; i < NX * NU; ++i) d.Bm[GT(t, NX * NU, i)] = dt * Fu[i];
 }
 
 // Q-function blocks shared by both solvers:

@@ -903,12 +903,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   static_assert(L::WQYU == L::CU + NU && L::QYUSIR == L::WQYU + NU * NU && L::IPR == L::QYUSIR + NU && L::ICOMP == L::IPR + 1, "contiguous replicated block");
   auto loadAB = [&](int tt, InAB &r) {   // this lane's slice of A_t, B_t (element e = q + G j; clamped past the end)
 #pragma unroll
-    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GT(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
 #pragma unroll
-    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GT(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
     // the terms every lane of the group needs (c_u, G_u^T YS^-1 G_u, G_u^T S^-1 rhat, residual maxima): one slice per lane
 #pragma unroll
-    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.cst[GI(tt, CST, L::CU + (e < C::RC ? e : C::RC - 1))]; }
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.cst[GT(tt, CST, L::CU + (e < C::RC ? e : C::RC - 1))]; }
   };
   auto storeAB = [&](int buf, const InAB &r) {
     double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU;
@@ -921,15 +921,16 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
     for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; if (e < C::RC) Lc[e] = r.c[j]; }
   };
   auto load2 = [&](int tt, In2 &r) {
-    const double *c = d.cst + GI(tt, CST, 0);
-    r.cxq = c[(size_t)(L::CX + qc) * kLS];
+    const double *c = d.cst + GT(tt, CST, 0);
+    const size_t ts = TSTRIDE;
+    r.cxq = c[(size_t)(L::CX + qc) * ts];
     if constexpr (Cons::HAS_X) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) r.WQyxq[u] = c[(size_t)(L::WQYX + u * NX + qc) * kLS];
-      r.QyxSirq = c[(size_t)(L::QYXSIR + qc) * kLS];
+      for (int u = 0; u < NU; ++u) r.WQyxq[u] = c[(size_t)(L::WQYX + u * NX + qc) * ts];
+      r.QyxSirq = c[(size_t)(L::QYXSIR + qc) * ts];
       // column qc of G_x^T YS^-1 G_x goes straight to LDS (indexed by a rolled loop below)
 #pragma unroll 4
-      for (int i = 0; i < NX; ++i) Ls[C::oWx + i * NX + qc] = c[(size_t)(L::WXQYX + i * NX + qc) * kLS];
+      for (int i = 0; i < NX; ++i) Ls[C::oWx + i * NX + qc] = c[(size_t)(L::WXQYX + i * NX + qc) * ts];
     }
   };
   for (;;) {
@@ -1112,6 +1113,10 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       st<NU>(d.k + GI(t, NU, 0), kLS, kk);
 #pragma unroll
       for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+      if (d.t4) {   // the copy the dX rollout below re-reads (wave-tiled K / k are for the wide kernels)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { d.Kt[G4(t, NU * NX + NU, u * NX + qc)] = KKc[u]; if (q == u) d.Kt[G4(t, NU * NX + NU, NU * NX + u)] = kk[u]; }
+      }
       // ---- round 3
       if constexpr (Cons::HAS_X) Qxq += c2.QyxSirq;
       inf_pr = dmax(inf_pr, Lc[NU + NU * NU + NU]); inf_comp = dmax(inf_comp, Lc[NU + NU * NU + NU + 1]);
@@ -1218,12 +1223,12 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
       static_assert(2 * GS <= 2 * NX * NX, "gain buffers fit the A area");
       auto load_r = [&](int tt, RIn &r) {
 #pragma unroll
-        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < C::RK ? e : C::RK - 1)]; }
-        r.kq = d.k[GI(tt, NU, q < NU ? q : NU - 1)];
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; const int ee = e < C::RK ? e : C::RK - 1; r.ks[j] = d.t4 ? d.Kt[G4(tt, NU * NX + NU, ee)] : d.K[GI(tt, NU * NX, ee)]; }
+        r.kq = d.t4 ? d.Kt[G4(tt, NU * NX + NU, NU * NX + (q < NU ? q : NU - 1))] : d.k[GI(tt, NU, q < NU ? q : NU - 1)];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GT(tt, NX * NX, qc * NX + j)];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GT(tt, NX * NU, qc * NU + j)];
       };
       auto store_r = [&](int buf, const RIn &r) {
         double *Lg = Ls + C::oA + buf * GS;

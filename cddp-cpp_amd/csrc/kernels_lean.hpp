@@ -114,13 +114,14 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
 #pragma unroll
     for (int r = 0; r < M; ++r) s1 += Qyu[r * NU + i] * Sir[r];
     QyuSir[i] = s1; }
-  double *o = d.cst + GI(t, L::SIZE, 0);
-  st<NX>(o + (size_t)L::CX * kLS, kLS, cx);
-  st<NU>(o + (size_t)L::CU * kLS, kLS, cu);
-  st<NU * NU>(o + (size_t)L::WQYU * kLS, kLS, WQyu);
-  st<NU>(o + (size_t)L::QYUSIR * kLS, kLS, QyuSir);
-  o[(size_t)L::IPR * kLS] = ipr;
-  o[(size_t)L::ICOMP * kLS] = icomp;
+  double *o = d.cst + GT(t, L::SIZE, 0);
+  const size_t ts = TSTRIDE;
+  st<NX>(o + (size_t)L::CX * ts, ts, cx);
+  st<NU>(o + (size_t)L::CU * ts, ts, cu);
+  st<NU * NU>(o + (size_t)L::WQYU * ts, ts, WQyu);
+  st<NU>(o + (size_t)L::QYUSIR * ts, ts, QyuSir);
+  o[(size_t)L::IPR * ts] = ipr;
+  o[(size_t)L::ICOMP * ts] = icomp;
   if constexpr (Cons::HAS_X) {
     double WQyx[NU * NX], QyxSir[NX], Wx[NX * M], WxQyx[NX * NX];
     mm_nn<NU, M, NX>(W, Qyx, WQyx);
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
 #pragma unroll
       for (int r = 0; r < M; ++r) Wx[i * M + r] = Qyx[r * NX + i] * YS[r];
     mm_nn<NX, M, NX>(Wx, Qyx, WxQyx);
-    st<NU * NX>(o + (size_t)L::WQYX * kLS, kLS, WQyx);
-    st<NX>(o + (size_t)L::QYXSIR * kLS, kLS, QyxSir);
-    st<NX * NX>(o + (size_t)L::WXQYX * kLS, kLS, WxQyx);
+    st<NU * NX>(o + (size_t)L::WQYX * ts, ts, WQyx);
+    st<NX>(o + (size_t)L::QYXSIR * ts, ts, QyxSir);
+    st<NX * NX>(o + (size_t)L::WXQYX * ts, ts, WxQyx);
   }
 }
 

@@ -144,12 +144,13 @@ __global__ __launch_bounds__(64) void k_te_condense(DevBuf d, const ProblemDev *
 #pragma unroll
       for (int c = 0; c < NU; ++c) R[i * NU + c] = 0.5 * (Rn[i * NU + c] + Rn[c * NU + i]);
   }
-  double *rec = d.te_cst + GI(t, C::REC, 0);
-  st<NX>(rec + (size_t)C::cQ * kLS, kLS, q);
-  st<NU>(rec + (size_t)C::cR * kLS, kLS, r);
-  st<NU * NU>(rec + (size_t)C::cRR * kLS, kLS, R);
-  rec[(size_t)C::cIPR * kLS] = ipr;
-  rec[(size_t)C::cICOMP * kLS] = icomp;
+  double *rec = d.te_cst + GT(t, C::REC, 0);
+  const size_t ts = TSTRIDE;
+  st<NX>(rec + (size_t)C::cQ * ts, ts, q);
+  st<NU>(rec + (size_t)C::cR * ts, ts, r);
+  st<NU * NU>(rec + (size_t)C::cRR * ts, ts, R);
+  rec[(size_t)C::cIPR * ts] = ipr;
+  rec[(size_t)C::cICOMP * ts] = icomp;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,11 +300,11 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
   struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
   auto loadAB = [&](int tt, InAB &r) {   // this lane's slices of A_t, B_t and of the step's LQ record
 #pragma unroll
-    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+    for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GT(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
 #pragma unroll
-    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+    for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GT(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
 #pragma unroll
-    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.te_cst[GI(tt, REC, e < REC ? e : REC - 1)]; }
+    for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; r.c[j] = d.te_cst[GT(tt, REC, e < REC ? e : REC - 1)]; }
   };
   auto storeAB = [&](const InAB &r) {
     double *La = Ls + C::oA, *Lb = Ls + C::oB, *Lc = Ls + C::oC;
@@ -573,6 +574,10 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       if (__ballot(bad) & gmask) return false;
 #pragma unroll
       for (int u = 0; u < NU; ++u) d.K[GI(t, NU * NX, u * NX + qc)] = KKc[u];
+      if (d.t4) {   // the copy the variant rollouts (P2) and the dX rollout (P5) re-read
+#pragma unroll
+        for (int u = 0; u < NU; ++u) d.Kt[G4(t, NU * NX + NU, u * NX + qc)] = KKc[u];
+      }
 #pragma unroll
       for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
       return true;
@@ -590,11 +595,11 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       struct RIn { double a[C::NA], bm[C::NB], ks[C::NK], kf[NU]; };
       auto load_r = [&](int tt, RIn &r) {
 #pragma unroll
-        for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GI(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
+        for (int j = 0; j < C::NA; ++j) { const int e = q + G * j; r.a[j] = d.A[GT(tt, NX * NX, e < NX * NX ? e : NX * NX - 1)]; }
 #pragma unroll
-        for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GI(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
+        for (int j = 0; j < C::NB; ++j) { const int e = q + G * j; r.bm[j] = d.Bm[GT(tt, NX * NU, e < NX * NU ? e : NX * NU - 1)]; }
 #pragma unroll
-        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < NU * NX ? e : NU * NX - 1)]; }
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; const int ee = e < NU * NX ? e : NU * NX - 1; r.ks[j] = d.t4 ? d.Kt[G4(tt, NU * NX + NU, ee)] : d.K[GI(tt, NU * NX, ee)]; }
 #pragma unroll
         for (int i = 0; i < NU; ++i) r.kf[i] = tek[(((size_t)tt * Bp + b) * NU + i) * VP + (hasv ? v : 0)];
       };
@@ -731,6 +736,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           const int t = idx / NU, i = idx - t * NU;
           const double ko = combine(tek + (((size_t)t * Bp + b) * NU + i) * VP);
           d.k[GI(t, NU, i)] = ko;
+          if (d.t4) d.Kt[G4(t, NU * NX + NU, NU * NX + i)] = ko;
           sn = dmax(sn, fabs(ko));
         }
         for (int idx = q; idx < (N + 1) * NX; idx += G) {
@@ -752,12 +758,12 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         static_assert(2 * GS <= 2 * NX * NX + 2 * NX * NU, "gain buffers fit the A/B area");
         auto load_g = [&](int tt, GIn &r) {
 #pragma unroll
-          for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; r.ks[j] = d.K[GI(tt, NU * NX, e < NU * NX ? e : NU * NX - 1)]; }
-          r.kq = d.k[GI(tt, NU, q < NU ? q : NU - 1)];
+          for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; const int ee = e < NU * NX ? e : NU * NX - 1; r.ks[j] = d.t4 ? d.Kt[G4(tt, NU * NX + NU, ee)] : d.K[GI(tt, NU * NX, ee)]; }
+          r.kq = d.t4 ? d.Kt[G4(tt, NU * NX + NU, NU * NX + (q < NU ? q : NU - 1))] : d.k[GI(tt, NU, q < NU ? q : NU - 1)];
 #pragma unroll
-          for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+          for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GT(tt, NX * NX, qc * NX + j)];
 #pragma unroll
-          for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+          for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GT(tt, NX * NU, qc * NU + j)];
         };
         auto store_g = [&](int buf, const GIn &r) {
           double *Lg = Ls + C::oA + buf * GS;
@@ -850,14 +856,14 @@ __global__ __launch_bounds__(64) void k_te_post(DevBuf d, const ProblemDev *__re
     // B^T p with B streamed a row at a time (row k enters every a_i as its k-th term: the sums run in the same order as column by
     // column, with nu accumulators instead of the nx nu block in registers)
     double r[NU], pn[NX], acc[NU];
-    ld<NU>(d.te_cst + GI(t, C::REC, C::cR), kLS, r);
+    ld<NU>(d.te_cst + GT(t, C::REC, C::cR), TSTRIDE, r);
     ld<NX>(d.Vx + GI(t + 1, NX, 0), kLS, pn);
 #pragma unroll
     for (int i = 0; i < NU; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       double Bk[NU];
-      ld<NU>(d.Bm + GI(t, NX * NU, k * NU), kLS, Bk);
+      ld<NU>(d.Bm + GT(t, NX * NU, k * NU), TSTRIDE, Bk);
 #pragma unroll
       for (int i = 0; i < NU; ++i) acc[i] += Bk[i] * pn[k];
     }

@@ -22,6 +22,7 @@ struct KernelSet {
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, int mode, hipStream_t);
   void (*stage)(const DevBuf &, int copy_xu, int ipddp, hipStream_t);
+  int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
 };
 
 template <class Model, class Cons, bool TERM = false>
@@ -49,7 +50,22 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "mfma");
   }
-  static void derivs(const DevBuf &d, int force, hipStream_t s) {
+  // Sub-tile-minor ("T4", kernels.hpp::GT) sweep-input stacks: exactly when the G = 16 cooperative sweep of this layout is the
+  // consumer -- the one-lane, matrix-core and full-DDP sweeps read the wave-tiled form.  Evaluated per launch (the tests switch
+  // CDDP_HIP_SWEEP between solves of one process); derivs() and backward() of one iteration see the same answer.
+  static int t4_layout(const DevBuf &d) {
+    if constexpr (CoopCfg<Model>::G != 16) return 0;
+    else {
+      if (lane_sweep_requested() || mfma_sweep_requested() || d.ddp) return 0;
+      if (const char *e = std::getenv("CDDP_HIP_T4")) { if (e[0] == '0') return 0; }
+      if constexpr (kLean) return d.cst ? 1 : 0;
+      else if constexpr (kTeCoop) return d.te_cst ? 1 : 0;
+      else return 0;
+    }
+  }
+  static void derivs(const DevBuf &d0, int force, hipStream_t s) {
+    DevBuf d = d0;
+    d.t4 = t4_layout(d0);
     if constexpr (kLean) {
       if (d.cst) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
                      // for nx > 8 the two register sets together would spill)
@@ -67,7 +83,9 @@ struct Launcher {
     if constexpr (kTeCoop)
       if (d.te_cst) hipLaunchKernelGGL((k_te_condense<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
   }
-  static void backward(const DevBuf &d, int solver, int force, int count_iter, hipStream_t s) {
+  static void backward(const DevBuf &d0, int solver, int force, int count_iter, hipStream_t s) {
+    DevBuf d = d0;
+    d.t4 = (solver == CDDP_HIP_SOLVER_IPDDP) ? t4_layout(d0) : 0;
     // lane-cooperative sweeps (kernels_coop.hpp) wherever a layout has one; CDDP_HIP_SWEEP=lane selects the
     // one-lane-per-trajectory kernels instead (comparison / experiments)
     // full DDP (use_ilqr = 0): the one-lane IPDDP kernels carry the tensor terms; CLDDP's backward pass has none
@@ -187,7 +205,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout;
     return k;
   }
 };

@@ -27,11 +27,6 @@
 
 #include "../../include/cddp_hip.h"
 
-namespace cddp_hostfn {   // host_models.cpp: dev_trig.hpp's log_shared / pow_shared compiled for the host (the routines the kernels call)
-double solver_log(double x);
-double solver_pow(double x, double y);
-}
-
 extern "C" int cddp_hip_internal_set_error(int code, const char *msg);   // capi.hip (thread-local last-error string)
 
 namespace {
@@ -106,7 +101,7 @@ void ip_reductions(const Ctx &c, const double *S, const double *Y, const double 
     const int dim = c.pl->constraint_dims[s];
     for (int t = 0; t < N; ++t) {
       double ls = 0.0;
-      for (int i = 0; i < dim; ++i) ls += cddp_hostfn::solver_log(std::max(S[(size_t)t * m + off + i], kEpsSlack));
+      for (int i = 0; i < dim; ++i) ls += std::log(std::max(S[(size_t)t * m + off + i], kEpsSlack));
       mer -= mu * ls;
     }
     off += dim;
@@ -336,11 +331,11 @@ struct LTraj {
 
 void lg_beta(double z, double delta, double &b0, double &b1, double &b2) {   // calculate_beta_derivatives (barrier.hpp:274-296)
   if (z > delta) {
-    if (z <= 1e-12) { b0 = -cddp_hostfn::solver_log(1e-12); b1 = -1.0 / 1e-12; b2 = 1.0 / (1e-12 * 1e-12); }
-    else { b0 = -cddp_hostfn::solver_log(z); b1 = -1.0 / z; b2 = 1.0 / (z * z); }
+    if (z <= 1e-12) { b0 = -std::log(1e-12); b1 = -1.0 / 1e-12; b2 = 1.0 / (1e-12 * 1e-12); }
+    else { b0 = -std::log(z); b1 = -1.0 / z; b2 = 1.0 / (z * z); }
   } else {
     const double td = (z - 2.0 * delta) / delta;
-    b0 = 0.5 * (td * td - 1.0) - cddp_hostfn::solver_log(delta); b1 = td / delta; b2 = 1.0 / (delta * delta);
+    b0 = 0.5 * (td * td - 1.0) - std::log(delta); b1 = td / delta; b2 = 1.0 / (delta * delta);
   }
 }
 
@@ -568,7 +563,7 @@ void ms_reset_filter(const Ctx &c, MTraj &t) {   // resetBarrierFilter :711-763
         double lsum = 0.0, l1 = 0.0;
         for (int i = 0; i < dim; ++i) {
           const size_t j = (size_t)s * m + off + i;
-          lsum += cddp_hostfn::solver_log(t.S[j]);
+          lsum += std::log(t.S[j]);
           const double pr = t.G[j] + t.S[j];
           ipr = std::max(ipr, std::fabs(pr)); l1 += std::fabs(pr);
           icomp = std::max(icomp, std::fabs(t.Y[j] * t.S[j] - t.mu));
@@ -904,7 +899,7 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
           for (int q = 0; q < pl->n_constraints; ++q) {
             const int dim = pl->constraint_dims[q];
             double lsum = 0.0, l1 = 0.0;
-            for (int i = 0; i < dim; ++i) { const size_t j = (size_t)s * m + off + i; lsum += cddp_hostfn::solver_log(Sn[j]); l1 += std::fabs(Gn[j] + Sn[j]); }
+            for (int i = 0; i < dim; ++i) { const size_t j = (size_t)s * m + off + i; lsum += std::log(Sn[j]); l1 += std::fabs(Gn[j] + Sn[j]); }
             merit_new -= t.mu * lsum; cv_new += l1; off += dim;
           }
           double d1 = 0.0;
@@ -946,7 +941,7 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
         } else if (o.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
           const double err = std::max(std::max(ms_scaled_inf_du(c, t), t.inf_pr), t.inf_comp);
           if (err <= 10.0 * t.mu) {
-            t.mu = std::max(o.tolerance / 10.0, std::min(o.barrier_mu_update_factor * t.mu, cddp_hostfn::solver_pow(t.mu, o.barrier_mu_update_power)));
+            t.mu = std::max(o.tolerance / 10.0, std::min(o.barrier_mu_update_factor * t.mu, std::pow(t.mu, o.barrier_mu_update_power)));
             ms_reset_filter(c, t);
           }
         } else {
@@ -961,7 +956,7 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
               else if (ratio < 0.1) fac = o.barrier_mu_update_factor * 0.3;
               else if (ratio < 0.5) fac = o.barrier_mu_update_factor * 0.6;
             }
-            const double lin = fac * t.mu, sup = cddp_hostfn::solver_pow(t.mu, o.barrier_mu_update_power);
+            const double lin = fac * t.mu, sup = std::pow(t.mu, o.barrier_mu_update_power);
             if (slow && t.mu > o.tolerance) t.mu = std::min(lin, sup);
             else t.mu = std::max(o.tolerance / 100.0, std::min(lin, sup));
             ms_reset_filter(c, t);
@@ -1167,13 +1162,13 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
                   else if (ratio < 0.1) factor = 0.3 * o.barrier_mu_update_factor;
                   else if (ratio < 0.5) factor = 0.6 * o.barrier_mu_update_factor;
                 }
-                const double linear = factor * mu, superlinear = cddp_hostfn::solver_pow(mu, o.barrier_mu_update_power);
+                const double linear = factor * mu, superlinear = std::pow(mu, o.barrier_mu_update_power);
                 mu = std::max(std::min(linear, superlinear), std::max(o.barrier_mu_min_value, o.tolerance / 100.0));
               }
             } else {
               const double kkt = std::max(std::max(t.inf_pr, sdu * o.ipddp_barrier_update_dual_weight), t.inf_comp);
               if (kkt <= o.ipddp_mu_kappa_epsilon * mu) {
-                const double linear = o.barrier_mu_update_factor * mu, superlinear = cddp_hostfn::solver_pow(mu, o.barrier_mu_update_power);
+                const double linear = o.barrier_mu_update_factor * mu, superlinear = std::pow(mu, o.barrier_mu_update_power);
                 mu = std::max(o.barrier_mu_min_value, std::min(linear, superlinear));
               }
             }

@@ -44,6 +44,7 @@ def load_oracle_api():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "host_arithmetic: gpu test of the host (plug-in) route -- the oracle stays in glibc arithmetic (trig_mode 0)")
 
 
 @pytest.fixture(scope="session")
@@ -57,7 +58,9 @@ def _oracle_arithmetic(request):
     solver core's log / pow of cddp-cpp_amd/csrc/dev_trig.hpp (oracle trig_mode 1) -- since round 4 the ONE shipped library is built
     that way, so the comparison is strict.  CPU tests (oracle vs the numpy twin, golden fixtures, reference pins) keep mode 0: glibc,
     the reference's own arithmetic."""
-    if request.node.get_closest_marker("gpu") is None:
+    # ... except the tests of the library's HOST route (`host_arithmetic` marker: cddp_hip_plugin_solve and the stack-fed sweeps a host
+    # loop drives -- user callbacks, host forward passes, host log / pow): host code calls the host libm, i.e. glibc, like the reference.
+    if request.node.get_closest_marker("gpu") is None or request.node.get_closest_marker("host_arithmetic") is not None:
         yield
         return
     oa = load_oracle_api()

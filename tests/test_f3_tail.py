@@ -20,9 +20,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "twin"))
 def _eval_all(api, p, x, u, hess=True):
     """(step, A = I + dt f_x, B = dt f_u, dt * Hessians) from the oracle and from the product's host models."""
     o = api.Oracle(p)
-    with api.shared_trig():   # the product's host models evaluate the straight-line sin / cos of dev_trig.hpp (the one build since round 4)
-        _, xn, Fx, Fu = o.dynamics(x, u)
-        H = o.hessians(x, u) if hess else None
+    _, xn, Fx, Fu = o.dynamics(x, u)
+    H = o.hessians(x, u) if hess else None
     mp = np.array(list(p.c.model_params), dtype=np.float64)
     r = api.model_eval(p.c.model, p.c.integrator, p.dt, mp, p.nx, p.nu, x, u, want=("step", "jac") + (("hess",) if hess else ()))
     return (xn, Fx, Fu, H), (r["step"], r["jac"][0], r["jac"][1], r.get("hess"))

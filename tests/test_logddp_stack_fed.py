@@ -12,6 +12,8 @@ import sys
 import numpy as np
 import pytest
 
+pytestmark = pytest.mark.host_arithmetic   # host route of the library: glibc on both sides (tests/conftest.py)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "twin"))
 

@@ -17,6 +17,8 @@ import sys
 import numpy as np
 import pytest
 
+pytestmark = pytest.mark.host_arithmetic   # host route of the library: glibc on both sides (tests/conftest.py)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 OK = ("OptimalSolutionFound", "AcceptableSolutionFound")
