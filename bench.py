@@ -334,6 +334,50 @@ MULTI_RANK_WORKLOADS = [
 ]
 
 
+def measure_mpc(api, rounds, device=0, workload="cartpole", batch=0):
+    """f1 caller side: receding-horizon re-solves on a RE-USED handle -- the caller pattern of
+    examples/ipddp_mpcc_rc.py:649-705 (solver.set_initial_state(state); solver.solve()) with the reference's warm-start branch
+    "existing solver state" (ipddp_solver.cpp:675-731: controls, slacks, duals, gains and regularisation kept).  Round 0 is the cold
+    solve; round k >= 1 starts every trajectory from the state its own previous plan predicted one step ahead (x_1 of the previous
+    solution: the plant is the model) and re-solves.  Few iterations per solve: launches and host polls, not kernels, dominate --
+    the line reports the device time (hipEvents, begin .. end of cddp_hip_solve's stream work) next to the wall time of the call."""
+    p, spread, desc = make_problem(api, workload, "ipddp")
+    B = batch if batch > 0 else DEFAULT_BATCH[workload]
+    x0 = api.batch_x0(p, B, 20260928 + 1, spread)
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B, device=device)
+    try:
+        hs.set_initial(x0, U0)
+        hs.solve()                      # code load / first touch
+        hs.set_initial(x0, U0)
+        t0 = time.perf_counter(); st0 = hs.solve(); cold_wall = time.perf_counter() - t0
+        r0 = hs.results()
+        hs.set_warm_start(True)
+        wall_solve = []; wall_step = []; dev_ms = []; iters = []; launches = []; conv = []
+        for _ in range(rounds):
+            t_step = time.perf_counter()
+            u0, x1 = hs.plan_head()     # the head of the plan goes back to the host: an MPC loop applies u_0 and restarts from x_1
+            hs.set_initial_state(x1)
+            t1 = time.perf_counter(); st = hs.solve(); t2 = time.perf_counter()
+            r = hs.results()
+            wall_solve.append(t2 - t1); wall_step.append(t2 - t_step); dev_ms.append(st.solve_ms); launches.append(int(st.kernel_launches))
+            iters.append(float(np.mean(r["iterations"])))
+            conv.append(int(np.sum((r["status"] == api.STATUS_OPTIMAL) | (r["status"] == api.STATUS_ACCEPTABLE))))
+        ws = float(np.mean(wall_solve)); wd = float(np.mean(dev_ms)) * 1e-3
+        return {
+            "workload": "MPC re-solves (f1): %s, B=%d, %d shift-by-one-step re-solves on a re-used handle, warm start = existing solver state" % (desc, B, rounds),
+            "solver": "IPDDP", "batch": B, "steps": rounds, "unit": "re-solved trajectories/s",
+            "value": B / ws, "ms_per_step": ws * 1e3, "ms_per_mpc_step_incl_readback": float(np.mean(wall_step)) * 1e3,
+            "device_ms_per_resolve": wd * 1e3, "host_fraction_of_solve_call": max(0.0, 1.0 - wd / ws),
+            "mean_iterations_per_resolve": float(np.mean(iters)), "iterations_by_round": iters, "kernel_launches_per_resolve": float(np.mean(launches)),
+            "converged_by_round": conv,
+            "cold": {"ms": cold_wall * 1e3, "device_ms": float(st0.solve_ms), "mean_iterations": float(np.mean(r0["iterations"])),
+                     "converged": int(np.sum((r0["status"] == api.STATUS_OPTIMAL) | (r0["status"] == api.STATUS_ACCEPTABLE)))},
+        }
+    finally:
+        hs.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +392,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch trajectories per GPU; strong: a fixed global batch (--global-batch or the BASELINE config's) over all GPUs")
     ap.add_argument("--global-batch", type=int, default=0)
+    ap.add_argument("--mpc", type=int, default=0, help="only the MPC re-solve measurement: K shift-and-re-solve rounds on a re-used handle (1 GPU), one JSON line")
     args = ap.parse_args()
 
     import torch
@@ -387,6 +432,11 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     api = load_api()
+    if args.mpc > 0:
+        if world != 1:
+            raise SystemExit("--mpc is a single-GPU measurement")
+        print(json.dumps(measure_mpc(api, args.mpc, device=local_rank, workload=args.workload, batch=args.batch)))
+        return
     p, spread, desc = make_problem(api, args.workload, args.solver)
     sh = load_module("cddp_sharding", "sharding.py")
     # one seeded global batch (seed = 20260928 + config_index), block-partitioned over the ranks.
@@ -505,6 +555,11 @@ def main():
                 out["other_workloads"].append(measure_other(api, wl, sv, label, device=local_rank))
             except Exception as e:   # a failing extra workload must not lose the headline line
                 out["other_workloads"].append({"workload": label, "error": "%s: %s" % (type(e).__name__, e)})
+        for wl in ("pendulum", "cartpole"):   # pendulum: converging re-solves (few iterations); cart-pole: the headline plant
+            try:
+                out["other_workloads"].append(measure_mpc(api, 8, device=local_rank, workload=wl))
+            except Exception as e:
+                out["other_workloads"].append({"workload": "MPC re-solves (%s)" % wl, "error": "%s: %s" % (type(e).__name__, e)})
     elif dist is not None and not args.no_other_workloads and headline:
         # under torchrun (any world size, 1 included): configs [3] / [4] with the batch partitioned over the ranks and the same
         # single collective -- every rank takes part, rank 0 keeps the lines

@@ -25,6 +25,17 @@ static __global__ void k_gather_records(DevBuf d, cddp_hip_gather_record *out) {
   out[b] = r;
 }
 
+// head of the plan: u_0 and x_1 of every trajectory's CURRENT iterate (batch-major), what a receding-horizon caller reads back
+static __global__ void k_gather_plan_head(DevBuf d, int nx, int nu, double *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX, *Uc = d.U + (size_t)cur * d.planeU;
+  double *o = out + (size_t)b * (nu + nx);
+  for (int i = 0; i < nu; ++i) o[i] = Uc[((((size_t)0 * d.NB + (size_t)(b >> 6)) * nu + i) * 64) + (size_t)(b & 63)];
+  for (int i = 0; i < nx; ++i) o[nu + i] = Xc[((((size_t)1 * d.NB + (size_t)(b >> 6)) * nx + i) * 64) + (size_t)(b & 63)];
+}
+
 // CDDPOptions::max_cpu_time expired (cddp_solver_base.cpp:77-90): the check sits after ++iter and before the
 // backward pass, so every trajectory still running reports the iteration the check fired in.
 static __global__ void k_mark_cpu_time(DevBuf d) {
@@ -88,6 +99,7 @@ struct Inner {
   int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
   std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll = nullptr;
+  double *d_head = nullptr, *h_head = nullptr; size_t head_cap = 0;   // cddp_hip_get_plan_head staging (device, pinned host)
   int *h_poll = nullptr;                         // pinned host words of the solve loop's poll: [0] running count, [1..] alpha histogram
 };
 
@@ -433,6 +445,8 @@ static int in_destroy(Inner *h) {
   if (h->ev_begin) { hipEventDestroy(h->ev_begin); hipEventDestroy(h->ev_end); }
   if (h->ev_poll) hipEventDestroy(h->ev_poll);
   if (h->h_poll) hipHostFree(h->h_poll);
+  if (h->d_head) hipFree(h->d_head);
+  if (h->h_head) hipHostFree(h->h_head);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1076,6 +1090,32 @@ static int in_get_history(Inner *h, int hist_batch, double *hist, int32_t *count
   return 0;
 }
 
+static int in_get_plan_head(Inner *h, double *u0, double *x1) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->has_state) return fail(-1, "cddp_hip_get_plan_head needs a solved or initialised handle");
+  HIPCHK(hipSetDevice(h->device));
+  const int B = h->d.B, nx = h->P.nx, nu = h->P.nu;
+  const size_t n = (size_t)B * (nx + nu);
+  if (h->head_cap < n) {
+    if (h->d_head) hipFree(h->d_head);
+    if (h->h_head) hipHostFree(h->h_head);
+    h->d_head = nullptr; h->h_head = nullptr; h->head_cap = 0;
+    HIPCHK(hipMalloc((void **)&h->d_head, n * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&h->h_head, n * sizeof(double)));
+    h->head_cap = n;
+  }
+  hipLaunchKernelGGL(k_gather_plan_head, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->d, nx, nu, h->d_head);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->h_head, h->d_head, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < B; ++b) {
+    const double *r = h->h_head + (size_t)b * (nx + nu);
+    if (u0) for (int i = 0; i < nu; ++i) u0[(size_t)b * nu + i] = r[i];
+    if (x1) for (int i = 0; i < nx; ++i) x1[(size_t)b * nx + i] = r[nu + i];
+  }
+  return 0;
+}
+
 static int in_write_gather_records_device(Inner *h, void *device_ptr) {
   if (!h || !device_ptr) return fail(-1, "null argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1234,6 +1274,7 @@ int cddp_hip_forward(cddp_hip_handle *h, const double *alphas, int n_alphas, cdd
   FOR_GROUPS(in_forward(q, alphas, n_alphas, OFF(trials, n_alphas)));
 }
 int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *r) { if (!r) return fail(-1, "null argument"); FOR_GROUPS(in_get_results(q, OFF(r, 1))); }
+int cddp_hip_get_plan_head(cddp_hip_handle *h, double *u0, double *x1) { FOR_GROUPS(in_get_plan_head(q, OFF(u0, h->nu), OFF(x1, h->nx))); }
 int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X, double *U) { FOR_GROUPS(in_get_trajectory(q, OFF(X, (h->N + 1) * h->nx), OFF(U, h->N * h->nu))); }
 int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k) { FOR_GROUPS(in_get_gains(q, OFF(K, h->N * h->nu * h->nx), OFF(k, h->N * h->nu))); }
 int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) { FOR_GROUPS(in_get_value(q, OFF(Vx, (h->N + 1) * h->nx), OFF(Vxx, (h->N + 1) * h->nx * h->nx))); }

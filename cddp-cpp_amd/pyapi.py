@@ -591,7 +591,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
-    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_allgather_results",
+    "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
@@ -695,6 +695,12 @@ class HipBatchSolver:
         X = np.zeros((self.B, self.p.N + 1, self.p.nx)); U = np.zeros((self.B, self.p.N, self.p.nu))
         self._check(self.lib.cddp_hip_get_trajectory(self.h, _ptr(X), _ptr(U)))
         return X, U
+
+    def plan_head(self):
+        """(u_0, x_1) of every trajectory's current iterate: what an MPC loop reads back (cddp_hip_get_plan_head)."""
+        u0 = np.zeros((self.B, self.p.nu)); x1 = np.zeros((self.B, self.p.nx))
+        self._check(self.lib.cddp_hip_get_plan_head(self.h, _ptr(u0), _ptr(x1)))
+        return u0, x1
 
     def gains(self):
         K = np.zeros((self.B, self.p.N, self.p.nu, self.p.nx)); k = np.zeros((self.B, self.p.N, self.p.nu))

@@ -401,6 +401,10 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats);
 
 /* ---- getters (host buffers, batch-major) -------------------------------- */
 int cddp_hip_get_results(cddp_hip_handle *h, cddp_hip_result *results /* batch */);
+/* Head of the plan (round 4): u_0[batch][nu] and x_1[batch][nx] of every trajectory's current iterate -- what a receding-horizon
+ * caller applies / re-starts from (examples/ipddp_mpcc_rc.py:649-705 reads sol.control_trajectory[0]); one small gather + one
+ * copy instead of the whole (N + 1) x nx x batch trajectory.  Either pointer may be NULL. */
+int cddp_hip_get_plan_head(cddp_hip_handle *h, double *u0, double *x1);
 int cddp_hip_get_trajectory(cddp_hip_handle *h, double *X /* B*(N+1)*nx */, double *U /* B*N*nu */);
 /* feedback_gains K_u (B*N*nu*nx) and feed-forward k_u (B*N*nu); either may be NULL. */
 int cddp_hip_get_gains(cddp_hip_handle *h, double *K, double *k);
