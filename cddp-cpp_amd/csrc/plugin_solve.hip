@@ -360,6 +360,8 @@ void lg_merit_terms(const Ctx &c, const double *X, const double *U, double mu, d
   }
 }
 
+inline bool aborted(const cddp_hip_plugin *pl) { return pl->abort_flag && *pl->abort_flag != 0; }
+
 int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const double *U0, cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
   const cddp_hip_plugin *pl = c.pl; const cddp_hip_options &o = *c.o;
   const int nx = c.nx, nu = c.nu, m = c.m, N = c.N; const double dt = c.dt;
@@ -390,6 +392,9 @@ int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const do
       lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx), Fxx, Fuu, Fux;
   if (!o.use_ilqr) { Fxx.resize(B * N * nx * nx * nx); Fuu.resize(B * N * nx * nu * nu); Fux.resize(B * N * nx * nu * nx); }
   std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  // K_u_ of each trajectory's LAST backward pass (the reference's solver object stops sweeping a problem when it ends; the batch keeps
+  // sweeping the others): the slice is kept at every sweep the trajectory still takes part in
+  std::vector<double> Kfin(Kout ? B * N * nu * nx : 0, 0.0);
   std::vector<double> regv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
   std::vector<int32_t> okv(B);
   std::vector<double> tfx(nx * nx), tfu(nx * nu), g(std::max(m, 1)), Gx((size_t)std::max(m, 1) * nx), Gu((size_t)std::max(m, 1) * nu);
@@ -403,6 +408,7 @@ int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const do
     bool any = false;
     for (auto &t : T) any = any || !t.done;
     if (!any) break;
+    if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
     if (o.max_cpu_time > 0.0) {
       const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
       if (el_ms > o.max_cpu_time * 1000.0) { for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; } break; }
@@ -456,11 +462,13 @@ int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const do
     if (!o.use_ilqr) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_backward(sh, CDDP_HIP_STACKS_LOGDDP, c.o, regv.data(), nullptr, 1, okv.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    if (Kout) for (size_t b = 0; b < B; ++b) if (!T[b].done) std::copy(Kb.begin() + b * N * nu * nx, Kb.begin() + (b + 1) * N * nu * nx, Kfin.begin() + b * N * nu * nx);
     { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
 
     for (size_t b = 0; b < B; ++b) {
       LTraj &t = T[b];
       if (t.done) continue;
+      if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
       { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
         if (!okv[b] && nb > 1) --nb;
         t.n_bwd += nb; }
@@ -520,7 +528,7 @@ int logddp_solve(const Ctx &c, int device, int batch, const double *x0, const do
     }
   }
   for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
-  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  if (Kout) std::copy(Kfin.begin(), Kfin.end(), Kout);
   for (size_t b = 0; b < B; ++b) {   // CDDPSolution (+ populateSolverSpecificSolution :286-291)
     const LTraj &t = T[b];
     cddp_hip_result &r = results[b];
@@ -688,6 +696,9 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
       lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx), dfc(B * N * nx);
   std::vector<double> ys(B * N * m), ss(B * N * m), gs(B * N * m), Gxs(B * N * m * nx), Gus(B * N * m * nu);
   std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  // K_u_ of each trajectory's LAST backward pass (the reference's solver object stops sweeping a problem when it ends; the batch keeps
+  // sweeping the others): the slice is kept at every sweep the trajectory still takes part in
+  std::vector<double> Kfin(Kout ? B * N * nu * nx : 0, 0.0);
   std::vector<double> kyb(B * N * m), Kyb(B * N * m * nx), ksb(B * N * m), Ksb(B * N * m * nx), dXb(m > 0 ? B * (N + 1) * nx : 0);
   std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
   std::vector<int32_t> okv(B);
@@ -705,6 +716,7 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
     bool any = false;
     for (auto &t : T) any = any || !t.done;
     if (!any) break;
+    if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
     if (o.max_cpu_time > 0.0) {
       const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
       if (el_ms > o.max_cpu_time * 1000.0) { for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; } break; }
@@ -758,12 +770,14 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
     if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, ys.data(), ss.data(), gs.data(), Gxs.data(), Gus.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_backward(sh, m > 0 ? CDDP_HIP_STACKS_MSIPDDP_PATH : CDDP_HIP_STACKS_MSIPDDP, c.o, regv.data(), m > 0 ? muv.data() : nullptr, 1, okv.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    if (Kout) for (size_t b = 0; b < B; ++b) if (!T[b].done) std::copy(Kb.begin() + b * N * nu * nx, Kb.begin() + (b + 1) * N * nu * nx, Kfin.begin() + b * N * nu * nx);
     if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
 
     for (size_t b = 0; b < B; ++b) {
       MTraj &t = T[b];
       if (t.done) continue;
+      if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
       { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
         if (!okv[b] && nb > 1) --nb;
         t.n_bwd += nb; }
@@ -967,7 +981,7 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
     }
   }
   for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
-  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  if (Kout) std::copy(Kfin.begin(), Kfin.end(), Kout);
   for (size_t b = 0; b < B; ++b) {   // CDDPSolution + populateSolverSpecificSolution :406-413
     const MTraj &t = T[b];
     cddp_hip_result &r = results[b];
@@ -987,6 +1001,9 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
                                      int device, int batch, const double *x0, const double *U0, const double *X0,
                                      cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
   if (!pl || !opt || !x0 || !results) return pfail(-1, "null argument");
+  if (pl->abi_version != CDDP_HIP_ABI_VERSION || pl->options_bytes != (int)sizeof(cddp_hip_options))
+    return pfail(-2, "ABI mismatch: caller built against version %d with a %d-byte cddp_hip_options, library has version %d and %d bytes",
+                 pl->abi_version, pl->options_bytes, CDDP_HIP_ABI_VERSION, (int)sizeof(cddp_hip_options));
   if (solver != CDDP_HIP_SOLVER_CLDDP && solver != CDDP_HIP_SOLVER_IPDDP && solver != CDDP_HIP_SOLVER_LOGDDP && solver != CDDP_HIP_SOLVER_MSIPDDP)
     return pfail(-2, "UnknownSolver - No solver registered for id %d", solver);
   if (!pl->discrete_dynamics || !pl->jacobians) return pfail(-2, "Dynamical system must be set before solving.");
@@ -1024,6 +1041,9 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   if (m > 0) { gy.resize(B * N * m); gs = gy; gg = gy; gGx.resize(B * N * m * nx); gGu.resize(B * N * m * nu); }
   if (!o.use_ilqr) { Fxx.resize(B * N * nx * nx * nx); Fuu.resize(B * N * nx * nu * nu); Fux.resize(B * N * nx * nu * nx); }
   std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  // K_u_ of each trajectory's LAST backward pass (the reference's solver object stops sweeping a problem when it ends; the batch keeps
+  // sweeping the others): the slice is kept at every sweep the trajectory still takes part in
+  std::vector<double> Kfin(Kout ? B * N * nu * nx : 0, 0.0);
   std::vector<double> kyb, Kyb, ksb, Ksb, dXb;
   if (m > 0) { kyb.resize(B * N * m); ksb = kyb; Kyb.resize(B * N * m * nx); Ksb = Kyb; dXb.resize(B * (N + 1) * nx); }
   std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
@@ -1036,6 +1056,7 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
     bool any = false;
     for (auto &t : T) any = any || !t.done;
     if (!any) break;
+    if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
     if (o.max_cpu_time > 0.0) {   // cddp_solver_base.cpp:77-90 (whole elapsed milliseconds)
       const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
       if (el_ms > o.max_cpu_time * 1000.0) {
@@ -1088,12 +1109,14 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
     const int branch = !c.ipddp() ? CDDP_HIP_STACKS_CLDDP : (m > 0 ? CDDP_HIP_STACKS_IPDDP_PATH : CDDP_HIP_STACKS_IPDDP);
     { int rc = cddp_hip_stacks_backward(sh, branch, opt, regv.data(), m > 0 ? muv.data() : nullptr, 1, okv.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    if (Kout) for (size_t b = 0; b < B; ++b) if (!T[b].done) std::copy(Kb.begin() + b * N * nu * nx, Kb.begin() + (b + 1) * N * nu * nx, Kfin.begin() + b * N * nu * nx);
     if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
 
     for (size_t b = 0; b < B; ++b) {
       Traj &t = T[b];
       if (t.done) continue;
+      if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
       // sweeps the retry loop ran: replay the schedule from the regularisation it started with
       { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
         if (!okv[b] && nb > 1) --nb;   // the loop stops when the schedule reaches reg_max: no sweep is run there
@@ -1232,7 +1255,7 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }   // max_iterations <= 0
 
   // ---- CDDPSolution fields (cddp_solver_base.cpp:161-171, ipddp_solver.cpp:2090-2097); feedback gains = K_u_ of the last sweep
-  if (Kout) { int rc = cddp_hip_stacks_get_gains(sh, Kout, nullptr, nullptr, nullptr, nullptr); if (rc && o.max_iterations > 0) std::fill(Kout, Kout + B * N * nu * nx, 0.0); }
+  if (Kout) std::copy(Kfin.begin(), Kfin.end(), Kout);
   for (size_t b = 0; b < B; ++b) {
     const Traj &t = T[b];
     cddp_hip_result &r = results[b];

@@ -661,8 +661,11 @@ int download(cddp_hip_stack_handle *h, const double *src, double *dst, int T, in
 
 extern "C" {
 
-int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m, int horizon, cddp_hip_stack_handle **out) {
+int cddp_hip_stacks_create_abi(int abi_version, int options_bytes, int device, int batch, int nx, int nu, int m, int horizon, cddp_hip_stack_handle **out) {
   if (!out) return sfail(-1, "null argument");
+  if (abi_version != CDDP_HIP_ABI_VERSION || options_bytes != (int)sizeof(cddp_hip_options))
+    return sfail(-2, "ABI mismatch: caller built against version %d with a %d-byte cddp_hip_options, library has version %d and %d bytes",
+                 abi_version, options_bytes, CDDP_HIP_ABI_VERSION, (int)sizeof(cddp_hip_options));
   if (batch <= 0 || nx <= 0 || nu <= 0 || m < 0 || horizon <= 0) return sfail(-1, "bad dimensions batch=%d nx=%d nu=%d m=%d N=%d", batch, nx, nu, m, horizon);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(-20, "no HIP device available: the stack-fed sweep has no CPU fallback");

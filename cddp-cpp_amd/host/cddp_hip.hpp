@@ -839,6 +839,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     if (ctx.hasTerminalConstraints()) throw std::runtime_error("HipBatchSolver: terminal constraints are not supported on host plug-in problems");
     PluginCtx pc; pc.sys = &ctx.getSystem(); pc.obj = &ctx.getObjective(); pc.nx = nx_; pc.nu = nu_; pc.m = 0;
     cddp_hip_plugin pl; std::memset(&pl, 0, sizeof(pl));
+    pl.abi_version = CDDP_HIP_ABI_VERSION; pl.options_bytes = (int)sizeof(cddp_hip_options);
     pl.user = &pc; pl.nx = nx_; pl.nu = nu_;
     const ControlConstraint *box = nullptr;
     if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP || kind_ == CDDP_HIP_SOLVER_MSIPDDP) {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HIP_LIB_PATH = os.environ.get("CDDP_HIP_LIB") or os.path.join(_HERE, "lib", "libcddp_hip.so")   # override: kernel experiments
 
-ABI_VERSION = 4          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
+ABI_VERSION = 5          # CDDP_HIP_ABI_VERSION of include/cddp_hip.h
 MAX_MODEL_PARAMS = 24
 NAME_LEN = 48
 
@@ -592,7 +592,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
-    "cddp_hip_backward_stacks", "cddp_hip_stacks_create", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
+    "cddp_hip_backward_stacks", "cddp_hip_stacks_create_abi", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
     "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
@@ -790,6 +790,7 @@ _F_CHS = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, _dp)
 
 class PluginStruct(C.Structure):
     _fields_ = [
+        ("abi_version", C.c_int32), ("options_bytes", C.c_int32), ("abort_flag", C.POINTER(C.c_int32)),
         ("user", C.c_void_p), ("nx", C.c_int32), ("nu", C.c_int32), ("n_constraints", C.c_int32),
         ("constraint_dims", C.c_int32 * PLUGIN_MAX_CONSTRAINTS),
         ("discrete_dynamics", _F_DYN), ("jacobians", _F_JAC), ("hessians", _F_HES),
@@ -820,6 +821,8 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     def vec(ptr, n):
         return np.ctypeslib.as_array(ptr, shape=(n,))
 
+    abort = C.c_int32(0)
+
     def guard(fn, default=None):
         def w(*a):
             if err:
@@ -828,6 +831,7 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
                 return fn(*a)
             except BaseException as e:   # noqa: B902 -- re-raised by the caller thread after the C call returns
                 err.append(e)
+                abort.value = 1      # cddp_hip_plugin::abort_flag: the C solve returns at its next check instead of iterating on stale data
                 return default
         return w
 
@@ -887,6 +891,7 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     lo = _arr(control_lower) if control_lower is not None else None
     up = _arr(control_upper) if control_upper is not None else None
     ps.control_lower, ps.control_upper = _ptr(lo), _ptr(up)
+    ps.abi_version = ABI_VERSION; ps.options_bytes = C.sizeof(Options); ps.abort_flag = C.pointer(abort)
     res = np.zeros(B, dtype=RESULT_DTYPE)
     X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); K = np.zeros((B, N, nu, nx))
     rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(solver), N, C.c_double(dt), C.byref(options), int(device), B, _ptr(x0), _ptr(U0), _ptr(X0),
@@ -912,7 +917,7 @@ class HipStackSolver:
         self.B, self.nx, self.nu, self.m, self.N = batch, nx, nu, m, horizon
         self.h = C.c_void_p()
         self.lib.cddp_hip_stacks_last_kernel_ms.restype = C.c_double
-        self._check(self.lib.cddp_hip_stacks_create(device, batch, nx, nu, m, horizon, C.byref(self.h)))
+        self._check(self.lib.cddp_hip_stacks_create_abi(ABI_VERSION, C.sizeof(Options), device, batch, nx, nu, m, horizon, C.byref(self.h)))
 
     def _check(self, rc):
         if rc != 0:

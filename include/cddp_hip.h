@@ -33,7 +33,7 @@ extern "C" {
  * A host built against version 1 is refused by cddp_hip_create instead of being read at shifted offsets.
  * 3: cddp_hip_options gained the LogDDP barrier fields, cddp_hip_plugin gained constraint_hessians.
  * 4: cddp_hip_options gained the MSIPDDP multi-shooting fields. */
-#define CDDP_HIP_ABI_VERSION 4
+#define CDDP_HIP_ABI_VERSION 5
 #define CDDP_HIP_MAX_MODEL_PARAMS 24
 #define CDDP_HIP_NAME_LEN 48
 #define CDDP_HIP_MAX_ALPHAS 32
@@ -488,8 +488,13 @@ enum cddp_hip_stacks_branch {
   CDDP_HIP_STACKS_LOGDDP = 3      /* logddp_solver.cpp:470-575: the caller folds the relaxed log barrier's gradients / Hessians (barrier.hpp:95-262)
                                      into lx, lu, lxx, luu, lux; handle with m = 0                     */
 };
-int cddp_hip_stacks_create(int device, int batch, int nx, int nu, int m /* total path dual dim, 0 = none */, int horizon,
-                           cddp_hip_stack_handle **out);
+/* ABI 5: cddp_hip_stacks_backward copies a cddp_hip_options from a caller pointer, so the handle is created against a stated ABI
+ * version and options size; C / C++ callers use the macro below, which passes the values of the header they compile against;
+ * other bindings pass their own.  A mismatch is refused. */
+int cddp_hip_stacks_create_abi(int abi_version, int options_bytes, int device, int batch, int nx, int nu,
+                               int m /* total path dual dim, 0 = none */, int horizon, cddp_hip_stack_handle **out);
+#define cddp_hip_stacks_create(device, batch, nx, nu, m, horizon, out) \
+  cddp_hip_stacks_create_abi(CDDP_HIP_ABI_VERSION, (int)sizeof(cddp_hip_options), (device), (batch), (nx), (nu), (m), (horizon), (out))
 int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h);
 /* Upload the dynamics / cost stacks of the current iterate.  The first call must supply all of them; later calls may
  * pass NULL for stacks that did not change (e.g. constant cost Hessians). */
@@ -584,6 +589,13 @@ int cddp_hip_model_eval(int model /* cddp_hip_model */, int integrator /* cddp_h
 
 #define CDDP_HIP_PLUGIN_MAX_CONSTRAINTS 8
 typedef struct cddp_hip_plugin {
+  /* ABI 5: the entry point copies a cddp_hip_options from a caller pointer, so the caller states which layout it was built against
+   * (cddp_hip_create has checked cddp_hip_problem::abi_version since round 2; this struct and the stack handles did not).  Set
+   * abi_version = CDDP_HIP_ABI_VERSION and options_bytes = sizeof(cddp_hip_options); a mismatch is refused. */
+  int32_t abi_version, options_bytes;
+  /* Optional (may be NULL): a word the caller sets non-zero to stop the solve -- e.g. a binding whose callback raised an exception.
+   * Checked once per outer iteration and after every batch of callbacks; cddp_hip_plugin_solve then returns -50. */
+  const volatile int32_t *abort_flag;
   void *user;
   int32_t nx, nu;
   int32_t n_constraints;

@@ -21,6 +21,7 @@ def lib(api):
 def declared_symbols():
     txt = open(os.path.join(REPO, "include", "cddp_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"^#define[^\n]*(\\\n[^\n]*)*", "", txt, flags=re.M)   # function-like macros (cddp_hip_stacks_create -> _abi) are not symbols
     return sorted(set(re.findall(r"\b(cddp_hip_[a-z_0-9]+)\s*\(", txt)))
 
 
@@ -33,7 +34,7 @@ def test_library_exports_every_declared_symbol(api, lib):
 
 
 def test_abi_version_and_status_strings(api, lib):
-    assert lib.cddp_hip_abi_version() == api.ABI_VERSION == 4
+    assert lib.cddp_hip_abi_version() == api.ABI_VERSION == 5
     want = ["Running", "OptimalSolutionFound", "AcceptableSolutionFound", "MaxIterationsReached",
             "RegularizationLimitReached_NotConverged", "MaxCpuTimeReached"]
     for i, w in enumerate(want):
@@ -95,3 +96,20 @@ def test_product_sources_do_not_reference_oracle():
                 continue
             txt = open(os.path.join(dp, fn), errors="ignore").read()
             assert "oracle/" not in txt and "cddp_oracle" not in txt, os.path.join(dp, fn)
+
+
+def test_plugin_and_stack_entry_points_refuse_another_abi(api, lib):
+    """cddp_hip_plugin_solve and the stack handles copy a cddp_hip_options from a caller pointer; since ABI 5 the caller
+    states the version and the struct size it was built against and a mismatch is refused BEFORE anything is read (no GPU needed)."""
+    import ctypes as C
+    h = C.c_void_p()
+    for abi, nbytes in ((api.ABI_VERSION - 1, C.sizeof(api.Options)), (api.ABI_VERSION, C.sizeof(api.Options) - 8)):
+        rc = lib.cddp_hip_stacks_create_abi(abi, nbytes, 0, 4, 2, 1, 0, 10, C.byref(h))
+        assert rc == -2 and b"ABI mismatch" in lib.cddp_hip_last_error()
+    ps = api.PluginStruct()
+    ps.abi_version = api.ABI_VERSION - 1; ps.options_bytes = C.sizeof(api.Options)
+    o = api.default_options()
+    x0 = (C.c_double * 2)(0.0, 0.0)
+    res = (C.c_char * 4096)()
+    rc = lib.cddp_hip_plugin_solve(C.byref(ps), api.SOLVER_IPDDP, 10, C.c_double(0.1), C.byref(o), 0, 1, x0, None, None, res, None, None, None)
+    assert rc == -2 and b"ABI mismatch" in lib.cddp_hip_last_error()
