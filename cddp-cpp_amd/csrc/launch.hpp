@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "kernels_te.hpp"
+#include "kernels_pcm.hpp"
 #include "kernels_elem.hpp"
 #include "kernels_mfma.hpp"
 
@@ -62,6 +63,18 @@ struct Launcher {
       else if constexpr (kTeCoop) return d.te_cst ? 1 : 0;
       else return 0;
     }
+  }
+  // Step sizes per rollout workgroup of the small path-constrained layouts: 1 = the two-wave form (default), CDDP_HIP_K4_NA = 2 | 3 =
+  // NA producers + ONE consumer per (tile, group of NA step sizes) (kernels_pcm.hpp).  Built to cut the wavefront count of the
+  // rollout launch (1408 -> 1056 / 939 at BASELINE config[1]) after round 3 traced its length to SIMD sharing; bitwise equal
+  // (tests/test_gpu_parity.py::test_multi_alpha_rollout_groups_agree_bitwise) and MEASURED SLOWER on MI355X
+  // (profiles/r04_k4_groups.md): C2 22.6 -> 25.5 / 30.3 ms of rollout class per solve with the trials of a group served one after
+  // the other, 30.1 / 28.7 with their per-step work in one straight-line block; pendulum 3.4 -> 5.8 / 6.0; C3 33 -> 55 / 80.  The
+  // consumer's per-trial work (~500 instructions per step: two logarithms, the slack / dual trials, cost, residual terms) is as long
+  // as the producer's RK4 step (~650), so one consumer behind two or three producers is the chain the launch waits for.  Opt-in.
+  static int k4_group() {
+    if (const char *e = std::getenv("CDDP_HIP_K4_NA")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) return v; }
+    return 1;
   }
   static void derivs(const DevBuf &d0, int force, hipStream_t s) {
     DevBuf d = d0;
@@ -164,9 +177,15 @@ struct Launcher {
       hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
     {
-      if constexpr (kLean)   // producer / consumer wave pair per (tile, alpha)
+      if constexpr (kLean) {
+        if constexpr (PcmTraits<Model, Cons>::kOk) {   // small layouts: NA producers + one consumer per (tile, group of NA step sizes), kernels_pcm.hpp
+          const int ng = k4_group();
+          if (ng == 3) { hipLaunchKernelGGL((k_forward_ipddp_pcm<Model, Cons, 3>), dim3((d.B + 63) / 64, (na + 2) / 3), dim3(256), 0, s, d, d.P, d.xref_traj, a0, na, phase_req, force); return; }
+          if (ng == 2) { hipLaunchKernelGGL((k_forward_ipddp_pcm<Model, Cons, 2>), dim3((d.B + 63) / 64, (na + 1) / 2), dim3(192), 0, s, d, d.P, d.xref_traj, a0, na, phase_req, force); return; }
+        }
+        // producer / consumer wave pair per (tile, alpha)
         hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
-      else {
+      } else {
         if constexpr (kTeCoop && Cons::M > 0) {   // same rollout after the cooperative terminal-equality sweep
           if (d.te_cst && !(lane_sweep_requested() || d.ddp)) {
             hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons, true>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);

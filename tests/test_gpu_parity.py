@@ -308,6 +308,32 @@ def test_full_solve_parity(api, oracle_built, case):
     hs.close()
 
 
+@pytest.mark.parametrize("case", ["cartpole_ipddp_box", "unicycle_ipddp_box_ball", "pendulum_ipddp_box"])
+def test_multi_alpha_rollout_groups_agree_bitwise(api, case, monkeypatch):
+    """kernels_pcm.hpp (opt-in, CDDP_HIP_K4_NA = 2 | 3): NA producer waves + one consumer wave per (tile, group of NA step sizes)
+    must leave every iterate, gain and counter exactly as the two-wave rollout does -- incl. ladders whose last group is short
+    (11 step sizes: groups of 3 + 3 + 3 + 2 and 2 x 5 + 1) and the two-stage ladder."""
+    p = make(api, case)
+    B = 96
+    x0 = api.batch_x0(p, B, 20261103, spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); S, Y, G = hs.duals(); hs.close()
+        return [r[f].copy() for f in r.dtype.names] + [X, U, K, k, S, Y, G, np.array([st.sweeps, st.rollouts, st.rollout_steps])]
+
+    monkeypatch.delenv("CDDP_HIP_K4_NA", raising=False)
+    ref = run()
+    for na, stages in (("2", None), ("3", None), ("3", "2")):
+        monkeypatch.setenv("CDDP_HIP_K4_NA", na)
+        if stages:
+            monkeypatch.setenv("CDDP_HIP_LS_STAGES", stages)
+        got = run()
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), (case, na, stages)
+
+
 @pytest.mark.parametrize("case", ["cartpole_ipddp_box", "unicycle_ipddp_box_ball", "cartpole_clddp_box"])
 def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
     """The speculative single-launch ladder and the two-stage ladder (alpha_0, then the rest for the trajectories
