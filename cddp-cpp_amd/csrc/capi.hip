@@ -128,7 +128,8 @@ int pool_put(ProblemDev &P, int &top, const double *src, int n) {
 // plants with device-side Hessian tensors (dev_models.hpp: Model::kHasHess) -- full DDP (options.use_ilqr = 0) needs them
 bool model_has_hessians(int model) {
   return model == CDDP_HIP_MODEL_PENDULUM || model == CDDP_HIP_MODEL_CARTPOLE || model == CDDP_HIP_MODEL_UNICYCLE || model == CDDP_HIP_MODEL_LTI ||
-         model == CDDP_HIP_MODEL_BICYCLE || model == CDDP_HIP_MODEL_CAR || model == CDDP_HIP_MODEL_MANIPULATOR || model == CDDP_HIP_MODEL_HCW;
+         model == CDDP_HIP_MODEL_BICYCLE || model == CDDP_HIP_MODEL_CAR || model == CDDP_HIP_MODEL_MANIPULATOR || model == CDDP_HIP_MODEL_HCW ||
+         model == CDDP_HIP_MODEL_QUADROTOR || model == CDDP_HIP_MODEL_QUADROTOR_EULER12 || model == CDDP_HIP_MODEL_MANIPULATOR7;   // round 4: blocked second-order duals
 }
 
 // cddp_hip_problem -> ProblemDev (constraints sorted by name as std::map iterates)
@@ -143,7 +144,7 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (!(p->options.reg_update_factor > 1.0) || !(p->options.reg_max_value > 0.0))
     return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", p->options.reg_update_factor, p->options.reg_max_value);
   if (!p->options.use_ilqr && !model_has_hessians(p->model))
-    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: on the device for pendulum, cart-pole, unicycle, LTI, bicycle, car, HCW and the 3-DOF manipulator (model id %d; the quadrotor's are host-only: plug-in solve)", p->model);
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors, which model id %d does not have", p->model);
   P.solver = p->solver; P.model = p->model; P.integrator = p->integrator;
   P.nx = p->nx; P.nu = p->nu; P.N = p->horizon; P.dt = p->dt; P.opt = p->options;
   P.ls_rule = p->options.enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
@@ -552,7 +553,7 @@ static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   if (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0))
     return fail(-2, "regularization.update_factor must be > 1 and max_value > 0 (got %g, %g)", opt->reg_update_factor, opt->reg_max_value);
   if (!opt->use_ilqr && !model_has_hessians(h->P.model))
-    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors: on the device for pendulum, cart-pole, unicycle, LTI, bicycle, car, HCW and the 3-DOF manipulator (model id %d; the quadrotor's are host-only: plug-in solve)", h->P.model);
+    return fail(-3, "use_ilqr=false needs the plant's Hessian tensors, which model id %d does not have", h->P.model);
   HIPCHK(hipSetDevice(h->device));
   double al[CDDP_HIP_MAX_ALPHAS];
   const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);

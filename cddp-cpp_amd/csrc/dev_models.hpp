@@ -127,6 +127,8 @@ template <int NP> DEV Dual2N<NP> dsqrt(const Dual2N<NP> &a) { const double r = s
 template <int NP> DEV Dual2N<NP> dasin(const Dual2N<NP> &a) { const double w = 1.0 - a.v * a.v, r = sqrt(w); return d2_unary<NP>(a, plant_asin(a.v), 1.0 / r, a.v / (w * r)); }
 template <int NP> DEV Dual2N<NP> dtan(const Dual2N<NP> &a) { const double t = plant_tan(a.v), g = 1.0 + t * t; return d2_unary<NP>(a, t, g, 2.0 * t * g); }
 template <int NP> DEV double dval(const Dual2N<NP> &a) { return a.v; }
+template <int NP> DEV Dual2N<NP> lift_sin(const Dual2N<NP> &a, double s, double c) { return d2_unary<NP>(a, s, c, -s); }   // trig_n on second-order duals
+template <int NP> DEV Dual2N<NP> lift_cos(const Dual2N<NP> &a, double s, double c) { return d2_unary<NP>(a, c, -s, -c); }
 
 // Hessian tensors by second-order duals of a templated functor F::template eval<S>(p, x, u, out): out_i's Hessian w.r.t. z = [x, u],
 // split into the solver's three blocks (f_xx[i] nx x nx, f_uu[i] nu x nu, f_ux[i] nu x nx), each entry divided by `div`
@@ -144,6 +146,61 @@ DEV void ad_hessian(const double *p, const double *x, const double *u, double di
     for (int a = 0; a < NU; ++a) for (int b = 0; b < NX; ++b) Fux[(i * NU + a) * NX + b] = xd[i].h[(NX + a) * NP + b] / div;
   }
 }
+
+// The same second-order terms WITHOUT materialising the tensors, for plants whose full dual2nd frame does not fit a GPU lane
+// (quadrotor: 17 seeds = 307 doubles per dual number, a 180-KB private frame; 7-joint arm: 21 seeds).  The Hessian of every output
+// is assembled from evaluations with 2 * BS seeds at a time: the seeded variables z = [x, u] are cut into blocks of BS, and for every
+// unordered pair of blocks (I, J) the functor is evaluated once with the variables of I in seed slots 0 .. BS-1 and those of J in
+// slots BS .. 2 BS - 1 (73 doubles per dual number at BS = 4).  Second-order forward mode is component-wise in the seed pair --
+// entry (a, b) of a product or a unary lift reads only the operands' value, d[a], d[b] and h[a][b] (operator* / d2_unary above) --
+// so every entry equals, bit for bit, the entry the full Dual2N<NX + NU> evaluation (ad_hessian, the host build) produces.
+// Accumulated directly into the solver's sums in its own order (for i: Q[e] += w[i] * (dt * F[i][e]), i ascending per entry):
+//   Qxx[a * NX + b] += w[i] (dt f_i,xx[a][b] / div),  Qux[a * NX + b] += w[i] (dt f_i,ux[a][b] / div),  Quu likewise.
+template <class F, int NX, int NU, int BS>
+DEV_NOINLINE void ad_tensor_terms_blocked(const double *p, const double *x, const double *u, const double *w, double dt, double div,
+                                          double *Qxx, double *Qux, double *Quu) {
+  constexpr int NP = NX + NU, NBK = (NP + BS - 1) / BS, NS = 2 * BS;
+  typedef Dual2N<NS> D;
+  for (int I = 0; I < NBK; ++I) {
+    for (int J = I; J < NBK; ++J) {
+      D xs[NX], us[NU], xd[NX];
+      for (int v = 0; v < NP; ++v) {
+        D z(v < NX ? x[v] : u[v - NX]);
+        const int blk = v / BS, off = v - blk * BS;
+        if (blk == I) z.d[off] = 1.0;
+        else if (blk == J) z.d[BS + off] = 1.0;
+        if (v < NX) xs[v] = z; else us[v - NX] = z;
+      }
+      F::template eval<D>(p, xs, us, xd);
+      // entries (row variable va, column variable vb) this pair owns: va in I, vb in J, and (I != J) va in J, vb in I
+      for (int pass = 0; pass < (I == J ? 1 : 2); ++pass) {
+        const int RB = pass == 0 ? I : J, CB = pass == 0 ? J : I;
+        for (int ra = 0; ra < BS; ++ra) {
+          const int va = RB * BS + ra;
+          if (va >= NP) break;
+          const int sa = (RB == I) ? ra : BS + ra;
+          for (int cb = 0; cb < BS; ++cb) {
+            const int vb = CB * BS + cb;
+            if (vb >= NP) break;
+            const int sb = (CB == I) ? cb : BS + cb;
+            double *dst;
+            if (va < NX && vb < NX) dst = Qxx + va * NX + vb;
+            else if (va >= NX && vb >= NX) dst = Quu + (va - NX) * NU + (vb - NX);
+            else if (va >= NX && vb < NX) dst = Qux + (va - NX) * NX + vb;
+            else continue;   // d2 f / dx du: the solver reads the (u, x) block only
+            double acc = *dst;
+            for (int i = 0; i < NX; ++i) acc = acc + w[i] * (dt * (xd[i].h[sa * NS + sb] / div));
+            *dst = acc;
+          }
+        }
+      }
+    }
+  }
+}
+
+// does the plant take its second-order terms from the blocked evaluation (a `HessDyn` functor typedef, device build only)?
+template <class M, class = void> struct HessBlocked { static constexpr bool value = false; };
+template <class M> struct HessBlocked<M, decltype((void)sizeof(typename M::HessDyn))> { static constexpr bool value = true; };
 
 // Jacobian by forward-mode duals of a templated dynamics functor F::template eval<S>(p, x, u, xd)
 template <class F, int NX, int NU>
@@ -531,8 +588,14 @@ struct QuadrotorModel {
   static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) {
     ad_hessian<QuadrotorDyn, NX, NU>(p, x, u, 1.0, Fxx, Fuu, Fux);
   }
+  static constexpr bool kHessBlocked = false;
 #else
   static constexpr bool kHasHess = false;
+  // device (round 4): the tensors are never materialised -- their contraction with the value gradient is assembled from 8-seed
+  // evaluations (ad_tensor_terms_blocked, bitwise the full 17-seed evaluation of the host build)
+  static constexpr bool kHessBlocked = true;
+  typedef QuadrotorDyn HessDyn;
+  static constexpr double kHessDiv = 1.0;
 #endif
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { QuadrotorDyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
@@ -571,7 +634,18 @@ struct Quad12Dyn {
 struct Quad12Model {
   static constexpr int ID = CDDP_HIP_MODEL_QUADROTOR_EULER12, NX = 12, NU = 4;
   static constexpr bool kDiscrete = false;
-  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
+  // full DDP (round 4): second-order duals through the plant's own expression, as the reference's base class does for a plant
+  // without overrides (dynamical_system.cpp:137-217); host build: the whole tensors, device: blocked contraction
+#ifdef CDDP_HOST_MODELS
+  static constexpr bool kHasHess = true;
+  static constexpr bool kHessBlocked = false;
+  static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) { ad_hessian<Quad12Dyn, NX, NU>(p, x, u, 1.0, Fxx, Fuu, Fux); }
+#else
+  static constexpr bool kHasHess = false;
+  static constexpr bool kHessBlocked = true;
+  typedef Quad12Dyn HessDyn;
+  static constexpr double kHessDiv = 1.0;
+#endif
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { Quad12Dyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<Quad12Dyn, NX, NU>(p, x, u, Fx, Fu);
@@ -689,7 +763,16 @@ struct Manip7Dyn {
 struct Manip7Model {
   static constexpr int ID = CDDP_HIP_MODEL_MANIPULATOR7, NX = 14, NU = 7;
   static constexpr bool kDiscrete = false;
-  static constexpr bool kHasHess = false;   // no restated Hessian tensors: options.use_ilqr = 0 is refused for this plant
+#ifdef CDDP_HOST_MODELS
+  static constexpr bool kHasHess = true;
+  static constexpr bool kHessBlocked = false;
+  static void hess(const double *p, const double *x, const double *u, double *Fxx, double *Fuu, double *Fux) { ad_hessian<Manip7Dyn, NX, NU>(p, x, u, 1.0, Fxx, Fuu, Fux); }
+#else
+  static constexpr bool kHasHess = false;
+  static constexpr bool kHessBlocked = true;   // see Quad12Model
+  typedef Manip7Dyn HessDyn;
+  static constexpr double kHessDiv = 1.0;
+#endif
   DEV static void f(const double *p, const double *x, const double *u, double *xd) { Manip7Dyn::eval<double>(p, x, u, xd); }
   DEV static void jac(const double *p, const double *x, const double *u, double *Fx, double *Fu) {
     ad_jacobian<Manip7Dyn, NX, NU>(p, x, u, Fx, Fu);

@@ -149,6 +149,8 @@ DEV void ddp_tensor_terms(const ProblemDev *P, const double *x, const double *u,
       for (int e = 0; e < NU * NX; ++e) Qux[e] = Qux[e] + w[i] * (dt * Fux[i * NU * NX + e]);
       for (int e = 0; e < NU * NU; ++e) Quu[e] = Quu[e] + w[i] * (dt * Fuu[i * NU * NU + e]);
     }
+  } else if constexpr (HessBlocked<Model>::value) {   // same sums, same order per entry; the tensors are never stored (dev_models.hpp)
+    ad_tensor_terms_blocked<typename Model::HessDyn, NX, NU, 4>(P->mp, x, u, w, P->dt, Model::kHessDiv, Qxx, Qux, Quu);
   }
 }
 
@@ -516,6 +518,20 @@ DEV bool te_backward(const DevBuf &d, int b, const double *Xc, const double *Uc,
           for (int a = 0; a < NU; ++a) for (int c = 0; c < NX; ++c) Mm[c * NU + a] = Mm[c * NU + a] + lam[i] * (dt * Fux[i * NU * NX + a * NX + c]);
           for (int e = 0; e < NU * NU; ++e) R[e] = R[e] + lam[i] * (dt * Fuu[i * NU * NU + e]);
         }
+        double Qs[NX * NX], Rs[NU * NU];
+        for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Qs[i * NX + c] = 0.5 * (Q[i * NX + c] + Q[c * NX + i]);
+        for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) Rs[i * NU + c] = 0.5 * (R[i * NU + c] + R[c * NU + i]);
+        for (int i = 0; i < NX * NX; ++i) Q[i] = Qs[i];
+        for (int i = 0; i < NU * NU; ++i) R[i] = Rs[i];
+      } else if constexpr (HessBlocked<Model>::value) {   // blocked second-order duals (dev_models.hpp): M accumulates from zero, transposed afterwards
+        double lam[NX], Mt[NU * NX];
+        ld<NX>(d.Lam + (size_t)d.cur[b] * d.planeX + GI(t + 1, NX, 0), kLS, lam);
+        bool fin = true;
+        for (int i = 0; i < NX; ++i) fin = fin && dfinite(lam[i]);
+        if (!fin) for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+        for (int i = 0; i < NU * NX; ++i) Mt[i] = 0.0;
+        ad_tensor_terms_blocked<typename Model::HessDyn, NX, NU, 4>(P->mp, x, u, lam, P->dt, Model::kHessDiv, Q, Mt, R);
+        for (int a = 0; a < NU; ++a) for (int c = 0; c < NX; ++c) Mm[c * NU + a] = Mt[a * NX + c];
         double Qs[NX * NX], Rs[NU * NU];
         for (int i = 0; i < NX; ++i) for (int c = 0; c < NX; ++c) Qs[i * NX + c] = 0.5 * (Q[i * NX + c] + Q[c * NX + i]);
         for (int i = 0; i < NU; ++i) for (int c = 0; c < NU; ++c) Rs[i * NU + c] = 0.5 * (R[i * NU + c] + R[c * NU + i]);

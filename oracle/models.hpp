@@ -84,7 +84,7 @@ inline Dual asin(const Dual &a) { Dual r; r.v = oasin(a.v); double g = 1.0 / std
 // Second-order forward mode (autodiff::dual2nd of the reference, dynamical_system.cpp:137-217, restated): value, gradient and
 // Hessian w.r.t. up to kD2 seeded variables z = [x, u].  Only used for the plants whose Hessians the reference takes from
 // autodiff (CartPole).
-constexpr int kD2 = 17;   // quadrotor: 13 + 4 seeds
+constexpr int kD2 = 21;   // quadrotor: 13 + 4 seeds; synthetic 7-joint arm: 14 + 7
 struct Dual2 {
   double v = 0.0, d[kD2], h[kD2][kD2];
   static int &n() { static thread_local int k = 0; return k; }   // active seeds (set by Model::hessians)
@@ -486,6 +486,12 @@ struct Model {
         // (ipddp_solver.cpp:1070-1082): an Eigen size mismatch, i.e. use_ilqr = false is not defined behaviour for this plant there.
         // Restated with the block the solver's formula needs (d2 f_i / du dx, nu x nx).
         ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { quadrotor_f<Dual2>(xs, us, xd); }, x, u, Fxx, Fuu, Fux);
+        return true;
+      case CDDP_HIP_MODEL_QUADROTOR_EULER12:  // synthetic plants: no overrides, i.e. the base class's dual2nd default on the plant's own expression
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { quad12_f<Dual2>(xs, us, xd); }, x, u, Fxx, Fuu, Fux);
+        return true;
+      case CDDP_HIP_MODEL_MANIPULATOR7:
+        ad_hess([&](const Dual2 *xs, const Dual2 *us, Dual2 *xd) { manip7_f<Dual2>(xs, us, xd); }, x, u, Fxx, Fuu, Fux);
         return true;
       default: return false;
     }

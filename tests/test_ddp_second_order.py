@@ -209,8 +209,49 @@ def test_hip_second_order_full_solve(api, oracle_built, name):
 
 
 @pytest.mark.gpu
-def test_second_order_mode_is_refused_without_hessians(api):
-    p = api.quadrotor_problem(api.SOLVER_IPDDP, 20, True)
-    p.options.use_ilqr = 0
-    with pytest.raises(api.HipError, match="Hessian"):
-        api.HipBatchSolver(p, 4)
+def test_second_order_mode_is_accepted_for_every_builtin_plant(api):
+    """Rounds 2-3 refused use_ilqr = 0 for the quadrotor and the two synthetic plants (no device Hessians); round 4 lifted that."""
+    for p in (api.quadrotor_problem(api.SOLVER_IPDDP, 20, True), api.quadrotor12_problem(api.SOLVER_IPDDP, 20, True), api.manipulator7_problem(api.SOLVER_IPDDP, 10)):
+        p.options.use_ilqr = 0
+        hs = api.HipBatchSolver(p, 4)
+        hs.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: full DDP on the large plants (VERDICT r03 missing #3).  The quadrotor's dual2nd frame (17 seeds, 307 doubles per dual
+# number) does not fit a GPU lane; the device assembles the second-order terms from 8-seed evaluations, one per pair of 4-variable
+# blocks (dev_models.hpp::ad_tensor_terms_blocked) -- component-wise the same arithmetic as the full evaluation.  Also the two
+# synthetic plants of BASELINE configs [3] / [4] (no Hessian overrides: the base class's dual2nd default on the plant's expression).
+# ------------------------------------------------------------------------------------------------------------------
+BIG_DDP_CASES = ["quadrotor_ipddp_box", "quad12_ipddp_box", "manip7_ipddp_box", "manip7_term_eq_parallel_ls"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BIG_DDP_CASES)
+def test_hip_second_order_large_plants_step_level(api, oracle_built, name):
+    p = _problem(api, name)
+    B = 3
+    x0 = api.batch_x0(p, B, 20261104, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    X0 = np.tile(p.X0_single, (B, 1, 1)) if hasattr(p, "X0_single") else None
+    if X0 is not None:
+        X0[:, 0, :] = x0
+    hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0, X0); hs.initialize()
+    ok = hs.backward()
+    K, k = hs.gains(); Vx, Vxx = hs.value(); dV, reg = hs.backward_scalars()
+    hs.close()
+    p1 = TERM_CASES[name](api) if name in TERM_CASES else make(api, name)     # Gauss-Newton twin of the same problem
+    worst = 0.0; moved = 0.0
+    for b in range(B):
+        o = api.Oracle(p); o.set_initial(x0[b], None if U0 is None else U0[b], None if X0 is None else X0[b]); o.initialize()
+        oko = o.backward(retry=True)
+        Ko, ko = o.gains(); Vxo, Vxxo = o.value(); dVo, rego = o.backward_scalars()
+        assert oko == ok[b] and reg[b] == rego, (name, b, reg[b], rego)
+        err = max(rel_err(g, r) for g, r in zip((K[b], k[b], Vx[b], Vxx[b], dV[b]), (Ko, ko, Vxo, Vxxo, dVo)))
+        worst = max(worst, err)
+        assert err < TOL, (name, b, err)
+        o1 = api.Oracle(p1); o1.set_initial(x0[b], None if U0 is None else U0[b], None if X0 is None else X0[b]); o1.initialize(); o1.backward(retry=True)
+        moved = max(moved, float(np.max(np.abs(o1.gains()[1] - ko))))
+    if name not in TERM_CASES:   # (terminal-equality branch: the costate iterate is the value-gradient proxy, zero at the first sweep, :1160-1178)
+        assert moved > 1e-8, "the second-order terms changed nothing (test_ipddp_solver.cpp:1512-1578 asks for > 1e-8 in k)"
+    print("%s full DDP: worst HIP-vs-oracle relative error %.2e, k moves by %.2e against Gauss-Newton" % (name, worst, moved))

@@ -14,9 +14,9 @@ def _cases(api):
         ("cartpole", api.cartpole_problem(api.SOLVER_IPDDP, True), True),
         ("unicycle", api.unicycle_problem(api.SOLVER_IPDDP, 20, True), True),
         ("quadrotor", api.quadrotor_problem(api.SOLVER_IPDDP, 10, True), True),     # host-only Hessians (17-seed second-order duals)
-        ("quad12", api.quadrotor12_problem(api.SOLVER_IPDDP, 10, True), False),
+        ("quad12", api.quadrotor12_problem(api.SOLVER_IPDDP, 10, True), True),       # round 4: dual2nd default on the plant's expression
         ("manipulator", api.manipulator_problem(api.SOLVER_IPDDP, 10), True),      # closed-form cross Hessian vs the oracle's dual2nd LU
-        ("manip7", api.manipulator7_problem(api.SOLVER_IPDDP, 10), False),
+        ("manip7", api.manipulator7_problem(api.SOLVER_IPDDP, 10), True),
         ("bicycle", api.bicycle_problem(api.SOLVER_IPDDP, 10), True),
         ("bicycle_rk4", api.bicycle_problem(api.SOLVER_IPDDP, 10, integrator=api.RK4), True),
         ("car", api.car_problem(api.SOLVER_IPDDP, 10), True),
@@ -66,8 +66,6 @@ def test_host_model_eval_errors(api):
         api.model_eval(p.c.model, p.c.integrator, p.dt, mp, 3, 1, np.zeros(3), np.zeros(1))
     with pytest.raises(api.HipError, match="no host evaluation"):
         api.model_eval(api.MODEL_LTI, p.c.integrator, p.dt, mp, 2, 1, np.zeros(2), np.zeros(1))
-    q = api.manipulator7_problem(api.SOLVER_IPDDP, 10)
-    with pytest.raises(api.HipError, match="no Hessian tensors"):
-        api.model_eval(q.c.model, q.c.integrator, q.dt, np.array(list(q.c.model_params)), q.nx, q.nu, np.zeros(14), np.zeros(7), want=("hess",))
+    # (every built-in plant has Hessian tensors since round 4: the 'no Hessian tensors' refusal has no subject left)
     with pytest.raises(api.HipError, match="Integration type not supported"):
         api.model_eval(p.c.model, 9, p.dt, mp, 2, 1, np.zeros(2), np.zeros(1))
