@@ -157,4 +157,53 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
   return status;
 }
 
+// boxqp_solve1 with its COMMON traces in straight-line code (round 4).  The iteration loop above costs ~80 instructions per pass plus
+// a dozen branches on a kernel whose every sweep step is one dependent chain replicated by the lanes of a trajectory (profiles/
+// r04_kernel_stats_clddp_base.md: the BoxQP is ~200 of the ~650 instructions of a cart-pole sweep step).  Nearly every call ends in
+// one of five ways, all inside the first two passes:
+//   A  pass 0: the clamped warm start is held against its bound by the gradient            -> ALL_CLAMPED, x = x0, not free
+//   B  pass 0: |grad| < min_gradient_norm                                                  -> SUCCESS, x = x0
+//   C  pass 0 takes the full Newton step (Armijo holds at step 1); pass 1: relative improvement below the threshold -> SUCCESS, x = x1
+//   D  ... pass 1: x1 sits on a bound with the gradient pushing outward                     -> ALL_CLAMPED, x = x1, not free
+//   E  ... pass 1: |grad| < min_gradient_norm                                              -> SUCCESS, x = x1
+// The routine evaluates exactly the statements of those traces (same operands, same order, selects instead of branches) and
+// returns their result; when ANY lane of the wavefront leaves them (a shortened step, a third pass, no descent, an out-of-range
+// gradient square, fewer than two passes allowed) every lane redoes the call with the loop -- a prefix of the same trace, so the
+// answer is the loop's in both cases.  tests/test_boxqp.py replays the reference-held inputs through both.
+DEV int boxqp_solve1_fast(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
+  const double xw = x;
+  const double x0 = dmin(dmax(xw, lower), upper);
+  auto objective = [&](double xv) { const double hx = 0.0 + H * xv; const double q = 0.0 + xv * hx; const double l = 0.0 + g * xv; return 0.5 * q + l; };
+  auto norm_ok = [](double ag) { return ag == 0.0 || (ag > 0x1p-500 && ag < 0x1p500); };   // sqrt(grad^2) == |grad| exactly
+  const double value0 = objective(x0);
+  const double newton = -ldlt1_solve(H, g);
+  // pass 0
+  const double grad0 = g + (0.0 + H * x0);
+  const bool clamped0 = (x0 == lower && grad0 > 0) || (x0 == upper && grad0 < 0);
+  const double ag0 = fabs(grad0);
+  const bool small0 = ag0 < o.boxqp_min_gradient_norm;
+  const double search0 = newton - x0;
+  const double sdotg0 = 0.0 + search0 * grad0;
+  const double x1 = dmin(dmax(x0 + 1.0 * search0, lower), upper);
+  const double value1 = objective(x1);
+  const bool step1 = (sdotg0 < 0) && (1.0 > o.boxqp_min_step_size) && ((value1 - value0) <= o.boxqp_armijo_constant * 1.0 * sdotg0);
+  // pass 1
+  const bool rel1 = fabs(value0 - value1) < o.boxqp_min_relative_improvement * fabs(value0);
+  const double grad1 = g + (0.0 + H * x1);
+  const bool clamped1 = (x1 == lower && grad1 > 0) || (x1 == upper && grad1 < 0);
+  const double ag1 = fabs(grad1);
+  const bool small1 = ag1 < o.boxqp_min_gradient_norm;
+  const bool exitA = clamped0;
+  const bool exitB = !clamped0 && norm_ok(ag0) && small0;
+  const bool pass1 = !clamped0 && norm_ok(ag0) && !small0 && step1;
+  const bool exitC = pass1 && rel1;
+  const bool exitD = pass1 && !rel1 && clamped1;
+  const bool exitE = pass1 && !rel1 && !clamped1 && norm_ok(ag1) && small1;
+  const bool fast = (o.boxqp_max_iterations >= 2) && (exitA || exitB || exitC || exitD || exitE);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) return boxqp_solve1(o, H, g, lower, upper, x, free_);
+  x = (exitA || exitB) ? x0 : x1;
+  free_ = (exitA || exitD) ? 0 : 1;
+  return (exitA || exitD) ? BQ_ALL_CLAMPED : BQ_SUCCESS;
+}
+
 }  // namespace cddp_dev

@@ -586,6 +586,13 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           Quu[0] = (2.0 * Rr[0]) + s; }
         qp_h = Quu[0] + reg;
         if (min_real_eig<1>(&qp_h) <= 0) return false;   // clddp_solver.cpp:133-140
+        // Q_ux[0, qc] needs T2 and the lane's column of A only: formed here, so the gain column's quotient Q_ux / (Q_uu + reg) is in
+        // flight beside the BoxQP's own division instead of behind its loop (two dependent ~150-cycle divisions per step otherwise)
+        { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += T2[j] * c1.Aq[j];
+          Quxc[0] = s; }
+        const double kq_free = -ldlt1_solve(qp_h, Quxc[0]);
         if (box < 0) {                                    // clddp_solver.cpp:142-145: k = -Q_uu_reg^-1 Q_u
           double H[1];
           inverse_pplu<1>(&qp_h, H);
@@ -595,8 +602,9 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           const ConDev &cc = P->cons[box];
           const double lb = P->pool[cc.off_lower] - c2.u[0], ub = P->pool[cc.off_upper] - c2.u[0];
           kk[0] = c2.k0[0];
-          const int stq = boxqp_solve1(o, qp_h, Qu[0], lb, ub, kk[0], qp_free);
+          const int stq = boxqp_solve1_fast(o, qp_h, Qu[0], lb, ub, kk[0], qp_free);   // straight-line common traces, the loop otherwise (dev_boxqp.hpp)
           if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+          KKc[0] = qp_free ? kq_free : 0.0;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -617,11 +625,13 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += T1[i * NX + j] * c1.Aq[j];
         Qxxc[i] = (2.0 * Qq[i]) + s; }
+      if constexpr (!kEarlyQP) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * c1.Aq[j];
         Quxc[u] = s; }
+      }
       if constexpr (!kEarlyQP) {
 #pragma unroll
         for (int u = 0; u < NU; ++u)
@@ -632,8 +642,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
             Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
       }
       if constexpr (kEarlyQP) {
-        if (box < 0) KKc[0] = 0.0 + (-qp_h) * Quxc[0];
-        else KKc[0] = qp_free ? -ldlt1_solve(qp_h, Quxc[0]) : 0.0;
+        if (box < 0) KKc[0] = 0.0 + (-qp_h) * Quxc[0];   // (box >= 0: set beside the BoxQP above)
       } else if constexpr (CLDDP) {
         double Quu_reg[NU * NU];
 #pragma unroll

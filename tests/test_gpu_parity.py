@@ -362,7 +362,8 @@ def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["term_eq_only", "path_term_eq", "pendulum_term_eq", "manipulator_term_eq",
-                                  "manip7_term_eq_parallel_ls", "cartpole_ipddp_box", "quadrotor_ipddp_box"])
+                                  "manip7_term_eq_parallel_ls", "cartpole_ipddp_box", "quadrotor_ipddp_box",
+                                  "cartpole_clddp_box", "pendulum_clddp_box"])   # CLDDP nu = 1: straight-line BoxQP (coop) vs its loop (lane)
 def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
     """The lane-cooperative sweeps (kernels_coop.hpp, kernels_te.hpp: column per lane, gradient variant per lane,
     two-role rollout) restate the one-lane-per-trajectory kernels sum for sum; CDDP_HIP_SWEEP=lane selects the
