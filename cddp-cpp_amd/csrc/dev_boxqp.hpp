@@ -106,6 +106,19 @@ DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g,
   return status;
 }
 
+// The BoxQP options as loop-invariant values.  A sweep kernel loads them ONCE in front of its step loop: read through the options
+// struct inside the step, every field is a scalar load plus an s_waitcnt inside conditionally executed code (which the compiler does
+// not hoist) -- eight dependent ~150-cycle round trips per step on the chain of the cart-pole CLDDP sweep (round 4, ISA of
+// k_backward_coop_plain<CartPoleModel, true>).
+struct BoxQPConst {
+  int max_it;
+  double min_grad, min_rel, step_dec, min_step, armijo;
+  DEV void load(const cddp_hip_options &o) {
+    max_it = o.boxqp_max_iterations; min_grad = o.boxqp_min_gradient_norm; min_rel = o.boxqp_min_relative_improvement;
+    step_dec = o.boxqp_step_decrease_factor; min_step = o.boxqp_min_step_size; armijo = o.boxqp_armijo_constant;
+  }
+};
+
 // N = 1: the same projected-Newton iteration written on scalars (no free-index lists, no factor object: the 1x1 "factor" of the
 // free block is H itself and LDLT's solve is D^+ with tolerance DBL_MIN, dev_linalg.hpp::ldlt1_solve).  Statement for statement
 // the N = 1 trace of boxqp_solve<N> above -- same values, same order of decisions, same exits -- so a control-limited single-input
@@ -118,7 +131,7 @@ DEV int boxqp_solve(const cddp_hip_options &o, const double *H, const double *g,
 //   * the objective at the accepted point was already evaluated by the line search (same function, same argument).
 // A dependent f64 division or square root costs ~150 cycles on gfx950 and the loop is replicated by every lane of a trajectory's
 // group, on the critical path of every sweep step.
-DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
+DEV int boxqp_solve1(const BoxQPConst &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
   int status = BQ_MAX_ITER;
   x = dmin(dmax(x, lower), upper);
   int clamped = 0;
@@ -127,8 +140,8 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
   double value = objective(x);
   double old_value = INFINITY;
   const double newton = -ldlt1_solve(H, g);      // -(H_free^+ grad_clamped): grad_clamped = g while the variable is free
-  for (int iter = 0; iter < o.boxqp_max_iterations; ++iter) {
-    if (iter > 0 && fabs(old_value - value) < o.boxqp_min_relative_improvement * fabs(old_value)) { status = BQ_SUCCESS; break; }
+  for (int iter = 0; iter < o.max_it; ++iter) {
+    if (iter > 0 && fabs(old_value - value) < o.min_rel * fabs(old_value)) { status = BQ_SUCCESS; break; }
     old_value = value;
     const double grad = g + (0.0 + H * x);
     clamped = ((x == lower && grad > 0) || (x == upper && grad < 0)) ? 1 : 0;
@@ -137,24 +150,29 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
     const double ag = fabs(grad);
     double grad_norm = ag;
     if (!(ag > 0x1p-500 && ag < 0x1p500)) grad_norm = sqrt(0.0 + grad * grad);   // also NaN
-    if (grad_norm < o.boxqp_min_gradient_norm) { status = BQ_SUCCESS; break; }
+    if (grad_norm < o.min_grad) { status = BQ_SUCCESS; break; }
     const double search = newton - x;
     const double sdotg = 0.0 + search * grad;
     if (sdotg >= 0) { status = BQ_NO_DESCENT; break; }
     double step = 1.0;
     bool ls_ok = false;
     double xn = x, value_new = value;
-    while (step > o.boxqp_min_step_size) {
+    while (step > o.min_step) {
       xn = dmin(dmax(x + step * search, lower), upper);
       value_new = objective(xn);
-      if ((value_new - value) <= o.boxqp_armijo_constant * step * sdotg) { ls_ok = true; break; }
-      step *= o.boxqp_step_decrease_factor;
+      if ((value_new - value) <= o.armijo * step * sdotg) { ls_ok = true; break; }
+      step *= o.step_dec;
     }
     if (!ls_ok) { status = BQ_MAX_LS; break; }
     x = xn;
     value = value_new;
   }
   return status;
+}
+
+DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
+  BoxQPConst c; c.load(o);
+  return boxqp_solve1(c, H, g, lower, upper, x, free_);
 }
 
 // boxqp_solve1 with its COMMON traces in straight-line code (round 4).  The iteration loop above costs ~80 instructions per pass plus
@@ -170,7 +188,7 @@ DEV int boxqp_solve1(const cddp_hip_options &o, const double H, const double g, 
 // returns their result; when ANY lane of the wavefront leaves them (a shortened step, a third pass, no descent, an out-of-range
 // gradient square, fewer than two passes allowed) every lane redoes the call with the loop -- a prefix of the same trace, so the
 // answer is the loop's in both cases.  tests/test_boxqp.py replays the reference-held inputs through both.
-DEV int boxqp_solve1_fast(const cddp_hip_options &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
+DEV int boxqp_solve1_fast(const BoxQPConst &o, const double H, const double g, const double lower, const double upper, double &x, int &free_) {
   const double xw = x;
   const double x0 = dmin(dmax(xw, lower), upper);
   auto objective = [&](double xv) { const double hx = 0.0 + H * xv; const double q = 0.0 + xv * hx; const double l = 0.0 + g * xv; return 0.5 * q + l; };
@@ -181,25 +199,25 @@ DEV int boxqp_solve1_fast(const cddp_hip_options &o, const double H, const doubl
   const double grad0 = g + (0.0 + H * x0);
   const bool clamped0 = (x0 == lower && grad0 > 0) || (x0 == upper && grad0 < 0);
   const double ag0 = fabs(grad0);
-  const bool small0 = ag0 < o.boxqp_min_gradient_norm;
+  const bool small0 = ag0 < o.min_grad;
   const double search0 = newton - x0;
   const double sdotg0 = 0.0 + search0 * grad0;
   const double x1 = dmin(dmax(x0 + 1.0 * search0, lower), upper);
   const double value1 = objective(x1);
-  const bool step1 = (sdotg0 < 0) && (1.0 > o.boxqp_min_step_size) && ((value1 - value0) <= o.boxqp_armijo_constant * 1.0 * sdotg0);
+  const bool step1 = (sdotg0 < 0) && (1.0 > o.min_step) && ((value1 - value0) <= o.armijo * 1.0 * sdotg0);
   // pass 1
-  const bool rel1 = fabs(value0 - value1) < o.boxqp_min_relative_improvement * fabs(value0);
+  const bool rel1 = fabs(value0 - value1) < o.min_rel * fabs(value0);
   const double grad1 = g + (0.0 + H * x1);
   const bool clamped1 = (x1 == lower && grad1 > 0) || (x1 == upper && grad1 < 0);
   const double ag1 = fabs(grad1);
-  const bool small1 = ag1 < o.boxqp_min_gradient_norm;
+  const bool small1 = ag1 < o.min_grad;
   const bool exitA = clamped0;
   const bool exitB = !clamped0 && norm_ok(ag0) && small0;
   const bool pass1 = !clamped0 && norm_ok(ag0) && !small0 && step1;
   const bool exitC = pass1 && rel1;
   const bool exitD = pass1 && !rel1 && clamped1;
   const bool exitE = pass1 && !rel1 && !clamped1 && norm_ok(ag1) && small1;
-  const bool fast = (o.boxqp_max_iterations >= 2) && (exitA || exitB || exitC || exitD || exitE);
+  const bool fast = (o.max_it >= 2) && (exitA || exitB || exitC || exitD || exitE);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) return boxqp_solve1(o, H, g, lower, upper, x, free_);
   x = (exitA || exitB) ? x0 : x1;
   free_ = (exitA || exitD) ? 0 : 1;

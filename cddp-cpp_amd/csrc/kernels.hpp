@@ -1198,6 +1198,10 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // X_[0] == initial state
   st<NX>(Xn + GI(0, NX, 0), kLS, x);
   double J = 0.0;
+  DynCtx dc;                       // loop-invariant plant / integrator constants in scalar registers (as the IPDDP producer keeps them)
+  dc.load(P->integrator, P->dt, P->mp);
+  typename Obj::Ctx oc;            // Q dt | R dt | goal hoisted for small plants, on the pool otherwise
+  Obj::load(P, oc);
   // One step of look-ahead on the (x_old, u_old, k, K) record of the current iterate, ping-pong register sets with the loop unrolled
   // by two (the idiom of the IPDDP rollouts): the record of step t + 1 does not depend on the trial, so its
   // HBM latency hides behind the integrator chain of step t (round 3: loads at the top of their own step, 238 us per launch).
@@ -1227,9 +1231,9 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
       u[i] = (c.uo[i] + alpha * c.kk[i]) + s;
       if (box >= 0) u[i] = dmin(dmax(u[i], lo[i]), hi[i]);
     }
-    J += Obj::running_cost(P, xrt, t, x, u);
+    J += Obj::running_cost(oc, xrt, t, x, u);
     double xn[NX];
-    Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+    Stepper<Model>::step(dc, x, u, xn);
     st<NU>(Un + GI(t, NU, 0), kLS, u);
     st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
@@ -1238,6 +1242,14 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   if constexpr (kPF) {
     Rec ra, rb;
     fetch(0, ra);
+    {   // prime the VMEM queue with one step's store pattern (rows rewritten by step 0), so that the loop-entry state the waitcnt
+        // pass joins with the back edge ends in stores, not loads: otherwise every step waits for vmcnt(0), i.e. for its own stores
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      st<NU>(Un + GI(0, NU, 0), kLS, z);
+      st<NX>(Xn + GI(1, NX, 0), kLS, z);
+    }
     int t = 0;
     for (; t + 1 < N; t += 2) { step(t, ra, rb); step(t + 1, rb, ra); }
     if (t < N) step(t, ra, rb);

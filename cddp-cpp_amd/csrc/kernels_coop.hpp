@@ -466,6 +466,12 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
   bool ok = false;
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, step_norm = 0;
+  // loop-invariant scalars of the control-limited step, fetched ONCE: inside the step they are scalar loads in conditionally executed
+  // code, i.e. dependent load + s_waitcnt round trips on the chain of every step (dev_boxqp.hpp::BoxQPConst)
+  BoxQPConst qpc; qpc.load(o);
+  [[maybe_unused]] double box_lo[NU], box_hi[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) { box_lo[i] = box >= 0 ? P->pool[P->cons[box].off_lower + i] : 0.0; box_hi[i] = box >= 0 ? P->pool[P->cons[box].off_upper + i] : 0.0; }
   // loop-invariant per-lane constants: column / row qc of Q dt, R dt, the goal state
   double Qq[NX], Qrow[NX], Rr[NU * NU], xg[NX];
   {
@@ -549,7 +555,11 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
         for (int k = 0; k < NX; ++k) s2 += c1.Aq[k] * Vx[k];
         Qxq = lxq + s2;
       }
-      Obj::lu(P, c2.u, Qu);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;   // Objective::lu on the hoisted R dt (same expression)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s += (2.0 * Rr[i * NU + j]) * c2.u[j];
+        Qu[i] = s; }
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s2 = 0.0;
 #pragma unroll
@@ -599,10 +609,9 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           kk[0] = 0.0 + (-H[0]) * Qu[0];
           qp_h = H[0];                                    // the inverse, for the gain column below
         } else {                                          // clddp_solver.cpp:147-178
-          const ConDev &cc = P->cons[box];
-          const double lb = P->pool[cc.off_lower] - c2.u[0], ub = P->pool[cc.off_upper] - c2.u[0];
+          const double lb = box_lo[0] - c2.u[0], ub = box_hi[0] - c2.u[0];
           kk[0] = c2.k0[0];
-          const int stq = boxqp_solve1_fast(o, qp_h, Qu[0], lb, ub, kk[0], qp_free);   // straight-line common traces, the loop otherwise (dev_boxqp.hpp)
+          const int stq = boxqp_solve1_fast(qpc, qp_h, Qu[0], lb, ub, kk[0], qp_free);   // straight-line common traces, the loop otherwise (dev_boxqp.hpp)
           if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
           KKc[0] = qp_free ? kq_free : 0.0;
         }
@@ -661,15 +670,14 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
             kk[i] = s; KKc[i] = s2;
           }
         } else {         // clddp_solver.cpp:147-178
-          const ConDev &cc = P->cons[box];
           double lb[NU], ub[NU];
 #pragma unroll
-          for (int i = 0; i < NU; ++i) { lb[i] = P->pool[cc.off_lower + i] - c2.u[i]; ub[i] = P->pool[cc.off_upper + i] - c2.u[i]; }
+          for (int i = 0; i < NU; ++i) { lb[i] = box_lo[i] - c2.u[i]; ub[i] = box_hi[i] - c2.u[i]; }
 #pragma unroll
           for (int i = 0; i < NU; ++i) kk[i] = c2.k0[i];
           if constexpr (NU == 1) {   // scalar BoxQP (dev_boxqp.hpp::boxqp_solve1): the N = 1 trace of the generic solver, nothing indexed
             int fr;
-            const int stq = boxqp_solve1(o, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
+            const int stq = boxqp_solve1(qpc, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
             if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
             KKc[0] = fr ? -ldlt1_solve(Quu_reg[0], Quxc[0]) : 0.0;
           } else {
