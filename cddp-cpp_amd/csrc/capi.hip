@@ -138,7 +138,11 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (p->abi_version != CDDP_HIP_ABI_VERSION) return fail(-2, "ABI version mismatch: got %d want %d", p->abi_version, CDDP_HIP_ABI_VERSION);
   if (p->nx <= 0 || p->nu <= 0 || p->horizon <= 0 || !(p->dt > 0)) return fail(-2, "bad dimensions nx=%d nu=%d N=%d dt=%g", p->nx, p->nu, p->horizon, p->dt);
   if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
-  if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP) return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
+  // (LogDDP, round 4: resident for the built-in plants with nx <= 8 -- kernels_logddp.hpp; MSIPDDP is served by cddp_hip_plugin_solve only)
+  if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP && p->solver != CDDP_HIP_SOLVER_LOGDDP)
+    return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
+  if (p->solver == CDDP_HIP_SOLVER_LOGDDP && !(p->options.logddp_relaxed_delta > 0.0))
+    return fail(-2, "Relaxation delta must be positive.");   // barrier.hpp:49-51
   // the device-resident retry loops (cddp_solver_base.cpp:93-111) terminate because the regularisation grows: a factor <= 1
   // is an endless loop on the reference's host and would be a wedged queue here
   if (!(p->options.reg_update_factor > 1.0) || !(p->options.reg_max_value > 0.0))
@@ -358,6 +362,10 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
     return fail(-4, "no kernel instantiation for model=%d nx=%d nu=%d with this constraint layout (m=%d, %d constraints)",
                 problem->model, problem->nx, problem->nu, m, nc);
   }
+  if (h->P.solver == CDDP_HIP_SOLVER_LOGDDP && !h->ks->has_logddp) {
+    delete h;
+    return fail(-4, "LogDDP is resident on the device for plants with nx <= 8 (model=%d has nx=%d): use cddp_hip_plugin_solve for this plant", problem->model, problem->nx);
+  }
   h->device = device;
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) { delete h; return fail(-10, "hipSetDevice: %s", hipGetErrorString(e)); }
@@ -377,6 +385,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   d.hist_cap = P.opt.max_iterations + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
   const bool ip = (P.solver == CDDP_HIP_SOLVER_IPDDP);
+  d.lg = (P.solver == CDDP_HIP_SOLVER_LOGDDP) ? 1 : 0;
 #define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { free_all(h); delete h; return rc_; } } while (0)
   DA(d.X, d.planeX * d.n_slots); DA(d.U, d.planeU * d.n_slots);
   if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
@@ -398,6 +407,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   DA(d.t_success, (size_t)d.n_alphas * Bp);
   DA(d.t_steps, (size_t)d.n_alphas * Bp); DA(d.n_fwd_steps, Bp); DA(d.cand, Bp);
   if (ip && P.n_cons > 0) DA(d.ev, (size_t)d.n_alphas * N * 2 * P.n_cons * Bp);
+  if (d.lg && P.n_cons > 0) DA(d.ev, (size_t)d.n_slots * N * P.n_cons * Bp);   // parked barrier sums per trial slot (kernels_logddp.hpp)
   DA(d.hist, (size_t)std::max(1, d.hist_batch) * d.hist_cap * kHistCols);
   DA(d.hist_n, std::max(1, d.hist_batch));
   if (ip && P.n_term > 0) {

@@ -93,6 +93,7 @@ struct DevBuf {
   unsigned long long *launched;            // rollouts actually executed (speculative alphas included)
   int *cand;                               // [Bp] best-merit rule: the trial whose costate K4b evaluates (k_pick_candidate), -1 = none
   int t4;                                  // 1: A / B / cst / te_cst stacks in the sub-tile-minor layout of the G = 16 cooperative sweeps (kernels.hpp::GT)
+  int lg;                                  // 1: the handle runs LogDDP (kernels_logddp.hpp); ev = [n_slots][N][NSEG] parked barrier sums per trial slot
   int xcd_map;                             // cooperative sweeps: groups of one 64-trajectory tile on one XCD (kernels_coop.hpp::coop_group); CDDP_HIP_XCD_MAP=0 turns it off
 };
 

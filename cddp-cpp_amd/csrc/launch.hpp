@@ -7,6 +7,7 @@
 #include "kernels_pcm.hpp"
 #include "kernels_elem.hpp"
 #include "kernels_mfma.hpp"
+#include "kernels_logddp.hpp"
 
 namespace cddp_dev {
 
@@ -23,6 +24,7 @@ struct KernelSet {
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, int mode, hipStream_t);
   void (*stage)(const DevBuf &, int copy_xu, int ipddp, hipStream_t);
+  bool has_logddp;   // the LogDDP kernels (kernels_logddp.hpp) are instantiated for this layout: one lane per trajectory, nx <= 8, no terminal set
   int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
 };
 
@@ -38,6 +40,9 @@ struct Launcher {
   // allocated its record stack (pT > 0, no terminal inequality, pT + 1 <= lanes per trajectory)
   static constexpr bool kTeCoop = TERM && !Cons::HAS_X;
   static constexpr int te_rec_size() { if constexpr (kTeCoop) return TeCfg<Model, Cons>::REC; else return 0; }
+  // LogDDP on the device (kernels_logddp.hpp): one-lane kernels, so the register-resident plants only (the nx >= 12 plants reach
+  // LogDDP through cddp_hip_plugin_solve as before)
+  static constexpr bool kLog = !TERM && Model::NX <= 8 && Model::kHasHess;
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static bool lane_sweep_requested() {   // read per launch (the tests switch it between solves of one process)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
@@ -103,6 +108,10 @@ struct Launcher {
     // one-lane-per-trajectory kernels instead (comparison / experiments)
     // full DDP (use_ilqr = 0): the one-lane IPDDP kernels carry the tensor terms; CLDDP's backward pass has none
     // (clddp_solver.cpp:79-204 ignores use_ilqr), so it keeps the cooperative sweep
+    if (solver == CDDP_HIP_SOLVER_LOGDDP) {
+      if constexpr (kLog) hipLaunchKernelGGL((k_backward_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      return;
+    }
     const bool lane_sweep = lane_sweep_requested() || (d.ddp && solver == CDDP_HIP_SOLVER_IPDDP);
     const dim3 gridC(coop_grid<CoopCfg<Model>::TPW>(d.B, d.xcd_map));   // whole XCD super-groups when lines are shared between blocks
     if (solver == CDDP_HIP_SOLVER_CLDDP) {
@@ -173,6 +182,10 @@ struct Launcher {
   static void forward(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
     if (na <= 0) return;
     const dim3 grid((d.B + 63) / 64, na);
+    if (solver == CDDP_HIP_SOLVER_LOGDDP) {
+      if constexpr (kLog) hipLaunchKernelGGL((k_forward_logddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      return;
+    }
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
@@ -199,7 +212,7 @@ struct Launcher {
   }
   // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
-    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP) return;
+    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP || solver == CDDP_HIP_SOLVER_LOGDDP) return;
     if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
     if constexpr (Model::NX > 8) {
       if (!force && first_only != 0) {   // one trial per trajectory: the streaming kernel (2 - 4 waves per SIMD instead of one)
@@ -210,11 +223,19 @@ struct Launcher {
     hipLaunchKernelGGL((k_costate<Model>), dim3((d.B + 63) / 64, d.N + 1), dim3(64), 0, s, d, a0, na, phase_req, force, force ? 0 : first_only);
   }
   static void update(const DevBuf &d, int stage, int n1, int is_last, int do_count, hipStream_t s) {
+    if (d.lg) {
+      if constexpr (kLog) hipLaunchKernelGGL((k_update_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, stage, n1, is_last, do_count);
+      return;
+    }
     DevBuf dd = d;
     if constexpr (kTeCoop && Cons::M > 0) dd.ev_valid = (d.te_cst && !(lane_sweep_requested() || d.ddp)) ? 1 : 0;
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, dd, d.P, d.xref_traj, stage, n1, is_last, do_count);
   }
   static void init(const DevBuf &d, int mode, hipStream_t s) {
+    if (d.lg) {
+      if constexpr (kLog) hipLaunchKernelGGL((k_init_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
+      return;
+    }
     hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
   }
   static void stage(const DevBuf &d, int copy_xu, int ipddp, hipStream_t s) {
@@ -224,7 +245,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog;
     return k;
   }
 };

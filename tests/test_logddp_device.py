@@ -1,0 +1,210 @@
+"""LogDDP resident on the device (VERDICT r03 "missing" #2): cddp_hip_create(solver = LOGDDP) for the built-in
+plants -- K0 / K2 / K4 / K5 variants of the batched core in cddp-cpp_amd/csrc/kernels_logddp.hpp -- against the CPU checker's
+LogDDP (oracle/cddp_oracle.cpp, the restatement of logddp_solver.cpp:43-707 + barrier.hpp:37-296 that rounds 2-3 pinned against
+its numpy twin and the reference's own LogDDP tests, tests/test_logddp.py).  Both sides run the shared straight-line log / sin /
+cos (oracle trig_mode 1, tests/conftest.py) with FMA contraction off, so the comparison is strict: identical status, iteration,
+sweep and rollout counts for every trajectory, traces and trajectories at 1e-9.
+
+Step level: initialize (nominal rollout, cost, barrier merit, violation), backward (gains, value expansion, dV, regularisation),
+every line-search trial.  Solve level: whole batches, both selection rules, full DDP, the reference's pendulum / unicycle LogDDP
+problems (tests/cddp_core/test_logddp_solver.cpp:154-277, 358-417) at their own sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    a = np.where(same_inf, 0.0, a); b = np.where(same_inf, 0.0, b)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def _lg(p, api, **opts):
+    p.c.solver = api.SOLVER_LOGDDP
+    for k, v in opts.items():
+        setattr(p.options, k, v)
+    return p
+
+
+def make(api, name):
+    S = api
+    L = S.SOLVER_LOGDDP
+    table = {
+        "pendulum_box": lambda: S.pendulum_problem(L, True),
+        "pendulum_unc": lambda: S.pendulum_problem(L, False),
+        "cartpole_box": lambda: S.cartpole_problem(L, True),
+        "cartpole_unc": lambda: S.cartpole_problem(L, False),
+        "cartpole_box_parallel": lambda: _lg(S.cartpole_problem(L, True), S, enable_parallel=1),
+        "cartpole_box_ddp": lambda: _lg(S.cartpole_problem(L, True), S, use_ilqr=0),
+        "cartpole_box_relaxed": lambda: _lg(S.cartpole_problem(L, True), S, logddp_relaxed_delta=0.3, logddp_mu_initial=0.1),
+        "cartpole_box_state": lambda: _state_box(S.cartpole_problem(L, True), [-1.5, -7.0, -8.0, -25.0], [1.5, 7.0, 8.0, 25.0]),
+        "unicycle_box_ball": lambda: S.unicycle_problem(L, 100, True),
+        "unicycle_box": lambda: S.unicycle_problem(L, 100, False),
+        "unicycle_box_ball_parallel": lambda: _lg(S.unicycle_problem(L, 100, True), S, enable_parallel=1),
+        "bicycle_box": lambda: S.bicycle_problem(L),
+        "car_box": lambda: S.car_problem(L),
+        "hcw_box": lambda: S.hcw_problem(L),
+        "unicycle_soc": lambda: S.unicycle_cone_problem(L),
+        "unicycle_thrust": lambda: S.unicycle_thrust_problem(L, two_sided=True),
+        "unicycle_maxthrust": lambda: S.unicycle_thrust_problem(L, two_sided=False),
+    }
+    return table[name]()
+
+
+def _state_box(p, lo, hi, name="StateConstraint"):
+    p.add_state_box(name, lo, hi)
+    return p
+
+
+CASES = ["pendulum_box", "pendulum_unc", "cartpole_box", "cartpole_unc", "cartpole_box_parallel", "cartpole_box_ddp", "cartpole_box_relaxed",
+         "cartpole_box_state", "unicycle_box_ball", "unicycle_box", "unicycle_box_ball_parallel", "bicycle_box", "car_box", "hcw_box",
+         "unicycle_soc", "unicycle_thrust", "unicycle_maxthrust"]
+
+
+def spread_for(p):
+    s = 0.1 * np.ones(p.nx)
+    if p.nx >= 6:
+        s[:] = 0.02
+    if p.nx == 4:
+        s[1] = 0.3
+    if p.nx == 3:
+        s[:] = 0.05
+    return s
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_step_level_parity(api, oracle_built, case):
+    """initialize -> backward -> forward(alphas) of the device LogDDP against the oracle's: cost / merit / violation of the nominal
+    rollout, K, k, V_x, V_xx, dV, the regularisation the retry loop ended on, and every trial record."""
+    p = make(api, case)
+    B = 8
+    x0 = api.batch_x0(p, B, 20270101, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0)
+    hs.initialize()
+    r0 = hs.results()
+    ok = hs.backward()
+    K, k = hs.gains()
+    Vx, Vxx = hs.value()
+    dV, reg = hs.backward_scalars()
+    alphas = api.Oracle(p).alphas()
+    trials = hs.forward(alphas)
+    for b in range(B):
+        o = api.Oracle(p)
+        o.set_initial(x0[b], None if U0 is None else U0[b], None)
+        o.initialize()
+        ro = o.result()
+        assert rel_err(r0["final_objective"][b], ro["final_objective"]) < TOL
+        assert rel_err(r0["merit_function"][b], ro["merit_function"]) < TOL
+        assert rel_err(r0["inf_pr"][b], ro["inf_pr"]) < TOL
+        assert r0["barrier_mu"][b] == p.options.logddp_mu_initial
+        ook = o.backward(retry=True)
+        assert ok[b] == ook
+        Ko, ko = o.gains(); Vxo, Vxxo = o.value(); dVo, rego = o.backward_scalars()
+        assert rel_err(K[b], Ko) < TOL, (case, b, rel_err(K[b], Ko))
+        assert rel_err(k[b], ko) < TOL
+        assert rel_err(Vx[b], Vxo) < TOL
+        assert rel_err(Vxx[b], Vxxo) < TOL
+        assert rel_err(dV[b][0], dVo[0]) < TOL      # LogDDP's dV_(1) enters nothing (the filter uses alpha dV_(0))
+        assert reg[b] == rego
+        for a, alpha in enumerate(alphas):
+            t = o.forward(alpha)
+            g = trials[b, a]
+            assert g["success"] == t["success"], (case, b, alpha, g, t)
+            if t["success"]:
+                assert rel_err(g["cost"], t["cost"]) < TOL
+                assert rel_err(g["merit_function"], t["merit_function"]) < TOL
+                assert rel_err(g["inf_pr"], t["inf_pr"]) < TOL
+    hs.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_full_solve_parity(api, oracle_built, case):
+    """cddp_hip_solve(LogDDP) vs the oracle's solve, whole batch: status, iterations, sweeps and rollouts identical for EVERY
+    trajectory; objective, barrier parameter, trajectories and gains at 1e-9; the per-iteration trace of trajectory 0."""
+    p = make(api, case)
+    p.options.return_iteration_info = 1
+    B = 24
+    x0 = api.batch_x0(p, B, 20270102, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0)
+    st = hs.solve()
+    res = hs.results()
+    X, U = hs.trajectory()
+    K, k = hs.gains()
+    hist = hs.history(B)
+    ores, oX, oU, oK, _ = api.oracle_solve_batch(p, x0, U0, None, n_threads=8)
+    for f in ("iterations", "status", "n_backward", "n_forward"):
+        assert np.array_equal(res[f], ores[f]), (case, f, res[f], ores[f])
+    assert rel_err(res["final_objective"], ores["final_objective"]) < TOL
+    assert rel_err(res["merit_function"], ores["merit_function"]) < TOL
+    assert rel_err(res["barrier_mu"], ores["barrier_mu"]) < 1e-15
+    assert rel_err(res["regularization"], ores["regularization"]) < 1e-15
+    assert rel_err(res["inf_du"], ores["inf_du"]) < 1e-8 and rel_err(res["inf_pr"], ores["inf_pr"]) < 1e-8
+    assert rel_err(X, oX) < TOL and rel_err(U, oU) < TOL and rel_err(K, oK) < 1e-8
+    o = api.Oracle(p); o.set_initial(x0[0], None if U0 is None else U0[0], None); o.solve()
+    oh = o.history()
+    assert hist[0].shape == oh.shape, (hist[0].shape, oh.shape)
+    assert rel_err(hist[0], oh) < 1e-8
+    assert st.n_converged == int(np.sum((ores["status"] == api.STATUS_OPTIMAL) | (ores["status"] == api.STATUS_ACCEPTABLE)))
+    hs.close()
+
+
+def test_reference_pendulum_problem(api, oracle_built):
+    """tests/cddp_core/test_logddp_solver.cpp:154-277 (SolvePendulum: N = 500, dt = 0.05, Euler, length = mass = 1, no damping, u in
+    [-10, 10], 100 iterations, tolerance 1e-3 / 1e-4, regularisation 1e-6, zero controls from the hanging state): the device solve
+    reproduces the oracle's trace and satisfies the reference's assertions (converged, cost below the initial cost, |u| <= 10)."""
+    N, dt = 500, 0.05
+    p = api.Problem(api.SOLVER_LOGDDP, api.MODEL_PENDULUM, api.EULER, 2, 1, N, dt, np.zeros((2, 2)), 0.1 * np.eye(1), 100.0 * np.eye(2), np.zeros(2),
+                    model_params=[1.0, 1.0, 0.0, 9.81])
+    p.add_control_box("ControlConstraint", [-10.0], [10.0])
+    o = p.options
+    o.max_iterations = 100; o.tolerance = 1e-3; o.acceptable_tolerance = 1e-4; o.reg_initial_value = 1e-6; o.return_iteration_info = 1
+    B = 4
+    x0 = np.tile(np.array([np.pi, 0.0]), (B, 1)); x0[1:, 0] -= 0.01 * np.arange(1, B)
+    U0 = np.zeros((B, N, 1))
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0)
+    hs.solve()
+    res = hs.results(); X, U = hs.trajectory(); hist = hs.history(B)
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0, None, n_threads=4)
+    for f in ("iterations", "status", "n_backward", "n_forward"):
+        assert np.array_equal(res[f], ores[f]), (f, res[f], ores[f])
+    assert rel_err(res["final_objective"], ores["final_objective"]) < TOL and rel_err(X, oX) < TOL and rel_err(U, oU) < TOL
+    assert res["status"][0] in (api.STATUS_OPTIMAL, api.STATUS_ACCEPTABLE)      # "Algorithm should converge"
+    assert res["iterations"][0] > 0 and res["final_objective"][0] < hist[0][0, 0]
+    assert np.max(np.abs(U[0])) <= 10.0
+    hs.close()
+
+
+def test_batch_solve_is_independent_of_neighbours(api):
+    """A trajectory's LogDDP result does not depend on what shares its wavefront: a batch of 100 against the same trajectories solved
+    in batches of 37 + 63 (bitwise)."""
+    p = make(api, "cartpole_box")
+    B = 100
+    x0 = api.batch_x0(p, B, 20270103, spread_for(p))
+
+    def run(sel):
+        hs = api.HipBatchSolver(p, len(sel)); hs.set_initial(x0[sel]); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); hs.close()
+        return r, X, U
+
+    r, X, U = run(np.arange(B))
+    r1, X1, U1 = run(np.arange(37)); r2, X2, U2 = run(np.arange(37, B))
+    for f in r.dtype.names:
+        assert np.array_equal(r[f], np.concatenate([r1[f], r2[f]])), f
+    assert np.array_equal(X, np.concatenate([X1, X2])) and np.array_equal(U, np.concatenate([U1, U2]))
+
+
+def test_large_plants_are_refused_with_a_pointer(api):
+    """The resident LogDDP kernels are one-lane kernels for nx <= 8: the quadrotor (nx = 13) is refused at create with the route
+    that does serve it (cddp_hip_plugin_solve) named in the message -- no silent fallback."""
+    p = api.quadrotor_problem(api.SOLVER_LOGDDP, 30, True)
+    with pytest.raises(RuntimeError, match="cddp_hip_plugin_solve"):
+        api.HipBatchSolver(p, 4)
