@@ -79,7 +79,7 @@ def algorithmic_bytes(nx, nu, N, m, ipddp):
 
 
 def make_problem(api, workload, solver):
-    sv = api.SOLVER_IPDDP if solver == "ipddp" else api.SOLVER_CLDDP
+    sv = {"ipddp": api.SOLVER_IPDDP, "clddp": api.SOLVER_CLDDP, "logddp": api.SOLVER_LOGDDP}[solver]
     if workload == "cartpole_unc":
         p = api.cartpole_problem(sv, False)
         spread = [0.1, 0.3, 0.1, 0.1]
@@ -192,6 +192,8 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
             sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
+        elif solver == "logddp":   # one-lane kernels of the resident LogDDP (kernels_logddp.hpp); scored with CLDDP's byte model (the
+            sweep_label = "k_derivs+k_backward_logddp"   # barrier rows it also reads are not credited)
         else:
             sweep_label = "k_derivs+k_backward_coop_plain"
         dom = (sweep_label, gbps_bwd, bwd_ms, bytes_bwd)
@@ -244,6 +246,7 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
 # timed region, so that the driver's record carries them too: (workload, solver, label)
 OTHER_WORKLOADS = [
     ("cartpole", "clddp", "C2 cart-pole CLDDP (BoxQP core), B=4096"),
+    ("cartpole", "logddp", "f4: cart-pole LogDDP resident on the device (relaxed log barrier of the control box), B=4096"),
     ("unicycle", "ipddp", "C3 unicycle N=200 box+ball, B=8192"),
     ("quadrotor", "ipddp", "C4 share: quadrotor nx=12 N=400, B=2048 (16384 / 8 GPUs)"),
     ("manip7", "ipddp", "C5 share: 7-joint arm nx=14 nu=7 N=150 terminal equality, 16 alphas, B=4096 (32768 / 8 GPUs)"),
@@ -384,7 +387,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: the BASELINE config's per-GPU batch of the workload)")
-    ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp"])
+    ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp", "logddp"])
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",

@@ -719,8 +719,12 @@ class HipBatchSolver : public ISolverAlgorithm {
     ctx.inf_pr_ = s[0].final_primal_infeasibility; ctx.inf_du_ = s[0].final_dual_infeasibility; ctx.inf_comp_ = s[0].final_complementary_infeasibility;
     return s[0];
   }
-  std::vector<CDDPSolution> solveBatch(CDDP &ctx, const std::vector<Vector> &x0s) { create(ctx, x0s); return collect(ctx, (int)x0s.size()); }
+  // NEW (no reference counterpart): one device-resident batch.  LogDDP batches of a built-in plant with nx <= 8 run on the
+  // resident LogDDP kernels (round 4, csrc/kernels_logddp.hpp: shared straight-line log / sin / cos, the arithmetic the parity
+  // tests pin); solve() keeps LogDDP on the plug-in route (host loop in the host libm, the reference's own arithmetic).
+  std::vector<CDDPSolution> solveBatch(CDDP &ctx, const std::vector<Vector> &x0s) { resident_batch_ = true; create(ctx, x0s); resident_batch_ = false; return collect(ctx, (int)x0s.size()); }
   cddp_hip_stats stats{};
+  bool resident_batch_ = false;
 
   static void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("cddp_hip: ") + cddp_hip_last_error()); }
 
@@ -728,7 +732,8 @@ class HipBatchSolver : public ISolverAlgorithm {
   void create(CDDP &ctx, const std::vector<Vector> &x0s) {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
-    plugin_ = ctx.needsHostPlugins() || kind_ == CDDP_HIP_SOLVER_LOGDDP || kind_ == CDDP_HIP_SOLVER_MSIPDDP;   // LogDDP, MSIPDDP: host loop + stack-fed GPU sweeps for every problem
+    const bool resident_logddp = kind_ == CDDP_HIP_SOLVER_LOGDDP && resident_batch_ && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8;
+    plugin_ = ctx.needsHostPlugins() || (kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || kind_ == CDDP_HIP_SOLVER_MSIPDDP;   // MSIPDDP, single LogDDP solves: host loop + stack-fed GPU sweeps
     if (plugin_) {
       const DynamicalSystem &sys = ctx.getSystem();
       nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;

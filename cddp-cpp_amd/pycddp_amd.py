@@ -10,7 +10,8 @@ constraint kinds the device has kernels for.  On top of it:
 Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Python subclasses of `DynamicalSystem`,
 `Objective` / `NonlinearObjective` and `Constraint` (the reference's trampolines, `bind_dynamics.cpp:31-103`, `bind_objective.cpp`,
 `bind_constraints.cpp`) run through the host plug-in solve (`cddp_hip_plugin_solve`: batched backward passes on the GPU, forward
-passes on the host, callbacks into Python) -- as do LogDDP and MSIPDDP for every problem; anything the core does not implement raises
+passes on the host, callbacks into Python) -- as do MSIPDDP and single LogDDP solves for every problem (`solve_batch` of LogDDP on a
+built-in plant with nx <= 8 runs on the resident LogDDP kernels); anything the core does not implement raises
 (terminal constraints on plug-in problems, un-instantiated layouts, path-constrained MSIPDDP outside nu = 1 / nx = nu).
 """
 import enum
@@ -698,6 +699,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         self._opt = options if options is not None else CDDPOptions()
         self._sys = None; self._obj = None; self._cons = {}; self._terms = {}
         self._X = None; self._U = None
+        self.logddp_route = "auto"    # NEW: "auto" (solve_batch of an eligible problem -> resident kernels, else the plug-in route) | "plugin" | "resident"
 
     # -- setters (snake_case names of the pybind layer)
     def set_initial_state(self, x0): self._x0 = np.asarray(x0, dtype=np.float64).copy()
@@ -784,17 +786,24 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
             else: raise NotImplementedError("terminal constraint type %s has no device kernel" % type(c).__name__)
         return p
 
-    def _solve(self, name, x0s):
+    def _solve(self, name, x0s, resident_batch=False):
         api = _api()
-        if name == "LogDDP":             # host loop + stack-fed GPU sweeps for every problem (cddp_hip_plugin_solve)
+        # LogDDP: solve() runs the host loop + stack-fed GPU sweeps (cddp_hip_plugin_solve: the host libm, the reference's own
+        # arithmetic); solve_batch() of a built-in plant with nx <= 8 runs on the resident LogDDP kernels (round 4,
+        # csrc/kernels_logddp.hpp: one device-resident batch in the library's shared straight-line log / sin / cos)
+        eligible = name == "LogDDP" and self._sys is not None and not self._needs_host_plugins() and self._sys.state_dim <= 8
+        if name == "LogDDP" and self.logddp_route == "resident" and not eligible:
+            raise NotImplementedError("the resident LogDDP kernels serve built-in plants with nx <= 8 and built-in objective / constraints")
+        resident_logddp = eligible and self.logddp_route != "plugin" and (resident_batch or self.logddp_route == "resident")
+        if name == "LogDDP" and not resident_logddp:
             return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
         if name == "MSIPDDP":            # same route; path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
             return self._solve_plugins(name, api.SOLVER_MSIPDDP, x0s)
-        if name not in ("CLDDP", "IPDDP"):
+        if name not in ("CLDDP", "IPDDP", "LogDDP"):
             sol = CDDPSolution()                 # cddp_core.cpp:243-265: unknown names do not throw
             sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
             return [sol for _ in range(len(x0s))]
-        kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_CLDDP
+        kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_LOGDDP if name == "LogDDP" else api.SOLVER_CLDDP
         if self._needs_host_plugins():
             return self._solve_plugins(name, kind, x0s)
         p = self._problem(kind)
@@ -829,7 +838,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                 s.history.step_length_primal = list(h[:, 2]); s.history.step_length_dual = list(h[:, 3])
                 s.history.dual_infeasibility = list(h[:, 4]); s.history.primal_infeasibility = list(h[:, 5])
                 s.history.complementary_infeasibility = list(h[:, 6])
-                s.history.barrier_mu = list(h[:, 7]) if name == "IPDDP" else []
+                s.history.barrier_mu = list(h[:, 7]) if name in ("IPDDP", "LogDDP") else []   # logddp_solver.cpp:278-284
                 s.history.regularization = list(h[:, 8])
             out.append(s)
         return out
@@ -932,7 +941,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
     def solve_batch(self, x0s, solver_type=SolverType.IPDDP):
         """One device-resident batch: solution i starts from x0s[i] (same problem, same initial trajectory guess)."""
         name = solver_type.value if isinstance(solver_type, SolverType) else str(solver_type)
-        return self._solve(name, list(x0s))
+        return self._solve(name, list(x0s), resident_batch=True)
 
 
 __all__ = [n for n in dir() if not n.startswith("_") and n not in ("enum", "importlib", "os", "sys", "np")]

@@ -118,6 +118,7 @@ def test_product_logddp_matches_the_oracle(api, pycddp, oracle_built, name):
         elif isinstance(c, T.ThrustMagnitude): sv.add_constraint(cname, pycddp.ThrustMagnitudeConstraint(c.mn, c.mx, c.eps) if c.mn is not None else pycddp.MaxThrustMagnitudeConstraint(c.mx, c.eps))
     if U0 is not None:
         sv.set_initial_trajectory([x0[0]] * (p.N + 1), list(np.asarray(U0)))
+    sv.logddp_route = "plugin"    # this module pins the HOST route (glibc on both sides); the resident kernels: tests/test_logddp_device.py
     sols = sv.solve_batch(list(x0), pycddp.SolverType.LogDDP)
     U0b = None if U0 is None else np.tile(np.asarray(U0)[None], (B, 1, 1))
     ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0b, None, n_threads=B)

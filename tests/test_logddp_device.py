@@ -208,3 +208,41 @@ def test_large_plants_are_refused_with_a_pointer(api):
     p = api.quadrotor_problem(api.SOLVER_LOGDDP, 30, True)
     with pytest.raises(RuntimeError, match="cddp_hip_plugin_solve"):
         api.HipBatchSolver(p, 4)
+
+
+def test_facade_solve_batch_runs_on_the_resident_kernels(api, oracle_built):
+    """pycddp-compatible facade: solve_batch(x0s, LogDDP) of a built-in plant with nx <= 8 is one device-resident batch (the same
+    result as the C-ABI handle gives, i.e. the oracle's trace); logddp_route = "plugin" keeps the host route; a plant the resident
+    kernels do not serve raises under logddp_route = "resident"."""
+    import importlib.util, os, sys
+    name = "pycddp_amd"
+    if name in sys.modules:
+        pycddp = sys.modules[name]
+    else:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cddp-cpp_amd", "pycddp_amd.py"))
+        pycddp = importlib.util.module_from_spec(spec); sys.modules[name] = pycddp; spec.loader.exec_module(pycddp)
+    p = make(api, "cartpole_box")
+    B = 6
+    x0 = api.batch_x0(p, B, 20270104, spread_for(p))
+    o = pycddp.CDDPOptions(); o.verbose = False; o.print_solver_header = False; o.return_iteration_info = True
+    o.max_iterations = p.options.max_iterations; o.tolerance = p.options.tolerance; o.acceptable_tolerance = p.options.acceptable_tolerance
+    o.regularization.initial_value = p.options.reg_initial_value
+    sv = pycddp.CDDP(x0[0], p.x_ref, p.N, p.dt, o)
+    sv.set_dynamical_system(pycddp.CartPole(p.dt, "rk4", *list(p.c.model_params)[:5]))
+    sv.set_objective(pycddp.QuadraticObjective(p.Q, p.R, p.Qf, p.x_ref, [], p.dt))
+    sv.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([-5.0]), np.array([5.0])))
+    sols = sv.solve_batch(list(x0), pycddp.SolverType.LogDDP)
+    pq = make(api, "cartpole_box"); pq.options.return_iteration_info = 1
+    ores, oX, oU, _, _ = api.oracle_solve_batch(pq, x0, None, None, n_threads=B)
+    for b in range(B):
+        s = sols[b]
+        assert s.solver_name == "LogDDP"
+        assert (s.status_message, s.iterations_completed) == (api.STATUS_STRINGS[int(ores["status"][b])], int(ores["iterations"][b]))
+        assert rel_err(s.final_objective, ores["final_objective"][b]) < TOL and rel_err(np.stack(s.state_trajectory), oX[b]) < TOL
+        assert s.final_barrier_mu == ores["barrier_mu"][b] and len(s.history.barrier_mu) == len(s.history.objective)
+    sq = pycddp.CDDP(np.zeros(13), np.zeros(13), 10, 0.02, o)
+    sq.set_dynamical_system(pycddp.Quadrotor(0.02, 1.0, np.eye(3), 0.2, "rk4"))
+    sq.set_objective(pycddp.QuadraticObjective(np.eye(13), np.eye(4), np.eye(13), np.zeros(13), [], 0.02))
+    sq.logddp_route = "resident"
+    with pytest.raises(NotImplementedError):
+        sq.solve_batch([np.zeros(13)], pycddp.SolverType.LogDDP)
