@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
-ORACLE_LIB_PATH = os.path.join(_HERE, "_build", "libcddp_oracle.so")
+ORACLE_LIB_PATH = os.environ.get("CDDP_ORACLE_LIB") or os.path.join(_HERE, "_build", "libcddp_oracle.so")   # override: the sanitizer build (make -C oracle sanitize)
 ORACLE_FAST_LIB_PATH = os.path.join(_HERE, "_build", "libcddp_oracle_fast.so")
 
 
