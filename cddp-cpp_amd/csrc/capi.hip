@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "launch.hpp"
 
@@ -101,6 +102,8 @@ struct Inner {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll = nullptr;
   double *d_head = nullptr, *h_head = nullptr; size_t head_cap = 0;   // cddp_hip_get_plan_head staging (device, pinned host)
   int *h_poll = nullptr;                         // pinned host words of the solve loop's poll: [0] running count, [1..] alpha histogram
+  std::map<unsigned long long, hipGraphExec_t> graphs;   // CDDP_HIP_GRAPH=1: captured iteration windows by (ladder shape, length, last flag)
+  std::map<unsigned long long, int> graph_launches;
 };
 
 namespace {
@@ -448,6 +451,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
 }
 
 static int in_destroy(Inner *h) {
+  if (h) { for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second); h->graphs.clear(); }
   if (!h) return 0;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
@@ -714,7 +718,7 @@ struct SolveRun {
   std::vector<int> ev_slot;         // ev_slot[6 * (iteration - 1) + point] = index into the pool, or -1
   size_t ev_used = 0;
   int launches = 0, outer = 0, it = 0, max_it = 0, na = 0;
-  bool two_stage_marks = false, first_rule = true, pinned = false, one_stage = true, done = false, cpu_time_hit = false;
+  bool two_stage_marks = false, first_rule = true, pinned = false, one_stage = true, done = false, cpu_time_hit = false, use_graph = false;
   int k1 = 1, k_cap = 1, k_cap2 = 1;
   long waves_all = 0, per_alpha_waves = 1, two_stage_max_waves = 768;
   std::vector<int> hist_now, hist_prev;
@@ -727,7 +731,15 @@ struct SolveRun {
                       (detail == CDDP_HIP_TIMING_ROLLOUT && (point == 1 || point == 2 || (two_stage_marks && (point == 3 || point == 4)))) ||
                       (detail == CDDP_HIP_TIMING_SWEEP && (point == 0 || point == 1));
     if (!want) return;
-    if (ev_used == h->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev_pool.push_back(e); }
+    // class-timing events: no system-scope fence at the record (hipEventDisableSystemFence) -- a default event releases to system
+    // scope, i.e. a cache write-back between two kernels of the chain; only the timestamps are read, after the solve's final sync.
+    // CDDP_HIP_EVENT_FENCE=1 restores the default flags (A/B: profiles/r04_graph_ab.md)
+    if (ev_used == h->ev_pool.size()) {
+      hipEvent_t e;
+      static const bool fence = [] { const char *v = std::getenv("CDDP_HIP_EVENT_FENCE"); return v && v[0] == '1'; }();
+      if ((fence ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableSystemFence)) != hipSuccess) return;
+      h->ev_pool.push_back(e);
+    }
     const size_t slot = (size_t)6 * (size_t)(outer - 1) + (size_t)point;
     if (ev_slot.size() <= slot) ev_slot.resize(slot + 1, -1);
     hipEventRecord(h->ev_pool[ev_used], h->stream);
@@ -792,7 +804,8 @@ struct SolveRun {
     // Class timing: up to six mark points per outer iteration (0 start, 1 after the sweep, 2 after rollout stage 1,
     // 3 after update 1, 4 after rollout stage 2, 5 after update 2).  Every event costs ~5 us of queue time, so only
     // the points the selected detail needs are recorded (cddp_hip_set_timing_detail): 2 per iteration by default.
-    detail = want_stats ? h->timing_detail : -1;
+    { const char *e = std::getenv("CDDP_HIP_GRAPH"); use_graph = e && e[0] == '1'; }
+    detail = (want_stats && !use_graph) ? h->timing_detail : -1;
     if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
     if (!h->ev_poll) HIPCHK(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
     poll_ev = h->ev_poll;
@@ -830,13 +843,81 @@ struct SolveRun {
     return 0;
   }
 
+  // The kernels of ONE outer iteration (K1 .. K5 in the current ladder shape), enqueued on the group's stream.
+  void enqueue_iteration(int last) {
+    const ProblemDev &P = h->P;
+    const DevBuf &d = h->d;
+    hipStream_t s = h->stream;
+    const KernelSet *ks = h->ks;
+    two_stage_marks = !one_stage;
+    mark(0);
+    ks->derivs(d, 0, s);
+    ks->backward(d, P.solver, 0, 1, s);
+    mark(1);
+    if (one_stage) {
+      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
+      mark(2);
+      ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 2, s);   // best-merit rule: the candidate winner's costate only (k_costate)
+      ks->update(d, 1, na, last, 1, s);
+      mark(3);
+      launches += 4;
+    } else {
+      ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+      mark(2);
+      ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+      ks->update(d, 1, k1, last, 0, s);
+      mark(3);
+      ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
+      mark(4);
+      ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
+      ks->update(d, 2, na, last, 1, s);
+      mark(5);
+      launches += 6;
+    }
+  }
+  static bool polled_iteration(int it, int max_it, bool pinned) { return it % 4 == 0 || it == max_it || (it <= 2 && !pinned); }
+
+  // CDDP_HIP_GRAPH=1 (experiment): the iterations between two polls are captured ONCE per (ladder shape, window
+  // length, last-iteration flag) into a hipGraph and replayed with one hipGraphLaunch -- every kernel argument of an iteration is
+  // a function of exactly those.  Measured on MI355X (profiles/r04_graph_ab.md): the gaps between dependent kernels are device-side
+  // (barrier packet + cache invalidate), not submission latency -- the host already runs four iterations ahead of the device --
+  // so replaying changes nothing measurable; class timing (hipEvents inside the window) is unavailable in this mode.  Off by default.
+  int advance_graph() {
+    const hipStream_t s = h->stream;
+    int w = 0;
+    while (it + w < max_it) { ++w; if (polled_iteration(it + w, max_it, pinned)) break; }
+    if (w == 0) { done = true; return 0; }
+    const int last = (it + w == max_it) ? 1 : 0;
+    const unsigned long long key = ((unsigned long long)(one_stage ? 0 : k1) << 16) | ((unsigned long long)w << 4) | (unsigned long long)last;
+    auto f = h->graphs.find(key);
+    if (f == h->graphs.end()) {
+      hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+      const int launches0 = launches;
+      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int j = 1; j <= w; ++j) enqueue_iteration((j == w) ? last : 0);
+      HIPCHK(hipStreamEndCapture(s, &g));
+      HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+      launches = launches0;
+      f = h->graphs.emplace(key, ge).first;
+      h->graph_launches.emplace(key, 0);
+    }
+    { const int l0 = launches; for (int j = 0; j < w; ++j) launches += one_stage ? 4 : 6; (void)l0; }
+    HIPCHK(hipGraphLaunch(f->second, s));
+    it += w; outer += w;
+    HIPCHK(hipMemcpyAsync(h->h_poll, h->d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_poll + 1, h->d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(poll_ev, s));
+    return 1;
+  }
+
   // enqueue iterations up to (and including) the next polled one
   int advance() {
     if (done) return 0;
     const ProblemDev &P = h->P;
     const DevBuf &d = h->d;
     hipStream_t s = h->stream;
-    const KernelSet *ks = h->ks;
+    if (use_graph && !(P.opt.max_cpu_time > 0.0)) return advance_graph();
     constexpr int kPollEvery = 4;
     while (it < max_it) {
       ++it;
@@ -852,35 +933,11 @@ struct SolveRun {
       }
       ++outer;
       const int last = (it == max_it) ? 1 : 0;
-      two_stage_marks = !one_stage;
-      mark(0);
-      ks->derivs(d, 0, s);
-      ks->backward(d, P.solver, 0, 1, s);
-      mark(1);
-      if (one_stage) {
-        ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
-        mark(2);
-        ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 2, s);   // best-merit rule: the candidate winner's costate only (k_costate)
-        ks->update(d, 1, na, last, 1, s);
-        mark(3);
-        launches += 4;
-      } else {
-        ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
-        mark(2);
-        ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
-        ks->update(d, 1, k1, last, 0, s);
-        mark(3);
-        ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
-        mark(4);
-        ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
-        ks->update(d, 2, na, last, 1, s);
-        mark(5);
-        launches += 6;
-      }
+      enqueue_iteration(last);
       // The "anything still running?" poll drains the group's queue (host round trip + an empty pipeline for the next
       // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
       // trajectory finished are launches whose every lane exits on its phase check.
-      if (it % kPollEvery == 0 || last || (it <= 2 && !pinned)) {   // (two early polls: the ladder statistics settle the shape)
+      if (polled_iteration(it, max_it, pinned)) {   // every kPollEvery iterations, the last one, and two early polls: the ladder statistics settle the shape
         HIPCHK(hipMemcpyAsync(h->h_poll, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(h->h_poll + 1, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(poll_ev, s));

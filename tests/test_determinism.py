@@ -59,3 +59,26 @@ def test_tile_groups_do_not_change_results(api, kind, monkeypatch):
         else:
             for a, b in zip(ref, cur):
                 assert np.array_equal(a, b), (kind, ng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cartpole_ipddp", "cartpole_clddp", "unicycle_ipddp"])
+def test_graph_replay_of_iteration_windows_is_bitwise_the_stream_loop(api, kind, monkeypatch):
+    """CDDP_HIP_GRAPH=1 (experiment): the iterations between two polls captured into a hipGraph per (ladder shape, window length,
+    last flag) and replayed -- same kernels, same arguments, so every result word is the same."""
+    p = {"cartpole_ipddp": lambda: api.cartpole_problem(api.SOLVER_IPDDP, True), "cartpole_clddp": lambda: api.cartpole_problem(api.SOLVER_CLDDP, True),
+         "unicycle_ipddp": lambda: api.unicycle_problem(api.SOLVER_IPDDP, 100, True)}[kind]()
+    B = 200
+    x0 = api.batch_x0(p, B, 20270201, 0.05 * np.ones(p.nx))
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0); st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); hs.close()
+        return [r[f].copy() for f in r.dtype.names] + [X, U, K, k, np.array([st.sweeps, st.rollouts, st.outer_iterations])]
+
+    monkeypatch.delenv("CDDP_HIP_GRAPH", raising=False)
+    ref = run()
+    monkeypatch.setenv("CDDP_HIP_GRAPH", "1")
+    got = run(); got2 = run()
+    for a, b, c in zip(ref, got, got2):
+        assert np.array_equal(a, b) and np.array_equal(a, c), kind
