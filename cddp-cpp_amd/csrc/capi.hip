@@ -367,7 +367,11 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   }
   if (h->P.solver == CDDP_HIP_SOLVER_LOGDDP && !h->ks->has_logddp) {
     delete h;
-    return fail(-4, "LogDDP is resident on the device for plants with nx <= 8 (model=%d has nx=%d): use cddp_hip_plugin_solve for this plant", problem->model, problem->nx);
+    return fail(-4, "LogDDP has no resident kernels for this layout (model=%d, nx=%d): use cddp_hip_plugin_solve", problem->model, problem->nx);
+  }
+  if (h->P.solver == CDDP_HIP_SOLVER_LOGDDP && !h->P.opt.use_ilqr && !h->ks->logddp_ddp) {
+    delete h;
+    return fail(-3, "LogDDP with use_ilqr=false needs the plant's explicit Hessian tensors, which model id %d keeps only in the blocked dual form: use cddp_hip_plugin_solve", problem->model);
   }
   h->device = device;
   hipError_t e = hipSetDevice(device);

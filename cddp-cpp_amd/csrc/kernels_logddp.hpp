@@ -290,7 +290,9 @@ __global__ __launch_bounds__(64) void k_backward_logddp(DevBuf d, const ProblemD
         for (int k = 0; k < NX; ++k) s += Bm[k * NU + i] * Vx[k];
         Qu[i] = Qu[i] + s; }
       q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
-      if (!o.use_ilqr) lg_tensor_terms<Model>(P, x, u, Vx, Qxx, Qux, Quu);    // :505-515
+      if constexpr (Model::kHasHess) {   // (plants whose tensors exist only in the blocked dual form: full DDP refused at create)
+        if (!o.use_ilqr) lg_tensor_terms<Model>(P, x, u, Vx, Qxx, Qux, Quu);    // :505-515
+      }
       if constexpr (M > 0) {   // :518-530
         double g[MM], Gx[MM * NX], Gu[MM * NU];
 #pragma unroll

@@ -24,6 +24,7 @@ struct KernelSet {
   void (*update)(const DevBuf &, int stage, int n1, int is_last, int do_count, hipStream_t);
   void (*init)(const DevBuf &, int mode, hipStream_t);
   void (*stage)(const DevBuf &, int copy_xu, int ipddp, hipStream_t);
+  bool logddp_ddp;   // LogDDP with use_ilqr = 0: the plant has explicit Hessian tensors (Model::kHasHess)
   bool has_logddp;   // the LogDDP kernels (kernels_logddp.hpp) are instantiated for this layout: one lane per trajectory, nx <= 8, no terminal set
   int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
 };
@@ -40,9 +41,13 @@ struct Launcher {
   // allocated its record stack (pT > 0, no terminal inequality, pT + 1 <= lanes per trajectory)
   static constexpr bool kTeCoop = TERM && !Cons::HAS_X;
   static constexpr int te_rec_size() { if constexpr (kTeCoop) return TeCfg<Model, Cons>::REC; else return 0; }
-  // LogDDP on the device (kernels_logddp.hpp): one-lane kernels, so the register-resident plants only (the nx >= 12 plants reach
-  // LogDDP through cddp_hip_plugin_solve as before)
-  static constexpr bool kLog = !TERM && Model::NX <= 8 && Model::kHasHess;
+  // LogDDP on the device (kernels_logddp.hpp): one-lane kernels for every plant without a terminal set.  Register-resident up to
+  // nx = 8; the nx >= 12 plants work through scratch in the sweep (12 KB per lane at the quadrotor: correct, slow -- the cooperative
+  // LDS-operand form the IPDDP sweeps have is not built for LogDDP).  Full DDP (use_ilqr = 0) needs the explicit Hessian tensors.
+#ifndef CDDP_LOGDDP_MAX_NX
+#define CDDP_LOGDDP_MAX_NX 16
+#endif
+  static constexpr bool kLog = !TERM && Model::NX <= CDDP_LOGDDP_MAX_NX;
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static bool lane_sweep_requested() {   // read per launch (the tests switch it between solves of one process)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
@@ -245,7 +250,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess;
     return k;
   }
 };

@@ -67,11 +67,12 @@ enum cddp_hip_integrator {
 enum cddp_hip_solver {
   CDDP_HIP_SOLVER_CLDDP = 0, CDDP_HIP_SOLVER_IPDDP = 1,
   CDDP_HIP_SOLVER_LOGDDP = 2,  /* logddp_solver.cpp:43-707 + barrier.hpp:37-296: single-shooting relaxed-log-barrier DDP.  Device-resident
-                                  through cddp_hip_create / cddp_hip_solve for the built-in plants with nx <= 8 (round 4,
+                                  through cddp_hip_create / cddp_hip_solve for the built-in plants (round 4; register-resident up to nx = 8,
                                   csrc/kernels_logddp.hpp: every path constraint of the problem enters the barrier; options logddp_*,
                                   filter_*, regularisation and line-search fields; terminal constraints are ignored as the reference's
                                   LogDDP ignores them; result.barrier_mu = mu, result.inf_pr = the violation of the last resetFilter);
-                                  larger plants and user plug-ins: cddp_hip_plugin_solve (host loop + stack-fed GPU sweeps) */
+                                  scratch-backed above; full DDP only for plants with explicit Hessian tensors); user plug-ins:
+                                  cddp_hip_plugin_solve (host loop + stack-fed GPU sweeps) */
   CDDP_HIP_SOLVER_MSIPDDP = 3  /* msipddp_solver.cpp: multiple-shooting interior-point DDP (costates, dynamics defects at segment
                                   boundaries); served by cddp_hip_plugin_solve like LogDDP.  Path constraints with nu > 1 and nx != nu are
                                   refused: the reference adds an (nx x nu) product to its (nu x nx) block Q_ux there (msipddp_solver.cpp:1398),

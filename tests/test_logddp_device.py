@@ -51,6 +51,9 @@ def make(api, name):
         "unicycle_soc": lambda: S.unicycle_cone_problem(L),
         "unicycle_thrust": lambda: S.unicycle_thrust_problem(L, two_sided=True),
         "unicycle_maxthrust": lambda: S.unicycle_thrust_problem(L, two_sided=False),
+        # the reference's own LogDDP tests solve the quadrotor (tests/cddp_core/test_logddp_solver.cpp:693-): nx = 13, scratch-backed sweep
+        "quadrotor_box": lambda: S.quadrotor_problem(L, 30, True),
+        "manipulator_box": lambda: S.manipulator_problem(L, 40, False, True),
     }
     return table[name]()
 
@@ -62,7 +65,7 @@ def _state_box(p, lo, hi, name="StateConstraint"):
 
 CASES = ["pendulum_box", "pendulum_unc", "cartpole_box", "cartpole_unc", "cartpole_box_parallel", "cartpole_box_ddp", "cartpole_box_relaxed",
          "cartpole_box_state", "unicycle_box_ball", "unicycle_box", "unicycle_box_ball_parallel", "bicycle_box", "car_box", "hcw_box",
-         "unicycle_soc", "unicycle_thrust", "unicycle_maxthrust"]
+         "unicycle_soc", "unicycle_thrust", "unicycle_maxthrust", "quadrotor_box", "manipulator_box"]
 
 
 def spread_for(p):
@@ -81,7 +84,7 @@ def test_step_level_parity(api, oracle_built, case):
     """initialize -> backward -> forward(alphas) of the device LogDDP against the oracle's: cost / merit / violation of the nominal
     rollout, K, k, V_x, V_xx, dV, the regularisation the retry loop ended on, and every trial record."""
     p = make(api, case)
-    B = 8
+    B = 8 if p.nx <= 4 else 3
     x0 = api.batch_x0(p, B, 20270101, spread_for(p))
     U0 = api.batch_U0(p, B)
     hs = api.HipBatchSolver(p, B)
@@ -129,7 +132,7 @@ def test_full_solve_parity(api, oracle_built, case):
     trajectory; objective, barrier parameter, trajectories and gains at 1e-9; the per-iteration trace of trajectory 0."""
     p = make(api, case)
     p.options.return_iteration_info = 1
-    B = 24
+    B = 24 if p.nx <= 8 else 6
     x0 = api.batch_x0(p, B, 20270102, spread_for(p))
     U0 = api.batch_U0(p, B)
     hs = api.HipBatchSolver(p, B)
@@ -202,10 +205,11 @@ def test_batch_solve_is_independent_of_neighbours(api):
     assert np.array_equal(X, np.concatenate([X1, X2])) and np.array_equal(U, np.concatenate([U1, U2]))
 
 
-def test_large_plants_are_refused_with_a_pointer(api):
-    """The resident LogDDP kernels are one-lane kernels for nx <= 8: the quadrotor (nx = 13) is refused at create with the route
-    that does serve it (cddp_hip_plugin_solve) named in the message -- no silent fallback."""
+def test_quadrotor_full_ddp_is_refused_with_a_pointer(api):
+    """The quadrotor's second-order tensors exist on the device only in the blocked dual form of the IPDDP sweeps: LogDDP with
+    use_ilqr = 0 is refused at create with the route that serves it named in the message -- no silent fallback."""
     p = api.quadrotor_problem(api.SOLVER_LOGDDP, 30, True)
+    p.options.use_ilqr = 0
     with pytest.raises(RuntimeError, match="cddp_hip_plugin_solve"):
         api.HipBatchSolver(p, 4)
 
