@@ -559,7 +559,8 @@ _hip_libs = {}
 
 
 def default_trig():
-    return "shared"
+    # (CDDP_HIP_LIB + CDDP_HIP_TRIG=libm: the hand-made device-libm comparison build of profiles/r04_trig_ab.md)
+    return "libm" if (os.environ.get("CDDP_HIP_LIB") and os.environ.get("CDDP_HIP_TRIG") == "libm") else "shared"
 
 
 def load_hip(trig=None):

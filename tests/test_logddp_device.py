@@ -186,6 +186,36 @@ def test_reference_pendulum_problem(api, oracle_built):
     hs.close()
 
 
+def test_reference_quadrotor_problem(api, oracle_built):
+    """tests/cddp_core/test_logddp_solver.cpp:693-890 (SolveQuadrotor): the quaternion quadrotor (nx = 13) tracking the figure-8
+    reference over N = 400, u in [0, 4]^4, hover controls rolled out as the guess, mu_initial 1e-1, relaxed delta 1e-5,
+    mu_update_factor 0.2, regularisation 1e-4, 100 iterations, tolerances 1e-5 -- solved by the resident LogDDP kernels (the
+    scratch-backed one-lane sweep of the nx >= 12 plants).  Decisions identical to the oracle's (iterations, sweeps, rollouts),
+    objective and trajectory at 1e-9; the reference's assertions (converged, |q_N| = 1 +- 0.1, |p_N - p_goal| < 0.5) hold."""
+    p = api.quadrotor_figure8_problem(api.SOLVER_LOGDDP)
+    o = p.options
+    o.max_iterations = 100; o.tolerance = 1e-5; o.acceptable_tolerance = 1e-5; o.reg_initial_value = 1e-4
+    o.logddp_mu_initial = 1e-1; o.logddp_relaxed_delta = 1e-5; o.logddp_mu_update_factor = 0.2; o.return_iteration_info = 1
+    U0 = api.batch_U0(p, 1)[0]
+    B = 2
+    x0 = np.tile(p.x0, (B, 1)); x0[1, :3] += np.array([0.1, -0.1, 0.05])
+    U0b = np.tile(U0, (B, 1, 1))
+    hs = api.HipBatchSolver(p, B)
+    hs.set_initial(x0, U0b)          # (LogDDP re-rolls the states out from the controls: the X guess is not read, :127-135)
+    st = hs.solve()
+    r = hs.results(); X, U = hs.trajectory(); hs.close()
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0b, None, n_threads=B)
+    print("LogDDP quadrotor figure-8: HIP iterations %s oracle %s status %s, %.0f ms for B = %d" %
+          (list(r["iterations"]), list(ores["iterations"]), [api.STATUS_STRINGS[int(s_)] for s_ in r["status"]], st.solve_ms, B))
+    for key in ("iterations", "status", "n_backward", "n_forward"):
+        assert np.array_equal(r[key], ores[key]), (key, r[key], ores[key])
+    assert rel_err(r["final_objective"], ores["final_objective"]) < TOL and rel_err(X, oX) < 1e-8 and rel_err(U, oU) < 1e-8
+    assert api.STATUS_STRINGS[int(r["status"][0])] in ("OptimalSolutionFound", "AcceptableSolutionFound")   # "Quadrotor algorithm should converge"
+    assert r["iterations"][0] > 0
+    assert abs(np.linalg.norm(X[0, -1, 3:7]) - 1.0) < 0.1
+    assert np.linalg.norm(X[0, -1, :3] - p.x_ref[:3]) < 0.5
+
+
 def test_batch_solve_is_independent_of_neighbours(api):
     """A trajectory's LogDDP result does not depend on what shares its wavefront: a batch of 100 against the same trajectories solved
     in batches of 37 + 63 (bitwise)."""
