@@ -915,7 +915,7 @@ class HipBatchSolver : public ISolverAlgorithm {
         const double *row = hist.data() + ((size_t)b * (max_it_ + 1) + i) * 9;
         s.history.objective.push_back(row[0]); s.history.merit_function.push_back(row[1]); s.history.step_length_primal.push_back(row[2]);
         s.history.step_length_dual.push_back(row[3]); s.history.dual_infeasibility.push_back(row[4]); s.history.primal_infeasibility.push_back(row[5]);
-        s.history.complementary_infeasibility.push_back(row[6]); if (kind_ == CDDP_HIP_SOLVER_IPDDP) s.history.barrier_mu.push_back(row[7]); s.history.regularization.push_back(row[8]);
+        s.history.complementary_infeasibility.push_back(row[6]); if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP) s.history.barrier_mu.push_back(row[7]); s.history.regularization.push_back(row[8]);
       }
     }
     return out;

@@ -306,6 +306,23 @@ static void gpu_tests() {
     int conv = 0; for (auto &s : sols) conv += (s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");
     EXPECT_TRUE(conv >= 120);
   }
+  {   // round 4: a LogDDP batch runs on the resident kernels (csrc/kernels_logddp.hpp); every trajectory keeps the torque box, the
+      // batch's trajectory 0 reports a history with its barrier parameter (logddp_solver.cpp:278-284), the cost decreases
+    cddp::CDDP solver = makePendulum(opt);
+    std::vector<cddp::Vector> x0s;
+    for (int b = 0; b < 96; ++b) x0s.push_back({3.14159265358979323846 - 0.002 * b, 0.0});
+    std::vector<cddp::CDDPSolution> sols = solver.solveBatch("LogDDP", x0s);
+    EXPECT_EQ((int)sols.size(), 96);
+    int ok = 0;
+    for (auto &s : sols) {
+      EXPECT_TRUE(s.solver_name == "LogDDP" && s.iterations_completed > 0);
+      for (auto &u : s.control_trajectory) EXPECT_TRUE(u[0] <= 20.0 + 1e-9 && u[0] >= -20.0 - 1e-9);
+      ok += (s.final_objective < s.history.objective.front() || s.history.objective.empty());
+    }
+    EXPECT_TRUE(ok == 96);
+    EXPECT_TRUE(!sols[0].history.barrier_mu.empty() && sols[0].history.barrier_mu.size() == sols[0].history.objective.size());
+    std::cout << "LogDDP batch (resident): " << sols[0].status_message << " iterations " << sols[0].iterations_completed << " mu " << sols[0].final_barrier_mu << "\n";
+  }
   {   // terminal equality constraint (tests/cddp_core/test_ipddp_solver.cpp:1580-1637 style): x_N pinned to the target
     cddp::CDDPOptions o2 = opt; o2.max_iterations = 100;
     cddp::CDDP solver = makePendulum(o2, 60);

@@ -82,3 +82,28 @@ def test_graph_replay_of_iteration_windows_is_bitwise_the_stream_loop(api, kind,
     got = run(); got2 = run()
     for a, b, c in zip(ref, got, got2):
         assert np.array_equal(a, b) and np.array_equal(a, c), kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cartpole_ipddp", "cartpole_logddp"])
+def test_successive_chunks_of_a_large_batch_do_not_change_results(api, kind, monkeypatch):
+    """A batch above 8192 trajectories is solved as successive chunks on the handle (capi.hip::pick_groups, one chunk in flight at a
+    time).  CDDP_HIP_CHUNK sets the chunk size: 1000 trajectories in chunks of 256 (4 chunks, the last one
+    short) against one group -- every result word, trajectory and gain the same bits, and the work counters add up."""
+    p = api.cartpole_problem(api.SOLVER_IPDDP if kind == "cartpole_ipddp" else api.SOLVER_LOGDDP, True)
+    B = 1000
+    x0 = api.batch_x0(p, B, 20270202, np.array([0.1, 0.3, 0.1, 0.1]))
+    monkeypatch.delenv("CDDP_HIP_GROUPS", raising=False)
+
+    def run(chunk, ng):
+        monkeypatch.setenv("CDDP_HIP_CHUNK", chunk)
+        hs = api.HipBatchSolver(p, B)
+        assert hs.num_groups() == ng
+        hs.set_initial(x0); st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); hs.close()
+        return [r[f].copy() for f in r.dtype.names] + [X, U, K, k, np.array([st.sweeps, st.rollouts, st.traj_iterations, st.rollout_steps, st.n_converged])]
+
+    ref = run("0", 1)
+    got = run("256", 4)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b), kind
