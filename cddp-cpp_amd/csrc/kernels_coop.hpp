@@ -581,7 +581,10 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
       // (a data-dependent loop of dependent divisions / square roots, replicated by the lanes of the group) run BEFORE the sixteen
       // T1 entries are fetched from LDS and Q_xx / Q_ux are formed: nothing of those is live across the loop, which is what had the
       // round-3 kernel at 256 VGPR + 124 AGPR with ~250 accvgpr moves per step.  Pure reordering of independent statements.
-      constexpr bool kEarlyQP = CLDDP && NU == 1 && !kQuad;
+#ifndef CDDP_EARLYQP
+#define CDDP_EARLYQP 1
+#endif
+      constexpr bool kEarlyQP = CLDDP && NU == 1 && !kQuad && CDDP_EARLYQP;
       double T1[NX * NX], T2[NU * NX];
       double Qxxc[NX], Quxc[NU], Quu[NU * NU];
       double kk[NU], KKc[NU];
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
           for (int i = 0; i < NU; ++i) kk[i] = c2.k0[i];
           if constexpr (NU == 1) {   // scalar BoxQP (dev_boxqp.hpp::boxqp_solve1): the N = 1 trace of the generic solver, nothing indexed
             int fr;
-            const int stq = boxqp_solve1(qpc, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
+            const int stq = boxqp_solve1_fast(qpc, Quu_reg[0], Qu[0], lb[0], ub[0], kk[0], fr);
             if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
             KKc[0] = fr ? -ldlt1_solve(Quu_reg[0], Quxc[0]) : 0.0;
           } else {

@@ -63,6 +63,7 @@ def _oracle_arithmetic(request):
     if request.node.get_closest_marker("gpu") is None or request.node.get_closest_marker("host_arithmetic") is not None:
         yield
         return
+    load_api()                      # (a worker whose first gpu test does not use the `api` fixture: the checker binds to that module)
     oa = load_oracle_api()
     prev = oa.set_trig_mode(1)
     try:
