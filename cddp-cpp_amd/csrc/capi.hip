@@ -96,6 +96,7 @@ struct Inner {
   bool initialized = false;
   bool has_state = false;        // gains / duals of an earlier initialize() or solve() live on the device (warm start)
   bool initial_dirty = false;    // set_initial() since the last initialize(): the caller supplied a new trajectory
+  bool ms_cache_started = false; // MSIPDDP: the per-step factor cache has been cleared once (it lives as long as the handle)
   size_t bytes = 0;
   int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
   std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
@@ -141,9 +142,11 @@ int flatten(const cddp_hip_problem *p, ProblemDev &P) {
   if (p->abi_version != CDDP_HIP_ABI_VERSION) return fail(-2, "ABI version mismatch: got %d want %d", p->abi_version, CDDP_HIP_ABI_VERSION);
   if (p->nx <= 0 || p->nu <= 0 || p->horizon <= 0 || !(p->dt > 0)) return fail(-2, "bad dimensions nx=%d nu=%d N=%d dt=%g", p->nx, p->nu, p->horizon, p->dt);
   if (!p->Q || !p->R || !p->Qf || !p->x_ref) return fail(-2, "objective matrices (Q, R, Qf, x_ref) must be set before solving");
-  // (LogDDP, round 4: resident for the built-in plants with nx <= 8 -- kernels_logddp.hpp; MSIPDDP is served by cddp_hip_plugin_solve only)
-  if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP && p->solver != CDDP_HIP_SOLVER_LOGDDP)
+  // (LogDDP and MSIPDDP, round 4: resident for the built-in plants -- kernels_logddp.hpp, kernels_msipddp.hpp)
+  if (p->solver != CDDP_HIP_SOLVER_CLDDP && p->solver != CDDP_HIP_SOLVER_IPDDP && p->solver != CDDP_HIP_SOLVER_LOGDDP && p->solver != CDDP_HIP_SOLVER_MSIPDDP)
     return fail(-2, "UnknownSolver - No solver registered for id %d", p->solver);
+  if (p->solver == CDDP_HIP_SOLVER_MSIPDDP && p->n_constraints > 0 && !(p->nu == 1 || p->nx == p->nu))
+    return fail(-3, "MSIPDDP with path constraints is only defined for nu = 1 or nx = nu: the reference adds an (nx x nu) product to its (nu x nx) block Q_ux (msipddp_solver.cpp:1398)");
   if (p->solver == CDDP_HIP_SOLVER_LOGDDP && !(p->options.logddp_relaxed_delta > 0.0))
     return fail(-2, "Relaxation delta must be positive.");   // barrier.hpp:49-51
   // the device-resident retry loops (cddp_solver_base.cpp:93-111) terminate because the regularisation grows: a factor <= 1
@@ -369,6 +372,18 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
     delete h;
     return fail(-4, "LogDDP has no resident kernels for this layout (model=%d, nx=%d): use cddp_hip_plugin_solve", problem->model, problem->nx);
   }
+  if (h->P.solver == CDDP_HIP_SOLVER_MSIPDDP && !h->ks->has_msipddp) {
+    delete h;
+    return fail(-4, "MSIPDDP has no resident kernels for this layout (model=%d, nx=%d; terminal sets and nx > 8 are served by cddp_hip_plugin_solve)", problem->model, problem->nx);
+  }
+  if (h->P.solver == CDDP_HIP_SOLVER_MSIPDDP && !h->P.opt.use_ilqr) {
+    bool curved = false;
+    for (int c = 0; c < h->P.n_cons; ++c) { const int kd = h->P.cons[c].kind; if (kd != CDDP_HIP_CON_CONTROL_BOX && kd != CDDP_HIP_CON_STATE_BOX && kd != CDDP_HIP_CON_LINEAR) curved = true; }
+    if (curved || !h->ks->logddp_ddp) {
+      delete h;
+      return fail(-3, "MSIPDDP with use_ilqr=false is resident for plants with explicit Hessian tensors and constraint rows without curvature: use cddp_hip_plugin_solve");
+    }
+  }
   if (h->P.solver == CDDP_HIP_SOLVER_LOGDDP && !h->P.opt.use_ilqr && !h->ks->logddp_ddp) {
     delete h;
     return fail(-3, "LogDDP with use_ilqr=false needs the plant's explicit Hessian tensors, which model id %d keeps only in the blocked dual form: use cddp_hip_plugin_solve", problem->model);
@@ -393,9 +408,19 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
   const bool ip = (P.solver == CDDP_HIP_SOLVER_IPDDP);
   d.lg = (P.solver == CDDP_HIP_SOLVER_LOGDDP) ? 1 : 0;
+  const bool ms = (P.solver == CDDP_HIP_SOLVER_MSIPDDP);
+  d.ms = ms ? 1 : 0;
+  d.filt_cap = ms ? P.opt.max_iterations + 2 : kFilterCap;
 #define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { free_all(h); delete h; return rc_; } } while (0)
   DA(d.X, d.planeX * d.n_slots); DA(d.U, d.planeU * d.n_slots);
   if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
+  if (ms) {   // kernels_msipddp.hpp: slack / dual / constraint / costate / dynamics-value planes per slot, costate gains, factor cache
+    if (m > 0) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots);
+                 DA(d.ks, (size_t)N * m * Bp); DA(d.ky, (size_t)N * m * Bp); DA(d.Ks, (size_t)N * m * nx * Bp); DA(d.Ky, (size_t)N * m * nx * Bp); }
+    DA(d.Lam, d.planeX * d.n_slots); DA(d.F, d.planeX * d.n_slots);
+    DA(d.kl, (size_t)N * nx * Bp);
+    if (m == 0) DA(d.fac, (size_t)N * (nu * nu + nu + 1) * Bp);
+  }
   DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
   DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
   if (ip && nx > 8) DA(d.Kt, (size_t)N * (nu * nx + nu) * Bp);   // G = 16 sweeps (launch.hpp::t4_layout)
@@ -405,7 +430,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   double **scal[] = {&d.cost, &d.merit, &d.inf_pr, &d.inf_du, &d.inf_comp, &d.step_norm, &d.alpha_pr, &d.alpha_du, &d.reg, &d.mu,
                      &d.dV0, &d.dV1, &d.phi, &d.theta, &d.filter_theta, &d.apr_max, &d.adu_max};
   for (double **sp : scal) DA(*sp, Bp);
-  DA(d.filt, (size_t)2 * kFilterCap * Bp);
+  DA(d.filt, (size_t)2 * d.filt_cap * Bp);
   int **iscal[] = {&d.filt_n, &d.iter, &d.status, &d.phase, &d.cur, &d.n_bwd, &d.n_fwd, &d.bwd_ok};
   for (int **sp : iscal) DA(*sp, Bp);
   double **tr[] = {&d.t_cost, &d.t_merit, &d.t_theta, &d.t_inf_pr, &d.t_inf_comp, &d.t_apr, &d.t_adu, &d.t_ysmin, &d.t_ysmax};
@@ -542,7 +567,7 @@ static int in_set_initial(Inner *h, const double *x0, const double *U0, const do
 // solver state" afterwards -- the live slack / dual / costate rows are staged into slot 0 (and X, U too unless the
 // caller supplied a new trajectory since), see k_init.
 static int run_initialize(Inner *h) {
-  const bool ip = (h->P.solver == CDDP_HIP_SOLVER_IPDDP);
+  const bool ip = (h->P.solver == CDDP_HIP_SOLVER_IPDDP) || (h->P.solver == CDDP_HIP_SOLVER_MSIPDDP);   // slack / dual / costate rows staged for a warm re-solve
   int mode = kInitCold;
   if (h->P.opt.warm_start) mode = h->has_state ? kInitWarmExisting : kInitWarmProvided;
   if (mode == kInitWarmExisting) {
@@ -551,6 +576,12 @@ static int run_initialize(Inner *h) {
   } else {
     int rc = restore_initial(h); if (rc) return rc;
   }
+  if (h->d.ms) {   // the reference's factor cache belongs to the solver object, not to one solve: invalid only before the handle's first initialize
+    DevBuf dd = h->d;
+    dd.ms_fresh = h->ms_cache_started ? 0 : 1;
+    h->ks->init(dd, mode, h->stream);
+    h->ms_cache_started = true;
+  } else
   h->ks->init(h->d, mode, h->stream);
   h->has_state = true;
   h->initial_dirty = false;
@@ -576,6 +607,8 @@ static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   double al[CDDP_HIP_MAX_ALPHAS];
   const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS);
   if (na != h->P.n_alphas) return fail(-3, "the line-search ladder size is fixed at create time (%d alphas, new options give %d)", h->P.n_alphas, na);
+  if (h->d.ms && opt->max_iterations + 2 > h->d.filt_cap)
+    return fail(-3, "max_iterations cannot grow beyond %d on an MSIPDDP handle (filter capacity fixed by cddp_hip_create)", h->d.filt_cap - 2);
   if (opt->max_iterations + 1 > h->d.hist_cap && h->P.opt.return_iteration_info)
     return fail(-3, "max_iterations cannot grow beyond %d on a handle created with return_iteration_info (history capacity)", h->d.hist_cap - 1);
   if ((opt->return_iteration_info != 0) != (h->P.opt.return_iteration_info != 0))
@@ -1107,7 +1140,7 @@ static int in_get_linearization(Inner *h, double *A, double *Bm) {
 
 static int in_get_duals(Inner *h, double *S, double *Y, double *G) {
   if (!h) return fail(-1, "null handle");
-  if (h->P.solver != CDDP_HIP_SOLVER_IPDDP || h->P.m == 0) return fail(-1, "no slack/dual trajectories for this problem");
+  if ((h->P.solver != CDDP_HIP_SOLVER_IPDDP && h->P.solver != CDDP_HIP_SOLVER_MSIPDDP) || h->P.m == 0) return fail(-1, "no slack/dual trajectories for this problem");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   const DevBuf &d = h->d;

@@ -94,6 +94,13 @@ struct DevBuf {
   int *cand;                               // [Bp] best-merit rule: the trial whose costate K4b evaluates (k_pick_candidate), -1 = none
   int t4;                                  // 1: A / B / cst / te_cst stacks in the sub-tile-minor layout of the G = 16 cooperative sweeps (kernels.hpp::GT)
   int lg;                                  // 1: the handle runs LogDDP (kernels_logddp.hpp); ev = [n_slots][N][NSEG] parked barrier sums per trial slot
+  // MSIPDDP resident (kernels_msipddp.hpp)
+  int ms;                                  // 1: the handle runs MSIPDDP
+  int ms_fresh;                            // set per init launch: first initialize of the handle (the per-step factor cache starts invalid)
+  int filt_cap;                            // rows per half of d.filt when ms (max_iterations + 2: MSIPDDP never bounds its filter between barrier updates)
+  double *F;                               // [n_slots] planes (stride planeX): dynamics values f(x_t, u_t) of every iterate / trial, rows 0 .. N-1
+  double *kl;                              // [N][nx][Bp] costate feed-forward gains k_lambda of the last sweep (K_lambda = V_xx(t+1) is d.Vxx)
+  double *fac;                             // [N][nu nu + nu + 1][Bp] unconstrained branch: cached LDLT of Q_uu per step (matrix | transpositions | valid)
   int xcd_map;                             // cooperative sweeps: groups of one 64-trajectory tile on one XCD (kernels_coop.hpp::coop_group); CDDP_HIP_XCD_MAP=0 turns it off
 };
 

@@ -1,0 +1,937 @@
+// MSIPDDP on the device: the reference's multiple-shooting interior-point DDP (msipddp_solver.cpp:33-1930) for
+// the built-in plants, as K0 / K2 / K4 / K5 variants of the batched core -- the same handle, trial slots, phase machine, ladder shapes
+// and host loop as CLDDP / IPDDP / LogDDP (capi.hip::SolveRun), K1 (k_derivs: A_t = I + dt f_x, B_t = dt f_u) unchanged.  Rounds 3-4
+// served MSIPDDP through the plug-in boundary only (cddp_hip_plugin_solve: GPU sweeps on caller-built stacks, host rollouts, one
+// trajectory at a time); here the whole solve is resident:
+//
+//   K0  k_init_msipddp      grid (batch)        initialize: cold start, multiple-shooting start (warm_start with a state guess that is
+//                                               not rolled out), warm re-solve; duals / slacks / costates, evaluateTrajectory,
+//                                               resetBarrierFilter                              (msipddp_solver.cpp:33-264, 425-763)
+//   K2  k_backward_msipddp  grid (batch)        Riccati sweep with the defects d_t = F_t - x_{t+1}: unconstrained branch with the
+//                                               reference's per-step factor cache, path-constrained KKT condensation; costate gains
+//                                               k_lambda, K_lambda; retry loop                  (msipddp_solver.cpp:1112-1430)
+//   K4  k_forward_msipddp   grid (batch x n_a)  multiple-shooting rollout with the three gap-closing rules at the segment boundaries,
+//                                               slack / dual / costate trials, dual step-size search, cost, barrier merit, violation,
+//                                               multi-point filter test                         (msipddp_solver.cpp:1432-1724, 771-808)
+//   K5  k_update_msipddp    grid (batch)        selection rule, applyForwardPassResult, checkConvergence, forward-pass failure handling
+//                                               (filter restoration / regularisation), barrier update + resetBarrierFilter
+//                                               (cddp_solver_base.cpp:29-186, msipddp_solver.cpp:287-398, 1751-1930)
+//
+// One trajectory per lane; every sum in the reference's order (the CPU checker's plain loops, oracle/linalg.hpp), FMA contraction off,
+// the logarithm / power the shared straight-line routines (dev_trig.hpp) -- the checker's MSIPDDP in its trig_mode 1 runs the same
+// operations, so tests/test_msipddp_device.py compares decisions exactly.
+//
+// Two properties of the reference are restated AS THEY ARE (the checker and its numpy twin do the same):
+//   * msipddp_solver.cpp:1169-1185 -- the unconstrained sweep keeps one LDLT of Q_uu per step and refactors a step only while its cached
+//     factor is invalid: after the first sweep that reaches a step, every later sweep solves that step with the FIRST factor.  The cache
+//     ([N][nu nu + nu + 1] per trajectory, d.fac) lives as long as the handle (the reference's workspace outlives initialize());
+//   * msipddp_solver.cpp:1398 -- the constrained sweep adds the (nx x nu) product Q_yx^T Y S^-1 Q_yu to the (nu x nx) block Q_ux: defined
+//     for nu = 1 (same linear layout) and nx = nu (elementwise); the kernels are instantiated for exactly those shapes.
+#pragma once
+#include "kernels_logddp.hpp"
+
+namespace cddp_dev {
+
+#define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
+
+// ---- multi-point filter on the per-trajectory columns d.filt [2 * d.filt_cap][Bp] (merit rows, then violation rows).  MSIPDDP never
+// bounds the filter between barrier updates (it prunes only inside a failed iteration, :371-398), so the capacity is max_iterations + 2.
+DEV void ms_filter_add(const DevBuf &d, int b, double mf, double cv) {   // acceptFilterEntry (interior_point_utils.cpp:79-95)
+  const int cap = d.filt_cap;
+  const int n = d.filt_n[b];
+  for (int i = 0; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(cap + i) * d.Bp + b];
+    if (fm <= mf && fv <= cv) return;
+  }
+  int w = 0;
+  for (int i = 0; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(cap + i) * d.Bp + b];
+    if (!(mf <= fm && cv <= fv)) { d.filt[(size_t)w * d.Bp + b] = fm; d.filt[(size_t)(cap + w) * d.Bp + b] = fv; ++w; }
+  }
+  if (w < cap) { d.filt[(size_t)w * d.Bp + b] = mf; d.filt[(size_t)(cap + w) * d.Bp + b] = cv; ++w; }
+  d.filt_n[b] = w;
+}
+DEV void ms_filter_prune(const DevBuf &d, int b) {   // pruneFilterToBestPoints (interior_point_utils.cpp:114-139)
+  const int cap = d.filt_cap;
+  const int n = d.filt_n[b];
+  if (n == 0) return;
+  double bvm = d.filt[b], bvv = d.filt[(size_t)cap * d.Bp + b];
+  double bmm = bvm, bmv = bvv;
+  for (int i = 1; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(cap + i) * d.Bp + b];
+    if (fv < bvv) { bvm = fm; bvv = fv; }
+    if (fm < bmm) { bmm = fm; bmv = fv; }
+  }
+  d.filt[b] = bvm; d.filt[(size_t)cap * d.Bp + b] = bvv;
+  int w = 1;
+  if (fabs(bmv - bvv) > 1e-12 || fabs(bmm - bvm) > 1e-12) { d.filt[(size_t)1 * d.Bp + b] = bmm; d.filt[(size_t)(cap + 1) * d.Bp + b] = bmv; w = 2; }
+  d.filt_n[b] = w;
+}
+DEV bool ms_filter_acceptable(const DevBuf &d, int b, const cddp_hip_options &o, double mf, double cv, double expected) {   // isFilterAcceptable :771-808
+  const int cap = d.filt_cap;
+  const int n = d.filt_n[b];
+  if (n == 0) return true;
+  double best_v = INFINITY, best_m = INFINITY;
+  bool dominated = false;
+  for (int i = 0; i < n; ++i) {
+    const double fm = d.filt[(size_t)i * d.Bp + b], fv = d.filt[(size_t)(cap + i) * d.Bp + b];
+    if (fm <= mf && fv <= cv) dominated = true;
+    if (fv < best_v) { best_v = fv; best_m = fm; }
+  }
+  if (dominated) return false;
+  const bool v_imp = cv < best_v * (1.0 - o.filter_violation_acceptance_threshold);
+  const bool m_imp = mf < best_m - o.filter_merit_acceptance_threshold * cv;
+  if (cv < o.filter_min_violation_for_armijo_check && expected < 0) return mf < best_m + o.filter_armijo_constant * expected;
+  if (cv < 1e-6 && mf <= best_m * (1.0 + 1e-8)) return true;
+  return v_imp || m_imp;
+}
+
+// initial slack / dual pair of one row (msipddp_solver.cpp:578-596 == :667-685)
+DEV void ms_init_pair(const cddp_hip_options &o, double mu, double g, double &s, double &y) {
+  s = dmax(o.ipddp_slack_var_init_scale, -g);
+  y = (s < 1e-12) ? mu / 1e-12 : mu / s;
+  y = dmax(o.ipddp_dual_var_init_scale * 0.01, dmin(y, o.ipddp_dual_var_init_scale * 100.0));
+}
+
+// resetBarrierFilter (:711-763) on the iterate of `slot`: merit, violation, residuals under `mu`; the filter restarts from that point.
+template <class Model, class Cons>
+DEV void ms_reset_filter(const DevBuf &d, int b, int slot, double mu, double cost) {
+  constexpr int NX = Model::NX, M = Cons::M, MM = M > 0 ? M : 1, NSEG = Cons::NSEG;
+  double mf = cost, ipr = 0.0, fcv = 0.0, icomp = 0.0, idef = 0.0;
+  if constexpr (M > 0) {
+    const double *Sc = d.S + (size_t)slot * d.planeM, *Yc = d.Y + (size_t)slot * d.planeM, *Gc = d.G + (size_t)slot * d.planeM;
+    const double *Fc = d.F + (size_t)slot * d.planeX, *Xc = d.X + (size_t)slot * d.planeX;
+    for (int t = 0; t < d.N; ++t) {
+      double s[MM], y[MM], g[MM], f[NX], x1[NX];
+      ld<M>(Sc + GI(t, M, 0), kLS, s); ld<M>(Yc + GI(t, M, 0), kLS, y); ld<M>(Gc + GI(t, M, 0), kLS, g);
+      ld<NX>(Fc + GI(t, NX, 0), kLS, f); ld<NX>(Xc + GI(t + 1, NX, 0), kLS, x1);
+#pragma unroll
+      for (int c = 0; c < NSEG; ++c) {
+        const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+        double lsum = 0.0, l1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+          if (i < dim) {
+            const int j = off + i;
+            lsum += solver_log(s[j]);
+            const double pr = g[j] + s[j];
+            ipr = dmax(ipr, fabs(pr)); l1 += fabs(pr);
+            icomp = dmax(icomp, fabs(y[j] * s[j] - mu));
+          }
+        }
+        mf -= mu * lsum; fcv += l1;
+      }
+      double n1 = 0.0, ni = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { const double r = f[i] - x1[i]; ni = dmax(ni, fabs(r)); n1 += fabs(r); }
+      idef = dmax(idef, ni);
+      fcv += n1;
+    }
+  }
+  d.inf_pr[b] = dmax(ipr, idef); d.merit[b] = mf; d.phi[b] = mf; d.inf_comp[b] = icomp;
+  d.filter_theta[b] = fcv; d.theta[b] = fcv;
+  d.filt[b] = mf; d.filt[(size_t)d.filt_cap * d.Bp + b] = fcv; d.filt_n[b] = 1;
+}
+
+// computeScaledDualInfeasibility (:1886-1930): inf_du / max(1, mean(|y|_1 + |s|_1) / 100), sums constraint-major as the reference walks them
+template <class Model, class Cons>
+DEV double ms_scaled_inf_du(const DevBuf &d, int b, int slot, double inf_du) {
+  constexpr int NU = Model::NU, M = Cons::M, NSEG = Cons::NSEG;
+  if constexpr (M == 0) return inf_du;
+  else {
+    const double *Sc = d.S + (size_t)slot * d.planeM, *Yc = d.Y + (size_t)slot * d.planeM;
+    double yn = 0.0, sn = 0.0;
+#pragma unroll
+    for (int c = 0; c < NSEG; ++c) {
+      const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      for (int t = 0; t < d.N; ++t) {
+        double ya = 0.0, sa = 0.0;
+        for (int i = 0; i < dim; ++i) { ya += fabs(Yc[GI(t, M, off + i)]); sa += fabs(Sc[GI(t, M, off + i)]); }
+        yn += ya; sn += sa;
+      }
+    }
+    const int total = d.N * M;
+    const int mpn = total + NU * d.N;
+    const double num = mpn > 0 ? (yn + sn) / (double)mpn : 0.0;
+    const double sd = dmax(100.0, num) / 100.0;
+    return inf_du / sd;
+  }
+}
+
+// ================================================================================ K0
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_init_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int mode) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1;
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.n_active = d.B;
+  if (b >= d.B) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const bool existing = (mode == kInitWarmExisting);
+  d.cur[b] = 0;
+  d.iter[b] = 0; d.status[b] = CDDP_HIP_STATUS_RUNNING; d.phase[b] = PH_ACTIVE;
+  d.n_bwd[b] = 0; d.n_fwd[b] = 0; d.n_fwd_steps[b] = 0; d.bwd_ok[b] = 0; d.filt_n[b] = 0;
+  if (b < d.hist_batch) d.hist_n[b] = 0;
+  if (!existing) d.reg[b] = o.reg_initial_value;
+  d.dV0[b] = 0.0; d.dV1[b] = 0.0; d.step_norm[b] = 0.0; d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
+  double *X0 = d.X, *U0 = d.U, *F0 = d.F, *L0 = d.Lam;
+  typename Cons::Ctx cc;
+  Cons::load(P, cc);
+  if constexpr (M == 0) {   // the factor cache belongs to the solver object (ms_workspace): cleared on the handle's first initialize only
+    if (d.ms_fresh) for (int t = 0; t < N; ++t) d.fac[GI(t, NU * NU + NU + 1, NU * NU + NU)] = 0.0;
+  }
+  double mu, cost = 0.0;
+  if (mode == kInitCold) {   // :199-263
+    mu = (M == 0) ? 1e-8 : o.barrier_mu_initial;
+    // initializeDualSlackCostateVariables (:643-709): duals / slacks from the constraint values on the GUESS (X is rolled out below)
+    for (int t = 0; t < N; ++t) {
+      if constexpr (M > 0) {
+        double x[NX], u[NU], g[MM], s[MM], y[MM];
+        ld<NX>(X0 + GI(t, NX, 0), kLS, x); ld<NU>(U0 + GI(t, NU, 0), kLS, u);
+        Cons::template eval<NX, NU>(cc, x, u, g);
+#pragma unroll
+        for (int j = 0; j < M; ++j) ms_init_pair(o, mu, g[j], s[j], y[j]);
+        st<M>(d.S + GI(t, M, 0), kLS, s); st<M>(d.Y + GI(t, M, 0), kLS, y);
+      }
+      double lam[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = o.msipddp_costate_var_init_scale * 1.0;
+      st<NX>(L0 + GI(t, NX, 0), kLS, lam);
+    }
+    // evaluateTrajectory (:425-455): rollout from the initial state, constraint values and dynamics values of the rolled-out iterate
+    double x[NX];
+    ld<NX>(X0 + GI(0, NX, 0), kLS, x);
+    for (int t = 0; t < N; ++t) {
+      double u[NU], xn[NX];
+      ld<NU>(U0 + GI(t, NU, 0), kLS, u);
+      cost += Obj::running_cost(P, xrt, t, x, u);
+      if constexpr (M > 0) { double g[MM]; Cons::template eval<NX, NU>(cc, x, u, g); st<M>(d.G + GI(t, M, 0), kLS, g); }
+      Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+      st<NX>(F0 + GI(t, NX, 0), kLS, xn);
+      st<NX>(X0 + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+    cost += Obj::terminal_cost(P, x);
+  } else {
+    // warm start (:95-197).  existing: gains / duals / costates of the last solve (staged into slot 0 by k_stage); provided: the state
+    // guess is kept as it is -- the multiple-shooting start -- and the first iterate carries its defects
+    if (!existing) {
+      double lam[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = o.msipddp_costate_var_init_scale * 1.0;
+      for (int t = 0; t < N; ++t) st<NX>(L0 + GI(t, NX, 0), kLS, lam);
+    }
+    cost = INFINITY;   // CDDP::initializeProblemIfNecessary (cddp_core.cpp:297): kept when no trajectory evaluation follows
+    if (existing || M > 0) {   // evaluateTrajectoryWarmStart (:457-495)
+      cost = 0.0;
+      double x[NX];
+      ld<NX>(X0 + GI(0, NX, 0), kLS, x);
+      for (int t = 0; t < N; ++t) {
+        double u[NU], xn[NX];
+        ld<NU>(U0 + GI(t, NU, 0), kLS, u);
+        cost += Obj::running_cost(P, xrt, t, x, u);
+        if constexpr (M > 0) { double g[MM]; Cons::template eval<NX, NU>(cc, x, u, g); st<M>(d.G + GI(t, M, 0), kLS, g); }
+        Stepper<Model>::step(P->integrator, P->dt, P->mp, x, u, xn);
+        st<NX>(F0 + GI(t, NX, 0), kLS, xn);
+        if (o.msipddp_use_controlled_rollout) {
+          st<NX>(X0 + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        } else ld<NX>(X0 + GI(t + 1, NX, 0), kLS, x);
+      }
+      cost += Obj::terminal_cost(P, x);
+    } else {
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      for (int t = 0; t < N; ++t) st<NX>(F0 + GI(t, NX, 0), kLS, z);   // dynamics_trajectory_ stays zero (:120)
+    }
+    if (existing) mu = o.barrier_mu_initial * 0.1;
+    else if (M == 0) mu = 1e-8;
+    else {
+      double mv = 0.0;   // computeMaxConstraintViolation (interior_point_utils.cpp:141-155), constraint-major; a maximum is order-free
+      if constexpr (M > 0) {
+        for (int t = 0; t < N; ++t) { double g[MM]; ld<M>(d.G + GI(t, M, 0), kLS, g);
+#pragma unroll
+          for (int j = 0; j < M; ++j) mv = dmax(mv, g[j]); }
+      }
+      if (mv <= o.tolerance) mu = o.tolerance * 0.01;
+      else if (mv <= 0.1) mu = o.tolerance;
+      else mu = o.barrier_mu_initial * 0.1;
+    }
+    if constexpr (M > 0) {   // initializeDualSlackCostateVariablesWarmStart (:497-641)
+      constexpr int NSEG = Cons::NSEG;
+      for (int t = 0; t < N; ++t) {
+        double g[MM], s[MM], y[MM];
+        ld<M>(d.G + GI(t, M, 0), kLS, g);
+        if (existing) { ld<M>(d.S + GI(t, M, 0), kLS, s); ld<M>(d.Y + GI(t, M, 0), kLS, y); }
+#pragma unroll
+        for (int c = 0; c < NSEG; ++c) {
+          const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+          bool need = !existing;
+          if (existing) {
+            bool stop = false;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+              if (i < dim && !stop) {
+                const int j = off + i;
+                if (y[j] <= 1e-12 || s[j] <= 1e-12) { need = true; stop = true; }
+                else {
+                  const double required = dmax(o.ipddp_slack_var_init_scale, -g[j]);
+                  if (s[j] < 0.1 * required) { need = true; stop = true; }
+                }
+              }
+          }
+          if (need) {
+#pragma unroll
+            for (int i = 0; i < MM; ++i) if (i < dim) ms_init_pair(o, mu, g[off + i], s[off + i], y[off + i]);
+          }
+        }
+        st<M>(d.S + GI(t, M, 0), kLS, s); st<M>(d.Y + GI(t, M, 0), kLS, y);
+      }
+    }
+  }
+  d.cost[b] = cost; d.mu[b] = mu;
+  d.alpha_pr[b] = o.ls_initial_step_size; d.alpha_du[b] = 0.0;
+  d.inf_du[b] = INFINITY;
+  ms_reset_filter<Model, Cons>(d, b, 0, mu, cost);
+  hist_push(d, b, mu);
+}
+
+// ================================================================================ K2
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1;
+  constexpr int FAC = NU * NU + NU + 1;
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  const double *Fc = d.F + (size_t)cur * d.planeX;
+  const double *Lc = d.Lam + (size_t)cur * d.planeX;
+  if (count_iter) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  typename Cons::Ctx cc;
+  Cons::load(P, cc);
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, idu = 0, ipr = 0, icomp = 0, idef = 0, snorm = 0;
+  for (;;) {
+    ++nb;
+    double xN[NX], Vx[NX], Vxx[NX * NX];
+    ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+    Obj::final_grad(P, xN, Vx);
+    const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * ((2.0 * Qf[i * NX + c]) + (2.0 * Qf[c * NX + i]));   // :1122
+    st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
+    dV0 = 0; dV1 = 0; idu = 0; ipr = 0; icomp = 0; idef = 0; snorm = 0;
+    bool fail = false;
+    for (int t = N - 1; t >= 0; --t) {
+      double A[NX * NX], Bm[NX * NU], x[NX], u[NU], lam[NX], dd[NX];
+      ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
+      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
+      ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+      ld<NU>(Uc + GI(t, NU, 0), kLS, u);
+      ld<NX>(Lc + GI(t, NX, 0), kLS, lam);
+      {
+        double f[NX], x1[NX];
+        ld<NX>(Fc + GI(t, NX, 0), kLS, f); ld<NX>(Xc + GI(t + 1, NX, 0), kLS, x1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dd[i] = f[i] - x1[i];   // defect (:1129-1131)
+      }
+      double Vd[NX], w[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Vxx[i * NX + j] * dd[j];
+        Vd[i] = s; w[i] = Vx[i] + s; }
+      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
+      Obj::lx(P, xrt, t, x, Qx);
+      Obj::lu(P, u, Qu);
+      [[maybe_unused]] double y[MM], sv[MM], g[MM], Gx[MM * NX], Gu[MM * NU];
+      if constexpr (M > 0) {
+#pragma unroll
+        for (int i = 0; i < MM * NX; ++i) Gx[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM * NU; ++i) Gu[i] = 0.0;
+        Cons::template jac<NX, NU>(cc, x, u, Gx, Gu);
+        ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, y);
+        ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, sv);
+        ld<M>(d.G + (size_t)cur * d.planeM + GI(t, M, 0), kLS, g);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s += Gx[r * NX + i] * y[r];
+          Qx[i] = Qx[i] + s; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s += Gu[r * NU + i] * y[r];
+          Qu[i] = Qu[i] + s; }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += A[k * NX + i] * w[k];
+        Qx[i] = Qx[i] + s; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Bm[k * NU + i] * w[k];
+        Qu[i] = Qu[i] + s; }
+      q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+      if constexpr (Model::kHasHess) {   // full DDP: the tensors weighted with the costates (:1151-1163, :1279-1310); the rows of the
+        if (!o.use_ilqr) lg_tensor_terms<Model>(P, x, u, lam, Qxx, Qux, Quu);   // layouts served here have no second derivatives
+      }
+      double kk[NU], KK[NU * NX];
+      // k_lambda, K_lambda (:1195-1196 == :1383-1384): K_lambda = sym(V_xx(t+1)) is V_xx(t+1) itself (stored symmetric, d.Vxx[t+1])
+      {
+        double kl[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) kl[i] = ((0.0 - lam[i]) + Vx[i]) + Vd[i];
+        st<NX>(d.kl + GI(t, NX, 0), kLS, kl);
+      }
+      if constexpr (M == 0) {
+        double Qs[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qs[i * NU + i] += reg;
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] = Qs[i];   // the reference regularises Q_uu itself in this branch (:1166-1167)
+        LDLTs<NU> f;
+        double *fc = d.fac + GI(t, FAC, 0);
+        const bool valid = fc[(size_t)(NU * NU + NU) * kLS] != 0.0;
+        if (!valid) {
+          f.compute(Qs, NU);
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) fc[(size_t)i * kLS] = f.m[i];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) fc[(size_t)(NU * NU + i) * kLS] = (double)f.tr[i];
+          fc[(size_t)(NU * NU + NU) * kLS] = f.ok ? 1.0 : 0.0;   // a failed factor is dropped (:1178-1182)
+        } else {
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) f.m[i] = fc[(size_t)i * kLS];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) f.tr[i] = (int)fc[(size_t)(NU * NU + i) * kLS];
+          f.ok = true;
+        }
+        if (!f.ok) { fail = true; break; }
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+        }
+      } else {
+        double YS[MM], pres[MM], cres[MM], rhat[MM], Sir[MM];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          YS[i] = y[i] / sv[i];
+          pres[i] = g[i] + sv[i];
+          cres[i] = y[i] * sv[i] - mu; rhat[i] = y[i] * pres[i] - cres[i]; Sir[i] = rhat[i] / sv[i];
+        }
+        // T_u = Q_yu^T Y S^-1 (nu x m), T_x = Q_yx^T Y S^-1 (nx x m): one non-zero product per entry of the diagonal factor
+        double GuYG[NU * NU], GuYGx[NU * NX], GxYGx[NX * NX], GxYGu[NX * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+          for (int c = 0; c < NU; ++c) { double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) s += (Gu[r * NU + i] * YS[r]) * Gu[r * NU + c];
+            GuYG[i * NU + c] = s; }
+#pragma unroll
+          for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) s += (Gu[r * NU + i] * YS[r]) * Gx[r * NX + c];
+            GuYGx[i * NX + c] = s; }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) s += (Gx[r * NX + i] * YS[r]) * Gx[r * NX + c];
+            GxYGx[i * NX + c] = s; }
+#pragma unroll
+          for (int c = 0; c < NU; ++c) { double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) s += (Gx[r * NX + i] * YS[r]) * Gu[r * NU + c];
+            GxYGu[i * NU + c] = s; }
+        }
+        double Qr[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qr[i * NU + c] = (0.5 * (Quu[i * NU + c] + Quu[c * NU + i])) + GuYG[i * NU + c];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+        LDLTs<NU> f;
+        f.compute(Qr, NU);
+        if (!f.ok) { fail = true; break; }
+        double GuS[NU], GxS[NX];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s += Gu[r * NU + i] * Sir[r];
+          GuS[i] = s; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s += Gx[r * NX + i] * Sir[r];
+          GxS[i] = s; }
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + GuS[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + c] + GuYGx[i * NX + c];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) KK[i * NX + c] = -col[i];
+        }
+        double temp[MM], ky[MM], ksv[MM], Ky[MM * NX], Ks[MM * NX];
+#pragma unroll
+        for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < NU; ++i) s += Gu[r * NU + i] * kk[i];
+          temp[r] = s;
+          ky[r] = (rhat[r] + y[r] * s) / sv[r];
+          ksv[r] = (0.0 - pres[r]) - s; }
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) s += Gu[r * NU + i] * KK[i * NX + c];
+            Ky[r * NX + c] = YS[r] * (Gx[r * NX + c] + s);
+            Ks[r * NX + c] = (0.0 - Gx[r * NX + c]) - s; }
+        st<M>(d.ky + GI(t, M, 0), kLS, ky); st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+        st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky); st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ks);
+        // the condensed blocks (:1391-1400), Q_ux with the reference's layout (:1398)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qu[i] = Qu[i] + GuS[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Qx[i] = Qx[i] + GxS[i];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) Qxx[i] = Qxx[i] + GxYGx[i];
+        if constexpr (NU == 1) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) Qux[c] = Qux[c] + GxYGu[c];
+        } else {
+          static_assert(NX == NU, "msipddp_solver.cpp:1398 defines the constrained recursion for nu = 1 or nx = nu only");
+#pragma unroll
+          for (int i = 0; i < NU * NX; ++i) Qux[i] = Qux[i] + GxYGu[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Quu[i] = Quu[i] + GuYG[i];
+#pragma unroll
+        for (int r = 0; r < M; ++r) { ipr = dmax(ipr, fabs(pres[r])); icomp = dmax(icomp, fabs(cres[r])); }
+      }
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+      // dV, V_x, V_xx (:1198-1206 == :1402-1410):  V_x = Q_x + K^T Q_u + Q_ux^T k + (K^T Q_uu) k,  V_xx likewise, then symmetrised
+      { double s0 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) s0 += kk[i] * Qu[i];
+        dV0 += s0;
+        double s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double q = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) q += Quu[i * NU + j] * kk[j];
+          s1 += kk[i] * q; }
+        dV1 += 0.5 * s1; }
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qu[j]; bb += Qux[j * NX + i] * kk[j]; c += KtQ[i * NU + j] * kk[j]; }
+        Vx[i] = ((Qx[i] + a) + bb) + c;
+      }
+      double Vn[NX * NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qux[j * NX + c]; bb += Qux[j * NX + i] * KK[j * NX + c]; e += KtQ[i * NU + j] * KK[j * NX + c]; }
+          Vn[i * NX + c] = ((Qxx[i * NX + c] + a) + bb) + e;
+        }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * (Vn[i * NX + c] + Vn[c * NX + i]);
+      st<NX>(d.Vx + GI(t, NX, 0), kLS, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { idu = dmax(idu, fabs(Qu[i])); snorm = dmax(snorm, fabs(kk[i])); }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) idef = dmax(idef, fabs(dd[i]));
+    }
+    if (!fail) { ok = true; break; }
+    if (force == 2) break;   // single un-retried pass (step-level API)
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = idu; d.step_norm[b] = snorm;
+    if constexpr (M == 0) { d.inf_pr[b] = idef; d.inf_comp[b] = 0.0; }
+    else { d.inf_pr[b] = dmax(ipr, idef); d.inf_comp[b] = icomp; }
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }   // cddp_solver_base.cpp:98-109
+  d.phase[b] = PH_FWD1;   // no early convergence test (base-class default)
+}
+
+// ================================================================================ K4
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, NSEG = Cons::NSEG, MM = M > 0 ? M : 1;
+  typedef Objective<NX, NU> Obj;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int a = a0 + blockIdx.y;
+  (void)na;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const int slot = trial_slot(cur, a);
+  const double *Xc = d.X + (size_t)cur * d.planeX, *Uc = d.U + (size_t)cur * d.planeU;
+  const double *Fc = d.F + (size_t)cur * d.planeX, *Lc = d.Lam + (size_t)cur * d.planeX;
+  double *Xn = d.X + (size_t)slot * d.planeX, *Un = d.U + (size_t)slot * d.planeU;
+  double *Fn = d.F + (size_t)slot * d.planeX, *Ln = d.Lam + (size_t)slot * d.planeX;
+  const double alpha = P->alphas[a];
+  const double mu = d.mu[b];
+  const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const int seg = o.msipddp_segment_length, rtype = o.msipddp_rollout_type;
+  const int n_alphas = d.n_alphas;
+  atomicAdd(d.launched, 1ull);
+  DynCtx dc;
+  dc.load(P->integrator, P->dt, P->mp);
+  typename Obj::Ctx oc;
+  Obj::load(P, oc);
+  typename Cons::Ctx cc;
+  Cons::load(P, cc);
+  double x[NX];
+  ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // r.X[0] = initial state (:1443; X_[0] is the initial state for every iterate)
+  st<NX>(Xn + GI(0, NX, 0), kLS, x);
+  double cost = 0.0, merit_b = 0.0, cv = 0.0;
+  bool alive = true;
+  int steps = N;
+  unsigned int ymask = 0xffffffffu;      // dual step sizes of the ladder that keep every row above its fraction-to-boundary bound so far
+  for (int t = 0; t < N; ++t) {
+    double xo[NX], uo[NU], kk[NU], KK[NU * NX], dx[NX], u[NU];
+    ld<NX>(Xc + GI(t, NX, 0), kLS, xo);
+    ld<NU>(Uc + GI(t, NU, 0), kLS, uo);
+    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+    [[maybe_unused]] double sn[MM];
+    if constexpr (M > 0) {   // slack trial and its fraction-to-boundary test (:1547-1560): the trial is abandoned at the first violation
+      double so[MM], ksv[MM], Ks[MM * NX];
+      ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, so);
+      ld<M>(d.ks + GI(t, M, 0), kLS, ksv);
+      ld<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ks);
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ks[r * NX + j] * dx[j];
+        sn[r] = (so[r] + alpha * ksv[r]) + s;
+        if (alive && sn[r] < (1.0 - tau) * so[r]) { alive = false; steps = t; } }
+      st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
+      // dual trials y + a_y k_y + K_y dx for every a_y of the ladder (:1612-1644): feasibility only; the rows are written once a_y is known
+      double yo[MM], ky[MM], Ky[MM * NX];
+      ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, yo);
+      ld<M>(d.ky + GI(t, M, 0), kLS, ky);
+      ld<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ky[r * NX + j] * dx[j];
+        const double bound = (1.0 - tau) * yo[r];
+        for (int q = 0; q < n_alphas; ++q) {
+          const double yn = (yo[r] + P->alphas[q] * ky[r]) + s;
+          if (yn < bound) ymask &= ~(1u << q);
+        } }
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += KK[i * NX + j] * dx[j];
+      u[i] = (uo[i] + alpha * kk[i]) + s; }
+    {   // costate trial (:1466-1467 == :1639-1641): lambda + a k_lambda + K_lambda dx, K_lambda = V_xx(t+1)
+      double lo[NX], kl[NX], Kl[NX * NX], ln[NX];
+      ld<NX>(Lc + GI(t, NX, 0), kLS, lo);
+      ld<NX>(d.kl + GI(t, NX, 0), kLS, kl);
+      ld<NX * NX>(d.Vxx + GI(t + 1, NX * NX, 0), kLS, Kl);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Kl[i * NX + j] * dx[j];
+        ln[i] = (lo[i] + alpha * kl[i]) + s; }
+      st<NX>(Ln + GI(t, NX, 0), kLS, ln);
+    }
+    double fn[NX], xn[NX];
+    Stepper<Model>::step(dc, x, u, fn);
+    // next state: the dynamics value inside a segment, a gap-closing rule at a segment boundary (:1483-1509 == :1575-1601)
+    const bool boundary = (seg > 1) && ((t + 1) % seg == 0) && (t + 1 < N);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = fn[i];
+    if (boundary && rtype != 1) {
+      double fo[NX], x1[NX];
+      ld<NX>(Fc + GI(t, NX, 0), kLS, fo);
+      ld<NX>(Xc + GI(t + 1, NX, 0), kLS, x1);
+      if (rtype == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = (x1[i] + (fn[i] - fo[i])) + alpha * (fo[i] - x1[i]);
+      } else {   // "hybrid": linearised closed-loop step
+        double A[NX * NX], Bm[NX * NU];
+        ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
+        ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double lin = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) { double bk = 0.0;
+#pragma unroll
+            for (int q = 0; q < NU; ++q) bk += Bm[i * NU + q] * KK[q * NX + j];
+            lin += (A[i * NX + j] + bk) * dx[j]; }
+          double bkk = 0.0;
+#pragma unroll
+          for (int q = 0; q < NU; ++q) bkk += Bm[i * NU + q] * kk[q];
+          xn[i] = (x1[i] + lin) + alpha * ((bkk + fo[i]) - x1[i]);
+        }
+      }
+    }
+    cost += Obj::running_cost(oc, xrt, t, x, u);
+    if constexpr (M > 0) {   // constraint values, barrier and violation terms of the trial (:1650-1672)
+      double g[MM];
+      Cons::template eval<NX, NU>(cc, x, u, g);
+      st<M>(d.G + (size_t)slot * d.planeM + GI(t, M, 0), kLS, g);
+#pragma unroll
+      for (int c = 0; c < NSEG; ++c) {
+        const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+        double lsum = 0.0, l1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); l1 += fabs(g[off + i] + sn[off + i]); }
+        merit_b -= mu * lsum; cv += l1;
+      }
+      double n1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) n1 += fabs(fn[i] - xn[i]);
+      cv += n1;
+    }
+    st<NU>(Un + GI(t, NU, 0), kLS, u);
+    st<NX>(Fn + GI(t, NX, 0), kLS, fn);
+    st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  }
+  cost += Obj::terminal_cost(P, x);
+  const size_t ti = (size_t)a * d.Bp + b;
+  bool success = false;
+  double merit = cost, theta = 0.0, adu = 1.0;
+  if constexpr (M == 0) {   // :1516-1530: expected-reduction ratio test
+    const double dJ = d.cost[b] - cost;
+    const double expected = -alpha * (d.dV0[b] + 0.5 * alpha * d.dV1[b]);
+    const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+    success = ratio > 1e-6;
+  } else {
+    merit = merit_b + cost;
+    theta = cv;
+    int q_sel = -1;
+    for (int q = 0; q < n_alphas; ++q) if (q_sel < 0 && ((ymask >> q) & 1u)) q_sel = q;
+    if (alive && q_sel >= 0) {
+      adu = P->alphas[q_sel];
+      // the dual rows of the accepted dual step (:1627-1637)
+      for (int t = 0; t < N; ++t) {
+        double xo[NX], xt[NX], dx[NX], yo[MM], ky[MM], Ky[MM * NX], yn[MM];
+        ld<NX>(Xc + GI(t, NX, 0), kLS, xo); ld<NX>(Xn + GI(t, NX, 0), kLS, xt);
+        ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, yo);
+        ld<M>(d.ky + GI(t, M, 0), kLS, ky);
+        ld<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = xt[i] - xo[i];
+#pragma unroll
+        for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += Ky[r * NX + j] * dx[j];
+          yn[r] = (yo[r] + adu * ky[r]) + s; }
+        st<M>(d.Y + (size_t)slot * d.planeM + GI(t, M, 0), kLS, yn);
+      }
+      success = ms_filter_acceptable(d, b, o, merit, theta, alpha * d.dV0[b]);
+    }
+  }
+  d.t_steps[ti] = steps;
+  d.t_success[ti] = success ? 1 : 0;
+  d.t_cost[ti] = cost; d.t_merit[ti] = merit; d.t_theta[ti] = theta; d.t_inf_pr[ti] = theta; d.t_inf_comp[ti] = 0.0;
+  d.t_apr[ti] = alpha; d.t_adu[ti] = adu;
+}
+
+// ================================================================================ K5
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, int stage, int n1, int is_last_iter, int do_count) {
+  constexpr int M = Cons::M;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int ph = d.phase[b];
+  const int n_alphas = d.n_alphas;
+  int ladder_bin = -1;
+  if ((stage == 1 && ph == PH_FWD1) || (stage == 2 && ph == PH_FWD2)) {
+    const int lo = (stage == 1) ? 0 : 1;
+    const int hi = (stage == 1) ? n1 : n_alphas;
+    int win = -1;
+    if (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) {
+      for (int a = lo; a < hi && win < 0; ++a) if (d.t_success[(size_t)a * d.Bp + b] == 1) win = a;
+    } else {   // success && merit < best.merit, strict (cddp_solver_base.cpp:280-286)
+      double best = INFINITY;
+      for (int a = lo; a < hi; ++a) {
+        const size_t ti = (size_t)a * d.Bp + b;
+        if (d.t_success[ti] != 0 && d.t_merit[ti] < best) { best = d.t_merit[ti]; win = a; }
+      }
+    }
+    if (win < 0 && hi < n_alphas) { d.phase[b] = PH_FWD2; goto count; }
+    ladder_bin = (win >= 0) ? win : n_alphas;
+    {
+      double mu = d.mu[b];
+      bool running = true;
+      const bool fp_success = win >= 0;
+      if (fp_success) {
+        const size_t ti = (size_t)win * d.Bp + b;
+        const int old_cur = d.cur[b];
+        const double w_cost = d.t_cost[ti], w_merit = d.t_merit[ti], w_apr = d.t_apr[ti], w_adu = d.t_adu[ti], w_theta = d.t_theta[ti];
+        const double dJ = d.cost[b] - w_cost;
+        const int na_walked = (P->ls_rule == CDDP_HIP_LS_FIRST_SUCCESS) ? win + 1 : n_alphas;
+        int ns = d.n_fwd_steps[b];
+        for (int a = 0; a < na_walked; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
+        d.n_fwd[b] = d.n_fwd[b] + na_walked;
+        d.n_fwd_steps[b] = ns;
+        const int slot_now = trial_slot(old_cur, win);
+        d.cur[b] = slot_now;
+        // applyForwardPassResult (:287-304)
+        d.cost[b] = w_cost; d.merit[b] = w_merit; d.phi[b] = w_merit; d.alpha_pr[b] = w_apr; d.alpha_du[b] = w_adu;
+        ms_filter_add(d, b, w_merit, w_theta);
+        hist_push(d, b, mu);
+        d.reg[b] = reg_decrease(o, d.reg[b]);
+        // checkConvergence (:306-364): the residuals are those of the last backward pass / filter reset, the duals the new iterate's
+        const double ipr = d.inf_pr[b], icomp = d.inf_comp[b];
+        const double metric = dmax(dmax(ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]), ipr), icomp);
+        int st = CDDP_HIP_STATUS_RUNNING;
+        const int iter = d.iter[b];
+        if (metric <= o.tolerance) st = CDDP_HIP_STATUS_OPTIMAL;
+        else if (fabs(dJ) < o.acceptable_tolerance && iter > 10 && ipr < sqrt(o.acceptable_tolerance) && icomp < sqrt(o.acceptable_tolerance)) st = CDDP_HIP_STATUS_ACCEPTABLE;
+        else if (iter >= 1 && d.step_norm[b] < o.tolerance * 10.0 && ipr < 1e-4) st = CDDP_HIP_STATUS_ACCEPTABLE;
+        if (st != CDDP_HIP_STATUS_RUNNING) { d.status[b] = st; d.phase[b] = PH_DONE; running = false; }
+      } else {
+        // handleForwardPassFailure (:371-398) with checkAndPerformFilterRestoration (:810-836)
+        const int nf0 = d.n_fwd[b]; int ns = d.n_fwd_steps[b];
+        for (int a = 0; a < n_alphas; ++a) ns += d.t_steps[(size_t)a * d.Bp + b];
+        d.n_fwd[b] = nf0 + n_alphas;
+        d.n_fwd_steps[b] = ns;
+        const int fn = d.filt_n[b];
+        bool needs = fn > 5;
+        if (!needs)
+          for (int i = 0; i < fn; ++i)
+            if (!dfinite(d.filt[(size_t)i * d.Bp + b]) || !dfinite(d.filt[(size_t)(d.filt_cap + i) * d.Bp + b])) { needs = true; break; }
+        if (needs && fn > 0) ms_filter_prune(d, b);
+        else {
+          const double reg = reg_increase(o, d.reg[b]);
+          d.reg[b] = reg;
+          if (reg >= o.reg_max_value) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; running = false; }
+        }
+      }
+      if (running) {
+        // postIterationUpdate -> updateBarrierParameters (:1751-1850)
+        if constexpr (M > 0) {
+          const int slot_now = d.cur[b];
+          bool reset = false;
+          if (o.barrier_strategy == CDDP_HIP_BARRIER_MONOTONIC) {
+            mu = dmax(o.barrier_mu_min_value, o.barrier_mu_update_factor * mu);
+            reset = true;
+          } else {
+            const double metric = dmax(dmax(ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]), d.inf_pr[b]), d.inf_comp[b]);
+            if (o.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
+              if (metric <= 10.0 * mu) {
+                const double lin = o.barrier_mu_update_factor * mu, sup = solver_pow(mu, o.barrier_mu_update_power);
+                mu = dmax(o.tolerance / 10.0, dmin(lin, sup));
+                reset = true;
+              }
+            } else {
+              const double threshold = (mu < 1e-5) ? dmax(metric * 10.0, mu * 100.0) : dmax(o.barrier_mu_update_factor * mu, mu * 2.0);
+              const bool slow = fp_success && d.alpha_pr[b] > 0 && (metric < 1e-3);
+              if (metric <= threshold || slow) {
+                double factor = o.barrier_mu_update_factor;
+                if (mu > 1e-12) {
+                  const double ratio = metric / mu;
+                  if (ratio < 0.01) factor = o.barrier_mu_update_factor * 0.1;
+                  else if (ratio < 0.1) factor = o.barrier_mu_update_factor * 0.3;
+                  else if (ratio < 0.5) factor = o.barrier_mu_update_factor * 0.6;
+                }
+                const double lin = factor * mu, sup = solver_pow(mu, o.barrier_mu_update_power);
+                if (slow && mu > o.tolerance) mu = dmin(lin, sup);
+                else mu = dmax(o.tolerance / 100.0, dmin(lin, sup));
+                reset = true;
+              }
+            }
+          }
+          if (reset) { d.mu[b] = mu; ms_reset_filter<Model, Cons>(d, b, slot_now, mu, d.cost[b]); }
+        }
+        d.phase[b] = PH_ACTIVE;
+      }
+    }
+  }
+count:
+  if (d.win_hist) {
+    for (int a = 0; a <= n_alphas; ++a) {
+      const unsigned long long m = __ballot(ladder_bin == a);
+      if (m != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(d.win_hist + a, (int)__popcll(m));
+    }
+  }
+  if (do_count) {
+    if (is_last_iter && d.phase[b] != PH_DONE) { d.status[b] = CDDP_HIP_STATUS_MAX_ITERATIONS; d.phase[b] = PH_DONE; }
+    if (d.phase[b] != PH_DONE) atomicAdd(d.n_active, 1);
+  }
+}
+
+#undef GI
+}  // namespace cddp_dev

@@ -8,6 +8,7 @@
 #include "kernels_elem.hpp"
 #include "kernels_mfma.hpp"
 #include "kernels_logddp.hpp"
+#include "kernels_msipddp.hpp"
 
 namespace cddp_dev {
 
@@ -25,6 +26,8 @@ struct KernelSet {
   void (*init)(const DevBuf &, int mode, hipStream_t);
   void (*stage)(const DevBuf &, int copy_xu, int ipddp, hipStream_t);
   bool logddp_ddp;   // LogDDP with use_ilqr = 0: the plant has explicit Hessian tensors (Model::kHasHess)
+  bool has_msipddp;  // the MSIPDDP kernels (kernels_msipddp.hpp) are instantiated for this layout: nx <= 8, no terminal set, and -- with path
+                     // constraints -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines)
   bool has_logddp;   // the LogDDP kernels (kernels_logddp.hpp) are instantiated for this layout: one lane per trajectory, nx <= 8, no terminal set
   int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
 };
@@ -48,6 +51,12 @@ struct Launcher {
 #define CDDP_LOGDDP_MAX_NX 16
 #endif
   static constexpr bool kLog = !TERM && Model::NX <= CDDP_LOGDDP_MAX_NX;
+  // MSIPDDP on the device (kernels_msipddp.hpp): one-lane kernels, register-resident shapes only; with path constraints only the shapes
+  // for which the reference's recursion is defined
+#ifndef CDDP_MSIPDDP_MAX_NX
+#define CDDP_MSIPDDP_MAX_NX 8
+#endif
+  static constexpr bool kMs = !TERM && Model::NX <= CDDP_MSIPDDP_MAX_NX && (Cons::M == 0 || Model::NU == 1 || Model::NX == Model::NU);
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static bool lane_sweep_requested() {   // read per launch (the tests switch it between solves of one process)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
@@ -115,6 +124,10 @@ struct Launcher {
     // (clddp_solver.cpp:79-204 ignores use_ilqr), so it keeps the cooperative sweep
     if (solver == CDDP_HIP_SOLVER_LOGDDP) {
       if constexpr (kLog) hipLaunchKernelGGL((k_backward_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      return;
+    }
+    if (solver == CDDP_HIP_SOLVER_MSIPDDP) {
+      if constexpr (kMs) hipLaunchKernelGGL((k_backward_msipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       return;
     }
     const bool lane_sweep = lane_sweep_requested() || (d.ddp && solver == CDDP_HIP_SOLVER_IPDDP);
@@ -191,6 +204,10 @@ struct Launcher {
       if constexpr (kLog) hipLaunchKernelGGL((k_forward_logddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
       return;
     }
+    if (solver == CDDP_HIP_SOLVER_MSIPDDP) {
+      if constexpr (kMs) hipLaunchKernelGGL((k_forward_msipddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      return;
+    }
     if (solver == CDDP_HIP_SOLVER_CLDDP)
       hipLaunchKernelGGL((k_forward_clddp<Model>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
     else
@@ -217,7 +234,7 @@ struct Launcher {
   }
   // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
-    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP || solver == CDDP_HIP_SOLVER_LOGDDP) return;
+    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP || solver == CDDP_HIP_SOLVER_LOGDDP || solver == CDDP_HIP_SOLVER_MSIPDDP) return;
     if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
     if constexpr (Model::NX > 8) {
       if (!force && first_only != 0) {   // one trial per trajectory: the streaming kernel (2 - 4 waves per SIMD instead of one)
@@ -232,6 +249,10 @@ struct Launcher {
       if constexpr (kLog) hipLaunchKernelGGL((k_update_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, stage, n1, is_last, do_count);
       return;
     }
+    if (d.ms) {
+      if constexpr (kMs) hipLaunchKernelGGL((k_update_msipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, stage, n1, is_last, do_count);
+      return;
+    }
     DevBuf dd = d;
     if constexpr (kTeCoop && Cons::M > 0) dd.ev_valid = (d.te_cst && !(lane_sweep_requested() || d.ddp)) ? 1 : 0;
     hipLaunchKernelGGL((k_update<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, dd, d.P, d.xref_traj, stage, n1, is_last, do_count);
@@ -239,6 +260,10 @@ struct Launcher {
   static void init(const DevBuf &d, int mode, hipStream_t s) {
     if (d.lg) {
       if constexpr (kLog) hipLaunchKernelGGL((k_init_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
+      return;
+    }
+    if (d.ms) {
+      if constexpr (kMs) hipLaunchKernelGGL((k_init_msipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
       return;
     }
     hipLaunchKernelGGL((k_init<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, mode);
@@ -250,7 +275,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess; k.has_msipddp = kMs;
     return k;
   }
 };
