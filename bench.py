@@ -79,7 +79,7 @@ def algorithmic_bytes(nx, nu, N, m, ipddp):
 
 
 def make_problem(api, workload, solver):
-    sv = {"ipddp": api.SOLVER_IPDDP, "clddp": api.SOLVER_CLDDP, "logddp": api.SOLVER_LOGDDP}[solver]
+    sv = {"ipddp": api.SOLVER_IPDDP, "clddp": api.SOLVER_CLDDP, "logddp": api.SOLVER_LOGDDP, "msipddp": api.SOLVER_MSIPDDP}[solver]
     if workload == "cartpole_unc":
         p = api.cartpole_problem(sv, False)
         spread = [0.1, 0.3, 0.1, 0.1]
@@ -171,7 +171,7 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
 
     st = stats of the last timed step, prof = stats of the untimed solve with every class bracketed, stats = all timed steps
     (they bracket the dominant class only)."""
-    ipddp = solver == "ipddp"
+    ipddp = solver in ("ipddp", "msipddp")   # MSIPDDP: the interior-point byte model (its costate / defect rows are not credited)
     b_fill, b_bwd, b_fwd = algorithmic_bytes(p.nx, p.nu, p.N, m, ipddp)
     # the dominant class: hipEvent time inside the timed steps; the others: from the profiling solve
     bwd_ms = float(np.mean([s.backward_ms for s in stats])) if sweep_dominates else float(prof.backward_ms)
@@ -186,12 +186,14 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
     gbps_bwd = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     gbps_fwd = bytes_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
     gbps_all = (bytes_bwd + bytes_fwd) / (solve_ms * 1e-3) / 1e9
-    lean = ipddp and m > 0
+    lean = solver == "ipddp" and m > 0
     if sweep_dominates:
         if workload == "manip7" and ipddp:
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
             sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
+        elif solver == "msipddp":  # one-lane kernels of the resident MSIPDDP (kernels_msipddp.hpp)
+            sweep_label = "k_derivs+k_backward_msipddp"
         elif solver == "logddp":   # one-lane kernels of the resident LogDDP (kernels_logddp.hpp); scored with CLDDP's byte model (the
             sweep_label = "k_derivs+k_backward_logddp"   # barrier rows it also reads are not credited)
         else:
@@ -247,6 +249,7 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
 OTHER_WORKLOADS = [
     ("cartpole", "clddp", "C2 cart-pole CLDDP (BoxQP core), B=4096"),
     ("cartpole", "logddp", "f4: cart-pole LogDDP resident on the device (relaxed log barrier of the control box), B=4096"),
+    ("pendulum", "msipddp", "f4: pendulum MSIPDDP resident on the device (multiple shooting, segment length 5, control box), B=4096"),
     ("unicycle", "ipddp", "C3 unicycle N=200 box+ball, B=8192"),
     ("quadrotor", "ipddp", "C4 share: quadrotor nx=12 N=400, B=2048 (16384 / 8 GPUs)"),
     ("manip7", "ipddp", "C5 share: 7-joint arm nx=14 nu=7 N=150 terminal equality, 16 alphas, B=4096 (32768 / 8 GPUs)"),
@@ -387,7 +390,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: the BASELINE config's per-GPU batch of the workload)")
-    ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp", "logddp"])
+    ap.add_argument("--solver", default="ipddp", choices=["ipddp", "clddp", "logddp", "msipddp"])
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "cartpole_unc", "unicycle", "pendulum", "quadrotor", "manip7"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",

@@ -17,7 +17,7 @@
 //                                               (filter restoration / regularisation), barrier update + resetBarrierFilter
 //                                               (cddp_solver_base.cpp:29-186, msipddp_solver.cpp:287-398, 1751-1930)
 //
-// One trajectory per lane; every sum in the reference's order (the CPU checker's plain loops, oracle/linalg.hpp), FMA contraction off,
+// One trajectory per lane; every sum in the reference's order (plain triple loops, k ascending: what the CPU checker runs), FMA contraction off,
 // the logarithm / power the shared straight-line routines (dev_trig.hpp) -- the checker's MSIPDDP in its trig_mode 1 runs the same
 // operations, so tests/test_msipddp_device.py compares decisions exactly.
 //

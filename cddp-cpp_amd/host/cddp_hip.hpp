@@ -679,6 +679,8 @@ class CDDP {
   // flatten to the C-ABI descriptor (buffers stay owned by *this / scratch)
   struct Flat { cddp_hip_problem p; std::vector<cddp_hip_constraint> cons; std::vector<cddp_hip_terminal_constraint> terms; std::vector<double> xref_traj; };
   void flatten(int solver, Flat &f) const;
+  int numPathConstraints() const { return (int)path_constraint_set_.size(); }
+  int numTerminalConstraints() const { return (int)terminal_constraint_set_.size(); }
   void initializeProblemIfNecessary();
 
  private:
@@ -719,7 +721,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     ctx.inf_pr_ = s[0].final_primal_infeasibility; ctx.inf_du_ = s[0].final_dual_infeasibility; ctx.inf_comp_ = s[0].final_complementary_infeasibility;
     return s[0];
   }
-  // NEW (no reference counterpart): one device-resident batch.  LogDDP batches of a built-in plant with nx <= 8 run on the
+  // NEW (no reference counterpart): one device-resident batch.  LogDDP / MSIPDDP batches of a built-in plant with nx <= 8 run on the
   // resident LogDDP kernels (round 4, csrc/kernels_logddp.hpp: shared straight-line log / sin / cos, the arithmetic the parity
   // tests pin); solve() keeps LogDDP on the plug-in route (host loop in the host libm, the reference's own arithmetic).
   std::vector<CDDPSolution> solveBatch(CDDP &ctx, const std::vector<Vector> &x0s) { resident_batch_ = true; create(ctx, x0s); resident_batch_ = false; return collect(ctx, (int)x0s.size()); }
@@ -733,7 +735,12 @@ class HipBatchSolver : public ISolverAlgorithm {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
     const bool resident_logddp = kind_ == CDDP_HIP_SOLVER_LOGDDP && resident_batch_ && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8;
-    plugin_ = ctx.needsHostPlugins() || (kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || kind_ == CDDP_HIP_SOLVER_MSIPDDP;   // MSIPDDP, single LogDDP solves: host loop + stack-fed GPU sweeps
+    // MSIPDDP batches: resident (csrc/kernels_msipddp.hpp) for a built-in plant with nx <= 8, no terminal set and -- once a path constraint
+    // is present -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines)
+    const bool resident_msipddp = kind_ == CDDP_HIP_SOLVER_MSIPDDP && resident_batch_ && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8 &&
+                                  ctx.numTerminalConstraints() == 0 &&
+                                  (ctx.numPathConstraints() == 0 || ctx.getSystem().getControlDim() == 1 || ctx.getSystem().getStateDim() == ctx.getSystem().getControlDim());
+    plugin_ = ctx.needsHostPlugins() || (kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || (kind_ == CDDP_HIP_SOLVER_MSIPDDP && !resident_msipddp);   // single LogDDP / MSIPDDP solves: host loop + stack-fed GPU sweeps
     if (plugin_) {
       const DynamicalSystem &sys = ctx.getSystem();
       nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;
@@ -915,7 +922,7 @@ class HipBatchSolver : public ISolverAlgorithm {
         const double *row = hist.data() + ((size_t)b * (max_it_ + 1) + i) * 9;
         s.history.objective.push_back(row[0]); s.history.merit_function.push_back(row[1]); s.history.step_length_primal.push_back(row[2]);
         s.history.step_length_dual.push_back(row[3]); s.history.dual_infeasibility.push_back(row[4]); s.history.primal_infeasibility.push_back(row[5]);
-        s.history.complementary_infeasibility.push_back(row[6]); if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP) s.history.barrier_mu.push_back(row[7]); s.history.regularization.push_back(row[8]);
+        s.history.complementary_infeasibility.push_back(row[6]); if (kind_ == CDDP_HIP_SOLVER_IPDDP || kind_ == CDDP_HIP_SOLVER_LOGDDP || kind_ == CDDP_HIP_SOLVER_MSIPDDP) s.history.barrier_mu.push_back(row[7]); s.history.regularization.push_back(row[8]);
       }
     }
     return out;
@@ -978,7 +985,7 @@ inline void CDDP::flatten(int solver, Flat &f) const {
   }
   p.n_constraints = (int)f.cons.size(); p.constraints = f.cons.empty() ? nullptr : f.cons.data();
   p.n_terminal = (int)f.terms.size(); p.terminal = f.terms.empty() ? nullptr : f.terms.data();
-  p.options = options_.toPOD();
+  p.options = options_.toPOD(solver == CDDP_HIP_SOLVER_MSIPDDP);
 }
 
 inline CDDPSolution CDDP::solve(const std::string &solver_type) {

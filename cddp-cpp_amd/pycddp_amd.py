@@ -699,6 +699,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         self._opt = options if options is not None else CDDPOptions()
         self._sys = None; self._obj = None; self._cons = {}; self._terms = {}
         self._X = None; self._U = None
+        self.msipddp_route = "auto"   # NEW: the same switch for MSIPDDP (resident kernels: csrc/kernels_msipddp.hpp)
         self.logddp_route = "auto"    # NEW: "auto" (solve_batch of an eligible problem -> resident kernels, else the plug-in route) | "plugin" | "resident"
 
     # -- setters (snake_case names of the pybind layer)
@@ -768,7 +769,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         traj = ob.reference_states if ob.reference_states else None
         p = api.Problem(solver_kind, s.model, _INTEGRATORS[s.integration_type], s.state_dim, s.control_dim, self._N, self._dt,
                         ob.Q, ob.R, ob.Qf, ob.reference_state, model_params=s.params, lti_A=s.lti_A, lti_B=s.lti_B,
-                        x_ref_traj=None if traj is None else np.stack(traj), options=self._opt.to_pod())
+                        x_ref_traj=None if traj is None else np.stack(traj), options=self._opt.to_pod(msipddp=(solver_kind == api.SOLVER_MSIPDDP)))
         for name in sorted(self._cons):          # std::map order
             c = self._cons[name]
             if isinstance(c, StateConstraint): p.add_state_box(name, c.lower, c.upper, c.scale)
@@ -797,13 +798,20 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         resident_logddp = eligible and self.logddp_route != "plugin" and (resident_batch or self.logddp_route == "resident")
         if name == "LogDDP" and not resident_logddp:
             return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
-        if name == "MSIPDDP":            # same route; path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
+        # MSIPDDP: same split (round 4, csrc/kernels_msipddp.hpp): solve_batch() of a built-in plant with nx <= 8, no terminal set and --
+        # with path constraints -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines) is one device-resident batch
+        ms_eligible = (name == "MSIPDDP" and self._sys is not None and not self._needs_host_plugins() and self._sys.state_dim <= 8 and not self._terms
+                       and (not self._cons or self._sys.control_dim == 1 or self._sys.state_dim == self._sys.control_dim))
+        if name == "MSIPDDP" and self.msipddp_route == "resident" and not ms_eligible:
+            raise NotImplementedError("the resident MSIPDDP kernels serve built-in plants with nx <= 8, built-in objective / constraints, no terminal set, and nu = 1 or nx = nu once a path constraint is present")
+        resident_msipddp = ms_eligible and self.msipddp_route != "plugin" and (resident_batch or self.msipddp_route == "resident")
+        if name == "MSIPDDP" and not resident_msipddp:   # path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
             return self._solve_plugins(name, api.SOLVER_MSIPDDP, x0s)
-        if name not in ("CLDDP", "IPDDP", "LogDDP"):
+        if name not in ("CLDDP", "IPDDP", "LogDDP", "MSIPDDP"):
             sol = CDDPSolution()                 # cddp_core.cpp:243-265: unknown names do not throw
             sol.solver_name = name; sol.status_message = "UnknownSolver - No solver registered for '%s'" % name
             return [sol for _ in range(len(x0s))]
-        kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_LOGDDP if name == "LogDDP" else api.SOLVER_CLDDP
+        kind = api.SOLVER_IPDDP if name == "IPDDP" else api.SOLVER_LOGDDP if name == "LogDDP" else api.SOLVER_MSIPDDP if name == "MSIPDDP" else api.SOLVER_CLDDP
         if self._needs_host_plugins():
             return self._solve_plugins(name, kind, x0s)
         p = self._problem(kind)
@@ -838,7 +846,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                 s.history.step_length_primal = list(h[:, 2]); s.history.step_length_dual = list(h[:, 3])
                 s.history.dual_infeasibility = list(h[:, 4]); s.history.primal_infeasibility = list(h[:, 5])
                 s.history.complementary_infeasibility = list(h[:, 6])
-                s.history.barrier_mu = list(h[:, 7]) if name in ("IPDDP", "LogDDP") else []   # logddp_solver.cpp:278-284
+                s.history.barrier_mu = list(h[:, 7]) if name in ("IPDDP", "LogDDP", "MSIPDDP") else []   # logddp_solver.cpp:278-284
                 s.history.regularization = list(h[:, 8])
             out.append(s)
         return out

@@ -73,10 +73,17 @@ enum cddp_hip_solver {
                                   LogDDP ignores them; result.barrier_mu = mu, result.inf_pr = the violation of the last resetFilter);
                                   scratch-backed above; full DDP only for plants with explicit Hessian tensors); user plug-ins:
                                   cddp_hip_plugin_solve (host loop + stack-fed GPU sweeps) */
-  CDDP_HIP_SOLVER_MSIPDDP = 3  /* msipddp_solver.cpp: multiple-shooting interior-point DDP (costates, dynamics defects at segment
-                                  boundaries); served by cddp_hip_plugin_solve like LogDDP.  Path constraints with nu > 1 and nx != nu are
-                                  refused: the reference adds an (nx x nu) product to its (nu x nx) block Q_ux there (msipddp_solver.cpp:1398),
-                                  which is only defined for nu = 1 (same linear layout) or nx = nu */
+  CDDP_HIP_SOLVER_MSIPDDP = 3  /* msipddp_solver.cpp:33-1930: multiple-shooting interior-point DDP (costates, dynamics defects at segment
+                                  boundaries, three gap-closing rollout rules, multi-point filter).  Device-resident through cddp_hip_create /
+                                  cddp_hip_solve for the built-in plants with nx <= 8 and no terminal set (round 4, csrc/kernels_msipddp.hpp;
+                                  options msipddp_*, ipddp_slack / dual init scales, barrier_*, filter_*, regularisation and line-search
+                                  fields; warm_start with a state guess in cddp_hip_set_initial is the multiple-shooting start: the guess
+                                  is NOT rolled out; result.barrier_mu = mu; cddp_hip_get_duals returns its slacks / duals); user
+                                  plug-ins, nx > 8 and terminal sets: cddp_hip_plugin_solve (host loop + stack-fed GPU sweeps).  Path
+                                  constraints with nu > 1 and nx != nu are refused by both routes: the reference adds an (nx x nu) product
+                                  to its (nu x nx) block Q_ux there (msipddp_solver.cpp:1398), which is only defined for nu = 1 (same
+                                  linear layout) or nx = nu.  The unconstrained branch keeps the reference's per-step factor cache
+                                  (msipddp_solver.cpp:1169-1185) for the lifetime of the handle */
 };
 
 /* Path-constraint kinds (reference include/cddp-cpp/cddp_core/constraint.hpp:144-404). */

@@ -328,6 +328,31 @@ static void gpu_tests() {
     EXPECT_TRUE(!sols[0].history.barrier_mu.empty() && sols[0].history.barrier_mu.size() == sols[0].history.objective.size());
     std::cout << "LogDDP batch (resident): " << sols[0].status_message << " iterations " << sols[0].iterations_completed << " mu " << sols[0].final_barrier_mu << "\n";
   }
+  {   // round 4: an MSIPDDP batch runs on the resident kernels (csrc/kernels_msipddp.hpp): multiple-shooting rollouts, costates, filter
+      // and barrier update on the device; every trajectory keeps the torque box (interior point: strictly), ends dynamically consistent
+      // (the gap-closing rule has removed the defects), and trajectory 0's history carries the barrier parameter
+    std::cerr << "[block] batched MSIPDDP (resident)" << std::endl;
+    cddp::CDDP solver = makePendulum(opt);
+    std::vector<cddp::Vector> x0s;
+    for (int b = 0; b < 96; ++b) x0s.push_back({3.14159265358979323846 - 0.002 * b, 0.0});
+    std::vector<cddp::CDDPSolution> sols = solver.solveBatch("MSIPDDP", x0s);
+    EXPECT_EQ((int)sols.size(), 96);
+    int ok = 0, conv = 0;
+    for (auto &s : sols) {
+      EXPECT_TRUE(s.solver_name == "MSIPDDP" && s.iterations_completed > 0);
+      for (auto &u : s.control_trajectory) EXPECT_TRUE(u[0] <= 20.0 + 1e-9 && u[0] >= -20.0 - 1e-9);
+      ok += (s.history.objective.empty() || s.final_objective < s.history.objective.front());
+      conv += (s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound");
+    }
+    EXPECT_TRUE(ok == 96);
+    EXPECT_TRUE(conv >= 90);
+    EXPECT_TRUE(!sols[0].history.barrier_mu.empty() && sols[0].history.barrier_mu.size() == sols[0].history.objective.size());
+    cddp::CDDP single = makePendulum(opt);   // the plug-in route (host loop, host libm) solves the same problem: same answer to solver tolerance
+    cddp::CDDPSolution one = single.solve("MSIPDDP");
+    EXPECT_TRUE(std::fabs(one.final_objective - sols[0].final_objective) <= 1e-3 * std::max(1.0, std::fabs(one.final_objective)));
+    std::cout << "MSIPDDP batch (resident): " << sols[0].status_message << " iterations " << sols[0].iterations_completed << " objective " << sols[0].final_objective
+              << " (plug-in route: " << one.iterations_completed << " iterations, " << one.final_objective << ")\n";
+  }
   {   // terminal equality constraint (tests/cddp_core/test_ipddp_solver.cpp:1580-1637 style): x_N pinned to the target
     std::cerr << "[block] terminal equality" << std::endl;
     cddp::CDDPOptions o2 = opt; o2.max_iterations = 100;

@@ -309,3 +309,44 @@ def test_undefined_constrained_shape_is_refused(api):
     p.c.solver = api.SOLVER_MSIPDDP
     with pytest.raises(RuntimeError, match="1398"):
         api.HipBatchSolver(p, 4)
+
+
+def test_facade_solve_batch_runs_on_the_resident_kernels(api, oracle_built):
+    """pycddp-compatible facade: solve_batch(x0s, MSIPDDP) of a built-in plant is one device-resident batch (the oracle's trace in the
+    library's arithmetic); msipddp_route = "plugin" keeps the host route; a layout the resident kernels do not serve raises under
+    msipddp_route = "resident"."""
+    import importlib.util, os, sys
+    name = "pycddp_amd"
+    if name in sys.modules:
+        pycddp = sys.modules[name]
+    else:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cddp-cpp_amd", "pycddp_amd.py"))
+        pycddp = importlib.util.module_from_spec(spec); sys.modules[name] = pycddp; spec.loader.exec_module(pycddp)
+    p, _ = make(api, "pendulum_box-hybrid")
+    B = 6
+    x0 = api.batch_x0(p, B, 20270206, spread_for(p))
+    o = pycddp.CDDPOptions(); o.verbose = False; o.print_solver_header = False; o.return_iteration_info = True
+    o.max_iterations = p.options.max_iterations; o.tolerance = p.options.tolerance; o.acceptable_tolerance = p.options.acceptable_tolerance
+    o.regularization.initial_value = p.options.reg_initial_value
+    o.msipddp.rollout_type = "hybrid"; o.msipddp.segment_length = p.options.msipddp_segment_length
+    o.msipddp.barrier.mu_initial = p.options.barrier_mu_initial
+    sv = pycddp.CDDP(x0[0], p.x_ref, p.N, p.dt, o)
+    mp = list(p.c.model_params)
+    sv.set_dynamical_system(pycddp.Pendulum(p.dt, mp[0], mp[1], mp[2], "euler"))
+    sv.set_objective(pycddp.QuadraticObjective(p.Q, p.R, p.Qf, p.x_ref, [], p.dt))
+    sv.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([-20.0]), np.array([20.0])))   # pyapi.pendulum_problem's box
+    sols = sv.solve_batch(list(x0), pycddp.SolverType.MSIPDDP)
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, None, None, n_threads=B)
+    for b in range(B):
+        s = sols[b]
+        assert s.solver_name == "MSIPDDP"
+        assert (s.status_message, s.iterations_completed) == (api.STATUS_STRINGS[int(ores["status"][b])], int(ores["iterations"][b]))
+        assert rel_err(s.final_objective, ores["final_objective"][b]) < TOL and rel_err(np.stack(s.state_trajectory), oX[b]) < TOL
+        assert s.final_barrier_mu == ores["barrier_mu"][b] and len(s.history.barrier_mu) == len(s.history.objective)
+    su = pycddp.CDDP(np.zeros(3), np.array([2.0, 2.0, 1.0]), 20, 0.03, o)
+    su.set_dynamical_system(pycddp.Unicycle(0.03, "euler"))
+    su.set_objective(pycddp.QuadraticObjective(np.zeros((3, 3)), 0.5 * np.eye(2), 50.0 * np.eye(3), np.array([2.0, 2.0, 1.0]), [], 0.03))
+    su.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([-1.0, -3.0]), np.array([1.0, 3.0])))
+    su.msipddp_route = "resident"
+    with pytest.raises(NotImplementedError):
+        su.solve_batch([np.zeros(3)], pycddp.SolverType.MSIPDDP)
