@@ -144,7 +144,23 @@ DEV double ms_scaled_inf_du(const DevBuf &d, int b, int slot, double inf_du) {
 #pragma unroll
     for (int c = 0; c < NSEG; ++c) {
       const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
-      for (int t = 0; t < d.N; ++t) {
+      constexpr int kTB = 8;   // steps per round trip: the loads of kTB steps in flight, then the ordered sums
+      int t = 0;
+      for (; t + kTB - 1 < d.N; t += kTB) {
+        double yv[kTB][M], sv[kTB][M];
+#pragma unroll
+        for (int k = 0; k < kTB; ++k)
+#pragma unroll
+          for (int i = 0; i < M; ++i) if (i < dim) { yv[k][i] = Yc[GI(t + k, M, off + i)]; sv[k][i] = Sc[GI(t + k, M, off + i)]; }
+#pragma unroll
+        for (int k = 0; k < kTB; ++k) {
+          double ya = 0.0, sa = 0.0;
+#pragma unroll
+          for (int i = 0; i < M; ++i) if (i < dim) { ya += fabs(yv[k][i]); sa += fabs(sv[k][i]); }
+          yn += ya; sn += sa;
+        }
+      }
+      for (; t < d.N; ++t) {
         double ya = 0.0, sa = 0.0;
         for (int i = 0; i < dim; ++i) { ya += fabs(Yc[GI(t, M, off + i)]); sa += fabs(Sc[GI(t, M, off + i)]); }
         yn += ya; sn += sa;
@@ -656,57 +672,79 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
   bool alive = true;
   int steps = N;
   unsigned int ymask = 0xffffffffu;      // dual step sizes of the ladder that keep every row above its fraction-to-boundary bound so far
-  for (int t = 0; t < N; ++t) {
-    double xo[NX], uo[NU], kk[NU], KK[NU * NX], dx[NX], u[NU];
-    ld<NX>(Xc + GI(t, NX, 0), kLS, xo);
-    ld<NU>(Uc + GI(t, NU, 0), kLS, uo);
-    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
-    ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+  // the ladder in registers (one scalar fetch per entry in front of the step loop instead of one per row, entry and step inside it)
+  constexpr int kAL = 16;
+  [[maybe_unused]] double al[kAL];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
+  for (int q = 0; q < kAL; ++q) al[q] = (q < n_alphas) ? P->alphas[q] : 0.0;
+  // One step's inputs: nominal state / control, gains, slack / dual rows and their gains, costate and its gains.  Fetched one step ahead
+  // (the rollout is ONE dependent instruction stream per wavefront: a load issued at the top of its own step is a full memory round
+  // trip on the chain) when the record fits the register file twice.
+  struct Rec {
+    double xo[NX], uo[NU], kk[NU], KK[NU * NX], lo[NX], kl[NX], Kl[NX * NX];
+    double so[MM], ksv[MM], Ks[MM * NX], yo[MM], ky[MM], Ky[MM * NX];
+  };
+  constexpr int REC = 3 * NX + 2 * NU + NU * NX + NX * NX + (M > 0 ? 4 * M + 2 * M * NX : 0);
+  constexpr bool kPF = REC <= 64;
+  auto fetch = [&](int tt, Rec &r) {
+    ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+    ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+    ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+    ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+    ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lo);
+    ld<NX>(d.kl + GI(tt, NX, 0), kLS, r.kl);
+    ld<NX * NX>(d.Vxx + GI(tt + 1, NX * NX, 0), kLS, r.Kl);
+    if constexpr (M > 0) {
+      ld<M>(d.S + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.so);
+      ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
+      ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ks);
+      ld<M>(d.Y + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.yo);
+      ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+    }
+  };
+  auto step = [&](const int t, const Rec &c, Rec &n) {
+    if constexpr (kPF) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
+    double dx[NX], u[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - c.xo[i];
     [[maybe_unused]] double sn[MM];
     if constexpr (M > 0) {   // slack trial and its fraction-to-boundary test (:1547-1560): the trial is abandoned at the first violation
-      double so[MM], ksv[MM], Ks[MM * NX];
-      ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, so);
-      ld<M>(d.ks + GI(t, M, 0), kLS, ksv);
-      ld<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ks);
 #pragma unroll
       for (int r = 0; r < M; ++r) { double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += Ks[r * NX + j] * dx[j];
-        sn[r] = (so[r] + alpha * ksv[r]) + s;
-        if (alive && sn[r] < (1.0 - tau) * so[r]) { alive = false; steps = t; } }
+        for (int j = 0; j < NX; ++j) s += c.Ks[r * NX + j] * dx[j];
+        sn[r] = (c.so[r] + alpha * c.ksv[r]) + s;
+        if (alive && sn[r] < (1.0 - tau) * c.so[r]) { alive = false; steps = t; } }
       st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
       // dual trials y + a_y k_y + K_y dx for every a_y of the ladder (:1612-1644): feasibility only; the rows are written once a_y is known
-      double yo[MM], ky[MM], Ky[MM * NX];
-      ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, yo);
-      ld<M>(d.ky + GI(t, M, 0), kLS, ky);
-      ld<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
 #pragma unroll
       for (int r = 0; r < M; ++r) { double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += Ky[r * NX + j] * dx[j];
-        const double bound = (1.0 - tau) * yo[r];
-        for (int q = 0; q < n_alphas; ++q) {
-          const double yn = (yo[r] + P->alphas[q] * ky[r]) + s;
+        for (int j = 0; j < NX; ++j) s += c.Ky[r * NX + j] * dx[j];
+        const double bound = (1.0 - tau) * c.yo[r];
+#pragma unroll
+        for (int q = 0; q < kAL; ++q) {
+          const double yn = (c.yo[r] + al[q] * c.ky[r]) + s;
+          if (q < n_alphas && yn < bound) ymask &= ~(1u << q);
+        }
+        for (int q = kAL; q < n_alphas; ++q) {   // a ladder longer than the register copy (CDDP_HIP_MAX_ALPHAS = 32)
+          const double yn = (c.yo[r] + P->alphas[q] * c.ky[r]) + s;
           if (yn < bound) ymask &= ~(1u << q);
         } }
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) { double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s += KK[i * NX + j] * dx[j];
-      u[i] = (uo[i] + alpha * kk[i]) + s; }
+      for (int j = 0; j < NX; ++j) s += c.KK[i * NX + j] * dx[j];
+      u[i] = (c.uo[i] + alpha * c.kk[i]) + s; }
     {   // costate trial (:1466-1467 == :1639-1641): lambda + a k_lambda + K_lambda dx, K_lambda = V_xx(t+1)
-      double lo[NX], kl[NX], Kl[NX * NX], ln[NX];
-      ld<NX>(Lc + GI(t, NX, 0), kLS, lo);
-      ld<NX>(d.kl + GI(t, NX, 0), kLS, kl);
-      ld<NX * NX>(d.Vxx + GI(t + 1, NX * NX, 0), kLS, Kl);
+      double ln[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += Kl[i * NX + j] * dx[j];
-        ln[i] = (lo[i] + alpha * kl[i]) + s; }
+        for (int j = 0; j < NX; ++j) s += c.Kl[i * NX + j] * dx[j];
+        ln[i] = (c.lo[i] + alpha * c.kl[i]) + s; }
       st<NX>(Ln + GI(t, NX, 0), kLS, ln);
     }
     double fn[NX], xn[NX];
@@ -732,11 +770,11 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
 #pragma unroll
           for (int j = 0; j < NX; ++j) { double bk = 0.0;
 #pragma unroll
-            for (int q = 0; q < NU; ++q) bk += Bm[i * NU + q] * KK[q * NX + j];
+            for (int q = 0; q < NU; ++q) bk += Bm[i * NU + q] * c.KK[q * NX + j];
             lin += (A[i * NX + j] + bk) * dx[j]; }
           double bkk = 0.0;
 #pragma unroll
-          for (int q = 0; q < NU; ++q) bkk += Bm[i * NU + q] * kk[q];
+          for (int q = 0; q < NU; ++q) bkk += Bm[i * NU + q] * c.kk[q];
           xn[i] = (x1[i] + lin) + alpha * ((bkk + fo[i]) - x1[i]);
         }
       }
@@ -747,8 +785,8 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
       Cons::template eval<NX, NU>(cc, x, u, g);
       st<M>(d.G + (size_t)slot * d.planeM + GI(t, M, 0), kLS, g);
 #pragma unroll
-      for (int c = 0; c < NSEG; ++c) {
-        const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      for (int cs = 0; cs < NSEG; ++cs) {
+        const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
         double lsum = 0.0, l1 = 0.0;
 #pragma unroll
         for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); l1 += fabs(g[off + i] + sn[off + i]); }
@@ -764,6 +802,15 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
     st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xn[i];
+  };
+  if constexpr (kPF) {
+    Rec ra, rb;
+    fetch(0, ra);
+    int t = 0;
+    for (; t + 1 < N; t += 2) { step(t, ra, rb); step(t + 1, rb, ra); }
+    if (t < N) step(t, ra, rb);
+  } else {
+    for (int t = 0; t < N; ++t) { Rec r; fetch(t, r); step(t, r, r); }
   }
   cost += Obj::terminal_cost(P, x);
   const size_t ti = (size_t)a * d.Bp + b;
@@ -836,6 +883,8 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
       double mu = d.mu[b];
       bool running = true;
       const bool fp_success = win >= 0;
+      [[maybe_unused]] double sdu = 0.0;
+      [[maybe_unused]] bool have_sdu = false;
       if (fp_success) {
         const size_t ti = (size_t)win * d.Bp + b;
         const int old_cur = d.cur[b];
@@ -855,7 +904,8 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
         d.reg[b] = reg_decrease(o, d.reg[b]);
         // checkConvergence (:306-364): the residuals are those of the last backward pass / filter reset, the duals the new iterate's
         const double ipr = d.inf_pr[b], icomp = d.inf_comp[b];
-        const double metric = dmax(dmax(ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]), ipr), icomp);
+        sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]); have_sdu = true;
+        const double metric = dmax(dmax(sdu, ipr), icomp);
         int st = CDDP_HIP_STATUS_RUNNING;
         const int iter = d.iter[b];
         if (metric <= o.tolerance) st = CDDP_HIP_STATUS_OPTIMAL;
@@ -889,7 +939,8 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
             mu = dmax(o.barrier_mu_min_value, o.barrier_mu_update_factor * mu);
             reset = true;
           } else {
-            const double metric = dmax(dmax(ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]), d.inf_pr[b]), d.inf_comp[b]);
+            if (!have_sdu) sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]);   // (after a failed pass: duals and inf_du unchanged)
+            const double metric = dmax(dmax(sdu, d.inf_pr[b]), d.inf_comp[b]);
             if (o.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
               if (metric <= 10.0 * mu) {
                 const double lin = o.barrier_mu_update_factor * mu, sup = solver_pow(mu, o.barrier_mu_update_power);

@@ -2346,6 +2346,10 @@ int cddp_oracle_solve_batch(const cddp_hip_problem *p, int batch, const double *
     for (;;) {
       int b = next.fetch_add(1);
       if (b >= batch) break;
+      // MSIPDDP keeps state that belongs to the solver OBJECT across initialize() calls (the per-step factor cache of
+      // msipddp_solver.cpp:1169-1185, and gains that send a warm start down the "existing state" branch): independent trajectories
+      // of a batch are independent solver objects, as each trajectory of a device handle owns its cache
+      if (p->solver == CDDP_HIP_SOLVER_MSIPDDP) { delete s; s = oracle::build(p); }
       s->set_initial(x0 + (size_t)b * nx, U0 ? U0 + (size_t)b * N * nu : nullptr, X0 ? X0 + (size_t)b * (N + 1) * nx : nullptr);
       s->initialize();
       s->solve();

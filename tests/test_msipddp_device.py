@@ -170,9 +170,9 @@ def test_full_solve_parity(api, oracle_built, case):
     X, U = hs.trajectory()
     K, k = hs.gains()
     hist = hs.history(B)
-    # one checker object per trajectory (n_threads = B): the reference's factor cache and gains belong to the solver OBJECT, and a
-    # re-used object would solve its second trajectory with the first one's factors / take the warm re-solve path
-    ores, oX, oU, oK, _ = api.oracle_solve_batch(p, x0, U0, X0, n_threads=B)
+    # (the checker's batch driver builds one solver object per MSIPDDP trajectory: the reference's factor cache and gains belong to the
+    #  solver OBJECT, and a re-used object would solve its second trajectory with the first one's factors / take the warm re-solve path)
+    ores, oX, oU, oK, _ = api.oracle_solve_batch(p, x0, U0, X0, n_threads=8)
     # A trajectory whose iterates overflow (the unconstrained branch with its stale factors, started from a dynamically inconsistent
     # guess) ends in NaN arithmetic, where the reference's acceptance test is std::copysign(1.0, NaN): the SIGN of a NaN, which x86 and
     # gfx950 arithmetic do not share.  Such trajectories are compared up to the blow-up by the history test below, not here.
@@ -219,7 +219,7 @@ def test_reference_pendulum_problem(api, oracle_built):
     hs.set_initial(x0, U0)
     hs.solve()
     res = hs.results(); X, U = hs.trajectory(); hist = hs.history(B)
-    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0, None, n_threads=B)
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, U0, None, n_threads=4)
     for f in ("iterations", "status", "n_backward", "n_forward"):
         assert np.array_equal(res[f], ores[f]), (f, res[f], ores[f])
     assert rel_err(res["final_objective"], ores["final_objective"]) < TOL and rel_err(X, oX) < TOL and rel_err(U, oU) < TOL
@@ -336,7 +336,7 @@ def test_facade_solve_batch_runs_on_the_resident_kernels(api, oracle_built):
     sv.set_objective(pycddp.QuadraticObjective(p.Q, p.R, p.Qf, p.x_ref, [], p.dt))
     sv.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([-20.0]), np.array([20.0])))   # pyapi.pendulum_problem's box
     sols = sv.solve_batch(list(x0), pycddp.SolverType.MSIPDDP)
-    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, None, None, n_threads=B)
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, None, None, n_threads=4)
     for b in range(B):
         s = sols[b]
         assert s.solver_name == "MSIPDDP"

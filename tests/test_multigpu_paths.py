@@ -108,11 +108,11 @@ def test_bench_default_line_carries_other_workloads():
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     ow = j["other_workloads"]
-    assert len(ow) == 7 and not any("error" in w for w in ow), ow     # C2-CLDDP, resident LogDDP (f4, round 4), C3, C4 / C5 shares, 2 x MPC
-    assert [w["solver"] for w in ow[:5]] == ["CLDDP", "LOGDDP", "IPDDP", "IPDDP", "IPDDP"]
-    for w in ow[:5]:
+    assert len(ow) == 8 and not any("error" in w for w in ow), ow     # C2-CLDDP, resident LogDDP + MSIPDDP (f4, round 4), C3, C4 / C5 shares, 2 x MPC
+    assert [w["solver"] for w in ow[:6]] == ["CLDDP", "LOGDDP", "MSIPDDP", "IPDDP", "IPDDP", "IPDDP"]
+    for w in ow[:6]:
         assert w["value"] > 0 and 0 < w["roofline"]["frac"] < 1 and w["steps"] == 3
-    for w in ow[5:]:   # the MPC re-solve lines (f1 caller side)
+    for w in ow[6:]:   # the MPC re-solve lines (f1 caller side)
         assert w["workload"].startswith("MPC re-solves") and w["value"] > 0 and w["steps"] == 8 and len(w["iterations_by_round"]) == 8
         assert w["mean_iterations_per_resolve"] <= w["cold"]["mean_iterations"] + 5
     assert j["config"]["batch_per_gpu"] == 4096 and j["roofline"]["frac"] > 0
