@@ -44,7 +44,7 @@ def test_bench_under_torchrun_one_rank(scaling):
     cddp_hip_comm_init, the RCCL all-gather inside the timed step -- everything of the N > 1 path except a second GPU."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--master-port", "29533" if scaling == "weak" else "29535", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--workload", "pendulum", "--no-cpu-baseline", "--scaling", scaling] + (["--global-batch", "1000"] if scaling == "strong" else ["--batch", "512"])
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
