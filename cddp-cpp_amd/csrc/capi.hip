@@ -761,6 +761,10 @@ struct SolveRun {
   std::vector<int> hist_now, hist_prev;
   hipEvent_t poll_ev = nullptr;
   std::chrono::steady_clock::time_point wall0;
+  // ping-pong of two half-batch groups (cddp_hip_solve): this group's rollout launches wait for the other group's last rollout and
+  // are followed by an event the other group waits for -- the two groups' rollouts never share the chip, each runs beside the other
+  // group's sweep / update kernels
+  hipEvent_t fwd_wait = nullptr, fwd_done = nullptr;
 
   void mark(int point) {
     if (detail < 0) return;
@@ -891,8 +895,10 @@ struct SolveRun {
     ks->derivs(d, 0, s);
     ks->backward(d, P.solver, 0, 1, s);
     mark(1);
+    if (fwd_wait) hipStreamWaitEvent(s, fwd_wait, 0);
     if (one_stage) {
       ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
+      if (fwd_done) hipEventRecord(fwd_done, s);
       mark(2);
       ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 2, s);   // best-merit rule: the candidate winner's costate only (k_costate)
       ks->update(d, 1, na, last, 1, s);
@@ -905,6 +911,7 @@ struct SolveRun {
       ks->update(d, 1, k1, last, 0, s);
       mark(3);
       ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
+      if (fwd_done) hipEventRecord(fwd_done, s);
       mark(4);
       ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
       ks->update(d, 2, na, last, 1, s);
@@ -949,8 +956,9 @@ struct SolveRun {
   }
 
   // enqueue iterations up to (and including) the next polled one
-  int advance() {
+  int advance(int max_new = 1 << 30) {   // returns 1: a poll is pending, 2: stopped at the cap (no poll), 0: nothing more to enqueue
     if (done) return 0;
+    int enq = 0;
     const ProblemDev &P = h->P;
     const DevBuf &d = h->d;
     hipStream_t s = h->stream;
@@ -980,6 +988,7 @@ struct SolveRun {
         HIPCHK(hipEventRecord(poll_ev, s));
         return 1;   // a poll is pending
       }
+      if (++enq >= max_new) return 2;
     }
     done = true;
     return 0;
@@ -1246,6 +1255,8 @@ struct cddp_hip_handle {
   std::vector<int> b0;       // first trajectory of each group
   int B = 0, device = 0;
   int conc = 1;              // groups in flight at once in cddp_hip_solve (pick_groups)
+  bool pingpong = false;     // two groups, rollouts alternating (CDDP_HIP_PINGPONG=1 with CDDP_HIP_GROUPS=2)
+  hipEvent_t ev_pp[2] = {nullptr, nullptr};
   int nx = 0, nu = 0, N = 0, m = 0, mT = 0, pT = 0;
   hipStream_t user_stream = nullptr;   // cddp_hip_set_stream: work is ordered after / before this stream's work
   bool have_user_stream = false;
@@ -1309,6 +1320,7 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   const int tiles = (batch + 63) / 64, ng = pick_groups(batch, problem->options.ls_max_iterations, &conc);
   cddp_hip_handle *h = new cddp_hip_handle();
   h->B = batch; h->device = device; h->conc = conc;
+  { const char *e = std::getenv("CDDP_HIP_PINGPONG"); h->pingpong = e && e[0] == '1'; }
   int t0 = 0;
   for (int k = 0; k < ng; ++k) {
     const int nt = tiles / ng + (k < tiles % ng ? 1 : 0);          // whole tiles per group, sizes differ by at most one tile
@@ -1330,6 +1342,7 @@ int cddp_hip_destroy(cddp_hip_handle *h) {
   if (!h) return 0;
   for (Inner *q : h->g) in_destroy(q);
   if (h->ev_fork) { hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
+  for (int k = 0; k < 2; ++k) if (h->ev_pp[k]) hipEventDestroy(h->ev_pp[k]);
   if (h->d_send) hipFree(h->d_send);
   delete h;
   return 0;
@@ -1443,6 +1456,21 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // every other group's end.
   const int conc = std::max(1, std::min(h->conc, ng));
   std::vector<int> pending(ng, 0);
+  if (h->pingpong && ng == 2) {
+    // two half-batch groups in lockstep, one iteration each in turn; rollouts serialised A1 B1 A2 B2 ... by events (SolveRun::fwd_wait)
+    if (!h->ev_pp[0]) for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&h->ev_pp[k], hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, 1); if (rc) return rc; run[k].fwd_wait = h->ev_pp[1 - k]; run[k].fwd_done = h->ev_pp[k]; }
+    for (;;) {
+      bool any = false;
+      for (int k = 0; k < 2; ++k) {
+        if (run[k].done || pending[k] == 1) continue;
+        int rc = run[k].advance(1); if (rc < 0) return rc;
+        pending[k] = rc; any = any || rc != 0;
+      }
+      for (int k = 0; k < 2; ++k) if (pending[k] == 1) { int rc = run[k].complete_poll(); if (rc) return rc; pending[k] = 0; any = true; }
+      if (!any) break;
+    }
+  } else
   for (int base = 0; base < ng; base += conc) {
     const int top = std::min(ng, base + conc);
     for (int k = base; k < top; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, conc); if (rc) return rc; }
