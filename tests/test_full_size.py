@@ -69,6 +69,11 @@ def _bench_problem(api, workload):
         return api.cartpole_problem(api.SOLVER_IPDDP, True), [0.1, 0.3, 0.1, 0.1], 4096
     if workload == "cartpole_clddp":
         return api.cartpole_problem(api.SOLVER_CLDDP, True), [0.1, 0.3, 0.1, 0.1], 4096
+    if workload == "cartpole_logddp":      # f4 lines of bench.py's other_workloads (resident LogDDP / MSIPDDP kernels, round 4)
+        return api.cartpole_problem(api.SOLVER_LOGDDP, True), [0.1, 0.3, 0.1, 0.1], 4096
+    if workload == "pendulum_msipddp":
+        p = api.pendulum_problem(api.SOLVER_MSIPDDP, True); p.c.solver = api.SOLVER_MSIPDDP
+        return p, [0.1, 0.1], 4096
     if workload == "unicycle":
         return api.unicycle_problem(api.SOLVER_IPDDP, 200, True), [0.05, 0.05, 0.05], 8192
     if workload == "quadrotor":
@@ -84,9 +89,10 @@ def test_bench_inputs_match(api):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("cddp_bench_module", os.path.join(repo, "bench.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    for wl, solver in (("cartpole", "ipddp"), ("unicycle", "ipddp"), ("quadrotor", "ipddp"), ("manip7", "ipddp")):
+    for wl, solver in (("cartpole", "ipddp"), ("unicycle", "ipddp"), ("quadrotor", "ipddp"), ("manip7", "ipddp"), ("cartpole", "logddp"), ("pendulum", "msipddp")):
         pb, sb, _ = mod.make_problem(api, wl, solver)
-        pt, st, B = _bench_problem(api, wl)
+        pt, st, B = _bench_problem(api, wl if solver == "ipddp" else wl + "_" + solver)
+        assert pb.c.solver == pt.c.solver
         assert list(sb) == list(st) and (pb.nx, pb.nu, pb.N) == (pt.nx, pt.nu, pt.N)
         assert np.array_equal(api.batch_x0(pb, 8, BENCH_SEED, sb), api.batch_x0(pt, 8, BENCH_SEED, st))
         assert mod.DEFAULT_BATCH[wl] == B
@@ -100,7 +106,8 @@ def test_bench_inputs_match(api):
 # Round 3: bounds tightened to the measured figures + a small margin (measured on MI355X, profiles/r02_parity_report.md and
 # r03: 0 of 4096 / 4096 / 8192 trajectories differ in any of the compared quantities): at most 0.2 % of the batch may differ
 # in (status, iterations) and at most 1 % in the strict comparison.
-WHOLE_BATCH = {"cartpole": (0.002, 0.01), "cartpole_clddp": (0.002, 0.01), "unicycle": (0.002, 0.01)}
+WHOLE_BATCH = {"cartpole": (0.002, 0.01), "cartpole_clddp": (0.002, 0.01), "unicycle": (0.002, 0.01),
+               "cartpole_logddp": (0.002, 0.01), "pendulum_msipddp": (0.002, 0.01)}
 
 
 @pytest.mark.parametrize("workload", list(WHOLE_BATCH))
