@@ -17,6 +17,8 @@
 // only lgkmcnt(0).  Lanes q >= NX (when G > NX) shadow column NX-1 and write the same values to the same places.
 #pragma once
 #include "kernels_lean.hpp"
+#include "kernels_logddp.hpp"   // LgCons: the relaxed barrier's gradients / Hessians (the LogDDP mode of the plain cooperative sweep)
+#include <type_traits>
 
 namespace cddp_dev {
 
@@ -439,10 +441,19 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 //                  in the value update)
 // Replicated per trajectory group: Q_u, Q_uu, the PD test / factor / BoxQP, k, dV.  Per lane: column qc of T1, T2,
 // Q_xx, Q_ux, K, V_xx and row qc of l_x, Q_x, V_x.  Same sums, same association as the fused per-lane kernels.
-template <class Model, bool CLDDP>
+//   LG != void     LogDDP (round 4; CLDDP = true selects the value-update association it shares with CLDDP): logddp_solver.cpp:363-590 --
+//                  the relaxed barrier's gradients / Hessians of the constraint list LG folded into Q_x, Q_u, Q_xx, Q_ux, Q_uu in
+//                  the reference's order (each lane evaluates the rows; it keeps its own column), LDLT of the regularised,
+//                  symmetrised Q_uu, un-regularised Q_uu in the value update, raw max |Q_u|, RegularizationLimitReached_Converged;
+//                  same sums, same association as the one-lane k_backward_logddp (tests/test_logddp_device.py compares them bitwise)
+template <class Model, bool CLDDP, class LG = void>
 __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                             int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU;
+  constexpr bool LOGDDP = !std::is_void<LG>::value;
+  static_assert(!LOGDDP || CLDDP, "the LogDDP mode shares the CLDDP branch of the value update");
+  typedef typename std::conditional<LOGDDP, LG, ConList<>>::type LCons;
+  constexpr int LM = LCons::M, LMM = LM > 0 ? LM : 1;
   typedef Objective<NX, NU> Obj;
   typedef CoopCfg<Model> C;
   constexpr bool kQuad = false;   // see k_backward_ipddp_coop (measured: no gain)
@@ -462,7 +473,10 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
   const double *Uc = d.U + (size_t)cur * d.planeU;
   if (count_iter && q == 0) d.iter[b] += 1;
   double reg = d.reg[b];
-  const int box = CLDDP ? P->clddp_box : -1;
+  const int box = (CLDDP && !LOGDDP) ? P->clddp_box : -1;
+  [[maybe_unused]] const double lg_mu = LOGDDP ? d.mu[b] : 0.0, lg_delta = o.logddp_relaxed_delta;
+  typename LCons::Ctx lcc;
+  LCons::load(P, lcc);
   bool ok = false;
   int nb = 0;
   double dV0 = 0, dV1 = 0, inf_du = 0, step_norm = 0;
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
       const double *Qf = P->pool + P->off_Qf;
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        Vc[i] = CLDDP ? 2.0 * Qf[i * NX + qc] : 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
+        Vc[i] = (CLDDP && !LOGDDP) ? 2.0 * Qf[i * NX + qc] : 0.5 * ((2.0 * Qf[i * NX + qc]) + (2.0 * Qf[qc * NX + i]));
     }
     dV0 = 0; dV1 = 0; inf_du = 0; step_norm = 0;
     {
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
       ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
       ld<NX>(Xc + GI(tt, NX, 0), kLS, r.x);
       ld<NU>(Uc + GI(tt, NU, 0), kLS, r.u);
-      if constexpr (CLDDP) ld<NU>(d.k + GI(tt, NU, 0), kLS, r.k0);   // BoxQP warm start x0 = k_u_[t] of the previous iteration
+      if constexpr (CLDDP && !LOGDDP) ld<NU>(d.k + GI(tt, NU, 0), kLS, r.k0);   // BoxQP warm start x0 = k_u_[t] of the previous iteration
     };
     auto step = [&](const int t, const In1 &c1, const In2 &c2, In1 &n1, In2 &n2) -> bool {
       const int tp = t > 0 ? t - 1 : 0;
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
 #ifndef CDDP_EARLYQP
 #define CDDP_EARLYQP 1
 #endif
-      constexpr bool kEarlyQP = CLDDP && NU == 1 && !kQuad && CDDP_EARLYQP;
+      constexpr bool kEarlyQP = CLDDP && !LOGDDP && NU == 1 && !kQuad && CDDP_EARLYQP;
       double T1[NX * NX], T2[NU * NX];
       double Qxxc[NX], Quxc[NU], Quu[NU * NU];
       double kk[NU], KKc[NU];
@@ -653,7 +667,62 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
             for (int j = 0; j < NX; ++j) s += T2[u * NX + j] * Bm[j * NU + v];
             Quu[u * NU + v] = (2.0 * Rr[u * NU + v]) + s; }
       }
-      if constexpr (kEarlyQP) {
+      if constexpr (LOGDDP) {
+        // logddp_solver.cpp:518-530: Q_x += mu g_x, Q_u += mu g_u, Q_xx += mu H_xx, Q_uu += mu H_uu, Q_ux += mu H_ux, constraint by
+        // constraint (LgCons::derivs, kernels_logddp.hpp).  The lane's column sits in full-size operands whose other columns are
+        // never read back; selects, not indexed stores (qc is a lane value)
+        if constexpr (LM > 0) {
+          double g[LMM], Gx[LMM * NX], Gu[LMM * NU];
+#pragma unroll
+          for (int i = 0; i < LMM * NX; ++i) Gx[i] = 0.0;
+#pragma unroll
+          for (int i = 0; i < LMM * NU; ++i) Gu[i] = 0.0;
+          LCons::template eval<NX, NU>(lcc, c2.x, c2.u, g);
+          LCons::template jac<NX, NU>(lcc, c2.x, c2.u, Gx, Gu);
+          double fQx[NX], fQxx[NX * NX], fQux[NU * NX];
+#pragma unroll
+          for (int a = 0; a < NX; ++a) {
+            fQx[a] = (a == qc) ? Qxq : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fQxx[i * NX + a] = (a == qc) ? Qxxc[i] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) fQux[u * NX + a] = (a == qc) ? Quxc[u] : 0.0;
+          }
+          LgCons<LCons>::template derivs<NX, NU>(P, g, Gx, Gu, c2.u, lg_mu, lg_delta, fQx, Qu, fQxx, Quu, fQux);
+#pragma unroll
+          for (int a = 0; a < NX; ++a) {
+            Qxq = (a == qc) ? fQx[a] : Qxq;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Qxxc[i] = (a == qc) ? fQxx[i * NX + a] : Qxxc[i];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) Quxc[u] = (a == qc) ? fQux[u * NX + a] : Quxc[u];
+          }
+        }
+        // Q_uu_reg = sym(Q_uu + reg I), LDLT (:533-543); the un-regularised Q_uu stays in the value update
+        double Qr[NU * NU], Qs[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Qr[i] = Quu[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+          for (int c = 0; c < NU; ++c) Qs[i * NU + c] = 0.5 * (Qr[i * NU + c] + Qr[c * NU + i]);
+        LDLTs<NU> f;
+        f.compute(Qs, NU);
+        if (!f.ok) return false;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Quxc[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+      } else if constexpr (kEarlyQP) {
         if (box < 0) KKc[0] = 0.0 + (-qp_h) * Quxc[0];   // (box >= 0: set beside the BoxQP above)
       } else if constexpr (CLDDP) {
         double Quu_reg[NU * NU];
@@ -804,7 +873,10 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
       d.Vx[GI(t, NX, qc)] = Vxq;
 #pragma unroll
       for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
-      if constexpr (CLDDP) {
+      if constexpr (LOGDDP) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Qu_error = dmax(Qu_error, fabs(Qu[i]));   // :576
+      } else if constexpr (CLDDP) {
         double sN = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) sN += fabs(Vx[i]);
@@ -828,7 +900,8 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
     }
     if (!fail && t == 0) fail = !step(0, a1, a2, b1, b2);
     if (!fail) {
-      if constexpr (CLDDP) {
+      if constexpr (LOGDDP) inf_du = Qu_error;
+      else if constexpr (CLDDP) {
         double scaling = o.termination_scaling_max_factor;
         scaling = dmax(scaling, norm_Vx / (N * NX)) / scaling;
         inf_du = Qu_error / scaling;
@@ -849,6 +922,11 @@ __global__ __launch_bounds__(64) void k_backward_coop_plain(DevBuf d, const Prob
     if constexpr (!CLDDP) { d.step_norm[b] = step_norm; d.inf_pr[b] = 0.0; d.inf_comp[b] = 0.0; d.apr_max[b] = 1.0; d.adu_max[b] = 1.0; }
   }
   if (force) return;
+  if constexpr (LOGDDP) {   // handleBackwardPassRegularizationLimit (:216-222); no early convergence test (base-class default)
+    if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT_CONVERGED; d.phase[b] = PH_DONE; return; }
+    d.phase[b] = PH_FWD1;
+    return;
+  }
   if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
   const bool conv = CLDDP ? (inf_du < o.tolerance)                      // clddp_solver.cpp:206-213
                           : (0.0 < o.tolerance && inf_du < o.tolerance);  // ipddp_solver.cpp:925-958, no barrier

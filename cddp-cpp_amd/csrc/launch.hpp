@@ -123,6 +123,14 @@ struct Launcher {
     // full DDP (use_ilqr = 0): the one-lane IPDDP kernels carry the tensor terms; CLDDP's backward pass has none
     // (clddp_solver.cpp:79-204 ignores use_ilqr), so it keeps the cooperative sweep
     if (solver == CDDP_HIP_SOLVER_LOGDDP) {
+      // lane-cooperative sweep (the LogDDP mode of k_backward_coop_plain) for the register-resident shapes; the one-lane kernel carries
+      // the tensor terms of full DDP, serves nx > 8 (scratch-backed) and CDDP_HIP_SWEEP=lane (comparison)
+      if constexpr (kLog && Model::NX <= 8) {
+        if (!lane_sweep_requested() && !d.ddp) {
+          hipLaunchKernelGGL((k_backward_coop_plain<Model, true, Cons>), dim3(coop_grid<CoopCfg<Model>::TPW>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          return;
+        }
+      }
       if constexpr (kLog) hipLaunchKernelGGL((k_backward_logddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
       return;
     }

@@ -22,6 +22,8 @@ prof quadrotor r04_pmc_traffic_quadrotor.json --workload quadrotor
 prof manip7 r04_pmc_traffic_manip7.json --workload manip7
 rocprofv3 --kernel-trace --stats -d $O/trace_logddp -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads --workload cartpole --solver logddp > $O/trace_logddp.log 2>&1
 python profiles/summarize_rocpd.py $O/trace_logddp/r_results.db $O/kernel_stats_cartpole_logddp.md | head -8 | cut -c1-160; rm -rf $O/trace_logddp
+rocprofv3 --kernel-trace --stats -d $O/trace_msipddp -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads --workload pendulum --solver msipddp > $O/trace_msipddp.log 2>&1
+python profiles/summarize_rocpd.py $O/trace_msipddp/r_results.db $O/kernel_stats_pendulum_msipddp.md | head -8 | cut -c1-160; rm -rf $O/trace_msipddp
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads > $O/pmc_sq.log 2>&1
 python profiles/summarize_pmc.py $O/pmc_sq > $O/pmc_sq_cartpole_ipddp.md; rm -rf $O/pmc_sq
 python bench.py --steps 10 --warmup 2 > $O/bench_cartpole_ipddp.json 2> $O/bench.err

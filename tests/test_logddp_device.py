@@ -216,6 +216,33 @@ def test_reference_quadrotor_problem(api, oracle_built):
     assert np.linalg.norm(X[0, -1, :3] - p.x_ref[:3]) < 0.5
 
 
+@pytest.mark.parametrize("case", ["pendulum_box", "cartpole_box", "cartpole_unc", "cartpole_box_state", "unicycle_box_ball", "bicycle_box", "hcw_box",
+                                  "unicycle_soc", "unicycle_thrust", "manipulator_box"])
+def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
+    """The LogDDP mode of the lane-cooperative sweep (kernels_coop.hpp::k_backward_coop_plain<Model, true, Cons>: a column per lane, the
+    barrier's gradients / Hessians evaluated by every lane of a trajectory's group) restates the one-lane k_backward_logddp sum for
+    sum: whole solves under CDDP_HIP_SWEEP=lane and under the default give the SAME bits (nx = 2 ... 6, every constraint kind; a batch
+    that is not a multiple of the trajectories per wavefront)."""
+    p = make(api, case)
+    B = 70 + 3
+    x0 = api.batch_x0(p, B, 20270105, spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); Vx, Vxx = hs.value(); hs.close()
+        return r, X, U, K, k, Vx, Vxx
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    a = run()
+    monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
+    b = run()
+    for f in a[0].dtype.names:
+        assert np.array_equal(a[0][f], b[0][f]), f
+    for u, v in zip(a[1:], b[1:]):
+        assert np.array_equal(u, v)
+
+
 def test_batch_solve_is_independent_of_neighbours(api):
     """A trajectory's LogDDP result does not depend on what shares its wavefront: a batch of 100 against the same trajectories solved
     in batches of 37 + 63 (bitwise)."""
