@@ -5,6 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final_r04; mkdir -p $O; rm -rf $O/*
 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -40 > $O/gpu_suite.log; tail -3 $O/gpu_suite.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 prof() {   # prof <tag> <traffic json name> <bench args...>
   local tag=$1 tj=$2; shift 2
   rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads "$@" > $O/trace_$tag.log 2>&1
