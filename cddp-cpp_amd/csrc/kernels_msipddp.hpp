@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
     double so[MM], ksv[MM], Ks[MM * NX], yo[MM], ky[MM], Ky[MM * NX];
   };
   constexpr int REC = 3 * NX + 2 * NU + NU * NX + NX * NX + (M > 0 ? 4 * M + 2 * M * NX : 0);
-  constexpr bool kPF = REC <= 64;
+  constexpr bool kPF = REC <= 32;   // cart-pole with its box (58 doubles): two copies took 256 VGPR + 168 AGPR, i.e. accvgpr moves on the chain
   auto fetch = [&](int tt, Rec &r) {
     ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
     ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
