@@ -825,6 +825,12 @@ struct SolveRun {
       // waves (CDDP_HIP_LS_TWO_MAX_WAVES; profiles/r03_ladder_sweep.md: 512 / 640 / 768 / 1024 -> 47.3 / 46.8 / 46.1 / 46.4 ms
       // per C2 solve on one box, differences at the box-to-box noise level).
       if (waves_all <= 2048 && (long)k1 * per_alpha_waves > two_stage_max_waves) one_stage = true;
+      // A ladder that fits the chip once (at most one wavefront per SIMD) and light per-step work (nx <= 8): a first stage of more than
+      // half of the ladder saves next to nothing over the whole ladder, while ONE trajectory past k1 costs a second full chain -- and
+      // the histogram of such solves drifts towards smaller steps from window to window (resident LogDDP, cart-pole: k1 = 6 ... 10 of 11
+      // during iterations 4 - 15; 34.3 -> 32.7 ms per solve with the whole ladder at once, profiles/r04_ladder_small.md).  Heavier plants keep the
+      // short first stage (C4 share, 704 wavefronts: 955 ms adaptive against 985 ms with the whole ladder at once).
+      if (waves_all <= 1024 && h->P.nx <= 8 && 2 * k1 > na) one_stage = true;
     }
     if (std::getenv("CDDP_HIP_DEBUG_LADDER")) {
       std::fprintf(stderr, "[ladder] it=%d total=%ld kq=%d -> %s k1=%d hist:", outer, total, kq, one_stage ? "one" : "two", k1);
@@ -919,7 +925,11 @@ struct SolveRun {
       launches += 6;
     }
   }
-  static bool polled_iteration(int it, int max_it, bool pinned) { return it % 4 == 0 || it == max_it || (it <= 2 && !pinned); }
+  static int poll_every() {   // CDDP_HIP_POLL_EVERY=n (experiment): iterations between two "anything still running?" polls (default 4)
+    static const int v = [] { const char *e = std::getenv("CDDP_HIP_POLL_EVERY"); const int n = e ? std::atoi(e) : 4; return n >= 1 ? n : 4; }();
+    return v;
+  }
+  static bool polled_iteration(int it, int max_it, bool pinned) { return it % poll_every() == 0 || it == max_it || (it <= 2 && !pinned); }
 
   // CDDP_HIP_GRAPH=1 (experiment): the iterations between two polls are captured ONCE per (ladder shape, window
   // length, last-iteration flag) into a hipGraph and replayed with one hipGraphLaunch -- every kernel argument of an iteration is
@@ -995,7 +1005,7 @@ struct SolveRun {
   }
 
   int complete_poll() {
-    constexpr int kPollEvery = 4;
+    const int kPollEvery = poll_every();
     HIPCHK(hipEventSynchronize(poll_ev));
     if (*h->h_poll == 0 || it >= max_it) { done = true; return 0; }
     for (int a = 0; a <= na; ++a) hist_now[a] = h->h_poll[1 + a];
