@@ -829,8 +829,8 @@ struct SolveRun {
       // half of the ladder saves next to nothing over the whole ladder, while ONE trajectory past k1 costs a second full chain -- and
       // the histogram of such solves drifts towards smaller steps from window to window (resident LogDDP, cart-pole: k1 = 6 ... 10 of 11
       // during iterations 4 - 15; 34.3 -> 32.7 ms per solve with the whole ladder at once, profiles/r04_ladder_small.md).  Heavier plants keep the
-      // short first stage (C4 share, 704 wavefronts: 955 ms adaptive against 985 ms with the whole ladder at once).
-      if (waves_all <= 1024 && h->P.nx <= 8 && 2 * k1 > na) one_stage = true;
+      // short first stage (C4 share, 704 wavefronts: 955 ms adaptive against 985 ms with the whole ladder at once).  "Half" became "a third" after a sweep (ladder_frac).
+      if (waves_all <= 1024 && h->P.nx <= 8 && ladder_frac() * k1 > na) one_stage = true;
     }
     if (std::getenv("CDDP_HIP_DEBUG_LADDER")) {
       std::fprintf(stderr, "[ladder] it=%d total=%ld kq=%d -> %s k1=%d hist:", outer, total, kq, one_stage ? "one" : "two", k1);
@@ -925,6 +925,7 @@ struct SolveRun {
       launches += 6;
     }
   }
+  static int ladder_frac() { static const int v = [] { const char *e = std::getenv("CDDP_HIP_LS_SMALL_FRAC"); const int n = e ? std::atoi(e) : 3; return n >= 1 ? n : 3; }(); return v; }   // "more than 1 / frac of the ladder" in the rule above (CDDP_HIP_LS_SMALL_FRAC; 2 / 3 / 4 / 11 -> C2-CLDDP 30.55 / 30.33 / 30.29 / 30.3 ms, pendulum MSIPDDP 15.2 / 15.0 / 15.05 / 17.3)
   static int poll_every() {   // CDDP_HIP_POLL_EVERY=n (experiment): iterations between two "anything still running?" polls (default 4)
     static const int v = [] { const char *e = std::getenv("CDDP_HIP_POLL_EVERY"); const int n = e ? std::atoi(e) : 4; return n >= 1 ? n : 4; }();
     return v;
