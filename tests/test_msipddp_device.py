@@ -350,3 +350,32 @@ def test_facade_solve_batch_runs_on_the_resident_kernels(api, oracle_built):
     su.msipddp_route = "resident"
     with pytest.raises(NotImplementedError):
         su.solve_batch([np.zeros(3)], pycddp.SolverType.MSIPDDP)
+
+
+@pytest.mark.parametrize("case", ["pendulum_box-hybrid", "pendulum_free", "cartpole_box-it20"])
+def test_groups_and_chunks_do_not_change_results(api, case, monkeypatch):
+    """A batch cut into successive chunks (what cddp_hip_solve does above 8192 trajectories; CDDP_HIP_CHUNK) or into concurrent tile
+    groups (CDDP_HIP_GROUPS) gives every trajectory the bits of the single-group solve -- the cold solve and a warm re-solve on the
+    used handle (each group owns its factor cache, filters and slots)."""
+    p, _ = make(api, case)
+    B = 200
+    x0 = api.batch_x0(p, B, 20270207, spread_for(p))
+
+    def run():
+        p.options.warm_start = 0
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0); hs.solve()
+        hs.set_warm_start(True); hs.set_initial_state(x0 + 0.01); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); ng = hs.num_groups(); hs.close()
+        return r, X, U, ng
+
+    monkeypatch.delenv("CDDP_HIP_CHUNK", raising=False); monkeypatch.delenv("CDDP_HIP_GROUPS", raising=False)
+    r0, X0, U0, n0 = run()
+    assert n0 == 1
+    for key, val, groups in (("CDDP_HIP_CHUNK", "64", 4), ("CDDP_HIP_GROUPS", "3", 3)):
+        monkeypatch.delenv("CDDP_HIP_CHUNK", raising=False); monkeypatch.delenv("CDDP_HIP_GROUPS", raising=False)
+        monkeypatch.setenv(key, val)
+        r, X, U, ng = run()
+        assert ng == groups
+        for f in r.dtype.names:
+            assert np.array_equal(r[f], r0[f]), (key, f)
+        assert np.array_equal(X, X0) and np.array_equal(U, U0)
