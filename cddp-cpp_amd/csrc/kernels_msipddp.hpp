@@ -101,32 +101,43 @@ DEV void ms_reset_filter(const DevBuf &d, int b, int slot, double mu, double cos
   if constexpr (M > 0) {
     const double *Sc = d.S + (size_t)slot * d.planeM, *Yc = d.Y + (size_t)slot * d.planeM, *Gc = d.G + (size_t)slot * d.planeM;
     const double *Fc = d.F + (size_t)slot * d.planeX, *Xc = d.X + (size_t)slot * d.planeX;
-    for (int t = 0; t < d.N; ++t) {
-      double s[MM], y[MM], g[MM], f[NX], x1[NX];
-      ld<M>(Sc + GI(t, M, 0), kLS, s); ld<M>(Yc + GI(t, M, 0), kLS, y); ld<M>(Gc + GI(t, M, 0), kLS, g);
-      ld<NX>(Fc + GI(t, NX, 0), kLS, f); ld<NX>(Xc + GI(t + 1, NX, 0), kLS, x1);
+    // rows of step t + 1 in flight while step t is reduced (one lane per trajectory: a load issued at the top of its own step is a
+    // memory round trip on the chain of K5)
+    struct Row { double s[MM], y[MM], g[MM], f[NX], x1[NX]; };
+    auto fetch = [&](int tt, Row &r) {
+      ld<M>(Sc + GI(tt, M, 0), kLS, r.s); ld<M>(Yc + GI(tt, M, 0), kLS, r.y); ld<M>(Gc + GI(tt, M, 0), kLS, r.g);
+      ld<NX>(Fc + GI(tt, NX, 0), kLS, r.f); ld<NX>(Xc + GI(tt + 1, NX, 0), kLS, r.x1);
+    };
+    auto reduce = [&](const int t, const Row &c, Row &n) {
+      fetch(t + 1 < d.N ? t + 1 : d.N - 1, n);
+      PIPELINE_FENCE();
 #pragma unroll
-      for (int c = 0; c < NSEG; ++c) {
-        const int off = Cons::seg_off(c), dim = Cons::seg_dim(c);
+      for (int cs = 0; cs < NSEG; ++cs) {
+        const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
         double lsum = 0.0, l1 = 0.0;
 #pragma unroll
         for (int i = 0; i < MM; ++i) {
           if (i < dim) {
             const int j = off + i;
-            lsum += solver_log(s[j]);
-            const double pr = g[j] + s[j];
+            lsum += solver_log(c.s[j]);
+            const double pr = c.g[j] + c.s[j];
             ipr = dmax(ipr, fabs(pr)); l1 += fabs(pr);
-            icomp = dmax(icomp, fabs(y[j] * s[j] - mu));
+            icomp = dmax(icomp, fabs(c.y[j] * c.s[j] - mu));
           }
         }
         mf -= mu * lsum; fcv += l1;
       }
       double n1 = 0.0, ni = 0.0;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double r = f[i] - x1[i]; ni = dmax(ni, fabs(r)); n1 += fabs(r); }
+      for (int i = 0; i < NX; ++i) { const double r = c.f[i] - c.x1[i]; ni = dmax(ni, fabs(r)); n1 += fabs(r); }
       idef = dmax(idef, ni);
       fcv += n1;
-    }
+    };
+    Row ra, rb;
+    fetch(0, ra);
+    int t = 0;
+    for (; t + 1 < d.N; t += 2) { reduce(t, ra, rb); reduce(t + 1, rb, ra); }
+    if (t < d.N) reduce(t, ra, rb);
   }
   d.inf_pr[b] = dmax(ipr, idef); d.merit[b] = mf; d.phi[b] = mf; d.inf_comp[b] = icomp;
   d.filter_theta[b] = fcv; d.theta[b] = fcv;
