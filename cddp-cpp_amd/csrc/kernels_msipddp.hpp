@@ -726,7 +726,8 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += c.Ks[r * NX + j] * dx[j];
         sn[r] = (c.so[r] + alpha * c.ksv[r]) + s;
-        if (alive && sn[r] < (1.0 - tau) * c.so[r]) { alive = false; steps = t; } }
+        const bool viol = alive && (sn[r] < (1.0 - tau) * c.so[r]);
+        steps = viol ? t : steps; alive = alive && !viol; }
       st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
       // dual trials y + a_y k_y + K_y dx for every a_y of the ladder (:1612-1644): feasibility only; the rows are written once a_y is known
 #pragma unroll
@@ -734,11 +735,14 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += c.Ky[r * NX + j] * dx[j];
         const double bound = (1.0 - tau) * c.yo[r];
+        // (branch-free: bits of ladder entries beyond n_alphas are set or not, and never read)
+        unsigned int bad = 0u;
 #pragma unroll
         for (int q = 0; q < kAL; ++q) {
           const double yn = (c.yo[r] + al[q] * c.ky[r]) + s;
-          if (q < n_alphas && yn < bound) ymask &= ~(1u << q);
+          bad |= (yn < bound) ? (1u << q) : 0u;
         }
+        ymask &= ~bad;
         for (int q = kAL; q < n_alphas; ++q) {   // a ladder longer than the register copy (CDDP_HIP_MAX_ALPHAS = 32)
           const double yn = (c.yo[r] + P->alphas[q] * c.ky[r]) + s;
           if (yn < bound) ymask &= ~(1u << q);
