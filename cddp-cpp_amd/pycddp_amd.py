@@ -10,8 +10,8 @@ constraint kinds the device has kernels for.  On top of it:
 Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallback.  Python subclasses of `DynamicalSystem`,
 `Objective` / `NonlinearObjective` and `Constraint` (the reference's trampolines, `bind_dynamics.cpp:31-103`, `bind_objective.cpp`,
 `bind_constraints.cpp`) run through the host plug-in solve (`cddp_hip_plugin_solve`: batched backward passes on the GPU, forward
-passes on the host, callbacks into Python) -- as do MSIPDDP and single LogDDP solves for every problem (`solve_batch` of LogDDP on a
-built-in plant with nx <= 8 runs on the resident LogDDP kernels); anything the core does not implement raises
+passes on the host, callbacks into Python) -- as do single MSIPDDP / LogDDP solves for every problem (`solve_batch` of LogDDP or
+MSIPDDP on a built-in plant with nx <= 8 runs on the resident kernels, switches `logddp_route` / `msipddp_route`); anything the core does not implement raises
 (terminal constraints on plug-in problems, un-instantiated layouts, path-constrained MSIPDDP outside nu = 1 / nx = nu).
 """
 import enum
