@@ -818,7 +818,7 @@ struct SolveRun {
       if (waves_all <= 2048) { one_stage = true; }
       else { one_stage = false; k1 = k_cap2; }
     } else {
-      one_stage = false; k1 = std::max(1, std::min(kq + 1, k_cap));   // + 1: the histogram drifts between polls
+      one_stage = false; k1 = std::max(1, std::min(kq + ladder_margin(), k_cap));   // + 1: the histogram drifts between polls (CDDP_HIP_LS_MARGIN)
       // A chip that the whole ladder fills at most twice (one-stage territory) gains from a short first stage only what the
       // smaller launch saves over the rollout's latency floor (C2: 291 -> ~200 us at five step sizes), and loses a full second
       // rollout + costate + update (~235 us) whenever ONE trajectory walks past k1: kept only for a first stage of at most 768
@@ -926,6 +926,7 @@ struct SolveRun {
     }
   }
   static int ladder_frac() { static const int v = [] { const char *e = std::getenv("CDDP_HIP_LS_SMALL_FRAC"); const int n = e ? std::atoi(e) : 3; return n >= 1 ? n : 3; }(); return v; }   // "more than 1 / frac of the ladder" in the rule above (CDDP_HIP_LS_SMALL_FRAC; 2 / 3 / 4 / 11 -> C2-CLDDP 30.55 / 30.33 / 30.29 / 30.3 ms, pendulum MSIPDDP 15.2 / 15.0 / 15.05 / 17.3)
+  static int ladder_margin() { static const int v = [] { const char *e = std::getenv("CDDP_HIP_LS_MARGIN"); const int n = e ? std::atoi(e) : 1; return (n >= 0 && n <= 8) ? n : 1; }(); return v; }
   static int poll_every() {   // CDDP_HIP_POLL_EVERY=n (experiment): iterations between two "anything still running?" polls (default 4)
     static const int v = [] { const char *e = std::getenv("CDDP_HIP_POLL_EVERY"); const int n = e ? std::atoi(e) : 4; return n >= 1 ? n : 4; }();
     return v;
