@@ -80,6 +80,22 @@ const std::vector<KernelSet> &registry() {
 
 }  // namespace
 
+// ---- CU-partitioned streams (round 5) --------------------------------------------------------------------------
+// CDDP_HIP_CUMASK = "<spec>[|<spec> ...]", one spec per tile group (the last one repeats), spec = comma-separated "X=lo-hi" with
+//   C = the group's main stream (derivative fill, condensation, post, costate, update), F = its rollout stream, W = its serial-sweep stream
+// and [lo, hi) a range of CU-mask bits.  On gfx942 / gfx950 the KFD maps mask bit i to XCC i % 8, then shader engine, then CU
+// (kfd_mqd_manager.c::mqd_symmetrically_map_cu_mask), so a contiguous bit range is a symmetric slice of every XCD.  A class without
+// a range runs on the main stream (F, W) or on an unmasked stream (C).  Kernels of one group on different streams are ordered by
+// events (SolveRun::enqueue_iteration, launch.hpp::sweep_hop_in / out); nothing else changes, so results are bitwise those of one
+// stream (tests/test_determinism.py).
+//   "X=x<digits>" instead of a range: the whole of the named XCDs (bits i with i % 8 among the digits).
+struct CuSpec { int lo[3] = {-1, -1, -1}, hi[3] = {-1, -1, -1}; unsigned xcd[3] = {0, 0, 0}; };   // index 0 = C, 1 = F, 2 = W; xcd: bit k = XCD k (0 = a range)
+struct CuPlan {
+  hipStream_t fwd = nullptr, sweep = nullptr;   // nullptr: the main stream
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // main->fwd, fwd->main (stage 1, stage 2); main->sweep, sweep->main
+  SweepHop hop{nullptr, nullptr, nullptr};
+};
+
 struct Inner {
   ProblemDev P;
   DevBuf d;
@@ -87,6 +103,7 @@ struct Inner {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  CuPlan cu;
   std::vector<void *> allocs;
   ProblemDev *dP = nullptr;
   double *d_xref_traj = nullptr;
@@ -100,9 +117,9 @@ struct Inner {
   size_t bytes = 0;
   int timing_detail = CDDP_HIP_TIMING_ROLLOUT;   // which kernel classes cddp_hip_solve brackets with events
   std::vector<hipEvent_t> ev_pool;               // reused across solves (creating an event per mark costs host time)
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll = nullptr, ev_poll2 = nullptr;
   double *d_head = nullptr, *h_head = nullptr; size_t head_cap = 0;   // cddp_hip_get_plan_head staging (device, pinned host)
-  int *h_poll = nullptr;                         // pinned host words of the solve loop's poll: [0] running count, [1..] alpha histogram
+  int *h_poll = nullptr;                         // pinned host words of the solve loop's polls, two slots of kPollWords: [0] running count, [1..] alpha histogram
   std::map<unsigned long long, hipGraphExec_t> graphs;   // CDDP_HIP_GRAPH=1: captured iteration windows by (ladder shape, length, last flag)
   std::map<unsigned long long, int> graph_launches;
 };
@@ -352,7 +369,52 @@ int cddp_hip_build_alphas(const cddp_hip_options *opt, double *alphas, int cap) 
   return n > cap ? cap : n;
 }
 
-static int in_create(const cddp_hip_problem *problem, int batch, int device, Inner **out) {
+
+// one "X=lo-hi,..." spec
+static bool parse_cu_spec(const std::string &t, CuSpec *o) {
+  size_t i = 0;
+  while (i < t.size()) {
+    size_t j = t.find(',', i); if (j == std::string::npos) j = t.size();
+    const std::string f = t.substr(i, j - i);
+    i = j + 1;
+    if (f.empty()) continue;
+    int lo = 0, hi = 0; char c = 0;
+    unsigned xm = 0;
+    if (f.size() >= 4 && f[1] == '=' && f[2] == 'x') {
+      c = f[0];
+      for (size_t q = 3; q < f.size(); ++q) { if (f[q] < '0' || f[q] > '7') return false; xm |= 1u << (f[q] - '0'); }
+      lo = 0; hi = 1024;
+    } else if (std::sscanf(f.c_str(), " %c=%d-%d", &c, &lo, &hi) != 3 || lo < 0 || hi <= lo || hi > 1024) return false;
+    const int k = (c == 'C') ? 0 : (c == 'F') ? 1 : (c == 'W') ? 2 : -1;
+    if (k < 0) return false;
+    o->lo[k] = lo; o->hi[k] = hi; o->xcd[k] = xm;
+  }
+  return true;
+}
+// the spec of group `gi` from CDDP_HIP_CUMASK (false: no partition requested / malformed -> plain streams)
+static bool cu_spec_for_group(int gi, CuSpec *o) {
+  const char *e = std::getenv("CDDP_HIP_CUMASK");
+  if (!e || !e[0]) return false;
+  std::vector<std::string> parts;
+  { std::string t(e); size_t i = 0; for (;;) { size_t j = t.find('|', i); parts.push_back(t.substr(i, j == std::string::npos ? j : j - i)); if (j == std::string::npos) break; i = j + 1; } }
+  const std::string &t = parts[std::min((size_t)gi, parts.size() - 1)];
+  CuSpec sp;
+  if (!parse_cu_spec(t, &sp)) { std::fprintf(stderr, "[cddp_hip] CDDP_HIP_CUMASK: cannot parse '%s' -- ignored\n", t.c_str()); return false; }
+  *o = sp;
+  return true;
+}
+static hipError_t make_stream(hipStream_t *s, int device, int lo, int hi, unsigned xcd = 0) {
+  if (lo < 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int ncu = 0;
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+  if (ncu <= 0) ncu = 256;
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int b = lo; b < hi && b < ncu; ++b) if (!xcd || ((xcd >> (b % 8)) & 1u)) mask[(size_t)b >> 5] |= 1u << (b & 31);
+  return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask.data());
+}
+
+static int in_create(const cddp_hip_problem *problem, int batch, int device, Inner **out, const CuSpec *cu = nullptr) {
   if (!problem || !out) return fail(-1, "null argument");
   if (batch <= 0) return fail(-1, "batch must be positive");
   int ndev = cddp_hip_device_count();
@@ -391,9 +453,16 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   h->device = device;
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) { delete h; return fail(-10, "hipSetDevice: %s", hipGetErrorString(e)); }
-  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  e = make_stream(&h->stream, device, cu ? cu->lo[0] : -1, cu ? cu->hi[0] : -1, cu ? cu->xcd[0] : 0);
   if (e != hipSuccess) { delete h; return fail(-10, "hipStreamCreate: %s", hipGetErrorString(e)); }
   h->own_stream = true;
+  if (cu && (cu->lo[1] >= 0 || cu->lo[2] >= 0)) {
+    if (cu->lo[1] >= 0) e = make_stream(&h->cu.fwd, device, cu->lo[1], cu->hi[1], cu->xcd[1]);
+    if (e == hipSuccess && cu->lo[2] >= 0) e = make_stream(&h->cu.sweep, device, cu->lo[2], cu->hi[2], cu->xcd[2]);
+    for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&h->cu.ev[k], hipEventDisableTiming);
+    if (e != hipSuccess) { delete h; return fail(-10, "CU-masked stream: %s", hipGetErrorString(e)); }
+    h->cu.hop = SweepHop{h->cu.sweep, h->cu.ev[4], h->cu.ev[5]};
+  }
 
   const ProblemDev &P = h->P;
   DevBuf &d = h->d;
@@ -484,14 +553,20 @@ static int in_destroy(Inner *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  if (h->cu.fwd) hipStreamSynchronize(h->cu.fwd);
+  if (h->cu.sweep) hipStreamSynchronize(h->cu.sweep);
   free_all(h);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->ev_begin) { hipEventDestroy(h->ev_begin); hipEventDestroy(h->ev_end); }
   if (h->ev_poll) hipEventDestroy(h->ev_poll);
+  if (h->ev_poll2) hipEventDestroy(h->ev_poll2);
   if (h->h_poll) hipHostFree(h->h_poll);
   if (h->d_head) hipFree(h->d_head);
   if (h->h_head) hipHostFree(h->h_head);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  if (h->cu.fwd) hipStreamDestroy(h->cu.fwd);
+  if (h->cu.sweep) hipStreamDestroy(h->cu.sweep);
+  for (hipEvent_t e : h->cu.ev) if (e) hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -759,7 +834,26 @@ struct SolveRun {
   int k1 = 1, k_cap = 1, k_cap2 = 1;
   long waves_all = 0, per_alpha_waves = 1, two_stage_max_waves = 768;
   std::vector<int> hist_now, hist_prev;
-  hipEvent_t poll_ev = nullptr;
+  // Polls are double-buffered (round 5): behind a poll the host enqueues run_ahead() more iterations (default 1; none behind the two early polls that settle the ladder shape) BEFORE it waits for
+  // the poll's words, so the group's queue does not drain while the host wakes up and enqueues (the poll only decides the ladder
+  // shape and whether anything is still running; surplus iterations after the last trajectory finished are launches whose every
+  // lane exits on its phase check).  A whole window ahead (4) lags the ladder adaptation of converging solves by a window and costs
+  // C3 more than the drain (profiles/r05_cumask.md); CDDP_HIP_RUNAHEAD=0 restores the drain-at-every-poll loop of rounds 1 - 4.
+  static constexpr int kPollWords = CDDP_HIP_MAX_ALPHAS + 2;
+  hipEvent_t poll_evs[2] = {nullptr, nullptr};
+  int win_enq = 0, win_dig = 0, win_it[2] = {0, 0};
+  int outstanding() const { return win_enq - win_dig; }
+  static int run_ahead() { static const int v = [] { const char *e = std::getenv("CDDP_HIP_RUNAHEAD"); const int n = e ? std::atoi(e) : 1; return (n >= 0 && n <= 16) ? n : 1; }(); return v; }
+  bool ran_ahead = false;
+  int post_poll(hipStream_t s) {
+    const int slot = win_enq & 1;
+    HIPCHK(hipMemcpyAsync(h->h_poll + slot * kPollWords, h->d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_poll + slot * kPollWords + 1, h->d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(poll_evs[slot], s));
+    win_it[slot] = it;
+    ++win_enq;
+    return 0;
+  }
   std::chrono::steady_clock::time_point wall0;
   // ping-pong of two half-batch groups (cddp_hip_solve): this group's rollout launches wait for the other group's last rollout and
   // are followed by an event the other group waits for -- the two groups' rollouts never share the chip, each runs beside the other
@@ -854,9 +948,10 @@ struct SolveRun {
     { const char *e = std::getenv("CDDP_HIP_GRAPH"); use_graph = e && e[0] == '1'; }
     detail = (want_stats && !use_graph) ? h->timing_detail : -1;
     if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
-    if (!h->ev_poll) HIPCHK(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
-    poll_ev = h->ev_poll;
-    if (!h->h_poll) HIPCHK(hipHostMalloc((void **)&h->h_poll, sizeof(int) * (CDDP_HIP_MAX_ALPHAS + 2)));
+    if (!h->ev_poll) { HIPCHK(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_poll2, hipEventDisableTiming)); }
+    poll_evs[0] = h->ev_poll; poll_evs[1] = h->ev_poll2;
+    win_enq = win_dig = 0; ran_ahead = false;
+    if (!h->h_poll) HIPCHK(hipHostMalloc((void **)&h->h_poll, sizeof(int) * 2 * kPollWords));
     HIPCHK(hipMemsetAsync(h->d_launched, 0, sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(h->ev_begin, s));
     { int rc = run_initialize(h); if (rc) return rc; }
@@ -896,28 +991,39 @@ struct SolveRun {
     const DevBuf &d = h->d;
     hipStream_t s = h->stream;
     const KernelSet *ks = h->ks;
+    // CU-partitioned streams (CuPlan): the rollout on its own stream, ordered against the main stream by two events per launch
+    hipStream_t sf = h->cu.fwd ? h->cu.fwd : s;
+    auto to_fwd = [&](int k) { if (sf != s) { hipEventRecord(h->cu.ev[k], s); hipStreamWaitEvent(sf, h->cu.ev[k], 0); } };
+    auto from_fwd = [&](int k) { if (sf != s) { hipEventRecord(h->cu.ev[k], sf); hipStreamWaitEvent(s, h->cu.ev[k], 0); } };
     two_stage_marks = !one_stage;
     mark(0);
     ks->derivs(d, 0, s);
+    tl_sweep_hop = h->cu.sweep ? &h->cu.hop : nullptr;
     ks->backward(d, P.solver, 0, 1, s);
+    tl_sweep_hop = nullptr;
     mark(1);
-    if (fwd_wait) hipStreamWaitEvent(s, fwd_wait, 0);
+    to_fwd(0);
+    if (fwd_wait) hipStreamWaitEvent(sf, fwd_wait, 0);
     if (one_stage) {
-      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, s);
-      if (fwd_done) hipEventRecord(fwd_done, s);
+      ks->forward(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 0, sf);
+      if (fwd_done) hipEventRecord(fwd_done, sf);
+      from_fwd(1);
       mark(2);
       ks->costate(d, P.solver, 0, na, PH_FWD1, 0, first_rule ? 1 : 2, s);   // best-merit rule: the candidate winner's costate only (k_costate)
       ks->update(d, 1, na, last, 1, s);
       mark(3);
       launches += 4;
     } else {
-      ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
+      ks->forward(d, P.solver, 0, k1, PH_FWD1, 0, 1, sf);
+      from_fwd(1);
       mark(2);
       ks->costate(d, P.solver, 0, k1, PH_FWD1, 0, 1, s);
       ks->update(d, 1, k1, last, 0, s);
       mark(3);
-      ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
-      if (fwd_done) hipEventRecord(fwd_done, s);
+      to_fwd(2);
+      ks->forward(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, sf);
+      if (fwd_done) hipEventRecord(fwd_done, sf);
+      from_fwd(3);
       mark(4);
       ks->costate(d, P.solver, k1, na - k1, PH_FWD2, 0, 1, s);
       ks->update(d, 2, na, last, 1, s);
@@ -961,9 +1067,7 @@ struct SolveRun {
     { const int l0 = launches; for (int j = 0; j < w; ++j) launches += one_stage ? 4 : 6; (void)l0; }
     HIPCHK(hipGraphLaunch(f->second, s));
     it += w; outer += w;
-    HIPCHK(hipMemcpyAsync(h->h_poll, h->d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_poll + 1, h->d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(poll_ev, s));
+    { int rc = post_poll(s); if (rc) return rc; }
     return 1;
   }
 
@@ -995,9 +1099,7 @@ struct SolveRun {
       // launches), so it is made every kPollEvery iterations; the up-to-3 surplus iterations after the last
       // trajectory finished are launches whose every lane exits on its phase check.
       if (polled_iteration(it, max_it, pinned)) {   // every kPollEvery iterations, the last one, and two early polls: the ladder statistics settle the shape
-        HIPCHK(hipMemcpyAsync(h->h_poll, d.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(h->h_poll + 1, d.win_hist, sizeof(int) * (na + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(poll_ev, s));
+        { int rc = post_poll(s); if (rc) return rc; }
         return 1;   // a poll is pending
       }
       if (++enq >= max_new) return 2;
@@ -1006,12 +1108,17 @@ struct SolveRun {
     return 0;
   }
 
-  int complete_poll() {
+  int complete_poll() {   // digests the OLDEST outstanding poll
     const int kPollEvery = poll_every();
-    HIPCHK(hipEventSynchronize(poll_ev));
-    if (*h->h_poll == 0 || it >= max_it) { done = true; return 0; }
-    for (int a = 0; a <= na; ++a) hist_now[a] = h->h_poll[1 + a];
-    adapt_ladder(it <= 2 ? 1 : (it == kPollEvery ? 2 : kPollEvery));
+    if (outstanding() <= 0) return 0;
+    const int slot = win_dig & 1;
+    HIPCHK(hipEventSynchronize(poll_evs[slot]));
+    ++win_dig;
+    const int *w = h->h_poll + slot * kPollWords;
+    const int pit = win_it[slot];
+    if (w[0] == 0 || pit >= max_it) { done = true; win_dig = win_enq; return 0; }   // (later polls, if any, are dropped: finish() drains the stream)
+    for (int a = 0; a <= na; ++a) hist_now[a] = w[1 + a];
+    adapt_ladder(pit <= 2 ? 1 : (pit == kPollEvery ? 2 : kPollEvery));
     return 0;
   }
 
@@ -1288,19 +1395,32 @@ namespace {
 //    times the 256 MB Infinity Cache.  A trajectory's result does not depend on its group (bitwise, tests/test_full_size.py,
 //    tests/test_determinism.py), so oversubscription costs nothing: the large batch runs at the throughput of its best chunk size
 //    (profiles/r04_batch_curve.md).  CDDP_HIP_CHUNK=<trajectories> overrides the chunk size (0 = never chunk).
-int pick_groups(int batch, int n_alphas, int *conc) {
+//  * round 5: STATIC CU PARTITION.  An IPDDP / CLDDP batch (or each chunk of a large one) of at least 32 tiles is cut into TWO groups that
+//    are solved concurrently, each with every kernel of its iterations on its own symmetric half of the chip (streams created with
+//    hipExtStreamCreateWithCUMask; mask bits [0, 128) and [128, 256) = half of the CUs of every XCD, see CuSpec).  Two independent
+//    half-chips at half the batch run 3 - 6 % faster than the whole chip at the whole batch (profiles/r05_cumask.md: C2 45.6 -> 42.8 ms,
+//    C3 81.5 -> 78.9, C4 share 955 -> 916, C5 share 1041 -> 992; CLDDP + 1.4 %, LogDDP 0, MSIPDDP - 4 %: not partitioned), while the
+//    same two groups WITHOUT masks lose 3 - 5 % (their wavefronts share SIMDs) and any split that moves one kernel class to another
+//    stream pays ~20 us of cross-stream events per iteration.  *part = slices (1 = no masks); CDDP_HIP_PARTITION=n overrides (1 = off).
+int pick_groups(int batch, int n_alphas, int solver, int *conc, int *part) {
   const int tiles = (batch + 63) / 64;
   const char *e = std::getenv("CDDP_HIP_GROUPS");
   int n = e ? std::atoi(e) : 0;
+  *part = 1;
   if (n > 0) { n = std::max(1, std::min(n, tiles)); *conc = n; return n; }
   *conc = 1;
   int chunk_tiles = std::max(16, 2816 / (2 * std::max(1, n_alphas)));     // 128 tiles (8192 trajectories) at 11 step sizes
+  bool chunking = true;
   if (const char *c = std::getenv("CDDP_HIP_CHUNK")) {
     const int v = std::atoi(c);
-    if (v <= 0) return 1;
-    chunk_tiles = std::max(1, (v + 63) / 64);
+    if (v <= 0) chunking = false; else chunk_tiles = std::max(1, (v + 63) / 64);
   }
-  return std::max(1, (tiles + chunk_tiles - 1) / chunk_tiles);
+  const int chunks = chunking ? std::max(1, (tiles + chunk_tiles - 1) / chunk_tiles) : 1;
+  int np = (solver == CDDP_HIP_SOLVER_IPDDP || solver == CDDP_HIP_SOLVER_CLDDP) ? 2 : 1;
+  if (const char *c = std::getenv("CDDP_HIP_PARTITION")) { const int v = std::atoi(c); if (v >= 1 && v <= 16 && 256 % v == 0) np = v; }
+  if (std::getenv("CDDP_HIP_CUMASK")) np = 1;                              // an explicit plan (experiments) replaces the default one
+  if (np > 1 && tiles / chunks >= 16 * np) { *conc = np; *part = np; return chunks * np; }
+  return chunks;
 }
 
 // ordering against a caller-supplied stream: fork = group streams wait for the user's stream, join = the reverse
@@ -1328,8 +1448,8 @@ extern "C" {
 int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp_hip_handle **out) {
   if (!problem || !out) return fail(-1, "null argument");
   if (batch <= 0) return fail(-1, "batch must be positive");
-  int conc = 1;
-  const int tiles = (batch + 63) / 64, ng = pick_groups(batch, problem->options.ls_max_iterations, &conc);
+  int conc = 1, part = 1;
+  const int tiles = (batch + 63) / 64, ng = pick_groups(batch, problem->options.ls_max_iterations, problem->solver, &conc, &part);
   cddp_hip_handle *h = new cddp_hip_handle();
   h->B = batch; h->device = device; h->conc = conc;
   { const char *e = std::getenv("CDDP_HIP_PINGPONG"); h->pingpong = e && e[0] == '1'; }
@@ -1340,7 +1460,10 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
     t0 += nt;
     if (last <= first) continue;
     Inner *q = nullptr;
-    int rc = in_create(problem, last - first, device, &q);
+    CuSpec cus;
+    bool have_cu = cu_spec_for_group(k, &cus);
+    if (!have_cu && part > 1) { const int w = 256 / part; cus.lo[0] = (k % part) * w; cus.hi[0] = cus.lo[0] + w; have_cu = true; }
+    int rc = in_create(problem, last - first, device, &q, have_cu ? &cus : nullptr);
     if (rc) { for (Inner *p : h->g) in_destroy(p); delete h; return rc; }
     h->g.push_back(q); h->b0.push_back(first);
   }
@@ -1467,7 +1590,6 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   // The whole-handle time is the span from group 0's begin to an end event group 0's stream records after it has waited for
   // every other group's end.
   const int conc = std::max(1, std::min(h->conc, ng));
-  std::vector<int> pending(ng, 0);
   if (h->pingpong && ng == 2) {
     // two half-batch groups in lockstep, one iteration each in turn; rollouts serialised A1 B1 A2 B2 ... by events (SolveRun::fwd_wait)
     if (!h->ev_pp[0]) for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&h->ev_pp[k], hipEventDisableTiming));
@@ -1475,26 +1597,28 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
     for (;;) {
       bool any = false;
       for (int k = 0; k < 2; ++k) {
-        if (run[k].done || pending[k] == 1) continue;
+        if (run[k].done || run[k].outstanding() > 0) continue;
         int rc = run[k].advance(1); if (rc < 0) return rc;
-        pending[k] = rc; any = any || rc != 0;
+        any = any || rc != 0;
       }
-      for (int k = 0; k < 2; ++k) if (pending[k] == 1) { int rc = run[k].complete_poll(); if (rc) return rc; pending[k] = 0; any = true; }
+      for (int k = 0; k < 2; ++k) if (run[k].outstanding() > 0) { int rc = run[k].complete_poll(); if (rc) return rc; any = true; }
       if (!any) break;
     }
   } else
   for (int base = 0; base < ng; base += conc) {
     const int top = std::min(ng, base + conc);
     for (int k = base; k < top; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, conc); if (rc) return rc; }
-    for (int k = base; k < top; ++k) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+    // each pass, per group: no poll outstanding -> enqueue iterations up to the next polled one; one outstanding and not yet run
+    // ahead -> enqueue run_ahead() more iterations behind it; otherwise digest the oldest poll.  So a group's queue holds work while
+    // the host waits for a poll, and the host never blocks on one group while another has nothing queued
     for (;;) {
       bool any = false;
       for (int k = base; k < top; ++k) {
-        if (!pending[k]) continue;
-        any = true;
-        { int rc = run[k].complete_poll(); if (rc) return rc; }
-        pending[k] = 0;
-        if (!run[k].done) { int rc = run[k].advance(); if (rc < 0) return rc; pending[k] = rc; }
+        SolveRun &r = run[k];
+        const int ra = (h->g[k]->P.opt.max_cpu_time > 0.0 || r.use_graph || r.it < SolveRun::poll_every()) ? 0 : SolveRun::run_ahead();
+        if (!r.done && r.outstanding() == 0) { int rc = r.advance(); if (rc < 0) return rc; r.ran_ahead = false; any = true; }
+        else if (!r.done && r.outstanding() == 1 && ra > 0 && !r.ran_ahead) { int rc = r.advance(ra); if (rc < 0) return rc; r.ran_ahead = true; any = true; }
+        else if (r.outstanding() > 0) { int rc = r.complete_poll(); if (rc) return rc; r.ran_ahead = r.outstanding() > 0; any = true; }
       }
       if (!any) break;
     }

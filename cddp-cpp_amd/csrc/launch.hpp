@@ -12,6 +12,25 @@
 
 namespace cddp_dev {
 
+// CU-partitioned streams (round 5, capi.hip::CuPlan): when the calling thread has set a hop, the SERIAL sweep kernel of backward() is
+// enqueued on the hop's stream (a stream created with hipExtStreamCreateWithCUMask) instead of the caller's, bracketed by two events:
+// the wide (batch x N) kernels before / after it stay on the caller's stream.  nullptr (the default): everything on one stream.
+struct SweepHop { hipStream_t s; hipEvent_t ev_in, ev_out; };
+inline thread_local const SweepHop *tl_sweep_hop = nullptr;
+inline hipStream_t sweep_hop_in(hipStream_t s) {
+  const SweepHop *h = tl_sweep_hop;
+  if (!h || h->s == s) return s;
+  hipEventRecord(h->ev_in, s);
+  hipStreamWaitEvent(h->s, h->ev_in, 0);
+  return h->s;
+}
+inline void sweep_hop_out(hipStream_t s) {
+  const SweepHop *h = tl_sweep_hop;
+  if (!h || h->s == s) return;
+  hipEventRecord(h->ev_out, h->s);
+  hipStreamWaitEvent(s, h->ev_out, 0);
+}
+
 struct KernelSet {
   int model, nx, nu, m;
   int cst_size;   // per-step doubles of the condensed-term stack (lean IPDDP backward), 0 = fused sweep
@@ -127,7 +146,8 @@ struct Launcher {
       // the tensor terms of full DDP, serves nx > 8 (scratch-backed) and CDDP_HIP_SWEEP=lane (comparison)
       if constexpr (kLog && Model::NX <= 8) {
         if (!lane_sweep_requested() && !d.ddp) {
-          hipLaunchKernelGGL((k_backward_coop_plain<Model, true, Cons>), dim3(coop_grid<CoopCfg<Model>::TPW>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          hipLaunchKernelGGL((k_backward_coop_plain<Model, true, Cons>), dim3(coop_grid<CoopCfg<Model>::TPW>(d.B, d.xcd_map)), dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+          sweep_hop_out(s);
           return;
         }
       }
@@ -143,8 +163,10 @@ struct Launcher {
     if (solver == CDDP_HIP_SOLVER_CLDDP) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_clddp<Model>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-      else
-        hipLaunchKernelGGL((k_backward_coop_plain<Model, true>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else {
+        hipLaunchKernelGGL((k_backward_coop_plain<Model, true>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+        sweep_hop_out(s);
+      }
     } else if constexpr (kLean) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_ipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
@@ -169,7 +191,10 @@ struct Launcher {
           if (hsel == 2)
             hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 2>), dim3(coop_grid<TPW2>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
           else
-            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          {
+            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+            sweep_hop_out(s);
+          }
         }
       }
       else {
@@ -182,19 +207,24 @@ struct Launcher {
             launched = true;
           }
         }
-        if (!launched)
-          hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+        if (!launched) {
+          hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+          sweep_hop_out(s);
+        }
       }
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
     } else if constexpr (!TERM && Cons::M == 0) {
       if (lane_sweep)
         hipLaunchKernelGGL((k_backward_ipddp<Model, Cons, TERM>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
-      else
-        hipLaunchKernelGGL((k_backward_coop_plain<Model, false>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      else {
+        hipLaunchKernelGGL((k_backward_coop_plain<Model, false>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+        sweep_hop_out(s);
+      }
     } else {
       if constexpr (kTeCoop) {
         if (d.te_cst && !lane_sweep) {
-          hipLaunchKernelGGL((k_backward_te_coop<Model, Cons>), gridC, dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+          hipLaunchKernelGGL((k_backward_te_coop<Model, Cons>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+          sweep_hop_out(s);
           // steps per block: as many as keep >= ~1024 waves in the grid (1 for small batches)
           const int tiles = (d.B + 63) / 64;
           int tstep = (int)(((long long)tiles * d.N) / 1024); if (tstep < 1) tstep = 1; if (tstep > 16) tstep = 16;

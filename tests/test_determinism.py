@@ -107,3 +107,33 @@ def test_successive_chunks_of_a_large_batch_do_not_change_results(api, kind, mon
     got = run("256", 4)
     for a, b in zip(ref, got):
         assert np.array_equal(a, b), kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cartpole_ipddp", "cartpole_clddp", "unicycle_ipddp"])
+@pytest.mark.parametrize("plan", ["F=0-192,W=192-256", "C=128-256,F=0-128", "F=0-176,W=176-208|F=0-176,W=208-240"])
+def test_cu_partitioned_streams_do_not_change_results(api, kind, plan, monkeypatch):
+    """CDDP_HIP_CUMASK (round 5): the rollout and the serial sweep of a tile group on streams created with
+    hipExtStreamCreateWithCUMask, ordered against the group's main stream by events -- same kernels, same arguments, same
+    order per trajectory (cddp_solver_base.cpp:29-186), so every result word is the one-stream solve's; also with two groups
+    whose rollouts alternate (CDDP_HIP_PINGPONG)."""
+    p = {"cartpole_ipddp": lambda: api.cartpole_problem(api.SOLVER_IPDDP, True), "cartpole_clddp": lambda: api.cartpole_problem(api.SOLVER_CLDDP, True),
+         "unicycle_ipddp": lambda: api.unicycle_problem(api.SOLVER_IPDDP, 100, True)}[kind]()
+    B = 600
+    x0 = api.batch_x0(p, B, 20270301, 0.05 * np.ones(p.nx))
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0); st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); hs.close()
+        return [r[f].copy() for f in r.dtype.names] + [X, U, K, k, np.array([st.sweeps, st.rollouts, st.traj_iterations, st.rollout_steps])]
+
+    for v in ("CDDP_HIP_CUMASK", "CDDP_HIP_GROUPS", "CDDP_HIP_PINGPONG"):
+        monkeypatch.delenv(v, raising=False)
+    ref = run()
+    monkeypatch.setenv("CDDP_HIP_CUMASK", plan)
+    for groups, pp in ((1, 0), (2, 0), (2, 1)):
+        monkeypatch.setenv("CDDP_HIP_GROUPS", str(groups))
+        monkeypatch.setenv("CDDP_HIP_PINGPONG", str(pp))
+        cur = run()
+        for a, b in zip(ref, cur):
+            assert np.array_equal(a, b), (kind, plan, groups, pp)
