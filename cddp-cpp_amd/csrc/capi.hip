@@ -122,6 +122,8 @@ struct Inner {
   int *h_poll = nullptr;                         // pinned host words of the solve loop's polls, two slots of kPollWords: [0] running count, [1..] alpha histogram
   std::map<unsigned long long, hipGraphExec_t> graphs;   // CDDP_HIP_GRAPH=1: captured iteration windows by (ladder shape, length, last flag)
   std::map<unsigned long long, int> graph_launches;
+  int last_t4 = 0;               // layout of the A / B stacks the last derivative fill wrote (launch.hpp::t4_layout at that launch)
+  unsigned env_sig = 0;          // kernel-selection environment the cached graphs were captured under (CDDP_HIP_SWEEP / T4 / K4_NA / COOP_H)
 };
 
 namespace {
@@ -470,16 +472,17 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
   d.ddp = P.opt.use_ilqr ? 0 : 1;
+  { const char *e = std::getenv("CDDP_HIP_TEST_FAIL_COSTATE"); d.fail_costate_mask = e ? std::atoi(e) : 0; }   // test hook, DevBuf::fail_costate_mask
   { const char *e = std::getenv("CDDP_HIP_XCD_MAP"); d.xcd_map = (e && e[0] == '0') ? 0 : 1; }
   d.t4 = 0;   // set per launch by launch.hpp::derivs / backward (kernels.hpp::GT)
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
-  d.hist_cap = P.opt.max_iterations + 1;
+  d.hist_cap = std::max(P.opt.max_iterations, 0) + 1;
   d.planeX = (size_t)(N + 1) * nx * Bp; d.planeU = (size_t)N * nu * Bp; d.planeM = (size_t)N * (m > 0 ? m : 0) * Bp;
   const bool ip = (P.solver == CDDP_HIP_SOLVER_IPDDP);
   d.lg = (P.solver == CDDP_HIP_SOLVER_LOGDDP) ? 1 : 0;
   const bool ms = (P.solver == CDDP_HIP_SOLVER_MSIPDDP);
   d.ms = ms ? 1 : 0;
-  d.filt_cap = ms ? P.opt.max_iterations + 2 : kFilterCap;
+  d.filt_cap = ms ? std::max(P.opt.max_iterations, 0) + 2 : kFilterCap;   // (a negative max_iterations is a legal no-op solve, SolveRun::begin)
 #define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { free_all(h); delete h; return rc_; } } while (0)
   DA(d.X, d.planeX * d.n_slots); DA(d.U, d.planeU * d.n_slots);
   if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
@@ -774,6 +777,7 @@ static int in_backward(Inner *h, int32_t *ok) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
   if (!h->initialized) { int rc = in_initialize(h); if (rc) return rc; }
+  h->last_t4 = h->ks->t4_layout(h->d);
   h->ks->derivs(h->d, 1, h->stream);
   h->ks->backward(h->d, h->P.solver, 1, 0, h->stream);
   HIPCHK(hipGetLastError());
@@ -997,6 +1001,7 @@ struct SolveRun {
     auto from_fwd = [&](int k) { if (sf != s) { hipEventRecord(h->cu.ev[k], sf); hipStreamWaitEvent(s, h->cu.ev[k], 0); } };
     two_stage_marks = !one_stage;
     mark(0);
+    h->last_t4 = ks->t4_layout(d);   // the layout this fill writes (cddp_hip_get_linearization reads it back with the same rule's answer)
     ks->derivs(d, 0, s);
     tl_sweep_hop = h->cu.sweep ? &h->cu.hop : nullptr;
     ks->backward(d, P.solver, 0, 1, s);
@@ -1051,6 +1056,15 @@ struct SolveRun {
     if (w == 0) { done = true; return 0; }
     const int last = (it + w == max_it) ? 1 : 0;
     const unsigned long long key = ((unsigned long long)(one_stage ? 0 : k1) << 16) | ((unsigned long long)w << 4) | (unsigned long long)last;
+    {   // a captured window bakes in the kernels launch.hpp selected from the environment: drop the cache when that selection changed
+      unsigned sig = 2166136261u;
+      for (const char *v : {"CDDP_HIP_SWEEP", "CDDP_HIP_T4", "CDDP_HIP_K4_NA", "CDDP_HIP_COOP_H"}) {
+        const char *e = std::getenv(v);
+        for (const char *c = e ? e : "-"; *c; ++c) sig = (sig ^ (unsigned char)*c) * 16777619u;
+        sig = (sig ^ 0xffu) * 16777619u;
+      }
+      if (sig != h->env_sig) { for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second); h->graphs.clear(); h->graph_launches.clear(); h->env_sig = sig; }
+    }
     auto f = h->graphs.find(key);
     if (f == h->graphs.end()) {
       hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
@@ -1258,8 +1272,8 @@ static int in_get_linearization(Inner *h, double *A, double *Bm) {
   HIPCHK(hipStreamSynchronize(h->stream));
   const DevBuf &d = h->d;
   std::vector<double> buf;
-  // (the layout the last derivative fill wrote: the rule of launch.hpp, a function of the handle and the environment)
-  const bool t4 = h->P.solver == CDDP_HIP_SOLVER_IPDDP && h->ks->t4_layout(d) != 0;
+  // the layout the LAST derivative fill wrote (recorded at that launch: the environment may have been switched since)
+  const bool t4 = h->P.solver == CDDP_HIP_SOLVER_IPDDP && h->last_t4 != 0;
   auto conv = t4 ? &from_t4 : &from_soa;
   if (A) { int rc = fetch(h, d.A, (size_t)d.N * h->P.nx * h->P.nx * d.Bp, buf); if (rc) return rc; conv(buf.data(), A, d.B, d.Bp, d.N, h->P.nx * h->P.nx); }
   if (Bm) { int rc = fetch(h, d.Bm, (size_t)d.N * h->P.nx * h->P.nu * d.Bp, buf); if (rc) return rc; conv(buf.data(), Bm, d.B, d.Bp, d.N, h->P.nx * h->P.nu); }
@@ -1449,7 +1463,9 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
   if (!problem || !out) return fail(-1, "null argument");
   if (batch <= 0) return fail(-1, "batch must be positive");
   int conc = 1, part = 1;
-  const int tiles = (batch + 63) / 64, ng = pick_groups(batch, problem->options.ls_max_iterations, problem->solver, &conc, &part);
+  double ladder[CDDP_HIP_MAX_ALPHAS];
+  const int n_ladder = cddp_hip_build_alphas(&problem->options, ladder, CDDP_HIP_MAX_ALPHAS);   // the real ladder length (it can stop early at ls_min_step_size)
+  const int tiles = (batch + 63) / 64, ng = pick_groups(batch, n_ladder, problem->solver, &conc, &part);
   cddp_hip_handle *h = new cddp_hip_handle();
   h->B = batch; h->device = device; h->conc = conc;
   { const char *e = std::getenv("CDDP_HIP_PINGPONG"); h->pingpong = e && e[0] == '1'; }
@@ -1585,6 +1601,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   HIPCHK(hipSetDevice(h->device));
   { int rc = fork_from_user(h); if (rc) return rc; }
   const int ng = (int)h->g.size();
+  const auto solve_t0 = std::chrono::steady_clock::now();
   std::vector<SolveRun> run(ng);
   // `conc` groups are in flight at a time (all of them with CDDP_HIP_GROUPS; one with the default chunking of a large batch).
   // The whole-handle time is the span from group 0's begin to an end event group 0's stream records after it has waited for
@@ -1607,7 +1624,7 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
   } else
   for (int base = 0; base < ng; base += conc) {
     const int top = std::min(ng, base + conc);
-    for (int k = base; k < top; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, conc); if (rc) return rc; }
+    for (int k = base; k < top; ++k) { int rc = run[k].begin(h->g[k], stats != nullptr, conc); if (rc) return rc; run[k].wall0 = solve_t0; }   // ONE max_cpu_time clock per solve, shared by successive chunks
     // each pass, per group: no poll outstanding -> enqueue iterations up to the next polled one; one outstanding and not yet run
     // ahead -> enqueue run_ahead() more iterations behind it; otherwise digest the oldest poll.  So a group's queue holds work while
     // the host waits for a poll, and the host never blocks on one group while another has nothing queued
@@ -1646,9 +1663,15 @@ int cddp_hip_solve(cddp_hip_handle *h, cddp_hip_stats *stats) {
       stats->backward_ms += gs[k].backward_ms / conc; stats->forward_ms += gs[k].forward_ms / conc; stats->update_ms += gs[k].update_ms / conc;
       stats->sweeps += gs[k].sweeps; stats->rollouts += gs[k].rollouts; stats->rollouts_launched += gs[k].rollouts_launched;
       stats->traj_iterations += gs[k].traj_iterations; stats->rollout_steps += gs[k].rollout_steps;
-      stats->outer_iterations = std::max(stats->outer_iterations, gs[k].outer_iterations);
       stats->n_converged += gs[k].n_converged; stats->kernel_launches += gs[k].kernel_launches;
       stats->timing_detail = gs[k].timing_detail;
+    }
+    // outer iterations = rounds of (sweep, rollout, update) launches the handle went through one after the other: the longest group of
+    // every concurrent set, summed over the successive sets (chunks) -- the divisor that matches the summed class times
+    for (int base = 0; base < ng; base += conc) {
+      int mx = 0;
+      for (int k = base; k < std::min(ng, base + conc); ++k) mx = std::max(mx, gs[k].outer_iterations);
+      stats->outer_iterations += mx;
     }
   }
   return 0;

@@ -28,6 +28,12 @@ DEV double dmax(double a, double b) { return (a < b) ? b : a; } // == std::max(a
 DEV double dmin(double a, double b) { return (b < a) ? b : a; } // == std::min(a,b)
 DEV double dclamp(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }  // std::clamp
 DEV bool dfinite(double v) { return fabs(v) <= DBL_MAX; }       // false for NaN and +-Inf
+// std::copysign(1.0, dJ) of the reference's accept test (clddp_solver.cpp:254, ipddp_solver.cpp:1848, msipddp_solver.cpp:1702) with the
+// zero case written out: dJ = cost - J_new of an unchanged trial is an exact +0 (x - x in round-to-nearest), for which copysign gives
+// +1; the library is built with -fno-signed-zeros, under which the sign BIT of a zero difference is not something the compiler has
+// to preserve, so the comparison form is used for every non-NaN value (identical to copysign for every non-zero dJ and for +0).
+// NaN keeps copysign's sign-bit rule (documented as not comparable across x86 and gfx950).
+DEV double sign_of_reduction(double dJ) { return (dJ != dJ) ? copysign(1.0, dJ) : ((dJ < 0.0) ? -1.0 : 1.0); }
 // Wave-uniform read-only data (reference trajectory, problem pool): route the address through SGPRs and load
 // through the CONSTANT address space so the compiler emits scalar (SMEM) loads.  A generic-pointer load becomes a
 // flat/global VECTOR load, which sits on the in-order vmcnt queue in front of the software-pipelined prefetch and

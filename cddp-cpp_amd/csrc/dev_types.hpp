@@ -52,6 +52,10 @@ constexpr int kSinkDoubles = 1024 * 64;   // 512 KB
 
 struct DevBuf {
   int B, Bp, N, n_slots, n_alphas, hist_batch, hist_cap, NB;   // NB = Bp / 64 wave tiles
+  int fail_costate_mask;                   // TEST HOOK (0 in production; environment variable CDDP_HIP_TEST_FAIL_COSTATE at create): the costate trial of
+                                           // alpha index i counts as non-finite when bit i is set -- the trial "passed every other test, costate not finite"
+                                           // (flag 2 of k_costate), i.e. the device's form of a forward pass the reference discards (cddp_solver_base.cpp:
+                                           // 280-296, ipddp_solver.cpp:1613-1616); forces the candidate walk of k_update (tests/test_gpu_parity_r2.py)
   const ProblemDev *P;
   const double *xref_traj;                 // [(N+1)][nx] shared by the batch, or null
   // iterate + line-search trial slots: [n_slots] planes

@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(64) void k_forward_clddp(DevBuf d, const ProblemDev
   J += Obj::terminal_cost(P, x);
   const double dJ = d.cost[b] - J;
   const double expected = -alpha * (d.dV0[b] + 0.5 * alpha * d.dV1[b]);
-  const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+  const double ratio = expected > 0.0 ? dJ / expected : sign_of_reduction(dJ);
   const size_t ti = (size_t)a * d.Bp + b;
   d.t_success[ti] = (ratio > o.filter_armijo_constant) ? 1 : 0;
   d.t_cost[ti] = J; d.t_merit[ti] = J; d.t_theta[ti] = 0.0; d.t_inf_pr[ti] = 0.0; d.t_inf_comp[ti] = 0.0;
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(64) void k_forward_ipddp(DevBuf d, const ProblemDev
   if (uncon) {   // ipddp_solver.cpp:1785-1792
     const double dJ = d.cost[b] - cost_new;
     const double expected = -a_pr * (d.dV0[b] + 0.5 * a_pr * d.dV1[b]);
-    const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+    const double ratio = expected > 0.0 ? dJ / expected : sign_of_reduction(dJ);
     accept = ratio > 1e-6;
   } else {        // ipddp_solver.cpp:1793-1834
     const double expected_improvement = a_pr * d.dV0[b];
@@ -1592,6 +1592,7 @@ DEV bool costate_trial_serial(const DevBuf &d, int b, int cur, int a) {
   const size_t ti = (size_t)a * d.Bp + b;
   const int slot = (a < cur) ? a : a + 1;   // trial_slot
   const double a_pr = d.t_apr[ti];
+  if ((d.fail_costate_mask >> a) & 1) return false;   // test hook (DevBuf::fail_costate_mask)
   bool finite = true;
   for (int t = 0; t <= d.N; ++t) {
     double xo[NX], lo[NX], vx[NX], xn[NX], lam[NX];

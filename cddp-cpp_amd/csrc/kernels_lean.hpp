@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64) void k_costate_one(DevBuf d, int a0, int na, in
     finite = finite && dfinite(lam);
     lamp[(size_t)i * kLS] = lam;
   }
-  if (!finite) d.t_success[ti] = 2;
+  if (!finite || ((d.fail_costate_mask >> only) & 1)) d.t_success[ti] = 2;
 }
 
 template <class Model>
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64) void k_costate(DevBuf d, int a0, int na, int ph
     // the blocks of the other steps pick the same trial whether or not they have seen it, so the launch is free of
     // ordering effects; k_update treats 2 as a failed trial and evaluates the costate of the next candidate itself
     // (costate_trial_serial) when the first-success rule stopped this kernel at the failed one.
-    if (!finite) d.t_success[ti] = 2;
+    if (!finite || ((d.fail_costate_mask >> a) & 1)) d.t_success[ti] = 2;
     else st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, lam);
   }
 }

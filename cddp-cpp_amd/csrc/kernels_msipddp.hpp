@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
   if constexpr (M == 0) {   // :1516-1530: expected-reduction ratio test
     const double dJ = d.cost[b] - cost;
     const double expected = -alpha * (d.dV0[b] + 0.5 * alpha * d.dV1[b]);
-    const double ratio = expected > 0.0 ? dJ / expected : copysign(1.0, dJ);
+    const double ratio = expected > 0.0 ? dJ / expected : sign_of_reduction(dJ);
     success = ratio > 1e-6;
   } else {
     merit = merit_b + cost;

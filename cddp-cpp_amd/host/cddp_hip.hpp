@@ -25,6 +25,7 @@
 //     "UnknownSolver - No solver registered for '<name>'" solution (cddp_core.cpp:243-265).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <algorithm>
@@ -566,6 +567,9 @@ struct CDDPSolution {
   std::vector<double> time_points; std::vector<Vector> state_trajectory, control_trajectory; std::vector<Matrix> feedback_gains;
   double final_primal_infeasibility = 0.0, final_dual_infeasibility = 0.0, final_complementary_infeasibility = 0.0, final_barrier_mu = 0.0;
   struct History { std::vector<double> objective, merit_function, step_length_primal, step_length_dual, dual_infeasibility, primal_infeasibility, complementary_infeasibility, barrier_mu, regularization; } history;
+  // NEW (no reference counterpart): which path solved the problem -- "resident" (device-resident batch kernels, the library's shared
+  // straight-line sin / cos / log) or "plugin" (host loop in the host libm + batched GPU backward passes); empty for UnknownSolver
+  std::string route, arithmetic;
 };
 enum class SolverType { CLDDP, LogDDP, IPDDP, MSIPDDP };
 class CDDP;
@@ -721,12 +725,23 @@ class HipBatchSolver : public ISolverAlgorithm {
     ctx.inf_pr_ = s[0].final_primal_infeasibility; ctx.inf_du_ = s[0].final_dual_infeasibility; ctx.inf_comp_ = s[0].final_complementary_infeasibility;
     return s[0];
   }
-  // NEW (no reference counterpart): one device-resident batch.  LogDDP / MSIPDDP batches of a built-in plant with nx <= 8 run on the
-  // resident LogDDP kernels (round 4, csrc/kernels_logddp.hpp: shared straight-line log / sin / cos, the arithmetic the parity
-  // tests pin); solve() keeps LogDDP on the plug-in route (host loop in the host libm, the reference's own arithmetic).
-  std::vector<CDDPSolution> solveBatch(CDDP &ctx, const std::vector<Vector> &x0s) { resident_batch_ = true; create(ctx, x0s); resident_batch_ = false; return collect(ctx, (int)x0s.size()); }
+  // NEW (no reference counterpart): one device-resident batch.
+  std::vector<CDDPSolution> solveBatch(CDDP &ctx, const std::vector<Vector> &x0s) { create(ctx, x0s); return collect(ctx, (int)x0s.size()); }
   cddp_hip_stats stats{};
-  bool resident_batch_ = false;
+  // Route of LogDDP / MSIPDDP problems (round 5): Auto = an eligible problem (built-in plant with nx <= 8, built-in
+  // objective / constraints; MSIPDDP also: no terminal set, and nu = 1 or nx = nu once a path constraint is present) runs on the resident
+  // kernels (csrc/kernels_logddp.hpp, kernels_msipddp.hpp: the library's shared straight-line log / sin / cos) from solve() AND
+  // solveBatch() -- one problem, one arithmetic, one iteration count whichever entry point is used; everything else takes the plug-in
+  // route (host loop in the host libm + stack-fed GPU sweeps).  Plugin forces the latter (the reference's own arithmetic, one
+  // trajectory at a time); the environment variable CDDP_HIP_F4_ROUTE=plugin|resident|auto sets the process-wide default.
+  enum class Route { Auto, Plugin, Resident };
+  Route route = defaultRoute();
+  static Route defaultRoute() {
+    const char *e = std::getenv("CDDP_HIP_F4_ROUTE");
+    if (e && std::string(e) == "plugin") return Route::Plugin;
+    if (e && std::string(e) == "resident") return Route::Resident;
+    return Route::Auto;
+  }
 
   static void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("cddp_hip: ") + cddp_hip_last_error()); }
 
@@ -734,13 +749,15 @@ class HipBatchSolver : public ISolverAlgorithm {
   void create(CDDP &ctx, const std::vector<Vector> &x0s) {
     ctx.initializeProblemIfNecessary();
     if (h_) { cddp_hip_destroy(h_); h_ = nullptr; }
-    const bool resident_logddp = kind_ == CDDP_HIP_SOLVER_LOGDDP && resident_batch_ && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8;
+    const bool resident_logddp = kind_ == CDDP_HIP_SOLVER_LOGDDP && route != Route::Plugin && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8;
     // MSIPDDP batches: resident (csrc/kernels_msipddp.hpp) for a built-in plant with nx <= 8, no terminal set and -- once a path constraint
     // is present -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines)
-    const bool resident_msipddp = kind_ == CDDP_HIP_SOLVER_MSIPDDP && resident_batch_ && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8 &&
+    const bool resident_msipddp = kind_ == CDDP_HIP_SOLVER_MSIPDDP && route != Route::Plugin && !ctx.needsHostPlugins() && ctx.getSystem().getStateDim() <= 8 &&
                                   ctx.numTerminalConstraints() == 0 &&
                                   (ctx.numPathConstraints() == 0 || ctx.getSystem().getControlDim() == 1 || ctx.getSystem().getStateDim() == ctx.getSystem().getControlDim());
-    plugin_ = ctx.needsHostPlugins() || (kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || (kind_ == CDDP_HIP_SOLVER_MSIPDDP && !resident_msipddp);   // single LogDDP / MSIPDDP solves: host loop + stack-fed GPU sweeps
+    if (route == Route::Resident && ((kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || (kind_ == CDDP_HIP_SOLVER_MSIPDDP && !resident_msipddp)))
+      throw std::runtime_error("cddp_hip: Route::Resident requested, but this LogDDP / MSIPDDP problem has no resident kernels (built-in plant with nx <= 8 ...)");
+    plugin_ = ctx.needsHostPlugins() || (kind_ == CDDP_HIP_SOLVER_LOGDDP && !resident_logddp) || (kind_ == CDDP_HIP_SOLVER_MSIPDDP && !resident_msipddp);   // host loop + stack-fed GPU sweeps
     if (plugin_) {
       const DynamicalSystem &sys = ctx.getSystem();
       nx_ = sys.getStateDim(); nu_ = sys.getControlDim(); N_ = ctx.getHorizon(); dt_ = ctx.getTimestep(); batch_ = (int)x0s.size(); ret_hist_ = false;
@@ -884,6 +901,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     for (int b = 0; b < B; ++b) {
       CDDPSolution &s = out[b];
       s.solver_name = getSolverName(); s.status_message = cddp_hip_status_string(r[b].status);
+      s.route = "plugin"; s.arithmetic = "host libm (plug-in callbacks and outer loop on the host, batched GPU backward passes)";
       s.iterations_completed = r[b].iterations; s.final_objective = r[b].final_objective;
       s.final_step_length = r[b].alpha_pr; s.final_regularization = r[b].regularization;
       s.final_primal_infeasibility = r[b].inf_pr; s.final_dual_infeasibility = r[b].inf_du; s.final_complementary_infeasibility = r[b].inf_comp; s.final_barrier_mu = r[b].barrier_mu;
@@ -910,6 +928,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     for (int b = 0; b < B; ++b) {
       CDDPSolution &s = out[b];
       s.solver_name = getSolverName(); s.status_message = cddp_hip_status_string(r[b].status);
+      s.route = "resident"; s.arithmetic = "device, shared straight-line sin / cos / log (csrc/dev_trig.hpp)";
       s.iterations_completed = r[b].iterations; s.solve_time_ms = stats.solve_ms; s.final_objective = r[b].final_objective;
       s.final_step_length = r[b].alpha_pr; s.final_regularization = r[b].regularization;
       s.final_primal_infeasibility = r[b].inf_pr; s.final_dual_infeasibility = r[b].inf_du; s.final_complementary_infeasibility = r[b].inf_comp; s.final_barrier_mu = r[b].barrier_mu;

@@ -688,6 +688,9 @@ class CDDPSolution:                 # cddp_core.hpp:54-103 / bind_solver.cpp:542
         self.final_primal_infeasibility = 0.0; self.final_dual_infeasibility = 0.0
         self.final_complementary_infeasibility = 0.0; self.final_barrier_mu = 0.0
         self.history = SolutionHistory()
+        # NEW (no reference counterpart): which path solved the problem -- "resident" (device-resident batch kernels, shared straight-line
+        # arithmetic) or "plugin" (host loop in the host libm + batched GPU backward passes); "" for an UnknownSolver result
+        self.route = ""; self.arithmetic = ""
 
 
 # ------------------------------------------------------------------------------------------------ CDDP
@@ -699,8 +702,13 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         self._opt = options if options is not None else CDDPOptions()
         self._sys = None; self._obj = None; self._cons = {}; self._terms = {}
         self._X = None; self._U = None
-        self.msipddp_route = "auto"   # NEW: the same switch for MSIPDDP (resident kernels: csrc/kernels_msipddp.hpp)
-        self.logddp_route = "auto"    # NEW: "auto" (solve_batch of an eligible problem -> resident kernels, else the plug-in route) | "plugin" | "resident"
+        # NEW: route of LogDDP / MSIPDDP problems.  "auto": an eligible problem (built-in plant, nx <= 8, ...) runs on the resident kernels
+        # (csrc/kernels_logddp.hpp, kernels_msipddp.hpp: the library's shared straight-line log / sin / cos) from BOTH solve() and
+        # solve_batch() -- the same problem gets the same arithmetic, hence the same iteration count and status, whichever entry point is
+        # used -- and everything else runs on the plug-in route (host loop in the host libm + stack-fed GPU sweeps);
+        # "plugin" / "resident" force one.  The route taken is recorded in CDDPSolution.route / .arithmetic.
+        self.msipddp_route = "auto"
+        self.logddp_route = "auto"
 
     # -- setters (snake_case names of the pybind layer)
     def set_initial_state(self, x0): self._x0 = np.asarray(x0, dtype=np.float64).copy()
@@ -789,13 +797,13 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
 
     def _solve(self, name, x0s, resident_batch=False):
         api = _api()
-        # LogDDP: solve() runs the host loop + stack-fed GPU sweeps (cddp_hip_plugin_solve: the host libm, the reference's own
-        # arithmetic); solve_batch() of a built-in plant with nx <= 8 runs on the resident LogDDP kernels (round 4,
-        # csrc/kernels_logddp.hpp: one device-resident batch in the library's shared straight-line log / sin / cos)
+        # LogDDP: a built-in plant with nx <= 8 runs on the resident LogDDP kernels (csrc/kernels_logddp.hpp: one device-resident batch in
+        # the library's shared straight-line log / sin / cos) from solve() and solve_batch() alike; other problems, or logddp_route =
+        # "plugin", take the host loop + stack-fed GPU sweeps (cddp_hip_plugin_solve: the host libm, the reference's own arithmetic)
         eligible = name == "LogDDP" and self._sys is not None and not self._needs_host_plugins() and self._sys.state_dim <= 8
         if name == "LogDDP" and self.logddp_route == "resident" and not eligible:
             raise NotImplementedError("the resident LogDDP kernels serve built-in plants with nx <= 8 and built-in objective / constraints")
-        resident_logddp = eligible and self.logddp_route != "plugin" and (resident_batch or self.logddp_route == "resident")
+        resident_logddp = eligible and self.logddp_route != "plugin"
         if name == "LogDDP" and not resident_logddp:
             return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
         # MSIPDDP: same split (round 4, csrc/kernels_msipddp.hpp): solve_batch() of a built-in plant with nx <= 8, no terminal set and --
@@ -804,7 +812,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                        and (not self._cons or self._sys.control_dim == 1 or self._sys.state_dim == self._sys.control_dim))
         if name == "MSIPDDP" and self.msipddp_route == "resident" and not ms_eligible:
             raise NotImplementedError("the resident MSIPDDP kernels serve built-in plants with nx <= 8, built-in objective / constraints, no terminal set, and nu = 1 or nx = nu once a path constraint is present")
-        resident_msipddp = ms_eligible and self.msipddp_route != "plugin" and (resident_batch or self.msipddp_route == "resident")
+        resident_msipddp = ms_eligible and self.msipddp_route != "plugin"
         if name == "MSIPDDP" and not resident_msipddp:   # path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
             return self._solve_plugins(name, api.SOLVER_MSIPDDP, x0s)
         if name not in ("CLDDP", "IPDDP", "LogDDP", "MSIPDDP"):
@@ -831,6 +839,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         for b in range(B):
             s = CDDPSolution()
             s.solver_name = name; s.status_message = api.STATUS_STRINGS[int(res["status"][b])]
+            s.route = "resident"; s.arithmetic = "device, shared straight-line sin / cos / log (csrc/dev_trig.hpp)"
             s.iterations_completed = int(res["iterations"][b]); s.solve_time_ms = float(st.solve_ms)
             s.final_objective = float(res["final_objective"][b]); s.final_step_length = float(res["alpha_pr"][b])
             s.final_regularization = float(res["regularization"][b])
@@ -921,6 +930,7 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
         for b in range(B):
             sol = CDDPSolution()
             sol.solver_name = name; sol.status_message = api.STATUS_STRINGS[int(res["status"][b])]
+            sol.route = "plugin"; sol.arithmetic = "host libm (plug-in callbacks and outer loop on the host, batched GPU backward passes)"
             sol.iterations_completed = int(res["iterations"][b]); sol.solve_time_ms = ms
             sol.final_objective = float(res["final_objective"][b]); sol.final_step_length = float(res["alpha_pr"][b])
             sol.final_regularization = float(res["regularization"][b])

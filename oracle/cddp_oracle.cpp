@@ -1989,10 +1989,16 @@ struct Solver {
 
   FPResult performForwardPass() {  // cddp_solver_base.cpp:248-317
     FPResult best; best.cost = best.merit = std::numeric_limits<double>::infinity(); best.success = false;
+    // failing_alpha_mask() (test hook, 0 by default): the forward pass of alpha index i is evaluated and then DISCARDED, the way the
+    // reference's parallel rule discards a forward pass that threw (cddp_solver_base.cpp:280-296; pinned by the reference's
+    // ParallelForwardPassKeepsSuccessfulAlphaWhenAnotherThrows, tests/cddp_core/test_cddp_core.cpp:414-435) and the way a trial whose
+    // costate is not finite fails (ipddp_solver.cpp:1613-1616).  The HIP library's counterpart is CDDP_HIP_TEST_FAIL_COSTATE.
+    const unsigned fail = (unsigned)failing_alpha_mask();
+    int idx = 0;
     if (!opt.enable_parallel) {
-      for (double a : alphas) { FPResult r = forwardPass(a); if (r.success) { best = r; break; } }
+      for (double a : alphas) { FPResult r = forwardPass(a); if ((fail >> idx++) & 1u) continue; if (r.success) { best = r; break; } }
     } else {
-      for (double a : alphas) { FPResult r = forwardPass(a); if (r.success && r.merit < best.merit) best = r; }
+      for (double a : alphas) { FPResult r = forwardPass(a); if ((fail >> idx++) & 1u) continue; if (r.success && r.merit < best.merit) best = r; }
     }
     return best;
   }
@@ -2261,6 +2267,7 @@ double cddp_oracle_scaled_inf_du(void *o) { return ((Solver *)o)->computeScaledD
 double cddp_oracle_get_mu(void *o) { return ((Solver *)o)->mu; }
 // libm-noise knob of models.hpp (process-wide): 0 = off (default), 1 = sin / cos results moved by -1 / 0 / +1 ulp
 void cddp_oracle_set_trig_noise(int v) { oracle::trig_noise() = v; }
+void cddp_oracle_set_failing_alphas(int mask) { oracle::failing_alpha_mask() = mask; }   // test hook, see Solver::performForwardPass
 void cddp_oracle_set_trig_mode(int v) { oracle::trig_mode() = v; }   // 0 = glibc, 1 = the HIP parity build's routine (models.hpp)
 // summation-order noise knob of linalg.hpp (process-wide): 0 = off (default), 1 = matrix-product entries moved by <= 1 ulp
 void cddp_oracle_set_matmul_noise(int v) { oracle::matmul_noise() = v; }

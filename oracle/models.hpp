@@ -61,6 +61,7 @@ inline double trig_perturb(double r, double a) {
 // add / mul / fma sequence per angle, so solves of the knife-edge plants are compared bit for bit instead of statistically
 // (tests/test_shared_trig_parity.py).  The default (glibc) mode stays the independent check.
 inline int &trig_mode() { static int v = 0; return v; }
+inline int &failing_alpha_mask() { static int v = 0; return v; }   // test hook of Solver::performForwardPass (cddp_oracle.cpp), 0 = off
 inline double base_sin(double a) { if (trig_mode() == 1) { double s, c; cddp_dev::sincos_1(a, &s, &c); return s; } return std::sin(a); }
 inline double base_cos(double a) { if (trig_mode() == 1) { double s, c; cddp_dev::sincos_1(a, &s, &c); return c; } return std::cos(a); }
 // log / pow of the solver core (barrier merit, barrier update, terminal-equality regularisation): glibc by default, the HIP parity

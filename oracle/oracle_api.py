@@ -219,6 +219,16 @@ def set_trig_mode(mode):
     return prev
 
 
+def set_failing_alphas(mask):
+    """Test hook: the forward pass of every alpha index whose bit is set is evaluated and discarded (cddp_oracle.cpp::performForwardPass;
+    the reference's parallel rule with a throwing forward pass, cddp_solver_base.cpp:280-296).  0 = off.  Process-global, both builds."""
+    for fast in (False, True):
+        path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
+        if fast and not os.path.exists(path):
+            continue
+        load_oracle(fast).cddp_oracle_set_failing_alphas(int(mask))
+
+
 class shared_trig:
     """Context manager: the oracle evaluates sin / cos / log / pow with the HIP library's routines (models.hpp::trig_mode 1) inside
     the block and returns to the previous mode afterwards (tests/conftest.py keeps mode 1 on for every `-m gpu` test)."""
@@ -239,6 +249,6 @@ def attach(api):
     """Expose the oracle entry points on the harness module `api` (cddp-cpp_amd/pyapi.py)."""
     mod = sys.modules[__name__]
     for name in ("ORACLE_LIB_PATH", "ORACLE_FAST_LIB_PATH", "load_oracle", "Oracle", "oracle_solve_batch", "oracle_boxqp",
-                 "oracle_ldlt_solve", "shared_trig", "set_trig_mode"):
+                 "oracle_ldlt_solve", "shared_trig", "set_trig_mode", "set_failing_alphas"):
         setattr(api, name, getattr(mod, name))
     return api

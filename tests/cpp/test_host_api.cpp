@@ -347,8 +347,16 @@ static void gpu_tests() {
     EXPECT_TRUE(ok == 96);
     EXPECT_TRUE(conv >= 90);
     EXPECT_TRUE(!sols[0].history.barrier_mu.empty() && sols[0].history.barrier_mu.size() == sols[0].history.objective.size());
+    // round 5: solve() of the same problem takes the same (resident) route as solveBatch() -- same arithmetic, same decisions
+    cddp::CDDP same = makePendulum(opt);
+    cddp::CDDPSolution same_one = same.solve("MSIPDDP");
+    EXPECT_TRUE(same_one.route == "resident" && sols[0].route == "resident");
+    EXPECT_TRUE(same_one.iterations_completed == sols[0].iterations_completed && same_one.status_message == sols[0].status_message && same_one.final_objective == sols[0].final_objective);
+    setenv("CDDP_HIP_F4_ROUTE", "plugin", 1);
     cddp::CDDP single = makePendulum(opt);   // the plug-in route (host loop, host libm) solves the same problem: same answer to solver tolerance
     cddp::CDDPSolution one = single.solve("MSIPDDP");
+    unsetenv("CDDP_HIP_F4_ROUTE");
+    EXPECT_TRUE(one.route == "plugin");
     EXPECT_TRUE(std::fabs(one.final_objective - sols[0].final_objective) <= 1e-3 * std::max(1.0, std::fabs(one.final_objective)));
     std::cout << "MSIPDDP batch (resident): " << sols[0].status_message << " iterations " << sols[0].iterations_completed << " objective " << sols[0].final_objective
               << " (plug-in route: " << one.iterations_completed << " iterations, " << one.final_objective << ")\n";

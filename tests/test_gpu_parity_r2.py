@@ -150,7 +150,7 @@ def test_variant_step_level(api, oracle_built, case):
 @pytest.mark.parametrize("case", list(VARIANTS))
 def test_variant_full_solve(api, oracle_built, case):
     """Solve-level parity of the variants with the rule of test_full_solve_parity (no waiver): identical status and
-    iteration count for EVERY trajectory; converged ones strict; >= 90 % of the batch strict; trajectory 0 strict."""
+    iteration count for EVERY trajectory, and every trajectory strict (work counts, objective 1e-7, X / U 1e-6)."""
     p = VARIANTS[case](api)
     B = 16
     res, X, U, K, ores, oX, oU, oK = _solve_both(api, p, B, 20260929)
@@ -160,6 +160,43 @@ def test_variant_full_solve(api, oracle_built, case):
     assert same_counts.all(), (case, list(zip(res["iterations"], ores["iterations"], res["status"], ores["status"])))
     assert strict[conv].all(), (case, strict, conv)
     assert strict[0] and strict.sum() == B, (case, strict)   # round 4: same arithmetic on both sides, every trajectory strict
+
+
+@pytest.mark.parametrize("case,parallel,mask", [("cartpole_ipddp_box", True, 1), ("cartpole_ipddp_box", True, 5), ("unicycle_ipddp_box_ball", True, 3),
+                                                ("cartpole_ipddp_box", False, 1), ("pendulum_ipddp_box", True, 1)])
+def test_discarded_candidate_moves_to_the_next_trial(api, oracle_built, case, parallel, mask, monkeypatch):
+    """The reference's parallel rule DISCARDS a forward pass that threw and keeps the best of the others
+    (cddp_solver_base.cpp:264-314; pinned by its ParallelForwardPassKeepsSuccessfulAlphaWhenAnotherThrows with a mock solver whose
+    alpha = 1 throws, tests/cddp_core/test_cddp_core.cpp:414-435); in IPDDP a trial whose costate is not finite fails the same way
+    (ipddp_solver.cpp:1613-1616).  On the device that is k_update's candidate walk: the least-merit trial carries flag 2 ("passed every
+    other test, costate not finite"), the remaining successful trials are walked in merit order and their costate is evaluated by
+    costate_trial_serial.  No finite problem reaches that branch on its own (V_xx dx overflows only after the cost does), so both sides
+    get the same mock: alpha indices in `mask` are evaluated and discarded (CDDP_HIP_TEST_FAIL_COSTATE / oracle set_failing_alphas).
+    Every trajectory: status, iterations, sweeps, rollouts identical and the iterate strict; and the mock did change the solve."""
+    p = (_parallel(api, case) if parallel else make(api, case))
+    B = 16
+    x0, U0, X0 = _inputs(api, p, B, 20260929)
+
+    def hip():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0, X0); hs.solve()
+        out = (hs.results().copy(),) + hs.trajectory() + hs.gains()[:1]; hs.close()
+        return out
+
+    plain = hip()[0]
+    monkeypatch.setenv("CDDP_HIP_TEST_FAIL_COSTATE", str(mask))
+    api.set_failing_alphas(mask)
+    try:
+        res, X, U, K = hip()
+        ores, oX, oU, oK, _ = api.oracle_solve_batch(p, x0, U0, X0, n_threads=8)
+    finally:
+        api.set_failing_alphas(0)
+    same_counts, same_work, strict, conv = _agreement(api, res, ores, X, oX, U, oU, K, oK)
+    _report("discarded_%s_%s_%d" % (case, "parallel" if parallel else "first", mask),
+            {"B": B, "same_counts": int(same_counts.sum()), "same_work": int(same_work.sum()), "strict": int(strict.sum()),
+             "changed_vs_plain": int(np.sum((res["n_forward"] != plain["n_forward"]) | (res["final_objective"] != plain["final_objective"])))})
+    assert same_counts.all() and same_work.all(), (case, list(zip(res["iterations"], ores["iterations"], res["n_forward"], ores["n_forward"])))
+    assert strict.all(), (case, strict)
+    assert np.any((res["n_forward"] != plain["n_forward"]) | (res["final_objective"] != plain["final_objective"]) | (res["iterations"] != plain["iterations"]))
 
 
 def test_best_merit_differs_from_first_success(api):

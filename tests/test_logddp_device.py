@@ -301,6 +301,17 @@ def test_facade_solve_batch_runs_on_the_resident_kernels(api, oracle_built):
         assert (s.status_message, s.iterations_completed) == (api.STATUS_STRINGS[int(ores["status"][b])], int(ores["iterations"][b]))
         assert rel_err(s.final_objective, ores["final_objective"][b]) < TOL and rel_err(np.stack(s.state_trajectory), oX[b]) < TOL
         assert s.final_barrier_mu == ores["barrier_mu"][b] and len(s.history.barrier_mu) == len(s.history.objective)
+        assert s.route == "resident"
+    # solve() and solve_batch([x0]) of one problem take the same route, hence the same arithmetic and the same decisions
+    for b in (0, B - 1):
+        sv.set_initial_state(x0[b])
+        sv._X = None; sv._U = None     # (solve() leaves its solution as the next initial guess, cddp_solver_base.cpp:161-171: start from the batch's guess again)
+        one = sv.solve(pycddp.SolverType.LogDDP)
+        assert one.route == "resident" and (one.status_message, one.iterations_completed) == (sols[b].status_message, sols[b].iterations_completed)
+        assert one.final_objective == sols[b].final_objective and np.array_equal(np.stack(one.control_trajectory), np.stack(sols[b].control_trajectory))
+    sv.logddp_route = "plugin"; sv._X = None; sv._U = None
+    assert sv.solve(pycddp.SolverType.LogDDP).route == "plugin"
+    sv.logddp_route = "auto"
     sq = pycddp.CDDP(np.zeros(13), np.zeros(13), 10, 0.02, o)
     sq.set_dynamical_system(pycddp.Quadrotor(0.02, 1.0, np.eye(3), 0.2, "rk4"))
     sq.set_objective(pycddp.QuadraticObjective(np.eye(13), np.eye(4), np.eye(13), np.zeros(13), [], 0.02))
