@@ -1500,6 +1500,7 @@ int cddp_hip_destroy(cddp_hip_handle *h) {
 }
 
 int cddp_hip_num_groups(cddp_hip_handle *h) { return h ? (int)h->g.size() : -1; }
+int cddp_hip_concurrency(cddp_hip_handle *h) { return h ? std::max(1, std::min(h->conc, (int)h->g.size())) : -1; }
 
 int cddp_hip_set_timing_detail(cddp_hip_handle *h, int detail) {
   if (!h) return fail(-1, "null handle");

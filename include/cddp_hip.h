@@ -476,6 +476,11 @@ int cddp_hip_batch(cddp_hip_handle *h);
  * device buffers and stream and cddp_hip_solve keeps all of them in flight).  Results do not depend on it.
  * Environment CDDP_HIP_GROUPS=n pins it at create time (1 = one stream). */
 int cddp_hip_num_groups(cddp_hip_handle *h);
+/* How many of those groups cddp_hip_solve keeps in flight AT ONCE (round 5).  1: the groups (chunks of a large batch) are solved one
+ * after the other.  2: the static CU partition of IPDDP / CLDDP batches of >= 32 tiles -- two groups, each with every kernel of its
+ * iterations on its own symmetric half of the chip (streams made with hipExtStreamCreateWithCUMask), so one "launch" of a kernel
+ * class in the timing model is the two concurrent half-batch launches.  No reference counterpart (the reference solves one problem). */
+int cddp_hip_concurrency(cddp_hip_handle *h);
 
 /* ---- stack-fed mode (host plugins) ---------------------------------------
  * Arbitrary DynamicalSystem / Objective / Constraint subclasses (e.g. the user-defined QuadraticScalarSystem of

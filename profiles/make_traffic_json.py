@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build the per-kernel HBM traffic JSON bench.py reads from a summarize_pmc.py table.
-usage: make_traffic_json.py pmc_counters.md "<source note>" [outer_iterations_per_solve] > rNN_x_pmc_traffic.json
+usage: make_traffic_json.py pmc_counters.md "<source note>" [outer_iterations_per_solve|0] [tile groups per solve] > rNN_x_pmc_traffic.json
 bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 correction, profiles/r01_c_pmc_calibration.md) + WRITE_SIZE x 1024."""
 import json
 import sys
@@ -14,12 +14,17 @@ fi, wi, di = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE"), hdr.index("dispat
 # the bench line's solve.max_iterations when no trajectory converges) the count is cross-checked against the sweep launches.
 def _disp(prefix):
     return sum(int(r[di].strip()) for r in rows[2:] if r[0].strip().strip("`").startswith(prefix))
-SOLVES = _disp("k_init")
+# round 5: a handle whose batch is cut into G concurrent tile groups (static CU partition, cddp_hip_num_groups) launches every kernel G
+# times per iteration and k_init G times per solve: the fourth argument names G
+GROUPS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+if _disp("k_init") % GROUPS:
+    raise SystemExit("k_init dispatches %d are not a multiple of %d tile groups" % (_disp("k_init"), GROUPS))
+SOLVES = _disp("k_init") // GROUPS
 if SOLVES <= 0:
     raise SystemExit("no k_init dispatches in %s: cannot tell how many solves the profiled command ran" % sys.argv[1])
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and int(sys.argv[3]) > 0:
     sweeps = _disp("k_backward")
-    if sweeps != SOLVES * int(sys.argv[3]):
+    if sweeps != SOLVES * GROUPS * int(sys.argv[3]):
         raise SystemExit("k_backward* dispatches %d != k_init dispatches %d x %s outer iterations" % (sweeps, SOLVES, sys.argv[3]))
 kern = {}
 for r in rows[2:]:
@@ -36,5 +41,5 @@ print(json.dumps({
                    "profiles/ubench/vmem.hip on this gfx950 stack (guide: x2 correction); WRITE_SIZE reads 0.976x "
                    "the bytes of hipMemset fills (no correction). profiles/r01_c_pmc_calibration.md",
     "unit": "bytes per launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024); bytes_per_solve = that x dispatches / solves in the profiled command",
-    "solves_in_profile": SOLVES,
+    "solves_in_profile": SOLVES, "tile_groups_per_solve": GROUPS,
     "kernels": kern}, indent=1))
