@@ -39,3 +39,13 @@ for f in "${SRCS[@]}"; do
 done
 g++ $CXXFLAGS "$HERE/dump_traces.cpp" "${OBJS[@]}" -o "$OUT/dump_traces" -pthread
 echo "built $OUT/dump_traces  (next: python oracle/ref_pin/compare_traces.py)"
+# Step 1b (round 5): the reference-side ADAPTER (integration/hip_batch_solver.cpp: ISolverAlgorithm over the C-ABI, registered as "IPDDP" /
+# "CLDDP" / "LogDDP" / "MSIPDDP") compiled against the same real headers and linked with the reference objects and libcddp_hip.so, plus its
+# registry / drop-in checks (integration/test_hip_registry.cpp: test_cddp_core.cpp:316-411, 463-483 restated; reference solver vs GPU solver
+# iteration counts on the pendulum / cart-pole examples).  Run  LD_LIBRARY_PATH=cddp-cpp_amd/lib oracle/_ref/test_hip_registry  on an MI355X box.
+HIPLIB="$REPO/cddp-cpp_amd/lib"
+[ -f "$HIPLIB/libcddp_hip.so" ] || fail "$HIPLIB/libcddp_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+g++ $CXXFLAGS -I"$REPO/include" -I"$REPO/integration" -c "$REPO/integration/hip_batch_solver.cpp" -o "$OUT/obj/hip_batch_solver.o"
+g++ $CXXFLAGS -I"$REPO/include" -I"$REPO/integration" "$REPO/integration/test_hip_registry.cpp" "$OUT/obj/hip_batch_solver.o" "${OBJS[@]}" \
+    -L"$HIPLIB" -lcddp_hip -Wl,-rpath,"$HIPLIB" -o "$OUT/test_hip_registry" -pthread
+echo "built $OUT/test_hip_registry  (run it on a box with an MI355X: exit code 0 = the registered GPU solvers reproduce the reference's)"
