@@ -687,10 +687,13 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const double *Xc = d.X + (size_t)cur * d.planeX;
   const double alpha = P->alphas[a];
   const double a_pr = dmin(alpha, d.apr_max[bb]);
-  auto wait_ge = [&](int *ctr, int need) {
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+  auto wait_ge = [&](int *ctr, int need) -> int {
+    int v;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
+    return v;
   };
+  const int kAbort = 2 * N + kRing;   // s_cons value with which a consumer whose 64 trials have all failed releases AND stops the producer
 
   if (producer) {
     // ------------------------------------------------------------------ producer: the dynamics chain
@@ -787,7 +790,9 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
       // publish step t.  Ring slots free up as the consumer retires steps; the counter is polled once every
       // kRing/2 steps for the next kRing/2 slots (an LDS round trip on the chain otherwise).
-      if (t >= kRing && (t % (kRing / 2)) == 0) wait_ge(&s_cons, t - kRing / 2);   // kRing / 2 >= 1
+      // (round 5: a consumer that has given the whole tile up -- every trial failed its fraction-to-boundary test -- also STOPS the
+      //  producer here: nobody reads the rows of those trials, and the wave otherwise kept its SIMD busy to the end of the horizon)
+      if (t >= kRing && (t % (kRing / 2)) == 0) { if (wait_ge(&s_cons, t - kRing / 2) >= kAbort) alive = false; }   // kRing / 2 >= 1
       {
         double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
 #pragma unroll
@@ -1061,7 +1066,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
       for (int j = 0; j <= kDepthC; ++j) step(t + j, R[j], R[(j + kDepthC) % (kDepthC + 1)]);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed: release the producer
-        __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (active) d.t_steps[ti] = fail_t;
         K4_TIME_END(1, t);
         return;
@@ -1075,7 +1080,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     for (int t = 0; t < N; ++t) {
       step(t, ra, ra);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
-        __hip_atomic_store(&s_cons, 2 * N + kRing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (active) d.t_steps[ti] = fail_t;
         return;
       }

@@ -505,6 +505,177 @@ __global__ __launch_bounds__(64) void k_forward_logddp(DevBuf d, const ProblemDe
   d.t_apr[ti] = alpha; d.t_adu[ti] = 1.0;
 }
 
+// ================================================================================ K4 (two-role)
+// Round 5: the single-shooting rollout as a PRODUCER / CONSUMER pair of wavefronts per (64-trajectory tile, alpha) -- the form of
+// kernels_lean.hpp::k_forward_ipddp_pc.  wave 0: u_t = u + a k + K dx, x_{t+1} = f(x_t, u_t), the non-finite test, X / U stores, l_f(x_N)
+// (logddp_solver.cpp:607-639); wave 1: running cost, g(x_t, u_t), the relaxed barrier's values and the violation (:641-666), the
+// filter test (:671-697) and the trial record.  An LDS ring carries (x_t, u_t); every accumulator sees its terms in the one-wave
+// kernel's order, so the pair is bitwise that kernel (tests/test_logddp_device.py::test_two_role_rollout_agrees_bitwise).
+template <class Model, class Cons>
+__global__ __launch_bounds__(128) void k_forward_logddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, NSEG = Cons::NSEG, MM = M > 0 ? M : 1, NS = NSEG > 0 ? NSEG : 1;
+  typedef Objective<NX, NU> Obj;
+  constexpr int RW = NX + NU;
+  constexpr int kRing = RW <= 8 ? 8 : (RW <= 16 ? 4 : 2);
+  __shared__ double s_ring[kRing * RW * 64];
+  __shared__ int s_prod, s_cons;
+  __shared__ int s_psteps[64];    // steps completed before the producer lane went non-finite (N = never)
+  __shared__ double s_pcost[64];  // l_f(x_N)
+  __shared__ double s_obj[Obj::kStage];
+  const int lane = threadIdx.x & 63;
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  const int b = blockIdx.x * 64 + lane;
+  const int a = a0 + blockIdx.y;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
+  if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
+  if (producer && lane == 0) { s_prod = 0; s_cons = 0; }
+  Obj::stage(P, s_obj, (int)threadIdx.x, 128);
+  __syncthreads();
+  const int bb = (b < d.B) ? b : 0;
+  const int cur = (b < d.B) ? d.cur[b] : 0;
+  const int slot = trial_slot(cur, a);
+  const double alpha = P->alphas[a];
+  auto wait_ge = [&](int *ctr, int need) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  if (producer) {
+    const double *Xc = d.X + (size_t)cur * d.planeX, *Uc = d.U + (size_t)cur * d.planeU;
+    double *Xn = d.X + (size_t)slot * d.planeX, *Un = d.U + (size_t)slot * d.planeU;
+    DynCtx dc;
+    dc.load(P->integrator, P->dt, P->mp);
+    double x[NX];
+    ld<NX>(Xc + GI(0, NX, 0), kLS, x);
+    st<NX>(Xn + GI(0, NX, 0), kLS, x);
+    bool finite = true;
+    int steps = N;
+    struct Rec { double xo[NX], uo[NU], kk[NU], KK[NU * NX]; };
+    auto fetch = [&](int tt, Rec &r) {
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+      ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+    };
+    constexpr bool kPing = sizeof(Rec) <= 40 * sizeof(double);
+    auto step = [&](const int t, Rec &c, Rec &n) {
+      if constexpr (kPing) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
+      double u[NU], dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = x[i] - c.xo[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += c.KK[i * NX + j] * dx[j];
+        u[i] = (c.uo[i] + alpha * c.kk[i]) + s;
+      }
+      if (t >= kRing && (t % (kRing / 2)) == 0) wait_ge(&s_cons, t - kRing / 2);
+      {
+        double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rs[i * 64] = x[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rs[(NX + i) * 64] = u[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if constexpr (!kPing) { fetch(t + 1 < N ? t + 1 : t, c); PIPELINE_FENCE(); }
+      double xn[NX];
+      Stepper<Model>::step(dc, x, u, xn);
+      bool fin = true;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) fin = fin && dfinite(xn[i]);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) fin = fin && dfinite(u[i]);
+      if (finite && !fin) { finite = false; steps = t; }
+      st<NU>(Un + GI(t, NU, 0), kLS, u);
+      st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    };
+    Rec ra, rb;
+    fetch(0, ra);
+    {
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      st<NU>(Un + GI(0, NU, 0), kLS, z);
+      st<NX>(Xn + GI(1, NX, 0), kLS, z);
+    }
+    int t = 0;
+    if constexpr (kPing) {
+      for (; t + 1 < N; t += 2) { step(t, ra, rb); step(t + 1, rb, ra); }
+      if (t < N) step(t, ra, rb);
+    } else {
+      for (; t < N; ++t) step(t, ra, ra);
+    }
+    s_pcost[lane] = Obj::terminal_cost(P, x);
+    s_psteps[lane] = finite ? N + 1 : steps;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+  // -------------------------------------------------------------------- consumer
+  double *evn = d.ev + (size_t)slot * lg_ev_plane<Cons>(d);
+  const double mu = d.mu[bb], delta = o.logddp_relaxed_delta;
+  if (active) atomicAdd(d.launched, 1ull);
+  typename Obj::Ctx oc;
+  Obj::load_staged(P, oc, s_obj);
+  typename Cons::Ctx cc;
+  Cons::load(P, cc);
+  double cost = 0.0, merit_b = 0.0, viol = 0.0;
+  if constexpr (M > 0) {   // the VMEM queue primed with one step's store pattern
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) evn[GI(0, NS, s)] = 0.0;
+  }
+  for (int t = 0; t < N; ++t) {
+    wait_ge(&s_prod, t + 1);
+    double x[NX], u[NU];
+    {
+      const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = rs[i * 64];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = rs[(NX + i) * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    cost += Obj::running_cost(oc, xrt, t, x, u);
+    if constexpr (M > 0) {
+      double g[MM], bs[NS];
+      Cons::template eval<NX, NU>(cc, x, u, g);
+      LgCons<Cons>::template values<NX, NU>(g, delta, bs, viol);
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s) { merit_b += mu * bs[s]; evn[GI(t, NS, s)] = bs[s]; }
+    }
+  }
+  wait_ge(&s_prod, N + kRing + 1);
+  if (!active) return;
+  cost += s_pcost[lane];
+  const int psteps = s_psteps[lane];
+  const bool finite = psteps > N;
+  const int steps = finite ? N : psteps;
+  const double merit = merit_b + cost;       // merit_function_new += cost_new (:669)
+  const double cv_old = d.filter_theta[b], cv_new = viol, merit_old = d.merit[b];
+  const double expected = alpha * d.dV0[b];
+  bool accept = false;
+  if (cv_new > o.filter_max_violation_threshold) {
+    if (cv_new < (1.0 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+  } else if (dmax(cv_new, cv_old) < o.filter_min_violation_for_armijo_check && expected < 0) {
+    if (merit < merit_old + o.filter_armijo_constant * expected) accept = true;
+  } else {
+    if (merit < merit_old - o.filter_merit_acceptance_threshold * cv_old || cv_new < (1.0 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+  }
+  const size_t ti = (size_t)a * d.Bp + b;
+  d.t_steps[ti] = steps;
+  d.t_success[ti] = (finite && accept) ? 1 : 0;
+  d.t_cost[ti] = cost; d.t_merit[ti] = merit; d.t_theta[ti] = 0.0; d.t_inf_pr[ti] = cv_new; d.t_inf_comp[ti] = 0.0;
+  d.t_apr[ti] = alpha; d.t_adu[ti] = 1.0;
+}
+
 // ================================================================================ K5
 template <class Model, class Cons>
 __global__ __launch_bounds__(64) void k_update_logddp(DevBuf d, const ProblemDev *__restrict__ Pk, int stage, int n1, int is_last_iter, int do_count) {

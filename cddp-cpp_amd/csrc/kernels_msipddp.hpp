@@ -29,6 +29,7 @@
 //     for nu = 1 (same linear layout) and nx = nu (elementwise); the kernels are instantiated for exactly those shapes.
 #pragma once
 #include "kernels_logddp.hpp"
+#include "kernels_lean.hpp"   // first_surviving_trial (K4b)
 
 namespace cddp_dev {
 
@@ -367,19 +368,33 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
     st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
     dV0 = 0; dV1 = 0; idu = 0; ipr = 0; icomp = 0; idef = 0; snorm = 0;
     bool fail = false;
-    for (int t = N - 1; t >= 0; --t) {
-      double A[NX * NX], Bm[NX * NU], x[NX], u[NU], lam[NX], dd[NX];
-      ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
-      ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
-      ld<NX>(Xc + GI(t, NX, 0), kLS, x);
-      ld<NU>(Uc + GI(t, NU, 0), kLS, u);
-      ld<NX>(Lc + GI(t, NX, 0), kLS, lam);
-      {
-        double f[NX], x1[NX];
-        ld<NX>(Fc + GI(t, NX, 0), kLS, f); ld<NX>(Xc + GI(t + 1, NX, 0), kLS, x1);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dd[i] = f[i] - x1[i];   // defect (:1129-1131)
+    // One step's inputs, fetched one step AHEAD (round 5): the sweep is one dependent instruction stream per wavefront, and the loads
+    // of a step issued at its own top were a memory round trip on that chain every step (same arithmetic, same order).
+    struct Rec { double A[NX * NX], Bm[NX * NU], x[NX], u[NU], lam[NX], f[NX], x1[NX], y[MM], sv[MM], g[MM]; };
+    auto fetch = [&](int tt, Rec &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.x);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.u);
+      ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lam);
+      ld<NX>(Fc + GI(tt, NX, 0), kLS, r.f); ld<NX>(Xc + GI(tt + 1, NX, 0), kLS, r.x1);
+      if constexpr (M > 0) {
+        ld<M>(d.Y + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.y);
+        ld<M>(d.S + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.sv);
+        ld<M>(d.G + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.g);
       }
+    };
+#ifndef CDDP_MS_SWEEP_PF
+#define CDDP_MS_SWEEP_PF 1
+#endif
+    constexpr bool kPF = CDDP_MS_SWEEP_PF && sizeof(Rec) <= 56 * sizeof(double);
+    auto step = [&](const int t, const Rec &c, Rec &n) -> bool {
+      if constexpr (kPF) { fetch(t > 0 ? t - 1 : 0, n); PIPELINE_FENCE(); }
+      const double (&A)[NX * NX] = c.A; const double (&Bm)[NX * NU] = c.Bm; const double (&x)[NX] = c.x; const double (&u)[NU] = c.u;
+      const double (&lam)[NX] = c.lam;
+      double dd[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dd[i] = c.f[i] - c.x1[i];   // defect (:1129-1131)
       double Vd[NX], w[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { double s = 0.0;
@@ -396,9 +411,8 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
 #pragma unroll
         for (int i = 0; i < MM * NU; ++i) Gu[i] = 0.0;
         Cons::template jac<NX, NU>(cc, x, u, Gx, Gu);
-        ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, y);
-        ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, sv);
-        ld<M>(d.G + (size_t)cur * d.planeM + GI(t, M, 0), kLS, g);
+#pragma unroll
+        for (int i = 0; i < M; ++i) { y[i] = c.y[i]; sv[i] = c.sv[i]; g[i] = c.g[i]; }
 #pragma unroll
         for (int i = 0; i < NX; ++i) { double s = 0.0;
 #pragma unroll
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
           for (int i = 0; i < NU; ++i) f.tr[i] = (int)fc[(size_t)(NU * NU + i) * kLS];
           f.ok = true;
         }
-        if (!f.ok) { fail = true; break; }
+        if (!f.ok) return false;
         double col[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) col[i] = Qu[i];
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
         for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
         LDLTs<NU> f;
         f.compute(Qr, NU);
-        if (!f.ok) { fail = true; break; }
+        if (!f.ok) return false;
         double GuS[NU], GxS[NX];
 #pragma unroll
         for (int i = 0; i < NU; ++i) { double s = 0.0;
@@ -626,6 +640,19 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
       for (int i = 0; i < NU; ++i) { idu = dmax(idu, fabs(Qu[i])); snorm = dmax(snorm, fabs(kk[i])); }
 #pragma unroll
       for (int i = 0; i < NX; ++i) idef = dmax(idef, fabs(dd[i]));
+      return true;
+    };
+    if constexpr (kPF) {
+      Rec ra, rb;
+      fetch(N - 1, ra);
+      int t = N - 1;
+      for (; t >= 1; t -= 2) {
+        if (!step(t, ra, rb)) { fail = true; break; }
+        if (!step(t - 1, rb, ra)) { fail = true; break; }
+      }
+      if (!fail && t == 0) fail = !step(0, ra, rb);
+    } else {
+      for (int t = N - 1; t >= 0; --t) { Rec r; fetch(t, r); if (!step(t, r, r)) { fail = true; break; } }
     }
     if (!fail) { ok = true; break; }
     if (force == 2) break;   // single un-retried pass (step-level API)
@@ -860,6 +887,409 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
         st<M>(d.Y + (size_t)slot * d.planeM + GI(t, M, 0), kLS, yn);
       }
       success = ms_filter_acceptable(d, b, o, merit, theta, alpha * d.dV0[b]);
+    }
+  }
+  d.t_steps[ti] = steps;
+  d.t_success[ti] = success ? 1 : 0;
+  d.t_cost[ti] = cost; d.t_merit[ti] = merit; d.t_theta[ti] = theta; d.t_inf_pr[ti] = theta; d.t_inf_comp[ti] = 0.0;
+  d.t_apr[ti] = alpha; d.t_adu[ti] = adu;
+}
+
+// ================================================================================ K4 (two-role) + K4b (dual rows)
+// Round 5: the multiple-shooting rollout as a PRODUCER / CONSUMER pair of wavefronts per (64-trajectory tile, alpha), the form the IPDDP
+// rollout has (kernels_lean.hpp::k_forward_ipddp_pc).  Only x_{t+1} = F(x_t, u_t(x_t)) (or its gap-closing rule at a segment boundary) is a
+// serial chain; one wave per SIMD leaves every dependent f64 operation's latency exposed, so everything else moves to a second wave:
+//   wave 0 (producer)  u_t = u + a k + K dx, F_t = f(x_t, u_t), x_{t+1} (inside a segment: F_t; at a boundary: :1483-1509), the defect
+//                      1-norm |F_t - x_{t+1}|_1, l_f(x_N); stores X, U, F of the trial                       (msipddp_solver.cpp:1462-1509)
+//   wave 1 (consumer)  slack trial + fraction-to-boundary test, dual feasibility of every ladder entry, costate trial, running cost,
+//                      g(x_t, u_t), barrier / violation sums, the filter test and the trial record            (:1547-1560, 1612-1724)
+// Channel: an LDS ring of kRing steps carrying (x_t, dx_t, u_t, |defect_{t-1}|_1) per lane and two LDS counters polled with s_sleep.
+// Every accumulator sees its own terms in the order of the one-wave kernel (the defect norm of step t - 1 is added in front of the
+// violation terms of step t, i.e. behind those of step t - 1), so the pair is bitwise the one-wave kernel
+// (tests/test_msipddp_device.py::test_two_role_rollout_agrees_bitwise).  The nominal F_t and x_{t+1} rows a boundary step needs ride in the
+// producer's prefetched record (the one-wave kernel fetched them at the boundary: a memory round trip on the chain every segment).
+// The DUAL ROWS of a trial (:1627-1637) are no longer written by the rollout: nobody reads them unless the trial is the one the selection
+// rule accepts, so k_duals_msipddp evaluates them at (batch x N) width for that trial only -- the one-wave kernel walked the horizon a
+// second time per trial, one memory round trip per step.
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_duals_msipddp(DevBuf d, int a0, int na, int phase_req, int force, int first_only) {
+  constexpr int NX = Model::NX, M = Cons::M, MM = M > 0 ? M : 1;
+  if constexpr (M > 0) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (b >= d.B) return;
+    if (!force && d.phase[b] != phase_req) return;
+    const int cur = d.cur[b];
+    int a_lo = a0, a_hi = a0 + na;
+    if (!force && first_only != 0) {
+      const int only = first_only == 2 ? d.cand[b] : first_surviving_trial(d, a0, na, b);
+      if (only < 0) return;
+      a_lo = only; a_hi = only + 1;
+    }
+    double xo[NX], yo[MM], ky[MM], Ky[MM * NX];
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+    ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, yo);
+    ld<M>(d.ky + GI(t, M, 0), kLS, ky);
+    ld<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
+    for (int a = a_lo; a < a_hi; ++a) {
+      const size_t ti = (size_t)a * d.Bp + b;
+      if (d.t_success[ti] != 1) continue;
+      const int slot = trial_slot(cur, a);
+      const double adu = d.t_adu[ti];
+      double xt[NX], dx[NX], yn[MM];
+      ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xt);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = xt[i] - xo[i];
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ky[r * NX + j] * dx[j];
+        yn[r] = (yo[r] + adu * ky[r]) + s; }
+      st<M>(d.Y + (size_t)slot * d.planeM + GI(t, M, 0), kLS, yn);
+    }
+  }
+}
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int phase_req, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, NSEG = Cons::NSEG, MM = M > 0 ? M : 1;
+  typedef Objective<NX, NU> Obj;
+  constexpr int RW = 2 * NX + NU + 1;      // doubles per lane per step: x_t, dx_t, u_t, |F_{t-1} - x_t|_1
+  constexpr int kRing = RW <= 12 ? 8 : (RW <= 24 ? 4 : 2);
+  __shared__ double s_ring[kRing * RW * 64];
+  __shared__ int s_prod, s_cons;
+  __shared__ double s_pcost[64], s_pn1[64];   // the producer lane's l_f(x_N) and its last defect norm
+  __shared__ double s_al[CDDP_HIP_MAX_ALPHAS];  // the ladder, for the per-lane look-ups of the dual step search's slow path
+  const int lane = threadIdx.x & 63;
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  const int b = blockIdx.x * 64 + lane;
+  const int a = a0 + blockIdx.y;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
+  if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in both waves: both leave
+  if (producer && lane == 0) { s_prod = 0; s_cons = 0; }
+  if (!producer && lane < CDDP_HIP_MAX_ALPHAS) s_al[lane] = (lane < d.n_alphas) ? P->alphas[lane] : 0.0;
+  __syncthreads();
+  // inactive lanes run along on their own (scratch) trial rows: unconditional stores, no exec-mask regions (see k_forward_ipddp_pc)
+  const int bb = (b < d.B) ? b : 0;
+  const int cur = (b < d.B) ? d.cur[b] : 0;
+  const int slot = trial_slot(cur, a);
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double alpha = P->alphas[a];
+  const int kAbort = 2 * N + kRing;        // s_cons value with which the consumer releases (and stops) the producer
+  auto wait_ge = [&](int *ctr, int need) -> int {
+    int v;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    return v;
+  };
+
+  if (producer) {
+    const double *Uc = d.U + (size_t)cur * d.planeU, *Fc = d.F + (size_t)cur * d.planeX;
+    double *Xn = d.X + (size_t)slot * d.planeX, *Un = d.U + (size_t)slot * d.planeU, *Fn = d.F + (size_t)slot * d.planeX;
+    const int seg = o.msipddp_segment_length, rtype = o.msipddp_rollout_type;
+    DynCtx dc;
+    dc.load(P->integrator, P->dt, P->mp);
+    double x[NX];
+    ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // r.X[0] = initial state (:1443)
+    st<NX>(Xn + GI(0, NX, 0), kLS, x);
+    struct PRec { double xo[NX], uo[NU], kk[NU], KK[NU * NX], fo[NX]; };
+    auto fetch = [&](int tt, PRec &r) {
+      ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
+      ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
+      ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+      ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+      ld<NX>(Fc + GI(tt, NX, 0), kLS, r.fo);
+    };
+    constexpr bool kPing = sizeof(PRec) <= 40 * sizeof(double);
+    double n1_prev = 0.0;
+    bool stop = false;
+    auto step = [&](const int t, PRec &c, PRec &n) {
+      // the record of step t + 1 (clamped): its x_old row is also the x1 of this step's gap-closing rule
+      if constexpr (kPing) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
+      double dx[NX], u[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = x[i] - c.xo[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += c.KK[i * NX + j] * dx[j];
+        u[i] = (c.uo[i] + alpha * c.kk[i]) + s; }
+      if (t >= kRing && (t % (kRing / 2)) == 0) { if (wait_ge(&s_cons, t - kRing / 2) >= kAbort) stop = true; }
+      {
+        double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { rs[i * 64] = x[i]; rs[(NX + i) * 64] = dx[i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rs[(2 * NX + i) * 64] = u[i];
+        rs[(2 * NX + NU) * 64] = n1_prev;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      double kk_keep[NU], KK_keep[NU * NX], fo[NX];   // what the "hybrid" rule reads of the record (dead otherwise)
+#pragma unroll
+      for (int i = 0; i < NU; ++i) kk_keep[i] = c.kk[i];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) KK_keep[i] = c.KK[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) fo[i] = c.fo[i];
+      if constexpr (!kPing) { fetch(t + 1 < N ? t + 1 : t, c); PIPELINE_FENCE(); }   // next record into the (dead) set, behind the integrator
+      double fn[NX], xn[NX];
+      Stepper<Model>::step(dc, x, u, fn);
+      const bool boundary = (seg > 1) && ((t + 1) % seg == 0) && (t + 1 < N);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = fn[i];
+      if (boundary && rtype != 1) {
+        const double *x1 = kPing ? n.xo : c.xo;      // X_c[t + 1]
+        if (rtype == 0) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xn[i] = (x1[i] + (fn[i] - fo[i])) + alpha * (fo[i] - x1[i]);
+        } else {   // "hybrid": linearised closed-loop step
+          double A[NX * NX], Bm[NX * NU];
+          ld<NX * NX>(d.A + GI(t, NX * NX, 0), kLS, A);
+          ld<NX * NU>(d.Bm + GI(t, NX * NU, 0), kLS, Bm);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            double lin = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { double bk = 0.0;
+#pragma unroll
+              for (int q = 0; q < NU; ++q) bk += Bm[i * NU + q] * KK_keep[q * NX + j];
+              lin += (A[i * NX + j] + bk) * dx[j]; }
+            double bkk = 0.0;
+#pragma unroll
+            for (int q = 0; q < NU; ++q) bkk += Bm[i * NU + q] * kk_keep[q];
+            xn[i] = (x1[i] + lin) + alpha * ((bkk + fo[i]) - x1[i]);
+          }
+        }
+      }
+      { double n1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) n1 += fabs(fn[i] - xn[i]);
+        n1_prev = n1; }
+      st<NU>(Un + GI(t, NU, 0), kLS, u);
+      st<NX>(Fn + GI(t, NX, 0), kLS, fn);
+      st<NX>(Xn + GI(t + 1, NX, 0), kLS, xn);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    };
+    auto prime = [&]() {   // the VMEM queue primed with one step's store pattern (see k_forward_ipddp_pc)
+      double z[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = 0.0;
+      st<NU>(Un + GI(0, NU, 0), kLS, z);
+      st<NX>(Fn + GI(0, NX, 0), kLS, z);
+      st<NX>(Xn + GI(1, NX, 0), kLS, z);
+    };
+    PRec ra, rb;
+    fetch(0, ra);
+    prime();
+    int t = 0;
+    if constexpr (kPing) {
+      for (; t + 1 < N && !stop; t += 2) { step(t, ra, rb); step(t + 1, rb, ra); }
+      if (t < N && !stop) step(t, ra, rb);
+    } else {
+      for (; t < N && !stop; ++t) step(t, ra, ra);
+    }
+    s_pcost[lane] = Obj::terminal_cost(P, x);
+    s_pn1[lane] = n1_prev;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const double *Lc = d.Lam + (size_t)cur * d.planeX;
+  double *Ln = d.Lam + (size_t)slot * d.planeX;
+  const double mu = d.mu[bb];
+  const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const int n_alphas = d.n_alphas;
+  const size_t ti = (size_t)a * d.Bp + bb;
+  if (active) atomicAdd(d.launched, 1ull);
+  typename Obj::Ctx oc;
+  Obj::load(P, oc);
+  typename Cons::Ctx cc;
+  Cons::load(P, cc);
+  double cost = 0.0, merit_b = 0.0, cv = 0.0;
+  bool alive = true;
+  int steps = N;
+  unsigned int ymask = 0xffffffffu;
+  constexpr int kAL = 16;
+  [[maybe_unused]] double al[kAL];
+#pragma unroll
+  for (int q = 0; q < kAL; ++q) al[q] = (q < n_alphas) ? P->alphas[q] : 0.0;
+  // Dual step search (:1612-1644) on a strictly decreasing ladder (what cddp_hip_build_alphas makes): for one row of one step the dual
+  // trial yn(a) = (y + a k_y) + K_y dx is a monotone function of a in IEEE arithmetic (a rounded product and two rounded sums with fixed
+  // other operands), so the ladder entries it rejects (yn < bound) are a PREFIX or a SUFFIX of the ladder (NaN / Inf cases included: a
+  // NaN trial is never "below", and an infinite K_y dx makes the trial one value wherever it is not NaN), and the entries every row
+  // of every step so far accepts are an interval [qL, qH).  Only its two ends are probed per row (2 trials instead of n_alphas); a lane
+  // whose end is rejected walks it inwards (LDS table).  First accepted entry = qL, exactly the lowest set bit of the one-wave kernel's
+  // mask.  A ladder that is not strictly decreasing keeps the mask form.
+  bool sorted_ladder = n_alphas <= CDDP_HIP_MAX_ALPHAS;
+  for (int q = 1; q < n_alphas; ++q) sorted_ladder = sorted_ladder && (P->alphas[q] < P->alphas[q - 1]);
+  int qL = 0, qH = n_alphas;
+  double aL = P->alphas[0], aH = P->alphas[n_alphas > 0 ? n_alphas - 1 : 0];
+  struct CRec {
+    double lo[NX], kl[NX], Kl[NX * NX];
+    double so[MM], ksv[MM], Ks[MM * NX], yo[MM], ky[MM], Ky[MM * NX];
+  };
+  auto fetch = [&](int tt, CRec &r) {
+    ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lo);
+    ld<NX>(d.kl + GI(tt, NX, 0), kLS, r.kl);
+    ld<NX * NX>(d.Vxx + GI(tt + 1, NX * NX, 0), kLS, r.Kl);
+    if constexpr (M > 0) {
+      ld<M>(d.S + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.so);
+      ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
+      ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ks);
+      ld<M>(d.Y + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.yo);
+      ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+    }
+  };
+  constexpr bool kPingC = sizeof(CRec) <= 40 * sizeof(double);
+  auto step = [&](const int t, CRec &c, CRec &n) {
+    if constexpr (kPingC) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
+    wait_ge(&s_prod, t + 1);
+    double x[NX], dx[NX], u[NU], n1_prev;
+    {
+      const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { x[i] = rs[i * 64]; dx[i] = rs[(NX + i) * 64]; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = rs[(2 * NX + i) * 64];
+      n1_prev = rs[(2 * NX + NU) * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    [[maybe_unused]] double sn[MM];
+    if constexpr (M > 0) {
+      cv += n1_prev;   // |F_{t-1} - x_t|_1: behind the violation terms of step t - 1, where the one-wave kernel adds it
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += c.Ks[r * NX + j] * dx[j];
+        sn[r] = (c.so[r] + alpha * c.ksv[r]) + s;
+        const bool viol = alive && (sn[r] < (1.0 - tau) * c.so[r]);
+        steps = viol ? t : steps; alive = alive && !viol; }
+      st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += c.Ky[r * NX + j] * dx[j];
+        const double bound = (1.0 - tau) * c.yo[r];
+        if (sorted_ladder) {
+          const double ynL = (c.yo[r] + aL * c.ky[r]) + s, ynH = (c.yo[r] + aH * c.ky[r]) + s;
+          const bool hit = (qL < qH) && ((ynL < bound) || (ynH < bound));
+          if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+            if (hit) {
+              while (qL < qH && ((c.yo[r] + s_al[qL] * c.ky[r]) + s) < bound) ++qL;
+              while (qH > qL && ((c.yo[r] + s_al[qH - 1] * c.ky[r]) + s) < bound) --qH;
+              aL = s_al[qL < n_alphas ? qL : n_alphas - 1]; aH = s_al[qH > 0 ? qH - 1 : 0];
+            }
+          }
+        } else {
+        unsigned int bad = 0u;
+        auto probe = [&](const int q0, const int q1) {
+#pragma unroll
+          for (int q = q0; q < q1; ++q) {
+            const double yn = (c.yo[r] + al[q] * c.ky[r]) + s;
+            bad |= (yn < bound) ? (1u << q) : 0u;
+          }
+        };
+        // (bits of ladder entries beyond n_alphas are never read; n_alphas is wave-uniform: scalar branches)
+        probe(0, 8);
+        if (n_alphas > 8) probe(8, 12);
+        if (n_alphas > 12) probe(12, 16);
+        ymask &= ~bad;
+        for (int q = kAL; q < n_alphas; ++q) {
+          const double yn = (c.yo[r] + P->alphas[q] * c.ky[r]) + s;
+          if (yn < bound) ymask &= ~(1u << q);
+        }
+        } }
+    }
+    {   // costate trial (:1466-1467 == :1639-1641)
+      double ln[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += c.Kl[i * NX + j] * dx[j];
+        ln[i] = (c.lo[i] + alpha * c.kl[i]) + s; }
+      st<NX>(Ln + GI(t, NX, 0), kLS, ln);
+    }
+    if constexpr (!kPingC) { fetch(t + 1 < N ? t + 1 : t, c); PIPELINE_FENCE(); }   // next record into the (dead) set, behind the cost / barrier terms
+    cost += Obj::running_cost(oc, xrt, t, x, u);
+    if constexpr (M > 0) {
+      double g[MM];
+      Cons::template eval<NX, NU>(cc, x, u, g);
+      st<M>(d.G + (size_t)slot * d.planeM + GI(t, M, 0), kLS, g);
+#pragma unroll
+      for (int cs = 0; cs < NSEG; ++cs) {
+        const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
+        double lsum = 0.0, l1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); l1 += fabs(g[off + i] + sn[off + i]); }
+        merit_b -= mu * lsum; cv += l1;
+      }
+    }
+  };
+  auto prime = [&]() {
+    double z[NX > MM ? NX : MM];
+#pragma unroll
+    for (int i = 0; i < (NX > MM ? NX : MM); ++i) z[i] = 0.0;
+    if constexpr (M > 0) { st<M>(d.S + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); st<M>(d.G + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); }
+    st<NX>(Ln + GI(0, NX, 0), kLS, z);
+  };
+  {
+    CRec ra, rb;
+    fetch(0, ra);
+    prime();
+    int t = 0;
+    bool all_dead = false;
+    if constexpr (kPingC) {
+      for (; t + 1 < N; t += 2) {
+        step(t, ra, rb); step(t + 1, rb, ra);
+        if (__builtin_amdgcn_ballot_w64(alive && active) == 0ull) { all_dead = true; break; }
+      }
+      if (!all_dead && t < N) step(t, ra, rb);
+    } else {
+      for (; t < N; ++t) {
+        step(t, ra, ra);
+        if (__builtin_amdgcn_ballot_w64(alive && active) == 0ull) { all_dead = true; break; }
+      }
+    }
+    if (all_dead) {   // every trial of the tile has been abandoned (M > 0 only: `alive` never drops otherwise): stop the producer
+      __hip_atomic_store(&s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (active) {
+        d.t_steps[ti] = steps; d.t_success[ti] = 0;
+        d.t_cost[ti] = cost; d.t_merit[ti] = merit_b + cost; d.t_theta[ti] = cv; d.t_inf_pr[ti] = cv; d.t_inf_comp[ti] = 0.0;
+        d.t_apr[ti] = alpha; d.t_adu[ti] = 1.0;
+      }
+      return;
+    }
+  }
+  wait_ge(&s_prod, N + kRing + 1);
+  if (!active) return;
+  // (the defect norm of step N - 1 is |F - F|_1: zero, or NaN exactly when F_{N-1} is not finite -- added like every other one)
+  if constexpr (M > 0) cv += s_pn1[lane];
+  cost += s_pcost[lane];
+  bool success = false;
+  double merit = cost, theta = 0.0, adu = 1.0;
+  if constexpr (M == 0) {   // :1516-1530: expected-reduction ratio test
+    const double dJ = d.cost[b] - cost;
+    const double expected = -alpha * (d.dV0[b] + 0.5 * alpha * d.dV1[b]);
+    const double ratio = expected > 0.0 ? dJ / expected : sign_of_reduction(dJ);
+    success = ratio > 1e-6;
+  } else {
+    merit = merit_b + cost;
+    theta = cv;
+    int q_sel = -1;
+    if (sorted_ladder) q_sel = (qL < qH) ? qL : -1;
+    else for (int q = 0; q < n_alphas; ++q) if (q_sel < 0 && ((ymask >> q) & 1u)) q_sel = q;
+    if (alive && q_sel >= 0) {
+      adu = P->alphas[q_sel];
+      success = ms_filter_acceptable(d, b, o, merit, theta, alpha * d.dV0[b]);   // the dual rows of the accepted trial: k_duals_msipddp
     }
   }
   d.t_steps[ti] = steps;

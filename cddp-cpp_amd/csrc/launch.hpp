@@ -81,6 +81,14 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "lane");
   }
+  static bool ms_lane_rollout_requested() {   // CDDP_HIP_MS_ROLLOUT=lane: the one-wave MSIPDDP rollout (it writes the dual rows itself)
+    const char *e = std::getenv("CDDP_HIP_MS_ROLLOUT");
+    return e && !std::strcmp(e, "lane");
+  }
+  static bool lg_lane_rollout_requested() {   // CDDP_HIP_LG_ROLLOUT=lane: the one-wave LogDDP rollout
+    const char *e = std::getenv("CDDP_HIP_LG_ROLLOUT");
+    return e && !std::strcmp(e, "lane");
+  }
   static bool elem_sweep_requested() {   // CDDP_HIP_SWEEP=elem: the element-ownership sweep (kernels_elem.hpp), where instantiated
     const char *e = std::getenv("CDDP_HIP_SWEEP");
     return e && !std::strcmp(e, "elem");
@@ -239,11 +247,19 @@ struct Launcher {
     if (na <= 0) return;
     const dim3 grid((d.B + 63) / 64, na);
     if (solver == CDDP_HIP_SOLVER_LOGDDP) {
-      if constexpr (kLog) hipLaunchKernelGGL((k_forward_logddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      // producer / consumer wave pair per (tile, alpha) (round 5); CDDP_HIP_LG_ROLLOUT=lane: the one-wave kernel (comparison: bitwise equal)
+      if constexpr (kLog) {
+        if (lg_lane_rollout_requested()) hipLaunchKernelGGL((k_forward_logddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+        else hipLaunchKernelGGL((k_forward_logddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
+      }
       return;
     }
     if (solver == CDDP_HIP_SOLVER_MSIPDDP) {
-      if constexpr (kMs) hipLaunchKernelGGL((k_forward_msipddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+      // producer / consumer wave pair per (tile, alpha) (round 5); CDDP_HIP_MS_ROLLOUT=lane: the one-wave kernel (comparison: bitwise equal)
+      if constexpr (kMs) {
+        if (ms_lane_rollout_requested()) hipLaunchKernelGGL((k_forward_msipddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+        else hipLaunchKernelGGL((k_forward_msipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
+      }
       return;
     }
     if (solver == CDDP_HIP_SOLVER_CLDDP)
@@ -272,7 +288,15 @@ struct Launcher {
   }
   // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
-    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP || solver == CDDP_HIP_SOLVER_LOGDDP || solver == CDDP_HIP_SOLVER_MSIPDDP) return;
+    if (solver == CDDP_HIP_SOLVER_MSIPDDP) {   // the dual rows of the trial the selection rule will take (the two-role rollout leaves them out)
+      if constexpr (kMs && Cons::M > 0) {
+        if (na <= 0 || ms_lane_rollout_requested()) return;
+        if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
+        hipLaunchKernelGGL((k_duals_msipddp<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, a0, na, phase_req, force, first_only);
+      }
+      return;
+    }
+    if (na <= 0 || solver == CDDP_HIP_SOLVER_CLDDP || solver == CDDP_HIP_SOLVER_LOGDDP) return;
     if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
     if constexpr (Model::NX > 8) {
       if (!force && first_only != 0) {   // one trial per trajectory: the streaming kernel (2 - 4 waves per SIMD instead of one)

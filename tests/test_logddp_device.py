@@ -243,6 +243,43 @@ def test_cooperative_and_lane_sweeps_agree_bitwise(api, case, monkeypatch):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("case", ["pendulum_box", "pendulum_unc", "cartpole_box", "cartpole_box_parallel", "cartpole_box_state", "unicycle_box_ball",
+                                  "bicycle_box", "unicycle_soc", "quadrotor_box", "manipulator_box"])
+def test_two_role_rollout_agrees_bitwise(api, case, monkeypatch):
+    """Round 5: the producer / consumer rollout (k_forward_logddp_pc) against the one-wave rollout it replaces (CDDP_HIP_LG_ROLLOUT=lane):
+    result words, trajectories and the trial records of a step-level forward pass are the same bits, under both ladder shapes."""
+    p = make(api, case)
+    B = 70 + 3
+    x0 = api.batch_x0(p, B, 20270302, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    if p.nx >= 12:
+        p.options.max_iterations = min(p.options.max_iterations, 12); p._rebuild()
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); hs.close()
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.initialize(); hs.backward()
+        tr = hs.forward(api.Oracle(p).alphas()); hs.close()
+        return r, X, U, tr
+
+    out = {}
+    for mode in ("lane", "pc"):
+        for stages in ("1", "2"):
+            if mode == "lane": monkeypatch.setenv("CDDP_HIP_LG_ROLLOUT", "lane")
+            else: monkeypatch.delenv("CDDP_HIP_LG_ROLLOUT", raising=False)
+            monkeypatch.setenv("CDDP_HIP_LS_STAGES", stages)
+            out[mode, stages] = run()
+    r0, Xr, Ur, tr0 = out["lane", "1"]
+    for key, (r, X, U, tr) in out.items():
+        for f in r.dtype.names:
+            assert np.array_equal(r[f], r0[f], equal_nan=(r[f].dtype.kind == "f")), (key, f)
+        assert np.array_equal(X, Xr, equal_nan=True) and np.array_equal(U, Ur, equal_nan=True), key
+        assert np.array_equal(tr["success"], tr0["success"]), key
+        ok = tr["success"] == 1
+        for f in ("cost", "merit_function"):
+            assert np.array_equal(tr[f][ok], tr0[f][ok]), (key, f)
+
+
 def test_batch_solve_is_independent_of_neighbours(api):
     """A trajectory's LogDDP result does not depend on what shares its wavefront: a batch of 100 against the same trajectories solved
     in batches of 37 + 63 (bitwise)."""
