@@ -264,16 +264,16 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
             sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
-        elif solver == "msipddp":  # one-lane kernels of the resident MSIPDDP (kernels_msipddp.hpp)
-            sweep_label = "k_derivs+k_backward_msipddp"
-        elif solver == "logddp":   # one-lane kernels of the resident LogDDP (kernels_logddp.hpp); scored with CLDDP's byte model (the
-            sweep_label = "k_derivs+k_backward_logddp"   # barrier rows it also reads are not credited)
+        elif solver == "msipddp":  # resident MSIPDDP (kernels_msipddp.hpp): the split path-constrained sweep (round 5), the fused one-lane kernel otherwise
+            sweep_label = "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post" if m > 0 else "k_derivs+k_backward_msipddp"
+        elif solver == "logddp":   # resident LogDDP: the LogDDP mode of the cooperative sweep up to nx = 8, scored with CLDDP's byte model (the
+            sweep_label = "k_derivs+k_backward_coop_plain" if p.nx <= 8 else "k_derivs+k_backward_logddp"   # barrier rows it also reads are not credited)
         else:
             sweep_label = "k_derivs+k_backward_coop_plain"
         dom = (sweep_label, gbps_bwd, bwd_ms, bytes_bwd)
         pmc_key = None
     else:
-        dom = ("k_forward_ipddp_pc" if lean else "k_forward_%s" % solver, gbps_fwd, fwd_ms, bytes_fwd)
+        dom = ("k_forward_ipddp_pc" if lean else ("k_forward_%s_pc" % solver if solver in ("msipddp", "logddp") else "k_forward_%s" % solver), gbps_fwd, fwd_ms, bytes_fwd)
         pmc_key = dom[0]
     PEAK = 8000.0   # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
     n_launch = max(1, st.outer_iterations)

@@ -492,6 +492,8 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
     DA(d.Lam, d.planeX * d.n_slots); DA(d.F, d.planeX * d.n_slots);
     DA(d.kl, (size_t)N * nx * Bp);
     if (m == 0) DA(d.fac, (size_t)N * (nu * nu + nu + 1) * Bp);
+    if (m > 0) { DA(d.ms_res, (size_t)3 * Bp); DA(d.ev, (size_t)d.n_slots * N * P.n_cons * Bp); }   // parked log-barrier sums per slot (k_update_msipddp replays them)
+    if (m > 0 && h->ks->ms_cst_size > 0) DA(d.cst, (size_t)N * h->ks->ms_cst_size * Bp);   // V-independent terms of the split sweep (k_ms_condense)
   }
   DA(d.A, (size_t)N * nx * nx * Bp); DA(d.Bm, (size_t)N * nx * nu * Bp);
   DA(d.K, (size_t)N * nu * nx * Bp); DA(d.k, (size_t)N * nu * Bp);
@@ -928,7 +930,9 @@ struct SolveRun {
       // the histogram of such solves drifts towards smaller steps from window to window (resident LogDDP, cart-pole: k1 = 6 ... 10 of 11
       // during iterations 4 - 15; 34.3 -> 32.7 ms per solve with the whole ladder at once, profiles/r04_ladder_small.md).  Heavier plants keep the
       // short first stage (C4 share, 704 wavefronts: 955 ms adaptive against 985 ms with the whole ladder at once).  "Half" became "a third" after a sweep (ladder_frac).
-      if (waves_all <= 1024 && h->P.nx <= 8 && ladder_frac() * k1 > na) one_stage = true;
+      // (the two-role rollouts of LogDDP / MSIPDDP, round 5, put two wavefronts per (tile, alpha) in the launch: the same ladders, twice the count)
+      const long small_cap = (h->P.solver == CDDP_HIP_SOLVER_LOGDDP || h->P.solver == CDDP_HIP_SOLVER_MSIPDDP) ? 2048 : 1024;
+      if (waves_all <= small_cap && h->P.nx <= 8 && ladder_frac() * k1 > na) one_stage = true;
     }
     if (std::getenv("CDDP_HIP_DEBUG_LADDER")) {
       std::fprintf(stderr, "[ladder] it=%d total=%ld kq=%d -> %s k1=%d hist:", outer, total, kq, one_stage ? "one" : "two", k1);

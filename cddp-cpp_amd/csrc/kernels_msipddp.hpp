@@ -95,11 +95,17 @@ DEV void ms_init_pair(const cddp_hip_options &o, double mu, double g, double &s,
 }
 
 // resetBarrierFilter (:711-763) on the iterate of `slot`: merit, violation, residuals under `mu`; the filter restarts from that point.
+// Round 5: the per-step sums of log s (one per constraint object) are PARKED per slot (d.ev, [slot][N][NSEG]; written here and by the
+// rollout for its trial) and the mu-independent pieces of the iterate (max |g + s|, max |F_t - x_{t+1}|, the violation sum) are kept in
+// d.ms_res, so that K5 replays the chain  merit -= mu_new * lsum_tc  instead of walking the horizon through two logarithms per row again
+// (ms_replay_filter below: same terms, same order).
+template <class Cons> DEV size_t ms_ev_plane(const DevBuf &d) { return (size_t)d.N * (Cons::NSEG > 0 ? Cons::NSEG : 1) * d.Bp; }
 template <class Model, class Cons>
 DEV void ms_reset_filter(const DevBuf &d, int b, int slot, double mu, double cost) {
-  constexpr int NX = Model::NX, M = Cons::M, MM = M > 0 ? M : 1, NSEG = Cons::NSEG;
+  constexpr int NX = Model::NX, M = Cons::M, MM = M > 0 ? M : 1, NSEG = Cons::NSEG, NS = NSEG > 0 ? NSEG : 1;
   double mf = cost, ipr = 0.0, fcv = 0.0, icomp = 0.0, idef = 0.0;
   if constexpr (M > 0) {
+    double *evs = d.ev + (size_t)slot * ms_ev_plane<Cons>(d);
     const double *Sc = d.S + (size_t)slot * d.planeM, *Yc = d.Y + (size_t)slot * d.planeM, *Gc = d.G + (size_t)slot * d.planeM;
     const double *Fc = d.F + (size_t)slot * d.planeX, *Xc = d.X + (size_t)slot * d.planeX;
     // rows of step t + 1 in flight while step t is reduced (one lane per trajectory: a load issued at the top of its own step is a
@@ -127,6 +133,7 @@ DEV void ms_reset_filter(const DevBuf &d, int b, int slot, double mu, double cos
           }
         }
         mf -= mu * lsum; fcv += l1;
+        evs[GI(t, NS, cs)] = lsum;
       }
       double n1 = 0.0, ni = 0.0;
 #pragma unroll
@@ -143,12 +150,49 @@ DEV void ms_reset_filter(const DevBuf &d, int b, int slot, double mu, double cos
   d.inf_pr[b] = dmax(ipr, idef); d.merit[b] = mf; d.phi[b] = mf; d.inf_comp[b] = icomp;
   d.filter_theta[b] = fcv; d.theta[b] = fcv;
   d.filt[b] = mf; d.filt[(size_t)d.filt_cap * d.Bp + b] = fcv; d.filt_n[b] = 1;
+  if constexpr (M > 0) { d.ms_res[b] = ipr; d.ms_res[(size_t)d.Bp + b] = idef; d.ms_res[(size_t)2 * d.Bp + b] = fcv; }
+}
+
+// resetBarrierFilter (:711-763) of K5 on the iterate of `slot` under a NEW mu, from what the rollout (or the reset above) left behind:
+//   merit      = cost - sum_t sum_c mu * lsum_tc       the parked sums replayed in the order of the loop above
+//   violation  = the iterate's own violation sum (d.ms_res[2]: the accepted trial's theta -- the same terms in the same order)
+//   inf_pr     = max(max |g + s|, max |F - x_next|)    (d.ms_res[0], [1]; maxima are order-free)
+//   inf_comp   = max |y s - mu| = the larger of |min(y s) - mu|, |max(y s) - mu|: x -> fl(x - mu) is monotone, so the extreme residuals
+//                sit at the extreme products (NaN products are skipped by either form); ys_lo / ys_hi come from K5's pass over the Y, S rows
+template <class Model, class Cons>
+DEV void ms_replay_filter(const DevBuf &d, int b, int slot, double mu, double cost, double ys_lo, double ys_hi) {
+  constexpr int M = Cons::M, NSEG = Cons::NSEG, NS = NSEG > 0 ? NSEG : 1;
+  static_assert(M > 0, "the barrier filter is reset for path-constrained problems only");
+  const double *evs = d.ev + (size_t)slot * ms_ev_plane<Cons>(d);
+  double mf = cost;
+  constexpr int kTB = 16;   // rows per round trip
+  int t = 0;
+  for (; t + kTB - 1 < d.N; t += kTB) {
+    double v[kTB][NS];
+#pragma unroll
+    for (int k = 0; k < kTB; ++k)
+#pragma unroll
+      for (int c = 0; c < NSEG; ++c) v[k][c] = evs[GI(t + k, NS, c)];
+#pragma unroll
+    for (int k = 0; k < kTB; ++k)
+#pragma unroll
+      for (int c = 0; c < NSEG; ++c) mf -= mu * v[k][c];
+  }
+  for (; t < d.N; ++t)
+    for (int c = 0; c < NSEG; ++c) mf -= mu * evs[GI(t, NS, c)];
+  double icomp = 0.0;
+  if (ys_lo <= ys_hi) { icomp = dmax(icomp, fabs(ys_lo - mu)); icomp = dmax(icomp, fabs(ys_hi - mu)); }
+  const double ipr = d.ms_res[b], idef = d.ms_res[(size_t)d.Bp + b], fcv = d.ms_res[(size_t)2 * d.Bp + b];
+  d.inf_pr[b] = dmax(ipr, idef); d.merit[b] = mf; d.phi[b] = mf; d.inf_comp[b] = icomp;
+  d.filter_theta[b] = fcv; d.theta[b] = fcv;
+  d.filt[b] = mf; d.filt[(size_t)d.filt_cap * d.Bp + b] = fcv; d.filt_n[b] = 1;
 }
 
 // computeScaledDualInfeasibility (:1886-1930): inf_du / max(1, mean(|y|_1 + |s|_1) / 100), sums constraint-major as the reference walks them
 template <class Model, class Cons>
-DEV double ms_scaled_inf_du(const DevBuf &d, int b, int slot, double inf_du) {
+DEV double ms_scaled_inf_du(const DevBuf &d, int b, int slot, double inf_du, double &ys_lo, double &ys_hi) {
   constexpr int NU = Model::NU, M = Cons::M, NSEG = Cons::NSEG;
+  ys_lo = INFINITY; ys_hi = -INFINITY;   // extreme products y s of the iterate (the same pass; ms_replay_filter)
   if constexpr (M == 0) return inf_du;
   else {
     const double *Sc = d.S + (size_t)slot * d.planeM, *Yc = d.Y + (size_t)slot * d.planeM;
@@ -168,13 +212,13 @@ DEV double ms_scaled_inf_du(const DevBuf &d, int b, int slot, double inf_du) {
         for (int k = 0; k < kTB; ++k) {
           double ya = 0.0, sa = 0.0;
 #pragma unroll
-          for (int i = 0; i < M; ++i) if (i < dim) { ya += fabs(yv[k][i]); sa += fabs(sv[k][i]); }
+          for (int i = 0; i < M; ++i) if (i < dim) { ya += fabs(yv[k][i]); sa += fabs(sv[k][i]); const double ys = yv[k][i] * sv[k][i]; ys_lo = dmin(ys_lo, ys); ys_hi = dmax(ys_hi, ys); }
           yn += ya; sn += sa;
         }
       }
       for (; t < d.N; ++t) {
         double ya = 0.0, sa = 0.0;
-        for (int i = 0; i < dim; ++i) { ya += fabs(Yc[GI(t, M, off + i)]); sa += fabs(Sc[GI(t, M, off + i)]); }
+        for (int i = 0; i < dim; ++i) { const double yv1 = Yc[GI(t, M, off + i)], sv1 = Sc[GI(t, M, off + i)]; ya += fabs(yv1); sa += fabs(sv1); const double ys = yv1 * sv1; ys_lo = dmin(ys_lo, ys); ys_hi = dmax(ys_hi, ys); }
         yn += ya; sn += sa;
       }
     }
@@ -672,6 +716,368 @@ __global__ __launch_bounds__(64) void k_backward_msipddp(DevBuf d, const Problem
   d.phase[b] = PH_FWD1;   // no early convergence test (base-class default)
 }
 
+// ================================================================================ K2, path-constrained, split (round 5)
+// The path-constrained sweep above spends most of its one-wave chain on work that does not depend on the value function: the constraint
+// Jacobians, Y S^-1, the residuals (three divisions per row) and the condensation products in front of the factorisation, the slack / dual
+// gains (another division per row) behind it.  Split as the IPDDP sweep is (kernels_lean.hpp):
+//   k_ms_condense   grid (batch x N)   l_x + G_x^T y, l_u + G_u^T y, the defect, Y S^-1, r_hat, the primal residual, the condensation
+//                                      products G^T (Y S^-1) G, G^T S^-1 r_hat and the step's residual maxima      -> d.cst [N][MsCst::SIZE]
+//   k_backward_msipddp_lean  (batch)   the value recursion only: w = V_x + V_xx d, Q blocks, regularised LDLT, k, K, k_lambda, V update
+//   k_ms_post       grid (batch x N)   k_y, k_s, K_y, K_s from k, K                                                  (:1367-1384)
+// Every entry is formed by the expression of the fused kernel in the same order (tests/test_msipddp_device.py::
+// test_split_and_fused_sweeps_agree_bitwise); full DDP (costate-weighted tensor terms) keeps the fused kernel.
+template <class Model, class Cons>
+struct MsCst {
+  static constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M > 0 ? Cons::M : 1;
+  static constexpr int oQx = 0, oQu = oQx + NX, oDd = oQu + NU, oGuYG = oDd + NX, oGuYGx = oGuYG + NU * NU, oGxYGx = oGuYGx + NU * NX,
+                       oGxYGu = oGxYGx + NX * NX, oGuS = oGxYGu + NX * NU, oGxS = oGuS + NU, oRes = oGxS + NX /* ipr, icomp of the step */,
+                       oSweep = oRes + 2 /* what the sweep reads ends here */, oYS = oSweep, oRhat = oYS + M, oPres = oRhat + M, SIZE = oPres + M;
+};
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_ms_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1;
+  typedef Objective<NX, NU> Obj;
+  typedef MsCst<Model, Cons> L;
+  if constexpr (M > 0) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (b >= d.B) return;
+    if (!force && d.phase[b] != PH_ACTIVE) return;
+    const ProblemDev *__restrict__ P = Pk;
+    const int cur = d.cur[b];
+    const double mu = d.mu[b];
+    typename Cons::Ctx cc;
+    Cons::load(P, cc);
+    double x[NX], u[NU], f[NX], x1[NX], y[MM], sv[MM], g[MM];
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, x);
+    ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, u);
+    ld<NX>(d.F + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, f);
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t + 1, NX, 0), kLS, x1);
+    ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, y);
+    ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, sv);
+    ld<M>(d.G + (size_t)cur * d.planeM + GI(t, M, 0), kLS, g);
+    double *out = d.cst + GI(t, L::SIZE, 0);
+    double dd[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dd[i] = f[i] - x1[i];
+    st<NX>(out + (size_t)L::oDd * kLS, kLS, dd);
+    double Qx[NX], Qu[NU], Gx[MM * NX], Gu[MM * NU];
+    Obj::lx(P, xrt, t, x, Qx);
+    Obj::lu(P, u, Qu);
+#pragma unroll
+    for (int i = 0; i < MM * NX; ++i) Gx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM * NU; ++i) Gu[i] = 0.0;
+    Cons::template jac<NX, NU>(cc, x, u, Gx, Gu);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < M; ++r) s += Gx[r * NX + i] * y[r];
+      Qx[i] = Qx[i] + s; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < M; ++r) s += Gu[r * NU + i] * y[r];
+      Qu[i] = Qu[i] + s; }
+    st<NX>(out + (size_t)L::oQx * kLS, kLS, Qx);
+    st<NU>(out + (size_t)L::oQu * kLS, kLS, Qu);
+    double YS[MM], pres[MM], cres[MM], rhat[MM], Sir[MM];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      YS[i] = y[i] / sv[i];
+      pres[i] = g[i] + sv[i];
+      cres[i] = y[i] * sv[i] - mu; rhat[i] = y[i] * pres[i] - cres[i]; Sir[i] = rhat[i] / sv[i];
+    }
+    st<M>(out + (size_t)L::oYS * kLS, kLS, YS); st<M>(out + (size_t)L::oRhat * kLS, kLS, rhat); st<M>(out + (size_t)L::oPres * kLS, kLS, pres);
+    double GuYG[NU * NU], GuYGx[NU * NX], GxYGx[NX * NX], GxYGu[NX * NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+#pragma unroll
+      for (int c = 0; c < NU; ++c) { double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s += (Gu[r * NU + i] * YS[r]) * Gu[r * NU + c];
+        GuYG[i * NU + c] = s; }
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s += (Gu[r * NU + i] * YS[r]) * Gx[r * NX + c];
+        GuYGx[i * NX + c] = s; }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s += (Gx[r * NX + i] * YS[r]) * Gx[r * NX + c];
+        GxYGx[i * NX + c] = s; }
+#pragma unroll
+      for (int c = 0; c < NU; ++c) { double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) s += (Gx[r * NX + i] * YS[r]) * Gu[r * NU + c];
+        GxYGu[i * NU + c] = s; }
+    }
+    st<NU * NU>(out + (size_t)L::oGuYG * kLS, kLS, GuYG); st<NU * NX>(out + (size_t)L::oGuYGx * kLS, kLS, GuYGx);
+    st<NX * NX>(out + (size_t)L::oGxYGx * kLS, kLS, GxYGx); st<NX * NU>(out + (size_t)L::oGxYGu * kLS, kLS, GxYGu);
+    double GuS[NU], GxS[NX];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < M; ++r) s += Gu[r * NU + i] * Sir[r];
+      GuS[i] = s; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < M; ++r) s += Gx[r * NX + i] * Sir[r];
+      GxS[i] = s; }
+    st<NU>(out + (size_t)L::oGuS * kLS, kLS, GuS); st<NX>(out + (size_t)L::oGxS * kLS, kLS, GxS);
+    double ipr = 0.0, icomp = 0.0;   // the step's share of the residual maxima (the sweep takes the maximum over the steps: order-free)
+#pragma unroll
+    for (int r = 0; r < M; ++r) { ipr = dmax(ipr, fabs(pres[r])); icomp = dmax(icomp, fabs(cres[r])); }
+    out[(size_t)(L::oRes + 0) * kLS] = ipr; out[(size_t)(L::oRes + 1) * kLS] = icomp;
+  }
+}
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_ms_post(DevBuf d, const ProblemDev *__restrict__ Pk, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1;
+  typedef MsCst<Model, Cons> L;
+  if constexpr (M > 0) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (b >= d.B) return;
+    if (force) { if (!d.bwd_ok[b]) return; }
+    else if (d.phase[b] != PH_FWD1) return;
+    const ProblemDev *__restrict__ P = Pk;
+    const int cur = d.cur[b];
+    typename Cons::Ctx cc;
+    Cons::load(P, cc);
+    double x[NX], u[NU], y[MM], sv[MM], kk[NU], KK[NU * NX], YS[MM], rhat[MM], pres[MM];
+    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, x);
+    ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, u);
+    ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, y);
+    ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, sv);
+    ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
+    ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+    const double *in = d.cst + GI(t, L::SIZE, 0);
+    ld<M>(in + (size_t)L::oYS * kLS, kLS, YS); ld<M>(in + (size_t)L::oRhat * kLS, kLS, rhat); ld<M>(in + (size_t)L::oPres * kLS, kLS, pres);
+    double Gx[MM * NX], Gu[MM * NU];
+#pragma unroll
+    for (int i = 0; i < MM * NX; ++i) Gx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM * NU; ++i) Gu[i] = 0.0;
+    Cons::template jac<NX, NU>(cc, x, u, Gx, Gu);
+    double ky[MM], ksv[MM], Ky[MM * NX], Ks[MM * NX];
+#pragma unroll
+    for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) s += Gu[r * NU + i] * kk[i];
+      ky[r] = (rhat[r] + y[r] * s) / sv[r];
+      ksv[r] = (0.0 - pres[r]) - s; }
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) s += Gu[r * NU + i] * KK[i * NX + c];
+        Ky[r * NX + c] = YS[r] * (Gx[r * NX + c] + s);
+        Ks[r * NX + c] = (0.0 - Gx[r * NX + c]) - s; }
+    st<M>(d.ky + GI(t, M, 0), kLS, ky); st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+    st<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky); st<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ks);
+  }
+}
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(64) void k_backward_msipddp_lean(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force, int count_iter) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
+  typedef Objective<NX, NU> Obj;
+  typedef MsCst<Model, Cons> L;
+  static_assert(M > 0, "the split sweep is the path-constrained branch");
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Lc = d.Lam + (size_t)cur * d.planeX;
+  if (count_iter) d.iter[b] += 1;
+  double reg = d.reg[b];
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, idu = 0, ipr = 0, icomp = 0, idef = 0, snorm = 0;
+  for (;;) {
+    ++nb;
+    double xN[NX], Vx[NX], Vxx[NX * NX];
+    ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+    Obj::final_grad(P, xN, Vx);
+    const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Vxx[i * NX + c] = 0.5 * ((2.0 * Qf[i * NX + c]) + (2.0 * Qf[c * NX + i]));   // :1122
+    st<NX>(d.Vx + GI(N, NX, 0), kLS, Vx);
+    st<NX * NX>(d.Vxx + GI(N, NX * NX, 0), kLS, Vxx);
+    dV0 = 0; dV1 = 0; idu = 0; ipr = 0; icomp = 0; idef = 0; snorm = 0;
+    bool fail = false;
+    struct Rec { double A[NX * NX], Bm[NX * NU], lam[NX], c[L::oSweep]; };
+    auto fetch = [&](int tt, Rec &r) {
+      ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
+      ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
+      ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lam);
+      ld<L::oSweep>(d.cst + GI(tt, L::SIZE, 0), kLS, r.c);
+    };
+    constexpr bool kPF = sizeof(Rec) <= 72 * sizeof(double);
+    auto step = [&](const int t, const Rec &c, Rec &n) -> bool {
+      if constexpr (kPF) { fetch(t > 0 ? t - 1 : 0, n); PIPELINE_FENCE(); }
+      const double (&A)[NX * NX] = c.A; const double (&Bm)[NX * NU] = c.Bm; const double (&lam)[NX] = c.lam;
+      const double *dd = c.c + L::oDd, *GuYG = c.c + L::oGuYG, *GuYGx = c.c + L::oGuYGx, *GxYGx = c.c + L::oGxYGx, *GxYGu = c.c + L::oGxYGu,
+                   *GuS = c.c + L::oGuS, *GxS = c.c + L::oGxS;
+      double Vd[NX], w[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Vxx[i * NX + j] * dd[j];
+        Vd[i] = s; w[i] = Vx[i] + s; }
+      double Qx[NX], Qu[NU], Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Qx[i] = c.c[L::oQx + i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] = c.c[L::oQu + i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += A[k * NX + i] * w[k];
+        Qx[i] = Qx[i] + s; }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += Bm[k * NU + i] * w[k];
+        Qu[i] = Qu[i] + s; }
+      q_blocks<NX, NU>(P, A, Bm, Vx, Vxx, Qxx, Qux, Quu);
+      double kk[NU], KK[NU * NX];
+      {
+        double kl[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) kl[i] = ((0.0 - lam[i]) + Vx[i]) + Vd[i];
+        st<NX>(d.kl + GI(t, NX, 0), kLS, kl);
+      }
+      double Qr[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int cc2 = 0; cc2 < NU; ++cc2) Qr[i * NU + cc2] = (0.5 * (Quu[i * NU + cc2] + Quu[cc2 * NU + i])) + GuYG[i * NU + cc2];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+      LDLTs<NU> f;
+      f.compute(Qr, NU);
+      if (!f.ok) return false;
+      double col[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) col[i] = Qu[i] + GuS[i];
+      f.solve(col);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+      for (int cc2 = 0; cc2 < NX; ++cc2) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qux[i * NX + cc2] + GuYGx[i * NX + cc2];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KK[i * NX + cc2] = -col[i];
+      }
+      // the condensed blocks (:1391-1400), Q_ux with the reference's layout (:1398)
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] = Qu[i] + GuS[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Qx[i] = Qx[i] + GxS[i];
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) Qxx[i] = Qxx[i] + GxYGx[i];
+      if constexpr (NU == 1) {
+#pragma unroll
+        for (int cc2 = 0; cc2 < NX; ++cc2) Qux[cc2] = Qux[cc2] + GxYGu[cc2];
+      } else {
+        static_assert(NX == NU, "msipddp_solver.cpp:1398 defines the constrained recursion for nu = 1 or nx = nu only");
+#pragma unroll
+        for (int i = 0; i < NU * NX; ++i) Qux[i] = Qux[i] + GxYGu[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu[i] = Quu[i] + GuYG[i];
+      ipr = dmax(ipr, c.c[L::oRes + 0]); icomp = dmax(icomp, c.c[L::oRes + 1]);
+      st<NU>(d.k + GI(t, NU, 0), kLS, kk);
+      st<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
+      { double s0 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) s0 += kk[i] * Qu[i];
+        dV0 += s0;
+        double s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double q = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) q += Quu[i * NU + j] * kk[j];
+          s1 += kk[i] * q; }
+        dV1 += 0.5 * s1; }
+      double KtQ[NX * NU];
+      mm_tn<NX, NU, NU>(KK, Quu, KtQ);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0, bb = 0.0, c3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qu[j]; bb += Qux[j * NX + i] * kk[j]; c3 += KtQ[i * NU + j] * kk[j]; }
+        Vx[i] = ((Qx[i] + a) + bb) + c3;
+      }
+      double Vn[NX * NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int cc2 = 0; cc2 < NX; ++cc2) {
+          double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { a += KK[j * NX + i] * Qux[j * NX + cc2]; bb += Qux[j * NX + i] * KK[j * NX + cc2]; e += KtQ[i * NU + j] * KK[j * NX + cc2]; }
+          Vn[i * NX + cc2] = ((Qxx[i * NX + cc2] + a) + bb) + e;
+        }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int cc2 = 0; cc2 < NX; ++cc2) Vxx[i * NX + cc2] = 0.5 * (Vn[i * NX + cc2] + Vn[cc2 * NX + i]);
+      st<NX>(d.Vx + GI(t, NX, 0), kLS, Vx);
+      st<NX * NX>(d.Vxx + GI(t, NX * NX, 0), kLS, Vxx);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { idu = dmax(idu, fabs(Qu[i])); snorm = dmax(snorm, fabs(kk[i])); }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) idef = dmax(idef, fabs(dd[i]));
+      return true;
+    };
+    if constexpr (kPF) {
+      Rec ra, rb;
+      fetch(N - 1, ra);
+      int t = N - 1;
+      for (; t >= 1; t -= 2) {
+        if (!step(t, ra, rb)) { fail = true; break; }
+        if (!step(t - 1, rb, ra)) { fail = true; break; }
+      }
+      if (!fail && t == 0) fail = !step(0, ra, rb);
+    } else {
+      for (int t = N - 1; t >= 0; --t) { Rec r; fetch(t, r); if (!step(t, r, r)) { fail = true; break; } }
+    }
+    if (!fail) { ok = true; break; }
+    if (force == 2) break;
+    reg = reg_increase(o, reg);
+    if (reg >= o.reg_max_value) break;
+  }
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = idu; d.step_norm[b] = snorm;
+    d.inf_pr[b] = dmax(ipr, idef); d.inf_comp[b] = icomp;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  d.phase[b] = PH_FWD1;
+}
+
 // ================================================================================ K4
 template <class Model, class Cons>
 __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int a0, int na, int phase_req, int force) {
@@ -707,6 +1113,8 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
   ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // r.X[0] = initial state (:1443; X_[0] is the initial state for every iterate)
   st<NX>(Xn + GI(0, NX, 0), kLS, x);
   double cost = 0.0, merit_b = 0.0, cv = 0.0;
+  [[maybe_unused]] double r_ipr = 0.0, r_idef = 0.0;   // max |g + s|, max |F_t - x_{t+1}| of the trial (kept for K5's filter reset, ms_replay_filter)
+  [[maybe_unused]] double *evn = (M > 0) ? d.ev + (size_t)slot * ms_ev_plane<Cons>(d) : nullptr;
   bool alive = true;
   int steps = N;
   unsigned int ymask = 0xffffffffu;      // dual step sizes of the ladder that keep every row above its fraction-to-boundary bound so far
@@ -831,12 +1239,13 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
         const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
         double lsum = 0.0, l1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); l1 += fabs(g[off + i] + sn[off + i]); }
+        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); const double pr = g[off + i] + sn[off + i]; l1 += fabs(pr); r_ipr = dmax(r_ipr, fabs(pr)); }
         merit_b -= mu * lsum; cv += l1;
+        evn[GI(t, (NSEG > 0 ? NSEG : 1), cs)] = lsum;
       }
       double n1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) n1 += fabs(fn[i] - xn[i]);
+      for (int i = 0; i < NX; ++i) { const double r = fn[i] - xn[i]; n1 += fabs(r); r_idef = dmax(r_idef, fabs(r)); }
       cv += n1;
     }
     st<NU>(Un + GI(t, NU, 0), kLS, u);
@@ -893,6 +1302,7 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
   d.t_success[ti] = success ? 1 : 0;
   d.t_cost[ti] = cost; d.t_merit[ti] = merit; d.t_theta[ti] = theta; d.t_inf_pr[ti] = theta; d.t_inf_comp[ti] = 0.0;
   d.t_apr[ti] = alpha; d.t_adu[ti] = adu;
+  if constexpr (M > 0) { d.t_ysmin[ti] = r_ipr; d.t_ysmax[ti] = r_idef; }
 }
 
 // ================================================================================ K4 (two-role) + K4b (dual rows)
@@ -958,7 +1368,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   constexpr int kRing = RW <= 12 ? 8 : (RW <= 24 ? 4 : 2);
   __shared__ double s_ring[kRing * RW * 64];
   __shared__ int s_prod, s_cons;
-  __shared__ double s_pcost[64], s_pn1[64];   // the producer lane's l_f(x_N) and its last defect norm
+  __shared__ double s_pcost[64], s_pn1[64], s_pidef[64];   // the producer lane's l_f(x_N), its last defect 1-norm, its largest defect entry
   __shared__ double s_al[CDDP_HIP_MAX_ALPHAS];  // the ladder, for the per-lane look-ups of the dual step search's slow path
   const int lane = threadIdx.x & 63;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
@@ -1004,7 +1414,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
       ld<NX>(Fc + GI(tt, NX, 0), kLS, r.fo);
     };
     constexpr bool kPing = sizeof(PRec) <= 40 * sizeof(double);
-    double n1_prev = 0.0;
+    double n1_prev = 0.0, r_idef = 0.0;
     bool stop = false;
     auto step = [&](const int t, PRec &c, PRec &n) {
       // the record of step t + 1 (clamped): its x_old row is also the x1 of this step's gap-closing rule
@@ -1067,7 +1477,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
       }
       { double n1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) n1 += fabs(fn[i] - xn[i]);
+        for (int i = 0; i < NX; ++i) { const double r = fn[i] - xn[i]; n1 += fabs(r); r_idef = dmax(r_idef, fabs(r)); }
         n1_prev = n1; }
       st<NU>(Un + GI(t, NU, 0), kLS, u);
       st<NX>(Fn + GI(t, NX, 0), kLS, fn);
@@ -1094,7 +1504,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
       for (; t < N && !stop; ++t) step(t, ra, ra);
     }
     s_pcost[lane] = Obj::terminal_cost(P, x);
-    s_pn1[lane] = n1_prev;
+    s_pn1[lane] = n1_prev; s_pidef[lane] = r_idef;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -1113,6 +1523,8 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   typename Cons::Ctx cc;
   Cons::load(P, cc);
   double cost = 0.0, merit_b = 0.0, cv = 0.0;
+  [[maybe_unused]] double r_ipr = 0.0;   // max |g + s| of the trial (K5's filter reset)
+  [[maybe_unused]] double *evn = (M > 0) ? d.ev + (size_t)slot * ms_ev_plane<Cons>(d) : nullptr;   // parked log-barrier sums of the trial
   bool alive = true;
   int steps = N;
   unsigned int ymask = 0xffffffffu;
@@ -1229,8 +1641,9 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
         const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
         double lsum = 0.0, l1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); l1 += fabs(g[off + i] + sn[off + i]); }
+        for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); const double pr = g[off + i] + sn[off + i]; l1 += fabs(pr); r_ipr = dmax(r_ipr, fabs(pr)); }
         merit_b -= mu * lsum; cv += l1;
+        evn[GI(t, (NSEG > 0 ? NSEG : 1), cs)] = lsum;
       }
     }
   };
@@ -1240,6 +1653,10 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
     for (int i = 0; i < (NX > MM ? NX : MM); ++i) z[i] = 0.0;
     if constexpr (M > 0) { st<M>(d.S + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); st<M>(d.G + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); }
     st<NX>(Ln + GI(0, NX, 0), kLS, z);
+    if constexpr (M > 0) {
+#pragma unroll
+      for (int cs = 0; cs < NSEG; ++cs) evn[GI(0, (NSEG > 0 ? NSEG : 1), cs)] = 0.0;
+    }
   };
   {
     CRec ra, rb;
@@ -1296,6 +1713,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   d.t_success[ti] = success ? 1 : 0;
   d.t_cost[ti] = cost; d.t_merit[ti] = merit; d.t_theta[ti] = theta; d.t_inf_pr[ti] = theta; d.t_inf_comp[ti] = 0.0;
   d.t_apr[ti] = alpha; d.t_adu[ti] = adu;
+  if constexpr (M > 0) { d.t_ysmin[ti] = r_ipr; d.t_ysmax[ti] = s_pidef[lane]; }
 }
 
 // ================================================================================ K5
@@ -1328,7 +1746,7 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
       double mu = d.mu[b];
       bool running = true;
       const bool fp_success = win >= 0;
-      [[maybe_unused]] double sdu = 0.0;
+      [[maybe_unused]] double sdu = 0.0, ys_lo = INFINITY, ys_hi = -INFINITY;
       [[maybe_unused]] bool have_sdu = false;
       if (fp_success) {
         const size_t ti = (size_t)win * d.Bp + b;
@@ -1349,7 +1767,10 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
         d.reg[b] = reg_decrease(o, d.reg[b]);
         // checkConvergence (:306-364): the residuals are those of the last backward pass / filter reset, the duals the new iterate's
         const double ipr = d.inf_pr[b], icomp = d.inf_comp[b];
-        sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]); have_sdu = true;
+        if constexpr (M > 0) {   // the mu-independent residual pieces of the new iterate (ms_replay_filter)
+          d.ms_res[b] = d.t_ysmin[ti]; d.ms_res[(size_t)d.Bp + b] = d.t_ysmax[ti]; d.ms_res[(size_t)2 * d.Bp + b] = w_theta;
+        }
+        sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b], ys_lo, ys_hi); have_sdu = true;
         const double metric = dmax(dmax(sdu, ipr), icomp);
         int st = CDDP_HIP_STATUS_RUNNING;
         const int iter = d.iter[b];
@@ -1383,8 +1804,9 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
           if (o.barrier_strategy == CDDP_HIP_BARRIER_MONOTONIC) {
             mu = dmax(o.barrier_mu_min_value, o.barrier_mu_update_factor * mu);
             reset = true;
+            if (!have_sdu) { sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b], ys_lo, ys_hi); have_sdu = true; }   // (for the extreme products y s)
           } else {
-            if (!have_sdu) sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b]);   // (after a failed pass: duals and inf_du unchanged)
+            if (!have_sdu) { sdu = ms_scaled_inf_du<Model, Cons>(d, b, slot_now, d.inf_du[b], ys_lo, ys_hi); have_sdu = true; }   // (after a failed pass: duals and inf_du unchanged)
             const double metric = dmax(dmax(sdu, d.inf_pr[b]), d.inf_comp[b]);
             if (o.barrier_strategy == CDDP_HIP_BARRIER_IPOPT) {
               if (metric <= 10.0 * mu) {
@@ -1410,7 +1832,7 @@ __global__ __launch_bounds__(64) void k_update_msipddp(DevBuf d, const ProblemDe
               }
             }
           }
-          if (reset) { d.mu[b] = mu; ms_reset_filter<Model, Cons>(d, b, slot_now, mu, d.cost[b]); }
+          if (reset) { d.mu[b] = mu; ms_replay_filter<Model, Cons>(d, b, slot_now, mu, d.cost[b], ys_lo, ys_hi); }
         }
         d.phase[b] = PH_ACTIVE;
       }

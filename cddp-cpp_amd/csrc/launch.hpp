@@ -48,6 +48,7 @@ struct KernelSet {
   bool has_msipddp;  // the MSIPDDP kernels (kernels_msipddp.hpp) are instantiated for this layout: nx <= 8, no terminal set, and -- with path
                      // constraints -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines)
   bool has_logddp;   // the LogDDP kernels (kernels_logddp.hpp) are instantiated for this layout: one lane per trajectory, nx <= 8, no terminal set
+  int ms_cst_size;   // MSIPDDP, path-constrained: per-step doubles of the condensed-term stack of the split sweep (kernels_msipddp.hpp::MsCst), 0 = none
   int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
 };
 
@@ -70,12 +71,15 @@ struct Launcher {
 #define CDDP_LOGDDP_MAX_NX 16
 #endif
   static constexpr bool kLog = !TERM && Model::NX <= CDDP_LOGDDP_MAX_NX;
-  // MSIPDDP on the device (kernels_msipddp.hpp): one-lane kernels, register-resident shapes only; with path constraints only the shapes
-  // for which the reference's recursion is defined
+  // MSIPDDP on the device (kernels_msipddp.hpp); with path constraints only the shapes for which the reference's recursion is defined
+  // (nu = 1 or nx = nu, msipddp_solver.cpp:1398).  Round 5: up to nx = 13, i.e. the unconstrained quadrotor runs resident (one-lane sweep
+  // through scratch: correct, slow -- 9 KB per lane); the reference's own MSIPDDPTest.SolveQuadrotor (test_msipddp_solver.cpp:565) adds a
+  // control box with nu = 4, nx = 13 -- a shape :1398 does not define -- and stays refused on both routes.
 #ifndef CDDP_MSIPDDP_MAX_NX
-#define CDDP_MSIPDDP_MAX_NX 8
+#define CDDP_MSIPDDP_MAX_NX 13
 #endif
   static constexpr bool kMs = !TERM && Model::NX <= CDDP_MSIPDDP_MAX_NX && (Cons::M == 0 || Model::NU == 1 || Model::NX == Model::NU);
+  static constexpr int ms_cst_size() { if constexpr (kMs && Cons::M > 0) return MsCst<Model, Cons>::SIZE; else return 0; }
   static dim3 gridB(const DevBuf &d) { return dim3((d.B + 63) / 64); }
   static bool lane_sweep_requested() {   // read per launch (the tests switch it between solves of one process)
     const char *e = std::getenv("CDDP_HIP_SWEEP");
@@ -105,7 +109,7 @@ struct Launcher {
     else {
       if (lane_sweep_requested() || mfma_sweep_requested() || d.ddp) return 0;
       if (const char *e = std::getenv("CDDP_HIP_T4")) { if (e[0] == '0') return 0; }
-      if constexpr (kLean) return d.cst ? 1 : 0;
+      if constexpr (kLean) return (d.cst && !d.ms && !d.lg) ? 1 : 0;   // (an MSIPDDP handle keeps its own condensed-term stack in d.cst: plain layout)
       else if constexpr (kTeCoop) return d.te_cst ? 1 : 0;
       else return 0;
     }
@@ -126,7 +130,7 @@ struct Launcher {
     DevBuf d = d0;
     d.t4 = t4_layout(d0);
     if constexpr (kLean) {
-      if (d.cst) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
+      if (d.cst && !d.ms && !d.lg) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
                      // for nx > 8 the two register sets together would spill)
         if constexpr (Model::NX <= 8) {
           hipLaunchKernelGGL((k_condense<Model, Cons, true>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
@@ -163,7 +167,20 @@ struct Launcher {
       return;
     }
     if (solver == CDDP_HIP_SOLVER_MSIPDDP) {
-      if constexpr (kMs) hipLaunchKernelGGL((k_backward_msipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      if constexpr (kMs) {
+        // path-constrained iLQR sweeps: condense (batch x N) -> value recursion -> post (batch x N) (round 5); the fused one-lane kernel
+        // carries the tensor terms of full DDP, the unconstrained branch with its factor cache, and CDDP_HIP_SWEEP=lane (comparison)
+        if constexpr (Cons::M > 0) {
+          if (d.cst && !d.ddp && !lane_sweep_requested()) {
+            const dim3 gridW((d.B + 63) / 64, d.N);
+            hipLaunchKernelGGL((k_ms_condense<Model, Cons>), gridW, dim3(64), 0, s, d, d.P, d.xref_traj, force);
+            hipLaunchKernelGGL((k_backward_msipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+            hipLaunchKernelGGL((k_ms_post<Model, Cons>), gridW, dim3(64), 0, s, d, d.P, force);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((k_backward_msipddp<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+      }
       return;
     }
     const bool lane_sweep = lane_sweep_requested() || (d.ddp && solver == CDDP_HIP_SOLVER_IPDDP);
@@ -337,7 +354,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess; k.has_msipddp = kMs;
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess; k.has_msipddp = kMs; k.ms_cst_size = ms_cst_size();
     return k;
   }
 };

@@ -113,3 +113,19 @@ def test_plugin_and_stack_entry_points_refuse_another_abi(api, lib):
     res = (C.c_char * 4096)()
     rc = lib.cddp_hip_plugin_solve(C.byref(ps), api.SOLVER_IPDDP, 10, C.c_double(0.1), C.byref(o), 0, 1, x0, None, None, res, None, None, None)
     assert rc == -2 and b"ABI mismatch" in lib.cddp_hip_last_error()
+
+
+def test_rccl_declarations_restated_in_comm_hip_match_the_installed_header():
+    """comm.hip declares the handful of RCCL types / entry points it binds with dlopen itself (the solver core builds without the RCCL headers).
+    Where rccl.h is installed, tests/cpp/test_rccl_abi.cpp holds those restatements to it at compile time: id size, enum values, signatures."""
+    import shutil, subprocess
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr) or shutil.which("g++") is None:
+        pytest.skip("no RCCL header / g++ here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(repo, "tests", "cpp", "test_rccl_abi.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the restated values the check pins are the ones comm.hip actually uses
+    src = open(os.path.join(repo, "cddp-cpp_amd", "csrc", "comm.hip")).read()
+    assert "char internal[128]" in src and "ncclUint8 = 1" in src and "ncclSuccess = 0" in src

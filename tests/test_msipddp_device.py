@@ -38,6 +38,7 @@ def make(api, name):
         "cartpole_box": lambda: S.cartpole_problem(MS, True),
         "cartpole_free": lambda: S.cartpole_problem(MS, False),
         "unicycle_free": lambda: _strip(S.unicycle_problem(MS, 60, False)),
+        "quadrotor_free": lambda: S.quadrotor_problem(MS, 40, False),   # nx = 13 (round 5: CDDP_MSIPDDP_MAX_NX = 13), no path constraints
     }
     p = table[base]()
     p.c.solver = MS
@@ -77,7 +78,7 @@ def _strip(p):
 CASES = ["pendulum_box", "pendulum_box-ms", "pendulum_box-hybrid", "pendulum_box-hybrid-ms", "pendulum_box-linear-ms", "pendulum_free",
          "pendulum_free-ms", "pendulum_free-hybrid-ms", "cartpole_box-hybrid", "cartpole_box-nonlinear-it25", "cartpole_box-ms",
          "cartpole_box-parallel", "cartpole_box-monotonic", "cartpole_box-ipopt", "cartpole_box-ddp-it30", "cartpole_box-ms-seg3",
-         "cartpole_box-ms-controlled", "unicycle_free-it1", "cartpole_free-it1", "pendulum_free-ddp-hybrid", "pendulum_free-seg1"]
+         "cartpole_box-ms-controlled", "unicycle_free-it1", "cartpole_free-it1", "pendulum_free-ddp-hybrid", "pendulum_free-seg1", "quadrotor_free-it1", "quadrotor_free-ms-hybrid-it1"]
 
 
 def spread_for(p):
@@ -86,6 +87,8 @@ def spread_for(p):
         s[1] = 0.3
     if p.nx == 3:
         s[:] = 0.05
+    if p.nx >= 6:
+        s[:] = 0.02
     return s
 
 
@@ -432,3 +435,33 @@ def test_two_role_rollout_agrees_bitwise(api, case, monkeypatch):
         assert np.array_equal(tr["success"], tr0["success"]), key
         for f in ("cost", "merit_function", "theta", "alpha_du"):
             assert np.array_equal(tr[f][ok], tr0[f][ok]), (key, f)
+
+
+@pytest.mark.parametrize("case", ["pendulum_box", "pendulum_box-hybrid-ms", "cartpole_box-hybrid", "cartpole_box-parallel", "cartpole_box-ms-seg3",
+                                  "cartpole_box-monotonic", "cartpole_box-ipopt"])
+def test_split_and_fused_sweeps_agree_bitwise(api, case, monkeypatch):
+    """Round 5: the path-constrained sweep split into k_ms_condense (batch x N) -> k_backward_msipddp_lean -> k_ms_post (batch x N) forms
+    every entry with the expression of the fused one-lane kernel (CDDP_HIP_SWEEP=lane): gains, value expansion, slack / dual gains'
+    effect on the solve, result words and trajectories are the same bits."""
+    p, ms_start = make(api, case)
+    B = 130
+    x0 = api.batch_x0(p, B, 20270303, spread_for(p))
+    X0 = guess(p, x0, ms_start)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, None, X0); hs.initialize(); ok = hs.backward()
+        K, k = hs.gains(); Vx, Vxx = hs.value(); dV, reg = hs.backward_scalars(); r1 = hs.results()
+        tr = hs.forward(api.Oracle(p).alphas()); hs.close()
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, None, X0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); d = hs.duals(); K2, k2 = hs.gains(); hs.close()
+        return (ok, K, k, Vx, Vxx, dV, reg, tr["success"], tr["cost"], tr["alpha_du"], X, U, K2, k2) + tuple(d), (r1, r)
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    a, ra = run()
+    monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
+    b, rb = run()
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert np.array_equal(u, v, equal_nan=True), i
+    for u, v in zip(ra, rb):
+        for f in u.dtype.names:
+            assert np.array_equal(u[f], v[f], equal_nan=(u[f].dtype.kind == "f")), f
