@@ -263,7 +263,8 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
         if workload == "manip7" and ipddp:
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
-            sweep_label = "k_derivs+k_condense+%s+k_post" % ("k_backward_ipddp_coop_big" if p.nx > 8 else "k_backward_ipddp_coop")
+            # (nx <= 8: the derivative fill is fused into k_condense<.., true>, launch.hpp::derivs -- there is no k_derivs launch)
+            sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big+k_post" if p.nx > 8 else "k_condense+k_backward_ipddp_coop+k_post"
         elif solver == "msipddp":  # resident MSIPDDP (kernels_msipddp.hpp): the split path-constrained sweep (round 5), the fused one-lane kernel otherwise
             sweep_label = "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post" if m > 0 else "k_derivs+k_backward_msipddp"
         elif solver == "logddp":   # resident LogDDP: the LogDDP mode of the cooperative sweep up to nx = 8, scored with CLDDP's byte model (the

@@ -14,6 +14,12 @@
 
 #include "launch.hpp"
 
+// 1 when a[0] > a[1] > ... > a[n - 1] (NaN-free): the ladders cddp_hip_build_alphas makes; DevBuf::ladder_sorted
+static int ladder_strictly_decreasing(const double *a, int n) {
+  for (int i = 1; i < n; ++i) if (!(a[i] < a[i - 1])) return 0;
+  return n > 0 ? 1 : 0;
+}
+
 using namespace cddp_dev;
 
 namespace cddp_dev {
@@ -471,6 +477,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   std::memset(&d, 0, sizeof(d));
   const int B = batch, Bp = (batch + 63) / 64 * 64, N = P.N, nx = P.nx, nu = P.nu, m = P.m;
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
+  d.ladder_sorted = ladder_strictly_decreasing(P.alphas, P.n_alphas);
   d.ddp = P.opt.use_ilqr ? 0 : 1;
   { const char *e = std::getenv("CDDP_HIP_TEST_FAIL_COSTATE"); d.fail_costate_mask = e ? std::atoi(e) : 0; }   // test hook, DevBuf::fail_costate_mask
   { const char *e = std::getenv("CDDP_HIP_XCD_MAP"); d.xcd_map = (e && e[0] == '0') ? 0 : 1; }
@@ -696,6 +703,7 @@ static int in_set_options(Inner *h, const cddp_hip_options *opt) {
   h->P.opt = *opt;
   h->d.ddp = opt->use_ilqr ? 0 : 1;
   for (int i = 0; i < na; ++i) h->P.alphas[i] = al[i];
+  h->d.ladder_sorted = ladder_strictly_decreasing(al, na);
   h->P.ls_rule = opt->enable_parallel ? CDDP_HIP_LS_BEST_MERIT : CDDP_HIP_LS_FIRST_SUCCESS;
   HIPCHK(hipMemcpyAsync(h->dP, &h->P, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -796,8 +804,10 @@ static int in_forward(Inner *h, const double *alphas, int n_alphas, cddp_hip_tri
   ProblemDev tmp = h->P;
   for (int i = 0; i < n_alphas; ++i) tmp.alphas[i] = alphas[i];
   HIPCHK(hipMemcpyAsync(h->dP, &tmp, sizeof(ProblemDev), hipMemcpyHostToDevice, h->stream));
-  h->ks->forward(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
-  h->ks->costate(h->d, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
+  DevBuf dcall = h->d;   // (the caller's ladder may be any set of step sizes)
+  dcall.ladder_sorted = ladder_strictly_decreasing(tmp.alphas, h->d.n_alphas);
+  h->ks->forward(dcall, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
+  h->ks->costate(dcall, h->P.solver, 0, n_alphas, PH_FWD1, 1, 0, h->stream);
   HIPCHK(hipGetLastError());
   const DevBuf &d = h->d;
   const size_t n = (size_t)n_alphas * d.Bp;

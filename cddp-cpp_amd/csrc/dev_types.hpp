@@ -105,6 +105,7 @@ struct DevBuf {
   double *F;                               // [n_slots] planes (stride planeX): dynamics values f(x_t, u_t) of every iterate / trial, rows 0 .. N-1
   double *kl;                              // [N][nx][Bp] costate feed-forward gains k_lambda of the last sweep (K_lambda = V_xx(t+1) is d.Vxx)
   double *fac;                             // [N][nu nu + nu + 1][Bp] unconstrained branch: cached LDLT of Q_uu per step (matrix | transpositions | valid)
+  int ladder_sorted;                       // the line-search ladder is strictly decreasing (what cddp_hip_build_alphas makes): the MSIPDDP rollout's dual step search probes only the two ends of the accepted interval
   double *ms_res;                          // [3][Bp] of the CURRENT iterate (mu-independent, kept for resetBarrierFilter): max |g + s|, max |F_t - x_{t+1}|, the violation sum
   int xcd_map;                             // cooperative sweeps: groups of one 64-trajectory tile on one XCD (kernels_coop.hpp::coop_group); CDDP_HIP_XCD_MAP=0 turns it off
 };

@@ -27,6 +27,24 @@ namespace cddp_dev {
 // hipcc sinks the prefetch loads of the software pipeline down to their first use (next iteration), which
 // removes the overlap; a compiler-level memory barrier right after issuing them pins them at the loop top.
 #define PIPELINE_FENCE() asm volatile("" ::: "memory")
+// Hand-over points of the rollouts' LDS rings (kernels_lean.hpp, kernels_logddp.hpp, kernels_msipddp.hpp): ring rows first, then the
+// counter.  Both are LDS operations of ONE wavefront, which the LDS pipeline executes in issue order, so a compiler barrier would do
+// (CDDP_RING_FENCE_WAIT=0: built, 257 bitwise / parity tests green, and NO measurable gain on C2 / C3 / LogDDP / MSIPDDP,
+// profiles/r05_ring_fence.md): the s_waitcnt lgkmcnt(0) stays -- it does not lean on that property and costs nothing measurable.
+#ifndef CDDP_RING_FENCE_WAIT
+#define CDDP_RING_FENCE_WAIT 1
+#endif
+// The consumer remembers the last value of the producer's counter it saw and polls again only when that value does not cover the step it
+// is about to take: with the producer ahead by several steps (the ring holds up to 8) a poll -- an LDS round trip on the consumer's
+// chain -- is needed once per several steps instead of every step.  CDDP_RING_LAZY_POLL=0: poll every step (rounds 1 - 4).
+#ifndef CDDP_RING_LAZY_POLL
+#define CDDP_RING_LAZY_POLL 1
+#endif
+#if CDDP_RING_FENCE_WAIT
+#define RING_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define RING_FENCE() asm volatile("" ::: "memory")
+#endif
 // Sub-tile-minor ("T4") layout of the SWEEP-INPUT stacks (A_t, B_t, condensed terms) of the G = 16 cooperative sweeps (nx > 8:
 // kernels_coop.hpp::k_backward_ipddp_coop_big, kernels_te.hpp::k_backward_te_coop).  A single-wave workgroup of those sweeps holds
 // 4 trajectories, i.e. 32 B of every 512-B row of the wave-tiled layout: sixteen workgroups share each row (four share each

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
         for (int i = 0; i < NU; ++i) rs[(2 * NX + i) * 64] = u[i];
         if (alive && !finite) { s_pstat[lane] = t; alive = false; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RING_FENCE();
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if constexpr (kEarly) {   // next step's record into the (now dead) register set, behind the integrator
@@ -868,6 +868,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   const double a_du = dmin(alpha, d.adu_max[bb]);
   const size_t ti = (size_t)a * d.Bp + bb;
   bool alive = active;
+  int seen_prod = 0;     // last value of the producer's counter this wave saw (wave-uniform)
   int fail_t = N;        // steps completed before the trial was abandoned (kept in a register, stored at the exits)
   if (alive) {
     atomicAdd(d.launched, 1ull);
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     } else if constexpr (!kEarly && !kChunk) load_step(t, cs);
     PIPELINE_FENCE();
     // take step t from the ring, then hand the slot back
-    wait_ge(&s_prod, t + 1);
+    if (!CDDP_RING_LAZY_POLL || seen_prod < t + 1) seen_prod = __builtin_amdgcn_readfirstlane(wait_ge(&s_prod, t + 1));
     double rx[NX], dx[NX], u[NU];
     {
       const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       for (int i = 0; i < NX; ++i) { rx[i] = rs[i * 64]; dx[i] = rs[(NX + i) * 64]; }
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = rs[(2 * NX + i) * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RING_FENCE();
       __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (alive && s_pstat[lane] <= t) { alive = false; fail_t = t; }

@@ -538,9 +538,11 @@ __global__ __launch_bounds__(128) void k_forward_logddp_pc(DevBuf d, const Probl
   const int cur = (b < d.B) ? d.cur[b] : 0;
   const int slot = trial_slot(cur, a);
   const double alpha = P->alphas[a];
-  auto wait_ge = [&](int *ctr, int need) {
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+  auto wait_ge = [&](int *ctr, int need) -> int {
+    int v;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
+    return v;
   };
   if (producer) {
     const double *Xc = d.X + (size_t)cur * d.planeX, *Uc = d.U + (size_t)cur * d.planeU;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(128) void k_forward_logddp_pc(DevBuf d, const Probl
         for (int i = 0; i < NX; ++i) rs[i * 64] = x[i];
 #pragma unroll
         for (int i = 0; i < NU; ++i) rs[(NX + i) * 64] = u[i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RING_FENCE();
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if constexpr (!kPing) { fetch(t + 1 < N ? t + 1 : t, c); PIPELINE_FENCE(); }
@@ -627,12 +629,13 @@ __global__ __launch_bounds__(128) void k_forward_logddp_pc(DevBuf d, const Probl
   typename Cons::Ctx cc;
   Cons::load(P, cc);
   double cost = 0.0, merit_b = 0.0, viol = 0.0;
+  int seen_prod = 0;     // last value of the producer's counter this wave saw (wave-uniform)
   if constexpr (M > 0) {   // the VMEM queue primed with one step's store pattern
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) evn[GI(0, NS, s)] = 0.0;
   }
   for (int t = 0; t < N; ++t) {
-    wait_ge(&s_prod, t + 1);
+    if (!CDDP_RING_LAZY_POLL || seen_prod < t + 1) seen_prod = __builtin_amdgcn_readfirstlane(wait_ge(&s_prod, t + 1));
     double x[NX], u[NU];
     {
       const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(128) void k_forward_logddp_pc(DevBuf d, const Probl
       for (int i = 0; i < NX; ++i) x[i] = rs[i * 64];
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = rs[(NX + i) * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RING_FENCE();
       __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     cost += Obj::running_cost(oc, xrt, t, x, u);

@@ -1318,44 +1318,89 @@ __global__ __launch_bounds__(64) void k_forward_msipddp(DevBuf d, const ProblemD
 // violation terms of step t, i.e. behind those of step t - 1), so the pair is bitwise the one-wave kernel
 // (tests/test_msipddp_device.py::test_two_role_rollout_agrees_bitwise).  The nominal F_t and x_{t+1} rows a boundary step needs ride in the
 // producer's prefetched record (the one-wave kernel fetched them at the boundary: a memory round trip on the chain every segment).
-// The DUAL ROWS of a trial (:1627-1637) are no longer written by the rollout: nobody reads them unless the trial is the one the selection
-// rule accepts, so k_duals_msipddp evaluates them at (batch x N) width for that trial only -- the one-wave kernel walked the horizon a
-// second time per trial, one memory round trip per step.
+// The ROWS of a trial -- slack, dual (:1627-1637), costate (:1639-1641), constraint values, parked log sums -- are no longer written by the
+// rollout: nobody reads them unless the trial is the one the selection rule accepts, so k_rows_msipddp forms them at (batch x N) width
+// for that trial only, from the trial's stored X / U rows with the rollout's own expressions (same operands, same order: same bits).  The
+// consumer keeps what DECIDES: the slack trial (fraction-to-boundary test, barrier and violation sums), the dual step search, cost and
+// merit.  Why: the consumer, not the dynamics chain, bounded the pair -- 24 row loads + 7 row stores per step against the ~16 outstanding
+// row operations a wavefront can hold (profiles/r05_ms_rollout_roles.md: consumer emptied 153 -> 70 us per launch, producer emptied 152);
+// the one-wave kernel even walked the horizon a second time per trial for the dual rows.
 template <class Model, class Cons>
-__global__ __launch_bounds__(64) void k_duals_msipddp(DevBuf d, int a0, int na, int phase_req, int force, int first_only) {
-  constexpr int NX = Model::NX, M = Cons::M, MM = M > 0 ? M : 1;
+__global__ __launch_bounds__(64) void k_rows_msipddp(DevBuf d, const ProblemDev *__restrict__ Pk, int a0, int na, int phase_req, int force, int first_only) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1, NSEG = Cons::NSEG, NS = NSEG > 0 ? NSEG : 1;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != phase_req) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const int cur = d.cur[b];
+  int a_lo = a0, a_hi = a0 + na;
+  if (!force && first_only != 0) {
+    const int only = first_only == 2 ? d.cand[b] : first_surviving_trial(d, a0, na, b);
+    if (only < 0) return;
+    a_lo = only; a_hi = only + 1;
+  }
+  double xo[NX], lo[NX], kl[NX], Kl[NX * NX];
+  ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+  ld<NX>(d.Lam + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, lo);
+  ld<NX>(d.kl + GI(t, NX, 0), kLS, kl);
+  ld<NX * NX>(d.Vxx + GI(t + 1, NX * NX, 0), kLS, Kl);
+  [[maybe_unused]] double so[MM], ksv[MM], Ks[MM * NX], yo[MM], ky[MM], Ky[MM * NX];
+  [[maybe_unused]] typename Cons::Ctx cc;
   if constexpr (M > 0) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    const int t = blockIdx.y;
-    if (b >= d.B) return;
-    if (!force && d.phase[b] != phase_req) return;
-    const int cur = d.cur[b];
-    int a_lo = a0, a_hi = a0 + na;
-    if (!force && first_only != 0) {
-      const int only = first_only == 2 ? d.cand[b] : first_surviving_trial(d, a0, na, b);
-      if (only < 0) return;
-      a_lo = only; a_hi = only + 1;
-    }
-    double xo[NX], yo[MM], ky[MM], Ky[MM * NX];
-    ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, xo);
+    Cons::load(P, cc);
+    ld<M>(d.S + (size_t)cur * d.planeM + GI(t, M, 0), kLS, so);
+    ld<M>(d.ks + GI(t, M, 0), kLS, ksv);
+    ld<M * NX>(d.Ks + GI(t, M * NX, 0), kLS, Ks);
     ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, yo);
     ld<M>(d.ky + GI(t, M, 0), kLS, ky);
     ld<M * NX>(d.Ky + GI(t, M * NX, 0), kLS, Ky);
-    for (int a = a_lo; a < a_hi; ++a) {
-      const size_t ti = (size_t)a * d.Bp + b;
-      if (d.t_success[ti] != 1) continue;
-      const int slot = trial_slot(cur, a);
-      const double adu = d.t_adu[ti];
-      double xt[NX], dx[NX], yn[MM];
-      ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xt);
+  }
+  for (int a = a_lo; a < a_hi; ++a) {
+    const size_t ti = (size_t)a * d.Bp + b;
+    if (d.t_success[ti] != 1) continue;
+    const int slot = trial_slot(cur, a);
+    const double alpha = d.t_apr[ti];
+    double xt[NX], dx[NX];
+    ld<NX>(d.X + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, xt);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) dx[i] = xt[i] - xo[i];
+    for (int i = 0; i < NX; ++i) dx[i] = xt[i] - xo[i];
+    {   // costate trial (:1466-1467 == :1639-1641): lambda + a k_lambda + K_lambda dx, K_lambda = V_xx(t+1)
+      double ln[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Kl[i * NX + j] * dx[j];
+        ln[i] = (lo[i] + alpha * kl[i]) + s; }
+      st<NX>(d.Lam + (size_t)slot * d.planeX + GI(t, NX, 0), kLS, ln);
+    }
+    if constexpr (M > 0) {
+      const double adu = d.t_adu[ti];
+      double ut[NU], sn[MM], yn[MM], g[MM];
+      ld<NU>(d.U + (size_t)slot * d.planeU + GI(t, NU, 0), kLS, ut);
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += Ks[r * NX + j] * dx[j];
+        sn[r] = (so[r] + alpha * ksv[r]) + s; }
 #pragma unroll
       for (int r = 0; r < M; ++r) { double s = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) s += Ky[r * NX + j] * dx[j];
         yn[r] = (yo[r] + adu * ky[r]) + s; }
+      Cons::template eval<NX, NU>(cc, xt, ut, g);
+      st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
       st<M>(d.Y + (size_t)slot * d.planeM + GI(t, M, 0), kLS, yn);
+      st<M>(d.G + (size_t)slot * d.planeM + GI(t, M, 0), kLS, g);
+      double *evn = d.ev + (size_t)slot * ms_ev_plane<Cons>(d);
+#pragma unroll
+      for (int cs = 0; cs < NSEG; ++cs) {   // the parked log sums K5's filter reset replays (ms_replay_filter): the rollout's own terms
+        const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
+        double lsum = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) if (i < dim) lsum += solver_log(sn[off + i]);
+        evn[GI(t, NS, cs)] = lsum;
+      }
     }
   }
 }
@@ -1370,6 +1415,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   __shared__ int s_prod, s_cons;
   __shared__ double s_pcost[64], s_pn1[64], s_pidef[64];   // the producer lane's l_f(x_N), its last defect 1-norm, its largest defect entry
   __shared__ double s_al[CDDP_HIP_MAX_ALPHAS];  // the ladder, for the per-lane look-ups of the dual step search's slow path
+  __shared__ int s_pq[64];                      // the producer lane's dual step: index of the first ladder entry every row of every step accepts, -1 = none
   const int lane = threadIdx.x & 63;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
   const int b = blockIdx.x * 64 + lane;
@@ -1405,13 +1451,30 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
     double x[NX];
     ld<NX>(Xc + GI(0, NX, 0), kLS, x);     // r.X[0] = initial state (:1443)
     st<NX>(Xn + GI(0, NX, 0), kLS, x);
-    struct PRec { double xo[NX], uo[NU], kk[NU], KK[NU * NX], fo[NX]; };
+    // Dual step search (:1612-1644), here because the PRODUCER has the slack (profiles/r05_ms_rollout_roles.md): on a strictly decreasing
+    // ladder (what cddp_hip_build_alphas makes; any other ladder runs the one-wave kernel, launch.hpp) the dual trial of one row of one
+    // step, yn(a) = (y + a k_y) + K_y dx, is a monotone function of a in IEEE arithmetic (a rounded product and two rounded sums with
+    // fixed other operands), so the ladder entries it rejects (yn < bound) are a PREFIX or a SUFFIX of the ladder (NaN / Inf cases
+    // included: a NaN trial is never "below", and an infinite K_y dx makes the trial one value wherever it is not NaN), and the entries
+    // every row of every step so far accepts are an interval [qL, qH).  Only its two ends are probed per row (2 trials instead of
+    // n_alphas); a lane whose end is rejected walks it inwards (LDS table).  First accepted entry = qL: the lowest set bit of the
+    // one-wave kernel's mask.
+    const int n_alphas = d.n_alphas;
+    [[maybe_unused]] const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - d.mu[bb]);
+    [[maybe_unused]] int qL = 0, qH = n_alphas;
+    [[maybe_unused]] double aL = P->alphas[0], aH = P->alphas[n_alphas > 0 ? n_alphas - 1 : 0];
+    struct PRec { double xo[NX], uo[NU], kk[NU], KK[NU * NX], fo[NX], yo[MM], ky[MM], Ky[MM * NX]; };
     auto fetch = [&](int tt, PRec &r) {
       ld<NX>(Xc + GI(tt, NX, 0), kLS, r.xo);
       ld<NU>(Uc + GI(tt, NU, 0), kLS, r.uo);
       ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
       ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
       ld<NX>(Fc + GI(tt, NX, 0), kLS, r.fo);
+      if constexpr (M > 0) {
+        ld<M>(d.Y + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.yo);
+        ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
+        ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
+      }
     };
     constexpr bool kPing = sizeof(PRec) <= 40 * sizeof(double);
     double n1_prev = 0.0, r_idef = 0.0;
@@ -1435,8 +1498,24 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
 #pragma unroll
         for (int i = 0; i < NU; ++i) rs[(2 * NX + i) * 64] = u[i];
         rs[(2 * NX + NU) * 64] = n1_prev;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RING_FENCE();
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if constexpr (M > 0) {   // dual feasibility of the two ends of the accepted interval (off the chain: nothing below reads it)
+#pragma unroll
+        for (int r = 0; r < M; ++r) { double sy = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) sy += c.Ky[r * NX + j] * dx[j];
+          const double bound = (1.0 - tau) * c.yo[r];
+          const double ynL = (c.yo[r] + aL * c.ky[r]) + sy, ynH = (c.yo[r] + aH * c.ky[r]) + sy;
+          const bool hit = (qL < qH) && ((ynL < bound) || (ynH < bound));
+          if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+            if (hit) {
+              while (qL < qH && ((c.yo[r] + s_al[qL] * c.ky[r]) + sy) < bound) ++qL;
+              while (qH > qL && ((c.yo[r] + s_al[qH - 1] * c.ky[r]) + sy) < bound) --qH;
+              aL = s_al[qL < n_alphas ? qL : n_alphas - 1]; aH = s_al[qH > 0 ? qH - 1 : 0];
+            }
+          } }
       }
       double kk_keep[NU], KK_keep[NU * NX], fo[NX];   // what the "hybrid" rule reads of the record (dead otherwise)
 #pragma unroll
@@ -1505,14 +1584,13 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
     }
     s_pcost[lane] = Obj::terminal_cost(P, x);
     s_pn1[lane] = n1_prev; s_pidef[lane] = r_idef;
+    if constexpr (M > 0) s_pq[lane] = (qL < qH) ? qL : -1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(&s_prod, N + kRing + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
   }
 
   // -------------------------------------------------------------------- consumer
-  const double *Lc = d.Lam + (size_t)cur * d.planeX;
-  double *Ln = d.Lam + (size_t)slot * d.planeX;
   const double mu = d.mu[bb];
   const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
   const int n_alphas = d.n_alphas;
@@ -1524,46 +1602,21 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   Cons::load(P, cc);
   double cost = 0.0, merit_b = 0.0, cv = 0.0;
   [[maybe_unused]] double r_ipr = 0.0;   // max |g + s| of the trial (K5's filter reset)
-  [[maybe_unused]] double *evn = (M > 0) ? d.ev + (size_t)slot * ms_ev_plane<Cons>(d) : nullptr;   // parked log-barrier sums of the trial
+  int seen_prod = 0;     // last value of the producer's counter this wave saw (wave-uniform)
   bool alive = true;
   int steps = N;
-  unsigned int ymask = 0xffffffffu;
-  constexpr int kAL = 16;
-  [[maybe_unused]] double al[kAL];
-#pragma unroll
-  for (int q = 0; q < kAL; ++q) al[q] = (q < n_alphas) ? P->alphas[q] : 0.0;
-  // Dual step search (:1612-1644) on a strictly decreasing ladder (what cddp_hip_build_alphas makes): for one row of one step the dual
-  // trial yn(a) = (y + a k_y) + K_y dx is a monotone function of a in IEEE arithmetic (a rounded product and two rounded sums with fixed
-  // other operands), so the ladder entries it rejects (yn < bound) are a PREFIX or a SUFFIX of the ladder (NaN / Inf cases included: a
-  // NaN trial is never "below", and an infinite K_y dx makes the trial one value wherever it is not NaN), and the entries every row
-  // of every step so far accepts are an interval [qL, qH).  Only its two ends are probed per row (2 trials instead of n_alphas); a lane
-  // whose end is rejected walks it inwards (LDS table).  First accepted entry = qL, exactly the lowest set bit of the one-wave kernel's
-  // mask.  A ladder that is not strictly decreasing keeps the mask form.
-  bool sorted_ladder = n_alphas <= CDDP_HIP_MAX_ALPHAS;
-  for (int q = 1; q < n_alphas; ++q) sorted_ladder = sorted_ladder && (P->alphas[q] < P->alphas[q - 1]);
-  int qL = 0, qH = n_alphas;
-  double aL = P->alphas[0], aH = P->alphas[n_alphas > 0 ? n_alphas - 1 : 0];
-  struct CRec {
-    double lo[NX], kl[NX], Kl[NX * NX];
-    double so[MM], ksv[MM], Ks[MM * NX], yo[MM], ky[MM], Ky[MM * NX];
-  };
+  struct CRec { double so[MM], ksv[MM], Ks[MM * NX]; };
   auto fetch = [&](int tt, CRec &r) {
-    ld<NX>(Lc + GI(tt, NX, 0), kLS, r.lo);
-    ld<NX>(d.kl + GI(tt, NX, 0), kLS, r.kl);
-    ld<NX * NX>(d.Vxx + GI(tt + 1, NX * NX, 0), kLS, r.Kl);
     if constexpr (M > 0) {
       ld<M>(d.S + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.so);
       ld<M>(d.ks + GI(tt, M, 0), kLS, r.ksv);
       ld<M * NX>(d.Ks + GI(tt, M * NX, 0), kLS, r.Ks);
-      ld<M>(d.Y + (size_t)cur * d.planeM + GI(tt, M, 0), kLS, r.yo);
-      ld<M>(d.ky + GI(tt, M, 0), kLS, r.ky);
-      ld<M * NX>(d.Ky + GI(tt, M * NX, 0), kLS, r.Ky);
     }
   };
   constexpr bool kPingC = sizeof(CRec) <= 40 * sizeof(double);
   auto step = [&](const int t, CRec &c, CRec &n) {
     if constexpr (kPingC) { fetch(t + 1 < N ? t + 1 : N - 1, n); PIPELINE_FENCE(); }
-    wait_ge(&s_prod, t + 1);
+    if (!CDDP_RING_LAZY_POLL || seen_prod < t + 1) seen_prod = __builtin_amdgcn_readfirstlane(wait_ge(&s_prod, t + 1));
     double x[NX], dx[NX], u[NU], n1_prev;
     {
       const double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
@@ -1572,7 +1625,7 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = rs[(2 * NX + i) * 64];
       n1_prev = rs[(2 * NX + NU) * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RING_FENCE();
       __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     [[maybe_unused]] double sn[MM];
@@ -1585,57 +1638,12 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
         sn[r] = (c.so[r] + alpha * c.ksv[r]) + s;
         const bool viol = alive && (sn[r] < (1.0 - tau) * c.so[r]);
         steps = viol ? t : steps; alive = alive && !viol; }
-      st<M>(d.S + (size_t)slot * d.planeM + GI(t, M, 0), kLS, sn);
-#pragma unroll
-      for (int r = 0; r < M; ++r) { double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) s += c.Ky[r * NX + j] * dx[j];
-        const double bound = (1.0 - tau) * c.yo[r];
-        if (sorted_ladder) {
-          const double ynL = (c.yo[r] + aL * c.ky[r]) + s, ynH = (c.yo[r] + aH * c.ky[r]) + s;
-          const bool hit = (qL < qH) && ((ynL < bound) || (ynH < bound));
-          if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
-            if (hit) {
-              while (qL < qH && ((c.yo[r] + s_al[qL] * c.ky[r]) + s) < bound) ++qL;
-              while (qH > qL && ((c.yo[r] + s_al[qH - 1] * c.ky[r]) + s) < bound) --qH;
-              aL = s_al[qL < n_alphas ? qL : n_alphas - 1]; aH = s_al[qH > 0 ? qH - 1 : 0];
-            }
-          }
-        } else {
-        unsigned int bad = 0u;
-        auto probe = [&](const int q0, const int q1) {
-#pragma unroll
-          for (int q = q0; q < q1; ++q) {
-            const double yn = (c.yo[r] + al[q] * c.ky[r]) + s;
-            bad |= (yn < bound) ? (1u << q) : 0u;
-          }
-        };
-        // (bits of ladder entries beyond n_alphas are never read; n_alphas is wave-uniform: scalar branches)
-        probe(0, 8);
-        if (n_alphas > 8) probe(8, 12);
-        if (n_alphas > 12) probe(12, 16);
-        ymask &= ~bad;
-        for (int q = kAL; q < n_alphas; ++q) {
-          const double yn = (c.yo[r] + P->alphas[q] * c.ky[r]) + s;
-          if (yn < bound) ymask &= ~(1u << q);
-        }
-        } }
-    }
-    {   // costate trial (:1466-1467 == :1639-1641)
-      double ln[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) s += c.Kl[i * NX + j] * dx[j];
-        ln[i] = (c.lo[i] + alpha * c.kl[i]) + s; }
-      st<NX>(Ln + GI(t, NX, 0), kLS, ln);
     }
     if constexpr (!kPingC) { fetch(t + 1 < N ? t + 1 : t, c); PIPELINE_FENCE(); }   // next record into the (dead) set, behind the cost / barrier terms
     cost += Obj::running_cost(oc, xrt, t, x, u);
     if constexpr (M > 0) {
       double g[MM];
       Cons::template eval<NX, NU>(cc, x, u, g);
-      st<M>(d.G + (size_t)slot * d.planeM + GI(t, M, 0), kLS, g);
 #pragma unroll
       for (int cs = 0; cs < NSEG; ++cs) {
         const int off = Cons::seg_off(cs), dim = Cons::seg_dim(cs);
@@ -1643,25 +1651,12 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
 #pragma unroll
         for (int i = 0; i < MM; ++i) if (i < dim) { lsum += solver_log(sn[off + i]); const double pr = g[off + i] + sn[off + i]; l1 += fabs(pr); r_ipr = dmax(r_ipr, fabs(pr)); }
         merit_b -= mu * lsum; cv += l1;
-        evn[GI(t, (NSEG > 0 ? NSEG : 1), cs)] = lsum;
       }
-    }
-  };
-  auto prime = [&]() {
-    double z[NX > MM ? NX : MM];
-#pragma unroll
-    for (int i = 0; i < (NX > MM ? NX : MM); ++i) z[i] = 0.0;
-    if constexpr (M > 0) { st<M>(d.S + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); st<M>(d.G + (size_t)slot * d.planeM + GI(0, M, 0), kLS, z); }
-    st<NX>(Ln + GI(0, NX, 0), kLS, z);
-    if constexpr (M > 0) {
-#pragma unroll
-      for (int cs = 0; cs < NSEG; ++cs) evn[GI(0, (NSEG > 0 ? NSEG : 1), cs)] = 0.0;
     }
   };
   {
     CRec ra, rb;
     fetch(0, ra);
-    prime();
     int t = 0;
     bool all_dead = false;
     if constexpr (kPingC) {
@@ -1701,12 +1696,10 @@ __global__ __launch_bounds__(128) void k_forward_msipddp_pc(DevBuf d, const Prob
   } else {
     merit = merit_b + cost;
     theta = cv;
-    int q_sel = -1;
-    if (sorted_ladder) q_sel = (qL < qH) ? qL : -1;
-    else for (int q = 0; q < n_alphas; ++q) if (q_sel < 0 && ((ymask >> q) & 1u)) q_sel = q;
+    const int q_sel = s_pq[lane];   // the producer's dual step search
     if (alive && q_sel >= 0) {
       adu = P->alphas[q_sel];
-      success = ms_filter_acceptable(d, b, o, merit, theta, alpha * d.dV0[b]);   // the dual rows of the accepted trial: k_duals_msipddp
+      success = ms_filter_acceptable(d, b, o, merit, theta, alpha * d.dV0[b]);   // the rows of the accepted trial: k_rows_msipddp
     }
   }
   d.t_steps[ti] = steps;

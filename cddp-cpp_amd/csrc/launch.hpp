@@ -274,7 +274,7 @@ struct Launcher {
     if (solver == CDDP_HIP_SOLVER_MSIPDDP) {
       // producer / consumer wave pair per (tile, alpha) (round 5); CDDP_HIP_MS_ROLLOUT=lane: the one-wave kernel (comparison: bitwise equal)
       if constexpr (kMs) {
-        if (ms_lane_rollout_requested()) hipLaunchKernelGGL((k_forward_msipddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);
+        if (ms_lane_rollout_requested() || !d.ladder_sorted) hipLaunchKernelGGL((k_forward_msipddp<Model, Cons>), grid, dim3(64), 0, s, d, d.P, d.xref_traj, a0, 0, phase_req, force);   // (a ladder that is not strictly decreasing: the one-wave kernel's mask form of the dual step search)
         else hipLaunchKernelGGL((k_forward_msipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
       }
       return;
@@ -305,11 +305,11 @@ struct Launcher {
   }
   // K4b: costate trial of the surviving trials (kernels_lean.hpp)
   static void costate(const DevBuf &d, int solver, int a0, int na, int phase_req, int force, int first_only, hipStream_t s) {
-    if (solver == CDDP_HIP_SOLVER_MSIPDDP) {   // the dual rows of the trial the selection rule will take (the two-role rollout leaves them out)
-      if constexpr (kMs && Cons::M > 0) {
-        if (na <= 0 || ms_lane_rollout_requested()) return;
+    if (solver == CDDP_HIP_SOLVER_MSIPDDP) {   // slack / dual / costate / constraint rows of the trial the selection rule will take (the two-role rollout leaves them out)
+      if constexpr (kMs) {
+        if (na <= 0 || ms_lane_rollout_requested() || !d.ladder_sorted) return;
         if (!force && first_only == 2) hipLaunchKernelGGL((k_pick_candidate<0>), dim3((d.B + 63) / 64), dim3(64), 0, s, d, a0, na, phase_req, force);
-        hipLaunchKernelGGL((k_duals_msipddp<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, a0, na, phase_req, force, first_only);
+        hipLaunchKernelGGL((k_rows_msipddp<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, a0, na, phase_req, force, first_only);
       }
       return;
     }

@@ -808,10 +808,13 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
             return self._solve_plugins(name, api.SOLVER_LOGDDP, x0s)
         # MSIPDDP: same split (round 4, csrc/kernels_msipddp.hpp): solve_batch() of a built-in plant with nx <= 8, no terminal set and --
         # with path constraints -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines) is one device-resident batch
-        ms_eligible = (name == "MSIPDDP" and self._sys is not None and not self._needs_host_plugins() and self._sys.state_dim <= 8 and not self._terms
+        # (round 5: the library accepts nx <= 13 -- the unconstrained quadrotor -- on one-lane, scratch-backed sweeps: "auto" keeps such a problem on
+        #  the plug-in route, msipddp_route = "resident" asks for the device)
+        ms_nx_cap = 13 if self.msipddp_route == "resident" else 8
+        ms_eligible = (name == "MSIPDDP" and self._sys is not None and not self._needs_host_plugins() and self._sys.state_dim <= ms_nx_cap and not self._terms
                        and (not self._cons or self._sys.control_dim == 1 or self._sys.state_dim == self._sys.control_dim))
         if name == "MSIPDDP" and self.msipddp_route == "resident" and not ms_eligible:
-            raise NotImplementedError("the resident MSIPDDP kernels serve built-in plants with nx <= 8, built-in objective / constraints, no terminal set, and nu = 1 or nx = nu once a path constraint is present")
+            raise NotImplementedError("the resident MSIPDDP kernels serve built-in plants with nx <= 13, built-in objective / constraints, no terminal set, and nu = 1 or nx = nu once a path constraint is present")
         resident_msipddp = ms_eligible and self.msipddp_route != "plugin"
         if name == "MSIPDDP" and not resident_msipddp:   # path constraints only for nu = 1 or nx = nu (msipddp_solver.cpp:1398, the library says so)
             return self._solve_plugins(name, api.SOLVER_MSIPDDP, x0s)

@@ -401,7 +401,7 @@ def test_groups_and_chunks_do_not_change_results(api, case, monkeypatch):
 @pytest.mark.parametrize("case", ["pendulum_box", "pendulum_box-hybrid-ms", "pendulum_box-linear-ms", "pendulum_free-ms", "cartpole_box-hybrid",
                                   "cartpole_box-parallel", "cartpole_box-ms-seg3", "cartpole_box-monotonic", "unicycle_free-it1", "pendulum_free-seg1"])
 def test_two_role_rollout_agrees_bitwise(api, case, monkeypatch):
-    """Round 5: the producer / consumer rollout (k_forward_msipddp_pc) with the wide dual-row kernel (k_duals_msipddp) against the
+    """Round 5: the producer / consumer rollout (k_forward_msipddp_pc) with the wide dual-row kernel (k_rows_msipddp) against the
     one-wave rollout it replaces (CDDP_HIP_MS_ROLLOUT=lane): every result word, the trajectories, the slack / dual rows of the final
     iterate and the trial records of a step-level forward pass are the same bits, under both ladder shapes."""
     p, ms_start = make(api, case)
