@@ -980,7 +980,7 @@ struct SolveRun {
     // per iteration; the first-success rule is then applied to the recorded trials, so results are unchanged.
     // (the two-role rollout of the path-constrained layouts runs two wavefronts per tile and alpha; with several tile
     // groups in flight the chip is shared: the group's wavefront count is scaled by the number of groups)
-    waves_all = (long)conc * (long)((d.B + 63) / 64) * na * (((P.solver == CDDP_HIP_SOLVER_IPDDP && (ks->cst_size > 0 || (d.te_cst && P.m > 0))) || P.solver == CDDP_HIP_SOLVER_MSIPDDP || P.solver == CDDP_HIP_SOLVER_LOGDDP) ? 2 : 1);
+    waves_all = (long)conc * (long)((d.B + 63) / 64) * na * (((P.solver == CDDP_HIP_SOLVER_IPDDP && (ks->cst_size > 0 || (d.te_cst && P.m > 0))) || P.solver == CDDP_HIP_SOLVER_MSIPDDP || P.solver == CDDP_HIP_SOLVER_LOGDDP) ? 2 : 1);   // (layouts with two consumer waves, KernelSet::k4_waves = 3, keep the count the ladder rules were tuned with: their third wave is light)
     // CDDP_HIP_LS_STAGES=2 forces the two-stage ladder (alpha_0 first, the rest only for trajectories that need it)
     // regardless of the fill heuristic -- same selected trials; used by the tests to cover both launch shapes.
     const char *ls_env = std::getenv("CDDP_HIP_LS_STAGES");

@@ -651,33 +651,51 @@ __device__ unsigned long long g_k4_times[16384 * 4];
 #define K4_TIME_BEGIN
 #define K4_TIME_END(role, steps)
 #endif
-template <class Model, class Cons, bool TERM = false>
-__global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
-                                                          int a0, int phase_req, int force) {
+// NC = 2 (round 5): TWO consumer waves per (tile, alpha), consumer c taking the steps t = c (mod 2).  For layouts whose consumer, not the
+// dynamics chain, sets the pace (unicycle with its box + ball rows: the Euler producer idles 60 % of the launch, profiles/r05_rollout_roles.md)
+// the per-step row work is independent from step to step; what is ORDERED across steps is kept ordered: the running cost is summed by the
+// producer (it has x_t, u_t and the slack), the first constraint object's |g + s| terms are parked per step like the other objects' and summed
+// in t order after the rollout by consumer 0, which also merges the two waves' maxima / minima / first failing step (order-free) and applies
+// the filter test.  A consumer whose 64 trials have all failed posts the step at which it saw that (s_abort); the other finishes its own steps
+// below that step (an earlier failure it alone can see decides the step count of the trial) and stops.  Bitwise the one-consumer kernel
+// (tests/test_gpu_parity.py::test_two_consumer_rollout_agrees_bitwise); NC = 1 is unchanged code.
+template <class Model, class Cons, bool TERM = false, int NC = 1>
+__global__ __launch_bounds__(64 * (1 + NC)) void k_forward_ipddp_pc(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                                    int a0, int phase_req, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
   static_assert(M > 0, "two-role rollout is for path-constrained problems");
   constexpr int RW = 2 * NX + NU;          // doubles per lane per step: x_t, dx_t, u_t
   constexpr int kRing = RW <= 10 ? 8 : (RW <= 20 ? 4 : 2);   // steps in flight between the two waves (<= 40 KB of LDS)
   __shared__ double s_ring[kRing * RW * 64];
+  static_assert(NC == 1 || NC == 2, "one or two consumer waves");
   __shared__ int s_prod;          // steps published by the producer
-  __shared__ int s_cons;          // steps retired by the consumer
+  __shared__ int s_consv[2];      // steps retired by consumer c (its own steps: c, c + NC, ...), + 1
+  [[maybe_unused]] __shared__ int s_abort;      // NC = 2: the step at which a consumer saw all 64 trials failed (INT_MAX: none)
+  [[maybe_unused]] __shared__ int s_done1;      // NC = 2: consumer 1 has published its partial results
+  constexpr int kL2 = NC > 1 ? 64 : 1;   // (no LDS for these in the one-consumer kernel: the nx >= 12 rings sit at an occupancy edge)
+  [[maybe_unused]] __shared__ int s_pfail[kL2], s_palive[kL2];   // NC = 2: consumer 1's first failing step / alive flag per lane
+  [[maybe_unused]] __shared__ double s_pmax[4 * kL2];            // NC = 2: consumer 1's ev_max, ev_icomp, ys_lo, ys_hi per lane
+  [[maybe_unused]] __shared__ double s_prun[kL2];                // NC = 2: the producer lane's running cost
   __shared__ int s_pstat[64];     // first step at which the producer lane went non-finite (N + 2 = never)
   __shared__ double s_pcost[64];  // the producer lane's terminal cost l_f(x_N)
   __shared__ double s_xN[TERM ? NX * 64 : 1];   // the producer lane's x_N (terminal residual of the trial)
   __shared__ double s_obj[Obj::kStage];         // Q dt | R dt | x_ref of a large plant (Objective::stage)
   const int lane = threadIdx.x & 63;
   K4_TIME_BEGIN
-  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+  const bool producer = wave == 0;
+  [[maybe_unused]] const int ci = NC > 1 ? wave - 1 : 0;   // consumer index (NC = 2)
+  int *const s_cons = &s_consv[0];
   const int b = blockIdx.x * 64 + lane;
   const int a = a0 + blockIdx.y;
   const ProblemDev *__restrict__ P = Pk;
   const cddp_hip_options &o = P->opt;
   const int N = d.N;
   const bool active = (b < d.B) && (force || d.phase[b] == phase_req);
-  if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in both waves: both leave
-  if (producer) { s_pstat[lane] = N + 2; if (lane == 0) { s_prod = 0; s_cons = 0; } }
-  Obj::stage(P, s_obj, (int)threadIdx.x, 128);
+  if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;   // same mask in every wave: all leave
+  if (producer) { s_pstat[lane] = N + 2; if (lane == 0) { s_prod = 0; s_consv[0] = 0; s_consv[1] = 0; if constexpr (NC > 1) { s_abort = 0x7fffffff; s_done1 = 0; } } }
+  Obj::stage(P, s_obj, (int)threadIdx.x, 64 * (1 + NC));
   __syncthreads();
   // Inactive lanes (padding, or a trajectory in another phase) run along on their OWN rows: their trial slots are
   // scratch (trial_slot never returns the current slot), so unconditional stores need no exec-mask branches.
@@ -713,6 +731,9 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     };
     DynCtx dc;   // loop-invariant constants in scalar registers
     dc.load(P->integrator, P->dt, P->mp);
+    [[maybe_unused]] typename Obj::Ctx oc_p;   // NC = 2: the producer sums the running cost
+    [[maybe_unused]] double run_cost_p = 0.0;
+    if constexpr (NC > 1) Obj::load_staged(P, oc_p, s_obj);
     // Prime the VMEM queue with the store pattern of one step (rows of step 0, rewritten by iteration 0): the
     // waitcnt pass joins the loop-entry state with the back-edge state, and an entry state whose newest
     // operations are the loads would make every iteration wait for vmcnt(0), i.e. for its own last stores.
@@ -792,7 +813,10 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       // kRing/2 steps for the next kRing/2 slots (an LDS round trip on the chain otherwise).
       // (round 5: a consumer that has given the whole tile up -- every trial failed its fraction-to-boundary test -- also STOPS the
       //  producer here: nobody reads the rows of those trials, and the wave otherwise kept its SIMD busy to the end of the horizon)
-      if (t >= kRing && (t % (kRing / 2)) == 0) { if (wait_ge(&s_cons, t - kRing / 2) >= kAbort) alive = false; }   // kRing / 2 >= 1
+      if (t >= kRing && (t % (kRing / 2)) == 0) {   // kRing / 2 >= 1
+        if (wait_ge(s_cons, t - kRing / 2) >= kAbort) alive = false;
+        if constexpr (NC > 1) { if (wait_ge(&s_consv[1], t - kRing / 2) >= kAbort) alive = false; }
+      }
       {
         double *rs = s_ring + (size_t)(t % kRing) * RW * 64 + lane;
 #pragma unroll
@@ -803,6 +827,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         RING_FENCE();
         __hip_atomic_store(&s_prod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      if constexpr (NC > 1) run_cost_p += Obj::running_cost(oc_p, xrt, t, x, u);   // t-ordered sum (the consumers take every other step)
       if constexpr (kEarly) {   // next step's record into the (now dead) register set, behind the integrator
         load_step(t + 1 < N ? t + 1 : t, cs);
         PIPELINE_FENCE();
@@ -847,6 +872,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
       }
     }
     if (alive) s_pcost[lane] = Obj::terminal_cost(P, x);
+    if constexpr (NC > 1) s_prun[lane] = run_cost_p;
     if constexpr (TERM) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) s_xN[i * 64 + lane] = x[i];
@@ -870,7 +896,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   bool alive = active;
   int seen_prod = 0;     // last value of the producer's counter this wave saw (wave-uniform)
   int fail_t = N;        // steps completed before the trial was abandoned (kept in a register, stored at the exits)
-  if (alive) {
+  if (alive && ci == 0) {
     atomicAdd(d.launched, 1ull);
     d.t_apr[ti] = a_pr; d.t_adu[ti] = a_du;
     d.t_success[ti] = 0;
@@ -895,16 +921,17 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   Cons::load(P, cc);
   typename Obj::Ctx oc;    // running-cost matrices (scalar registers for small plants, LDS for large ones)
   Obj::load_staged(P, oc, s_obj);
-  auto prime = [&]() {   // prime the VMEM queue with one step's store pattern (see the producer)
+  auto prime = [&]() {   // prime the VMEM queue with one step's store pattern (see the producer): the rows of this wave's FIRST step
     double z[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) z[i] = 0.0;
-    st<M>(Sn + GI(0, M, 0), kLS, z);
-    st<M>(Yn + GI(0, M, 0), kLS, z);
-    st<M>(Gn + GI(0, M, 0), kLS, z);
-    double *ev = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
+    const int tp = (NC > 1 && ci < N) ? ci : 0;
+    st<M>(Sn + GI(tp, M, 0), kLS, z);
+    st<M>(Yn + GI(tp, M, 0), kLS, z);
+    st<M>(Gn + GI(tp, M, 0), kLS, z);
+    double *ev = d.ev + GI((size_t)a * N + tp, 2 * Cons::NSEG, 0);
 #pragma unroll
-    for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
+    for (int c = 0; c < Cons::NSEG; ++c) { if (c > 0 || NC > 1) ev[(size_t)(Cons::NSEG + c) * kLS] = 0.0; ev[(size_t)c * kLS] = 0.0; }
   };
   constexpr bool kPing = sizeof(StepIn) <= 40 * sizeof(double);   // see the producer
   constexpr bool kEarly = !kPing && sizeof(StepIn) <= 96 * sizeof(double);
@@ -927,7 +954,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   Chunk ck0, ck1;
   auto step = [&](const int t, StepIn &cs, StepIn &nxt) {
     if constexpr (kPing) {
-      const int tn = t + kDepthC < N ? t + kDepthC : N - 1;   // unconditional (clamped) prefetch
+      const int tn = t + NC * kDepthC < N ? t + NC * kDepthC : N - 1;   // unconditional (clamped) prefetch: this consumer's next step
       load_step(tn, nxt);
     } else if constexpr (!kEarly && !kChunk) load_step(t, cs);
     PIPELINE_FENCE();
@@ -941,7 +968,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = rs[(2 * NX + i) * 64];
       RING_FENCE();
-      __hip_atomic_store(&s_cons, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&s_consv[ci], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (alive && s_pstat[lane] <= t) { alive = false; fail_t = t; }
     double sn[M], yn[M];
@@ -1032,7 +1059,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     }
     double g[M];
     Cons::template eval<NX, NU>(cc, rx, u, g);
-    run_cost += Obj::running_cost(oc, xrt, t, rx, u);   // same t-ordered sum the fused rollout keeps (:1726-1748)
+    if constexpr (NC == 1) run_cost += Obj::running_cost(oc, xrt, t, rx, u);   // same t-ordered sum the fused rollout keeps (:1726-1748); NC = 2: the producer's
     st<M>(Gn + GI(t, M, 0), kLS, g);
     // Per-step terms of computeTheta / computeBarrierMerit / computePrimalAndComplementarity, parked exactly as
     // in k_forward_ipddp: the first constraint object's |g+s| terms accumulate in t order right here, the other
@@ -1052,12 +1079,52 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
         ls += solver_log(dmax(sn[off + i], kEpsSlack));
       }
       ev_max = dmax(ev_max, ninf);
-      if (c == 0) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;
+      if (c == 0 && NC == 1) ev_total0 += n1; else ev[(size_t)(Cons::NSEG + c) * kLS] = n1;   // (NC = 2: the first object's terms are parked too)
       ev[(size_t)c * kLS] = ls;
     }
   };
   StepIn ra;
-  if constexpr (kPing) {
+  if constexpr (NC > 1) {
+    static_assert(NC == 1 || (kPing && kDepthC == 1), "two consumers: ping-pong records with one step of look-ahead only");
+    // consumer ci walks t = ci, ci + NC, ...; two register sets, the record of its NEXT step in flight while the current one is reduced
+    StepIn R0, R1;
+    load_step(ci < N ? ci : N - 1, R0);
+    prime();
+    auto stop_at = [&](int tt) { return tt > __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    int t = ci, last = -1;
+    bool stopped = false;
+    for (; t + NC < N; t += 2 * NC) {
+      if (stop_at(t)) { stopped = true; break; }
+      step(t, R0, R1); last = t;
+      if (stop_at(t + NC)) { stopped = true; break; }
+      step(t + NC, R1, R0); last = t + NC;
+      if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed in this wave's steps: post the step, stop the producer
+        __hip_atomic_fetch_min(&s_abort, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        stopped = true; break;
+      }
+    }
+    if (!stopped && t < N && !stop_at(t)) step(t, R0, R1);
+    const bool aborted = __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0x7fffffff;
+    if (aborted) __hip_atomic_store(&s_consv[ci], kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases and stops the producer
+    if (ci == 1) {   // hand the partial results to consumer 0 (its parked rows first: workgroup-scope release)
+      s_pfail[lane] = fail_t; s_palive[lane] = alive ? 1 : 0;
+      s_pmax[lane] = ev_max; s_pmax[64 + lane] = ev_icomp; s_pmax[128 + lane] = ys_lo; s_pmax[192 + lane] = ys_hi;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_store(&s_done1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return;
+    }
+    wait_ge(&s_done1, 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    fail_t = s_pfail[lane] < fail_t ? s_pfail[lane] : fail_t;
+    alive = alive && (s_palive[lane] != 0);
+    ev_max = dmax(ev_max, s_pmax[lane]); ev_icomp = dmax(ev_icomp, s_pmax[64 + lane]);
+    ys_lo = dmin(ys_lo, s_pmax[128 + lane]); ys_hi = dmax(ys_hi, s_pmax[192 + lane]);
+    if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0x7fffffff) {   // (either wave may have posted it meanwhile)
+      __hip_atomic_store(&s_consv[0], kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (active) d.t_steps[ti] = fail_t;
+      return;
+    }
+  } else if constexpr (kPing) {
     StepIn R[kDepthC + 1];   // see the producer
 #pragma unroll
     for (int j = 0; j < kDepthC; ++j) load_step(j < N ? j : N - 1, R[j]);
@@ -1067,7 +1134,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
 #pragma unroll
       for (int j = 0; j <= kDepthC; ++j) step(t + j, R[j], R[(j + kDepthC) % (kDepthC + 1)]);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {   // every trial of the tile has failed: release the producer
-        __hip_atomic_store(&s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (active) d.t_steps[ti] = fail_t;
         K4_TIME_END(1, t);
         return;
@@ -1081,7 +1148,7 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
     for (int t = 0; t < N; ++t) {
       step(t, ra, ra);
       if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
-        __hip_atomic_store(&s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(s_cons, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (active) d.t_steps[ti] = fail_t;
         return;
       }
@@ -1092,10 +1159,20 @@ __global__ __launch_bounds__(128) void k_forward_ipddp_pc(DevBuf d, const Proble
   if (active) d.t_steps[ti] = fail_t;
   if (alive && s_pstat[lane] <= N) alive = false;
   if (!alive) return;
+  if constexpr (NC > 1) run_cost = s_prun[lane];
   const double cost_new = run_cost + s_pcost[lane];   // + l_f(x_N)
-  double total = ev_total0, mer = cost_new;
   const double *evb = d.ev + GI((size_t)a * N, 2 * Cons::NSEG, 0);
   const size_t tstride = (size_t)d.NB * (2 * Cons::NSEG) * kLS;
+  if constexpr (NC > 1) {   // the first object's parked |g + s| terms, in t order (what the one-consumer kernel accumulates on the fly)
+    const double *q = evb + (size_t)Cons::NSEG * kLS;
+    int t = 0;
+    for (; t + 3 < N; t += 4) {
+      const double v0 = q[(size_t)t * tstride], v1 = q[(size_t)(t + 1) * tstride], v2 = q[(size_t)(t + 2) * tstride], v3 = q[(size_t)(t + 3) * tstride];
+      ev_total0 += v0; ev_total0 += v1; ev_total0 += v2; ev_total0 += v3;
+    }
+    for (; t < N; ++t) ev_total0 += q[(size_t)t * tstride];
+  }
+  double total = ev_total0, mer = cost_new;
   for (int c = 1; c < Cons::NSEG; ++c) {
     const double *q = evb + (size_t)(Cons::NSEG + c) * kLS;
     int t = 0;

@@ -48,8 +48,18 @@ struct KernelSet {
   bool has_msipddp;  // the MSIPDDP kernels (kernels_msipddp.hpp) are instantiated for this layout: nx <= 8, no terminal set, and -- with path
                      // constraints -- nu = 1 or nx = nu (the shapes msipddp_solver.cpp:1398 defines)
   bool has_logddp;   // the LogDDP kernels (kernels_logddp.hpp) are instantiated for this layout: one lane per trajectory, nx <= 8, no terminal set
+  int k4_waves;      // wavefronts per (tile, alpha) of the IPDDP rollout launch: 2 (producer + consumer), 3 where two consumers run (PcTwoConsumers), 1 for the one-wave kernels
   int ms_cst_size;   // MSIPDDP, path-constrained: per-step doubles of the condensed-term stack of the split sweep (kernels_msipddp.hpp::MsCst), 0 = none
   int (*t4_layout)(const DevBuf &);   // 1 when derivs() / backward() of this handle use the sub-tile-minor stacks (kernels.hpp::GT) under the current environment
+};
+
+// Layouts whose two-role rollout runs TWO consumer waves (k_forward_ipddp_pc<.., NC = 2>): the consumer, not the dynamics chain, sets the
+// pace there (profiles/r05_rollout_roles.md: unicycle with box + ball rows, Euler producer idle 60 % of the launch).  Opt-in (k4_consumers).
+template <class Model, class Cons> struct PcTwoConsumers { static constexpr bool value = false; };
+template <class Cons> struct PcTwoConsumers<UnicycleModel, Cons> {
+  // (the consumer's per-step record must be the ping-pong kind with one step of look-ahead: 16 < doubles <= 40, kernels_lean.hpp::StepIn)
+  static constexpr int kRec = 5 * Cons::M + UnicycleModel::NU * UnicycleModel::NX + (Cons::HAS_X ? UnicycleModel::NX : 1) + (Cons::NEEDS_U ? UnicycleModel::NU : 1);
+  static constexpr bool value = Cons::M >= 4 && kRec > 16 && kRec <= 40;
 };
 
 template <class Model, class Cons, bool TERM = false>
@@ -122,6 +132,15 @@ struct Launcher {
   // the other, 30.1 / 28.7 with their per-step work in one straight-line block; pendulum 3.4 -> 5.8 / 6.0; C3 33 -> 55 / 80.  The
   // consumer's per-trial work (~500 instructions per step: two logarithms, the slack / dual trials, cost, residual terms) is as long
   // as the producer's RK4 step (~650), so one consumer behind two or three producers is the chain the launch waits for.  Opt-in.
+  // Consumer waves of the two-role rollout where both forms are instantiated (PcTwoConsumers).  Default ONE: the two-consumer kernel is
+  // bitwise equal (tests/test_gpu_parity.py::test_two_consumer_rollout_agrees_bitwise) and 18 % faster as a kernel on the whole chip
+  // (C3 ladder of 4 / 11 step sizes: 446 -> 386 / 1499 -> 1215 us), but inside the solve its third wavefront per (tile, step size) breaks the
+  // one-wavefront-per-SIMD fit of the adaptive ladder on a group's half of the chip (64 tiles x 4 step sizes x 3 = 768 on 512 SIMDs): C3
+  // 78.8 -> 79.7 ms per solve (profiles/r05_rollout_roles.md).  CDDP_HIP_K4_CONSUMERS=2 opts in.
+  static int k4_consumers() {
+    if (const char *e = std::getenv("CDDP_HIP_K4_CONSUMERS")) { if (e[0] == '2') return 2; }
+    return 1;
+  }
   static int k4_group() {
     if (const char *e = std::getenv("CDDP_HIP_K4_NA")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) return v; }
     return 1;
@@ -289,7 +308,10 @@ struct Launcher {
           if (ng == 3) { hipLaunchKernelGGL((k_forward_ipddp_pcm<Model, Cons, 3>), dim3((d.B + 63) / 64, (na + 2) / 3), dim3(256), 0, s, d, d.P, d.xref_traj, a0, na, phase_req, force); return; }
           if (ng == 2) { hipLaunchKernelGGL((k_forward_ipddp_pcm<Model, Cons, 2>), dim3((d.B + 63) / 64, (na + 1) / 2), dim3(192), 0, s, d, d.P, d.xref_traj, a0, na, phase_req, force); return; }
         }
-        // producer / consumer wave pair per (tile, alpha)
+        // producer / consumer wave pair per (tile, alpha); CDDP_HIP_K4_CONSUMERS=2: two consumers where instantiated (opt-in, k4_consumers)
+        if constexpr (PcTwoConsumers<Model, Cons>::value) {
+          if (k4_consumers() == 2) { hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons, false, 2>), grid, dim3(192), 0, s, d, d.P, d.xref_traj, a0, phase_req, force); return; }
+        }
         hipLaunchKernelGGL((k_forward_ipddp_pc<Model, Cons>), grid, dim3(128), 0, s, d, d.P, d.xref_traj, a0, phase_req, force);
       } else {
         if constexpr (kTeCoop && Cons::M > 0) {   // same rollout after the cooperative terminal-equality sweep
@@ -354,7 +376,7 @@ struct Launcher {
     KernelSet k;
     k.model = Model::ID; k.nx = Model::NX; k.nu = Model::NU; k.m = Cons::M; k.name = name; k.cst_size = cst_size(); k.te_rec_size = te_rec_size(); k.te_group = CoopCfg<Model>::G;
     k.matches = &matches; k.derivs = &derivs; k.backward = &backward; k.forward = &forward;
-    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess; k.has_msipddp = kMs; k.ms_cst_size = ms_cst_size();
+    k.costate = &costate; k.update = &update; k.init = &init; k.stage = &stage; k.t4_layout = &t4_layout; k.has_logddp = kLog; k.logddp_ddp = Model::kHasHess; k.has_msipddp = kMs; k.ms_cst_size = ms_cst_size(); k.k4_waves = (kLean && PcTwoConsumers<Model, Cons>::value) ? 3 : 2;
     return k;
   }
 };

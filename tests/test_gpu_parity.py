@@ -334,6 +334,37 @@ def test_multi_alpha_rollout_groups_agree_bitwise(api, case, monkeypatch):
             assert np.array_equal(a, b), (case, na, stages)
 
 
+@pytest.mark.parametrize("case", ["unicycle_ipddp_box_ball", "unicycle_ipddp_box"])
+def test_two_consumer_rollout_agrees_bitwise(api, case, monkeypatch):
+    """Round 5 (opt-in, CDDP_HIP_K4_CONSUMERS=2; measured no gain inside the solve): TWO consumer waves per (tile, step size) for the unicycle
+    layouts (k_forward_ipddp_pc<.., NC = 2>: consumer c takes the steps
+    t = c mod 2, the producer sums the running cost, the first object's |g + s| terms are parked and summed in t order afterwards, the
+    waves' maxima / first failing steps are merged).  Against the default one-consumer kernel: every result word,
+    iterate, gain, dual row and the work counters (incl. the credited rollout steps, i.e. each trial's first failing step) are the same
+    bits -- under both ladder shapes, for a batch with a ragged last tile, and for the trial records of a step-level forward pass."""
+    p = make(api, case)
+    B = 150
+    x0 = api.batch_x0(p, B, 20270305, spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); st = hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); S, Y, G = hs.duals(); hs.close()
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.initialize(); hs.backward()
+        tr = hs.forward(api.Oracle(p).alphas()); hs.close()
+        return [r[f].copy() for f in r.dtype.names] + [X, U, K, k, S, Y, G, np.array([st.sweeps, st.rollouts, st.rollout_steps])] + [tr[f].copy() for f in tr.dtype.names]
+
+    monkeypatch.delenv("CDDP_HIP_K4_CONSUMERS", raising=False)
+    monkeypatch.delenv("CDDP_HIP_LS_STAGES", raising=False)
+    ref = run()
+    for stages in (None, "1", "2"):
+        monkeypatch.setenv("CDDP_HIP_K4_CONSUMERS", "2")
+        if stages: monkeypatch.setenv("CDDP_HIP_LS_STAGES", stages)
+        got = run()
+        for i, (a_, b_) in enumerate(zip(ref, got)):
+            assert np.array_equal(a_, b_, equal_nan=(a_.dtype.kind == "f")), (case, stages, i)
+
+
 @pytest.mark.parametrize("case", ["cartpole_ipddp_box", "unicycle_ipddp_box_ball", "cartpole_clddp_box"])
 def test_two_stage_ladder_selects_the_same_trials(api, case, monkeypatch):
     """The speculative single-launch ladder and the two-stage ladder (alpha_0, then the rest for the trajectories
