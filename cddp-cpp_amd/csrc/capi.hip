@@ -1306,6 +1306,19 @@ static int in_get_duals(Inner *h, double *S, double *Y, double *G) {
   return 0;
 }
 
+// Costate trajectory of the current iterate (Lambda_ of ipddp_solver.hpp / msipddp_solver.hpp): IPDDP N + 1 rows (k_costate / k_costate_one write
+// the accepted trial's), MSIPDDP N rows (k_rows_msipddp)
+static int costate_rows(const Inner *h) { return h->P.solver == CDDP_HIP_SOLVER_IPDDP ? h->d.N + 1 : h->d.N; }
+static int in_get_costates(Inner *h, double *Lambda, int32_t *rows) {
+  if (!h) return fail(-1, "null handle");
+  if (h->P.solver != CDDP_HIP_SOLVER_IPDDP && h->P.solver != CDDP_HIP_SOLVER_MSIPDDP) return fail(-1, "no costate trajectory for this solver (IPDDP and MSIPDDP carry one)");
+  if (rows) *rows = costate_rows(h);
+  if (!Lambda) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return fetch_current(h, h->d.Lam, h->d.planeX, costate_rows(h), h->P.nx, Lambda);
+}
+
 static int in_get_terminal(Inner *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
   if (!h) return fail(-1, "null handle");
   HIPCHK(hipSetDevice(h->device));
@@ -1565,6 +1578,11 @@ int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx) { FOR_GROUPS
 int cddp_hip_get_linearization(cddp_hip_handle *h, double *A, double *Bm) { FOR_GROUPS(in_get_linearization(q, OFF(A, h->N * h->nx * h->nx), OFF(Bm, h->N * h->nx * h->nu))); }
 int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G) {
   FOR_GROUPS(in_get_duals(q, OFF(S, h->N * h->m), OFF(Y, h->N * h->m), OFF(G, h->N * h->m)));
+}
+int cddp_hip_get_costates(cddp_hip_handle *h, double *Lambda, int32_t *rows) {
+  if (!h) return fail(-1, "null handle");
+  const int r = (h->g.empty() || !h->g[0]) ? 0 : costate_rows(h->g[0]);
+  FOR_GROUPS(in_get_costates(q, OFF(Lambda, r * h->nx), rows));
 }
 int cddp_hip_get_terminal(cddp_hip_handle *h, double *S_T, double *Y_T, double *G_T, double *Lambda_T, int32_t *dims) {
   FOR_GROUPS(in_get_terminal(q, OFF(S_T, h->mT), OFF(Y_T, h->mT), OFF(G_T, h->mT), OFF(Lambda_T, h->pT), dims));

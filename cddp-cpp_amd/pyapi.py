@@ -590,7 +590,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_status_string", "cddp_hip_build_alphas", "cddp_hip_create", "cddp_hip_destroy",
     "cddp_hip_set_stream", "cddp_hip_set_initial", "cddp_hip_initialize", "cddp_hip_backward",
     "cddp_hip_forward", "cddp_hip_solve", "cddp_hip_get_results", "cddp_hip_get_trajectory",
-    "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_backward_scalars",
+    "cddp_hip_get_gains", "cddp_hip_get_value", "cddp_hip_get_linearization", "cddp_hip_get_duals", "cddp_hip_get_costates", "cddp_hip_get_backward_scalars",
     "cddp_hip_get_history", "cddp_hip_get_terminal", "cddp_hip_write_gather_records_device", "cddp_hip_dual_dim", "cddp_hip_batch",
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_concurrency", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create_abi", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
@@ -728,6 +728,14 @@ class HipBatchSolver:
         if self.m:
             self._check(self.lib.cddp_hip_get_duals(self.h, _ptr(S), _ptr(Y), _ptr(G)))
         return S, Y, G
+
+    def costates(self):
+        """Costate trajectory Lambda of the current iterate, (B, rows, nx): rows = N + 1 (IPDDP) or N (MSIPDDP) (cddp_hip_get_costates)."""
+        rows = C.c_int32(0)
+        self._check(self.lib.cddp_hip_get_costates(self.h, None, C.byref(rows)))
+        L = np.zeros((self.B, rows.value, self.p.nx))
+        self._check(self.lib.cddp_hip_get_costates(self.h, _ptr(L), C.byref(rows)))
+        return L
 
     def terminal(self):
         dims = np.zeros(2, dtype=np.int32)

@@ -428,6 +428,10 @@ int cddp_hip_get_value(cddp_hip_handle *h, double *Vx, double *Vxx);
 int cddp_hip_get_linearization(cddp_hip_handle *h, double *A /* B*N*nx*nx */, double *Bm /* B*N*nx*nu */);
 /* Slack / dual / constraint residual trajectories, B*N*m each (m = total path dual dim). */
 int cddp_hip_get_duals(cddp_hip_handle *h, double *S, double *Y, double *G);
+/* Costate trajectory of the current iterate: Lambda_[t] = Lambda_[t] + alpha_pr k_lambda[t] + K_lambda[t] dx_t of the accepted forward pass
+ * (ipddp_solver.cpp:1613-1616, 1660-1663: N + 1 rows; msipddp_solver.cpp:1466-1467, 1639-1641: N rows).  *rows receives the row count,
+ * Lambda (B * rows * nx, may be NULL to query the count) the rows.  IPDDP and MSIPDDP handles only (added in round 5; ABI version unchanged). */
+int cddp_hip_get_costates(cddp_hip_handle *h, double *Lambda, int32_t *rows);
 /* Terminal-constraint state (IPDDP): stacked terminal-inequality slack / dual / residual
  * S_T, Y_T, G_T (B*mT each) and terminal-equality multipliers Lambda_T (B*pT); any may be NULL.
  * dims[0] = mT, dims[1] = pT (S_T_, Y_T_, G_T_, Lambda_T_eq_ of ipddp_solver.hpp). */

@@ -2234,6 +2234,15 @@ int cddp_oracle_get_duals(void *o, double *S, double *Y, double *G) {
   }
   return 0;
 }
+// costate trajectory of the current iterate (IPDDP: N + 1 rows, MSIPDDP: N rows); returns the row count, Lam may be null
+int cddp_oracle_get_costates(void *o, double *Lam) {
+  Solver *s = (Solver *)o;
+  const int rows = (int)s->Lambda.size();
+  if (Lam)
+    for (int t = 0; t < rows; ++t)
+      for (int i = 0; i < s->nx; ++i) Lam[(size_t)t * s->nx + i] = (s->Lambda[t].size() == s->nx) ? s->Lambda[t](i) : 0.0;
+  return rows;
+}
 // stacked terminal state in std::map order: inequality (S_T, Y_T, G_T) and equality multipliers
 int cddp_oracle_get_terminal(void *o, double *ST, double *YT, double *GT, double *LamT, int *dims) {
   Solver *s = (Solver *)o; int mT = 0;

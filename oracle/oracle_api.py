@@ -128,6 +128,14 @@ class Oracle:
             self.lib.cddp_oracle_get_duals(self.h, _api()._ptr(S), _api()._ptr(Y), _api()._ptr(G))
         return S, Y, G
 
+    def costates(self):
+        """Costate trajectory Lambda of the current iterate (rows, nx): N + 1 rows under IPDDP, N under MSIPDDP."""
+        rows = self.lib.cddp_oracle_get_costates(self.h, None)
+        L = np.zeros((rows, self.p.nx))
+        if rows:
+            self.lib.cddp_oracle_get_costates(self.h, _api()._ptr(L))
+        return L
+
     def terminal(self):
         dims = np.zeros(2, dtype=np.int32)
         self.lib.cddp_oracle_get_terminal(self.h, None, None, None, None, dims.ctypes.data_as(C.POINTER(C.c_int32)))

@@ -305,6 +305,10 @@ def test_full_solve_parity(api, oracle_built, case):
     assert hist[0].shape == oh.shape, (hist[0].shape, oh.shape)
     assert rel_err(hist[0], oh) < 1e-6
     assert st.n_converged == int(np.sum((ores["status"] == 1) | (ores["status"] == 2)))
+    if p.c.solver == api.SOLVER_IPDDP:   # the costate rows K4b writes for the accepted trial (cddp_hip_get_costates, round 5): N + 1 rows
+        L = hs.costates(); oL = o.costates()
+        assert L.shape == (B,) + oL.shape and oL.shape == (p.N + 1, p.nx), (L.shape, oL.shape)
+        assert rel_err(L[0], oL) < 1e-6, (case, rel_err(L[0], oL))
     hs.close()
 
 

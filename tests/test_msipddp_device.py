@@ -194,6 +194,10 @@ def test_full_solve_parity(api, oracle_built, case):
     oh = o.history()
     assert hist[0].shape == oh.shape, (hist[0].shape, oh.shape)
     assert rel_err(hist[0], oh) < 1e-8
+    if fin[0]:   # the costate rows k_rows_msipddp forms for the accepted trial (cddp_hip_get_costates, round 5): N rows
+        L = hs.costates(); oL = o.costates()
+        assert L.shape == (B,) + oL.shape and oL.shape == (p.N, p.nx), (L.shape, oL.shape)
+        assert rel_err(L[0], oL) < TOL, (case, rel_err(L[0], oL))
     if fin.all():
         assert st.n_converged == int(np.sum((ores["status"] == api.STATUS_OPTIMAL) | (ores["status"] == api.STATUS_ACCEPTABLE)))
     if p.dual_dim() > 0:
