@@ -266,7 +266,9 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
             # (nx <= 8: the derivative fill is fused into k_condense<.., true>, launch.hpp::derivs -- there is no k_derivs launch)
             sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big+k_post" if p.nx > 8 else "k_condense+k_backward_ipddp_coop+k_post"
         elif solver == "msipddp":  # resident MSIPDDP (kernels_msipddp.hpp): the split path-constrained sweep (round 5), the fused one-lane kernel otherwise
-            sweep_label = "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post" if m > 0 else "k_derivs+k_backward_msipddp"
+            # (path rows, nx <= 8: the derivative fill rides in k_ms_condense<.., true> -- no k_derivs launch)
+            sweep_label = (("k_ms_condense+k_backward_msipddp_lean+k_ms_post" if p.nx <= 8 else "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post")
+                           if m > 0 else "k_derivs+k_backward_msipddp")
         elif solver == "logddp":   # resident LogDDP: the LogDDP mode of the cooperative sweep up to nx = 8, scored with CLDDP's byte model (the
             sweep_label = "k_derivs+k_backward_coop_plain" if p.nx <= 8 else "k_derivs+k_backward_logddp"   # barrier rows it also reads are not credited)
         else:

@@ -734,7 +734,9 @@ struct MsCst {
                        oSweep = oRes + 2 /* what the sweep reads ends here */, oYS = oSweep, oRhat = oYS + M, oPres = oRhat + M, SIZE = oPres + M;
 };
 
-template <class Model, class Cons>
+// WITH_DERIVS (register-resident plants): the same (batch x N) pass also writes A_t = I + dt f_x, B_t = dt f_u (K1: x, u are read once and the
+// iteration has one launch less, as k_condense<.., true> does for IPDDP); it is then the first kernel of the iteration and resets the counter.
+template <class Model, class Cons, bool WITH_DERIVS = false>
 __global__ __launch_bounds__(64) void k_ms_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M, MM = M > 0 ? M : 1;
   typedef Objective<NX, NU> Obj;
@@ -742,6 +744,7 @@ __global__ __launch_bounds__(64) void k_ms_condense(DevBuf d, const ProblemDev *
   if constexpr (M > 0) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     const int t = blockIdx.y;
+    if constexpr (WITH_DERIVS) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !force) *d.n_active = 0; }
     if (b >= d.B) return;
     if (!force && d.phase[b] != PH_ACTIVE) return;
     const ProblemDev *__restrict__ P = Pk;
@@ -752,6 +755,21 @@ __global__ __launch_bounds__(64) void k_ms_condense(DevBuf d, const ProblemDev *
     double x[NX], u[NU], f[NX], x1[NX], y[MM], sv[MM], g[MM];
     ld<NX>(d.X + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, x);
     ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, u);
+    if constexpr (WITH_DERIVS) {   // identical to k_derivs (plain layout: MSIPDDP handles never use the sub-tile-minor stacks)
+      double Fx[NX * NX], Fu[NX * NU];
+      Model::jac(P->mp, x, u, Fx, Fu);
+      const double dt = P->dt;
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          double a = dt * Fx[i * NX + j];
+          if (i == j) a += 1.0;
+          d.A[GI(t, NX * NX, i * NX + j)] = a;
+        }
+#pragma unroll
+      for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = dt * Fu[i];
+    }
     ld<NX>(d.F + (size_t)cur * d.planeX + GI(t, NX, 0), kLS, f);
     ld<NX>(d.X + (size_t)cur * d.planeX + GI(t + 1, NX, 0), kLS, x1);
     ld<M>(d.Y + (size_t)cur * d.planeM + GI(t, M, 0), kLS, y);

@@ -99,6 +99,9 @@ struct Launcher {
     const char *e = std::getenv("CDDP_HIP_MS_ROLLOUT");
     return e && !std::strcmp(e, "lane");
   }
+  // MSIPDDP: the path-constrained iLQR sweep runs split (condense -> recursion -> post) unless full DDP or CDDP_HIP_SWEEP=lane ask for the fused
+  // one-lane kernel; derivs() and backward() of one iteration see the same answer
+  static bool ms_split_sweep(const DevBuf &d) { return d.ms && d.cst && !d.ddp && !lane_sweep_requested(); }
   static bool lg_lane_rollout_requested() {   // CDDP_HIP_LG_ROLLOUT=lane: the one-wave LogDDP rollout
     const char *e = std::getenv("CDDP_HIP_LG_ROLLOUT");
     return e && !std::strcmp(e, "lane");
@@ -161,6 +164,9 @@ struct Launcher {
         }
       }
     }
+    if constexpr (kMs && Cons::M > 0 && Model::NX <= 8) {   // MSIPDDP, split sweep: the derivative fill rides in k_ms_condense<.., true> (backward())
+      if (ms_split_sweep(d)) return;
+    }
     hipLaunchKernelGGL((k_derivs<Model>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
     if constexpr (kTeCoop)
       if (d.te_cst) hipLaunchKernelGGL((k_te_condense<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
@@ -190,9 +196,10 @@ struct Launcher {
         // path-constrained iLQR sweeps: condense (batch x N) -> value recursion -> post (batch x N) (round 5); the fused one-lane kernel
         // carries the tensor terms of full DDP, the unconstrained branch with its factor cache, and CDDP_HIP_SWEEP=lane (comparison)
         if constexpr (Cons::M > 0) {
-          if (d.cst && !d.ddp && !lane_sweep_requested()) {
+          if (ms_split_sweep(d)) {
             const dim3 gridW((d.B + 63) / 64, d.N);
-            hipLaunchKernelGGL((k_ms_condense<Model, Cons>), gridW, dim3(64), 0, s, d, d.P, d.xref_traj, force);
+            if constexpr (Model::NX <= 8) hipLaunchKernelGGL((k_ms_condense<Model, Cons, true>), gridW, dim3(64), 0, s, d, d.P, d.xref_traj, force);   // + A_t, B_t (derivs() skipped K1)
+            else hipLaunchKernelGGL((k_ms_condense<Model, Cons, false>), gridW, dim3(64), 0, s, d, d.P, d.xref_traj, force);
             hipLaunchKernelGGL((k_backward_msipddp_lean<Model, Cons>), gridB(d), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
             hipLaunchKernelGGL((k_ms_post<Model, Cons>), gridW, dim3(64), 0, s, d, d.P, force);
             return;
