@@ -264,7 +264,7 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
             # (nx <= 8: the derivative fill is fused into k_condense<.., true>, launch.hpp::derivs -- there is no k_derivs launch)
-            sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big+k_post" if p.nx > 8 else "k_condense+k_backward_ipddp_coop+k_post"
+            sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big2+k_post" if p.nx > 8 else "k_condense+k_backward_ipddp_coop+k_post"
         elif solver == "msipddp":  # resident MSIPDDP (kernels_msipddp.hpp): the split path-constrained sweep (round 5), the fused one-lane kernel otherwise
             # (path rows, nx <= 8: the derivative fill rides in k_ms_condense<.., true> -- no k_derivs launch)
             sweep_label = (("k_ms_condense+k_backward_msipddp_lean+k_ms_post" if p.nx <= 8 else "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post")

@@ -19,6 +19,7 @@
 #include "kernels_lean.hpp"
 #include "kernels_logddp.hpp"   // LgCons: the relaxed barrier's gradients / Hessians (the LogDDP mode of the plain cooperative sweep)
 #include <type_traits>
+#include <utility>
 
 namespace cddp_dev {
 
@@ -1386,5 +1387,573 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop_big(DevBuf d, const 
   d.phase[b] = PH_FWD1;
 }
 
+// ================================================================================ cooperative sweep, nx > 8, TWO wavefronts per group
+// (round 5)  k_backward_ipddp_coop_big runs ~2 340 VALU instructions per step on ONE wavefront per four
+// trajectories (512 wavefronts for the 2048-trajectory C4 share on 1024 SIMDs), and the second half of them -- Q_uu, its pivoted
+// factorisation, the two solves -- does not depend on the first half (T1 = A^T V_xx, Q_xx = l_xx + T1 A).  Here a workgroup is two
+// wavefronts that own the SAME four trajectories and the same columns:
+//   wave 0 (the A side)     T1[:, q], Q_xx[:, q] (in place), rows [0, R0) of the value update, rows [0, R0) of the V_xx store
+//   wave 1 (the gain side)  T2[:, q], Q_x[q], Q_u, Q_ux[:, q], Q_uu, factor, k, K[:, q], K^T Q_uu, V_x[q], the step statistics,
+//                           rows [R0, nx) of the value update and of the V_xx store, the gain stores, the dX rollout epilogue
+// with two s_barriers per step (gain side -> A side: K, Q_ux, K^T Q_uu and the factorisation's verdict; both -> both: the new V_xx).
+// The T1 / Q_xx / V_xx area is double-buffered by step parity, so the symmetrised read of V_xx[t + 1] needs no third barrier.
+// A barrier must be reached by both wavefronts the same number of times, so nothing leaves the loop early: every trajectory of the
+// group runs its own little state machine (its own t; t = N is the pseudo-step that (re)starts a pass from the terminal cost after
+// a failed factorisation raised the regularisation), the other lanes' work is predicated, and the loop ends when no trajectory of
+// the group is sweeping.  Every element is still accumulated by ONE lane in the reference's order: bitwise the one-wave kernel
+// (tests/test_gpu_parity.py::test_two_wave_sweep_agrees_bitwise).
+// the value `v` holds in lane K of the caller's ROW of 16 lanes (DPP row_newbcast, gfx90a+: the only DPP control 64-bit moves take).
+// With 16 lanes per trajectory a row IS a trajectory group, and lane l of it owns column l: an operand that lives in another
+// column's registers costs one v_mov_b64_dpp instead of an LDS write, a wait and a read.  Every lane of a row must be active.
+template <int K> DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
+template <class F, int... Is> DEV void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> DEV void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+#ifndef BIG2_EXP
+#define BIG2_EXP 0   // timing experiments only (profiles/r05_big2_roles.md): the product is 0
+#endif
+template <class Model, class Cons>
+struct CoopBig2Cfg {
+  static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = 64 / G, G2 = 2 * G;
+  static constexpr int NA = (NX * NX + G2 - 1) / G2, NB = (NX * NU + G2 - 1) / G2;   // per-lane slices of A, B (both wavefronts fetch)
+  static constexpr int RC = NU + NU * NU + NU + 2, NC = (RC + G2 - 1) / G2;          // replicated condensed terms c_u .. icomp
+  static constexpr int RK = NU * NX, NK = (RK + G - 1) / G;                          // gain block (rollout epilogue: one wavefront)
+  static constexpr int NE = NU * NU + NU, NQ = (NE + G - 1) / G;                     // Q_uu entries and Q_u, spread over the gain side
+  static constexpr int oA = 0, oB = oA + 2 * NX * NX, oM = oB + 2 * NX * NU, oT2 = oM + 2 * NX * NX, oKK = oT2 + NU * NX,
+                       oQux = oKK + NU * NX, oKtQ = oQux + NU * NX, oVx = oKtQ + NX * NU, oDx = oVx + NX,
+                       oC = oDx + NX, oQuu = oC + 2 * RC, oFlag = oQuu + NE, oKv = oFlag + 1, RAW = oKv + NU;
+  static constexpr int STRIDE = (RAW + 31) / 32 * 32 + 4;
+#ifndef CDDP_BIG2_R0
+#define CDDP_BIG2_R0 ((NX * 3 + 3) / 4)
+#endif
+  static constexpr int R0 = CDDP_BIG2_R0;                                              // value-update rows of the A side (it has the slack)
+};
+
+DEV void wg_sync() { if (BIG2_EXP == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class Model, class Cons>
+__global__ __launch_bounds__(128) void k_backward_ipddp_coop_big2(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+                                                                  int force, int count_iter) {
+  static_assert(!Cons::HAS_X, "state-constrained shapes run the one-wave kernel");
+  constexpr int NX = Model::NX, NU = Model::NU;
+  typedef Objective<NX, NU> Obj;
+  typedef CstLayout<Model, Cons> L;
+  typedef CoopBig2Cfg<Model, Cons> C;
+  constexpr int CST = L::SIZE, G = C::G, G2 = C::G2, R0 = C::R0, RC = C::RC;
+  __shared__ double lds[C::TPW * C::STRIDE];
+  __shared__ double ldsQ[NX * NX];   // Q dt (loop-invariant, shared by the trajectories of the group)
+  __shared__ double ldsR[NU * NU];   // R dt
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const double *Qp = Pk->pool + Pk->off_Qdt, *Rp = Pk->pool + Pk->off_Rdt;
+    for (int e = threadIdx.x; e < NX * NX; e += 128) ldsQ[e] = Qp[e];
+    for (int e = threadIdx.x; e < NU * NU; e += 128) ldsR[e] = Rp[e];
+  }
+  const int q = lane % G, tl = lane / G;
+  const int qc = q < NX ? q : NX - 1;          // owned column (lanes past nx shadow the last one)
+  unsigned long long tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = 0;
+  auto tick = [&](const int k) {
+    if (BIG2_EXP == 9) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_readcyclecounter(); tk_acc[k] += now - tk_last; tk_last = now; __builtin_amdgcn_sched_barrier(0); }
+  };
+  const int q2 = q + G * w;                    // slice index of the cooperative fetches
+  const int b_raw = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
+  const int b = b_raw < d.B ? b_raw : d.B - 1; // (addresses only; a trajectory past the end never sweeps)
+  bool act = b_raw < d.B && (force || d.phase[b] == PH_ACTIVE);
+  const bool was_act = act;
+  double *Ls = lds + tl * C::STRIDE;
+  const ProblemDev *__restrict__ P = Pk;
+  const cddp_hip_options &o = P->opt;
+  const int N = d.N;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  static_assert(L::WQYU == L::CU + NU && L::QYUSIR == L::WQYU + NU * NU && L::IPR == L::QYUSIR + NU && L::ICOMP == L::IPR + 1, "contiguous replicated block");
+  // Every stack is laid out step-major with NB * 64 * E doubles per step (wave-tiled and four-wide layouts alike): the element
+  // offsets of this lane are fixed, a step adds t * tstr * E.
+  const size_t tstr = (size_t)d.NB * 64;
+  struct InAB { double a[C::NA], bm[C::NB], c[C::NC]; };
+  size_t offA[C::NA], offB[C::NB], offC[C::NC];
+#pragma unroll
+  for (int j = 0; j < C::NA; ++j) { const int e = q2 + G2 * j; offA[j] = GT(0, NX * NX, e < NX * NX ? e : NX * NX - 1); }
+#pragma unroll
+  for (int j = 0; j < C::NB; ++j) { const int e = q2 + G2 * j; offB[j] = GT(0, NX * NU, e < NX * NU ? e : NX * NU - 1); }
+#pragma unroll
+  for (int j = 0; j < C::NC; ++j) { const int e = q2 + G2 * j; offC[j] = GT(0, CST, L::CU + (e < RC ? e : RC - 1)); }
+  auto loadAB = [&](const size_t tb, InAB &r) {   // this lane's slice of A_t, B_t and of the replicated condensed terms (element e = q2 + G2 j)
+    const double *pa = d.A + tb * (NX * NX), *pb = d.Bm + tb * (NX * NU), *pc = d.cst + tb * CST;
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) r.a[j] = pa[offA[j]];
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) r.bm[j] = pb[offB[j]];
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) r.c[j] = pc[offC[j]];
+  };
+  auto storeAB = [&](int buf, const InAB &r) {
+    double *La = Ls + C::oA + buf * NX * NX, *Lb = Ls + C::oB + buf * NX * NU, *Lc = Ls + C::oC + buf * RC;
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) { const int e = q2 + G2 * j; if (e < NX * NX) La[e] = r.a[j]; }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) { const int e = q2 + G2 * j; if (e < NX * NU) Lb[e] = r.bm[j]; }
+#pragma unroll
+    for (int j = 0; j < C::NC; ++j) { const int e = q2 + G2 * j; if (e < RC) Lc[e] = r.c[j]; }
+  };
+  const size_t offVxx = GI(0, NX * NX, qc);
+  int t = N;                       // the step this trajectory runs next (N: start of a pass)
+  wg_sync();                       // ldsQ / ldsR
+  static_assert(G == 16, "a trajectory group is a DPP row");
+  // Operands that another column's lane holds come by row broadcast (row_bcast<K>), not through LDS: A[k, i] is lane i's A[k, qc],
+  // T1[i, j] lane j's T1[i, qc], K[j, i] lane i's K[j, qc], ...  LDS carries what crosses the two wavefronts (K, Q_ux, K^T Q_uu one
+  // way, Q_xx / Vn rows the other), the transposed read of the value update, and the few dynamically indexed operands of Q_uu.
+  if (w == 0) {
+    // ------------------------------------------------------------------------------------------------ the A side
+    double Vc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Vc[i] = 0.0;
+    // EVERY global store of the sweep is issued here, one step late, in the window this side would otherwise spend waiting at barrier 1
+    // (a store of 64 lanes scattered over 16 lines takes ~100 cycles to issue: 2 100 cycles per step on the gain side's critical path,
+    //  profiles/r05_big2_roles.md): the step's V_xx column is this side's Vc, its V_x / k / K come through LDS
+    const size_t offVx = GI(0, NX, qc), offk = GI(0, NU, q < NU ? q : NU - 1), offK = GI(0, NU * NX, qc);
+    bool pv_ok = false, pg_ok = false;      // pending: the value rows (index pt_v), the gains (index pt_g)
+    int pt_v = 0, pt_g = 0;
+    double pVxq = 0.0, pkq = 0.0, pK[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) pK[u] = 0.0;
+    auto flush = [&]() {
+      if (pv_ok) {
+        const size_t tb = (size_t)pt_v * tstr;
+        d.Vx[tb * NX + offVx] = pVxq;
+        double *pv = d.Vxx + tb * (NX * NX) + offVxx;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pv[(size_t)i * NX * 64] = Vc[i];
+      }
+      if (pg_ok && !(BIG2_EXP == 9 && pt_g < 10)) {
+        const size_t tb = (size_t)pt_g * tstr;
+        if (q < NU) d.k[tb * NU + offk] = pkq;
+        double *pKp = d.K + tb * (NU * NX) + offK;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pKp[(size_t)u * NX * 64] = pK[u];
+        if (d.t4) {   // the copy the dX rollout below re-reads (wave-tiled K / k are for the wide kernels)
+#pragma unroll
+          for (int u = 0; u < NU; ++u) d.Kt[G4(pt_g, NU * NX + NU, u * NX + qc)] = pK[u];
+          if (q < NU) d.Kt[G4(pt_g, NU * NX + NU, NU * NX + q)] = pkq;
+        }
+      }
+      pv_ok = false; pg_ok = false;
+    };
+    if (BIG2_EXP == 9) tk_last = __builtin_readcyclecounter();
+    while (__builtin_amdgcn_ballot_w64(act) != 0) {
+      const bool isN = t >= N;
+      const int ts = isN ? N - 1 : t, tp = isN ? N - 1 : (t > 0 ? t - 1 : 0);
+      InAB nab;
+      loadAB((size_t)tp * tstr, nab);
+      PIPELINE_FENCE();
+      const double *La = Ls + C::oA + (ts & 1) * NX * NX;
+      double *Mb = Ls + C::oM + (t & 1) * NX * NX;
+      double Aq[NX], lq[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { Aq[j] = La[j * NX + qc]; lq[j] = ldsQ[j * NX + qc]; }
+      tick(0);
+      // round 1: T1[i, qc] = sum_k A[k, i] V[k, qc]
+      double T1[NX];
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s += row_bcast<i>(Aq[k]) * Vc[k];
+        T1[i] = s;
+      });
+      tick(1);
+      // round 2: Q_xx[i, qc] = 2 Q dt [i, qc] + sum_j T1[i, j] A[j, qc]
+      double Qxx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double s = 0.0;
+        static_for<NX>([&](auto J) { constexpr int j = decltype(J)::value; s += row_bcast<j>(T1[i]) * Aq[j]; });
+        Qxx[i] = (2.0 * lq[i]) + s;
+      }
+#pragma unroll
+      for (int i = R0; i < NX; ++i) Mb[i * NX + qc] = Qxx[i];          // the gain side's rows of the value update
+      flush();                                                          // the previous step's stores
+      tick(2);
+      wg_sync();                                                        // ---- barrier 1: K, Q_ux, K^T Q_uu, the verdict
+      tick(3);
+      // rows [0, R0) of Vn[i, qc] = ((Q_xx[i, qc] + K[:, i] . Q_ux[:, qc]) + Q_ux[:, i] . K[:, qc]) + (K^T Q_uu)[i, :] . K[:, qc]
+      double Quxq[NU], KKc[NU], KtQq[NU];
+      const int verdict = (int)Ls[C::oFlag];                            // 0 step done, 1 restart the pass, 2 give up
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { Quxq[u] = Ls[C::oQux + u * NX + qc]; KKc[u] = Ls[C::oKK + u * NX + qc]; KtQq[u] = Ls[C::oKtQ + qc * NU + u]; }
+      const double kq = Ls[C::oKv + (q < NU ? q : NU - 1)];
+      double Vn[R0];
+      static_for<R0>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += row_bcast<i>(KKc[j]) * Quxq[j]; bb += row_bcast<i>(Quxq[j]) * KKc[j]; e += row_bcast<i>(KtQq[j]) * KKc[j]; }
+        Vn[i] = ((Qxx[i] + a) + bb) + e;
+      });
+      if (__builtin_amdgcn_ballot_w64(isN) != 0) {                     // start of a pass: terminal cost, Vn[i, qc] = 2 Qf[i, qc]
+        const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+        for (int i = 0; i < R0; ++i) { const double v = 2.0 * Qf[i * NX + qc]; Vn[i] = isN ? v : Vn[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < R0; ++i) Mb[i * NX + qc] = Vn[i];
+      tick(4);
+      storeAB(tp & 1, nab);
+      if (BIG2_EXP == 9) lds_sync();
+      tick(5);
+      wg_sync();                                                        // ---- barrier 2: Vn, V_x
+      tick(6);
+      {
+        double mr[NX], mc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { mr[i] = i < R0 ? Vn[i < R0 ? i : 0] : Mb[i * NX + qc]; mc[i] = Mb[qc * NX + i]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const double vxq = Ls[C::oVx + qc];
+        const bool good = act && (isN || verdict == 0);
+        if (good) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) Vc[i] = 0.5 * (mr[i] + mc[i]);
+          pv_ok = true; pt_v = isN ? N : t; pVxq = vxq;
+          if (!isN) {
+            pg_ok = true; pt_g = t; pkq = kq;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) pK[u] = KKc[u];
+          }
+        }
+      }
+      // next state of this trajectory (the gain side takes the same decisions)
+      if (act) {
+        if (isN) t = N - 1;
+        else if (verdict == 1) t = N;
+        else if (verdict == 2) act = false;
+        else if (t == 0) act = false;
+        else t = t - 1;
+      }
+      tick(7);
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wg_sync();                                                          // the rollout epilogue of the gain side re-reads K, k
+    if (BIG2_EXP == 9 && q == 0 && was_act) {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) d.k[GI(j, NU, 1)] = (double)tk_acc[j];
+    }
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- the gain side
+  if (count_iter && q == 0 && act) d.iter[b] += 1;
+  double reg = d.reg[b];
+  const double mu = d.mu[b];
+  bool ok = false;
+  int nb = 0;
+  double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
+  {
+    const size_t offCx = GT(0, CST, L::CX + qc);
+    double Vc[NX], Vx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { Vc[i] = 0.0; Vx[i] = 0.0; }
+    if (BIG2_EXP == 9) tk_last = __builtin_readcyclecounter();
+    while (__builtin_amdgcn_ballot_w64(act) != 0) {
+      const bool isN = t >= N;
+      const int ts = isN ? N - 1 : t, tp = isN ? N - 1 : (t > 0 ? t - 1 : 0);
+      const double cxq = d.cst[(size_t)ts * tstr * CST + offCx];
+      InAB nab;
+      loadAB((size_t)tp * tstr, nab);
+      PIPELINE_FENCE();
+      const double *La = Ls + C::oA + (ts & 1) * NX * NX, *Lb = Ls + C::oB + (ts & 1) * NX * NU;
+      const double *Lc = Ls + C::oC + (ts & 1) * RC;   // c_u | G_u^T YS^-1 G_u | G_u^T S^-1 rhat | ipr | icomp
+      double *Mb = Ls + C::oM + (t & 1) * NX * NX;
+      double Aq[NX], Br[NU], Lcr[RC];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) Br[u] = Lb[qc * NU + u];             // row qc of B: B[k, u] is lane k's Br[u]
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Aq[j] = La[j * NX + qc];
+#pragma unroll
+      for (int e = 0; e < RC; ++e) Lcr[e] = Lc[e];
+      __builtin_amdgcn_sched_barrier(0);
+      tick(0);
+      // ---- round 1: T2[u, qc] = sum_k B[k, u] V[k, qc], Q_x[qc]
+      double T2[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double s = 0.0;
+        static_for<NX>([&](auto K) { constexpr int k = decltype(K)::value; s += row_bcast<k>(Br[u]) * Vc[k]; });
+        T2[u] = s;
+        Ls[C::oT2 + u * NX + qc] = s;      // (the dynamically indexed operands of Q_uu below)
+      }
+      double Qxq;
+      { double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += Aq[k] * Vx[k];
+        Qxq = cxq + s2; }
+      tick(1);
+      // ---- round 2: Q_ux[:, qc] = T2 A[:, qc]; Q_uu = 2 R dt + T2 B and Q_u = c_u + B^T V_x, one entry (or a few) per lane, one LDS round
+      double Quxq[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double s = 0.0;
+        static_for<NX>([&](auto J) { constexpr int j = decltype(J)::value; s += row_bcast<j>(T2[u]) * Aq[j]; });
+        Quxq[u] = s;
+      }
+      lds_sync();
+      double lt[C::NQ * NX], cb[C::NQ * NX], addend[C::NQ];
+#pragma unroll
+      for (int jq = 0; jq < C::NQ; ++jq) {
+        const int e = q + G * jq;
+        const int ee = e < C::NE ? e : C::NE - 1;
+        const bool isQuu = ee < NU * NU;
+        const int u = ee / NU, v = ee - u * NU;
+        const int rT = isQuu ? u : 0, cB = isQuu ? v : ee - NU * NU;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { lt[jq * NX + j] = Ls[C::oT2 + rT * NX + j]; cb[jq * NX + j] = Lb[j * NU + cB]; }
+        const double a0 = ldsR[isQuu ? ee : 0], a1 = Lc[cB];
+        addend[jq] = isQuu ? 2.0 * a0 : a1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jq = 0; jq < C::NQ; ++jq) {
+        const int e = q + G * jq;
+        const bool isQuu = (e < C::NE ? e : C::NE - 1) < NU * NU;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += (isQuu ? lt[jq * NX + j] : Vx[j]) * cb[jq * NX + j];
+        if (e < C::NE) Ls[C::oQuu + e] = addend[jq] + s;
+      }
+      lds_sync();
+      tick(2);
+      double Quu[NU * NU], Qu[NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu[i] = Ls[C::oQuu + i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] = Ls[C::oQuu + NU * NU + i];
+      __builtin_amdgcn_sched_barrier(0);
+      double Qr[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Qr[i * NU + c] = 0.5 * (Quu[i * NU + c] + Quu[c * NU + i]) + Lcr[NU + i * NU + c];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qr[i * NU + i] += reg;
+      double kk[NU], KKc[NU];
+      bool fok = true;
+      if (NU == 1) {
+        kk[0] = -ldlt1_solve(Qr[0], Qu[0] + Lcr[NU + NU * NU]);
+        KKc[0] = -ldlt1_solve(Qr[0], Quxq[0]);
+      } else {
+        LDLTs<NU> f;
+        f.compute(Qr, NU);
+        fok = f.ok;
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Qu[i] + Lcr[NU + NU * NU + i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = Quxq[i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) KKc[i] = -col[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) Qu[i] += Lcr[NU + NU * NU + i];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Quu[i] += Lcr[NU + i];
+      double KtQq[NU];   // row qc of K^T Q_uu (condensed Q_uu), mm_tn's expression
+#pragma unroll
+      for (int j = 0; j < NU; ++j) { double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s += KKc[u] * Quu[u * NU + j];
+        KtQq[j] = s; }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { Ls[C::oKK + u * NX + qc] = KKc[u]; Ls[C::oQux + u * NX + qc] = Quxq[u]; Ls[C::oKtQ + qc * NU + u] = KtQq[u]; }
+      // the verdict of this step: 0 done, 1 the factorisation failed and the pass restarts with more regularisation, 2 it failed for good
+      int verdict = 0;
+      double reg_next = reg;
+      if (!isN && !fok) {
+        verdict = 2;
+        if (force != 2) { reg_next = reg_increase(o, reg); if (!(reg_next >= o.reg_max_value)) verdict = 1; }
+      }
+      if (q == 0) {
+        Ls[C::oFlag] = (double)verdict;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) Ls[C::oKv + u] = kk[u];
+      }
+      if (BIG2_EXP == 9) lds_sync();
+      tick(3);
+      wg_sync();                                                        // ---- barrier 1
+      tick(4);
+      constexpr int R1 = NX - R0;
+      double qx[R1 > 0 ? R1 : 1];
+#pragma unroll
+      for (int il = 0; il < R1; ++il) qx[il] = Mb[(R0 + il) * NX + qc];
+      const bool good = act && !isN && verdict == 0;
+      // ---- round 3 (computed for every lane; what a pass start or a failed step must not keep is discarded below)
+      double Quuk[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s1 += Quu[i * NU + j] * kk[j];
+        Quuk[i] = s1; }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { s0 += kk[i] * Qu[i]; s1 += kk[i] * Quuk[i]; }
+      double Vxq;
+      {
+        double a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += KKc[j] * Qu[j]; bb += Quxq[j] * kk[j]; c += KtQq[j] * kk[j]; }
+        Vxq = ((Qxq + a) + bb) + c;
+      }
+      if (good) {
+        inf_pr = dmax(inf_pr, Lcr[NU + NU * NU + NU]); inf_comp = dmax(inf_comp, Lcr[NU + NU * NU + NU + 1]);
+        dV0 += s0; dV1 += 0.5 * s1;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(Qu[i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+      }
+      double Vn[R1 > 0 ? R1 : 1];
+      static_for<R1>([&](auto IL) {
+        constexpr int il = decltype(IL)::value, i = R0 + il;
+        double a = 0.0, bb = 0.0, e = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { a += row_bcast<i>(KKc[j]) * Quxq[j]; bb += row_bcast<i>(Quxq[j]) * KKc[j]; e += row_bcast<i>(KtQq[j]) * KKc[j]; }
+        Vn[il] = ((qx[il] + a) + bb) + e;
+      });
+      if (__builtin_amdgcn_ballot_w64(isN) != 0) {   // start of a pass: terminal cost, statistics cleared
+        double xN[NX], g[NX];
+        ld<NX>(Xc + GI(N, NX, 0), kLS, xN);
+        Obj::final_grad(P, xN, g);
+        double gq = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) if (i == qc) gq = g[i];
+        Vxq = isN ? gq : Vxq;
+        const double *Qf = P->pool + P->off_Qf;
+#pragma unroll
+        for (int il = 0; il < R1; ++il) { const double v = 2.0 * Qf[(R0 + il) * NX + qc]; Vn[il] = isN ? v : Vn[il]; }
+        if (isN && act) { ++nb; dV0 = 0; dV1 = 0; inf_du = 0; inf_pr = 0; inf_comp = 0; step_norm = 0; }
+      }
+#pragma unroll
+      for (int il = 0; il < R1; ++il) Mb[(R0 + il) * NX + qc] = Vn[il];
+      Ls[C::oVx + qc] = Vxq;
+      if (BIG2_EXP == 9) lds_sync();
+      tick(5);
+      storeAB(tp & 1, nab);
+      if (BIG2_EXP == 9) lds_sync();
+      tick(6);
+      wg_sync();                                                        // ---- barrier 2
+      tick(7);
+      {
+        double mr[NX], mc[NX], vxr[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { mr[i] = i >= R0 ? Vn[i >= R0 ? i - R0 : 0] : Mb[i * NX + qc]; mc[i] = Mb[qc * NX + i]; }
+        static_for<NX>([&](auto I) { constexpr int i = decltype(I)::value; vxr[i] = row_bcast<i>(Vxq); });
+        __builtin_amdgcn_sched_barrier(0);
+        const bool good2 = act && (isN || verdict == 0);
+        if (good2) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { Vc[i] = 0.5 * (mr[i] + mc[i]); Vx[i] = vxr[i]; }
+        }
+        tick(8);
+      }
+      if (act) {
+        if (isN) t = N - 1;
+        else if (verdict == 1) { t = N; reg = reg_next; }
+        else if (verdict == 2) { act = false; if (force != 2) reg = reg_next; }
+        else if (t == 0) { act = false; ok = true; }
+        else t = t - 1;
+      }
+      tick(9);
+    }
+  }
+  wg_sync();                                                            // the A side's last stores (K, k of step 0) are out
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (BIG2_EXP == 9 && q == 0 && was_act) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) d.k[GI(j, NU, 0)] = (double)tk_acc[j];
+  }
+  if (!was_act) return;
+  bool conv = false;
+  if (ok) {
+    const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+    const double asn = fabs(d.alpha_pr[b]) * step_norm;
+    const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+    conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    if ((!conv || force) && BIG2_EXP != 1) {
+      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}; this wavefront alone
+      // (the A side has left), so an LDS round trip needs lgkmcnt(0) only
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      struct RIn { double ks[C::NK], kq, Aq[NX], Bq[NU]; };
+      constexpr int GS = NU + NU * NX;   // LDS doubles per gain buffer (2 GS <= 2 nx^2)
+      static_assert(2 * GS <= 2 * NX * NX, "gain buffers fit the A area");
+      auto load_r = [&](int tt, RIn &r) {
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; const int ee = e < C::RK ? e : C::RK - 1; r.ks[j] = d.t4 ? d.Kt[G4(tt, NU * NX + NU, ee)] : d.K[GI(tt, NU * NX, ee)]; }
+        r.kq = d.t4 ? d.Kt[G4(tt, NU * NX + NU, NU * NX + (q < NU ? q : NU - 1))] : d.k[GI(tt, NU, q < NU ? q : NU - 1)];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GT(tt, NX * NX, qc * NX + j)];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GT(tt, NX * NU, qc * NU + j)];
+      };
+      auto store_r = [&](int buf, const RIn &r) {
+        double *Lg = Ls + C::oA + buf * GS;
+        if (q < NU) Lg[q] = r.kq;
+#pragma unroll
+        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; if (e < C::RK) Lg[NU + e] = r.ks[j]; }
+      };
+      RIn rc, rn;
+      auto rstep = [&](const int t) {
+        const int tn = t + 1 < N - 1 ? t + 1 : t;
+        load_r(tn, rn);
+        PIPELINE_FENCE();
+        d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+        if (t < N - 1) {
+          const double *Lg = Ls + C::oA + (t & 1) * GS;
+          double du[NU];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += Lg[NU + i * NX + j] * dx[j];
+            du[i] = Lg[i] + a; }
+          double a = 0.0, c = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
+          const double dxq = (a + c) + 0.0;
+          lds_sync();
+          Ls[C::oDx + qc] = dxq;
+          store_r((t & 1) ^ 1, rn);
+          lds_sync();
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+        }
+        rc = rn;
+      };
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
+      load_r(0, rc);
+      store_r(0, rc);
+      lds_sync();
+      for (int t = 0; t < N; ++t) rstep(t);
+    }
+  }
+  if (q != 0) return;
+  d.reg[b] = reg;
+  d.n_bwd[b] += nb;
+  d.bwd_ok[b] = ok ? 1 : 0;
+  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;
+  if (ok) {
+    d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
+    d.inf_pr[b] = inf_pr; d.inf_comp[b] = inf_comp;
+  }
+  if (force) return;
+  if (!ok) { d.status[b] = CDDP_HIP_STATUS_REG_LIMIT; d.phase[b] = PH_DONE; return; }
+  if (conv) { d.status[b] = CDDP_HIP_STATUS_OPTIMAL; d.phase[b] = PH_DONE; hist_push(d, b, mu); return; }
+  d.phase[b] = PH_FWD1;
+}
+
 #undef GI
+
 }  // namespace cddp_dev

@@ -243,7 +243,14 @@ struct Launcher {
             hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 2>), dim3(coop_grid<TPW2>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
           else
           {
-            hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+            // default (round 5): two wavefronts per group of trajectories -- the A side and the gain side of a step run side by side
+            // (k_backward_ipddp_coop_big2); CDDP_HIP_COOP_W=1 keeps the one-wave kernel (bitwise the same results)
+            bool two = !Cons::HAS_X;
+            if (const char *e = std::getenv("CDDP_HIP_COOP_W")) { if (e[0] == '1') two = false; }
+            if constexpr (!Cons::HAS_X) {
+              if (two) hipLaunchKernelGGL((k_backward_ipddp_coop_big2<Model, Cons>), gridC, dim3(128), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
+            }
+            if (!two) hipLaunchKernelGGL((k_backward_ipddp_coop_big<Model, Cons, 1>), gridC, dim3(64), 0, sweep_hop_in(s), d, d.P, d.xref_traj, force, count_iter);
             sweep_hop_out(s);
           }
         }

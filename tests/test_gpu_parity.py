@@ -470,18 +470,92 @@ def test_row_split_sweep_agrees_bitwise(api, case, monkeypatch):
         return r, X, U, K, k, Vx, Vxx
 
     monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
-    out = {}
-    for h in ("1", "2"):
-        monkeypatch.setenv("CDDP_HIP_COOP_H", h)
-        out[h] = run()
     monkeypatch.delenv("CDDP_HIP_COOP_H", raising=False)
+    out = {}
+    monkeypatch.setenv("CDDP_HIP_COOP_W", "1")          # one wavefront per group, one lane per column
+    out["1"] = run()
+    monkeypatch.setenv("CDDP_HIP_COOP_H", "2")          # one wavefront per group, two lanes per column
+    out["2"] = run()
+    monkeypatch.delenv("CDDP_HIP_COOP_H", raising=False)
+    monkeypatch.delenv("CDDP_HIP_COOP_W", raising=False)
+    out["two_wave"] = run()                             # the default (round 5): A side / gain side on two wavefronts
     monkeypatch.setenv("CDDP_HIP_SWEEP", "lane")
     out["lane"] = run()
-    for other in ("2", "lane"):
+    for other in ("2", "two_wave", "lane"):
         a, b = out["1"], out[other]
         assert np.array_equal(a[0]["iterations"], b[0]["iterations"]) and np.array_equal(a[0]["status"], b[0]["status"]), other
         assert np.array_equal(a[0]["final_objective"], b[0]["final_objective"]), other
+        for key in a[0].dtype.names:
+            assert np.array_equal(a[0][key], b[0][key], equal_nan=True), (other, key)
         for i in range(1, 7): assert np.array_equal(a[i], b[i]), (other, i)
+
+
+@pytest.mark.parametrize("case,reg0", [("quad12_ipddp_box", 0.0), ("quad12_ipddp_box", 1e-9), ("manip7_ipddp_box", 0.0)])
+def test_two_wave_sweep_agrees_bitwise(api, case, reg0, monkeypatch):
+    """k_backward_ipddp_coop_big2 against the one-wave kernel on a batch whose trajectories do NOT move in step: a spread of
+    initial states wide enough that some factorisations fail and restart their pass with more regularisation (the per-trajectory
+    state machine of the two-wave kernel), a batch that leaves a partial group, and a short iteration budget so that trajectories
+    stop in different states.  Result words, work counts, trajectories, gains and value function: the same bits."""
+    p = make(api, case)
+    p.options.max_iterations = 12
+    if reg0 > 0.0: p.options.reg_initial_value = reg0
+    B = 150
+    x0 = api.batch_x0(p, B, 20270311, 6.0 * spread_for(p))
+    U0 = api.batch_U0(p, B)
+
+    def run():
+        hs = api.HipBatchSolver(p, B)
+        hs.set_initial(x0, U0); hs.solve()
+        r = hs.results(); X, U = hs.trajectory(); K, k = hs.gains(); Vx, Vxx = hs.value(); hs.close()
+        return r, X, U, K, k, Vx, Vxx
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    monkeypatch.delenv("CDDP_HIP_COOP_H", raising=False)
+    monkeypatch.setenv("CDDP_HIP_COOP_W", "1")
+    a = run()
+    monkeypatch.delenv("CDDP_HIP_COOP_W", raising=False)
+    b = run()
+    for key in a[0].dtype.names:
+        assert np.array_equal(a[0][key], b[0][key], equal_nan=True), key
+    for i in range(1, 7): assert np.array_equal(a[i], b[i], equal_nan=True), i
+    print("backward passes per iteration (max over the batch):", np.max(a[0]["n_backward"] / np.maximum(1, a[0]["iterations"])))
+
+
+@pytest.mark.parametrize("case", ["quad12_ipddp_box", "quadrotor_ipddp_box"])
+def test_two_wave_sweep_restarts_agree_bitwise(api, case, monkeypatch):
+    """The restart path of k_backward_ipddp_coop_big2: trajectories whose factorisation fails (a NaN control late in the horizon makes
+    B_t and V_x non-finite) restart their pass with more regularisation, pass after pass up to the limit, while the other trajectories
+    of the same group of four walk down the horizon -- every trajectory of a group at its own step.  Step level (initialize ->
+    backward), against the one-wave kernel: verdicts, regularisation, pass counts, gains, value function, the same bits."""
+    p = make(api, case)
+    p.options.reg_initial_value = 1e2
+    B = 23
+    x0 = api.batch_x0(p, B, 20270312, spread_for(p))
+    U0 = api.batch_U0(p, B)
+    if U0 is None: U0 = np.zeros((B, p.N, p.nu))
+    U0 = np.array(U0, copy=True)
+    bad = [1, 6, 7, 13, 22]
+    for b in bad: U0[b, p.N - 3, 0] = np.nan
+
+    def run():
+        hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.initialize()
+        ok = hs.backward()
+        K, k = hs.gains(); Vx, Vxx = hs.value(); dV, reg = hs.backward_scalars(); r = hs.results(); hs.close()
+        return ok, K, k, Vx, Vxx, dV, reg, r["n_backward"]
+
+    monkeypatch.delenv("CDDP_HIP_SWEEP", raising=False)
+    monkeypatch.delenv("CDDP_HIP_COOP_H", raising=False)
+    monkeypatch.setenv("CDDP_HIP_COOP_W", "1")
+    a = run()
+    monkeypatch.delenv("CDDP_HIP_COOP_W", raising=False)
+    b = run()
+    assert not a[0][bad].any() and a[0][[i for i in range(B) if i not in bad]].all(), a[0]
+    assert (a[7][bad] > 1).all(), a[7]          # more than one pass: the restarts happened
+    good = [i for i in range(B) if i not in bad]
+    for i in range(8):
+        assert np.array_equal(a[i][good], b[i][good]), i
+    for i in (0, 6, 7):                          # verdict, regularisation, pass count of the failed ones (their stacks hold a failed pass)
+        assert np.array_equal(a[i][bad], b[i][bad]), i
 
 
 @pytest.mark.parametrize("sweep", ["coop", "lane"])
