@@ -1879,64 +1879,57 @@ __global__ __launch_bounds__(128) void k_backward_ipddp_coop_big2(DevBuf d, cons
     const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
     conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
     if ((!conv || force) && BIG2_EXP != 1) {
-      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}; this wavefront alone
-      // (the A side has left), so an LDS round trip needs lgkmcnt(0) only
-      double dx[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-      struct RIn { double ks[C::NK], kq, Aq[NX], Bq[NU]; };
-      constexpr int GS = NU + NU * NX;   // LDS doubles per gain buffer (2 GS <= 2 nx^2)
-      static_assert(2 * GS <= 2 * NX * NX, "gain buffers fit the A area");
+      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}, lane u < nu the control
+      // row du[u] = k[u] + K[u, :] dx; dx and du travel by row broadcast, so a step is one short dependent chain with no LDS round
+      // trip, and the rows of K, A, B of the next steps (independent of dx) are fetched three steps ahead -- the one-wave kernel
+      // waits for an HBM round trip every step (2.5 us of it, 1 ms of a 3.8 ms launch at C4).  Whole rows (trajectories) are
+      // active or not: the broadcasts see every lane of their row.
+      struct RIn { double Kr[NX], kq, Ar[NX], Br[NU]; };
+      const int ui = q < NU ? q : NU - 1;
+      constexpr int EK = NU * NX + NU;
+      const double *baseK = d.t4 ? d.Kt + G4(0, EK, ui * NX) : d.K + GI(0, NU * NX, ui * NX);
+      const double *basek = d.t4 ? d.Kt + G4(0, EK, NU * NX + ui) : d.k + GI(0, NU, ui);
+      const size_t sK = d.t4 ? tstr * EK : tstr * (NU * NX), sk = d.t4 ? tstr * EK : tstr * NU, se = d.t4 ? 4 : 64;
+      const double *baseA = d.A + GT(0, NX * NX, qc * NX), *baseB = d.Bm + GT(0, NX * NU, qc * NU);
+      const size_t sa = TSTRIDE;
       auto load_r = [&](int tt, RIn &r) {
+        tt = tt < N - 1 ? tt : N - 2;
+        tt = tt > 0 ? tt : 0;
+        const double *pK = baseK + (size_t)tt * sK, *pA = baseA + (size_t)tt * tstr * (NX * NX), *pB = baseB + (size_t)tt * tstr * (NX * NU);
 #pragma unroll
-        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; const int ee = e < C::RK ? e : C::RK - 1; r.ks[j] = d.t4 ? d.Kt[G4(tt, NU * NX + NU, ee)] : d.K[GI(tt, NU * NX, ee)]; }
-        r.kq = d.t4 ? d.Kt[G4(tt, NU * NX + NU, NU * NX + (q < NU ? q : NU - 1))] : d.k[GI(tt, NU, q < NU ? q : NU - 1)];
+        for (int jj = 0; jj < NX; ++jj) r.Kr[jj] = pK[(size_t)jj * se];
+        r.kq = basek[(size_t)tt * sk];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GT(tt, NX * NX, qc * NX + j)];
+        for (int jj = 0; jj < NX; ++jj) r.Ar[jj] = pA[(size_t)jj * sa];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GT(tt, NX * NU, qc * NU + j)];
+        for (int jj = 0; jj < NU; ++jj) r.Br[jj] = pB[(size_t)jj * sa];
       };
-      auto store_r = [&](int buf, const RIn &r) {
-        double *Lg = Ls + C::oA + buf * GS;
-        if (q < NU) Lg[q] = r.kq;
-#pragma unroll
-        for (int j = 0; j < C::NK; ++j) { const int e = q + G * j; if (e < C::RK) Lg[NU + e] = r.ks[j]; }
-      };
-      RIn rc, rn;
-      auto rstep = [&](const int t) {
-        const int tn = t + 1 < N - 1 ? t + 1 : t;
-        load_r(tn, rn);
+      double dxq = 0.0;
+      double *pdX = d.dX + GI(0, NX, qc);
+      auto rstep = [&](const int t, const RIn &rc, RIn &rl) {   // rc: the rows of step t; rl: free buffer, takes the rows of step t + 3
+        if (t >= N) return;
+        load_r(t + 3, rl);
         PIPELINE_FENCE();
-        d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+        pdX[(size_t)t * tstr * NX] = dxq;
         if (t < N - 1) {
-          const double *Lg = Ls + C::oA + (t & 1) * GS;
-          double du[NU];
+          double dx[NX], du[NU];
+          static_for<NX>([&](auto J) { constexpr int jj = decltype(J)::value; dx[jj] = row_bcast<jj>(dxq); });
+          double au = 0.0;
 #pragma unroll
-          for (int i = 0; i < NU; ++i) { double a = 0.0;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) a += Lg[NU + i * NX + j] * dx[j];
-            du[i] = Lg[i] + a; }
+          for (int jj = 0; jj < NX; ++jj) au += rc.Kr[jj] * dx[jj];
+          const double du_own = rc.kq + au;
+          static_for<NU>([&](auto U) { constexpr int u = decltype(U)::value; du[u] = row_bcast<u>(du_own); });
           double a = 0.0, c = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+          for (int jj = 0; jj < NX; ++jj) a += rc.Ar[jj] * dx[jj];
 #pragma unroll
-          for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
-          const double dxq = (a + c) + 0.0;
-          lds_sync();
-          Ls[C::oDx + qc] = dxq;
-          store_r((t & 1) ^ 1, rn);
-          lds_sync();
-#pragma unroll
-          for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+          for (int jj = 0; jj < NU; ++jj) c += rc.Br[jj] * du[jj];
+          dxq = (a + c) + 0.0;
         }
-        rc = rn;
       };
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
-      load_r(0, rc);
-      store_r(0, rc);
-      lds_sync();
-      for (int t = 0; t < N; ++t) rstep(t);
+      RIn r0, r1, r2, r3;
+      load_r(0, r0); load_r(1, r1); load_r(2, r2);
+      for (int t = 0; t < N; t += 4) { rstep(t, r0, r3); rstep(t + 1, r1, r0); rstep(t + 2, r2, r1); rstep(t + 3, r3, r2); }
     }
   }
   if (q != 0) return;

@@ -28,6 +28,23 @@ namespace cddp_dev {
 
 #define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
 
+// NGRP groups of LDS operands, group g + 1 fetched (ldg) before group g is reduced (cmp), a scheduling barrier in between: left to
+// itself the compiler issues one ds_read, waits for it and multiplies -- one LDS round trip per operand (profiles/r05_big2_roles.md)
+#ifndef CDDP_TE_STAGED
+#define CDDP_TE_STAGED 1
+#endif
+template <int NGRP, int BN, class LD, class CMP> DEV void lds_pipe(LD &&ldg, CMP &&cmp) {
+  double b0[BN], b1[BN];
+  ldg(0, b0);
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    if (g + 1 < NGRP) { if ((g & 1) == 0) ldg(g + 1, b1); else ldg(g + 1, b0); }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((g & 1) == 0) cmp(g, b0); else cmp(g, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <class Model, class Cons>
 struct TeCfg {
   static constexpr int NX = Model::NX, NU = Model::NU, G = CoopCfg<Model>::G, TPW = 64 / G;
@@ -400,11 +417,21 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (CDDP_TE_STAGED) {
+        lds_pipe<NU, NX>([&](const int u, auto &buf) {
+#pragma unroll
+          for (int k = 0; k < NX; ++k) buf[k] = Lb[k * NU + u];
+        }, [&](const int u, const auto &buf) { double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) s += buf[k] * Vc[k];
+          Ls[C::oT2 + u * NX + qc] = s; });
+      } else {
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) s += Lb[k * NU + u] * Vc[k];
         Ls[C::oT2 + u * NX + qc] = s; }
+      }
       lds_sync();
       // round 2a: Q + A^T P A (in place over T1, row by row), Q_ux column; the entries of Q_uu spread over the lanes
       {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
@@ -436,6 +463,34 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         }
       }
       double Quxq[NU];
+      if constexpr (CDDP_TE_STAGED) {
+        lds_pipe<NU, NX>([&](const int u, auto &buf) {
+#pragma unroll
+          for (int j = 0; j < NX; ++j) buf[j] = Ls[C::oT2 + u * NX + j];
+        }, [&](const int u, const auto &buf) { double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += buf[j] * Aq[j];
+          Quxq[u] = s + 0.0;            // + M^T, M = 0 without G_x
+          Ls[C::oQux + u * NX + qc] = Quxq[u]; });
+        lds_pipe<C::NQ, 2 * NX + 2>([&](const int j, auto &buf) {
+          const int e = q + G * j;
+          const int ee = e < NU * NU ? e : NU * NU - 1;
+          const int u = ee / NU, w = ee - u * NU;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) { buf[k] = Ls[C::oT2 + u * NX + k]; buf[NX + k] = Lb[k * NU + w]; }
+          buf[2 * NX] = Lc[C::cRR + u * NU + w]; buf[2 * NX + 1] = Lc[C::cRR + w * NU + u];
+        }, [&](const int j, const auto &buf) {
+          const int e = q + G * j;
+          const int ee = e < NU * NU ? e : NU * NU - 1;
+          const int u = ee / NU, w = ee - u * NU;
+          double s = 0.0;               // (B^T P) B; (B^T P^T) B is the same number: P is exactly symmetric
+#pragma unroll
+          for (int k = 0; k < NX; ++k) s += buf[k] * buf[NX + k];
+          double ruw = buf[2 * NX], rwu = buf[2 * NX + 1];
+          if (u == w) { ruw += reg; rwu += reg; }
+          if (e < NU * NU) Ls[C::oQuu + e] = 0.5 * (((ruw + s) + rwu) + s);
+        });
+      } else {
 #pragma unroll
       for (int u = 0; u < NU; ++u) { double s = 0.0;
 #pragma unroll
@@ -453,6 +508,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         double ruw = Lc[C::cRR + u * NU + w], rwu = Lc[C::cRR + w * NU + u];
         if (u == w) { ruw += reg; rwu += reg; }
         if (e < NU * NU) Ls[C::oQuu + e] = 0.5 * (((ruw + s) + rwu) + s);
+      }
       }
       lds_sync();
       // round 2b: factor (replicated; lane 0 parks it in LDS for the variant solves), K column, row of K^T Q_uu
@@ -483,11 +539,21 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) bad = bad || !dfinite(KKc[i]);
+      if constexpr (CDDP_TE_STAGED) {
+        lds_pipe<NU, NU>([&](const int j, auto &buf) {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) buf[u] = Ls[C::oQuu + u * NU + j];
+        }, [&](const int j, const auto &buf) { double s = 0.0;     // row qc of K^T Q_uu
+#pragma unroll
+          for (int u = 0; u < NU; ++u) s += KKc[u] * buf[u];
+          Ls[C::oKtQ + qc * NU + j] = s; });
+      } else {
 #pragma unroll
       for (int j = 0; j < NU; ++j) { double s = 0.0;     // row qc of K^T Q_uu
 #pragma unroll
         for (int u = 0; u < NU; ++u) s += KKc[u] * Ls[C::oQuu + u * NU + j];
         Ls[C::oKtQ + qc * NU + j] = s; }
+      }
 #pragma unroll
       for (int u = 0; u < NU; ++u) Ls[C::oKK + u * NX + qc] = KKc[u];
       lds_sync();
@@ -501,11 +567,22 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         double drift[NX], Qu[NU], kk[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) drift[i] = pv[i] + 0.0;     // + P * 0 (no affine dynamics term)
+        if constexpr (CDDP_TE_STAGED) {
+          lds_pipe<NU, NX + 1>([&](const int i, auto &buf) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) buf[k] = Lb[k * NU + i];
+            buf[NX] = Lc[C::cR + i];
+          }, [&](const int i, const auto &buf) { double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) a += buf[k] * drift[k];
+            Qu[i] = buf[NX] + a; });
+        } else {
 #pragma unroll
         for (int i = 0; i < NU; ++i) { double a = 0.0;
 #pragma unroll
           for (int k = 0; k < NX; ++k) a += Lb[k * NU + i] * drift[k];
           Qu[i] = Lc[C::cR + i] + a; }
+        }
         if constexpr (NU == 1) kk[0] = -ldlt1_solve(Ls[C::oQuu], Qu[0]);
         else {
           double col[NU];
@@ -515,6 +592,24 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int i = 0; i < NU; ++i) kk[i] = -col[i];
         }
+        if constexpr (CDDP_TE_STAGED) {
+          lds_pipe<NX, NX + 3 * NU + 1>([&](const int i, auto &buf) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) buf[k] = La[k * NX + i];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { buf[NX + j] = Ls[C::oQux + j * NX + i]; buf[NX + NU + j] = Ls[C::oKK + j * NX + i]; buf[NX + 2 * NU + j] = Ls[C::oKtQ + i * NU + j]; }
+            buf[NX + 3 * NU] = Lc[C::cQ + i];
+          }, [&](const int i, const auto &buf) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) a += buf[k] * drift[k];
+            const double Qx = buf[NX + 3 * NU] + a;
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { a1 += buf[NX + j] * kk[j]; a2 += buf[NX + NU + j] * Qu[j]; a3 += buf[NX + 2 * NU + j] * kk[j]; }
+            Ls[C::oPv + i * G + q] = ((Qx + a1) + a2) + a3;
+          });
+        } else {
 #pragma unroll 4
         for (int i = 0; i < NX; ++i) {
           double a = 0.0;
@@ -525,6 +620,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int j = 0; j < NU; ++j) { a1 += Ls[C::oQux + j * NX + i] * kk[j]; a2 += Ls[C::oKK + j * NX + i] * Qu[j]; a3 += Ls[C::oKtQ + i * NU + j] * kk[j]; }
           Ls[C::oPv + i * G + q] = ((Qx + a1) + a2) + a3;
+        }
         }
         lds_sync();
 #pragma unroll
