@@ -21,6 +21,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef CDDP_DX_PREFETCH_DEEP
+#define CDDP_DX_PREFETCH_DEEP 1
+#endif
+
 namespace cddp_dev {
 
 #define GI(t, E, e) (((((size_t)(t)) * (size_t)d.NB + (size_t)(b >> 6)) * (E) + (e)) * 64 + (size_t)(b & 63))
@@ -412,11 +416,52 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
 #pragma unroll
       for (int i = 0; i < NX; ++i) Ls[C::oDx + i] = 0.0;
       lds_sync();
+      // (round 5) the rows of step t + 3 are requested while step t runs: a step is ~150 cycles of dependent arithmetic, a fetch one
+      // memory round trip -- with the rows of step t + 1 requested at the top of step t, every step waited for its own round trip
+      constexpr bool kDeep = CDDP_DX_PREFETCH_DEEP && sizeof(RIn) <= 24 * sizeof(double);
+      if constexpr (kDeep) {
+        auto dstep = [&](const int t, const RIn &rc, RIn &rl) {
+          if (t >= N) return;
+          const int tn = t + 3 < N - 1 ? t + 3 : (N - 2 > 0 ? N - 2 : 0);
+          load_r(tn, rl);
+          PIPELINE_FENCE();
+          if constexpr (kQuad) d.dX[GI(t, NX, qc)] = dxown; else d.dX[GI(t, NX, qc)] = Ls[C::oDx + qc];
+          if (t < N - 1) {
+            double du[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+              for (int j = 0; j < NX; ++j) a += rc.KK[i * NX + j] * dx[j];
+              du[i] = rc.kk[i] + a; }
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
+            const double dxq = (a + c) + 0.0;
+            if constexpr (kQuad) {
+              dxown = dxq;
+              quad_gather<NX>(dxq, dx);
+            } else {
+              lds_sync();
+              Ls[C::oDx + qc] = dxq;
+              lds_sync();
+#pragma unroll
+              for (int i = 0; i < NX; ++i) dx[i] = Ls[C::oDx + i];
+            }
+          }
+        };
+        auto clampt = [&](int tt) { return tt < N - 1 ? tt : (N - 2 > 0 ? N - 2 : 0); };
+        RIn r0, r1, r2, r3;
+        load_r(0, r0); load_r(clampt(1), r1); load_r(clampt(2), r2);
+        for (int t = 0; t < N; t += 4) { dstep(t, r0, r3); dstep(t + 1, r1, r0); dstep(t + 2, r2, r1); dstep(t + 3, r3, r2); }
+      } else {
       RIn ra, rb;
       load_r(0, ra);
       int t = 0;
       for (; t + 1 < N; t += 2) { rstep(t, ra, rb); rstep(t + 1, rb, ra); }
       if (t < N) rstep(t, ra, rb);
+      }
     }
   }
   if (q != 0) return;

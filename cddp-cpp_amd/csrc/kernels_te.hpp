@@ -721,6 +721,28 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         PIPELINE_FENCE();
         const double *La = Ls + C::rA + (t & 1) * NX * NX, *Lb = Ls + C::rB + (t & 1) * NX * NU, *Lk = Ls + C::rK + (t & 1) * NU * NX;
         double du[NU];
+        if constexpr (CDDP_TE_STAGED) {
+          lds_pipe<NU, NX>([&](const int i, auto &buf) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) buf[j] = Lk[i * NX + j];
+          }, [&](const int i, const auto &buf) { double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += buf[j] * dx[j];
+            du[i] = rc.kf[i] + a; });
+          lds_pipe<NX, NX + NU>([&](const int i, auto &buf) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) buf[j] = La[i * NX + j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) buf[NX + j] = Lb[i * NU + j];
+          }, [&](const int i, const auto &buf) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += buf[j] * dx[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) c += buf[NX + j] * du[j];
+            Ls[C::rPv + i * G + q] = (a + c) + 0.0;
+          });
+        } else {
 #pragma unroll
         for (int i = 0; i < NU; ++i) { double a = 0.0;
 #pragma unroll
@@ -734,6 +756,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
           for (int j = 0; j < NU; ++j) c += Lb[i * NU + j] * du[j];
           Ls[C::rPv + i * G + q] = (a + c) + 0.0;
+        }
         }
         store_r((t & 1) ^ 1, rn);
         lds_sync();
@@ -845,7 +868,57 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
       for (int j = 0; j < G; ++j) step_norm = dmax(step_norm, Ls[C::oRed + j]);
       // ---- P5: linear-policy rollout dX with the final gains (ipddp_solver.cpp:1511-1520); lane qc = row qc
-      {
+      if constexpr (G == 16 && CDDP_TE_STAGED) {
+        // (as the epilogue of k_backward_ipddp_coop_big2: dx and du by row broadcast, the rows of K, A, B two steps ahead)
+        struct RIn5 { double Kr[NX], kq, Ar[NX], Br[NU]; };
+        const size_t tstr = (size_t)d.NB * 64;
+        const int ui = q < NU ? q : NU - 1;
+        constexpr int EK = NU * NX + NU;
+        const double *baseK = d.t4 ? d.Kt + G4(0, EK, ui * NX) : d.K + GI(0, NU * NX, ui * NX);
+        const double *basek = d.t4 ? d.Kt + G4(0, EK, NU * NX + ui) : d.k + GI(0, NU, ui);
+        const size_t sK = d.t4 ? tstr * EK : tstr * (NU * NX), sk = d.t4 ? tstr * EK : tstr * NU, se = d.t4 ? 4 : 64;
+        const double *baseA = d.A + GT(0, NX * NX, qc * NX), *baseB = d.Bm + GT(0, NX * NU, qc * NU);
+        const size_t sa = TSTRIDE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // P4's k (this wavefront's own stores) is re-read below
+        auto load5 = [&](int tt, RIn5 &r) {
+          tt = tt < N - 1 ? tt : N - 2;
+          tt = tt > 0 ? tt : 0;
+          const double *pK = baseK + (size_t)tt * sK, *pA = baseA + (size_t)tt * tstr * (NX * NX), *pB = baseB + (size_t)tt * tstr * (NX * NU);
+#pragma unroll
+          for (int jj = 0; jj < NX; ++jj) r.Kr[jj] = pK[(size_t)jj * se];
+          r.kq = basek[(size_t)tt * sk];
+#pragma unroll
+          for (int jj = 0; jj < NX; ++jj) r.Ar[jj] = pA[(size_t)jj * sa];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) r.Br[jj] = pB[(size_t)jj * sa];
+        };
+        double dxq = 0.0;
+        double *pdX = d.dX + GI(0, NX, qc);
+        auto step5 = [&](const int t, const RIn5 &rc5, RIn5 &rl5) {   // rc5: the rows of step t; rl5 takes the rows of step t + 2
+          if (t >= N) return;
+          load5(t + 2, rl5);
+          PIPELINE_FENCE();
+          pdX[(size_t)t * tstr * NX] = dxq;
+          if (t < N - 1) {
+            double dxb[NX], du[NU];
+            static_for<NX>([&](auto J) { constexpr int jj = decltype(J)::value; dxb[jj] = row_bcast<jj>(dxq); });
+            double au = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NX; ++jj) au += rc5.Kr[jj] * dxb[jj];
+            const double du_own = rc5.kq + au;
+            static_for<NU>([&](auto U) { constexpr int u = decltype(U)::value; du[u] = row_bcast<u>(du_own); });
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NX; ++jj) a += rc5.Ar[jj] * dxb[jj];
+#pragma unroll
+            for (int jj = 0; jj < NU; ++jj) c += rc5.Br[jj] * du[jj];
+            dxq = (a + c) + 0.0;
+          }
+        };
+        RIn5 r0, r1, r2;
+        load5(0, r0); load5(1, r1);
+        for (int t = 0; t < N; t += 3) { step5(t, r0, r2); step5(t + 1, r1, r0); step5(t + 2, r2, r1); }
+      } else {
         double dxr[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) dxr[i] = 0.0;
