@@ -33,6 +33,14 @@ namespace cddp_dev {
 #ifndef CDDP_TE_STAGED
 #define CDDP_TE_STAGED 1
 #endif
+// reduced terminal system on the lanes of the group (TeCfg::kP3Par) / recombination rows fetched four trips ahead; 0: the one-lane
+// system and one row per trip (the forms these are held bitwise to)
+#ifndef CDDP_TE_P3PAR
+#define CDDP_TE_P3PAR 1
+#endif
+#ifndef CDDP_TE_P4UNR
+#define CDDP_TE_P4UNR 4
+#endif
 template <int NGRP, int BN, class LD, class CMP> DEV void lds_pipe(LD &&ldg, CMP &&cmp) {
   double b0[BN], b1[BN];
   ldg(0, b0);
@@ -223,6 +231,79 @@ DEV void ldlt_mem_solve(const double *m, const double *trd, int n, int ld, doubl
   for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int kk = i + 1; kk < n; ++kk) s -= m[kk * ld + i] * x[kk]; x[i] = s; }
   for (int k = n - 1; k >= 0; --k) { const int t = (int)trd[k]; if (t != k) { const double v = x[k]; x[k] = x[t]; x[t] = v; } }
 }
+// ldlt_mem_compute on the G lanes of a trajectory (lane q; gmask = the group's lanes): the pivot search reads the diagonal in one
+// batch and compares in the one-lane order; the elements of a transposition, the entries of temp and the rows below the pivot
+// (their update sum and their division) are spread over the lanes; m_kk - s is formed by every lane (each needs the pivot).  Every
+// entry goes through the operations of the one-lane loop in the same order: same bits.  The return value is the same on every lane.
+template <int G, int PM>
+DEV bool ldlt_mem_compute_coop(double *m, double *trd, double *temp, int n, int ld, int q, unsigned long long gmask) {
+  if (n <= 1) { if (n == 1 && q == 0) trd[0] = 0.0; return true; }
+  bool found_zero_pivot = false, ret = true, lret = true;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    {
+      double dv[PM];
+#pragma unroll
+      for (int i = 0; i < PM; ++i) { const int ii = i < n ? i : 0; dv[i] = m[ii * ld + ii]; }
+      double bigv = 0.0;
+#pragma unroll
+      for (int i = 0; i < PM; ++i) {
+        const double v = fabs(dv[i]);
+        if (i == k) bigv = v;
+        else if (i > k && i < n && v > bigv) { bigv = v; big = i; }
+      }
+    }
+    if (q == 0) trd[k] = (double)big;
+    if (k != big) {
+      const int s = n - big - 1, mid = big - k - 1, total = k + s + 1 + mid;
+      for (int e = q; e < total; e += G) {
+        int ia, ib;
+        if (e < k) { ia = k * ld + e; ib = big * ld + e; }
+        else if (e < k + s) { const int i = e - k; ia = (big + 1 + i) * ld + k; ib = (big + 1 + i) * ld + big; }
+        else if (e == k + s) { ia = k * ld + k; ib = big * ld + big; }
+        else { const int i = k + 1 + (e - k - s - 1); ia = i * ld + k; ib = big * ld + i; }
+        const double t = m[ia]; m[ia] = m[ib]; m[ib] = t;
+      }
+      lds_sync();
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = q; j < k; j += G) temp[j] = m[j * ld + j] * m[k * ld + j];
+      lds_sync();
+    }
+    double akk = m[k * ld + k];
+    if (k > 0) {
+      double s = 0.0;
+      for (int j = 0; j < k; ++j) s += m[k * ld + j] * temp[j];
+      akk -= s;
+    }
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < n; ++j) {
+        if (q == 0) trd[j] = (double)j;
+        for (int i = j + 1; i < n; ++i) ret = ret && (m[i * ld + j] == 0.0);
+      }
+      lds_sync();
+      return ret;
+    }
+    for (int i = q; i < rs; i += G) {
+      double v = m[(k + 1 + i) * ld + k];
+      if (k > 0) {
+        double t = 0.0;
+        for (int j = 0; j < k; ++j) t += m[(k + 1 + i) * ld + j] * temp[j];
+        v -= t;
+      }
+      if (valid) v /= akk; else lret = lret && (v == 0.0);
+      m[(k + 1 + i) * ld + k] = v;
+    }
+    if (k > 0 && q == 0) m[k * ld + k] = akk;
+    lds_sync();
+    if (found_zero_pivot && valid) ret = false;
+    else if (!valid) found_zero_pivot = true;
+  }
+  if (__ballot(!lret) & gmask) ret = false;
+  return ret;
+}
 DEV void singular_minmax_mem(double *U, const double *A, int n, int ld, double &smax, double &smin) {   // one-sided Jacobi
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) U[i * ld + j] = A[i * ld + j];
   for (int sweep = 0; sweep < 80; ++sweep) {
@@ -332,6 +413,14 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
     for (int j = 0; j < C::NC; ++j) { const int e = q + G * j; if (e < REC) Lc[e] = r.c[j]; }
   };
+#ifndef TE_EXP
+#define TE_EXP 0   // 9: phase timers (profiles/r05_big2_roles.md); the product is 0
+#endif
+  unsigned long long tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = 0;
+  auto tick = [&](const int k) {
+    if (TE_EXP == 9) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_readcyclecounter(); tk_acc[k] += now - tk_last; tk_last = now; __builtin_amdgcn_sched_barrier(0); }
+  };
+  if (TE_EXP == 9) tk_last = __builtin_readcyclecounter();
   for (;;) {
     ++nb;
     inf_pr = 0; inf_comp = 0; step_norm = 0;
@@ -433,6 +522,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         Ls[C::oT2 + u * NX + qc] = s; }
       }
       lds_sync();
+      tick(8);
       // round 2a: Q + A^T P A (in place over T1, row by row), Q_ux column; the entries of Q_uu spread over the lanes
       {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
         constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RWP = NX;
@@ -511,6 +601,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       }
       }
       lds_sync();
+      tick(9);
       // round 2b: factor (replicated; lane 0 parks it in LDS for the variant solves), K column, row of K^T Q_uu
       double KKc[NU];
       if constexpr (NU == 1) {
@@ -557,6 +648,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
       for (int u = 0; u < NU; ++u) Ls[C::oKK + u * NX + qc] = KKc[u];
       lds_sync();
+      tick(10);
       // next step's A, B, record: fetched behind the factorisation (its registers are free again), landed in LDS at
       // the end of the step -- the gradient variant and round 3 cover the latency
       loadAB(tp, nab);
@@ -632,6 +724,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
 #pragma unroll
         for (int i = 0; i < NX; ++i) tep[(((size_t)t * Bp + b) * NX + i) * VP + v] = pv[i];
       }
+      tick(11);
       // round 3: P_t column (in place over the lane's own Q + A^T P A column)
       {   // row groups software-pipelined: the operands of group g + 1 leave LDS before group g is reduced
         constexpr int GR = 2, NGRP = (NX + GR - 1) / GR, RWP = 3 * NU + 1;
@@ -662,6 +755,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      tick(12);
       storeAB(nab);   // A_{t-1}, B_{t-1}, record: nothing reads the step's own copies any more
       lds_sync();
 #pragma unroll
@@ -676,6 +770,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       }
 #pragma unroll
       for (int i = 0; i < NX; ++i) d.Vxx[GI(t, NX * NX, i * NX + qc)] = Vc[i];
+      tick(13);
       return true;
     };
     {
@@ -683,8 +778,10 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
       loadAB(N - 1, nab);
       storeAB(nab);
       lds_sync();
+      tick(0);
       for (int t = N - 1; t >= 0; --t)
         if (!step(t, nab)) { fail = true; break; }
+      tick(1);
     }
     if (!fail) {
       // ---- P2: closed-loop linear rollout of every variant (lane v), dx0 = 0 (rolloutLinearPolicy :368-392)
@@ -770,8 +867,93 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int i = 0; i < NX; ++i) Ls[C::oXT + v * NX + i] = dx[i];
       }
       lds_sync();
-      // ---- P3: reduced terminal system (:550-617), one lane; operands in LDS (overlaying the sweep area)
-      if (q == 0) {
+      tick(2);
+      // ---- P3: reduced terminal system (:550-617); operands in LDS (overlaying the sweep area)
+      if constexpr (CDDP_TE_P3PAR != 0) {
+        // (round 5) the lanes of the group share the system: every entry of A_s, A_s^T A_s, A_s^T b, of the shifted matrix and of
+        // the residual is its own sequential sum (entries / rows spread over the lanes), the factorisation runs with one lane per
+        // row (ldlt_mem_compute_coop); the scales stay in sequence, every accept / skip decision is taken by all lanes on the
+        // same LDS values.  Same work area as the one-lane form below, which it is held bitwise to.
+        const int p = pT, ld_ = pT;
+        double *As = Ls, *AtA = As + p * p, *Sh = AtA + p * p, *Uw = Sh + p * p, *rhs = Uw + p * p, *Atb = rhs + p,
+               *lam = Atb + p, *best = lam + p, *temp = best + p, *trd = temp + p;
+        const double *xT = Ls + C::oXT;
+        for (int e = q; e < p * p; e += G) {
+          const int r = e / p, i = e - r * p;
+          const int cr = ldsCol[r];
+          double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) a += ((k == cr) ? 1.0 : 0.0) * (xT[(i + 1) * NX + k] - xT[k]);
+          As[r * ld_ + i] = a;
+        }
+        for (int r = q; r < p; r += G) {
+          const int cr = ldsCol[r];
+          double hx = 0.0;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) hx += ((k == cr) ? 1.0 : 0.0) * xT[k];
+          rhs[r] = (-Ls[C::oH + r]) - hx;
+        }
+        lds_sync();
+        tick(6);
+        for (int e = q; e < p * p; e += G) {
+          const int i = e / p, c = e - i * p;
+          double a = 0.0; for (int k = 0; k < p; ++k) a += As[k * ld_ + i] * As[k * ld_ + c];
+          AtA[i * ld_ + c] = a;
+        }
+        for (int i = q; i < p; i += G) { double a = 0.0; for (int k = 0; k < p; ++k) a += As[k * ld_ + i] * rhs[k]; Atb[i] = a; best[i] = 0.0; }
+        lds_sync();
+        tick(7);
+        double tr = 0.0;
+        for (int i = 0; i < p; ++i) tr += AtA[i * ld_ + i];
+        const double trace_term = (tr > 1.0 ? tr / (p > 1 ? p : 1) : 1.0);
+        const double base_floor = dmax(1e-10, o.ipddp_jacobian_regularization_value * solver_pow(dmax(mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+        const double regv = dmax(base_floor, 1e-6 * trace_term);
+        double svd_reg = 0.0;   // (only a non-finite system runs the Jacobi sweeps: see the one-lane form below)
+        if (!dfinite(tr)) {
+          if (q == 0) {
+            double smax, smin;
+            singular_minmax_mem(Uw, As, p, ld_, smax, smin);
+            temp[0] = dmax(1e-8 * smax - smin, 0.0);
+          }
+          lds_sync();
+          svd_reg = temp[0];
+          lds_sync();
+        }
+        const double reg_base = dmax(regv, svd_reg);
+        double rn2 = 0.0; for (int r = 0; r < p; ++r) rn2 += rhs[r] * rhs[r];
+        const double cap = 100.0 * (1.0 + sqrt(rn2));
+        double best_res = INFINITY; bool found = false;
+        tick(14);
+        for (int sc = 0; sc < 5; ++sc) {
+          const double scale = (sc == 0) ? 1.0 : (sc == 1) ? 10.0 : (sc == 2) ? 100.0 : (sc == 3) ? 1e3 : 1e4;
+          const double reg_i = dmax(reg_base * scale, 1e-12);
+          for (int e = q; e < p * p; e += G) { const int i = e / p, c = e - i * p; Sh[i * ld_ + c] = AtA[i * ld_ + c] + reg_i * ((i == c) ? 1.0 : 0.0); }
+          for (int i = q; i < p; i += G) lam[i] = Atb[i];
+          lds_sync();
+          if (!ldlt_mem_compute_coop<G, C::PMAX>(Sh, trd, temp, p, ld_, q, gmask)) continue;
+          if (q == 0) ldlt_mem_solve(Sh, trd, p, ld_, lam);
+          lds_sync();
+          bool fin = true; double ln = 0.0;
+          for (int i = 0; i < p; ++i) { const double li = lam[i]; fin = fin && dfinite(li); ln += li * li; }
+          if (!fin) continue;
+          ln = sqrt(ln);
+          if (ln > cap) {
+            const double f2 = cap / dmax(ln, 1e-12);
+            for (int i = q; i < p; i += G) lam[i] = lam[i] * f2;
+            lds_sync();
+          }
+          for (int r = q; r < p; r += G) { double a = 0.0; for (int i = 0; i < p; ++i) a += As[r * ld_ + i] * lam[i]; const double e = a - rhs[r]; Uw[r] = e * e; }
+          lds_sync();
+          double res = 0.0;
+          for (int r = 0; r < p; ++r) res += Uw[r];
+          res = sqrt(res);
+          if (!dfinite(res)) continue;
+          if (!found || res < best_res) { for (int i = q; i < p; i += G) best[i] = lam[i]; best_res = res; found = true; }
+        }
+        lds_sync();
+        tick(15);
+        for (int i = q; i < p; i += G) { const double bv = found ? best[i] : 0.0; d.dLamT[(size_t)i * Bp + b] = bv; Ls[C::oBest + i] = bv; }
+      } else if (q == 0) {
         const int p = pT, ld_ = pT;
         double *As = Ls, *AtA = As + p * p, *Sh = AtA + p * p, *Uw = Sh + p * p, *rhs = Uw + p * p, *Atb = rhs + p,
                *lam = Atb + p, *best = lam + p, *temp = best + p, *trd = temp + p;
@@ -834,6 +1016,7 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
         for (int i = 0; i < p; ++i) { d.dLamT[(size_t)i * Bp + b] = best[i]; Ls[C::oBest + i] = best[i]; }
       }
       lds_sync();
+      tick(3);
       // ---- P4: recombination (:619-634); elements (t, i) spread over the lanes of the group
       double sn = 0.0;
       {
@@ -851,6 +1034,56 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           for (int w = 0; w < C::PMAX; ++w) if (w < pT) ko += bw[w] * (rv[w + 1] - k0);
           return ko;
         };
+        if constexpr (CDDP_TE_P4UNR > 1) {
+          // the rows of UNR trips leave memory before the first is combined (one row per trip: a memory round trip per trip)
+          constexpr int UNR = CDDP_TE_P4UNR;
+          auto combine_r = [&](const double (&rv)[VP]) {
+            const double k0 = rv[0];
+            double ko = k0;
+#pragma unroll
+            for (int w = 0; w < C::PMAX; ++w) if (w < pT) ko += bw[w] * (rv[w + 1] - k0);
+            return ko;
+          };
+          const int nk = N * NU, np = (N + 1) * NX;
+          for (int idx0 = q; idx0 < nk; idx0 += G * UNR) {
+            double rv[UNR][VP];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+              const int idx = idx0 + G * j < nk ? idx0 + G * j : idx0;
+              const double *row = tek + ((size_t)(idx / NU) * Bp * NU + (size_t)b * NU + (idx % NU)) * VP;
+#pragma unroll
+              for (int w = 0; w < VP; ++w) rv[j][w] = row[w];
+            }
+            PIPELINE_FENCE();
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+              const int idx = idx0 + G * j;
+              if (idx < nk) {
+                const int t = idx / NU, i = idx - t * NU;
+                const double ko = combine_r(rv[j]);
+                d.k[GI(t, NU, i)] = ko;
+                if (d.t4) d.Kt[G4(t, NU * NX + NU, NU * NX + i)] = ko;
+                sn = dmax(sn, fabs(ko));
+              }
+            }
+          }
+          for (int idx0 = q; idx0 < np; idx0 += G * UNR) {
+            double rv[UNR][VP];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+              const int idx = idx0 + G * j < np ? idx0 + G * j : idx0;
+              const double *row = tep + ((size_t)(idx / NX) * Bp * NX + (size_t)b * NX + (idx % NX)) * VP;
+#pragma unroll
+              for (int w = 0; w < VP; ++w) rv[j][w] = row[w];
+            }
+            PIPELINE_FENCE();
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+              const int idx = idx0 + G * j;
+              if (idx < np) { const int t = idx / NX, i = idx - t * NX; d.Vx[GI(t, NX, i)] = combine_r(rv[j]); }
+            }
+          }
+        } else {
         for (int idx = q; idx < N * NU; idx += G) {
           const int t = idx / NU, i = idx - t * NU;
           const double ko = combine(tek + (((size_t)t * Bp + b) * NU + i) * VP);
@@ -862,11 +1095,13 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           const int t = idx / NX, i = idx - t * NX;
           d.Vx[GI(t, NX, i)] = combine(tep + (((size_t)t * Bp + b) * NX + i) * VP);
         }
+        }
       }
       Ls[C::oRed + q] = sn;
       lds_sync();
 #pragma unroll
       for (int j = 0; j < G; ++j) step_norm = dmax(step_norm, Ls[C::oRed + j]);
+      tick(4);
       // ---- P5: linear-policy rollout dX with the final gains (ipddp_solver.cpp:1511-1520); lane qc = row qc
       if constexpr (G == 16 && CDDP_TE_STAGED) {
         // (as the epilogue of k_backward_ipddp_coop_big2: dx and du by row broadcast, the rows of K, A, B two steps ahead)
@@ -974,6 +1209,11 @@ __global__ __launch_bounds__(64) void k_backward_te_coop(DevBuf d, const Problem
           }
           gc = gn;
         }
+      }
+      tick(5);
+      if (TE_EXP == 9 && q == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d.k[GI(j, NU, 0)] = (double)tk_acc[j];
       }
       ok = true;
       break;

@@ -141,9 +141,26 @@ def _manip7_term(S):
     return p
 
 
+def _manip7_term_short(S):
+    # four steps of 10 ms cannot carry the arm to the goal: A_s (sensitivity of x_T to the terminal multipliers) is badly
+    # conditioned -- the reduced system's pivoting, regularisation scales and step cap (ipddp_solver.cpp:550-617) decide the step
+    p = S.manipulator7_problem(S.SOLVER_IPDDP, 4, terminal_equality=True, n_alphas=16)
+    p.options.max_iterations = 12
+    return p
+
+
+def _pendulum_term_one_step(S):
+    # one control for two terminal rows: A_s^T A_s is singular, only the regularisation shift makes the factorisation go through
+    p = S.pendulum_problem(S.SOLVER_IPDDP, True, horizon=1)
+    p.add_terminal_equality("TerminalTarget", [0.0, 0.0])
+    p.options.max_iterations = 12
+    return p
+
+
 TERM_CASES = {"term_ineq_only": _term_ineq_only, "term_eq_only": _term_eq_only, "path_term_eq": _path_term_eq,
               "path_term_ineq": _path_term_ineq, "pendulum_term_eq": _pendulum_term, "manipulator_term_eq": _manip_term,
-              "manip7_term_eq_parallel_ls": _manip7_term}
+              "manip7_term_eq_parallel_ls": _manip7_term, "manip7_term_eq_short": _manip7_term_short,
+              "pendulum_term_eq_one_step": _pendulum_term_one_step}
 
 
 # ---- option branches of the ABI that have device code of their own: every one gets the step-level
