@@ -80,14 +80,41 @@ template <int TPW> inline unsigned coop_grid(int B, int enable) {
   return (n + SUPER - 1) / SUPER * SUPER;
 }
 
-template <class Model, class Cons>
-__global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
+// Role-split form (round 6), NH > 0: the workgroup is the recursion wavefront (wave 0: the code of the single-wave kernel, unchanged
+// arithmetic and order) plus NH HELPER wavefronts on the otherwise idle SIMDs of the CU.
+//   phase 1 (backward in t)  helpers evaluate what k_condense<.., true> evaluates -- A_t, B_t and every V-independent condensation term
+//            (condense_eval: the same device function) -- for blocks of SPB = 64 / TPW steps x TPW trajectories (one lane per
+//            (trajectory, step)), and hand the records to the recursion through an LDS ring of RB blocks; A_t, B_t also go to global
+//            memory (the dX rollout and the host getter read them); the condensed-term stack is never written or re-read.
+//   phase 2 (forward in t)   the recursion wave runs the linear-policy rollout dX as before.
+// Protocol (LDS words, polled with s_sleep): s_ready[slot] = global block number + 1 once a block is in the ring; s_ret = steps the
+// recursion has taken into registers (a block's slot is rewritten only after that block is retired); s_verdict = passes requested so
+// far (a failed factorisation restarts the sweep with a larger regularisation: the helpers produce the blocks again) or kDone;
+// s_hdone counts helpers whose global stores are released.  Every lane of the recursion wave walks all N steps of a pass (a lane whose
+// factorisation failed idles through the rest of the pass), so block accounting is wave-uniform.
+template <class Model, class Cons, int RB>
+struct RoleCfg {
+  typedef CoopCfg<Model> C;
+  typedef CstLayout<Model, Cons> L;
+  static constexpr int NX = Model::NX, NU = Model::NU;
+  static constexpr int oA = 0, oB = oA + NX * NX, oC = oB + NX * NU, REC = oC + L::SIZE;
+  static constexpr int RECP = REC | 1;          // odd record stride: the 16 / 8 trajectories of a step start in distinct LDS banks
+  static constexpr int SPB = 64 / C::TPW;       // steps per block (= helper lanes per trajectory)
+  static constexpr int R = SPB * RB;            // ring capacity in steps
+  static constexpr int RING = R * C::TPW * RECP;
+  static constexpr int kDone = 1 << 30;
+};
+
+template <class Model, class Cons, int NH = 0, int RB = 2>
+__global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt,
                                                             int force, int count_iter) {
   constexpr int NX = Model::NX, NU = Model::NU;
   typedef Objective<NX, NU> Obj;
   typedef CstLayout<Model, Cons> L;
   typedef CoopCfg<Model> C;
+  typedef RoleCfg<Model, Cons, RB> RC;
   constexpr int CST = L::SIZE;
+  constexpr bool ROLES = NH > 0;
   // kQuad: at G = 4 the lanes of a trajectory are a DPP quad, so rounds 1, 2 and the rollout's dx exchange can be quad broadcasts
   // instead of LDS rounds (bitwise equal; tests/test_gpu_parity.py ran green with it).  MEASURED on MI355X (round 3,
   // profiles/r03_element_sweep.md): no gain -- sweep class 16.5 ms vs 16.2 ms per C2 solve, C3 44.5 vs 42.8, CLDDP 19.5 vs 18.5.
@@ -95,16 +122,92 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
   // multiplies and adds), and the ~30 v_mov_dpp that replace ~20 LDS operations are more instructions, not fewer.  Off.
   constexpr bool kQuad = false;
   __shared__ double lds[C::TPW * C::STRIDE];
-  const int lane = threadIdx.x;
-  const int q = lane % C::G, tl = lane / C::G;
+  [[maybe_unused]] __shared__ double s_ring[ROLES ? RC::RING : 1];
+  [[maybe_unused]] __shared__ int s_ready[ROLES ? RB : 1];
+  [[maybe_unused]] __shared__ int s_ret, s_verdict, s_hdone;
+  const int lane = threadIdx.x & 63;
+  [[maybe_unused]] const int wave = ROLES ? (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) : 0;
+  const bool helper = ROLES && wave > 0;
+  const int q = lane % C::G, tl = helper ? lane % C::TPW : lane / C::G;
   const int qc = q < NX ? q : NX - 1;
   const int b = coop_group<C::TPW>((int)blockIdx.x, d.xcd_map) * C::TPW + tl;
+  const ProblemDev *__restrict__ P = Pk;
+  const int N = d.N;
+  [[maybe_unused]] auto wait_ge = [&](int *ctr, int need) -> int {
+    int v;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    return v;
+  };
+  if constexpr (ROLES) {
+    // (this launch replaces k_condense<.., true>, the first kernel of an outer iteration: see k_derivs)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
+    const bool act = (b < d.B) && (force || d.phase[b] == PH_ACTIVE);
+    if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;   // the same trajectories in every wave of the workgroup: all leave
+    if (threadIdx.x == 0) {
+      s_ret = 0; s_verdict = 1; s_hdone = 0;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) s_ready[i] = 0;
+    }
+    __syncthreads();
+    const int nblk = (N + RC::SPB - 1) / RC::SPB;
+    if (helper) {
+      // ---------------------------------------------------------------- helper wavefront: lane = (step offset so, trajectory tl)
+      const int hidx = wave - 1;
+      const int so = lane / C::TPW;
+      const int cur = act ? d.cur[b] : 0;
+      const double *Xc = d.X + (size_t)cur * d.planeX;
+      const double *Uc = d.U + (size_t)cur * d.planeU;
+      const double *Sc = d.S + (size_t)cur * d.planeM;
+      const double *Yc = d.Y + (size_t)cur * d.planeM;
+      const double *Gc = d.G + (size_t)cur * d.planeM;
+      const double mu = act ? d.mu[b] : 1.0;
+      constexpr int M = Cons::M;
+      for (int pass = 0;; ++pass) {
+        for (int j = hidx; j < nblk; j += NH) {
+          const int gj = pass * nblk + j;
+          const int t = N - 1 - (j * RC::SPB + so);
+          const bool valid = act && t >= 0;
+          double A[NX * NX], Bq[NX * NU], c[CST];
+          if (valid) {
+            double x[NX], u[NU], y[M], sv[M], g[M];
+            ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+            ld<NU>(Uc + GI(t, NU, 0), kLS, u);
+            ld<M>(Yc + GI(t, M, 0), kLS, y);
+            ld<M>(Sc + GI(t, M, 0), kLS, sv);
+            ld<M>(Gc + GI(t, M, 0), kLS, g);
+            condense_eval<Model, Cons, true>(P, xrt, t, x, u, y, sv, g, mu, A, Bq, c);
+          }
+          if (gj >= RB) wait_ge(&s_ret, (gj - RB + 1) * RC::SPB);   // the slot's previous block has been taken into registers
+          if (valid) {
+            double *r = s_ring + ((size_t)((gj % RB) * RC::SPB + so) * C::TPW + tl) * RC::RECP;
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) r[RC::oA + i] = A[i];
+#pragma unroll
+            for (int i = 0; i < NX * NU; ++i) r[RC::oB + i] = Bq[i];
+#pragma unroll
+            for (int i = 0; i < CST; ++i) r[RC::oC + i] = c[i];
+            if (pass == 0) {
+#pragma unroll
+              for (int i = 0; i < NX * NX; ++i) d.A[GI(t, NX * NX, i)] = A[i];
+#pragma unroll
+              for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = Bq[i];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(&s_ready[gj % RB], gj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (wait_ge(&s_verdict, pass + 2) >= RC::kDone) break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // A_t, B_t visible to the recursion wave's dX rollout
+      if (lane == 0) __hip_atomic_fetch_add(&s_hdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return;
+    }
+  }
   if (b >= d.B) return;
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;
-  const ProblemDev *__restrict__ P = Pk;
   const cddp_hip_options &o = P->opt;
-  const int N = d.N;
   const int cur = d.cur[b];
   const double *Xc = d.X + (size_t)cur * d.planeX;
   if (count_iter && q == 0) d.iter[b] += 1;
@@ -146,12 +249,49 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
     bool fail = false;
     struct In1 { double A[NX * NX], Aq[NX]; };
     struct In2 { double Bm[NX * NU], cu[NU], WQyu[NU * NU], QyuSir[NU], ipr, icomp, cxq, WQyxq[NU], QyxSirq, WxQyxq[NX]; };
+    // ROLES: the step records come from the helpers' LDS ring (slot of step index k = N - 1 - t in this pass)
+    [[maybe_unused]] const int pbase = ROLES ? (((nb - 1) * ((N + RC::SPB - 1) / RC::SPB)) % RB) : 0;
+    [[maybe_unused]] auto ring_rec = [&](int tt) -> const double * {
+      const int k = N - 1 - tt;
+      const int slot = ((pbase + k / RC::SPB) % RB) * RC::SPB + (k % RC::SPB);
+      return s_ring + ((size_t)slot * C::TPW + tl) * RC::RECP;
+    };
     auto load1 = [&](int tt, In1 &r) {
+      if constexpr (ROLES) {
+        const double *rr = ring_rec(tt) + RC::oA;
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) r.A[i] = rr[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) r.Aq[j] = rr[j * NX + qc];
+        return;
+      }
       ld<NX * NX>(d.A + GI(tt, NX * NX, 0), kLS, r.A);
 #pragma unroll
       for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, j * NX + qc)];
     };
     auto load2 = [&](int tt, In2 &r) {
+      if constexpr (ROLES) {
+        const double *rr = ring_rec(tt);
+#pragma unroll
+        for (int i = 0; i < NX * NU; ++i) r.Bm[i] = rr[RC::oB + i];
+        const double *c = rr + RC::oC;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r.cu[i] = c[L::CU + i];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) r.WQyu[i] = c[L::WQYU + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r.QyuSir[i] = c[L::QYUSIR + i];
+        r.ipr = c[L::IPR]; r.icomp = c[L::ICOMP];
+        r.cxq = c[L::CX + qc];
+        if constexpr (Cons::HAS_X) {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) r.WQyxq[u] = c[L::WQYX + u * NX + qc];
+          r.QyxSirq = c[L::QYXSIR + qc];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) r.WxQyxq[i] = c[L::WXQYX + i * NX + qc];
+        }
+        return;
+      }
       ld<NX * NU>(d.Bm + GI(tt, NX * NU, 0), kLS, r.Bm);
       const double *c = d.cst + GI(tt, CST, 0);
       ld<NU>(c + (size_t)L::CU * kLS, kLS, r.cu);
@@ -349,6 +489,46 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
     };
     In1 a1, b1;
     In2 a2, b2;
+    if constexpr (ROLES) {
+      // Block accounting at wave level: before the records of step index k + 1 are fetched (inside step k) their block must be in
+      // the ring; once the last step of a block has run, the block is retired.  Every lane still in the pass loop walks all N steps.
+      const int nblk = (N + RC::SPB - 1) / RC::SPB;
+      const int gb0 = (nb - 1) * nblk;
+      auto need_block = [&](int k) {   // the block of step index k (this pass)
+        const int j = k / RC::SPB;
+        wait_ge(&s_ready[(gb0 + j) % RB], gb0 + j + 1);
+      };
+      auto retire = [&](int k) {       // step index k has run: its record and the prefetched one are in registers
+        if ((k + 1) % RC::SPB == 0 || k == N - 1) {
+          lds_sync();
+          const int done = (k == N - 1) ? (gb0 + nblk) * RC::SPB : gb0 * RC::SPB + k + 1;
+          __hip_atomic_store(&s_ret, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+      need_block(0);
+      load1(N - 1, a1);
+      load2(N - 1, a2);
+      int t = N - 1;
+      for (; t >= 1; t -= 2) {
+        const int k = N - 1 - t;
+        if ((k + 1) % RC::SPB == 0) need_block(k + 1);
+        if (!fail) fail = !step(t, a1, a2, b1, b2);
+        retire(k);
+        if ((k + 2) % RC::SPB == 0 && k + 2 < N) need_block(k + 2);
+        if (!fail) fail = !step(t - 1, b1, b2, a1, a2);
+        retire(k + 1);
+      }
+      if (t == 0) {
+        if (!fail) fail = !step(0, a1, a2, b1, b2);
+        retire(N - 1);
+      }
+      bool cont = false;
+      if (!fail) ok = true;
+      else if (force != 2) { reg = reg_increase(o, reg); cont = reg < o.reg_max_value; }
+      const bool any_cont = __builtin_amdgcn_ballot_w64(cont) != 0ull;   // (the lanes still in the pass loop)
+      __hip_atomic_store(&s_verdict, any_cont ? nb + 1 : RC::kDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!cont) break;
+    } else {
     load1(N - 1, a1);
     load2(N - 1, a2);
     int t = N - 1;
@@ -361,6 +541,11 @@ __global__ __launch_bounds__(64) void k_backward_ipddp_coop(DevBuf d, const Prob
     if (force == 2) break;
     reg = reg_increase(o, reg);
     if (reg >= o.reg_max_value) break;
+    }
+  }
+  if constexpr (ROLES) {   // the helpers' A_t, B_t stores, before the dX rollout reads them
+    wait_ge(&s_hdone, NH);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   bool conv = false;
   if (ok) {

@@ -30,35 +30,18 @@ struct CstLayout {
 };
 
 // ================================================================================ K1b
-// WITH_DERIVS: the same (batch x N) pass also writes A_t = I + dt f_x, B_t = dt f_u (K1, cddp_solver_base.cpp:319-394):
-// x, u are read once and one launch is saved per iteration.
-template <class Model, class Cons, bool WITH_DERIVS = false>
-__global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
+// The per-(trajectory, step) arithmetic of K1b as ONE device function, shared by the wide kernel below and by the helper
+// wavefronts of the role-split sweep (kernels_coop.hpp::k_backward_ipddp_coop<.., NH > 0>): same expressions, same order.
+// c[] is the condensed-term record in CstLayout order; WITH_DERIVS also fills A_t = I + dt f_x, B_t = dt f_u (K1,
+// cddp_solver_base.cpp:319-394).
+template <class Model, class Cons, bool WITH_DERIVS>
+DEV void condense_eval(const ProblemDev *__restrict__ P, const double *__restrict__ xrt, const int t, const double *x, const double *u,
+                       const double *y, const double *s, const double *g, const double mu, double *A, double *Bq, double *c) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
   typedef CstLayout<Model, Cons> L;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int t = blockIdx.y;
-  if constexpr (WITH_DERIVS) {   // first kernel of an outer iteration (see k_derivs)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
-  }
-  if (b >= d.B) return;
-  if (!force && d.phase[b] != PH_ACTIVE) return;
-  const ProblemDev *__restrict__ P = Pk;
-  const int cur = d.cur[b];
-  const double *Xc = d.X + (size_t)cur * d.planeX;
-  const double *Uc = d.U + (size_t)cur * d.planeU;
-  const double *Sc = d.S + (size_t)cur * d.planeM;
-  const double *Yc = d.Y + (size_t)cur * d.planeM;
-  const double *Gc = d.G + (size_t)cur * d.planeM;
-  const double mu = d.mu[b];
   const double s_floor = dmax(mu * 1e-3, kEpsSlack);
-  double x[NX], u[NU], y[M], s[M], g[M], Qyx[M * NX], Qyu[M * NU];
-  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
-  ld<NU>(Uc + GI(t, NU, 0), kLS, u);
-  ld<M>(Yc + GI(t, M, 0), kLS, y);
-  ld<M>(Sc + GI(t, M, 0), kLS, s);
-  ld<M>(Gc + GI(t, M, 0), kLS, g);
+  double Qyx[M * NX], Qyu[M * NU];
   if constexpr (WITH_DERIVS) {   // identical to k_derivs
     double Fx[NX * NX], Fu[NX * NU];
     Model::jac(P->mp, x, u, Fx, Fu);
@@ -69,10 +52,10 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
       for (int j = 0; j < NX; ++j) {
         double a = dt * Fx[i * NX + j];
         if (i == j) a += 1.0;
-        d.A[GI(t, NX * NX, i * NX + j)] = a;
+        A[i * NX + j] = a;
       }
 #pragma unroll
-    for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = dt * Fu[i];
+    for (int i = 0; i < NX * NU; ++i) Bq[i] = dt * Fu[i];
   }
 #pragma unroll
   for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
@@ -114,14 +97,16 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
 #pragma unroll
     for (int r = 0; r < M; ++r) s1 += Qyu[r * NU + i] * Sir[r];
     QyuSir[i] = s1; }
-  double *o = d.cst + GT(t, L::SIZE, 0);
-  const size_t ts = TSTRIDE;
-  st<NX>(o + (size_t)L::CX * ts, ts, cx);
-  st<NU>(o + (size_t)L::CU * ts, ts, cu);
-  st<NU * NU>(o + (size_t)L::WQYU * ts, ts, WQyu);
-  st<NU>(o + (size_t)L::QYUSIR * ts, ts, QyuSir);
-  o[(size_t)L::IPR * ts] = ipr;
-  o[(size_t)L::ICOMP * ts] = icomp;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) c[L::CX + i] = cx[i];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) c[L::CU + i] = cu[i];
+#pragma unroll
+  for (int i = 0; i < NU * NU; ++i) c[L::WQYU + i] = WQyu[i];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) c[L::QYUSIR + i] = QyuSir[i];
+  c[L::IPR] = ipr;
+  c[L::ICOMP] = icomp;
   if constexpr (Cons::HAS_X) {
     double WQyx[NU * NX], QyxSir[NX], Wx[NX * M], WxQyx[NX * NX];
     mm_nn<NU, M, NX>(W, Qyx, WQyx);
@@ -135,10 +120,53 @@ __global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__r
 #pragma unroll
       for (int r = 0; r < M; ++r) Wx[i * M + r] = Qyx[r * NX + i] * YS[r];
     mm_nn<NX, M, NX>(Wx, Qyx, WxQyx);
-    st<NU * NX>(o + (size_t)L::WQYX * ts, ts, WQyx);
-    st<NX>(o + (size_t)L::QYXSIR * ts, ts, QyxSir);
-    st<NX * NX>(o + (size_t)L::WXQYX * ts, ts, WxQyx);
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) c[L::WQYX + i] = WQyx[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) c[L::QYXSIR + i] = QyxSir[i];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) c[L::WXQYX + i] = WxQyx[i];
   }
+}
+
+// WITH_DERIVS: the same (batch x N) pass also writes A_t = I + dt f_x, B_t = dt f_u (K1, cddp_solver_base.cpp:319-394):
+// x, u are read once and one launch is saved per iteration.
+template <class Model, class Cons, bool WITH_DERIVS = false>
+__global__ __launch_bounds__(64) void k_condense(DevBuf d, const ProblemDev *__restrict__ Pk, const double *__restrict__ xrt, int force) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
+  typedef CstLayout<Model, Cons> L;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.y;
+  if constexpr (WITH_DERIVS) {   // first kernel of an outer iteration (see k_derivs)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
+  }
+  if (b >= d.B) return;
+  if (!force && d.phase[b] != PH_ACTIVE) return;
+  const ProblemDev *__restrict__ P = Pk;
+  const int cur = d.cur[b];
+  const double *Xc = d.X + (size_t)cur * d.planeX;
+  const double *Uc = d.U + (size_t)cur * d.planeU;
+  const double *Sc = d.S + (size_t)cur * d.planeM;
+  const double *Yc = d.Y + (size_t)cur * d.planeM;
+  const double *Gc = d.G + (size_t)cur * d.planeM;
+  const double mu = d.mu[b];
+  double x[NX], u[NU], y[M], s[M], g[M];
+  ld<NX>(Xc + GI(t, NX, 0), kLS, x);
+  ld<NU>(Uc + GI(t, NU, 0), kLS, u);
+  ld<M>(Yc + GI(t, M, 0), kLS, y);
+  ld<M>(Sc + GI(t, M, 0), kLS, s);
+  ld<M>(Gc + GI(t, M, 0), kLS, g);
+  double A[WITH_DERIVS ? NX * NX : 1], Bq[WITH_DERIVS ? NX * NU : 1], c[L::SIZE];
+  condense_eval<Model, Cons, WITH_DERIVS>(P, xrt, t, x, u, y, s, g, mu, A, Bq, c);
+  if constexpr (WITH_DERIVS) {
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) d.A[GI(t, NX * NX, i)] = A[i];
+#pragma unroll
+    for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = Bq[i];
+  }
+  double *o = d.cst + GT(t, L::SIZE, 0);
+  const size_t ts = TSTRIDE;
+  st<L::SIZE>(o, ts, c);
 }
 
 // ================================================================================ K2 (lean)

@@ -148,12 +148,32 @@ struct Launcher {
     if (const char *e = std::getenv("CDDP_HIP_K4_NA")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) return v; }
     return 1;
   }
+  // Role-split sweep (round 6, kernels_coop.hpp::k_backward_ipddp_coop<.., NH > 0>): helper wavefronts in the sweep workgroup evaluate
+  // what k_condense<.., true> evaluates and feed the recursion wave through an LDS ring -- one launch instead of two, no condensed-term
+  // stack.  CDDP_HIP_SWEEP_ROLES = 0 (the separate kernels; comparison side of the bitwise test) | 1 | 2 | 3 helpers; read per launch, derivs()
+  // and backward() of one iteration see the same answer.
+  template <int RB> static constexpr bool roles_fit() {
+    if constexpr (!kLean || Model::NX > 8) return false;
+    else return (size_t)RoleCfg<Model, Cons, RB>::RING * 8 + (size_t)CoopCfg<Model>::TPW * CoopCfg<Model>::STRIDE * 8 <= (size_t)72 * 1024;   // two workgroups per CU
+  }
+  static constexpr bool kRoles = roles_fit<2>();
+  static int roles_nh(const DevBuf &d) {
+    if constexpr (!kRoles) return 0;
+    else {
+      if (!(d.cst && !d.ms && !d.lg) || d.ddp) return 0;
+      if (lane_sweep_requested() || elem_sweep_requested()) return 0;
+      int nh = 1;   // measured (profiles/r06_sweep_roles.md): one helper 43.1 -> 39.9 ms at C2, 77.5 -> 67.5 at C3; two / three helpers: 40.4 / 41.2 and 77.9 / 80.1
+      if (const char *e = std::getenv("CDDP_HIP_SWEEP_ROLES")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) nh = v; }
+      return nh;
+    }
+  }
   static void derivs(const DevBuf &d0, int force, hipStream_t s) {
     DevBuf d = d0;
     d.t4 = t4_layout(d0);
     if constexpr (kLean) {
       if (d.cst && !d.ms && !d.lg) {   // IPDDP with path constraints: derivative fill fused into the condensation pass (small plants;
                      // for nx > 8 the two register sets together would spill)
+        if (roles_nh(d0) > 0) return;   // ... or evaluated by the helper wavefronts of the sweep itself (backward())
         if constexpr (Model::NX <= 8) {
           hipLaunchKernelGGL((k_condense<Model, Cons, true>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, d.xref_traj, force);
           return;
@@ -262,6 +282,27 @@ struct Launcher {
         if constexpr (Model::NX <= 4 && Model::NU <= 2) {
           if (elem_sweep_requested()) {
             hipLaunchKernelGGL((k_backward_ipddp_elem<Model, Cons>), dim3(coop_grid<4>(d.B, d.xcd_map)), dim3(64), 0, s, d, d.P, d.xref_traj, force, count_iter);
+            launched = true;
+          }
+        }
+        if constexpr (kRoles) {
+          const int nh = launched ? 0 : roles_nh(d0);
+          if (nh > 0) {
+            const hipStream_t ss = sweep_hop_in(s);
+            // ring depth: helpers + the block being consumed + one of slack, while two workgroups still fit a CU
+            if (nh == 1) {
+              if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 1, 3>), gridC, dim3(128), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+              else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 1, 2>), gridC, dim3(128), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+            } else if (nh == 2) {
+              if constexpr (roles_fit<4>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 4>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+              else if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 3>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+              else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 2>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+            } else {
+              if constexpr (roles_fit<4>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 4>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+              else if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 3>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+              else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 2>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
+            }
+            sweep_hop_out(s);
             launched = true;
           }
         }
