@@ -12,3 +12,9 @@ extern "C" int cddp_hip_debug_k4_times(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cddp_dev::g_k4_times), sizeof(unsigned long long) * (size_t)n);
 }
 #endif
+
+#ifdef CDDP_ROLES_TIMING
+extern "C" int cddp_hip_debug_roles_times(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cddp_dev::g_roles_times), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

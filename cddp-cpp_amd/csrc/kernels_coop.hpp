@@ -92,6 +92,16 @@ template <int TPW> inline unsigned coop_grid(int B, int enable) {
 // far (a failed factorisation restarts the sweep with a larger regularisation: the helpers produce the blocks again) or kDone;
 // s_hdone counts helpers whose global stores are released.  Every lane of the recursion wave walks all N steps of a pass (a lane whose
 // factorisation failed idles through the rest of the pass), so block accounting is wave-uniform.
+#ifdef CDDP_ROLES_TIMING   // experiment: stamps of the LAST role-split sweep launch (profiles/scripts/roles_times.py), 16 words per workgroup
+__device__ unsigned long long g_roles_times[4096 * 16];
+#define ROLES_STAMP(i) do { if (lane == 0 && blockIdx.x < 4096) g_roles_times[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define ROLES_ACC(i, dt) do { if (lane == 0 && blockIdx.x < 4096) g_roles_times[(size_t)blockIdx.x * 16 + (i)] += (dt); } while (0)
+#define ROLES_ZERO(i) do { if (lane == 0 && blockIdx.x < 4096) g_roles_times[(size_t)blockIdx.x * 16 + (i)] = 0ull; } while (0)
+#else
+#define ROLES_STAMP(i)
+#define ROLES_ACC(i, dt)
+#define ROLES_ZERO(i)
+#endif
 template <class Model, class Cons, int RB>
 struct RoleCfg {
   typedef CoopCfg<Model> C;
@@ -125,6 +135,13 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
   [[maybe_unused]] __shared__ double s_ring[ROLES ? RC::RING : 1];
   [[maybe_unused]] __shared__ int s_ready[ROLES ? RB : 1];
   [[maybe_unused]] __shared__ int s_ret, s_verdict, s_hdone;
+  // phase 2: which trajectories take the linear-policy rollout, the dX ring's counters, the step caps (IEEE bit patterns of values >= 0
+  // order like unsigned integers: ds_min_u64)
+  [[maybe_unused]] __shared__ int s_need[ROLES ? C::TPW : 1], s_phase2, s_dxprod, s_cur[ROLES ? NH : 1], s_pdone, s_take;
+  [[maybe_unused]] __shared__ unsigned long long s_aprv[ROLES ? C::TPW : 1], s_aduv[ROLES ? C::TPW : 1];
+  // the phase-1 ring is dead by then: its memory carries dx_t for RD steps
+  [[maybe_unused]] constexpr int RD = ROLES ? (RC::RING / (C::TPW * NX)) / RC::SPB * RC::SPB : 1;
+  static_assert(!ROLES || RD >= 2 * RC::SPB, "dX ring shorter than two blocks");
   const int lane = threadIdx.x & 63;
   [[maybe_unused]] const int wave = ROLES ? (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) : 0;
   const bool helper = ROLES && wave > 0;
@@ -139,13 +156,113 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
     asm volatile("" ::: "memory");
     return v;
   };
+  // Phase 2 of the role-split form: what k_post evaluates, in blocks of SPB steps x TPW trajectories (lane = (step offset so, trajectory)).
+  // Blocks are handed out through ONE packed LDS counter (low half: next block from the front, high half: next block from the back): the
+  // helpers take from the front, behind the dX rollout; the recursion wave, once its rollout is finished, takes from the back as long as
+  // the dX ring still holds the block (steps >= N - RD).  A block is taken exactly once (the add / subtract returns the old pair; the take
+  // is valid while front <= back).  The next block is taken -- and its rows requested -- before the current one is reduced.
+  [[maybe_unused]] auto post_phase = [&](const int so, const bool need, const double mu, const int cur, const bool front, const int hidx) {
+    if constexpr (ROLES) {
+      constexpr int M = Cons::M;
+      constexpr int kNone = 1 << 29;
+      const int nblk = (N + RC::SPB - 1) / RC::SPB;
+      const double *Xc = d.X + (size_t)cur * d.planeX;
+      const double *Uc = d.U + (size_t)cur * d.planeU;
+      const double *Sc = d.S + (size_t)cur * d.planeM;
+      const double *Yc = d.Y + (size_t)cur * d.planeM;
+      const double *Gc = d.G + (size_t)cur * d.planeM;
+      const double tau = dmax(P->opt.barrier_min_fraction_to_boundary, 1.0 - mu);
+      unsigned long long run_apr = (unsigned long long)__double_as_longlong(1.0), run_adu = run_apr;
+      const int i_min = (front || RD >= N) ? 0 : (N - RD + RC::SPB - 1) / RC::SPB;
+      int expect = nblk - 1;   // (back) the block the next take would return
+      const bool leader = lane == (int)__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1;
+      auto take = [&]() -> int {
+        if (!front && expect < i_min) return -1;
+        int v = 0;
+        if (leader) v = front ? __hip_atomic_fetch_add(&s_take, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                              : __hip_atomic_fetch_sub(&s_take, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        v = __builtin_amdgcn_readfirstlane(v);
+        const int f = v & 0xffff, bk = v >> 16;
+        if (f > bk) return -1;
+        expect = bk - 1;
+        return front ? f : bk;
+      };
+      struct PIn { double x[NX], y[M], sv[M], g[M], kk[NU], KK[NU * NX], uj[NU], ys[M]; };
+      auto pload = [&](int i, PIn &r) {
+        const int t = i * RC::SPB + so;
+        if (need && i >= 0 && t < N) {
+          ld<NX>(Xc + GI(t, NX, 0), kLS, r.x);
+          ld<M>(Yc + GI(t, M, 0), kLS, r.y);
+          ld<M>(Sc + GI(t, M, 0), kLS, r.sv);
+          ld<M>(Gc + GI(t, M, 0), kLS, r.g);
+          ld<NU>(d.k + GI(t, NU, 0), kLS, r.kk);
+          ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, r.KK);
+          if constexpr (Cons::NEEDS_U) ld<NU>(Uc + GI(t, NU, 0), kLS, r.uj);
+          ld<M>(d.ys + GI(t, M, 0), kLS, r.ys);
+        }
+      };
+      auto pproc = [&](const int i, const PIn &in, const int inext) {
+        const int t = i * RC::SPB + so;
+        const bool valid = need && t < N;
+        double ky[M], ksv[M], Ky[M * NX], Ksm[M * NX], ysv[M];
+        if (valid) {
+#pragma unroll
+          for (int r = 0; r < M; ++r) ysv[r] = in.ys[r];
+          post_rows<Model, Cons, true>(P, in.x, in.uj, in.y, in.sv, in.g, in.kk, in.KK, mu, ky, ksv, ysv, Ky, Ksm);
+          st<M>(d.ky + GI(t, M, 0), kLS, ky);
+          st<M>(d.ks + GI(t, M, 0), kLS, ksv);
+        }
+        const int last = (i + 1) * RC::SPB < N ? (i + 1) * RC::SPB : N;   // dx_0 .. dx_{last - 1} cover the block
+        wait_ge(&s_dxprod, last);
+        if (valid) {
+          const double *slot = s_ring + ((size_t)(t % RD) * C::TPW + tl) * NX;
+          double dx[NX];
+#pragma unroll
+          for (int k = 0; k < NX; ++k) dx[k] = slot[k];
+          double apr = 1.0, adu = 1.0;
+          post_caps<NX, M>(ky, ksv, Ky, Ksm, in.sv, in.y, dx, tau, apr, adu);
+          // (k_post: if (apr < 1.0) atomic_min_pos(...): a NaN cap is dropped, a negative one counts as 0)
+          if (apr < 1.0) { const unsigned long long v = (unsigned long long)__double_as_longlong(apr >= 0.0 ? apr : 0.0); run_apr = v < run_apr ? v : run_apr; }
+          if (adu < 1.0) { const unsigned long long v = (unsigned long long)__double_as_longlong(adu >= 0.0 ? adu : 0.0); run_adu = v < run_adu ? v : run_adu; }
+        }
+        if (front) {   // the dX rollout may rewrite the slots of every block below the one this helper works on next
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(&s_cur[hidx], inext >= 0 ? inext : kNone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+      PIn pa, pb;
+      int i0 = take();
+      if (front) __hip_atomic_store(&s_cur[hidx], i0 >= 0 ? i0 : kNone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pload(i0, pa);
+      while (i0 >= 0) {
+        const int i1 = take();
+        pload(i1, pb);
+        PIPELINE_FENCE();
+        pproc(i0, pa, i1);
+        if (i1 < 0) break;
+        const int i2 = take();
+        pload(i2, pa);
+        PIPELINE_FENCE();
+        pproc(i1, pb, i2);
+        i0 = i2;
+      }
+      if (need) {
+        __hip_atomic_fetch_min(&s_aprv[tl], run_apr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(&s_aduv[tl], run_adu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
   if constexpr (ROLES) {
     // (this launch replaces k_condense<.., true>, the first kernel of an outer iteration: see k_derivs)
     if (blockIdx.x == 0 && threadIdx.x == 0 && !force) *d.n_active = 0;
     const bool act = (b < d.B) && (force || d.phase[b] == PH_ACTIVE);
     if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;   // the same trajectories in every wave of the workgroup: all leave
     if (threadIdx.x == 0) {
-      s_ret = 0; s_verdict = 1; s_hdone = 0;
+      s_ret = 0; s_verdict = 1; s_hdone = 0; s_phase2 = 0; s_dxprod = 0; s_pdone = 0;
+      s_take = (((N + RC::SPB - 1) / RC::SPB - 1) << 16);     // front = 0, back = last block
+#pragma unroll
+      for (int i = 0; i < NH; ++i) s_cur[i] = 0;              // block a helper works on (nothing below it is still needed by that helper)
 #pragma unroll
       for (int i = 0; i < RB; ++i) s_ready[i] = 0;
     }
@@ -155,6 +272,7 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
       // ---------------------------------------------------------------- helper wavefront: lane = (step offset so, trajectory tl)
       const int hidx = wave - 1;
       const int so = lane / C::TPW;
+      if (hidx == 0) { ROLES_STAMP(8); ROLES_ZERO(13); }
       const int cur = act ? d.cur[b] : 0;
       const double *Xc = d.X + (size_t)cur * d.planeX;
       const double *Uc = d.U + (size_t)cur * d.planeU;
@@ -163,21 +281,28 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
       const double *Gc = d.G + (size_t)cur * d.planeM;
       const double mu = act ? d.mu[b] : 1.0;
       constexpr int M = Cons::M;
+      // (the rows of a block are requested one block ahead: a pass of this wave is otherwise one memory round trip + the arithmetic)
+      struct HIn { double x[NX], u[NU], y[M], sv[M], g[M]; };
+      auto hload = [&](int j, HIn &r) {
+        const int t = N - 1 - (j * RC::SPB + so);
+        if (act && j < nblk && t >= 0) {
+          ld<NX>(Xc + GI(t, NX, 0), kLS, r.x);
+          ld<NU>(Uc + GI(t, NU, 0), kLS, r.u);
+          ld<M>(Yc + GI(t, M, 0), kLS, r.y);
+          ld<M>(Sc + GI(t, M, 0), kLS, r.sv);
+          ld<M>(Gc + GI(t, M, 0), kLS, r.g);
+        }
+      };
       for (int pass = 0;; ++pass) {
-        for (int j = hidx; j < nblk; j += NH) {
+        auto hstep = [&](const int j, const HIn &in, HIn &nxt) {
+          if (j >= nblk) return;
+          hload(j + NH, nxt);
+          PIPELINE_FENCE();
           const int gj = pass * nblk + j;
           const int t = N - 1 - (j * RC::SPB + so);
           const bool valid = act && t >= 0;
-          double A[NX * NX], Bq[NX * NU], c[CST];
-          if (valid) {
-            double x[NX], u[NU], y[M], sv[M], g[M];
-            ld<NX>(Xc + GI(t, NX, 0), kLS, x);
-            ld<NU>(Uc + GI(t, NU, 0), kLS, u);
-            ld<M>(Yc + GI(t, M, 0), kLS, y);
-            ld<M>(Sc + GI(t, M, 0), kLS, sv);
-            ld<M>(Gc + GI(t, M, 0), kLS, g);
-            condense_eval<Model, Cons, true>(P, xrt, t, x, u, y, sv, g, mu, A, Bq, c);
-          }
+          double A[NX * NX], Bq[NX * NU], c[CST], ysr[M];
+          if (valid) condense_eval<Model, Cons, true>(P, xrt, t, in.x, in.u, in.y, in.sv, in.g, mu, A, Bq, c, ysr);
           if (gj >= RB) wait_ge(&s_ret, (gj - RB + 1) * RC::SPB);   // the slot's previous block has been taken into registers
           if (valid) {
             double *r = s_ring + ((size_t)((gj % RB) * RC::SPB + so) * C::TPW + tl) * RC::RECP;
@@ -192,15 +317,28 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
               for (int i = 0; i < NX * NX; ++i) d.A[GI(t, NX * NX, i)] = A[i];
 #pragma unroll
               for (int i = 0; i < NX * NU; ++i) d.Bm[GI(t, NX * NU, i)] = Bq[i];
+              st<M>(d.ys + GI(t, M, 0), kLS, ysr);   // Y S^-1 (K3's third row set): mu-, y- and s-dependent only, phase 2 reads it back
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __hip_atomic_store(&s_ready[gj % RB], gj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+          if (hidx == 0 && gj == 0) ROLES_STAMP(9);
+        };
+        HIn ha, hb;
+        hload(hidx, ha);
+        for (int j = hidx; j < nblk; j += 2 * NH) { hstep(j, ha, hb); hstep(j + NH, hb, ha); }
+        if (hidx == 0 && pass == 0) ROLES_STAMP(10);
         if (wait_ge(&s_verdict, pass + 2) >= RC::kDone) break;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // A_t, B_t visible to the recursion wave's dX rollout
       if (lane == 0) __hip_atomic_fetch_add(&s_hdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // ---- phase 2 (forward in t): what k_post evaluates, block by block behind the recursion wave's dX rollout
+      if (wait_ge(&s_phase2, 1) != 1) return;                  // nobody takes a step (converged / failed): nothing to post
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // K, k of the sweep
+      if (hidx == 0) ROLES_STAMP(11);
+      post_phase(so, act && s_need[tl] != 0, mu, cur, true, hidx);
+      if (hidx == 0) ROLES_STAMP(12);
+      if (lane == 0) __hip_atomic_fetch_add(&s_pdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
     }
   }
@@ -208,6 +346,7 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
   if (!force && d.phase[b] != PH_ACTIVE) return;
   double *Ls = lds + tl * C::STRIDE;
   const cddp_hip_options &o = P->opt;
+  if constexpr (ROLES) { ROLES_STAMP(0); ROLES_ZERO(6); ROLES_ZERO(7); }
   const int cur = d.cur[b];
   const double *Xc = d.X + (size_t)cur * d.planeX;
   if (count_iter && q == 0) d.iter[b] += 1;
@@ -496,7 +635,13 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
       const int gb0 = (nb - 1) * nblk;
       auto need_block = [&](int k) {   // the block of step index k (this pass)
         const int j = k / RC::SPB;
+#ifdef CDDP_ROLES_TIMING
+        const unsigned long long w0 = wall_clock64();
+#endif
         wait_ge(&s_ready[(gb0 + j) % RB], gb0 + j + 1);
+#ifdef CDDP_ROLES_TIMING
+        if (k > 0) ROLES_ACC(6, wall_clock64() - w0);
+#endif
       };
       auto retire = [&](int k) {       // step index k has run: its record and the prefetched one are in registers
         if ((k + 1) % RC::SPB == 0 || k == N - 1) {
@@ -506,6 +651,7 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
         }
       };
       need_block(0);
+      if (nb == 1) ROLES_STAMP(1);
       load1(N - 1, a1);
       load2(N - 1, a2);
       int t = N - 1;
@@ -544,10 +690,140 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
     }
   }
   if constexpr (ROLES) {   // the helpers' A_t, B_t stores, before the dX rollout reads them
+    ROLES_STAMP(2);
     wait_ge(&s_hdone, NH);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   bool conv = false;
+  [[maybe_unused]] double apr_cap = 1.0, adu_cap = 1.0;
+  if constexpr (ROLES) {
+    if (ok) {
+      const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
+      const double asn = fabs(d.alpha_pr[b]) * step_norm;
+      const double sdu_early = scaled_inf_du_v<Model, Cons>(d, b, cur, inf_du);   // computeScaledDualInfeasibility (:931)
+      conv = (inf_pr < tol && sdu_early < tol && inf_comp < tol && asn < o.tolerance * 10.0);
+    }
+    const bool need = ok && (!conv || force);   // the trajectories k_post serves: phase FWD1 / (force) a successful sweep
+    const bool any_need = __builtin_amdgcn_ballot_w64(need) != 0ull;
+    if (q == 0) {
+      s_need[tl] = need ? 1 : 0;
+      s_aprv[tl] = (unsigned long long)__double_as_longlong(1.0); s_aduv[tl] = (unsigned long long)__double_as_longlong(1.0);
+    }
+    double *dxr = s_ring;
+    dxr[((size_t)0 * C::TPW + tl) * NX + qc] = 0.0;              // dx_0 = 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // K, k of the sweep visible to the helpers
+    lds_sync();
+    __hip_atomic_store(&s_dxprod, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&s_phase2, any_need ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ROLES_STAMP(3);
+    if (any_need) {
+      // rolloutLinearPolicy, dx0 = 0 (ipddp_solver.cpp:1511-1520): lane qc computes row qc of dx_{t+1}; every lane of the wave walks the
+      // horizon (a trajectory that takes no step computes on its stale gains: nobody reads its rows), so the ring counters are wave-uniform
+      double dx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+      // One wave sustains ~16 row loads per memory round trip (profiles/ubench/vmem.hip), and that -- not the ~90-cycle arithmetic of a
+      // step -- paces this loop (round 6 stamps: 0.19 us per step at C2 with NU + NU NX + NX + NU = 10 loads per step, 0.5 at C3 with 13).
+      // At G = 4 the gains, which every lane of a trajectory needs whole, are therefore fetched ONE COLUMN PER LANE (lane q: K[:, q] and
+      // k[q]) and spread over the quad by DPP broadcasts: NU + 1 + NX + NU loads per step instead of NU + NU NX + NX + NU.
+      constexpr bool kQ = C::G == 4;
+      constexpr bool kQL = kQ && NU <= 4;
+      struct RIn { double kk[kQL ? 1 : NU], KK[kQL ? NU : NU * NX], Aq[NX], Bq[NU]; };
+      const int qk = q < NU ? q : NU - 1;   // (kQL) the entry of k this lane fetches
+      auto load_r = [&](int tt, RIn &r) {
+        if constexpr (kQL) {
+          r.kk[0] = d.k[GI(tt, NU, qk)];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) r.KK[i] = d.K[GI(tt, NU * NX, i * NX + qc)];
+        } else {
+          ld<NU>(d.k + GI(tt, NU, 0), kLS, r.kk);
+          ld<NU * NX>(d.K + GI(tt, NU * NX, 0), kLS, r.KK);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) r.Aq[j] = d.A[GI(tt, NX * NX, qc * NX + j)];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) r.Bq[j] = d.Bm[GI(tt, NX * NU, qc * NU + j)];
+      };
+      auto clampt = [&](int tt) { return tt < N - 1 ? tt : (N - 2 > 0 ? N - 2 : 0); };
+      // A step is ~150 cycles of dependent arithmetic; the rows of step t + D - 1 are requested while step t runs (D register sets), so
+      // that a memory round trip (0.4 - 1 us under load) is covered; at G = 4 the lanes of a trajectory are a DPP quad and exchange the
+      // rows of dx by quad broadcast -- the LDS write only feeds the ring and is published one step late, when it has long landed
+      // (round 6 stamps, profiles/r06_sweep_roles.md: 0.37 us per step with D = 4 and two LDS round trips on the chain).
+      // (D - 1 steps of rows in flight: at most ~56 loads, the vmcnt counter holds 63; the main loop has NO branch around a load --
+      //  the waitcnt pass merges the states at every join and would otherwise wait for all but the newest step's rows)
+      constexpr int kRows = (int)(sizeof(RIn) / sizeof(double));
+#ifdef CDDP_ROLES_D
+      constexpr int D = CDDP_ROLES_D;
+#else
+      constexpr int D = kRows > 28 ? 2 : (1 + 56 / kRows > 8 ? 8 : 1 + 56 / kRows);
+#endif
+      auto dstep = [&](const int t, const RIn &rc, RIn &rl, const bool fetch) {
+        if (fetch) { load_r(clampt(t + D - 1), rl); PIPELINE_FENCE(); }
+        lds_sync();                                                    // dx_t went into the ring one step ago
+        __hip_atomic_store(&s_dxprod, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        double du[NU];
+        if constexpr (kQL) {
+          double kv[4];
+          quad_gather<NU>(rc.kk[0], kv);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) {
+            double Kr[4];
+            quad_gather<NX>(rc.KK[i], Kr);
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a += Kr[j] * dx[j];
+            du[i] = kv[i] + a;
+          }
+        } else {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) a += rc.KK[i * NX + j] * dx[j];
+          du[i] = rc.kk[i] + a; }
+        }
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) a += rc.Aq[j] * dx[j];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) c += rc.Bq[j] * du[j];
+        const double dxq = (a + c) + 0.0;
+        const int w = t + 1;
+        if (w % RC::SPB == 0 && w >= RD) {   // the slot's previous tenant (step w - RD and its block) has been read by every helper
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) wait_ge(&s_cur[hh], (w - RD) / RC::SPB + 1);
+        }
+        double *slot = dxr + ((size_t)(w % RD) * C::TPW + tl) * NX;
+        slot[qc] = dxq;
+        if constexpr (kQ) quad_gather<NX>(dxq, dx);
+        else {
+          lds_sync();
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dx[i] = slot[i];
+        }
+      };
+      {
+        RIn R[D];
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_r(clampt(j), R[j]);
+        int t = 0;
+        for (; t + D <= N - 1; t += D) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) dstep(t + j, R[j], R[(j + D - 1) % D], true);
+        }
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) if (t + j < N - 1) dstep(t + j, R[j], R[j], false);   // (their rows are in the sets already)
+      }
+      lds_sync();
+      __hip_atomic_store(&s_dxprod, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ROLES_STAMP(4);
+      post_phase(q, need, mu, cur, false, -1);   // the rollout is done: this wave takes blocks from the back
+      ROLES_STAMP(14);
+      wait_ge(&s_pdone, NH);
+      ROLES_STAMP(5);
+      lds_sync();
+      if (need) { apr_cap = __longlong_as_double((long long)s_aprv[tl]); adu_cap = __longlong_as_double((long long)s_aduv[tl]); }
+    }
+  } else
   if (ok) {
     const double tol = dmax(o.tolerance, o.ipddp_barrier_tol_mult * mu);
     const double asn = fabs(d.alpha_pr[b]) * step_norm;
@@ -653,7 +929,8 @@ __global__ __launch_bounds__(64 * (1 + NH)) void k_backward_ipddp_coop(DevBuf d,
   d.reg[b] = reg;
   d.n_bwd[b] += nb;
   d.bwd_ok[b] = ok ? 1 : 0;
-  d.apr_max[b] = 1.0; d.adu_max[b] = 1.0;        // K3 lowers them by atomic min
+  if constexpr (ROLES) { d.apr_max[b] = apr_cap; d.adu_max[b] = adu_cap; }   // the helpers' minima over the horizon (1.0: no step taken)
+  else { d.apr_max[b] = 1.0; d.adu_max[b] = 1.0; }        // K3 lowers them by atomic min
   if (ok) {
     d.dV0[b] = dV0; d.dV1[b] = dV1; d.inf_du[b] = inf_du; d.step_norm[b] = step_norm;
     d.inf_pr[b] = inf_pr; d.inf_comp[b] = inf_comp;

@@ -36,7 +36,8 @@ struct CstLayout {
 // cddp_solver_base.cpp:319-394).
 template <class Model, class Cons, bool WITH_DERIVS>
 DEV void condense_eval(const ProblemDev *__restrict__ P, const double *__restrict__ xrt, const int t, const double *x, const double *u,
-                       const double *y, const double *s, const double *g, const double mu, double *A, double *Bq, double *c) {
+                       const double *y, const double *s, const double *g, const double mu, double *A, double *Bq, double *c,
+                       double *ys_out = nullptr) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
   typedef Objective<NX, NU> Obj;
   typedef CstLayout<Model, Cons> L;
@@ -85,6 +86,10 @@ DEV void condense_eval(const ProblemDev *__restrict__ P, const double *__restric
     const double rhat = y[i] * rp - rc;
     Sir[i] = clip_sgn(rhat, ss);
     ipr = dmax(ipr, fabs(rp)); icomp = dmax(icomp, fabs(rc));
+  }
+  if (ys_out) {   // (role-split sweep) the ratios Y S^-1 k_post would form again from the same y, s, mu
+#pragma unroll
+    for (int i = 0; i < M; ++i) ys_out[i] = YS[i];
   }
   double W[NU * M], WQyu[NU * NU], QyuSir[NU];
 #pragma unroll
@@ -426,6 +431,64 @@ DEV void atomic_min_pos(double *addr, double v) {   // v >= 0: the IEEE bit patt
 }
 
 // ================================================================================ K3
+// The per-(trajectory, step) arithmetic of K3 in two device functions, shared by the wide kernel below and by the helper wavefronts of the
+// role-split sweep (kernels_coop.hpp): post_rows = everything that does not need dx_t -- k_y, k_s, Y S^-1 and the rows of K_y, K_s
+// (ipddp_solver.cpp:1458-1486); post_caps = dS, dY of the linear-policy rollout (:1522-1532) and the fraction-to-boundary caps (:2939-2988).
+// HAVE_YS: ysv[] comes in (the role-split sweep's helpers stored the ratios when they condensed the step) instead of being formed here.
+template <class Model, class Cons, bool HAVE_YS = false>
+DEV void post_rows(const ProblemDev *__restrict__ P, const double *x, const double *uj, const double *y, const double *s, const double *g,
+                   const double *kk, const double *KK, const double mu, double *ky, double *ksv, double *ysv, double *Ky, double *Ksm) {
+  constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
+  const double s_floor = dmax(mu * 1e-3, kEpsSlack);
+  double Qyx[M * NX], Qyu[M * NU];
+#pragma unroll
+  for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
+  Cons::template jac<NX, NU>(P, x, uj, Qyx, Qyu);
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    const double ss = dmax(s[r], s_floor);
+    double YSr;
+    if constexpr (HAVE_YS) YSr = ysv[r]; else { YSr = clip_pos(y[r], ss); ysv[r] = YSr; }
+    const double rp = g[r] + s[r];
+    const double rc = y[r] * s[r] - mu;
+    const double rhat = y[r] * rp - rc;
+    double temp = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) temp += Qyu[r * NU + i] * kk[i];
+    ky[r] = clip_sgn(rhat + y[r] * temp, ss);
+    ksv[r] = (-rp) - temp;
+#pragma unroll
+    for (int cc = 0; cc < NX; ++cc) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) s2 += Qyu[r * NU + i] * KK[i * NX + cc];
+      const double inner = Qyx[r * NX + cc] + s2;
+      Ky[r * NX + cc] = dmin(dmax(YSr * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
+      Ksm[r * NX + cc] = (-Qyx[r * NX + cc]) - s2;
+    }
+  }
+}
+template <int NX, int M>
+DEV void post_caps(const double *ky, const double *ksv, const double *Ky, const double *Ksm, const double *s, const double *y, const double *dx,
+                   const double tau, double &apr, double &adu) {
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    double a = 0.0, c = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
+    const double ds = ksv[r] + a;
+    const double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
+    // apr, adu start at 1 and only fall, so a quotient >= 1 changes nothing; with a negative denominator the exact quotient num / den
+    // is >= 1 exactly when num <= den, and rounding to nearest keeps it >= 1 (1 is representable): the division is evaluated only by
+    // wavefronts in which some lane's cap can bind -- same bits, most steps of a solve skip both divisions
+    const double nps = -tau * s[r], npy = -tau * y[r];
+    if (__builtin_amdgcn_ballot_w64(ds < 0.0 && !(nps <= ds)) != 0ull) { if (ds < 0.0) apr = dmin(apr, nps / ds); }
+    if (__builtin_amdgcn_ballot_w64(dy < 0.0 && !(npy <= dy)) != 0ull) { if (dy < 0.0) adu = dmin(adu, npy / dy); }
+  }
+}
+
 template <class Model, class Cons>
 __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restrict__ Pk, int force) {
   constexpr int NX = Model::NX, NU = Model::NU, M = Cons::M;
@@ -442,9 +505,8 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
   const double *Yc = d.Y + (size_t)cur * d.planeM;
   const double *Gc = d.G + (size_t)cur * d.planeM;
   const double mu = d.mu[b];
-  const double s_floor = dmax(mu * 1e-3, kEpsSlack);
   const double tau = dmax(o.barrier_min_fraction_to_boundary, 1.0 - mu);
-  double x[NX], y[M], s[M], g[M], Qyx[M * NX], Qyu[M * NU], kk[NU], KK[NU * NX], dx[NX];
+  double x[NX], y[M], s[M], g[M], kk[NU], KK[NU * NX], dx[NX];
   ld<NX>(Xc + GI(t, NX, 0), kLS, x);
   ld<M>(Yc + GI(t, M, 0), kLS, y);
   ld<M>(Sc + GI(t, M, 0), kLS, s);
@@ -452,45 +514,12 @@ __global__ __launch_bounds__(64) void k_post(DevBuf d, const ProblemDev *__restr
   ld<NU>(d.k + GI(t, NU, 0), kLS, kk);
   ld<NU * NX>(d.K + GI(t, NU * NX, 0), kLS, KK);
   ld<NX>(d.dX + GI(t, NX, 0), kLS, dx);
-#pragma unroll
-  for (int i = 0; i < M * NX; ++i) Qyx[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < M * NU; ++i) Qyu[i] = 0.0;
   double uj[NU];
   if constexpr (Cons::NEEDS_U) ld<NU>(d.U + (size_t)cur * d.planeU + GI(t, NU, 0), kLS, uj);
-  Cons::template jac<NX, NU>(P, x, uj, Qyx, Qyu);
   double ky[M], ksv[M], Ky[M * NX], Ksm[M * NX], ysv[M];
   double apr = 1.0, adu = 1.0;
-#pragma unroll
-  for (int r = 0; r < M; ++r) {
-    const double ss = dmax(s[r], s_floor);
-    const double YSr = clip_pos(y[r], ss);
-    ysv[r] = YSr;
-    const double rp = g[r] + s[r];
-    const double rc = y[r] * s[r] - mu;
-    const double rhat = y[r] * rp - rc;
-    double temp = 0.0;
-#pragma unroll
-    for (int i = 0; i < NU; ++i) temp += Qyu[r * NU + i] * kk[i];
-    ky[r] = clip_sgn(rhat + y[r] * temp, ss);
-    ksv[r] = (-rp) - temp;
-    double a = 0.0, c = 0.0;
-#pragma unroll
-    for (int cc = 0; cc < NX; ++cc) {
-      double s2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) s2 += Qyu[r * NU + i] * KK[i * NX + cc];
-      const double inner = Qyx[r * NX + cc] + s2;
-      Ky[r * NX + cc] = dmin(dmax(YSr * inner, -kMaxBarrierRatio), kMaxBarrierRatio);
-      Ksm[r * NX + cc] = (-Qyx[r * NX + cc]) - s2;
-    }
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { a += Ksm[r * NX + j] * dx[j]; c += Ky[r * NX + j] * dx[j]; }
-    const double ds = ksv[r] + a;
-    const double dy = dmin(dmax(ky[r] + c, -kMaxBarrierRatio), kMaxBarrierRatio);
-    if (ds < 0.0) apr = dmin(apr, -tau * s[r] / ds);
-    if (dy < 0.0) adu = dmin(adu, -tau * y[r] / dy);
-  }
+  post_rows<Model, Cons>(P, x, uj, y, s, g, kk, KK, mu, ky, ksv, ysv, Ky, Ksm);
+  post_caps<NX, M>(ky, ksv, Ky, Ksm, s, y, dx, tau, apr, adu);
   // The feedback blocks K_s = -(G_x + G_u K), K_y = clamp(YS (G_x + G_u K)) are NOT stored: the rollout consumer
   // rebuilds the rows it needs from K and YS with this very arithmetic (2 M NX fewer rows per step to write here
   // and to read there, where VMEM issue is the scarce resource).

@@ -150,7 +150,7 @@ struct Launcher {
   }
   // Role-split sweep (round 6, kernels_coop.hpp::k_backward_ipddp_coop<.., NH > 0>): helper wavefronts in the sweep workgroup evaluate
   // what k_condense<.., true> evaluates and feed the recursion wave through an LDS ring -- one launch instead of two, no condensed-term
-  // stack.  CDDP_HIP_SWEEP_ROLES = 0 (the separate kernels; comparison side of the bitwise test) | 1 | 2 | 3 helpers; read per launch, derivs()
+  // stack.  CDDP_HIP_SWEEP_ROLES = 0 (the separate kernels; comparison side of the bitwise test) | 1 | 2 helpers; read per launch, derivs()
   // and backward() of one iteration see the same answer.
   template <int RB> static constexpr bool roles_fit() {
     if constexpr (!kLean || Model::NX > 8) return false;
@@ -163,7 +163,7 @@ struct Launcher {
       if (!(d.cst && !d.ms && !d.lg) || d.ddp) return 0;
       if (lane_sweep_requested() || elem_sweep_requested()) return 0;
       int nh = 1;   // measured (profiles/r06_sweep_roles.md): one helper 43.1 -> 39.9 ms at C2, 77.5 -> 67.5 at C3; two / three helpers: 40.4 / 41.2 and 77.9 / 80.1
-      if (const char *e = std::getenv("CDDP_HIP_SWEEP_ROLES")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) nh = v; }
+      if (const char *e = std::getenv("CDDP_HIP_SWEEP_ROLES")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) nh = v; }
       return nh;
     }
   }
@@ -293,14 +293,10 @@ struct Launcher {
             if (nh == 1) {
               if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 1, 3>), gridC, dim3(128), 0, ss, d, d.P, d.xref_traj, force, count_iter);
               else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 1, 2>), gridC, dim3(128), 0, ss, d, d.P, d.xref_traj, force, count_iter);
-            } else if (nh == 2) {
+            } else {
               if constexpr (roles_fit<4>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 4>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
               else if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 3>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
               else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 2, 2>), gridC, dim3(192), 0, ss, d, d.P, d.xref_traj, force, count_iter);
-            } else {
-              if constexpr (roles_fit<4>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 4>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
-              else if constexpr (roles_fit<3>()) hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 3>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
-              else hipLaunchKernelGGL((k_backward_ipddp_coop<Model, Cons, 3, 2>), gridC, dim3(256), 0, ss, d, d.P, d.xref_traj, force, count_iter);
             }
             sweep_hop_out(s);
             launched = true;
@@ -311,6 +307,7 @@ struct Launcher {
           sweep_hop_out(s);
         }
       }
+      if constexpr (kRoles) { if (roles_nh(d0) > 0 && !lane_sweep && !elem_sweep_requested()) return; }   // the role-split sweep's helpers did K3's work
       hipLaunchKernelGGL((k_post<Model, Cons>), dim3((d.B + 63) / 64, d.N), dim3(64), 0, s, d, d.P, force);
     } else if constexpr (!TERM && Cons::M == 0) {
       if (lane_sweep)
