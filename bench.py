@@ -110,10 +110,11 @@ def make_problem(api, workload, solver):
 
 
 # committed PMC traffic summaries (profiles/make_traffic_json.py) per (workload, solver, batch)
-TRAFFIC_FILES = {("cartpole", "ipddp", 4096): "r05_pmc_traffic.json", ("quadrotor", "ipddp", 2048): "r05_pmc_traffic_quadrotor.json",
+TRAFFIC_FILES = {("cartpole", "ipddp", 4096): "r06_pmc_traffic.json", ("quadrotor", "ipddp", 2048): "r05_pmc_traffic_quadrotor.json",
                  ("manip7", "ipddp", 4096): "r05_pmc_traffic_manip7.json", ("cartpole", "clddp", 4096): "r05_pmc_traffic_clddp.json",
-                 ("unicycle", "ipddp", 8192): "r05_pmc_traffic_unicycle.json", ("cartpole", "logddp", 4096): "r05_pmc_traffic_logddp.json",
+                 ("unicycle", "ipddp", 8192): "r06_pmc_traffic_unicycle.json", ("cartpole", "logddp", 4096): "r05_pmc_traffic_logddp.json",
                  ("pendulum", "msipddp", 4096): "r05_pmc_traffic_msipddp.json"}
+ASSOC_ORDER_FILE = "r06_assoc_order.json"             # tests/test_cross_arithmetic.py::test_bench_batch_against_eigen_order_checker, collected by profiles/scripts/collect_parity_reports.py
 CROSS_ARITHMETIC_FILE = "r05_cross_arithmetic.json"   # tests/test_cross_arithmetic.py's reports, copied from gpurun_out/
 STRONG_GLOBAL_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 16384, "manip7": 32768}
 DEFAULT_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 2048, "manip7": 4096}
@@ -149,7 +150,7 @@ def cpu_baseline(api, p, x0, U0, budget_s=20.0):
     the capacity fitted to the workload's largest matrix (-DORACLE_MAT_CAP).  Each build walks a THREAD LADDER 1, 2, 4, ... up to the
     CPUs this process may use (available_cpus(): affinity capped by the cgroup quota, not os.cpu_count()), one work-queue run per
     rung on the first trajectories of the same batch (at least 8 per rung, so the single-thread figure is not a two-trajectory sample);
-    `value` is the best rung of the faster build and `cores` the thread count of THAT rung."""
+    `value` is the best rung of the faster build, `threads` the thread count of THAT rung and `cores` the CPUs the lease may use."""
     ncpu, cpu_info = available_cpus()
     oa = load_oracle_api()
     oa.attach(api)
@@ -212,7 +213,7 @@ def cpu_baseline(api, p, x0, U0, budget_s=20.0):
                 "provides fewer physical cores than the affinity mask / quota advertises or the cores are shared SMT siblings; the checker itself "
                 "is a lock-free work queue of independent solver objects (oracle/cddp_oracle.cpp::cddp_oracle_solve_batch)" % (rb["threads"], scaling))
     return {
-        "value": rb["value"], "unit": "trajectories/s", "cores": rb["threads"], "kind": "port",
+        "value": rb["value"], "unit": "trajectories/s", "cores": ncpu, "threads": rb["threads"], "kind": "port",   # cores = CPUs the lease may use; threads = the best rung's thread count
         "sample": "first %d trajectories of the same batch on %d host threads (best rung of the ladder %s), oracle (Eigen-free CPU restatement, "
                   "-O3 -march=native, build '%s')" % (rb["sample_trajectories"], rb["threads"], [r for r in ladder], best),
         "single_thread_value": rb.get("single_thread_value"), "single_thread_trajectories": rb.get("single_thread_trajectories"),
@@ -235,6 +236,16 @@ def parity_block():
         out["cross_arithmetic_source"] = "profiles/%s (%s)" % (CROSS_ARITHMETIC_FILE, cj["source"])
     except Exception:
         out["cross_arithmetic_vs_glibc_checker"] = None
+    # round 6: summation ORDER -- the library (serial sums) against the checker in Eigen 3.4's SSE2 packet order as restated in
+    # oracle/linalg.hpp::assoc_mode (a reading of Eigen's kernels, not a measurement: no Eigen in the build image)
+    try:
+        aj = json.load(open(os.path.join(REPO, "profiles", ASSOC_ORDER_FILE)))
+        out["summation_order_vs_eigen_packet_model"] = {
+            w: {"compared": d["compared"], "count_flip_frac": d["count_flip_frac"], "work_flip_frac": d["work_flip_frac"],
+                "objective_1e-7_mismatch_frac": d["objective_1e-7_mismatch_frac"], "bitwise_equal_objective_frac": d["bitwise_equal_objective_frac"]} for w, d in aj["workloads"].items()}
+        out["summation_order_source"] = "profiles/%s (%s)" % (ASSOC_ORDER_FILE, aj["source"])
+    except Exception:
+        out["summation_order_vs_eigen_packet_model"] = None
     return out
 
 
@@ -264,7 +275,8 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
             sweep_label = "k_derivs+k_te_condense+k_backward_te_coop+k_te_post"
         elif lean:
             # (nx <= 8: the derivative fill is fused into k_condense<.., true>, launch.hpp::derivs -- there is no k_derivs launch)
-            sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big2+k_post" if p.nx > 8 else "k_condense+k_backward_ipddp_coop+k_post"
+            # (round 6, nx <= 8: ONE launch -- the role-split sweep's helper wavefronts do k_condense's and k_post's work, kernels_coop.hpp)
+            sweep_label = "k_derivs+k_condense+k_backward_ipddp_coop_big2+k_post" if p.nx > 8 else "k_backward_ipddp_coop"
         elif solver == "msipddp":  # resident MSIPDDP (kernels_msipddp.hpp): the split path-constrained sweep (round 5), the fused one-lane kernel otherwise
             # (path rows, nx <= 8: the derivative fill rides in k_ms_condense<.., true> -- no k_derivs launch)
             sweep_label = (("k_ms_condense+k_backward_msipddp_lean+k_ms_post" if p.nx <= 8 else "k_derivs+k_ms_condense+k_backward_msipddp_lean+k_ms_post")
@@ -307,6 +319,11 @@ def roofline_block(api, p, m, B, workload, solver, st, prof, stats, sweep_domina
     exceeds = [name for name, g in (("backward", gbps_bwd), ("forward", gbps_fwd), ("whole_solve", gbps_all)) if g > PEAK]
     return {
         "bound": "hbm", "kernel": dom[0], "achieved": dom[1], "peak": PEAK, "unit": "GB/s", "frac": dom[1] / PEAK,
+        # the two readings of `frac` under the static CU partition: `frac_paired` = the concurrent launches of all tile
+        # groups together against the whole chip's peak (= frac); `frac_per_kernel_on_its_partition` = ONE group's launch (what a rocprof
+        # per-kernel average times) against the whole chip's peak, i.e. frac / groups in flight.  The overlap itself is kept as a kernel-trace
+        # excerpt with both groups' start / end stamps: profiles/r06_group_overlap.md
+        "frac_paired": dom[1] / PEAK, "frac_per_kernel_on_its_partition": dom[1] / PEAK / max(1, concurrency),
         "concurrent_groups": concurrency, "tile_groups": groups,
         "launch_definition": ("one launch = the %d concurrent half-batch launches of the static CU partition (each group on its own half of the CUs, "
                               "cddp_hip_concurrency); class times are the mean over the concurrent groups' streams, so a per-kernel rocprof "

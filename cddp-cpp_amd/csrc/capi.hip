@@ -411,16 +411,31 @@ static bool cu_spec_for_group(int gi, CuSpec *o) {
   *o = sp;
   return true;
 }
+static int device_cu_count(int device) {
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+  return ncu;
+}
+// A mask that selects no CU of THIS device (a spec written for 256 CUs on a 128-CU partition), or a runtime that refuses the masked
+// stream, must not fail the handle: the group then runs on a plain stream (same results -- the partition is placement only).
 static hipError_t make_stream(hipStream_t *s, int device, int lo, int hi, unsigned xcd = 0) {
   if (lo < 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-  int ncu = 0;
-  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-  if (ncu <= 0) ncu = 256;
+  const int ncu = device_cu_count(device);
   const int words = (ncu + 31) / 32;
   std::vector<uint32_t> mask((size_t)words, 0u);
-  for (int b = lo; b < hi && b < ncu; ++b) if (!xcd || ((xcd >> (b % 8)) & 1u)) mask[(size_t)b >> 5] |= 1u << (b & 31);
-  return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask.data());
+  int bits = 0;
+  for (int b = lo; b < hi && b < ncu; ++b) if (!xcd || ((xcd >> (b % 8)) & 1u)) { mask[(size_t)b >> 5] |= 1u << (b & 31); ++bits; }
+  if (bits == 0) {
+    std::fprintf(stderr, "[cddp_hip] CU mask [%d, %d) selects none of the device's %d CUs: plain stream instead\n", lo, hi, ncu);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  }
+  const hipError_t e = hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask.data());
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  std::fprintf(stderr, "[cddp_hip] hipExtStreamCreateWithCUMask([%d, %d) of %d CUs): %s -- plain stream instead\n", lo, hi, ncu, hipGetErrorString(e));
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
+static int in_destroy(Inner *h);
 
 static int in_create(const cddp_hip_problem *problem, int batch, int device, Inner **out, const CuSpec *cu = nullptr) {
   if (!problem || !out) return fail(-1, "null argument");
@@ -468,7 +483,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
     if (cu->lo[1] >= 0) e = make_stream(&h->cu.fwd, device, cu->lo[1], cu->hi[1], cu->xcd[1]);
     if (e == hipSuccess && cu->lo[2] >= 0) e = make_stream(&h->cu.sweep, device, cu->lo[2], cu->hi[2], cu->xcd[2]);
     for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&h->cu.ev[k], hipEventDisableTiming);
-    if (e != hipSuccess) { delete h; return fail(-10, "CU-masked stream: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { const int rc_ = fail(-10, "CU-masked stream: %s", hipGetErrorString(e)); in_destroy(h); return rc_; }   // (streams / events created so far go with it)
     h->cu.hop = SweepHop{h->cu.sweep, h->cu.ev[4], h->cu.ev[5]};
   }
 
@@ -479,7 +494,8 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   d.B = B; d.Bp = Bp; d.NB = Bp / 64; d.N = N; d.n_alphas = P.n_alphas; d.n_slots = P.n_alphas + 1;
   d.ladder_sorted = ladder_strictly_decreasing(P.alphas, P.n_alphas);
   d.ddp = P.opt.use_ilqr ? 0 : 1;
-  { const char *e = std::getenv("CDDP_HIP_TEST_FAIL_COSTATE"); d.fail_costate_mask = e ? std::atoi(e) : 0; }   // test hook, DevBuf::fail_costate_mask
+  { const char *e = std::getenv("CDDP_HIP_TEST_FAIL_COSTATE"); d.fail_costate_mask = e ? std::atoi(e) : 0;   // test hook, DevBuf::fail_costate_mask
+    if (d.fail_costate_mask) std::fprintf(stderr, "[cddp_hip] TEST HOOK active: CDDP_HIP_TEST_FAIL_COSTATE=%d discards line-search trials -- results are not the solver's\n", d.fail_costate_mask); }
   { const char *e = std::getenv("CDDP_HIP_XCD_MAP"); d.xcd_map = (e && e[0] == '0') ? 0 : 1; }
   d.t4 = 0;   // set per launch by launch.hpp::derivs / backward (kernels.hpp::GT)
   d.hist_batch = P.opt.return_iteration_info ? std::min(B, 64) : 0;
@@ -490,7 +506,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   const bool ms = (P.solver == CDDP_HIP_SOLVER_MSIPDDP);
   d.ms = ms ? 1 : 0;
   d.filt_cap = ms ? std::max(P.opt.max_iterations, 0) + 2 : kFilterCap;   // (a negative max_iterations is a legal no-op solve, SolveRun::begin)
-#define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { free_all(h); delete h; return rc_; } } while (0)
+#define DA(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) { in_destroy(h); return rc_; } } while (0)
   DA(d.X, d.planeX * d.n_slots); DA(d.U, d.planeU * d.n_slots);
   if (ip) { DA(d.S, d.planeM * d.n_slots); DA(d.Y, d.planeM * d.n_slots); DA(d.G, d.planeM * d.n_slots); DA(d.Lam, d.planeX * d.n_slots); }
   if (ms) {   // kernels_msipddp.hpp: slack / dual / constraint / costate / dynamics-value planes per slot, costate gains, factor cache
@@ -555,7 +571,7 @@ static int in_create(const cddp_hip_problem *problem, int batch, int device, Inn
   d.P = h->dP;
   d.launched = h->d_launched;
   e = hipStreamSynchronize(h->stream);
-  if (e != hipSuccess) { free_all(h); delete h; return fail(-10, "device initialisation failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { const int rc_ = fail(-10, "device initialisation failed: %s", hipGetErrorString(e)); in_destroy(h); return rc_; }
   *out = h;
   return 0;
 }
@@ -964,6 +980,10 @@ struct SolveRun {
     // 3 after update 1, 4 after rollout stage 2, 5 after update 2).  Every event costs ~5 us of queue time, so only
     // the points the selected detail needs are recorded (cddp_hip_set_timing_detail): 2 per iteration by default.
     { const char *e = std::getenv("CDDP_HIP_GRAPH"); use_graph = e && e[0] == '1'; }
+    if (use_graph && conc > 1) {   // captured kernel nodes do not carry a stream's CU mask: the static partition is lost in replay (experiment switch; results unchanged)
+      static bool said = false;
+      if (!said) { said = true; std::fprintf(stderr, "[cddp_hip] CDDP_HIP_GRAPH=1: graph replay does not keep the CU-masked streams' partition; the tile groups share the whole chip\n"); }
+    }
     detail = (want_stats && !use_graph) ? h->timing_detail : -1;
     if (!h->ev_begin) { HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end)); }
     if (!h->ev_poll) { HIPCHK(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_poll2, hipEventDisableTiming)); }
@@ -1011,8 +1031,8 @@ struct SolveRun {
     const KernelSet *ks = h->ks;
     // CU-partitioned streams (CuPlan): the rollout on its own stream, ordered against the main stream by two events per launch
     hipStream_t sf = h->cu.fwd ? h->cu.fwd : s;
-    auto to_fwd = [&](int k) { if (sf != s) { hipEventRecord(h->cu.ev[k], s); hipStreamWaitEvent(sf, h->cu.ev[k], 0); } };
-    auto from_fwd = [&](int k) { if (sf != s) { hipEventRecord(h->cu.ev[k], sf); hipStreamWaitEvent(s, h->cu.ev[k], 0); } };
+    auto to_fwd = [&](int k) { if (sf != s) { order_check(hipEventRecord(h->cu.ev[k], s)); order_check(hipStreamWaitEvent(sf, h->cu.ev[k], 0)); } };
+    auto from_fwd = [&](int k) { if (sf != s) { order_check(hipEventRecord(h->cu.ev[k], sf)); order_check(hipStreamWaitEvent(s, h->cu.ev[k], 0)); } };
     two_stage_marks = !one_stage;
     mark(0);
     h->last_t4 = ks->t4_layout(d);   // the layout this fill writes (cddp_hip_get_linearization reads it back with the same rule's answer)
@@ -1072,7 +1092,8 @@ struct SolveRun {
     const unsigned long long key = ((unsigned long long)(one_stage ? 0 : k1) << 16) | ((unsigned long long)w << 4) | (unsigned long long)last;
     {   // a captured window bakes in the kernels launch.hpp selected from the environment: drop the cache when that selection changed
       unsigned sig = 2166136261u;
-      for (const char *v : {"CDDP_HIP_SWEEP", "CDDP_HIP_T4", "CDDP_HIP_K4_NA", "CDDP_HIP_COOP_H"}) {
+      for (const char *v : {"CDDP_HIP_SWEEP", "CDDP_HIP_T4", "CDDP_HIP_K4_NA", "CDDP_HIP_COOP_H", "CDDP_HIP_COOP_W", "CDDP_HIP_MS_ROLLOUT", "CDDP_HIP_LG_ROLLOUT",
+                            "CDDP_HIP_K4_CONSUMERS", "CDDP_HIP_SWEEP_ROLES"}) {   // every variable launch.hpp reads per launch
         const char *e = std::getenv(v);
         for (const char *c = e ? e : "-"; *c; ++c) sig = (sig ^ (unsigned char)*c) * 16777619u;
         sig = (sig ^ 0xffu) * 16777619u;
@@ -1156,6 +1177,10 @@ struct SolveRun {
     HIPCHK(hipEventRecord(h->ev_end, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    if (tl_order_error != hipSuccess) {   // a cross-stream ordering call of this solve failed (launch.hpp::order_check): the results may come from racing kernels
+      const hipError_t oe = tl_order_error; tl_order_error = hipSuccess;
+      return fail(-10, "stream ordering (event record / wait) failed during the solve: %s", hipGetErrorString(oe));
+    }
     if (!stats) return 0;
     std::memset(stats, 0, sizeof(*stats));
     float ms = 0;
@@ -1505,7 +1530,12 @@ int cddp_hip_create(const cddp_hip_problem *problem, int batch, int device, cddp
     Inner *q = nullptr;
     CuSpec cus;
     bool have_cu = cu_spec_for_group(k, &cus);
-    if (!have_cu && part > 1) { const int w = 256 / part; cus.lo[0] = (k % part) * w; cus.hi[0] = cus.lo[0] + w; have_cu = true; }
+    if (!have_cu && part > 1) {
+      // slice k of `part` equal slices of the CU-mask bits of THIS device (bit i = XCC i % 8, so a multiple of 8 bits is the same number of
+      // CUs on every XCD); a device or partition mode too small for two CUs per XCD and slice runs unpartitioned
+      const int w = device_cu_count(device) / part / 8 * 8;
+      if (w >= 16) { cus.lo[0] = (k % part) * w; cus.hi[0] = cus.lo[0] + w; have_cu = true; }
+    }
     int rc = in_create(problem, last - first, device, &q, have_cu ? &cus : nullptr);
     if (rc) { for (Inner *p : h->g) in_destroy(p); delete h; return rc; }
     h->g.push_back(q); h->b0.push_back(first);

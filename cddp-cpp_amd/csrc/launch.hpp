@@ -17,18 +17,22 @@ namespace cddp_dev {
 // the wide (batch x N) kernels before / after it stay on the caller's stream.  nullptr (the default): everything on one stream.
 struct SweepHop { hipStream_t s; hipEvent_t ev_in, ev_out; };
 inline thread_local const SweepHop *tl_sweep_hop = nullptr;
+// A failed event record / stream wait would leave two streams of one group unordered (kernels racing on K, k, V and the trial slots) without
+// any launch failing: the first such error is latched here and cddp_hip_solve / backward return it (capi.hip::take_order_error).
+inline thread_local hipError_t tl_order_error = hipSuccess;
+inline void order_check(hipError_t e) { if (e != hipSuccess && tl_order_error == hipSuccess) tl_order_error = e; }
 inline hipStream_t sweep_hop_in(hipStream_t s) {
   const SweepHop *h = tl_sweep_hop;
   if (!h || h->s == s) return s;
-  hipEventRecord(h->ev_in, s);
-  hipStreamWaitEvent(h->s, h->ev_in, 0);
+  order_check(hipEventRecord(h->ev_in, s));
+  order_check(hipStreamWaitEvent(h->s, h->ev_in, 0));
   return h->s;
 }
 inline void sweep_hop_out(hipStream_t s) {
   const SweepHop *h = tl_sweep_hop;
   if (!h || h->s == s) return;
-  hipEventRecord(h->ev_out, h->s);
-  hipStreamWaitEvent(s, h->ev_out, 0);
+  order_check(hipEventRecord(h->ev_out, h->s));
+  order_check(hipStreamWaitEvent(s, h->ev_out, 0));
 }
 
 struct KernelSet {

@@ -317,10 +317,17 @@ bool flatten(CDDP &ctx, int kind, FlatProblem &f) {
     if (!describeTerminal(kv.first, *kv.second, nx, f.cons)) return false;
   // resident LogDDP / MSIPDDP kernels: the shapes the library instantiates (csrc/launch.hpp: nx <= 8, no terminal set; MSIPDDP with path
   // constraints only for nu = 1 or nx = nu, the shapes msipddp_solver.cpp:1398 defines) -- everything else runs on the plug-in route
-  if ((kind == CDDP_HIP_SOLVER_LOGDDP || kind == CDDP_HIP_SOLVER_MSIPDDP) && (nx > 8 || !f.cons.t.empty())) return false;
+  // The same routing rule as the other two front ends (pycddp_amd.py `logddp_route` / `msipddp_route`, host/cddp_hip.hpp Route): "auto" keeps
+  // nx <= 8 on the resident kernels; CDDP_HIP_F4_ROUTE=resident also sends MSIPDDP up to nx = 13 there (one-lane, scratch-backed sweeps:
+  // correct, slow), CDDP_HIP_F4_ROUTE=plugin sends every LogDDP / MSIPDDP problem to the host plug-in route (host libm = the reference's
+  // arithmetic; the resident kernels use the library's shared log / sin / cos, so knife-edge iteration counts can differ between the routes).
+  const char *f4 = std::getenv("CDDP_HIP_F4_ROUTE");
+  const std::string f4route = f4 ? f4 : "auto";
+  const int ms_nx_cap = (f4route == "resident") ? 13 : 8;
+  if (kind == CDDP_HIP_SOLVER_LOGDDP && (nx > 8 || !f.cons.t.empty())) return false;
+  if (kind == CDDP_HIP_SOLVER_MSIPDDP && (nx > ms_nx_cap || !f.cons.t.empty())) return false;
   if (kind == CDDP_HIP_SOLVER_MSIPDDP && !f.cons.c.empty() && !(nu == 1 || nx == nu)) return false;
-  if (const char *e = std::getenv("CDDP_HIP_F4_ROUTE"))
-    if ((kind == CDDP_HIP_SOLVER_LOGDDP || kind == CDDP_HIP_SOLVER_MSIPDDP) && std::string(e) == "plugin") return false;
+  if ((kind == CDDP_HIP_SOLVER_LOGDDP || kind == CDDP_HIP_SOLVER_MSIPDDP) && f4route == "plugin") return false;
   cddp_hip_problem &p = f.p;
   std::memset(&p, 0, sizeof(p));
   p.abi_version = CDDP_HIP_ABI_VERSION; p.solver = kind; p.model = f.model.id; p.integrator = integratorId(sys.getIntegrationType());

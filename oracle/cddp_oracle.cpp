@@ -792,7 +792,7 @@ struct Solver {
       const Mat BtP = B[t].T() * Pn;
       const Mat Q_uu = 0.5 * (R[t] + BtP * B[t] + R[t].T() + B[t].T() * Pn.T() * B[t]);
       const Mat Q_ux = BtP * A[t] + M[t].T();
-      const Mat Q_xu = Q_ux.T();
+      const Mat Q_xu = Q_ux.T().plain();
       const Vec drift = pn + Pn * Vec::Zero(nx);
       const Vec Q_x = q[t] + A[t].T() * drift;
       const Vec Q_u = r[t] + B[t].T() * drift;
@@ -2280,6 +2280,10 @@ void cddp_oracle_set_failing_alphas(int mask) { oracle::failing_alpha_mask() = m
 void cddp_oracle_set_trig_mode(int v) { oracle::trig_mode() = v; }   // 0 = glibc, 1 = the HIP parity build's routine (models.hpp)
 // summation-order noise knob of linalg.hpp (process-wide): 0 = off (default), 1 = matrix-product entries moved by <= 1 ulp
 void cddp_oracle_set_matmul_noise(int v) { oracle::matmul_noise() = v; }
+// summation-order model of the reference's Eigen build (linalg.hpp::assoc_mode): 0 = serial (default), 1 = Eigen 3.4 SSE2 packet order
+void cddp_oracle_set_assoc_mode(int v) { oracle::assoc_mode() = v; }
+// the three summation orders of linalg.hpp on a caller's terms (unit tests): kind 0 serial, 1 redux (dot / norm / sum), 2 row-major gemv
+double cddp_oracle_sum_order(int kind, const double *p, int n) { return kind == 1 ? oracle::redux_order(p, n) : (kind == 2 ? oracle::gemv_row_order(p, n) : oracle::serial_order(p, n)); }
 void cddp_oracle_set_inf_du(void *o, double v) { ((Solver *)o)->inf_du = v; }
 void cddp_oracle_set_check_state_stationarity(void *o, int v) { ((Solver *)o)->opt.ipddp_check_state_stationarity = v; }
 

@@ -35,8 +35,47 @@ namespace oracle {
 #endif
 constexpr int kMatCap = ORACLE_MAT_CAP;
 
+// Summation-ORDER knob (test infrastructure, default 0 = every sum serial, left to right -- the order the HIP kernels keep).
+// assoc_mode() == 1 models the association Eigen 3.4 gives the reference's sums in a plain x86-64 Release build (SSE2, 2-wide Packet2d,
+// no FMA; the reference cannot be built here, so this is a reading of Eigen's kernels, not a measurement -- DESIGN.md section 5):
+//   * redux (Redux.h, LinearVectorizedTraversal, no unrolling: .dot, .sum, .squaredNorm / .norm, .lpNorm<1>, inner products v^T w):
+//     two Packet2d accumulators over the indices {0,1},{4,5},... and {2,3},{6,7},..., added to each other, a leftover whole packet added,
+//     horizontal add lane 0 + lane 1, then the odd tail element -- redux_order();
+//   * row-major matrix x vector (GeneralMatrixVector.h, RowMajor: X.transpose() * v and v.transpose() * X of column-major X): ONE Packet2d
+//     accumulator per output row, started from zero, over the index pairs in order, horizontal add, then the scalar tail -- gemv_row_order();
+//   * column-major matrix x vector, and every matrix x matrix product (lazy coefficient-based below the GEMM threshold, the GEBP kernel above
+//     it): each output accumulates over the inner index in order -- serial, as in mode 0.
+// What is NOT modelled: runtime pointer alignment of block expressions (first_default_aligned can shift the packets by one element),
+// expression templates that fuse differently from the restated statement, dynamic-size heuristics above 128 columns.
+inline int &assoc_mode() { static int v = 0; return v; }
+inline double serial_order(const double *p, int n) { double s = 0.0; for (int i = 0; i < n; ++i) s += p[i]; return s; }
+inline double redux_order(const double *p, int n) {
+  const int ps = 2;
+  const int alignedSize2 = (n / (2 * ps)) * (2 * ps), alignedSize = (n / ps) * ps;
+  if (!alignedSize) { double res = n > 0 ? p[0] : 0.0; for (int i = 1; i < n; ++i) res += p[i]; return res; }
+  double a0 = p[0], a1 = p[1];
+  if (alignedSize > ps) {
+    double b0 = p[2], b1 = p[3];
+    for (int i = 2 * ps; i < alignedSize2; i += 2 * ps) { a0 += p[i]; a1 += p[i + 1]; b0 += p[i + 2]; b1 += p[i + 3]; }
+    a0 += b0; a1 += b1;
+    if (alignedSize > alignedSize2) { a0 += p[alignedSize2]; a1 += p[alignedSize2 + 1]; }
+  }
+  double res = a0 + a1;
+  for (int i = alignedSize; i < n; ++i) res += p[i];
+  return res;
+}
+inline double gemv_row_order(const double *p, int n) {
+  double c0 = 0.0, c1 = 0.0;
+  int j = 0;
+  for (; j + 2 <= n; j += 2) { c0 = p[j] + c0; c1 = p[j + 1] + c1; }
+  double cc = c0 + c1;
+  for (; j < n; ++j) cc += p[j];
+  return 0.0 + cc;   // res[i] += alpha * cc0 on a zeroed destination
+}
+
 struct Mat {
   int r = 0, c = 0;
+  bool tv = false;   // this value is X.transpose() of a column-major X used as an operand (set by T(), consumed by operator*; copies drop it)
   double a[kMatCap];
   Mat() {}
   Mat(int r_, int c_) : r(r_), c(c_) {
@@ -44,7 +83,7 @@ struct Mat {
     for (int i = 0; i < r * c; ++i) a[i] = 0.0;
   }
   Mat(const Mat &o) : r(o.r), c(o.c) { for (int i = 0; i < r * c; ++i) a[i] = o.a[i]; }
-  Mat &operator=(const Mat &o) { r = o.r; c = o.c; for (int i = 0; i < r * c; ++i) a[i] = o.a[i]; return *this; }
+  Mat &operator=(const Mat &o) { r = o.r; c = o.c; tv = false; for (int i = 0; i < r * c; ++i) a[i] = o.a[i]; return *this; }
   double &operator()(int i, int j) { return a[i * c + j]; }
   double operator()(int i, int j) const { return a[i * c + j]; }
   double &operator()(int i) { return a[i]; }           // vector access (c==1 or r==1)
@@ -57,12 +96,16 @@ struct Mat {
     Mat m(r, c); for (int i = 0; i < r * c; ++i) m.a[i] = p[i]; return m;
   }
   bool allFinite() const { for (int i = 0; i < r * c; ++i) if (!std::isfinite(a[i])) return false; return true; }
-  Mat T() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); return m; }
+  Mat T() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); m.tv = !tv; return m; }
+  Mat plain() const { Mat m(*this); m.tv = false; return m; }   // a transposed value stored in a matrix of its own (MatrixXd X = Y.transpose())
   double lpNormInf() const { double v = 0; for (int i = 0; i < r * c; ++i) v = std::max(v, std::fabs(a[i])); return v; }
-  double lpNorm1() const { double v = 0; for (int i = 0; i < r * c; ++i) v += std::fabs(a[i]); return v; }
-  double squaredNorm() const { double v = 0; for (int i = 0; i < r * c; ++i) v += a[i] * a[i]; return v; }
+  double lpNorm1() const { if (assoc_mode() == 1) { double p[kMatCap]; for (int i = 0; i < r * c; ++i) p[i] = std::fabs(a[i]); return redux_order(p, r * c); }
+                           double v = 0; for (int i = 0; i < r * c; ++i) v += std::fabs(a[i]); return v; }
+  double squaredNorm() const { if (assoc_mode() == 1) { double p[kMatCap]; for (int i = 0; i < r * c; ++i) p[i] = a[i] * a[i]; return redux_order(p, r * c); }
+                               double v = 0; for (int i = 0; i < r * c; ++i) v += a[i] * a[i]; return v; }
   double norm() const { return std::sqrt(squaredNorm()); }
-  double dot(const Mat &o) const { double v = 0; for (int i = 0; i < r * c; ++i) v += a[i] * o.a[i]; return v; }
+  double dot(const Mat &o) const { if (assoc_mode() == 1) { double p[kMatCap]; for (int i = 0; i < r * c; ++i) p[i] = a[i] * o.a[i]; return redux_order(p, r * c); }
+                                   double v = 0; for (int i = 0; i < r * c; ++i) v += a[i] * o.a[i]; return v; }
   double trace() const { double v = 0; for (int i = 0; i < std::min(r, c); ++i) v += (*this)(i, i); return v; }
   double minCoeff() const { double v = a[0]; for (int i = 1; i < r * c; ++i) v = std::min(v, a[i]); return v; }
   double maxCoeff() const { double v = a[0]; for (int i = 1; i < r * c; ++i) v = std::max(v, a[i]); return v; }
@@ -111,10 +154,22 @@ inline Mat operator*(const Mat &A, const Mat &B) {
   assert(A.c == B.r);
   Mat m(A.r, B.c);
   const bool noisy = matmul_noise() != 0 && A.c >= 2;
+  // assoc_mode 1: which Eigen kernel the product runs through (see assoc_mode()): 0 serial, 1 redux (inner product), 2 row-major gemv
+  int kind = 0;
+  if (assoc_mode() == 1 && A.c >= 2) {
+    if (A.r == 1 && B.c == 1) kind = 1;
+    else if (B.c == 1) kind = A.tv ? 2 : 0;          // X^T v: row-major lhs; X v: column-major lhs
+    else if (A.r == 1) kind = B.tv ? 0 : 2;          // v^T X = (X^T v)^T
+  }
   for (int i = 0; i < A.r; ++i)
     for (int j = 0; j < B.c; ++j) {
       double s = 0.0;
-      for (int k = 0; k < A.c; ++k) s += A(i, k) * B(k, j);
+      if (kind == 0) { for (int k = 0; k < A.c; ++k) s += A(i, k) * B(k, j); }
+      else {
+        double p[kMatCap];
+        for (int k = 0; k < A.c; ++k) p[k] = A(i, k) * B(k, j);
+        s = kind == 1 ? redux_order(p, A.c) : gemv_row_order(p, A.c);
+      }
       m(i, j) = noisy ? matmul_perturb(s) : s;
     }
   return m;

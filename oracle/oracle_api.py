@@ -237,6 +237,16 @@ def set_failing_alphas(mask):
         load_oracle(fast).cddp_oracle_set_failing_alphas(int(mask))
 
 
+def set_assoc_mode(mode):
+    """Summation-order model (linalg.hpp::assoc_mode): 0 = every sum serial (default, the order the HIP kernels keep), 1 = the association
+    Eigen 3.4's SSE2 kernels give the reference's dot products, norms and transposed matrix-vector products.  Process-global, both builds."""
+    for fast in (False, True):
+        path = ORACLE_FAST_LIB_PATH if fast else ORACLE_LIB_PATH
+        if fast and not os.path.exists(path):
+            continue
+        load_oracle(fast).cddp_oracle_set_assoc_mode(int(mode))
+
+
 class shared_trig:
     """Context manager: the oracle evaluates sin / cos / log / pow with the HIP library's routines (models.hpp::trig_mode 1) inside
     the block and returns to the previous mode afterwards (tests/conftest.py keeps mode 1 on for every `-m gpu` test)."""
@@ -257,6 +267,6 @@ def attach(api):
     """Expose the oracle entry points on the harness module `api` (cddp-cpp_amd/pyapi.py)."""
     mod = sys.modules[__name__]
     for name in ("ORACLE_LIB_PATH", "ORACLE_FAST_LIB_PATH", "load_oracle", "Oracle", "oracle_solve_batch", "oracle_boxqp",
-                 "oracle_ldlt_solve", "shared_trig", "set_trig_mode", "set_failing_alphas"):
+                 "oracle_ldlt_solve", "shared_trig", "set_trig_mode", "set_failing_alphas", "set_assoc_mode"):
         setattr(api, name, getattr(mod, name))
     return api

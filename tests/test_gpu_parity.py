@@ -298,11 +298,10 @@ def test_full_solve_parity(api, oracle_built, case):
     mism = [(b, int(res["iterations"][b]), int(ores["iterations"][b]), int(res["status"][b]), int(ores["status"][b]))
             for b in range(B) if res["iterations"][b] != ores["iterations"][b] or res["status"][b] != ores["status"][b]]
     assert not mism, (case, mism)
-    # Trajectories that terminate Optimal/Acceptable must agree in every counter and to 1e-6 in the
-    # trajectories.  A solve that runs into MaxIterations / RegularizationLimit is a chaotic map of its
-    # rounding (FMA contraction on the GPU, none in the oracle build): there the knife-edge line-search
-    # decisions may differ after dozens of iterations, so only status + iteration count (checked above)
-    # are compared, and at most 10% of the batch may differ that way.
+    # Every trajectory must agree in every counter and to 1e-6 in the trajectories (`shared`: the library and the checker run the same
+    # sin / cos / log / pow and neither contracts to FMA, so even the solves that end at MaxIterations / RegularizationLimit -- chaotic
+    # maps of their rounding -- take the same line-search decisions).  Only a checker in glibc arithmetic (`shared` false, a hand-made
+    # comparison build) is allowed 10 % of non-converged trajectories that part ways after dozens of iterations.
     conv = (ores["status"] == api.STATUS_OPTIMAL) | (ores["status"] == api.STATUS_ACCEPTABLE)
     strict = np.ones(B, dtype=bool)
     for b in range(B):
