@@ -447,6 +447,88 @@ MULTI_RANK_WORKLOADS = [
 ]
 
 
+def stackfed_bytes(nx, nu, N, m, clddp):
+    """SURVEY 8(d) B_bwd per trajectory for the stack-fed sweep -- here the bytes ARE the traffic: every f_x / f_u / l_x / l_u / l_xx / l_uu / l_ux
+    (+ y, s, g, G_x, G_u) row is read from HBM once, every gain / value (+ slack / dual gain) row written once."""
+    dyn = nx * nx + nx * nu; cost = nx + nu + nx * nx + nu * nu + nu * nx; gain = nu * nx + nu; val = nx + nx * nx
+    if clddp or m == 0:
+        return 8.0 * (N * (dyn + cost + gain + val) + val)
+    con_in = 3 * m + m * nx + m * nu; con_out = 2 * m + 2 * m * nx
+    return 8.0 * (N * (dyn + cost + con_in + gain + val + con_out) + val)
+
+
+# north_star's literal form: "coalesced HBM loads of the (N x batch) stacks of f_x / f_u / l_xx / l_uu / l_ux" -- the stack-fed sweeps of the host
+# plug-in route (cddp_hip_stacks_backward, stacks.hip / stacks_coop.hpp).  (nx, nu, m, N, base batch, label, batch multipliers of the curve)
+STACKFED_SHAPES = [
+    (4, 1, 2, 100, 4096, "C2 shape", (1, 4, 16, 32)),
+    (3, 2, 5, 200, 8192, "C3 shape", (1, 4, 8)),
+    (12, 4, 8, 400, 2048, "C4-share shape", (1,)),
+    (14, 7, 14, 150, 4096, "C5-share shape", (1,)),
+]
+# `bench.py --stackfed`: longer curves (tens of GB of stacks for the nx >= 12 shapes: minutes of host-side tiling and upload, not part of the default line)
+STACKFED_SHAPES_FULL = [
+    (4, 1, 2, 100, 4096, "C2 shape", (1, 4, 16, 32, 64)),
+    (3, 2, 5, 200, 8192, "C3 shape", (1, 4, 8, 16)),
+    (12, 4, 8, 400, 2048, "C4-share shape", (1, 2, 4)),
+    (14, 7, 14, 150, 4096, "C5-share shape", (1, 2, 4)),
+]
+
+
+def measure_stackfed(api, device=0, shapes=None, reps=3):
+    """One line per (shape, branch): kernel time (hipEvents around the single launch, cddp_hip_stacks_last_kernel_ms, best of `reps`) of the
+    stack-fed IPDDP path-row sweep and the CLDDP sweep on random well-conditioned stacks (the arithmetic does not depend on the values), the
+    default sweep form of the shape, with a batch curve up to a chip-filling batch for the small shapes.  The stacks of the larger batches
+    are the base batch tiled (uploaded whole: the sweep reads every row once either way)."""
+    rng = np.random.default_rng(1)
+    opt = api.default_options()
+    PEAK = 8000.0
+    lines = []
+    for (nx, nu, m, N, B0, label, mults) in (shapes or STACKFED_SHAPES):
+        fx = np.tile(np.eye(nx), (B0, N, 1, 1)) + 0.05 * rng.standard_normal((B0, N, nx, nx)); fu = 0.1 * rng.standard_normal((B0, N, nx, nu))
+        lx = rng.standard_normal((B0, N, nx)); lu = rng.standard_normal((B0, N, nu))
+        lxx = np.tile(np.eye(nx), (B0, N, 1, 1)); luu = np.tile(np.eye(nu), (B0, N, 1, 1)); lux = np.zeros((B0, N, nu, nx))
+        VxN = rng.standard_normal((B0, nx)); VxxN = np.tile(10.0 * np.eye(nx), (B0, 1, 1))
+        y = np.full((B0, N, m), 0.5); sl = np.full((B0, N, m), 0.4); g = -sl + 0.01 * rng.standard_normal((B0, N, m))
+        Gx = 0.1 * rng.standard_normal((B0, N, m, nx)); Gu = 0.3 * rng.standard_normal((B0, N, m, nu))
+        for branch, mm, bname in ((api.STACKS_IPDDP_PATH, m, "IPDDP, path rows"), (api.STACKS_CLDDP, 0, "CLDDP")):
+            curve = []
+            for mult in mults:
+                B = B0 * mult
+                rep = lambda a: np.ascontiguousarray(np.concatenate([a] * mult, axis=0)) if mult > 1 else a
+                try:
+                    hs = api.HipStackSolver(B, nx, nu, mm, N, device=device)
+                except api.HipError as e:
+                    curve.append({"batch": B, "error": str(e)}); continue
+                try:
+                    hs.set_stacks(rep(fx), rep(fu), rep(lx), rep(lu), rep(lxx), rep(luu), rep(lux), rep(VxN), rep(VxxN))
+                    mu = None
+                    if mm:
+                        hs.set_constraint_stacks(rep(y), rep(sl), rep(g), rep(Gx), rep(Gu)); mu = np.full(B, 0.1)
+                    ms = []
+                    ok = None
+                    for _ in range(reps + 1):
+                        ok = hs.backward(branch, opt, np.full(B, 1e-6), mu, retry=False); ms.append(hs.kernel_ms())
+                    t = min(ms[1:])
+                    byt = stackfed_bytes(nx, nu, N, mm, branch == api.STACKS_CLDDP) * B
+                    curve.append({"batch": B, "kernel_ms": t, "GBps": byt / t / 1e6, "frac": byt / t / 1e6 / PEAK, "form": "coop" if hs.sweep_form() == 1 else "lane",
+                                  "sweeps_ok": int(ok.sum()), "stack_bytes": byt})
+                finally:
+                    hs.close()
+            good = [c for c in curve if "frac" in c]
+            best = max(good, key=lambda c: c["frac"]) if good else None
+            lines.append({
+                "workload": "stack-fed sweep (g1, cddp_hip_stacks_backward): %s nx=%d nu=%d m=%d N=%d, %s" % (label, nx, nu, mm, N, bname),
+                "solver": "stack-fed " + bname, "unit": "trajectory sweeps/s",
+                "batch": best["batch"] if best else None, "value": (best["batch"] / (best["kernel_ms"] * 1e-3)) if best else None,
+                "ms_per_step": best["kernel_ms"] if best else None,
+                "roofline": None if not best else {"bound": "hbm", "kernel": "k_stacks_backward" + ("_coop" if best["form"] == "coop" else ""), "achieved": best["GBps"], "peak": PEAK,
+                                                   "unit": "GB/s", "frac": best["frac"], "traffic": best["stack_bytes"],
+                                                   "traffic_note": "the stacks are read / the gain rows written exactly once per sweep: algorithmic bytes = HBM traffic (no in-kernel derivative evaluation)"},
+                "batch_curve": curve,
+            })
+    return lines
+
+
 def measure_mpc(api, rounds, device=0, workload="cartpole", batch=0):
     """f1 caller side: receding-horizon re-solves on a RE-USED handle -- the caller pattern of
     examples/ipddp_mpcc_rc.py:649-705 (solver.set_initial_state(state); solver.solve()) with the reference's warm-start branch
@@ -477,7 +559,31 @@ def measure_mpc(api, rounds, device=0, workload="cartpole", batch=0):
             iters.append(float(np.mean(r["iterations"])))
             conv.append(int(np.sum((r["status"] == api.STATUS_OPTIMAL) | (r["status"] == api.STATUS_ACCEPTABLE))))
         ws = float(np.mean(wall_solve)); wd = float(np.mean(dev_ms)) * 1e-3
+        # ---- the reference's OTHER warm start: a caller that builds a fresh problem per MPC step and seeds it with the
+        # previous plan shifted by one step (X_[1:] + repeated last state, U_[1:] + repeated last control) takes the "provided trajectory" branch
+        # (ipddp_solver.cpp:733-816: barrier parameter from the seed's largest violation, duals re-initialised, gains zero).  Same handle,
+        # cddp_hip_forget_solver_state between steps; the cold solve's plan is the first seed.
+        prov = None
+        try:
+            hs.set_warm_start(False); hs.set_initial(x0, U0); hs.solve(); hs.set_warm_start(True)
+            p_wall = []; p_dev = []; p_it = []; p_conv = []
+            for _ in range(rounds):
+                X, U = hs.trajectory()
+                Xs = np.concatenate([X[:, 1:], X[:, -1:]], axis=1); Us = np.concatenate([U[:, 1:], U[:, -1:]], axis=1)
+                hs.forget_solver_state()
+                hs.set_initial(np.ascontiguousarray(Xs[:, 0]), np.ascontiguousarray(Us), np.ascontiguousarray(Xs))
+                t1 = time.perf_counter(); st = hs.solve(); t2 = time.perf_counter()
+                r = hs.results()
+                p_wall.append(t2 - t1); p_dev.append(st.solve_ms); p_it.append(float(np.mean(r["iterations"])))
+                p_conv.append(int(np.sum((r["status"] == api.STATUS_OPTIMAL) | (r["status"] == api.STATUS_ACCEPTABLE))))
+            prov = {"warm_start": "provided trajectory (previous plan shifted by one step) on a forgotten solver state: cddp_hip_forget_solver_state + cddp_hip_set_initial + cddp_hip_solve",
+                    "value": B / float(np.mean(p_wall)), "ms_per_step": float(np.mean(p_wall)) * 1e3, "device_ms_per_resolve": float(np.mean(p_dev)),
+                    "mean_iterations_per_resolve": float(np.mean(p_it)), "iterations_by_round": p_it, "converged_by_round": p_conv,
+                    "note": "the timed call excludes the host-side shift and the 2 x upload of the seed (set_initial)"}
+        except Exception as e:   # the second mode must not cost the first its line
+            prov = {"error": repr(e)}
         return {
+            "provided_trajectory_warm_start": prov,
             "workload": "MPC re-solves (f1): %s, B=%d, %d shift-by-one-step re-solves on a re-used handle, warm start = existing solver state" % (desc, B, rounds),
             "solver": "IPDDP", "batch": B, "steps": rounds, "unit": "re-solved trajectories/s",
             "value": B / ws, "ms_per_step": ws * 1e3, "ms_per_mpc_step_incl_readback": float(np.mean(wall_step)) * 1e3,
@@ -505,6 +611,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch trajectories per GPU; strong: a fixed global batch (--global-batch or the BASELINE config's) over all GPUs")
     ap.add_argument("--global-batch", type=int, default=0)
+    ap.add_argument("--stackfed", action="store_true", help="only the stack-fed sweep lines (batch curves), one JSON line")
     ap.add_argument("--mpc", type=int, default=0, help="only the MPC re-solve measurement: K shift-and-re-solve rounds on a re-used handle (1 GPU), one JSON line")
     args = ap.parse_args()
 
@@ -545,6 +652,9 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     api = load_api()
+    if args.stackfed:
+        print(json.dumps({"stackfed": measure_stackfed(api, device=local_rank, shapes=STACKFED_SHAPES_FULL)}))
+        return
     if args.mpc > 0:
         if world != 1:
             raise SystemExit("--mpc is a single-GPU measurement")
@@ -670,6 +780,10 @@ def main():
                 out["other_workloads"].append({"workload": label, "error": "%s: %s" % (type(e).__name__, e)})
         # pendulum and unicycle (C3): converging solves, where a warm start pays (few iterations per re-solve); the cart-pole example never
         # converges inside its 80-iteration cap (cold or warm), so its re-solve line would measure the cap, not warm starts: dropped
+        try:   # north_star's literal form: the stack-fed sweeps of the plug-in route
+            out["other_workloads"].extend(measure_stackfed(api, device=local_rank))
+        except Exception as e:
+            out["other_workloads"].append({"workload": "stack-fed sweeps", "error": "%s: %s" % (type(e).__name__, e)})
         for wl in ("pendulum", "unicycle"):
             try:
                 out["other_workloads"].append(measure_mpc(api, 8, device=local_rank, workload=wl))

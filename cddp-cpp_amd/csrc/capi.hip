@@ -1590,6 +1590,11 @@ int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0) {
   if (!x0) return fail(-1, "null argument");
   FOR_GROUPS(in_set_initial_state(q, OFF(x0, h->nx)));
 }
+int cddp_hip_forget_solver_state(cddp_hip_handle *h) {
+  if (!h) return fail(-1, "null handle");
+  for (Inner *q : h->g) { q->has_state = false; q->initialized = false; }   // (run_initialize: warm_start now means "provided trajectory"; the MSIPDDP factor cache stays with the handle as documented)
+  return 0;
+}
 int cddp_hip_set_duals(cddp_hip_handle *h, const double *S, const double *Y) { FOR_GROUPS(in_set_duals(q, OFF(S, h->N * h->m), OFF(Y, h->N * h->m))); }
 int cddp_hip_set_barrier_state(cddp_hip_handle *h, const double *mu, const double *reg) { FOR_GROUPS(in_set_barrier_state(q, OFF(mu, 1), OFF(reg, 1))); }
 int cddp_hip_set_terminal(cddp_hip_handle *h, const double *S_T, const double *Y_T, const double *Lambda_T) {

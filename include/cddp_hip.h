@@ -383,6 +383,14 @@ int cddp_hip_set_options(cddp_hip_handle *h, const cddp_hip_options *options);
  * (CDDP::setInitialTrajectory). */
 int cddp_hip_set_initial_state(cddp_hip_handle *h, const double *x0);
 
+/* Forget the solver state of the handle -- gains, slack / dual / costate / terminal variables, regularisation -- as if the reference's
+ * solver OBJECT were constructed anew, without re-allocating anything: with options.warm_start the next initialize / solve then takes the
+ * reference's "warm start with provided trajectory" branch (ipddp_solver.cpp:733-816, clddp_solver.cpp:35-60: the trajectory of the last
+ * cddp_hip_set_initial, barrier parameter from its largest violation, duals re-initialised) instead of "existing solver state"
+ * (:653-731).  The MPC caller that builds a fresh problem per step (examples/ipddp_mpcc_rc.py:649-705, test_ipddp_solver.cpp's warm-start
+ * tests) is cddp_hip_forget_solver_state + cddp_hip_set_initial(x0, shifted U, shifted X) + cddp_hip_solve on one long-lived handle. */
+int cddp_hip_forget_solver_state(cddp_hip_handle *h);
+
 /* Overwrite the path slack / dual variables S[b][t][m], Y[b][t][m] (either may be NULL) and the terminal
  * slack / dual / multipliers S_T[b][mT], Y_T[b][mT], Lambda_T[b][pT] of an initialised handle: the
  * reference's IPDDPSolverTestAccess::setPathInterior / setTerminalInterior / setTerminalEqualityMultiplier,

@@ -49,3 +49,33 @@ def test_k_th_mpc_resolve_matches_the_oracle(api, oracle_built, case):
                 _, Uo = o.trajectory()
                 assert rel(Un[b], Uo) < 1e-5, (case, b)
     hs.close()
+
+
+@pytest.mark.parametrize("case", ["pendulum_ipddp_box", "unicycle_ipddp_box_ball", "pendulum_clddp_box"])
+def test_forgotten_solver_state_is_a_new_solver_object(api, oracle_built, case):
+    """cddp_hip_forget_solver_state (round 6): the MPC caller that builds a fresh problem per step and seeds it with the shifted previous
+    plan takes the reference's "warm start with provided trajectory" branch (ipddp_solver.cpp:733-816).  On ONE long-lived handle,
+    forget + set_initial(shifted plan) + solve must give the bits a NEW handle gives for the same seed, and what a new oracle object gives."""
+    import test_gpu_parity as T
+    p = T.make(api, case)
+    B = 6
+    x0 = api.batch_x0(p, B, 20261103, T.spread_for(p))
+    U0 = api.batch_U0(p, B)
+    hs = api.HipBatchSolver(p, B); hs.set_initial(x0, U0); hs.solve()
+    hs.set_warm_start(True)
+    for k in range(3):
+        X, U = hs.trajectory()
+        Xs = np.ascontiguousarray(np.concatenate([X[:, 1:], X[:, -1:]], axis=1)); Us = np.ascontiguousarray(np.concatenate([U[:, 1:], U[:, -1:]], axis=1))
+        x1 = np.ascontiguousarray(Xs[:, 0])
+        hs.forget_solver_state(); hs.set_initial(x1, Us, Xs); hs.solve()
+        r = hs.results(); Xa, Ua = hs.trajectory()
+        fresh = api.HipBatchSolver(p, B); fresh.set_initial(x1, Us, Xs); fresh.solve()
+        rf = fresh.results(); Xf, Uf = fresh.trajectory(); fresh.close()
+        for name in ("iterations", "status", "n_backward", "n_forward", "final_objective"):
+            assert np.array_equal(r[name], rf[name]), (k, name)
+        assert np.array_equal(Xa, Xf) and np.array_equal(Ua, Uf)
+        for b in range(B):
+            o = api.Oracle(p); o.set_warm_start(True); o.set_initial(x1[b], Us[b], Xs[b]); q = o.solve()
+            assert q["iterations"] == r["iterations"][b] and q["status"] == r["status"][b], (k, b, q["iterations"], r["iterations"][b])
+            assert rel(q["final_objective"], r["final_objective"][b]) < 1e-7
+    hs.close()
