@@ -17,7 +17,10 @@
 // terminal constraints (the stack-fed sweeps have no terminal-constraint branch), warm starts.
 // This file uses only the public C-ABI of include/cddp_hip.h for the GPU part.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +44,29 @@ constexpr double kEpsSlack = 1e-10, kSlackOffset = 1e-4, kMaxRatio = 1e6;   // i
 const double kInf = std::numeric_limits<double>::infinity();
 inline bool fin(double v) { return std::fabs(v) <= std::numeric_limits<double>::max(); }
 inline double clampd(double v, double lo, double hi) { return std::min(std::max(v, lo), hi); }
+
+// Host threads of the per-trajectory work (derivative / stack fill, forward passes, updates): the trajectories of a batch are independent
+// problems, and the reference itself fans its line search out with std::async (cddp_solver_base.cpp:264-314).  1 (the default) keeps every
+// callback on the calling thread, as documented since round 3; cddp_hip_plugin_set_host_threads(n) / CDDP_HIP_PLUGIN_THREADS=n (0 = one per
+// hardware thread) let n threads call the plug-in's callbacks CONCURRENTLY -- for thread-safe (C / C++) plug-ins only; the Python facade
+// keeps 1 (its callbacks serialise on the interpreter lock anyway).  Results do not depend on the count: every trajectory's arithmetic is
+// its own (tests/test_host_plugins.py::test_plugin_host_threads_do_not_change_results).
+int g_host_threads = -1;   // -1: unset (environment, then 1)
+int host_threads(int batch) {
+  int n = g_host_threads;
+  if (n < 0) { const char *e = std::getenv("CDDP_HIP_PLUGIN_THREADS"); n = e ? std::atoi(e) : 1; }
+  if (n == 0) n = (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(n, batch));
+}
+template <class F> void par_for(size_t n, int threads, F &&f) {
+  if (threads <= 1 || n <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::atomic<size_t> next{0};
+  auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) return; f(i); } };
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; ++t) th.emplace_back(work);
+  work();
+  for (auto &x : th) x.join();
+}
 
 struct Trial {   // ForwardPassResult (cddp_core.hpp:105-145)
   bool success = false;
@@ -997,6 +1023,12 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
 
 }  // namespace
 
+extern "C" int cddp_hip_plugin_set_host_threads(int n) {
+  if (n < 0) return pfail(-2, "host thread count must be >= 0 (0 = one per hardware thread)");
+  g_host_threads = n;
+  return 0;
+}
+
 extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int horizon, double dt, const cddp_hip_options *opt,
                                      int device, int batch, const double *x0, const double *U0, const double *X0,
                                      cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
@@ -1048,8 +1080,9 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   if (m > 0) { kyb.resize(B * N * m); ksb = kyb; Kyb.resize(B * N * m * nx); Ksb = Kyb; dXb.resize(B * (N + 1) * nx); }
   std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
   std::vector<int32_t> okv(B);
-  std::vector<double> tfx(nx * nx), tfu(nx * nu);
   const bool first_rule = !o.enable_parallel;
+  std::atomic<bool> abort_seen{false};
+  const int n_threads = host_threads((int)B);
   const auto wall0 = std::chrono::steady_clock::now();
 
   for (int it = 1; it <= o.max_iterations; ++it) {
@@ -1066,11 +1099,12 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
     }
     // ---- precomputeDynamicsDerivatives / precomputeConstraintGradients on the host (cddp_solver_base.cpp:319-394,
     //      ipddp_solver.cpp:2145-2250), cost derivatives (objective.hpp): the stacks of every running trajectory
-    for (size_t b = 0; b < B; ++b) {
+    auto fill_stacks = [&](size_t b) {   // (one host thread per trajectory when the caller allows it: cddp_hip_plugin_set_host_threads)
       Traj &t = T[b];
+      std::vector<double> tfx((size_t)nx * nx), tfu((size_t)nx * nu);
       regv[b] = t.done ? std::max(t.reg, o.reg_min_value) : t.reg;
       muv[b] = (t.mu > 0.0) ? t.mu : 1.0;
-      if (t.done) continue;
+      if (t.done) return;
       t.iter += 1;
       for (int s = 0; s < N; ++s) {
         const double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
@@ -1098,7 +1132,8 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
       }
       pl->terminal_cost_derivatives(pl->user, t.X.data() + (size_t)N * nx, VxN.data() + b * nx, VxxN.data() + b * nx * nx);
       std::copy(t.U.begin(), t.U.end(), Ubuf.begin() + b * N * nu);
-    }
+    };
+    par_for(B, n_threads, fill_stacks);
     { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
     if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, gy.data(), gs.data(), gg.data(), gGx.data(), gGu.data()); if (rc) return rc; }
     if (!o.use_ilqr && c.ipddp()) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
@@ -1113,16 +1148,16 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
     if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
 
-    for (size_t b = 0; b < B; ++b) {
+    auto advance = [&](size_t b) {
       Traj &t = T[b];
-      if (t.done) continue;
-      if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
+      if (t.done) return;
+      if (aborted(pl)) { abort_seen.store(true); return; }
       // sweeps the retry loop ran: replay the schedule from the regularisation it started with
       { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
         if (!okv[b] && nb > 1) --nb;   // the loop stops when the schedule reaches reg_max: no sweep is run there
         t.n_bwd += nb; }
       t.reg = s_reg[b];
-      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; continue; }   // handleBackwardPassRegularizationLimit
+      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; return; }   // handleBackwardPassRegularizationLimit
       t.dV0 = dVb[b * 2]; t.dV1 = dVb[b * 2 + 1]; t.inf_du = s_du[b];
       Gains g;
       g.K = Kb.data() + b * N * nu * nx; g.k = kb.data() + b * N * nu; g.Vx = Vxb.data() + b * (N + 1) * nx; g.Vxx = Vxxb.data() + b * (N + 1) * nx * nx;
@@ -1148,7 +1183,7 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
           conv = (t.inf_pr < tol && sdu < tol && t.inf_comp < tol && std::fabs(t.alpha_pr) * t.step_norm < o.tolerance * 10.0);
         }
       }
-      if (conv) { t.status = CDDP_HIP_STATUS_OPTIMAL; t.done = true; continue; }
+      if (conv) { t.status = CDDP_HIP_STATUS_OPTIMAL; t.done = true; return; }
       // ---- performForwardPass (cddp_solver_base.cpp:248-317): first success, or lowest merit among the successes
       Trial best; bool have = false;
       int walked = 0;
@@ -1250,7 +1285,9 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
         }
       }
       if (!t.done && it == o.max_iterations) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
-    }
+    };
+    par_for(B, n_threads, advance);
+    if (abort_seen.load() || aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
   }
   for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }   // max_iterations <= 0
 

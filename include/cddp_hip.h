@@ -602,7 +602,7 @@ int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
  *                                (clddp_solver.cpp:85-86, 147-178, 227-228) or NULL; CLDDP ignores every other constraint.
  * The GPU runs the backward pass of the whole batch (stack-fed sweeps above); the forward pass needs the plug-in's f(x, u) and runs
  * on the host (csrc/plugin_solve.hip).  All trajectories of the batch share the plug-in; they differ in x0 / U0 / X0.  Callbacks are
- * called from the calling thread only.  Not supported: terminal constraints, warm starts (use the built-in plants for those).
+ * called from the calling thread only unless cddp_hip_plugin_set_host_threads says otherwise.  Not supported: terminal constraints, warm starts (use the built-in plants for those).
  * solver = CDDP_HIP_SOLVER_LOGDDP runs the reference's LogDDP (logddp_solver.cpp:43-707: single shooting, relaxed log barrier of every
  * path constraint folded into the cost derivatives on the host, Riccati sweep of the batch on the GPU, filter line search on the
  * host); it takes the same callbacks, plus constraint_hessians when a constraint has curvature. */
@@ -646,6 +646,11 @@ typedef struct cddp_hip_plugin {
 /* ISolverAlgorithm::initialize + solve for `batch` trajectories of a host plug-in problem.  x0: batch*nx; U0: batch*N*nu or NULL
  * (zeros); X0: batch*(N+1)*nx or NULL (x0 replicated).  results: batch records; X (batch*(N+1)*nx), U (batch*N*nu), K
  * (batch*N*nu*nx, feedback gains of the last sweep) may be NULL. */
+/* Host threads that run the per-trajectory host work of cddp_hip_plugin_solve's IPDDP / CLDDP loop (derivative fill, forward passes, updates;
+ * the reference fans its own line search out with std::async, cddp_solver_base.cpp:264-314).  Default 1: callbacks on the calling thread
+ * only.  n > 1 (0 = one per hardware thread): the plug-in's callbacks are called CONCURRENTLY for different trajectories -- for thread-safe
+ * plug-ins.  Process-wide; CDDP_HIP_PLUGIN_THREADS is the default when this was never called.  Results do not depend on the count. */
+int cddp_hip_plugin_set_host_threads(int n);
 int cddp_hip_plugin_solve(const cddp_hip_plugin *plugin, int solver /* cddp_hip_solver */, int horizon, double dt,
                           const cddp_hip_options *options, int device, int batch, const double *x0, const double *U0, const double *X0,
                           cddp_hip_result *results, double *X, double *U, double *K);

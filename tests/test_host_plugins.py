@@ -153,6 +153,36 @@ def test_python_pendulum_plugin_matches_the_oracle(api, pycddp, oracle_built, so
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["IPDDP", "CLDDP"])
+def test_plugin_host_threads_do_not_change_results(api, pycddp, solver):
+    """cddp_hip_plugin_set_host_threads (round 6): the per-trajectory host work of the plug-in solve -- derivative fill, forward passes, updates
+    -- on four threads (the Python callbacks then arrive from worker threads and serialise on the interpreter lock) gives the bits of one thread."""
+    PyPendulum, _, _ = make_plants(pycddp)
+    p = api.pendulum_problem(api.SOLVER_IPDDP if solver == "IPDDP" else api.SOLVER_CLDDP, True)
+    B = 9
+    x0 = api.batch_x0(p, B, 20260930, [0.1, 0.1])
+    lib = api.load_hip()
+
+    def run():
+        o = _options(pycddp, max_iterations=25, tolerance=1e-4, acceptable_tolerance=1e-5)
+        o.regularization.initial_value = 1e-6
+        return _solve_plugin(pycddp, PyPendulum(0.02, 0.5, 1.0, 0.01), np.zeros((2, 2)), 0.1 * np.eye(1), 100.0 * np.eye(2), np.zeros(2), 100, 0.02, o,
+                             [("ControlConstraint", pycddp.ControlConstraint(np.array([-20.0]), np.array([20.0])))], list(x0), pycddp.SolverType[solver])
+    try:
+        assert lib.cddp_hip_plugin_set_host_threads(1) == 0
+        one = run()
+        assert lib.cddp_hip_plugin_set_host_threads(4) == 0
+        four = run()
+    finally:
+        lib.cddp_hip_plugin_set_host_threads(1)
+    assert lib.cddp_hip_plugin_set_host_threads(-1) != 0
+    for a, b in zip(one, four):
+        assert a.status_message == b.status_message and a.iterations_completed == b.iterations_completed and a.final_objective == b.final_objective
+        assert np.array_equal(np.stack(a.state_trajectory), np.stack(b.state_trajectory)) and np.array_equal(np.stack(a.control_trajectory), np.stack(b.control_trajectory))
+        assert np.array_equal(np.stack(a.feedback_gains), np.stack(b.feedback_gains))
+
+
+@pytest.mark.gpu
 def test_python_unicycle_plugin_with_box_and_ball_matches_the_oracle(api, pycddp, oracle_built):
     """nx = 3, nu = 2, two constraint objects (control box 'control_limits' + ball 'obstacle': m = 5, one row reads x): the stacking
     order, the constraint-major merit / violation sums and the G_x terms of the plug-in path against the oracle."""
