@@ -566,6 +566,7 @@ int sfail(int code, const char *fmt, ...) {
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return sfail(-10, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 #include "stacks_coop.hpp"
+#include "stacks_te.hpp"
 
 template <int NX, int NU, int M>
 void launch(const StackArgs &a, hipStream_t s) {
@@ -627,6 +628,9 @@ struct cddp_hip_stack_handle {
   double *d_QuuF = nullptr; int *d_fvalid = nullptr;            // allocated by the first cddp_hip_stacks_factor_cache(h, 1)
   bool factor_cache = false;
   bool have_dyn = false, have_con = false, swept = false;
+  StackTeArgs te{};             // terminal-equality branch (stacks_te.hpp): buffers of the last cddp_hip_set_terminal_equality
+  int te_cap = 0;               // rows the te buffers were sized for
+  bool have_te = false, swept_te = false;
   double last_ms = 0.0;
   std::vector<double> tmp;
 };
@@ -803,9 +807,74 @@ int cddp_hip_set_constraint_stacks(cddp_hip_stack_handle *h, const double *y, co
   return 0;
 }
 
+// Terminal-equality data of the reduced-LQR branch (stacks_te.hpp): H_T [B][pT][nx] (dense rows of the stacked terminal-equality Jacobian),
+// b_T [B][pT] = -h_T(x_N), lambda_prev [B][pT] (Lambda_T_eq_ of the iterate), floor [B] = max(1e-10, jacobian_regularization_value *
+// pow(max(mu, 0), jacobian_regularization_exponent)) evaluated by the caller.
+int cddp_hip_set_terminal_equality(cddp_hip_stack_handle *h, int pT, const double *HT, const double *bT, const double *lambda_prev, const double *reg_floor) {
+  if (!h || !HT || !bT || !lambda_prev || !reg_floor) return sfail(-1, "null argument");
+  if (pT < 1 || pT > kPTS) return sfail(-3, "terminal-equality rows must be 1 .. %d on the stack-fed route (got %d)", kPTS, pT);
+  if (h->m != 0) return sfail(-1, "the terminal-equality branch takes the path constraints condensed into the LQ stacks: use a handle created with m = 0");
+  if (!pick_te(h->nx, h->nu)) return sfail(-3, "no terminal-equality stack kernel for nx = %d, nu = %d", h->nx, h->nu);
+  SCHK(hipSetDevice(h->device));
+  const int N = h->N, nx = h->nx, nu = h->nu, Bp = h->Bp;
+  if (pT > h->te_cap) {
+    int rc;
+    double *p = nullptr;
+    if ((rc = salloc(h, &p, (size_t)pT * nx * Bp))) return rc; h->te.HT = p;
+    if ((rc = salloc(h, &p, (size_t)pT * Bp))) return rc; h->te.bT = p;
+    if ((rc = salloc(h, &p, (size_t)pT * Bp))) return rc; h->te.lam_prev = p;
+    if ((rc = salloc(h, &p, (size_t)Bp))) return rc; h->te.floor_ = p;
+    if ((rc = salloc(h, &h->te.te_p, (size_t)(pT + 1) * (N + 1) * nx * Bp))) return rc;
+    if ((rc = salloc(h, &h->te.te_k, (size_t)(pT + 1) * N * nu * Bp))) return rc;
+    if ((rc = salloc(h, &h->te.dlam, (size_t)pT * Bp))) return rc;
+    if (!h->te.dX && (rc = salloc(h, &h->te.dX, (size_t)(N + 1) * nx * Bp))) return rc;
+    h->te_cap = pT;
+  }
+  h->te.pT = pT;
+  int rc;
+  if ((rc = upload(h, HT, const_cast<double *>(h->te.HT), pT, nx))) return rc;
+  if ((rc = upload(h, bT, const_cast<double *>(h->te.bT), 1, pT))) return rc;
+  if ((rc = upload(h, lambda_prev, const_cast<double *>(h->te.lam_prev), 1, pT))) return rc;
+  if ((rc = upload(h, reg_floor, const_cast<double *>(h->te.floor_), 1, 1))) return rc;
+  h->have_te = true;
+  return 0;
+}
+
+int cddp_hip_stacks_get_terminal(cddp_hip_stack_handle *h, double *dlambda, double *dX) {
+  if (!h) return sfail(-1, "null handle");
+  if (!h->swept_te) return sfail(-1, "no terminal-equality sweep result");
+  SCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = download(h, h->te.dlam, dlambda, 1, h->te.pT))) return rc;
+  if ((rc = download(h, h->te.dX, dX, h->N + 1, h->nx))) return rc;
+  return 0;
+}
+
 int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hip_options *opt, const double *reg, const double *mu,
                              int retry, int32_t *ok) {
   if (!h || !opt || !reg) return sfail(-1, "null argument");
+  if (branch == CDDP_HIP_STACKS_IPDDP_TERM_EQ) {   // reduced LQR with terminal equality rows (stacks_te.hpp)
+    if (!h->have_dyn) return sfail(-1, "cddp_hip_set_stacks must be called before cddp_hip_stacks_backward");
+    if (!h->have_te) return sfail(-1, "cddp_hip_set_terminal_equality must be called before the terminal-equality sweep");
+    if (h->a.Fxx) return sfail(-1, "the terminal-equality branch takes the second-order terms folded into its Q / R / M stacks (ipddp_solver.cpp:1160-1178): drop the Hessian stacks");
+    for (int b = 0; b < h->B; ++b) if (!(reg[b] >= 0.0)) return sfail(-2, "regularisation of trajectory %d must be non-negative (got %g)", b, reg[b]);
+    if (retry && (!(opt->reg_update_factor > 1.0) || !(opt->reg_max_value > 0.0)))
+      return sfail(-2, "retry needs regularization.update_factor > 1 and max_value > 0 (got %g, %g)", opt->reg_update_factor, opt->reg_max_value);
+    SCHK(hipSetDevice(h->device));
+    SCHK(hipMemcpyAsync(h->d_reg, reg, sizeof(double) * h->B, hipMemcpyHostToDevice, h->stream));
+    StackArgs a = h->a;
+    a.branch = branch; a.opt = *opt; a.mu = nullptr; a.lo = a.up = a.U = nullptr; a.QuuF = nullptr; a.fvalid = nullptr;
+    a.reg_factor = retry ? opt->reg_update_factor : 0.0; a.reg_max = opt->reg_max_value; a.tau_min = opt->barrier_min_fraction_to_boundary;
+    SCHK(hipEventRecord(h->e0, h->stream));
+    pick_te(h->nx, h->nu)(a, h->te, h->stream);
+    SCHK(hipEventRecord(h->e1, h->stream));
+    SCHK(hipGetLastError());
+    if (ok) SCHK(hipMemcpyAsync(ok, a.ok, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    SCHK(hipStreamSynchronize(h->stream));
+    float ms = 0; hipEventElapsedTime(&ms, h->e0, h->e1);
+    h->last_ms = ms; h->swept = true; h->swept_te = true; h->used_coop = 0;
+    return 0;
+  }
   if (branch != CDDP_HIP_STACKS_CLDDP && branch != CDDP_HIP_STACKS_IPDDP && branch != CDDP_HIP_STACKS_IPDDP_PATH && branch != CDDP_HIP_STACKS_LOGDDP &&
       branch != CDDP_HIP_STACKS_MSIPDDP && branch != CDDP_HIP_STACKS_MSIPDDP_PATH)
     return sfail(-2, "unknown stack-fed branch %d", branch);

@@ -595,7 +595,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_concurrency", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create_abi", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
-    "cddp_hip_stacks_get_scalars", "cddp_hip_plugin_solve", "cddp_hip_plugin_set_host_threads", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
+    "cddp_hip_stacks_get_scalars", "cddp_hip_set_terminal_equality", "cddp_hip_stacks_get_terminal", "cddp_hip_plugin_solve", "cddp_hip_plugin_set_host_threads", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 
@@ -920,7 +920,7 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     return res, X, U, K
 
 
-STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP, STACKS_MSIPDDP_PATH = 0, 1, 2, 3, 4, 5
+STACKS_CLDDP, STACKS_IPDDP, STACKS_IPDDP_PATH, STACKS_LOGDDP, STACKS_MSIPDDP, STACKS_MSIPDDP_PATH, STACKS_IPDDP_TERM_EQ = 0, 1, 2, 3, 4, 5, 6
 
 
 class HipStackSolver:
@@ -976,6 +976,18 @@ class HipStackSolver:
     def set_constraint_stacks(self, y=None, s=None, g=None, Gx=None, Gu=None):
         a = [(_arr(v) if v is not None else None) for v in (y, s, g, Gx, Gu)]
         self._check(self.lib.cddp_hip_set_constraint_stacks(self.h, *[_ptr(v) for v in a]))
+
+    def set_terminal_equality(self, H_T, b_T, lambda_prev, reg_floor):
+        """Terminal-equality branch (STACKS_IPDDP_TERM_EQ): H_T (B,pT,nx), b_T = -h_T (B,pT), lambda_prev (B,pT), reg_floor (B,)."""
+        H = _arr(H_T); pT = H.shape[1]
+        a = [_arr(b_T).reshape(self.B, pT), _arr(lambda_prev).reshape(self.B, pT), _arr(np.broadcast_to(np.asarray(reg_floor, dtype=np.float64), (self.B,)))]
+        self.pT = pT
+        self._check(self.lib.cddp_hip_set_terminal_equality(self.h, pT, _ptr(H), _ptr(a[0]), _ptr(a[1]), _ptr(a[2])))
+
+    def terminal(self):
+        dlam = np.zeros((self.B, self.pT)); dX = np.zeros((self.B, self.N + 1, self.nx))
+        self._check(self.lib.cddp_hip_stacks_get_terminal(self.h, _ptr(dlam), _ptr(dX)))
+        return dlam, dX
 
     def backward(self, branch, options, reg, mu=None, retry=False):
         reg = _arr(np.broadcast_to(np.asarray(reg, dtype=np.float64), (self.B,)))

@@ -514,6 +514,10 @@ enum cddp_hip_stacks_branch {
   CDDP_HIP_STACKS_MSIPDDP_PATH = 5, /* msipddp_solver.cpp:1222-1420 (path constraints; handle with m > 0, defect stack): the condensation with
                                      plain y / s ratios (no slack floor, no clipping), Q_ux updated as :1398 writes it -- nu = 1 or nx = nu
                                      only --, no linear-policy rollout / step caps */
+  CDDP_HIP_STACKS_IPDDP_TERM_EQ = 6, /* ipddp_solver.cpp:1120-1353, 413-639: the reduced LQR with terminal-equality rows.  The stacks carry the LQ
+                                   * model the reference builds at :1143-1245 (fx = A, fu = B, lx = q, lu = r, lxx = Q, luu = R WITHOUT the
+                                   * regularisation, lux = M as nx x nu, VxN = q_N, VxxN = Q_N; path constraints condensed by the caller) and
+                                   * cddp_hip_set_terminal_equality the dense H_T, b_T = -h_T, previous multipliers (handle with m = 0) */
   CDDP_HIP_STACKS_LOGDDP = 3      /* logddp_solver.cpp:470-575: the caller folds the relaxed log barrier's gradients / Hessians (barrier.hpp:95-262)
                                      into lx, lu, lxx, luu, lux; handle with m = 0                     */
 };
@@ -573,6 +577,16 @@ int cddp_hip_stacks_get_constraint_gains(cddp_hip_stack_handle *h, double *k_y, 
  * and computeMaxStepSizes' (alpha_pr_max, alpha_du_max) (ipddp_solver.cpp:2939-2988; 1 without path constraints). */
 int cddp_hip_stacks_get_scalars(cddp_hip_stack_handle *h, double *reg, double *inf_du, double *inf_pr, double *inf_comp,
                                 double *step_norm, double *alpha_pr_max, double *alpha_du_max);
+/* Terminal-equality branch (CDDP_HIP_STACKS_IPDDP_TERM_EQ; ipddp_solver.cpp:478-639): H_T [B][pT][nx] = the stacked terminal-equality
+ * Jacobian (dense rows), b_T [B][pT] = -h_T(x_N), lambda_prev [B][pT] = Lambda_T_eq_ of the iterate, reg_floor [B] = max(1e-10,
+ * options.ipddp.jacobian_regularization_value * pow(max(mu, 0), jacobian_regularization_exponent)) evaluated by the caller (:577-578: the
+ * plug-in route keeps the host's elementary functions).  1 <= pT <= 8; handle created with m = 0. */
+int cddp_hip_set_terminal_equality(cddp_hip_stack_handle *h, int pT, const double *H_T, const double *b_T, const double *lambda_prev,
+                                   const double *reg_floor);
+/* Results of the terminal-equality sweep: lambda_delta = dLambda_T_eq_ (B*pT) and the linear-policy rollout dX (B*(N+1)*nx) of the
+ * recombined gains (:1252-1268); K, k, Vx (= k_lambda), Vxx (= K_lambda) come through cddp_hip_stacks_get_gains, the regularisation used,
+ * inf_du and step_norm through cddp_hip_stacks_get_scalars.  Either may be NULL. */
+int cddp_hip_stacks_get_terminal(cddp_hip_stack_handle *h, double *lambda_delta, double *dX);
 /* One-shot unconstrained form (create + upload + one launch + download + destroy): Gauss-Newton sweep of
  * ipddp_solver.cpp:1048-1118 when reg_in_value != 0, clddp_solver.cpp:79-204 without bounds otherwise, scalar `reg`. */
 int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,

@@ -361,3 +361,48 @@ def test_stack_handle_argument_checks(api):
     with pytest.raises(api.HipError):
         h0.backward(7, opt, 1e-6)                                      # unknown branch
     h0.close()
+
+
+# ---- round 6: the terminal-equality branch of the stack-fed sweeps (stacks_te.hpp, CDDP_HIP_STACKS_IPDDP_TERM_EQ) -------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 1, 2), (1, 1, 1, 8), (2, 1, 2, 12), (3, 2, 2, 20), (4, 1, 3, 15)])
+def test_terminal_equality_stack_sweep_against_the_twin(api, shape):
+    """solveTerminalEqualityLQR (ipddp_solver.cpp:478-639) on host-fed LQ stacks: dense H_T, previous multipliers, cross terms M, indefinite-free
+    random models -- gains, value recursion (P, p), multiplier step, linear-policy rollout, max |r + B^T p| and max |k| against the numpy twin's
+    restatement (oracle/twin/cddp_twin_te.py), per trajectory."""
+    import cddp_twin_te as TE
+    nx, nu, pT, N = shape
+    B = 5
+    rng = np.random.default_rng(nx * 100 + nu * 10 + pT)
+    A = np.tile(np.eye(nx), (B, N, 1, 1)) + 0.1 * rng.standard_normal((B, N, nx, nx)); Bm = 0.3 * rng.standard_normal((B, N, nx, nu))
+    def spd(n, lead):
+        W = rng.standard_normal(lead + (n, n)); return np.einsum("...ij,...kj->...ik", W, W) / n + 0.5 * np.eye(n)
+    Q = spd(nx, (B, N)); R = spd(nu, (B, N)); QN = spd(nx, (B,))
+    q = rng.standard_normal((B, N, nx)); r = rng.standard_normal((B, N, nu)); qN = rng.standard_normal((B, nx))
+    M = 0.05 * rng.standard_normal((B, N, nx, nu))
+    HT = rng.standard_normal((B, pT, nx)); bT = rng.standard_normal((B, pT)); lam_prev = 0.3 * rng.standard_normal((B, pT))
+    mu, rs, rexp, reg = 0.05, 1e-8, 0.25, 1e-6
+    floor = max(1e-10, rs * mu ** rexp)
+    hs = api.HipStackSolver(B, nx, nu, 0, N)
+    hs.set_stacks(A, Bm, q, r, Q, R, M, qN, QN)                    # fx = A, fu = B, lx = q, lu = r, lxx = Q, luu = R, lux = M (nx x nu), VxN = q_N, VxxN = Q_N
+    hs.set_terminal_equality(HT, bT, lam_prev, floor)
+    ok = hs.backward(api.STACKS_IPDDP_TERM_EQ, api.default_options(), reg, None, retry=False)
+    K, k, p, P, dV = hs.gains()
+    sc = hs.scalars()
+    dlam, dX = hs.terminal()
+    hs.close()
+    assert ok.all()
+    for b in range(B):
+        Rr = [R[b, t] + reg * np.eye(nu) for t in range(N)]
+        okt, Kt, kt, Pt, pt, lam_tot, lam_d = TE.terminal_equality_lqr([Q[b, t] for t in range(N)] + [QN[b]], [q[b, t] for t in range(N)] + [qN[b]], Rr, [r[b, t] for t in range(N)],
+                                                                       [M[b, t] for t in range(N)], [A[b, t] for t in range(N)], [Bm[b, t] for t in range(N)], [np.zeros(nx)] * N,
+                                                                       np.zeros(nx), HT[b], bT[b], mu, rs, rexp, lam_prev[b])
+        assert okt
+        tol = lambda ref: 1e-9 * max(1.0, float(np.max(np.abs(ref))))
+        assert np.max(np.abs(K[b] - np.stack(Kt))) < tol(np.stack(Kt)) and np.max(np.abs(k[b] - np.stack(kt))) < tol(np.stack(kt))
+        assert np.max(np.abs(P[b] - np.stack(Pt))) < tol(np.stack(Pt)) and np.max(np.abs(p[b] - np.stack(pt))) < tol(np.stack(pt))
+        assert np.max(np.abs(dlam[b] - lam_d)) < tol(lam_d)
+        dXt, _ = TE.rollout_linear([A[b, t] for t in range(N)], [Bm[b, t] for t in range(N)], [np.zeros(nx)] * N, Kt, kt, np.zeros(nx))
+        assert np.max(np.abs(dX[b] - np.stack(dXt))) < tol(np.stack(dXt))
+        inf_du = max(float(np.max(np.abs(r[b, t] + Bm[b, t].T @ pt[t + 1]))) for t in range(N))
+        assert abs(sc["inf_du"][b] - inf_du) < 1e-9 * max(1.0, inf_du) and abs(sc["step_norm"][b] - max(float(np.max(np.abs(v))) for v in kt)) < 1e-9 * max(1.0, float(np.max(np.abs(np.stack(kt)))))
