@@ -13,8 +13,8 @@
 //                                                           2548-2660, 2778-2937; interior_point_utils.cpp:79-139
 //   CLDDP  initialize / forwardPass / convergence           clddp_solver.cpp:28-75, 206-277
 //
-// (kernels.hpp holds the same logic as device code: k_init, k_forward_ipddp, k_forward_clddp, k_update.)  Not supported here:
-// terminal constraints (the stack-fed sweeps have no terminal-constraint branch), warm starts.
+// (kernels.hpp holds the same logic as device code: k_init, k_forward_ipddp, k_forward_clddp, k_update.)  Round 6: terminal constraints
+// (cddp_hip_plugin_solve_terminal, ipddp_terminal_solve below) and the "provided trajectory" warm start.
 // This file uses only the public C-ABI of include/cddp_hip.h for the GPU part.
 #include <algorithm>
 #include <atomic>
@@ -161,6 +161,7 @@ double total_cost(const Ctx &c, const double *X, const double *U) {   // CDDPSol
   return J;
 }
 
+void repair_interior(const cddp_hip_options &o, double *s, double *y, int dim);   // (defined with the terminal-constraint code below)
 // ---- ISolverAlgorithm::initialize ------------------------------------------------------------------------------------
 void initialize(const Ctx &c, Traj &T, const double *x0, const double *U0, const double *X0) {
   const int nx = c.nx, nu = c.nu, N = c.N, m = c.m;
@@ -177,7 +178,9 @@ void initialize(const Ctx &c, Traj &T, const double *x0, const double *U0, const
     T.inf_pr = T.inf_du = T.inf_comp = kInf; T.alpha_pr = o.ls_initial_step_size; T.alpha_du = 0.0; T.mu = 0.0;
     return;
   }
-  // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, slack / dual initialisation, cost, filter reset
+  // IPDDP cold start (ipddp_solver.cpp:819-913): re-rollout X from U, mu, g, slack / dual initialisation, cost, filter reset; with
+  // options.warm_start (round 6) the "warm start with provided trajectory" branch (:733-816): a stateless call has no existing solver
+  // state, so the barrier parameter follows the seed's largest constraint value and the duals are initialised from it
   T.mu = (m == 0) ? std::max(o.tolerance / 10.0, o.barrier_mu_min_value) : o.barrier_mu_initial;
   T.alpha_pr = T.alpha_du = 1.0;
   T.S.assign((size_t)N * m, 0.0); T.Y = T.S; T.G = T.S; T.Lam.assign((size_t)(N + 1) * nx, 0.0);
@@ -186,19 +189,34 @@ void initialize(const Ctx &c, Traj &T, const double *x0, const double *U0, const
   for (int t = 0; t < N; ++t) {
     double *x = T.X.data() + (size_t)t * nx, *u = T.U.data() + (size_t)t * nu;
     cost += c.pl->running_cost(c.pl->user, x, u, t);
-    if (m > 0) {
-      double *g = T.G.data() + (size_t)t * m, *s = T.S.data() + (size_t)t * m, *y = T.Y.data() + (size_t)t * m;
-      c.pl->constraints(c.pl->user, x, u, t, g, nullptr, nullptr);
-      for (int i = 0; i < m; ++i) {   // initializeDualSlackVariables (:2456-2468)
-        s[i] = std::max(o.ipddp_slack_var_init_scale, -g[i] + kSlackOffset);
-        y[i] = (T.mu * o.ipddp_dual_var_init_scale) / std::max(s[i], kEpsSlack);
-      }
-    }
+    if (m > 0) c.pl->constraints(c.pl->user, x, u, t, T.G.data() + (size_t)t * m, nullptr, nullptr);
     c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, xn.data());
     std::copy(xn.begin(), xn.end(), T.X.begin() + (size_t)(t + 1) * nx);
   }
   cost += c.pl->terminal_cost(c.pl->user, T.X.data() + (size_t)N * nx);
   T.cost = cost;
+  if (o.warm_start && m > 0) {   // :779-799
+    double mv = 0.0;
+    for (size_t j = 0; j < T.G.size(); ++j) mv = std::max(mv, T.G[j]);
+    if (mv <= o.tolerance) T.mu = std::max(o.tolerance, o.barrier_mu_min_value);
+    else if (mv <= 0.1) T.mu = std::max(o.tolerance * 10.0, o.barrier_mu_initial * 0.01);
+    else T.mu = o.barrier_mu_initial * 0.1;
+  }
+  {   // initializeDualSlackVariables (:2456-2468) / initializeDualSlackVariablesWarmStart without existing duals (:2345-2426), object by object
+    int off = 0;
+    for (int sidx = 0; sidx < (m > 0 ? c.pl->n_constraints : 0); ++sidx) {
+      const int dim = c.pl->constraint_dims[sidx];
+      for (int t = 0; t < N; ++t) {
+        double *g = T.G.data() + (size_t)t * m + off, *s = T.S.data() + (size_t)t * m + off, *y = T.Y.data() + (size_t)t * m + off;
+        for (int i = 0; i < dim; ++i) {
+          s[i] = std::max(o.ipddp_slack_var_init_scale, -g[i] + kSlackOffset);
+          y[i] = (T.mu * o.ipddp_dual_var_init_scale) / std::max(s[i], kEpsSlack);
+        }
+        repair_interior(o, s, y, dim);
+      }
+      off += dim;
+    }
+  }
   double phi = cost, theta = 0.0, ipr = 0.0, icomp = 0.0;   // resetFilter (:2484-2519)
   if (m > 0) ip_reductions(c, T.S.data(), T.Y.data(), T.G.data(), T.mu, cost, phi, theta, ipr, icomp);
   T.merit = T.phi = phi; T.inf_pr = ipr; T.inf_comp = icomp; T.inf_du = 0.0;
@@ -1021,6 +1039,660 @@ int msipddp_solve(const Ctx &c, int device, int batch, const double *x0, const d
   return 0;
 }
 
+// ======================================================================================================================
+// IPDDP with TERMINAL constraints for host plug-ins (round 6).  The reference's own user-plant regression pairs a
+// DynamicalSystem subclass with a TerminalEqualityConstraint and use_ilqr = false (tests/cddp_core/test_ipddp_solver.cpp:292-346,
+// 1512-1578).  Division of labour as above: callbacks, LQ-model assembly (the path constraints condensed into Q, q, R, r, M exactly as
+// ipddp_solver.cpp:1143-1245 does; terminal-inequality barrier terms added to V_x, V_xx, :1000-1031) and the filter line search on the
+// host; the Riccati work on the GPU -- the reduced LQR with terminal-equality rows (CDDP_HIP_STACKS_IPDDP_TERM_EQ, stacks_te.hpp) or,
+// with terminal inequalities only, the ordinary stack-fed sweeps on the modified terminal value.  Also here: the "warm start with
+// provided trajectory" initialisation (:733-816) when options.warm_start is set (a stateless call has no existing solver state).
+// ======================================================================================================================
+constexpr double kEpsDual = 1e-10;   // EPS_DUAL ipddp_solver.cpp:37
+
+struct TermInfo {
+  const cddp_hip_plugin_terminal *tc = nullptr;
+  int nobj = 0, rows = 0, mT = 0, pT = 0;
+  int dim[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS], eq[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS], src[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS], dst[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS];
+  // evaluate -> (g_T rows of the inequality objects in object order | h_T rows of the equality objects in object order) (+ Jacobian rows)
+  void eval(void *user, int nx, const double *xN, double *gT, double *GTx, double *hT, double *HT, std::vector<double> &r, std::vector<double> &rx) const {
+    if (!tc || rows == 0) return;
+    r.assign((size_t)rows, 0.0); rx.assign((size_t)rows * nx, 0.0);
+    tc->evaluate(user, xN, r.data(), (GTx || HT) ? rx.data() : nullptr);
+    for (int s = 0; s < nobj; ++s)
+      for (int i = 0; i < dim[s]; ++i) {
+        if (eq[s]) { if (hT) hT[dst[s] + i] = r[src[s] + i]; if (HT) std::copy(rx.begin() + (size_t)(src[s] + i) * nx, rx.begin() + (size_t)(src[s] + i + 1) * nx, HT + (size_t)(dst[s] + i) * nx); }
+        else { if (gT) gT[dst[s] + i] = r[src[s] + i]; if (GTx) std::copy(rx.begin() + (size_t)(src[s] + i) * nx, rx.begin() + (size_t)(src[s] + i + 1) * nx, GTx + (size_t)(dst[s] + i) * nx); }
+      }
+  }
+};
+
+struct TTraj : Traj {
+  std::vector<double> ST, YT, GT, dST, dYT, LamT, dLamT;              // terminal slack / dual / residual (mT), multipliers (pT)
+  std::vector<double> ky, Ky, ks, Ks;                                  // path gains of the last sweep (host-formed in the terminal-equality branch)
+  std::vector<double> gGx;                                             // G_x of the last backward pass (computeScaledDualInfeasibility)
+  double l_pr = 0.0, l_comp = 0.0;                                     // terminal (and, in the reduced-LQR branch, path) residual maxima of the last sweep
+};
+struct TTrial : Trial { std::vector<double> ST, YT, GT, LamT; };
+
+void repair_interior(const cddp_hip_options &o, double *s, double *y, int dim) {   // repairWarmstartInterior (:233-262), one constraint object
+  if (!o.ipddp_warmstart_repair || dim <= 0) return;
+  double mn = kInf, mny = kInf;
+  for (int i = 0; i < dim; ++i) { s[i] = std::max(s[i], o.ipddp_warmstart_s_min); mn = std::min(mn, s[i]); }
+  if (mn < o.ipddp_warmstart_s_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) s[i] = s[i] * o.ipddp_warmstart_interior_factor;
+  for (int i = 0; i < dim; ++i) { y[i] = std::max(y[i], o.ipddp_warmstart_y_min); mny = std::min(mny, y[i]); }
+  if (mny < o.ipddp_warmstart_y_min * o.ipddp_warmstart_interior_factor) for (int i = 0; i < dim; ++i) y[i] = y[i] * o.ipddp_warmstart_interior_factor;
+}
+
+// computeTheta / computeBarrierMerit / computePrimalAndComplementarity with the terminal terms (ipddp_solver.cpp:2778-2937): path objects
+// (constraint-major, then t), then the terminal-inequality objects, then the stacked terminal-equality residual
+void ip_reductions_t(const Ctx &c, const TermInfo &ti, const double *S, const double *Y, const double *G, const double *ST, const double *YT, const double *GT,
+                     const double *LamT, const double *hT, double mu, double cost0, double &phi, double &theta, double &inf_pr, double &inf_comp) {
+  const int m = c.m, N = c.N;
+  const bool l2 = c.o->ipddp_theta_norm_l2 != 0;
+  double total = 0.0, max_entry = 0.0, ipr = 0.0, icomp = 0.0, mer = cost0;
+  int off = 0;
+  for (int s = 0; s < (m > 0 ? c.pl->n_constraints : 0); ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < N; ++t) {
+      double n1 = 0.0, ninf = 0.0;
+      for (int i = 0; i < dim; ++i) {
+        const size_t j = (size_t)t * m + off + i;
+        const double r = G[j] + S[j];
+        n1 += l2 ? r * r : std::fabs(r);
+        ninf = std::max(ninf, std::fabs(r));
+      }
+      total += n1; max_entry = std::max(max_entry, ninf);
+    }
+    off += dim;
+  }
+  for (int s = 0; s < ti.nobj; ++s) if (!ti.eq[s]) {
+    double n1 = 0.0, ninf = 0.0;
+    for (int i = 0; i < ti.dim[s]; ++i) { const double r = GT[ti.dst[s] + i] + ST[ti.dst[s] + i]; n1 += l2 ? r * r : std::fabs(r); ninf = std::max(ninf, std::fabs(r)); }
+    total += n1; max_entry = std::max(max_entry, ninf);
+  }
+  if (ti.pT > 0) {
+    double n1 = 0.0, ninf = 0.0;
+    for (int i = 0; i < ti.pT; ++i) { n1 += l2 ? hT[i] * hT[i] : std::fabs(hT[i]); ninf = std::max(ninf, std::fabs(hT[i])); }
+    total += n1; max_entry = std::max(max_entry, ninf);
+  }
+  off = 0;
+  for (int s = 0; s < (m > 0 ? c.pl->n_constraints : 0); ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < N; ++t) {
+      double ls = 0.0;
+      for (int i = 0; i < dim; ++i) ls += std::log(std::max(S[(size_t)t * m + off + i], kEpsSlack));
+      mer -= mu * ls;
+    }
+    off += dim;
+  }
+  for (int s = 0; s < ti.nobj; ++s) if (!ti.eq[s]) {
+    double ls = 0.0;
+    for (int i = 0; i < ti.dim[s]; ++i) ls += std::log(std::max(ST[ti.dst[s] + i], kEpsSlack));
+    mer -= mu * ls;
+  }
+  if (ti.pT > 0) { double dp = 0.0; for (int i = 0; i < ti.pT; ++i) dp += LamT[i] * hT[i]; mer += dp; }
+  off = 0;
+  for (int s = 0; s < (m > 0 ? c.pl->n_constraints : 0); ++s) {
+    const int dim = c.pl->constraint_dims[s];
+    for (int t = 0; t < N; ++t)
+      for (int i = 0; i < dim; ++i) {
+        const size_t j = (size_t)t * m + off + i;
+        ipr = std::max(ipr, std::fabs(G[j] + S[j])); icomp = std::max(icomp, std::fabs(Y[j] * S[j] - mu));
+      }
+    off += dim;
+  }
+  for (int i = 0; i < ti.mT; ++i) { ipr = std::max(ipr, std::fabs(GT[i] + ST[i])); icomp = std::max(icomp, std::fabs(YT[i] * ST[i] - mu)); }
+  for (int i = 0; i < ti.pT; ++i) ipr = std::max(ipr, std::fabs(hT[i]));
+  const double th = l2 ? std::sqrt(total) : total;
+  theta = std::max(th, max_entry);
+  phi = mer; inf_pr = ipr; inf_comp = icomp;
+}
+
+// resetFilter (:2484-2519)
+void reset_filter_t(const Ctx &c, const TermInfo &ti, TTraj &T, std::vector<double> &r, std::vector<double> &rx) {
+  std::vector<double> hT((size_t)std::max(ti.pT, 1), 0.0);
+  if (ti.pT > 0) ti.eval(c.pl->user, c.nx, T.X.data() + (size_t)c.N * c.nx, nullptr, nullptr, hT.data(), nullptr, r, rx);
+  double phi, theta, ipr, icomp;
+  ip_reductions_t(c, ti, T.S.data(), T.Y.data(), T.G.data(), T.ST.data(), T.YT.data(), T.GT.data(), T.LamT.data(), hT.data(), T.mu, T.cost, phi, theta, ipr, icomp);
+  T.merit = T.phi = phi; T.inf_pr = ipr; T.inf_comp = icomp;
+  T.filter_theta = std::max(theta, 1e-8);
+  T.theta = std::max(T.filter_theta, std::max(c.o->ipddp_theta_0_floor, 1e-8));
+  T.filter.clear();
+  if (ti.mT > 0 || ti.pT > 0) filter_accept(T.filter, T.phi, T.filter_theta);
+}
+
+// IPDDPSolver::initialize: cold start (:819-913) or, with options.warm_start, "warm start with provided trajectory" (:733-816)
+void initialize_t(const Ctx &c, const TermInfo &ti, TTraj &T, const double *x0, const double *U0, const double *X0) {
+  const int nx = c.nx, nu = c.nu, N = c.N, m = c.m;
+  const cddp_hip_options &o = *c.o;
+  const bool warm = o.warm_start != 0;
+  T.X.assign((size_t)(N + 1) * nx, 0.0); T.U.assign((size_t)N * nu, 0.0);
+  if (U0) std::copy(U0, U0 + (size_t)N * nu, T.U.begin());
+  (void)X0;   // both branches re-roll X out from the controls (:868-874, :771-777)
+  std::copy(x0, x0 + nx, T.X.begin());
+  T.reg = o.reg_initial_value; T.iter = 0; T.status = CDDP_HIP_STATUS_RUNNING; T.done = false; T.n_bwd = T.n_fwd = 0;
+  T.dV0 = T.dV1 = 0.0; T.step_norm = 0.0; T.filter.clear(); T.alpha_pr = T.alpha_du = 1.0;
+  T.S.assign((size_t)N * m, 0.0); T.Y = T.S; T.G = T.S; T.Lam.assign((size_t)(N + 1) * nx, 0.0);
+  T.ST.assign((size_t)std::max(ti.mT, 1), 0.0); T.YT = T.ST; T.GT = T.ST; T.dST = T.ST; T.dYT = T.ST;
+  T.LamT.assign((size_t)std::max(ti.pT, 1), 0.0); T.dLamT = T.LamT;
+  std::vector<double> r, rx, xn(nx);
+  double cost = 0.0;
+  for (int t = 0; t < N; ++t) {   // evaluateTrajectory (:2252-2296) / re-rollout + evaluateTrajectoryWarmStart (:2296-2343): same numbers
+    double *x = T.X.data() + (size_t)t * nx, *u = T.U.data() + (size_t)t * nu;
+    cost += c.pl->running_cost(c.pl->user, x, u, t);
+    if (m > 0) c.pl->constraints(c.pl->user, x, u, t, T.G.data() + (size_t)t * m, nullptr, nullptr);
+    c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, xn.data());
+    std::copy(xn.begin(), xn.end(), T.X.begin() + (size_t)(t + 1) * nx);
+  }
+  cost += c.pl->terminal_cost(c.pl->user, T.X.data() + (size_t)N * nx);
+  T.cost = cost;
+  if (ti.mT > 0) ti.eval(c.pl->user, nx, T.X.data() + (size_t)N * nx, T.GT.data(), nullptr, nullptr, nullptr, r, rx);
+  if (!warm) T.mu = o.barrier_mu_initial;   // (a terminal set exists: never the unconstrained value)
+  else {   // :779-799: barrier parameter from the seed's largest constraint value
+    double mv = 0.0;
+    for (size_t j = 0; j < T.G.size(); ++j) mv = std::max(mv, T.G[j]);
+    for (int i = 0; i < ti.mT; ++i) mv = std::max(mv, T.GT[i]);
+    if (mv <= o.tolerance) T.mu = std::max(o.tolerance, o.barrier_mu_min_value);
+    else if (mv <= 0.1) T.mu = std::max(o.tolerance * 10.0, o.barrier_mu_initial * 0.01);
+    else T.mu = o.barrier_mu_initial * 0.1;
+  }
+  {   // initializeDualSlackVariables (:2428-2482) / ...WarmStart without existing duals (:2345-2426)
+    int off = 0;
+    for (int s = 0; s < (m > 0 ? c.pl->n_constraints : 0); ++s) {
+      const int dim = c.pl->constraint_dims[s];
+      for (int t = 0; t < N; ++t) {
+        double *g = T.G.data() + (size_t)t * m + off, *sv = T.S.data() + (size_t)t * m + off, *y = T.Y.data() + (size_t)t * m + off;
+        for (int i = 0; i < dim; ++i) { sv[i] = std::max(o.ipddp_slack_var_init_scale, -g[i] + kSlackOffset); y[i] = (T.mu * o.ipddp_dual_var_init_scale) / std::max(sv[i], kEpsSlack); }
+        repair_interior(o, sv, y, dim);
+      }
+      off += dim;
+    }
+    for (int s = 0; s < ti.nobj; ++s) if (!ti.eq[s]) {   // :889-908 / initializeTerminalWarmstartDualSlack (:294-353)
+      double *g = T.GT.data() + ti.dst[s], *sv = T.ST.data() + ti.dst[s], *y = T.YT.data() + ti.dst[s];
+      for (int i = 0; i < ti.dim[s]; ++i) { sv[i] = std::max(o.ipddp_slack_var_init_scale, -g[i] + kSlackOffset); y[i] = (T.mu * o.ipddp_dual_var_init_scale) / std::max(sv[i], kEpsSlack); }
+      repair_interior(o, sv, y, ti.dim[s]);
+    }
+  }
+  reset_filter_t(c, ti, T, r, rx);
+  T.inf_du = 0.0;
+}
+
+// forwardPass with terminal sets (ipddp_solver.cpp:1571-1876)
+TTrial forward_ipddp_t(const Ctx &c, const TermInfo &ti, const TTraj &T, const Gains &g, double alpha, const double *GTx0) {
+  const int nx = c.nx, nu = c.nu, N = c.N, m = c.m;
+  const cddp_hip_options &o = *c.o;
+  const bool hti = ti.mT > 0, hte = ti.pT > 0;
+  TTrial r;
+  const double mu = T.mu;
+  const double tau = (m == 0 && !hti) ? 1.0 : std::max(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+  const double a_pr = std::min(alpha, T.apr_max), a_du = std::min(alpha, T.adu_max);
+  r.alpha_pr = a_pr; r.alpha_du = a_du;
+  r.cost = T.cost; r.merit = T.phi; r.theta = T.theta;
+  r.X.assign(T.X.size(), 0.0); r.U.assign(T.U.size(), 0.0); r.Lam.assign(T.Lam.size(), 0.0);
+  r.S = T.S; r.Y = T.Y; r.G.assign(T.S.size(), 0.0);
+  r.ST = T.ST; r.YT = T.YT; r.GT = T.GT; r.LamT = T.LamT;
+  std::copy(T.X.begin(), T.X.begin() + nx, r.X.begin());
+  std::vector<double> dx(nx), rr, rrx;
+  for (int t = 0; t <= N; ++t) {
+    const double *x = r.X.data() + (size_t)t * nx, *xo = T.X.data() + (size_t)t * nx;
+    for (int i = 0; i < nx; ++i) dx[i] = x[i] - xo[i];
+    for (int i = 0; i < nx; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < nx; ++j) s += g.Vxx[((size_t)t * nx + i) * nx + j] * dx[j];
+      const double lam = (T.Lam[(size_t)t * nx + i] + a_pr * g.Vx[(size_t)t * nx + i]) + s;
+      if (!fin(lam)) return r;
+      r.Lam[(size_t)t * nx + i] = lam;
+    }
+    if (t == N) break;
+    for (int q = 0; q < m; ++q) {
+      const size_t j = (size_t)t * m + q;
+      double ps = 0.0, py = 0.0;
+      for (int i = 0; i < nx; ++i) { ps = ps + g.Ks[j * nx + i] * dx[i]; py = py + g.Ky[j * nx + i] * dx[i]; }
+      const double sn = (T.S[j] + a_pr * g.ks[j]) + ps;
+      const double yn = (T.Y[j] + a_du * g.ky[j]) + py;
+      if (sn < (1.0 - tau) * T.S[j] || yn < (1.0 - tau) * T.Y[j]) return r;
+      if (!fin(sn) || !fin(yn)) return r;
+      r.S[j] = sn; r.Y[j] = yn;
+    }
+    const double *uo = T.U.data() + (size_t)t * nu;
+    double *u = r.U.data() + (size_t)t * nu;
+    for (int i = 0; i < nu; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < nx; ++j) s += g.K[((size_t)t * nu + i) * nx + j] * dx[j];
+      u[i] = (uo[i] + a_pr * g.k[(size_t)t * nu + i]) + s;
+    }
+    double *xn = r.X.data() + (size_t)(t + 1) * nx;
+    c.pl->discrete_dynamics(c.pl->user, x, u, t * c.dt, xn);
+    for (int i = 0; i < nx; ++i) if (!fin(xn[i])) return r;
+    for (int i = 0; i < nu; ++i) if (!fin(u[i])) return r;
+  }
+  // dx holds x_N' - x_N here
+  if (hti) {   // terminal slack / dual trial (:1667-1714); Jacobian and residual of the CURRENT iterate's x_N
+    const double floor0 = std::max(mu * 1e-3, kEpsSlack);
+    for (int s = 0; s < ti.nobj; ++s) if (!ti.eq[s]) {
+      for (int i = 0; i < ti.dim[s]; ++i) {
+        const int j = ti.dst[s] + i;
+        const double ksT = -(T.GT[j] + T.ST[j]);
+        double kd = 0.0;
+        for (int k = 0; k < nx; ++k) kd += (-GTx0[(size_t)j * nx + k]) * dx[k];                 // K_s_T * dx
+        r.ST[j] = (T.ST[j] + a_pr * ksT) + kd;
+        const double s_safe = std::max(T.ST[j], floor0);
+        const double r_d = T.YT[j] * T.ST[j] - mu;
+        const double dual_ratio = clampd(T.YT[j] / s_safe, 0.0, kMaxRatio);
+        const double kyv = clampd((-r_d - T.YT[j] * ksT) / s_safe, -kMaxRatio, kMaxRatio);
+        double dotv = 0.0;
+        for (int k = 0; k < nx; ++k) dotv += (-(dual_ratio * (-GTx0[(size_t)j * nx + k]))) * dx[k];
+        r.YT[j] = (T.YT[j] + a_du * kyv) + dotv;
+      }
+      for (int i = 0; i < ti.dim[s]; ++i) {
+        const int j = ti.dst[s] + i;
+        const double s_floor = std::max((1.0 - tau) * T.ST[j], floor0);
+        if (r.ST[j] < s_floor || r.YT[j] < (1.0 - tau) * T.YT[j]) return r;
+      }
+      for (int i = 0; i < ti.dim[s]; ++i) if (!fin(r.ST[ti.dst[s] + i]) || !fin(r.YT[ti.dst[s] + i])) return r;
+    }
+  }
+  if (hte) for (int i = 0; i < ti.pT; ++i) { r.LamT[i] = T.LamT[i] + a_pr * T.dLamT[i]; if (!fin(r.LamT[i])) return r; }
+  double cost_new = 0.0;
+  for (int t = 0; t < N; ++t) {
+    const double *x = r.X.data() + (size_t)t * nx, *u = r.U.data() + (size_t)t * nu;
+    cost_new += c.pl->running_cost(c.pl->user, x, u, t);
+    if (m > 0) c.pl->constraints(c.pl->user, x, u, t, r.G.data() + (size_t)t * m, nullptr, nullptr);
+  }
+  cost_new += c.pl->terminal_cost(c.pl->user, r.X.data() + (size_t)N * nx);
+  std::vector<double> hTn((size_t)std::max(ti.pT, 1), 0.0);
+  ti.eval(c.pl->user, nx, r.X.data() + (size_t)N * nx, hti ? r.GT.data() : nullptr, nullptr, hte ? hTn.data() : nullptr, nullptr, rr, rrx);
+  double phi_new, theta_new, ipr, icomp;
+  ip_reductions_t(c, ti, r.S.data(), r.Y.data(), r.G.data(), r.ST.data(), r.YT.data(), r.GT.data(), r.LamT.data(), hTn.data(), mu, cost_new, phi_new, theta_new, ipr, icomp);
+  if (!fin(phi_new) || !fin(theta_new) || !fin(ipr) || !fin(icomp)) return r;
+  bool accept = false;
+  {   // filter acceptance (:1793-1834): a terminal set exists
+    const double expected_improvement = a_pr * T.dV0;
+    const bool fe = T.filter.empty();
+    const double cv_old = fe ? 0.0 : T.filter.back().second;
+    const double high_ref = fe ? T.filter_theta : cv_old;
+    const double merit_old = T.merit;
+    if (theta_new > o.filter_max_violation_threshold) {
+      if (theta_new < (1 - o.filter_violation_acceptance_threshold) * high_ref) accept = true;
+    } else if (std::max(theta_new, cv_old) < o.filter_min_violation_for_armijo_check && expected_improvement < 0) {
+      if (phi_new < merit_old + o.filter_armijo_constant * expected_improvement) accept = true;
+    } else {
+      if (phi_new < merit_old - o.filter_merit_acceptance_threshold * theta_new ||
+          theta_new < (1 - o.filter_violation_acceptance_threshold) * cv_old) accept = true;
+    }
+  }
+  r.cost = cost_new; r.merit = phi_new; r.theta = theta_new; r.inf_pr = ipr; r.inf_comp = icomp;
+  r.success = accept;
+  return r;
+}
+
+int ipddp_terminal_solve(const Ctx &c, const TermInfo &ti, int device, int batch, const double *x0, const double *U0, const double *X0,
+                         cddp_hip_result *results, double *Xout, double *Uout, double *Kout, double *Tout) {
+  const cddp_hip_plugin *pl = c.pl; const cddp_hip_options &o = *c.o; const cddp_hip_options *opt = c.o;
+  const int nx = c.nx, nu = c.nu, m = c.m, N = c.N, mT = ti.mT, pT = ti.pT; const double dt = c.dt;
+  const bool hti = mT > 0, hte = pT > 0, no_barrier = (m == 0 && !hti);
+  const size_t B = (size_t)batch;
+  // terminal-equality rows: the reduced LQR takes the path constraints condensed (handle with m = 0); otherwise the ordinary sweeps
+  cddp_hip_stack_handle *sh = nullptr;
+  { int rc = cddp_hip_stacks_create(device, batch, nx, nu, hte ? 0 : m, N, &sh); if (rc) return rc; }
+  struct Guard { cddp_hip_stack_handle *h; ~Guard() { if (h) cddp_hip_stacks_destroy(h); } } guard{sh};
+  std::vector<TTraj> T(B);
+  const int n_threads = host_threads((int)B);
+  par_for(B, n_threads, [&](size_t b) { initialize_t(c, ti, T[b], x0 + b * nx, U0 ? U0 + b * N * nu : nullptr, X0 ? X0 + b * (N + 1) * nx : nullptr); });
+
+  std::vector<double> fx(B * N * nx * nx), fu(B * N * nx * nu), lx(B * N * nx), lu(B * N * nu), lxx(B * N * nx * nx), luu(B * N * nu * nu),
+      lux(B * N * nu * nx), VxN(B * nx), VxxN(B * nx * nx);
+  std::vector<double> gy, gs, gg, gGx, gGu, Fxx, Fuu, Fux;
+  if (m > 0) { gy.resize(B * N * m); gs = gy; gg = gy; gGx.resize(B * N * m * nx); gGu.resize(B * N * m * nu); }
+  if (!o.use_ilqr) { Fxx.resize(B * N * nx * nx * nx); Fuu.resize(B * N * nx * nu * nu); Fux.resize(B * N * nx * nu * nx); }
+  std::vector<double> Kb(B * N * nu * nx), kb(B * N * nu), Vxb(B * (N + 1) * nx), Vxxb(B * (N + 1) * nx * nx), dVb(B * 2);
+  std::vector<double> Kfin(Kout ? B * N * nu * nx : 0, 0.0);
+  std::vector<double> kyb, Kyb, ksb, Ksb, dXb(B * (N + 1) * nx, 0.0);
+  if (m > 0) { kyb.resize(B * N * m); ksb = kyb; Kyb.resize(B * N * m * nx); Ksb = Kyb; }
+  std::vector<double> GTxb(B * (size_t)std::max(mT, 1) * nx, 0.0), HTb(B * (size_t)std::max(pT, 1) * nx, 0.0), bTb(B * (size_t)std::max(pT, 1), 0.0),
+      lamb(B * (size_t)std::max(pT, 1), 0.0), floorb(B, 0.0), dlamb(B * (size_t)std::max(pT, 1), 0.0);
+  std::vector<double> regv(B), muv(B), s_reg(B), s_du(B), s_pr(B), s_comp(B), s_sn(B), s_apr(B), s_adu(B);
+  std::vector<int32_t> okv(B);
+  const bool first_rule = !o.enable_parallel;
+  std::atomic<bool> abort_seen{false};
+  const auto wall0 = std::chrono::steady_clock::now();
+
+  for (int it = 1; it <= o.max_iterations; ++it) {
+    bool any = false;
+    for (auto &t : T) any = any || !t.done;
+    if (!any) break;
+    if (aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
+    if (o.max_cpu_time > 0.0) {
+      const double el_ms = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - wall0).count();
+      if (el_ms > o.max_cpu_time * 1000.0) { for (auto &t : T) if (!t.done) { t.iter += 1; t.status = CDDP_HIP_STATUS_MAX_CPU_TIME; t.done = true; } break; }
+    }
+    // ---- host: derivatives, terminal value, LQ model
+    auto fill = [&](size_t b) {
+      TTraj &t = T[b];
+      regv[b] = t.done ? std::max(t.reg, o.reg_min_value) : t.reg;
+      muv[b] = (t.mu > 0.0) ? t.mu : 1.0;
+      floorb[b] = std::max(1e-10, o.ipddp_jacobian_regularization_value * std::pow(std::max(t.mu, 0.0), o.ipddp_jacobian_regularization_exponent));
+      if (t.done) return;
+      t.iter += 1;
+      const double mu = t.mu, fl0 = std::max(mu * 1e-3, kEpsSlack);
+      std::vector<double> tfx((size_t)nx * nx), tfu((size_t)nx * nu), r, rx, hT((size_t)std::max(pT, 1), 0.0);
+      double *Vx = VxN.data() + b * nx, *Vxx = VxxN.data() + b * nx * nx;
+      const double *xN = t.X.data() + (size_t)N * nx;
+      pl->terminal_cost_derivatives(pl->user, xN, Vx, Vxx);
+      { std::vector<double> S2((size_t)nx * nx); for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) S2[i * nx + j] = 0.5 * (Vxx[i * nx + j] + Vxx[j * nx + i]); std::copy(S2.begin(), S2.end(), Vxx); }
+      t.l_pr = 0.0; t.l_comp = 0.0;
+      double *GTx = GTxb.data() + b * (size_t)std::max(mT, 1) * nx, *HT = HTb.data() + b * (size_t)std::max(pT, 1) * nx;
+      ti.eval(pl->user, nx, xN, hti ? t.GT.data() : nullptr, hti ? GTx : nullptr, hte ? hT.data() : nullptr, hte ? HT : nullptr, r, rx);
+      for (int s = 0; s < ti.nobj; ++s) if (!ti.eq[s]) {   // terminal-inequality barrier terms (:1000-1031), object by object
+        const int d0 = ti.dst[s], dim = ti.dim[s];
+        std::vector<double> sig(dim), bg(dim);
+        for (int i = 0; i < dim; ++i) {
+          const double s_safe = std::max(t.ST[d0 + i], fl0), y_safe = std::max(t.YT[d0 + i], kEpsDual);
+          sig[i] = clampd(y_safe / s_safe, 0.0, kMaxRatio);
+          bg[i] = y_safe + clampd((y_safe * t.GT[d0 + i] + mu) / s_safe, -kMaxRatio, kMaxRatio);
+        }
+        for (int j = 0; j < nx; ++j) { double a = 0.0; for (int i = 0; i < dim; ++i) a += GTx[(size_t)(d0 + i) * nx + j] * bg[i]; Vx[j] += a; }
+        for (int j = 0; j < nx; ++j) for (int k = 0; k < nx; ++k) { double a = 0.0; for (int i = 0; i < dim; ++i) a += (GTx[(size_t)(d0 + i) * nx + j] * sig[i]) * GTx[(size_t)(d0 + i) * nx + k]; Vxx[j * nx + k] += a; }
+        { std::vector<double> S2((size_t)nx * nx); for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) S2[i * nx + j] = 0.5 * (Vxx[i * nx + j] + Vxx[j * nx + i]); std::copy(S2.begin(), S2.end(), Vxx); }
+        for (int i = 0; i < dim; ++i) { t.l_pr = std::max(t.l_pr, std::fabs(t.GT[d0 + i] + t.ST[d0 + i])); t.l_comp = std::max(t.l_comp, std::fabs(t.YT[d0 + i] * t.ST[d0 + i] - mu)); }
+      }
+      if (hte) {
+        for (int i = 0; i < pT; ++i) { t.l_pr = std::max(t.l_pr, std::fabs(hT[i])); bTb[b * pT + i] = -hT[i]; lamb[b * pT + i] = t.LamT[i]; t.dLamT[i] = -hT[i]; }
+      }
+      if (m > 0) t.gGx.assign((size_t)N * m * nx, 0.0);
+      for (int s = 0; s < N; ++s) {
+        const double *x = t.X.data() + (size_t)s * nx, *u = t.U.data() + (size_t)s * nu;
+        const size_t bs = b * N + s;
+        pl->jacobians(pl->user, x, u, s * dt, tfx.data(), tfu.data());
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double a = dt * tfx[i * nx + j]; if (i == j) a += 1.0; fx[(bs * nx + i) * nx + j] = a; }
+        for (int i = 0; i < nx * nu; ++i) fu[bs * nx * nu + i] = dt * tfu[i];
+        double *q = lx.data() + bs * nx, *rr = lu.data() + bs * nu, *Q = lxx.data() + bs * nx * nx, *R = luu.data() + bs * nu * nu, *Mx = lux.data() + bs * nu * nx;
+        pl->running_cost_derivatives(pl->user, x, u, s, q, rr, Q, R, Mx);
+        if (!o.use_ilqr) {
+          double *pxx = Fxx.data() + bs * nx * nx * nx, *puu = Fuu.data() + bs * nx * nu * nu, *pux = Fux.data() + bs * nx * nu * nx;
+          pl->hessians(pl->user, x, u, s * dt, pxx, puu, pux);
+          for (int e = 0; e < nx * nx * nx; ++e) pxx[e] = dt * pxx[e];
+          for (int e = 0; e < nx * nu * nu; ++e) puu[e] = dt * puu[e];
+          for (int e = 0; e < nx * nu * nx; ++e) pux[e] = dt * pux[e];
+        }
+        if (m > 0) {
+          pl->constraints(pl->user, x, u, s, gg.data() + bs * m, gGx.data() + bs * m * nx, gGu.data() + bs * m * nu);
+          std::copy(t.G.begin() + (size_t)s * m, t.G.begin() + (size_t)(s + 1) * m, gg.begin() + bs * m);
+          std::copy(t.S.begin() + (size_t)s * m, t.S.begin() + (size_t)(s + 1) * m, gs.begin() + bs * m);
+          std::copy(t.Y.begin() + (size_t)s * m, t.Y.begin() + (size_t)(s + 1) * m, gy.begin() + bs * m);
+          std::copy(gGx.begin() + bs * m * nx, gGx.begin() + (bs + 1) * m * nx, t.gGx.begin() + (size_t)s * m * nx);
+        }
+        if (!hte) continue;
+        // ---- LQ model of the reduced LQR (:1143-1247): Q = sym(l_xx), R = sym(l_uu), M = l_ux^T, (+ second-order terms weighed with the
+        //      costate iterate, :1160-1178), path constraints condensed (:1180-1245); the regularisation is added by the sweep
+        std::vector<double> Qs((size_t)nx * nx), Rs((size_t)nu * nu), Mm((size_t)nx * nu);
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) Qs[i * nx + j] = 0.5 * (Q[i * nx + j] + Q[j * nx + i]);
+        for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) Rs[i * nu + j] = 0.5 * (R[i * nu + j] + R[j * nu + i]);
+        for (int a = 0; a < nu; ++a) for (int cix = 0; cix < nx; ++cix) Mm[cix * nu + a] = Mx[a * nx + cix];
+        if (!o.use_ilqr) {
+          const double *lam = t.Lam.data() + (size_t)(s + 1) * nx;
+          bool lf = true; for (int i = 0; i < nx; ++i) lf = lf && fin(lam[i]);
+          const double *pxx = Fxx.data() + bs * nx * nx * nx, *puu = Fuu.data() + bs * nx * nu * nu, *pux = Fux.data() + bs * nx * nu * nx;
+          for (int i = 0; i < nx; ++i) {
+            const double li = lf ? lam[i] : 0.0;
+            for (int e = 0; e < nx * nx; ++e) Qs[e] = Qs[e] + li * pxx[(size_t)i * nx * nx + e];
+            for (int a = 0; a < nu; ++a) for (int cix = 0; cix < nx; ++cix) Mm[cix * nu + a] = Mm[cix * nu + a] + li * pux[(size_t)i * nu * nx + a * nx + cix];
+            for (int e = 0; e < nu * nu; ++e) Rs[e] = Rs[e] + li * puu[(size_t)i * nu * nu + e];
+          }
+          std::vector<double> Q2(Qs), R2(Rs);
+          for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) Qs[i * nx + j] = 0.5 * (Q2[i * nx + j] + Q2[j * nx + i]);
+          for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) Rs[i * nu + j] = 0.5 * (R2[i * nu + j] + R2[j * nu + i]);
+        }
+        if (m > 0) {
+          const double *y = gy.data() + bs * m, *sv = gs.data() + bs * m, *g = gg.data() + bs * m, *Qyx = gGx.data() + bs * m * nx, *Qyu = gGu.data() + bs * m * nu;
+          std::vector<double> YS(m), ypS(m);
+          for (int i = 0; i < m; ++i) {
+            const double ss = std::max(sv[i], fl0);
+            YS[i] = clampd(y[i] / ss, 0.0, kMaxRatio);
+            const double rp = g[i] + sv[i], rc = y[i] * sv[i] - mu, rhat = y[i] * rp - rc;
+            ypS[i] = y[i] + clampd(rhat / ss, -kMaxRatio, kMaxRatio);
+            t.l_pr = std::max(t.l_pr, std::fabs(rp)); t.l_comp = std::max(t.l_comp, std::fabs(rc));
+          }
+          for (int i = 0; i < nx; ++i) { double a = 0.0; for (int r2 = 0; r2 < m; ++r2) a += Qyx[r2 * nx + i] * ypS[r2]; q[i] += a; }
+          for (int i = 0; i < nu; ++i) { double a = 0.0; for (int r2 = 0; r2 < m; ++r2) a += Qyu[r2 * nu + i] * ypS[r2]; rr[i] += a; }
+          std::vector<double> Qn(Qs), Rn(Rs);
+          for (int i = 0; i < nx; ++i) for (int cix = 0; cix < nx; ++cix) { double a = 0.0; for (int r2 = 0; r2 < m; ++r2) a += (Qyx[r2 * nx + i] * YS[r2]) * Qyx[r2 * nx + cix]; Qn[i * nx + cix] = Qs[i * nx + cix] + a; }
+          for (int i = 0; i < nu; ++i) for (int cix = 0; cix < nx; ++cix) { double a = 0.0; for (int r2 = 0; r2 < m; ++r2) a += (Qyu[r2 * nu + i] * YS[r2]) * Qyx[r2 * nx + cix]; Mm[cix * nu + i] += a; }
+          for (int i = 0; i < nu; ++i) for (int cix = 0; cix < nu; ++cix) { double a = 0.0; for (int r2 = 0; r2 < m; ++r2) a += (Qyu[r2 * nu + i] * YS[r2]) * Qyu[r2 * nu + cix]; Rn[i * nu + cix] = Rs[i * nu + cix] + a; }
+          for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) Qs[i * nx + j] = 0.5 * (Qn[i * nx + j] + Qn[j * nx + i]);
+          for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) Rs[i * nu + j] = 0.5 * (Rn[i * nu + j] + Rn[j * nu + i]);
+        }
+        std::copy(Qs.begin(), Qs.end(), Q); std::copy(Rs.begin(), Rs.end(), R); std::copy(Mm.begin(), Mm.end(), Mx);   // (the lux slot carries M as nx x nu)
+      }
+    };
+    par_for(B, n_threads, fill);
+    { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
+    if (hte) {
+      { int rc = cddp_hip_set_terminal_equality(sh, pT, HTb.data(), bTb.data(), lamb.data(), floorb.data()); if (rc) return rc; }
+      { int rc = cddp_hip_stacks_backward(sh, CDDP_HIP_STACKS_IPDDP_TERM_EQ, opt, regv.data(), nullptr, 1, okv.data()); if (rc) return rc; }
+      { int rc = cddp_hip_stacks_get_terminal(sh, dlamb.data(), dXb.data()); if (rc) return rc; }
+    } else {
+      if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, gy.data(), gs.data(), gg.data(), gGx.data(), gGu.data()); if (rc) return rc; }
+      if (!o.use_ilqr) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
+      { int rc = cddp_hip_stacks_backward(sh, m > 0 ? CDDP_HIP_STACKS_IPDDP_PATH : CDDP_HIP_STACKS_IPDDP, opt, regv.data(), m > 0 ? muv.data() : nullptr, 1, okv.data()); if (rc) return rc; }
+      if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
+    }
+    { int rc = cddp_hip_stacks_get_gains(sh, Kb.data(), kb.data(), Vxb.data(), Vxxb.data(), dVb.data()); if (rc) return rc; }
+    { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
+    if (Kout) for (size_t b = 0; b < B; ++b) if (!T[b].done) std::copy(Kb.begin() + b * N * nu * nx, Kb.begin() + (b + 1) * N * nu * nx, Kfin.begin() + b * N * nu * nx);
+
+    auto advance = [&](size_t b) {
+      TTraj &t = T[b];
+      if (t.done) return;
+      if (aborted(pl)) { abort_seen.store(true); return; }
+      { int nb = 1; double r = t.reg; while (r < s_reg[b] && nb < 64) { r = reg_increase(o, r); ++nb; }
+        if (!okv[b] && nb > 1) --nb;
+        t.n_bwd += nb; }
+      t.reg = s_reg[b];
+      if (!okv[b]) { t.status = CDDP_HIP_STATUS_REG_LIMIT; t.done = true; return; }
+      const double mu = t.mu, fl0 = std::max(mu * 1e-3, kEpsSlack);
+      const double tau = std::max(o.barrier_min_fraction_to_boundary, 1.0 - mu);
+      const double *Kt = Kb.data() + b * N * nu * nx, *kt = kb.data() + b * N * nu;
+      double *dX = dXb.data() + b * (N + 1) * nx;
+      double apr = 1.0, adu = 1.0;
+      t.inf_du = s_du[b]; t.step_norm = s_sn[b];
+      if (hte) {
+        t.dV0 = 0.0; t.dV1 = 0.0;
+        t.inf_pr = t.l_pr; t.inf_comp = t.l_comp;
+        for (int i = 0; i < pT; ++i) t.dLamT[i] = dlamb[b * pT + i];
+        if (m > 0) {   // slack / dual gains and directions from the final K, k and dX (:1270-1312)
+          t.ky.assign((size_t)N * m, 0.0); t.ks = t.ky; t.Ky.assign((size_t)N * m * nx, 0.0); t.Ks = t.Ky;
+          for (int s = 0; s < N; ++s) {
+            const size_t bs = b * N + s;
+            const double *y = gy.data() + bs * m, *sv = gs.data() + bs * m, *g = gg.data() + bs * m, *Qyx = gGx.data() + bs * m * nx, *Qyu = gGu.data() + bs * m * nu;
+            for (int r2 = 0; r2 < m; ++r2) {
+              const double ss = std::max(sv[r2], fl0), YSr = clampd(y[r2] / ss, 0.0, kMaxRatio);
+              const double rp = g[r2] + sv[r2], rc = y[r2] * sv[r2] - mu, rhat = y[r2] * rp - rc;
+              double temp = 0.0;
+              for (int i = 0; i < nu; ++i) temp += Qyu[r2 * nu + i] * kt[(size_t)s * nu + i];
+              const double kyv = clampd((rhat + y[r2] * temp) / ss, -kMaxRatio, kMaxRatio), ksv = (-rp) - temp;
+              double a = 0.0, cc = 0.0;
+              for (int j = 0; j < nx; ++j) {
+                double s2 = 0.0;
+                for (int i = 0; i < nu; ++i) s2 += Qyu[r2 * nu + i] * Kt[((size_t)s * nu + i) * nx + j];
+                const double inner = Qyx[r2 * nx + j] + s2;
+                const double Kyv = std::min(std::max(YSr * inner, -kMaxRatio), kMaxRatio), Ksv = (-Qyx[r2 * nx + j]) - s2;
+                t.Ky[((size_t)s * m + r2) * nx + j] = Kyv; t.Ks[((size_t)s * m + r2) * nx + j] = Ksv;
+                a += Ksv * dX[(size_t)s * nx + j]; cc += Kyv * dX[(size_t)s * nx + j];
+              }
+              t.ky[(size_t)s * m + r2] = kyv; t.ks[(size_t)s * m + r2] = ksv;
+              const double ds = ksv + a, dy = std::min(std::max(kyv + cc, -kMaxRatio), kMaxRatio);
+              if (ds < 0.0) apr = std::min(apr, -tau * sv[r2] / ds);
+              if (dy < 0.0) adu = std::min(adu, -tau * y[r2] / dy);
+            }
+          }
+        }
+      } else {
+        t.dV0 = dVb[b * 2]; t.dV1 = dVb[b * 2 + 1];
+        t.inf_pr = std::max((m > 0) ? s_pr[b] : 0.0, t.l_pr); t.inf_comp = std::max((m > 0) ? s_comp[b] : 0.0, t.l_comp);
+        if (m > 0) {
+          apr = s_apr[b]; adu = s_adu[b];
+          t.ky.assign(kyb.begin() + b * N * m, kyb.begin() + (b + 1) * N * m); t.ks.assign(ksb.begin() + b * N * m, ksb.begin() + (b + 1) * N * m);
+          t.Ky.assign(Kyb.begin() + b * N * m * nx, Kyb.begin() + (b + 1) * N * m * nx); t.Ks.assign(Ksb.begin() + b * N * m * nx, Ksb.begin() + (b + 1) * N * m * nx);
+        } else {   // rolloutLinearPolicy on the host (:1511-1520): the unconstrained stack sweep does not form dX
+          std::vector<double> dx(nx, 0.0), dxn(nx), du(nu);
+          for (int s = 0; s < N; ++s) {
+            std::copy(dx.begin(), dx.end(), dX + (size_t)s * nx);
+            const size_t bs = b * N + s;
+            for (int i = 0; i < nu; ++i) { double a = 0.0; for (int j = 0; j < nx; ++j) a += Kt[((size_t)s * nu + i) * nx + j] * dx[j]; du[i] = kt[(size_t)s * nu + i] + a; }
+            for (int i = 0; i < nx; ++i) { double a = 0.0, cc = 0.0; for (int j = 0; j < nx; ++j) a += fx[(bs * nx + i) * nx + j] * dx[j]; for (int j = 0; j < nu; ++j) cc += fu[(bs * nx + i) * nu + j] * du[j]; dxn[i] = (a + cc) + 0.0; }
+            dx = dxn;
+          }
+          std::copy(dx.begin(), dx.end(), dX + (size_t)N * nx);
+        }
+      }
+      const double *GTx = GTxb.data() + b * (size_t)std::max(mT, 1) * nx;
+      for (int i = 0; i < mT; ++i) {   // terminal-inequality directions (:1315-1346 == :1534-1561) and their step caps (:2939-2988)
+        const double r_p = t.GT[i] + t.ST[i], r_d = t.ST[i] * t.YT[i] - mu;
+        double gd = 0.0;
+        for (int j = 0; j < nx; ++j) gd += GTx[(size_t)i * nx + j] * dX[(size_t)N * nx + j];
+        const double dsT = (-r_p) - gd;
+        const double s_safe = std::max(t.ST[i], fl0);
+        const double dual_ratio = clampd(t.YT[i] / s_safe, 0.0, kMaxRatio), affine = clampd(-r_d / s_safe, -kMaxRatio, kMaxRatio);
+        const double dyT = clampd(affine - dual_ratio * dsT, -kMaxRatio, kMaxRatio);
+        t.dST[i] = dsT; t.dYT[i] = dyT;
+        if (dsT < 0.0) apr = std::min(apr, -tau * t.ST[i] / dsT);
+        if (dyT < 0.0) adu = std::min(adu, -tau * t.YT[i] / dyT);
+      }
+      t.apr_max = clampd(apr, 0.0, 1.0); t.adu_max = clampd(adu, 0.0, 1.0);
+      Gains g;
+      g.K = Kt; g.k = kt; g.Vx = Vxb.data() + b * (N + 1) * nx; g.Vxx = Vxxb.data() + b * (N + 1) * nx * nx;
+      g.ky = t.ky.data(); g.Ky = t.Ky.data(); g.ks = t.ks.data(); g.Ks = t.Ks.data();
+      // ---- checkEarlyConvergence (:925-958)
+      bool conv = false;
+      {
+        const double sdu = scaled_inf_du(c, t, t.gGx);
+        if (no_barrier) conv = (t.inf_pr < o.tolerance && sdu < o.tolerance);
+        else {
+          const double tol = std::max(o.tolerance, o.ipddp_barrier_tol_mult * t.mu);
+          conv = (t.inf_pr < tol && sdu < tol && t.inf_comp < tol && std::fabs(t.alpha_pr) * t.step_norm < o.tolerance * 10.0);
+        }
+      }
+      if (conv) { t.status = CDDP_HIP_STATUS_OPTIMAL; t.done = true; return; }
+      TTrial best; bool have = false;
+      int walked = 0;
+      for (double a : c.alphas) {
+        TTrial r = forward_ipddp_t(c, ti, t, g, a, GTx);
+        ++walked;
+        if (!r.success) continue;
+        if (first_rule) { best = std::move(r); have = true; break; }
+        if (!have || r.merit < best.merit) { best = std::move(r); have = true; }
+      }
+      t.n_fwd += first_rule ? walked : (int)c.alphas.size();
+      if (have) {
+        const double dJ = t.cost - best.cost;
+        t.X.swap(best.X); t.U.swap(best.U); t.Lam.swap(best.Lam);
+        t.cost = best.cost; t.merit = best.merit; t.alpha_pr = best.alpha_pr; t.alpha_du = best.alpha_du;
+        if (m > 0) { t.S.swap(best.S); t.Y.swap(best.Y); t.G.swap(best.G); }
+        if (hti) { t.ST = best.ST; t.YT = best.YT; t.GT = best.GT; }
+        if (hte) t.LamT = best.LamT;
+        t.inf_pr = best.inf_pr; t.inf_comp = best.inf_comp; t.phi = best.merit; t.filter_theta = best.theta; t.theta = best.theta;
+        // ---- updateBarrierParameters(true) (:2548-2660)
+        const double sdu = scaled_inf_du(c, t, t.gGx);
+        double mu2 = t.mu; const double mu_old = mu2;
+        if (!no_barrier) {
+          if (o.barrier_strategy == CDDP_HIP_BARRIER_ADAPTIVE) {
+            const double kkt = std::max(std::max(t.inf_pr, sdu), t.inf_comp);
+            const double threshold = std::max(o.barrier_mu_update_factor * mu2, 2.0 * mu2);
+            if (kkt <= threshold) {
+              double factor = o.barrier_mu_update_factor;
+              if (mu2 > 1e-20) {
+                const double ratio = kkt / std::max(mu2, 1e-20);
+                if (ratio < 0.01) factor = 0.1 * o.barrier_mu_update_factor;
+                else if (ratio < 0.1) factor = 0.3 * o.barrier_mu_update_factor;
+                else if (ratio < 0.5) factor = 0.6 * o.barrier_mu_update_factor;
+              }
+              const double linear = factor * mu2, superlinear = std::pow(mu2, o.barrier_mu_update_power);
+              mu2 = std::max(std::min(linear, superlinear), std::max(o.barrier_mu_min_value, o.tolerance / 100.0));
+            }
+          } else {
+            const double kkt = std::max(std::max(t.inf_pr, sdu * o.ipddp_barrier_update_dual_weight), t.inf_comp);
+            if (kkt <= o.ipddp_mu_kappa_epsilon * mu2) {
+              const double linear = o.barrier_mu_update_factor * mu2, superlinear = std::pow(mu2, o.barrier_mu_update_power);
+              mu2 = std::max(o.barrier_mu_min_value, std::min(linear, superlinear));
+            }
+          }
+        }
+        t.mu = mu2;
+        std::vector<double> r, rx, hT((size_t)std::max(pT, 1), 0.0);
+        if (hte) ti.eval(pl->user, nx, t.X.data() + (size_t)N * nx, nullptr, nullptr, hT.data(), nullptr, r, rx);
+        double phi_n, theta_n, ipr, icomp;
+        ip_reductions_t(c, ti, t.S.data(), t.Y.data(), t.G.data(), t.ST.data(), t.YT.data(), t.GT.data(), t.LamT.data(), hT.data(), mu2, t.cost, phi_n, theta_n, ipr, icomp);
+        const double ftheta = std::max(theta_n, 1e-8);
+        const bool reset = (mu2 < mu_old) && (mu2 > 0.0);
+        if (reset) { t.filter.clear(); filter_accept(t.filter, t.phi, ftheta); }   // (:2629-2637: re-seeded because a terminal set exists)
+        else { filter_accept(t.filter, t.phi, ftheta); if ((int)t.filter.size() > o.ipddp_max_filter_size) filter_prune(t.filter); }
+        t.inf_pr = ipr; t.inf_comp = icomp; t.merit = t.phi = phi_n; t.filter_theta = ftheta;
+        t.theta = std::max(ftheta, std::max(o.ipddp_theta_0_floor, 1e-8));
+        t.reg = reg_decrease(o, t.reg);
+        // ---- checkConvergence (:1953-2025)
+        const double sdu2 = scaled_inf_du(c, t, t.gGx);
+        const double pr = t.inf_pr, scomp = t.inf_comp, sn = t.step_norm;
+        int st = CDDP_HIP_STATUS_RUNNING; bool done = false;
+        if (no_barrier) {
+          if (pr < o.tolerance && sdu2 < o.tolerance) { st = CDDP_HIP_STATUS_OPTIMAL; done = true; }
+          else if (o.acceptable_tolerance > 0.0) {
+            const double sq = std::sqrt(o.acceptable_tolerance);
+            bool acc = (pr < sq && sdu2 < sq && t.iter > 50);
+            if (dJ > 0.0) acc = acc || (dJ < o.acceptable_tolerance && t.iter > 50 && pr < sq && sdu2 < sq);
+            if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; done = true; }
+          }
+        } else {
+          const double tol = std::max(o.tolerance, o.ipddp_barrier_tol_mult * mu2);
+          if (pr < tol && sdu2 < tol && scomp < tol && sn < o.tolerance * 10.0) { st = CDDP_HIP_STATUS_OPTIMAL; done = true; }
+          else if (o.acceptable_tolerance > 0.0) {
+            const double at = std::sqrt(o.acceptable_tolerance);
+            const double bat = std::max(o.barrier_mu_min_value * 100.0, o.tolerance / 10.0);
+            const bool akkt = pr < at && sdu2 < at && scomp < at, bpc = mu2 <= bat;
+            bool acc = akkt && bpc && t.iter > 10 && std::fabs(dJ) < o.acceptable_tolerance;
+            acc = acc || (akkt && bpc && t.iter >= 1 && sn < o.tolerance * 10.0 && pr < 1e-4);
+            if (acc) { st = CDDP_HIP_STATUS_ACCEPTABLE; done = true; }
+          }
+        }
+        if (done) { t.status = st; t.done = true; }
+      } else {
+        // ---- handleForwardPassFailure (:2037-2082): a second increase when a barrier and terminal-equality rows coexist
+        t.reg = reg_increase(o, t.reg);
+        if (!no_barrier && hte) t.reg = reg_increase(o, t.reg);
+        if (t.reg >= o.reg_max_value) {
+          const double sdu = scaled_inf_du(c, t, t.gGx);
+          const double base = std::sqrt(std::max(o.acceptable_tolerance, o.tolerance));
+          const double at = no_barrier ? base : std::max(base, o.ipddp_barrier_tol_mult * t.mu);
+          const bool acc = o.acceptable_tolerance > 0.0 && t.inf_pr < at && sdu < at && (no_barrier || t.inf_comp < at);
+          t.status = acc ? CDDP_HIP_STATUS_ACCEPTABLE : CDDP_HIP_STATUS_REG_LIMIT; t.done = true;
+        }
+      }
+      if (!t.done && it == o.max_iterations) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+    };
+    par_for(B, n_threads, advance);
+    if (abort_seen.load() || aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
+  }
+  for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }
+  if (Kout) std::copy(Kfin.begin(), Kfin.end(), Kout);
+  for (size_t b = 0; b < B; ++b) {
+    const TTraj &t = T[b];
+    cddp_hip_result &r = results[b];
+    std::memset(&r, 0, sizeof(r));
+    r.final_objective = t.cost; r.merit_function = t.merit; r.inf_pr = t.inf_pr; r.inf_du = t.inf_du; r.inf_comp = t.inf_comp;
+    r.barrier_mu = t.mu; r.regularization = t.reg; r.alpha_pr = t.alpha_pr; r.alpha_du = t.alpha_du; r.step_norm = t.step_norm;
+    r.iterations = t.iter; r.status = t.status; r.n_backward = t.n_bwd; r.n_forward = t.n_fwd;
+    if (Xout) std::copy(t.X.begin(), t.X.end(), Xout + b * (N + 1) * nx);
+    if (Uout) std::copy(t.U.begin(), t.U.end(), Uout + b * N * nu);
+    if (Tout) {   // [S_T (mT) | Y_T (mT) | Lambda_T (pT)] per trajectory
+      double *o2 = Tout + b * (size_t)(2 * mT + pT);
+      for (int i = 0; i < mT; ++i) { o2[i] = t.ST[i]; o2[mT + i] = t.YT[i]; }
+      for (int i = 0; i < pT; ++i) o2[2 * mT + i] = t.LamT[i];
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int cddp_hip_plugin_set_host_threads(int n) {
@@ -1029,9 +1701,25 @@ extern "C" int cddp_hip_plugin_set_host_threads(int n) {
   return 0;
 }
 
+static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_terminal *tc, int solver, int horizon, double dt, const cddp_hip_options *opt,
+                             int device, int batch, const double *x0, const double *U0, const double *X0,
+                             cddp_hip_result *results, double *Xout, double *Uout, double *Kout, double *Tout);
+
 extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int horizon, double dt, const cddp_hip_options *opt,
                                      int device, int batch, const double *x0, const double *U0, const double *X0,
                                      cddp_hip_result *results, double *Xout, double *Uout, double *Kout) {
+  return plugin_solve_impl(pl, nullptr, solver, horizon, dt, opt, device, batch, x0, U0, X0, results, Xout, Uout, Kout, nullptr);
+}
+
+extern "C" int cddp_hip_plugin_solve_terminal(const cddp_hip_plugin *pl, const cddp_hip_plugin_terminal *tc, int solver, int horizon, double dt,
+                                              const cddp_hip_options *opt, int device, int batch, const double *x0, const double *U0, const double *X0,
+                                              cddp_hip_result *results, double *Xout, double *Uout, double *Kout, double *terminal_out) {
+  return plugin_solve_impl(pl, tc, solver, horizon, dt, opt, device, batch, x0, U0, X0, results, Xout, Uout, Kout, terminal_out);
+}
+
+static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_terminal *tc, int solver, int horizon, double dt, const cddp_hip_options *opt,
+                             int device, int batch, const double *x0, const double *U0, const double *X0,
+                             cddp_hip_result *results, double *Xout, double *Uout, double *Kout, double *Tout) {
   if (!pl || !opt || !x0 || !results) return pfail(-1, "null argument");
   if (pl->abi_version != CDDP_HIP_ABI_VERSION || pl->options_bytes != (int)sizeof(cddp_hip_options))
     return pfail(-2, "ABI mismatch: caller built against version %d with a %d-byte cddp_hip_options, library has version %d and %d bytes",
@@ -1054,6 +1742,18 @@ extern "C" int cddp_hip_plugin_solve(const cddp_hip_plugin *pl, int solver, int 
   Ctx c; c.pl = pl; c.o = opt; c.solver = solver; c.nx = nx; c.nu = nu; c.m = m; c.N = N; c.dt = dt;
   { double al[CDDP_HIP_MAX_ALPHAS]; const int na = cddp_hip_build_alphas(opt, al, CDDP_HIP_MAX_ALPHAS); c.alphas.assign(al, al + na); }
   const cddp_hip_options &o = *opt;
+  // Terminal constraints: only IPDDP reads the terminal set (clddp / logddp / msipddp_solver.cpp never touch getTerminalConstraintSet)
+  if (tc && tc->n_terminal > 0 && solver == CDDP_HIP_SOLVER_IPDDP) {
+    if (tc->n_terminal > CDDP_HIP_PLUGIN_MAX_CONSTRAINTS || !tc->evaluate) return pfail(-2, "bad terminal-constraint description (%d objects)", tc->n_terminal);
+    TermInfo ti; ti.tc = tc; ti.nobj = tc->n_terminal;
+    for (int s2 = 0; s2 < ti.nobj; ++s2) {
+      ti.dim[s2] = tc->dims[s2]; ti.eq[s2] = tc->equality[s2] ? 1 : 0; ti.src[s2] = ti.rows; ti.rows += ti.dim[s2];
+      if (ti.dim[s2] <= 0) return pfail(-2, "terminal constraint %d has %d rows", s2, ti.dim[s2]);
+      if (ti.eq[s2]) { ti.dst[s2] = ti.pT; ti.pT += ti.dim[s2]; } else { ti.dst[s2] = ti.mT; ti.mT += ti.dim[s2]; }
+    }
+    if (ti.pT > 8) return pfail(-3, "more than 8 terminal-equality rows (%d) on the plug-in route", ti.pT);
+    return ipddp_terminal_solve(c, ti, device, batch, x0, U0, X0, results, Xout, Uout, Kout, Tout);
+  }
   if (solver == CDDP_HIP_SOLVER_LOGDDP) return logddp_solve(c, device, batch, x0, U0, results, Xout, Uout, Kout);
   if (solver == CDDP_HIP_SOLVER_MSIPDDP) return msipddp_solve(c, device, batch, x0, U0, X0, results, Xout, Uout, Kout);
 

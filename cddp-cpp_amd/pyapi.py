@@ -595,7 +595,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_concurrency", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create_abi", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
-    "cddp_hip_stacks_get_scalars", "cddp_hip_set_terminal_equality", "cddp_hip_stacks_get_terminal", "cddp_hip_plugin_solve", "cddp_hip_plugin_set_host_threads", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
+    "cddp_hip_stacks_get_scalars", "cddp_hip_set_terminal_equality", "cddp_hip_stacks_get_terminal", "cddp_hip_plugin_solve", "cddp_hip_plugin_solve_terminal", "cddp_hip_plugin_set_host_threads", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 
@@ -817,9 +817,17 @@ class PluginStruct(C.Structure):
     ]
 
 
+_F_TERM = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, _dp)
+
+
+class PluginTerminalStruct(C.Structure):   # cddp_hip_plugin_terminal
+    _fields_ = [("n_terminal", C.c_int32), ("dims", C.c_int32 * PLUGIN_MAX_CONSTRAINTS), ("equality", C.c_int32 * PLUGIN_MAX_CONSTRAINTS), ("evaluate", _F_TERM)]
+
+
 def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, discrete_dynamics, jacobians, running_cost, terminal_cost,
                  running_cost_derivatives, terminal_cost_derivatives, hessians=None, constraints=None, constraint_dims=(),
-                 control_lower=None, control_upper=None, constraint_hessians=None, device=0, trig=None):
+                 control_lower=None, control_upper=None, constraint_hessians=None, device=0, trig=None,
+                 terminal=None, terminal_dims=(), terminal_equality=(), want_terminal=False):
     """CDDP::solve() for HOST plug-ins through the C-ABI (cddp_hip_plugin_solve): the callables are the reference's virtual functions
     on numpy vectors -- discrete_dynamics(x, u, t) -> x_next; jacobians(x, u, t) -> (f_x, f_u) continuous-time;
     hessians(x, u, t) -> (f_xx[nx][nx][nx], f_uu[nx][nu][nu], f_ux[nx][nu][nx]); running_cost(x, u, index) -> float;
@@ -827,7 +835,10 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     -> (l_x, l_xx); constraints(x, u, index, want_jacobians) -> (g - upper, G_x, G_u) stacked in name order.  The GPU runs the
     batched backward passes, the host the forward passes.  An exception raised by a callable stops the solve and is re-raised here.
     solver = SOLVER_LOGDDP runs the reference's LogDDP on the same callbacks; constraint_hessians(x, u, index) -> (g_xx[m][nx][nx],
-    g_uu[m][nu][nu], g_ux[m][nu][nx]) or None supplies constraint curvature to its relaxed log barrier.  Returns (results, X, U, K)."""
+    g_uu[m][nu][nu], g_ux[m][nu][nx]) or None supplies constraint curvature to its relaxed log barrier.  Returns (results, X, U, K).
+    terminal(x_N, want_jacobian) -> (r, r_x) with the residual rows of every terminal-constraint object stacked in name order (terminal_dims,
+    terminal_equality: 1 = TerminalEqualityConstraint-like, 0 = inequality g_T <= 0) runs cddp_hip_plugin_solve_terminal; want_terminal adds a
+    fifth return value, the dict {S_T, Y_T, Lambda_T} of the final iterate."""
     lib = load_hip(trig)
     x0 = _arr(x0).reshape(-1, nx); B = x0.shape[0]; N = int(horizon)
     U0 = _arr(U0).reshape(B, N, nu) if U0 is not None else None
@@ -911,12 +922,34 @@ def plugin_solve(solver, nx, nu, horizon, dt, options, x0, U0=None, X0=None, *, 
     ps.abi_version = ABI_VERSION; ps.options_bytes = C.sizeof(Options); ps.abort_flag = C.pointer(abort)
     res = np.zeros(B, dtype=RESULT_DTYPE)
     X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); K = np.zeros((B, N, nu, nx))
-    rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(solver), N, C.c_double(dt), C.byref(options), int(device), B, _ptr(x0), _ptr(U0), _ptr(X0),
-                                   res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K))
+    tout = None
+    if terminal is not None and len(terminal_dims) > 0:
+        rows = int(sum(terminal_dims))
+        mT = int(sum(d for d, e in zip(terminal_dims, terminal_equality) if not e)); pT = rows - mT
+
+        def _term(_, x, r, rx):
+            rv, Rx = terminal(vec(x, nx).copy(), bool(rx))
+            vec(r, rows)[:] = np.asarray(rv, dtype=np.float64).reshape(rows)
+            if rx: vec(rx, rows * nx)[:] = np.asarray(Rx, dtype=np.float64).reshape(rows * nx)
+
+        ts = PluginTerminalStruct()
+        ts.n_terminal = len(terminal_dims)
+        for i, (dmy, e) in enumerate(zip(terminal_dims, terminal_equality)):
+            ts.dims[i] = int(dmy); ts.equality[i] = 1 if e else 0
+        keep.append(_F_TERM(guard(_term))); ts.evaluate = keep[-1]
+        tbuf = np.zeros((B, max(1, 2 * mT + pT)))
+        rc = lib.cddp_hip_plugin_solve_terminal(C.byref(ps), C.byref(ts), int(solver), N, C.c_double(dt), C.byref(options), int(device), B, _ptr(x0), _ptr(U0), _ptr(X0),
+                                                res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K), _ptr(tbuf))
+        tout = {"S_T": tbuf[:, :mT].copy(), "Y_T": tbuf[:, mT:2 * mT].copy(), "Lambda_T": tbuf[:, 2 * mT:2 * mT + pT].copy()}
+    else:
+        rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(solver), N, C.c_double(dt), C.byref(options), int(device), B, _ptr(x0), _ptr(U0), _ptr(X0),
+                                       res.ctypes.data_as(C.c_void_p), _ptr(X), _ptr(U), _ptr(K))
     if err:
         raise err[0]
     if rc != 0:
         raise HipError("cddp_hip error %d: %s" % (rc, lib.cddp_hip_last_error().decode()))
+    if want_terminal:
+        return res, X, U, K, tout
     return res, X, U, K
 
 

@@ -12,7 +12,7 @@ Everything goes through the C-ABI (`include/cddp_hip.h`); there is no CPU fallba
 `bind_constraints.cpp`) run through the host plug-in solve (`cddp_hip_plugin_solve`: batched backward passes on the GPU, forward
 passes on the host, callbacks into Python) -- as do single MSIPDDP / LogDDP solves for every problem (`solve_batch` of LogDDP or
 MSIPDDP on a built-in plant with nx <= 8 runs on the resident kernels, switches `logddp_route` / `msipddp_route`); anything the core does not implement raises
-(terminal constraints on plug-in problems, un-instantiated layouts, path-constrained MSIPDDP outside nu = 1 / nx = nu).
+(un-instantiated layouts, path-constrained MSIPDDP outside nu = 1 / nx = nu).
 """
 import enum
 import importlib.util
@@ -662,14 +662,24 @@ class MaxThrustMagnitudeConstraint(_BuiltinConstraint):   # constraint.hpp:929-1
     def get_control_hessian(self, x, u, index=0): return [_norm_hessian(u, self.epsilon)]
 
 
-class TerminalEqualityConstraint:   # terminal_constraint.hpp
+class TerminalEqualityConstraint:   # terminal_constraint.hpp:55-158: h(x_N) = x_N - target, Jacobian I
     def __init__(self, target_state):
         self.target = np.asarray(target_state, dtype=np.float64)
 
+    def get_dual_dim(self): return int(self.target.size)
+    def evaluate(self, final_state, control=None, index=0): return np.asarray(final_state, dtype=np.float64) - self.target
+    def get_state_jacobian(self, final_state, control=None, index=0): return np.eye(self.target.size, np.asarray(final_state).size)
 
-class TerminalInequalityConstraint:
+
+class TerminalInequalityConstraint:   # terminal_constraint.hpp:160-260: g_T(x_N) = A_N x_N - b_N <= 0
     def __init__(self, A, b):
         self.A = np.asarray(A, dtype=np.float64); self.b = np.asarray(b, dtype=np.float64)
+        if self.A.shape[0] != self.b.size:
+            raise ValueError("TerminalInequalityConstraint: A_N rows and b_N size mismatch.")
+
+    def get_dual_dim(self): return int(self.A.shape[0])
+    def evaluate(self, final_state, control=None, index=0): return self.A @ np.asarray(final_state, dtype=np.float64) - self.b
+    def get_state_jacobian(self, final_state, control=None, index=0): return self.A
 
 
 # ------------------------------------------------------------------------------------------------ solution
@@ -874,8 +884,6 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
 
     def _solve_plugins(self, name, kind, x0s):
         api = _api()
-        if self._terms:
-            raise NotImplementedError("terminal constraints are not supported on host plug-in problems")
         s, ob = self._sys, self._obj
         nx, nu, N, dt = s.state_dim, s.control_dim, self._N, self._dt
         names = sorted(self._cons)          # std::map order
@@ -909,6 +917,18 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
             return (np.stack([np.asarray(h) for h in s.get_state_hessian(x, u, t)]), np.stack([np.asarray(h) for h in s.get_control_hessian(x, u, t)]),
                     np.stack([np.asarray(h) for h in s.get_cross_hessian(x, u, t)]))
 
+        # terminal set (round 6): only IPDDP reads it (ipddp_solver.cpp:84-215); objects in std::map order, equality = TerminalEqualityConstraint
+        tnames = sorted(self._terms) if kind == api.SOLVER_IPDDP else []
+        tcons = [self._terms[n] for n in tnames]
+        tdims = [int(c.get_dual_dim()) for c in tcons]
+        teq = [1 if isinstance(c, TerminalEqualityConstraint) else 0 for c in tcons]
+
+        def terminal(xN, want):   # evaluateTerminal{Equality,Inequality}Residual / Jacobian (:118-201): evaluate(x_N) and getStateJacobian(x_N)
+            r = np.concatenate([np.asarray(c.evaluate(xN), dtype=np.float64).reshape(-1) for c in tcons])
+            if not want:
+                return r, None
+            return r, np.vstack([np.asarray(c.get_state_jacobian(xN), dtype=np.float64).reshape(-1, nx) for c in tcons])
+
         B = len(x0s)
         x0 = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64) for x in x0s]))
         U0 = None if self._U is None else np.ascontiguousarray(np.tile(self._U, (B, 1, 1)))
@@ -927,7 +947,8 @@ class CDDP:                         # cddp_core.hpp:214-423 / bind_solver.cpp:57
                                                       ob.get_running_cost_cross_hessian(x, u, i)),
             terminal_cost_derivatives=lambda x: (ob.get_final_cost_gradient(x), ob.get_final_cost_hessian(x)),
             constraints=constraints if cons else None, constraint_dims=dims, control_lower=lo, control_upper=up,
-            constraint_hessians=constraint_hessians if (cons and (kind == api.SOLVER_LOGDDP or (kind == api.SOLVER_MSIPDDP and not self._opt.use_ilqr))) else None)
+            constraint_hessians=constraint_hessians if (cons and (kind == api.SOLVER_LOGDDP or (kind == api.SOLVER_MSIPDDP and not self._opt.use_ilqr))) else None,
+            terminal=terminal if tcons else None, terminal_dims=tdims, terminal_equality=teq)
         ms = (_time.perf_counter() - t0) * 1e3
         out = []
         for b in range(B):

@@ -616,7 +616,8 @@ int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
  *                                (clddp_solver.cpp:85-86, 147-178, 227-228) or NULL; CLDDP ignores every other constraint.
  * The GPU runs the backward pass of the whole batch (stack-fed sweeps above); the forward pass needs the plug-in's f(x, u) and runs
  * on the host (csrc/plugin_solve.hip).  All trajectories of the batch share the plug-in; they differ in x0 / U0 / X0.  Callbacks are
- * called from the calling thread only unless cddp_hip_plugin_set_host_threads says otherwise.  Not supported: terminal constraints, warm starts (use the built-in plants for those).
+ * called from the calling thread only unless cddp_hip_plugin_set_host_threads says otherwise.  Terminal constraints: cddp_hip_plugin_solve_terminal
+ * below.  Warm starts: a stateless call can only take the "provided trajectory" branch; the terminal entry point implements it.
  * solver = CDDP_HIP_SOLVER_LOGDDP runs the reference's LogDDP (logddp_solver.cpp:43-707: single shooting, relaxed log barrier of every
  * path constraint folded into the cost derivatives on the host, Riccati sweep of the batch on the GPU, filter line search on the
  * host); it takes the same callbacks, plus constraint_hessians when a constraint has curvature. */
@@ -660,6 +661,26 @@ typedef struct cddp_hip_plugin {
 /* ISolverAlgorithm::initialize + solve for `batch` trajectories of a host plug-in problem.  x0: batch*nx; U0: batch*N*nu or NULL
  * (zeros); X0: batch*(N+1)*nx or NULL (x0 replicated).  results: batch records; X (batch*(N+1)*nx), U (batch*N*nu), K
  * (batch*N*nu*nx, feedback gains of the last sweep) may be NULL. */
+/* Terminal constraints of a plug-in problem (round 6; CDDP::addTerminalConstraint, cddp_core.cpp:173-179).  Only IPDDP reads them
+ * (ipddp_solver.cpp:84-215): objects in std::map (name) order, each either a terminal EQUALITY (TerminalEqualityConstraint: residual
+ * h(x_N), rows stacked into H_T / Lambda_T_eq) or a terminal INEQUALITY (TerminalInequalityConstraint: residual g_T(x_N) <= 0 with slack /
+ * dual S_T, Y_T).  evaluate returns the residual rows of ALL objects stacked in that order (sum of dims) and, when rx != NULL, their state
+ * Jacobian rows (sum of dims x nx, row-major).  At most 8 equality rows in total. */
+typedef struct cddp_hip_plugin_terminal {
+  int32_t n_terminal;
+  int32_t dims[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS];
+  int32_t equality[CDDP_HIP_PLUGIN_MAX_CONSTRAINTS];   /* 1 = equality, 0 = inequality */
+  void (*evaluate)(void *user, const double *x_terminal, double *r, double *rx);   /* user = cddp_hip_plugin::user */
+} cddp_hip_plugin_terminal;
+/* cddp_hip_plugin_solve with a terminal set.  The Riccati work stays on the GPU: with terminal-equality rows the reduced LQR of
+ * ipddp_solver.cpp:478-639, 1120-1353 (CDDP_HIP_STACKS_IPDDP_TERM_EQ; the host condenses the path constraints into its LQ stacks as :1143-1245
+ * does), otherwise the ordinary stack-fed sweeps on the terminal value with the terminal-inequality barrier terms (:1000-1031).
+ * options.warm_start: the "warm start with provided trajectory" initialisation (:733-816) from (x0, U0).  terminal_out (optional):
+ * per trajectory [S_T (inequality rows) | Y_T | Lambda_T_eq (equality rows)].  terminal == NULL or n_terminal == 0: cddp_hip_plugin_solve. */
+int cddp_hip_plugin_solve_terminal(const cddp_hip_plugin *plugin, const cddp_hip_plugin_terminal *terminal, int solver /* cddp_hip_solver */,
+                                   int horizon, double dt, const cddp_hip_options *options, int device, int batch, const double *x0,
+                                   const double *U0, const double *X0, cddp_hip_result *results, double *X, double *U, double *K,
+                                   double *terminal_out);
 /* Host threads that run the per-trajectory host work of cddp_hip_plugin_solve's IPDDP / CLDDP loop (derivative fill, forward passes, updates;
  * the reference fans its own line search out with std::async, cddp_solver_base.cpp:264-314).  Default 1: callbacks on the calling thread
  * only.  n > 1 (0 = one per hardware thread): the plug-in's callbacks are called CONCURRENTLY for different trajectories -- for thread-safe

@@ -342,24 +342,130 @@ def test_python_nonlinear_objective_dispatches_through_solver(api, pycddp, oracl
     assert np.max(np.abs(np.stack(sol.state_trajectory) - np.stack(ref.state_trajectory))) < 1e-3
 
 
+def _twin_plants():
+    class TwinQSS:        # tests/cddp_core/test_ipddp_solver.cpp:291-346
+        nx, nu, discrete = 1, 1, True
+        def step(self, x, u, t): return np.array([x[0] + u[0] + 0.5 * x[0] * x[0]])
+        def jac(self, x, u, t): return np.array([[1.0 + x[0]]]), np.eye(1)
+        def hess(self, x, u, t): return np.ones((1, 1, 1)), np.zeros((1, 1, 1)), np.zeros((1, 1, 1))
+
+    class TwinDI:         # double integrator, python/tests/test_custom_dynamics.py
+        nx, nu, discrete = 2, 1, False
+        def f(self, x, u, t): return np.array([x[1], u[0]])
+        def jac(self, x, u, t): return np.array([[0.0, 1.0], [0.0, 0.0]]), np.array([[0.0], [1.0]])
+        def hess(self, x, u, t): return np.zeros((2, 2, 2)), np.zeros((2, 1, 1)), np.zeros((2, 1, 2))
+    return TwinQSS, TwinDI
+
+
+TERMINAL_PLUGIN_CASES = {
+    # name: (plant, N, dt, x0, Q, R, Qf, path box or None, terminal spec {name: ("eq", target) | ("ineq", A, b)}, use_ilqr)
+    "qss_term_eq_ilqr": ("qss", 8, 1.0, [1.0], 0.0, 1e-2, 0.0, None, {"TerminalTarget": ("eq", [0.0])}, True),
+    "qss_term_eq_ddp": ("qss", 8, 1.0, [1.0], 0.0, 1e-2, 0.0, None, {"TerminalTarget": ("eq", [0.0])}, False),      # test_ipddp_solver.cpp:1512-1578 as a solve
+    "qss_box_term_eq": ("qss", 8, 1.0, [0.6], 0.1, 1e-1, 0.0, (-0.5, 0.5), {"TerminalTarget": ("eq", [0.0])}, True),
+    "qss_term_ineq": ("qss", 8, 1.0, [0.5], 1.0, 1e-1, 1.0, None, {"TerminalBand": ("ineq", [[1.0], [-1.0]], [0.05, 0.05])}, True),
+    "di_box_term_eq": ("di", 12, 0.1, [1.0, 0.0], 1.0, 0.1, 1.0, (-8.0, 8.0), {"T": ("eq", [0.0, 0.0])}, True),
+    "di_term_eq_and_ineq": ("di", 12, 0.1, [1.0, 0.0], 1.0, 0.1, 1.0, None, {"A_ineq": ("ineq", [[0.0, 1.0]], [0.4]), "B_eq": ("eq", [0.2, 0.0])}, True),
+    "di_box_term_ineq": ("di", 12, 0.1, [1.0, 0.0], 1.0, 0.1, 10.0, (-6.0, 6.0), {"T": ("ineq", [[1.0, 0.0], [0.0, 1.0]], [0.3, 0.3])}, True),
+}
+
+
 @pytest.mark.gpu
-def test_plugin_solve_rejects_what_it_cannot_do(api, pycddp):
+@pytest.mark.parametrize("case", list(TERMINAL_PLUGIN_CASES))
+def test_plugin_solve_with_terminal_constraints_against_the_twin(api, pycddp, case):
+    """user plants with TERMINAL constraints on the plug-in route (cddp_hip_plugin_solve_terminal) -- the reference pairs
+    its user-defined QuadraticScalarSystem with a TerminalEqualityConstraint and use_ilqr = false (tests/cddp_core/test_ipddp_solver.cpp:292-346,
+    1512-1578).  Terminal equality (reduced LQR on the GPU: CDDP_HIP_STACKS_IPDDP_TERM_EQ), terminal inequality (barrier terms in the terminal
+    value), both, with and without a path box, Gauss-Newton and full DDP: status, iterations, objective, trajectory against the numpy twin."""
+    import cddp_twin as T
+    plant, N, dt, x0, Qs, Rs, Qfs, box, term, use_ilqr = TERMINAL_PLUGIN_CASES[case]
+    _, _, QSS = make_plants(pycddp)
+    TwinQSS, TwinDI = _twin_plants()
+
     class DI(pycddp.DynamicalSystem):
         def __init__(self): super().__init__(2, 1, 0.1, "euler")
         def get_continuous_dynamics(self, s, c, t=0.0): return np.array([s[1], c[0]])
         def get_state_jacobian(self, s, c, t=0.0): return np.array([[0.0, 1.0], [0.0, 0.0]])
         def get_control_jacobian(self, s, c, t=0.0): return np.array([[0.0], [1.0]])
-    sv = pycddp.CDDP(np.array([1.0, 0.0]), np.zeros(2), 8, 0.1, _options(pycddp, max_iterations=3))
+        def get_state_hessian(self, s, c, t=0.0): return [np.zeros((2, 2)), np.zeros((2, 2))]
+        def get_control_hessian(self, s, c, t=0.0): return [np.zeros((1, 1)), np.zeros((1, 1))]
+        def get_cross_hessian(self, s, c, t=0.0): return [np.zeros((1, 2)), np.zeros((1, 2))]
+    nx = 1 if plant == "qss" else 2
+    okw = dict(max_iterations=40, tolerance=1e-6, acceptable_tolerance=1e-6, use_ilqr=use_ilqr)
+    o = _options(pycddp, **okw)
+    o.regularization.initial_value = 1e-6; o.ipddp.barrier.mu_initial = 1e-1
+    x0 = np.array(x0, float); goal = np.zeros(nx)
+    sv = pycddp.CDDP(x0, goal, N, dt, o)
+    sv.set_dynamical_system(QSS() if plant == "qss" else DI())
+    sv.set_objective(pycddp.QuadraticObjective(Qs * np.eye(nx), Rs * np.eye(1), Qfs * np.eye(nx), goal, [], dt))
+    cons = {}
+    if box is not None:
+        sv.add_constraint("ControlConstraint", pycddp.ControlConstraint(np.array([box[0]]), np.array([box[1]])))
+        cons["ControlConstraint"] = T.ControlBox([box[0]], [box[1]])
+    for name, spec in term.items():
+        sv.add_terminal_constraint(name, pycddp.TerminalEqualityConstraint(np.array(spec[1], float)) if spec[0] == "eq"
+                                   else pycddp.TerminalInequalityConstraint(np.array(spec[1], float), np.array(spec[2], float)))
+    assert sv._needs_host_plugins()
+    sol = sv.solve(pycddp.SolverType.IPDDP)
+    assert sol.route == "plugin"
+    tw = T.Twin(dict(solver="IPDDP", model=TwinQSS() if plant == "qss" else TwinDI(), integrator="euler", dt=dt, N=N, Q=Qs * np.eye(nx), R=Rs * np.eye(1),
+                     Qf=Qfs * np.eye(nx), xref=list(goal), constraints=cons, terminal=term,
+                     options=dict(max_iterations=40, tolerance=1e-6, acceptable_tolerance=1e-6, reg_initial_value=1e-6, mu_initial=1e-1, use_ilqr=use_ilqr)))
+    tw.set_initial(x0, None)
+    r = tw.solve()
+    assert sol.status_message == T.STATUS[r["status"]] and sol.iterations_completed == r["iterations"], (case, sol.status_message, sol.iterations_completed, r["status"], r["iterations"])
+    assert abs(sol.final_objective - r["final_objective"]) < 1e-8 * max(1.0, abs(r["final_objective"]))
+    assert np.max(np.abs(np.stack(sol.state_trajectory) - tw.X)) < 1e-7 and np.max(np.abs(np.stack(sol.control_trajectory) - tw.U)) < 1e-7
+    # the terminal set did its work: equality rows closed to the solver's tolerance class, inequality rows satisfied
+    xN = np.stack(sol.state_trajectory)[-1]
+    for name, spec in term.items():
+        if spec[0] == "eq" and sol.status_message in ("OptimalSolutionFound", "AcceptableSolutionFound"):
+            assert np.max(np.abs(xN - np.array(spec[1]))) < 1e-3, (case, xN)
+        if spec[0] == "ineq" and sol.status_message in ("OptimalSolutionFound", "AcceptableSolutionFound"):
+            assert np.all(np.array(spec[1]) @ xN - np.array(spec[2]) < 1e-6), (case, xN)
+
+
+@pytest.mark.gpu
+def test_plugin_full_ddp_needs_hessian_virtuals(api, pycddp):
+    class DI(pycddp.DynamicalSystem):
+        def __init__(self): super().__init__(2, 1, 0.1, "euler")
+        def get_continuous_dynamics(self, s, c, t=0.0): return np.array([s[1], c[0]])
+        def get_state_jacobian(self, s, c, t=0.0): return np.array([[0.0, 1.0], [0.0, 0.0]])
+        def get_control_jacobian(self, s, c, t=0.0): return np.array([[0.0], [1.0]])
+    sv = pycddp.CDDP(np.array([1.0, 0.0]), np.zeros(2), 8, 0.1, _options(pycddp, max_iterations=3, use_ilqr=False))
     sv.set_dynamical_system(DI())
     sv.set_objective(pycddp.QuadraticObjective(np.eye(2), 0.1 * np.eye(1), 10.0 * np.eye(2), np.zeros(2), [], 0.1))
-    sv.add_terminal_constraint("T", pycddp.TerminalEqualityConstraint(np.zeros(2)))
-    with pytest.raises(NotImplementedError, match="terminal constraints"):
-        sv.solve(pycddp.SolverType.IPDDP)
-    sv.remove_terminal_constraint("T")
-    o = _options(pycddp, max_iterations=3, use_ilqr=False)
-    sv.set_options(o)
     with pytest.raises(RuntimeError, match="do not support getContinuousDynamicsAutodiff"):   # full DDP needs the Hessian callbacks
         sv.solve(pycddp.SolverType.IPDDP)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_box", [True, False])
+def test_plugin_warm_start_with_provided_trajectory_matches_the_oracle(api, pycddp, oracle_built, with_box):
+    """options.warm_start on the plug-in route (round 6): a stateless call takes the reference's "warm start with provided trajectory"
+    branch (ipddp_solver.cpp:733-816: barrier parameter from the seed's largest constraint value, duals initialised from the seed).  The Python
+    pendulum plug-in seeded with a control guess against a NEW oracle object started the same way."""
+    PyPendulum, _, _ = make_plants(pycddp)
+    p = api.pendulum_problem(api.SOLVER_IPDDP, with_box)
+    p.options.warm_start = 1; p.options.max_iterations = 30; p.options.tolerance = 1e-4; p.options.acceptable_tolerance = 1e-5; p.options.reg_initial_value = 1e-6
+    B = 4
+    x0 = api.batch_x0(p, B, 20260931, [0.1, 0.1])
+    rng = np.random.default_rng(5)
+    U0 = 2.0 * rng.standard_normal((100, 1))
+    o = _options(pycddp, max_iterations=30, tolerance=1e-4, acceptable_tolerance=1e-5, warm_start=True)
+    o.regularization.initial_value = 1e-6
+    cons = [("ControlConstraint", pycddp.ControlConstraint(np.array([-20.0]), np.array([20.0])))] if with_box else []
+    sv = pycddp.CDDP(x0[0], np.zeros(2), 100, 0.02, o)
+    sv.set_dynamical_system(PyPendulum(0.02, 0.5, 1.0, 0.01))
+    sv.set_objective(pycddp.QuadraticObjective(np.zeros((2, 2)), 0.1 * np.eye(1), 100.0 * np.eye(2), np.zeros(2), [], 0.02))
+    for name, c in cons:
+        sv.add_constraint(name, c)
+    sv.set_initial_trajectory([x0[0]] * 101, [U0[t] for t in range(100)])
+    sols = sv.solve_batch(list(x0), pycddp.SolverType.IPDDP)
+    for b in range(B):
+        orc = api.Oracle(p); orc.set_warm_start(True); orc.set_initial(x0[b], U0, None); q = orc.solve()
+        s = sols[b]
+        assert s.status_message == api.STATUS_STRINGS[int(q["status"])] and s.iterations_completed == q["iterations"], (b, s.status_message, s.iterations_completed, q["status"], q["iterations"])
+        assert abs(s.final_objective - q["final_objective"]) <= 1e-8 * max(1.0, abs(q["final_objective"]))
 
 
 @pytest.mark.gpu
