@@ -653,6 +653,7 @@ class CDDP {
   const Objective &getObjective() const { return *objective_; }
   const std::map<std::string, std::unique_ptr<Constraint>> &getConstraintSet() const { return path_constraint_set_; }
   bool hasTerminalConstraints() const { return !terminal_constraint_set_.empty(); }
+  const std::map<std::string, std::unique_ptr<TerminalConstraint>> &getTerminalConstraintSet() const { return terminal_constraint_set_; }   // cddp_core.hpp:305-319
   // true when some plug-in is a user subclass without a device kernel: the solve then goes through cddp_hip_plugin_solve
   bool needsHostPlugins() const {
     if (!system_ || !objective_) return false;
@@ -781,6 +782,7 @@ class HipBatchSolver : public ISolverAlgorithm {
   // ---- host plug-in route: the reference's virtual functions behind the flat callbacks of cddp_hip_plugin ----
   struct PluginCtx {
     const DynamicalSystem *sys; const Objective *obj; std::vector<const Constraint *> cons; int nx, nu, m;
+    std::vector<cddp_hip_terminal_constraint> terms;   // terminal set in std::map order (round 6: cddp_hip_plugin_solve_terminal)
     std::exception_ptr error;   // a C++ exception must not unwind through the C library: parked here, rethrown after the call
     Vector x, u;
     void load(const double *xp, const double *up) { x.assign(xp, xp + nx); if (up) u.assign(up, up + nu); }
@@ -864,8 +866,20 @@ class HipBatchSolver : public ISolverAlgorithm {
       }
     });
   }
+  // residual rows (and state-Jacobian rows) of the terminal set: h = x_N - target (identity rows), g_T = A_N x_N - b_N (rows of A_N)
+  // (terminal_constraint.hpp:75-113, 180-219)
+  static void cbTerminal(void *p, const double *xN, double *r, double *rx) {
+    auto *c = (PluginCtx *)p; const int nx = c->nx;
+    int row = 0;
+    for (const cddp_hip_terminal_constraint &t : c->terms) {
+      for (int i = 0; i < t.dim; ++i, ++row) {
+        if (rx) std::fill(rx + (size_t)row * nx, rx + (size_t)(row + 1) * nx, 0.0);
+        if (t.kind == CDDP_HIP_TERM_EQUALITY) { r[row] = xN[i] - t.target[i]; if (rx) rx[(size_t)row * nx + i] = 1.0; }
+        else { double a = 0.0; for (int k = 0; k < nx; ++k) a += t.A[(size_t)i * nx + k] * xN[k]; r[row] = a - t.b[i]; if (rx) std::copy(t.A + (size_t)i * nx, t.A + (size_t)(i + 1) * nx, rx + (size_t)row * nx); }
+      }
+    }
+  }
   std::vector<CDDPSolution> collectPlugin(CDDP &ctx, int B) {
-    if (ctx.hasTerminalConstraints()) throw std::runtime_error("HipBatchSolver: terminal constraints are not supported on host plug-in problems");
     PluginCtx pc; pc.sys = &ctx.getSystem(); pc.obj = &ctx.getObjective(); pc.nx = nx_; pc.nu = nu_; pc.m = 0;
     cddp_hip_plugin pl; std::memset(&pl, 0, sizeof(pl));
     pl.abi_version = CDDP_HIP_ABI_VERSION; pl.options_bytes = (int)sizeof(cddp_hip_options);
@@ -894,7 +908,20 @@ class HipBatchSolver : public ISolverAlgorithm {
     std::vector<cddp_hip_result> r(B);
     std::vector<double> X((size_t)B * (N + 1) * nx), U((size_t)B * N * nu), K((size_t)B * N * nu * nx);
     cddp_hip_options o = ctx.getOptions().toPOD(kind_ == CDDP_HIP_SOLVER_MSIPDDP);
-    const int rc = cddp_hip_plugin_solve(&pl, kind_, N, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(), r.data(), X.data(), U.data(), K.data());
+    cddp_hip_plugin_terminal tc; std::memset(&tc, 0, sizeof(tc));
+    if (kind_ == CDDP_HIP_SOLVER_IPDDP && ctx.hasTerminalConstraints()) {   // only IPDDP reads the terminal set (ipddp_solver.cpp:84-215)
+      for (auto &kv : ctx.getTerminalConstraintSet()) {
+        if (tc.n_terminal == CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) throw std::runtime_error("HipBatchSolver: too many terminal constraints for the plug-in solve");
+        cddp_hip_terminal_constraint t; std::memset(&t, 0, sizeof(t)); kv.second->fill(t);
+        if (t.kind == CDDP_HIP_TERM_EQUALITY && t.dim != nx) throw std::invalid_argument("TerminalEqualityConstraint: final_state dimension mismatch.");
+        tc.dims[tc.n_terminal] = t.dim; tc.equality[tc.n_terminal] = (t.kind == CDDP_HIP_TERM_EQUALITY) ? 1 : 0; ++tc.n_terminal;
+        pc.terms.push_back(t);
+      }
+      tc.evaluate = cbTerminal;
+    }
+    const int rc = tc.n_terminal > 0
+        ? cddp_hip_plugin_solve_terminal(&pl, &tc, kind_, N, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(), r.data(), X.data(), U.data(), K.data(), nullptr)
+        : cddp_hip_plugin_solve(&pl, kind_, N, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(), r.data(), X.data(), U.data(), K.data());
     if (pc.error) std::rethrow_exception(pc.error);
     check(rc);
     std::vector<CDDPSolution> out(B);

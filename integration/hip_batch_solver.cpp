@@ -349,6 +349,7 @@ struct PluginCtx {
   const DynamicalSystem *sys = nullptr;
   const Objective *obj = nullptr;
   std::vector<const Constraint *> cons;
+  std::vector<const Constraint *> terms;   // terminal set in std::map order (cddp_hip_plugin_solve_terminal)
   int nx = 0, nu = 0, m = 0;
   std::exception_ptr error;   // a C++ exception must not unwind through the C library: parked here, rethrown after the call
   volatile int32_t abort_flag = 0;
@@ -371,6 +372,23 @@ void cbDyn(void *p, const double *x, const double *u, double t, double *xn) {
     const Eigen::VectorXd r = c->sys->getDiscreteDynamics(c->x, c->u, t);
     if (r.size() != c->nx) throw std::runtime_error("getDiscreteDynamics: unexpected size");
     std::copy(r.data(), r.data() + c->nx, xn);
+  });
+}
+void cbTerminal(void *p, const double *xN, double *r, double *rx) {   // residual and state-Jacobian rows of the terminal set, stacked in std::map order
+  auto *c = static_cast<PluginCtx *>(p);
+  guarded(c, [&] {
+    c->load(xN, nullptr);
+    int row = 0;
+    for (const Constraint *k : c->terms) {
+      const Eigen::VectorXd v = k->evaluate(c->x, Eigen::VectorXd());
+      for (int i = 0; i < v.size(); ++i) r[row + i] = v(i);
+      if (rx) {
+        const Eigen::MatrixXd J = k->getStateJacobian(c->x, Eigen::VectorXd());
+        if (J.rows() != v.size() || J.cols() != c->nx) throw std::runtime_error("terminal getStateJacobian: unexpected shape");
+        for (int i = 0; i < J.rows(); ++i) for (int j = 0; j < c->nx; ++j) rx[(size_t)(row + i) * c->nx + j] = J(i, j);
+      }
+      row += (int)v.size();
+    }
   });
 }
 void cbJac(void *p, const double *x, const double *u, double t, double *fx, double *fu) {   // CONTINUOUS-time f_x, f_u (cddp_solver_base.cpp:340-344 forms A, B)
@@ -532,8 +550,7 @@ class HipBatchSolver : public ISolverAlgorithm {
     FlatProblem f;
     plugin_ = !flatten(ctx, kind_, f);
     if (plugin_) {
-      if (!ctx.getTerminalConstraintSet().empty()) throw std::runtime_error("cddp_hip adapter: terminal constraints are served for built-in plants / objectives only (cddp_hip_plugin_solve has none)");
-      return;   // nothing to create: cddp_hip_plugin_solve is one call
+      return;   // nothing to create: cddp_hip_plugin_solve / cddp_hip_plugin_solve_terminal is one call
     }
     const int B = (int)x0s.size();
     check(cddp_hip_create(&f.p, B, device_, &h_));
@@ -588,8 +605,24 @@ class HipBatchSolver : public ISolverAlgorithm {
     std::vector<cddp_hip_result> r(B);
     std::vector<double> X((size_t)B * (N_ + 1) * nx_), U((size_t)B * N_ * nu_), K((size_t)B * N_ * nu_ * nx_);
     const cddp_hip_options o = toPOD(opt, kind_ == CDDP_HIP_SOLVER_MSIPDDP);
-    const int rc = cddp_hip_plugin_solve(&pl, kind_, N_, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(),
-                                         r.data(), X.data(), U.data(), K.data());
+    // terminal set (only IPDDP reads it, ipddp_solver.cpp:84-215): ANY Constraint subclass -- evaluate(x_N) and getStateJacobian(x_N) through the
+    // virtuals, classified as the reference classifies them (dynamic_cast to TerminalEqualityConstraint / TerminalInequalityConstraint, :84-105)
+    cddp_hip_plugin_terminal tc; std::memset(&tc, 0, sizeof(tc));
+    if (kind_ == CDDP_HIP_SOLVER_IPDDP) {
+      for (const auto &kv : ctx.getTerminalConstraintSet()) {
+        const bool eq = dynamic_cast<const TerminalEqualityConstraint *>(kv.second.get()) != nullptr;
+        if (!eq && dynamic_cast<const TerminalInequalityConstraint *>(kv.second.get()) == nullptr) continue;   // neither layout lists it
+        if (tc.n_terminal == CDDP_HIP_PLUGIN_MAX_CONSTRAINTS) throw std::runtime_error("cddp_hip adapter: too many terminal constraints for the plug-in solve");
+        tc.dims[tc.n_terminal] = kv.second->getDualDim(); tc.equality[tc.n_terminal] = eq ? 1 : 0; ++tc.n_terminal;
+        pc.terms.push_back(kv.second.get());
+      }
+      tc.evaluate = cbTerminal;
+    }
+    const int rc = tc.n_terminal > 0
+        ? cddp_hip_plugin_solve_terminal(&pl, &tc, kind_, N_, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(),
+                                         r.data(), X.data(), U.data(), K.data(), nullptr)
+        : cddp_hip_plugin_solve(&pl, kind_, N_, dt_, &o, device_, B, x0.data(), U0.empty() ? nullptr : U0.data(), X0.empty() ? nullptr : X0.data(),
+                                r.data(), X.data(), U.data(), K.data());
     if (pc.error) std::rethrow_exception(pc.error);   // the plug-in's own exception, as the reference would have propagated it
     check(rc);
     std::vector<CDDPSolution> out(B);

@@ -439,6 +439,41 @@ static void gpu_tests() {
       for (int t = 0; t < 8; ++t) { x = QuadraticScalarSystem().getDiscreteDynamics(x, s.control_trajectory[t], 0.0); EXPECT_TRUE(std::fabs(x[0] - s.state_trajectory[t + 1][0]) < 1e-15); }
       EXPECT_TRUE(std::fabs(cost.evaluate(s.state_trajectory, s.control_trajectory) - s.final_objective) < 1e-12);
     }
+    // round 6: the reference's user plant WITH a terminal equality (tests/cddp_core/test_ipddp_solver.cpp:292-346, 1512-1578), Gauss-Newton
+    // and full DDP, through cddp_hip_plugin_solve_terminal (reduced LQR on the GPU): the terminal state is driven to the target, the two
+    // Hessian models take different paths, the returned trajectory is the plant's own rollout
+    {
+      double k0[2] = {0.0, 0.0};
+      for (int ddp = 0; ddp < 2; ++ddp) {
+        cddp::CDDPOptions o5 = opt; o5.max_iterations = 60; o5.use_ilqr = !ddp; o5.tolerance = 1e-6; o5.acceptable_tolerance = 1e-6; o5.return_iteration_info = false; o5.ipddp.barrier.mu_initial = 0.1;
+        cddp::Vector goal = {0.0};
+        cddp::QuadraticObjective cost(0.0 * cddp::Matrix::Identity(1), 1e-2 * cddp::Matrix::Identity(1), 0.0 * cddp::Matrix::Identity(1), goal, std::vector<cddp::Vector>{}, 1.0);
+        cddp::CDDP p(cddp::Vector{1.0}, goal, 8, 1.0, std::make_unique<QuadraticScalarSystem>(), std::make_unique<cddp::QuadraticObjective>(cost), o5);
+        p.addTerminalConstraint("TerminalTarget", std::make_unique<cddp::TerminalEqualityConstraint>(goal));
+        cddp::CDDPSolution s = p.solve("IPDDP");
+        std::cout << "QuadraticScalarSystem + TerminalEqualityConstraint use_ilqr=" << !ddp << ": " << s.status_message << " iterations " << s.iterations_completed
+                  << " cost " << s.final_objective << " x_N " << s.state_trajectory.back()[0] << "\n";
+        EXPECT_TRUE(s.route == "plugin" && s.iterations_completed > 0);
+        // (the plant's reported Jacobian is not the derivative of its step, so convergence is not the claim -- the numpy twin driven by the same
+        //  plug-in pins status / iterations / trajectory in tests/test_host_plugins.py; a converged solve must sit on the target)
+        if (s.status_message == "OptimalSolutionFound" || s.status_message == "AcceptableSolutionFound") EXPECT_TRUE(std::fabs(s.state_trajectory.back()[0]) < 1e-3);
+        cddp::Vector x = {1.0};
+        for (int t = 0; t < 8; ++t) { x = QuadraticScalarSystem().getDiscreteDynamics(x, s.control_trajectory[t], 0.0); EXPECT_TRUE(std::fabs(x[0] - s.state_trajectory[t + 1][0]) < 1e-15); }
+        k0[ddp] = s.control_trajectory[0][0];
+      }
+      std::cout << "first control, Gauss-Newton vs full DDP: " << k0[0] << " " << k0[1] << "\n";
+      EXPECT_TRUE(std::fabs(k0[0] - k0[1]) > 1e-8);   // the second-order terms reach the reduced LQR (test_ipddp_solver.cpp:1576)
+      // a consistent user plant with a terminal equality and a control box: converges onto the target
+      cddp::CDDPOptions o6 = o2; o6.max_iterations = 80;
+      cddp::CDDP tp = makeHostPendulum(o6, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
+      tp.addTerminalConstraint("TerminalTarget", std::make_unique<cddp::TerminalEqualityConstraint>(cddp::Vector{0.0, 0.0}));
+      cddp::CDDPSolution ts = tp.solve("IPDDP");
+      std::cout << "host pendulum + control box + TerminalEqualityConstraint: " << ts.status_message << " iterations " << ts.iterations_completed << " cost " << ts.final_objective
+                << " x_N " << ts.state_trajectory.back()[0] << " " << ts.state_trajectory.back()[1] << "\n";
+      EXPECT_TRUE(ts.route == "plugin");
+      EXPECT_TRUE(ts.status_message == "OptimalSolutionFound" || ts.status_message == "AcceptableSolutionFound");
+      EXPECT_TRUE(std::fabs(ts.state_trajectory.back()[0]) < 1e-3 && std::fabs(ts.state_trajectory.back()[1]) < 1e-3);
+    }
     // an exception thrown inside a user virtual surfaces to the caller of solve()
     cddp::CDDP boom = makeHostPendulum(o2, std::make_unique<HostPendulum>(0.02, 0.5, 1.0, 0.01, 150), pendulumCost(), std::make_unique<cddp::ControlConstraint>(cddp::Vector{-20.0}, cddp::Vector{20.0}));
     bool threw = false;
