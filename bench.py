@@ -529,6 +529,58 @@ def measure_stackfed(api, device=0, shapes=None, reps=3):
     return lines
 
 
+def measure_plugin(api, device=0, batch=4096):
+    """One cddp_hip_plugin_solve line: the control-limited pendulum written as a USER plug-in in C (tests/cpp/pendulum_plugin.c:
+    dynamics, Jacobians, cost and constraint callbacks), IPDDP, the batch's host work on every CPU the lease owns (cddp_hip_plugin_set_host_threads),
+    the backward passes as stack-fed GPU sweeps.  Reported: trajectories / s and where the time goes (host callbacks + line search vs GPU sections)."""
+    import ctypes as C
+    so = "/tmp/cddp_pendulum_plugin_%d.so" % os.getpid()
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, os.path.join(REPO, "tests", "cpp", "pendulum_plugin.c"), "-lm"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    pl = C.CDLL(so)
+
+    class Params(C.Structure):
+        _fields_ = [(n, C.c_double) for n in ("dt", "length", "mass", "damping", "gravity", "Qf", "R", "umax")]
+    prm = Params(0.02, 0.5, 1.0, 0.01, 9.81, 100.0, 0.1, 20.0)
+    p = api.pendulum_problem(api.SOLVER_IPDDP, True)
+    lib = api.load_hip()
+    ps = api.PluginStruct()
+    ps.abi_version = api.ABI_VERSION; ps.options_bytes = C.sizeof(api.Options); ps.user = C.cast(C.pointer(prm), C.c_void_p)
+    ps.nx, ps.nu, ps.n_constraints = 2, 1, 1
+    ps.constraint_dims[0] = 2
+    for field, sym, ftype in (("discrete_dynamics", "pend_dynamics", api._F_DYN), ("jacobians", "pend_jacobians", api._F_JAC), ("running_cost", "pend_running_cost", api._F_RC),
+                              ("terminal_cost", "pend_terminal_cost", api._F_TC), ("running_cost_derivatives", "pend_running_cost_derivatives", api._F_RCD),
+                              ("terminal_cost_derivatives", "pend_terminal_cost_derivatives", api._F_TCD), ("constraints", "pend_constraints", api._F_CON)):
+        setattr(ps, field, C.cast(getattr(pl, sym), ftype))
+    B, N = batch, 100
+    x0 = api.batch_x0(p, B, 20260928 + 7, [0.1, 0.1])
+    res = np.zeros(B, dtype=api.RESULT_DTYPE)
+    ncpu, _ = available_cpus()
+    out = {}
+    for threads in (1, ncpu):
+        lib.cddp_hip_plugin_set_host_threads(int(threads))
+        t0 = time.perf_counter()
+        rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(api.SOLVER_IPDDP), N, C.c_double(0.02), C.byref(p.options), int(device), B, api._ptr(x0), None, None,
+                                       res.ctypes.data_as(C.c_void_p), None, None, None)
+        wall = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("cddp_hip_plugin_solve: %s" % lib.cddp_hip_last_error().decode())
+        tot, gpu, ker = C.c_double(), C.c_double(), C.c_double(); sw, th = C.c_int(), C.c_int()
+        lib.cddp_hip_plugin_last_stats(C.byref(tot), C.byref(gpu), C.byref(ker), C.byref(sw), C.byref(th))
+        out[threads] = {"threads": th.value, "wall_ms": wall * 1e3, "value": B / wall, "gpu_section_ms": gpu.value, "sweep_kernel_ms": ker.value, "batch_sweeps": sw.value,
+                        "host_ms": tot.value - gpu.value, "host_fraction": (tot.value - gpu.value) / max(tot.value, 1e-9)}
+    lib.cddp_hip_plugin_set_host_threads(1)
+    best = out[ncpu]
+    conv = int(np.sum((res["status"] == api.STATUS_OPTIMAL) | (res["status"] == api.STATUS_ACCEPTABLE)))
+    byt = stackfed_bytes(2, 1, N, 2, False) * B * best["batch_sweeps"]
+    return {"workload": "host plug-in solve (g1, cddp_hip_plugin_solve): pendulum nx=2 nu=1 N=100 control box as C callbacks (tests/cpp/pendulum_plugin.c), IPDDP, B=%d" % B,
+            "solver": "IPDDP (plug-in route)", "batch": B, "unit": "trajectories/s", "value": best["value"], "ms_per_step": best["wall_ms"],
+            "host_threads": best["threads"], "time_split": best, "single_thread": out[1], "mean_iterations": float(np.mean(res["iterations"])), "converged": conv,
+            "roofline": {"bound": "hbm", "kernel": "k_stacks_backward (inside the plug-in solve)", "achieved": byt / (best["sweep_kernel_ms"] * 1e-3) / 1e9 if best["sweep_kernel_ms"] > 0 else None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": (byt / (best["sweep_kernel_ms"] * 1e-3) / 1e9 / 8000.0) if best["sweep_kernel_ms"] > 0 else None,
+                         "note": "the sweeps' kernel time only; the call is bound by the host side (time_split.host_fraction)"}}
+
+
 def measure_mpc(api, rounds, device=0, workload="cartpole", batch=0):
     """f1 caller side: receding-horizon re-solves on a RE-USED handle -- the caller pattern of
     examples/ipddp_mpcc_rc.py:649-705 (solver.set_initial_state(state); solver.solve()) with the reference's warm-start branch
@@ -653,7 +705,7 @@ def main():
 
     api = load_api()
     if args.stackfed:
-        print(json.dumps({"stackfed": measure_stackfed(api, device=local_rank, shapes=STACKFED_SHAPES_FULL)}))
+        print(json.dumps({"stackfed": measure_stackfed(api, device=local_rank, shapes=STACKFED_SHAPES_FULL), "plugin": measure_plugin(api, device=local_rank)}))
         return
     if args.mpc > 0:
         if world != 1:
@@ -784,6 +836,10 @@ def main():
             out["other_workloads"].extend(measure_stackfed(api, device=local_rank))
         except Exception as e:
             out["other_workloads"].append({"workload": "stack-fed sweeps", "error": "%s: %s" % (type(e).__name__, e)})
+        try:
+            out["other_workloads"].append(measure_plugin(api, device=local_rank))
+        except Exception as e:
+            out["other_workloads"].append({"workload": "host plug-in solve", "error": "%s: %s" % (type(e).__name__, e)})
         for wl in ("pendulum", "unicycle"):
             try:
                 out["other_workloads"].append(measure_mpc(api, 8, device=local_rank, workload=wl))

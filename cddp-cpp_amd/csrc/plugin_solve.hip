@@ -52,6 +52,15 @@ inline double clampd(double v, double lo, double hi) { return std::min(std::max(
 // keeps 1 (its callbacks serialise on the interpreter lock anyway).  Results do not depend on the count: every trajectory's arithmetic is
 // its own (tests/test_host_plugins.py::test_plugin_host_threads_do_not_change_results).
 int g_host_threads = -1;   // -1: unset (environment, then 1)
+// Time split of the LAST IPDDP / CLDDP plug-in solve of this process (cddp_hip_plugin_last_stats; bench.py's plug-in line): wall time of the
+// whole call, of the GPU sections (upload of the stacks, the sweep launch, download of the gains -- cddp_hip_set_stacks .. cddp_hip_stacks_get_*),
+// the sweeps' kernel time (hipEvents, cddp_hip_stacks_last_kernel_ms) and the batch sweeps run
+struct PluginStats { double total_ms = 0, gpu_section_ms = 0, kernel_ms = 0; int sweeps = 0, threads = 1; };
+PluginStats g_last_stats;
+struct StatClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 int host_threads(int batch) {
   int n = g_host_threads;
   if (n < 0) { const char *e = std::getenv("CDDP_HIP_PLUGIN_THREADS"); n = e ? std::atoi(e) : 1; }
@@ -1695,6 +1704,15 @@ int ipddp_terminal_solve(const Ctx &c, const TermInfo &ti, int device, int batch
 
 }  // namespace
 
+extern "C" int cddp_hip_plugin_last_stats(double *total_ms, double *gpu_section_ms, double *kernel_ms, int *sweeps, int *threads) {
+  if (total_ms) *total_ms = g_last_stats.total_ms;
+  if (gpu_section_ms) *gpu_section_ms = g_last_stats.gpu_section_ms;
+  if (kernel_ms) *kernel_ms = g_last_stats.kernel_ms;
+  if (sweeps) *sweeps = g_last_stats.sweeps;
+  if (threads) *threads = g_last_stats.threads;
+  return 0;
+}
+
 extern "C" int cddp_hip_plugin_set_host_threads(int n) {
   if (n < 0) return pfail(-2, "host thread count must be >= 0 (0 = one per hardware thread)");
   g_host_threads = n;
@@ -1783,6 +1801,8 @@ static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_te
   const bool first_rule = !o.enable_parallel;
   std::atomic<bool> abort_seen{false};
   const int n_threads = host_threads((int)B);
+  const StatClock total_clock;
+  g_last_stats = PluginStats(); g_last_stats.threads = n_threads;
   const auto wall0 = std::chrono::steady_clock::now();
 
   for (int it = 1; it <= o.max_iterations; ++it) {
@@ -1834,6 +1854,7 @@ static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_te
       std::copy(t.U.begin(), t.U.end(), Ubuf.begin() + b * N * nu);
     };
     par_for(B, n_threads, fill_stacks);
+    const StatClock gpu_clock;
     { int rc = cddp_hip_set_stacks(sh, fx.data(), fu.data(), lx.data(), lu.data(), lxx.data(), luu.data(), lux.data(), VxN.data(), VxxN.data()); if (rc) return rc; }
     if (m > 0) { int rc = cddp_hip_set_constraint_stacks(sh, gy.data(), gs.data(), gg.data(), gGx.data(), gGu.data()); if (rc) return rc; }
     if (!o.use_ilqr && c.ipddp()) { int rc = cddp_hip_set_hessian_stacks(sh, Fxx.data(), Fuu.data(), Fux.data()); if (rc) return rc; }
@@ -1847,6 +1868,7 @@ static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_te
     if (Kout) for (size_t b = 0; b < B; ++b) if (!T[b].done) std::copy(Kb.begin() + b * N * nu * nx, Kb.begin() + (b + 1) * N * nu * nx, Kfin.begin() + b * N * nu * nx);
     if (m > 0) { int rc = cddp_hip_stacks_get_constraint_gains(sh, kyb.data(), Kyb.data(), ksb.data(), Ksb.data(), dXb.data()); if (rc) return rc; }
     { int rc = cddp_hip_stacks_get_scalars(sh, s_reg.data(), s_du.data(), s_pr.data(), s_comp.data(), s_sn.data(), s_apr.data(), s_adu.data()); if (rc) return rc; }
+    g_last_stats.gpu_section_ms += gpu_clock.ms(); g_last_stats.kernel_ms += cddp_hip_stacks_last_kernel_ms(sh); g_last_stats.sweeps += 1;
 
     auto advance = [&](size_t b) {
       Traj &t = T[b];
@@ -1990,6 +2012,7 @@ static int plugin_solve_impl(const cddp_hip_plugin *pl, const cddp_hip_plugin_te
     if (abort_seen.load() || aborted(pl)) return pfail(-50, "aborted by the caller (cddp_hip_plugin::abort_flag)");
   }
   for (auto &t : T) if (!t.done) { t.status = CDDP_HIP_STATUS_MAX_ITERATIONS; t.done = true; }   // max_iterations <= 0
+  g_last_stats.total_ms = total_clock.ms();
 
   // ---- CDDPSolution fields (cddp_solver_base.cpp:161-171, ipddp_solver.cpp:2090-2097); feedback gains = K_u_ of the last sweep
   if (Kout) std::copy(Kfin.begin(), Kfin.end(), Kout);

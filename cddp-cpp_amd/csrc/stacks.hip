@@ -599,17 +599,13 @@ LaunchFn pick_coop(int nx, int nu, int m) {
   return nullptr;
 }
 
-void to_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
-  for (int b = 0; b < B; ++b)
-    for (int t = 0; t < T; ++t)
-      for (int e = 0; e < E; ++e) dst[((size_t)t * E + e) * Bp + b] = src[((size_t)b * T + t) * E + e];
+// batch-major [b][r] <-> stack [r][Bp] (r = t * E + e), one thread per element, b fastest: the stack side is coalesced
+__global__ void k_stack_transpose(double *aos, double *soa, int B, int Bp, int R, int to_stack) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (b >= B) return;
+  if (to_stack) soa[(size_t)r * Bp + b] = aos[(size_t)b * R + r];
+  else aos[(size_t)b * R + r] = soa[(size_t)r * Bp + b];
 }
-void from_soa(const double *src, double *dst, int B, int Bp, int T, int E) {
-  for (int b = 0; b < B; ++b)
-    for (int t = 0; t < T; ++t)
-      for (int e = 0; e < E; ++e) dst[((size_t)b * T + t) * E + e] = src[((size_t)t * E + e) * Bp + b];
-}
-
 }  // namespace
 
 struct cddp_hip_stack_handle {
@@ -632,7 +628,7 @@ struct cddp_hip_stack_handle {
   int te_cap = 0;               // rows the te buffers were sized for
   bool have_te = false, swept_te = false;
   double last_ms = 0.0;
-  std::vector<double> tmp;
+  double *d_stage = nullptr; size_t stage_cap = 0;   // batch-major staging buffer of upload() / download()
 };
 
 namespace {
@@ -644,21 +640,37 @@ int salloc(cddp_hip_stack_handle *h, double **p, size_t n) {
   *p = (double *)q;
   return 0;
 }
+// Host arrays are batch-major [b][t][e], the stacks [t][e][Bp].  Round 6: the transposition runs on the DEVICE (k_stack_transpose) around one
+// contiguous copy -- the host loop it replaces (a write stride of Bp * 8 bytes per element) moved 1.1 GB/s and was 94 % of a plug-in solve
+// (bench.py's plug-in line: 4096 pendulum trajectories, 30 sweeps: 4.35 s of 4.65 s; profiles/r06_plugin_route.md).
+int stage_reserve(cddp_hip_stack_handle *h, size_t n) {
+  if (n <= h->stage_cap) return 0;
+  if (h->d_stage) { SCHK(hipStreamSynchronize(h->stream)); SCHK(hipFree(h->d_stage)); h->d_stage = nullptr; h->stage_cap = 0; }
+  void *q = nullptr;
+  SCHK(hipMalloc(&q, n * sizeof(double)));
+  h->d_stage = (double *)q; h->stage_cap = n;
+  return 0;
+}
 int upload(cddp_hip_stack_handle *h, const double *src, double *dst, int T, int E) {
   if (!src) return 0;
-  const size_t n = (size_t)T * E * h->Bp;
-  h->tmp.assign(n, 0.0);
-  to_soa(src, h->tmp.data(), h->B, h->Bp, T, E);
-  SCHK(hipMemcpyAsync(dst, h->tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  SCHK(hipStreamSynchronize(h->stream));   // tmp is reused by the next upload
+  const size_t n = (size_t)T * E * h->B;
+  if (n == 0) return 0;
+  { int rc = stage_reserve(h, n); if (rc) return rc; }
+  SCHK(hipMemcpyAsync(h->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, dst, h->B, h->Bp, T * E, 1);
+  SCHK(hipGetLastError());
+  SCHK(hipStreamSynchronize(h->stream));   // the caller may reuse src; the staging buffer is reused by the next upload
   return 0;
 }
 int download(cddp_hip_stack_handle *h, const double *src, double *dst, int T, int E) {
   if (!dst) return 0;
-  const size_t n = (size_t)T * E * h->Bp;
-  h->tmp.resize(n);
-  SCHK(hipMemcpy(h->tmp.data(), src, n * sizeof(double), hipMemcpyDeviceToHost));
-  from_soa(h->tmp.data(), dst, h->B, h->Bp, T, E);
+  const size_t n = (size_t)T * E * h->B;
+  if (n == 0) return 0;
+  { int rc = stage_reserve(h, n); if (rc) return rc; }
+  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, const_cast<double *>(src), h->B, h->Bp, T * E, 0);
+  SCHK(hipGetLastError());
+  SCHK(hipMemcpyAsync(dst, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 }  // namespace
@@ -705,6 +717,7 @@ int cddp_hip_stacks_destroy(cddp_hip_stack_handle *h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void *q : h->allocs) hipFree(q);
+  if (h->d_stage) hipFree(h->d_stage);
   if (h->e0) { hipEventDestroy(h->e0); hipEventDestroy(h->e1); }
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;

@@ -595,7 +595,7 @@ EXPORTED_SYMBOLS = [
     "cddp_hip_set_timing_detail", "cddp_hip_history_capacity", "cddp_hip_set_barrier_state", "cddp_hip_num_groups", "cddp_hip_concurrency", "cddp_hip_comm_unique_id", "cddp_hip_comm_init", "cddp_hip_comm_destroy", "cddp_hip_comm_info", "cddp_hip_get_plan_head", "cddp_hip_allgather_results",
     "cddp_hip_backward_stacks", "cddp_hip_stacks_create_abi", "cddp_hip_stacks_destroy", "cddp_hip_set_stacks", "cddp_hip_set_defect_stack", "cddp_hip_set_control_box", "cddp_hip_set_hessian_stacks", "cddp_hip_set_constraint_stacks",
     "cddp_hip_stacks_backward", "cddp_hip_stacks_last_kernel_ms", "cddp_hip_stacks_last_sweep_form", "cddp_hip_stacks_factor_cache", "cddp_hip_stacks_get_gains", "cddp_hip_stacks_get_constraint_gains",
-    "cddp_hip_stacks_get_scalars", "cddp_hip_set_terminal_equality", "cddp_hip_stacks_get_terminal", "cddp_hip_plugin_solve", "cddp_hip_plugin_solve_terminal", "cddp_hip_plugin_set_host_threads", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
+    "cddp_hip_stacks_get_scalars", "cddp_hip_set_terminal_equality", "cddp_hip_stacks_get_terminal", "cddp_hip_plugin_solve", "cddp_hip_plugin_solve_terminal", "cddp_hip_plugin_set_host_threads", "cddp_hip_plugin_last_stats", "cddp_hip_model_eval", "cddp_hip_set_options", "cddp_hip_set_initial_state", "cddp_hip_forget_solver_state", "cddp_hip_set_duals", "cddp_hip_set_terminal",
 ]
 
 

@@ -686,6 +686,9 @@ int cddp_hip_plugin_solve_terminal(const cddp_hip_plugin *plugin, const cddp_hip
  * only.  n > 1 (0 = one per hardware thread): the plug-in's callbacks are called CONCURRENTLY for different trajectories -- for thread-safe
  * plug-ins.  Process-wide; CDDP_HIP_PLUGIN_THREADS is the default when this was never called.  Results do not depend on the count. */
 int cddp_hip_plugin_set_host_threads(int n);
+/* Time split of this process's LAST IPDDP / CLDDP cddp_hip_plugin_solve (any output may be NULL): wall ms of the whole call, of its GPU
+ * sections (stack upload + sweep launch + gain download), the sweeps' kernel ms (hipEvents), batch sweeps launched, host threads used. */
+int cddp_hip_plugin_last_stats(double *total_ms, double *gpu_section_ms, double *kernel_ms, int *sweeps, int *threads);
 int cddp_hip_plugin_solve(const cddp_hip_plugin *plugin, int solver /* cddp_hip_solver */, int horizon, double dt,
                           const cddp_hip_options *options, int device, int batch, const double *x0, const double *U0, const double *X0,
                           cddp_hip_result *results, double *X, double *U, double *K);

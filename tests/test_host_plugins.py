@@ -183,6 +183,50 @@ def test_plugin_host_threads_do_not_change_results(api, pycddp, solver):
 
 
 @pytest.mark.gpu
+def test_c_plugin_matches_the_oracle_on_many_threads(api, oracle_built, tmp_path):
+    """A user plug-in written in C (tests/cpp/pendulum_plugin.c: the plant, objective and control box of examples/cddp_pendulum.cpp as callbacks),
+    solved with the batch's host work on eight threads: every trajectory makes the oracle's decisions (the callbacks are the built-in pendulum's
+    arithmetic), and cddp_hip_plugin_last_stats accounts for the call."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path / "pendulum_plugin.so")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, os.path.join(REPO, "tests", "cpp", "pendulum_plugin.c"), "-lm"])
+    pl = C.CDLL(so)
+
+    class Params(C.Structure):
+        _fields_ = [(n, C.c_double) for n in ("dt", "length", "mass", "damping", "gravity", "Qf", "R", "umax")]
+    prm = Params(0.02, 0.5, 1.0, 0.01, 9.81, 100.0, 0.1, 20.0)
+    p = api.pendulum_problem(api.SOLVER_IPDDP, True)
+    lib = api.load_hip()
+    ps = api.PluginStruct()
+    ps.abi_version = api.ABI_VERSION; ps.options_bytes = C.sizeof(api.Options); ps.user = C.cast(C.pointer(prm), C.c_void_p)
+    ps.nx, ps.nu, ps.n_constraints = 2, 1, 1
+    ps.constraint_dims[0] = 2
+    for field, sym, ftype in (("discrete_dynamics", "pend_dynamics", api._F_DYN), ("jacobians", "pend_jacobians", api._F_JAC), ("running_cost", "pend_running_cost", api._F_RC),
+                              ("terminal_cost", "pend_terminal_cost", api._F_TC), ("running_cost_derivatives", "pend_running_cost_derivatives", api._F_RCD),
+                              ("terminal_cost_derivatives", "pend_terminal_cost_derivatives", api._F_TCD), ("constraints", "pend_constraints", api._F_CON)):
+        setattr(ps, field, C.cast(getattr(pl, sym), ftype))
+    B, N = 40, 100
+    x0 = api.batch_x0(p, B, 20260932, [0.1, 0.1])
+    res = np.zeros(B, dtype=api.RESULT_DTYPE); X = np.zeros((B, N + 1, 2)); U = np.zeros((B, N, 1))
+    try:
+        assert lib.cddp_hip_plugin_set_host_threads(8) == 0
+        rc = lib.cddp_hip_plugin_solve(C.byref(ps), int(api.SOLVER_IPDDP), N, C.c_double(0.02), C.byref(p.options), 0, B, api._ptr(x0), None, None,
+                                       res.ctypes.data_as(C.c_void_p), api._ptr(X), api._ptr(U), None)
+    finally:
+        lib.cddp_hip_plugin_set_host_threads(1)
+    assert rc == 0, lib.cddp_hip_last_error().decode()
+    tot, gpu, ker = C.c_double(), C.c_double(), C.c_double(); sw, th = C.c_int(), C.c_int()
+    assert lib.cddp_hip_plugin_last_stats(C.byref(tot), C.byref(gpu), C.byref(ker), C.byref(sw), C.byref(th)) == 0
+    assert th.value == 8 and sw.value >= int(res["iterations"].max()) and 0.0 < ker.value <= gpu.value <= tot.value
+    ores, oX, oU, _, _ = api.oracle_solve_batch(p, x0, None, None, n_threads=8)
+    assert np.array_equal(res["iterations"], ores["iterations"]) and np.array_equal(res["status"], ores["status"])
+    assert np.array_equal(res["n_backward"], ores["n_backward"]) and np.array_equal(res["n_forward"], ores["n_forward"])
+    assert np.max(np.abs(res["final_objective"] - ores["final_objective"]) / np.maximum(1.0, np.abs(ores["final_objective"]))) < 1e-9
+    assert np.max(np.abs(X - oX)) < 1e-8 and np.max(np.abs(U - oU)) < 1e-7
+
+
+@pytest.mark.gpu
 def test_python_unicycle_plugin_with_box_and_ball_matches_the_oracle(api, pycddp, oracle_built):
     """nx = 3, nu = 2, two constraint objects (control box 'control_limits' + ball 'obstacle': m = 5, one row reads x): the stacking
     order, the constraint-major merit / violation sums and the G_x terms of the plug-in path against the oracle."""
