@@ -110,10 +110,10 @@ def make_problem(api, workload, solver):
 
 
 # committed PMC traffic summaries (profiles/make_traffic_json.py) per (workload, solver, batch)
-TRAFFIC_FILES = {("cartpole", "ipddp", 4096): "r06_pmc_traffic.json", ("quadrotor", "ipddp", 2048): "r05_pmc_traffic_quadrotor.json",
-                 ("manip7", "ipddp", 4096): "r05_pmc_traffic_manip7.json", ("cartpole", "clddp", 4096): "r05_pmc_traffic_clddp.json",
-                 ("unicycle", "ipddp", 8192): "r06_pmc_traffic_unicycle.json", ("cartpole", "logddp", 4096): "r05_pmc_traffic_logddp.json",
-                 ("pendulum", "msipddp", 4096): "r05_pmc_traffic_msipddp.json"}
+TRAFFIC_FILES = {("cartpole", "ipddp", 4096): "r06_pmc_traffic.json", ("quadrotor", "ipddp", 2048): "r06_pmc_traffic_quadrotor.json",
+                 ("manip7", "ipddp", 4096): "r06_pmc_traffic_manip7.json", ("cartpole", "clddp", 4096): "r06_pmc_traffic_clddp.json",
+                 ("unicycle", "ipddp", 8192): "r06_pmc_traffic_unicycle.json", ("cartpole", "logddp", 4096): "r06_pmc_traffic_logddp.json",
+                 ("pendulum", "msipddp", 4096): "r06_pmc_traffic_msipddp.json"}
 ASSOC_ORDER_FILE = "r06_assoc_order.json"             # tests/test_cross_arithmetic.py::test_bench_batch_against_eigen_order_checker, collected by profiles/scripts/collect_parity_reports.py
 CROSS_ARITHMETIC_FILE = "r05_cross_arithmetic.json"   # tests/test_cross_arithmetic.py's reports, copied from gpurun_out/
 STRONG_GLOBAL_BATCH = {"cartpole": 4096, "cartpole_unc": 4096, "pendulum": 4096, "unicycle": 8192, "quadrotor": 16384, "manip7": 32768}
