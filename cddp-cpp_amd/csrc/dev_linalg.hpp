@@ -335,6 +335,24 @@ DEV double min_real_eig(const double *M) {
   double S[N * N];
   for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) S[i * N + j] = 0.5 * (M[i * N + j] + M[j * N + i]);
   for (int sweep = 0; sweep < 60; ++sweep) {
+    // Every caller only asks for the SIGN (`min_real_eig(Q) <= 0`, clddp_solver.cpp:133-140).  Once the current iterate certifies it -- all
+    // Gershgorin discs right of +margin (positive definite), or a diagonal entry = a Rayleigh quotient below -margin (an eigenvalue below it)
+    // -- the remaining sweeps (the reference-shaped loop runs on until the off-diagonal sum of squares underflows 1e-300) can only move the
+    // answer by O(N eps |S|), six orders below the margin: same decision, a fraction of the rotations (round 6: the stack-fed CLDDP sweep at
+    // nx = 12, nu = 4 repeated this test in every lane of a trajectory, 25 ms per sweep against 5 ms for the IPDDP form).
+    {
+      double lo = INFINITY, dmn = INFINITY, scale = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) if (j != i) r += fabs(S[i * N + j]);
+        lo = dmin(lo, S[i * N + i] - r); dmn = dmin(dmn, S[i * N + i]); scale = dmax(scale, fabs(S[i * N + i]) + r);
+      }
+      const double margin = 1e-8 * scale;
+      if (lo > margin) return lo;
+      if (dmn < -margin) return dmn;
+    }
     double off = 0;
     for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j) off += S[i * N + j] * S[i * N + j];
     if (off < 1e-300) break;
