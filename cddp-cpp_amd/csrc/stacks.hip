@@ -1014,4 +1014,10 @@ int cddp_hip_backward_stacks(int device, int batch, int nx, int nu, int horizon,
   return rc;
 }
 
+#ifdef SC_TIMING
+int cddp_hip_debug_sc_times(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_times), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 }  // extern "C"

@@ -40,21 +40,52 @@ struct SCfg {
 // the same for the matrix-sized quantities, rolled: unrolled, the scheduler hoists every LDS read of the phase and the kernel
 // needs all 512 registers plus scratch
 // "for c in my columns of an NC-column matrix"
-// Global element e of step t of an [t][E][Bp] stack: a wave-uniform 64-bit base (SGPR pair) plus a 32-bit lane offset, so the access
-// is "global_load v, v_off, s[base]" -- written as base + ((t * E + e) * Bp + b) the compiler strength-reduces EVERY access into its own
-// 64-bit VGPR pointer that lives across the whole sweep (~70 pairs: the first version spilled 250 registers).  eu = the part of the
-// element index that does not depend on the lane (e - gl).
-DEV double *sc_at(const double *base, int t, int E, int eu, unsigned lane8, unsigned bp8, int Bp) {
-  const unsigned long long v = (unsigned long long)(base + ((size_t)t * E + eu) * Bp);
+// Global element e of step t of an [t][E][Bp] stack: "global_load v, v_off, s[base]" with ONE wave-uniform 64-bit base per (stack, step)
+// (SGPR pair: stack + t E Bp) and a 32-bit lane offset that does not depend on the stack or the step -- element e = e_it * 16 + gl of
+// trajectory b sits at ((e_it * 16 + gl) Bp + b) * 8 behind the base: the offsets vo.v[e_it] are formed once per kernel and kept opaque
+// (round 6: with the element's uniform part folded into the base instead, every access carried its own s_add / s_addc / shift chain --
+// ~1 900 of the 7 000 instructions of a step at nx = 12; a wavefront alone on its SIMD issues one instruction per ~5 cycles, so the
+// instruction count is the step time).  Written as base + ((t * E + e) * Bp + b) the compiler strength-reduces EVERY access into its
+// own 64-bit VGPR pointer that lives across the whole sweep (~70 pairs: the first version spilled 250 registers).
+// (address space 1: the laundered pointer would otherwise be a FLAT access, which counts in lgkmcnt as well -- every lds_sync() behind
+// the step's prefetch then waited for the prefetch itself)
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) char gchar;
+// the kernel's argument block, as the kernel-argument segment holds it (k_stacks_backward_coop has ONE parameter, at offset 0)
+typedef const __attribute__((address_space(4))) StackArgs *sc_kargs_t;
+template <int KMAX>
+struct SCOff {
+  unsigned v[KMAX], b8, bp8;
+  DEV void init(int gl, int b, int Bp) {
+    bp8 = (unsigned)Bp * 8u; b8 = (unsigned)b * 8u;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { v[k] = ((unsigned)(k * 16 + gl) * (unsigned)Bp + (unsigned)b) * 8u; asm volatile("" : "+v"(v[k])); }
+  }
+};
+template <int NX, int NU, int M> struct SCOffFor {
+  static constexpr int MMx = (M > 0 ? M : 1) * NX, E = NX * NX > MMx ? NX * NX : MMx;
+  typedef SCOff<(E + 15) / 16> type;
+};
+// One buffer resource per (stack, step): base = stack + t E Bp in an SGPR quad, no stride, no range to speak of; every access is then ONE
+// instruction, buffer_load / buffer_store dwordx2 v, v_off, s[rsrc], s_off offen.  (global_load with a 64-bit SGPR base + 32-bit VGPR
+// offset would do as well, but the zero-extension of the loop-invariant offsets is hoisted out of the step loop and the instruction
+// selector then sees a 64-bit VGPR add per access.)  Offsets are 32-bit: the host side keeps the cooperative form to E Bp 8 < 2^32.
+typedef unsigned int sc_u32x2 __attribute__((ext_vector_type(2)));
+DEV __amdgpu_buffer_rsrc_t sc_rsrc(const double *base, int t, int E, int Bp) {
+  const unsigned long long v = (unsigned long long)(base + (size_t)t * E * Bp);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull)), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  char *q = (char *)(((unsigned long long)hi << 32) | lo);
-  (void)bp8;
-  return (double *)(q + lane8);
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)0xffffffff, 0x00020000);
 }
-#define SC_G(stack, t, E, e) (*sc_at((stack), (t), (E), (e) - gl, lane8, bp8, bpo))
-// the same for an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): uniform step
-// base, per-lane 32-bit offset e * Bp + b
-#define SC_GV(stack, t, E, e) (*(double *)((char *)sc_at((stack), (t), (E), 0, 0u, bp8, bpo) + ((unsigned)(e) * bp8 + (unsigned)b * 8u)))
+DEV double sc_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+DEV void sc_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sc_u32x2, x), r, voff, soff, 0); }
+// element e of an SC_EACH(E, e) loop
+#define SC_LD(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[e##_it], 0u)
+#define SC_ST(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[e##_it], 0u, (x))
+// element eu + gl, eu uniform (a column owner walking rows): the uniform part rides in the scalar offset
+#define SC_LDU(stack, t, E, eu) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8)
+#define SC_STU(stack, t, E, eu, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8, (x))
+// an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): per-lane 32-bit offset e * Bp + b
+#define SC_LDV(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), (unsigned)(e) * vo.bp8 + vo.b8, 0u)
 // The step index and the batch pitch are laundered through an empty asm once per step: otherwise the optimiser turns every access into
 // its own loop-carried 64-bit induction variable (~70 SGPR pairs, spilled to VGPR lanes: 628 v_readlane / v_writelane in the step
 // loop); laundered, the address arithmetic stays inside the step on the otherwise idle scalar unit.
@@ -90,20 +121,19 @@ struct SCRec {
   static constexpr int MM = M > 0 ? M : 1;
   double A[cdiv(NX * NX)], Bm[cdiv(NX * NU)], lx[cdiv(NX)], lu[cdiv(NU)], lxx[cdiv(NX * NX)], luu[cdiv(NU * NU)], lux[cdiv(NU * NX)];
   double y[cdiv(MM)], s[cdiv(MM)], g[cdiv(MM)], Gx[cdiv(MM * NX)], Gu[cdiv(MM * NU)];
-  DEV void fetch(const StackArgs &a, int t0, int b, int gl) {
+  template <class AT, class VO> DEV void fetch(const AT &a, int t0, int gl, const VO &vo) {
     SC_OPAQUE(t, bpo, t0);
-    const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
-    SC_EACH(NX * NX, e) A[e_it] = SC_G(a.fx, t, NX * NX, e);
-    SC_EACH(NX * NU, e) Bm[e_it] = SC_G(a.fu, t, NX * NU, e);
-    SC_EACH(NX, e) lx[e_it] = SC_G(a.lx, t, NX, e);
-    SC_EACH(NU, e) lu[e_it] = SC_G(a.lu, t, NU, e);
-    SC_EACH(NX * NX, e) lxx[e_it] = SC_G(a.lxx, t, NX * NX, e);
-    SC_EACH(NU * NU, e) luu[e_it] = SC_G(a.luu, t, NU * NU, e);
-    SC_EACH(NU * NX, e) lux[e_it] = SC_G(a.lux, t, NU * NX, e);
+    SC_EACH(NX * NX, e) A[e_it] = SC_LD(a.fx, t, NX * NX, e);
+    SC_EACH(NX * NU, e) Bm[e_it] = SC_LD(a.fu, t, NX * NU, e);
+    SC_EACH(NX, e) lx[e_it] = SC_LD(a.lx, t, NX, e);
+    SC_EACH(NU, e) lu[e_it] = SC_LD(a.lu, t, NU, e);
+    SC_EACH(NX * NX, e) lxx[e_it] = SC_LD(a.lxx, t, NX * NX, e);
+    SC_EACH(NU * NU, e) luu[e_it] = SC_LD(a.luu, t, NU * NU, e);
+    SC_EACH(NU * NX, e) lux[e_it] = SC_LD(a.lux, t, NU * NX, e);
     if constexpr (M > 0) {
-      SC_EACH(M, e) { y[e_it] = SC_G(a.y, t, M, e); s[e_it] = SC_G(a.s, t, M, e); g[e_it] = SC_G(a.g, t, M, e); }
-      SC_EACH(M * NX, e) Gx[e_it] = SC_G(a.Gx, t, M * NX, e);
-      SC_EACH(M * NU, e) Gu[e_it] = SC_G(a.Gu, t, M * NU, e);
+      SC_EACH(M, e) { y[e_it] = SC_LD(a.y, t, M, e); s[e_it] = SC_LD(a.s, t, M, e); g[e_it] = SC_LD(a.g, t, M, e); }
+      SC_EACH(M * NX, e) Gx[e_it] = SC_LD(a.Gx, t, M * NX, e);
+      SC_EACH(M * NU, e) Gu[e_it] = SC_LD(a.Gu, t, M * NU, e);
     }
   }
   DEV void park(double *__restrict__ L, int gl) const {
@@ -163,12 +193,18 @@ DEV void sc_rows(const double *__restrict__ L, const double (&v)[K], Addr addr, 
   sc_rows_t<R, K>(L, addr, [&](int k, double x) { return x * v[k]; }, out);
 }
 
+#ifdef SC_TIMING   // experiment: cycles per section of the step loop, summed over the sweep, per workgroup (profiles/scripts/sc_times.py)
+__device__ unsigned long long g_sc_times[4096 * 16];
+#define SC_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); tk_acc[k] += now_ - tk_last; tk_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SC_TICK(k) do { } while (0)
+#endif
 template <int NX, int NU, int M>
-DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__restrict__ L, const double reg, const double mu, double &dV0,
-                    double &dV1, double &inf_du, double &inf_pr, double &inf_comp, double &step_norm) {
+DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl, const typename SCOffFor<NX, NU, M>::type &vo, double *__restrict__ L, const double reg,
+                    const double mu, double &dV0, double &dV1, double &inf_du, double &inf_pr, double &inf_comp, double &step_norm) {
   typedef SCfg<NX, NU, M> C;
+  const StackArgs &a = a0;
   const int N = a.N, bpo = a.Bp;
-  const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
   const bool lg = a.branch == CDDP_HIP_STACKS_LOGDDP;
   const bool msp = a.branch == CDDP_HIP_STACKS_MSIPDDP_PATH;
   const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP || msp;
@@ -183,8 +219,8 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
     SC_LOOP(NX * NX, e) L[C::oVxx + e] = a.VxxN[(size_t)e * a.Bp + b];
   }
   lds_sync();
-  SC_EACH(NX, i) SC_G(a.Vx, N, NX, i) = L[C::oVx + i];
-  SC_LOOP(NX * NX, e) SC_G(a.Vxx, N, NX * NX, e) = L[C::oVxx + e];
+  SC_EACH(NX, i) SC_ST(a.Vx, N, NX, i, L[C::oVx + i]);
+  SC_EACH(NX * NX, e) SC_ST(a.Vxx, N, NX * NX, e, L[C::oVxx + e]);
   dV0 = dV1 = 0.0; inf_du = inf_pr = inf_comp = step_norm = 0.0;
   double norm_Vx = 0.0;
   if (!ip && !lg) {
@@ -192,9 +228,20 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
     for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
   }
   SCRec<NX, NU, M> rec;
-  rec.fetch(a, N - 1, b, gl);
+  rec.fetch(a, N - 1, gl, vo);
+#ifdef SC_TIMING
+  unsigned long long tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = __builtin_readcyclecounter();
+#endif
+  const bool have_Fxx = a0.Fxx != nullptr;
   for (int t_ = N - 1; t_ >= 0; --t_) {
     SC_OPAQUE(t, bpo, t_);
+    // The ~45 stack pointers of the argument block do not fit the scalar registers next to the step's buffer resources: kept across
+    // the loop they were parked in VGPR lanes and came back through ~390 v_readlane per step.  Read through a pointer the optimiser
+    // cannot see through, they are re-fetched from the kernel-argument segment (scalar cache) where a step needs them.
+    sc_kargs_t kp = (sc_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const auto &a = *kp;
+    SC_TICK(15);
     // ---------------------------------------------------------------- step record -> LDS (fetched during the previous step)
     rec.park(L, gl);
     // w = V_x, or V_x + V_xx d_t under multiple shooting (V of step t + 1 is already in LDS)
@@ -202,14 +249,15 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       SC_EACH(NX, i) {
         double s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NX; ++k) s1 += L[C::oVxx + i * NX + k] * SC_GV(a.dfc, t, NX, k);
+        for (int k = 0; k < NX; ++k) s1 += L[C::oVxx + i * NX + k] * SC_LDV(a.dfc, t, NX, k);
         L[C::oW + i] = L[C::oVx + i] + s1;
       }
     } else {
       SC_EACH(NX, i) L[C::oW + i] = L[C::oVx + i];
     }
     lds_sync();
-    if (t > 0) rec.fetch(a, t - 1, b, gl);   // in flight behind this step's arithmetic
+    SC_TICK(0);
+    if (t > 0) rec.fetch(a, t - 1, gl, vo);   // in flight behind this step's arithmetic
     // ---------------------------------------------------------------- Q_x, Q_u, T1 = A^T V_xx, T2 = B^T V_xx
     SC_EACH(NX, i) {
       double q = L[C::oQx + i];
@@ -237,6 +285,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       for (int k = 0; k < NX; ++k) s2 += L[C::oB + k * NU + i] * L[C::oW + k];
       L[C::oQu + i] = q + s2;
     }
+    SC_TICK(1);
     // column owners: lane c keeps column c of the right-hand operand in registers and walks the rows; the other operand arrives
     // as group-wide broadcast reads (one LDS address per trajectory and instruction)
     SC_COLS(NX, c) {
@@ -247,6 +296,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       sc_rows<NU, NX>(L, v, [](int i, int k) { return C::oB + k * NU + i; }, [&](int i, double s1) { L[C::oT2 + i * NX + c] = s1; });
     }
     lds_sync();
+    SC_TICK(2);
     // ---------------------------------------------------------------- Q_xx += T1 A, Q_ux += T2 A, Q_uu += T2 B (+ tensor terms)
     SC_COLS(NX, c) {
       double v[NX];
@@ -255,13 +305,13 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       sc_rows<NX, NX>(L, v, [](int i, int k) { return C::oT1 + i * NX + k; }, [&](int i, double s1) {
         const int e = i * NX + c;
         double q = L[C::oQxx + e] + s1;
-        if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fxx, t, NX * NX * NX, j * NX * NX + e);
+        if (have_Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_LDU(a.Fxx, t, NX * NX * NX, j * NX * NX + i * NX);
         L[C::oQxx + e] = q;
       });
       sc_rows<NU, NX>(L, v, [](int i, int k) { return C::oT2 + i * NX + k; }, [&](int i, double s1) {
         const int e = i * NX + c;
         double q = L[C::oQux + e] + s1;
-        if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fux, t, NX * NU * NX, j * NU * NX + e);
+        if (have_Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_LDU(a.Fux, t, NX * NU * NX, j * NU * NX + i * NX);
         L[C::oQux + e] = q;
       });
     }
@@ -271,10 +321,11 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
 #pragma unroll
       for (int k = 0; k < NX; ++k) s1 += L[C::oT2 + i * NX + k] * L[C::oB + k * NU + c];
       double q = L[C::oQuu + e] + s1;
-      if (a.Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_G(a.Fuu, t, NX * NU * NU, j * NU * NU + e);
+      if (have_Fxx) for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * SC_LDU(a.Fuu, t, NX * NU * NU, j * NU * NU + e_it * 16);
       L[C::oQuu + e] = q;
     }
     lds_sync();
+    SC_TICK(3);
     // ---------------------------------------------------------------- gains
     double kk[NU];
     if constexpr (M > 0) {
@@ -313,6 +364,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
                          [&](int i, double s2) { L[C::oRx + i * NX + c] = L[C::oQux + i * NX + c] + s2; });
       }
       lds_sync();
+      SC_TICK(4);
       {
         double Qr[NU * NU];
 #pragma unroll
@@ -334,13 +386,14 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         }
       }
       lds_sync();
+      SC_TICK(5);
       // slack / dual direction gains (:1458-1472)
       SC_EACH(M, r) {
         double temp = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; ++i) temp += L[C::oGu + r * NU + i] * kk[i];
-        SC_G(a.ky, t, M, r) = msp ? (L[C::oRhat + r] + L[C::oY + r] * temp) / L[C::oSs + r] : clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]);
-        SC_G(a.ks, t, M, r) = (-L[C::oRp + r]) - temp;
+        SC_ST(a.ky, t, M, r, msp ? (L[C::oRhat + r] + L[C::oY + r] * temp) / L[C::oSs + r] : clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]));
+        SC_ST(a.ks, t, M, r, (-L[C::oRp + r]) - temp);
       }
       SC_COLS(NX, c) {
         double kc[NU];
@@ -354,10 +407,11 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
           const int e = r * NX + c;
           const double gx = L[C::oGx + e];
           const double inner = gx + s2;
-          SC_G(a.Ky, t, M * NX, e) = msp ? L[C::oYS + r] * inner : dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS);
-          SC_G(a.Ks, t, M * NX, e) = (-gx) - s2;
+          SC_STU(a.Ky, t, M * NX, r * NX, msp ? L[C::oYS + r] * inner : dclamp(L[C::oYS + r] * inner, -kMaxRatioS, kMaxRatioS));
+          SC_STU(a.Ks, t, M * NX, r * NX, (-gx) - s2);
         }
       }
+      SC_TICK(6);
       // condensed terms into the Q blocks (:1488-1492)
       SC_EACH(NX, i) {
         double s1 = 0.0;
@@ -406,7 +460,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       const bool cached = caching && a.fvalid[(size_t)t * a.Bp + b] != 0;
       SC_EACH(NU * NU, e) {
         if (!lg) L[C::oQuu + e] = qs[e_it];
-        L[C::oQr + e] = cached ? SC_G(a.QuuF, t, NU * NU, e) : qs[e_it];
+        L[C::oQr + e] = cached ? SC_LD(a.QuuF, t, NU * NU, e) : qs[e_it];
       }
       lds_sync();
       {
@@ -416,7 +470,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         SCFactor<NU> f;
         if (!f.compute(Qr)) { if (caching && gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 0; return false; }
         if (caching && !cached) {
-          SC_EACH(NU * NU, e) SC_G(a.QuuF, t, NU * NU, e) = L[C::oQr + e];
+          SC_EACH(NU * NU, e) SC_ST(a.QuuF, t, NU * NU, e, L[C::oQr + e]);
           if (gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 1;
         }
         double col[NU];
@@ -444,10 +498,10 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       if (a.lo) {
         double lb[NU], ub[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { const double ut = SC_GV(a.U, t, NU, i); lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = SC_GV(a.k, t, NU, i); }
+        for (int i = 0; i < NU; ++i) { const double ut = SC_LDV(a.U, t, NU, i); lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = SC_LDV(a.k, t, NU, i); }
         int free_[NU];
         LDLTd<NU> Hfree;
-        const int stq = boxqp_solve<NU>(a.opt, Qr, Qu, lb, ub, kk, free_, Hfree);
+        const int stq = boxqp_solve<NU>(a0.opt, Qr, Qu, lb, ub, kk, free_, Hfree);
         if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
         int free_idx[NU]; int nf = 0;
         for (int i = 0; i < NU; ++i) if (free_[i]) free_idx[nf++] = i;
@@ -483,8 +537,9 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       }
     }
     lds_sync();
-    SC_EACH(NU, i) SC_G(a.k, t, NU, i) = kk[i];
-    SC_LOOP(NU * NX, e) SC_G(a.K, t, NU * NX, e) = L[C::oKK + e];
+    SC_TICK(7);
+    SC_EACH(NU, i) SC_ST(a.k, t, NU, i, kk[i]);
+    SC_EACH(NU * NX, e) SC_ST(a.K, t, NU * NX, e, L[C::oKK + e]);
     {   // expected-decrease terms: the scalar chain every lane repeats
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -506,6 +561,7 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
       L[C::oKtQ + e] = s1;
     }
     lds_sync();
+    SC_TICK(8);
     // ---------------------------------------------------------------- value update
     double vxn[(NX + 15) / 16];
     SC_EACH(NX, i) {
@@ -536,19 +592,24 @@ DEV bool sweep_coop(const StackArgs &a, const int b, const int gl, double *__res
         L[C::oVn + i * NX + c] = ((L[C::oQxx + i * NX + c] + p) + q) + r;
       }
     }
-    SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; SC_G(a.Vx, t, NX, i) = vxn[i_it]; }
+    SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; SC_ST(a.Vx, t, NX, i, vxn[i_it]); }
     lds_sync();
-    SC_LOOP(NX * NX, e) {
+    SC_TICK(9);
+    SC_EACH(NX * NX, e) {
       const int i = e / NX, c = e - i * NX;
       const double v = 0.5 * (L[C::oVn + i * NX + c] + L[C::oVn + c * NX + i]);
-      L[C::oVxx + e] = v; SC_G(a.Vxx, t, NX * NX, e) = v;
+      L[C::oVxx + e] = v; SC_ST(a.Vxx, t, NX * NX, e, v);
     }
     if (!ip && !lg) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
     }
     lds_sync();
+    SC_TICK(10);
   }
+#ifdef SC_TIMING
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) for (int k = 0; k < 16; ++k) g_sc_times[blockIdx.x * 16 + k] = tk_acc[k];
+#endif
   if constexpr (M > 0) {   // the lanes hold partial maxima over their constraint rows
     L[C::oRed + gl] = inf_pr; L[C::oRed + 16 + gl] = inf_comp;
     lds_sync();
@@ -573,24 +634,23 @@ struct SCRoll {
   static constexpr int MM = M > 0 ? M : 1;
   double Ks[cdiv(MM)][NX], Ky[cdiv(MM)][NX], ks[cdiv(MM)], ky[cdiv(MM)], s[cdiv(MM)], y[cdiv(MM)];
   double K[cdiv(NU)][NX], k[cdiv(NU)], fx[cdiv(NX)][NX], fu[cdiv(NX)][NU];
-  DEV void load(const StackArgs &a, int t0, int b, int gl) {
+  template <class AT, class VO> DEV void load(const AT &a, int t0, int gl, const VO &vo) {
     SC_OPAQUE(t, bpo, t0);
-    const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
     SC_EACH(M, r) {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) { Ks[r_it][j] = SC_GV(a.Ks, t, M * NX, r * NX + j); Ky[r_it][j] = SC_GV(a.Ky, t, M * NX, r * NX + j); }
-      ks[r_it] = SC_G(a.ks, t, M, r); ky[r_it] = SC_G(a.ky, t, M, r); s[r_it] = SC_G(a.s, t, M, r); y[r_it] = SC_G(a.y, t, M, r);
+      for (int j = 0; j < NX; ++j) { Ks[r_it][j] = SC_LDV(a.Ks, t, M * NX, r * NX + j); Ky[r_it][j] = SC_LDV(a.Ky, t, M * NX, r * NX + j); }
+      ks[r_it] = SC_LD(a.ks, t, M, r); ky[r_it] = SC_LD(a.ky, t, M, r); s[r_it] = SC_LD(a.s, t, M, r); y[r_it] = SC_LD(a.y, t, M, r);
     }
     SC_EACH(NU, i) {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) K[i_it][j] = SC_GV(a.K, t, NU * NX, i * NX + j);
-      k[i_it] = SC_G(a.k, t, NU, i);
+      for (int j = 0; j < NX; ++j) K[i_it][j] = SC_LDV(a.K, t, NU * NX, i * NX + j);
+      k[i_it] = SC_LD(a.k, t, NU, i);
     }
     SC_EACH(NX, i) {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) fx[i_it][j] = SC_GV(a.fx, t, NX * NX, i * NX + j);
+      for (int j = 0; j < NX; ++j) fx[i_it][j] = SC_LDV(a.fx, t, NX * NX, i * NX + j);
 #pragma unroll
-      for (int j = 0; j < NU; ++j) fu[i_it][j] = SC_GV(a.fu, t, NX * NU, i * NU + j);
+      for (int j = 0; j < NU; ++j) fu[i_it][j] = SC_LDV(a.fu, t, NX * NU, i * NU + j);
     }
   }
 };
@@ -603,12 +663,14 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
   const int b = sc_group((int)blockIdx.x) * 4 + tl;
   if (b >= a.B) return;
   double *L = sc_lds + tl * C::STRIDE;
+  typename SCOffFor<NX, NU, M>::type vo;
+  vo.init(gl, b, a.Bp);
   const double mu = a.mu ? a.mu[b] : 0.0;
   double reg = a.reg_in[b];
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
   bool ok = false;
   for (;;) {
-    ok = sweep_coop<NX, NU, M>(a, b, gl, L, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
+    ok = sweep_coop<NX, NU, M>(a, b, gl, vo, L, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
     if (ok || !(a.reg_factor > 1.0)) break;
     reg = reg * a.reg_factor;
     if (!(reg > 0.0)) reg = (a.opt.reg_min_value > 0.0) ? a.opt.reg_min_value : a.reg_max;
@@ -622,16 +684,15 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
     if (ok && a.branch != CDDP_HIP_STACKS_MSIPDDP_PATH) {   // rolloutLinearPolicy from dx0 = 0, dS / dY, computeMaxStepSizes (ipddp_solver.cpp:1511-1532, 2939-2988)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the gains were written through other lanes of this group
       const int N = a.N;
-      const unsigned bp8 = (unsigned)a.Bp * 8u, lane8 = ((unsigned)gl * (unsigned)a.Bp + (unsigned)b) * 8u;
       const double tau = dmax(a.tau_min, 1.0 - mu);
       SC_EACH(NX, i) L[C::oW + i] = 0.0;
       lds_sync();
       const int bpo = a.Bp;
       SCRoll<NX, NU, M> cur, nxt;   // the rows a lane needs at a step do not depend on dx: fetched one step ahead
-      cur.load(a, 0, b, gl);
+      cur.load(a, 0, gl, vo);
       for (int t_ = 0; t_ < N; ++t_) {
-        if (t_ + 1 < N) nxt.load(a, t_ + 1, b, gl);
-        SC_EACH(NX, i) SC_G(a.dX, t_, NX, i) = L[C::oW + i];
+        if (t_ + 1 < N) nxt.load(a, t_ + 1, gl, vo);
+        SC_EACH(NX, i) SC_ST(a.dX, t_, NX, i, L[C::oW + i]);
         SC_EACH(M, r) {
           double p = 0.0, q = 0.0;
 #pragma unroll
@@ -662,7 +723,7 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
         lds_sync();
         cur = nxt;
       }
-      SC_EACH(NX, i) SC_G(a.dX, N, NX, i) = L[C::oW + i];
+      SC_EACH(NX, i) SC_ST(a.dX, N, NX, i, L[C::oW + i]);
       L[C::oRed + gl] = apr; L[C::oRed + 16 + gl] = adu;
       lds_sync();
 #pragma unroll
