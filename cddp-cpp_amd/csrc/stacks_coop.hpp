@@ -62,10 +62,7 @@ struct SCOff {
     for (int k = 0; k < KMAX; ++k) { v[k] = ((unsigned)(k * 16 + gl) * (unsigned)Bp + (unsigned)b) * 8u; asm volatile("" : "+v"(v[k])); }
   }
 };
-template <int NX, int NU, int M> struct SCOffFor {
-  static constexpr int MMx = (M > 0 ? M : 1) * NX, E = NX * NX > MMx ? NX * NX : MMx;
-  typedef SCOff<(E + 15) / 16> type;
-};
+template <int NX, int NU, int M> struct SCOffFor { typedef SCOff<1> type; };
 // One buffer resource per (stack, step): base = stack + t E Bp in an SGPR quad, no stride, no range to speak of; every access is then ONE
 // instruction, buffer_load / buffer_store dwordx2 v, v_off, s[rsrc], s_off offen.  (global_load with a 64-bit SGPR base + 32-bit VGPR
 // offset would do as well, but the zero-extension of the loop-invariant offsets is hoisted out of the step loop and the instruction
@@ -79,13 +76,17 @@ DEV __amdgpu_buffer_rsrc_t sc_rsrc(const double *base, int t, int E, int Bp) {
 DEV double sc_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 DEV void sc_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sc_u32x2, x), r, voff, soff, 0); }
 // element e of an SC_EACH(E, e) loop
-#define SC_LD(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[e##_it], 0u)
-#define SC_ST(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[e##_it], 0u, (x))
+// (the lane offset of element 0 in the VGPR offset, the sixteen-element stride e_it * 16 Bp 8 in the instruction's SCALAR offset: one offset
+//  register for the whole kernel -- a table of per-e_it offsets was 9 - 13 more, and at nx >= 13 they were spilled and came back through
+//  scratch loads whose vmcnt(0) waits serialised the prefetch stream)
+#define SC_LD(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(e##_it * 128) * (unsigned)bpo)
+#define SC_ST(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(e##_it * 128) * (unsigned)bpo, (x))
 // element eu + gl, eu uniform (a column owner walking rows): the uniform part rides in the scalar offset
 #define SC_LDU(stack, t, E, eu) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8)
 #define SC_STU(stack, t, E, eu, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8, (x))
 // an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): per-lane 32-bit offset e * Bp + b
 #define SC_LDV(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), (unsigned)(e) * vo.bp8 + vo.b8, 0u)
+#define SC_STV(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), (unsigned)(e) * vo.bp8 + vo.b8, 0u, (x))
 // The step index and the batch pitch are laundered through an empty asm once per step: otherwise the optimiser turns every access into
 // its own loop-carried 64-bit induction variable (~70 SGPR pairs, spilled to VGPR lanes: 628 v_readlane / v_writelane in the step
 // loop); laundered, the address arithmetic stays inside the step on the otherwise idle scalar unit.
@@ -121,34 +122,49 @@ struct SCRec {
   static constexpr int MM = M > 0 ? M : 1;
   double A[cdiv(NX * NX)], Bm[cdiv(NX * NU)], lx[cdiv(NX)], lu[cdiv(NU)], lxx[cdiv(NX * NX)], luu[cdiv(NU * NU)], lux[cdiv(NU * NX)];
   double y[cdiv(MM)], s[cdiv(MM)], g[cdiv(MM)], Gx[cdiv(MM * NX)], Gu[cdiv(MM * NU)];
-  template <class AT, class VO> DEV void fetch(const AT &a, int t0, int gl, const VO &vo) {
+  // Three groups, each fetched where the step's arithmetic hides its issue and parked as soon as the LDS areas it lands in are dead (round 6):
+  // A (f_x, f_u: dead after the Q blocks), C (y, s, g, G_x, G_u: dead after the condensation), Q (l_x .. l_ux: dead after V_n).  Fetched as ONE
+  // record at the top of the step, its 36 (nx = 12) to 69 (nx = 14) doubles per lane sat in registers through every product of the step.
+  template <class AT, class VO> DEV void fetchA(const AT &a, int t0, int gl, const VO &vo) {
     SC_OPAQUE(t, bpo, t0);
     SC_EACH(NX * NX, e) A[e_it] = SC_LD(a.fx, t, NX * NX, e);
     SC_EACH(NX * NU, e) Bm[e_it] = SC_LD(a.fu, t, NX * NU, e);
-    SC_EACH(NX, e) lx[e_it] = SC_LD(a.lx, t, NX, e);
-    SC_EACH(NU, e) lu[e_it] = SC_LD(a.lu, t, NU, e);
-    SC_EACH(NX * NX, e) lxx[e_it] = SC_LD(a.lxx, t, NX * NX, e);
-    SC_EACH(NU * NU, e) luu[e_it] = SC_LD(a.luu, t, NU * NU, e);
-    SC_EACH(NU * NX, e) lux[e_it] = SC_LD(a.lux, t, NU * NX, e);
+  }
+  template <class AT, class VO> DEV void fetchC(const AT &a, int t0, int gl, const VO &vo) {
     if constexpr (M > 0) {
+      SC_OPAQUE(t, bpo, t0);
       SC_EACH(M, e) { y[e_it] = SC_LD(a.y, t, M, e); s[e_it] = SC_LD(a.s, t, M, e); g[e_it] = SC_LD(a.g, t, M, e); }
       SC_EACH(M * NX, e) Gx[e_it] = SC_LD(a.Gx, t, M * NX, e);
       SC_EACH(M * NU, e) Gu[e_it] = SC_LD(a.Gu, t, M * NU, e);
     }
   }
-  DEV void park(double *__restrict__ L, int gl) const {
+  template <class AT, class VO> DEV void fetchQ(const AT &a, int t0, int gl, const VO &vo) {
+    SC_OPAQUE(t, bpo, t0);
+    SC_EACH(NX, e) lx[e_it] = SC_LD(a.lx, t, NX, e);
+    SC_EACH(NU, e) lu[e_it] = SC_LD(a.lu, t, NU, e);
+    SC_EACH(NX * NX, e) lxx[e_it] = SC_LD(a.lxx, t, NX * NX, e);
+    SC_EACH(NU * NU, e) luu[e_it] = SC_LD(a.luu, t, NU * NU, e);
+    SC_EACH(NU * NX, e) lux[e_it] = SC_LD(a.lux, t, NU * NX, e);
+  }
+  template <class AT, class VO> DEV void fetch(const AT &a, int t0, int gl, const VO &vo) { fetchA(a, t0, gl, vo); fetchC(a, t0, gl, vo); fetchQ(a, t0, gl, vo); }
+  DEV void park(double *__restrict__ L, int gl) const { parkA(L, gl); parkC(L, gl); parkQ(L, gl); }
+  DEV void parkA(double *__restrict__ L, int gl) const {
     SC_EACH(NX * NX, e) L[C::oA + e] = A[e_it];
     SC_EACH(NX * NU, e) L[C::oB + e] = Bm[e_it];
-    SC_EACH(NX, e) L[C::oQx + e] = lx[e_it];
-    SC_EACH(NU, e) L[C::oQu + e] = lu[e_it];
-    SC_EACH(NX * NX, e) L[C::oQxx + e] = lxx[e_it];
-    SC_EACH(NU * NU, e) L[C::oQuu + e] = luu[e_it];
-    SC_EACH(NU * NX, e) L[C::oQux + e] = lux[e_it];
+  }
+  DEV void parkC(double *__restrict__ L, int gl) const {
     if constexpr (M > 0) {
       SC_EACH(M, e) { L[C::oY + e] = y[e_it]; L[C::oS + e] = s[e_it]; L[C::oGg + e] = g[e_it]; }
       SC_EACH(M * NX, e) L[C::oGx + e] = Gx[e_it];
       SC_EACH(M * NU, e) L[C::oGu + e] = Gu[e_it];
     }
+  }
+  DEV void parkQ(double *__restrict__ L, int gl) const {
+    SC_EACH(NX, e) L[C::oQx + e] = lx[e_it];
+    SC_EACH(NU, e) L[C::oQu + e] = lu[e_it];
+    SC_EACH(NX * NX, e) L[C::oQxx + e] = lxx[e_it];
+    SC_EACH(NU * NU, e) L[C::oQuu + e] = luu[e_it];
+    SC_EACH(NU * NX, e) L[C::oQux + e] = lux[e_it];
   }
 };
 
@@ -193,14 +209,117 @@ DEV void sc_rows(const double *__restrict__ L, const double (&v)[K], Addr addr, 
   sc_rows_t<R, K>(L, addr, [&](int k, double x) { return x * v[k]; }, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- register-tiled products
+// Round 6.  A wavefront that is alone on its SIMD pays every LDS round trip in full, and the compiler cannot move an LDS read above an
+// LDS write through the same pointer: a section written "for each output: read operands, reduce, write" is one exposed round trip per
+// output (the step loop carried ~490 s_waitcnt; profiles/r06_stackfed_coop.md).  Every section below is therefore "all reads -> registers,
+// arithmetic, all writes", and the matrix products are tiled: the R x CC outputs are cut into BR x BC blocks, one per lane of the group,
+// so that a lane reads (BR + BC) operands per k for BR BC multiply-adds (one column per lane needs 1 + 1 / rows reads per multiply-add
+// and leaves 16 - CC lanes idle).  Each output element is still ONE sequential sum over k ascending from 0.0 of the same products.
+#ifndef SC_V1_NX
+#define SC_V1_NX 13   // state sizes from here on keep the column-per-lane step (sweep_coop_v1)
+#endif
+#ifndef SC_MM_BUDGET
+#define SC_MM_BUDGET 24   // doubles of operands per chunk of a tiled product (two chunks in flight)
+#endif
+constexpr int sc_tile_pick(int R, int CC, bool tall) {   // BR * 256 + BC: fewest outputs per lane with at most sixteen blocks, then the fewest operand reads
+  int best = 256 * R + CC, bestArea = 1 << 30, bestSum = 1 << 30;
+  for (int br = 1; br <= R; ++br)
+    for (int bc = 1; bc <= CC; ++bc) {
+      if (((R + br - 1) / br) * ((CC + bc - 1) / bc) > 16) continue;
+      const int area = br * bc, sum = br + bc;
+      const bool better = area < bestArea || (area == bestArea && (sum < bestSum || (sum == bestSum && tall && br > bc)));
+      if (better) { best = br * 256 + bc; bestArea = area; bestSum = sum; }
+    }
+  return best;
+}
+template <int R, int CC, bool TALL = false>
+struct SCTile {
+  static constexpr int pk = sc_tile_pick(R, CC, TALL), BR = pk >> 8, BC = pk & 255, NBR = (R + BR - 1) / BR, NBC = (CC + BC - 1) / BC;
+  static constexpr bool kAll = NBR * NBC == 16;
+  int ri[BR], cj[BC];   // LDS operand indices (clamped into the matrix: a lane past the edge reads a valid element and writes nothing)
+  bool vr[BR], vc[BC];
+  DEV void init(int gl) {
+    const int bi0 = gl / NBC, bj = gl - bi0 * NBC;
+    const bool act = kAll || bi0 < NBR;
+    const int bi = kAll ? bi0 : (bi0 < NBR ? bi0 : NBR - 1);
+#pragma unroll
+    for (int r = 0; r < BR; ++r) { const int i = bi * BR + r; vr[r] = act && ((R % BR) == 0 || i < R); ri[r] = ((R % BR) == 0 || i < R) ? i : R - 1; }
+#pragma unroll
+    for (int q = 0; q < BC; ++q) { const int c = bj * BC + q; vc[q] = (CC % BC) == 0 || c < CC; cj[q] = ((CC % BC) == 0 || c < CC) ? c : CC - 1; }
+  }
+};
+struct SCNoMid { DEV int operator()(int) const { return 0; } };
+// out(i, c, sum_{k < K} lhs(i, k) [* mid(k)] * rhs(k, c), pre(i, c)) for the lane's block; lhs / rhs / mid give LDS indices, pre(i, c) a value that
+// is read BEFORE anything is written (the old value of an updated entry, ...), out does the writes
+template <int R, int CC, int K, bool MID, bool TALL = false, class LA, class RA, class MA, class Pre, class Out>
+DEV void sc_mm(const double *__restrict__ L, const int gl, LA lhs, RA rhs, MA mid, Pre pre, Out out) {
+  typedef SCTile<R, CC, TALL> T;
+  constexpr int BR = T::BR, BC = T::BC;
+  constexpr int KC0 = SC_MM_BUDGET / (BR + BC + (MID ? 1 : 0)), KC = KC0 < 1 ? 1 : (KC0 > K ? K : KC0), NCH = (K + KC - 1) / KC;
+  T tl; tl.init(gl);
+  decltype(pre(0, 0)) pv[BR][BC];
+  double acc[BR][BC];
+#pragma unroll
+  for (int r = 0; r < BR; ++r)
+#pragma unroll
+    for (int q = 0; q < BC; ++q) { pv[r][q] = pre(tl.ri[r], tl.cj[q]); acc[r][q] = 0.0; }
+  struct Chunk { double a[KC][BR], b[KC][BC], m[KC]; };
+  auto ldc = [&](const int ch, Chunk &c) {
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = ch * KC + kk;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) c.a[kk][r] = L[lhs(tl.ri[r], k)];
+#pragma unroll
+        for (int q = 0; q < BC; ++q) c.b[kk][q] = L[rhs(k, tl.cj[q])];
+        if (MID) c.m[kk] = L[mid(k)];
+      }
+    }
+  };
+  auto cmp = [&](const int ch, const Chunk &c) {
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = ch * KC + kk;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+          const double am = MID ? c.a[kk][r] * c.m[kk] : c.a[kk][r];
+#pragma unroll
+          for (int q = 0; q < BC; ++q) acc[r][q] += am * c.b[kk][q];
+        }
+      }
+    }
+  };
+  Chunk c0, c1;
+  ldc(0, c0);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) { if ((ch & 1) == 0) ldc(ch + 1, c1); else ldc(ch + 1, c0); }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((ch & 1) == 0) cmp(ch, c0); else cmp(ch, c1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < BR; ++r)
+#pragma unroll
+    for (int q = 0; q < BC; ++q)
+      if (tl.vr[r] && tl.vc[q]) out(tl.ri[r], tl.cj[q], acc[r][q], pv[r][q]);
+}
+
 #ifdef SC_TIMING   // experiment: cycles per section of the step loop, summed over the sweep, per workgroup (profiles/scripts/sc_times.py)
 __device__ unsigned long long g_sc_times[4096 * 16];
 #define SC_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); tk_acc[k] += now_ - tk_last; tk_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SC_TICK(k) do { } while (0)
 #endif
+// =====================================================================================================================================
+// The step as rounds 3 - 5 wrote it (one column of a product per lane, operands double-buffered two rows at a time), kept for nx >= 13: the
+// tiled step below needs more registers than a wavefront has there (nx = 14, nu = 7, m = 14: ~210 scratch accesses per step, 13 -> 27 ms
+// per sweep; profiles/r06_stackfed_coop.md), and at nx = 13 the two measure alike.  Same arithmetic, same addressing macros.
 template <int NX, int NU, int M>
-DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl, const typename SCOffFor<NX, NU, M>::type &vo, double *__restrict__ L, const double reg,
+DEV bool sweep_coop_v1(const StackArgs &a0, const int b, const int gl, const typename SCOffFor<NX, NU, M>::type &vo, double *__restrict__ L, const double reg,
                     const double mu, double &dV0, double &dV1, double &inf_du, double &inf_pr, double &inf_comp, double &step_norm) {
   typedef SCfg<NX, NU, M> C;
   const StackArgs &a = a0;
@@ -626,6 +745,483 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl, const typena
   return true;
 }
 
+
+template <int NX, int NU, int M>
+DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typename SCOffFor<NX, NU, M>::type &vo, double *__restrict__ L, const double reg,
+                    const double mu, double &dV0, double &dV1, double &inf_du, double &inf_pr, double &inf_comp, double &step_norm) {
+  typedef SCfg<NX, NU, M> C;
+  const StackArgs &a = a0;
+  const int gl = gl0;
+  const int N = a.N, bpo = a.Bp;
+  // (a handle with path rows only takes the two path branches, stacks.hip: compile-time there, so that the value update carries one form)
+  const bool lg = M > 0 ? false : a.branch == CDDP_HIP_STACKS_LOGDDP;
+  const bool msp = a.branch == CDDP_HIP_STACKS_MSIPDDP_PATH;
+  const bool ms = a.branch == CDDP_HIP_STACKS_MSIPDDP || msp;
+  const bool ip = M > 0 ? true : (a.branch != CDDP_HIP_STACKS_CLDDP && !lg);
+  SC_EACH(NX, i) L[C::oVx + i] = a.VxN[(size_t)i * a.Bp + b];
+  if (ip || lg) {
+    SC_LOOP(NX * NX, e) {
+      const int i = e / NX, c = e - i * NX;
+      L[C::oVxx + e] = 0.5 * (a.VxxN[(size_t)(i * NX + c) * a.Bp + b] + a.VxxN[(size_t)(c * NX + i) * a.Bp + b]);
+    }
+  } else {
+    SC_LOOP(NX * NX, e) L[C::oVxx + e] = a.VxxN[(size_t)e * a.Bp + b];
+  }
+  lds_sync();
+  SC_EACH(NX, i) SC_ST(a.Vx, N, NX, i, L[C::oVx + i]);
+  SC_EACH(NX * NX, e) SC_ST(a.Vxx, N, NX * NX, e, L[C::oVxx + e]);
+  dV0 = dV1 = 0.0; inf_du = inf_pr = inf_comp = step_norm = 0.0;
+  double norm_Vx = 0.0;
+  if (!ip && !lg) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
+  }
+#ifndef SC_SPLIT_NX
+#define SC_SPLIT_NX 13   // from this state size on, the step record is fetched and parked in three groups (SCRec)
+#endif
+  constexpr bool kSplit = NX >= SC_SPLIT_NX;
+  SCRec<NX, NU, M> rec;
+  rec.fetchA(a, N - 1, gl, vo); rec.fetchC(a, N - 1, gl, vo); rec.fetchQ(a, N - 1, gl, vo);
+  rec.parkA(L, gl); rec.parkC(L, gl); rec.parkQ(L, gl);
+#ifdef SC_TIMING
+  unsigned long long tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = __builtin_readcyclecounter();
+  const unsigned long long tk_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: slots 12 / 13 = start / end of the sweep, 14 = HW_ID | XCC_ID << 32
+#endif
+  const bool have_Fxx = a0.Fxx != nullptr;
+  for (int t_ = N - 1; t_ >= 0; --t_) {
+    SC_OPAQUE(t, bpo, t_);
+    // The ~45 stack pointers of the argument block do not fit the scalar registers next to the step's buffer resources: kept across
+    // the loop they were parked in VGPR lanes and came back through ~390 v_readlane per step.  Read through a pointer the optimiser
+    // cannot see through, they are re-fetched from the kernel-argument segment (scalar cache) where a step needs them.
+    sc_kargs_t kp = (sc_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const auto &a = *kp;
+    // everything that hangs on the lane index (element and block indices, LDS addresses) is re-derived per step from an opaque copy:
+    // as loop invariants they were hoisted out of the step loop and held well over a hundred registers across it
+    int gl = gl0;
+    asm volatile("" : "+v"(gl));
+    // (the range is what turns "element e_it * 16 + gl exists" into a compile-time fact for all but the last e_it; only where it pays: with it
+    //  the nx = 4 / m = 2 and nx = 3 / m = 5 instantiations of the cross-check shapes stop in the backend, "illegal VGPR to SGPR copy", ROCm 7.2)
+    if constexpr (NX >= 12) gl &= 15;
+    const int glt = gl;
+    SC_TICK(15);
+    // (the step's record is in LDS: parked group by group during the previous step, by the prologue for the first one)
+    // w = V_x, or V_x + V_xx d_t under multiple shooting (V of step t + 1 is already in LDS)
+    if (ms) {
+      SC_EACH(NX, i) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s1 += L[C::oVxx + i * NX + k] * SC_LDV(a.dfc, t, NX, k);
+        L[C::oW + i] = L[C::oVx + i] + s1;
+      }
+    } else {
+      SC_EACH(NX, i) L[C::oW + i] = L[C::oVx + i];
+    }
+    lds_sync();
+    SC_TICK(0);
+    if (t > 0) { rec.fetchA(a, t - 1, gl, vo); if (!kSplit) { rec.fetchC(a, t - 1, gl, vo); rec.fetchQ(a, t - 1, gl, vo); } }
+    // ---------------------------------------------------------------- Q_x, Q_u, T1 = A^T V_xx, T2 = B^T V_xx
+    {
+      double qx[(NX + 15) / 16], qu[(NU + 15) / 16];
+      SC_EACH(NX, i) {
+        double q = L[C::oQx + i];
+        if constexpr (M > 0) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += L[C::oGx + r * NX + i] * L[C::oY + r];
+          q = q + s1;
+        }
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += L[C::oA + k * NX + i] * L[C::oW + k];
+        qx[i_it] = q + s2;
+      }
+      SC_EACH(NU, i) {
+        double q = L[C::oQu + i];
+        if constexpr (M > 0) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += L[C::oGu + r * NU + i] * L[C::oY + r];
+          q = q + s1;
+        }
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s2 += L[C::oB + k * NU + i] * L[C::oW + k];
+        qu[i_it] = q + s2;
+      }
+      SC_EACH(NX, i) L[C::oQx + i] = qx[i_it];
+      SC_EACH(NU, i) L[C::oQu + i] = qu[i_it];
+    }
+    SC_TICK(1);
+    sc_mm<NX, NX, NX, false>(L, glt, [](int i, int k) { return C::oA + k * NX + i; }, [](int k, int c) { return C::oVxx + k * NX + c; }, SCNoMid(),
+                             [](int, int) { return 0.0; }, [&](int i, int c, double s1, double) { L[C::oT1 + i * NX + c] = s1; });
+    sc_mm<NU, NX, NX, false>(L, glt, [](int i, int k) { return C::oB + k * NU + i; }, [](int k, int c) { return C::oVxx + k * NX + c; }, SCNoMid(),
+                             [](int, int) { return 0.0; }, [&](int i, int c, double s1, double) { L[C::oT2 + i * NX + c] = s1; });
+    lds_sync();
+    SC_TICK(2);
+    // ---------------------------------------------------------------- Q_xx += T1 A, Q_ux += T2 A, Q_uu += T2 B (+ tensor terms)
+    sc_mm<NX, NX, NX, false>(L, glt, [](int i, int k) { return C::oT1 + i * NX + k; }, [](int k, int c) { return C::oA + k * NX + c; }, SCNoMid(),
+                             [&](int i, int c) { return L[C::oQxx + i * NX + c]; }, [&](int i, int c, double s1, double old) { L[C::oQxx + i * NX + c] = old + s1; });
+    sc_mm<NU, NX, NX, false>(L, glt, [](int i, int k) { return C::oT2 + i * NX + k; }, [](int k, int c) { return C::oA + k * NX + c; }, SCNoMid(),
+                             [&](int i, int c) { return L[C::oQux + i * NX + c]; }, [&](int i, int c, double s1, double old) { L[C::oQux + i * NX + c] = old + s1; });
+    sc_mm<NU, NU, NX, false>(L, glt, [](int i, int k) { return C::oT2 + i * NX + k; }, [](int k, int c) { return C::oB + k * NU + c; }, SCNoMid(),
+                             [&](int i, int c) { return L[C::oQuu + i * NU + c]; }, [&](int i, int c, double s1, double old) { L[C::oQuu + i * NU + c] = old + s1; });
+    if (have_Fxx) {   // second-order dynamics terms (use_ilqr = false), added to the finished sums in the same order; rolled: a cold path that must not shape the step's register allocation
+      lds_sync();
+      const __amdgpu_buffer_rsrc_t rFxx = sc_rsrc(a.Fxx, t, NX * NX * NX, bpo), rFux = sc_rsrc(a.Fux, t, NX * NU * NX, bpo), rFuu = sc_rsrc(a.Fuu, t, NX * NU * NU, bpo);
+#pragma nounroll
+      for (int e = gl; e < NX * NX; e += 16) {
+        double q = L[C::oQxx + e];
+#pragma nounroll
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFxx, (unsigned)(j * NX * NX + e) * vo.bp8 + vo.b8, 0u);
+        L[C::oQxx + e] = q;
+      }
+#pragma nounroll
+      for (int e = gl; e < NU * NX; e += 16) {
+        double q = L[C::oQux + e];
+#pragma nounroll
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFux, (unsigned)(j * NU * NX + e) * vo.bp8 + vo.b8, 0u);
+        L[C::oQux + e] = q;
+      }
+#pragma nounroll
+      for (int e = gl; e < NU * NU; e += 16) {
+        double q = L[C::oQuu + e];
+#pragma nounroll
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFuu, (unsigned)(j * NU * NU + e) * vo.bp8 + vo.b8, 0u);
+        L[C::oQuu + e] = q;
+      }
+    }
+    lds_sync();
+    if (kSplit && t > 0) { rec.parkA(L, gl); rec.fetchC(a, t - 1, gl, vo); }
+    SC_TICK(3);
+    // ---------------------------------------------------------------- gains
+    double kk[NU];
+    if constexpr (M > 0) {
+      const double s_floor = dmax(mu * 1e-3, kEpsSlackS);
+      SC_EACH(M, r) {
+        const double y = L[C::oY + r], s = L[C::oS + r], g = L[C::oGg + r];
+        const double ssafe = msp ? s : dmax(s, s_floor);
+        const double rp = g + s;
+        const double rc = y * s - mu;
+        const double rhat = y * rp - rc;
+        L[C::oSs + r] = ssafe; L[C::oYS + r] = msp ? y / s : clipp(y, ssafe); L[C::oRp + r] = rp; L[C::oRhat + r] = rhat;
+        L[C::oSir + r] = msp ? rhat / s : clips(rhat, ssafe);
+        inf_pr = dmax(inf_pr, fabs(rp)); inf_comp = dmax(inf_comp, fabs(rc));
+      }
+      lds_sync();
+      {   // R_u first (registers), then the two products; nothing below reads what they write
+        double ru[(NU + 15) / 16];
+        SC_EACH(NU, i) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += L[C::oGu + r * NU + i] * L[C::oSir + r];
+          ru[i_it] = L[C::oQu + i] + s1;
+        }
+        SC_EACH(NU, i) L[C::oRu + i] = ru[i_it];
+      }
+      sc_mm<NU, NU, M, true>(L, glt, [](int i, int r) { return C::oGu + r * NU + i; }, [](int r, int c) { return C::oGu + r * NU + c; },
+                             [](int r) { return C::oYS + r; }, [&](int i, int c) { return 0.5 * (L[C::oQuu + i * NU + c] + L[C::oQuu + c * NU + i]); },
+                             [&](int i, int c, double s1, double sym) {
+        double q = sym + s1;
+        if (i == c) q += reg;
+        L[C::oQr + i * NU + c] = q;
+      });
+      sc_mm<NU, NX, M, true>(L, glt, [](int i, int r) { return C::oGu + r * NU + i; }, [](int r, int c) { return C::oGx + r * NX + c; },
+                             [](int r) { return C::oYS + r; }, [&](int i, int c) { return L[C::oQux + i * NX + c]; },
+                             [&](int i, int c, double s2, double qux) { L[C::oRx + i * NX + c] = qux + s2; });
+      lds_sync();
+      SC_TICK(4);
+      {
+        double Qr[NU * NU], col[NU], colx[(NX + 15) / 16][NU];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Qr[i] = L[C::oQr + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = L[C::oRu + i];
+        SC_EACH(NX, c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) colx[c_it][i] = L[C::oRx + i * NX + c];
+        }
+        SCFactor<NU> f;
+        if (!f.compute(Qr)) return false;
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        SC_EACH(NX, c) f.solve(colx[c_it]);
+        SC_EACH(NX, c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) L[C::oKK + i * NX + c] = -colx[c_it][i];
+        }
+      }
+      lds_sync();
+      SC_TICK(5);
+      // slack / dual direction gains (:1458-1472): global stores only
+      SC_EACH(M, r) {
+        double temp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) temp += L[C::oGu + r * NU + i] * kk[i];
+        SC_ST(a.ky, t, M, r, msp ? (L[C::oRhat + r] + L[C::oY + r] * temp) / L[C::oSs + r] : clips(L[C::oRhat + r] + L[C::oY + r] * temp, L[C::oSs + r]));
+        SC_ST(a.ks, t, M, r, (-L[C::oRp + r]) - temp);
+      }
+      {
+        struct GY { double gx, ys; };
+        const __amdgpu_buffer_rsrc_t rKy = sc_rsrc(a.Ky, t, M * NX, bpo), rKs = sc_rsrc(a.Ks, t, M * NX, bpo);   // (formed outside the lane-dependent write guard)
+        sc_mm<M, NX, NU, false>(L, glt, [](int r, int i) { return C::oGu + r * NU + i; }, [](int i, int c) { return C::oKK + i * NX + c; }, SCNoMid(),
+                                [&](int r, int c) { GY v; v.gx = L[C::oGx + r * NX + c]; v.ys = L[C::oYS + r]; return v; },
+                                [&](int r, int c, double s2, GY v) {
+          const double inner = v.gx + s2;
+          const unsigned off = (unsigned)(r * NX + c) * vo.bp8 + vo.b8;
+          sc_st(rKy, off, 0u, msp ? v.ys * inner : dclamp(v.ys * inner, -kMaxRatioS, kMaxRatioS));
+          sc_st(rKs, off, 0u, (-v.gx) - s2);
+        });
+      }
+      SC_TICK(6);
+      // condensed terms into the Q blocks (:1488-1492)
+      {
+        double qx[(NX + 15) / 16], qu[(NU + 15) / 16];
+        SC_EACH(NX, i) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += L[C::oGx + r * NX + i] * L[C::oSir + r];
+          qx[i_it] = L[C::oQx + i] + s1;
+        }
+        SC_EACH(NU, i) qu[i_it] = L[C::oRu + i];
+        SC_EACH(NX, i) L[C::oQx + i] = qx[i_it];
+        SC_EACH(NU, i) L[C::oQu + i] = qu[i_it];
+      }
+      sc_mm<NX, NX, M, true>(L, glt, [](int i, int r) { return C::oGx + r * NX + i; }, [](int r, int c) { return C::oGx + r * NX + c; },
+                             [](int r) { return C::oYS + r; }, [&](int i, int c) { return L[C::oQxx + i * NX + c]; },
+                             [&](int i, int c, double s1, double old) { L[C::oQxx + i * NX + c] = old + s1; });
+      sc_mm<NU, NU, M, true>(L, glt, [](int i, int r) { return C::oGu + r * NU + i; }, [](int r, int c) { return C::oGu + r * NU + c; },
+                             [](int r) { return C::oYS + r; }, [&](int i, int c) { return L[C::oQuu + i * NU + c]; },
+                             [&](int i, int c, double s1, double old) { L[C::oQuu + i * NU + c] = old + s1; });
+      if (msp) {   // msipddp_solver.cpp:1398 (see stacks.hip::sweep)
+        double qn[(NU * NX + 15) / 16];
+        SC_EACH(NU * NX, e) {
+          const int i = e / NX, c = e - i * NX;
+          const int pi = (NU == 1) ? c : i, pc = (NU == 1) ? 0 : c;
+          double s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < M; ++r) s1 += (L[C::oGx + r * NX + pi] * L[C::oYS + r]) * L[C::oGu + r * NU + (pc < NU ? pc : 0)];
+          qn[e_it] = L[C::oQux + e] + s1;
+        }
+        SC_EACH(NU * NX, e) L[C::oQux + e] = qn[e_it];
+      } else {
+        double rx[(NU * NX + 15) / 16];
+        SC_EACH(NU * NX, e) rx[e_it] = L[C::oRx + e];
+        SC_EACH(NU * NX, e) L[C::oQux + e] = rx[e_it];
+      }
+    } else if (ip || lg) {
+      // IPDDP: Q_uu = sym(Q_uu) + reg I, kept (:1084-1101).  LogDDP: factor sym(Q_uu + reg I), Q_uu itself untouched (:524-548)
+      double qs[(NU * NU + 15) / 16];
+      SC_EACH(NU * NU, e) {
+        const int i = e / NU, c = e - i * NU;
+        double p = L[C::oQuu + i * NU + c], q = L[C::oQuu + c * NU + i];
+        if (lg) { if (i == c) { p += reg; q += reg; } qs[e_it] = 0.5 * (p + q); }
+        else { double v = 0.5 * (p + q); if (i == c) v += reg; qs[e_it] = v; }
+      }
+      lds_sync();
+      const bool caching = ms && !lg && a.QuuF != nullptr;   // MSIPDDP's per-step factor cache (msipddp_solver.cpp:1169-1185)
+      const bool cached = caching && a.fvalid[(size_t)t * a.Bp + b] != 0;
+      SC_EACH(NU * NU, e) {
+        if (!lg) L[C::oQuu + e] = qs[e_it];
+        L[C::oQr + e] = cached ? SC_LD(a.QuuF, t, NU * NU, e) : qs[e_it];
+      }
+      lds_sync();
+      {
+        double Qr[NU * NU];
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Qr[i] = L[C::oQr + i];
+        SCFactor<NU> f;
+        if (!f.compute(Qr)) { if (caching && gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 0; return false; }
+        if (caching && !cached) {
+          SC_EACH(NU * NU, e) SC_ST(a.QuuF, t, NU * NU, e, L[C::oQr + e]);
+          if (gl == 0) a.fvalid[(size_t)t * a.Bp + b] = 1;
+        }
+        double col[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) col[i] = L[C::oQu + i];
+        f.solve(col);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kk[i] = -col[i];
+        SC_EACH(NX, c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) col[i] = L[C::oQux + i * NX + c];
+          f.solve(col);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) L[C::oKK + i * NX + c] = -col[i];
+        }
+      }
+    } else {
+      // CLDDP: PD test on Q_uu + reg I, BoxQP or dense inverse (clddp_solver.cpp:130-178); every lane of the group repeats it
+      double Qr[NU * NU], Qu[NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Qr[i] = L[C::oQuu + i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { Qr[i * NU + i] += reg; Qu[i] = L[C::oQu + i]; }
+      if (min_real_eig<NU>(Qr) <= 0) return false;
+      if (a.lo) {
+        double lb[NU], ub[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const double ut = SC_LDV(a.U, t, NU, i); lb[i] = a.lo[i] - ut; ub[i] = a.up[i] - ut; kk[i] = SC_LDV(a.k, t, NU, i); }
+        int free_[NU];
+        LDLTd<NU> Hfree;
+        const int stq = boxqp_solve<NU>(a0.opt, Qr, Qu, lb, ub, kk, free_, Hfree);
+        if (stq == BQ_HESSIAN_NOT_PD || stq == BQ_NO_DESCENT) return false;
+        int free_idx[NU]; int nf = 0;
+        for (int i = 0; i < NU; ++i) if (free_[i]) free_idx[nf++] = i;
+        SC_EACH(NX, c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) L[C::oKK + i * NX + c] = 0.0;
+          if (nf > 0) {
+            double col[NU];
+            for (int i = 0; i < nf; ++i) col[i] = L[C::oQux + free_idx[i] * NX + c];
+            Hfree.solve(col);
+            for (int i = 0; i < nf; ++i) L[C::oKK + free_idx[i] * NX + c] = -col[i];
+          }
+        }
+      } else {
+        double H[NU * NU];
+        inverse_pplu<NU>(Qr, H);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          double s1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) s1 += (-H[i * NU + j]) * Qu[j];
+          kk[i] = s1;
+        }
+        SC_EACH(NX, c) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) s2 += (-H[i * NU + j]) * L[C::oQux + j * NX + c];
+            L[C::oKK + i * NX + c] = s2;
+          }
+        }
+      }
+    }
+    lds_sync();
+    if (kSplit && t > 0) { rec.parkC(L, gl); rec.fetchQ(a, t - 1, gl, vo); }
+    SC_TICK(7);
+    SC_EACH(NU, i) SC_ST(a.k, t, NU, i, kk[i]);
+    SC_EACH(NU * NX, e) SC_ST(a.K, t, NU * NX, e, L[C::oKK + e]);
+    {   // expected-decrease terms: the scalar chain every lane repeats
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) q += L[C::oQuu + i * NU + j] * kk[j];
+        s0 += L[C::oQu + i] * kk[i]; s1 += kk[i] * q;
+      }
+      dV0 += s0; dV1 += 0.5 * s1;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) { inf_du = dmax(inf_du, fabs(L[C::oQu + i])); step_norm = dmax(step_norm, fabs(kk[i])); }
+    }
+    // K^T Q_uu
+    sc_mm<NX, NU, NU, false>(L, glt, [](int i, int k) { return C::oKK + k * NX + i; }, [](int k, int j) { return C::oQuu + k * NU + j; }, SCNoMid(),
+                             [](int, int) { return 0.0; }, [&](int i, int j, double s1, double) { L[C::oKtQ + i * NU + j] = s1; });
+    lds_sync();
+    SC_TICK(8);
+    // ---------------------------------------------------------------- value update
+    double vxn[(NX + 15) / 16];
+    SC_EACH(NX, i) {
+      double p = 0.0, q = 0.0, r = 0.0;
+      if (ip) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { p += L[C::oKK + j * NX + i] * L[C::oQu + j]; q += L[C::oQux + j * NX + i] * kk[j]; r += L[C::oKtQ + i * NU + j] * kk[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { p += L[C::oKtQ + i * NU + j] * kk[j]; q += L[C::oQux + j * NX + i] * kk[j]; r += L[C::oKK + j * NX + i] * L[C::oQu + j]; }
+      }
+      vxn[i_it] = ((L[C::oQx + i] + p) + q) + r;
+    }
+    {   // V_n(i, c) = ((Q_xx + p) + q) + r, three NU-term sums per entry; the lane's block of entries, rows fetched one ahead
+      typedef SCTile<NX, NX, true> T;
+      constexpr int BR = T::BR, BC = T::BC;
+      T tl; tl.init(glt);
+      double kc[NU][BC], qc[NU][BC], vn[BR][BC];
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int q = 0; q < BC; ++q) { kc[j][q] = L[C::oKK + j * NX + tl.cj[q]]; qc[j][q] = L[C::oQux + j * NX + tl.cj[q]]; }
+      struct Row { double kr[NU], qr[NU], tr[NU], qxx[BC]; };
+      auto ldr = [&](const int r, Row &w) {
+        const int i = tl.ri[r];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { w.kr[j] = L[C::oKK + j * NX + i]; w.qr[j] = L[C::oQux + j * NX + i]; w.tr[j] = L[C::oKtQ + i * NU + j]; }
+#pragma unroll
+        for (int q = 0; q < BC; ++q) w.qxx[q] = L[C::oQxx + i * NX + tl.cj[q]];
+      };
+      auto cmpr = [&](const int r, const Row &w) {
+#pragma unroll
+        for (int c = 0; c < BC; ++c) {
+          double p = 0.0, q = 0.0, rr = 0.0;
+          if (ip) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { p += w.kr[j] * qc[j][c]; q += w.qr[j] * kc[j][c]; rr += w.tr[j] * kc[j][c]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { p += w.tr[j] * kc[j][c]; q += w.qr[j] * kc[j][c]; rr += w.kr[j] * qc[j][c]; }
+          }
+          vn[r][c] = ((w.qxx[c] + p) + q) + rr;
+        }
+      };
+      Row w0, w1;
+      ldr(0, w0);
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        if (r + 1 < BR) { if ((r & 1) == 0) ldr(r + 1, w1); else ldr(r + 1, w0); }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((r & 1) == 0) cmpr(r, w0); else cmpr(r, w1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int c = 0; c < BC; ++c)
+          if (tl.vr[r] && tl.vc[c]) L[C::oVn + tl.ri[r] * NX + tl.cj[c]] = vn[r][c];
+    }
+    SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; SC_ST(a.Vx, t, NX, i, vxn[i_it]); }
+    lds_sync();
+    SC_TICK(9);
+    if (t > 0) { if (!kSplit) { rec.parkA(L, gl); rec.parkC(L, gl); } rec.parkQ(L, gl); }
+    {
+      double vs[(NX * NX + 15) / 16];
+      SC_EACH(NX * NX, e) {
+        const int i = e / NX, c = e - i * NX;
+        vs[e_it] = 0.5 * (L[C::oVn + i * NX + c] + L[C::oVn + c * NX + i]);
+      }
+      SC_EACH(NX * NX, e) { L[C::oVxx + e] = vs[e_it]; SC_ST(a.Vxx, t, NX * NX, e, vs[e_it]); }
+    }
+    if (!ip && !lg) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
+    }
+    lds_sync();
+    SC_TICK(10);
+  }
+#ifdef SC_TIMING
+  tk_acc[12] = tk_rt0; tk_acc[13] = __builtin_amdgcn_s_memrealtime();
+  tk_acc[14] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) for (int k = 0; k < 16; ++k) g_sc_times[blockIdx.x * 16 + k] = tk_acc[k];
+#endif
+  if constexpr (M > 0) {   // the lanes hold partial maxima over their constraint rows
+    L[C::oRed + gl] = inf_pr; L[C::oRed + 16 + gl] = inf_comp;
+    lds_sync();
+    inf_pr = 0.0; inf_comp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { inf_pr = dmax(inf_pr, L[C::oRed + i]); inf_comp = dmax(inf_comp, L[C::oRed + 16 + i]); }
+    lds_sync();
+  }
+  if (!ip && !lg) {
+    double sc = a.tau_min;
+    sc = dmax(sc, norm_Vx / (double)(N * NX)) / sc;
+    inf_du = inf_du / sc;
+  }
+  return true;
+}
+
 // Rows of one step of the linear-policy rollout, per lane: constraint row r = lane (K_s, K_y, k_s, k_y, s, y), control row i = lane
 // (K, k), state row i = lane (A, B).
 template <int NX, int NU, int M>
@@ -670,7 +1266,8 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
   bool ok = false;
   for (;;) {
-    ok = sweep_coop<NX, NU, M>(a, b, gl, vo, L, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
+    if constexpr (NX >= SC_V1_NX) ok = sweep_coop_v1<NX, NU, M>(a, b, gl, vo, L, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
+    else ok = sweep_coop<NX, NU, M>(a, b, gl, vo, L, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
     if (ok || !(a.reg_factor > 1.0)) break;
     reg = reg * a.reg_factor;
     if (!(reg > 0.0)) reg = (a.opt.reg_min_value > 0.0) ? a.opt.reg_min_value : a.reg_max;

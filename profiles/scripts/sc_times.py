@@ -38,4 +38,14 @@ for i, nme in enumerate(names):
     v = np.median(t[:, i]) / N; tot += v
     print("  %-28s %9.1f" % (nme, v))
 print("  %-28s %9.1f  (kernel: %.1f us per step)" % ("sum", tot, ms * 1e3 / N))
+rt0, rt1 = t[:, 12] / 100.0, t[:, 13] / 100.0   # us
+hw = t[:, 14].astype(np.uint64)
+cu = ((hw >> np.uint64(8)) & np.uint64(15)).astype(int); se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(int); sh = ((hw >> np.uint64(12)) & np.uint64(1)).astype(int); xcc = ((hw >> np.uint64(32)) & np.uint64(15)).astype(int)
+simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+t00 = rt0.min()
+print("  workgroup wall time (100 MHz clock): duration median %.1f us, min %.1f, max %.1f; starts: %d within 50 us of the first, latest start %.1f us, last end %.1f us" % (
+    np.median(rt1 - rt0), (rt1 - rt0).min(), (rt1 - rt0).max(), int((rt0 - t00 < 50).sum()), (rt0 - t00).max(), (rt1 - t00).max()))
+key = xcc * 1000 + se * 100 + sh * 16 + cu
+u, cnt = np.unique(key[rt0 - t00 < 50], return_counts=True)
+print("  first-round workgroups per CU: %d CUs used, histogram of workgroups per CU %s; SIMD histogram %s" % (len(u), np.bincount(cnt).tolist(), np.bincount(simd).tolist()))
 hs.close()
