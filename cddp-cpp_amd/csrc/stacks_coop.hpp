@@ -26,10 +26,17 @@ struct SCfg {
   static constexpr int MM = M > 0 ? M : 1;
   enum : int {
     oVxx = 0, oVx = oVxx + NX * NX, oA = oVx + NX, oB = oA + NX * NX, oW = oB + NX * NU, oQx = oW + NX, oQu = oQx + NX,
-    oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oT1 = oQuu + NU * NU, oT2 = oT1 + NX * NX, oKK = oT2 + NU * NX,
-    okk = oKK + NU * NX, oKtQ = okk + NU, oQr = oKtQ + NX * NU, oRu = oQr + NU * NU, oRx = oRu + NU,
-    oY = oRx + NU * NX, oS = oY + MM, oGg = oS + MM, oGx = oGg + MM, oGu = oGx + MM * NX, oYS = oGu + MM * NU, oSir = oYS + MM,
-    oRhat = oSir + MM, oRp = oRhat + MM, oSs = oRp + MM, oRed = oSs + MM, SIZE0 = oRed + 32,
+    oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oT1 = oQuu + NU * NU, oT2 = oT1 + NX * NX, oFree = oT2 + NU * NX,
+    // (round 6) Overlays, by the order a step touches its areas -- T1 = A^T V and T2 = B^T V are dead once the Q blocks exist, f_u once Q_uu
+    // does, R_x before V_n (which also overlays T1) is written, and nothing reads the reduction row inside the sweep:
+    //   gains K in T2, K^T Q_uu in f_u's area, regularised Q_uu / R_u / R_x in T1 (where they fit), the reduction row in Q_xx's area.
+    // 389 doubles less per trajectory at nx = 14, nu = 7, m = 14: three workgroups per CU instead of two.
+    oKK = oT2, oKtQ = oB,
+    kOvl = (NU * NX + NU * NU + NU <= NX * NX) ? 1 : 0,
+    oQr = kOvl ? oT1 : oFree, oRu = oQr + NU * NU, oRx = oRu + NU,
+    oY = kOvl ? oFree : oRx + NU * NX, oS = oY + MM, oGg = oS + MM, oGx = oGg + MM, oGu = oGx + MM * NX, oYS = oGu + MM * NU, oSir = oYS + MM,
+    oRhat = oSir + MM, oRp = oRhat + MM, oSs = oRp + MM, oEnd = oSs + MM,
+    kRedOvl = (NX * NX >= 32) ? 1 : 0, oRed = kRedOvl ? oQxx : oEnd, SIZE0 = kRedOvl ? oEnd : oEnd + 32,
     STRIDE = SIZE0 | 1   // odd: the four trajectories of a wavefront start in different LDS banks
   };
   static constexpr int oVn = oT1;   // V_xx before symmetrisation overlays T1 (dead after the A-products)
@@ -122,9 +129,9 @@ struct SCRec {
   static constexpr int MM = M > 0 ? M : 1;
   double A[cdiv(NX * NX)], Bm[cdiv(NX * NU)], lx[cdiv(NX)], lu[cdiv(NU)], lxx[cdiv(NX * NX)], luu[cdiv(NU * NU)], lux[cdiv(NU * NX)];
   double y[cdiv(MM)], s[cdiv(MM)], g[cdiv(MM)], Gx[cdiv(MM * NX)], Gu[cdiv(MM * NU)];
-  // Three groups, each fetched where the step's arithmetic hides its issue and parked as soon as the LDS areas it lands in are dead (round 6):
-  // A (f_x, f_u: dead after the Q blocks), C (y, s, g, G_x, G_u: dead after the condensation), Q (l_x .. l_ux: dead after V_n).  Fetched as ONE
-  // record at the top of the step, its 36 (nx = 12) to 69 (nx = 14) doubles per lane sat in registers through every product of the step.
+  // (three groups: fetched / parked group by group in the middle of a step -- each behind the last reader of its LDS areas -- was tried to
+  //  shorten the record's register life and measured slower at nx = 12, 28.4 k -> 33.8 k clocks per step: the VMEM issue of a group is
+  //  only hidden behind a long stretch of arithmetic; and it does not combine with K^T Q_uu living in f_u's area)
   template <class AT, class VO> DEV void fetchA(const AT &a, int t0, int gl, const VO &vo) {
     SC_OPAQUE(t, bpo, t0);
     SC_EACH(NX * NX, e) A[e_it] = SC_LD(a.fx, t, NX * NX, e);
@@ -776,13 +783,9 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
 #pragma unroll
     for (int i = 0; i < NX; ++i) norm_Vx += fabs(L[C::oVx + i]);
   }
-#ifndef SC_SPLIT_NX
-#define SC_SPLIT_NX 13   // from this state size on, the step record is fetched and parked in three groups (SCRec)
-#endif
-  constexpr bool kSplit = NX >= SC_SPLIT_NX;
   SCRec<NX, NU, M> rec;
-  rec.fetchA(a, N - 1, gl, vo); rec.fetchC(a, N - 1, gl, vo); rec.fetchQ(a, N - 1, gl, vo);
-  rec.parkA(L, gl); rec.parkC(L, gl); rec.parkQ(L, gl);
+  rec.fetch(a, N - 1, gl, vo);
+  rec.park(L, gl);
 #ifdef SC_TIMING
   unsigned long long tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = __builtin_readcyclecounter();
   const unsigned long long tk_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: slots 12 / 13 = start / end of the sweep, 14 = HW_ID | XCC_ID << 32
@@ -819,7 +822,7 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
     }
     lds_sync();
     SC_TICK(0);
-    if (t > 0) { rec.fetchA(a, t - 1, gl, vo); if (!kSplit) { rec.fetchC(a, t - 1, gl, vo); rec.fetchQ(a, t - 1, gl, vo); } }
+    if (t > 0) rec.fetch(a, t - 1, gl, vo);   // in flight behind this step's arithmetic, parked at its end
     // ---------------------------------------------------------------- Q_x, Q_u, T1 = A^T V_xx, T2 = B^T V_xx
     {
       double qx[(NX + 15) / 16], qu[(NU + 15) / 16];
@@ -892,7 +895,6 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
       }
     }
     lds_sync();
-    if (kSplit && t > 0) { rec.parkA(L, gl); rec.fetchC(a, t - 1, gl, vo); }
     SC_TICK(3);
     // ---------------------------------------------------------------- gains
     double kk[NU];
@@ -1101,7 +1103,6 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
       }
     }
     lds_sync();
-    if (kSplit && t > 0) { rec.parkC(L, gl); rec.fetchQ(a, t - 1, gl, vo); }
     SC_TICK(7);
     SC_EACH(NU, i) SC_ST(a.k, t, NU, i, kk[i]);
     SC_EACH(NU * NX, e) SC_ST(a.K, t, NU * NX, e, L[C::oKK + e]);
@@ -1185,7 +1186,7 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
     SC_EACH(NX, i) { L[C::oVx + i] = vxn[i_it]; SC_ST(a.Vx, t, NX, i, vxn[i_it]); }
     lds_sync();
     SC_TICK(9);
-    if (t > 0) { if (!kSplit) { rec.parkA(L, gl); rec.parkC(L, gl); } rec.parkQ(L, gl); }
+    if (t > 0) rec.park(L, gl);   // every area the record lands in is dead by now (V_n is in T1, the next reads are of V_n only)
     {
       double vs[(NX * NX + 15) / 16];
       SC_EACH(NX * NX, e) {
