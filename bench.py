@@ -458,32 +458,35 @@ def stackfed_bytes(nx, nu, N, m, clddp):
 
 
 # north_star's literal form: "coalesced HBM loads of the (N x batch) stacks of f_x / f_u / l_xx / l_uu / l_ux" -- the stack-fed sweeps of the host
-# plug-in route (cddp_hip_stacks_backward, stacks.hip / stacks_coop.hpp).  (nx, nu, m, N, base batch, label, batch multipliers of the curve)
+# plug-in route (cddp_hip_stacks_backward, stacks.hip / stacks_coop.hpp).  (nx, nu, m, N, label, batches of the curve)
+# The nx >= 12 shapes run sixteen lanes per trajectory, one 4-trajectory workgroup per SIMD: 4096 trajectories fill the chip at nx = 12
+# (four workgroups per CU), 3072 at nx = 14 (three per CU: 51 KB of LDS each); the BASELINE shares (2048, 4096) are on the curve.
 STACKFED_SHAPES = [
-    (4, 1, 2, 100, 4096, "C2 shape", (1, 4, 16, 32)),
-    (3, 2, 5, 200, 8192, "C3 shape", (1, 4, 8)),
-    (12, 4, 8, 400, 2048, "C4-share shape", (1,)),
-    (14, 7, 14, 150, 4096, "C5-share shape", (1,)),
+    (4, 1, 2, 100, "C2 shape", (4096, 16384, 65536, 131072)),
+    (3, 2, 5, 200, "C3 shape", (8192, 32768, 65536)),
+    (12, 4, 8, 400, "C4-share shape", (2048, 4096)),
+    (14, 7, 14, 150, "C5-share shape", (3072, 4096)),
 ]
 # `bench.py --stackfed`: longer curves (tens of GB of stacks for the nx >= 12 shapes: minutes of host-side tiling and upload, not part of the default line)
 STACKFED_SHAPES_FULL = [
-    (4, 1, 2, 100, 4096, "C2 shape", (1, 4, 16, 32, 64)),
-    (3, 2, 5, 200, 8192, "C3 shape", (1, 4, 8, 16)),
-    (12, 4, 8, 400, 2048, "C4-share shape", (1, 2, 4)),
-    (14, 7, 14, 150, 4096, "C5-share shape", (1, 2, 4)),
+    (4, 1, 2, 100, "C2 shape", (4096, 16384, 65536, 131072, 262144)),
+    (3, 2, 5, 200, "C3 shape", (8192, 32768, 65536, 131072)),
+    (12, 4, 8, 400, "C4-share shape", (2048, 4096, 8192)),
+    (14, 7, 14, 150, "C5-share shape", (3072, 4096, 6144, 12288)),
 ]
 
 
 def measure_stackfed(api, device=0, shapes=None, reps=3):
     """One line per (shape, branch): kernel time (hipEvents around the single launch, cddp_hip_stacks_last_kernel_ms, best of `reps`) of the
     stack-fed IPDDP path-row sweep and the CLDDP sweep on random well-conditioned stacks (the arithmetic does not depend on the values), the
-    default sweep form of the shape, with a batch curve up to a chip-filling batch for the small shapes.  The stacks of the larger batches
-    are the base batch tiled (uploaded whole: the sweep reads every row once either way)."""
+    default sweep form of the shape, with a batch curve up to a chip-filling batch.  The stacks of the larger batches
+    are the smallest batch tiled (uploaded whole: the sweep reads every row once either way)."""
     rng = np.random.default_rng(1)
     opt = api.default_options()
     PEAK = 8000.0
     lines = []
-    for (nx, nu, m, N, B0, label, mults) in (shapes or STACKFED_SHAPES):
+    for (nx, nu, m, N, label, batches) in (shapes or STACKFED_SHAPES):
+        B0 = min(batches)
         fx = np.tile(np.eye(nx), (B0, N, 1, 1)) + 0.05 * rng.standard_normal((B0, N, nx, nx)); fu = 0.1 * rng.standard_normal((B0, N, nx, nu))
         lx = rng.standard_normal((B0, N, nx)); lu = rng.standard_normal((B0, N, nu))
         lxx = np.tile(np.eye(nx), (B0, N, 1, 1)); luu = np.tile(np.eye(nu), (B0, N, 1, 1)); lux = np.zeros((B0, N, nu, nx))
@@ -492,9 +495,9 @@ def measure_stackfed(api, device=0, shapes=None, reps=3):
         Gx = 0.1 * rng.standard_normal((B0, N, m, nx)); Gu = 0.3 * rng.standard_normal((B0, N, m, nu))
         for branch, mm, bname in ((api.STACKS_IPDDP_PATH, m, "IPDDP, path rows"), (api.STACKS_CLDDP, 0, "CLDDP")):
             curve = []
-            for mult in mults:
-                B = B0 * mult
-                rep = lambda a: np.ascontiguousarray(np.concatenate([a] * mult, axis=0)) if mult > 1 else a
+            for B in batches:
+                mult = (B + B0 - 1) // B0
+                rep = lambda a: np.ascontiguousarray(np.concatenate([a] * mult, axis=0)[:B]) if B != B0 else a
                 try:
                     hs = api.HipStackSolver(B, nx, nu, mm, N, device=device)
                 except api.HipError as e:

@@ -936,6 +936,16 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
       if (!std::strcmp(e, "coop") && h->fn_coop) f = h->fn_coop;
       else if (!std::strcmp(e, "lane") && h->fn) f = h->fn;
     }
+    if (f == h->fn_coop) {
+      // the cooperative form addresses an element of a step record through a 32-bit byte offset behind the record's base (stacks_coop.hpp)
+      const long long nx = h->nx, nu = h->nu, m = h->m > 0 ? h->m : 1;
+      long long emax = nx * nx > m * nx ? nx * nx : m * nx;
+      if (a.Fxx) emax = nx * nx * nx;
+      if ((emax + 16) * (long long)h->Bp * 8 >= (1ll << 32)) {
+        if (h->fn) f = h->fn;
+        else return sfail(-4, "cooperative stack-fed sweep: batch %d too large for its 32-bit record offsets (nx=%d%s) -- split the batch", h->B, h->nx, a.Fxx ? ", with Hessian stacks" : "");
+      }
+    }
     h->used_coop = (f == h->fn_coop) ? 1 : 0;
     f(a, h->stream);
   }
