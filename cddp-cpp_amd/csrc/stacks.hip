@@ -37,6 +37,10 @@ constexpr double kMaxRatioS = 1e6;            // MAX_BARRIER_RATIO    ipddp_solv
 
 struct StackArgs {
   int B, Bp, N, branch;
+  int t4;                                      // 1: the (N x batch) stacks are tile-minor, [t][b / 4][e][b % 4] -- the step record of the FOUR trajectories a
+                                               // cooperative workgroup owns is contiguous (E x 32 B: whole 128-B lines per load instead of sixteen 32-B pieces
+                                               // of lines that four workgroups share); the handles whose default sweep is the cooperative one (nx > 8).
+                                               // 0: [t][e][Bp], one coalesced 512-B row per element for the one-lane kernels.  [1][E][Bp] inputs stay plain.
   double reg_factor, reg_max, tau_min;
   const double *reg_in, *mu;                   // [Bp]
   const double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *VxN, *VxxN;
@@ -54,13 +58,17 @@ struct StackArgs {
   int *ok;
 };
 
-#define SI(t, E, e) ((((size_t)(t)) * (E) + (e)) * (size_t)a.Bp + (size_t)b)
+// (T4: a compile-time parameter of the one-lane kernel -- the tile-minor instantiations exist for the nx > 8 shapes only, as the bitwise
+//  cross-check of the cooperative sweep on its own layout; written as a run-time select in every index, the nx = 6 / m = 6 instantiation
+//  came out of ROCm 7.2 reading mu wrong)
+#define SI(t, E, e) (T4 ? ((((size_t)(t)) * (size_t)(a.Bp >> 2) + (size_t)(b >> 2)) * (E) + (e)) * 4 + (size_t)(b & 3) \
+                        : ((((size_t)(t)) * (E) + (e)) * (size_t)a.Bp + (size_t)b))
 
 DEV double clipp(double num, double den) { return dclamp(num / den, 0.0, kMaxRatioS); }
 DEV double clips(double num, double den) { return dclamp(num / den, -kMaxRatioS, kMaxRatioS); }
 
 // One backward sweep at regularisation `reg`; returns false where the reference's backwardPass returns false.
-template <int NX, int NU, int M>
+template <int NX, int NU, int M, bool T4>
 DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, double &dV1, double &inf_du, double &inf_pr,
                double &inf_comp, double &step_norm) {
   constexpr int MM = M > 0 ? M : 1;
@@ -494,7 +502,7 @@ DEV bool sweep(const StackArgs &a, int b, double reg, double mu, double &dV0, do
   return true;
 }
 
-template <int NX, int NU, int M>
+template <int NX, int NU, int M, bool T4>
 __global__ __launch_bounds__(64) void k_stacks_backward(StackArgs a) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(64) void k_stacks_backward(StackArgs a) {
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
   bool ok = false;
   for (;;) {   // "retry with larger regularisation" loop of cddp_solver_base.cpp:93-111 (reg_factor <= 1: a single attempt)
-    ok = sweep<NX, NU, M>(a, b, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
+    ok = sweep<NX, NU, M, T4>(a, b, reg, mu, dV0, dV1, inf_du, inf_pr, inf_comp, step_norm);
     if (ok || !(a.reg_factor > 1.0)) break;
     reg = reg * a.reg_factor;
     if (!(reg > 0.0)) reg = (a.opt.reg_min_value > 0.0) ? a.opt.reg_min_value : a.reg_max;   // 0 is a fixed point of reg * f (kernels.hpp::reg_increase)
@@ -570,7 +578,10 @@ int sfail(int code, const char *fmt, ...) {
 
 template <int NX, int NU, int M>
 void launch(const StackArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL((k_stacks_backward<NX, NU, M>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  if constexpr (NX > 8) {
+    if (a.t4) { hipLaunchKernelGGL((k_stacks_backward<NX, NU, M, true>), dim3((a.B + 63) / 64), dim3(64), 0, s, a); return; }
+  }
+  hipLaunchKernelGGL((k_stacks_backward<NX, NU, M, false>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
 }
 typedef void (*LaunchFn)(const StackArgs &, hipStream_t);
 
@@ -600,11 +611,13 @@ LaunchFn pick_coop(int nx, int nu, int m) {
 }
 
 // batch-major [b][r] <-> stack [r][Bp] (r = t * E + e), one thread per element, b fastest: the stack side is coalesced
-__global__ void k_stack_transpose(double *aos, double *soa, int B, int Bp, int R, int to_stack) {
+__global__ void k_stack_transpose(double *aos, double *soa, int B, int Bp, int R, int to_stack, int E, int t4) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (b >= B) return;
-  if (to_stack) soa[(size_t)r * Bp + b] = aos[(size_t)b * R + r];
-  else aos[(size_t)b * R + r] = soa[(size_t)r * Bp + b];
+  size_t si = (size_t)r * Bp + b;
+  if (t4) { const int t = r / E, e = r - t * E; si = (((size_t)t * (size_t)(Bp >> 2) + (size_t)(b >> 2)) * E + e) * 4 + (size_t)(b & 3); }
+  if (to_stack) soa[si] = aos[(size_t)b * R + r];
+  else aos[(size_t)b * R + r] = soa[si];
 }
 }  // namespace
 
@@ -657,7 +670,8 @@ int upload(cddp_hip_stack_handle *h, const double *src, double *dst, int T, int 
   if (n == 0) return 0;
   { int rc = stage_reserve(h, n); if (rc) return rc; }
   SCHK(hipMemcpyAsync(h->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, dst, h->B, h->Bp, T * E, 1);
+  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, dst, h->B, h->Bp, T * E, 1, E,
+                     (h->a.t4 && T > 1) ? 1 : 0);
   SCHK(hipGetLastError());
   SCHK(hipStreamSynchronize(h->stream));   // the caller may reuse src; the staging buffer is reused by the next upload
   return 0;
@@ -667,7 +681,8 @@ int download(cddp_hip_stack_handle *h, const double *src, double *dst, int T, in
   const size_t n = (size_t)T * E * h->B;
   if (n == 0) return 0;
   { int rc = stage_reserve(h, n); if (rc) return rc; }
-  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, const_cast<double *>(src), h->B, h->Bp, T * E, 0);
+  hipLaunchKernelGGL(k_stack_transpose, dim3((unsigned)((h->B + 255) / 256), (unsigned)(T * E)), dim3(256), 0, h->stream, h->d_stage, const_cast<double *>(src), h->B, h->Bp, T * E, 0, E,
+                     (h->a.t4 && T > 1) ? 1 : 0);
   SCHK(hipGetLastError());
   SCHK(hipMemcpyAsync(dst, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   SCHK(hipStreamSynchronize(h->stream));
@@ -691,6 +706,10 @@ int cddp_hip_stacks_create_abi(int abi_version, int options_bytes, int device, i
   SCHK(hipSetDevice(device));
   cddp_hip_stack_handle *h = new cddp_hip_stack_handle();
   h->device = device; h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->nx = nx; h->nu = nu; h->m = m; h->N = horizon; h->fn = fn; h->fn_coop = fn_coop;
+  {   // tile-minor stacks where the cooperative sweep is the default (CDDP_HIP_STACKS_LAYOUT=plain | t4 overrides: the cross-check of the two)
+    h->a.t4 = (nx > 8 && fn_coop) ? 1 : 0;
+    if (const char *e = std::getenv("CDDP_HIP_STACKS_LAYOUT")) { if (!std::strcmp(e, "plain")) h->a.t4 = 0; else if (!std::strcmp(e, "t4") && nx > 8 && fn_coop) h->a.t4 = 1; }
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return sfail(-10, "hipStreamCreate failed"); }
   hipEventCreate(&h->e0); hipEventCreate(&h->e1);
   const size_t Bp = h->Bp, N = horizon;
@@ -828,6 +847,7 @@ int cddp_hip_set_terminal_equality(cddp_hip_stack_handle *h, int pT, const doubl
   if (pT < 1 || pT > kPTS) return sfail(-3, "terminal-equality rows must be 1 .. %d on the stack-fed route (got %d)", kPTS, pT);
   if (h->m != 0) return sfail(-1, "the terminal-equality branch takes the path constraints condensed into the LQ stacks: use a handle created with m = 0");
   if (!pick_te(h->nx, h->nu)) return sfail(-3, "no terminal-equality stack kernel for nx = %d, nu = %d", h->nx, h->nu);
+  if (h->a.t4) return sfail(-3, "the terminal-equality stack kernel reads [t][e][batch] stacks: this handle was created tile-minor (CDDP_HIP_STACKS_LAYOUT=t4)");
   SCHK(hipSetDevice(h->device));
   const int N = h->N, nx = h->nx, nu = h->nu, Bp = h->Bp;
   if (pT > h->te_cap) {
@@ -936,7 +956,7 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
       if (!std::strcmp(e, "coop") && h->fn_coop) f = h->fn_coop;
       else if (!std::strcmp(e, "lane") && h->fn) f = h->fn;
     }
-    if (f == h->fn_coop) {
+    if (f == h->fn_coop && !a.t4) {
       // the cooperative form addresses an element of a step record through a 32-bit byte offset behind the record's base (stacks_coop.hpp)
       const long long nx = h->nx, nu = h->nu, m = h->m > 0 ? h->m : 1;
       long long emax = nx * nx > m * nx ? nx * nx : m * nx;

@@ -62,11 +62,19 @@ typedef __attribute__((address_space(1))) char gchar;
 typedef const __attribute__((address_space(4))) StackArgs *sc_kargs_t;
 template <int KMAX>
 struct SCOff {
-  unsigned v[KMAX], b8, bp8;
-  DEV void init(int gl, int b, int Bp) {
-    bp8 = (unsigned)Bp * 8u; b8 = (unsigned)b * 8u;
+  // Two layouts (StackArgs::t4).  Plain [t][e][Bp]: element e of trajectory b sits (e Bp + b) 8 bytes behind the step's base.  Tile-minor
+  // [t][b / 4][e][b % 4]: (e 4 + b % 4) 8 bytes behind base + (b / 4) E 32 -- the four trajectories of the workgroup share a contiguous
+  // E x 32-byte record, and a load of sixteen consecutive elements is 512 contiguous bytes.  In both, a step is E Bp doubles.
+  unsigned v[KMAX], b8;   // byte offset of the lane's element gl / of the trajectory inside an element
+  int t4, goff;           // layout; (b / 4) * 4 under t4 (the record's offset is E * goff doubles), else 0
+  DEV void init(int gl, int tl, int b, int Bp, int t4_) {
+    t4 = t4_; goff = t4_ ? (b >> 2) * 4 : 0;
+    b8 = t4_ ? (unsigned)tl * 8u : (unsigned)b * 8u;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { v[k] = ((unsigned)(k * 16 + gl) * (unsigned)Bp + (unsigned)b) * 8u; asm volatile("" : "+v"(v[k])); }
+    for (int k = 0; k < KMAX; ++k) {
+      v[k] = t4_ ? ((unsigned)(k * 16 + gl) * 4u + (unsigned)tl) * 8u : ((unsigned)(k * 16 + gl) * (unsigned)Bp + (unsigned)b) * 8u;
+      asm volatile("" : "+v"(v[k]));
+    }
   }
 };
 template <int NX, int NU, int M> struct SCOffFor { typedef SCOff<1> type; };
@@ -75,8 +83,8 @@ template <int NX, int NU, int M> struct SCOffFor { typedef SCOff<1> type; };
 // offset would do as well, but the zero-extension of the loop-invariant offsets is hoisted out of the step loop and the instruction
 // selector then sees a 64-bit VGPR add per access.)  Offsets are 32-bit: the host side keeps the cooperative form to E Bp 8 < 2^32.
 typedef unsigned int sc_u32x2 __attribute__((ext_vector_type(2)));
-DEV __amdgpu_buffer_rsrc_t sc_rsrc(const double *base, int t, int E, int Bp) {
-  const unsigned long long v = (unsigned long long)(base + (size_t)t * E * Bp);
+DEV __amdgpu_buffer_rsrc_t sc_rsrc(const double *base, int t, int E, int Bp, int goff) {
+  const unsigned long long v = (unsigned long long)(base + (size_t)t * E * Bp + (size_t)E * goff);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull)), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)0xffffffff, 0x00020000);
 }
@@ -86,14 +94,16 @@ DEV void sc_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
 // (the lane offset of element 0 in the VGPR offset, the sixteen-element stride e_it * 16 Bp 8 in the instruction's SCALAR offset: one offset
 //  register for the whole kernel -- a table of per-e_it offsets was 9 - 13 more, and at nx >= 13 they were spilled and came back through
 //  scratch loads whose vmcnt(0) waits serialised the prefetch stream)
-#define SC_LD(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(e##_it * 128) * (unsigned)bpo)
-#define SC_ST(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(e##_it * 128) * (unsigned)bpo, (x))
+#define SC_ES8 (vo.t4 ? 32u : (unsigned)bpo * 8u)   /* bytes from one element to the next */
+#define SC_RS(stack, t, E) sc_rsrc((stack), (t), (E), bpo, vo.goff)
+#define SC_LD(stack, t, E, e) sc_ld(SC_RS(stack, t, E), vo.v[0], (unsigned)(e##_it * 16) * SC_ES8)
+#define SC_ST(stack, t, E, e, x) sc_st(SC_RS(stack, t, E), vo.v[0], (unsigned)(e##_it * 16) * SC_ES8, (x))
 // element eu + gl, eu uniform (a column owner walking rows): the uniform part rides in the scalar offset
-#define SC_LDU(stack, t, E, eu) sc_ld(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8)
-#define SC_STU(stack, t, E, eu, x) sc_st(sc_rsrc((stack), (t), (E), bpo), vo.v[0], (unsigned)(eu) * vo.bp8, (x))
-// an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): per-lane 32-bit offset e * Bp + b
-#define SC_LDV(stack, t, E, e) sc_ld(sc_rsrc((stack), (t), (E), bpo), (unsigned)(e) * vo.bp8 + vo.b8, 0u)
-#define SC_STV(stack, t, E, e, x) sc_st(sc_rsrc((stack), (t), (E), bpo), (unsigned)(e) * vo.bp8 + vo.b8, 0u, (x))
+#define SC_LDU(stack, t, E, eu) sc_ld(SC_RS(stack, t, E), vo.v[0], (unsigned)(eu) * SC_ES8)
+#define SC_STU(stack, t, E, eu, x) sc_st(SC_RS(stack, t, E), vo.v[0], (unsigned)(eu) * SC_ES8, (x))
+// an element index that is NOT "uniform + gl" (a row owner walking its row, the replicated scalar pieces): per-lane 32-bit offset
+#define SC_LDV(stack, t, E, e) sc_ld(SC_RS(stack, t, E), (unsigned)(e) * SC_ES8 + vo.b8, 0u)
+#define SC_STV(stack, t, E, e, x) sc_st(SC_RS(stack, t, E), (unsigned)(e) * SC_ES8 + vo.b8, 0u, (x))
 // The step index and the batch pitch are laundered through an empty asm once per step: otherwise the optimiser turns every access into
 // its own loop-carried 64-bit induction variable (~70 SGPR pairs, spilled to VGPR lanes: 628 v_readlane / v_writelane in the step
 // loop); laundered, the address arithmetic stays inside the step on the otherwise idle scalar unit.
@@ -871,26 +881,26 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
                              [&](int i, int c) { return L[C::oQuu + i * NU + c]; }, [&](int i, int c, double s1, double old) { L[C::oQuu + i * NU + c] = old + s1; });
     if (have_Fxx) {   // second-order dynamics terms (use_ilqr = false), added to the finished sums in the same order; rolled: a cold path that must not shape the step's register allocation
       lds_sync();
-      const __amdgpu_buffer_rsrc_t rFxx = sc_rsrc(a.Fxx, t, NX * NX * NX, bpo), rFux = sc_rsrc(a.Fux, t, NX * NU * NX, bpo), rFuu = sc_rsrc(a.Fuu, t, NX * NU * NU, bpo);
+      const __amdgpu_buffer_rsrc_t rFxx = SC_RS(a.Fxx, t, NX * NX * NX), rFux = SC_RS(a.Fux, t, NX * NU * NX), rFuu = SC_RS(a.Fuu, t, NX * NU * NU);
 #pragma nounroll
       for (int e = gl; e < NX * NX; e += 16) {
         double q = L[C::oQxx + e];
 #pragma nounroll
-        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFxx, (unsigned)(j * NX * NX + e) * vo.bp8 + vo.b8, 0u);
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFxx, (unsigned)(j * NX * NX + e) * SC_ES8 + vo.b8, 0u);
         L[C::oQxx + e] = q;
       }
 #pragma nounroll
       for (int e = gl; e < NU * NX; e += 16) {
         double q = L[C::oQux + e];
 #pragma nounroll
-        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFux, (unsigned)(j * NU * NX + e) * vo.bp8 + vo.b8, 0u);
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFux, (unsigned)(j * NU * NX + e) * SC_ES8 + vo.b8, 0u);
         L[C::oQux + e] = q;
       }
 #pragma nounroll
       for (int e = gl; e < NU * NU; e += 16) {
         double q = L[C::oQuu + e];
 #pragma nounroll
-        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFuu, (unsigned)(j * NU * NU + e) * vo.bp8 + vo.b8, 0u);
+        for (int j = 0; j < NX; ++j) q = q + L[C::oVx + j] * sc_ld(rFuu, (unsigned)(j * NU * NU + e) * SC_ES8 + vo.b8, 0u);
         L[C::oQuu + e] = q;
       }
     }
@@ -966,12 +976,12 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
       }
       {
         struct GY { double gx, ys; };
-        const __amdgpu_buffer_rsrc_t rKy = sc_rsrc(a.Ky, t, M * NX, bpo), rKs = sc_rsrc(a.Ks, t, M * NX, bpo);   // (formed outside the lane-dependent write guard)
+        const __amdgpu_buffer_rsrc_t rKy = SC_RS(a.Ky, t, M * NX), rKs = SC_RS(a.Ks, t, M * NX);   // (formed outside the lane-dependent write guard)
         sc_mm<M, NX, NU, false>(L, glt, [](int r, int i) { return C::oGu + r * NU + i; }, [](int i, int c) { return C::oKK + i * NX + c; }, SCNoMid(),
                                 [&](int r, int c) { GY v; v.gx = L[C::oGx + r * NX + c]; v.ys = L[C::oYS + r]; return v; },
                                 [&](int r, int c, double s2, GY v) {
           const double inner = v.gx + s2;
-          const unsigned off = (unsigned)(r * NX + c) * vo.bp8 + vo.b8;
+          const unsigned off = (unsigned)(r * NX + c) * SC_ES8 + vo.b8;
           sc_st(rKy, off, 0u, msp ? v.ys * inner : dclamp(v.ys * inner, -kMaxRatioS, kMaxRatioS));
           sc_st(rKs, off, 0u, (-v.gx) - s2);
         });
@@ -1223,31 +1233,69 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
   return true;
 }
 
-// Rows of one step of the linear-policy rollout, per lane: constraint row r = lane (K_s, K_y, k_s, k_y, s, y), control row i = lane
-// (K, k), state row i = lane (A, B).
+// Round 6: the rollout's rows as TWO lane-parallel streams instead of five stack-by-stack ones.  A step needs a row of K_s and of K_y per
+// constraint row and a row of K per control and of f_x (+ f_u) per state, each reduced against the same dx: lanes 0 - 7 take K_s rows and lanes
+// 8 - 15 the K_y rows of the same constraint rows, and the NU + NX row tasks "K row | f_x row" are dealt over the sixteen lanes -- one
+// instruction stream per element index j serves both halves (per-lane 64-bit pointers; a buffer resource would be per stack): 31 loads per
+// step at nx = 12 where the stack-by-stack form issued 57 (and the same for the multiply-adds).  vmcnt tracks 63 loads: two steps in flight.
 template <int NX, int NU, int M>
-struct SCRoll {
-  static constexpr int cdiv(int x) { return (x + 15) / 16; }
-  static constexpr int MM = M > 0 ? M : 1;
-  double Ks[cdiv(MM)][NX], Ky[cdiv(MM)][NX], ks[cdiv(MM)], ky[cdiv(MM)], s[cdiv(MM)], y[cdiv(MM)];
-  double K[cdiv(NU)][NX], k[cdiv(NU)], fx[cdiv(NX)][NX], fu[cdiv(NX)][NU];
-  template <class AT, class VO> DEV void load(const AT &a, int t0, int gl, const VO &vo) {
-    SC_OPAQUE(t, bpo, t0);
-    SC_EACH(M, r) {
+struct SCRoll2 {
+  static constexpr int MM = M > 0 ? M : 1, RM = (MM + 7) / 8, RX = (NU + NX + 15) / 16;
+  double cm[RM][NX], c0[RM], c1[RM];      // K_s | K_y row, k_s | k_y, s | y
+  double rx[RX][NX], fu[RX][NU], kv[RX];  // K | f_x row, f_u row, k
+};
+template <int NX, int NU, int M>
+struct SCRollPtr {   // the lane's element-0 addresses at step 0 and its strides per step, in doubles
+  typedef SCRoll2<NX, NU, M> S;
+  const gdouble *cm[S::RM], *c0[S::RM], *c1[S::RM], *rx[S::RX], *fu[S::RX], *kv[S::RX];
+  unsigned rx_stride[S::RX];
+  bool cvalid[S::RM], isK[S::RX], isF[S::RX];
+  int row[S::RX];
+  size_t es;   // doubles from one element to the next (Bp, or 4 in the tile-minor layout)
+  template <class AT> DEV void init(const AT &a, int gl, int tl, int b) {
+    const size_t Bp = (size_t)a.Bp;
+    const bool t4 = a.t4 != 0;
+    es = t4 ? 4 : Bp;
+    auto at = [&](int E, int e) -> size_t { return t4 ? ((size_t)(b >> 2) * E + e) * 4 + (size_t)tl : (size_t)e * Bp + (size_t)b; };   // element e of step 0
+    const int half = gl >> 3;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) { Ks[r_it][j] = SC_LDV(a.Ks, t, M * NX, r * NX + j); Ky[r_it][j] = SC_LDV(a.Ky, t, M * NX, r * NX + j); }
-      ks[r_it] = SC_LD(a.ks, t, M, r); ky[r_it] = SC_LD(a.ky, t, M, r); s[r_it] = SC_LD(a.s, t, M, r); y[r_it] = SC_LD(a.y, t, M, r);
+    for (int p = 0; p < S::RM; ++p) {
+      const int r0 = (gl & 7) + 8 * p;
+      cvalid[p] = r0 < M;
+      const int r = r0 < M ? r0 : M - 1;
+      cm[p] = (const gdouble *)(half ? a.Ky : a.Ks) + at(M * NX, r * NX);
+      c0[p] = (const gdouble *)(half ? a.ky : a.ks) + at(M, r);
+      c1[p] = (const gdouble *)(half ? a.y : a.s) + at(M, r);
     }
-    SC_EACH(NU, i) {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) K[i_it][j] = SC_LDV(a.K, t, NU * NX, i * NX + j);
-      k[i_it] = SC_LD(a.k, t, NU, i);
+    for (int p = 0; p < S::RX; ++p) {
+      const int id = gl + 16 * p;
+      isK[p] = id < NU; isF[p] = id >= NU && id < NU + NX;
+      row[p] = isK[p] ? id : (isF[p] ? id - NU : 0);
+      rx[p] = isK[p] ? (const gdouble *)a.K + at(NU * NX, row[p] * NX) : (const gdouble *)a.fx + at(NX * NX, row[p] * NX);
+      rx_stride[p] = (unsigned)((isK[p] ? NU * NX : NX * NX) * (int)Bp);
+      fu[p] = (const gdouble *)a.fu + at(NX * NU, (isF[p] ? row[p] : 0) * NU);
+      kv[p] = (const gdouble *)a.k + at(NU, isK[p] ? row[p] : 0);
     }
-    SC_EACH(NX, i) {
+  }
+  DEV void load(S &w, int t, int Bp_) const {
+    const size_t Bp = (size_t)Bp_, tt = (size_t)t;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) fx[i_it][j] = SC_LDV(a.fx, t, NX * NX, i * NX + j);
+    for (int p = 0; p < S::RM; ++p) {
+      const gdouble *q = cm[p] + tt * (size_t)(M * NX) * Bp;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) fu[i_it][j] = SC_LDV(a.fu, t, NX * NU, i * NU + j);
+      for (int j = 0; j < NX; ++j) w.cm[p][j] = q[(size_t)j * es];
+      w.c0[p] = c0[p][tt * (size_t)M * Bp]; w.c1[p] = c1[p][tt * (size_t)M * Bp];
+    }
+#pragma unroll
+    for (int p = 0; p < S::RX; ++p) {
+      const gdouble *q = rx[p] + tt * (size_t)rx_stride[p];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) w.rx[p][j] = q[(size_t)j * es];
+      const gdouble *f = fu[p] + tt * (size_t)(NX * NU) * Bp;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) w.fu[p][j] = f[(size_t)j * es];
+      w.kv[p] = kv[p][tt * (size_t)NU * Bp];
     }
   }
 };
@@ -1261,7 +1309,7 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
   if (b >= a.B) return;
   double *L = sc_lds + tl * C::STRIDE;
   typename SCOffFor<NX, NU, M>::type vo;
-  vo.init(gl, b, a.Bp);
+  vo.init(gl, tl, b, a.Bp, a.t4);
   const double mu = a.mu ? a.mu[b] : 0.0;
   double reg = a.reg_in[b];
   double dV0 = 0, dV1 = 0, inf_du = 0, inf_pr = 0, inf_comp = 0, step_norm = 0;
@@ -1286,41 +1334,67 @@ __global__ __launch_bounds__(64) void k_stacks_backward_coop(StackArgs a) {
       SC_EACH(NX, i) L[C::oW + i] = 0.0;
       lds_sync();
       const int bpo = a.Bp;
-      SCRoll<NX, NU, M> cur, nxt;   // the rows a lane needs at a step do not depend on dx: fetched one step ahead
-      cur.load(a, 0, gl, vo);
-      for (int t_ = 0; t_ < N; ++t_) {
-        if (t_ + 1 < N) nxt.load(a, t_ + 1, gl, vo);
+      typedef SCRoll2<NX, NU, M> RS;
+      SCRollPtr<NX, NU, M> rp;
+      rp.init(a, gl, tl, b);
+      const int half = gl >> 3;
+      double cap = 1.0;   // the lane's share of alpha_pr (lanes 0 - 7) or alpha_du (lanes 8 - 15)
+      auto rstep = [&](const int t_, const RS &w) {   // one step on the rows in w
         SC_EACH(NX, i) SC_ST(a.dX, t_, NX, i, L[C::oW + i]);
-        SC_EACH(M, r) {
-          double p = 0.0, q = 0.0;
+        double dxr[NX];
 #pragma unroll
-          for (int j = 0; j < NX; ++j) { const double dxj = L[C::oW + j]; p += cur.Ks[r_it][j] * dxj; q += cur.Ky[r_it][j] * dxj; }
-          const double ds = cur.ks[r_it] + p;
-          const double dy = dclamp(cur.ky[r_it] + q, -kMaxRatioS, kMaxRatioS);
-          if (ds < 0.0) apr = dmin(apr, -tau * cur.s[r_it] / ds);
-          if (dy < 0.0) adu = dmin(adu, -tau * cur.y[r_it] / dy);
+        for (int j = 0; j < NX; ++j) dxr[j] = L[C::oW + j];
+#pragma unroll
+        for (int p = 0; p < RS::RM; ++p) {
+          double pq = 0.0;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) pq += w.cm[p][j] * dxr[j];
+          const double d0 = w.c0[p] + pq;                                                  // dS_r on lanes 0 - 7, dY_r (clamped) on lanes 8 - 15
+          const double dd = half == 0 ? d0 : dclamp(d0, -kMaxRatioS, kMaxRatioS);
+          if (rp.cvalid[p] && dd < 0.0) cap = dmin(cap, -tau * w.c1[p] / dd);
         }
-        SC_EACH(NU, i) {
-          double p = 0.0;
+        double rs[RS::RX];
 #pragma unroll
-          for (int j = 0; j < NX; ++j) p += cur.K[i_it][j] * L[C::oW + j];
-          L[C::oQu + i] = cur.k[i_it] + p;
-        }
-        lds_sync();
-        double dxn[(NX + 15) / 16];
-        SC_EACH(NX, i) {
-          double p = 0.0, q = 0.0;
+        for (int p = 0; p < RS::RX; ++p) {
+          double sx = 0.0;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) p += cur.fx[i_it][j] * L[C::oW + j];
-#pragma unroll
-          for (int j = 0; j < NU; ++j) q += cur.fu[i_it][j] * L[C::oQu + j];
-          dxn[i_it] = (p + q) + 0.0;
+          for (int j = 0; j < NX; ++j) sx += w.rx[p][j] * dxr[j];
+          rs[p] = sx;
+          if (rp.isK[p]) L[C::oQu + rp.row[p]] = w.kv[p] + sx;
         }
         lds_sync();
-        SC_EACH(NX, i) L[C::oW + i] = dxn[i_it];
+        double dur[NU], dxn[RS::RX];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) dur[j] = L[C::oQu + j];
+#pragma unroll
+        for (int p = 0; p < RS::RX; ++p) {
+          double q = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) q += w.fu[p][j] * dur[j];
+          dxn[p] = (rs[p] + q) + 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < RS::RX; ++p) if (rp.isF[p]) L[C::oW + rp.row[p]] = dxn[p];
         lds_sync();
-        cur = nxt;
+      };
+      constexpr int NBUF = (NX <= 12) ? 3 : 2;   // rows of NBUF - 1 steps in flight (registers; vmcnt)
+      RS st[NBUF];
+#pragma unroll
+      for (int u = 0; u < NBUF - 1; ++u) rp.load(st[u], u < N ? u : N - 1, bpo);
+      int t0 = 0;
+      for (; t0 + NBUF <= N; t0 += NBUF) {   // no branch around a load: the wait-count pass would merge "in flight" and "landed" at the join
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+          const int tn = t0 + u + NBUF - 1;
+          rp.load(st[(u + NBUF - 1) % NBUF], tn < N ? tn : N - 1, bpo);
+          rstep(t0 + u, st[u]);
+        }
       }
+      for (int u = 0; t0 + u < N; ++u) {   // tail: at most NBUF - 1 steps, their rows are in st[0 .. NBUF - 2]
+        if (u == 0) rstep(t0, st[0]);
+        else if (NBUF > 2 && u == 1) rstep(t0 + 1, st[1 % NBUF]);
+      }
+      apr = half == 0 ? cap : 1.0; adu = half == 0 ? 1.0 : cap;
       SC_EACH(NX, i) SC_ST(a.dX, N, NX, i, L[C::oW + i]);
       L[C::oRed + gl] = apr; L[C::oRed + 16 + gl] = adu;
       lds_sync();

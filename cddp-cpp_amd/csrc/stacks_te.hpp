@@ -15,6 +15,7 @@ namespace {
 
 constexpr int kPTS = 8;   // terminal-equality rows of a plug-in problem (stack-fed route)
 
+constexpr bool T4 = false;   // SI(): the terminal-equality kernels read [t][e][batch] stacks only (cddp_hip_set_terminal_equality refuses a tile-minor handle)
 struct StackTeArgs {
   int pT;
   const double *HT;       // [pT][nx][Bp]

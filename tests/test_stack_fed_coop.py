@@ -103,6 +103,38 @@ def test_cooperative_sweep_is_bitwise_the_lane_sweep(api, shape):
     hs.close()
 
 
+@pytest.mark.parametrize("shape", [(12, 4, 0), (12, 4, 8), (13, 4, 8), (14, 7, 0)], ids=lambda s: "nx%d_nu%d_m%d" % s)
+def test_large_state_sweeps_on_the_batch_minor_layout(api, shape, monkeypatch):
+    """Round 6: handles whose default sweep is the cooperative one (nx > 8) keep their stacks tile-minor, [t][b / 4][e][b % 4] (the step record of
+    the four trajectories of a workgroup contiguous); CDDP_HIP_STACKS_LAYOUT=plain keeps [t][e][batch] -- both kernels read both layouts, and
+    every comparison above ran on the default.  Same comparison on the other layout, and the two layouts against each other."""
+    nx, nu, m = shape
+    monkeypatch.setenv("CDDP_HIP_STACKS_LAYOUT", "plain")
+    if shape in SHAPES:   # (its closing assertion on clamped / free BoxQP rows is tuned to these shapes' data)
+        test_cooperative_sweep_is_bitwise_the_lane_sweep(api, shape)
+    rng = np.random.default_rng(7)
+    B, N = 11, 9
+    stacks = make_stacks(rng, B, N, nx, nu)
+    opt = api.default_options(); reg = np.full(B, 1e-6)
+    out = {}
+    for layout in ("plain", "t4"):
+        monkeypatch.setenv("CDDP_HIP_STACKS_LAYOUT", layout)
+        hs = api.HipStackSolver(B, nx, nu, m, N)
+        hs.set_stacks(*stacks)
+        mu = None
+        if m:
+            r2 = np.random.default_rng(8)
+            y = 0.5 + 0.4 * r2.random((B, N, m)); s = 0.2 + 0.4 * r2.random((B, N, m)); g = -s + 0.01 * r2.standard_normal((B, N, m))
+            hs.set_constraint_stacks(y, s, g, 0.1 * r2.standard_normal((B, N, m, nx)), 0.3 * r2.standard_normal((B, N, m, nu)))
+            mu = np.full(B, 0.05)
+        ok = hs.backward(api.STACKS_IPDDP_PATH if m else api.STACKS_IPDDP, opt, reg, mu, retry=False)
+        assert ok.all() and hs.sweep_form() == 1
+        out[layout] = list(hs.gains()) + (list(hs.constraint_gains()) if m else [])
+        hs.close()
+    for a, c in zip(out["plain"], out["t4"]):
+        assert np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("shape", [(4, 1, 0), (3, 2, 5), (6, 3, 6), (12, 4, 0), (12, 4, 8)], ids=lambda s: "nx%d_nu%d_m%d" % s)
 def test_cooperative_sweep_hessian_stacks(api, shape):
     """Full DDP (use_ilqr = false): the dt-scaled dynamics Hessian tensors weighted with V_x (ipddp_solver.cpp:1070-1082, 1396-1408;
