@@ -236,6 +236,9 @@ DEV void sc_rows(const double *__restrict__ L, const double (&v)[K], Addr addr, 
 #ifndef SC_V1_NX
 #define SC_V1_NX 13   // state sizes from here on keep the column-per-lane step (sweep_coop_v1)
 #endif
+#ifndef SC_FETCH_LATE
+#define SC_FETCH_LATE 0
+#endif
 #ifndef SC_MM_BUDGET
 #define SC_MM_BUDGET 24   // doubles of operands per chunk of a tiled product (two chunks in flight)
 #endif
@@ -832,7 +835,9 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
     }
     lds_sync();
     SC_TICK(0);
+#if !SC_FETCH_LATE
     if (t > 0) rec.fetch(a, t - 1, gl, vo);   // in flight behind this step's arithmetic, parked at its end
+#endif
     // ---------------------------------------------------------------- Q_x, Q_u, T1 = A^T V_xx, T2 = B^T V_xx
     {
       double qx[(NX + 15) / 16], qu[(NU + 15) / 16];
@@ -1134,6 +1139,9 @@ DEV bool sweep_coop(const StackArgs &a0, const int b, const int gl0, const typen
                              [](int, int) { return 0.0; }, [&](int i, int j, double s1, double) { L[C::oKtQ + i * NU + j] = s1; });
     lds_sync();
     SC_TICK(8);
+#if SC_FETCH_LATE
+    if (t > 0) rec.fetch(a, t - 1, gl, vo);   // behind V_n and the symmetrisation (~5 k clocks), parked at the end of the step
+#endif
     // ---------------------------------------------------------------- value update
     double vxn[(NX + 15) / 16];
     SC_EACH(NX, i) {
