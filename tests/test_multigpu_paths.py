@@ -108,11 +108,16 @@ def test_bench_default_line_carries_other_workloads():
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     ow = j["other_workloads"]
-    assert len(ow) == 8 and not any("error" in w for w in ow), ow     # C2-CLDDP, resident LogDDP + MSIPDDP (f4, round 4), C3, C4 / C5 shares, 2 x MPC
+    assert len(ow) == 17 and not any("error" in w for w in ow), ow    # C2-CLDDP, resident LogDDP + MSIPDDP (f4, round 4), C3, C4 / C5 shares, 8 stack-fed sweeps + the plug-in solve (g1, round 6), 2 x MPC
     assert [w["solver"] for w in ow[:6]] == ["CLDDP", "LOGDDP", "MSIPDDP", "IPDDP", "IPDDP", "IPDDP"]
     for w in ow[:6]:
         assert w["value"] > 0 and 0 < w["roofline"]["frac"] < 1 and w["steps"] == 3
-    for w in ow[6:]:   # the MPC re-solve lines (f1 caller side)
+    for w in ow[6:14]:   # north_star's literal form: one launch over host-fed (N x batch) stacks, path rows and CLDDP, four shapes
+        assert w["workload"].startswith("stack-fed sweep") and w["value"] > 0 and 0 < w["roofline"]["frac"] < 1
+        assert all(c["sweeps_ok"] == c["batch"] for c in w["batch_curve"]) and w["roofline"]["traffic"] == max(w["batch_curve"], key=lambda c: c["frac"])["stack_bytes"]
+    assert [w["batch_curve"][0]["form"] for w in ow[6:14]] == ["lane"] * 4 + ["coop"] * 4
+    assert ow[14]["workload"].startswith("host plug-in solve") and ow[14]["converged"] == ow[14]["batch"] and ow[14]["time_split"]["host_ms"] > 0
+    for w in ow[15:]:   # the MPC re-solve lines (f1 caller side)
         assert w["workload"].startswith("MPC re-solves") and w["value"] > 0 and w["steps"] == 8 and len(w["iterations_by_round"]) == 8
         assert w["mean_iterations_per_resolve"] <= w["cold"]["mean_iterations"] + 5
     assert j["config"]["batch_per_gpu"] == 4096 and j["roofline"]["frac"] > 0
