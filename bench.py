@@ -17,6 +17,7 @@ import ctypes
 import importlib.util
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -476,6 +477,29 @@ STACKFED_SHAPES_FULL = [
 ]
 
 
+STACKFED_TRAFFIC_FILE = os.path.join(REPO, "profiles", "r06_pmc_traffic_stackfed.json")
+
+
+def stackfed_traffic(nx, m, clddp, best):
+    """`traffic` of a stack-fed line: FETCH_SIZE x 2 + WRITE_SIZE of ONE sweep launch of this shape / branch / batch / form (profiles/scripts/
+    stackfed_traffic_r06.sh), or None where that batch was not profiled.  Every stack is read and every gain row written once -- that is the
+    algorithmic figure -- and with path rows the linear-policy rollout behind the sweep re-reads f_x, f_u, K, K_s, K_y: 1.5 x."""
+    try:
+        tj = json.load(open(STACKFED_TRAFFIC_FILE))
+    except OSError:
+        return {"traffic": None, "traffic_source": "no " + os.path.relpath(STACKFED_TRAFFIC_FILE, REPO)}
+    pat = re.compile(r"^nx%d_%s_(\d+)_%s_%s$" % (nx, "clddp" if clddp or m == 0 else "path", best["form"], "t4" if nx > 8 else "plain"))
+    hits = sorted((abs(int(pat.match(k).group(1)) - best["batch"]), int(pat.match(k).group(1)), k) for k in tj["launches"] if pat.match(k))
+    if not hits:
+        return {"traffic": None, "traffic_source": "shape not in %s" % os.path.relpath(STACKFED_TRAFFIC_FILE, REPO)}
+    _, pb, key = hits[0]
+    byt = tj["launches"][key]["bytes_per_launch"] * best["batch"] / pb   # (every byte of a sweep is per trajectory: a launch of another batch scales)
+    return {"traffic": byt, "traffic_over_algorithmic": byt / best["stack_bytes"],
+            "hbm_rate_GBps": byt / best["kernel_ms"] / 1e6, "hbm_frac": byt / best["kernel_ms"] / 1e6 / 8000.0,
+            "traffic_source": "%s [%s%s]: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of one launch (separate passes); with path rows the rollout behind the sweep re-reads f_x, f_u, K, K_s, K_y" % (
+                os.path.relpath(STACKFED_TRAFFIC_FILE, REPO), key, "" if pb == best["batch"] else ", scaled from batch %d" % pb)}
+
+
 def measure_stackfed(api, device=0, shapes=None, reps=3):
     """One line per (shape, branch): kernel time (hipEvents around the single launch, cddp_hip_stacks_last_kernel_ms, best of `reps`) of the
     stack-fed IPDDP path-row sweep and the CLDDP sweep on random well-conditioned stacks (the arithmetic does not depend on the values), the
@@ -525,8 +549,8 @@ def measure_stackfed(api, device=0, shapes=None, reps=3):
                 "batch": best["batch"] if best else None, "value": (best["batch"] / (best["kernel_ms"] * 1e-3)) if best else None,
                 "ms_per_step": best["kernel_ms"] if best else None,
                 "roofline": None if not best else {"bound": "hbm", "kernel": "k_stacks_backward" + ("_coop" if best["form"] == "coop" else ""), "achieved": best["GBps"], "peak": PEAK,
-                                                   "unit": "GB/s", "frac": best["frac"], "traffic": best["stack_bytes"],
-                                                   "traffic_note": "the stacks are read / the gain rows written exactly once per sweep: algorithmic bytes = HBM traffic (no in-kernel derivative evaluation)"},
+                                                   "unit": "GB/s", "frac": best["frac"], "algorithmic_bytes_per_launch": best["stack_bytes"],
+                                                   **stackfed_traffic(nx, mm, branch == api.STACKS_CLDDP, best)},
                 "batch_curve": curve,
             })
     return lines
