@@ -576,9 +576,14 @@ int sfail(int code, const char *fmt, ...) {
 #include "stacks_coop.hpp"
 #include "stacks_te.hpp"
 
+// the shapes pick_coop() instantiates (kept next to it)
+constexpr bool sc_has_coop(int nx, int nu, int m) {
+  return (nx == 4 && nu == 1 && (m == 0 || m == 2)) || (nx == 3 && nu == 2 && (m == 0 || m == 5)) || (nx == 6 && nu == 3 && (m == 0 || m == 6)) ||
+         (nx == 12 && nu == 4 && (m == 0 || m == 8)) || (nx == 13 && nu == 4 && (m == 0 || m == 8)) || (nx == 14 && nu == 7 && (m == 0 || m == 14));
+}
 template <int NX, int NU, int M>
 void launch(const StackArgs &a, hipStream_t s) {
-  if constexpr (NX > 8) {
+  if constexpr (sc_has_coop(NX, NU, M)) {   // (tile-minor stacks exist only where a cooperative kernel does)
     if (a.t4) { hipLaunchKernelGGL((k_stacks_backward<NX, NU, M, true>), dim3((a.B + 63) / 64), dim3(64), 0, s, a); return; }
   }
   hipLaunchKernelGGL((k_stacks_backward<NX, NU, M, false>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
@@ -599,7 +604,7 @@ LaunchFn pick(int nx, int nu, int m) {
 // lane-cooperative form (stacks_coop.hpp): the default for nx > 8, where the one-lane kernel runs from scratch memory; the small
 // shapes are instantiated for the bitwise cross-check of the two forms (CDDP_HIP_STACKS_SWEEP=coop | lane overrides the default)
 LaunchFn pick_coop(int nx, int nu, int m) {
-#define PICK(X, U, MM) if (nx == X && nu == U && m == MM) return &launch_coop<X, U, MM>;
+#define PICK(X, U, MM) static_assert(sc_has_coop(X, U, MM), "sc_has_coop() lists the cooperative shapes"); if (nx == X && nu == U && m == MM) return &launch_coop<X, U, MM>;
 #ifdef CDDP_STACKS_DEV_SHAPE
   PICK(12, 4, 8)
 #else
@@ -626,6 +631,7 @@ struct cddp_hip_stack_handle {
   LaunchFn fn = nullptr;        // one lane per trajectory
   LaunchFn fn_coop = nullptr;   // sixteen lanes per trajectory (stacks_coop.hpp)
   int used_coop = 0;            // form of the last sweep
+  bool coop_default = false;    // the handle's default sweep (and stack layout) is the cooperative one
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<void *> allocs;
@@ -707,8 +713,14 @@ int cddp_hip_stacks_create_abi(int abi_version, int options_bytes, int device, i
   cddp_hip_stack_handle *h = new cddp_hip_stack_handle();
   h->device = device; h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->nx = nx; h->nu = nu; h->m = m; h->N = horizon; h->fn = fn; h->fn_coop = fn_coop;
   {   // tile-minor stacks where the cooperative sweep is the default (CDDP_HIP_STACKS_LAYOUT=plain | t4 overrides: the cross-check of the two)
-    h->a.t4 = (nx > 8 && fn_coop) ? 1 : 0;
-    if (const char *e = std::getenv("CDDP_HIP_STACKS_LAYOUT")) { if (!std::strcmp(e, "plain")) h->a.t4 = 0; else if (!std::strcmp(e, "t4") && nx > 8 && fn_coop) h->a.t4 = 1; }
+    // Which sweep is the handle's default: the cooperative one (sixteen lanes per trajectory: 16 x the wavefronts of the one-lane form) from
+    // nx = 6 on, where the one-lane kernel runs from scratch memory (nx 6 / m 6: 10.2 -> 1.0 ms at 4096 trajectories, 21 -> 15 ms at 65536), and
+    // -- round 6 -- for the smaller shapes WITH PATH ROWS while the batch leaves the chip mostly empty under the one-lane form (B / 64 wavefronts
+    // on 1024 SIMDs): C2 shape 0.92 -> 0.49 ms at 4096, 0.98 -> 0.65 at 8192 (1.02 -> 1.27 at 16384: one-lane from there), C3 shape 3.2 -> 1.4 ms
+    // at 8192, 3.3 -> 2.9 at 16384.  The CLDDP / unconstrained sweeps of those shapes stay one-lane (0.19 vs 0.27 ms).  profiles/r06_plugin_route.md
+    h->coop_default = fn_coop && (nx >= 6 || !fn || (m > 0 && batch <= (nx <= 3 ? 16384 : 8192)));
+    h->a.t4 = h->coop_default ? 1 : 0;
+    if (const char *e = std::getenv("CDDP_HIP_STACKS_LAYOUT")) { if (!std::strcmp(e, "plain")) h->a.t4 = 0; else if (!std::strcmp(e, "t4") && fn_coop) h->a.t4 = 1; }
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return sfail(-10, "hipStreamCreate failed"); }
   hipEventCreate(&h->e0); hipEventCreate(&h->e1);
@@ -847,7 +859,7 @@ int cddp_hip_set_terminal_equality(cddp_hip_stack_handle *h, int pT, const doubl
   if (pT < 1 || pT > kPTS) return sfail(-3, "terminal-equality rows must be 1 .. %d on the stack-fed route (got %d)", kPTS, pT);
   if (h->m != 0) return sfail(-1, "the terminal-equality branch takes the path constraints condensed into the LQ stacks: use a handle created with m = 0");
   if (!pick_te(h->nx, h->nu)) return sfail(-3, "no terminal-equality stack kernel for nx = %d, nu = %d", h->nx, h->nu);
-  if (h->a.t4) return sfail(-3, "the terminal-equality stack kernel reads [t][e][batch] stacks: this handle was created tile-minor (CDDP_HIP_STACKS_LAYOUT=t4)");
+  if (h->a.t4 && h->nx < 6) return sfail(-3, "the terminal-equality stack kernel of this shape reads [t][e][batch] stacks: the handle was created tile-minor (CDDP_HIP_STACKS_LAYOUT=t4)");
   SCHK(hipSetDevice(h->device));
   const int N = h->N, nx = h->nx, nu = h->nu, Bp = h->Bp;
   if (pT > h->te_cap) {
@@ -951,7 +963,7 @@ int cddp_hip_stacks_backward(cddp_hip_stack_handle *h, int branch, const cddp_hi
   a.tau_min = (branch == CDDP_HIP_STACKS_CLDDP) ? opt->termination_scaling_max_factor : opt->barrier_min_fraction_to_boundary;
   SCHK(hipEventRecord(h->e0, h->stream));
   {   // ONE launch; nx > 8 defaults to the cooperative form
-    LaunchFn f = (h->nx > 8 && h->fn_coop) ? h->fn_coop : (h->fn ? h->fn : h->fn_coop);
+    LaunchFn f = (h->coop_default && h->fn_coop) ? h->fn_coop : (h->fn ? h->fn : h->fn_coop);
     if (const char *e = std::getenv("CDDP_HIP_STACKS_SWEEP")) {
       if (!std::strcmp(e, "coop") && h->fn_coop) f = h->fn_coop;
       else if (!std::strcmp(e, "lane") && h->fn) f = h->fn;

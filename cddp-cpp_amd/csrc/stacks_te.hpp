@@ -15,7 +15,6 @@ namespace {
 
 constexpr int kPTS = 8;   // terminal-equality rows of a plug-in problem (stack-fed route)
 
-constexpr bool T4 = false;   // SI(): the terminal-equality kernels read [t][e][batch] stacks only (cddp_hip_set_terminal_equality refuses a tile-minor handle)
 struct StackTeArgs {
   int pT;
   const double *HT;       // [pT][nx][Bp]
@@ -53,7 +52,7 @@ DEV void te_singular_minmax(const double *A, int n, double &smax, double &smin) 
 }
 
 // One pass at regularisation `reg`; false where the reference's backwardPass returns false (failed factorisation, non-finite recursion).
-template <int NX, int NU>
+template <int NX, int NU, bool T4>   // T4: SI() on tile-minor stacks (the nx = 6 handles, whose default sweep is the cooperative one)
 DEV bool te_sweep(const StackArgs &a, const StackTeArgs &e, int b, double reg, double &inf_du, double &step_norm) {
   const int N = a.N, pT = e.pT;
 #define TP(v, t, i) e.te_p[((((size_t)(v)) * (N + 1) + (t)) * NX + (i)) * (size_t)a.Bp + (size_t)b]
@@ -232,7 +231,7 @@ DEV bool te_sweep(const StackArgs &a, const StackTeArgs &e, int b, double reg, d
   return true;
 }
 
-template <int NX, int NU>
+template <int NX, int NU, bool T4>
 __global__ __launch_bounds__(64) void k_stacks_te(StackArgs a, StackTeArgs e) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(64) void k_stacks_te(StackArgs a, StackTeArgs e) {
   double inf_du = 0, step_norm = 0;
   bool ok = false;
   for (;;) {   // "increase the regularisation and retry" (cddp_solver_base.cpp:93-111)
-    ok = te_sweep<NX, NU>(a, e, b, reg, inf_du, step_norm);
+    ok = te_sweep<NX, NU, T4>(a, e, b, reg, inf_du, step_norm);
     if (ok || !(a.reg_factor > 1.0)) break;
     reg = reg * a.reg_factor;
     if (!(reg > 0.0)) reg = (a.opt.reg_min_value > 0.0) ? a.opt.reg_min_value : a.reg_max;
@@ -256,7 +255,10 @@ __global__ __launch_bounds__(64) void k_stacks_te(StackArgs a, StackTeArgs e) {
 
 template <int NX, int NU>
 void launch_te(const StackArgs &a, const StackTeArgs &e, hipStream_t s) {
-  hipLaunchKernelGGL((k_stacks_te<NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a, e);
+  if constexpr (NX >= 6) {
+    if (a.t4) { hipLaunchKernelGGL((k_stacks_te<NX, NU, true>), dim3((a.B + 63) / 64), dim3(64), 0, s, a, e); return; }
+  }
+  hipLaunchKernelGGL((k_stacks_te<NX, NU, false>), dim3((a.B + 63) / 64), dim3(64), 0, s, a, e);
 }
 typedef void (*LaunchTeFn)(const StackArgs &, const StackTeArgs &, hipStream_t);
 

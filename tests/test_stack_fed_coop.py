@@ -103,15 +103,16 @@ def test_cooperative_sweep_is_bitwise_the_lane_sweep(api, shape):
     hs.close()
 
 
-@pytest.mark.parametrize("shape", [(12, 4, 0), (12, 4, 8), (13, 4, 8), (14, 7, 0)], ids=lambda s: "nx%d_nu%d_m%d" % s)
+@pytest.mark.parametrize("shape", [(4, 1, 2), (3, 2, 0), (6, 3, 6), (12, 4, 0), (12, 4, 8), (13, 4, 8), (14, 7, 0)], ids=lambda s: "nx%d_nu%d_m%d" % s)
 def test_large_state_sweeps_on_the_batch_minor_layout(api, shape, monkeypatch):
     """Round 6: handles whose default sweep is the cooperative one (nx > 8) keep their stacks tile-minor, [t][b / 4][e][b % 4] (the step record of
     the four trajectories of a workgroup contiguous); CDDP_HIP_STACKS_LAYOUT=plain keeps [t][e][batch] -- both kernels read both layouts, and
     every comparison above ran on the default.  Same comparison on the other layout, and the two layouts against each other."""
     nx, nu, m = shape
-    monkeypatch.setenv("CDDP_HIP_STACKS_LAYOUT", "plain")
-    if shape in SHAPES:   # (its closing assertion on clamped / free BoxQP rows is tuned to these shapes' data)
-        test_cooperative_sweep_is_bitwise_the_lane_sweep(api, shape)
+    for layout in ("plain", "t4"):   # (the default of a handle depends on its shape and batch: both, explicitly)
+        monkeypatch.setenv("CDDP_HIP_STACKS_LAYOUT", layout)
+        if shape in SHAPES:   # (its closing assertion on clamped / free BoxQP rows is tuned to these shapes' data)
+            test_cooperative_sweep_is_bitwise_the_lane_sweep(api, shape)
     rng = np.random.default_rng(7)
     B, N = 11, 9
     stacks = make_stacks(rng, B, N, nx, nu)
@@ -127,6 +128,7 @@ def test_large_state_sweeps_on_the_batch_minor_layout(api, shape, monkeypatch):
             y = 0.5 + 0.4 * r2.random((B, N, m)); s = 0.2 + 0.4 * r2.random((B, N, m)); g = -s + 0.01 * r2.standard_normal((B, N, m))
             hs.set_constraint_stacks(y, s, g, 0.1 * r2.standard_normal((B, N, m, nx)), 0.3 * r2.standard_normal((B, N, m, nu)))
             mu = np.full(B, 0.05)
+        monkeypatch.setenv("CDDP_HIP_STACKS_SWEEP", "coop")
         ok = hs.backward(api.STACKS_IPDDP_PATH if m else api.STACKS_IPDDP, opt, reg, mu, retry=False)
         assert ok.all() and hs.sweep_form() == 1
         out[layout] = list(hs.gains()) + (list(hs.constraint_gains()) if m else [])
@@ -190,11 +192,19 @@ def test_cooperative_sweep_retry_loop(api, shape):
 def test_large_state_defaults_to_the_cooperative_form(api):
     rng = np.random.default_rng(3)
     opt = api.default_options()
-    for (nx, nu, m), want in (((12, 4, 0), 1), ((4, 1, 0), 0)):
+    for (nx, nu, m), want in (((12, 4, 0), 1), ((4, 1, 0), 0), ((6, 3, 0), 1)):
         hs = api.HipStackSolver(5, nx, nu, m, 6)
         hs.set_stacks(*make_stacks(rng, 5, 6, nx, nu))
         os.environ.pop("CDDP_HIP_STACKS_SWEEP", None)
         assert hs.backward(api.STACKS_IPDDP, opt, np.full(5, 1e-6)).all()
+        assert hs.sweep_form() == want
+        hs.close()
+    # round 6: small shapes with path rows take the cooperative form while the batch leaves the chip mostly empty under the one-lane one
+    for B, want in ((70, 1), (8192 + 64, 0)):
+        hs = api.HipStackSolver(B, 4, 1, 2, 3)
+        hs.set_stacks(*make_stacks(rng, B, 3, 4, 1))
+        hs.set_constraint_stacks(np.full((B, 3, 2), 0.5), np.full((B, 3, 2), 0.4), np.full((B, 3, 2), -0.39), np.zeros((B, 3, 2, 4)), np.tile(np.array([[1.0], [-1.0]]), (B, 3, 1, 1)))
+        assert hs.backward(api.STACKS_IPDDP_PATH, opt, np.full(B, 1e-6), np.full(B, 0.1)).all()
         assert hs.sweep_form() == want
         hs.close()
     # a shape that exists only in the cooperative form (the 7-joint arm with its control box: the one-lane kernel would need
