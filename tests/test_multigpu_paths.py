@@ -116,7 +116,9 @@ def test_bench_default_line_carries_other_workloads():
         assert w["workload"].startswith("stack-fed sweep") and w["value"] > 0 and 0 < w["roofline"]["frac"] < 1
         assert all(c["sweeps_ok"] == c["batch"] for c in w["batch_curve"]) and w["roofline"]["algorithmic_bytes_per_launch"] == max(w["batch_curve"], key=lambda c: c["frac"])["stack_bytes"]
         assert w["roofline"]["traffic"] is None or 0.95 < w["roofline"]["traffic_over_algorithmic"] < 2.0   # counters of the same launch (profiles/r06_pmc_traffic_stackfed.json)
-    assert [w["batch_curve"][0]["form"] for w in ow[6:14]] == ["lane"] * 4 + ["coop"] * 4
+    # the form of the first (smallest) and of the last batch of each curve: small shapes with path rows start cooperative and end one-lane
+    assert [w["batch_curve"][0]["form"] for w in ow[6:14]] == ["coop", "lane", "coop", "lane"] + ["coop"] * 4
+    assert [w["batch_curve"][-1]["form"] for w in ow[6:14]] == ["lane"] * 4 + ["coop"] * 4
     assert ow[14]["workload"].startswith("host plug-in solve") and ow[14]["converged"] == ow[14]["batch"] and ow[14]["time_split"]["host_ms"] > 0
     for w in ow[15:]:   # the MPC re-solve lines (f1 caller side)
         assert w["workload"].startswith("MPC re-solves") and w["value"] > 0 and w["steps"] == 8 and len(w["iterations_by_round"]) == 8
