@@ -22,14 +22,14 @@ for w in d.get("other_workloads", []):
     elif w.get("roofline") and "classes_ms" in w: row(w["workload"].split(", B=")[0].split(" (")[0] if w["workload"].startswith("C") else w["workload"].split(", B=")[0].replace("f4: ", ""), w["batch"], w["ms_per_step"], w["value"], w["roofline"])
     else: rest.append(w)
 print()
-print("| stack-fed sweep (g1), one launch | branch | form | batch -> kernel ms, fraction of 8 TB/s by the 8(d) B_bwd bytes (every stack read, every gain row written ONCE) | counters of the best launch: traffic / algorithmic, HBM rate |")
+print("| stack-fed sweep (g1), one launch | branch | default form (c = cooperative, l = one lane per trajectory) | batch -> kernel ms, fraction of 8 TB/s by the 8(d) B_bwd bytes (every stack read, every gain row written ONCE) | counters of the best launch: traffic / algorithmic, HBM rate |")
 print("|---|---|---|---|---|")
 for w in sf:
     lab = w["workload"].split("): ")[1]
     shape, br = lab.rsplit(", ", 1) if "path rows" not in lab else (lab.rsplit(", ", 2)[0], "IPDDP, path rows")
     rf = w.get("roofline") or {}
     tr = ("%.2f x, %.2f TB/s (%.2f of peak)" % (rf["traffic_over_algorithmic"], rf["hbm_rate_GBps"] / 1e3, rf["hbm_frac"])) if rf.get("traffic") else "--"
-    print("| %s | %s | %s | %s | %s |" % (shape, br, w["batch_curve"][0].get("form"), ", ".join("%d: %.2f ms, %s%.3f%s" % (c["batch"], c["kernel_ms"], "**" if c is max(w["batch_curve"], key=lambda q: q.get("frac", 0)) else "", c["frac"], "**" if c is max(w["batch_curve"], key=lambda q: q.get("frac", 0)) else "") for c in w["batch_curve"] if "frac" in c), tr))
+    print("| %s | %s | %s | %s | %s |" % (shape, br, "c" if all(c.get("form") == "coop" for c in w["batch_curve"]) else ("l" if all(c.get("form") == "lane" for c in w["batch_curve"]) else "c up to %d, then l" % max(c["batch"] for c in w["batch_curve"] if c.get("form") == "coop")), ", ".join("%d: %.2f ms, %s%.3f%s" % (c["batch"], c["kernel_ms"], "**" if c is max(w["batch_curve"], key=lambda q: q.get("frac", 0)) else "", c["frac"], "**" if c is max(w["batch_curve"], key=lambda q: q.get("frac", 0)) else "") for c in w["batch_curve"] if "frac" in c), tr))
 print()
 for w in rest:
     if w["workload"].startswith("host plug-in"):
